@@ -1,0 +1,408 @@
+"""Generate the golden vectors under tests/golden/*.npz by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, which never travels):
+    python tests/golden/make_golden.py
+It puts /root/reference on sys.path together with scratch stand-ins for the three
+absent third-party packages (tests/golden/_shims: lietorch, torchvision,
+pytorch_lightning) and registers the reference's own C++ CPU op (compiled into
+oracle/_ref by oracle/build_ref.py) as `como_backends`.  Inputs are the seeded
+synthetic scenes of como_amd/synth.py; every output stored here was computed by
+reference code (como.*), never by this repository's oracle or kernels.
+The fixtures are data only: inputs + reference outputs.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(HERE, "_shims"))
+sys.path.insert(0, "/root/reference")
+
+from oracle import build_ref  # noqa: E402
+
+build_ref.build()
+sys.modules["como_backends"] = build_ref.load()
+
+import como.odom.backend.photo as rphoto  # noqa: E402
+import como.odom.backend.linear_system as rlin  # noqa: E402
+import como.odom.backend.sparse_map as rsm  # noqa: E402
+import como.odom.frontend.photo_tracking as rtrack  # noqa: E402
+import como.odom.frontend.two_frame_sfm as rsfm  # noqa: E402
+import como.depth_cov.core.samplers as rsamp  # noqa: E402
+import como.depth_cov.core.gaussian_kernel as rgk  # noqa: E402
+from como.depth_cov.core.DepthCovModule import DepthCovModule  # noqa: E402
+from como.geometry.camera import backprojection, projection  # noqa: E402
+from como.geometry.lie_algebra import invertSE3, invertSE3_J  # noqa: E402
+from como.geometry.transforms import transform_points  # noqa: E402
+from como.odom.factors.pose_prior_factors import linearize_pose_prior  # noqa: E402
+from como.odom.factors.scalar_prior_factors import linearize_scalar_prior, linearize_multi_scalar_prior  # noqa: E402
+from como.odom.factors.gp_priors import gp_ml_cost, mean_log_depth_cost  # noqa: E402
+from como.odom.factors.depth_prior import log_depth_prior  # noqa: E402
+from como.odom.factors.pixel_prior import pixel_prior_cost  # noqa: E402
+from como.utils.coords import normalize_coordinates, get_test_coords, swap_coords_xy  # noqa: E402
+from como.utils.image_processing import (ImageGradientModule, ImagePyramidModule,  # noqa: E402
+                                         IntrinsicsPyramidModule, DepthPyramidModule)
+
+from como_amd import synth  # noqa: E402
+
+import como_backends  # noqa: E402
+
+
+def npy(d):
+    out = {}
+    for k, v in d.items():
+        if torch.is_tensor(v):
+            out[k] = v.detach().cpu().numpy()
+        else:
+            out[k] = np.asarray(v)
+    return out
+
+
+def save(name, d):
+    p = os.path.join(HERE, name)
+    np.savez_compressed(p, **npy(d))
+    print(f"{name}: {os.path.getsize(p) / 1024:.1f} KiB, {len(d)} arrays")
+
+
+def ref_model(seed=0):
+    torch.manual_seed(seed)
+    model = DepthCovModule()
+    model.eval()
+    return model
+
+
+def ref_prep_predictor(model, cov_params_img, coords_m, photo_size, dtype):
+    """Call sequence of reference Mapping.prep_predictor (Mapping.py:430-468)."""
+    b, _, h, w = cov_params_img.shape
+    coords_m_norm = normalize_coordinates(coords_m, (h, w))
+    E_m = rgk.interpolate_kernel_params(cov_params_img, coords_m_norm)
+    coords_n_all = get_test_coords(photo_size, device="cpu", batch_size=b)
+    coords_n_norm = normalize_coordinates(coords_n_all.to(dtype=dtype), (h, w))
+    E_n = rgk.interpolate_kernel_params(cov_params_img, coords_n_norm)
+    with torch.no_grad():
+        K_mm = model.cov_modules[-1](coords_m_norm, E_m)
+        m = coords_m.shape[1]
+        K_mm += torch.diag_embed(1e-6 * torch.ones(b, m))
+        L_mm, _ = torch.linalg.cholesky_ex(K_mm, upper=False)
+        I_mm = torch.eye(m, dtype=K_mm.dtype).unsqueeze(0).repeat(b, 1, 1)
+        K_mm_inv = torch.cholesky_solve(I_mm, L_mm, upper=False)
+        K_nm = model.cross_cov_modules[-1](coords_n_norm, E_n, coords_m_norm, E_m)
+        Kt = (K_nm @ K_mm_inv).reshape(b, photo_size[0], photo_size[1], -1)
+    return K_mm_inv, L_mm, Kt, E_m, K_mm
+
+
+def window_case(dtype, B, H, W, m, window, seed, with_recent, aff_noise=0.02, save_dense=True, window_full=True):
+    """One reference Mapping.iterate()-equivalent: scaffold -> dense ref -> photo system -> anchors -> solve."""
+    model = ref_model()
+    pred = lambda cov, cm: ref_prep_predictor(model, cov, cm, (H, W), dtype)[:3]
+    st = synth.make_window(B=B, H=H, W=W, m=m, dtype=dtype, seed=seed, predictor=pred, aff_noise=aff_noise)
+    K = st["intrinsics"]
+    corr = st["correspondence_mask"]
+    P_m = st["P_m"].clone()
+    kf_poses, kf_aff = st["kf_poses"], st["kf_aff_params"]
+    out = {k: st[k] for k in ("intrinsics", "kf_poses", "kf_aff_params", "kf_img_and_grads", "cov_params_img",
+                              "coords_m", "correspondence_mask", "P_m", "kf_timestamps")}
+    out.update({"K_mm_inv": st["K_mm_inv"], "L_mm": st["L_mm"]})
+    if save_dense:
+        out["Knm_Kmminv"] = st["Knm_Kmminv"]
+    # --- scaffold (Mapping.prep_geometry_scaffold, Mapping.py:603-659; no re-init triggered here)
+    remap, paired = rsm.get_batch_remap_function(corr)
+    landmark_ids, _ = paired
+    point_inds = rlin.landmark_to_batched_3d_point_inds(landmark_ids, B)
+    median0 = torch.full((B,), 2.5, dtype=dtype)
+    reinit = P_m.clone()
+    pm, logzm, z_mask, dlogzm_dzm, dzm_dPwm, dzm_dTwc, dpm_dPwm, dpm_dTwc = rsm.setup_point_to_frame(
+        P_m, kf_poses, remap, K, reinit_P=reinit, median_depths=median0)
+    assert not z_mask.any()
+    dlogzm_dTwc = dlogzm_dzm @ dzm_dTwc
+    out.update({"median_depths_in": median0, "pm": pm, "logzm": logzm, "dlogzm_dzm": dlogzm_dzm, "dzm_dPwm": dzm_dPwm,
+                "dzm_dTwc": dzm_dTwc, "dpm_dPwm": dpm_dPwm, "dpm_dTwc": dpm_dTwc, "point_inds": point_inds})
+    # --- dense reference (Mapping.prep_dense_ref, Mapping.py:661-699)
+    coords_n, _ = rsm.subselect_pixels(st["kf_img_and_grads"], window)
+    bi = torch.arange(B).unsqueeze(1).repeat(1, coords_n.shape[1])
+    vals_n = st["kf_img_and_grads"][bi, :1, coords_n[:, :, 0], coords_n[:, :, 1]]
+    Kt_rows = st["Knm_Kmminv"][bi, coords_n[:, :, 0], coords_n[:, :, 1], :].clone()
+    Pwn, dPwn_dTwc, dPwn_dzm, med, dlogzn_dlogzm, logzn = rsm.setup_test_points(
+        pm, logzm, kf_poses, Kt_rows, coords_n, K, dlogzm_dTwc, dlogzm_dzm)
+    out.update({"coords_n": coords_n, "vals_n": vals_n, "Pwn": Pwn, "dPwn_dTwc": dPwn_dTwc, "median_depths": med,
+                "logzn": logzn})
+    if save_dense:
+        out["dPwn_dzm"] = dPwn_dzm
+    # --- recent (one-way) frames
+    if with_recent:
+        g = torch.Generator().manual_seed(seed + 5)
+        scene = synth.PlaneScene(seed=seed, freq_scale=W / 640.0)
+        K64 = synth.intrinsics_for(H, W)
+        ts = torch.tensor([0.5, 1.5, 2.5], dtype=dtype)[: max(1, B - 1)]
+        Tg = synth.gt_poses(B)
+        rec_imgs, rec_T = [], []
+        for t in ts.tolist():
+            k0 = int(t)
+            xi = torch.zeros(1, 6, dtype=torch.float64)
+            xi[0, 1] = (t * np.pi / 180.0)
+            Tr = synth.se3_exp(xi)[0]
+            Tr[0, 3] = 0.05 * t
+            Tr[1, 3] = 0.01 * t
+            I, _ = scene.render(Tr, K64, H, W)
+            rec_imgs.append(I)
+            rec_T.append(Tr @ synth.se3_exp(1e-3 * torch.randn((1, 6), generator=g, dtype=torch.float64))[0])
+        recent_img = synth.scharr_and_stack(torch.stack(rec_imgs)[:, None].to(dtype))
+        recent_poses = torch.stack(rec_T).to(dtype)
+        recent_aff = (0.02 * torch.randn((len(ts), 2, 1), generator=g, dtype=torch.float64)).to(dtype)
+        recent_ts = ts
+    else:
+        recent_img = torch.empty((0, 3, H, W), dtype=dtype)
+        recent_poses = torch.empty((0, 4, 4), dtype=dtype)
+        recent_aff = torch.empty((0, 2, 1), dtype=dtype)
+        recent_ts = torch.empty((0,), dtype=dtype)
+    out.update({"recent_poses": recent_poses, "recent_aff_params": recent_aff, "recent_img_and_grads": recent_img,
+                "recent_timestamps": recent_ts})
+    # --- system (Mapping.setup_system, Mapping.py:701-747)
+    nrec = recent_poses.shape[0]
+    L = P_m.shape[0]
+    dim = 8 * B + 8 * nrec + 3 * L
+    Hm = torch.zeros((dim, dim), dtype=dtype)
+    gv = torch.zeros((dim,), dtype=dtype)
+    kf_inds = torch.arange(8 * B).reshape(B, 8)
+    if nrec > 0:
+        recent_inds = torch.arange(8 * nrec).reshape(nrec, 8) + 8 * B
+    else:
+        recent_inds = torch.empty((0), dtype=torch.long)
+    lm_start = 8 * B + 8 * nrec
+    landmark_inds = point_inds + lm_start
+    cfg = {"nonmax_suppression_window": window, "pairwise_batch_size": 128, "radius_thresh": 0.0, "degrees_thresh": 0.0}
+    err, kf_pairs, ow_pairs = rphoto.create_photo_system(
+        kf_poses, kf_aff, recent_poses, recent_aff, Pwn, dPwn_dTwc, dPwn_dzm, dzm_dPwm, med, vals_n,
+        st["kf_img_and_grads"], recent_img, st["kf_timestamps"], recent_ts, K, Hm, gv, cfg, kf_inds, recent_inds,
+        landmark_inds)
+    out.update({"kf_inds": kf_inds, "recent_inds": recent_inds, "landmark_inds": landmark_inds,
+                "lm_start": lm_start, "photo_err": err, "H_photo": Hm.clone(), "g_photo": gv.clone(),
+                "kf_ref_ids": kf_pairs[0], "kf_target_ids": kf_pairs[1],
+                "ow_kf_ids": ow_pairs[0], "ow_target_ids": ow_pairs[1]})
+    # --- per-pair masks / residuals of the keyframe pairs through the reference's own functions (photo.py:104-128)
+    rid, tid = torch.tensor(kf_pairs[0]), torch.tensor(kf_pairs[1])
+    Tcw_t, _ = invertSE3_J(kf_poses[tid])
+    Pcj, _, _ = transform_points(Tcw_t, Pwn[rid])
+    vals_t, _, valid = rphoto.interp_img(st["kf_img_and_grads"][tid], Pcj, K[0])
+    vis = torch.exp(kf_aff[tid][:, 0:1, :] - kf_aff[rid][:, 0:1, :]) * vals_n[rid]
+    r = vals_t - vis + (kf_aff[tid][:, 1:2, :] - kf_aff[rid][:, 1:2, :])
+    pj, _ = projection(K[0], Pcj)
+    out.update({"kfpair_valid": valid, "kfpair_r": r[..., 0], "kfpair_pj": pj, "kfpair_Pcj": Pcj})
+    if not with_recent:
+        out["sigma_r"] = 1.4826 * torch.median(torch.abs(r[valid]))
+    # --- priors exactly as reference Mapping.iterate applies them (Mapping.py:809-917)
+    kf_pose_inds, kf_aff_inds = kf_inds[:, :6], kf_inds[:, 6:]
+    dlogzm_dPwm = dlogzm_dzm @ dzm_dPwm
+    log_med = torch.log(med[:, None, None])
+    e_gp = gp_ml_cost(logzm, log_med, st["L_mm"], dlogzm_dPwm, dlogzm_dTwc, landmark_inds, kf_pose_inds, Hm, gv, sigma=1e0)
+    out.update({"H_gp": Hm.clone(), "g_gp": gv.clone()})
+    e_ld = log_depth_prior(logzm, log_med, dlogzm_dPwm, dlogzm_dTwc, st["obs_ref_mask"], landmark_inds, kf_pose_inds,
+                           Hm, gv, mode="first_mean", sigma_first=1e0, sigma_all=1e-0)
+    out.update({"H_ld": Hm.clone(), "g_ld": gv.clone()})
+    e_px = pixel_prior_cost(pm, st["pm_first_obs"], dpm_dPwm, dpm_dTwc, st["obs_ref_mask"], landmark_inds, kf_pose_inds,
+                            Hm, gv, mode="first", pixel_sigma_first=1e-2, pixel_sigma_all=3.33e-1)
+    out.update({"H_px": Hm.clone(), "g_px": gv.clone()})
+    pose_anchor = st["poses_gt"][0:1].clone()
+    aff_anchor = torch.zeros((1, 2, 1), dtype=dtype)
+    e1 = linearize_pose_prior(kf_poses[0:1], pose_anchor, Hm, gv, [kf_pose_inds[0, 0], kf_pose_inds[0, -1] + 1], sigma=1e-6)
+    e2 = linearize_scalar_prior(kf_aff[0, 0:1, :], aff_anchor[0, 0:1, :], Hm, gv,
+                                [kf_aff_inds[0, 0], kf_aff_inds[0, 0] + 1], sigma=1e-4)
+    e3 = linearize_scalar_prior(kf_aff[0, 1:2, :], aff_anchor[0, 1:2, :], Hm, gv,
+                                [kf_aff_inds[0, 1], kf_aff_inds[0, 1] + 1], sigma=1e-4)
+    lm_flat = torch.arange(3 * L).reshape(L, 3) + lm_start
+    fix = corr[0, :]
+    P_anchor = st["P_gt"][fix, :]
+    out.update({"pose_anchor": pose_anchor, "aff_anchor": aff_anchor, "P_anchor": P_anchor, "fix_mask": fix,
+                "obs_ref_mask": st["obs_ref_mask"], "pm_first_obs": st["pm_first_obs"], "window_full": window_full})
+    if window_full:
+        e4 = linearize_multi_scalar_prior(P_m[fix, :].flatten(), P_anchor.flatten(), Hm, gv, lm_flat[fix, :].flatten(), sigma=1e-4)
+    else:
+        scale_anchor = torch.mean(torch.log(st["depth_gt"][0])).reshape(1, 1, 1).to(dtype)
+        out["init_scale_anchor"] = scale_anchor
+        e4 = mean_log_depth_cost(logzm[0:1], st["Knm_Kmminv"][0:1].view(1, -1, m), scale_anchor, dlogzm_dPwm[0:1],
+                                 dlogzm_dTwc[0:1], landmark_inds[0:1], kf_pose_inds[0:1], Hm, gv, 1e-2)
+    out.update({"prior_err": torch.stack([torch.as_tensor(e, dtype=torch.float64).reshape(()) for e in (e_gp, e_ld, e_px, e1, e2, e3, e4)]),
+                "H_full": Hm.clone(), "g_full": gv.clone()})
+    _, info = torch.linalg.cholesky_ex(Hm)
+    print("   cholesky info:", int(info))
+    delta = rlin.solve_system(Hm, gv)
+    kp, ka, rp, ra, Pn = rlin.update_vars(delta, kf_poses, kf_aff, kf_inds, recent_poses, recent_aff, recent_inds,
+                                           P_m, lm_start)
+    out.update({"delta": delta, "kf_poses_new": kp, "kf_aff_new": ka, "P_new": Pn})
+    if nrec > 0:
+        out.update({"recent_poses_new": rp, "recent_aff_new": ra})
+    return out
+
+
+def tracking_case(H, W, levels, seed, dtype=torch.float32):
+    tp = synth.make_tracking_pair(H=H, W=W, dtype=dtype, seed=seed, levels=levels)
+    K = tp["intrinsics"]
+    grad = ImageGradientModule(1, "cpu", dtype)
+    pyr = ImagePyramidModule(1, 0, levels, "cpu", dtype)
+    ipyr = IntrinsicsPyramidModule(0, levels, "cpu")
+    dpyr = DepthPyramidModule(0, levels, "nearest_neighbor", "cpu")
+    K_pyr = ipyr(K, [1.0, 1.0])
+    ref_pyr = pyr(tp["img_ref"])
+    cur_pyr = pyr(tp["img_cur"])
+    depth_pyr = dpyr(tp["depth_ref"])
+    vals_pyr, P_pyr, J_pyr, mask_pyr = [], [], [], []
+    out = {k: tp[k] for k in ("img_ref", "depth_ref", "img_cur", "intrinsics", "Tji_gt", "Tji_init")}
+    for i in range(levels):
+        gx, gy = grad(ref_pyr[i])
+        tc = get_test_coords(ref_pyr[i].shape[-2:], device="cpu", batch_size=1)
+        bi = torch.zeros((1, tc.shape[1]), dtype=torch.long)
+        vals = ref_pyr[i][bi, :, tc[:, :, 0], tc[:, :, 1]]
+        dI_dw = torch.stack((gx[bi, :, tc[:, :, 0], tc[:, :, 1]], gy[bi, :, tc[:, :, 0], tc[:, :, 1]]), dim=-1)
+        depths = depth_pyr[i][bi, 0, tc[:, :, 0], tc[:, :, 1]].unsqueeze(-1)
+        P, _ = backprojection(K_pyr[i], swap_coords_xy(tc), depths)
+        p_all, _ = projection(K_pyr[i], P)
+        hh, ww = depth_pyr[i].shape[-2:]
+        mask = ((p_all[:, :, 0] >= -50) & (p_all[:, :, 0] <= ww - 1 + 50) & (p_all[:, :, 1] >= -50)
+                & (p_all[:, :, 1] <= hh - 1 + 50) & (P[:, :, 2] > 1e-4))
+        J = rtrack.precalc_jacobians(dI_dw, P, vals, K_pyr[i])
+        vals_pyr.append(vals); P_pyr.append(P); J_pyr.append(J); mask_pyr.append(mask)
+        out.update({f"K_l{i}": K_pyr[i], f"ref_l{i}": ref_pyr[i], f"cur_l{i}": cur_pyr[i], f"depth_l{i}": depth_pyr[i],
+                    f"gx_l{i}": gx, f"gy_l{i}": gy, f"vals_l{i}": vals, f"P_l{i}": P, f"J_l{i}": J, f"mask_l{i}": mask})
+    aff0 = torch.zeros((1, 2, 1), dtype=dtype)
+    # single iteration at the finest level
+    l = levels - 1
+    A_norm = 1.0 / torch.as_tensor((cur_pyr[l].shape[-1], cur_pyr[l].shape[-2]), dtype=dtype)
+    Jc = J_pyr[l].clone()
+    T1, a1, delta, mse, gn, pj, valid, depth = rtrack.tracking_iter(
+        tp["Tji_init"], P_pyr[l], K_pyr[l], cur_pyr[l], aff0, vals_pyr[l], Jc, 0.1, A_norm)
+    out.update({"it_T": T1, "it_aff": a1, "it_delta": delta, "it_mse": mse, "it_grad_norm": gn, "it_pj": pj,
+                "it_valid": valid, "it_depth": depth})
+    term = {"max_iter": 50, "delta_norm": 1e-3, "rel_tol": 1e-3, "grad_norm": 1.0}
+    Tf, af = rtrack.photo_tracking_pyr(tp["Tji_init"], aff0, vals_pyr, P_pyr, [j.clone() for j in J_pyr], mask_pyr,
+                                       K_pyr, cur_pyr, 0.1, term)
+    out.update({"pyr_T": Tf, "pyr_aff": af})
+    return out
+
+
+def sfm_case(H, W, m, seed, dtype=torch.float64):
+    model = ref_model()
+    st = synth.make_window(B=2, H=H, W=W, m=m, dtype=dtype, seed=seed,
+                           predictor=lambda cov, cm: ref_prep_predictor(model, cov, cm, (H, W), dtype)[:3])
+    K = st["intrinsics"][0]
+    tc = get_test_coords((H, W), device="cpu", batch_size=1)
+    vals_i = st["kf_img_and_grads"][0:1, 0:1].reshape(1, 1, -1)
+    Kt = st["Knm_Kmminv"][0:1].reshape(1, H * W, m)
+    Tji = invertSE3(st["kf_poses"][1:2]) @ st["kf_poses"][0:1]
+    # log-depths of KF0's inducing points from GT depth
+    cm = st["coords_m"][0].long()
+    logz = torch.log(st["depth_gt"][0][cm[:, 0], cm[:, 1]]).reshape(1, m, 1) + 0.01
+    D = 6 + m
+    Hm = torch.zeros((D, D), dtype=dtype)
+    gv = torch.zeros((D,), dtype=dtype)
+    aff = torch.zeros((1, 2, 1), dtype=dtype)
+    err, log_depth, coords_j, depths_j, valid, Pi = rsfm.construct_photo_system(
+        Tji, logz, aff, tc, vals_i, Kt, st["kf_img_and_grads"][1:2], K, 0.1, Hm, gv)
+    return {"Tji": Tji, "logz_m": logz, "coords_i": tc, "vals_i": vals_i, "Kt": Kt, "img_and_grads_j": st["kf_img_and_grads"][1:2],
+            "K": K, "H": Hm, "g": gv, "err": err, "log_depth": log_depth, "valid": valid, "Pi": Pi}
+
+
+def cov_case(H, W, seed):
+    dtype = torch.float32
+    cov = synth.synthetic_cov_params(1, H, W, seed=seed, dtype=torch.float64).to(dtype)
+    g = torch.Generator().manual_seed(seed)
+    x1 = torch.rand((2, 7, 2), generator=g) * 2 - 1
+    x2 = torch.rand((2, 33, 2), generator=g) * 2 - 1
+    c1 = rgk.interpolate_kernel_params(cov.expand(2, -1, -1, -1), x1)
+    c2 = rgk.interpolate_kernel_params(cov.expand(2, -1, -1, -1), x2)
+    K12 = como_backends.cross_covariance(x1, c1, x2, c2, 0.8)
+    out = {"cov_params_img": cov, "x1": x1, "E1": c1, "x2": x2, "E2": c2, "scale": 0.8, "K12": K12}
+    # strided-view call (the sampler passes slices, samplers.py:167-172)
+    xs = torch.rand((1, 12, 2), generator=g) * 2 - 1
+    Es = rgk.interpolate_kernel_params(cov, xs)
+    out["K_slice"] = como_backends.cross_covariance(xs[:, :5], Es[:, :5], xs[:, 3:], Es[:, 3:], 1.0)
+    out["xs"], out["Es"] = xs, Es
+    # Python twin on the same inputs, float64 (mapping path)
+    model = ref_model()
+    out["K12_py64"] = model.cross_cov_modules[-1](x1.double(), c1.double(), x2.double(), c2.double())
+    out["K11_py64"] = model.cov_modules[-1](x1.double(), c1.double())
+    # full greedy sampler run through the reference (samplers.py:36-107)
+    num, border, dist_thresh = 16, 3, 0.1
+    signal_var = model.get_scale(-1).detach().float()
+    coords, dom_inds = rsamp.sample_sparse_coords(cov, num, "greedy_conditional_entropy", max_stdev_thresh=-1.0, border=border,
+                                                  dist_thresh=dist_thresh, signal_var=signal_var, fixed_var=None)
+    out.update({"samp_num": num, "samp_border": border, "samp_dist_thresh": dist_thresh, "samp_coords": coords,
+                "samp_domain_inds": dom_inds})
+    # explicit append sequence with state snapshots
+    dom = rsamp.get_coords_domain(cov, border=border)
+    dn = normalize_coordinates(dom, (H, W)).float()
+    Ed = rsamp.get_cov_domain(dom, cov)
+    n = 6
+    L = torch.eye(n).unsqueeze(0).repeat(1, 1, 1)
+    obs = torch.zeros((1, n, dn.shape[1]))
+    pick = dom_inds[0, :n]
+    xs2, Es2 = dn[:, pick], Ed[:, pick]
+    K00 = como_backends.cross_covariance(xs2[:, :1], Es2[:, :1], xs2[:, :1].clone(), Es2[:, :1].clone(), 1.0)
+    L[:, :1, :1] = torch.linalg.cholesky(K00)
+    obs[:, :1] = rsamp.get_obs_info(L[:, :1, :1], como_backends.cross_covariance(xs2[:, :1], Es2[:, :1], dn, Ed, 1.0))
+    var = rsamp.calc_var(obs[:, :1], torch.tensor(1.0))
+    out.update({"app_L0": L.clone(), "app_obs0": obs.clone(), "app_var0": var.clone(), "app_x": xs2, "app_E": Es2,
+                "app_dn": dn, "app_Ed": Ed})
+    for i in range(1, n):
+        k_ni = como_backends.cross_covariance(xs2[:, :i], Es2[:, :i], xs2[:, i:i + 1], Es2[:, i:i + 1], 1.0)
+        k_id = como_backends.cross_covariance(xs2[:, i:i + 1], Es2[:, i:i + 1], dn, Ed, 1.0)
+        como_backends.get_new_chol_obs_info(L, obs, var, k_ni, k_id, 1.0, i)
+    out.update({"app_L": L, "app_obs": obs, "app_var": var})
+    return out
+
+
+def image_case(seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand((2, 1, 40, 56), generator=g, dtype=torch.float64)
+    gx, gy = ImageGradientModule(1, "cpu", torch.float64)(img)
+    pyr = ImagePyramidModule(1, 0, 3, "cpu", torch.float64)(img)
+    K = synth.intrinsics_for(40, 56)
+    Kp = IntrinsicsPyramidModule(0, 3, "cpu")(K, [1.0, 1.0])
+    raw = torch.randn((1, 3, 9, 11), generator=g)
+    raw[:, :2] = raw[:, :2] * 5
+    cov = rgk.kernel_params_to_covariance(rgk.normalize_params_cov(raw))
+    return {"img": img, "gx": gx, "gy": gy, "pyr0": pyr[0], "pyr1": pyr[1], "pyr2": pyr[2],
+            "K": K, "K0": Kp[0], "K1": Kp[1], "K2": Kp[2], "raw": raw, "cov": cov}
+
+
+def fullsize_scalars():
+    """A few full-size (640x480) reference scalars (inputs are regenerated from seeds by the tests)."""
+    out = {}
+    tp = synth.make_tracking_pair(H=480, W=640, dtype=torch.float32, seed=3, levels=1)
+    K = tp["intrinsics"]
+    gx, gy = ImageGradientModule(1, "cpu", torch.float32)(tp["img_ref"])
+    tc = get_test_coords((480, 640), device="cpu", batch_size=1)
+    bi = torch.zeros((1, tc.shape[1]), dtype=torch.long)
+    vals = tp["img_ref"][bi, :, tc[:, :, 0], tc[:, :, 1]]
+    dI_dw = torch.stack((gx[bi, :, tc[:, :, 0], tc[:, :, 1]], gy[bi, :, tc[:, :, 0], tc[:, :, 1]]), dim=-1)
+    depths = tp["depth_ref"][bi, 0, tc[:, :, 0], tc[:, :, 1]].unsqueeze(-1)
+    P, _ = backprojection(K, swap_coords_xy(tc), depths)
+    J = rtrack.precalc_jacobians(dI_dw, P, vals, K)
+    A_norm = 1.0 / torch.as_tensor((640, 480), dtype=torch.float32)
+    aff0 = torch.zeros((1, 2, 1))
+    T1, a1, delta, mse, gn, pj, valid, depth = rtrack.tracking_iter(tp["Tji_init"], P, K, tp["img_cur"], aff0, vals, J, 0.1, A_norm)
+    out.update({"trk_delta": delta, "trk_mse": mse, "trk_grad_norm": gn, "trk_nvalid": valid.sum(), "trk_T": T1, "trk_aff": a1})
+    return out
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full"]
+    if "ba" in which:
+        save("ba_window_f64.npz", window_case(torch.float64, 3, 48, 64, 8, 2, seed=1, with_recent=False))
+        save("ba_window_f32.npz", window_case(torch.float32, 3, 48, 64, 8, 2, seed=1, with_recent=False))
+        save("ba_window_recent_f64.npz", window_case(torch.float64, 4, 48, 64, 8, 2, seed=2, with_recent=True, save_dense=False,
+                                                     window_full=False))
+    if "track" in which:
+        save("tracking_f32.npz", tracking_case(96, 128, 3, seed=0))
+    if "sfm" in which:
+        save("sfm_f64.npz", sfm_case(48, 64, 8, seed=4))
+    if "cov" in which:
+        save("cov_ops_f32.npz", cov_case(48, 64, seed=5))
+    if "image" in which:
+        save("image_ops.npz", image_case(seed=6))
+    if "full" in which:
+        save("fullsize_scalars.npz", fullsize_scalars())

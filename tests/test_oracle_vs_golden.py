@@ -1,0 +1,218 @@
+"""The CPU oracle against the golden vectors captured from the reference (tests/golden/make_golden.py).
+
+These are the pins of the oracle: masks bit-exact, floating point within
+the tolerances written below.  CPU only.
+"""
+import pytest
+import torch
+
+from oracle import dense_ref, depthcov, geom, image, photo_ba, priors, sfm, tracking
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item()
+
+
+TOL = {torch.float64: 1e-10, torch.float32: 2e-5}
+
+
+@pytest.mark.parametrize("name", ["ba_window_f64.npz", "ba_window_f32.npz"])
+def test_predictor_and_dense_ref(golden, name):
+    G = golden(name)
+    dt = G["kf_poses"].dtype
+    tol = TOL[dt]
+    K = G["intrinsics"][0]
+    Kinv, L, Kt = depthcov.prep_predictor(G["cov_params_img"], G["coords_m"], 1.0)
+    assert rel(Kinv, G["K_mm_inv"]) < tol * 10
+    assert rel(L, G["L_mm"]) < tol
+    assert rel(Kt, G["Knm_Kmminv"]) < tol * 10
+    Pb, ids = dense_ref.batched_landmarks(G["P_m"], G["correspondence_mask"])
+    p, logz, zm, dlogz_dz, dz_dPw, dz_dTwc, dp_dPw, dp_dTwc = dense_ref.project_landmarks(
+        G["kf_poses"], Pb, K, Pb, G["median_depths_in"])
+    assert torch.equal(p, G["pm"]) and torch.equal(logz, G["logzm"])
+    for a, b in ((dlogz_dz, G["dlogzm_dzm"]), (dz_dPw, G["dzm_dPwm"]), (dz_dTwc, G["dzm_dTwc"]),
+                 (dp_dPw, G["dpm_dPwm"]), (dp_dTwc, G["dpm_dTwc"])):
+        assert rel(a, b) < tol
+    cn = dense_ref.subselect_pixels(G["kf_img_and_grads"], 2)
+    assert torch.equal(cn, G["coords_n"])
+    B = cn.shape[0]
+    bi = torch.arange(B)[:, None].expand(-1, cn.shape[1])
+    Pw, dT, dz, med, logzn = dense_ref.dense_reference(
+        G["logzm"], G["kf_poses"], G["Knm_Kmminv"][bi, cn[..., 0], cn[..., 1], :], cn, K,
+        G["dlogzm_dzm"] @ G["dzm_dTwc"], G["dlogzm_dzm"])
+    assert torch.equal(Pw, G["Pwn"])            # feeds the validity mask -> bit-exact
+    assert torch.equal(med, G["median_depths"])
+    assert rel(dT, G["dPwn_dTwc"]) < tol and rel(dz, G["dPwn_dzm"]) < tol and rel(logzn, G["logzn"]) < tol
+
+
+@pytest.mark.parametrize("name", ["ba_window_f64.npz", "ba_window_f32.npz"])
+def test_batch_photo_cost(golden, name):
+    G = golden(name)
+    dt = G["kf_poses"].dtype
+    tol = TOL[dt]
+    K = G["intrinsics"][0]
+    D = G["H_photo"].shape[0]
+    H = torch.zeros((D, D), dtype=dt)
+    g = torch.zeros(D, dtype=dt)
+    rid, tid = G["kf_ref_ids"].long(), G["kf_target_ids"].long()
+    err, aux = photo_ba.batch_photo_cost(
+        G["vals_n"][rid], G["kf_aff_params"][rid], G["Pwn"][rid], G["kf_poses"][tid], G["kf_aff_params"][tid],
+        G["kf_img_and_grads"][tid], G["dPwn_dTwc"][rid], G["dPwn_dzm"][rid], G["dzm_dPwm"][rid], G["kf_inds"][rid],
+        G["kf_inds"][tid], G["landmark_inds"][rid], K, H, g, return_aux=True)
+    assert torch.equal(aux["valid"], G["kfpair_valid"])          # masks bit-exact
+    assert 0 < aux["valid"].sum() < aux["valid"].numel()
+    assert (aux["r"] - G["kfpair_r"]).abs().max() < tol
+    assert abs(aux["sigma"].item() - G["sigma_r"].item()) < tol
+    assert abs(err.item() - G["photo_err"].item()) / G["photo_err"].item() < tol
+    assert rel(H, G["H_photo"]) < tol and rel(g, G["g_photo"]) < tol
+    assert torch.equal(H, H.T) or rel(H, H.T) < 1e-12
+
+
+def _system_from_photo(G):
+    return G["H_photo"].clone(), G["g_photo"].clone()
+
+
+@pytest.mark.parametrize("name", ["ba_window_f64.npz", "ba_window_recent_f64.npz"])
+def test_priors_solve_update(golden, name):
+    G = golden(name)
+    dt = G["kf_poses"].dtype
+    tol = 1e-9
+    H, g = _system_from_photo(G)
+    kf_pose_inds, kf_aff_inds = G["kf_inds"][:, :6], G["kf_inds"][:, 6:]
+    lmk = G["landmark_inds"]
+    dlogzm_dPw = G["dlogzm_dzm"] @ G["dzm_dPwm"]
+    dlogzm_dTwc = G["dlogzm_dzm"] @ G["dzm_dTwc"]
+    log_med = torch.log(G["median_depths"])[:, None, None]
+    e = [priors.gp_ml_cost(G["logzm"], log_med, G["L_mm"], dlogzm_dPw, dlogzm_dTwc, lmk, kf_pose_inds, H, g, 1.0)]
+    assert rel(H, G["H_gp"]) < tol and rel(g, G["g_gp"]) < tol
+    e.append(priors.log_depth_prior_first_mean(G["logzm"], log_med, dlogzm_dPw, dlogzm_dTwc, G["obs_ref_mask"], lmk,
+                                               kf_pose_inds, H, g, 1.0))
+    assert rel(H, G["H_ld"]) < tol and rel(g, G["g_ld"]) < tol
+    e.append(priors.pixel_prior_first(G["pm"], G["pm_first_obs"], G["dpm_dPwm"], G["dpm_dTwc"], G["obs_ref_mask"], lmk,
+                                      kf_pose_inds, H, g, 1e-2))
+    assert rel(H, G["H_px"]) < tol and rel(g, G["g_px"]) < tol
+    e.append(priors.pose_prior(G["kf_poses"][0:1], G["pose_anchor"], H, g, 0, 1e-6))
+    e.append(priors.scalar_prior(G["kf_aff_params"][0, 0], G["aff_anchor"][0, 0], H, g, kf_aff_inds[0, 0:1], 1e-4))
+    e.append(priors.scalar_prior(G["kf_aff_params"][0, 1], G["aff_anchor"][0, 1], H, g, kf_aff_inds[0, 1:2], 1e-4))
+    L = G["P_m"].shape[0]
+    lm_start = int(G["lm_start"])
+    if bool(G["window_full"]):
+        fix = G["fix_mask"]
+        inds = (torch.arange(3 * L).reshape(L, 3) + lm_start)[fix].reshape(-1)
+        e.append(priors.scalar_prior(G["P_m"][fix].reshape(-1), G["P_anchor"].reshape(-1), H, g, inds, 1e-4))
+    else:
+        depthK = depthcov.prep_predictor(G["cov_params_img"][0:1], G["coords_m"][0:1], 1.0)[2]
+        m = G["coords_m"].shape[1]
+        e.append(priors.mean_log_depth_cost(G["logzm"][0:1], depthK.reshape(1, -1, m), G["init_scale_anchor"], dlogzm_dPw[0:1],
+                                            dlogzm_dTwc[0:1], lmk[0:1], kf_pose_inds[0:1], H, g, 1e-2))
+    assert rel(torch.stack([x.reshape(()) for x in e]).double(), G["prior_err"]) < 1e-6
+    assert rel(H, G["H_full"]) < tol and rel(g, G["g_full"]) < tol
+    delta, info = photo_ba.solve_system(G["H_full"], G["g_full"])
+    assert int(info) == 0
+    assert rel(delta, G["delta"]) < 1e-7
+    rp = G.get("recent_poses", torch.empty(0, 4, 4, dtype=dt))
+    ra = G.get("recent_aff_params", torch.empty(0, 2, 1, dtype=dt))
+    kp, ka, rpn, ran, Pn = photo_ba.update_vars(G["delta"], G["kf_poses"], G["kf_aff_params"], G["kf_inds"], rp, ra,
+                                                G["recent_inds"], G["P_m"], lm_start)
+    assert rel(kp, G["kf_poses_new"]) < 1e-12 and rel(ka, G["kf_aff_new"]) < 1e-12 and rel(Pn, G["P_new"]) < 1e-12
+    if rp.shape[0]:
+        assert rel(rpn, G["recent_poses_new"]) < 1e-12
+
+
+def test_create_photo_system_with_one_way_frames(golden):
+    G = golden("ba_window_recent_f64.npz")
+    dt = G["kf_poses"].dtype
+    K = G["intrinsics"][0]
+    D = G["H_photo"].shape[0]
+    H = torch.zeros((D, D), dtype=dt)
+    g = torch.zeros(D, dtype=dt)
+    Kt = depthcov.prep_predictor(G["cov_params_img"], G["coords_m"], 1.0)[2]
+    cn = G["coords_n"]
+    bi = torch.arange(cn.shape[0])[:, None].expand(-1, cn.shape[1])
+    Pw, dT, dz, med, _ = dense_ref.dense_reference(G["logzm"], G["kf_poses"], Kt[bi, cn[..., 0], cn[..., 1], :], cn, K,
+                                                   G["dlogzm_dzm"] @ G["dzm_dTwc"], G["dlogzm_dzm"])
+    err, kfp, owp = photo_ba.create_photo_system(
+        G["kf_poses"], G["kf_aff_params"], G["recent_poses"], G["recent_aff_params"], Pw, dT, dz, G["dzm_dPwm"], G["vals_n"],
+        G["kf_img_and_grads"], G["recent_img_and_grads"], G["kf_timestamps"], G["recent_timestamps"], K, H, g, 128,
+        G["kf_inds"], G["recent_inds"], G["landmark_inds"])
+    assert kfp[0] == G["kf_ref_ids"].tolist() and kfp[1] == G["kf_target_ids"].tolist()
+    assert owp[0] == G["ow_kf_ids"].tolist() and owp[1] == G["ow_target_ids"].tolist()
+    assert abs(float(err) - G["photo_err"].item()) / G["photo_err"].item() < 1e-9
+    assert rel(H, G["H_photo"]) < 1e-9 and rel(g, G["g_photo"]) < 1e-9
+
+
+def test_tracking(golden):
+    T = golden("tracking_f32.npz")
+    l = 2
+    o = tracking.tracking_iter(T["Tji_init"][0], T[f"P_l{l}"][0], T[f"K_l{l}"], T[f"cur_l{l}"][0, 0], torch.zeros(2),
+                               T[f"vals_l{l}"][0, :, 0], T[f"J_l{l}"][0, :, 0, :])
+    assert torch.equal(o["valid"], T["it_valid"][0])                     # mask bit-exact
+    assert torch.equal(torch.stack((o["u"], o["v"]), -1), T["it_pj"][0])  # projected coords bit-exact
+    assert torch.equal(o["depth"], T["it_depth"][0, :, 0])
+    assert rel(o["delta"], T["it_delta"][0, :, 0]) < 1e-4
+    assert abs(o["mse"].item() - T["it_mse"].item()) < 1e-5
+    assert rel(o["T"], T["it_T"][0]) < 1e-6
+    J = tracking.ic_jacobians(torch.stack((T[f"gx_l{l}"].reshape(-1), T[f"gy_l{l}"].reshape(-1)), -1), T[f"P_l{l}"][0],
+                              T[f"vals_l{l}"][0, :, 0], T[f"K_l{l}"])
+    assert rel(J, T[f"J_l{l}"][0, :, 0, :]) < 1e-6
+    term = {"max_iter": 50, "delta_norm": 1e-3, "rel_tol": 1e-3, "grad_norm": 1.0}
+    Tf, af, its = tracking.pyramid_tracking(
+        T["Tji_init"][0], torch.zeros(2), [T[f"vals_l{i}"][0, :, 0] for i in range(3)], [T[f"P_l{i}"][0] for i in range(3)],
+        [T[f"J_l{i}"][0, :, 0, :] for i in range(3)], [T[f"mask_l{i}"][0] for i in range(3)],
+        [T[f"K_l{i}"] for i in range(3)], [T[f"cur_l{i}"][0, 0] for i in range(3)], term)
+    assert (Tf - T["pyr_T"][0]).abs().max() < 1e-5 and (af - T["pyr_aff"][0, :, 0]).abs().max() < 1e-5
+
+
+def test_two_frame_sfm(golden):
+    S = golden("sfm_f64.npz")
+    D = S["H"].shape[0]
+    H = torch.zeros((D, D), dtype=torch.float64)
+    g = torch.zeros(D, dtype=torch.float64)
+    o = sfm.construct_photo_system(S["Tji"][0], S["logz_m"][0, :, 0], S["coords_i"][0], S["vals_i"][0, 0], S["Kt"][0],
+                                   S["img_and_grads_j"][0], S["K"], H, g)
+    assert torch.equal(o["valid"], S["valid"][0])
+    assert rel(H, S["H"]) < 1e-9 and rel(g, S["g"]) < 1e-9
+    assert abs(o["err"].item() - S["err"].item()) / S["err"].item() < 1e-9
+
+
+def test_cov_ops(golden):
+    C = golden("cov_ops_f32.npz")
+    K12 = depthcov.cross_cov_native(C["x1"], C["E1"], C["x2"], C["E2"], float(C["scale"]))
+    assert rel(K12, C["K12"]) < 5e-7
+    Ks = depthcov.cross_cov_native(C["xs"][:, :5], C["Es"][:, :5], C["xs"][:, 3:], C["Es"][:, 3:], 1.0)
+    assert rel(Ks, C["K_slice"]) < 5e-7
+    Kp = depthcov.cross_cov_py(C["x1"].double(), C["E1"].double(), C["x2"].double(), C["E2"].double(), 1.0)
+    assert rel(Kp, C["K12_py64"]) < 1e-14
+    assert rel(depthcov.cross_cov_py(C["x1"].double(), C["E1"].double(), C["x1"].double(), C["E1"].double(), 1.0),
+               C["K11_py64"]) < 1e-14
+    Em = depthcov.interp_cov_params(C["cov_params_img"].expand(2, -1, -1, -1), C["x1"])
+    assert rel(Em, C["E1"]) < 1e-6
+    idx, coords, *_ = depthcov.greedy_sampler(C["cov_params_img"], int(C["samp_num"]), 1.0, int(C["samp_border"]),
+                                              float(C["samp_dist_thresh"]))
+    assert torch.equal(idx, C["samp_domain_inds"][0]) and torch.equal(coords, C["samp_coords"][0])
+    L, obs, var = C["app_L0"].clone(), C["app_obs0"].clone(), C["app_var0"].clone()
+    for i in range(1, 6):
+        k_ni = depthcov.cross_cov_native(C["app_x"][:, :i], C["app_E"][:, :i], C["app_x"][:, i:i + 1], C["app_E"][:, i:i + 1], 1.0)
+        k_id = depthcov.cross_cov_native(C["app_x"][:, i:i + 1], C["app_E"][:, i:i + 1], C["app_dn"], C["app_Ed"], 1.0)
+        depthcov.chol_append(L, obs, var, k_ni, k_id, 1.0, i)
+    assert rel(L, C["app_L"]) < 1e-6 and rel(obs, C["app_obs"]) < 1e-5 and (var - C["app_var"]).abs().max() < 1e-5
+
+
+def test_image_ops(golden):
+    I = golden("image_ops.npz")
+    gx, gy = image.scharr(I["img"])
+    assert rel(gx, I["gx"]) < 1e-14 and rel(gy, I["gy"]) < 1e-14
+    pyr = image.image_pyramid(I["img"], 0, 3)
+    Kp = image.intrinsics_pyramid(I["K"], 0, 3)
+    for i in range(3):
+        assert rel(pyr[i], I[f"pyr{i}"]) < 1e-14 and torch.equal(Kp[i], I[f"K{i}"])
+
+
+def test_ref_native_op_matches_fixture(golden):
+    """oracle/_ref (the reference's own C++ op) is what produced the fixture: check it still loads and agrees."""
+    from oracle import build_ref
+    m = build_ref.load()
+    if m is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference)")
+    C = golden("cov_ops_f32.npz")
+    assert torch.equal(m.cross_covariance(C["x1"], C["E1"], C["x2"], C["E2"], float(C["scale"])), C["K12"])
