@@ -1,0 +1,100 @@
+"""ctypes binding of libcomo_hip.so (the C ABI declared in include/como_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, the caller gets a RuntimeError.
+torch is imported first so that the HIP runtime torch bundles (libamdhip64.so, soname .so.7) is the one
+the library binds to -- one runtime, one set of streams.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcomo_hip.so")
+_lib = None
+
+c_void_p, c_int, c_long, c_double, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_double, ctypes.c_float
+
+
+class BAArgs(ctypes.Structure):
+    """Mirror of `struct como_ba_args` (include/como_hip.h) -- field order must match."""
+    _fields_ = [
+        ("b", c_int), ("n", c_int), ("m", c_int), ("H", c_int), ("W", c_int), ("zmode", c_int), ("chunks", c_int),
+        ("phase", c_int), ("h_is_f64", c_int),
+        ("Pwn", c_void_p), ("vals", c_void_p), ("dPwn_dTwc", c_void_p), ("zjac", c_void_p), ("uvec", c_void_p),
+        ("pixidx", c_void_p), ("invz", c_void_p), ("kt_slot_stride", c_long), ("poses_all", c_void_p),
+        ("aff_all", c_void_p), ("img_base", c_void_p), ("K", c_void_p), ("ref_slot", c_void_p), ("ref_aff", c_void_p),
+        ("tgt_aff", c_void_p), ("tgt_pose", c_void_p), ("tgt_img", c_void_p), ("pose_ref_inds", c_void_p),
+        ("pose_tgt_inds", c_void_p), ("landmark_inds", c_void_p), ("dzdP", c_void_p), ("Hmat", c_void_p),
+        ("gvec", c_void_p), ("D", c_long), ("err_out", c_void_p), ("sigma_out", c_void_p), ("pj_out", c_void_p),
+        ("pair_blocks_out", c_void_p), ("ws_r", c_void_p), ("ws_valid", c_void_p), ("ws_hists", c_void_p),
+        ("ws_pair", c_void_p), ("ws_partials", c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/como_hip.h declares
+SIGNATURES = {
+    "como_abi_version": (c_int, []),
+    "como_select_workspace_bytes": (c_int, []),
+    "como_select_begin": (c_int, [c_void_p, c_void_p]),
+    "como_select_hist_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_int, c_void_p]),
+    "como_select_hist_f64": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_int, c_void_p]),
+    "como_select_finish_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "como_select_finish_f64": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "como_track_partials_bytes": (c_long, []),
+    "como_track_iter_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 9),
+    "como_track_iter_f64": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 9),
+    "como_ba_partials_elems": (c_long, [c_int, c_int, c_int]),
+    "como_ba_linearize_f32": (c_int, [ctypes.POINTER(BAArgs), c_void_p]),
+    "como_ba_linearize_f64": (c_int, [ctypes.POINTER(BAArgs), c_void_p]),
+    "como_cross_covariance_f32": (c_int, [c_void_p] * 4 + [c_float, c_void_p, c_int, c_int, c_int,
+                                                        ctypes.POINTER(c_long), c_void_p]),
+    "como_cross_covariance_f64": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int, c_int, c_int,
+                                                        ctypes.POINTER(c_long), c_void_p]),
+    "como_chol_append_obs_info_f32": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int, c_int, c_void_p]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"como_amd: {LIB_PATH} is missing -- the HIP extension is not built. "
+                "Run `python -m como_amd.build` (or __graft_entry__.build()). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"como_amd: {what} failed with status {rc} "
+                           f"({ {1: 'bad argument', 2: 'launch failure'}.get(rc, 'unknown') })")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("como_amd: tensors must live on the GPU (the HIP path has no CPU fallback)")
+
+
+def suffix(dtype):
+    if dtype == torch.float32:
+        return "f32"
+    if dtype == torch.float64:
+        return "f64"
+    raise RuntimeError(f"como_amd: unsupported dtype {dtype}")

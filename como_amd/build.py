@@ -1,0 +1,56 @@
+"""Build libcomo_hip.so (all HIP kernels + the C ABI) for gfx950 with hipcc, in-tree.
+
+    python -m como_amd.build            # incremental
+    python -m como_amd.build --force
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libcomo_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-result"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps():
+    hdr = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cuh", ".h"))]
+    hdr.append(os.path.join(os.path.dirname(HERE), "include", "como_hip.h"))
+    return hdr
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIBDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    newest_hdr = max(os.path.getmtime(h) for h in _deps())
+    procs = []
+    for src in sources():
+        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        objs.append(obj)
+        if (not force and os.path.exists(obj)
+                and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_hdr)):
+            continue
+        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{out.decode()}")
+    if procs or not os.path.exists(LIB) or force:
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,485 @@
+// Window bundle adjustment: photometric linearisation of all keyframe pairs on the device.
+//
+// Reference path: como/odom/backend/photo.py:83-233 (`batch_photo_cost`), gray images (c = 1):
+//   per pair (i -> j) and reference pixel n:  P_cj = T_wcj^-1 P_wn ; sample [I, gx, gy]_j ;
+//   r = I_j - e^{a_j - a_i} I_i + (b_j - b_i) ; GLOBAL sigma = 1.4826 median|r| over all valid
+//   pixels of all pairs ; Huber ; row = [J_i (8) | J_j (8) | J_z (m)] ; blocks J^T J, J^T r ;
+//   z -> 3-D landmark expansion with the per-frame constant dz/dP_w ; scatter into dense H, g.
+//
+// Kernel chain (all on `stream`, no host synchronisation):
+//   ba_pair_setup   : per-pair target inverse pose (exact op order), affine scale / bias
+//   ba_residual     : warp + bilinear sample + residual + validity mask + pass-0 |r| histogram
+//   select_hist x(P-1)
+//   ba_blocks       : per (pair, pixel-chunk) workgroup; per wave: phase A = per-pixel rows (VALU,
+//                     staged in LDS), phase B = the symmetric (16+m)x(16+m) Gram matrix of the rows
+//                     on the MATRIX cores (v_mfma_f32_16x16x4_f32 / v_mfma_f64_16x16x4_f64, K = pixels),
+//                     J^T r by VALU FMAs + wave shuffles.  J is never written to memory.
+//   ba_reduce_assemble : ordered (deterministic) fp64 sum of the per-wave partials, landmark expansion,
+//                     accumulation into H (both triangles) and g.
+//
+// Algorithmic traffic (SURVEY.md section 8d unit B): (34 + m) scalars per pixel-pair.
+#include "select.cuh"
+#include "../../include/como_hip.h"
+
+namespace como {
+
+template <typename T> int select_hist(const T*, const uint8_t*, long, uint32_t*, int, hipStream_t);
+
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Acc4 { typedef T type __attribute__((ext_vector_type(4))); };
+
+__device__ __forceinline__ typename Acc4<float>::type mfma16(float a, float b, typename Acc4<float>::type c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ typename Acc4<double>::type mfma16(double a, double b, typename Acc4<double>::type c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+// C/D register layout of the 16x16x4 MFMA: row of (lane, reg); column is lane & 15 for both.
+template <typename T> __host__ __device__ constexpr int mfma_row(int lane, int reg);
+template <> __host__ __device__ constexpr int mfma_row<float>(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+template <> __host__ __device__ constexpr int mfma_row<double>(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+
+struct BAPairs {
+  const int* ref_slot;     // [b] index of the reference keyframe's slot in the per-reference arrays
+  const int* ref_aff;      // [b] index into aff_all of the reference affine params
+  const int* tgt_aff;      // [b] index into aff_all of the target affine params
+  const int* tgt_pose;     // [b] index into poses_all of the target pose
+  const long* tgt_img;     // [b] element offset of the target [I,gx,gy] stack relative to img_base
+};
+
+template <typename T>
+__global__ void ba_pair_setup_kernel(const T* __restrict__ poses_all, const T* __restrict__ aff_all, BAPairs pr, int b,
+                                     T* __restrict__ pair_T, T* __restrict__ pair_aff) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= b) return;
+  invert_pose34(poses_all + 16 * (long)pr.tgt_pose[p], pair_T + 12 * (long)p);   // photo.py:105
+  const T* ai = aff_all + 2 * (long)pr.ref_aff[p];
+  const T* aj = aff_all + 2 * (long)pr.tgt_aff[p];
+  pair_aff[2 * p + 0] = exp(aj[0] - ai[0]);                                      // photo.py:115
+  pair_aff[2 * p + 1] = aj[1] - ai[1];                                           // photo.py:117
+}
+
+// Everything one (pair, pixel) needs from the warp; shared by pass 1 and pass 2.
+template <typename T>
+struct Warp {
+  T X, Y, Z, u, v;
+  bool ok;
+};
+
+template <typename T>
+__device__ __forceinline__ Warp<T> warp_point(const T* __restrict__ M, T fx, T fy, T cx, T cy, T Px, T Py, T Pz, int H, int W) {
+  Warp<T> w;
+  rigid_apply(M, Px, Py, Pz, w.X, w.Y, w.Z);            // photo.py:106, transforms.py:17-23
+  w.u = project1(fx, w.X, w.Z, cx);                     // camera.py:20-26
+  w.v = project1(fy, w.Y, w.Z, cy);
+  w.ok = in_image(w.u, w.v, H, W) && (w.Z > T(0));      // photo.py:15-21
+  return w;
+}
+
+// ---------------------------------------- pass 1 -------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ba_residual_kernel(
+    const T* __restrict__ Pwn, const T* __restrict__ vals, BAPairs pr, const T* __restrict__ pair_T,
+    const T* __restrict__ pair_aff, const T* __restrict__ img_base, const T* __restrict__ Kmat, int H, int W, int n,
+    T* __restrict__ r_out, uint8_t* __restrict__ valid_out, T* __restrict__ pj_out, uint32_t* __restrict__ hists) {
+  using KeyT = typename KeyOf<T>::type;
+  __shared__ uint32_t lh[SEL_BINS];
+  for (int b = threadIdx.x; b < SEL_BINS; b += 256) lh[b] = 0;
+  const int p = blockIdx.y;
+  const int slot = pr.ref_slot[p];
+  const T* M = pair_T + 12 * (long)p;
+  T Mr[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mr[k] = M[k];
+  const T scale = pair_aff[2 * p], bias = pair_aff[2 * p + 1];
+  const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  const T ax = T(1) / T(W), ay = T(1) / T(H);
+  const T* img = img_base + pr.tgt_img[p];
+  const long HW = (long)H * W;
+  __syncthreads();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const long ri = (long)slot * n + i;
+    Warp<T> w = warp_point(Mr, fx, fy, cx, cy, Pwn[3 * ri], Pwn[3 * ri + 1], Pwn[3 * ri + 2], H, W);
+    Taps<T> t = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
+    const T It = tap_sum(img, t);
+    const T r = It - scale * vals[ri] + bias;           // photo.py:114-118
+    const long oi = (long)p * n + i;
+    r_out[oi] = r;
+    valid_out[oi] = w.ok ? 1 : 0;
+    if (pj_out) { pj_out[2 * oi] = w.u; pj_out[2 * oi + 1] = w.v; }
+    if (w.ok) atomicAdd(&lh[sel_digit<KeyT>(abs_key(r), 0)], 1u);
+  }
+  __syncthreads();
+  sel_flush(lh, hists);
+}
+
+// ---------------------------------------- pass 2 -------------------------------------------------
+constexpr int JP_STRIDE = 66;   // LDS row stride of the staged pose rows: conflict-free for both phases
+
+// Row layout of one residual: 80 columns = 5 blocks of 16: block 0 = [J_i (8) | J_j (8)], blocks 1..4 = depth
+// columns.  Lane-column ci of depth block t owns depth column kcol(t, ci) = 4 ci + (t - 1): every lane loads ONE
+// contiguous quad (4ci..4ci+3) of the m-wide K~ / dPwn_dzm row (a fully coalesced 1 KiB wave load per 4 pixels)
+// and feeds element t-1 of it to block t.  m <= 64, m % 4 == 0; columns >= m are zero.
+struct BACfg {
+  static constexpr int NB = 5;
+  static constexpr int NT = NB * (NB + 1) / 2;         // 15 upper-triangular 16x16 tiles
+  static constexpr int REC = NT * 256 + NB * 16 + 16;  // per-wave partial record (elements) = 3936
+};
+__host__ __device__ constexpr int kcol(int t, int ci) { return 4 * ci + (t - 1); }
+
+template <typename T> struct V4 { T x, y, z, w; };
+template <typename T>
+__device__ __forceinline__ V4<T> load4(const T* __restrict__ p) {
+  V4<T> v;
+  if constexpr (sizeof(T) == 4) {
+    const float4 f = *reinterpret_cast<const float4*>(p);
+    v.x = f.x; v.y = f.y; v.z = f.z; v.w = f.w;
+  } else {
+    const double2 a = *reinterpret_cast<const double2*>(p);
+    const double2 b = *reinterpret_cast<const double2*>(p + 2);
+    v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
+  }
+  return v;
+}
+
+// ZMODE 0: materialised dPwn_dzm (slots, n, 3, m) exactly as the reference passes it (photo.py:92)
+// ZMODE 1: factored rank-1 form  dPwn_dzm[n,:,k] = uvec[n,:] * Kt[pix(n), k] * invz[k]
+//          (sparse_map.py:184-230: R_wc ray z_n * K~[n,k] / z_mk), K~ read straight from the dense predictor.
+template <typename T, int ZMODE>
+__global__ __launch_bounds__(256) void ba_blocks_kernel(
+    const T* __restrict__ Pwn, const T* __restrict__ vals, const T* __restrict__ dPwn_dTwc,
+    const T* __restrict__ zjac,      // ZMODE 0: dPwn_dzm ; ZMODE 1: K~ dense (slots_kf, HW_kt, m)
+    const T* __restrict__ uvec,      // ZMODE 1: (slots, n, 3)
+    const int* __restrict__ pixidx,  // ZMODE 1: (slots, n) row index into K~ of that slot (nullptr -> identity)
+    const T* __restrict__ invz,      // ZMODE 1: (slots, m)
+    long kt_slot_stride,             // ZMODE 1: elements between consecutive slots of K~
+    BAPairs pr, const T* __restrict__ pair_T, const T* __restrict__ pair_aff, const T* __restrict__ img_base,
+    const T* __restrict__ Kmat, int H, int W, int n, int m, int chunk_len, const uint32_t* __restrict__ hists,
+    T* __restrict__ partials, T* __restrict__ sigma_out) {
+  using KeyT = typename KeyOf<T>::type;
+  using Cfg = BACfg;
+  using acc_t = typename Acc4<T>::type;
+  __shared__ SelScratch sc;
+  constexpr int STG = 16 * JP_STRIDE + 64 * 5;                  // per-wave staging elements
+  constexpr int LDS_ELEMS = (4 * STG > 2 * Cfg::REC) ? 4 * STG : 2 * Cfg::REC;
+  __shared__ T lds[LDS_ELEMS];                                  // staging, later reused for the cross-wave reduction
+
+  KeyT prefix; uint32_t k_rem, nv;
+  sel_resolve<KeyT>(hists, SelCfg<KeyT>::NPASS, &sc, prefix, k_rem, nv);
+  const T sigma = T(1.4826) * key_value(prefix);          // photo.py:128
+  const T info_sqrt = T(1) / sigma;                       // photo.py:68
+  if (sigma_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sigma_out[0] = sigma; sigma_out[1] = (T)nv; }
+
+  const int p = blockIdx.y;
+  const int slot = pr.ref_slot[p];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  T* Jp = lds + wv * STG;                   // [16][JP_STRIDE]
+  T* Sv = Jp + 16 * JP_STRIDE;         // [5][64]: 0 = r~, 1..3 = s*dI/dPw (ZMODE 0) or 1 = s*(dI/dPw . u), 4 = pixel row (as int bits)
+
+  T Mr[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mr[k] = pair_T[12 * (long)p + k];
+  const T scale = pair_aff[2 * p], bias = pair_aff[2 * p + 1];
+  const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  const T ax = T(1) / T(W), ay = T(1) / T(H);
+  const T* img = img_base + pr.tgt_img[p];
+  const long HW = (long)H * W;
+
+  T invz4[4] = {T(0), T(0), T(0), T(0)};
+  if constexpr (ZMODE == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
+  }
+
+  acc_t acc[Cfg::NT];
+#pragma unroll
+  for (int t = 0; t < Cfg::NT; ++t) acc[t] = acc_t{T(0), T(0), T(0), T(0)};
+  T gacc[Cfg::NB];
+#pragma unroll
+  for (int t = 0; t < Cfg::NB; ++t) gacc[t] = T(0);
+  T err = T(0);
+
+  const int begin = blockIdx.x * chunk_len;
+  const int end = min(n, begin + chunk_len);
+  for (int tile = begin + wv * 64; tile < end; tile += 256) {
+    // ------------------------- phase A: lane = pixel ------------------------------------------
+    {
+      const int i = tile + lane;
+      const bool inr = i < end;
+      const long ri = (long)slot * n + (inr ? i : (end - 1));
+      Warp<T> w = warp_point(Mr, fx, fy, cx, cy, Pwn[3 * ri], Pwn[3 * ri + 1], Pwn[3 * ri + 2], H, W);
+      Taps<T> tp = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
+      const T It = tap_sum(img, tp), gx = tap_sum(img + HW, tp), gy = tap_sum(img + 2 * HW, tp);
+      const T Iref_s = scale * vals[ri];
+      const T r = It - Iref_s + bias;
+      const bool ok = inr && w.ok;
+      const T wr = r * info_sqrt;
+      const T wgt = ok ? huber(wr) : T(0);                 // photo.py:70-72
+      const T ws = sqrt(wgt);
+      const T s = ok ? info_sqrt * ws : T(0);              // invalid pixels contribute exactly zero
+      err += ok ? (ws * wr) * (ws * wr) : T(0);            // photo.py:79
+      // dI/dP_cj = [gx gy] dp/dP_c  (camera.py:28-35), zeroed when invalid so no NaN/inf leaks through s = 0
+      const T iz = ok ? T(1) / w.Z : T(0);
+      const T a0 = gx * fx * iz, a1 = gy * fy * iz;
+      const T a2 = -(a0 * w.X + a1 * w.Y) * iz;
+      // dI/dP_w = dI/dP_c R_cw  (photo.py:135)
+      const T b0 = a0 * Mr[0] + a1 * Mr[4] + a2 * Mr[8];
+      const T b1 = a0 * Mr[1] + a1 * Mr[5] + a2 * Mr[9];
+      const T b2 = a0 * Mr[2] + a1 * Mr[6] + a2 * Mr[10];
+      // reference-pose block: dI/dP_w dP_w/dT_wci (photo.py:145)
+      const T* D = dPwn_dTwc + 18 * ri;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Jp[k * JP_STRIDE + lane] = s * (b0 * D[k] + b1 * D[6 + k] + b2 * D[12 + k]);
+      Jp[6 * JP_STRIDE + lane] = s * Iref_s;               // photo.py:121
+      Jp[7 * JP_STRIDE + lane] = -s;
+      // target-pose block: dP_c/dT_wcj = [[P_c]x, -I]  (= dPc/dTcw (-Ad(T_wc)), photo.py:107,146)
+      const T Xc = ok ? w.X : T(0), Yc = ok ? w.Y : T(0), Zc = ok ? w.Z : T(0);
+      Jp[8 * JP_STRIDE + lane] = s * (a1 * Zc - a2 * Yc);
+      Jp[9 * JP_STRIDE + lane] = s * (a2 * Xc - a0 * Zc);
+      Jp[10 * JP_STRIDE + lane] = s * (a0 * Yc - a1 * Xc);
+      Jp[11 * JP_STRIDE + lane] = -s * a0;
+      Jp[12 * JP_STRIDE + lane] = -s * a1;
+      Jp[13 * JP_STRIDE + lane] = -s * a2;
+      Jp[14 * JP_STRIDE + lane] = -s * Iref_s;
+      Jp[15 * JP_STRIDE + lane] = s;
+      Sv[0 * 64 + lane] = s * r;                           // whitened residual r~
+      if constexpr (ZMODE == 0) {
+        Sv[1 * 64 + lane] = s * b0; Sv[2 * 64 + lane] = s * b1; Sv[3 * 64 + lane] = s * b2;
+      } else {
+        const T* U = uvec + 3 * ri;
+        Sv[1 * 64 + lane] = s * (b0 * U[0] + b1 * U[1] + b2 * U[2]);
+        reinterpret_cast<int*>(Sv + 4 * 64)[lane] = pixidx ? pixidx[ri] : (inr ? i : (end - 1));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ------------------------- phase B: 4 pixels per MFMA step --------------------------------
+    const long zbase0 = (long)slot * n;
+#pragma unroll 2
+    for (int st = 0; st < 16; ++st) {
+      const int px = 4 * st + q;                           // this lane's pixel inside the tile
+      T a[Cfg::NB];
+      a[0] = Jp[c * JP_STRIDE + px];
+      const T rt = Sv[px];
+      if constexpr (ZMODE == 0) {
+        const int i = min(tile + px, end - 1);
+        const T* Zr = zjac + (zbase0 + i) * 3 * (long)m;
+        const T d0 = Sv[64 + px], d1 = Sv[128 + px], d2 = Sv[192 + px];
+        V4<T> z0{T(0), T(0), T(0), T(0)}, z1 = z0, z2 = z0;
+        if (4 * c < m) { z0 = load4(Zr + 4 * c); z1 = load4(Zr + m + 4 * c); z2 = load4(Zr + 2 * (long)m + 4 * c); }
+        const T j0 = d0 * z0.x + d1 * z1.x + d2 * z2.x;
+        const T j1 = d0 * z0.y + d1 * z1.y + d2 * z2.y;
+        const T j2 = d0 * z0.z + d1 * z1.z + d2 * z2.z;
+        const T j3 = d0 * z0.w + d1 * z1.w + d2 * z2.w;
+        a[1] = j0; a[2] = j1; a[3] = j2; a[4] = j3;
+      } else {
+        const int row = reinterpret_cast<const int*>(Sv + 4 * 64)[px];
+        const T* Kr = zjac + (long)slot * kt_slot_stride + (long)row * m;
+        const T sz = Sv[64 + px];
+        V4<T> k4{T(0), T(0), T(0), T(0)};
+        if (4 * c < m) k4 = load4(Kr + 4 * c);
+        a[1] = sz * k4.x * invz4[0]; a[2] = sz * k4.y * invz4[1]; a[3] = sz * k4.z * invz4[2]; a[4] = sz * k4.w * invz4[3];
+      }
+#pragma unroll
+      for (int t = 0; t < Cfg::NB; ++t) gacc[t] += a[t] * rt;
+      int tt = 0;
+#pragma unroll
+      for (int ti = 0; ti < Cfg::NB; ++ti)
+#pragma unroll
+        for (int tj = ti; tj < Cfg::NB; ++tj) { acc[tt] = mfma16(a[ti], a[tj], acc[tt]); ++tt; }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  // ------------------------- epilogue: ordered cross-wave reduction, one record per workgroup ---
+#pragma unroll
+  for (int t = 0; t < Cfg::NB; ++t) {
+    gacc[t] += __shfl_xor(gacc[t], 16, 64);
+    gacc[t] += __shfl_xor(gacc[t], 32, 64);
+  }
+  err = wave_sum(err);
+  auto put = [&](T* dst) {
+#pragma unroll
+    for (int t = 0; t < Cfg::NT; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) dst[t * 256 + rg * 64 + lane] = acc[t][rg];
+    if (lane < 16) {
+#pragma unroll
+      for (int t = 0; t < Cfg::NB; ++t) dst[Cfg::NT * 256 + t * 16 + lane] = gacc[t];
+    }
+    if (lane == 0) dst[Cfg::NT * 256 + Cfg::NB * 16] = err;
+  };
+  auto add = [&](const T* src) {
+#pragma unroll
+    for (int t = 0; t < Cfg::NT; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) acc[t][rg] += src[t * 256 + rg * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < Cfg::NB; ++t) gacc[t] += src[Cfg::NT * 256 + t * 16 + (lane & 15)];
+    err += src[Cfg::NT * 256 + Cfg::NB * 16];
+  };
+  __syncthreads();                                   // every wave is done with its staging area
+  if (wv >= 2) put(lds + (wv - 2) * Cfg::REC);
+  __syncthreads();
+  if (wv < 2) add(lds + wv * Cfg::REC);              // wave0 += wave2, wave1 += wave3
+  __syncthreads();
+  if (wv == 1) put(lds);
+  __syncthreads();
+  if (wv == 0) {
+    add(lds);
+    put(partials + (long)(p * gridDim.x + blockIdx.x) * Cfg::REC);
+  }
+}
+
+// ---------------------------------------- stage 2 ------------------------------------------------
+// One thread per record element: fixed-order fp64 sum over the pair's wave partials, then the
+// landmark expansion (photo.py:169-182) and accumulation into H / g (photo.py:184-231).
+template <typename T, typename TH>
+__global__ __launch_bounds__(256) void ba_reduce_assemble_kernel(
+    const T* __restrict__ partials, int nrec_per_pair, BAPairs pr, const long* __restrict__ pose_ref_inds,
+    const long* __restrict__ pose_tgt_inds, const long* __restrict__ landmark_inds, const T* __restrict__ dzdP,
+    int m, TH* __restrict__ Hm, long D, TH* __restrict__ gv, double* __restrict__ err_out,
+    double* __restrict__ pair_blocks) {
+  using Cfg = BACfg;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int p = blockIdx.y;
+  if (e >= Cfg::NT * 256 + Cfg::NB * 16 + 1) return;
+  const T* base = partials + (long)p * nrec_per_pair * Cfg::REC + e;
+  double s = 0;
+  for (int w = 0; w < nrec_per_pair; ++w) s += (double)base[(long)w * Cfg::REC];
+  if (pair_blocks) pair_blocks[(long)p * Cfg::REC + e] = s;
+  const int slot = pr.ref_slot[p];
+  const long* pri = pose_ref_inds + 8 * (long)p;
+  const long* pti = pose_tgt_inds + 8 * (long)p;
+  const long* lmi = landmark_inds + 3 * (long)m * p;
+  const T* dz = dzdP + 3 * (long)slot;
+  // column id -> (kind, index): block 0 entry i: pose index (i<8 ref, else target); block t>=1: depth kcol(t,i)
+  if (e < Cfg::NT * 256) {
+    const int tt = e >> 8, rg = (e >> 6) & 3, lane = e & 63;
+    int ti = 0, tj = 0, cnt = 0;
+    for (int a = 0; a < Cfg::NB; ++a)
+      for (int b = a; b < Cfg::NB; ++b) { if (cnt == tt) { ti = a; tj = b; } ++cnt; }
+    const int ri = mfma_row<T>(lane, rg), ci = lane & 15;
+    if (ti == 0 && tj == 0) {
+      const long ia = ri < 8 ? pri[ri] : pti[ri - 8];
+      const long ib = ci < 8 ? pri[ci] : pti[ci - 8];
+      atomicAdd(&Hm[ia * D + ib], (TH)s);
+    } else if (ti == 0) {
+      const int k = kcol(tj, ci);
+      if (k < m) {
+        const long ia = ri < 8 ? pri[ri] : pti[ri - 8];
+        for (int d = 0; d < 3; ++d) {
+          const TH v = (TH)(s * (double)dz[d]);
+          const long il = lmi[3 * k + d];
+          atomicAdd(&Hm[ia * D + il], v);
+          atomicAdd(&Hm[il * D + ia], v);
+        }
+      }
+    } else {
+      const int k1 = kcol(ti, ri), k2 = kcol(tj, ci);
+      if (k1 < m && k2 < m) {
+        for (int d1 = 0; d1 < 3; ++d1)
+          for (int d2 = 0; d2 < 3; ++d2) {
+            const TH v = (TH)((double)dz[d1] * s * (double)dz[d2]);
+            const long i1 = lmi[3 * k1 + d1], i2 = lmi[3 * k2 + d2];
+            atomicAdd(&Hm[i1 * D + i2], v);
+            if (ti != tj) atomicAdd(&Hm[i2 * D + i1], v);
+          }
+      }
+    }
+  } else if (e < Cfg::NT * 256 + Cfg::NB * 16) {
+    const int t = (e - Cfg::NT * 256) >> 4, ci = e & 15;
+    const double gval = -s;                                  // get_gradient: g = -sum J r (linear_system.py:24-26)
+    if (t == 0) {
+      const long ia = ci < 8 ? pri[ci] : pti[ci - 8];
+      atomicAdd(&gv[ia], (TH)gval);
+    } else {
+      const int k = kcol(t, ci);
+      if (k < m)
+        for (int d = 0; d < 3; ++d) atomicAdd(&gv[lmi[3 * k + d]], (TH)(gval * (double)dz[d]));
+    }
+  } else {
+    atomicAdd(err_out, s);
+  }
+}
+
+// ---------------------------------------- host side ----------------------------------------------
+template <typename T>
+int ba_linearize(const como_ba_args* A, hipStream_t s) {
+  using KeyT = typename KeyOf<T>::type;
+  if (!A || A->b <= 0 || A->n <= 0 || A->m <= 0 || A->m > 64 || (A->m & 3) || A->H < 3 || A->W < 3) return COMO_ERR_ARG;
+  if (!A->Pwn || !A->vals || !A->dPwn_dTwc || !A->zjac || !A->poses_all || !A->aff_all || !A->img_base || !A->K ||
+      !A->ref_slot || !A->ref_aff || !A->tgt_aff || !A->tgt_pose || !A->tgt_img || !A->ws_r || !A->ws_valid ||
+      !A->ws_hists || !A->ws_pair || !A->ws_partials)
+    return COMO_ERR_ARG;
+  if (A->zmode == 1 && (!A->uvec || !A->invz)) return COMO_ERR_ARG;
+  BAPairs pr{A->ref_slot, A->ref_aff, A->tgt_aff, A->tgt_pose, A->tgt_img};
+  const int b = A->b, n = A->n, m = A->m;
+  T* pair_T = (T*)A->ws_pair;
+  T* pair_aff = pair_T + 12 * (long)b;
+  uint32_t* hists = (uint32_t*)A->ws_hists;
+
+  if (A->phase & 1) {
+    if (hipMemsetAsync(hists, 0, 6 * SEL_BINS * sizeof(uint32_t), s) != hipSuccess) return COMO_ERR_LAUNCH;
+    hipLaunchKernelGGL(ba_pair_setup_kernel<T>, dim3((b + 63) / 64), dim3(64), 0, s, (const T*)A->poses_all,
+                       (const T*)A->aff_all, pr, b, pair_T, pair_aff);
+    COMO_CHECK_LAUNCH();
+    int gx = (n + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(ba_residual_kernel<T>, dim3(gx, b), dim3(256), 0, s, (const T*)A->Pwn, (const T*)A->vals, pr,
+                       pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, (T*)A->ws_r,
+                       (uint8_t*)A->ws_valid, (T*)A->pj_out, hists);
+    COMO_CHECK_LAUNCH();
+  }
+  // digit passes 1..P-1 (multi-GPU: the caller all-reduces hists between phases 1, 2a.. and 4)
+  for (int ps = 1; ps < SelCfg<KeyT>::NPASS; ++ps) {
+    if (A->phase & (2 << (ps - 1))) {
+      int rc = select_hist<T>((const T*)A->ws_r, (const uint8_t*)A->ws_valid, (long)b * n, hists, ps, s);
+      if (rc) return rc;
+    }
+  }
+  if (A->phase & 64) {
+    const int chunks = A->chunks;
+    if (chunks <= 0) return COMO_ERR_ARG;
+    int chunk_len = (n + chunks - 1) / chunks;
+    chunk_len = ((chunk_len + 255) / 256) * 256;
+    if ((long)chunk_len * chunks < n) return COMO_ERR_ARG;
+    dim3 grid(chunks, b), blk(256);
+#define LAUNCH_BLOCKS(ZM)                                                                                            \
+  hipLaunchKernelGGL((ba_blocks_kernel<T, ZM>), grid, blk, 0, s, (const T*)A->Pwn, (const T*)A->vals,                 \
+                     (const T*)A->dPwn_dTwc, (const T*)A->zjac, (const T*)A->uvec, A->pixidx, (const T*)A->invz,      \
+                     A->kt_slot_stride, pr, pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, m, \
+                     chunk_len, hists, (T*)A->ws_partials, (T*)A->sigma_out)
+    if (A->zmode == 0) { LAUNCH_BLOCKS(0); } else { LAUNCH_BLOCKS(1); }
+#undef LAUNCH_BLOCKS
+    COMO_CHECK_LAUNCH();
+  }
+  if (A->phase & 128) {
+    if (!A->pose_ref_inds || !A->pose_tgt_inds || !A->landmark_inds || !A->dzdP || !A->Hmat || !A->gvec || !A->err_out)
+      return COMO_ERR_ARG;
+    const int nrec = A->chunks;
+#define LAUNCH_ASM(TH)                                                                                               \
+  hipLaunchKernelGGL((ba_reduce_assemble_kernel<T, TH>), dim3((BACfg::REC + 255) / 256, b), dim3(256), 0, s,          \
+                     (const T*)A->ws_partials, nrec, pr, A->pose_ref_inds, A->pose_tgt_inds, A->landmark_inds,        \
+                     (const T*)A->dzdP, m, (TH*)A->Hmat, A->D, (TH*)A->gvec, (double*)A->err_out,                     \
+                     (double*)A->pair_blocks_out)
+    if (A->h_is_f64) { LAUNCH_ASM(double); } else { LAUNCH_ASM(float); }
+#undef LAUNCH_ASM
+    COMO_CHECK_LAUNCH();
+  }
+  return COMO_OK;
+}
+
+}  // namespace como
+
+extern "C" {
+
+long como_ba_partials_elems(int b, int chunks, int m) {
+  (void)m;
+  return (long)b * chunks * como::BACfg::REC;
+}
+
+int como_ba_linearize_f32(const como_ba_args* a, como_stream_t stream) { return como::ba_linearize<float>(a, (hipStream_t)stream); }
+int como_ba_linearize_f64(const como_ba_args* a, como_stream_t stream) { return como::ba_linearize<double>(a, (hipStream_t)stream); }
+
+}  // extern "C"

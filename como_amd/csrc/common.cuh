@@ -1,0 +1,134 @@
+// Shared device helpers for the como_amd HIP kernels (gfx950 / CDNA4, wave64).
+//
+// Mask-feeding arithmetic (pose inverse, rigid transform, projection) must reproduce
+// the reference's torch-CPU operation order bit for bit: every multiply/add is
+// individually rounded, no FMA contraction ("#pragma clang fp contract(off)"), IEEE
+// division (hipcc default).  Everything else may contract.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define COMO_OK 0
+#define COMO_ERR_ARG 1
+#define COMO_ERR_LAUNCH 2
+
+#define COMO_CHECK_LAUNCH()                                   \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return COMO_ERR_LAUNCH;            \
+  } while (0)
+
+namespace como {
+
+constexpr int WAVE = 64;
+
+// ---- exact-order primitives (reference geometry/*.py as executed by torch CPU) ----------
+template <typename T>
+__device__ __forceinline__ T dot3_seq(T a0, T a1, T a2, T x, T y, T z) {
+#pragma clang fp contract(off)
+  return (a0 * x + a1 * y) + a2 * z;
+}
+
+// P' = R P + t with the 3x4 row-major matrix M (rows r0 r1 r2 | t): transforms.py:17-23
+template <typename T>
+__device__ __forceinline__ void rigid_apply(const T* __restrict__ M, T X, T Y, T Z, T& x, T& y, T& z) {
+#pragma clang fp contract(off)
+  x = dot3_seq(M[0], M[1], M[2], X, Y, Z) + M[3];
+  y = dot3_seq(M[4], M[5], M[6], X, Y, Z) + M[7];
+  z = dot3_seq(M[8], M[9], M[10], X, Y, Z) + M[11];
+}
+
+// u = fx*X/Z + cx: camera.py:20-26
+template <typename T>
+__device__ __forceinline__ T project1(T f, T X, T Z, T c) {
+#pragma clang fp contract(off)
+  return (f * X) / Z + c;
+}
+
+// inverse of a 4x4 row-major pose into a 3x4 row-major [R^T | -(R^T t)]: lie_algebra.py:83-93
+template <typename T>
+__device__ __forceinline__ void invert_pose34(const T* __restrict__ Tm, T* __restrict__ out) {
+#pragma clang fp contract(off)
+  for (int i = 0; i < 3; ++i) {
+    out[i * 4 + 0] = Tm[0 * 4 + i];
+    out[i * 4 + 1] = Tm[1 * 4 + i];
+    out[i * 4 + 2] = Tm[2 * 4 + i];
+    out[i * 4 + 3] = -dot3_seq(Tm[0 * 4 + i], Tm[1 * 4 + i], Tm[2 * 4 + i], Tm[3], Tm[7], Tm[11]);
+  }
+}
+
+// 1 <= u < W-1 and 1 <= v < H-1 : photo.py:15-21, photo_utils.py:12-18
+template <typename T>
+__device__ __forceinline__ bool in_image(T u, T v, int H, int W) {
+  return (u >= T(1)) && (u < T(W - 1)) && (v >= T(1)) && (v < T(H - 1));
+}
+
+// Sample position grid_sample(align_corners=False) really uses after the reference's
+// normalize_coordinates: x_norm = (2a) u + a - 1 (a = 1/size in the CALLER's dtype, coords.py:12-20),
+// then ATen's CPU unnormalize (x_norm + 1) * (size / 2) - 0.5.  Only sampled VALUES depend on this.
+template <typename T>
+__device__ __forceinline__ T grid_position(T u, int size, T a) {
+#pragma clang fp contract(off)
+  T xn = (T(2) * a) * u + a - T(1);
+  return (xn + T(1)) * (T(size) / T(2)) - T(0.5);
+}
+
+// bilinear taps with zero padding
+template <typename T>
+struct Taps {
+  int i00, i01, i10, i11;   // linear indices (clamped)
+  T w00, w01, w10, w11;     // weights (0 where the tap is outside)
+};
+
+template <typename T>
+__device__ __forceinline__ Taps<T> make_taps(T x, T y, int H, int W) {
+  Taps<T> t;
+  T xf = floor(x), yf = floor(y);
+  T wx = x - xf, wy = y - yf;
+  // guard against non-finite coordinates (pixels that are invalid anyway)
+  bool fin = (fabs(x) < T(1e9)) && (fabs(y) < T(1e9));
+  int x0 = fin ? (int)xf : -4, y0 = fin ? (int)yf : -4;
+  int x1 = x0 + 1, y1 = y0 + 1;
+  bool vx0 = (x0 >= 0) && (x0 < W), vx1 = (x1 >= 0) && (x1 < W);
+  bool vy0 = (y0 >= 0) && (y0 < H), vy1 = (y1 >= 0) && (y1 < H);
+  int cx0 = min(max(x0, 0), W - 1), cx1 = min(max(x1, 0), W - 1);
+  int cy0 = min(max(y0, 0), H - 1), cy1 = min(max(y1, 0), H - 1);
+  t.i00 = cy0 * W + cx0; t.i01 = cy0 * W + cx1; t.i10 = cy1 * W + cx0; t.i11 = cy1 * W + cx1;
+  t.w00 = (vx0 && vy0) ? (T(1) - wy) * (T(1) - wx) : T(0);
+  t.w01 = (vx1 && vy0) ? (T(1) - wy) * wx : T(0);
+  t.w10 = (vx0 && vy1) ? wy * (T(1) - wx) : T(0);
+  t.w11 = (vx1 && vy1) ? wy * wx : T(0);
+  return t;
+}
+
+template <typename T>
+__device__ __forceinline__ T tap_sum(const T* __restrict__ plane, const Taps<T>& t) {
+  return t.w00 * plane[t.i00] + t.w01 * plane[t.i01] + t.w10 * plane[t.i10] + t.w11 * plane[t.i11];
+}
+
+// Huber weight: robust_loss.py:9-16
+template <typename T>
+__device__ __forceinline__ T huber(T x) {
+  T a = fabs(x);
+  return (a < T(1.345)) ? T(1) : T(1.345) / a;
+}
+
+// ---- order-preserving integer keys of |r| for the exact median ---------------------------
+__device__ __forceinline__ uint32_t abs_key(float r) { return __float_as_uint(fabsf(r)); }
+__device__ __forceinline__ uint64_t abs_key(double r) { return (uint64_t)__double_as_longlong(fabs(r)); }
+__device__ __forceinline__ float key_value(uint32_t k) { return __uint_as_float(k); }
+__device__ __forceinline__ double key_value(uint64_t k) { return __longlong_as_double((long long)k); }
+
+template <typename T> struct KeyOf;
+template <> struct KeyOf<float> { using type = uint32_t; static constexpr int BITS = 32; };
+template <> struct KeyOf<double> { using type = uint64_t; static constexpr int BITS = 64; };
+
+// ---- wave / block reductions ----------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+}  // namespace como

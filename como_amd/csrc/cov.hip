@@ -1,0 +1,129 @@
+// DepthCov native ops: the two functions the reference exports from its `como_backends` extension.
+//
+//   cross_covariance       como/backend/src/cov_gpu.cu:17-84  (CPU twin src/cov_cpu.cpp:17-64)
+//   get_new_chol_obs_info  como/backend/src/cov_gpu.cu:132-215 (CPU twin src/cov_cpu.cpp:66-85)
+//
+// Numerics follow the reference's device code: safe_sqrt / matern are `float` functions even when the
+// kernel is dispatched for double (include/kernel_functions.h:5-14), and the 1e-8 sits inside
+// sqrt(1/det + 1e-8) (cov_gpu.cu:51) -- unlike the Python twin (depth_cov/core/kernels.py:55-66).
+#include "common.cuh"
+#include "../../include/como_hip.h"
+
+namespace como {
+
+__device__ __forceinline__ float ref_safe_sqrt(float x) { return (float)sqrt((double)x + 1e-8); }
+__device__ __forceinline__ float ref_matern(float Q) {
+  const float tmp = (float)(1.73205080757 * (double)ref_safe_sqrt(Q));
+  return (1.0f + tmp) * expf(-tmp);
+}
+
+struct CovStrides {
+  long x1[3], E1[4], x2[3], E2[4];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void cross_cov_kernel(const T* __restrict__ x1, const T* __restrict__ E1,
+                                                        const T* __restrict__ x2, const T* __restrict__ E2, T scale,
+                                                        T* __restrict__ K12, int N, int M, CovStrides st) {
+  const int b = blockIdx.y;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long)N * M) return;
+  const int i = (int)(p / M), j = (int)(p % M);
+  const T* xa = x1 + b * st.x1[0] + i * st.x1[1];
+  const T* xb = x2 + b * st.x2[0] + j * st.x2[1];
+  const T* Ea = E1 + b * st.E1[0] + i * st.E1[1];
+  const T* Eb = E2 + b * st.E2[0] + j * st.E2[1];
+  const T a00 = Ea[0], a01 = Ea[st.E1[3]], a10 = Ea[st.E1[2]], a11 = Ea[st.E1[2] + st.E1[3]];
+  const T b00 = Eb[0], b01 = Eb[st.E2[3]], b10 = Eb[st.E2[2]], b11 = Eb[st.E2[2] + st.E2[3]];
+  const T dx = xa[0] - xb[0];
+  const T dy = xa[st.x1[2]] - xb[st.x2[2]];
+  const T e00 = a00 + b00, e01 = a01 + b01, e11 = a11 + b11;
+  const T det_inv = (T)(1.0 / (double)(e00 * e11 - e01 * e01));
+  T Q = (e11 * dx * dx) - T(2) * (e01 * dx * dy) + (e00 * dy * dy);
+  Q = (T)((double)Q * (0.5 * (double)det_inv));
+  const T d1 = a00 * a11 - a01 * a10;
+  const T d2 = b00 * b11 - b01 * b10;
+  T pw;
+  if constexpr (sizeof(T) == 4) pw = powf(d1 * d2, 0.25f); else pw = pow(d1 * d2, 0.25);
+  const T C = (T)(2.0 * (double)pw * (double)ref_safe_sqrt((float)det_inv));
+  K12[((long)b * N + i) * M + j] = scale * C * (T)ref_matern((float)Q);
+}
+
+// One wave per batch element: forward substitution for the new Cholesky row (cov_gpu.cu:132-160).
+__global__ __launch_bounds__(64) void chol_row_kernel(float* __restrict__ L, const float* __restrict__ k_ni, float k_ii,
+                                                      int n, int N) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  float* Lb = L + (long)b * n * n;
+  float sum = (lane < N) ? k_ni[(long)b * N + lane] : 0.f;
+  float sumsq = 0.f;
+  for (int i = 0; i < N; ++i) {
+    float li = 0.f;
+    if (lane == i) li = sum / Lb[(long)i * n + i];
+    li = __shfl(li, i, 64);
+    sumsq += li * li;
+    if (lane == i) Lb[(long)N * n + i] = li;
+    if (lane > i && lane < N) sum -= Lb[(long)lane * n + i] * li;
+  }
+  if (lane == 0) Lb[(long)N * n + N] = sqrtf(k_ii - sumsq);
+}
+
+// obs_info row N and variance downdate over the whole domain (cov_gpu.cu:162-182); streams N rows of length d.
+__global__ __launch_bounds__(256) void obs_info_kernel(const float* __restrict__ k_id, const float* __restrict__ L,
+                                                       float* __restrict__ obs_info, float* __restrict__ var, int n,
+                                                       int d, int N) {
+  __shared__ float lrow[64];
+  const int b = blockIdx.y;
+  const float* Lb = L + (long)b * n * n + (long)N * n;
+  if (threadIdx.x <= N && threadIdx.x < 64) lrow[threadIdx.x] = Lb[threadIdx.x];
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= d) return;
+  float* ob = obs_info + (long)b * n * d;
+  float sum = k_id[(long)b * d + j];
+  for (int i = 0; i < N; ++i) sum -= ob[(long)i * d + j] * lrow[i];
+  const float v = sum / lrow[N];
+  ob[(long)N * d + j] = v;
+  var[(long)b * d + j] -= v * v;
+}
+
+template <typename T>
+int cross_cov(const T* x1, const T* E1, const T* x2, const T* E2, T scale, T* K12, int B, int N, int M,
+              const long* strides_host, hipStream_t s) {
+  if (!x1 || !E1 || !x2 || !E2 || !K12 || !strides_host || B < 0 || N < 0 || M < 0) return COMO_ERR_ARG;
+  if (B == 0 || N == 0 || M == 0) return COMO_OK;
+  CovStrides st;
+  for (int k = 0; k < 3; ++k) { st.x1[k] = strides_host[k]; st.x2[k] = strides_host[7 + k]; }
+  for (int k = 0; k < 4; ++k) { st.E1[k] = strides_host[3 + k]; st.E2[k] = strides_host[10 + k]; }
+  const long total = (long)N * M;
+  dim3 grid((unsigned)((total + 255) / 256), B);
+  hipLaunchKernelGGL(cross_cov_kernel<T>, grid, dim3(256), 0, s, x1, E1, x2, E2, scale, K12, N, M, st);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+}  // namespace como
+
+extern "C" {
+
+int como_cross_covariance_f32(const float* x1, const float* E1, const float* x2, const float* E2, float scale,
+                              float* K12, int B, int N, int M, const long* strides_host, como_stream_t stream) {
+  return como::cross_cov<float>(x1, E1, x2, E2, scale, K12, B, N, M, strides_host, (hipStream_t)stream);
+}
+int como_cross_covariance_f64(const double* x1, const double* E1, const double* x2, const double* E2, double scale,
+                              double* K12, int B, int N, int M, const long* strides_host, como_stream_t stream) {
+  return como::cross_cov<double>(x1, E1, x2, E2, scale, K12, B, N, M, strides_host, (hipStream_t)stream);
+}
+
+int como_chol_append_obs_info_f32(float* L, float* obs_info, float* var, const float* k_ni, const float* k_id,
+                                  float k_ii, int B, int n, int d, int N, como_stream_t stream) {
+  if (!L || !obs_info || !var || !k_ni || !k_id || B <= 0 || n <= 0 || n > 64 || d <= 0 || N < 0 || N >= n)
+    return COMO_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(como::chol_row_kernel, dim3(B), dim3(64), 0, s, L, k_ni, k_ii, n, N);
+  COMO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(como::obs_info_kernel, dim3((d + 255) / 256, B), dim3(256), 0, s, k_id, L, obs_info, var, n, d, N);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+}  // extern "C"

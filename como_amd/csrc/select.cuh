@@ -1,0 +1,118 @@
+// Exact device-wide k-th element (lower median, torch.median semantics) by MSB-first radix
+// select over order-preserving integer keys of |r|.
+//
+// Reference semantics: sigma = 1.4826 * median(|r| over valid pixels of ALL pairs in the batch)
+// (como/odom/backend/photo.py:124-128, frontend/photo_tracking.py:131-134,
+//  frontend/two_frame_sfm.py:258-261).  A histogram *approximation* would change sigma and break
+// pose parity, so the select is exact: 3 digit passes for float keys (11+11+10 bits), 6 for double.
+//
+// Layout: `hists` = NPASS x 2048 uint32 counters in device memory, zeroed before pass 0.
+// Pass p histograms digit p of the keys whose higher digits equal the already-resolved prefix.
+// No host round trip: every workgroup of a later kernel re-derives (prefix, k) from the
+// finished histograms in its prologue (`resolve`), which costs one 8 KiB L2 read per pass.
+// Multi-GPU: the per-rank histograms of a pass are summed with one all-reduce between passes.
+#pragma once
+#include "common.cuh"
+
+namespace como {
+
+constexpr int SEL_BINS = 2048;
+
+template <typename KeyT> struct SelCfg;
+template <> struct SelCfg<uint32_t> {
+  static constexpr int NPASS = 3;
+  __host__ __device__ static constexpr int shift(int p) { return p == 0 ? 21 : (p == 1 ? 10 : 0); }
+  __host__ __device__ static constexpr int bits(int p) { return p == 2 ? 10 : 11; }
+};
+template <> struct SelCfg<uint64_t> {
+  static constexpr int NPASS = 6;
+  __host__ __device__ static constexpr int shift(int p) {
+    return p == 0 ? 53 : p == 1 ? 42 : p == 2 ? 31 : p == 3 ? 20 : p == 4 ? 10 : 0;
+  }
+  __host__ __device__ static constexpr int bits(int p) { return p >= 4 ? 10 : 11; }
+};
+
+template <typename KeyT>
+__device__ __forceinline__ uint32_t sel_digit(KeyT key, int p) {
+  return (uint32_t)((key >> SelCfg<KeyT>::shift(p)) & (KeyT)((1u << SelCfg<KeyT>::bits(p)) - 1u));
+}
+
+// true if `key` agrees with `prefix` on all digits above digit p
+template <typename KeyT>
+__device__ __forceinline__ bool sel_match(KeyT key, KeyT prefix, int p) {
+  if (p == 0) return true;
+  const int sh = SelCfg<KeyT>::shift(p - 1);
+  return (key >> sh) == (prefix >> sh);
+}
+
+struct SelScratch {           // LDS scratch for resolve(): 256-thread blocks
+  uint32_t wave_tot[4];
+  uint32_t found_bin;
+  uint32_t found_below;
+  uint32_t total;
+};
+
+// Cooperative (whole 256-thread block) resolution of digits 0..npass_done-1.
+// Returns prefix (key bits resolved so far), k_rem (rank inside the remaining candidate set) and
+// nvalid (sum of the pass-0 histogram).  All threads return identical values.
+template <typename KeyT>
+__device__ void sel_resolve(const uint32_t* __restrict__ hists, int npass_done, SelScratch* sc,
+                            KeyT& prefix, uint32_t& k_rem, uint32_t& nvalid) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  prefix = 0;
+  k_rem = 0;
+  nvalid = 0;
+  for (int p = 0; p < npass_done; ++p) {
+    const uint32_t* h = hists + p * SEL_BINS;
+    uint32_t c[8];
+    uint32_t local = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // written by earlier kernels (or an all-reduce) -> plain loads are coherent across launches
+      c[j] = h[tid * 8 + j];
+      local += c[j];
+    }
+    // inclusive scan of `local` across the block
+    uint32_t incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) sc->wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wv; ++w) base += sc->wave_tot[w];
+    const uint32_t tot = sc->wave_tot[0] + sc->wave_tot[1] + sc->wave_tot[2] + sc->wave_tot[3];
+    if (p == 0) {
+      nvalid = tot;
+      k_rem = (tot > 0) ? (tot - 1) / 2 : 0;   // lower median index
+    }
+    const uint32_t excl = base + incl - local;
+    if (tid == 0) { sc->found_bin = 0; sc->found_below = 0; }
+    __syncthreads();
+    if (local > 0 && k_rem >= excl && k_rem < excl + local) {
+      uint32_t run = excl;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (k_rem >= run && k_rem < run + c[j]) { sc->found_bin = tid * 8 + j; sc->found_below = run; }
+        run += c[j];
+      }
+    }
+    __syncthreads();
+    prefix |= ((KeyT)sc->found_bin) << SelCfg<KeyT>::shift(p);
+    k_rem -= sc->found_below;
+    __syncthreads();
+  }
+}
+
+// Accumulate a block-local LDS histogram into the global one (skipping empty bins).
+__device__ __forceinline__ void sel_flush(const uint32_t* lds_hist, uint32_t* __restrict__ ghist) {
+  for (int b = threadIdx.x; b < SEL_BINS; b += blockDim.x) {
+    uint32_t v = lds_hist[b];
+    if (v) atomicAdd(&ghist[b], v);
+  }
+}
+
+}  // namespace como

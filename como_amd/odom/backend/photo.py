@@ -1,0 +1,183 @@
+"""Drop-in for the reference's como/odom/backend/photo.py on MI355X.
+
+`batch_photo_cost` / `create_photo_system` keep the reference's argument lists and in-place
+accumulation into `H`, `g` (photo.py:83-99, 236-258).  The work happens in the HIP kernel chain of
+csrc/ba.hip through the C ABI entry `como_ba_linearize_*`; there is no CPU fallback.
+
+`photo_system_factored` is the internal fast path SURVEY.md section 8(b) allows: the same maths from the
+rank-1 factors of dPwn_dzm (K~ rows, R_wc ray z_n, 1/z_m) so the (b,n,3,m) tensor is never built.
+"""
+import ctypes
+
+import torch
+
+from como_amd import _lib
+from como_amd.odom.backend.graph_pair_construction import setup_photometric_pairs
+
+_ws = {}
+last_aux = {}   # diagnostics of the most recent call: valid mask, sigma, nvalid (tests / callers that want them)
+
+
+def _buf(name, shape, dtype, device):
+    key = (name, str(device))
+    t = _ws.get(key)
+    numel = 1
+    for s in shape:
+        numel *= int(s)
+    if t is None or t.dtype != dtype or t.numel() < numel:
+        t = torch.empty(max(numel, 1), device=device, dtype=dtype)
+        _ws[key] = t
+    return t[:numel].view(*shape)
+
+
+def default_chunks(b, n, dtype):
+    """Pixel chunks per pair: about two resident rounds of 256-thread workgroups on 256 CUs."""
+    per_cu = 3 if dtype == torch.float32 else 1
+    want = max(1, (2 * 256 * per_cu + b - 1) // b)
+    return int(max(1, min(want, (n + 255) // 256)))
+
+
+def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac, poses_all, aff_all, img_base, K,
+              ref_slot, ref_aff, tgt_aff, tgt_pose, tgt_img, pose_ref_inds, pose_tgt_inds, landmark_inds, dzdP, H, g,
+              err_out, uvec=None, pixidx=None, invz=None, kt_slot_stride=0, chunks=None, phase=0xFF, want_pj=False,
+              want_blocks=False, sigma_out=None):
+    """Thin marshalling layer over como_ba_linearize_* (see include/como_hip.h for every field)."""
+    dev = Pwn.device
+    L = _lib.lib()
+    if chunks is None:
+        chunks = default_chunks(b, n, dtype)
+    a = _lib.BAArgs()
+    a.b, a.n, a.m, a.H, a.W, a.zmode, a.chunks, a.phase = b, n, m, H_img, W_img, zmode, chunks, phase
+    a.h_is_f64 = 1 if H.dtype == torch.float64 else 0
+    ws_r = _buf("r", (b, n), dtype, dev)
+    ws_valid = _buf("valid", (b, n), torch.uint8, dev)
+    ws_hists = _buf("hists", (L.como_select_workspace_bytes() // 4,), torch.int32, dev)
+    ws_pair = _buf("pair", (b * 14,), dtype, dev)
+    ws_part = _buf("partials", (L.como_ba_partials_elems(b, chunks, m),), dtype, dev)
+    if sigma_out is None:
+        sigma_out = _buf("sigma", (2,), dtype, dev)
+    pj = _buf("pj", (b, n, 2), dtype, dev) if want_pj else None
+    blocks = _buf("blocks", (b, 3936), torch.float64, dev) if want_blocks else None
+    keep = [Pwn, vals, dPwn_dTwc, zjac, uvec, pixidx, invz, poses_all, aff_all, img_base, K, ref_slot, ref_aff, tgt_aff,
+            tgt_pose, tgt_img, pose_ref_inds, pose_tgt_inds, landmark_inds, dzdP, H, g, err_out]
+    _lib.require_cuda(*keep)
+    for name, t in (("Pwn", Pwn), ("vals", vals), ("dPwn_dTwc", dPwn_dTwc), ("zjac", zjac), ("uvec", uvec),
+                    ("pixidx", pixidx), ("invz", invz), ("poses_all", poses_all), ("aff_all", aff_all), ("K", K),
+                    ("ref_slot", ref_slot), ("ref_aff", ref_aff), ("tgt_aff", tgt_aff), ("tgt_pose", tgt_pose),
+                    ("tgt_img", tgt_img), ("pose_ref_inds", pose_ref_inds), ("pose_tgt_inds", pose_tgt_inds),
+                    ("landmark_inds", landmark_inds), ("dzdP", dzdP), ("Hmat", H), ("gvec", g), ("err_out", err_out)):
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError(f"como_amd: {name} must be contiguous")
+        setattr(a, name, _lib.ptr(t))
+    a.img_base = img_base if isinstance(img_base, int) else _lib.ptr(img_base)
+    a.kt_slot_stride = int(kt_slot_stride)
+    a.D = H.shape[1]
+    a.sigma_out, a.pj_out, a.pair_blocks_out = _lib.ptr(sigma_out), _lib.ptr(pj), _lib.ptr(blocks)
+    a.ws_r, a.ws_valid, a.ws_hists, a.ws_pair, a.ws_partials = (_lib.ptr(ws_r), _lib.ptr(ws_valid), _lib.ptr(ws_hists),
+                                                                 _lib.ptr(ws_pair), _lib.ptr(ws_part))
+    fn = getattr(L, "como_ba_linearize_" + _lib.suffix(dtype))
+    _lib.check(fn(ctypes.byref(a), _lib.stream_ptr(dev)), "como_ba_linearize")
+    last_aux.clear()
+    last_aux.update({"valid": ws_valid, "r": ws_r, "sigma": sigma_out, "pj": pj, "blocks": blocks, "hists": ws_hists,
+                     "chunks": chunks})
+    return sigma_out
+
+
+def _i32(x, device):
+    return torch.as_tensor(x, dtype=torch.int32, device=device).contiguous()
+
+
+def batch_photo_cost(vals_i, aff_params_i, Pwn, Twcj, aff_params_j, img_and_grads_j, dPwn_dTwci, dPwn_dzm, dzm_dPwm,
+                     pose_ref_inds, pose_target_inds, landmark_inds, intrinsics, H, g):
+    """reference photo.py:83-233: accumulates the photometric normal equations of b pairs into H, g; returns the
+    robustified total error (0-dim tensor).  Gray images only (c = 1)."""
+    b, n, _, m, _ = dPwn_dzm.shape
+    if vals_i.shape[2] != 1:
+        raise RuntimeError("como_amd: gray images (c = 1) only")
+    if m % 4 != 0 or m > 64:
+        raise RuntimeError("como_amd: m must be a multiple of 4 and <= 64")
+    dev, dt = vals_i.device, vals_i.dtype
+    Hh, Ww = img_and_grads_j.shape[-2:]
+    ar = torch.arange(b, dtype=torch.int32, device=dev)
+    aff_all = torch.cat((aff_params_i.reshape(b, 2), aff_params_j.reshape(b, 2)), dim=0).contiguous()
+    img = img_and_grads_j.contiguous()
+    err = torch.zeros((), dtype=torch.float64, device=dev)
+    linearize(dtype=dt, b=b, n=n, m=m, H_img=Hh, W_img=Ww, zmode=0, Pwn=Pwn.contiguous(), vals=vals_i.reshape(b, n).contiguous(),
+              dPwn_dTwc=dPwn_dTwci.contiguous(), zjac=dPwn_dzm.contiguous(), poses_all=Twcj.contiguous(), aff_all=aff_all,
+              img_base=img, K=intrinsics.contiguous(), ref_slot=ar, ref_aff=ar, tgt_aff=(ar + b).contiguous(), tgt_pose=ar,
+              tgt_img=(torch.arange(b, dtype=torch.int64, device=dev) * (3 * Hh * Ww)).contiguous(),
+              pose_ref_inds=pose_ref_inds.contiguous(), pose_tgt_inds=pose_target_inds.contiguous(),
+              landmark_inds=landmark_inds.contiguous(), dzdP=dzm_dPwm[:, 0, 0, :].contiguous(), H=H, g=g, err_out=err,
+              want_pj=True)
+    last_aux["valid"] = last_aux["valid"].bool()
+    return err.to(dt)
+
+
+def create_photo_system(kf_poses, kf_aff_params, recent_poses, recent_aff_params, Pwn, dPwn_dTwc, dPwn_dzm, dzm_dPwm,
+                        median_depths, vals_n, kf_img_and_grads, recent_img_and_grads, kf_timestamps, recent_timestamps,
+                        intrinsics, H, g, photo_construction_cfg, kf_inds, recent_inds, landmark_inds):
+    """reference photo.py:236-353: pair graph + batches of <= pairwise_batch_size pairs (the robust scale is per batch).
+    Returns (err, [kf_ref_ids, kf_target_ids], [one_way_kf_ids, one_way_target_ids])."""
+    kf_ref_ids, kf_target_ids, ow_kf_ids, ow_target_ids = setup_photometric_pairs(
+        kf_poses, recent_poses, kf_timestamps, recent_timestamps, median_depths, photo_construction_cfg)
+    all_ref = kf_ref_ids + ow_kf_ids
+    nkf = len(kf_target_ids)
+    bs = photo_construction_cfg["pairwise_batch_size"]
+    dev = kf_poses.device
+    err = 0.0
+    for b1 in range(0, len(all_ref), bs):
+        b2 = min(b1 + bs, len(all_ref))
+        rid = torch.as_tensor(all_ref[b1:b2], device=dev)
+        kt = torch.as_tensor(kf_target_ids[b1:min(b2, nkf)], dtype=torch.long, device=dev)
+        rt = torch.as_tensor(ow_target_ids[max(b1, nkf) - nkf:max(b2, nkf) - nkf], dtype=torch.long, device=dev)
+        if rt.numel():
+            t_pose = torch.cat((kf_poses[kt], recent_poses[rt]))
+            t_aff = torch.cat((kf_aff_params[kt], recent_aff_params[rt]))
+            t_img = torch.cat((kf_img_and_grads[kt], recent_img_and_grads[rt]))
+            t_ind = torch.cat((kf_inds[kt], recent_inds[rt]))
+        else:
+            t_pose, t_aff, t_img, t_ind = kf_poses[kt], kf_aff_params[kt], kf_img_and_grads[kt], kf_inds[kt]
+        err = err + batch_photo_cost(vals_n[rid], kf_aff_params[rid], Pwn[rid], t_pose, t_aff, t_img, dPwn_dTwc[rid],
+                                     dPwn_dzm[rid], dzm_dPwm[rid], kf_inds[rid], t_ind, landmark_inds[rid],
+                                     intrinsics[0, ...], H, g)
+    return err, [kf_ref_ids, kf_target_ids], [ow_kf_ids, ow_target_ids]
+
+
+class PairTable:
+    """Device-resident description of the pair graph of one window topology (built once per keyframe change,
+    reused by every GN iteration: no per-iteration host->device traffic)."""
+
+    def __init__(self, ref_ids, tgt_ids, tgt_is_recent, num_kf, kf_inds, recent_inds, landmark_inds, img_stride,
+                 recent_img_offset, device):
+        b = len(ref_ids)
+        self.b = b
+        self.ref_slot = _i32(ref_ids, device)
+        self.ref_aff = _i32(ref_ids, device)
+        tgt_frame = [t + (num_kf if r else 0) for t, r in zip(tgt_ids, tgt_is_recent)]
+        self.tgt_aff = _i32(tgt_frame, device)
+        self.tgt_pose = _i32(tgt_frame, device)
+        off = [(recent_img_offset + t * img_stride) if r else t * img_stride for t, r in zip(tgt_ids, tgt_is_recent)]
+        self.tgt_img = torch.as_tensor(off, dtype=torch.int64, device=device)
+        rid = torch.as_tensor(ref_ids, dtype=torch.long, device=device)
+        self.pose_ref_inds = kf_inds[rid].contiguous()
+        rows = []
+        for t, r in zip(tgt_ids, tgt_is_recent):
+            rows.append(recent_inds[t] if r else kf_inds[t])
+        self.pose_tgt_inds = torch.stack(rows).contiguous()
+        self.landmark_inds = landmark_inds[rid].contiguous()
+
+
+def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uvec, Kt, pixidx, invz, dzdP, img_base, K,
+                          H_img, W_img, H, g, err_out, chunks=None, phase=0xFF, sigma_out=None):
+    """Fast path: same normal equations as batch_photo_cost from the rank-1 factors of dPwn_dzm.
+    Per-keyframe arrays (slots = keyframes): Pwn (B,n,3) vals (B,n) dPwn_dTwc (B,n,3,6) uvec (B,n,3) invz (B,m)
+    Kt (B,rows,m) dense predictor, pixidx (B,n) int32 rows of Kt (None = identity), dzdP (B,3)."""
+    B, n = vals.shape
+    m = Kt.shape[-1]
+    return linearize(dtype=vals.dtype, b=table.b, n=n, m=m, H_img=H_img, W_img=W_img, zmode=1, Pwn=Pwn, vals=vals,
+                     dPwn_dTwc=dPwn_dTwc, zjac=Kt, uvec=uvec, pixidx=pixidx, invz=invz,
+                     kt_slot_stride=Kt.stride(0), poses_all=poses_all, aff_all=aff_all, img_base=img_base, K=K,
+                     ref_slot=table.ref_slot, ref_aff=table.ref_aff, tgt_aff=table.tgt_aff, tgt_pose=table.tgt_pose,
+                     tgt_img=table.tgt_img, pose_ref_inds=table.pose_ref_inds, pose_tgt_inds=table.pose_tgt_inds,
+                     landmark_inds=table.landmark_inds, dzdP=dzdP, H=H, g=g, err_out=err_out, chunks=chunks,
+                     phase=phase, sigma_out=sigma_out)

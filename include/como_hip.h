@@ -1,0 +1,138 @@
+/* como_hip.h -- C ABI of libcomo_hip.so: the MI355X (gfx950) hot path of COMO's dense photometric
+ * Gauss-Newton backend and DepthCov inference path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter name ends in `_host`;
+ *   - tensors are dense row-major in the layouts the reference's Python passes around
+ *     (cited per function as reference file:line under /root/reference);
+ *   - no allocation, no exceptions, no host synchronisation inside: the caller owns every buffer
+ *     (outputs and workspaces) and the `stream`; calls only enqueue work on `stream`;
+ *   - return value: 0 = ok, 1 = bad argument, 2 = launch failure.
+ *   - como_stream_t is a hipStream_t (opaque pointer; NULL = default stream).
+ *
+ * Reference interfaces replaced
+ *   como_backends.cross_covariance      como/backend/include/cov.h:10, src/cov.cpp:5-32, src/cov_gpu.cu:17-84
+ *   como_backends.get_new_chol_obs_info como/backend/include/cov.h:18-20, src/cov.cpp:34-65, src/cov_gpu.cu:132-215
+ *   (the functions below marked "python path" replace pure-PyTorch code of the reference, so their
+ *    "FFI" is the Python operator boundary listed in INTEGRATION.md)
+ */
+#ifndef COMO_HIP_H
+#define COMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* como_stream_t;
+
+int como_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Exact k-th select (lower median of |r| over valid entries; torch.median semantics).
+ * python path: photo.py:124-128, photo_tracking.py:131-134, two_frame_sfm.py:258-261.
+ * `hists` = workspace of como_select_workspace_bytes() bytes.  Protocol:
+ *   como_select_begin; como_select_hist_*(pass = 0..P-1) [P = 3 for f32, 6 for f64; multi-GPU: sum the
+ *   ranks' hists of pass p with an all-reduce before pass p+1]; como_select_finish_* -> out3 =
+ *   {median, 1.4826*median, nvalid}. */
+int como_select_workspace_bytes(void);
+int como_select_begin(void* hists, como_stream_t stream);
+int como_select_hist_f32(const float* r, const uint8_t* valid, long n, void* hists, int pass, como_stream_t stream);
+int como_select_hist_f64(const double* r, const uint8_t* valid, long n, void* hists, int pass, como_stream_t stream);
+int como_select_finish_f32(const void* hists, float* out3, como_stream_t stream);
+int como_select_finish_f64(const void* hists, double* out3, como_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Tracking: one inverse-compositional GN iteration (python path: frontend/photo_tracking.py:117-143).
+ *   Tji (4,4)  K (3,3)  aff (2)  P (N,3)  vals_i (N)  img (H,W)  J8 (N,8) [column 6 is overwritten with
+ *   -e^{-a} I_j as the reference does in place]  r_ws (N) workspace  valid_out (N) u8
+ *   pj_out (N,2) / depth_out (N) optional (NULL to skip)  hists: select workspace
+ *   partials: como_track_partials_bytes() bytes
+ *   out (105): [0:64) H | [64:72) g | [72:80) delta | [80:96) T_new | [96:98) aff_new | 98 mean_sq_err |
+ *              99 grad_norm | 100 total_err | 101 sigma | 102 nvalid | 103 |delta| | 104 cholesky info */
+long como_track_partials_bytes(void);
+int como_track_iter_f32(const float* Tji, const float* K, const float* aff, const float* P, const float* vals_i,
+                        const float* img, int H, int W, long N, float* J8, float* r_ws, uint8_t* valid_out,
+                        float* pj_out, float* depth_out, void* hists, void* partials, float* out, como_stream_t stream);
+int como_track_iter_f64(const double* Tji, const double* K, const double* aff, const double* P, const double* vals_i,
+                        const double* img, int H, int W, long N, double* J8, double* r_ws, uint8_t* valid_out,
+                        double* pj_out, double* depth_out, void* hists, void* partials, double* out,
+                        como_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Window BA linearisation (python path: backend/photo.py:83-233 batch_photo_cost).
+ * All scalar tensors have the element type of the entry point (f32 / f64) except H, g (see h_is_f64).
+ * "slot" = row of the per-reference-keyframe arrays a pair reads (several pairs may share a slot). */
+typedef struct como_ba_args {
+  int b;                     /* pairs in this batch */
+  int n;                     /* reference pixels per slot */
+  int m;                     /* inducing points per keyframe: multiple of 4, <= 64 */
+  int H, W;                  /* target image size */
+  int zmode;                 /* 0: zjac = dPwn_dzm (slots,n,3,m) as photo.py:92 receives it
+                                1: factored: zjac = K~ rows (slot, row, m); dPwn_dzm[n,:,k] = uvec[n,:] K~[pix(n),k] invz[k] */
+  int chunks;                /* pixel chunks per pair (grid.x of the block kernel); partial records = b*chunks */
+  int phase;                 /* bit mask: 1 setup+residual(+hist pass 0), 2<<(p-1) hist pass p>=1, 64 blocks, 128 reduce+assemble */
+  int h_is_f64;              /* element type of Hmat / gvec: 1 = double, 0 = float */
+  const void* Pwn;           /* (slots,n,3)   photo.py:86 */
+  const void* vals;          /* (slots,n)     photo.py:84 */
+  const void* dPwn_dTwc;     /* (slots,n,3,6) photo.py:90 */
+  const void* zjac;          /* see zmode */
+  const void* uvec;          /* zmode 1: (slots,n,3) */
+  const int* pixidx;         /* zmode 1: (slots,n) row of K~ per reference pixel, NULL = identity */
+  const void* invz;          /* zmode 1: (slots,m) = dlogz_m/dz_m = 1/z_m */
+  long kt_slot_stride;       /* zmode 1: elements between slots of K~ */
+  const void* poses_all;     /* (F,4,4) target poses T_wc */
+  const void* aff_all;       /* (A,2) affine brightness params */
+  const void* img_base;      /* base pointer of the [I,gx,gy] (3,H,W) stacks */
+  const void* K;             /* (3,3) intrinsics */
+  const int* ref_slot;       /* [b] */
+  const int* ref_aff;        /* [b] index into aff_all */
+  const int* tgt_aff;        /* [b] index into aff_all */
+  const int* tgt_pose;       /* [b] index into poses_all */
+  const long* tgt_img;       /* [b] element offset of the target stack from img_base */
+  const long* pose_ref_inds; /* (b,8) rows of H for the reference pose+affine   photo.py:93 */
+  const long* pose_tgt_inds; /* (b,8)                                            photo.py:94 */
+  const long* landmark_inds; /* (b,3m)                                           photo.py:95 */
+  const void* dzdP;          /* (slots,3) = dzm_dPwm[:,0,0,:]                    photo.py:92,169-182 */
+  void* Hmat;                /* (D,D) accumulated in place, both triangles */
+  void* gvec;                /* (D) */
+  long D;
+  double* err_out;           /* scalar, accumulated (+=) */
+  void* sigma_out;           /* optional (2): {sigma_r, nvalid} in the entry point's element type */
+  void* pj_out;              /* optional (b,n,2) projected pixel coordinates */
+  double* pair_blocks_out;   /* optional (b, 3936): reduced raw per-pair records (tests) */
+  void* ws_r;                /* (b,n) residual workspace */
+  uint8_t* ws_valid;         /* (b,n) validity mask (an OUTPUT as well: bit-exact vs photo.py:15-21) */
+  void* ws_hists;            /* como_select_workspace_bytes() */
+  void* ws_pair;             /* b*14 elements */
+  void* ws_partials;         /* como_ba_partials_elems(b, chunks, m) elements */
+} como_ba_args;
+
+long como_ba_partials_elems(int b, int chunks, int m);
+int como_ba_linearize_f32(const como_ba_args* args_host, como_stream_t stream);
+int como_ba_linearize_f64(const como_ba_args* args_host, como_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DepthCov native ops (the reference's only FFI, pybind module `como_backends`).
+ *
+ * como_cross_covariance_*  replaces  cross_covariance(x1,E1,x2,E2,scale) -> K12
+ *   reference: como/backend/include/cov.h:10, src/cov.cpp:5-32, src/cov_gpu.cu:17-84, src/cov_cpu.cpp:17-64
+ *   x1 (B,N,2) E1 (B,N,2,2) x2 (B,M,2) E2 (B,M,2,2) may be strided views (the sampler passes slices,
+ *   depth_cov/core/samplers.py:167-172,266-268): strides_host[14] = element strides of x1[3], E1[4], x2[3], E2[4]
+ *   (a HOST array).  K12 (B,N,M) dense, caller-allocated.
+ * como_chol_append_obs_info_f32  replaces  get_new_chol_obs_info(L,obs_info,var,k_ni,k_id,k_ii,N)
+ *   reference: include/cov.h:18-20, src/cov.cpp:34-65, src/cov_gpu.cu:132-215, src/cov_cpu.cpp:66-85
+ *   L (B,n,n) obs_info (B,n,d) var (B,d) k_ni (B,N,1) k_id (B,1,d), all contiguous float32; row N of L and
+ *   obs_info and all of var are updated in place.  n <= 64. */
+int como_cross_covariance_f32(const float* x1, const float* E1, const float* x2, const float* E2, float scale,
+                              float* K12, int B, int N, int M, const long* strides_host, como_stream_t stream);
+int como_cross_covariance_f64(const double* x1, const double* E1, const double* x2, const double* E2, double scale,
+                              double* K12, int B, int N, int M, const long* strides_host, como_stream_t stream);
+int como_chol_append_obs_info_f32(float* L, float* obs_info, float* var, const float* k_ni, const float* k_id,
+                                  float k_ii, int B, int n, int d, int N, como_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMO_HIP_H */

@@ -86,9 +86,9 @@ def se3_exp(xi):
 def grid_position(u, size, a):
     """Sample position grid_sample actually uses after the reference's normalise step:
     x_norm = (2a) u + a - 1 (coords.py:12-20, a = 1/size as the caller built it -- float32 in the
-    two-frame path, two_frame_sfm.py:187-190) then ((x_norm + 1) * size - 1) / 2 (align_corners=False)."""
+    two-frame path, two_frame_sfm.py:187-190) then (x_norm + 1) * (size / 2) - 0.5 (ATen CPU, align_corners=False)."""
     xn = (2 * a) * u + a - 1
-    return ((xn + 1) * size - 1) / 2
+    return (xn + 1) * (size / 2) - 0.5
 
 
 def bilinear_zeros(img, u, v, ax=None, ay=None):

@@ -33,3 +33,31 @@ def golden():
             cache[name] = load_golden(name)
         return cache[name]
     return get
+
+
+# ---- diagnostics: every gpu test records the errors it measured; dumped to gpurun_out/gpu_report.json ----
+_REPORT = []
+
+
+def report(name, **vals):
+    rec = {"name": name}
+    for k, v in vals.items():
+        if torch.is_tensor(v):
+            v = v.item() if v.numel() == 1 else v.tolist()
+        rec[k] = v
+    _REPORT.append(rec)
+    print("REPORT", rec)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if _REPORT:
+        import json
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "gpu_report.json"), "w") as f:
+            json.dump(_REPORT, f, indent=1, default=str)
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item()

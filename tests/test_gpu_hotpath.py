@@ -1,0 +1,304 @@
+"""Parity of the HIP hot path (through the C ABI) with the golden vectors and the CPU oracle.
+
+Bars: validity masks and everything that feeds them bit-exact; floating point within the tolerance
+written next to each assert.  Run with `-m gpu` on an MI355X.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import load_golden, rel_err, report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(t):
+    return t.to(DEV).contiguous() if torch.is_tensor(t) else t
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("n", [1, 7, 1000, 250_003])
+def test_exact_median_select(dtype, n):
+    from como_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(n)
+    r = torch.randn(n, generator=g, dtype=dtype) * torch.exp(3 * torch.randn(n, generator=g, dtype=dtype))
+    r[::5] = 0.25          # many ties
+    valid = (torch.rand(n, generator=g) < 0.7)
+    valid[0] = True
+    rd, vd = dev(r), dev(valid.to(torch.uint8))
+    hists = torch.empty(L.como_select_workspace_bytes() // 4, dtype=torch.int32, device=DEV)
+    out = torch.empty(3, dtype=dtype, device=DEV)
+    sfx = _lib.suffix(dtype)
+    s = _lib.stream_ptr()
+    _lib.check(L.como_select_begin(hists.data_ptr(), s), "begin")
+    for p in range(3 if dtype == torch.float32 else 6):
+        _lib.check(getattr(L, "como_select_hist_" + sfx)(rd.data_ptr(), vd.data_ptr(), n, hists.data_ptr(), p, s), "hist")
+    _lib.check(getattr(L, "como_select_finish_" + sfx)(hists.data_ptr(), out.data_ptr(), s), "finish")
+    ref = torch.median(r[valid].abs())
+    o = out.cpu()
+    report("select", dtype=str(dtype), n=n, got=o[0], want=ref, nvalid=o[2])
+    assert o[0].item() == ref.item()                       # exact
+    assert int(o[2].item()) == int(valid.sum())
+    assert o[1].item() == (torch.tensor(1.4826, dtype=dtype) * ref).item()
+
+
+# ------------------------------------------------------------------------------------------------
+def _tracking_inputs(T, l):
+    return (dev(T["Tji_init"]), dev(T[f"P_l{l}"]), dev(T[f"K_l{l}"]), dev(T[f"cur_l{l}"]),
+            torch.zeros((1, 2, 1), device=DEV), dev(T[f"vals_l{l}"]), dev(T[f"J_l{l}"].clone()))
+
+
+def test_tracking_iter_vs_golden():
+    import como_amd.odom.frontend.photo_tracking as pt
+    T = load_golden("tracking_f32.npz")
+    l = 2
+    Tji, P, K, img, aff, vals, J = _tracking_inputs(T, l)
+    A_norm = 1.0 / torch.as_tensor((img.shape[-1], img.shape[-2]), device=DEV, dtype=torch.float32)
+    Tn, an, delta, mse, gn, pj, valid, depth = pt.tracking_iter(Tji, P, K, img, aff, vals, J, 0.1, A_norm)
+    report("tracking_iter", mask_mismatch=(valid.cpu() != T["it_valid"]).sum(), pj_mismatch=(pj.cpu() != T["it_pj"]).sum(),
+           depth_mismatch=(depth.cpu() != T["it_depth"]).sum(), delta_rel=rel_err(delta, T["it_delta"]),
+           T_err=(Tn.cpu() - T["it_T"]).abs().max(), mse=mse, mse_ref=T["it_mse"], gn=gn, gn_ref=T["it_grad_norm"])
+    assert torch.equal(valid.cpu(), T["it_valid"])                    # mask bit-exact
+    assert torch.equal(pj.cpu(), T["it_pj"])                          # projected coordinates bit-exact
+    assert torch.equal(depth.cpu(), T["it_depth"])
+    assert rel_err(delta, T["it_delta"]) < 2e-4                       # fp32 8x8 solve
+    assert (Tn.cpu() - T["it_T"]).abs().max() < 1e-5
+    assert (an.cpu() - T["it_aff"]).abs().max() < 1e-5
+    assert abs(mse.item() - T["it_mse"].item()) < 1e-4 * T["it_mse"].item()
+    assert abs(gn.item() - T["it_grad_norm"].item()) < 1e-4 * T["it_grad_norm"].item()
+    # the in-place side effect of the reference: dI_dT[..., 6] = -e^{-a} I_j
+    assert torch.isfinite(J[..., 6]).all()
+
+
+def test_tracking_pyramid_vs_golden():
+    import como_amd.odom.frontend.photo_tracking as pt
+    T = load_golden("tracking_f32.npz")
+    term = {"max_iter": 50, "delta_norm": 1e-3, "rel_tol": 1e-3, "grad_norm": 1.0}
+    Tf, af = pt.photo_tracking_pyr(dev(T["Tji_init"]), torch.zeros((1, 2, 1), device=DEV),
+                                   [dev(T[f"vals_l{i}"]) for i in range(3)], [dev(T[f"P_l{i}"]) for i in range(3)],
+                                   [dev(T[f"J_l{i}"].clone()) for i in range(3)], [dev(T[f"mask_l{i}"]) for i in range(3)],
+                                   [dev(T[f"K_l{i}"]) for i in range(3)], [dev(T[f"cur_l{i}"]) for i in range(3)], 0.1, term)
+    report("tracking_pyr", T_err=(Tf.cpu() - T["pyr_T"]).abs().max(), aff_err=(af.cpu() - T["pyr_aff"]).abs().max(),
+           gt_err=(Tf.cpu() - T["Tji_gt"]).abs().max())
+    assert (Tf.cpu() - T["pyr_T"]).abs().max() < 1e-4                 # pose within 1e-4 of the reference
+    assert (af.cpu() - T["pyr_aff"]).abs().max() < 1e-4
+
+
+def test_tracking_iter_vs_oracle_fullsize():
+    """640x480, N = 307,200: against the oracle and the reference scalars stored in fullsize_scalars.npz."""
+    import como_amd.odom.frontend.photo_tracking as pt
+    from como_amd import synth
+    from oracle import image as oimg, tracking as otrk
+    tp = synth.make_tracking_pair(H=480, W=640, dtype=torch.float32, seed=3, levels=1)
+    K = tp["intrinsics"]
+    gx, gy = oimg.scharr(tp["img_ref"])
+    v, u = torch.meshgrid(torch.arange(480.), torch.arange(640.), indexing="ij")
+    z = tp["depth_ref"][0, 0]
+    P = torch.stack(((u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z), -1).reshape(-1, 3)
+    # same construction as the reference's backprojection: z * ray (camera.py:43-54)
+    ray = torch.stack(((u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], torch.ones_like(u)), -1).reshape(-1, 3)
+    P = z.reshape(-1, 1) * ray
+    vals = tp["img_ref"].reshape(-1)
+    J = otrk.ic_jacobians(torch.stack((gx.reshape(-1), gy.reshape(-1)), -1), P, vals, K)
+    o = otrk.tracking_iter(tp["Tji_init"][0], P, K, tp["img_cur"][0, 0], torch.zeros(2), vals, J)
+    out = pt.tracking_iter(dev(tp["Tji_init"]), dev(P[None]), dev(K), dev(tp["img_cur"]), torch.zeros((1, 2, 1), device=DEV),
+                           dev(vals[None, :, None]), dev(J[None, :, None, :].clone()), 0.1, None)
+    Tn, an, delta, mse, gn, pj, valid, depth = out
+    F = load_golden("fullsize_scalars.npz")
+    report("tracking_full", mask_mismatch=(valid[0].cpu() != o["valid"]).sum(), nvalid=valid.sum(), nvalid_ref=F["trk_nvalid"],
+           delta_rel=rel_err(delta[0, :, 0], o["delta"]), delta_rel_ref=rel_err(delta[0, :, 0], F["trk_delta"][0, :, 0]),
+           T_err=(Tn[0].cpu() - o["T"]).abs().max())
+    assert torch.equal(valid[0].cpu(), o["valid"])
+    assert torch.equal(pj[0, :, 0].cpu(), o["u"]) and torch.equal(pj[0, :, 1].cpu(), o["v"])
+    assert rel_err(delta[0, :, 0], o["delta"]) < 5e-4
+    assert int(valid.sum()) == int(F["trk_nvalid"])
+    assert rel_err(delta[0, :, 0], F["trk_delta"][0, :, 0]) < 5e-4
+    assert (Tn[0].cpu() - F["trk_T"][0]).abs().max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+def _ba_call(G, dt_h=None):
+    import como_amd.odom.backend.photo as photo
+    dt = G["kf_poses"].dtype
+    rid, tid = G["kf_ref_ids"].long(), G["kf_target_ids"].long()
+    D = G["H_photo"].shape[0]
+    H = torch.zeros((D, D), dtype=dt_h or dt, device=DEV)
+    g = torch.zeros(D, dtype=dt_h or dt, device=DEV)
+    err = photo.batch_photo_cost(dev(G["vals_n"][rid]), dev(G["kf_aff_params"][rid]), dev(G["Pwn"][rid]), dev(G["kf_poses"][tid]),
+                                 dev(G["kf_aff_params"][tid]), dev(G["kf_img_and_grads"][tid]), dev(G["dPwn_dTwc"][rid]),
+                                 dev(G["dPwn_dzm"][rid]), dev(G["dzm_dPwm"][rid]), dev(G["kf_inds"][rid]), dev(G["kf_inds"][tid]),
+                                 dev(G["landmark_inds"][rid]), dev(G["intrinsics"][0]), H, g)
+    return H, g, err, photo.last_aux
+
+
+@pytest.mark.parametrize("name,tol", [("ba_window_f64.npz", 1e-9), ("ba_window_f32.npz", 3e-4)])
+def test_batch_photo_cost_vs_golden(name, tol):
+    G = load_golden(name)
+    H, g, err, aux = _ba_call(G)
+    valid = aux["valid"].cpu()
+    sig = aux["sigma"].cpu()
+    report("ba_golden", case=name, mask_mismatch=(valid != G["kfpair_valid"]).sum(), pj_mismatch=(aux["pj"].cpu() != G["kfpair_pj"]).sum(),
+           r_err=(aux["r"].cpu() - G["kfpair_r"]).abs().max(), sigma=sig[0], sigma_ref=G["sigma_r"], nvalid=sig[1],
+           H_rel=rel_err(H, G["H_photo"]), g_rel=rel_err(g, G["g_photo"]), err=err, err_ref=G["photo_err"],
+           H_asym=(H - H.T).abs().max())
+    assert torch.equal(valid, G["kfpair_valid"])                       # masks bit-exact
+    assert torch.equal(aux["pj"].cpu(), G["kfpair_pj"])                # projected coordinates bit-exact
+    assert (aux["r"].cpu() - G["kfpair_r"]).abs().max() < (1e-12 if tol < 1e-6 else 1e-5)
+    assert abs(sig[0].item() - G["sigma_r"].item()) <= (1e-12 if tol < 1e-6 else 2e-6)
+    assert int(sig[1].item()) == int(G["kfpair_valid"].sum())
+    assert rel_err(H, G["H_photo"]) < tol and rel_err(g, G["g_photo"]) < tol
+    assert abs(err.item() - G["photo_err"].item()) / G["photo_err"].item() < tol
+
+
+def test_gram_layout_vs_oracle():
+    """Raw per-pair 80x80 Gram blocks against the oracle's (asymmetric -> catches any MFMA row/col mix-up)."""
+    from oracle import photo_ba
+    import como_amd.odom.backend.photo as photo
+    G = load_golden("ba_window_f64.npz")
+    rid, tid = G["kf_ref_ids"].long(), G["kf_target_ids"].long()
+    r, valid, J = photo_ba.pair_rows(G["vals_n"][rid], G["kf_aff_params"][rid], G["Pwn"][rid], G["kf_poses"][tid], G["kf_aff_params"][tid],
+                                     G["kf_img_and_grads"][tid], G["dPwn_dTwc"][rid], G["dPwn_dzm"][rid], G["intrinsics"][0])
+    sigma = photo_ba.robust_scale(r, valid)
+    Gm, gv, err = photo_ba.pair_blocks(r, valid, J, sigma)
+    b, n, _, m, _ = G["dPwn_dzm"][rid].shape
+    D = G["H_photo"].shape[0]
+    H = torch.zeros((D, D), dtype=torch.float64, device=DEV)
+    g = torch.zeros(D, dtype=torch.float64, device=DEV)
+    e = torch.zeros((), dtype=torch.float64, device=DEV)
+    ar = torch.arange(b, dtype=torch.int32, device=DEV)
+    aff_all = torch.cat((G["kf_aff_params"][rid].reshape(b, 2), G["kf_aff_params"][tid].reshape(b, 2))).to(DEV)
+    Hh, Ww = G["kf_img_and_grads"].shape[-2:]
+    photo.linearize(dtype=torch.float64, b=b, n=n, m=m, H_img=Hh, W_img=Ww, zmode=0, Pwn=dev(G["Pwn"][rid]),
+                    vals=dev(G["vals_n"][rid].reshape(b, n)), dPwn_dTwc=dev(G["dPwn_dTwc"][rid]), zjac=dev(G["dPwn_dzm"][rid]),
+                    poses_all=dev(G["kf_poses"][tid]), aff_all=aff_all, img_base=dev(G["kf_img_and_grads"][tid]),
+                    K=dev(G["intrinsics"][0]), ref_slot=ar, ref_aff=ar, tgt_aff=(ar + b).contiguous(), tgt_pose=ar,
+                    tgt_img=torch.arange(b, dtype=torch.int64, device=DEV) * (3 * Hh * Ww),
+                    pose_ref_inds=dev(G["kf_inds"][rid]), pose_tgt_inds=dev(G["kf_inds"][tid]),
+                    landmark_inds=dev(G["landmark_inds"][rid]), dzdP=dev(G["dzm_dPwm"][rid][:, 0, 0, :]), H=H, g=g, err_out=e,
+                    want_blocks=True, chunks=3)
+    raw = photo.last_aux["blocks"].cpu()                        # (b, 3936)
+    got = torch.zeros((b, 80, 80), dtype=torch.float64)
+    gg = torch.zeros((b, 80), dtype=torch.float64)
+
+    def col(t, ci):
+        return ci if t == 0 else 16 + 4 * ci + (t - 1)
+    tt = 0
+    for ti in range(5):
+        for tj in range(ti, 5):
+            for rg in range(4):
+                for lane in range(64):
+                    ri, ci = (lane >> 4) + 4 * rg, lane & 15     # f64 MFMA layout
+                    got[:, col(ti, ri), col(tj, ci)] = raw[:, tt * 256 + rg * 64 + lane]
+            tt += 1
+    for t in range(5):
+        for ci in range(16):
+            gg[:, col(t, ci)] = -raw[:, 15 * 256 + t * 16 + ci]
+    want = torch.zeros((b, 80, 80), dtype=torch.float64)
+    want[:, :16 + m, :16 + m] = Gm
+    iu = torch.triu(torch.ones(80, 80, dtype=torch.bool))
+    # only the upper block triangle is produced (diagonal blocks are full)
+    blk = torch.zeros(80, 80, dtype=torch.bool)
+    for ti in range(5):
+        for tj in range(ti, 5):
+            rows = [col(ti, i) for i in range(16)]
+            cols = [col(tj, j) for j in range(16)]
+            blk[np.ix_(rows, cols)] = True
+    d = ((got - want) * blk).abs().max() / want.abs().max()
+    dg = (gg[:, :16 + m] - gv).abs().max() / gv.abs().max()
+    report("gram_layout", gram_rel=d, g_rel=dg, err=photo.last_aux["blocks"][:, 15 * 256 + 80].sum(), err_ref=err)
+    assert d < 1e-10 and dg < 1e-10
+
+
+def test_create_photo_system_recent_vs_golden():
+    """Keyframe + one-way (recent) pairs in one batch: the whole create_photo_system contract."""
+    import como_amd.odom.backend.photo as photo
+    from oracle import dense_ref, depthcov
+    G = load_golden("ba_window_recent_f64.npz")
+    K = G["intrinsics"][0]
+    Kt = depthcov.prep_predictor(G["cov_params_img"], G["coords_m"], 1.0)[2]     # inputs only (oracle == golden-checked)
+    cn = G["coords_n"]
+    bi = torch.arange(cn.shape[0])[:, None].expand(-1, cn.shape[1])
+    Pw, dT, dz, med, _ = dense_ref.dense_reference(G["logzm"], G["kf_poses"], Kt[bi, cn[..., 0], cn[..., 1], :], cn, K,
+                                                   G["dlogzm_dzm"] @ G["dzm_dTwc"], G["dlogzm_dzm"])
+    D = G["H_photo"].shape[0]
+    H = torch.zeros((D, D), dtype=torch.float64, device=DEV)
+    g = torch.zeros(D, dtype=torch.float64, device=DEV)
+    cfg = {"pairwise_batch_size": 128, "radius_thresh": 0.0, "degrees_thresh": 0.0}
+    err, kfp, owp = photo.create_photo_system(dev(G["kf_poses"]), dev(G["kf_aff_params"]), dev(G["recent_poses"]), dev(G["recent_aff_params"]),
+                                              dev(Pw), dev(dT), dev(dz), dev(G["dzm_dPwm"]), dev(med), dev(G["vals_n"]),
+                                              dev(G["kf_img_and_grads"]), dev(G["recent_img_and_grads"]), dev(G["kf_timestamps"]),
+                                              dev(G["recent_timestamps"]), dev(G["intrinsics"]), H, g, cfg, dev(G["kf_inds"]),
+                                              dev(G["recent_inds"]), dev(G["landmark_inds"]))
+    report("ba_recent", H_rel=rel_err(H, G["H_photo"]), g_rel=rel_err(g, G["g_photo"]), err=err, err_ref=G["photo_err"])
+    assert kfp[0] == G["kf_ref_ids"].tolist() and owp[1] == G["ow_target_ids"].tolist()
+    assert rel_err(H, G["H_photo"]) < 1e-9 and rel_err(g, G["g_photo"]) < 1e-9
+    assert abs(float(err) - G["photo_err"].item()) / G["photo_err"].item() < 1e-9
+
+
+def test_factored_path_matches_reference_signature_path():
+    """zmode 1 (rank-1 factors, K~ read in place) == zmode 0 (materialised dPwn_dzm) on the same window."""
+    import como_amd.odom.backend.photo as photo
+    G = load_golden("ba_window_f64.npz")
+    H0, g0, err0, _ = _ba_call(G)
+    B, n = G["coords_n"].shape[:2]
+    m = G["coords_m"].shape[1]
+    K = G["intrinsics"][0]
+    cn = G["coords_n"]
+    Hh, Ww = G["kf_img_and_grads"].shape[-2:]
+    ray = torch.stack(((cn[..., 1].double() - K[0, 2]) / K[0, 0], (cn[..., 0].double() - K[1, 2]) / K[1, 1],
+                       torch.ones(B, n, dtype=torch.float64)), -1)
+    zn = torch.exp(G["logzn"])
+    uvec = torch.einsum("bij,bnj->bni", G["kf_poses"][:, :3, :3], ray * zn)
+    invz = G["dlogzm_dzm"][:, :, 0, 0]
+    pixidx = (cn[..., 0] * Ww + cn[..., 1]).to(torch.int32)
+    D = G["H_photo"].shape[0]
+    H = torch.zeros((D, D), dtype=torch.float64, device=DEV)
+    g = torch.zeros(D, dtype=torch.float64, device=DEV)
+    e = torch.zeros((), dtype=torch.float64, device=DEV)
+    rid, tid = G["kf_ref_ids"].tolist(), G["kf_target_ids"].tolist()
+    table = photo.PairTable(rid, tid, [False] * len(rid), B, dev(G["kf_inds"]), dev(G["recent_inds"]), dev(G["landmark_inds"]),
+                            3 * Hh * Ww, 0, DEV)
+    photo.photo_system_factored(table, poses_all=dev(G["kf_poses"]), aff_all=dev(G["kf_aff_params"].reshape(B, 2)), Pwn=dev(G["Pwn"]),
+                                vals=dev(G["vals_n"].reshape(B, n)), dPwn_dTwc=dev(G["dPwn_dTwc"]), uvec=dev(uvec),
+                                Kt=dev(G["Knm_Kmminv"].reshape(B, Hh * Ww, m)), pixidx=dev(pixidx), invz=dev(invz),
+                                dzdP=dev(G["dzm_dPwm"][:, 0, 0, :]), img_base=dev(G["kf_img_and_grads"]), K=dev(K), H_img=Hh, W_img=Ww,
+                                H=H, g=g, err_out=e)
+    report("ba_factored", H_rel=rel_err(H, H0), g_rel=rel_err(g, g0), H_rel_ref=rel_err(H, G["H_photo"]), err=e, err0=err0)
+    assert rel_err(H, H0) < 1e-10 and rel_err(g, g0) < 1e-10
+    assert rel_err(H, G["H_photo"]) < 1e-9
+
+
+def test_mixed_precision_f32_pixels_f64_system():
+    """f32 per-pixel path accumulating into an f64 system (the bench configuration): within fp32 tolerance of the f64 golden."""
+    G32 = load_golden("ba_window_f32.npz")
+    G64 = load_golden("ba_window_f64.npz")
+    H, g, err, _ = _ba_call(G32, dt_h=torch.float64)
+    report("ba_mixed", H_rel=rel_err(H, G64["H_photo"]), g_rel=rel_err(g, G64["g_photo"]))
+    assert rel_err(H, G64["H_photo"]) < 3e-4 and rel_err(g, G64["g_photo"]) < 3e-4
+
+
+# ------------------------------------------------------------------------------------------------
+def test_como_backends_vs_golden():
+    import como_amd.como_backends as cb
+    C = load_golden("cov_ops_f32.npz")
+    K12 = cb.cross_covariance(dev(C["x1"]), dev(C["E1"]), dev(C["x2"]), dev(C["E2"]), float(C["scale"]))
+    xs, Es = dev(C["xs"]), dev(C["Es"])
+    Ks = cb.cross_covariance(xs[:, :5], Es[:, :5], xs[:, 3:], Es[:, 3:], 1.0)          # strided views
+    K64 = cb.cross_covariance(dev(C["x1"].double()), dev(C["E1"].double()), dev(C["x2"].double()), dev(C["E2"].double()), float(C["scale"]))
+    L, obs, var = dev(C["app_L0"].clone()), dev(C["app_obs0"].clone()), dev(C["app_var0"].clone())
+    ax, aE, dn, Ed = dev(C["app_x"]), dev(C["app_E"]), dev(C["app_dn"]), dev(C["app_Ed"])
+    for i in range(1, 6):
+        k_ni = cb.cross_covariance(ax[:, :i], aE[:, :i], ax[:, i:i + 1], aE[:, i:i + 1], 1.0)
+        k_id = cb.cross_covariance(ax[:, i:i + 1], aE[:, i:i + 1], dn, Ed, 1.0)
+        assert cb.get_new_chol_obs_info(L, obs, var, k_ni, k_id, 1.0, i) is None
+    report("como_backends", K12=rel_err(K12, C["K12"]), Ks=rel_err(Ks, C["K_slice"]), K64=rel_err(K64, C["K12"].double()),
+           L=rel_err(L, C["app_L"]), obs=rel_err(obs, C["app_obs"]), var=(var.cpu() - C["app_var"]).abs().max())
+    assert rel_err(K12, C["K12"]) < 2e-6 and rel_err(Ks, C["K_slice"]) < 2e-6 and rel_err(K64, C["K12"].double()) < 2e-6
+    assert rel_err(L, C["app_L"]) < 1e-5 and rel_err(obs, C["app_obs"]) < 1e-4 and (var.cpu() - C["app_var"]).abs().max() < 1e-5
+    with pytest.raises(RuntimeError):
+        cb.get_new_chol_obs_info(L.transpose(1, 2), obs, var, k_ni, k_id, 1.0, 1)      # "must be contiguous"
+    with pytest.raises(RuntimeError):
+        cb.cross_covariance(C["x1"], dev(C["E1"]), dev(C["x2"]), dev(C["E2"]), 1.0)    # mixed devices
