@@ -68,8 +68,11 @@ def run(dtype, window, iters=10):
 
 if __name__ == "__main__":
     out = {}
+    sel = sys.argv[1:]
     for dtype, nm in ((torch.float32, "f32"), (torch.float64, "f64")):
         for window in (1, 4):
+            if sel and f"{nm}_w{window}" not in sel:
+                continue
             out[f"{nm}_w{window}"] = run(dtype, window)
             print(nm, window, out[f"{nm}_w{window}"], flush=True)
     json.dump(out, open("gpurun_out/quick_bench.json", "w"), indent=1)
