@@ -36,11 +36,11 @@ class BAArgs(ctypes.Structure):
 SIGNATURES = {
     "como_abi_version": (c_int, []),
     "como_select_workspace_bytes": (c_int, []),
-    "como_select_begin": (c_int, [c_void_p, c_void_p]),
-    "como_select_hist_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_int, c_void_p]),
-    "como_select_hist_f64": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_int, c_void_p]),
-    "como_select_finish_f32": (c_int, [c_void_p, c_void_p, c_void_p]),
-    "como_select_finish_f64": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "como_select_begin": (c_int, [c_void_p, c_int, c_void_p]),
+    "como_select_hist_f32": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
+    "como_select_hist_f64": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
+    "como_select_finish_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "como_select_finish_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "como_track_partials_bytes": (c_long, []),
     "como_track_iter_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 9),
     "como_track_iter_f64": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 9),
@@ -52,6 +52,14 @@ SIGNATURES = {
     "como_cross_covariance_f64": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int, c_int, c_int,
                                                         ctypes.POINTER(c_long), c_void_p]),
     "como_chol_append_obs_info_f32": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int, c_int, c_void_p]),
+    "como_dense_ref_f32": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8),
+    "como_dense_ref_f64": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8),
+    "como_kernel_matrix_f32": (c_int, [c_void_p] * 4 + [c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "como_kernel_matrix_f64": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "como_ktilde_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
+                                c_void_p, c_void_p]),
+    "como_ktilde_f64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int, c_int, c_int,
+                                c_void_p, c_void_p]),
 }
 
 

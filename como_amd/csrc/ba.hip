@@ -23,7 +23,7 @@
 
 namespace como {
 
-template <typename T> int select_hist(const T*, const uint8_t*, long, uint32_t*, int, hipStream_t);
+template <typename T> int select_hist(const T*, const uint8_t*, long, int, uint32_t*, int, hipStream_t);
 
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct Acc4 { typedef T type __attribute__((ext_vector_type(4))); };
@@ -77,7 +77,7 @@ __device__ __forceinline__ Warp<T> warp_point(const T* __restrict__ M, T fx, T f
 }
 
 // ---------------------------------------- pass 1 -------------------------------------------------
-template <typename T>
+template <typename T, bool SOA>
 __global__ __launch_bounds__(256) void ba_residual_kernel(
     const T* __restrict__ Pwn, const T* __restrict__ vals, BAPairs pr, const T* __restrict__ pair_T,
     const T* __restrict__ pair_aff, const T* __restrict__ img_base, const T* __restrict__ Kmat, int H, int W, int n,
@@ -97,17 +97,27 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(
   const T* img = img_base + pr.tgt_img[p];
   const long HW = (long)H * W;
   __syncthreads();
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+  const int stride = gridDim.x * 256;
+  const int iters = (n + stride - 1) / stride;          // uniform trip count (whole waves for the aggregated histogram)
+  for (int it = 0; it < iters; ++it) {
+    const int i0 = it * stride + blockIdx.x * 256 + threadIdx.x;
+    const bool inr = i0 < n;
+    const int i = inr ? i0 : n - 1;
     const long ri = (long)slot * n + i;
-    Warp<T> w = warp_point(Mr, fx, fy, cx, cy, Pwn[3 * ri], Pwn[3 * ri + 1], Pwn[3 * ri + 2], H, W);
+    T Px, Py, Pz;
+    if constexpr (SOA) { Px = Pwn[((long)slot * 3 + 0) * n + i]; Py = Pwn[((long)slot * 3 + 1) * n + i]; Pz = Pwn[((long)slot * 3 + 2) * n + i]; }
+    else { Px = Pwn[3 * ri]; Py = Pwn[3 * ri + 1]; Pz = Pwn[3 * ri + 2]; }
+    Warp<T> w = warp_point(Mr, fx, fy, cx, cy, Px, Py, Pz, H, W);
     Taps<T> t = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
     const T It = tap_sum(img, t);
     const T r = It - scale * vals[ri] + bias;           // photo.py:114-118
-    const long oi = (long)p * n + i;
-    r_out[oi] = r;
-    valid_out[oi] = w.ok ? 1 : 0;
-    if (pj_out) { pj_out[2 * oi] = w.u; pj_out[2 * oi + 1] = w.v; }
-    if (w.ok) atomicAdd(&lh[sel_digit<KeyT>(abs_key(r), 0)], 1u);
+    if (inr) {
+      const long oi = (long)p * n + i;
+      r_out[oi] = r;
+      valid_out[oi] = w.ok ? 1 : 0;
+      if (pj_out) { pj_out[2 * oi] = w.u; pj_out[2 * oi + 1] = w.v; }
+    }
+    sel_lds_add_aggregated(lh, sel_digit<KeyT>(abs_key(r), 0), inr && w.ok);
   }
   __syncthreads();
   sel_flush(lh, hists);
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int q = lane >> 4, c = lane & 15;
   T* Jp = lds + wv * STG;                   // [16][JP_STRIDE]
-  T* Sv = Jp + 16 * JP_STRIDE;         // [5][64]: 0 = r~, 1..3 = s*dI/dPw (ZMODE 0) or 1 = s*(dI/dPw . u), 4 = pixel row (as int bits)
+  T* Sv = Jp + 16 * JP_STRIDE;         // [5][64]: 0 = r~, 1..3 = s*dI/dPw (ZMODE 0) or 1 = s*(dI/dPw . u) (ZMODE 1)
 
   T Mr[12];
 #pragma unroll
@@ -202,13 +212,35 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
 
   const int begin = blockIdx.x * chunk_len;
   const int end = min(n, begin + chunk_len);
+  // K~ quads of the tile are fetched BEFORE phase A (they depend only on the pixel index), PF steps deep: the
+  // matrix-core phase then runs from registers/LDS only.  f32: whole tile (16 steps, 64 VGPRs); f64: ring of 8.
+  constexpr int PF = (sizeof(T) == 4) ? 16 : 8;
+  V4<T> kq[PF];
   for (int tile = begin + wv * 64; tile < end; tile += 256) {
+    int myrow = 0;
+    if constexpr (ZMODE == 1) {
+      const int i = min(tile + lane, end - 1);
+      myrow = pixidx ? pixidx[(long)slot * n + i] : i;
+#pragma unroll
+      for (int st = 0; st < PF; ++st) {
+        const int row = __shfl(myrow, 4 * st + q, 64);
+        kq[st] = V4<T>{T(0), T(0), T(0), T(0)};
+        if (4 * c < m) kq[st] = load4(zjac + (long)slot * kt_slot_stride + (long)row * m + 4 * c);
+      }
+    }
     // ------------------------- phase A: lane = pixel ------------------------------------------
     {
       const int i = tile + lane;
       const bool inr = i < end;
-      const long ri = (long)slot * n + (inr ? i : (end - 1));
-      Warp<T> w = warp_point(Mr, fx, fy, cx, cy, Pwn[3 * ri], Pwn[3 * ri + 1], Pwn[3 * ri + 2], H, W);
+      const int ic = inr ? i : (end - 1);
+      const long ri = (long)slot * n + ic;
+      T Px, Py, Pz;
+      if constexpr (ZMODE == 1) {       // fast path: structure-of-arrays planes (slot, component, n)
+        Px = Pwn[((long)slot * 3 + 0) * n + ic]; Py = Pwn[((long)slot * 3 + 1) * n + ic]; Pz = Pwn[((long)slot * 3 + 2) * n + ic];
+      } else {
+        Px = Pwn[3 * ri]; Py = Pwn[3 * ri + 1]; Pz = Pwn[3 * ri + 2];
+      }
+      Warp<T> w = warp_point(Mr, fx, fy, cx, cy, Px, Py, Pz, H, W);
       Taps<T> tp = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
       const T It = tap_sum(img, tp), gx = tap_sum(img + HW, tp), gy = tap_sum(img + 2 * HW, tp);
       const T Iref_s = scale * vals[ri];
@@ -228,9 +260,16 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
       const T b1 = a0 * Mr[1] + a1 * Mr[5] + a2 * Mr[9];
       const T b2 = a0 * Mr[2] + a1 * Mr[6] + a2 * Mr[10];
       // reference-pose block: dI/dP_w dP_w/dT_wci (photo.py:145)
-      const T* D = dPwn_dTwc + 18 * ri;
+      if constexpr (ZMODE == 1) {
+        const T* D = dPwn_dTwc + (long)slot * 18 * n + ic;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Jp[k * JP_STRIDE + lane] = s * (b0 * D[k] + b1 * D[6 + k] + b2 * D[12 + k]);
+        for (int k = 0; k < 6; ++k)
+          Jp[k * JP_STRIDE + lane] = s * (b0 * D[(long)k * n] + b1 * D[(long)(6 + k) * n] + b2 * D[(long)(12 + k) * n]);
+      } else {
+        const T* D = dPwn_dTwc + 18 * ri;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Jp[k * JP_STRIDE + lane] = s * (b0 * D[k] + b1 * D[6 + k] + b2 * D[12 + k]);
+      }
       Jp[6 * JP_STRIDE + lane] = s * Iref_s;               // photo.py:121
       Jp[7 * JP_STRIDE + lane] = -s;
       // target-pose block: dP_c/dT_wcj = [[P_c]x, -I]  (= dPc/dTcw (-Ad(T_wc)), photo.py:107,146)
@@ -247,15 +286,14 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
       if constexpr (ZMODE == 0) {
         Sv[1 * 64 + lane] = s * b0; Sv[2 * 64 + lane] = s * b1; Sv[3 * 64 + lane] = s * b2;
       } else {
-        const T* U = uvec + 3 * ri;
-        Sv[1 * 64 + lane] = s * (b0 * U[0] + b1 * U[1] + b2 * U[2]);
-        reinterpret_cast<int*>(Sv + 4 * 64)[lane] = pixidx ? pixidx[ri] : (inr ? i : (end - 1));
+        const T* U = uvec + (long)slot * 3 * n + ic;
+        Sv[1 * 64 + lane] = s * (b0 * U[0] + b1 * U[n] + b2 * U[2 * (long)n]);
       }
     }
     __builtin_amdgcn_wave_barrier();
     // ------------------------- phase B: 4 pixels per MFMA step --------------------------------
     const long zbase0 = (long)slot * n;
-#pragma unroll 2
+#pragma unroll
     for (int st = 0; st < 16; ++st) {
       const int px = 4 * st + q;                           // this lane's pixel inside the tile
       T a[Cfg::NB];
@@ -273,11 +311,15 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
         const T j3 = d0 * z0.w + d1 * z1.w + d2 * z2.w;
         a[1] = j0; a[2] = j1; a[3] = j2; a[4] = j3;
       } else {
-        const int row = reinterpret_cast<const int*>(Sv + 4 * 64)[px];
-        const T* Kr = zjac + (long)slot * kt_slot_stride + (long)row * m;
         const T sz = Sv[64 + px];
-        V4<T> k4{T(0), T(0), T(0), T(0)};
-        if (4 * c < m) k4 = load4(Kr + 4 * c);
+        const V4<T> k4 = kq[st % PF];
+        if constexpr (PF < 16) {          // ring refill: the quad of step st + PF lands while PF steps of MFMAs run
+          if (st + PF < 16) {
+            const int row = __shfl(myrow, 4 * (st + PF) + q, 64);
+            kq[st % PF] = V4<T>{T(0), T(0), T(0), T(0)};
+            if (4 * c < m) kq[st % PF] = load4(zjac + (long)slot * kt_slot_stride + (long)row * m + 4 * c);
+          }
+        }
         a[1] = sz * k4.x * invz4[0]; a[2] = sz * k4.y * invz4[1]; a[3] = sz * k4.z * invz4[2]; a[4] = sz * k4.w * invz4[3];
       }
 #pragma unroll
@@ -426,15 +468,20 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
     COMO_CHECK_LAUNCH();
     int gx = (n + 255) / 256;
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(ba_residual_kernel<T>, dim3(gx, b), dim3(256), 0, s, (const T*)A->Pwn, (const T*)A->vals, pr,
-                       pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, (T*)A->ws_r,
-                       (uint8_t*)A->ws_valid, (T*)A->pj_out, hists);
+    if (A->zmode == 1)
+      hipLaunchKernelGGL((ba_residual_kernel<T, true>), dim3(gx, b), dim3(256), 0, s, (const T*)A->Pwn, (const T*)A->vals, pr,
+                         pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, (T*)A->ws_r,
+                         (uint8_t*)A->ws_valid, (T*)A->pj_out, hists);
+    else
+      hipLaunchKernelGGL((ba_residual_kernel<T, false>), dim3(gx, b), dim3(256), 0, s, (const T*)A->Pwn, (const T*)A->vals, pr,
+                         pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, (T*)A->ws_r,
+                         (uint8_t*)A->ws_valid, (T*)A->pj_out, hists);
     COMO_CHECK_LAUNCH();
   }
   // digit passes 1..P-1 (multi-GPU: the caller all-reduces hists between phases 1, 2a.. and 4)
   for (int ps = 1; ps < SelCfg<KeyT>::NPASS; ++ps) {
     if (A->phase & (2 << (ps - 1))) {
-      int rc = select_hist<T>((const T*)A->ws_r, (const uint8_t*)A->ws_valid, (long)b * n, hists, ps, s);
+      int rc = select_hist<T>((const T*)A->ws_r, (const uint8_t*)A->ws_valid, (long)b * n, 1, hists, ps, s);
       if (rc) return rc;
     }
   }

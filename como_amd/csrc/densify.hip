@@ -1,0 +1,283 @@
+// Dense reference points and the GP predictor K~ = K_nm K_mm^-1.
+//
+// dense_ref  (per GN iteration)  reference: como/odom/backend/sparse_map.py:184-230
+//   (backproject_cloud + setup_test_points) and Mapping.prep_dense_ref (Mapping.py:661-699).
+//   Per selected pixel n of keyframe b: logz_n = K~[n,:] logz_m, z_n = e^{logz_n}, P_c = z_n ray,
+//   P_w = T_wc P_c, and the FACTORS of the Jacobians instead of the (B,n,3,m) tensor the reference builds:
+//     dPwn_dzm[n,:,k] = uvec[n,:] * K~[n,k] / z_mk          with uvec = R_wc ray z_n
+//     dPwn_dTwc       = [-R [P_c]x , R] + uvec (x) (K~[n,:] dlogz_m/dT_wc)
+//   plus the pass-0 histogram of z_n for the exact per-keyframe median depth (sparse_map.py:220).
+//   HBM-bound: one m-wide K~ row (4m B) read per pixel, 25 scalars written (structure-of-arrays planes).
+//
+// ktilde     (once per keyframe)  reference: como/odom/Mapping.py:430-468 (prep_predictor), kernel formulas of
+//   como/depth_cov/core/kernels.py:22-88 (the Python twin: C = 2 d1^.25 d2^.25 / sqrt(det + 1e-8), coordinate
+//   differences cast to float32) and the bilinear border lookup of gaussian_kernel.py:52-79.
+#include "select.cuh"
+#include "../../include/como_hip.h"
+
+namespace como {
+
+template <typename T> int select_hist(const T*, const uint8_t*, long, int, uint32_t*, int, hipStream_t);
+
+template <typename T> struct Q4 { T x, y, z, w; };
+template <typename T>
+__device__ __forceinline__ Q4<T> ld4(const T* __restrict__ p) {
+  Q4<T> v;
+  if constexpr (sizeof(T) == 4) {
+    const float4 f = *reinterpret_cast<const float4*>(p);
+    v.x = f.x; v.y = f.y; v.z = f.z; v.w = f.w;
+  } else {
+    const double2 a = *reinterpret_cast<const double2*>(p);
+    const double2 b = *reinterpret_cast<const double2*>(p + 2);
+    v.x = a.x; v.y = a.y; v.z = b.x; v.w = b.y;
+  }
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dense_ref_kernel(
+    const T* __restrict__ Kt, long kt_slot_stride, const int* __restrict__ pixidx, const T* __restrict__ logzm,
+    const T* __restrict__ Twc, const T* __restrict__ Kmat, const T* __restrict__ dlogzm_dTwc, int n, int m, int Wimg,
+    T* __restrict__ Pwn, T* __restrict__ dPwn_dTwc, T* __restrict__ uvec, T* __restrict__ zbuf, T* __restrict__ logzn_out,
+    uint32_t* __restrict__ hists) {
+  using KeyT = typename KeyOf<T>::type;
+  __shared__ uint32_t lh[SEL_BINS];
+  __shared__ T coef[64][8];          // per inducing point: {logz_m, dlogz_m/dT (6), 0}
+  const int b = blockIdx.y;
+  for (int k = threadIdx.x; k < SEL_BINS; k += 256) lh[k] = 0;
+  for (int k = threadIdx.x; k < 64 * 8; k += 256) {
+    const int j = k >> 3, e = k & 7;
+    T v = T(0);
+    if (j < m) {
+      if (e == 0) v = logzm[(long)b * m + j];
+      else if (e < 7) v = dlogzm_dTwc[((long)b * m + j) * 6 + (e - 1)];
+    }
+    coef[j][e] = v;
+  }
+  T Tm[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Tm[k] = Twc[16 * (long)b + k];
+  const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  __syncthreads();
+  const int stride = gridDim.x * 256;
+  const int iters = (n + stride - 1) / stride;
+  for (int it = 0; it < iters; ++it) {
+    const int i0 = it * stride + blockIdx.x * 256 + threadIdx.x;
+    const bool inr = i0 < n;
+    const int i = inr ? i0 : n - 1;
+    const int row = pixidx ? pixidx[(long)b * n + i] : i;
+    const T* Kr = Kt + (long)b * kt_slot_stride + (long)row * m;
+    T acc[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+    for (int j = 0; j < m; j += 4) {
+      const Q4<T> kv = ld4(Kr + j);
+      const T kk[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int a = 0; a < 7; ++a) acc[a] += kk[e] * coef[j + e][a];
+      }
+    }
+    const T logz = acc[0];
+    const T z = exp(logz);                                       // depth.py:6-9
+    T rx, ry;
+    {
+#pragma clang fp contract(off)
+      rx = (T(row % Wimg) - cx) / fx;                            // camera.py:43-47 with p = (col, row)
+      ry = (T(row / Wimg) - cy) / fy;
+    }
+    const T Xc = z * rx, Yc = z * ry, Zc = z;                    // P = z * ray
+    T Xw, Yw, Zw;
+    rigid_apply(Tm, Xc, Yc, Zc, Xw, Yw, Zw);                     // transforms.py:17-23 (exact order: feeds masks)
+    const T u0 = Tm[0] * Xc + Tm[1] * Yc + Tm[2] * Zc;           // uvec = R (ray z)
+    const T u1 = Tm[4] * Xc + Tm[5] * Yc + Tm[6] * Zc;
+    const T u2 = Tm[8] * Xc + Tm[9] * Yc + Tm[10] * Zc;
+    if (inr) {
+      const long base3 = (long)b * 3 * n + i, base18 = (long)b * 18 * n + i;
+      Pwn[base3] = Xw; Pwn[base3 + n] = Yw; Pwn[base3 + 2 * (long)n] = Zw;
+      uvec[base3] = u0; uvec[base3 + n] = u1; uvec[base3 + 2 * (long)n] = u2;
+      const T uu[3] = {u0, u1, u2};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const T r0 = Tm[r * 4 + 0], r1 = Tm[r * 4 + 1], r2 = Tm[r * 4 + 2];
+        // -(R [P_c]x) row r, then R row r; plus uvec_r * dlogz_n/dT
+        const T s0 = -(r1 * Zc - r2 * Yc), s1 = -(r2 * Xc - r0 * Zc), s2 = -(r0 * Yc - r1 * Xc);
+        dPwn_dTwc[base18 + (long)(r * 6 + 0) * n] = s0 + uu[r] * acc[1];
+        dPwn_dTwc[base18 + (long)(r * 6 + 1) * n] = s1 + uu[r] * acc[2];
+        dPwn_dTwc[base18 + (long)(r * 6 + 2) * n] = s2 + uu[r] * acc[3];
+        dPwn_dTwc[base18 + (long)(r * 6 + 3) * n] = r0 + uu[r] * acc[4];
+        dPwn_dTwc[base18 + (long)(r * 6 + 4) * n] = r1 + uu[r] * acc[5];
+        dPwn_dTwc[base18 + (long)(r * 6 + 5) * n] = r2 + uu[r] * acc[6];
+      }
+      zbuf[(long)b * n + i] = Zc;
+      if (logzn_out) logzn_out[(long)b * n + i] = logz;
+    }
+    sel_lds_add_aggregated(lh, sel_digit<KeyT>(abs_key(Zc), 0), inr);
+  }
+  __syncthreads();
+  sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
+}
+
+// ---- K~ --------------------------------------------------------------------------------------------------------
+// bilinear lookup with border padding at normalised (row, col) coordinates (grid_sample align_corners=False)
+template <typename T>
+__device__ __forceinline__ void cov_lookup(const T* __restrict__ cov, int H, int W, T rn, T cn, T* E) {
+  T y = ((rn + T(1)) * T(H) - T(1)) / T(2);
+  T x = ((cn + T(1)) * T(W) - T(1)) / T(2);
+  x = fmin(fmax(x, T(0)), T(W - 1));
+  y = fmin(fmax(y, T(0)), T(H - 1));
+  const T xf = floor(x), yf = floor(y);
+  const T wx = x - xf, wy = y - yf;
+  const int x0 = (int)xf, y0 = (int)yf;
+  const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+  const long HW = (long)H * W;
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch) {
+    const T* pl = cov + ch * HW;
+    E[ch] = pl[(long)y0 * W + x0] * ((T(1) - wy) * (T(1) - wx)) + pl[(long)y0 * W + x1] * ((T(1) - wy) * wx) +
+            pl[(long)y1 * W + x0] * (wy * (T(1) - wx)) + pl[(long)y1 * W + x1] * (wy * wx);
+  }
+}
+
+// Python-twin kernel value (kernels.py:22-88): note diff is cast to float32 there.
+template <typename T>
+__device__ __forceinline__ T kernel_py(T r1, T c1, const T* E1, T r2, T c2, const T* E2) {
+  const T d0 = (T)(float)(r1 - r2), d1 = (T)(float)(c1 - c2);
+  const T e00 = E1[0] + E2[0], e01 = E1[1] + E2[1], e11 = E1[3] + E2[3];
+  T q = e11 * (d0 * d0);
+  q += T(-2) * e01 * d0 * d1;
+  q += e00 * (d1 * d1);
+  const T det = e00 * e11 - e01 * e01;
+  q = (q / det) * T(0.5);
+  const T da = sqrt(sqrt(E1[0] * E1[3] - E1[1] * E1[2]));
+  const T db = sqrt(sqrt(E2[0] * E2[3] - E2[1] * E2[2]));
+  const T C = T(2) * da * db / sqrt(det + T(1e-8));
+  const T tmp = T(1.7320508075688772) * sqrt(q + T(1e-8));
+  return ((T(1) + tmp) * exp(-tmp)) * C;
+}
+
+// out[b, i, j] = scale * k(x1_i, x2_j)   (CovarianceModule / CrossCovarianceModule forward, covariance.py:10-39)
+template <typename T>
+__global__ __launch_bounds__(256) void kernel_matrix_py_kernel(const T* __restrict__ x1, const T* __restrict__ E1,
+                                                               const T* __restrict__ x2, const T* __restrict__ E2, T scale,
+                                                               T* __restrict__ out, int N, int M) {
+  const int b = blockIdx.y;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  if (p >= (long)N * M) return;
+  const int i = (int)(p / M), j = (int)(p % M);
+  const T* a = x1 + ((long)b * N + i) * 2;
+  const T* c = x2 + ((long)b * M + j) * 2;
+  out[((long)b * N + i) * M + j] =
+      kernel_py(a[0], a[1], E1 + ((long)b * N + i) * 4, c[0], c[1], E2 + ((long)b * M + j) * 4) * scale;
+}
+
+// K~ rows for every photo pixel: thread = pixel; k_nm (m values) in registers, then the m x m product with
+// K_mm^-1 staged in LDS.  m <= 64.
+template <typename T>
+__global__ __launch_bounds__(256) void ktilde_kernel(const T* __restrict__ cov, int Hc, int Wc, const T* __restrict__ xm,
+                                                     const T* __restrict__ Em, const T* __restrict__ Kinv, T scale,
+                                                     int Hp, int Wp, int m, T* __restrict__ out) {
+  __shared__ T sK[64 * 64];
+  __shared__ T sx[64 * 2];
+  __shared__ T sE[64 * 4];
+  const int b = blockIdx.y;
+  for (int k = threadIdx.x; k < m * m; k += 256) sK[k] = Kinv[(long)b * m * m + k];
+  for (int k = threadIdx.x; k < m * 2; k += 256) sx[k] = xm[(long)b * m * 2 + k];
+  for (int k = threadIdx.x; k < m * 4; k += 256) sE[k] = Em[(long)b * m * 4 + k];
+  __syncthreads();
+  const long np = (long)Hp * Wp;
+  const T ar = T(1) / T(Hc), ac = T(1) / T(Wc);
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < np; p += (long)gridDim.x * 256) {
+    const int row = (int)(p / Wp), col = (int)(p % Wp);
+    T rn, cn;
+    {
+#pragma clang fp contract(off)
+      rn = (T(2) * ar) * T(row) + ar - T(1);           // normalize_coordinates, coords.py:12-15
+      cn = (T(2) * ac) * T(col) + ac - T(1);
+    }
+    T En[4];
+    cov_lookup(cov + (long)b * 4 * Hc * Wc, Hc, Wc, rn, cn, En);
+    T kn[64];
+#pragma unroll 4
+    for (int j = 0; j < 64; ++j) kn[j] = (j < m) ? kernel_py(rn, cn, En, sx[2 * j], sx[2 * j + 1], sE + 4 * j) * scale : T(0);
+    T* o = out + ((long)b * np + p) * m;
+    for (int j = 0; j < m; ++j) {
+      T s = T(0);
+#pragma unroll
+      for (int k = 0; k < 64; ++k) s += kn[k] * ((k < m) ? sK[k * m + j] : T(0));
+      o[j] = s;
+    }
+  }
+}
+
+template <typename T>
+int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logzm, const T* Twc, const T* Kmat,
+              const T* dlogzm_dTwc, int B, int n, int m, int Wimg, T* Pwn, T* dPwn_dTwc, T* uvec, T* zbuf, T* logzn_out,
+              void* hists_v, T* med_out3, hipStream_t s) {
+  using KeyT = typename KeyOf<T>::type;
+  if (!Kt || !logzm || !Twc || !Kmat || !dlogzm_dTwc || !Pwn || !dPwn_dTwc || !uvec || !zbuf || !hists_v || !med_out3 ||
+      B <= 0 || n <= 0 || m <= 0 || m > 64 || (m & 3) || Wimg <= 0)
+    return COMO_ERR_ARG;
+  uint32_t* hists = (uint32_t*)hists_v;
+  if (hipMemsetAsync(hists, 0, (size_t)B * 6 * SEL_BINS * sizeof(uint32_t), s) != hipSuccess) return COMO_ERR_LAUNCH;
+  int gx = (n + 255) / 256;
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(dense_ref_kernel<T>, dim3(gx, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
+                     dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists);
+  COMO_CHECK_LAUNCH();
+  for (int p = 1; p < SelCfg<KeyT>::NPASS; ++p) {
+    int rc = select_hist<T>(zbuf, nullptr, n, B, hists, p, s);
+    if (rc) return rc;
+  }
+  return COMO_OK;
+}
+
+}  // namespace como
+
+extern "C" {
+
+int como_select_finish_f32(const void*, int, float*, como_stream_t);
+int como_select_finish_f64(const void*, int, double*, como_stream_t);
+
+int como_dense_ref_f32(const float* Kt, long kt_slot_stride, const int* pixidx, const float* logzm, const float* Twc,
+                       const float* K, const float* dlogzm_dTwc, int B, int n, int m, int Wimg, float* Pwn,
+                       float* dPwn_dTwc, float* uvec, float* zbuf, float* logzn_out, void* hists, float* med_out3,
+                       como_stream_t stream) {
+  int rc = como::dense_ref<float>(Kt, kt_slot_stride, pixidx, logzm, Twc, K, dlogzm_dTwc, B, n, m, Wimg, Pwn, dPwn_dTwc, uvec,
+                                  zbuf, logzn_out, hists, med_out3, (hipStream_t)stream);
+  if (rc) return rc;
+  return como_select_finish_f32(hists, B, med_out3, stream);
+}
+int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx, const double* logzm, const double* Twc,
+                       const double* K, const double* dlogzm_dTwc, int B, int n, int m, int Wimg, double* Pwn,
+                       double* dPwn_dTwc, double* uvec, double* zbuf, double* logzn_out, void* hists, double* med_out3,
+                       como_stream_t stream) {
+  int rc = como::dense_ref<double>(Kt, kt_slot_stride, pixidx, logzm, Twc, K, dlogzm_dTwc, B, n, m, Wimg, Pwn, dPwn_dTwc, uvec,
+                                   zbuf, logzn_out, hists, med_out3, (hipStream_t)stream);
+  if (rc) return rc;
+  return como_select_finish_f64(hists, B, med_out3, stream);
+}
+
+#define COMO_DEF_KMAT(SFX, T)                                                                                          \
+  int como_kernel_matrix_##SFX(const T* x1, const T* E1, const T* x2, const T* E2, T scale, T* out, int B, int N, int M, \
+                               como_stream_t stream) {                                                                 \
+    if (!x1 || !E1 || !x2 || !E2 || !out || B < 0 || N < 0 || M < 0) return COMO_ERR_ARG;                              \
+    if (!B || !N || !M) return COMO_OK;                                                                                \
+    hipLaunchKernelGGL(como::kernel_matrix_py_kernel<T>, dim3((unsigned)(((long)N * M + 255) / 256), B), dim3(256), 0,  \
+                       (hipStream_t)stream, x1, E1, x2, E2, scale, out, N, M);                                         \
+    COMO_CHECK_LAUNCH();                                                                                               \
+    return COMO_OK;                                                                                                    \
+  }                                                                                                                    \
+  int como_ktilde_##SFX(const T* cov, int Hc, int Wc, const T* xm, const T* Em, const T* Kinv, T scale, int B, int Hp,   \
+                        int Wp, int m, T* out, como_stream_t stream) {                                                 \
+    if (!cov || !xm || !Em || !Kinv || !out || B <= 0 || m <= 0 || m > 64 || Hp <= 0 || Wp <= 0) return COMO_ERR_ARG;  \
+    long blocks = ((long)Hp * Wp + 255) / 256;                                                                         \
+    if (blocks > 1024) blocks = 1024;                                                                                  \
+    hipLaunchKernelGGL(como::ktilde_kernel<T>, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, cov, Hc,   \
+                       Wc, xm, Em, Kinv, scale, Hp, Wp, m, out);                                                       \
+    COMO_CHECK_LAUNCH();                                                                                               \
+    return COMO_OK;                                                                                                    \
+  }
+COMO_DEF_KMAT(f32, float)
+COMO_DEF_KMAT(f64, double)
+
+}  // extern "C"

@@ -10,12 +10,16 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const T* __restrict__ 
   using KeyT = typename KeyOf<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
   __shared__ SelScratch sc;
+  // blockIdx.y = segment: independent selects over consecutive length-n slices (e.g. one median per keyframe)
+  r += (long)blockIdx.y * n;
+  if (valid) valid += (long)blockIdx.y * n;
+  hists += (long)blockIdx.y * 6 * SEL_BINS;
   for (int b = threadIdx.x; b < SEL_BINS; b += 256) lh[b] = 0;
   KeyT prefix; uint32_t k_rem, nv;
   sel_resolve<KeyT>(hists, pass, &sc, prefix, k_rem, nv);   // contains __syncthreads (also orders the lh init)
   __syncthreads();
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    if (valid[i]) {
+    if (!valid || valid[i]) {
       KeyT key = abs_key(r[i]);
       if (sel_match<KeyT>(key, prefix, pass)) atomicAdd(&lh[sel_digit<KeyT>(key, pass)], 1u);
     }
@@ -29,6 +33,8 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const uint32_t* __re
   using KeyT = typename KeyOf<T>::type;
   __shared__ SelScratch sc;
   KeyT prefix; uint32_t k_rem, nv;
+  hists += (long)blockIdx.x * 6 * SEL_BINS;
+  out3 += 3 * (long)blockIdx.x;
   sel_resolve<KeyT>(hists, SelCfg<KeyT>::NPASS, &sc, prefix, k_rem, nv);
   if (threadIdx.x == 0) {
     T med = nv ? key_value(prefix) : T(NAN);
@@ -39,13 +45,14 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const uint32_t* __re
 }
 
 template <typename T>
-int select_hist(const T* r, const uint8_t* valid, long n, uint32_t* hists, int pass, hipStream_t s) {
+int select_hist(const T* r, const uint8_t* valid, long n, int nseg, uint32_t* hists, int pass, hipStream_t s) {
   using KeyT = typename KeyOf<T>::type;
-  if (!r || !valid || !hists || n < 0 || pass < 0 || pass >= SelCfg<KeyT>::NPASS) return COMO_ERR_ARG;
+  if (!r || !hists || n < 0 || nseg < 1 || pass < 0 || pass >= SelCfg<KeyT>::NPASS) return COMO_ERR_ARG;
   long blocks = (n + 255) / 256;
   if (blocks < 1) blocks = 1;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(select_hist_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, r, valid, n, hists, pass);
+  const long cap = (nseg >= 4) ? 256 : 512;          // few, fat workgroups: the flush is <= blocks*2048 global atomics
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(select_hist_kernel<T>, dim3((unsigned)blocks, nseg), dim3(256), 0, s, r, valid, n, hists, pass);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }
@@ -56,31 +63,31 @@ extern "C" {
 
 int como_abi_version(void) { return 1; }
 
-int como_select_workspace_bytes(void) { return 6 * como::SEL_BINS * (int)sizeof(uint32_t); }
+int como_select_workspace_bytes(void) { return 6 * como::SEL_BINS * (int)sizeof(uint32_t); }   /* per segment */
 
-int como_select_begin(void* hists, como_stream_t stream_) {
-  if (!hists) return COMO_ERR_ARG;
-  if (hipMemsetAsync(hists, 0, como_select_workspace_bytes(), (hipStream_t)stream_) != hipSuccess) return COMO_ERR_LAUNCH;
+int como_select_begin(void* hists, int nseg, como_stream_t stream_) {
+  if (!hists || nseg < 1) return COMO_ERR_ARG;
+  if (hipMemsetAsync(hists, 0, (size_t)nseg * como_select_workspace_bytes(), (hipStream_t)stream_) != hipSuccess) return COMO_ERR_LAUNCH;
   return COMO_OK;
 }
 
-int como_select_hist_f32(const float* r, const uint8_t* valid, long n, void* hists, int pass, como_stream_t stream) {
-  return como::select_hist<float>(r, valid, n, (uint32_t*)hists, pass, (hipStream_t)stream);
+int como_select_hist_f32(const float* r, const uint8_t* valid, long n, int nseg, void* hists, int pass, como_stream_t stream) {
+  return como::select_hist<float>(r, valid, n, nseg, (uint32_t*)hists, pass, (hipStream_t)stream);
 }
-int como_select_hist_f64(const double* r, const uint8_t* valid, long n, void* hists, int pass, como_stream_t stream) {
-  return como::select_hist<double>(r, valid, n, (uint32_t*)hists, pass, (hipStream_t)stream);
+int como_select_hist_f64(const double* r, const uint8_t* valid, long n, int nseg, void* hists, int pass, como_stream_t stream) {
+  return como::select_hist<double>(r, valid, n, nseg, (uint32_t*)hists, pass, (hipStream_t)stream);
 }
-int como_select_finish_f32(const void* hists, float* out3, como_stream_t stream_) {
+int como_select_finish_f32(const void* hists, int nseg, float* out3, como_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!hists || !out3) return COMO_ERR_ARG;
-  hipLaunchKernelGGL(como::select_finish_kernel<float>, dim3(1), dim3(256), 0, stream, (const uint32_t*)hists, out3);
+  if (!hists || !out3 || nseg < 1) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::select_finish_kernel<float>, dim3(nseg), dim3(256), 0, stream, (const uint32_t*)hists, out3);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }
-int como_select_finish_f64(const void* hists, double* out3, como_stream_t stream_) {
+int como_select_finish_f64(const void* hists, int nseg, double* out3, como_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (!hists || !out3) return COMO_ERR_ARG;
-  hipLaunchKernelGGL(como::select_finish_kernel<double>, dim3(1), dim3(256), 0, stream, (const uint32_t*)hists, out3);
+  if (!hists || !out3 || nseg < 1) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::select_finish_kernel<double>, dim3(nseg), dim3(256), 0, stream, (const uint32_t*)hists, out3);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }
@@ -88,6 +95,6 @@ int como_select_finish_f64(const void* hists, double* out3, como_stream_t stream
 }  // extern "C"
 
 namespace como {
-template int select_hist<float>(const float*, const uint8_t*, long, uint32_t*, int, hipStream_t);
-template int select_hist<double>(const double*, const uint8_t*, long, uint32_t*, int, hipStream_t);
+template int select_hist<float>(const float*, const uint8_t*, long, int, uint32_t*, int, hipStream_t);
+template int select_hist<double>(const double*, const uint8_t*, long, int, uint32_t*, int, hipStream_t);
 }  // namespace como

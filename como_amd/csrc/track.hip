@@ -16,7 +16,7 @@
 
 namespace como {
 
-template <typename T> int select_hist(const T*, const uint8_t*, long, uint32_t*, int, hipStream_t);
+template <typename T> int select_hist(const T*, const uint8_t*, long, int, uint32_t*, int, hipStream_t);
 
 constexpr int TRK_ACC = 46;   // 36 (H upper) + 8 (g) + err + spare
 constexpr int TRK_MAX_BLOCKS = 1024;
@@ -41,7 +41,12 @@ __global__ __launch_bounds__(256) void track_residual_kernel(
   const T ax = T(1) / T(W), ay = T(1) / T(H);     // A_norm, photo_tracking.py:154-156
   const T ea = exp(-aff[0]), bb = aff[1];
   __syncthreads();
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
+  const long stride = (long)gridDim.x * 256;
+  const long iters = (N + stride - 1) / stride;               // uniform trip count (the aggregated histogram needs whole waves)
+  for (long it = 0; it < iters; ++it) {
+    const long i0 = it * stride + (long)blockIdx.x * 256 + threadIdx.x;
+    const bool inr = i0 < N;
+    const long i = inr ? i0 : N - 1;
     const T X = P[3 * i + 0], Y = P[3 * i + 1], Z = P[3 * i + 2];
     T hx, hy, hz;
     rigid_apply(Pm, X, Y, Z, hx, hy, hz);          // p_h = A P + b
@@ -51,12 +56,14 @@ __global__ __launch_bounds__(256) void track_residual_kernel(
     const T It = tap_sum(img, t);
     const T tmp = ea * It;                          // photo_tracking.py:124
     const T r = (tmp + bb) - vals_i[i];
-    J8[8 * i + 6] = -tmp;                           // dI_dT[..., 6] = -tmp (in-place, photo_tracking.py:125)
-    r_out[i] = r;
-    valid_out[i] = ok ? 1 : 0;
-    if (pj_out) { pj_out[2 * i] = u; pj_out[2 * i + 1] = v; }
-    if (depth_out) depth_out[i] = hz;
-    if (ok) atomicAdd(&lh[sel_digit<KeyT>(abs_key(r), 0)], 1u);
+    if (inr) {
+      J8[8 * i + 6] = -tmp;                         // dI_dT[..., 6] = -tmp (in-place, photo_tracking.py:125)
+      r_out[i] = r;
+      valid_out[i] = ok ? 1 : 0;
+      if (pj_out) { pj_out[2 * i] = u; pj_out[2 * i + 1] = v; }
+      if (depth_out) depth_out[i] = hz;
+    }
+    sel_lds_add_aggregated(lh, sel_digit<KeyT>(abs_key(r), 0), inr && ok);
   }
   __syncthreads();
   sel_flush(lh, hists);
@@ -223,7 +230,7 @@ int track_iter(const T* Tji, const T* Kmat, const T* aff, const T* P, const T* v
                      H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists);
   COMO_CHECK_LAUNCH();
   for (int p = 1; p < SelCfg<KeyT>::NPASS; ++p) {
-    int rc = select_hist<T>(r_ws, valid_out, N, hists, p, s);
+    int rc = select_hist<T>(r_ws, valid_out, N, 1, hists, p, s);
     if (rc) return rc;
   }
   int rblocks = (int)((N + 255) / 256);

@@ -1,0 +1,51 @@
+"""DepthCov covariance modules and the GP predictor on the GPU.
+
+Mirrors the reference's como/depth_cov/core/covariance.py (CovarianceModule / CrossCovarianceModule forward, Python-twin
+kernel formula of kernels.py:22-88) and Mapping.prep_predictor (Mapping.py:430-468); the kernel-matrix assembly and the
+fused K~ = K_nm K_mm^-1 run in csrc/densify.hip.  `scale` = scale_prior * exp(scale_param) (covariance.py:19-20).
+"""
+import torch
+
+from como_amd import _lib
+from como_amd.depth_cov.core.gaussian_kernel import interpolate_kernel_params
+from como_amd.utils.coords import normalize_coordinates
+
+
+def kernel_matrix(x1, E1, x2, E2, scale):
+    """(B,N,2),(B,N,2,2),(B,M,2),(B,M,2,2) -> (B,N,M); CrossCovarianceModule.forward (covariance.py:33-39)."""
+    _lib.require_cuda(x1, E1, x2, E2)
+    dt = E1.dtype
+    B, N, M = x1.shape[0], x1.shape[1], x2.shape[1]
+    out = torch.empty((B, N, M), dtype=dt, device=x1.device)
+    fn = getattr(_lib.lib(), "como_kernel_matrix_" + _lib.suffix(dt))
+    rc = fn(x1.to(dt).contiguous().data_ptr(), E1.contiguous().data_ptr(), x2.to(dt).contiguous().data_ptr(),
+            E2.contiguous().data_ptr(), float(scale), out.data_ptr(), B, N, M, _lib.stream_ptr(x1.device))
+    _lib.check(rc, "como_kernel_matrix")
+    return out
+
+
+def covariance(coords, E, scale):
+    """CovarianceModule.forward (covariance.py:22-26)."""
+    return kernel_matrix(coords, E, coords, E, scale)
+
+
+def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None):
+    """Mapping.prep_predictor (Mapping.py:430-468): returns (K_mm_inv (B,m,m), L_mm (B,m,m), Knm_Kmminv (B,H,W,m)).
+    K_nm (H*W x m per keyframe) is never materialised."""
+    _lib.require_cuda(cov_params_img, coords_m)
+    B, _, Hc, Wc = cov_params_img.shape
+    dt, dev = cov_params_img.dtype, cov_params_img.device
+    Hp, Wp = photo_img_size or (Hc, Wc)
+    m = coords_m.shape[1]
+    cm = normalize_coordinates(coords_m.to(dt), (Hc, Wc))
+    Em = interpolate_kernel_params(cov_params_img, cm)
+    K_mm = covariance(cm, Em, scale)
+    K_mm = K_mm + torch.diag_embed((1e-6 * torch.ones(B, m, device=dev)).to(dt))      # float32 jitter as Mapping.py:450
+    L_mm, _ = torch.linalg.cholesky_ex(K_mm, upper=False)
+    K_mm_inv = torch.cholesky_solve(torch.eye(m, dtype=dt, device=dev).expand(B, m, m), L_mm, upper=False).contiguous()
+    out = torch.empty((B, Hp, Wp, m), dtype=dt, device=dev)
+    fn = getattr(_lib.lib(), "como_ktilde_" + _lib.suffix(dt))
+    rc = fn(cov_params_img.contiguous().data_ptr(), Hc, Wc, cm.contiguous().data_ptr(), Em.contiguous().data_ptr(),
+            K_mm_inv.data_ptr(), float(scale), B, Hp, Wp, m, out.data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "como_ktilde")
+    return K_mm_inv, L_mm, out

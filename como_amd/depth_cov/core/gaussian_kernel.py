@@ -1,0 +1,26 @@
+"""Covariance-image helpers (reference como/depth_cov/core/gaussian_kernel.py): elementwise torch ops on the device."""
+import math
+
+import torch
+
+
+def normalize_params_cov(kernel_img, det_eps=1e-8, corr_coeff_max=0.99):
+    """Network output (B,3,H,W) -> (x, z, off-diagonal): gaussian_kernel.py:6-22."""
+    x = torch.exp(torch.clamp(kernel_img[:, 0], min=math.log(1e-3), max=math.log(1e4)))
+    z = torch.exp(torch.clamp(kernel_img[:, 1], min=math.log(1e-3), max=math.log(1e4)))
+    rho = corr_coeff_max * torch.tanh(kernel_img[:, 2])
+    return torch.stack((x, z, torch.sqrt(x * z - det_eps) * rho), dim=1).float()
+
+
+def kernel_params_to_covariance(kernel_img_norm):
+    """(B,3,H,W) -> (B,4,H,W) = [E00, E01, E10, E11]: gaussian_kernel.py:25-49."""
+    x, z, o = kernel_img_norm[:, 0], kernel_img_norm[:, 1], kernel_img_norm[:, 2]
+    return torch.stack((x, o, o, z), dim=1)
+
+
+def interpolate_kernel_params(kernel_img, x):
+    """Bilinear, border-padded lookup at normalised (row, col) coordinates -> (B,N,2,2): gaussian_kernel.py:52-79."""
+    B, N = x.shape[:2]
+    grid = x.flip(-1).unsqueeze(1)
+    s = torch.nn.functional.grid_sample(kernel_img, grid, mode="bilinear", padding_mode="border", align_corners=False)
+    return s.squeeze(2).permute(0, 2, 1).reshape(B, N, 2, 2)

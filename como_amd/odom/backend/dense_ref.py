@@ -1,0 +1,40 @@
+"""Factored dense reference points on the GPU (HIP kernel csrc/densify.hip `dense_ref`).
+
+Replaces the per-pixel part of the reference's Mapping.prep_dense_ref / sparse_map.setup_test_points
+(Mapping.py:661-699, sparse_map.py:184-230) without ever building dPwn_dzm (B,n,3,m): the outputs are the rank-1
+factors the BA kernel consumes (structure-of-arrays planes), plus the exact per-keyframe median depth.
+"""
+import torch
+
+from como_amd import _lib
+
+_ws = {}
+
+
+def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_logz=True):
+    """logzm (B,m,1) Twc (B,4,4) Kt (B,rows,m) pixidx (B,n) int32 or None K (3,3) dlogzm_dTwc (B,m,1,6).
+    Returns Pwn (B,3,n), dPwn_dTwc (B,18,n), uvec (B,3,n), median depth (B,), logzn (B,n)."""
+    _lib.require_cuda(logzm, Twc, Kt, K, dlogzm_dTwc)
+    dt, dev = Kt.dtype, Kt.device
+    B, rows, m = Kt.shape
+    n = pixidx.shape[1] if pixidx is not None else rows
+    L = _lib.lib()
+    key = (str(dev), dt, B, n)
+    ws = _ws.get(key)
+    if ws is None:
+        ws = {"Pwn": torch.empty((B, 3, n), device=dev, dtype=dt), "dT": torch.empty((B, 18, n), device=dev, dtype=dt),
+              "uvec": torch.empty((B, 3, n), device=dev, dtype=dt), "z": torch.empty((B, n), device=dev, dtype=dt),
+              "logz": torch.empty((B, n), device=dev, dtype=dt), "med": torch.empty((B, 3), device=dev, dtype=dt),
+              "hists": torch.empty((B * L.como_select_workspace_bytes() // 4,), device=dev, dtype=torch.int32)}
+        _ws.clear()
+        _ws[key] = ws
+    lz = logzm.reshape(B, m).to(dt).contiguous()
+    dl = dlogzm_dTwc.reshape(B, m, 6).to(dt).contiguous()
+    Tw = Twc.to(dt).contiguous()
+    Kc = K.to(dt).contiguous()
+    fn = getattr(L, "como_dense_ref_" + _lib.suffix(dt))
+    rc = fn(Kt.data_ptr(), Kt.stride(0), _lib.ptr(pixidx), lz.data_ptr(), Tw.data_ptr(), Kc.data_ptr(), dl.data_ptr(), B, n, m,
+            int(Wimg), ws["Pwn"].data_ptr(), ws["dT"].data_ptr(), ws["uvec"].data_ptr(), ws["z"].data_ptr(),
+            ws["logz"].data_ptr() if want_logz else None, ws["hists"].data_ptr(), ws["med"].data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "como_dense_ref")
+    return ws["Pwn"], ws["dT"], ws["uvec"], ws["med"][:, 0], ws["logz"]

@@ -1,0 +1,33 @@
+"""Coordinate helpers (reference como/utils/coords.py)."""
+import torch
+
+
+def swap_coords_xy(coords):
+    return coords.flip(-1)
+
+
+def normalize_coordinates(x_pixel, dims):
+    """Pixel -> [-1,1] with pixel centres at fractional positions: x_norm = 2 A x + A - 1, A = 1/dims (coords.py:12-15)."""
+    A = 1.0 / torch.as_tensor(dims, device=x_pixel.device, dtype=x_pixel.dtype)
+    return 2 * A * x_pixel + A - 1
+
+
+def normalize_coordinates_A(x_pixel, A):
+    return 2 * A * x_pixel + A - 1
+
+
+def unnormalize_coordinates(x_norm, dims):
+    A = torch.as_tensor(dims, device=x_norm.device, dtype=x_norm.dtype) / 2.0
+    return A * x_norm + A - 0.5
+
+
+def get_test_coords(img_size, device, batch_size=1):
+    h, w = img_size
+    r, c = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+    return torch.stack((r.reshape(-1), c.reshape(-1)), dim=1).repeat(batch_size, 1, 1)
+
+
+def get_coord_img(img_size, device, batch_size=1):
+    h, w = img_size
+    r, c = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+    return torch.stack((r, c), dim=-1).unsqueeze(0).repeat(batch_size, 1, 1, 1)

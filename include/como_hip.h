@@ -35,13 +35,16 @@ int como_abi_version(void);
  * `hists` = workspace of como_select_workspace_bytes() bytes.  Protocol:
  *   como_select_begin; como_select_hist_*(pass = 0..P-1) [P = 3 for f32, 6 for f64; multi-GPU: sum the
  *   ranks' hists of pass p with an all-reduce before pass p+1]; como_select_finish_* -> out3 =
- *   {median, 1.4826*median, nvalid}. */
+ *   {median, 1.4826*median, nvalid}.
+ * Segments: `nseg` independent selects over consecutive length-n slices of r / valid (one median per keyframe,
+ * sparse_map.py:220); hists holds nseg * como_select_workspace_bytes() bytes, out3 is (nseg,3).  valid may be NULL
+ * (all entries valid). */
 int como_select_workspace_bytes(void);
-int como_select_begin(void* hists, como_stream_t stream);
-int como_select_hist_f32(const float* r, const uint8_t* valid, long n, void* hists, int pass, como_stream_t stream);
-int como_select_hist_f64(const double* r, const uint8_t* valid, long n, void* hists, int pass, como_stream_t stream);
-int como_select_finish_f32(const void* hists, float* out3, como_stream_t stream);
-int como_select_finish_f64(const void* hists, double* out3, como_stream_t stream);
+int como_select_begin(void* hists, int nseg, como_stream_t stream);
+int como_select_hist_f32(const float* r, const uint8_t* valid, long n, int nseg, void* hists, int pass, como_stream_t stream);
+int como_select_hist_f64(const double* r, const uint8_t* valid, long n, int nseg, void* hists, int pass, como_stream_t stream);
+int como_select_finish_f32(const void* hists, int nseg, float* out3, como_stream_t stream);
+int como_select_finish_f64(const void* hists, int nseg, double* out3, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tracking: one inverse-compositional GN iteration (python path: frontend/photo_tracking.py:117-143).
@@ -74,11 +77,11 @@ typedef struct como_ba_args {
   int chunks;                /* pixel chunks per pair (grid.x of the block kernel); partial records = b*chunks */
   int phase;                 /* bit mask: 1 setup+residual(+hist pass 0), 2<<(p-1) hist pass p>=1, 64 blocks, 128 reduce+assemble */
   int h_is_f64;              /* element type of Hmat / gvec: 1 = double, 0 = float */
-  const void* Pwn;           /* (slots,n,3)   photo.py:86 */
+  const void* Pwn;           /* zmode 0: (slots,n,3) photo.py:86 ; zmode 1: planes (slots,3,n) */
   const void* vals;          /* (slots,n)     photo.py:84 */
-  const void* dPwn_dTwc;     /* (slots,n,3,6) photo.py:90 */
+  const void* dPwn_dTwc;     /* zmode 0: (slots,n,3,6) photo.py:90 ; zmode 1: planes (slots,18,n) */
   const void* zjac;          /* see zmode */
-  const void* uvec;          /* zmode 1: (slots,n,3) */
+  const void* uvec;          /* zmode 1: planes (slots,3,n) */
   const int* pixidx;         /* zmode 1: (slots,n) row of K~ per reference pixel, NULL = identity */
   const void* invz;          /* zmode 1: (slots,m) = dlogz_m/dz_m = 1/z_m */
   long kt_slot_stride;       /* zmode 1: elements between slots of K~ */
@@ -131,6 +134,37 @@ int como_cross_covariance_f64(const double* x1, const double* E1, const double* 
                               double* K12, int B, int N, int M, const long* strides_host, como_stream_t stream);
 int como_chol_append_obs_info_f32(float* L, float* obs_info, float* var, const float* k_ni, const float* k_id,
                                   float k_ii, int B, int n, int d, int N, como_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense reference points in factored form (python path: backend/sparse_map.py:184-230 backproject_cloud +
+ * setup_test_points, Mapping.py:661-699).  Inputs: Kt (B,rows,m) dense predictor (slot stride given), pixidx (B,n)
+ * rows of the selected pixels (NULL = identity), logzm (B,m), Twc (B,4,4), K (3,3), dlogzm_dTwc (B,m,6).
+ * Outputs (structure-of-arrays planes): Pwn (B,3,n), dPwn_dTwc (B,18,n) [full Jacobian incl. the path through
+ * logz_m(T_wc)], uvec (B,3,n) = R_wc ray z_n, zbuf (B,n) = depth, logzn_out (B,n) optional,
+ * med_out3 (B,3) = {exact median depth (sparse_map.py:220), 1.4826*median, n}.  hists: B * select workspace. */
+int como_dense_ref_f32(const float* Kt, long kt_slot_stride, const int* pixidx, const float* logzm, const float* Twc,
+                       const float* K, const float* dlogzm_dTwc, int B, int n, int m, int Wimg, float* Pwn,
+                       float* dPwn_dTwc, float* uvec, float* zbuf, float* logzn_out, void* hists, float* med_out3,
+                       como_stream_t stream);
+int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx, const double* logzm, const double* Twc,
+                       const double* K, const double* dlogzm_dTwc, int B, int n, int m, int Wimg, double* Pwn,
+                       double* dPwn_dTwc, double* uvec, double* zbuf, double* logzn_out, void* hists, double* med_out3,
+                       como_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DepthCov covariance-kernel assembly, Python-twin formula (python path: depth_cov/core/kernels.py:22-88,
+ * covariance.py:10-39) and conditioning (Mapping.py:430-468 prep_predictor).
+ * como_kernel_matrix_*: out (B,N,M) = scale * k(x1_i,E1_i ; x2_j,E2_j); x (B,.,2) normalised (row,col), E (B,.,2,2).
+ * como_ktilde_*: out (B,Hp,Wp,m) = K_nm K_mm^-1 for every photo pixel; cov (B,4,Hc,Wc) covariance image,
+ *   xm (B,m,2) / Em (B,m,2,2) inducing points, Kinv (B,m,m) = K_mm^-1.  K_nm is never written to memory. */
+int como_kernel_matrix_f32(const float* x1, const float* E1, const float* x2, const float* E2, float scale, float* out,
+                           int B, int N, int M, como_stream_t stream);
+int como_kernel_matrix_f64(const double* x1, const double* E1, const double* x2, const double* E2, double scale,
+                           double* out, int B, int N, int M, como_stream_t stream);
+int como_ktilde_f32(const float* cov, int Hc, int Wc, const float* xm, const float* Em, const float* Kinv, float scale,
+                    int B, int Hp, int Wp, int m, float* out, como_stream_t stream);
+int como_ktilde_f64(const double* cov, int Hc, int Wc, const double* xm, const double* Em, const double* Kinv,
+                    double scale, int B, int Hp, int Wp, int m, double* out, como_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -22,10 +22,10 @@ def run(dtype, window, iters=10):
     ray = torch.stack(((u.reshape(-1) - 319.5) / 525, (v.reshape(-1) - 239.5) / 525, torch.ones(n, dtype=dtype, device=dev)), -1)
     poses = torch.eye(4, dtype=dtype, device=dev).repeat(B, 1, 1)
     poses[:, 0, 3] = 0.05 * torch.arange(B, dtype=dtype, device=dev)
-    Pwn = (z[..., None] * ray[None]) + poses[:, None, :3, 3]
+    Pwn = ((z[..., None] * ray[None]) + poses[:, None, :3, 3]).permute(0, 2, 1).contiguous()
     vals = torch.rand((B, n), dtype=dtype, device=dev)
-    dT = torch.randn((B, n, 3, 6), dtype=dtype, device=dev)
-    uvec = torch.randn((B, n, 3), dtype=dtype, device=dev)
+    dT = torch.randn((B, 18, n), dtype=dtype, device=dev)
+    uvec = torch.randn((B, 3, n), dtype=dtype, device=dev)
     Kt = torch.rand((B, Hh * Ww, m), dtype=dtype, device=dev) / m
     pix = ((v.reshape(-1) * Ww + u.reshape(-1)).to(torch.int32))[None].repeat(B, 1).contiguous()
     invz = 0.4 * torch.ones((B, m), dtype=dtype, device=dev)

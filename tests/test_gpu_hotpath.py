@@ -33,10 +33,10 @@ def test_exact_median_select(dtype, n):
     out = torch.empty(3, dtype=dtype, device=DEV)
     sfx = _lib.suffix(dtype)
     s = _lib.stream_ptr()
-    _lib.check(L.como_select_begin(hists.data_ptr(), s), "begin")
+    _lib.check(L.como_select_begin(hists.data_ptr(), 1, s), "begin")
     for p in range(3 if dtype == torch.float32 else 6):
-        _lib.check(getattr(L, "como_select_hist_" + sfx)(rd.data_ptr(), vd.data_ptr(), n, hists.data_ptr(), p, s), "hist")
-    _lib.check(getattr(L, "como_select_finish_" + sfx)(hists.data_ptr(), out.data_ptr(), s), "finish")
+        _lib.check(getattr(L, "como_select_hist_" + sfx)(rd.data_ptr(), vd.data_ptr(), n, 1, hists.data_ptr(), p, s), "hist")
+    _lib.check(getattr(L, "como_select_finish_" + sfx)(hists.data_ptr(), 1, out.data_ptr(), s), "finish")
     ref = torch.median(r[valid].abs())
     o = out.cpu()
     report("select", dtype=str(dtype), n=n, got=o[0], want=ref, nvalid=o[2])
@@ -261,8 +261,9 @@ def test_factored_path_matches_reference_signature_path():
     rid, tid = G["kf_ref_ids"].tolist(), G["kf_target_ids"].tolist()
     table = photo.PairTable(rid, tid, [False] * len(rid), B, dev(G["kf_inds"]), dev(G["recent_inds"]), dev(G["landmark_inds"]),
                             3 * Hh * Ww, 0, DEV)
-    photo.photo_system_factored(table, poses_all=dev(G["kf_poses"]), aff_all=dev(G["kf_aff_params"].reshape(B, 2)), Pwn=dev(G["Pwn"]),
-                                vals=dev(G["vals_n"].reshape(B, n)), dPwn_dTwc=dev(G["dPwn_dTwc"]), uvec=dev(uvec),
+    soa = lambda t, k: dev(t.reshape(B, n, k).permute(0, 2, 1))          # fast path takes (B, k, n) planes
+    photo.photo_system_factored(table, poses_all=dev(G["kf_poses"]), aff_all=dev(G["kf_aff_params"].reshape(B, 2)), Pwn=soa(G["Pwn"], 3),
+                                vals=dev(G["vals_n"].reshape(B, n)), dPwn_dTwc=soa(G["dPwn_dTwc"], 18), uvec=soa(uvec, 3),
                                 Kt=dev(G["Knm_Kmminv"].reshape(B, Hh * Ww, m)), pixidx=dev(pixidx), invz=dev(invz),
                                 dzdP=dev(G["dzm_dPwm"][:, 0, 0, :]), img_base=dev(G["kf_img_and_grads"]), K=dev(K), H_img=Hh, W_img=Ww,
                                 H=H, g=g, err_out=e)
@@ -302,3 +303,72 @@ def test_como_backends_vs_golden():
         cb.get_new_chol_obs_info(L.transpose(1, 2), obs, var, k_ni, k_id, 1.0, 1)      # "must be contiguous"
     with pytest.raises(RuntimeError):
         cb.cross_covariance(C["x1"], dev(C["E1"]), dev(C["x2"]), dev(C["E2"]), 1.0)    # mixed devices
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,tol", [("ba_window_f64.npz", 1e-12), ("ba_window_f32.npz", 2e-5)])
+def test_dense_reference_factored_vs_golden(name, tol):
+    from como_amd.odom.backend.dense_ref import dense_reference_factored
+    G = load_golden(name)
+    B, n = G["coords_n"].shape[:2]
+    m = G["coords_m"].shape[1]
+    Hh, Ww = G["kf_img_and_grads"].shape[-2:]
+    cn = G["coords_n"]
+    pixidx = (cn[..., 0] * Ww + cn[..., 1]).to(torch.int32)
+    dl = G["dlogzm_dzm"] @ G["dzm_dTwc"]
+    Pwn, dT, uvec, med, logzn = dense_reference_factored(dev(G["logzm"]), dev(G["kf_poses"]), dev(G["Knm_Kmminv"].reshape(B, Hh * Ww, m)),
+                                                         dev(pixidx), dev(G["intrinsics"][0]), dev(dl), Ww)
+    Pw = Pwn.permute(0, 2, 1).cpu()
+    dTa = dT.permute(0, 2, 1).reshape(B, n, 3, 6).cpu()
+    # rank-1 reconstruction of the tensor the reference materialises
+    dz = torch.einsum("bni,bnk,bk->bnik", uvec.permute(0, 2, 1).cpu(), G["Knm_Kmminv"].reshape(B, -1, m)[torch.arange(B)[:, None], pixidx.long()],
+                      G["dlogzm_dzm"][:, :, 0, 0])
+    report("dense_ref", case=name, Pwn=rel_err(Pw, G["Pwn"]), Pwn_exact=bool(torch.equal(Pw, G["Pwn"])), dT=rel_err(dTa, G["dPwn_dTwc"]),
+           dz=rel_err(dz, G["dPwn_dzm"][..., 0]), med=(med.cpu() - G["median_depths"]).abs().max(), logz=rel_err(logzn.cpu(), G["logzn"][..., 0]))
+    assert rel_err(Pw, G["Pwn"]) < tol and rel_err(dTa, G["dPwn_dTwc"]) < tol * 10
+    assert rel_err(dz, G["dPwn_dzm"][..., 0]) < tol * 10
+    assert (med.cpu() - G["median_depths"]).abs().max() < tol * 10
+
+
+@pytest.mark.parametrize("name,tol", [("ba_window_f64.npz", 1e-9), ("ba_window_f32.npz", 2e-4)])
+def test_prep_predictor_vs_golden(name, tol):
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    G = load_golden(name)
+    Kinv, L, Kt = prep_predictor(dev(G["cov_params_img"]), dev(G["coords_m"]), 1.0)
+    report("prep_predictor", case=name, Kinv=rel_err(Kinv, G["K_mm_inv"]), L=rel_err(L, G["L_mm"]), Kt=rel_err(Kt, G["Knm_Kmminv"]))
+    assert rel_err(L, G["L_mm"]) < tol and rel_err(Kinv, G["K_mm_inv"]) < tol * 50 and rel_err(Kt, G["Knm_Kmminv"]) < tol * 50
+
+
+def _window_state(G):
+    st = {k: dev(G[k]) for k in ("intrinsics", "kf_poses", "kf_aff_params", "kf_img_and_grads", "coords_m", "correspondence_mask",
+                                 "P_m", "kf_timestamps", "obs_ref_mask", "pm_first_obs", "L_mm", "Knm_Kmminv", "pose_anchor", "P_anchor")}
+    return st
+
+
+@pytest.mark.parametrize("pix", [torch.float64, torch.float32])
+def test_window_iterate_vs_golden(pix):
+    """One full Mapping.iterate()-equivalent (scaffold -> dense ref -> photo system -> priors -> solve -> update)."""
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    import copy
+    G = load_golden("ba_window_f64.npz")
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = 2
+    wb = WindowBA(_window_state(G), cfg=cfg, pix_dtype=pix, window_full=True)
+    wb.median_depths = dev(G["median_depths_in"])
+    H, g = wb.linearize()
+    Hrel, grel = rel_err(H, G["H_full"]), rel_err(g, G["g_full"])
+    wb2 = WindowBA(_window_state(G), cfg=cfg, pix_dtype=pix, window_full=True)
+    wb2.median_depths = dev(G["median_depths_in"])
+    delta = wb2.iterate()
+    perr = (wb2.kf_poses.cpu() - G["kf_poses_new"]).abs().max().item()
+    report("window_iterate", pix=str(pix), H_rel=Hrel, g_rel=grel, delta_rel=rel_err(delta, G["delta"]), pose_err=perr,
+           P_err=(wb2.P_m.cpu() - G["P_new"]).abs().max(), info=int(lin_info()))
+    tol = 1e-8 if pix == torch.float64 else 2e-3
+    assert Hrel < tol and grel < tol
+    assert perr < (1e-9 if pix == torch.float64 else 1e-4)           # poses within 1e-4 of the reference
+    assert (wb2.P_m.cpu() - G["P_new"]).abs().max() < (1e-8 if pix == torch.float64 else 5e-3)
+
+
+def lin_info():
+    import como_amd.odom.backend.linear_system as ls
+    return ls.solve_system.last_info
