@@ -21,7 +21,20 @@
 #include "select.cuh"
 #include "../../include/como_hip.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace como {
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I = 0..N-1 (guarantees static register indexing)
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 template <typename T> int select_hist(const T*, const uint8_t*, long, int, uint32_t*, int, hipStream_t);
 
@@ -136,6 +149,13 @@ struct BACfg {
   static constexpr int REC = NT * 256 + NB * 16 + 16;  // per-wave partial record (elements) = 3936
 };
 __host__ __device__ constexpr int kcol(int t, int ci) { return 4 * ci + (t - 1); }
+// upper-triangular tile enumeration: tile tt = (ti, tj >= ti), rows in order
+__host__ __device__ constexpr int tile_first(int ti) { return ti * BACfg::NB - ti * (ti - 1) / 2; }
+__host__ __device__ constexpr int tile_row(int tt) {
+  int ti = 0;
+  while (ti + 1 < BACfg::NB && tile_first(ti + 1) <= tt) ++ti;
+  return ti;
+}
 
 template <typename T> struct V4 { T x, y, z, w; };
 template <typename T>
@@ -221,12 +241,12 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
     if constexpr (ZMODE == 1) {
       const int i = min(tile + lane, end - 1);
       myrow = pixidx ? pixidx[(long)slot * n + i] : i;
-#pragma unroll
-      for (int st = 0; st < PF; ++st) {
+      static_for<PF>([&](auto ic) {
+        constexpr int st = decltype(ic)::value;
         const int row = __shfl(myrow, 4 * st + q, 64);
         kq[st] = V4<T>{T(0), T(0), T(0), T(0)};
         if (4 * c < m) kq[st] = load4(zjac + (long)slot * kt_slot_stride + (long)row * m + 4 * c);
-      }
+      });
     }
     // ------------------------- phase A: lane = pixel ------------------------------------------
     {
@@ -293,8 +313,8 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
     __builtin_amdgcn_wave_barrier();
     // ------------------------- phase B: 4 pixels per MFMA step --------------------------------
     const long zbase0 = (long)slot * n;
-#pragma unroll
-    for (int st = 0; st < 16; ++st) {
+    static_for<16>([&](auto ic) {
+      constexpr int st = decltype(ic)::value;
       const int px = 4 * st + q;                           // this lane's pixel inside the tile
       T a[Cfg::NB];
       a[0] = Jp[c * JP_STRIDE + px];
@@ -322,14 +342,13 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
         }
         a[1] = sz * k4.x * invz4[0]; a[2] = sz * k4.y * invz4[1]; a[3] = sz * k4.z * invz4[2]; a[4] = sz * k4.w * invz4[3];
       }
-#pragma unroll
-      for (int t = 0; t < Cfg::NB; ++t) gacc[t] += a[t] * rt;
-      int tt = 0;
-#pragma unroll
-      for (int ti = 0; ti < Cfg::NB; ++ti)
-#pragma unroll
-        for (int tj = ti; tj < Cfg::NB; ++tj) { acc[tt] = mfma16(a[ti], a[tj], acc[tt]); ++tt; }
-    }
+      static_for<Cfg::NB>([&](auto it) { gacc[decltype(it)::value] += a[decltype(it)::value] * rt; });
+      static_for<Cfg::NT>([&](auto it) {
+        constexpr int tt = decltype(it)::value;
+        constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
+        acc[tt] = mfma16(a[ti], a[tj], acc[tt]);
+      });
+    });
     __builtin_amdgcn_wave_barrier();
   }
 
@@ -466,8 +485,11 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
     hipLaunchKernelGGL(ba_pair_setup_kernel<T>, dim3((b + 63) / 64), dim3(64), 0, s, (const T*)A->poses_all,
                        (const T*)A->aff_all, pr, b, pair_T, pair_aff);
     COMO_CHECK_LAUNCH();
+    // ~1024 workgroups in total: every workgroup ends with global atomics on the few hot digit-0 bins, which
+    // serialise per address at the memory side (~15 ns each) -- 14k workgroups cost > 200 us there.
     int gx = (n + 255) / 256;
-    if (gx > 1024) gx = 1024;
+    const int cap = (1024 + b - 1) / b;
+    if (gx > cap) gx = cap;
     if (A->zmode == 1)
       hipLaunchKernelGGL((ba_residual_kernel<T, true>), dim3(gx, b), dim3(256), 0, s, (const T*)A->Pwn, (const T*)A->vals, pr,
                          pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, (T*)A->ws_r,

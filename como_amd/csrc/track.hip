@@ -225,7 +225,7 @@ int track_iter(const T* Tji, const T* Kmat, const T* aff, const T* P, const T* v
   uint32_t* hists = (uint32_t*)hists_v;
   if (hipMemsetAsync(hists, 0, 6 * SEL_BINS * sizeof(uint32_t), s) != hipSuccess) return COMO_ERR_LAUNCH;
   long blocks = (N + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (blocks > 1024) blocks = 1024;   // bounded: the digit-0 flush serialises per hot bin at the memory-side atomics
   hipLaunchKernelGGL(track_residual_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, Tji, Kmat, aff, P, vals_i, img,
                      H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists);
   COMO_CHECK_LAUNCH();

@@ -330,12 +330,14 @@ def test_dense_reference_factored_vs_golden(name, tol):
     assert (med.cpu() - G["median_depths"]).abs().max() < tol * 10
 
 
-@pytest.mark.parametrize("name,tol", [("ba_window_f64.npz", 1e-9), ("ba_window_f32.npz", 2e-4)])
+@pytest.mark.parametrize("name,tol", [("ba_window_f64.npz", 1e-7), ("ba_window_f32.npz", 2e-4)])
 def test_prep_predictor_vs_golden(name, tol):
     from como_amd.depth_cov.core.covariance import prep_predictor
     G = load_golden(name)
     Kinv, L, Kt = prep_predictor(dev(G["cov_params_img"]), dev(G["coords_m"]), 1.0)
     report("prep_predictor", case=name, Kinv=rel_err(Kinv, G["K_mm_inv"]), L=rel_err(L, G["L_mm"]), Kt=rel_err(Kt, G["Knm_Kmminv"]))
+    # f64: the reference's Python twin casts coordinate differences to float32 (kernels.py:25), so its own K_mm carries
+    # ~1e-8 relative noise; the tolerance reflects that, not the kernel.
     assert rel_err(L, G["L_mm"]) < tol and rel_err(Kinv, G["K_mm_inv"]) < tol * 50 and rel_err(Kt, G["Knm_Kmminv"]) < tol * 50
 
 
