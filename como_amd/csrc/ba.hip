@@ -94,7 +94,8 @@ template <typename T, bool SOA>
 __global__ __launch_bounds__(256) void ba_residual_kernel(
     const T* __restrict__ Pwn, const T* __restrict__ vals, BAPairs pr, const T* __restrict__ pair_T,
     const T* __restrict__ pair_aff, const T* __restrict__ img_base, const T* __restrict__ Kmat, int H, int W, int n,
-    T* __restrict__ r_out, uint8_t* __restrict__ valid_out, T* __restrict__ pj_out, uint32_t* __restrict__ hists) {
+    int pix_begin, int pix_end, T* __restrict__ r_out, uint8_t* __restrict__ valid_out, T* __restrict__ pj_out,
+    uint32_t* __restrict__ hists) {
   using KeyT = typename KeyOf<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
   for (int b = threadIdx.x; b < SEL_BINS; b += 256) lh[b] = 0;
@@ -111,11 +112,12 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(
   const long HW = (long)H * W;
   __syncthreads();
   const int stride = gridDim.x * 256;
-  const int iters = (n + stride - 1) / stride;          // uniform trip count (whole waves for the aggregated histogram)
+  const int nl = pix_end - pix_begin;                   // this rank's pixel range [pix_begin, pix_end) of every pair
+  const int iters = (nl + stride - 1) / stride;         // uniform trip count (whole waves for the aggregated histogram)
   for (int it = 0; it < iters; ++it) {
-    const int i0 = it * stride + blockIdx.x * 256 + threadIdx.x;
-    const bool inr = i0 < n;
-    const int i = inr ? i0 : n - 1;
+    const int i0 = pix_begin + it * stride + blockIdx.x * 256 + threadIdx.x;
+    const bool inr = i0 < pix_end;
+    const int i = inr ? i0 : pix_end - 1;
     const long ri = (long)slot * n + i;
     T Px, Py, Pz;
     if constexpr (SOA) { Px = Pwn[((long)slot * 3 + 0) * n + i]; Py = Pwn[((long)slot * 3 + 1) * n + i]; Pz = Pwn[((long)slot * 3 + 2) * n + i]; }
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(
     const T It = tap_sum(img, t);
     const T r = It - scale * vals[ri] + bias;           // photo.py:114-118
     if (inr) {
-      const long oi = (long)p * n + i;
+      const long oi = (long)p * nl + (i - pix_begin);
       r_out[oi] = r;
       valid_out[oi] = w.ok ? 1 : 0;
       if (pj_out) { pj_out[2 * oi] = w.u; pj_out[2 * oi + 1] = w.v; }
@@ -184,8 +186,8 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
     const T* __restrict__ invz,      // ZMODE 1: (slots, m)
     long kt_slot_stride,             // ZMODE 1: elements between consecutive slots of K~
     BAPairs pr, const T* __restrict__ pair_T, const T* __restrict__ pair_aff, const T* __restrict__ img_base,
-    const T* __restrict__ Kmat, int H, int W, int n, int m, int chunk_len, const uint32_t* __restrict__ hists,
-    T* __restrict__ partials, T* __restrict__ sigma_out) {
+    const T* __restrict__ Kmat, int H, int W, int n, int m, int pix_begin, int pix_end, int chunk_len,
+    const uint32_t* __restrict__ hists, T* __restrict__ partials, T* __restrict__ sigma_out) {
   using KeyT = typename KeyOf<T>::type;
   using Cfg = BACfg;
   using acc_t = typename Acc4<T>::type;
@@ -230,8 +232,8 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
   for (int t = 0; t < Cfg::NB; ++t) gacc[t] = T(0);
   T err = T(0);
 
-  const int begin = blockIdx.x * chunk_len;
-  const int end = min(n, begin + chunk_len);
+  const int begin = pix_begin + blockIdx.x * chunk_len;
+  const int end = min(pix_end, begin + chunk_len);
   // K~ quads of the tile are fetched BEFORE phase A (they depend only on the pixel index), PF steps deep: the
   // matrix-core phase then runs from registers/LDS only.  f32: whole tile (16 steps, 64 VGPRs); f64: ring of 8.
   constexpr int PF = (sizeof(T) == 4) ? 16 : 8;
@@ -476,6 +478,9 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
   if (A->zmode == 1 && (!A->uvec || !A->invz)) return COMO_ERR_ARG;
   BAPairs pr{A->ref_slot, A->ref_aff, A->tgt_aff, A->tgt_pose, A->tgt_img};
   const int b = A->b, n = A->n, m = A->m;
+  const int pb = A->pix_begin, pe = (A->pix_end > 0) ? A->pix_end : n;
+  if (pb < 0 || pe > n || pb >= pe) return COMO_ERR_ARG;
+  const int nl = pe - pb;
   T* pair_T = (T*)A->ws_pair;
   T* pair_aff = pair_T + 12 * (long)b;
   uint32_t* hists = (uint32_t*)A->ws_hists;
@@ -487,38 +492,38 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
     COMO_CHECK_LAUNCH();
     // ~1024 workgroups in total: every workgroup ends with global atomics on the few hot digit-0 bins, which
     // serialise per address at the memory side (~15 ns each) -- 14k workgroups cost > 200 us there.
-    int gx = (n + 255) / 256;
+    int gx = (nl + 255) / 256;
     const int cap = (1024 + b - 1) / b;
     if (gx > cap) gx = cap;
     if (A->zmode == 1)
       hipLaunchKernelGGL((ba_residual_kernel<T, true>), dim3(gx, b), dim3(256), 0, s, (const T*)A->Pwn, (const T*)A->vals, pr,
-                         pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, (T*)A->ws_r,
+                         pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, pb, pe, (T*)A->ws_r,
                          (uint8_t*)A->ws_valid, (T*)A->pj_out, hists);
     else
       hipLaunchKernelGGL((ba_residual_kernel<T, false>), dim3(gx, b), dim3(256), 0, s, (const T*)A->Pwn, (const T*)A->vals, pr,
-                         pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, (T*)A->ws_r,
+                         pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, pb, pe, (T*)A->ws_r,
                          (uint8_t*)A->ws_valid, (T*)A->pj_out, hists);
     COMO_CHECK_LAUNCH();
   }
   // digit passes 1..P-1 (multi-GPU: the caller all-reduces hists between phases 1, 2a.. and 4)
   for (int ps = 1; ps < SelCfg<KeyT>::NPASS; ++ps) {
     if (A->phase & (2 << (ps - 1))) {
-      int rc = select_hist<T>((const T*)A->ws_r, (const uint8_t*)A->ws_valid, (long)b * n, 1, hists, ps, s);
+      int rc = select_hist<T>((const T*)A->ws_r, (const uint8_t*)A->ws_valid, (long)b * nl, 1, hists, ps, s);
       if (rc) return rc;
     }
   }
   if (A->phase & 64) {
     const int chunks = A->chunks;
     if (chunks <= 0) return COMO_ERR_ARG;
-    int chunk_len = (n + chunks - 1) / chunks;
+    int chunk_len = (nl + chunks - 1) / chunks;
     chunk_len = ((chunk_len + 255) / 256) * 256;
-    if ((long)chunk_len * chunks < n) return COMO_ERR_ARG;
+    if ((long)chunk_len * chunks < nl) return COMO_ERR_ARG;
     dim3 grid(chunks, b), blk(256);
 #define LAUNCH_BLOCKS(ZM)                                                                                            \
   hipLaunchKernelGGL((ba_blocks_kernel<T, ZM>), grid, blk, 0, s, (const T*)A->Pwn, (const T*)A->vals,                 \
                      (const T*)A->dPwn_dTwc, (const T*)A->zjac, (const T*)A->uvec, A->pixidx, (const T*)A->invz,      \
                      A->kt_slot_stride, pr, pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, m, \
-                     chunk_len, hists, (T*)A->ws_partials, (T*)A->sigma_out)
+                     pb, pe, chunk_len, hists, (T*)A->ws_partials, (T*)A->sigma_out)
     if (A->zmode == 0) { LAUNCH_BLOCKS(0); } else { LAUNCH_BLOCKS(1); }
 #undef LAUNCH_BLOCKS
     COMO_CHECK_LAUNCH();

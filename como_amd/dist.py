@@ -1,0 +1,62 @@
+"""One-process-per-GPU data parallelism for the window BA (torch.distributed; backend "nccl" IS RCCL on ROCm).
+
+The reference has no distributed code at all; this is the one strategy the path needs:
+every rank holds the whole window (images 29 MB, K~ 630 MB at 8 x 640x480 -- nothing next to 288 GB of HBM) and
+linearises its own contiguous share of the reference pixels of EVERY keyframe pair (perfect balance, unlike sharding
+14 pairs over 8 ranks).  Two kinds of exchange per GN iteration:
+  * the robust scale is a GLOBAL exact median (photo.py:124-128): the 2048-bin histogram of each radix-select digit
+    pass is summed across ranks (8 KiB all-reduce, 3 for float keys / 6 for double) -- every rank then resolves the
+    same k-th key, bit for bit;
+  * the normal equations: H | g | err packed in one buffer, ONE all-reduce(sum) (D^2 + D + 1 doubles, 4.6 MB at
+    D = 760), after which every rank adds the priors and solves redundantly (no broadcast of delta).
+Payloads are latency-bound on xGMI (tens of microseconds); see DESIGN.md for the accounting.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class Shard:
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+
+    def pixel_range(self, n):
+        per = (n + self.world - 1) // self.world
+        per = ((per + 63) // 64) * 64                      # whole 64-pixel wave tiles
+        b = min(n, self.rank * per)
+        e = min(n, b + per)
+        if e <= b:                                         # degenerate tiny problems: give the last pixel to idle ranks
+            b, e = n - 1, n
+        return b, e
+
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def max_scalar(self, v, device):
+        t = torch.tensor([v], dtype=torch.float64, device=device)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier(group=self.group)
+
+
+def init_from_env(backend=None):
+    """Read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run) and return (Shard, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_cuda = torch.cuda.is_available()
+    device = torch.device(f"cuda:{local}") if use_cuda else torch.device("cpu")
+    if use_cuda:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
+    return Shard(rank, world), device

@@ -40,23 +40,31 @@ def default_chunks(b, n, dtype):
 def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac, poses_all, aff_all, img_base, K,
               ref_slot, ref_aff, tgt_aff, tgt_pose, tgt_img, pose_ref_inds, pose_tgt_inds, landmark_inds, dzdP, H, g,
               err_out, uvec=None, pixidx=None, invz=None, kt_slot_stride=0, chunks=None, phase=0xFF, want_pj=False,
-              want_blocks=False, sigma_out=None):
-    """Thin marshalling layer over como_ba_linearize_* (see include/como_hip.h for every field)."""
+              want_blocks=False, sigma_out=None, pix_range=None, reduce_hists=None, events=None):
+    """Thin marshalling layer over como_ba_linearize_* (see include/como_hip.h for every field).
+
+    pix_range=(begin, end): this rank's share of the reference pixels of every pair (multi-GPU shard).
+    reduce_hists(view): called on the (2048,) int32 histogram of each radix-select digit pass right after it is produced
+        (multi-GPU: an all-reduce(sum), so every rank resolves the same exact median); splits the chain into phases.
+    events: optional dict filled with (start, end) torch.cuda.Event pairs around the block kernel ("blocks")."""
     dev = Pwn.device
     L = _lib.lib()
+    pb, pe = pix_range if pix_range is not None else (0, n)
+    nl = pe - pb
     if chunks is None:
-        chunks = default_chunks(b, n, dtype)
+        chunks = default_chunks(b, nl, dtype)
     a = _lib.BAArgs()
     a.b, a.n, a.m, a.H, a.W, a.zmode, a.chunks, a.phase = b, n, m, H_img, W_img, zmode, chunks, phase
+    a.pix_begin, a.pix_end = pb, pe
     a.h_is_f64 = 1 if H.dtype == torch.float64 else 0
-    ws_r = _buf("r", (b, n), dtype, dev)
-    ws_valid = _buf("valid", (b, n), torch.uint8, dev)
+    ws_r = _buf("r", (b, nl), dtype, dev)
+    ws_valid = _buf("valid", (b, nl), torch.uint8, dev)
     ws_hists = _buf("hists", (L.como_select_workspace_bytes() // 4,), torch.int32, dev)
     ws_pair = _buf("pair", (b * 14,), dtype, dev)
     ws_part = _buf("partials", (L.como_ba_partials_elems(b, chunks, m),), dtype, dev)
     if sigma_out is None:
         sigma_out = _buf("sigma", (2,), dtype, dev)
-    pj = _buf("pj", (b, n, 2), dtype, dev) if want_pj else None
+    pj = _buf("pj", (b, nl, 2), dtype, dev) if want_pj else None
     blocks = _buf("blocks", (b, 3936), torch.float64, dev) if want_blocks else None
     keep = [Pwn, vals, dPwn_dTwc, zjac, uvec, pixidx, invz, poses_all, aff_all, img_base, K, ref_slot, ref_aff, tgt_aff,
             tgt_pose, tgt_img, pose_ref_inds, pose_tgt_inds, landmark_inds, dzdP, H, g, err_out]
@@ -76,7 +84,31 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     a.ws_r, a.ws_valid, a.ws_hists, a.ws_pair, a.ws_partials = (_lib.ptr(ws_r), _lib.ptr(ws_valid), _lib.ptr(ws_hists),
                                                                  _lib.ptr(ws_pair), _lib.ptr(ws_part))
     fn = getattr(L, "como_ba_linearize_" + _lib.suffix(dtype))
-    _lib.check(fn(ctypes.byref(a), _lib.stream_ptr(dev)), "como_ba_linearize")
+    stream = _lib.stream_ptr(dev)
+
+    def run(ph):
+        a.phase = ph
+        _lib.check(fn(ctypes.byref(a), stream), "como_ba_linearize")
+
+    if reduce_hists is None and events is None:
+        run(phase)
+    else:
+        npass = 3 if dtype == torch.float32 else 6
+        run(1)
+        for ps in range(npass):
+            if reduce_hists is not None:
+                reduce_hists(ws_hists[ps * 2048:(ps + 1) * 2048])
+            if ps + 1 < npass:
+                run(2 << ps)
+        if events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run(64)
+            e1.record()
+            events.setdefault("blocks", []).append((e0, e1))
+        else:
+            run(64)
+        run(128)
     last_aux.clear()
     last_aux.update({"valid": ws_valid, "r": ws_r, "sigma": sigma_out, "pj": pj, "blocks": blocks, "hists": ws_hists,
                      "chunks": chunks})
@@ -168,7 +200,8 @@ class PairTable:
 
 
 def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uvec, Kt, pixidx, invz, dzdP, img_base, K,
-                          H_img, W_img, H, g, err_out, chunks=None, phase=0xFF, sigma_out=None):
+                          H_img, W_img, H, g, err_out, chunks=None, phase=0xFF, sigma_out=None, pix_range=None,
+                          reduce_hists=None, events=None):
     """Fast path: same normal equations as batch_photo_cost from the rank-1 factors of dPwn_dzm.
     Per-keyframe arrays (slots = keyframes): Pwn (B,n,3) vals (B,n) dPwn_dTwc (B,n,3,6) uvec (B,n,3) invz (B,m)
     Kt (B,rows,m) dense predictor, pixidx (B,n) int32 rows of Kt (None = identity), dzdP (B,3)."""
@@ -180,4 +213,4 @@ def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uv
                      ref_slot=table.ref_slot, ref_aff=table.ref_aff, tgt_aff=table.tgt_aff, tgt_pose=table.tgt_pose,
                      tgt_img=table.tgt_img, pose_ref_inds=table.pose_ref_inds, pose_tgt_inds=table.pose_tgt_inds,
                      landmark_inds=table.landmark_inds, dzdP=dzdP, H=H, g=g, err_out=err_out, chunks=chunks,
-                     phase=phase, sigma_out=sigma_out)
+                     phase=phase, sigma_out=sigma_out, pix_range=pix_range, reduce_hists=reduce_hists, events=events)

@@ -32,8 +32,11 @@ DEFAULT_CFG = {
 
 
 class WindowBA:
-    def __init__(self, state, cfg=None, pix_dtype=torch.float32, window_full=True, dense_ref="hip"):
-        """state: dict as produced by como_amd.synth.make_window (plus K_mm_inv / L_mm / Knm_Kmminv)."""
+    def __init__(self, state, cfg=None, pix_dtype=torch.float32, window_full=True, dense_ref="hip", shard=None):
+        """state: dict as produced by como_amd.synth.make_window (plus K_mm_inv / L_mm / Knm_Kmminv).
+        shard: como_amd.dist.Shard for the one-process-per-GPU data-parallel mode (None = single GPU)."""
+        self.shard = shard
+        self.events = None
         self.cfg = cfg or DEFAULT_CFG
         self.dev = state["kf_poses"].device
         self.dt = torch.float64
@@ -98,9 +101,13 @@ class WindowBA:
         self.kf_pairs, self.one_way_pairs = [ref, tgt], [ow_kf, ow_t]
         self.table = photo.PairTable(ref + ow_kf, tgt + ow_t, [False] * len(ref) + [True] * len(ow_kf), B, self.kf_inds,
                                      self.recent_inds, self.landmark_inds, 3 * self.Himg * self.Wimg, 0, dev)
-        self.H = torch.zeros((self.dim, self.dim), device=dev, dtype=self.dt)
-        self.g = torch.zeros((self.dim,), device=dev, dtype=self.dt)
-        self.err = torch.zeros((), device=dev, dtype=torch.float64)
+        # H | g | err packed in ONE buffer: the multi-GPU exchange of the normal equations is a single all-reduce
+        D = self.dim
+        self.sys = torch.zeros((D * D + D + 1,), device=dev, dtype=self.dt)
+        self.H = self.sys[:D * D].view(D, D)
+        self.g = self.sys[D * D:D * D + D]
+        self.err = self.sys[D * D + D:].view(())
+        self.pix_range = self.shard.pixel_range(self.n) if self.shard is not None else None
         self.sigma = torch.zeros(2, device=dev, dtype=self.pix_dtype)
 
     # ---- one Gauss-Newton iteration ------------------------------------------------------------------------------
@@ -143,9 +150,7 @@ class WindowBA:
         self.median_depths = med.to(self.dt)
         self.pm, self.logzm = pm, logzm
         H, g = self.H, self.g
-        H.zero_()
-        g.zero_()
-        self.err.zero_()
+        self.sys.zero_()
         p = self.pix_dtype
         poses_all = torch.cat((self.kf_poses, self.recent_poses)).to(p).contiguous()
         aff_all = torch.cat((self.kf_aff_params, self.recent_aff_params)).reshape(-1, 2).to(p).contiguous()
@@ -153,11 +158,15 @@ class WindowBA:
                                     dPwn_dTwc=dPwn_dTwc, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx,
                                     invz=dlogzm_dzm[:, :, 0, 0].to(p).contiguous(), dzdP=dzm_dPwm[:, 0, 0, :].to(p).contiguous(),
                                     img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=H, g=g,
-                                    err_out=self.err, sigma_out=self.sigma)
+                                    err_out=self.err, sigma_out=self.sigma, pix_range=self.pix_range,
+                                    reduce_hists=(self.shard.all_reduce_sum if self.shard is not None else None),
+                                    events=self.events)
+        if self.shard is not None:
+            self.shard.all_reduce_sum(self.sys)          # normal equations of all shards: H | g | err in one collective
         kf_pose_inds, kf_aff_inds = self.kf_inds[:, :6], self.kf_inds[:, 6:]
         log_med = torch.log(self.median_depths[:, None, None])
         sg = self.cfg["sigmas"]
-        e = [self.err]
+        e = [self.err.clone()]
         e.append(gp_ml_cost(logzm, log_med, self.L_mm, dlogzm_dPwm, dlogzm_dTwc, self.landmark_inds, kf_pose_inds, H, g, sigma=1e0))
         e.append(log_depth_prior(logzm, log_med, dlogzm_dPwm, dlogzm_dTwc, self.obs_ref_mask, self.landmark_inds, kf_pose_inds,
                                  H, g, mode="first_mean", sigma_first=1e0, sigma_all=1e-0))

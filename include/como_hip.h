@@ -77,6 +77,8 @@ typedef struct como_ba_args {
   int chunks;                /* pixel chunks per pair (grid.x of the block kernel); partial records = b*chunks */
   int phase;                 /* bit mask: 1 setup+residual(+hist pass 0), 2<<(p-1) hist pass p>=1, 64 blocks, 128 reduce+assemble */
   int h_is_f64;              /* element type of Hmat / gvec: 1 = double, 0 = float */
+  int pix_begin, pix_end;    /* reference-pixel range [begin,end) of every pair handled by this call (multi-GPU shard);
+                                pix_end <= 0 means n.  ws_r / ws_valid / pj_out are then (b, end-begin). */
   const void* Pwn;           /* zmode 0: (slots,n,3) photo.py:86 ; zmode 1: planes (slots,3,n) */
   const void* vals;          /* (slots,n)     photo.py:84 */
   const void* dPwn_dTwc;     /* zmode 0: (slots,n,3,6) photo.py:90 ; zmode 1: planes (slots,18,n) */
@@ -105,8 +107,8 @@ typedef struct como_ba_args {
   void* sigma_out;           /* optional (2): {sigma_r, nvalid} in the entry point's element type */
   void* pj_out;              /* optional (b,n,2) projected pixel coordinates */
   double* pair_blocks_out;   /* optional (b, 3936): reduced raw per-pair records (tests) */
-  void* ws_r;                /* (b,n) residual workspace */
-  uint8_t* ws_valid;         /* (b,n) validity mask (an OUTPUT as well: bit-exact vs photo.py:15-21) */
+  void* ws_r;                /* (b,n_local) residual workspace */
+  uint8_t* ws_valid;         /* (b,n_local) validity mask (an OUTPUT as well: bit-exact vs photo.py:15-21) */
   void* ws_hists;            /* como_select_workspace_bytes() */
   void* ws_pair;             /* b*14 elements */
   void* ws_partials;         /* como_ba_partials_elems(b, chunks, m) elements */
