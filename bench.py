@@ -46,14 +46,13 @@ def cpu_baseline(args, state_cpu):
     """The oracle ("port") timed on the host cores: same algorithmic structure as the reference's CPU path
     (materialised Jacobian rows, batched Gram products, index_add assembly, cholesky_ex + cholesky_solve)."""
     from oracle import dense_ref as odr, photo_ba as oba
-    torch.set_num_threads(os.cpu_count() or 1)
     st = state_cpu
     K = st["intrinsics"][0]
     B = st["kf_poses"].shape[0]
     H, W = st["kf_img_and_grads"].shape[-2:]
     m = st["coords_m"].shape[1]
     Pb, ids = odr.batched_landmarks(st["P_m"], st["correspondence_mask"])
-    med0 = torch.full((B,), 2.5, dtype=torch.float64)
+    med0 = st["median_depth_init"].double()
     L = st["P_m"].shape[0]
     D = 8 * B + 3 * L
     kf_inds = torch.arange(8 * B).reshape(B, 8)
@@ -79,13 +78,23 @@ def cpu_baseline(args, state_cpu):
         t2 = time.perf_counter()
         return t1 - t0, t2 - t1
 
+    # pick the fastest thread count for these small-tensor ops (256 threads on a 256-core host is ~100x slower than 16)
+    best = None
+    for nt in sorted({8, 16, 32, min(64, os.cpu_count() or 8)}):
+        if nt > (os.cpu_count() or 8):
+            continue
+        torch.set_num_threads(nt)
+        a, b2 = one_iter()
+        if best is None or a + b2 < best[0]:
+            best = (a + b2, nt)
+    torch.set_num_threads(best[1])
     one_iter()
     reps = 3
     lin, sol = zip(*[one_iter() for _ in range(reps)])
     lin, sol = sorted(lin)[reps // 2], sorted(sol)[reps // 2]
     scale = (args.height * args.width) / cn.shape[1] if args.window == 1 else 16.0 / (args.window ** 2)
     t_iter = lin * scale + sol
-    return {"value": 1.0 / t_iter, "unit": "GN iters/s", "cores": os.cpu_count() or 1, "kind": "port",
+    return {"value": 1.0 / t_iter, "unit": "GN iters/s", "cores": best[1], "kind": "port",
             "sample": f"oracle (torch-CPU, float64) GN iteration on the window-4 sub-selection of the same window "
                       f"(n={cn.shape[1]} px/KF, {len(ref)} pairs, D={D}), median of {reps}: linearise {lin * 1e3:.0f} ms, "
                       f"solve {sol * 1e3:.0f} ms; linearisation time scaled x{scale:g} to this workload's pixel count"}

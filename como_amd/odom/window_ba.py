@@ -61,7 +61,7 @@ class WindowBA:
         self.img = state["kf_img_and_grads"].to(pix_dtype).contiguous()
         self.Kt = state["Knm_Kmminv"].to(pix_dtype).reshape(B, self.Himg * self.Wimg, self.m).contiguous()
         self.K_pix = self.intrinsics[0].to(pix_dtype).contiguous()
-        self.median_depths = torch.full((B,), 2.5, device=self.dev, dtype=self.dt)
+        self.median_depths = f64(state["median_depth_init"]) if "median_depth_init" in state else torch.full((B,), 1.0, device=self.dev, dtype=self.dt)
         self.window_full = window_full
         self.pose_anchor = self.kf_poses[0:1].clone() if "pose_anchor" not in state else f64(state["pose_anchor"])
         self.aff_anchor = torch.zeros((1, 2, 1), device=self.dev, dtype=self.dt)

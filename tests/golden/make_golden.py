@@ -113,7 +113,7 @@ def window_case(dtype, B, H, W, m, window, seed, with_recent, aff_noise=0.02, sa
     remap, paired = rsm.get_batch_remap_function(corr)
     landmark_ids, _ = paired
     point_inds = rlin.landmark_to_batched_3d_point_inds(landmark_ids, B)
-    median0 = torch.full((B,), 2.5, dtype=dtype)
+    median0 = st["median_depth_init"].clone()
     reinit = P_m.clone()
     pm, logzm, z_mask, dlogzm_dzm, dzm_dPwm, dzm_dTwc, dpm_dPwm, dpm_dTwc = rsm.setup_point_to_frame(
         P_m, kf_poses, remap, K, reinit_P=reinit, median_depths=median0)
@@ -145,8 +145,8 @@ def window_case(dtype, B, H, W, m, window, seed, with_recent, aff_noise=0.02, sa
             xi = torch.zeros(1, 6, dtype=torch.float64)
             xi[0, 1] = (t * np.pi / 180.0)
             Tr = synth.se3_exp(xi)[0]
-            Tr[0, 3] = 0.05 * t
-            Tr[1, 3] = 0.01 * t
+            Tr[0, 3] = 0.02 * t
+            Tr[1, 3] = 0.004 * t
             I, _ = scene.render(Tr, K64, H, W)
             rec_imgs.append(I)
             rec_T.append(Tr @ synth.se3_exp(1e-3 * torch.randn((1, 6), generator=g, dtype=torch.float64))[0])
@@ -206,7 +206,7 @@ def window_case(dtype, B, H, W, m, window, seed, with_recent, aff_noise=0.02, sa
     e_px = pixel_prior_cost(pm, st["pm_first_obs"], dpm_dPwm, dpm_dTwc, st["obs_ref_mask"], landmark_inds, kf_pose_inds,
                             Hm, gv, mode="first", pixel_sigma_first=1e-2, pixel_sigma_all=3.33e-1)
     out.update({"H_px": Hm.clone(), "g_px": gv.clone()})
-    pose_anchor = st["poses_gt"][0:1].clone()
+    pose_anchor = st["pose_anchor"].clone()
     aff_anchor = torch.zeros((1, 2, 1), dtype=dtype)
     e1 = linearize_pose_prior(kf_poses[0:1], pose_anchor, Hm, gv, [kf_pose_inds[0, 0], kf_pose_inds[0, -1] + 1], sigma=1e-6)
     e2 = linearize_scalar_prior(kf_aff[0, 0:1, :], aff_anchor[0, 0:1, :], Hm, gv,
@@ -215,7 +215,7 @@ def window_case(dtype, B, H, W, m, window, seed, with_recent, aff_noise=0.02, sa
                                 [kf_aff_inds[0, 1], kf_aff_inds[0, 1] + 1], sigma=1e-4)
     lm_flat = torch.arange(3 * L).reshape(L, 3) + lm_start
     fix = corr[0, :]
-    P_anchor = st["P_gt"][fix, :]
+    P_anchor = st["P_anchor"]
     out.update({"pose_anchor": pose_anchor, "aff_anchor": aff_anchor, "P_anchor": P_anchor, "fix_mask": fix,
                 "obs_ref_mask": st["obs_ref_mask"], "pm_first_obs": st["pm_first_obs"], "window_full": window_full})
     if window_full:
