@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="do not capture the iteration into a hipGraph")
     args = ap.parse_args()
 
     shard, device = cdist.init_from_env()
@@ -131,16 +132,25 @@ def main():
 
     for _ in range(args.warmup):
         wb.iterate()
-    wb.events = {}                                   # HIP events around the dominant kernel, inside the timed region
+    graphed = (not args.eager) and wb.capture()
+    if not graphed and not args.eager and shard.rank == 0:
+        print("hipGraph capture failed:", getattr(wb, "capture_error", "multi-GPU path is eager"), file=sys.stderr)
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wb.iterate()
+        wb.step()
     torch.cuda.synchronize()
     shard.barrier()
     elapsed = shard.max_scalar(time.perf_counter() - t0, device)
 
+    # roofline probe: the dominant kernel's duration from HIP events on the launch stream (events cannot sit inside a
+    # captured graph, so the same kernel on the same data is timed in eager iterations right after the timed region;
+    # profiles/ holds the rocprofv3 --kernel-trace --stats summary of this command for cross-checking)
+    wb.events = {}
+    for _ in range(5):
+        wb.iterate()
+    torch.cuda.synchronize()
     ms_step = elapsed / args.steps * 1e3
     ev = wb.events.get("blocks", [])
     blk_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
@@ -163,7 +173,7 @@ def main():
                                    f"n={wb.n} reference px/KF (window={args.window}), m=64, D={wb.dim}; one step = full GN "
                                    f"iteration (scaffold, dense ref, photometric system, priors, Cholesky solve, update)",
                        "pixel_pairs_per_iter": npairs * wb.n, "system_dim": wb.dim, "pix_dtype": args.dtype,
-                       "system_dtype": "f64", "parallelism": f"dp{args.gpus} (reference-pixel shards of every pair)"},
+                       "system_dtype": "f64", "hip_graph": bool(graphed), "parallelism": f"dp{args.gpus} (reference-pixel shards of every pair)"},
             "roofline": {"bound": "hbm", "kernel": "ba_blocks_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": blk_ms,
                          "algorithmic_bytes_per_launch": pixel_pairs_rank * bytes_per},

@@ -40,10 +40,33 @@ def landmark_to_batched_3d_point_inds(landmark_inds, num_kf):
     return p + torch.arange(3, device=lm.device).repeat(lm.shape[1])[None, :]
 
 
+_chol_ws = {}
+
+
 def solve_system(H, g):
-    L, info = torch.linalg.cholesky_ex(H, upper=False, check_errors=False)
+    """delta (D,1) = H^-1 g by dense Cholesky (reference :101-112).  float64 systems on the GPU run the blocked HIP
+    factorisation of csrc/chol.hip (graph-capturable, ~10x hipSOLVER at D = 760); float32 systems (the reference-signature
+    path with a float32 H) go through torch.linalg.  `solve_system.last_info` holds the factorisation status (device int)."""
+    if H.is_cuda and H.dtype == torch.float64:
+        from como_amd import _lib
+        L = _lib.lib()
+        D = H.shape[0]
+        key = (str(H.device), D)
+        ws = _chol_ws.get(key)
+        if ws is None:
+            ws = (torch.empty(L.como_chol_workspace_bytes(D) // 8, dtype=torch.float64, device=H.device),
+                  torch.zeros(1, dtype=torch.int32, device=H.device))
+            _chol_ws[key] = ws
+        delta = torch.empty((D, 1), dtype=torch.float64, device=H.device)
+        Hc = H if H.is_contiguous() else H.contiguous()
+        rc = L.como_chol_solve_f64(Hc.data_ptr(), g.contiguous().data_ptr(), delta.data_ptr(), ws[0].data_ptr(), D,
+                                   ws[1].data_ptr(), _lib.stream_ptr(H.device))
+        _lib.check(rc, "como_chol_solve")
+        solve_system.last_info = ws[1]
+        return delta
+    Lf, info = torch.linalg.cholesky_ex(H, upper=False, check_errors=False)
     solve_system.last_info = info
-    return torch.cholesky_solve(g[:, None], L, upper=False)
+    return torch.cholesky_solve(g[:, None], Lf, upper=False)
 
 
 def update_vars(delta, kf_poses, kf_aff_params, kf_inds, recent_poses, recent_aff_params, recent_inds, P,

@@ -4,11 +4,26 @@ import torch
 from como_amd.odom.factors.prior_accumulate import accumulate, logz_chain
 
 
-def gp_ml_cost(logzm, log_median_depths, L_mm, dlogzm_dPw, dlogzm_dTwc, p_inds_batched, pose_inds_batched, H, g, sigma):
-    """r = L_mm^-1 (logz_m - log median depth), information 1/sigma^2 (gp_priors.py:7-81)."""
+_linv_cache = {}
+
+
+def _linv(L_mm):
+    """L_mm^-1 (B,m,m).  L_mm changes only when a keyframe is added, so the triangular inverse is cached per tensor
+    (data pointer + version) instead of being recomputed every GN iteration as the reference does (gp_priors.py:22-23)."""
+    key = (L_mm.data_ptr(), L_mm._version, tuple(L_mm.shape))
+    hit = _linv_cache.get("k")
+    if hit is not None and hit[0] == key:
+        return hit[1]
     B, m, _ = L_mm.shape
     eye = torch.eye(m, dtype=L_mm.dtype, device=L_mm.device).expand(B, m, m)
     Linv = torch.linalg.solve_triangular(L_mm, eye, upper=False)
+    _linv_cache["k"] = (key, Linv)
+    return Linv
+
+
+def gp_ml_cost(logzm, log_median_depths, L_mm, dlogzm_dPw, dlogzm_dTwc, p_inds_batched, pose_inds_batched, H, g, sigma):
+    """r = L_mm^-1 (logz_m - log median depth), information 1/sigma^2 (gp_priors.py:7-81)."""
+    Linv = _linv(L_mm)
     r = (Linv @ (logzm - log_median_depths))[..., 0]
     J_T, J_P = logz_chain(Linv, dlogzm_dPw, dlogzm_dTwc)
     return accumulate(H, g, pose_inds_batched, p_inds_batched, J_T, J_P, r, torch.full_like(r, 1.0 / sigma**2))

@@ -91,6 +91,10 @@ class WindowBA:
         self.lm_start = 8 * B + 8 * nrec
         self.landmark_inds = self.point_inds + self.lm_start
         self.landmark_inds_flat = torch.arange(3 * L, device=dev).reshape(L, 3) + self.lm_start
+        # index lists of the oldest keyframe's landmarks (their anchors, Mapping.py:884-898): precomputed -- boolean-mask
+        # indexing inside the iteration would synchronise with the host (and cannot be captured in a hipGraph)
+        self.fix_idx = torch.nonzero(self.correspondence_mask[0])[:, 0]
+        self.fix_inds_flat = self.landmark_inds_flat[self.fix_idx].flatten().contiguous()
         first_obs = torch.argmax(self.correspondence_mask.int(), dim=0)
         fom = torch.zeros_like(self.correspondence_mask)
         fom[first_obs, torch.arange(L, device=dev)] = True
@@ -130,7 +134,7 @@ class WindowBA:
         # landmarks re-initialised in their first-observation frame are moved for good (Mapping.py:645-648)
         flag = torch.zeros((self.P_m.shape[0], 1), device=self.dev, dtype=self.dt)
         flag.index_add_(0, lm_ids.reshape(-1), (fom & z_mask).reshape(-1, 1).to(self.dt))
-        self.P_m = torch.where(flag > 0, init_Pm, self.P_m)
+        self.P_m.copy_(torch.where(flag > 0, init_Pm, self.P_m))
         return out
 
     def dense_reference(self, logzm, dlogzm_dTwc):
@@ -147,7 +151,7 @@ class WindowBA:
         dlogzm_dTwc = dlogzm_dzm @ dzm_dTwc
         dlogzm_dPwm = dlogzm_dzm @ dzm_dPwm
         Pwn, dPwn_dTwc, uvec, med, logzn = self.dense_reference(logzm, dlogzm_dTwc)
-        self.median_depths = med.to(self.dt)
+        self.median_depths.copy_(med)
         self.pm, self.logzm = pm, logzm
         H, g = self.H, self.g
         self.sys.zero_()
@@ -176,9 +180,8 @@ class WindowBA:
         e.append(linearize_scalar_prior(self.kf_aff_params[0, 0:1, :], self.aff_anchor[0, 0:1, :], H, g, [6, 7], sigma=sg["scale_prior"]))
         e.append(linearize_scalar_prior(self.kf_aff_params[0, 1:2, :], self.aff_anchor[0, 1:2, :], H, g, [7, 8], sigma=sg["scale_prior"]))
         if self.window_full:
-            fix = self.correspondence_mask[0]
-            e.append(linearize_multi_scalar_prior(self.P_m[fix].flatten(), self.P_m_anchors.flatten(), H, g,
-                                                  self.landmark_inds_flat[fix].flatten(), sigma=sg["scale_prior"]))
+            e.append(linearize_multi_scalar_prior(self.P_m[self.fix_idx].flatten(), self.P_m_anchors.flatten(), H, g,
+                                                  self.fix_inds_flat, sigma=sg["scale_prior"]))
         else:
             e.append(mean_log_depth_cost(logzm[0:1], self.Kt[0:1].to(self.dt), self.init_scale_anchor, dlogzm_dPwm[0:1],
                                          dlogzm_dTwc[0:1], self.landmark_inds[0:1], kf_pose_inds[0:1], H, g,
@@ -187,10 +190,59 @@ class WindowBA:
         return H, g
 
     def iterate(self):
+        """One GN iteration, eager.  State tensors are updated IN PLACE (fixed addresses -> capturable)."""
         H, g = self.linearize()
-        delta = lin_sys.solve_system(H, g)
-        (self.kf_poses, self.kf_aff_params, self.recent_poses, self.recent_aff_params, self.P_m) = lin_sys.update_vars(
-            delta, self.kf_poses, self.kf_aff_params, self.kf_inds, self.recent_poses, self.recent_aff_params, self.recent_inds,
-            self.P_m, self.lm_start)
+        delta = self.solve(H, g)
+        kp, ka, rp, ra, Pn = lin_sys.update_vars(delta, self.kf_poses, self.kf_aff_params, self.kf_inds, self.recent_poses,
+                                                 self.recent_aff_params, self.recent_inds, self.P_m, self.lm_start)
+        self.kf_poses.copy_(kp)
+        self.kf_aff_params.copy_(ka)
+        self.P_m.copy_(Pn)
+        if self.recent_poses.shape[0] > 0:
+            self.recent_poses.copy_(rp)
+            self.recent_aff_params.copy_(ra)
         self.delta = delta
         return delta
+
+    def solve(self, H, g):
+        return lin_sys.solve_system(H, g)
+
+    # ---- hipGraph: the iteration is ~200 small launches; replaying a captured graph removes the host from the loop
+    def capture(self, warmup=3):
+        """Capture one GN iteration into a hipGraph (torch.cuda.CUDAGraph).  Returns True on success; on failure the
+        object stays usable in eager mode."""
+        if self.shard is not None:
+            return False                      # collectives between kernels: keep the multi-GPU path eager
+        self.graph = None
+        try:
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self.iterate()
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            ev = self.events
+            self.events = None
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.iterate()
+            self.events = ev
+            self.graph = g
+            return True
+        except Exception as e:   # noqa: BLE001
+            self.graph = None
+            import traceback
+            self.capture_error = traceback.format_exc()[-1500:]
+            try:
+                torch.cuda.synchronize(self.dev)
+            except Exception:   # noqa: BLE001
+                pass
+            return False
+
+    def step(self):
+        """One GN iteration: graph replay when captured, eager otherwise."""
+        if getattr(self, "graph", None) is not None:
+            self.graph.replay()
+            return self.delta
+        return self.iterate()

@@ -168,6 +168,15 @@ int como_ktilde_f32(const float* cov, int Hc, int Wc, const float* xm, const flo
 int como_ktilde_f64(const double* cov, int Hc, int Wc, const double* xm, const double* Em, const double* Kinv,
                     double scale, int B, int Hp, int Wp, int m, double* out, como_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Dense SPD solve delta = H^-1 g, float64 (python path: backend/linear_system.py:101-112 solve_system).
+ * H (D,D) row-major (lower triangle read), g (D), delta (D) out, workspace of como_chol_workspace_bytes(D) bytes,
+ * info (1 int, device): 0 = ok, i > 0 = leading minor i not positive definite (cholesky_ex's info, reported instead
+ * of being ignored as the reference does). */
+long como_chol_workspace_bytes(int D);
+int como_chol_solve_f64(const double* H, const double* g, double* delta, void* workspace, int D, int* info,
+                        como_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

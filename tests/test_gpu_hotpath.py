@@ -374,3 +374,24 @@ def test_window_iterate_vs_golden(pix):
 def lin_info():
     import como_amd.odom.backend.linear_system as ls
     return ls.solve_system.last_info
+
+
+@pytest.mark.parametrize("D", [5, 63, 64, 65, 200, 760, 1500])
+def test_cholesky_solve(D):
+    import como_amd.odom.backend.linear_system as ls
+    g0 = torch.Generator().manual_seed(D)
+    A = torch.randn((D, D + 8), generator=g0, dtype=torch.float64)
+    H = A @ A.T + 1e-3 * torch.eye(D, dtype=torch.float64)
+    H[0, 0] += 1e12                                      # the pose-anchor scale of the real system
+    g = torch.randn(D, generator=g0, dtype=torch.float64)
+    ref = torch.cholesky_solve(g[:, None], torch.linalg.cholesky(H))
+    d = ls.solve_system(dev(H), dev(g))
+    resid = (H @ d.cpu() - g[:, None]).abs().max() / g.abs().max()
+    report("chol", D=D, rel=rel_err(d, ref), resid=resid, info=int(ls.solve_system.last_info))
+    assert int(ls.solve_system.last_info) == 0
+    assert rel_err(d, ref) < 1e-8
+    Hbad = H.clone()
+    k = D // 2
+    Hbad[k, k] = -1.0
+    ls.solve_system(dev(Hbad), dev(g))
+    assert int(ls.solve_system.last_info) == k + 1        # first non-positive pivot, 1-based (cholesky_ex convention)
