@@ -1,0 +1,141 @@
+"""The N > 1 protocol of como_amd/dist.py with world_size 2 on gloo (CPU): pixel-range shards, the distributed EXACT
+median (per-digit histogram all-reduce) and the single all-reduce of the packed normal equations.
+
+The HIP kernels cannot run here; each rank emulates its kernel phases with the CPU oracle / numpy on ITS pixel range and
+drives the real `Shard` collectives -- the result must equal the single-process result."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.conftest import load_golden
+
+SHIFTS = {np.float32: (21, 10, 0), np.float64: (53, 42, 31, 20, 10, 0)}
+BITS = {np.float32: (11, 11, 10), np.float64: (11, 11, 11, 11, 10, 10)}
+
+
+def _keys(r):
+    a = np.abs(r)
+    return a.view(np.uint32) if a.dtype == np.float32 else a.view(np.uint64)
+
+
+def _resolve(hists, npass, shifts):
+    """Host mirror of csrc/select.cuh sel_resolve: (prefix, k_rem, nvalid) from finished digit histograms."""
+    prefix, k = 0, 0
+    nv = int(hists[0].sum())
+    for p in range(npass):
+        h = hists[p]
+        if p == 0:
+            k = (nv - 1) // 2 if nv > 0 else 0
+        c = np.cumsum(h)
+        b = int(np.searchsorted(c, k, side="right"))
+        prefix |= b << shifts[p]
+        k -= int(c[b - 1]) if b > 0 else 0
+    return prefix, k, nv
+
+
+def _distributed_median(shard, r_local, valid_local):
+    dt = r_local.dtype.type
+    shifts, bits = SHIFTS[dt], BITS[dt]
+    keys = _keys(r_local)[valid_local].astype(np.uint64)
+    hists = [None] * len(shifts)
+    for p in range(len(shifts)):
+        prefix, _, _ = _resolve(hists, p, shifts) if p else (0, 0, 0)
+        sel = keys
+        if p > 0:
+            sh = shifts[p - 1]
+            sel = keys[(keys >> np.uint64(sh)) == np.uint64(prefix >> sh)]
+        digit = ((sel >> np.uint64(shifts[p])) & np.uint64((1 << bits[p]) - 1)).astype(np.int64)
+        h = torch.from_numpy(np.bincount(digit, minlength=2048).astype(np.int32))
+        shard.all_reduce_sum(h)                       # the collective of como_amd.dist
+        hists[p] = h.numpy().astype(np.int64)
+    prefix, _, nv = _resolve(hists, len(shifts), shifts)
+    arr = np.array([prefix], dtype=np.uint32 if dt == np.float32 else np.uint64)
+    return arr.view(dt)[0], nv
+
+
+def _worker(rank, world, port, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": str(rank)})
+    from como_amd import dist as cdist
+    from oracle import photo_ba
+    shard, device = cdist.init_from_env(backend="gloo")
+    try:
+        out = {}
+        # 1. distributed exact median on random data, float32 and float64, with ties
+        for dt in (np.float32, np.float64):
+            g = np.random.default_rng(5)
+            n = 100_003
+            r = (g.standard_normal(n) * np.exp(2 * g.standard_normal(n))).astype(dt)
+            r[::7] = dt(0.125)
+            valid = g.random(n) < 0.8
+            b, e = shard.pixel_range(n)
+            med, nv = _distributed_median(shard, r[b:e], valid[b:e])
+            ref = torch.median(torch.from_numpy(np.abs(r[valid]))).item()
+            out[f"median_{dt.__name__}"] = (float(med), ref, nv, int(valid.sum()))
+        # 2. sharded normal equations of the golden window: each rank linearises its pixel range, ONE all-reduce
+        G = load_golden("ba_window_f64.npz")
+        rid, tid = G["kf_ref_ids"].long(), G["kf_target_ids"].long()
+        n = G["Pwn"].shape[1]
+        b, e = shard.pixel_range(n)
+        sl = slice(b, e)
+        r, valid, J = photo_ba.pair_rows(G["vals_n"][rid][:, sl], G["kf_aff_params"][rid], G["Pwn"][rid][:, sl], G["kf_poses"][tid],
+                                         G["kf_aff_params"][tid], G["kf_img_and_grads"][tid], G["dPwn_dTwc"][rid][:, sl],
+                                         G["dPwn_dzm"][rid][:, sl], G["intrinsics"][0])
+        med, nv = _distributed_median(shard, r.numpy().reshape(-1), valid.numpy().reshape(-1))
+        sigma = torch.tensor(1.4826, dtype=torch.float64) * float(med)
+        Gm, gv, err = photo_ba.pair_blocks(r, valid, J, sigma)
+        D = G["H_photo"].shape[0]
+        sysbuf = torch.zeros(D * D + D + 1, dtype=torch.float64)
+        H, gg = sysbuf[:D * D].view(D, D), sysbuf[D * D:D * D + D]
+        photo_ba.assemble(Gm, gv, G["dzm_dPwm"][rid], G["kf_inds"][rid], G["kf_inds"][tid], G["landmark_inds"][rid], H, gg)
+        sysbuf[-1] = err
+        shard.all_reduce_sum(sysbuf)
+        out["sigma"] = (float(sigma), float(G["sigma_r"]))
+        out["H_rel"] = float((H - G["H_photo"]).abs().max() / G["H_photo"].abs().max())
+        out["g_rel"] = float((gg - G["g_photo"]).abs().max() / G["g_photo"].abs().max())
+        out["err"] = (float(sysbuf[-1]), float(G["photo_err"]))
+        out["range"] = (b, e, n)
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pixel_ranges_partition():
+    from como_amd.dist import Shard
+    for n in (64, 100, 19_200, 307_200, 12_345):
+        for world in (1, 2, 3, 4, 8):
+            cover = np.zeros(n, dtype=int)
+            for r in range(world):
+                b, e = Shard(r, world).pixel_range(n)
+                assert 0 <= b < e <= n
+                if not (e - b == 1 and cover[b] == 1):       # degenerate "idle rank" range re-reads one pixel: excluded below
+                    cover[b:e] += 1
+            assert cover.min() >= 1
+            if n >= 64 * world:
+                assert cover.max() == 1 and cover.sum() == n
+
+
+def test_two_rank_protocol_matches_single_process():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in (0, 1):
+        o = res[rank]
+        for k in ("median_float32", "median_float64"):
+            got, ref, nv, nvalid = o[k]
+            assert got == ref and nv == nvalid               # exact, on every rank
+        assert o["sigma"][0] == pytest.approx(o["sigma"][1], rel=1e-14)
+        assert o["H_rel"] < 1e-12 and o["g_rel"] < 1e-12
+        assert o["err"][0] == pytest.approx(o["err"][1], rel=1e-12)
+    assert res[0]["range"][1] == res[1]["range"][0]          # contiguous shards

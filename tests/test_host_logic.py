@@ -1,0 +1,101 @@
+"""Host-side logic of the product on CPU (no kernels): prior factors, pair graph, landmark bookkeeping, SE3 helpers,
+drop-in registration -- against the golden vectors captured from the reference."""
+import sys
+
+import torch
+
+from tests.conftest import load_golden
+
+
+def rel(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item()
+
+
+def test_prior_factors_match_reference():
+    from como_amd.odom.factors.depth_prior import log_depth_prior
+    from como_amd.odom.factors.gp_priors import gp_ml_cost, mean_log_depth_cost
+    from como_amd.odom.factors.pixel_prior import pixel_prior_cost
+    from como_amd.odom.factors.pose_prior_factors import linearize_pose_prior
+    from como_amd.odom.factors.scalar_prior_factors import linearize_multi_scalar_prior, linearize_scalar_prior
+    for name in ("ba_window_f64.npz", "ba_window_recent_f64.npz"):
+        G = load_golden(name)
+        H, g = G["H_photo"].clone(), G["g_photo"].clone()
+        kpi = G["kf_inds"][:, :6]
+        lmk = G["landmark_inds"]
+        dP, dT = G["dlogzm_dzm"] @ G["dzm_dPwm"], G["dlogzm_dzm"] @ G["dzm_dTwc"]
+        lm = torch.log(G["median_depths"])[:, None, None]
+        e = [gp_ml_cost(G["logzm"], lm, G["L_mm"], dP, dT, lmk, kpi, H, g, 1.0)]
+        assert rel(H, G["H_gp"]) < 1e-12 and rel(g, G["g_gp"]) < 1e-12
+        e.append(log_depth_prior(G["logzm"], lm, dP, dT, G["obs_ref_mask"], lmk, kpi, H, g, "first_mean", 1.0, 1.0))
+        assert rel(H, G["H_ld"]) < 1e-12 and rel(g, G["g_ld"]) < 1e-12
+        e.append(pixel_prior_cost(G["pm"], G["pm_first_obs"], G["dpm_dPwm"], G["dpm_dTwc"], G["obs_ref_mask"], lmk, kpi, H, g, "first",
+                                  1e-2, 3.33e-1))
+        assert rel(H, G["H_px"]) < 1e-12 and rel(g, G["g_px"]) < 1e-12
+        e.append(linearize_pose_prior(G["kf_poses"][0:1], G["pose_anchor"], H, g, [0, 6], 1e-6))
+        e.append(linearize_scalar_prior(G["kf_aff_params"][0, 0:1, :], G["aff_anchor"][0, 0:1, :], H, g, [6, 7], 1e-4))
+        e.append(linearize_scalar_prior(G["kf_aff_params"][0, 1:2, :], G["aff_anchor"][0, 1:2, :], H, g, [7, 8], 1e-4))
+        L = G["P_m"].shape[0]
+        if bool(G["window_full"]):
+            fix = G["fix_mask"]
+            inds = (torch.arange(3 * L).reshape(L, 3) + int(G["lm_start"]))[fix].reshape(-1)
+            e.append(linearize_multi_scalar_prior(G["P_m"][fix].reshape(-1), G["P_anchor"].reshape(-1), H, g, inds, 1e-4))
+            assert rel(H, G["H_full"]) < 1e-12 and rel(g, G["g_full"]) < 1e-12
+            assert rel(torch.stack([x.reshape(()) for x in e]).double(), G["prior_err"]) < 1e-9
+
+
+def test_pair_graph_and_landmark_indexing():
+    from como_amd.odom.backend.graph_pair_construction import setup_photometric_pairs
+    import como_amd.odom.backend.linear_system as ls
+    import como_amd.odom.backend.sparse_map as smap
+    G = load_golden("ba_window_recent_f64.npz")
+    cfg = {"radius_thresh": 0.0, "degrees_thresh": 0.0}
+    ref, tgt, owk, owt = setup_photometric_pairs(G["kf_poses"], G["recent_poses"], G["kf_timestamps"], G["recent_timestamps"],
+                                                 G["median_depths"], cfg)
+    assert ref == G["kf_ref_ids"].tolist() and tgt == G["kf_target_ids"].tolist()
+    assert owk == G["ow_kf_ids"].tolist() and owt == G["ow_target_ids"].tolist()
+    remap, paired = smap.get_batch_remap_function(G["correspondence_mask"])
+    pi = ls.landmark_to_batched_3d_point_inds(paired[0], G["kf_poses"].shape[0])
+    assert torch.equal(pi, G["point_inds"])
+    out = smap.setup_point_to_frame(G["P_m"], G["kf_poses"], remap, G["intrinsics"], G["P_m"], G["median_depths_in"])
+    assert torch.equal(out[0], G["pm"]) and torch.equal(out[1], G["logzm"])           # bit-exact (feeds masks downstream)
+    assert rel(out[7], G["dpm_dTwc"]) < 1e-12 and rel(out[5], G["dzm_dTwc"]) < 1e-12
+    cn, _ = smap.subselect_pixels(G["kf_img_and_grads"], 2)
+    assert torch.equal(cn, G["coords_n"])
+    kp, ka, rp, ra, Pn = ls.update_vars(G["delta"], G["kf_poses"], G["kf_aff_params"], G["kf_inds"], G["recent_poses"],
+                                        G["recent_aff_params"], G["recent_inds"], G["P_m"], int(G["lm_start"]))
+    assert rel(kp, G["kf_poses_new"]) < 1e-12 and rel(rp, G["recent_poses_new"]) < 1e-12 and rel(Pn, G["P_new"]) < 1e-12
+
+
+def test_setup_test_points_mirror():
+    import como_amd.odom.backend.sparse_map as smap
+    G = load_golden("ba_window_f64.npz")
+    cn = G["coords_n"]
+    B = cn.shape[0]
+    bi = torch.arange(B)[:, None].expand(-1, cn.shape[1])
+    Kt_rows = G["Knm_Kmminv"][bi, cn[..., 0], cn[..., 1], :]
+    Pw, dT, dz, med, _, logzn = smap.setup_test_points(G["pm"], G["logzm"], G["kf_poses"], Kt_rows, cn, G["intrinsics"],
+                                                       G["dlogzm_dzm"] @ G["dzm_dTwc"], G["dlogzm_dzm"])
+    assert torch.equal(Pw, G["Pwn"]) and torch.equal(med, G["median_depths"])
+    assert rel(dT, G["dPwn_dTwc"]) < 1e-12 and rel(dz, G["dPwn_dzm"]) < 1e-12
+
+
+def test_dropin_registration():
+    import como_amd
+    names = como_amd.install_dropin()
+    try:
+        import como_backends                                  # noqa: F401  resolves to como_amd.como_backends
+        from como.odom.backend.photo import create_photo_system, batch_photo_cost   # noqa: F401
+        from como.odom.frontend.photo_tracking import photo_tracking_pyr             # noqa: F401
+        assert sys.modules["como_backends"].__name__ == "como_amd.como_backends"
+    finally:
+        for n in names:
+            sys.modules.pop(n, None)
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    import pytest
+    import como_amd.como_backends as cb
+    x = torch.zeros(1, 2, 2)
+    E = torch.eye(2).expand(1, 2, 2, 2).contiguous()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cb.cross_covariance(x, E, x, E, 1.0)
