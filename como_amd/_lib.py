@@ -32,6 +32,19 @@ class BAArgs(ctypes.Structure):
     ]
 
 
+class WinArgs(ctypes.Structure):
+    """Mirror of `struct como_win_args` (include/como_hip.h) -- field order must match."""
+    _fields_ = ([(n, c_int) for n in ("B", "F", "m", "L", "nfix", "pix_is_f64", "median_new_is_f32", "median_new_stride")]
+                + [("D", c_long)]
+                + [(n, c_void_p) for n in ("poses", "aff", "K", "median", "pm_first", "Kmm_inv", "pose_anchor", "aff_anchor",
+                                          "P_anchor", "P_m", "lm_ids", "first_frame", "first_slot", "fix_lm", "first_mask",
+                                          "pose_inds", "landmark_inds", "fix_inds", "median_new", "pm", "logzm", "invz", "dzdP",
+                                          "dlogz_dT", "dlogz_dP", "dp_dP", "dp_dT", "init_Pm", "reinit_flag", "px_logzm",
+                                          "px_invz", "px_dzdP", "px_dlogz_dT", "px_poses", "px_aff")]
+                + [(n, c_double) for n in ("s_gp", "s_ld", "s_px", "s_pose", "s_aff", "s_lm")]
+                + [(n, c_void_p) for n in ("H", "g", "err")])
+
+
 # name -> (restype, argtypes); every symbol include/como_hip.h declares
 SIGNATURES = {
     "como_abi_version": (c_int, []),
@@ -62,6 +75,9 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "como_chol_workspace_bytes": (c_long, [c_int]),
     "como_chol_solve_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "como_win_scaffold": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
+    "como_win_priors": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
+    "como_win_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
 }
 
 

@@ -1,0 +1,410 @@
+// Fused O(B*m) bookkeeping of one window-BA Gauss-Newton iteration.
+//
+// In the reference these are ~400 tiny PyTorch launches per iteration (landmark projection, prior factors, variable
+// update); here they are three kernels, so the whole iteration is ~45 launches and stays graph-capturable:
+//
+//   win_scaffold : per keyframe b, lane j = inducing point j: landmark -> camera frame (exact op order), re-init test,
+//                  z, log z, pixel p and the Jacobians the priors and the dense-reference kernel need.
+//                  reference: como/odom/backend/sparse_map.py:18-60 (project_landmarks), Mapping.py:603-659.
+//   win_priors   : all prior factors of Mapping.iterate (Mapping.py:809-917) accumulated into H, g:
+//                  GP marginal-likelihood prior (factors/gp_priors.py:7-81), log-depth prior mode "first_mean"
+//                  (depth_prior.py:7-141), pixel prior mode "first" (pixel_prior.py:6-130), pose anchor
+//                  (pose_prior_factors.py:5-19), affine anchors and fixed-landmark anchors / mean-log-depth prior
+//                  (scalar_prior_factors.py:4-34, gp_priors.py:84-150).
+//                  The log-depth-space priors share the residual r0 = logz_m - log(median), so they collapse to
+//                  M = K_mm^-1/s_gp^2 + diag(first/s_ld^2), w = M r0, chained once through dlogz/dT, dlogz/dP.
+//   win_update   : T <- T Exp(delta), affine += delta, P += delta (linear_system.py:115-152).
+#include "common.cuh"
+#include "../../include/como_hip.h"
+
+namespace como {
+
+__device__ inline void se3_exp_f64(const double* xi, double* Tm) {
+  const double wx = xi[0], wy = xi[1], wz = xi[2];
+  const double th2 = wx * wx + wy * wy + wz * wz;
+  double a, b, c;
+  if (th2 < 1e-12) {
+    a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0;
+  } else {
+    const double th = sqrt(th2);
+    a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = (th - sin(th)) / (th2 * th);
+  }
+  const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+  double W2[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) W2[i * 3 + j] = W[i * 3] * W[j] + W[i * 3 + 1] * W[3 + j] + W[i * 3 + 2] * W[6 + j];
+  for (int i = 0; i < 3; ++i) {
+    double t = 0;
+    for (int j = 0; j < 3; ++j) {
+      const double e = (i == j) ? 1.0 : 0.0;
+      Tm[i * 4 + j] = e + a * W[i * 3 + j] + b * W2[i * 3 + j];
+      t += (e + b * W[i * 3 + j] + c * W2[i * 3 + j]) * xi[3 + j];
+    }
+    Tm[i * 4 + 3] = t;
+  }
+  Tm[12] = Tm[13] = Tm[14] = 0.0;
+  Tm[15] = 1.0;
+}
+
+struct ScaffoldOut {
+  double* pm;         // (B,m,2)
+  double* logzm;      // (B,m)
+  double* invz;       // (B,m)      dlogz/dz = 1/z
+  double* dzdP;       // (B,3)      R_cw[2,:]
+  double* dlogz_dT;   // (B,m,6)
+  double* dlogz_dP;   // (B,m,3)
+  double* dp_dP;      // (B,m,6)    2x3
+  double* dp_dT;      // (B,m,12)   2x6
+  double* init_Pm;    // (L,3)      re-initialisation point of every landmark
+  int* reinit_flag;   // (L)        1 if the landmark's first observer re-initialised it
+};
+
+// pix-dtype mirrors for the per-pixel kernels
+template <typename TP>
+struct ScaffoldPix {
+  TP* logzm;      // (B,m)
+  TP* invz;       // (B,m)
+  TP* dzdP;       // (B,3)
+  TP* dlogz_dT;   // (B,m,6)
+  TP* poses;      // (F,16)
+  TP* aff;        // (F,2)
+};
+
+template <typename TP>
+__global__ __launch_bounds__(64) void win_scaffold_kernel(
+    const double* __restrict__ poses, const double* __restrict__ aff, int F, const double* __restrict__ P_m,
+    const int* __restrict__ lm_ids, const int* __restrict__ first_frame, const int* __restrict__ first_slot,
+    const double* __restrict__ Kmat, const double* __restrict__ median, const double* __restrict__ pm_first, int B, int m,
+    ScaffoldOut o, ScaffoldPix<TP> px) {
+  const int b = blockIdx.x, j = threadIdx.x;
+  // pix-dtype copies of ALL frame poses / affine params (keyframes then recent frames)
+  for (int e = b * 64 + j; e < F * 16; e += gridDim.x * 64) px.poses[e] = (TP)poses[e];
+  for (int e = b * 64 + j; e < F * 2; e += gridDim.x * 64) px.aff[e] = (TP)aff[e];
+  if (b >= B || j >= m) return;
+  double Tcw[12];
+  invert_pose34(poses + 16 * (long)b, Tcw);                         // sparse_map.py:20, lie_algebra.py:83-95
+  const int l = lm_ids[(long)b * m + j];
+  // re-initialisation point: back-projection from the landmark's FIRST observer at that frame's median depth
+  const int fb = first_frame[l], fj = first_slot[l];
+  const double fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  double iw[3];
+  {
+    const double* pf = pm_first + ((long)fb * m + fj) * 2;
+    const double zi = median[fb];
+    const double rx = (pf[0] - cx) / fx, ry = (pf[1] - cy) / fy;       // camera.py:43-54
+    double Mw[12];
+    const double* Tw = poses + 16 * (long)fb;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Mw[k] = Tw[k];
+    rigid_apply(Mw, zi * rx, zi * ry, zi, iw[0], iw[1], iw[2]);
+  }
+  double X, Y, Z;
+  rigid_apply(Tcw, P_m[3 * (long)l], P_m[3 * (long)l + 1], P_m[3 * (long)l + 2], X, Y, Z);
+  const bool zbad = Z < 0.1 * median[b];                             // sparse_map.py:26-28
+  if (zbad) rigid_apply(Tcw, iw[0], iw[1], iw[2], X, Y, Z);
+  if (fb == b && fj == j) {                                          // this thread IS the first observer
+    o.init_Pm[3 * (long)l] = iw[0]; o.init_Pm[3 * (long)l + 1] = iw[1]; o.init_Pm[3 * (long)l + 2] = iw[2];
+    o.reinit_flag[l] = zbad ? 1 : 0;
+  }
+  const long bj = (long)b * m + j;
+  const double iz = 1.0 / Z;
+  const double logz = log(Z);
+  o.logzm[bj] = logz;
+  o.invz[bj] = iz;
+  px.logzm[bj] = (TP)logz;
+  px.invz[bj] = (TP)iz;
+  double u, v;
+  u = project1(fx, X, Z, cx);
+  v = project1(fy, Y, Z, cy);
+  o.pm[2 * bj] = u;
+  o.pm[2 * bj + 1] = v;
+  // dz/dT_wc = row 2 of [[P_c]x, -I] ; dlogz = dz / z      (sparse_map.py:46-55)
+  const double dzT[6] = {-Y, X, 0.0, 0.0, 0.0, -1.0};
+#pragma unroll
+  for (int a = 0; a < 6; ++a) { o.dlogz_dT[6 * bj + a] = dzT[a] * iz; px.dlogz_dT[6 * bj + a] = (TP)(dzT[a] * iz); }
+  const double r20 = Tcw[8], r21 = Tcw[9], r22 = Tcw[10];
+  o.dlogz_dP[3 * bj] = r20 * iz; o.dlogz_dP[3 * bj + 1] = r21 * iz; o.dlogz_dP[3 * bj + 2] = r22 * iz;
+  if (j == 0) {
+    o.dzdP[3 * b] = r20; o.dzdP[3 * b + 1] = r21; o.dzdP[3 * b + 2] = r22;
+    px.dzdP[3 * b] = (TP)r20; px.dzdP[3 * b + 1] = (TP)r21; px.dzdP[3 * b + 2] = (TP)r22;
+  }
+  // dp/dP_c (camera.py:28-35), then dp/dP_w = dp/dP_c R_cw, dp/dT_wc = dp/dP_c [[P_c]x, -I]
+  const double a00 = fx * iz, a02 = -(fx * X * iz) * iz, a11 = fy * iz, a12 = -(fy * Y * iz) * iz;
+  double* dP = o.dp_dP + 6 * bj;
+  dP[0] = a00 * Tcw[0] + a02 * Tcw[8]; dP[1] = a00 * Tcw[1] + a02 * Tcw[9]; dP[2] = a00 * Tcw[2] + a02 * Tcw[10];
+  dP[3] = a11 * Tcw[4] + a12 * Tcw[8]; dP[4] = a11 * Tcw[5] + a12 * Tcw[9]; dP[5] = a11 * Tcw[6] + a12 * Tcw[10];
+  double* dT = o.dp_dT + 12 * bj;
+  // [P]x = [[0,-Z,Y],[Z,0,-X],[-Y,X,0]]
+  dT[0] = a02 * (-Y);            dT[1] = a00 * (-Z) + a02 * X;  dT[2] = a00 * Y;
+  dT[3] = -a00;                  dT[4] = 0.0;                   dT[5] = -a02;
+  dT[6] = a11 * Z + a12 * (-Y);  dT[7] = a12 * X;               dT[8] = a11 * (-X);
+  dT[9] = 0.0;                   dT[10] = -a11;                 dT[11] = -a12;
+}
+
+__global__ void win_apply_reinit_kernel(double* __restrict__ P_m, const double* __restrict__ init_Pm,
+                                        const int* __restrict__ flag, int L) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < L && flag[l]) {                                             // Mapping.py:645-648
+    P_m[3 * (long)l] = init_Pm[3 * (long)l]; P_m[3 * (long)l + 1] = init_Pm[3 * (long)l + 1]; P_m[3 * (long)l + 2] = init_Pm[3 * (long)l + 2];
+  }
+}
+
+struct PriorArgs {
+  const double* logzm; const double* dlogz_dT; const double* dlogz_dP; const double* pm; const double* pm_first;
+  const double* dp_dP; const double* dp_dT; const uint8_t* first_mask; const double* Kmm_inv;
+  const void* median; int median_is_f32; int median_stride;
+  const long* pose_inds;      // (B,8)
+  const long* landmark_inds;  // (B,3m)
+  const double* poses; const double* aff; const double* pose_anchor; const double* aff_anchor;
+  const double* P_m; const double* P_anchor; const long* fix_inds;  // (nfix*3) rows of H ; P_anchor (nfix,3); fix_lm (nfix)
+  const int* fix_lm; int nfix;
+  double s_gp, s_ld, s_px, s_pose, s_aff, s_lm;   // sigmas
+  double* H; double* g; long D; double* err;      // err: 8 doubles
+};
+
+__global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int m) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* M = sm;                 // m x m
+  double* MG = M + m * m;         // m x 6
+  double* w = MG + m * 6;         // m
+  double* r0 = w + m;             // m
+  double* G = r0 + m;             // m x 6
+  double* dP = G + m * 6;         // m x 3
+  double* red = dP + m * 3;       // 64 scratch
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const double med = A.median_is_f32 ? (double)((const float*)A.median)[(long)b * A.median_stride]
+                                     : ((const double*)A.median)[(long)b * A.median_stride];
+  const double logmed = log(med);
+  const double i_gp = 1.0 / (A.s_gp * A.s_gp), i_ld = 1.0 / (A.s_ld * A.s_ld), i_px = 1.0 / (A.s_px * A.s_px);
+  for (int e = tid; e < m * m; e += 256) {
+    const int i = e / m, j = e % m;
+    double v = A.Kmm_inv[(long)b * m * m + e] * i_gp;
+    if (i == j && A.first_mask[(long)b * m + i]) v += i_ld;
+    M[e] = v;
+  }
+  for (int e = tid; e < m; e += 256) r0[e] = A.logzm[(long)b * m + e] - logmed;
+  for (int e = tid; e < m * 6; e += 256) G[e] = A.dlogz_dT[(long)b * m * 6 + e];
+  for (int e = tid; e < m * 3; e += 256) dP[e] = A.dlogz_dP[(long)b * m * 3 + e];
+  __syncthreads();
+  for (int e = tid; e < m; e += 256) {
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += M[e * m + k] * r0[k];
+    w[e] = s;
+  }
+  for (int e = tid; e < m * 6; e += 256) {
+    const int i = e / 6, a = e % 6;
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += M[i * m + k] * G[k * 6 + a];
+    MG[e] = s;
+  }
+  __syncthreads();
+  const long* pi = A.pose_inds + 8 * (long)b;
+  const long* li = A.landmark_inds + 3 * (long)m * b;
+  const long D = A.D;
+  // H_TT, g_T  (log-depth-space priors)
+  if (tid < 36) {
+    const int a = tid / 6, c = tid % 6;
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += G[k * 6 + a] * MG[k * 6 + c];
+    atomicAdd(&A.H[pi[a] * D + pi[c]], s);
+  } else if (tid < 42) {
+    const int a = tid - 36;
+    double s = 0;
+    for (int k = 0; k < m; ++k) s += G[k * 6 + a] * w[k];
+    atomicAdd(&A.g[pi[a]], -s);
+  }
+  // H_TP (both triangles), g_P
+  for (int e = tid; e < 6 * m * 3; e += 256) {
+    const int a = e / (3 * m), q = e % (3 * m), j = q / 3, d = q % 3;
+    const double v = MG[j * 6 + a] * dP[j * 3 + d];
+    atomicAdd(&A.H[pi[a] * D + li[q]], v);
+    atomicAdd(&A.H[li[q] * D + pi[a]], v);
+  }
+  for (int q = tid; q < 3 * m; q += 256) atomicAdd(&A.g[li[q]], -w[q / 3] * dP[q]);
+  // H_PP
+  for (int e = tid; e < 9 * m * m; e += 256) {
+    const int q1 = e / (3 * m), q2 = e % (3 * m);
+    const double v = M[(q1 / 3) * m + (q2 / 3)] * dP[q1] * dP[q2];
+    atomicAdd(&A.H[li[q1] * D + li[q2]], v);
+  }
+  // errors: gp = r0^T (Kinv/s^2) r0, ld = sum first r0^2 / s^2
+  if (tid < 64) {
+    double egp = 0, eld = 0;
+    for (int i = tid; i < m; i += 64) {
+      const double fi = A.first_mask[(long)b * m + i] ? i_ld : 0.0;
+      eld += fi * r0[i] * r0[i];
+      egp += r0[i] * (w[i] - fi * r0[i]);
+    }
+    egp = wave_sum(egp); eld = wave_sum(eld);
+    if (tid == 0) { atomicAdd(&A.err[0], egp); atomicAdd(&A.err[1], eld); }
+  }
+  // pixel prior, mode "first": one thread per first-observed landmark of this keyframe
+  double epx = 0;
+  if (tid < m && A.first_mask[(long)b * m + tid]) {
+    const int j = tid;
+    const long bj = (long)b * m + j;
+    const double r[2] = {A.pm[2 * bj] - A.pm_first[2 * bj], A.pm[2 * bj + 1] - A.pm_first[2 * bj + 1]};
+    const double* JP = A.dp_dP + 6 * bj;     // 2x3
+    const double* JT = A.dp_dT + 12 * bj;    // 2x6
+    for (int d = 0; d < 3; ++d) {
+      for (int d2 = 0; d2 < 3; ++d2) atomicAdd(&A.H[li[3 * j + d] * D + li[3 * j + d2]], i_px * (JP[d] * JP[d2] + JP[3 + d] * JP[3 + d2]));
+      atomicAdd(&A.g[li[3 * j + d]], -i_px * (JP[d] * r[0] + JP[3 + d] * r[1]));
+      for (int a = 0; a < 6; ++a) {
+        const double v = i_px * (JT[a] * JP[d] + JT[6 + a] * JP[3 + d]);
+        atomicAdd(&A.H[pi[a] * D + li[3 * j + d]], v);
+        atomicAdd(&A.H[li[3 * j + d] * D + pi[a]], v);
+      }
+    }
+    for (int a = 0; a < 6; ++a) {
+      for (int c = 0; c < 6; ++c) atomicAdd(&A.H[pi[a] * D + pi[c]], i_px * (JT[a] * JT[c] + JT[6 + a] * JT[6 + c]));
+      atomicAdd(&A.g[pi[a]], -i_px * (JT[a] * r[0] + JT[6 + a] * r[1]));
+    }
+    epx = i_px * (r[0] * r[0] + r[1] * r[1]);
+  }
+  if (tid < 64) {
+    epx = wave_sum(epx);
+    if (tid == 0) atomicAdd(&A.err[2], epx);
+  }
+  // anchors on keyframe 0 (Mapping.py:855-900)
+  if (b == 0 && tid == 0) {
+    // pose prior: xi = -Log(T0^-1 anchor) with the reference's SE3_logmap (lie_algebra.py:127-176)
+    double Ti[12];
+    invert_pose34(A.poses, Ti);
+    double T[12];
+    const double* An = A.pose_anchor;
+    for (int i = 0; i < 3; ++i)
+      for (int j2 = 0; j2 < 4; ++j2)
+        T[i * 4 + j2] = Ti[i * 4] * An[j2] + Ti[i * 4 + 1] * An[4 + j2] + Ti[i * 4 + 2] * An[8 + j2] + (j2 == 3 ? Ti[i * 4 + 3] : 0.0);
+    const double tr = T[0] + T[5] + T[10];
+    const double tr3 = tr - 3.0;
+    const double theta = acos(0.5 * (tr - 1.0));
+    const double mag = (tr3 < -1e-6) ? theta / (2.0 * sin(theta)) : 0.5 - tr3 / 12.0 + tr3 * tr3 / 60.0;
+    const double wv[3] = {mag * (T[9] - T[6]), mag * (T[2] - T[8]), mag * (T[4] - T[1])};
+    double th = sqrt(wv[0] * wv[0] + wv[1] * wv[1] + wv[2] * wv[2]);
+    th = fmax(th, 1e-6);
+    const double wn[3] = {wv[0] / th, wv[1] / th, wv[2] / th};
+    const double tt[3] = {T[3], T[7], T[11]};
+    const double wxt[3] = {wn[1] * tt[2] - wn[2] * tt[1], wn[2] * tt[0] - wn[0] * tt[2], wn[0] * tt[1] - wn[1] * tt[0]};
+    const double wxwxt[3] = {wn[1] * wxt[2] - wn[2] * wxt[1], wn[2] * wxt[0] - wn[0] * wxt[2], wn[0] * wxt[1] - wn[1] * wxt[0]};
+    const double cf = 1.0 - th / (2.0 * tan(0.5 * th));
+    double xi[6];
+    for (int i = 0; i < 3; ++i) { xi[i] = -wv[i]; xi[3 + i] = -(tt[i] - (0.5 * tt[i]) * wxt[i] + cf * wxwxt[i]); }
+    const double isq = 1.0 / A.s_pose;
+    const double jtj = (double)((float)isq * (float)isq);          // float32 J^T J of the reference (torch.eye default dtype)
+    double ep = 0;
+    for (int a = 0; a < 6; ++a) {
+      atomicAdd(&A.H[pi[a] * D + pi[a]], jtj);
+      atomicAdd(&A.g[pi[a]], -(isq * (isq * xi[a])));
+      ep += (isq * xi[a]) * (isq * xi[a]);
+    }
+    // affine anchors
+    const double ia = (1.0 / A.s_aff) * (1.0 / A.s_aff);
+    double ea = 0;
+    for (int q = 0; q < 2; ++q) {
+      const double r = A.aff[q] - A.aff_anchor[q];
+      atomicAdd(&A.H[pi[6 + q] * D + pi[6 + q]], ia);
+      atomicAdd(&A.g[pi[6 + q]], -ia * r);
+      ea += ia * r * r;
+    }
+    atomicAdd(&A.err[3], ep);
+    atomicAdd(&A.err[4], ea);
+  }
+  if (b == 0 && A.nfix > 0) {
+    const double il = (1.0 / A.s_lm) * (1.0 / A.s_lm);
+    double el = 0;
+    for (int e = tid; e < 3 * A.nfix; e += 256) {
+      const int f = e / 3, d = e % 3;
+      const double r = A.P_m[3 * (long)A.fix_lm[f] + d] - A.P_anchor[e];
+      const long ii = A.fix_inds[e];
+      atomicAdd(&A.H[ii * D + ii], il);
+      atomicAdd(&A.g[ii], -il * r);
+      el += il * r * r;
+    }
+    red[tid & 63] = 0;
+    el = wave_sum(el);
+    if ((tid & 63) == 0) atomicAdd(&A.err[5], el);
+  }
+}
+
+__global__ __launch_bounds__(256) void win_update_kernel(const double* __restrict__ delta, double* __restrict__ poses,
+                                                         double* __restrict__ aff, const long* __restrict__ frame_inds,
+                                                         int F, double* __restrict__ P_m, int L, long lm_start) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  if (tid < F) {
+    const long* ix = frame_inds + 8 * (long)tid;
+    double xi[6], E[16], Tn[16];
+    for (int a = 0; a < 6; ++a) xi[a] = delta[ix[a]];
+    se3_exp_f64(xi, E);
+    double* T = poses + 16 * (long)tid;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        double t = 0;
+        for (int k = 0; k < 4; ++k) t += T[i * 4 + k] * E[k * 4 + j];
+        Tn[i * 4 + j] = t;
+      }
+    for (int e = 0; e < 16; ++e) T[e] = Tn[e];
+    aff[2 * tid] += delta[ix[6]];
+    aff[2 * tid + 1] += delta[ix[7]];
+  }
+  for (int e = tid; e < 3 * L; e += gridDim.x * 256) P_m[e] += delta[lm_start + e];
+}
+
+}  // namespace como
+
+extern "C" {
+
+int como_win_scaffold(const como_win_args* a, como_stream_t stream) {
+  using namespace como;
+  if (!a || a->B <= 0 || a->m <= 0 || a->m > 64 || a->F < a->B) return COMO_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  ScaffoldOut o{a->pm, a->logzm, a->invz, a->dzdP, a->dlogz_dT, a->dlogz_dP, a->dp_dP, a->dp_dT, a->init_Pm, a->reinit_flag};
+  const int grid = a->B > (a->F * 16 + 63) / 64 ? a->B : (a->F * 16 + 63) / 64;
+  if (a->pix_is_f64) {
+    ScaffoldPix<double> px{(double*)a->px_logzm, (double*)a->px_invz, (double*)a->px_dzdP, (double*)a->px_dlogz_dT,
+                           (double*)a->px_poses, (double*)a->px_aff};
+    hipLaunchKernelGGL(win_scaffold_kernel<double>, dim3(grid), dim3(64), 0, s, a->poses, a->aff, a->F, a->P_m, a->lm_ids,
+                       a->first_frame, a->first_slot, a->K, a->median, a->pm_first, a->B, a->m, o, px);
+  } else {
+    ScaffoldPix<float> px{(float*)a->px_logzm, (float*)a->px_invz, (float*)a->px_dzdP, (float*)a->px_dlogz_dT,
+                          (float*)a->px_poses, (float*)a->px_aff};
+    hipLaunchKernelGGL(win_scaffold_kernel<float>, dim3(grid), dim3(64), 0, s, a->poses, a->aff, a->F, a->P_m, a->lm_ids,
+                       a->first_frame, a->first_slot, a->K, a->median, a->pm_first, a->B, a->m, o, px);
+  }
+  COMO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(win_apply_reinit_kernel, dim3((a->L + 255) / 256), dim3(256), 0, s, a->P_m, a->init_Pm, a->reinit_flag, a->L);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_win_priors(const como_win_args* a, como_stream_t stream) {
+  using namespace como;
+  if (!a || a->B <= 0 || a->m <= 0 || a->m > 64 || !a->H || !a->g || !a->err) return COMO_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  PriorArgs A;
+  A.logzm = a->logzm; A.dlogz_dT = a->dlogz_dT; A.dlogz_dP = a->dlogz_dP; A.pm = a->pm; A.pm_first = a->pm_first;
+  A.dp_dP = a->dp_dP; A.dp_dT = a->dp_dT; A.first_mask = a->first_mask; A.Kmm_inv = a->Kmm_inv;
+  A.median = a->median_new; A.median_is_f32 = a->median_new_is_f32; A.median_stride = a->median_new_stride;
+  A.pose_inds = a->pose_inds; A.landmark_inds = a->landmark_inds; A.poses = a->poses; A.aff = a->aff;
+  A.pose_anchor = a->pose_anchor; A.aff_anchor = a->aff_anchor; A.P_m = a->P_m; A.P_anchor = a->P_anchor;
+  A.fix_inds = a->fix_inds; A.fix_lm = a->fix_lm; A.nfix = a->nfix;
+  A.s_gp = a->s_gp; A.s_ld = a->s_ld; A.s_px = a->s_px; A.s_pose = a->s_pose; A.s_aff = a->s_aff; A.s_lm = a->s_lm;
+  A.H = a->H; A.g = a->g; A.D = a->D; A.err = a->err;
+  const int m = a->m;
+  const size_t lds = (size_t)(m * m + m * 6 + m + m + m * 6 + m * 3 + 64) * sizeof(double);
+  hipLaunchKernelGGL(win_priors_kernel, dim3(a->B), dim3(256), lds, s, A, a->B, m);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_win_update(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
+                    long lm_start, como_stream_t stream) {
+  if (!delta || !poses || !aff || !frame_inds || !P_m || F <= 0 || L <= 0) return COMO_ERR_ARG;
+  int blocks = (3 * L + 255) / 256;
+  if (blocks < (F + 255) / 256) blocks = (F + 255) / 256;
+  hipLaunchKernelGGL(como::win_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, delta, poses, aff, frame_inds, F,
+                     P_m, L, lm_start);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+}  // extern "C"

@@ -11,8 +11,9 @@ from como_amd import _lib
 _ws = {}
 
 
-def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_logz=True):
-    """logzm (B,m,1) Twc (B,4,4) Kt (B,rows,m) pixidx (B,n) int32 or None K (3,3) dlogzm_dTwc (B,m,1,6).
+def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_logz=True, med_out=None):
+    """logzm (B,m[,1]) Twc (B,4,4) Kt (B,rows,m) pixidx (B,n) int32 or None K (3,3) dlogzm_dTwc (B,m[,1],6).
+    med_out: optional caller-owned (B,3) buffer for {median depth, 1.4826*median, n} (fixed address for fused chains).
     Returns Pwn (B,3,n), dPwn_dTwc (B,18,n), uvec (B,3,n), median depth (B,), logzn (B,n)."""
     _lib.require_cuda(logzm, Twc, Kt, K, dlogzm_dTwc)
     dt, dev = Kt.dtype, Kt.device
@@ -28,6 +29,7 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
               "hists": torch.empty((B * L.como_select_workspace_bytes() // 4,), device=dev, dtype=torch.int32)}
         _ws.clear()
         _ws[key] = ws
+    med = med_out if med_out is not None else ws["med"]
     lz = logzm.reshape(B, m).to(dt).contiguous()
     dl = dlogzm_dTwc.reshape(B, m, 6).to(dt).contiguous()
     Tw = Twc.to(dt).contiguous()
@@ -35,6 +37,6 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
     fn = getattr(L, "como_dense_ref_" + _lib.suffix(dt))
     rc = fn(Kt.data_ptr(), Kt.stride(0), _lib.ptr(pixidx), lz.data_ptr(), Tw.data_ptr(), Kc.data_ptr(), dl.data_ptr(), B, n, m,
             int(Wimg), ws["Pwn"].data_ptr(), ws["dT"].data_ptr(), ws["uvec"].data_ptr(), ws["z"].data_ptr(),
-            ws["logz"].data_ptr() if want_logz else None, ws["hists"].data_ptr(), ws["med"].data_ptr(), _lib.stream_ptr(dev))
+            ws["logz"].data_ptr() if want_logz else None, ws["hists"].data_ptr(), med.data_ptr(), _lib.stream_ptr(dev))
     _lib.check(rc, "como_dense_ref")
-    return ws["Pwn"], ws["dT"], ws["uvec"], ws["med"][:, 0], ws["logz"]
+    return ws["Pwn"], ws["dT"], ws["uvec"], med[:, 0], ws["logz"]

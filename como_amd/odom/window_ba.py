@@ -1,28 +1,35 @@
 """Headless keyframe-window bundle adjustment: the call sequence of the reference's `Mapping.iterate`
 (como/odom/Mapping.py:760-968) without the GUI / process plumbing around it.
 
-    scaffold (project landmarks)          Mapping.prep_geometry_scaffold  :603-659   small torch ops
-    dense reference points                Mapping.prep_dense_ref          :661-699   HIP (factored, no (B,n,3,m) tensor)
-    photometric normal equations          create_photo_system             backend/photo.py:236-353   HIP (csrc/ba.hip)
-    priors                                Mapping.iterate                 :809-917   small torch ops
-    solve + update                        lin_sys.solve_system/update_vars  linear_system.py:101-152
+    scaffold (project landmarks)          Mapping.prep_geometry_scaffold  :603-659   HIP win_scaffold   (csrc/window.hip)
+    dense reference points                Mapping.prep_dense_ref          :661-699   HIP dense_ref      (csrc/densify.hip)
+    photometric normal equations          create_photo_system   backend/photo.py:236-353   HIP ba_*     (csrc/ba.hip)
+    priors                                Mapping.iterate                 :809-917   HIP win_priors     (csrc/window.hip)
+    solve                                 lin_sys.solve_system  linear_system.py:101-112   HIP chol_*   (csrc/chol.hip)
+    update                                lin_sys.update_vars   linear_system.py:115-152   HIP win_update
 
-State tensors live on one GPU.  `pix_dtype` is the element type of the per-pixel path (images, K~, dense
-points: float32 for the mixed-precision configuration, float64 to mirror config/como.yml:28); the system
-(H, g, poses, landmarks, priors, solve) is always float64.
+`fused=True` (default) runs the ~45-launch HIP chain above; `fused=False` runs the same iteration through the
+reference-signature mirrors (torch ops for the O(B m) parts) -- both are checked against the golden vectors.
+State tensors live on one GPU and are updated in place (fixed addresses: the iteration is hipGraph-capturable).
+`pix_dtype` is the element type of the per-pixel path (float32 = mixed precision, float64 = config/como.yml:28);
+the system (H, g, poses, landmarks, priors, solve) is always float64.
 """
+import ctypes
+
 import torch
 
 import como_amd.odom.backend.linear_system as lin_sys
 import como_amd.odom.backend.photo as photo
 import como_amd.odom.backend.sparse_map as smap
+from como_amd import _lib
+from como_amd.geometry.camera import backprojection
+from como_amd.odom.backend.dense_ref import dense_reference_factored
 from como_amd.odom.backend.graph_pair_construction import setup_photometric_pairs
 from como_amd.odom.factors.depth_prior import log_depth_prior
 from como_amd.odom.factors.gp_priors import gp_ml_cost, mean_log_depth_cost
 from como_amd.odom.factors.pixel_prior import pixel_prior_cost
 from como_amd.odom.factors.pose_prior_factors import linearize_pose_prior
 from como_amd.odom.factors.scalar_prior_factors import linearize_multi_scalar_prior, linearize_scalar_prior
-from como_amd.geometry.camera import backprojection
 
 DEFAULT_CFG = {
     "photo_construction": {"nonmax_suppression_window": 4, "pairwise_batch_size": 128, "radius_thresh": 0.0,
@@ -32,47 +39,58 @@ DEFAULT_CFG = {
 
 
 class WindowBA:
-    def __init__(self, state, cfg=None, pix_dtype=torch.float32, window_full=True, dense_ref="hip", shard=None):
+    def __init__(self, state, cfg=None, pix_dtype=torch.float32, window_full=True, shard=None, fused=True):
         """state: dict as produced by como_amd.synth.make_window (plus K_mm_inv / L_mm / Knm_Kmminv).
         shard: como_amd.dist.Shard for the one-process-per-GPU data-parallel mode (None = single GPU)."""
         self.shard = shard
         self.events = None
+        self.graph = None
         self.cfg = cfg or DEFAULT_CFG
         self.dev = state["kf_poses"].device
         self.dt = torch.float64
         self.pix_dtype = pix_dtype
+        self.fused = fused and window_full
         f64 = lambda t: t.to(self.dt).contiguous()
-        self.intrinsics = f64(state["intrinsics"])
-        self.kf_poses = f64(state["kf_poses"])
-        self.kf_aff_params = f64(state["kf_aff_params"])
-        self.P_m = f64(state["P_m"])
-        self.correspondence_mask = state["correspondence_mask"]
-        self.obs_ref_mask = state["obs_ref_mask"]
-        self.pm_first_obs = f64(state["pm_first_obs"])
-        self.L_mm = f64(state["L_mm"])
-        self.kf_timestamps = state["kf_timestamps"]
-        self.recent_poses = torch.empty((0, 4, 4), device=self.dev, dtype=self.dt)
-        self.recent_aff_params = torch.empty((0, 2, 1), device=self.dev, dtype=self.dt)
-        self.recent_timestamps = torch.empty((0,), device=self.dev, dtype=self.dt)
+        dev = self.dev
         B, _, self.Himg, self.Wimg = state["kf_img_and_grads"].shape
         self.B = B
         self.m = state["coords_m"].shape[1]
+        nrec = 0
+        self.F = B + nrec
+        self.intrinsics = f64(state["intrinsics"])
+        # all frame poses / affine params in ONE buffer each (keyframes first): the views below alias it
+        self.poses_all = torch.zeros((self.F, 4, 4), device=dev, dtype=self.dt)
+        self.aff_all = torch.zeros((self.F, 2), device=dev, dtype=self.dt)
+        self.poses_all[:B] = f64(state["kf_poses"])
+        self.aff_all[:B] = f64(state["kf_aff_params"]).reshape(B, 2)
+        self.kf_poses = self.poses_all[:B]
+        self.kf_aff_params = self.aff_all[:B].view(B, 2, 1)
+        self.recent_poses = self.poses_all[B:]
+        self.recent_aff_params = self.aff_all[B:].view(nrec, 2, 1)
+        self.recent_timestamps = torch.empty((0,), device=dev, dtype=self.dt)
+        self.P_m = f64(state["P_m"])
+        self.correspondence_mask = state["correspondence_mask"]
+        self.obs_ref_mask = state["obs_ref_mask"].contiguous()
+        self.pm_first_obs = f64(state["pm_first_obs"])
+        self.L_mm = f64(state["L_mm"])
+        self.K_mm_inv = f64(state["K_mm_inv"])
+        self.kf_timestamps = state["kf_timestamps"]
         # per-pixel data in pix_dtype
         self.img = state["kf_img_and_grads"].to(pix_dtype).contiguous()
         self.Kt = state["Knm_Kmminv"].to(pix_dtype).reshape(B, self.Himg * self.Wimg, self.m).contiguous()
         self.K_pix = self.intrinsics[0].to(pix_dtype).contiguous()
-        self.median_depths = f64(state["median_depth_init"]) if "median_depth_init" in state else torch.full((B,), 1.0, device=self.dev, dtype=self.dt)
+        self.median_depths = (f64(state["median_depth_init"]) if "median_depth_init" in state
+                              else torch.full((B,), 1.0, device=dev, dtype=self.dt))
         self.window_full = window_full
-        self.pose_anchor = self.kf_poses[0:1].clone() if "pose_anchor" not in state else f64(state["pose_anchor"])
-        self.aff_anchor = torch.zeros((1, 2, 1), device=self.dev, dtype=self.dt)
+        self.pose_anchor = f64(state["pose_anchor"]) if "pose_anchor" in state else self.kf_poses[0:1].clone()
+        self.aff_anchor = torch.zeros((1, 2, 1), device=dev, dtype=self.dt)
         self.P_m_anchors = f64(state["P_anchor"]) if "P_anchor" in state else self.P_m[self.correspondence_mask[0]].clone()
         self.init_scale_anchor = state.get("init_scale_anchor")
-        self.dense_ref = dense_ref
         self._prepare_topology()
 
     # ---- things that change only when the keyframe set changes ---------------------------------------------------
     def _prepare_topology(self):
-        B, dev = self.B, self.dev
+        B, dev, m = self.B, self.dev, self.m
         w = self.cfg["photo_construction"]["nonmax_suppression_window"]
         coords_n, _ = smap.subselect_pixels(self.img, w)                       # Mapping.py:665-668
         self.coords_n = coords_n
@@ -83,22 +101,29 @@ class WindowBA:
         landmark_ids, _ = paired
         self.point_inds = lin_sys.landmark_to_batched_3d_point_inds(landmark_ids, B)
         L = self.P_m.shape[0]
-        nrec = self.recent_poses.shape[0]
+        self.L = L
+        nrec = self.F - B
         self.dim = 8 * B + 8 * nrec + 3 * L
         self.kf_inds = torch.arange(8 * B, device=dev).reshape(B, 8)
         self.recent_inds = (torch.arange(8 * nrec, device=dev).reshape(nrec, 8) + 8 * B) if nrec else \
             torch.empty((0), device=dev, dtype=torch.long)
+        self.frame_inds = torch.arange(8 * self.F, device=dev).reshape(self.F, 8).contiguous()
         self.lm_start = 8 * B + 8 * nrec
-        self.landmark_inds = self.point_inds + self.lm_start
+        self.landmark_inds = (self.point_inds + self.lm_start).contiguous()
         self.landmark_inds_flat = torch.arange(3 * L, device=dev).reshape(L, 3) + self.lm_start
         # index lists of the oldest keyframe's landmarks (their anchors, Mapping.py:884-898): precomputed -- boolean-mask
         # indexing inside the iteration would synchronise with the host (and cannot be captured in a hipGraph)
         self.fix_idx = torch.nonzero(self.correspondence_mask[0])[:, 0]
         self.fix_inds_flat = self.landmark_inds_flat[self.fix_idx].flatten().contiguous()
-        first_obs = torch.argmax(self.correspondence_mask.int(), dim=0)
+        self.lm_ids = (self.point_inds[:, ::3] // 3).to(torch.int32).contiguous()          # (B,m)
+        first_obs = torch.argmax(self.correspondence_mask.int(), dim=0)                    # first observer keyframe
         fom = torch.zeros_like(self.correspondence_mask)
         fom[first_obs, torch.arange(L, device=dev)] = True
         self.first_obs_mask = self.remap(fom, False)
+        slot_of = torch.full((B, L), -1, device=dev, dtype=torch.int32)
+        slot_of.scatter_(1, self.lm_ids.long(), torch.arange(m, device=dev, dtype=torch.int32)[None].expand(B, m).contiguous())
+        self.first_frame = first_obs.to(torch.int32).contiguous()
+        self.first_slot = slot_of[first_obs, torch.arange(L, device=dev)].contiguous()
         ref, tgt, ow_kf, ow_t = setup_photometric_pairs(self.kf_poses, self.recent_poses, self.kf_timestamps,
                                                         self.recent_timestamps, self.median_depths,
                                                         self.cfg["photo_construction"])
@@ -111,10 +136,78 @@ class WindowBA:
         self.H = self.sys[:D * D].view(D, D)
         self.g = self.sys[D * D:D * D + D]
         self.err = self.sys[D * D + D:].view(())
-        self.pix_range = self.shard.pixel_range(self.n) if self.shard is not None else None
+        self.prior_err = torch.zeros(8, device=dev, dtype=self.dt)
         self.sigma = torch.zeros(2, device=dev, dtype=self.pix_dtype)
+        self.pix_range = self.shard.pixel_range(self.n) if self.shard is not None else None
+        self._prepare_fused()
 
-    # ---- one Gauss-Newton iteration ------------------------------------------------------------------------------
+    def _prepare_fused(self):
+        B, m, L, F, dev, p = self.B, self.m, self.L, self.F, self.dev, self.pix_dtype
+        z64 = lambda *s: torch.zeros(s, device=dev, dtype=self.dt)
+        zp = lambda *s: torch.zeros(s, device=dev, dtype=p)
+        self.w = {"pm": z64(B, m, 2), "logzm": z64(B, m), "invz": z64(B, m), "dzdP": z64(B, 3), "dlogz_dT": z64(B, m, 6),
+                  "dlogz_dP": z64(B, m, 3), "dp_dP": z64(B, m, 6), "dp_dT": z64(B, m, 12), "init_Pm": z64(L, 3),
+                  "reinit_flag": torch.zeros(L, device=dev, dtype=torch.int32),
+                  "px_logzm": zp(B, m), "px_invz": zp(B, m), "px_dzdP": zp(B, 3), "px_dlogz_dT": zp(B, m, 6),
+                  "px_poses": zp(F, 4, 4), "px_aff": zp(F, 2),
+                  "med3": zp(B, 3)}
+        self.first_mask_u8 = self.obs_ref_mask.to(torch.uint8).contiguous()
+        self.fix_lm = self.fix_idx.to(torch.int32).contiguous()
+        self.aff_anchor2 = self.aff_anchor.reshape(2).contiguous()
+        a = _lib.WinArgs()
+        a.B, a.F, a.m, a.L, a.nfix = B, F, m, L, int(self.fix_lm.numel())
+        a.pix_is_f64 = 1 if p == torch.float64 else 0
+        a.median_new_is_f32 = 1 if p == torch.float32 else 0
+        a.median_new_stride = 3
+        a.D = self.dim
+        ptr = _lib.ptr
+        a.poses, a.aff, a.K, a.median = ptr(self.poses_all), ptr(self.aff_all), ptr(self.intrinsics), ptr(self.median_depths)
+        a.pm_first, a.Kmm_inv = ptr(self.pm_first_obs), ptr(self.K_mm_inv)
+        a.pose_anchor, a.aff_anchor, a.P_anchor, a.P_m = ptr(self.pose_anchor), ptr(self.aff_anchor2), ptr(self.P_m_anchors), ptr(self.P_m)
+        a.lm_ids, a.first_frame, a.first_slot, a.fix_lm = ptr(self.lm_ids), ptr(self.first_frame), ptr(self.first_slot), ptr(self.fix_lm)
+        a.first_mask, a.pose_inds, a.landmark_inds, a.fix_inds = (ptr(self.first_mask_u8), ptr(self.kf_inds), ptr(self.landmark_inds),
+                                                                  ptr(self.fix_inds_flat))
+        a.median_new = ptr(self.w["med3"])
+        for k in ("pm", "logzm", "invz", "dzdP", "dlogz_dT", "dlogz_dP", "dp_dP", "dp_dT", "init_Pm", "reinit_flag", "px_logzm",
+                  "px_invz", "px_dzdP", "px_dlogz_dT", "px_poses", "px_aff"):
+            setattr(a, k, ptr(self.w[k]))
+        sg = self.cfg["sigmas"]
+        a.s_gp, a.s_ld, a.s_px, a.s_pose, a.s_aff, a.s_lm = 1.0, 1.0, 1e-2, sg["pose_prior"], sg["scale_prior"], sg["scale_prior"]
+        a.H, a.g, a.err = ptr(self.H), ptr(self.g), ptr(self.prior_err)
+        self.win_args = a
+
+    # ---- fused HIP chain -----------------------------------------------------------------------------------------
+    def linearize_fused(self):
+        L, a, w, dev = _lib.lib(), self.win_args, self.w, self.dev
+        s = _lib.stream_ptr(dev)
+        _lib.check(L.como_win_scaffold(ctypes.byref(a), s), "como_win_scaffold")
+        Pwn, dT, uvec, med, _ = dense_reference_factored(w["px_logzm"], w["px_poses"][:self.B], self.Kt, self.pixidx, self.K_pix,
+                                                         w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"])
+        self.sys.zero_()
+        self.prior_err.zero_()
+        photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=Pwn, vals=self.vals_n,
+                                    dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],
+                                    img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=self.H, g=self.g,
+                                    err_out=self.err, sigma_out=self.sigma, pix_range=self.pix_range,
+                                    reduce_hists=(self.shard.all_reduce_sum if self.shard is not None else None),
+                                    events=self.events)
+        if self.shard is not None:
+            self.shard.all_reduce_sum(self.sys)          # normal equations of all shards: H | g | err in one collective
+        _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")
+        self.median_depths.copy_(med)
+        return self.H, self.g
+
+    def iterate_fused(self):
+        H, g = self.linearize_fused()
+        delta = lin_sys.solve_system(H, g)
+        rc = _lib.lib().como_win_update(delta.data_ptr(), self.poses_all.data_ptr(), self.aff_all.data_ptr(),
+                                        self.frame_inds.data_ptr(), self.F, self.P_m.data_ptr(), self.L, self.lm_start,
+                                        _lib.stream_ptr(self.dev))
+        _lib.check(rc, "como_win_update")
+        self.delta = delta
+        return delta
+
+    # ---- the same iteration through the reference-signature mirrors (torch ops for the O(B m) parts) ---------------
     def scaffold(self):
         """Mapping.prep_geometry_scaffold (:603-659) without host synchronisation."""
         K = self.intrinsics
@@ -122,14 +215,11 @@ class WindowBA:
         init_Pc, _ = backprojection(K[0], self.pm_first_obs, depth_init)
         init_Pw = smap.rigid_apply_exact(self.kf_poses, init_Pc)                  # (B,m,3)
         # re-initialisation point of a landmark = back-projection from its FIRST observer at the median depth (:625-634)
-        lm_ids = self.point_inds[:, ::3] // 3 - 0                                 # (B,m) landmark id of every batched slot
-        lm_ids = (self.point_inds[:, ::3]) // 3
+        lm_ids = self.lm_ids.long()
         fom = self.first_obs_mask
         init_Pm = torch.zeros_like(self.P_m)
         init_Pm.index_add_(0, lm_ids.reshape(-1), (init_Pw * fom[..., None]).reshape(-1, 3))
-        reinit_b = init_Pm[lm_ids]                                                # (B,m,3), same remap as P_m
-        Pwm = self.P_m[lm_ids]
-        out = smap.project_landmarks(self.kf_poses, Pwm, K[0], reinit_b, self.median_depths)
+        out = smap.project_landmarks(self.kf_poses, self.P_m[lm_ids], K[0], init_Pm[lm_ids], self.median_depths)
         z_mask = out[2]
         # landmarks re-initialised in their first-observation frame are moved for good (Mapping.py:645-648)
         flag = torch.zeros((self.P_m.shape[0], 1), device=self.dev, dtype=self.dt)
@@ -137,27 +227,21 @@ class WindowBA:
         self.P_m.copy_(torch.where(flag > 0, init_Pm, self.P_m))
         return out
 
-    def dense_reference(self, logzm, dlogzm_dTwc):
-        if self.dense_ref == "hip":
-            from como_amd.odom.backend.dense_ref import dense_reference_factored
-            return dense_reference_factored(logzm.to(self.pix_dtype), self.kf_poses.to(self.pix_dtype), self.Kt, self.pixidx,
-                                            self.K_pix, dlogzm_dTwc.to(self.pix_dtype), self.Wimg)
-        p = self.pix_dtype
-        return smap.dense_reference_factored_torch(logzm.to(p), self.kf_poses.to(p), self.Kt, self.pixidx, self.coords_n,
-                                                  self.K_pix, dlogzm_dTwc.to(p))
-
     def linearize(self):
+        if self.fused:
+            return self.linearize_fused()
         pm, logzm, z_mask, dlogzm_dzm, dzm_dPwm, dzm_dTwc, dpm_dPwm, dpm_dTwc = self.scaffold()
         dlogzm_dTwc = dlogzm_dzm @ dzm_dTwc
         dlogzm_dPwm = dlogzm_dzm @ dzm_dPwm
-        Pwn, dPwn_dTwc, uvec, med, logzn = self.dense_reference(logzm, dlogzm_dTwc)
+        p = self.pix_dtype
+        Pwn, dPwn_dTwc, uvec, med, _ = dense_reference_factored(logzm.to(p), self.kf_poses.to(p), self.Kt, self.pixidx, self.K_pix,
+                                                                dlogzm_dTwc.to(p), self.Wimg, want_logz=False)
         self.median_depths.copy_(med)
         self.pm, self.logzm = pm, logzm
         H, g = self.H, self.g
         self.sys.zero_()
-        p = self.pix_dtype
-        poses_all = torch.cat((self.kf_poses, self.recent_poses)).to(p).contiguous()
-        aff_all = torch.cat((self.kf_aff_params, self.recent_aff_params)).reshape(-1, 2).to(p).contiguous()
+        poses_all = self.poses_all.to(p).contiguous()
+        aff_all = self.aff_all.to(p).contiguous()
         photo.photo_system_factored(self.table, poses_all=poses_all, aff_all=aff_all, Pwn=Pwn, vals=self.vals_n,
                                     dPwn_dTwc=dPwn_dTwc, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx,
                                     invz=dlogzm_dzm[:, :, 0, 0].to(p).contiguous(), dzdP=dzm_dPwm[:, 0, 0, :].to(p).contiguous(),
@@ -166,8 +250,8 @@ class WindowBA:
                                     reduce_hists=(self.shard.all_reduce_sum if self.shard is not None else None),
                                     events=self.events)
         if self.shard is not None:
-            self.shard.all_reduce_sum(self.sys)          # normal equations of all shards: H | g | err in one collective
-        kf_pose_inds, kf_aff_inds = self.kf_inds[:, :6], self.kf_inds[:, 6:]
+            self.shard.all_reduce_sum(self.sys)
+        kf_pose_inds = self.kf_inds[:, :6]
         log_med = torch.log(self.median_depths[:, None, None])
         sg = self.cfg["sigmas"]
         e = [self.err.clone()]
@@ -191,28 +275,24 @@ class WindowBA:
 
     def iterate(self):
         """One GN iteration, eager.  State tensors are updated IN PLACE (fixed addresses -> capturable)."""
+        if self.fused:
+            return self.iterate_fused()
         H, g = self.linearize()
-        delta = self.solve(H, g)
+        delta = lin_sys.solve_system(H, g)
         kp, ka, rp, ra, Pn = lin_sys.update_vars(delta, self.kf_poses, self.kf_aff_params, self.kf_inds, self.recent_poses,
                                                  self.recent_aff_params, self.recent_inds, self.P_m, self.lm_start)
         self.kf_poses.copy_(kp)
         self.kf_aff_params.copy_(ka)
         self.P_m.copy_(Pn)
-        if self.recent_poses.shape[0] > 0:
-            self.recent_poses.copy_(rp)
-            self.recent_aff_params.copy_(ra)
         self.delta = delta
         return delta
 
-    def solve(self, H, g):
-        return lin_sys.solve_system(H, g)
-
-    # ---- hipGraph: the iteration is ~200 small launches; replaying a captured graph removes the host from the loop
+    # ---- hipGraph: replaying a captured iteration removes the host from the loop -----------------------------------
     def capture(self, warmup=3):
         """Capture one GN iteration into a hipGraph (torch.cuda.CUDAGraph).  Returns True on success; on failure the
-        object stays usable in eager mode."""
+        object stays usable in eager mode (the reason is kept in self.capture_error)."""
         if self.shard is not None:
-            return False                      # collectives between kernels: keep the multi-GPU path eager
+            return False                      # collectives between kernels: the multi-GPU path stays eager
         self.graph = None
         try:
             side = torch.cuda.Stream(device=self.dev)
@@ -230,9 +310,9 @@ class WindowBA:
             self.events = ev
             self.graph = g
             return True
-        except Exception as e:   # noqa: BLE001
-            self.graph = None
+        except Exception:   # noqa: BLE001
             import traceback
+            self.graph = None
             self.capture_error = traceback.format_exc()[-1500:]
             try:
                 torch.cuda.synchronize(self.dev)
@@ -242,7 +322,7 @@ class WindowBA:
 
     def step(self):
         """One GN iteration: graph replay when captured, eager otherwise."""
-        if getattr(self, "graph", None) is not None:
+        if self.graph is not None:
             self.graph.replay()
             return self.delta
         return self.iterate()

@@ -177,6 +177,47 @@ long como_chol_workspace_bytes(int D);
 int como_chol_solve_f64(const double* H, const double* g, double* delta, void* workspace, int D, int* info,
                         como_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused O(B*m) bookkeeping of one window GN iteration (python path: Mapping.prep_geometry_scaffold
+ * Mapping.py:603-659 + sparse_map.py:18-60; the prior factors of Mapping.iterate :809-917 = odom/factors/*.py;
+ * linear_system.update_vars :115-152).  All state is float64; px_* are mirrors in the per-pixel dtype. */
+typedef struct como_win_args {
+  int B, F, m, L, nfix;          /* keyframes, frames (keyframes + recent), inducing points per KF, landmarks, anchored landmarks */
+  int pix_is_f64;                /* element type of the px_* outputs */
+  int median_new_is_f32;         /* element type / stride of median_new (the dense-reference kernel's med_out3) */
+  int median_new_stride;
+  long D;
+  const double* poses;           /* (F,4,4) T_wc, keyframes first */
+  const double* aff;             /* (F,2) */
+  const double* K;               /* (3,3) */
+  const double* median;          /* (B) median depths of the PREVIOUS iteration (re-init test, sparse_map.py:26) */
+  const double* pm_first;        /* (B,m,2) first-observation pixel (x,y) */
+  const double* Kmm_inv;         /* (B,m,m) */
+  const double* pose_anchor;     /* (4,4) */
+  const double* aff_anchor;      /* (2) */
+  const double* P_anchor;        /* (nfix,3) */
+  double* P_m;                   /* (L,3) landmarks, re-initialised in place */
+  const int* lm_ids;             /* (B,m) landmark of every (keyframe, slot) */
+  const int* first_frame;        /* (L) first observer keyframe of a landmark */
+  const int* first_slot;         /* (L) its slot there */
+  const int* fix_lm;             /* (nfix) anchored landmark ids */
+  const uint8_t* first_mask;     /* (B,m) obs_ref_mask */
+  const long* pose_inds;         /* (B,8) rows of H */
+  const long* landmark_inds;     /* (B,3m) */
+  const long* fix_inds;          /* (nfix*3) rows of H of the anchored landmark coordinates */
+  const void* median_new;        /* (B) median depths of THIS iteration's dense reference (priors use log of it) */
+  double* pm; double* logzm; double* invz; double* dzdP; double* dlogz_dT; double* dlogz_dP; double* dp_dP; double* dp_dT;
+  double* init_Pm; int* reinit_flag;
+  void* px_logzm; void* px_invz; void* px_dzdP; void* px_dlogz_dT; void* px_poses; void* px_aff;
+  double s_gp, s_ld, s_px, s_pose, s_aff, s_lm;   /* sigmas: 1, 1, 1e-2, cfg pose_prior, cfg scale_prior, cfg scale_prior */
+  double* H; double* g; double* err;              /* err: 8 doubles {gp, log-depth, pixel, pose, affine, landmarks, -, -} */
+} como_win_args;
+
+int como_win_scaffold(const como_win_args* args_host, como_stream_t stream);
+int como_win_priors(const como_win_args* args_host, como_stream_t stream);
+int como_win_update(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
+                    long lm_start, como_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,10 +40,6 @@ def timed(fn, n=10):
 
 
 res = {}
-res["scaffold_ms"], sc = timed(wb.scaffold)
-pm, logzm, z_mask, dlogzm_dzm, dzm_dPwm, dzm_dTwc, dpm_dPwm, dpm_dTwc = sc
-dl = dlogzm_dzm @ dzm_dTwc
-res["dense_ref_ms"], _ = timed(lambda: wb.dense_reference(logzm, dl))
 res["linearize_total_ms"], _ = timed(wb.linearize)
 H, g = wb.linearize()
 res["solve_ms"], delta = timed(lambda: lin_sys.solve_system(H, g))

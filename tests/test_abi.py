@@ -45,6 +45,21 @@ def test_ba_args_struct_matches_header_field_order():
     assert fields == [f[0] for f in _lib.BAArgs._fields_]
 
 
+def test_win_args_struct_matches_header_field_order():
+    from como_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "como_hip.h")).read()
+    body = hdr[hdr.index("typedef struct como_win_args {"):hdr.index("} como_win_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S).split("{", 1)[1]
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        toks = decl.replace("*", " ").replace(",", " ").split()
+        fields += [t for t in toks if t not in ("const", "void", "int", "long", "double", "uint8_t")]
+    assert fields == [f[0] for f in _lib.WinArgs._fields_]
+
+
 def test_product_never_imports_the_oracle():
     bad = []
     for base, _, files in os.walk(os.path.join(ROOT, "como_amd")):

@@ -343,27 +343,28 @@ def test_prep_predictor_vs_golden(name, tol):
 
 def _window_state(G):
     st = {k: dev(G[k]) for k in ("intrinsics", "kf_poses", "kf_aff_params", "kf_img_and_grads", "coords_m", "correspondence_mask",
-                                 "P_m", "kf_timestamps", "obs_ref_mask", "pm_first_obs", "L_mm", "Knm_Kmminv", "pose_anchor", "P_anchor")}
+                                 "P_m", "kf_timestamps", "obs_ref_mask", "pm_first_obs", "L_mm", "K_mm_inv", "Knm_Kmminv", "pose_anchor", "P_anchor")}
     return st
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("pix", [torch.float64, torch.float32])
-def test_window_iterate_vs_golden(pix):
+def test_window_iterate_vs_golden(pix, fused):
     """One full Mapping.iterate()-equivalent (scaffold -> dense ref -> photo system -> priors -> solve -> update)."""
     from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
     import copy
     G = load_golden("ba_window_f64.npz")
     cfg = copy.deepcopy(DEFAULT_CFG)
     cfg["photo_construction"]["nonmax_suppression_window"] = 2
-    wb = WindowBA(_window_state(G), cfg=cfg, pix_dtype=pix, window_full=True)
-    wb.median_depths = dev(G["median_depths_in"])
+    wb = WindowBA(_window_state(G), cfg=cfg, pix_dtype=pix, window_full=True, fused=fused)
+    wb.median_depths.copy_(dev(G["median_depths_in"]))
     H, g = wb.linearize()
     Hrel, grel = rel_err(H, G["H_full"]), rel_err(g, G["g_full"])
-    wb2 = WindowBA(_window_state(G), cfg=cfg, pix_dtype=pix, window_full=True)
-    wb2.median_depths = dev(G["median_depths_in"])
+    wb2 = WindowBA(_window_state(G), cfg=cfg, pix_dtype=pix, window_full=True, fused=fused)
+    wb2.median_depths.copy_(dev(G["median_depths_in"]))
     delta = wb2.iterate()
     perr = (wb2.kf_poses.cpu() - G["kf_poses_new"]).abs().max().item()
-    report("window_iterate", pix=str(pix), H_rel=Hrel, g_rel=grel, delta_rel=rel_err(delta, G["delta"]), pose_err=perr,
+    report("window_iterate", pix=str(pix), fused=fused, H_rel=Hrel, g_rel=grel, delta_rel=rel_err(delta, G["delta"]), pose_err=perr,
            P_err=(wb2.P_m.cpu() - G["P_new"]).abs().max(), info=int(lin_info()))
     tol = 1e-8 if pix == torch.float64 else 2e-3
     assert Hrel < tol and grel < tol
