@@ -394,6 +394,224 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
   }
 }
 
+// ---------------------------------------- pass 2, software-pipelined fast path ---------------------
+// Same maths as ba_blocks_kernel<T, 1>, restructured so that NO memory latency sits between two matrix-core phases
+// of a wave (PMC on the straightforward version: MFMA pipe 44 % busy, 20 k of 28 k wave-cycles per tile spent
+// outside phase B, mostly waiting on the two dependent load rounds of phase A).  Per wave and tile t:
+//     S2(t)   consume the loads issued one tile ago -> 16 pose/affine entries + depth scale + r~ -> LDS
+//     S1(t+1) warp the NEXT tile's points (loaded two stages ago), issue its 12 tap loads + 22 plane loads
+//     S0(t+2) issue the P_w loads of the tile after that
+//     S3(t)   16 MFMA steps; after consuming K~ quad `st` the same register is re-loaded for tile t+1
+// so every load has a full matrix phase (~7.7 k cycles) to land.
+template <typename T, int WPS>
+__global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
+    const T* __restrict__ Pwn, const T* __restrict__ vals, const T* __restrict__ dPwn_dTwc, const T* __restrict__ Kt,
+    const T* __restrict__ uvec, const int* __restrict__ pixidx, const T* __restrict__ invz, long kt_slot_stride,
+    BAPairs pr, const T* __restrict__ pair_T, const T* __restrict__ pair_aff, const T* __restrict__ img_base,
+    const T* __restrict__ Kmat, int H, int W, int n, int m, int pix_begin, int pix_end, int chunk_len,
+    const uint32_t* __restrict__ hists, T* __restrict__ partials, T* __restrict__ sigma_out) {
+  using KeyT = typename KeyOf<T>::type;
+  using Cfg = BACfg;
+  using acc_t = typename Acc4<T>::type;
+  __shared__ SelScratch sc;
+  constexpr int STG = 16 * JP_STRIDE + 64 * 2;
+  constexpr int LDS_ELEMS = (4 * STG > 2 * Cfg::REC) ? 4 * STG : 2 * Cfg::REC;
+  __shared__ T lds[LDS_ELEMS];
+
+  KeyT prefix; uint32_t k_rem, nv;
+  sel_resolve<KeyT>(hists, SelCfg<KeyT>::NPASS, &sc, prefix, k_rem, nv);
+  const T sigma = T(1.4826) * key_value(prefix);
+  const T info_sqrt = T(1) / sigma;
+  if (sigma_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sigma_out[0] = sigma; sigma_out[1] = (T)nv; }
+
+  const int p = blockIdx.y;
+  const int slot = pr.ref_slot[p];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  T* Jp = lds + wv * STG;
+  T* Sv = Jp + 16 * JP_STRIDE;              // [0] r~, [1] s (dI/dPw . u)
+  T Mr[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mr[k] = pair_T[12 * (long)p + k];
+  const T scale = pair_aff[2 * p], bias = pair_aff[2 * p + 1];
+  const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  const T ax = T(1) / T(W), ay = T(1) / T(H);
+  const T* img = img_base + pr.tgt_img[p];
+  const long HW = (long)H * W;
+  T invz4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
+  // lanes whose quad lies beyond m read quad 0 instead (finite values) and are nulled by invz4 = 0: keeps every load
+  // unconditional, so the compiler can count outstanding loads exactly (no exec-mask branches -> no vmcnt(0) stalls)
+  const T* KtS = Kt + (long)slot * kt_slot_stride + ((4 * c < m) ? 4 * c : 0);
+
+  acc_t acc[Cfg::NT];
+#pragma unroll
+  for (int t = 0; t < Cfg::NT; ++t) acc[t] = acc_t{T(0), T(0), T(0), T(0)};
+  T gacc[Cfg::NB];
+#pragma unroll
+  for (int t = 0; t < Cfg::NB; ++t) gacc[t] = T(0);
+  T err = T(0);
+
+  const int begin = pix_begin + blockIdx.x * chunk_len;
+  const int end = min(pix_end, begin + chunk_len);
+  constexpr int PF = 8;
+  V4<T> kq[PF];
+
+  // ---- pipeline registers ----
+  T pw0, pw1, pw2;                     // S0: P_w of the tile that S1 will warp next
+  T tv[12], Dv[18], Uv[3], valv;       // S1: loaded values of the tile S2 will consume
+  T wX = 0, wY = 0, wZ = 0, w00 = 0, w01 = 0, w10 = 0, w11 = 0;
+  bool wok = false;
+  int row_cur = 0, row_nxt = 0;
+
+  auto s0_load = [&](int tile) {
+    const int ic = min(tile + lane, end - 1);
+    pw0 = Pwn[((long)slot * 3 + 0) * n + ic]; pw1 = Pwn[((long)slot * 3 + 1) * n + ic]; pw2 = Pwn[((long)slot * 3 + 2) * n + ic];
+  };
+  auto s1_issue = [&](int tile) {
+    const int i = tile + lane;
+    const bool inr = i < end;
+    const int ic = inr ? i : (end - 1);
+    Warp<T> w = warp_point(Mr, fx, fy, cx, cy, pw0, pw1, pw2, H, W);
+    Taps<T> tp = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
+    wX = w.X; wY = w.Y; wZ = w.Z; wok = inr && w.ok;
+    w00 = tp.w00; w01 = tp.w01; w10 = tp.w10; w11 = tp.w11;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const T* P = img + pl * HW;
+      tv[4 * pl + 0] = P[tp.i00]; tv[4 * pl + 1] = P[tp.i01]; tv[4 * pl + 2] = P[tp.i10]; tv[4 * pl + 3] = P[tp.i11];
+    }
+    const T* D = dPwn_dTwc + (long)slot * 18 * n + ic;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) Dv[k] = D[(long)k * n];
+    const T* U = uvec + (long)slot * 3 * n + ic;
+    Uv[0] = U[0]; Uv[1] = U[n]; Uv[2] = U[2 * (long)n];
+    valv = vals[(long)slot * n + ic];
+    row_nxt = pixidx ? pixidx[(long)slot * n + ic] : ic;
+  };
+  auto s2_rows = [&]() {
+    const T It = w00 * tv[0] + w01 * tv[1] + w10 * tv[2] + w11 * tv[3];
+    const T gx = w00 * tv[4] + w01 * tv[5] + w10 * tv[6] + w11 * tv[7];
+    const T gy = w00 * tv[8] + w01 * tv[9] + w10 * tv[10] + w11 * tv[11];
+    const T Iref_s = scale * valv;
+    const T r = It - Iref_s + bias;
+    const bool ok = wok;
+    const T wr = r * info_sqrt;
+    const T wgt = ok ? huber(wr) : T(0);
+    const T ws = sqrt(wgt);
+    const T s = ok ? info_sqrt * ws : T(0);
+    err += ok ? (ws * wr) * (ws * wr) : T(0);
+    const T iz = ok ? T(1) / wZ : T(0);
+    const T a0 = gx * fx * iz, a1 = gy * fy * iz;
+    const T a2 = -(a0 * wX + a1 * wY) * iz;
+    const T b0 = a0 * Mr[0] + a1 * Mr[4] + a2 * Mr[8];
+    const T b1 = a0 * Mr[1] + a1 * Mr[5] + a2 * Mr[9];
+    const T b2 = a0 * Mr[2] + a1 * Mr[6] + a2 * Mr[10];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) Jp[k * JP_STRIDE + lane] = s * (b0 * Dv[k] + b1 * Dv[6 + k] + b2 * Dv[12 + k]);
+    Jp[6 * JP_STRIDE + lane] = s * Iref_s;
+    Jp[7 * JP_STRIDE + lane] = -s;
+    const T Xc = ok ? wX : T(0), Yc = ok ? wY : T(0), Zc = ok ? wZ : T(0);
+    Jp[8 * JP_STRIDE + lane] = s * (a1 * Zc - a2 * Yc);
+    Jp[9 * JP_STRIDE + lane] = s * (a2 * Xc - a0 * Zc);
+    Jp[10 * JP_STRIDE + lane] = s * (a0 * Yc - a1 * Xc);
+    Jp[11 * JP_STRIDE + lane] = -s * a0;
+    Jp[12 * JP_STRIDE + lane] = -s * a1;
+    Jp[13 * JP_STRIDE + lane] = -s * a2;
+    Jp[14 * JP_STRIDE + lane] = -s * Iref_s;
+    Jp[15 * JP_STRIDE + lane] = s;
+    Sv[lane] = s * r;
+    Sv[64 + lane] = s * (b0 * Uv[0] + b1 * Uv[1] + b2 * Uv[2]);
+  };
+
+  const int tile0 = begin + wv * 64;
+  if (tile0 < end) {
+    // prologue: tile0 through S0+S1, its first PF K~ quads, S0 of the next tile
+    s0_load(tile0);
+    s1_issue(tile0);
+    row_cur = row_nxt;
+    static_for<PF>([&](auto ic_) {
+      constexpr int st = decltype(ic_)::value;
+      const int row = __shfl(row_cur, 4 * st + q, 64);
+      kq[st] = load4(KtS + (long)row * m);
+    });
+    s0_load(tile0 + 256);
+  }
+  for (int tile = tile0; tile < end; tile += 256) {
+    s2_rows();                                   // S2(t)
+    s1_issue(tile + 256);                        // S1(t+1): its loads fly during S3(t) (clamped + masked past the end)
+    s0_load(tile + 512);                         // S0(t+2)
+    __builtin_amdgcn_wave_barrier();
+    for (int half = 0; half < 16 / PF; ++half) {  // S3(t): PF steps unrolled (static ring index), 16/PF rounds
+      static_for<PF>([&](auto ic_) {
+        constexpr int sl = decltype(ic_)::value;
+        const int st = half * PF + sl;
+        const int px = 4 * st + q;
+        T a[Cfg::NB];
+        a[0] = Jp[c * JP_STRIDE + px];
+        const T rt = Sv[px];
+        const T sz = Sv[64 + px];
+        const V4<T> k4 = kq[sl];
+        {   // refill this ring slot: step st+PF of this tile, or step st+PF-16 of the next tile
+          const int nst = st + PF;
+          const bool same = nst < 16;          // (for the last tile row_nxt is a clamped in-range row: a harmless re-read)
+          const int row = __shfl(same ? row_cur : row_nxt, 4 * (same ? nst : nst - 16) + q, 64);
+          kq[sl] = load4(KtS + (long)row * m);
+        }
+        a[1] = sz * k4.x * invz4[0]; a[2] = sz * k4.y * invz4[1]; a[3] = sz * k4.z * invz4[2]; a[4] = sz * k4.w * invz4[3];
+        static_for<Cfg::NB>([&](auto it) { gacc[decltype(it)::value] += a[decltype(it)::value] * rt; });
+        static_for<Cfg::NT>([&](auto it) {
+          constexpr int tt = decltype(it)::value;
+          constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
+          acc[tt] = mfma16(a[ti], a[tj], acc[tt]);
+        });
+      });
+    }
+    __builtin_amdgcn_wave_barrier();
+    row_cur = row_nxt;
+  }
+
+  // ---- epilogue: ordered cross-wave reduction, one record per workgroup (identical to ba_blocks_kernel) ----
+#pragma unroll
+  for (int t = 0; t < Cfg::NB; ++t) {
+    gacc[t] += __shfl_xor(gacc[t], 16, 64);
+    gacc[t] += __shfl_xor(gacc[t], 32, 64);
+  }
+  err = wave_sum(err);
+  auto put = [&](T* dst) {
+#pragma unroll
+    for (int t = 0; t < Cfg::NT; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) dst[t * 256 + rg * 64 + lane] = acc[t][rg];
+    if (lane < 16) {
+#pragma unroll
+      for (int t = 0; t < Cfg::NB; ++t) dst[Cfg::NT * 256 + t * 16 + lane] = gacc[t];
+    }
+    if (lane == 0) dst[Cfg::NT * 256 + Cfg::NB * 16] = err;
+  };
+  auto add = [&](const T* src) {
+#pragma unroll
+    for (int t = 0; t < Cfg::NT; ++t)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) acc[t][rg] += src[t * 256 + rg * 64 + lane];
+#pragma unroll
+    for (int t = 0; t < Cfg::NB; ++t) gacc[t] += src[Cfg::NT * 256 + t * 16 + (lane & 15)];
+    err += src[Cfg::NT * 256 + Cfg::NB * 16];
+  };
+  __syncthreads();
+  if (wv >= 2) put(lds + (wv - 2) * Cfg::REC);
+  __syncthreads();
+  if (wv < 2) add(lds + wv * Cfg::REC);
+  __syncthreads();
+  if (wv == 1) put(lds);
+  __syncthreads();
+  if (wv == 0) {
+    add(lds);
+    put(partials + (long)(p * gridDim.x + blockIdx.x) * Cfg::REC);
+  }
+}
+
 // ---------------------------------------- stage 2 ------------------------------------------------
 // One thread per record element: fixed-order fp64 sum over the pair's wave partials, then the
 // landmark expansion (photo.py:169-182) and accumulation into H / g (photo.py:184-231).
@@ -524,7 +742,26 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
                      (const T*)A->dPwn_dTwc, (const T*)A->zjac, (const T*)A->uvec, A->pixidx, (const T*)A->invz,      \
                      A->kt_slot_stride, pr, pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, m, \
                      pb, pe, chunk_len, hists, (T*)A->ws_partials, (T*)A->sigma_out)
-    if (A->zmode == 0) { LAUNCH_BLOCKS(0); } else { LAUNCH_BLOCKS(1); }
+    if (A->zmode == 0) {
+      LAUNCH_BLOCKS(0);
+    } else if (A->variant == 1) {
+      LAUNCH_BLOCKS(1);                                    // straightforward fused version (kept for A/B runs)
+    } else {
+      // float32 only: the double build of the pipelined kernel needs > 512 registers (spills) -- the float64 pixel
+      // path keeps the straightforward kernel.  variant 0: two waves per SIMD (244 VGPRs, no spills); 3: one wave.
+#define LAUNCH_PIPE(WPS)                                                                                             \
+  hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, WPS>), grid, blk, 0, s, (const float*)A->Pwn, (const float*)A->vals, \
+                     (const float*)A->dPwn_dTwc, (const float*)A->zjac, (const float*)A->uvec, A->pixidx,             \
+                     (const float*)A->invz, A->kt_slot_stride, pr, (const float*)pair_T, (const float*)pair_aff,      \
+                     (const float*)A->img_base, (const float*)A->K, A->H, A->W, n, m, pb, pe, chunk_len, hists,       \
+                     (float*)A->ws_partials, (float*)A->sigma_out)
+      if constexpr (sizeof(T) == 4) {
+        if (A->variant == 3) { LAUNCH_PIPE(1); } else { LAUNCH_PIPE(2); }
+      } else {
+        LAUNCH_BLOCKS(1);
+      }
+#undef LAUNCH_PIPE
+    }
 #undef LAUNCH_BLOCKS
     COMO_CHECK_LAUNCH();
   }

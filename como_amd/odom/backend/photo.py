@@ -15,6 +15,7 @@ from como_amd import _lib
 from como_amd.odom.backend.graph_pair_construction import setup_photometric_pairs
 
 _ws = {}
+BLOCK_VARIANT = int(__import__("os").environ.get("COMO_BA_VARIANT", "0"))   # 0 = software-pipelined block kernel, 1 = plain
 last_aux = {}   # diagnostics of the most recent call: valid mask, sigma, nvalid (tests / callers that want them)
 
 
@@ -56,6 +57,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     a = _lib.BAArgs()
     a.b, a.n, a.m, a.H, a.W, a.zmode, a.chunks, a.phase = b, n, m, H_img, W_img, zmode, chunks, phase
     a.pix_begin, a.pix_end = pb, pe
+    a.variant = BLOCK_VARIANT
     a.h_is_f64 = 1 if H.dtype == torch.float64 else 0
     ws_r = _buf("r", (b, nl), dtype, dev)
     ws_valid = _buf("valid", (b, nl), torch.uint8, dev)
