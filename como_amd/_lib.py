@@ -20,7 +20,7 @@ class BAArgs(ctypes.Structure):
     """Mirror of `struct como_ba_args` (include/como_hip.h) -- field order must match."""
     _fields_ = [
         ("b", c_int), ("n", c_int), ("m", c_int), ("H", c_int), ("W", c_int), ("zmode", c_int), ("chunks", c_int),
-        ("phase", c_int), ("h_is_f64", c_int), ("variant", c_int), ("pix_begin", c_int), ("pix_end", c_int),
+        ("phase", c_int), ("h_is_f64", c_int), ("variant", c_int), ("stagger", c_int), ("pix_begin", c_int), ("pix_end", c_int),
         ("Pwn", c_void_p), ("vals", c_void_p), ("dPwn_dTwc", c_void_p), ("zjac", c_void_p), ("uvec", c_void_p),
         ("pixidx", c_void_p), ("invz", c_void_p), ("kt_slot_stride", c_long), ("poses_all", c_void_p),
         ("aff_all", c_void_p), ("img_base", c_void_p), ("K", c_void_p), ("ref_slot", c_void_p), ("ref_aff", c_void_p),

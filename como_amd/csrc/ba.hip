@@ -403,13 +403,13 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
 //     S0(t+2) issue the P_w loads of the tile after that
 //     S3(t)   16 MFMA steps; after consuming K~ quad `st` the same register is re-loaded for tile t+1
 // so every load has a full matrix phase (~7.7 k cycles) to land.
-template <typename T, int WPS>
+template <typename T, int WPS, int ABL = 0>   // ABL (ablation, timing only): 1 = no MFMA, 2 = no S2 arithmetic, 3 = no loads in S1
 __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
     const T* __restrict__ Pwn, const T* __restrict__ vals, const T* __restrict__ dPwn_dTwc, const T* __restrict__ Kt,
     const T* __restrict__ uvec, const int* __restrict__ pixidx, const T* __restrict__ invz, long kt_slot_stride,
     BAPairs pr, const T* __restrict__ pair_T, const T* __restrict__ pair_aff, const T* __restrict__ img_base,
     const T* __restrict__ Kmat, int H, int W, int n, int m, int pix_begin, int pix_end, int chunk_len,
-    const uint32_t* __restrict__ hists, T* __restrict__ partials, T* __restrict__ sigma_out) {
+    const uint32_t* __restrict__ hists, T* __restrict__ partials, T* __restrict__ sigma_out, int stagger) {
   using KeyT = typename KeyOf<T>::type;
   using Cfg = BACfg;
   using acc_t = typename Acc4<T>::type;
@@ -491,6 +491,17 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
     row_nxt = pixidx ? pixidx[(long)slot * n + ic] : ic;
   };
   auto s2_rows = [&]() {
+    if constexpr (ABL == 2) {
+#pragma unroll
+      for (int k2 = 0; k2 < 12; ++k2) asm volatile("" ::"v"(tv[k2]));
+#pragma unroll
+      for (int k2 = 0; k2 < 18; ++k2) asm volatile("" ::"v"(Dv[k2]));
+      asm volatile("" ::"v"(Uv[0]), "v"(Uv[1]), "v"(Uv[2]), "v"(valv));
+#pragma unroll
+      for (int k2 = 0; k2 < 16; ++k2) Jp[k2 * JP_STRIDE + lane] = T(0.001) * T(k2 + lane);
+      Sv[lane] = T(0.01); Sv[64 + lane] = T(0.02);
+      return;
+    }
     const T It = w00 * tv[0] + w01 * tv[1] + w10 * tv[2] + w11 * tv[3];
     const T gx = w00 * tv[4] + w01 * tv[5] + w10 * tv[6] + w11 * tv[7];
     const T gy = w00 * tv[8] + w01 * tv[9] + w10 * tv[10] + w11 * tv[11];
@@ -525,6 +536,14 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
     Sv[64 + lane] = s * (b0 * Uv[0] + b1 * Uv[1] + b2 * Uv[2]);
   };
 
+  // Phase stagger: the two waves that share a SIMD (one from each co-resident workgroup) would otherwise run in
+  // lockstep -- both in the VALU stages, then both fighting for the matrix pipe.  Odd hardware wave slots start half a
+  // tile period later, so one wave's S3 overlaps the other's S2/S1 from then on (all tiles take the same time).
+  if (stagger > 0) {
+    const unsigned wave_slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4);   // HW_REG_HW_ID.WAVE_ID
+    if (wave_slot & 1u)
+      for (int k = 0; k < stagger; ++k) __builtin_amdgcn_s_sleep(16);                   // 16 x 64 cycles each
+  }
   const int tile0 = begin + wv * 64;
   if (tile0 < end) {
     // prologue: tile0 through S0+S1, its first PF K~ quads, S0 of the next tile
@@ -561,11 +580,15 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
         }
         a[1] = sz * k4.x * invz4[0]; a[2] = sz * k4.y * invz4[1]; a[3] = sz * k4.z * invz4[2]; a[4] = sz * k4.w * invz4[3];
         static_for<Cfg::NB>([&](auto it) { gacc[decltype(it)::value] += a[decltype(it)::value] * rt; });
-        static_for<Cfg::NT>([&](auto it) {
-          constexpr int tt = decltype(it)::value;
-          constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
-          acc[tt] = mfma16(a[ti], a[tj], acc[tt]);
-        });
+        if constexpr (ABL == 1) {
+          asm volatile("" ::"v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]));
+        } else {
+          static_for<Cfg::NT>([&](auto it) {
+            constexpr int tt = decltype(it)::value;
+            constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
+            acc[tt] = mfma16(a[ti], a[tj], acc[tt]);
+          });
+        }
       });
     }
     __builtin_amdgcn_wave_barrier();
@@ -754,13 +777,23 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
                      (const float*)A->dPwn_dTwc, (const float*)A->zjac, (const float*)A->uvec, A->pixidx,             \
                      (const float*)A->invz, A->kt_slot_stride, pr, (const float*)pair_T, (const float*)pair_aff,      \
                      (const float*)A->img_base, (const float*)A->K, A->H, A->W, n, m, pb, pe, chunk_len, hists,       \
-                     (float*)A->ws_partials, (float*)A->sigma_out)
+                     (float*)A->ws_partials, (float*)A->sigma_out, A->stagger)
+#define LAUNCH_PIPE_ABL(AB)                                                                                           \
+  hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2, AB>), grid, blk, 0, s, (const float*)A->Pwn, (const float*)A->vals, \
+                     (const float*)A->dPwn_dTwc, (const float*)A->zjac, (const float*)A->uvec, A->pixidx,             \
+                     (const float*)A->invz, A->kt_slot_stride, pr, (const float*)pair_T, (const float*)pair_aff,      \
+                     (const float*)A->img_base, (const float*)A->K, A->H, A->W, n, m, pb, pe, chunk_len, hists,       \
+                     (float*)A->ws_partials, (float*)A->sigma_out, A->stagger)
       if constexpr (sizeof(T) == 4) {
-        if (A->variant == 3) { LAUNCH_PIPE(1); } else { LAUNCH_PIPE(2); }
+        if (A->variant == 3) { LAUNCH_PIPE(1); }
+        else if (A->variant == 11) { LAUNCH_PIPE_ABL(1); }
+        else if (A->variant == 12) { LAUNCH_PIPE_ABL(2); }
+        else { LAUNCH_PIPE(2); }
       } else {
         LAUNCH_BLOCKS(1);
       }
 #undef LAUNCH_PIPE
+#undef LAUNCH_PIPE_ABL
     }
 #undef LAUNCH_BLOCKS
     COMO_CHECK_LAUNCH();

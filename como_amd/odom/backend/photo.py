@@ -16,6 +16,7 @@ from como_amd.odom.backend.graph_pair_construction import setup_photometric_pair
 
 _ws = {}
 BLOCK_VARIANT = int(__import__("os").environ.get("COMO_BA_VARIANT", "0"))   # 0 = software-pipelined block kernel, 1 = plain
+BLOCK_STAGGER = int(__import__("os").environ.get("COMO_BA_STAGGER", "0"))
 last_aux = {}   # diagnostics of the most recent call: valid mask, sigma, nvalid (tests / callers that want them)
 
 
@@ -58,6 +59,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     a.b, a.n, a.m, a.H, a.W, a.zmode, a.chunks, a.phase = b, n, m, H_img, W_img, zmode, chunks, phase
     a.pix_begin, a.pix_end = pb, pe
     a.variant = BLOCK_VARIANT
+    a.stagger = BLOCK_STAGGER
     a.h_is_f64 = 1 if H.dtype == torch.float64 else 0
     ws_r = _buf("r", (b, nl), dtype, dev)
     ws_valid = _buf("valid", (b, nl), torch.uint8, dev)

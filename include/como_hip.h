@@ -78,6 +78,7 @@ typedef struct como_ba_args {
   int phase;                 /* bit mask: 1 setup+residual(+hist pass 0), 2<<(p-1) hist pass p>=1, 64 blocks, 128 reduce+assemble */
   int h_is_f64;              /* element type of Hmat / gvec: 1 = double, 0 = float */
   int variant;               /* zmode 1 only: 0 = software-pipelined block kernel (float32; default), 1 = straightforward one */
+  int stagger;               /* pipelined kernel: start delay (x1024 cycles) of odd hardware wave slots, 0 = none */
   int pix_begin, pix_end;    /* reference-pixel range [begin,end) of every pair handled by this call (multi-GPU shard);
                                 pix_end <= 0 means n.  ws_r / ws_valid / pj_out are then (b, end-begin). */
   const void* Pwn;           /* zmode 0: (slots,n,3) photo.py:86 ; zmode 1: planes (slots,3,n) */

@@ -68,10 +68,12 @@ def run(dtype, window, iters=10):
 
 if __name__ == "__main__":
     out = {}
-    sel = [a for a in sys.argv[1:] if not a.startswith("v=")]
+    sel = [a for a in sys.argv[1:] if not (a.startswith("v=") or a.startswith("s="))]
     for a in sys.argv[1:]:
         if a.startswith("v="):
             photo.BLOCK_VARIANT = int(a[2:])
+        if a.startswith("s="):
+            photo.BLOCK_STAGGER = int(a[2:])
     for dtype, nm in ((torch.float32, "f32"), (torch.float64, "f64")):
         for window in (1, 4):
             if sel and f"{nm}_w{window}" not in sel:
