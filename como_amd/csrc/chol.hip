@@ -6,10 +6,9 @@
 //
 //   chol_pack      : W (Dp x Dp workspace) <- lower(H), with g appended as row D (so the forward substitution
 //                    L y = g falls out of the factorisation: row D of L is y^T) and an identity pad up to Dp = 64 * nb.
-//   chol_panel(k)  : grid = 1 + #tiles (i,j), k < j <= i.  Every workgroup factors the CBxCB diagonal block A_kk in LDS
-//                    (redundantly -- the CUs would idle otherwise), solves its two panel blocks L_ik, L_jk against it
-//                    and updates ITS trailing tile A_ij -= L_ik L_jk^T.  Workgroup 0 stores L_kk, diagonal-tile
-//                    workgroups store L_ik.  A non-positive pivot is reported in `info` (1-based, first failure)
+//   chol_first / chol_panel(k): look-ahead panels (see the kernels): one launch per 32-column panel, the panel solve is
+//                    a GEMM against the pre-inverted diagonal block, the next diagonal block is factored and inverted
+//                    by the workgroup that just updated it.  A non-positive pivot is reported in `info` (1-based, first failure)
 //                    instead of being swallowed; the factorisation then continues with pivot 1 as a defined value.
 //   chol_backsub   : one workgroup, L^T delta = y, right-to-left over the 64-blocks.
 #include "common.cuh"
@@ -37,16 +36,7 @@ __global__ __launch_bounds__(256) void chol_pack_kernel(const double* __restrict
   W[idx] = v;
 }
 
-// ---- register-resident 32x32 tile kernels: lane r of wave 0 owns row r; cross-lane operands come from
-// v_readlane (compile-time lane index), every loop is unrolled at compile time -> no LDS / memory latency on the
-// serial pivot chain.
-__device__ __forceinline__ double readlane_d(double x, int l) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_readlane(lo, l);
-  hi = __builtin_amdgcn_readlane(hi, l);
-  return __hiloint2double(hi, lo);
-}
-
+// ---- register-resident 32x32 tile kernels: lane r of wave 0 owns row r, every loop is unrolled at compile time.
 // reciprocal: hardware estimate + two Newton steps (double accuracy)
 __device__ __forceinline__ double fast_rcp(double d) {
   double r = __builtin_amdgcn_rcp(d);
@@ -60,67 +50,129 @@ __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...
 template <int N, typename F>
 __device__ __forceinline__ void sfor(F&& f) { sfor_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
-// Right-looking Cholesky of the tile held as rows in a[CB] (lanes 0..CB-1).  On exit lane r holds L[r][0..r].
-__device__ __forceinline__ void factor_rows(double (&a)[CB], int lane, int row0, int D, int* __restrict__ info, bool report) {
-  sfor<CB>([&](auto ic) {
-    constexpr int c = decltype(ic)::value;
-    double d = readlane_d(a[c], c);
-    if (!(d > 0.0)) {
-      if (report && lane == 0 && row0 + c < D) atomicCAS(info, 0, row0 + c + 1);
+// Factor the CBxCB tile held by 256 threads (thread (ty, tx) owns elements (ty+16a, tx+16b), lower part valid) and invert
+// the factor, fused into ONE rolled loop with a single barrier per pivot.  (A fully unrolled single-wave register
+// version was instruction-fetch bound: ~40 KB of straight-line code executed once per launch.)
+//   step c, publish : owners of column c store the raw column; owners of inverse row c-1 store X[c-1][:]
+//   barrier
+//   step c, apply   : A[r][cc] -= A[r][c] A[cc][c] / d  (cc > c);   L[:,c] = A[:,c] / sqrt(d) -> Lw
+//                     S[i][:] -= L[i][c-1] X[c-1][:]     (i > c-1)   (forward substitution, one pivot behind)
+// sC: 3 x CB doubles (column ring: read during two steps), sX: 2 x CB doubles; oL, oX: CB x CLD staging tiles (global
+// stores inside the loop would stall every barrier on vmcnt(0)).
+__device__ __forceinline__ void factor_invert_tile(double (&v)[2][2], double* sC, double* sX, double* oL, double* oX,
+                                                   double* __restrict__ Lw,
+                                                   double* __restrict__ Iw, int Dp, int k, int D, int* __restrict__ info) {
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const long kk = (long)k * CB;
+  double S[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) S[a][b] = (ty + 16 * a == tx + 16 * b) ? 1.0 : 0.0;
+  double isq_prev = 0.0, pend0 = 0.0, pend1 = 0.0;
+  int ring = 0;                                        // c % 3
+  // every step: all LDS stores, ONE barrier, all LDS loads in one batch, then arithmetic only (selects, no branches):
+  // each extra store->load ordering inside a step costs a full LDS round trip on the serial chain
+  for (int c = 0; c <= CB; ++c) {
+    double* col = sC + ring * CB;
+    const double* colp = sC + (ring == 0 ? 2 : ring - 1) * CB;
+    double* xr = sX + (c & 1) * CB;
+    const int t = c - 1;
+    if (c < CB && tx == (c & 15)) {
+      const bool hi = c >= 16;
+      col[ty] = hi ? v[0][1] : v[0][0];
+      col[ty + 16] = hi ? v[1][1] : v[1][0];
+    }
+    if (c > 0) {
+      if (tx == (t & 15)) {                            // column t of L, finished in the previous step
+        oL[ty * CLD + t] = pend0;
+        oL[(ty + 16) * CLD + t] = pend1;
+      }
+      if (ty == (t & 15)) {                            // row t of the inverse
+        const bool hi = t >= 16;
+        const double x0 = (hi ? S[1][0] : S[0][0]) * isq_prev, x1 = (hi ? S[1][1] : S[0][1]) * isq_prev;
+        xr[tx] = x0;
+        xr[tx + 16] = x1;
+        oX[t * CLD + tx] = (tx <= t) ? x0 : 0.0;
+        oX[t * CLD + tx + 16] = (tx + 16 <= t) ? x1 : 0.0;
+      }
+    }
+    __syncthreads();
+    const int cs = (c < CB) ? c : CB - 1;
+    double d = col[cs];
+    const double c0 = col[tx], c1 = col[tx + 16], r0 = col[ty], r1 = col[ty + 16];
+    double x0 = xr[tx], x1 = xr[tx + 16];
+    const double p0 = colp[ty], p1 = colp[ty + 16];
+    if (c == 0) { x0 = 0.0; x1 = 0.0; }                 // nothing published yet (0 * garbage would poison S)
+    if (c < CB && !(d > 0.0)) {
+      if (tid == 0 && kk + c < D) atomicCAS(info, 0, (int)kk + c + 1);
       d = 1.0;
     }
-    // 1/sqrt(d) from the hardware estimate + two Newton steps (full double accuracy, ~12 instructions instead of
-    // the ~70 of an IEEE sqrt followed by an IEEE divide -- this chain is the serial critical path of the solve)
-    double inv = __builtin_amdgcn_rsq(d);
-    inv = inv * (1.5 - 0.5 * d * inv * inv);
-    inv = inv * (1.5 - 0.5 * d * inv * inv);
-    const double ld = d * inv;
-    a[c] = (lane == c) ? ld : a[c] * inv;
-    sfor<CB - 1 - c>([&](auto jc) {
-      constexpr int cc = c + 1 + decltype(jc)::value;
-      a[cc] -= a[c] * readlane_d(a[c], cc);          // A[r][cc] -= L[r][c] L[cc][c]
-    });
-  });
+    const double rinv = fast_rcp(d);
+    double isq = __builtin_amdgcn_rsq(d);
+    isq = isq * (1.5 - 0.5 * d * isq * isq);
+    isq = isq * (1.5 - 0.5 * d * isq * isq);
+    const bool live = c < CB;
+    const double w0 = r0 * rinv, w1 = r1 * rinv;
+    const double m0 = (live && tx > c) ? c0 : 0.0, m1 = (live && tx + 16 > c) ? c1 : 0.0;
+    v[0][0] -= w0 * m0;
+    v[0][1] -= w0 * m1;
+    v[1][0] -= w1 * m0;
+    v[1][1] -= w1 * m1;
+    pend0 = (ty == c) ? d * isq : r0 * isq;
+    pend1 = (ty + 16 == c) ? d * isq : r1 * isq;
+    const double l0 = (c > 0 && ty > t) ? p0 * isq_prev : 0.0, l1 = (c > 0 && ty + 16 > t) ? p1 * isq_prev : 0.0;
+    S[0][0] -= l0 * x0;
+    S[0][1] -= l0 * x1;
+    S[1][0] -= l1 * x0;
+    S[1][1] -= l1 * x1;
+    isq_prev = isq;
+    ring = (ring == 2) ? 0 : ring + 1;
+  }
+  __syncthreads();
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int r = e / CB, c = e % CB;
+    if (c <= r) Lw[(kk + r) * Dp + kk + c] = oL[r * CLD + c];
+    Iw[(long)k * CB * CB + e] = oX[r * CLD + c];
+  }
 }
 
-// x <- x L^-T (row per lane, all 64 lanes: two 32-row blocks at once); L rows live in a[] of lanes 0..CB-1.
-__device__ __forceinline__ void trsm_rows(double (&x)[CB], const double (&a)[CB]) {
-  sfor<CB>([&](auto ic) {
-    constexpr int c = decltype(ic)::value;
-    sfor<c>([&](auto jt) {
-      constexpr int t = decltype(jt)::value;
-      x[c] -= x[t] * readlane_d(a[t], c);            // L[c][t] sits in lane c
-    });
-    x[c] *= fast_rcp(readlane_d(a[c], c));
-  });
+// Look-ahead blocked Cholesky.  chol_first: L_00, L_00^-1.  chol_panel(k), k = 0..nb-2, one launch each, one workgroup
+// per trailing tile (i, j), k < j <= i:  L_ik = A_ik L_kk^-T as a 32^3 GEMM against the PRE-INVERTED diagonal block
+// (no serial triangular solve), A_ij -= L_ik L_jk^T, and the workgroup that owns tile (k+1, k+1) immediately factors and
+// inverts it for the next launch -- the only serial work left on the critical path of a panel.
+// W: working copy (trailing tiles updated in place); Lw: the factor (a SEPARATE matrix: other workgroups of the launch
+// still read the un-factored panel blocks from W); Iw: inverses of the diagonal blocks of L (nb x CB x CB).
+__global__ __launch_bounds__(256) void chol_first_kernel(const double* __restrict__ W, double* __restrict__ Lw,
+                                                         double* __restrict__ Iw, int Dp, int D, int* __restrict__ info) {
+  __shared__ double sC[3 * CB];
+  __shared__ double sX[2 * CB];
+  __shared__ double oL[CB * CLD];
+  __shared__ double oX[CB * CLD];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  double v[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int r = ty + 16 * a, c = tx + 16 * b;
+      v[a][b] = (c <= r) ? W[(long)r * Dp + c] : 0.0;
+    }
+  factor_invert_tile(v, sC, sX, oL, oX, Lw, Iw, Dp, 0, D, info);
 }
 
-// inverse of the lower-triangular tile: lane j computes column j of L^-1 (stored as row j of inv^T): forward substitution
-__device__ __forceinline__ void invert_rows(double (&v)[CB], const double (&a)[CB], int lane) {
-  // v[i] = (L^-1)[i][lane]
-  sfor<CB>([&](auto ii) {
-    constexpr int i = decltype(ii)::value;
-    double s = (lane == i) ? 1.0 : 0.0;
-    sfor<i>([&](auto jt) {
-      constexpr int t = decltype(jt)::value;
-      s -= readlane_d(a[t], i) * v[t];               // L[i][t] (lane i) * inv[t][lane]
-    });
-    v[i] = s * fast_rcp(readlane_d(a[i], i));
-  });
-}
-
-// W: working copy (trailing tiles updated in place); Lw: the factor (blocks go to a SEPARATE matrix because other
-// workgroups of the same launch still read the un-factored panel blocks A_ik / A_kk from W); Iw: inverses of the
-// diagonal blocks of L (nb x CB x CB, [k][i][j] = (L_kk^-1)[i][j]) for the back-substitution.
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ W, double* __restrict__ Lw,
                                                          double* __restrict__ Iw, int Dp, int D, int k, int nb,
                                                          int* __restrict__ info) {
-  __shared__ double sI[CB * CLD];      // L_ik
+  __shared__ double sV[CB * CLD];      // L_kk^-1
+  __shared__ double sA[CB * CLD];      // A_ik
+  __shared__ double sB[CB * CLD];      // A_jk
+  __shared__ double sI[CB * CLD];      // L_ik (later: the rings of factor_invert_tile)
   __shared__ double sJ[CB * CLD];      // L_jk
   const int tid = threadIdx.x;
   int ti = -1, tj = -1;
-  if (blockIdx.x > 0) {
-    int t = blockIdx.x - 1;
+  {
+    int t = blockIdx.x;
     for (int i = k + 1; i < nb; ++i) {
       const int cnt = i - k;                 // j = k+1 .. i
       if (t < cnt) { ti = i; tj = k + 1 + t; break; }
@@ -128,53 +180,48 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ W,
     }
   }
   const long kk = (long)k * CB;
-  if (tid < 64) {                            // wave 0: factor + triangular solves in registers
-    const int lane = tid;
-    double a[CB], x[CB];
-    {
-      const int r = lane & (CB - 1);
-      const double* src = W + (kk + r) * Dp + kk;
-#pragma unroll
-      for (int c = 0; c < CB; ++c) a[c] = src[c];
-    }
-    if (ti >= 0) {
-      const int r = lane & (CB - 1);
-      const double* src = W + ((long)((lane < CB) ? ti : tj) * CB + r) * Dp + kk;
-#pragma unroll
-      for (int c = 0; c < CB; ++c) x[c] = src[c];
-    }
-    factor_rows(a, lane, (int)kk, D, info, blockIdx.x == 0);
-    if (blockIdx.x == 0) {
-      if (lane < CB) {
-        double* dst = Lw + (kk + lane) * Dp + kk;
-#pragma unroll
-        for (int c = 0; c < CB; ++c)
-          if (c <= lane) dst[c] = a[c];
-      }
-      double v[CB];
-      invert_rows(v, a, lane);
-      if (lane < CB) {
-#pragma unroll
-        for (int i = 0; i < CB; ++i) Iw[((long)k * CB + i) * CB + lane] = (i >= lane) ? v[i] : 0.0;
-      }
-    } else {
-      trsm_rows(x, a);
-      double* dstS = (lane < CB) ? sI : sJ;
-      const int r = lane & (CB - 1);
-#pragma unroll
-      for (int c = 0; c < CB; ++c) dstS[r * CLD + c] = x[c];
-      if (tj == ti && lane < CB) {           // the diagonal-tile workgroup of block-row i publishes L_ik
-        double* dst = Lw + ((long)ti * CB + r) * Dp + kk;
-#pragma unroll
-        for (int c = 0; c < CB; ++c) dst[c] = x[c];
-      }
-    }
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int r = e / CB, c = e % CB;
+    sV[r * CLD + c] = Iw[((long)k * CB + r) * CB + c];
+    sA[r * CLD + c] = W[((long)ti * CB + r) * Dp + kk + c];
+    sB[r * CLD + c] = W[((long)tj * CB + r) * Dp + kk + c];
   }
-  if (blockIdx.x == 0) return;
   __syncthreads();
-  // A_ij -= L_ik L_jk^T : 16x16 threads, (CB/16)^2 outputs each
   const int tx = tid & 15, ty = tid >> 4;
   constexpr int RT = CB / 16;
+  // L_ik[r][c] = sum_t A_ik[r][t] Linv[c][t]   (and the same for j)
+  {
+    double ai[RT][RT], aj[RT][RT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+      for (int b = 0; b < RT; ++b) { ai[a][b] = 0.0; aj[a][b] = 0.0; }
+#pragma unroll 8
+    for (int t = 0; t < CB; ++t) {
+      double xi[RT], xj[RT], vv[RT];
+#pragma unroll
+      for (int a = 0; a < RT; ++a) { xi[a] = sA[(ty + 16 * a) * CLD + t]; xj[a] = sB[(ty + 16 * a) * CLD + t]; vv[a] = sV[(tx + 16 * a) * CLD + t]; }
+#pragma unroll
+      for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < RT; ++b) { ai[a][b] += xi[a] * vv[b]; aj[a][b] += xj[a] * vv[b]; }
+    }
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+      for (int b = 0; b < RT; ++b) {
+        sI[(ty + 16 * a) * CLD + tx + 16 * b] = ai[a][b];
+        sJ[(ty + 16 * a) * CLD + tx + 16 * b] = aj[a][b];
+      }
+  }
+  __syncthreads();
+  if (tj == ti) {   // the diagonal-tile workgroup of block-row i publishes L_ik
+    for (int e = tid; e < CB * CB; e += 256) {
+      const int r = e / CB, c = e % CB;
+      Lw[((long)ti * CB + r) * Dp + kk + c] = sI[r * CLD + c];
+    }
+  }
+  // A_ij -= L_ik L_jk^T : 16x16 threads, (CB/16)^2 outputs each
   double acc[RT][RT];
 #pragma unroll
   for (int a = 0; a < RT; ++a)
@@ -190,13 +237,28 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ W,
 #pragma unroll
       for (int b = 0; b < RT; ++b) acc[a][b] += xi[a] * xj[b];
   }
+  const bool next_diag = (ti == k + 1) && (tj == k + 1);
+  if (!next_diag) {
 #pragma unroll
-  for (int a = 0; a < RT; ++a)
+    for (int a = 0; a < RT; ++a)
 #pragma unroll
-    for (int b = 0; b < RT; ++b) {
-      const int r = ty + 16 * a, c = tx + 16 * b;
-      if (ti != tj || c <= r) W[((long)ti * CB + r) * Dp + (long)tj * CB + c] -= acc[a][b];
-    }
+      for (int b = 0; b < RT; ++b) {
+        const int r = ty + 16 * a, c = tx + 16 * b;
+        if (ti != tj || c <= r) W[((long)ti * CB + r) * Dp + (long)tj * CB + c] -= acc[a][b];
+      }
+  } else {
+    // the updated diagonal tile stays in registers and is factored + inverted right here for the next launch
+    double v[2][2];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+      for (int b = 0; b < RT; ++b) {
+        const int r = ty + 16 * a, c = tx + 16 * b;
+        v[a][b] = (c <= r) ? W[((long)ti * CB + r) * Dp + (long)tj * CB + c] - acc[a][b] : 0.0;
+      }
+    __syncthreads();                                   // sA / sB / sI / sJ are dead: rings in sI, staging tiles in sA / sB
+    factor_invert_tile(v, sI, sI + 3 * CB, sA, sB, Lw, Iw, Dp, k + 1, D, info);
+  }
 }
 
 // L^T delta = y with y = row D of L (columns 0..D-1).  One workgroup of 1024 threads.
@@ -258,10 +320,12 @@ int como_chol_solve_f64(const double* H, const double* g, double* delta, void* w
   hipLaunchKernelGGL(chol_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, H, g, W, D, Dp, info);
   COMO_CHECK_LAUNCH();
   if (Dp > 4096) return COMO_ERR_ARG;
-  for (int k = 0; k < nb; ++k) {
+  hipLaunchKernelGGL(chol_first_kernel, dim3(1), dim3(256), 0, s, W, Lw, Iw, Dp, D, info);
+  COMO_CHECK_LAUNCH();
+  for (int k = 0; k + 1 < nb; ++k) {
     const int r = nb - 1 - k;
     const int tiles = r * (r + 1) / 2;
-    hipLaunchKernelGGL(chol_panel_kernel, dim3(1 + tiles), dim3(256), 0, s, W, Lw, Iw, Dp, D, k, nb, info);
+    hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(256), 0, s, W, Lw, Iw, Dp, D, k, nb, info);
     COMO_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(1024), 0, s, Lw, Iw, Dp, D, nb, delta);
