@@ -117,6 +117,127 @@ __global__ __launch_bounds__(256) void dense_ref_kernel(
   sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
 }
 
+// float32 fast path: the (pixels x m) . (m x 7) product runs on the matrix cores straight out of the load registers.
+// One wave owns 64 consecutive pixels; load (it, s) of lane (c = l & 15, q = l >> 4) fetches the 16 bytes
+// K~[pixel 16 it + c][16 s + 4 q ..+3], i.e. every wave-load touches 16 rows x 64 contiguous bytes (the thread-per-row
+// version touched 64 rows x 16 bytes: four times the cache-line lookups for the same data).  Those registers ARE the A
+// operands of v_mfma_f32_16x16x4_f32 (row = l & 15, k = l >> 4; the k permutation k = 16 s + 4 q + e is applied to the
+// coefficient operand too); D (rows 4 q + r, column l & 15) goes through a 2 KB LDS transpose so that the epilogue
+// (exp, ray, pose Jacobian, 27 coalesced plane stores) runs one pixel per lane.
+typedef float mf4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
+    const float* __restrict__ Kt, long kt_slot_stride, const int* __restrict__ pixidx, const float* __restrict__ logzm,
+    const float* __restrict__ Twc, const float* __restrict__ Kmat, const float* __restrict__ dlogzm_dTwc, int n, int m,
+    int Wimg, float* __restrict__ Pwn, float* __restrict__ dPwn_dTwc, float* __restrict__ uvec, float* __restrict__ zbuf,
+    float* __restrict__ logzn_out, uint32_t* __restrict__ hists) {
+  using T = float;
+  using KeyT = typename KeyOf<T>::type;
+  __shared__ uint32_t lh[SEL_BINS];
+  __shared__ float sD[4][64 * 9];
+  const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
+  for (int k = tid; k < SEL_BINS; k += 256) lh[k] = 0;
+  float bop[16];                      // coefficient operand: column c of {logz_m, dlogz_m/dT (6), 0...}, k = 16 s + 4 q + e
+#pragma unroll
+  for (int se = 0; se < 16; ++se) {
+    const int k = 16 * (se >> 2) + 4 * q + (se & 3);
+    float v = 0.f;
+    if (k < m) {
+      if (c == 0) v = logzm[(long)b * m + k];
+      else if (c < 7) v = dlogzm_dTwc[((long)b * m + k) * 6 + (c - 1)];
+    }
+    bop[se] = v;
+  }
+  T Tm[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Tm[k] = Twc[16 * (long)b + k];
+  const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  __syncthreads();
+  float* myD = sD[wv];
+  const int tiles = (n + 63) >> 6;
+  for (int tile = blockIdx.x * 4 + wv; tile < tiles; tile += gridDim.x * 4) {
+    const int px0 = tile << 6;
+    float4 kv[4][4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int ii = min(px0 + 16 * it + c, n - 1);
+      const int rw = pixidx ? pixidx[(long)b * n + ii] : ii;
+      const float* Kr = Kt + (long)b * kt_slot_stride + (long)rw * m;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int kk = min(16 * s + 4 * q, m - 4);           // clamped: the matching coefficients are zero
+        kv[it][s] = *reinterpret_cast<const float4*>(Kr + kk);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      mf4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[it][s].x, bop[4 * s + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[it][s].y, bop[4 * s + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[it][s].z, bop[4 * s + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[it][s].w, bop[4 * s + 3], acc, 0, 0, 0);
+      }
+      if (c < 8) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) myD[(16 * it + 4 * q + r) * 9 + c] = acc[r];
+      }
+    }
+    wave_lds_fence();
+    T a7[7];
+#pragma unroll
+    for (int a = 0; a < 7; ++a) a7[a] = myD[lane * 9 + a];
+    wave_lds_fence();
+    const int i0 = px0 + lane;
+    const bool inr = i0 < n;
+    const int i = inr ? i0 : n - 1;
+    const int row = pixidx ? pixidx[(long)b * n + i] : i;
+    const T logz = a7[0];
+    const T z = exp(logz);                                       // depth.py:6-9
+    T rx, ry;
+    {
+#pragma clang fp contract(off)
+      rx = (T(row % Wimg) - cx) / fx;                            // camera.py:43-47 with p = (col, row)
+      ry = (T(row / Wimg) - cy) / fy;
+    }
+    const T Xc = z * rx, Yc = z * ry, Zc = z;
+    T Xw, Yw, Zw;
+    rigid_apply(Tm, Xc, Yc, Zc, Xw, Yw, Zw);
+    const T u0 = Tm[0] * Xc + Tm[1] * Yc + Tm[2] * Zc;
+    const T u1 = Tm[4] * Xc + Tm[5] * Yc + Tm[6] * Zc;
+    const T u2 = Tm[8] * Xc + Tm[9] * Yc + Tm[10] * Zc;
+    if (inr) {
+      const long base3 = (long)b * 3 * n + i, base18 = (long)b * 18 * n + i;
+      Pwn[base3] = Xw; Pwn[base3 + n] = Yw; Pwn[base3 + 2 * (long)n] = Zw;
+      uvec[base3] = u0; uvec[base3 + n] = u1; uvec[base3 + 2 * (long)n] = u2;
+      const T uu[3] = {u0, u1, u2};
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const T r0 = Tm[r * 4 + 0], r1 = Tm[r * 4 + 1], r2 = Tm[r * 4 + 2];
+        const T s0 = -(r1 * Zc - r2 * Yc), s1 = -(r2 * Xc - r0 * Zc), s2 = -(r0 * Yc - r1 * Xc);
+        dPwn_dTwc[base18 + (long)(r * 6 + 0) * n] = s0 + uu[r] * a7[1];
+        dPwn_dTwc[base18 + (long)(r * 6 + 1) * n] = s1 + uu[r] * a7[2];
+        dPwn_dTwc[base18 + (long)(r * 6 + 2) * n] = s2 + uu[r] * a7[3];
+        dPwn_dTwc[base18 + (long)(r * 6 + 3) * n] = r0 + uu[r] * a7[4];
+        dPwn_dTwc[base18 + (long)(r * 6 + 4) * n] = r1 + uu[r] * a7[5];
+        dPwn_dTwc[base18 + (long)(r * 6 + 5) * n] = r2 + uu[r] * a7[6];
+      }
+      zbuf[(long)b * n + i] = Zc;
+      if (logzn_out) logzn_out[(long)b * n + i] = logz;
+    }
+    sel_lds_add_aggregated(lh, sel_digit<KeyT>(abs_key(Zc), 0), inr);
+  }
+  __syncthreads();
+  sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
+}
+
 // ---- K~ --------------------------------------------------------------------------------------------------------
 // bilinear lookup with border padding at normalised (row, col) coordinates (grid_sample align_corners=False)
 template <typename T>
@@ -221,8 +342,15 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
   if (hipMemsetAsync(hists, 0, (size_t)B * 6 * SEL_BINS * sizeof(uint32_t), s) != hipSuccess) return COMO_ERR_LAUNCH;
   int gx = (n + 255) / 256;
   if (gx > 512) gx = 512;
-  hipLaunchKernelGGL(dense_ref_kernel<T>, dim3(gx, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
-                     dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists);
+  if constexpr (sizeof(T) == 4) {
+    int gm = ((n + 63) / 64 + 3) / 4;
+    if (gm > 256) gm = 256;
+    hipLaunchKernelGGL(dense_ref_mfma_kernel, dim3(gm, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
+                       dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists);
+  } else {
+    hipLaunchKernelGGL(dense_ref_kernel<T>, dim3(gx, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
+                       dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists);
+  }
   COMO_CHECK_LAUNCH();
   for (int p = 1; p < SelCfg<KeyT>::NPASS; ++p) {
     int rc = select_hist<T>(zbuf, nullptr, n, B, hists, p, s);

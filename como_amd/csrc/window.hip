@@ -171,7 +171,10 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
   double* G = r0 + m;             // m x 6
   double* dP = G + m * 6;         // m x 3
   double* red = dP + m * 3;       // 64 scratch
-  const int b = blockIdx.x, tid = threadIdx.x;
+  // grid (B, S): every slice rebuilds the small m x m prologue in LDS and scatters 1/S of H_TP / H_PP (the 9 m^2
+  // fp64 atomics per keyframe were the whole cost with one workgroup per keyframe); slice 0 adds everything else
+  const int b = blockIdx.x, tid = threadIdx.x, slice = blockIdx.y, nsl = gridDim.y;
+  const bool lead = slice == 0;
   const double med = A.median_is_f32 ? (double)((const float*)A.median)[(long)b * A.median_stride]
                                      : ((const double*)A.median)[(long)b * A.median_stride];
   const double logmed = log(med);
@@ -202,32 +205,34 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
   const long* li = A.landmark_inds + 3 * (long)m * b;
   const long D = A.D;
   // H_TT, g_T  (log-depth-space priors)
-  if (tid < 36) {
+  if (lead && tid < 36) {
     const int a = tid / 6, c = tid % 6;
     double s = 0;
     for (int k = 0; k < m; ++k) s += G[k * 6 + a] * MG[k * 6 + c];
     atomicAdd(&A.H[pi[a] * D + pi[c]], s);
-  } else if (tid < 42) {
+  } else if (lead && tid < 42) {
     const int a = tid - 36;
     double s = 0;
     for (int k = 0; k < m; ++k) s += G[k * 6 + a] * w[k];
     atomicAdd(&A.g[pi[a]], -s);
   }
   // H_TP (both triangles), g_P
-  for (int e = tid; e < 6 * m * 3; e += 256) {
+  for (int e = tid + 256 * slice; e < 6 * m * 3; e += 256 * nsl) {
     const int a = e / (3 * m), q = e % (3 * m), j = q / 3, d = q % 3;
     const double v = MG[j * 6 + a] * dP[j * 3 + d];
     atomicAdd(&A.H[pi[a] * D + li[q]], v);
     atomicAdd(&A.H[li[q] * D + pi[a]], v);
   }
-  for (int q = tid; q < 3 * m; q += 256) atomicAdd(&A.g[li[q]], -w[q / 3] * dP[q]);
+  if (lead)
+    for (int q = tid; q < 3 * m; q += 256) atomicAdd(&A.g[li[q]], -w[q / 3] * dP[q]);
   // H_PP
-  for (int e = tid; e < 9 * m * m; e += 256) {
+  for (int e = tid + 256 * slice; e < 9 * m * m; e += 256 * nsl) {
     const int q1 = e / (3 * m), q2 = e % (3 * m);
     const double v = M[(q1 / 3) * m + (q2 / 3)] * dP[q1] * dP[q2];
     atomicAdd(&A.H[li[q1] * D + li[q2]], v);
   }
   // errors: gp = r0^T (Kinv/s^2) r0, ld = sum first r0^2 / s^2
+  if (!lead) return;
   if (tid < 64) {
     double egp = 0, eld = 0;
     for (int i = tid; i < m; i += 64) {
@@ -391,7 +396,7 @@ int como_win_priors(const como_win_args* a, como_stream_t stream) {
   A.H = a->H; A.g = a->g; A.D = a->D; A.err = a->err;
   const int m = a->m;
   const size_t lds = (size_t)(m * m + m * 6 + m + m + m * 6 + m * 3 + 64) * sizeof(double);
-  hipLaunchKernelGGL(win_priors_kernel, dim3(a->B), dim3(256), lds, s, A, a->B, m);
+  hipLaunchKernelGGL(win_priors_kernel, dim3(a->B, 16), dim3(256), lds, s, A, a->B, m);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }
