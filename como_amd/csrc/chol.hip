@@ -50,90 +50,99 @@ __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...
 template <int N, typename F>
 __device__ __forceinline__ void sfor(F&& f) { sfor_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
 
-// Factor the CBxCB tile held by 256 threads (thread (ty, tx) owns elements (ty+16a, tx+16b), lower part valid) and invert
-// the factor, fused into ONE rolled loop with a single barrier per pivot.  (A fully unrolled single-wave register
-// version was instruction-fetch bound: ~40 KB of straight-line code executed once per launch.)
-//   step c, publish : owners of column c store the raw column; owners of inverse row c-1 store X[c-1][:]
-//   barrier
-//   step c, apply   : A[r][cc] -= A[r][c] A[cc][c] / d  (cc > c);   L[:,c] = A[:,c] / sqrt(d) -> Lw
-//                     S[i][:] -= L[i][c-1] X[c-1][:]     (i > c-1)   (forward substitution, one pivot behind)
-// sC: 3 x CB doubles (column ring: read during two steps), sX: 2 x CB doubles; oL, oX: CB x CLD staging tiles (global
-// stores inside the loop would stall every barrier on vmcnt(0)).
-__device__ __forceinline__ void factor_invert_tile(double (&v)[2][2], double* sC, double* sX, double* oL, double* oX,
-                                                   double* __restrict__ Lw,
-                                                   double* __restrict__ Iw, int Dp, int k, int D, int* __restrict__ info) {
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+__device__ __forceinline__ double rcp_refined(double d) {      // hardware estimate (24 bits) + one cubic correction
+  const double r = __builtin_amdgcn_rcp(d);
+  const double e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+__device__ __forceinline__ double rsq_refined(double d) {      // hardware estimate + two Newton steps
+  double r = __builtin_amdgcn_rsq(d);
+  r = r * (1.5 - 0.5 * d * r * r);
+  r = r * (1.5 - 0.5 * d * r * r);
+  return r;
+}
+
+// Factor a CBxCB tile and invert the factor with 512 threads in ONE rolled loop, one barrier per pivot.
+// Measured cost model on MI355X (scripts/micro): one wave issues ~1 VALU instruction per 6 cycles, an LDS store ->
+// barrier -> load hop is ~150 cycles, f64 FMAs are not the problem.  The pivot loop is therefore bound by the
+// INSTRUCTIONS each wave executes per pivot, so the work is split by role:
+//   threads   0..255 (F): thread (ty, tx) owns A[ty+16a][tx+16b]; step c: load raw column c, 1/d, rank-1 update,
+//                         owners of column c+1 store it raw (oC[c+1][:]) for the next step
+//   threads 256..511 (I): thread (ty, tx) owns S[ty+16a][tx+16b] (S = I initially); step c handles pivot t = c-1:
+//                         load raw column t and raw row t of S, 1/sqrt(d) -> sq[t], S[i][:] -= L[i][t] X[t][:],
+//                         owners of row t+1 store it raw (oS[t+1][:])
+// Nothing is scaled inside the loop: L[r][c] = oC[c][r] * sq[c] and L^-1[t][j] = oS[t][j] * sq[t] are formed by
+// the copy-out.  (Earlier versions: a fully unrolled single-wave register kernel was instruction-fetch bound -- 40 KB
+// of straight-line code executed once; 256 threads doing both roles took 1100 cycles per pivot.)
+// oC, oS: CB x CB doubles each; sq: CB doubles.
+__device__ __forceinline__ void factor_invert_tile(double (&v)[2][2], double* oC, double* oS, double* sq,
+                                                   double* __restrict__ Lw, double* __restrict__ Iw, int Dp, int k, int D,
+                                                   int* __restrict__ info) {
+  const int tid = threadIdx.x, role = tid >> 8, lt = tid & 255, tx = lt & 15, ty = lt >> 4;
   const long kk = (long)k * CB;
-  double S[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) S[a][b] = (ty + 16 * a == tx + 16 * b) ? 1.0 : 0.0;
-  double isq_prev = 0.0, pend0 = 0.0, pend1 = 0.0;
-  int ring = 0;                                        // c % 3
-  // every step: all LDS stores, ONE barrier, all LDS loads in one batch, then arithmetic only (selects, no branches):
-  // each extra store->load ordering inside a step costs a full LDS round trip on the serial chain
-  for (int c = 0; c <= CB; ++c) {
-    double* col = sC + ring * CB;
-    const double* colp = sC + (ring == 0 ? 2 : ring - 1) * CB;
-    double* xr = sX + (c & 1) * CB;
-    const int t = c - 1;
-    if (c < CB && tx == (c & 15)) {
-      const bool hi = c >= 16;
-      col[ty] = hi ? v[0][1] : v[0][0];
-      col[ty + 16] = hi ? v[1][1] : v[1][0];
-    }
-    if (c > 0) {
-      if (tx == (t & 15)) {                            // column t of L, finished in the previous step
-        oL[ty * CLD + t] = pend0;
-        oL[(ty + 16) * CLD + t] = pend1;
+  if (role == 0) {
+    if (tx == 0) { oC[ty] = v[0][0]; oC[ty + 16] = v[1][0]; }
+    for (int c = 0; c <= CB; ++c) {
+      __syncthreads();
+      if (c == CB) break;
+      const double* col = oC + c * CB;
+      double d = col[c];
+      const double c0 = col[tx], c1 = col[tx + 16], r0 = col[ty], r1 = col[ty + 16];
+      if (!(d > 0.0)) {
+        if (tid == 0 && kk + c < D) atomicCAS(info, 0, (int)kk + c + 1);
+        d = 1.0;
       }
-      if (ty == (t & 15)) {                            // row t of the inverse
-        const bool hi = t >= 16;
-        const double x0 = (hi ? S[1][0] : S[0][0]) * isq_prev, x1 = (hi ? S[1][1] : S[0][1]) * isq_prev;
-        xr[tx] = x0;
-        xr[tx + 16] = x1;
-        oX[t * CLD + tx] = (tx <= t) ? x0 : 0.0;
-        oX[t * CLD + tx + 16] = (tx + 16 <= t) ? x1 : 0.0;
+      const double rinv = rcp_refined(d);
+      const double w0 = r0 * rinv, w1 = r1 * rinv;
+      const double m0 = (tx > c) ? c0 : 0.0, m1 = (tx + 16 > c) ? c1 : 0.0;
+      v[0][0] -= w0 * m0;
+      v[0][1] -= w0 * m1;
+      v[1][0] -= w1 * m0;
+      v[1][1] -= w1 * m1;
+      if (c + 1 < CB && tx == ((c + 1) & 15)) {
+        const bool hi = c + 1 >= 16;
+        double* nxt = oC + (c + 1) * CB;
+        nxt[ty] = hi ? v[0][1] : v[0][0];
+        nxt[ty + 16] = hi ? v[1][1] : v[1][0];
       }
     }
-    __syncthreads();
-    const int cs = (c < CB) ? c : CB - 1;
-    double d = col[cs];
-    const double c0 = col[tx], c1 = col[tx + 16], r0 = col[ty], r1 = col[ty + 16];
-    double x0 = xr[tx], x1 = xr[tx + 16];
-    const double p0 = colp[ty], p1 = colp[ty + 16];
-    if (c == 0) { x0 = 0.0; x1 = 0.0; }                 // nothing published yet (0 * garbage would poison S)
-    if (c < CB && !(d > 0.0)) {
-      if (tid == 0 && kk + c < D) atomicCAS(info, 0, (int)kk + c + 1);
-      d = 1.0;
+  } else {
+    double S[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) S[a][b] = (ty + 16 * a == tx + 16 * b) ? 1.0 : 0.0;
+    if (ty == 0) { oS[tx] = S[0][0]; oS[tx + 16] = S[0][1]; }
+    for (int c = 0; c <= CB; ++c) {
+      __syncthreads();
+      if (c == 0) continue;
+      const int t = c - 1;
+      const double* col = oC + t * CB;
+      const double* row = oS + t * CB;
+      double d = col[t];
+      const double p0 = col[ty], p1 = col[ty + 16], x0 = row[tx], x1 = row[tx + 16];
+      if (!(d > 0.0)) d = 1.0;
+      const double isq = rsq_refined(d);
+      if (lt == 0) sq[t] = isq;
+      const double xs0 = x0 * isq, xs1 = x1 * isq;                 // X[t][:]
+      const double l0 = (ty > t) ? p0 * isq : 0.0, l1 = (ty + 16 > t) ? p1 * isq : 0.0;
+      S[0][0] -= l0 * xs0;
+      S[0][1] -= l0 * xs1;
+      S[1][0] -= l1 * xs0;
+      S[1][1] -= l1 * xs1;
+      if (t + 1 < CB && ty == ((t + 1) & 15)) {
+        const bool hi = t + 1 >= 16;
+        double* nxt = oS + (t + 1) * CB;
+        nxt[tx] = hi ? S[1][0] : S[0][0];
+        nxt[tx + 16] = hi ? S[1][1] : S[0][1];
+      }
     }
-    const double rinv = fast_rcp(d);
-    double isq = __builtin_amdgcn_rsq(d);
-    isq = isq * (1.5 - 0.5 * d * isq * isq);
-    isq = isq * (1.5 - 0.5 * d * isq * isq);
-    const bool live = c < CB;
-    const double w0 = r0 * rinv, w1 = r1 * rinv;
-    const double m0 = (live && tx > c) ? c0 : 0.0, m1 = (live && tx + 16 > c) ? c1 : 0.0;
-    v[0][0] -= w0 * m0;
-    v[0][1] -= w0 * m1;
-    v[1][0] -= w1 * m0;
-    v[1][1] -= w1 * m1;
-    pend0 = (ty == c) ? d * isq : r0 * isq;
-    pend1 = (ty + 16 == c) ? d * isq : r1 * isq;
-    const double l0 = (c > 0 && ty > t) ? p0 * isq_prev : 0.0, l1 = (c > 0 && ty + 16 > t) ? p1 * isq_prev : 0.0;
-    S[0][0] -= l0 * x0;
-    S[0][1] -= l0 * x1;
-    S[1][0] -= l1 * x0;
-    S[1][1] -= l1 * x1;
-    isq_prev = isq;
-    ring = (ring == 2) ? 0 : ring + 1;
   }
   __syncthreads();
-  for (int e = tid; e < CB * CB; e += 256) {
+  for (int e = tid; e < CB * CB; e += 512) {
     const int r = e / CB, c = e % CB;
-    if (c <= r) Lw[(kk + r) * Dp + kk + c] = oL[r * CLD + c];
-    Iw[(long)k * CB * CB + e] = oX[r * CLD + c];
+    if (c <= r) Lw[(kk + r) * Dp + kk + c] = oC[c * CB + r] * sq[c];
+    Iw[(long)k * CB * CB + e] = (c <= r) ? oS[e] * sq[r] : 0.0;
   }
 }
 
@@ -143,33 +152,34 @@ __device__ __forceinline__ void factor_invert_tile(double (&v)[2][2], double* sC
 // inverts it for the next launch -- the only serial work left on the critical path of a panel.
 // W: working copy (trailing tiles updated in place); Lw: the factor (a SEPARATE matrix: other workgroups of the launch
 // still read the un-factored panel blocks from W); Iw: inverses of the diagonal blocks of L (nb x CB x CB).
-__global__ __launch_bounds__(256) void chol_first_kernel(const double* __restrict__ W, double* __restrict__ Lw,
+__global__ __launch_bounds__(512) void chol_first_kernel(const double* __restrict__ W, double* __restrict__ Lw,
                                                          double* __restrict__ Iw, int Dp, int D, int* __restrict__ info) {
-  __shared__ double sC[3 * CB];
-  __shared__ double sX[2 * CB];
-  __shared__ double oL[CB * CLD];
-  __shared__ double oX[CB * CLD];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  double v[2][2];
+  __shared__ double oC[CB * CB];
+  __shared__ double oS[CB * CB];
+  __shared__ double sq[CB];
+  const int tx = threadIdx.x & 15, ty = (threadIdx.x & 255) >> 4;
+  double v[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  if (threadIdx.x < 256) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int r = ty + 16 * a, c = tx + 16 * b;
-      v[a][b] = (c <= r) ? W[(long)r * Dp + c] : 0.0;
-    }
-  factor_invert_tile(v, sC, sX, oL, oX, Lw, Iw, Dp, 0, D, info);
+      for (int b = 0; b < 2; ++b) {
+        const int r = ty + 16 * a, c = tx + 16 * b;
+        v[a][b] = (c <= r) ? W[(long)r * Dp + c] : 0.0;
+      }
+  }
+  factor_invert_tile(v, oC, oS, sq, Lw, Iw, Dp, 0, D, info);
 }
 
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ W, double* __restrict__ Lw,
+__global__ __launch_bounds__(512) void chol_panel_kernel(double* __restrict__ W, double* __restrict__ Lw,
                                                          double* __restrict__ Iw, int Dp, int D, int k, int nb,
                                                          int* __restrict__ info) {
   __shared__ double sV[CB * CLD];      // L_kk^-1
-  __shared__ double sA[CB * CLD];      // A_ik
-  __shared__ double sB[CB * CLD];      // A_jk
-  __shared__ double sI[CB * CLD];      // L_ik (later: the rings of factor_invert_tile)
+  __shared__ double sA[CB * CLD];      // A_ik   (later: raw columns of the next diagonal tile)
+  __shared__ double sB[CB * CLD];      // A_jk   (later: raw rows of its inverse)
+  __shared__ double sI[CB * CLD];      // L_ik   (later: 1/sqrt(pivots))
   __shared__ double sJ[CB * CLD];      // L_jk
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, half = tid >> 8, lt = tid & 255;
   int ti = -1, tj = -1;
   {
     int t = blockIdx.x;
@@ -180,84 +190,78 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ W,
     }
   }
   const long kk = (long)k * CB;
-  for (int e = tid; e < CB * CB; e += 256) {
+  for (int e = tid; e < CB * CB; e += 512) {
     const int r = e / CB, c = e % CB;
     sV[r * CLD + c] = Iw[((long)k * CB + r) * CB + c];
     sA[r * CLD + c] = W[((long)ti * CB + r) * Dp + kk + c];
     sB[r * CLD + c] = W[((long)tj * CB + r) * Dp + kk + c];
   }
   __syncthreads();
-  const int tx = tid & 15, ty = tid >> 4;
+  const int tx = lt & 15, ty = lt >> 4;
   constexpr int RT = CB / 16;
-  // L_ik[r][c] = sum_t A_ik[r][t] Linv[c][t]   (and the same for j)
+  // L_ik[r][c] = sum_t A_ik[r][t] Linv[c][t]  (threads 0..255), the same for L_jk (threads 256..511)
   {
-    double ai[RT][RT], aj[RT][RT];
+    const double* src = half ? sB : sA;
+    double* dst = half ? sJ : sI;
+    double ai[RT][RT];
 #pragma unroll
     for (int a = 0; a < RT; ++a)
 #pragma unroll
-      for (int b = 0; b < RT; ++b) { ai[a][b] = 0.0; aj[a][b] = 0.0; }
+      for (int b = 0; b < RT; ++b) ai[a][b] = 0.0;
 #pragma unroll 8
     for (int t = 0; t < CB; ++t) {
-      double xi[RT], xj[RT], vv[RT];
+      double xi[RT], vv[RT];
 #pragma unroll
-      for (int a = 0; a < RT; ++a) { xi[a] = sA[(ty + 16 * a) * CLD + t]; xj[a] = sB[(ty + 16 * a) * CLD + t]; vv[a] = sV[(tx + 16 * a) * CLD + t]; }
+      for (int a = 0; a < RT; ++a) { xi[a] = src[(ty + 16 * a) * CLD + t]; vv[a] = sV[(tx + 16 * a) * CLD + t]; }
 #pragma unroll
       for (int a = 0; a < RT; ++a)
 #pragma unroll
-        for (int b = 0; b < RT; ++b) { ai[a][b] += xi[a] * vv[b]; aj[a][b] += xj[a] * vv[b]; }
+        for (int b = 0; b < RT; ++b) ai[a][b] += xi[a] * vv[b];
     }
 #pragma unroll
     for (int a = 0; a < RT; ++a)
 #pragma unroll
-      for (int b = 0; b < RT; ++b) {
-        sI[(ty + 16 * a) * CLD + tx + 16 * b] = ai[a][b];
-        sJ[(ty + 16 * a) * CLD + tx + 16 * b] = aj[a][b];
-      }
+      for (int b = 0; b < RT; ++b) dst[(ty + 16 * a) * CLD + tx + 16 * b] = ai[a][b];
   }
   __syncthreads();
   if (tj == ti) {   // the diagonal-tile workgroup of block-row i publishes L_ik
-    for (int e = tid; e < CB * CB; e += 256) {
+    for (int e = tid; e < CB * CB; e += 512) {
       const int r = e / CB, c = e % CB;
       Lw[((long)ti * CB + r) * Dp + kk + c] = sI[r * CLD + c];
     }
   }
-  // A_ij -= L_ik L_jk^T : 16x16 threads, (CB/16)^2 outputs each
-  double acc[RT][RT];
-#pragma unroll
-  for (int a = 0; a < RT; ++a)
-#pragma unroll
-    for (int b = 0; b < RT; ++b) acc[a][b] = 0.0;
-#pragma unroll 8
-  for (int t = 0; t < CB; ++t) {
-    double xi[RT], xj[RT];
-#pragma unroll
-    for (int a = 0; a < RT; ++a) { xi[a] = sI[(ty + 16 * a) * CLD + t]; xj[a] = sJ[(tx + 16 * a) * CLD + t]; }
-#pragma unroll
-    for (int a = 0; a < RT; ++a)
-#pragma unroll
-      for (int b = 0; b < RT; ++b) acc[a][b] += xi[a] * xj[b];
-  }
   const bool next_diag = (ti == k + 1) && (tj == k + 1);
-  if (!next_diag) {
+  // A_ij -= L_ik L_jk^T : 16x16 threads, (CB/16)^2 outputs each (threads 0..255)
+  double v[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  if (half == 0) {
+    double acc[RT][RT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+      for (int b = 0; b < RT; ++b) acc[a][b] = 0.0;
+#pragma unroll 8
+    for (int t = 0; t < CB; ++t) {
+      double xi[RT], xj[RT];
+#pragma unroll
+      for (int a = 0; a < RT; ++a) { xi[a] = sI[(ty + 16 * a) * CLD + t]; xj[a] = sJ[(tx + 16 * a) * CLD + t]; }
+#pragma unroll
+      for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < RT; ++b) acc[a][b] += xi[a] * xj[b];
+    }
 #pragma unroll
     for (int a = 0; a < RT; ++a)
 #pragma unroll
       for (int b = 0; b < RT; ++b) {
         const int r = ty + 16 * a, c = tx + 16 * b;
-        if (ti != tj || c <= r) W[((long)ti * CB + r) * Dp + (long)tj * CB + c] -= acc[a][b];
+        double* w = W + ((long)ti * CB + r) * Dp + (long)tj * CB + c;
+        if (next_diag) v[a][b] = (c <= r) ? *w - acc[a][b] : 0.0;   // stays on chip: factored + inverted right below
+        else if (ti != tj || c <= r) *w -= acc[a][b];
       }
-  } else {
-    // the updated diagonal tile stays in registers and is factored + inverted right here for the next launch
-    double v[2][2];
-#pragma unroll
-    for (int a = 0; a < RT; ++a)
-#pragma unroll
-      for (int b = 0; b < RT; ++b) {
-        const int r = ty + 16 * a, c = tx + 16 * b;
-        v[a][b] = (c <= r) ? W[((long)ti * CB + r) * Dp + (long)tj * CB + c] - acc[a][b] : 0.0;
-      }
-    __syncthreads();                                   // sA / sB / sI / sJ are dead: rings in sI, staging tiles in sA / sB
-    factor_invert_tile(v, sI, sI + 3 * CB, sA, sB, Lw, Iw, Dp, k + 1, D, info);
+  }
+  if (next_diag) {
+    __syncthreads();                                   // sA / sB / sI are dead now
+    factor_invert_tile(v, sA, sB, sI, Lw, Iw, Dp, k + 1, D, info);
   }
 }
 
@@ -320,12 +324,12 @@ int como_chol_solve_f64(const double* H, const double* g, double* delta, void* w
   hipLaunchKernelGGL(chol_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, H, g, W, D, Dp, info);
   COMO_CHECK_LAUNCH();
   if (Dp > 4096) return COMO_ERR_ARG;
-  hipLaunchKernelGGL(chol_first_kernel, dim3(1), dim3(256), 0, s, W, Lw, Iw, Dp, D, info);
+  hipLaunchKernelGGL(chol_first_kernel, dim3(1), dim3(512), 0, s, W, Lw, Iw, Dp, D, info);
   COMO_CHECK_LAUNCH();
   for (int k = 0; k + 1 < nb; ++k) {
     const int r = nb - 1 - k;
     const int tiles = r * (r + 1) / 2;
-    hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(256), 0, s, W, Lw, Iw, Dp, D, k, nb, info);
+    hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(512), 0, s, W, Lw, Iw, Dp, D, k, nb, info);
     COMO_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(1024), 0, s, Lw, Iw, Dp, D, nb, delta);

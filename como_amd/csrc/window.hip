@@ -179,11 +179,23 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
                                      : ((const double*)A.median)[(long)b * A.median_stride];
   const double logmed = log(med);
   const double i_gp = 1.0 / (A.s_gp * A.s_gp), i_ld = 1.0 / (A.s_ld * A.s_ld), i_px = 1.0 / (A.s_px * A.s_px);
-  for (int e = tid; e < m * m; e += 256) {
-    const int i = e / m, j = e % m;
-    double v = A.Kmm_inv[(long)b * m * m + e] * i_gp;
-    if (i == j && A.first_mask[(long)b * m + i]) v += i_ld;
-    M[e] = v;
+  {
+    double kin[16];                                  // m <= 64: at most 16 elements per thread, all loads in flight at once
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u;
+      kin[u] = (e < m * m) ? A.Kmm_inv[(long)b * m * m + e] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int e = tid + 256 * u;
+      if (e < m * m) {
+        const int i = e / m, j = e % m;
+        double v = kin[u] * i_gp;
+        if (i == j && A.first_mask[(long)b * m + i]) v += i_ld;
+        M[e] = v;
+      }
+    }
   }
   for (int e = tid; e < m; e += 256) r0[e] = A.logzm[(long)b * m + e] - logmed;
   for (int e = tid; e < m * 6; e += 256) G[e] = A.dlogz_dT[(long)b * m * 6 + e];
@@ -243,31 +255,44 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
     egp = wave_sum(egp); eld = wave_sum(eld);
     if (tid == 0) { atomicAdd(&A.err[0], egp); atomicAdd(&A.err[1], eld); }
   }
-  // pixel prior, mode "first": one thread per first-observed landmark of this keyframe
-  double epx = 0;
-  if (tid < m && A.first_mask[(long)b * m + tid]) {
+  // pixel prior, mode "first": one lane per first-observed landmark of this keyframe.  Landmark rows / columns are
+  // private to the lane; the pose block and pose gradient are shared by all lanes, so they are wave-reduced first
+  // (64 same-address fp64 atomics per entry serialise at ~45 ns each: that was 80% of this kernel).
+  if (tid < 64) {
     const int j = tid;
-    const long bj = (long)b * m + j;
+    const bool act = j < m && A.first_mask[(long)b * m + (j < m ? j : 0)];
+    const long bj = (long)b * m + (act ? j : 0);
     const double r[2] = {A.pm[2 * bj] - A.pm_first[2 * bj], A.pm[2 * bj + 1] - A.pm_first[2 * bj + 1]};
     const double* JP = A.dp_dP + 6 * bj;     // 2x3
     const double* JT = A.dp_dT + 12 * bj;    // 2x6
-    for (int d = 0; d < 3; ++d) {
-      for (int d2 = 0; d2 < 3; ++d2) atomicAdd(&A.H[li[3 * j + d] * D + li[3 * j + d2]], i_px * (JP[d] * JP[d2] + JP[3 + d] * JP[3 + d2]));
-      atomicAdd(&A.g[li[3 * j + d]], -i_px * (JP[d] * r[0] + JP[3 + d] * r[1]));
-      for (int a = 0; a < 6; ++a) {
-        const double v = i_px * (JT[a] * JP[d] + JT[6 + a] * JP[3 + d]);
-        atomicAdd(&A.H[pi[a] * D + li[3 * j + d]], v);
-        atomicAdd(&A.H[li[3 * j + d] * D + pi[a]], v);
+    double jp[6], jt[12];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) jp[k] = JP[k];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) jt[k] = JT[k];
+    if (act) {
+      for (int d = 0; d < 3; ++d) {
+        for (int d2 = 0; d2 < 3; ++d2) atomicAdd(&A.H[li[3 * j + d] * D + li[3 * j + d2]], i_px * (jp[d] * jp[d2] + jp[3 + d] * jp[3 + d2]));
+        atomicAdd(&A.g[li[3 * j + d]], -i_px * (jp[d] * r[0] + jp[3 + d] * r[1]));
+        for (int a = 0; a < 6; ++a) {
+          const double v = i_px * (jt[a] * jp[d] + jt[6 + a] * jp[3 + d]);
+          atomicAdd(&A.H[pi[a] * D + li[3 * j + d]], v);
+          atomicAdd(&A.H[li[3 * j + d] * D + pi[a]], v);
+        }
       }
     }
+    const double on = act ? i_px : 0.0;
+#pragma unroll
     for (int a = 0; a < 6; ++a) {
-      for (int c = 0; c < 6; ++c) atomicAdd(&A.H[pi[a] * D + pi[c]], i_px * (JT[a] * JT[c] + JT[6 + a] * JT[6 + c]));
-      atomicAdd(&A.g[pi[a]], -i_px * (JT[a] * r[0] + JT[6 + a] * r[1]));
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        const double v = wave_sum(on * (jt[a] * jt[c] + jt[6 + a] * jt[6 + c]));
+        if (tid == 0) atomicAdd(&A.H[pi[a] * D + pi[c]], v);
+      }
+      const double gv = wave_sum(on * (jt[a] * r[0] + jt[6 + a] * r[1]));
+      if (tid == 0) atomicAdd(&A.g[pi[a]], -gv);
     }
-    epx = i_px * (r[0] * r[0] + r[1] * r[1]);
-  }
-  if (tid < 64) {
-    epx = wave_sum(epx);
+    const double epx = wave_sum(on * (r[0] * r[0] + r[1] * r[1]));
     if (tid == 0) atomicAdd(&A.err[2], epx);
   }
   // anchors on keyframe 0 (Mapping.py:855-900)
