@@ -75,6 +75,15 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "como_chol_workspace_bytes": (c_long, [c_int]),
     "como_chol_solve_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "como_nn_conv2d_f32": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p]),
+    "como_nn_groupnorm_f32": (c_int, [c_void_p] * 6 + [c_int] * 4 + [c_float, c_float, c_int, c_void_p]),
+    "como_nn_maxpool2_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "como_nn_upsample2x_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "como_nn_normalize_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
+                                      c_void_p]),
+    "como_nn_cov_act_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "como_nn_resize_aa_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "como_nn_resize_aa_f64": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "como_win_scaffold": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
     "como_win_priors": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
     "como_win_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),

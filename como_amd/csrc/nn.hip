@@ -1,0 +1,332 @@
+// DepthCov covariance network (float32 inference), gfx950.
+//
+// Reference: como/depth_cov/nn/UNet.py:8-78 (UNet.forward), como/depth_cov/nn/layers.py:5-75 (ResidualConv, DownConv,
+// UpConv), como/depth_cov/core/DepthCovModule.py:80-87, como/depth_cov/core/gaussian_kernel.py:6-49 (output
+// activation), como/odom/Mapping.py:409-428 (run_model: antialiased bilinear resize in and out).
+//
+// conv2d (3x3 / 1x1, stride 1, "same" zero padding) is an implicit GEMM on v_mfma_f32_16x16x4_f32:
+//   D[cout, px] += W[cout, k] * patch[k, px],   k = (ky, kx, cin)
+//   A operand: lane (l & 15 = cout, l >> 4 = k)  <- weights pre-transposed to [ky][kx][cin][cout] (cout contiguous)
+//   B operand: lane (l & 15 = px,   l >> 4 = k)  <- NCHW input: 16 consecutive pixels of 4 channel planes per step
+//   D        : lane (l & 15 = px, rows 4 (l >> 4) + r = cout) -> NCHW stores of 16 consecutive pixels per cout
+// One wave owns 64 consecutive (linearised) pixels x 16*MT output channels.  The whole network is ~3 GFLOP at
+// 192x256: it is launch-count bound, not MFMA bound; the kernels are kept simple and exact-shape.
+#include "common.cuh"
+#include "../../include/como_hip.h"
+
+namespace como {
+
+typedef float nf4 __attribute__((ext_vector_type(4)));
+
+template <int KS, int MT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, float* __restrict__ out, int Cin,
+                                                        int CinP, int Cout, int H, int W, int out_ctot, int out_coff) {
+  constexpr int PAD = KS / 2;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+  const int HW = H * W;
+  const int p0 = (blockIdx.x * 4 + wv) * 64;
+  if (p0 >= HW) return;
+  const int co0 = blockIdx.y * 16 * MT;
+  const int n = blockIdx.z;
+  const float* inb = in + (long)n * Cin * HW;
+  int py[4], px[4];
+  bool pv[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int p = p0 + 16 * t + c;
+    pv[t] = p < HW;
+    const int pc = pv[t] ? p : HW - 1;
+    py[t] = pc / W;
+    px[t] = pc - py[t] * W;
+  }
+  nf4 acc[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[mt][t] = nf4{0.f, 0.f, 0.f, 0.f};
+  for (int ky = 0; ky < KS; ++ky) {
+    for (int kx = 0; kx < KS; ++kx) {
+      int off[4];
+      bool ok[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int yy = py[t] + ky - PAD, xx = px[t] + kx - PAD;
+        ok[t] = pv[t] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        off[t] = ok[t] ? yy * W + xx : 0;
+      }
+      const float* wk = wt + (long)(ky * KS + kx) * CinP * Cout;
+      for (int ci0 = 0; ci0 < CinP; ci0 += 4) {
+        const int ci = ci0 + q;
+        float a[MT], b[4];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int co = co0 + 16 * mt + c;
+          a[mt] = (co < Cout) ? wk[(long)ci * Cout + co] : 0.f;
+        }
+        const bool cv = ci < Cin;
+        const float* ip = inb + (long)(cv ? ci : 0) * HW;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[t] = (cv && ok[t]) ? ip[off[t]] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[t], acc[mt][t], 0, 0, 0);
+      }
+    }
+  }
+  float* ob = out + ((long)n * out_ctot + out_coff) * HW;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + 16 * mt + 4 * q + r;
+      if (co >= Cout) continue;
+      const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int p = p0 + 16 * t + c;
+        if (p < HW) ob[(long)co * HW + p] = acc[mt][t][r] + bv;
+      }
+    }
+}
+
+// GroupNorm statistics: one workgroup per (sample, group); mean and 1/sqrt(var + eps) (biased variance), fp64 sums.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int C, int G, int HW, float eps,
+                                                       float* __restrict__ stats) {
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int cg = C / G;
+  const long cnt = (long)cg * HW;
+  const float* p = x + ((long)n * C + (long)g * cg) * HW;
+  double s = 0.0, ss = 0.0;
+  for (long i = threadIdx.x; i < cnt; i += 256) {
+    const double v = p[i];
+    s += v;
+    ss += v * v;
+  }
+  __shared__ double rs[4], rss[4];
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rss[threadIdx.x >> 6] = ss; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double S = rs[0] + rs[1] + rs[2] + rs[3], SS = rss[0] + rss[1] + rss[2] + rss[3];
+    const double mean = S / (double)cnt;
+    double var = SS / (double)cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[2 * blockIdx.x] = (float)mean;
+    stats[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+
+// y = GroupNorm(x) (affine), then  act == 1: y = LeakyReLU(y);  act == 2: y = LeakyReLU(residual + y)   (layers.py:23-27)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ residual, float* __restrict__ out, int C,
+                                                       int G, int HW, float slope, int act, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long nc = i / HW;
+  const int ch = (int)(nc % C);
+  const int n = (int)(nc / C);
+  const int g = ch / (C / G);
+  const float mean = stats[2 * (n * G + g)], rstd = stats[2 * (n * G + g) + 1];
+  float y = (x[i] - mean) * rstd * gamma[ch] + beta[ch];
+  if (act == 2) y += residual[i];
+  if (act) y = y > 0.f ? y : y * slope;
+  out[i] = y;
+}
+
+__global__ __launch_bounds__(256) void maxpool2_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                       long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int Ho = H / 2, Wo = W / 2;
+  const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+  const long nc = i / ((long)Wo * Ho);
+  const float* p = in + nc * H * W + (long)(2 * y) * W + 2 * x;
+  out[i] = fmaxf(fmaxf(p[0], p[1]), fmaxf(p[W], p[W + 1]));
+}
+
+// bilinear x2, align_corners = False (nn.Upsample, layers.py:55): src = (dst + 0.5) / 2 - 0.5 clamped at 0
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ in, float* __restrict__ out, int H, int W,
+                                                         long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int Wo = 2 * W, Ho = 2 * H;
+  const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+  const long nc = i / ((long)Wo * Ho);
+  const float sy = fmaxf((y + 0.5f) * 0.5f - 0.5f, 0.f), sx = fmaxf((x + 0.5f) * 0.5f - 0.5f, 0.f);
+  const int y0 = (int)sy, x0 = (int)sx;
+  const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+  const float wy = sy - y0, wx = sx - x0;
+  const float* p = in + nc * H * W;
+  out[i] = (1.f - wy) * ((1.f - wx) * p[(long)y0 * W + x0] + wx * p[(long)y0 * W + x1]) +
+           wy * ((1.f - wx) * p[(long)y1 * W + x0] + wx * p[(long)y1 * W + x1]);
+}
+
+struct Norm3 { float mean[3], sd[3]; };
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ in, float* __restrict__ out, int HW,
+                                                        Norm3 nm, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ch = (int)((i / HW) % 3);
+  out[i] = (in[i] - nm.mean[ch]) / nm.sd[ch];                  // torchvision Normalize: sub_(mean).div_(std)
+}
+
+// normalize_params_cov + kernel_params_to_covariance (gaussian_kernel.py:6-49): 3 channels -> E = [x, s, s, z]
+__global__ __launch_bounds__(256) void cov_act_kernel(const float* __restrict__ in, float* __restrict__ out, int HW,
+                                                      long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long n = i / HW, p = i % HW;
+  const float* k = in + n * 3 * HW + p;
+  const float lo = (float)-6.907755278982137, hi = (float)9.210340371976184;   // log(1e-3), log(1e4)
+  const float x = expf(fminf(fmaxf(k[0], lo), hi));
+  const float z = expf(fminf(fmaxf(k[HW], lo), hi));
+  const float cc = 0.99f * tanhf(k[2 * (long)HW]);
+  const float s = sqrtf(x * z - 1e-8f) * cc;
+  float* o = out + n * 4 * HW + p;
+  o[0] = x; o[HW] = s; o[2 * (long)HW] = s; o[3 * (long)HW] = z;
+}
+
+// Antialiased bilinear resize (torchvision TF.resize(antialias=True) -> aten _upsample_bilinear2d_aa; weights as in
+// aten/native/cpu/UpSampleKernel.cpp HelperInterpLinear::aa_filter / _compute_indices_min_size_weights_aa):
+// triangle filter of support max(scale, 1) around centre scale * (i + 0.5), normalised.
+template <typename T>
+__device__ __forceinline__ void aa_taps(int i, T scale, int in_size, int& xmin, int& xsize, T& invscale, T& center) {
+  const T support = (scale >= T(1)) ? scale : T(1);
+  center = scale * (T(i) + T(0.5));
+  invscale = (scale >= T(1)) ? T(1) / scale : T(1);
+  xmin = max((int)(center - support + T(0.5)), 0);
+  xsize = min((int)(center + support + T(0.5)), in_size) - xmin;
+}
+template <typename T>
+__device__ __forceinline__ T aa_w(int j, int xmin, T center, T invscale) {
+  T x = (T(j + xmin) - center + T(0.5)) * invscale;
+  x = x < T(0) ? -x : x;
+  return x < T(1) ? T(1) - x : T(0);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void resize_aa_kernel(const T* __restrict__ in, T* __restrict__ out, int Hi, int Wi, int Ho,
+                                                        int Wo, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+  const long nc = i / ((long)Wo * Ho);
+  const T sy = (T)Hi / (T)Ho, sx = (T)Wi / (T)Wo;
+  int ymin, ysz, xmin, xsz;
+  T yinv, ycen, xinv, xcen;
+  aa_taps<T>(y, sy, Hi, ymin, ysz, yinv, ycen);
+  aa_taps<T>(x, sx, Wi, xmin, xsz, xinv, xcen);
+  T wys = T(0), wxs = T(0);
+  for (int j = 0; j < ysz; ++j) wys += aa_w<T>(j, ymin, ycen, yinv);
+  for (int j = 0; j < xsz; ++j) wxs += aa_w<T>(j, xmin, xcen, xinv);
+  const T* p = in + nc * Hi * Wi;
+  // separable, horizontal pass first (aten runs the W pass, then the H pass on the intermediate)
+  T accv = T(0);
+  for (int jy = 0; jy < ysz; ++jy) {
+    const T wy = aa_w<T>(jy, ymin, ycen, yinv) / wys;
+    T row = T(0);
+    for (int jx = 0; jx < xsz; ++jx) row += (aa_w<T>(jx, xmin, xcen, xinv) / wxs) * p[(long)(ymin + jy) * Wi + xmin + jx];
+    accv += wy * row;
+  }
+  out[i] = accv;
+}
+
+}  // namespace como
+
+extern "C" {
+
+int como_nn_conv2d_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
+                       int H, int W, int ks, int out_ctot, int out_coff, como_stream_t stream) {
+  using namespace como;
+  if (!in || !wt || !out || N <= 0 || Cin <= 0 || CinP < Cin || (CinP & 3) || Cout <= 0 || H <= 0 || W <= 0 ||
+      (ks != 1 && ks != 3) || out_ctot < out_coff + Cout)
+    return COMO_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const int HW = H * W;
+  const unsigned gx = (unsigned)((HW + 255) / 256);
+  const int mt = (Cout >= 32) ? 2 : 1;
+  const dim3 grid(gx, (unsigned)((Cout + 16 * mt - 1) / (16 * mt)), (unsigned)N);
+  if (ks == 3 && mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<3, 2>), grid, dim3(256), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff);
+  else if (ks == 3) hipLaunchKernelGGL((conv_mfma_kernel<3, 1>), grid, dim3(256), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff);
+  else if (mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<1, 2>), grid, dim3(256), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff);
+  else hipLaunchKernelGGL((conv_mfma_kernel<1, 1>), grid, dim3(256), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_nn_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* residual, float* out,
+                          float* stats, int N, int C, int G, int HW, float eps, float slope, int act, como_stream_t stream) {
+  using namespace como;
+  if (!x || !gamma || !beta || !out || !stats || N <= 0 || C <= 0 || G <= 0 || (C % G) || HW <= 0 || act < 0 || act > 2 ||
+      (act == 2 && !residual))
+    return COMO_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)(N * G)), dim3(256), 0, s, x, C, G, HW, eps, stats);
+  COMO_CHECK_LAUNCH();
+  const long total = (long)N * C * HW;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, stats, gamma, beta, residual,
+                     out, C, G, HW, slope, act, total);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_nn_maxpool2_f32(const float* in, float* out, int NC, int H, int W, como_stream_t stream) {
+  if (!in || !out || NC <= 0 || H < 2 || W < 2) return COMO_ERR_ARG;
+  const long total = (long)NC * (H / 2) * (W / 2);
+  hipLaunchKernelGGL(como::maxpool2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     H, W, total);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_nn_upsample2x_f32(const float* in, float* out, int NC, int H, int W, como_stream_t stream) {
+  if (!in || !out || NC <= 0 || H <= 0 || W <= 0) return COMO_ERR_ARG;
+  const long total = (long)NC * H * W * 4;
+  hipLaunchKernelGGL(como::upsample2x_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     out, H, W, total);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_nn_normalize_f32(const float* in, float* out, int N, int HW, const float* mean3, const float* std3,
+                          como_stream_t stream) {
+  if (!in || !out || !mean3 || !std3 || N <= 0 || HW <= 0) return COMO_ERR_ARG;
+  como::Norm3 nm;
+  for (int k = 0; k < 3; ++k) { nm.mean[k] = mean3[k]; nm.sd[k] = std3[k]; }
+  const long total = (long)N * 3 * HW;
+  hipLaunchKernelGGL(como::normalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     HW, nm, total);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_nn_cov_act_f32(const float* in, float* out, int N, int HW, como_stream_t stream) {
+  if (!in || !out || N <= 0 || HW <= 0) return COMO_ERR_ARG;
+  const long total = (long)N * HW;
+  hipLaunchKernelGGL(como::cov_act_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     HW, total);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_nn_resize_aa_f32(const float* in, float* out, int NC, int Hi, int Wi, int Ho, int Wo, como_stream_t stream) {
+  if (!in || !out || NC <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return COMO_ERR_ARG;
+  const long total = (long)NC * Ho * Wo;
+  hipLaunchKernelGGL(como::resize_aa_kernel<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     in, out, Hi, Wi, Ho, Wo, total);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+int como_nn_resize_aa_f64(const double* in, double* out, int NC, int Hi, int Wi, int Ho, int Wo, como_stream_t stream) {
+  if (!in || !out || NC <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0) return COMO_ERR_ARG;
+  const long total = (long)NC * Ho * Wo;
+  hipLaunchKernelGGL(como::resize_aa_kernel<double>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     in, out, Hi, Wi, Ho, Wo, total);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,160 @@
+"""DepthCov UNet on the HIP kernels of csrc/nn.hip (float32 inference).
+
+Mirror of como/depth_cov/nn/UNet.py:8-78 and como/depth_cov/nn/layers.py:5-75.  Parameters come from a state dict with the
+reference's own key names (``base.conv1.weight`` ... ``up_convs.4.upsample.1.bias``, ``feature_convs.3.weight``), so a
+DepthCov checkpoint's ``gaussian_cov_net.*`` entries load unchanged.  Every convolution is an MFMA implicit GEMM; torch is
+used for buffers only.
+"""
+import ctypes
+
+import torch
+
+from como_amd import _lib
+
+LEAKY_SLOPE = 0.01      # nn.LeakyReLU default (layers.py:8)
+GN_GROUPS = 16          # nn.GroupNorm(16, C) (layers.py:17)
+GN_EPS = 1e-5
+
+
+def _relayout(w):
+    """torch conv weight (Cout, Cin, k, k) -> [k*k][CinP][Cout] with CinP = Cin rounded up to 4."""
+    cout, cin, k, _ = w.shape
+    cinp = (cin + 3) // 4 * 4
+    out = torch.zeros((k * k, cinp, cout), dtype=torch.float32, device=w.device)
+    out[:, :cin, :] = w.permute(2, 3, 1, 0).reshape(k * k, cin, cout)
+    return out.contiguous(), cin, cinp, cout, k
+
+
+class _Conv:
+    def __init__(self, weight, bias):
+        self.wt, self.cin, self.cinp, self.cout, self.k = _relayout(weight.float())
+        self.bias = bias.float().contiguous()
+
+    def __call__(self, x, out=None, coff=0):
+        N, C, H, W = x.shape
+        assert C == self.cin and x.dtype == torch.float32 and x.is_contiguous()
+        if out is None:
+            out = torch.empty((N, self.cout, H, W), dtype=torch.float32, device=x.device)
+        rc = _lib.lib().como_nn_conv2d_f32(x.data_ptr(), self.wt.data_ptr(), self.bias.data_ptr(), out.data_ptr(), N,
+                                           self.cin, self.cinp, self.cout, H, W, self.k, out.shape[1], coff,
+                                           _lib.stream_ptr(x.device))
+        _lib.check(rc, "como_nn_conv2d_f32")
+        return out
+
+
+def _groupnorm(x, gamma, beta, act, residual=None):
+    N, C, H, W = x.shape
+    out = torch.empty_like(x)
+    stats = torch.empty((N * GN_GROUPS * 2,), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().como_nn_groupnorm_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                          residual.data_ptr() if residual is not None else None, out.data_ptr(),
+                                          stats.data_ptr(), N, C, GN_GROUPS, H * W, GN_EPS, LEAKY_SLOPE, act,
+                                          _lib.stream_ptr(x.device))
+    _lib.check(rc, "como_nn_groupnorm_f32")
+    return out
+
+
+class ResidualConv:
+    """layers.py:5-27: act(conv3(x) + norm(conv2(act(norm(conv1(x)))))) -- ONE GroupNorm module used twice."""
+
+    def __init__(self, sd, prefix):
+        self.conv1 = _Conv(sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"])
+        self.conv2 = _Conv(sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"])
+        self.conv3 = _Conv(sd[prefix + "conv3.weight"], sd[prefix + "conv3.bias"])
+        self.gamma = sd[prefix + "norm.weight"].float().contiguous()
+        self.beta = sd[prefix + "norm.bias"].float().contiguous()
+
+    def __call__(self, x):
+        y = _groupnorm(self.conv1(x), self.gamma, self.beta, 1)
+        y2 = self.conv2(y)
+        skip = self.conv3(x)
+        return _groupnorm(y2, self.gamma, self.beta, 2, residual=skip)
+
+
+def maxpool2(x):
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().como_nn_maxpool2_f32(x.data_ptr(), out.data_ptr(), N * C, H, W, _lib.stream_ptr(x.device)),
+               "como_nn_maxpool2_f32")
+    return out
+
+
+def upsample2x(x):
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().como_nn_upsample2x_f32(x.data_ptr(), out.data_ptr(), N * C, H, W, _lib.stream_ptr(x.device)),
+               "como_nn_upsample2x_f32")
+    return out
+
+
+def normalize_imagenet(x):
+    """transforms.Normalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]) (UNet.py:24-27)."""
+    N, C, H, W = x.shape
+    assert C == 3
+    out = torch.empty_like(x)
+    mean = (ctypes.c_float * 3)(0.485, 0.456, 0.406)
+    std = (ctypes.c_float * 3)(0.229, 0.224, 0.225)
+    _lib.check(_lib.lib().como_nn_normalize_f32(x.data_ptr(), out.data_ptr(), N, H * W, mean, std, _lib.stream_ptr(x.device)),
+               "como_nn_normalize_f32")
+    return out
+
+
+def cov_activation(f):
+    """gk.kernel_params_to_covariance(gk.normalize_params_cov(f)) : (N,3,H,W) -> (N,4,H,W)."""
+    N, C, H, W = f.shape
+    assert C == 3
+    out = torch.empty((N, 4, H, W), dtype=torch.float32, device=f.device)
+    _lib.check(_lib.lib().como_nn_cov_act_f32(f.data_ptr(), out.data_ptr(), N, H * W, _lib.stream_ptr(f.device)),
+               "como_nn_cov_act_f32")
+    return out
+
+
+def resize_aa(x, size):
+    """TF.resize(x, size, BILINEAR, antialias=True) (Mapping.py:411-426) for float32 / float64 NCHW tensors."""
+    _lib.require_cuda(x)
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    out = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device)
+    fn = getattr(_lib.lib(), "como_nn_resize_aa_" + _lib.suffix(x.dtype))
+    _lib.check(fn(x.data_ptr(), out.data_ptr(), N * C, H, W, Ho, Wo, _lib.stream_ptr(x.device)), "como_nn_resize_aa")
+    return out
+
+
+class UNet:
+    """UNet.forward (UNet.py:57-78): returns the per-level feature maps AFTER the output activation is applied by the caller
+    (`feature_act`), finest level last."""
+
+    def __init__(self, state_dict, num_levels=5, prefix="", feature_act=None):
+        sd = state_dict
+        self.num_levels = num_levels
+        self.base = ResidualConv(sd, prefix + "base.")
+        self.down = [ResidualConv(sd, f"{prefix}down_convs.{i}.conv_block.") for i in range(num_levels)]
+        self.up_conv = [_Conv(sd[f"{prefix}up_convs.{i}.upsample.1.weight"], sd[f"{prefix}up_convs.{i}.upsample.1.bias"])
+                        for i in range(num_levels)]
+        self.up_block = [ResidualConv(sd, f"{prefix}up_convs.{i}.conv_block.") for i in range(num_levels)]
+        self.feature = [_Conv(sd[f"{prefix}feature_convs.{i}.weight"], sd[f"{prefix}feature_convs.{i}.bias"])
+                        for i in range(num_levels - 1)]
+        self.feature_act = feature_act
+
+    def forward(self, x):
+        _lib.require_cuda(x)
+        x = normalize_imagenet(x.float().contiguous())
+        enc = [self.base(x)]
+        for i in range(self.num_levels):
+            enc.append(self.down[i](maxpool2(enc[-1])))                     # DownConv (layers.py:30-43)
+        out = []
+        dec = enc[-1]
+        for i in range(self.num_levels - 1, -1, -1):                         # UpConv (layers.py:46-75)
+            skip = enc[i]
+            N, c, H, W = skip.shape
+            cat = torch.empty((N, 2 * c, H, W), dtype=torch.float32, device=x.device)
+            self.up_conv[i](upsample2x(dec), out=cat, coff=0)
+            cat[:, c:].copy_(skip)
+            dec = self.up_block[i](cat)
+            if i < self.num_levels - 1:
+                f = self.feature[i](dec)
+                out.append(self.feature_act(f) if self.feature_act else f)
+        return out
+
+    __call__ = forward

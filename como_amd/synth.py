@@ -288,3 +288,39 @@ def make_tracking_pair(H=480, W=640, dtype=torch.float32, device="cpu", seed=0, 
         "Tji_init": T10_init.to(dtype).to(device),
         "levels": levels,
     }
+
+
+def depthcov_state_dict(seed=0, num_levels=5, base=16, feature_channels=3, device="cpu"):
+    """Seeded float32 parameters for the DepthCov network under the reference's state_dict key names
+    (como/depth_cov/core/DepthCovModule.py:22-31 -> UNet(num_levels=5, in=3, base=16, feature=3, k=3)).  There is no
+    checkpoint in this environment: weights are He-scaled normal draws from numpy's RandomState (bit-reproducible),
+    GroupNorm gains near 1."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    sd = {}
+
+    def conv(name, cout, cin, k):
+        sd[name + ".weight"] = torch.from_numpy((rs.randn(cout, cin, k, k) * np.sqrt(2.0 / (cin * k * k))).astype(np.float32))
+        sd[name + ".bias"] = torch.from_numpy((0.05 * rs.randn(cout)).astype(np.float32))
+
+    def resblock(prefix, cin, cout):
+        conv(prefix + "conv1", cout, cin, 3)
+        conv(prefix + "conv2", cout, cout, 3)
+        conv(prefix + "conv3", cout, cin, 1)
+        sd[prefix + "norm.weight"] = torch.from_numpy((1.0 + 0.1 * rs.randn(cout)).astype(np.float32))
+        sd[prefix + "norm.bias"] = torch.from_numpy((0.1 * rs.randn(cout)).astype(np.float32))
+
+    p = "gaussian_cov_net."
+    resblock(p + "base.", 3, base)
+    c = base
+    for i in range(num_levels):
+        resblock(f"{p}down_convs.{i}.conv_block.", c, 2 * c)
+        conv(f"{p}up_convs.{i}.upsample.1", c, 2 * c, 3)
+        resblock(f"{p}up_convs.{i}.conv_block.", 2 * c, c)
+        if i < num_levels - 1:
+            conv(f"{p}feature_convs.{i}", feature_channels, c, 1)
+        c *= 2
+    for i in range(num_levels - 1):
+        sd[f"cov_modules.{i}.scale_param"] = torch.tensor(0.0)
+        sd[f"log_depth_var_scales.{i}"] = torch.tensor(0.0)
+    return {k: v.to(device) for k, v in sd.items()}

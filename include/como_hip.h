@@ -220,6 +220,32 @@ int como_win_priors(const como_win_args* args_host, como_stream_t stream);
 int como_win_update(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
                     long lm_start, como_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * DepthCov covariance network, float32 inference (python path: como/depth_cov/nn/UNet.py:57-78 UNet.forward,
+ * como/depth_cov/nn/layers.py:5-75 ResidualConv / DownConv / UpConv, DepthCovModule.py:80-87, the output
+ * activation gaussian_kernel.py:6-49 and Mapping.run_model's antialiased resizes Mapping.py:409-428).
+ * All tensors NCHW contiguous.
+ *  conv2d   : stride 1, zero "same" padding, ks in {1,3}; wt is the torch weight (Cout,Cin,ks,ks) re-laid as
+ *             [ks*ks][CinP][Cout] with CinP = Cin rounded up to 4 (zero rows); bias may be NULL; the result is written
+ *             to channels [out_coff, out_coff+Cout) of an (N,out_ctot,H,W) tensor (torch.cat of UpConv, layers.py:72).
+ *  groupnorm: nn.GroupNorm(G, C) (biased variance, eps) followed by act: 0 none, 1 LeakyReLU(slope),
+ *             2 LeakyReLU(residual + y) (ResidualConv.forward, layers.py:23-27); stats: (N*G*2) float scratch.
+ *  maxpool2 : nn.MaxPool2d(2); upsample2x: nn.Upsample(scale 2, bilinear, align_corners=False);
+ *  normalize: torchvision Normalize(mean, std) on 3 channels (mean3/std3 are HOST pointers);
+ *  cov_act  : normalize_params_cov + kernel_params_to_covariance, (N,3,HW) -> (N,4,HW) = [x, s, s, z];
+ *  resize_aa: F.interpolate(mode="bilinear", antialias=True, align_corners=False). */
+int como_nn_conv2d_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
+                       int H, int W, int ks, int out_ctot, int out_coff, como_stream_t stream);
+int como_nn_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* residual, float* out,
+                          float* stats, int N, int C, int G, int HW, float eps, float slope, int act, como_stream_t stream);
+int como_nn_maxpool2_f32(const float* in, float* out, int NC, int H, int W, como_stream_t stream);
+int como_nn_upsample2x_f32(const float* in, float* out, int NC, int H, int W, como_stream_t stream);
+int como_nn_normalize_f32(const float* in, float* out, int N, int HW, const float* mean3, const float* std3,
+                          como_stream_t stream);
+int como_nn_cov_act_f32(const float* in, float* out, int N, int HW, como_stream_t stream);
+int como_nn_resize_aa_f32(const float* in, float* out, int NC, int Hi, int Wi, int Ho, int Wo, como_stream_t stream);
+int como_nn_resize_aa_f64(const double* in, double* out, int NC, int Hi, int Wi, int Ho, int Wo, como_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

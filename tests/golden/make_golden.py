@@ -388,9 +388,41 @@ def fullsize_scalars():
     return out
 
 
+def net_case(seed=0):
+    """DepthCovModule.forward (DepthCovModule.py:80-87) and Mapping.run_model (Mapping.py:409-428) of the reference with the
+    seeded weights of synth.depthcov_state_dict; images are seeded smooth noise in [0,1]."""
+    import torchvision.transforms.functional as TF
+    model = DepthCovModule()
+    sd = synth.depthcov_state_dict(seed)
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all("scale" in k or "var" in k for k in missing), (missing, unexpected)
+    model.eval()
+    gen = torch.Generator().manual_seed(seed + 100)
+    rgb = synth.smooth_noise(1, 3, 64, 96, gen, cells=5, dtype=torch.float32)
+    rgb = (rgb - rgb.amin()) / (rgb.amax() - rgb.amin())
+    with torch.no_grad():
+        covs = model(rgb)
+        raw = model.gaussian_cov_net.feature_convs[0]  # noqa: F841  (kept: documents the level order below)
+    out = {"rgb": rgb, "seed": seed}
+    for i, c in enumerate(covs):
+        out[f"cov_level{i}"] = c
+    # run_model at a reduced size pair (image 72x100 -> network 32x64 -> 72x100), same call sequence
+    rgb_big = synth.smooth_noise(1, 3, 72, 100, gen, cells=6, dtype=torch.float32)
+    rgb_big = (rgb_big - rgb_big.amin()) / (rgb_big.amax() - rgb_big.amin())
+    net_size = [32, 64]
+    with torch.no_grad():
+        rgb_r = TF.resize(rgb_big, net_size, interpolation=TF.InterpolationMode.BILINEAR, antialias=True).float()
+        cov = model(rgb_r)[-1].to(dtype=torch.float64)
+        cov_up = TF.resize(cov, rgb_big.shape[-2:], interpolation=TF.InterpolationMode.BILINEAR, antialias=True)
+    out.update({"rgb_big": rgb_big, "rgb_resized": rgb_r, "run_model_cov": cov_up, "net_size": np.array(net_size)})
+    return out
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full"]
+    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net"]
+    if "net" in which:
+        save("depthcov_net.npz", net_case(seed=0))
     if "ba" in which:
         save("ba_window_f64.npz", window_case(torch.float64, 3, 48, 64, 8, 2, seed=1, with_recent=False))
         save("ba_window_f32.npz", window_case(torch.float32, 3, 48, 64, 8, 2, seed=1, with_recent=False))

@@ -396,3 +396,69 @@ def test_cholesky_solve(D):
     Hbad[k, k] = -1.0
     ls.solve_system(dev(Hbad), dev(g))
     assert int(ls.solve_system.last_info) == k + 1        # first non-positive pivot, 1-based (cholesky_ex convention)
+
+
+# ------------------------------------------------------------------------------------------------
+# DepthCov covariance network (a36): HIP layers vs torch CPU ops, then the whole network vs the reference's output.
+def test_nn_layers_vs_torch():
+    import torch.nn.functional as F
+    from como_amd.depth_cov.nn import UNet as U
+    g = torch.Generator().manual_seed(3)
+    for (cin, cout, k, H, W) in [(3, 16, 3, 20, 28), (16, 32, 3, 6, 8), (48, 16, 1, 9, 7), (32, 3, 1, 12, 16), (64, 64, 3, 3, 4)]:
+        x = torch.randn(2, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        b = torch.randn(cout, generator=g)
+        ref = F.conv2d(x, w, b, padding=k // 2)
+        got = U._Conv(dev(w), dev(b))(dev(x))
+        e = rel_err(got, ref)
+        report(f"nn_conv_{cin}_{cout}_{k}", rel_err=e)
+        assert e < 2e-6, (cin, cout, k, e)                 # fp32 accumulation order only
+    x = torch.randn(2, 32, 10, 12, generator=g) * 3 + 1
+    ga, be, res = torch.randn(32, generator=g), torch.randn(32, generator=g), torch.randn(2, 32, 10, 12, generator=g)
+    ref = F.leaky_relu(res + F.group_norm(x, 16, ga, be, 1e-5), 0.01)
+    got = U._groupnorm(dev(x), dev(ga), dev(be), 2, residual=dev(res))
+    assert rel_err(got, ref) < 2e-6
+    ref = F.leaky_relu(F.group_norm(x, 16, ga, be, 1e-5), 0.01)
+    assert rel_err(U._groupnorm(dev(x), dev(ga), dev(be), 1), ref) < 2e-6
+    assert torch.equal(U.maxpool2(dev(x)).cpu(), F.max_pool2d(x, 2))
+    up = F.interpolate(x, scale_factor=(2, 2), mode="bilinear", align_corners=False)
+    assert rel_err(U.upsample2x(dev(x)), up) < 1e-6
+    for dt, tol in ((torch.float32, 2e-6), (torch.float64, 1e-13)):
+        img = torch.rand(1, 3, 72, 100, generator=g).to(dt)
+        for size in ((32, 64), (72, 100), (150, 211), (19, 23)):
+            ref = F.interpolate(img, size=list(size), mode="bilinear", antialias=True, align_corners=False)
+            e = rel_err(U.resize_aa(dev(img), size), ref)
+            assert e < tol, (dt, size, e)
+
+
+def test_depthcov_network_vs_reference():
+    """DepthCovModule.forward and Mapping.run_model on the seeded weights: HIP network vs the reference's outputs
+    (golden) and vs the CPU oracle.  fp32 tolerance 2e-4 relative to the largest covariance entry (30 conv / GroupNorm
+    layers deep, MFMA accumulation order)."""
+    from como_amd.depth_cov.core.DepthCovModule import DepthCovModule, run_model
+    from como_amd.synth import depthcov_state_dict
+    from oracle import unet as ounet
+    g = load_golden("depthcov_net.npz")
+    sd_cpu = depthcov_state_dict(int(g["seed"]))
+    model = DepthCovModule({k: dev(v) for k, v in sd_cpu.items()})
+    covs = model(dev(g["rgb"]))
+    assert len(covs) == 4
+    for i, c in enumerate(covs):
+        e = rel_err(c, g[f"cov_level{i}"])
+        report(f"depthcov_level{i}", rel_err=e)
+        assert e < 2e-4, (i, e)
+    cov = run_model(model, dev(g["rgb_big"]), network_size=g["net_size"].tolist())
+    assert cov.dtype == torch.float64 and tuple(cov.shape) == tuple(g["run_model_cov"].shape)
+    e = rel_err(cov, g["run_model_cov"])
+    report("depthcov_run_model", rel_err=e)
+    assert e < 2e-4
+    # full operating size of the reference (192x256 network, 480x640 image) against the oracle
+    gen = torch.Generator().manual_seed(11)
+    rgb = torch.rand(1, 3, 480, 640, generator=gen)
+    rgb = torch.nn.functional.avg_pool2d(rgb, 9, stride=1, padding=4)
+    with torch.no_grad():
+        ref = ounet.run_model(sd_cpu, rgb)
+    got = run_model(model, dev(rgb))
+    e = rel_err(got, ref)
+    report("depthcov_run_model_480x640", rel_err=e)
+    assert e < 2e-4

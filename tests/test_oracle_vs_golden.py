@@ -216,3 +216,21 @@ def test_ref_native_op_matches_fixture(golden):
         pytest.skip("oracle/_ref not built (needs /root/reference)")
     C = golden("cov_ops_f32.npz")
     assert torch.equal(m.cross_covariance(C["x1"], C["E1"], C["x2"], C["E2"], float(C["scale"])), C["K12"])
+
+
+def test_depthcov_network_oracle_matches_reference(golden):
+    """oracle/unet.py vs the reference's DepthCovModule.forward / Mapping.run_model on the seeded weights."""
+    from oracle import unet as ounet
+    from como_amd.synth import depthcov_state_dict
+    g = golden("depthcov_net.npz")
+    sd = depthcov_state_dict(int(g["seed"]))
+    with torch.no_grad():
+        covs = ounet.depthcov_forward(sd, g["rgb"])
+        for i, c in enumerate(covs):
+            ref = g[f"cov_level{i}"]
+            assert c.shape == ref.shape
+            assert rel(c, ref) < 1e-6, (i, rel(c, ref))
+        r = ounet.resize_aa(g["rgb_big"], g["net_size"].tolist())
+        assert rel(r, g["rgb_resized"]) < 1e-7
+        cov = ounet.run_model(sd, g["rgb_big"], network_size=g["net_size"].tolist())
+        assert cov.dtype == torch.float64 and rel(cov, g["run_model_cov"]) < 1e-6
