@@ -84,6 +84,14 @@ SIGNATURES = {
     "como_nn_cov_act_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "como_nn_resize_aa_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "como_nn_resize_aa_f64": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "como_img_grads_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "como_img_grads_f64": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "como_img_blur_down_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
+    "como_img_blur_down_f64": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
+    "como_subselect_pixels_f32": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p] * 3),
+    "como_subselect_pixels_f64": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p] * 3),
+    "como_track_precalc_jac_f32": (c_int, [c_void_p] * 5 + [c_long, c_void_p]),
+    "como_track_precalc_jac_f64": (c_int, [c_void_p] * 5 + [c_long, c_void_p]),
     "como_win_scaffold": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
     "como_win_priors": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
     "como_win_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),

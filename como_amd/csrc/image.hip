@@ -1,0 +1,151 @@
+// Per-frame image operators (gfx950): Scharr gradients, [1 2 1]^2 blur + decimation, max-gradient pixel sub-selection,
+// inverse-compositional tracking Jacobians.
+//
+// Reference: como/utils/image_processing.py:8-44 (ImageGradientModule: Scharr/32, reflect padding), :47-87
+// (GaussianBlurModule / ImagePyramidModule: blur then [0::2, 0::2]), como/odom/backend/sparse_map.py:116-142
+// (subselect_pixels: max_pool2d(return_indices) of sqrt(gx^2+gy^2)), como/odom/frontend/photo_tracking.py:46-74
+// (precalc_jacobians).  All HBM-bound stencils: one thread per output element, rows coalesced.
+#include "common.cuh"
+#include "../../include/como_hip.h"
+
+namespace como {
+
+__device__ __forceinline__ int reflect1(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+// out (N, 3C, H, W) = cat(img, gx, gy) along channels (Mapping.get_img_and_grads layout)
+template <typename T>
+__global__ __launch_bounds__(256) void img_grads_kernel(const T* __restrict__ img, T* __restrict__ out, int C, int H, int W,
+                                                        long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W), y = (int)((i / W) % H);
+  const long nc = i / ((long)W * H);
+  const int c = (int)(nc % C);
+  const long n = nc / C;
+  const T* p = img + nc * H * W;
+  const int xm = reflect1(x - 1, W), xp = reflect1(x + 1, W), ym = reflect1(y - 1, H), yp = reflect1(y + 1, H);
+  const T tl = p[(long)ym * W + xm], tc = p[(long)ym * W + x], tr = p[(long)ym * W + xp];
+  const T ml = p[(long)y * W + xm], mc = p[(long)y * W + x], mr = p[(long)y * W + xp];
+  const T bl = p[(long)yp * W + xm], bc = p[(long)yp * W + x], br = p[(long)yp * W + xp];
+  const T k3 = T(3) / T(32), k10 = T(10) / T(32);           // the reference's kernel entries (1/32 * {3, 10})
+  const T gx = k3 * (tr - tl) + k10 * (mr - ml) + k3 * (br - bl);
+  const T gy = k3 * (bl - tl) + k10 * (bc - tc) + k3 * (br - tr);
+  const long HW = (long)H * W, pix = (long)y * W + x;
+  T* o = out + n * 3 * C * HW;
+  o[(long)c * HW + pix] = mc;
+  o[(long)(C + c) * HW + pix] = gx;
+  o[(long)(2 * C + c) * HW + pix] = gy;
+}
+
+// out (NC, ceil(H/2), ceil(W/2)) = blur(img)[0::2, 0::2]
+template <typename T>
+__global__ __launch_bounds__(256) void blur_down_kernel(const T* __restrict__ img, T* __restrict__ out, int H, int W, int Ho,
+                                                        int Wo, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int xo = (int)(i % Wo), yo = (int)((i / Wo) % Ho);
+  const long nc = i / ((long)Wo * Ho);
+  const T* p = img + nc * H * W;
+  const int x = 2 * xo, y = 2 * yo;
+  const int xm = reflect1(x - 1, W), xp = reflect1(x + 1, W), ym = reflect1(y - 1, H), yp = reflect1(y + 1, H);
+  const T k1 = T(1) / T(16), k2 = T(2) / T(16), k4 = T(4) / T(16);
+  out[i] = k1 * (p[(long)ym * W + xm] + p[(long)ym * W + xp] + p[(long)yp * W + xm] + p[(long)yp * W + xp]) +
+           k2 * (p[(long)ym * W + x] + p[(long)y * W + xm] + p[(long)y * W + xp] + p[(long)yp * W + x]) + k4 * p[(long)y * W + x];
+}
+
+// One thread per window cell: first maximum of sqrt(gx^2 + gy^2) in row-major scan (max_pool2d semantics).
+// img_and_grads (B, 3, H, W) gray; coords (B, n, 2) int64 (row, col); pixidx (B, n) int32 = row*W + col (may be NULL).
+template <typename T>
+__global__ __launch_bounds__(256) void subselect_kernel(const T* __restrict__ iag, int H, int W, int win, long* __restrict__ coords,
+                                                        int* __restrict__ pixidx, long total) {
+#pragma clang fp contract(off)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int Wo = W / win, Ho = H / win;
+  const int cx = (int)(i % Wo), cy = (int)((i / Wo) % Ho);
+  const long b = i / ((long)Wo * Ho);
+  const T* gx = iag + (b * 3 + 1) * H * W;
+  const T* gy = iag + (b * 3 + 2) * H * W;
+  T best = T(0);
+  int bi = -1;
+  for (int dy = 0; dy < win; ++dy)
+    for (int dx = 0; dx < win; ++dx) {
+      const int idx = (cy * win + dy) * W + cx * win + dx;
+      const T a = gx[idx], c = gy[idx];
+      const T v = sqrt(a * a + c * c);
+      if (bi < 0 || v > best || (v != v && best == best)) { best = v; bi = idx; }   // NaN propagates like max_pool2d
+    }
+  coords[2 * i] = bi / W;
+  coords[2 * i + 1] = bi % W;
+  if (pixidx) pixidx[i] = bi;
+}
+
+// J (N, 8) = [dI/dw . dpi/dP . [-[P]x , I3] (6), vals, 1]   (photo_tracking.py:46-74, c = 1)
+template <typename T>
+__global__ __launch_bounds__(256) void precalc_jac_kernel(const T* __restrict__ dI_dw, const T* __restrict__ P,
+                                                          const T* __restrict__ vals, const T* __restrict__ K,
+                                                          T* __restrict__ J, long N) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const T fx = K[0], fy = K[4];
+  const T X = P[3 * i], Y = P[3 * i + 1], Z = P[3 * i + 2];
+  const T gx = dI_dw[2 * i], gy = dI_dw[2 * i + 1];
+  // dI/dP = dI/dw . [[fx/Z, 0, -fx X/Z^2], [0, fy/Z, -fy Y/Z^2]]
+  const T a = gx * (fx / Z), b = gy * (fy / Z);
+  const T c = gx * (-(fx * X / Z) / Z) + gy * (-(fy * Y / Z) / Z);
+  // dP/dT = [-[P]x , I]:  -[P]x = [[0, Z, -Y], [-Z, 0, X], [Y, -X, 0]]
+  T* o = J + 8 * i;
+  o[0] = b * (-Z) + c * Y;
+  o[1] = a * Z + c * (-X);
+  o[2] = a * (-Y) + b * X;
+  o[3] = a;
+  o[4] = b;
+  o[5] = c;
+  o[6] = vals[i];
+  o[7] = T(1);
+}
+
+}  // namespace como
+
+extern "C" {
+
+#define COMO_DEF_IMAGE(SFX, T)                                                                                          \
+  int como_img_grads_##SFX(const T* img, T* out, int N, int C, int H, int W, como_stream_t stream) {                   \
+    if (!img || !out || N <= 0 || C <= 0 || H < 2 || W < 2) return COMO_ERR_ARG;                                       \
+    const long total = (long)N * C * H * W;                                                                            \
+    hipLaunchKernelGGL(como::img_grads_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,                 \
+                       (hipStream_t)stream, img, out, C, H, W, total);                                                 \
+    COMO_CHECK_LAUNCH();                                                                                               \
+    return COMO_OK;                                                                                                    \
+  }                                                                                                                    \
+  int como_img_blur_down_##SFX(const T* img, T* out, int NC, int H, int W, como_stream_t stream) {                     \
+    if (!img || !out || NC <= 0 || H < 2 || W < 2) return COMO_ERR_ARG;                                                \
+    const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;                                                                      \
+    const long total = (long)NC * Ho * Wo;                                                                             \
+    hipLaunchKernelGGL(como::blur_down_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,                 \
+                       (hipStream_t)stream, img, out, H, W, Ho, Wo, total);                                            \
+    COMO_CHECK_LAUNCH();                                                                                               \
+    return COMO_OK;                                                                                                    \
+  }                                                                                                                    \
+  int como_subselect_pixels_##SFX(const T* img_and_grads, int B, int H, int W, int window, long* coords, int* pixidx,   \
+                                  como_stream_t stream) {                                                              \
+    if (!img_and_grads || !coords || B <= 0 || window <= 0 || H < window || W < window) return COMO_ERR_ARG;            \
+    const long total = (long)B * (H / window) * (W / window);                                                          \
+    hipLaunchKernelGGL(como::subselect_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,                 \
+                       (hipStream_t)stream, img_and_grads, H, W, window, coords, pixidx, total);                       \
+    COMO_CHECK_LAUNCH();                                                                                               \
+    return COMO_OK;                                                                                                    \
+  }                                                                                                                    \
+  int como_track_precalc_jac_##SFX(const T* dI_dw, const T* P, const T* vals, const T* K, T* J, long N,                 \
+                                   como_stream_t stream) {                                                             \
+    if (!dI_dw || !P || !vals || !K || !J || N < 0) return COMO_ERR_ARG;                                               \
+    if (!N) return COMO_OK;                                                                                            \
+    hipLaunchKernelGGL(como::precalc_jac_kernel<T>, dim3((unsigned)((N + 255) / 256)), dim3(256), 0,                   \
+                       (hipStream_t)stream, dI_dw, P, vals, K, J, N);                                                  \
+    COMO_CHECK_LAUNCH();                                                                                               \
+    return COMO_OK;                                                                                                    \
+  }
+COMO_DEF_IMAGE(f32, float)
+COMO_DEF_IMAGE(f64, double)
+
+}  // extern "C"

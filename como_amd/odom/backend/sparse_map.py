@@ -91,17 +91,29 @@ def setup_point_to_frame(Pw_all, Twc, remap_variable_to_batch, K, reinit_P, medi
     return project_landmarks(Twc, Pwm, K[0, ...], rPwm, median_depths)
 
 
-def subselect_pixels(kf_img_and_grads, photo_window_size):
+def subselect_pixels(kf_img_and_grads, photo_window_size, want_pixidx=False):
     """Pixel of maximum gradient magnitude per window (sparse_map.py:116-142).
-    Returns coords (B,n,2) long (row, col) and batch_inds (B,n)."""
+    Returns coords (B,n,2) long (row, col) and batch_inds (B,n) [and the int32 linear pixel index for
+    como_dense_ref's K~ row lookup].  Gray CUDA tensors run csrc/image.hip; colour falls back to the torch formula."""
     B, c3, H, W = kf_img_and_grads.shape
     c = c3 // 3
-    gn = torch.sqrt(torch.sum(kf_img_and_grads[:, c:2 * c] ** 2 + kf_img_and_grads[:, 2 * c:] ** 2, dim=1))
-    _, idx = torch.nn.functional.max_pool2d(gn[:, None], kernel_size=photo_window_size, return_indices=True)
-    idx = idx.reshape(B, -1)
-    coords = torch.stack((idx // W, idx % W), dim=-1)
-    bi = torch.arange(B, device=idx.device)[:, None].expand(-1, idx.shape[1])
-    return coords, bi
+    if c == 1 and kf_img_and_grads.is_cuda:
+        from como_amd import _lib
+        x = kf_img_and_grads.contiguous()
+        n = (H // photo_window_size) * (W // photo_window_size)
+        coords = torch.empty((B, n, 2), dtype=torch.long, device=x.device)
+        pixidx = torch.empty((B, n), dtype=torch.int32, device=x.device)
+        fn = getattr(_lib.lib(), "como_subselect_pixels_" + _lib.suffix(x.dtype))
+        _lib.check(fn(x.data_ptr(), B, H, W, int(photo_window_size), coords.data_ptr(), pixidx.data_ptr(),
+                      _lib.stream_ptr(x.device)), "como_subselect_pixels")
+    else:
+        gn = torch.sqrt(torch.sum(kf_img_and_grads[:, c:2 * c] ** 2 + kf_img_and_grads[:, 2 * c:] ** 2, dim=1))
+        _, idx = torch.nn.functional.max_pool2d(gn[:, None], kernel_size=photo_window_size, return_indices=True)
+        idx = idx.reshape(B, -1)
+        coords = torch.stack((idx // W, idx % W), dim=-1)
+        pixidx = idx.to(torch.int32)
+    bi = torch.arange(B, device=coords.device)[:, None].expand(-1, coords.shape[1])
+    return (coords, bi, pixidx) if want_pixidx else (coords, bi)
 
 
 def backproject_cloud(logz_m, Knm_Kmminv, coords_n, intrinsics):

@@ -30,7 +30,16 @@ def _workspace(device, dtype, N):
 
 def precalc_jacobians(dI_dw, P, vals, intrinsics):
     """Inverse-compositional Jacobians at theta = 0 (reference photo_tracking.py:46-74).
-    dI_dw (B,N,c,2), P (B,N,3), vals (B,N,c) -> (B,N,c,8).  Once per keyframe per level: torch ops."""
+    dI_dw (B,N,c,2), P (B,N,3), vals (B,N,c) -> (B,N,c,8).  Gray CUDA input runs csrc/image.hip."""
+    if P.is_cuda and dI_dw.shape[2] == 1:
+        B, N = P.shape[:2]
+        dt = P.dtype
+        J = torch.empty((B, N, 1, 8), dtype=dt, device=P.device)
+        fn = getattr(_lib.lib(), "como_track_precalc_jac_" + _lib.suffix(dt))
+        _lib.check(fn(dI_dw.to(dt).contiguous().data_ptr(), P.contiguous().data_ptr(), vals.to(dt).contiguous().data_ptr(),
+                      intrinsics.to(dt).contiguous().data_ptr(), J.data_ptr(), B * N, _lib.stream_ptr(P.device)),
+                   "como_track_precalc_jac")
+        return J
     fx, fy = intrinsics[0, 0], intrinsics[1, 1]
     X, Y, Z = P[..., 0], P[..., 1], P[..., 2]
     zero = torch.zeros_like(Z)

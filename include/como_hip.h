@@ -246,6 +246,30 @@ int como_nn_cov_act_f32(const float* in, float* out, int N, int HW, como_stream_
 int como_nn_resize_aa_f32(const float* in, float* out, int NC, int Hi, int Wi, int Ho, int Wo, como_stream_t stream);
 int como_nn_resize_aa_f64(const double* in, double* out, int NC, int Hi, int Wi, int Ho, int Wo, como_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-frame image operators (python paths: como/utils/image_processing.py:8-44 ImageGradientModule,
+ * :47-87 GaussianBlurModule + ImagePyramidModule level step, como/odom/backend/sparse_map.py:116-142
+ * subselect_pixels, como/odom/frontend/photo_tracking.py:46-74 precalc_jacobians).  NCHW contiguous.
+ *  img_grads       : img (N,C,H,W) -> out (N,3C,H,W) = cat(img, Scharr_x/32, Scharr_y/32), reflect padding
+ *                    (the layout Mapping.get_img_and_grads / Tracking build with torch.cat).
+ *  img_blur_down   : [1 2 1]^2/16 blur (reflect) followed by [0::2, 0::2]: (NC,H,W) -> (NC,ceil(H/2),ceil(W/2)).
+ *  subselect_pixels: gray img_and_grads (B,3,H,W); per window x window cell the FIRST maximum of sqrt(gx^2+gy^2)
+ *                    (max_pool2d(return_indices) semantics); coords (B,n,2) int64 (row,col), n = (H/w)(W/w);
+ *                    pixidx (B,n) int32 = row*W+col or NULL (the K~ row index of como_dense_ref_*).
+ *  track_precalc_jac: dI_dw (N,2), P (N,3), vals (N), K (3,3) -> J (N,8), c = 1. */
+int como_img_grads_f32(const float* img, float* out, int N, int C, int H, int W, como_stream_t stream);
+int como_img_grads_f64(const double* img, double* out, int N, int C, int H, int W, como_stream_t stream);
+int como_img_blur_down_f32(const float* img, float* out, int NC, int H, int W, como_stream_t stream);
+int como_img_blur_down_f64(const double* img, double* out, int NC, int H, int W, como_stream_t stream);
+int como_subselect_pixels_f32(const float* img_and_grads, int B, int H, int W, int window, long* coords, int* pixidx,
+                              como_stream_t stream);
+int como_subselect_pixels_f64(const double* img_and_grads, int B, int H, int W, int window, long* coords, int* pixidx,
+                              como_stream_t stream);
+int como_track_precalc_jac_f32(const float* dI_dw, const float* P, const float* vals, const float* K, float* J, long N,
+                               como_stream_t stream);
+int como_track_precalc_jac_f64(const double* dI_dw, const double* P, const double* vals, const double* K, double* J, long N,
+                               como_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
