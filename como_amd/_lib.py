@@ -21,6 +21,7 @@ class BAArgs(ctypes.Structure):
     _fields_ = [
         ("b", c_int), ("n", c_int), ("m", c_int), ("H", c_int), ("W", c_int), ("zmode", c_int), ("chunks", c_int),
         ("phase", c_int), ("h_is_f64", c_int), ("variant", c_int), ("stagger", c_int), ("pix_begin", c_int), ("pix_end", c_int),
+        ("anorm_f32", c_int),
         ("Pwn", c_void_p), ("vals", c_void_p), ("dPwn_dTwc", c_void_p), ("zjac", c_void_p), ("uvec", c_void_p),
         ("pixidx", c_void_p), ("invz", c_void_p), ("kt_slot_stride", c_long), ("poses_all", c_void_p),
         ("aff_all", c_void_p), ("img_base", c_void_p), ("K", c_void_p), ("ref_slot", c_void_p), ("ref_aff", c_void_p),
@@ -65,8 +66,8 @@ SIGNATURES = {
     "como_cross_covariance_f64": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int, c_int, c_int,
                                                         ctypes.POINTER(c_long), c_void_p]),
     "como_chol_append_obs_info_f32": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int, c_int, c_void_p]),
-    "como_dense_ref_f32": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8),
-    "como_dense_ref_f64": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8),
+    "como_dense_ref_f32": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 9),
+    "como_dense_ref_f64": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 9),
     "como_kernel_matrix_f32": (c_int, [c_void_p] * 4 + [c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "como_kernel_matrix_f64": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int, c_int, c_int, c_void_p]),
     "como_ktilde_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,

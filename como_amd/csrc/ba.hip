@@ -58,6 +58,7 @@ struct BAPairs {
   const int* tgt_aff;      // [b] index into aff_all of the target affine params
   const int* tgt_pose;     // [b] index into poses_all of the target pose
   const long* tgt_img;     // [b] element offset of the target [I,gx,gy] stack relative to img_base
+  int anorm_f32;           // sampling normalisation rounded to float32 first (two_frame_sfm.py:187-190)
 };
 
 template <typename T>
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(
   for (int k = 0; k < 12; ++k) Mr[k] = M[k];
   const T scale = pair_aff[2 * p], bias = pair_aff[2 * p + 1];
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
-  const T ax = T(1) / T(W), ay = T(1) / T(H);
+  const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
   const T* img = img_base + pr.tgt_img[p];
   const long HW = (long)H * W;
   __syncthreads();
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
   for (int k = 0; k < 12; ++k) Mr[k] = pair_T[12 * (long)p + k];
   const T scale = pair_aff[2 * p], bias = pair_aff[2 * p + 1];
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
-  const T ax = T(1) / T(W), ay = T(1) / T(H);
+  const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
   const T* img = img_base + pr.tgt_img[p];
   const long HW = (long)H * W;
 
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
   for (int k = 0; k < 12; ++k) Mr[k] = pair_T[12 * (long)p + k];
   const T scale = pair_aff[2 * p], bias = pair_aff[2 * p + 1];
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
-  const T ax = T(1) / T(W), ay = T(1) / T(H);
+  const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
   const T* img = img_base + pr.tgt_img[p];
   const long HW = (long)H * W;
   T invz4[4];
@@ -717,7 +718,7 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
       !A->ws_hists || !A->ws_pair || !A->ws_partials)
     return COMO_ERR_ARG;
   if (A->zmode == 1 && (!A->uvec || !A->invz)) return COMO_ERR_ARG;
-  BAPairs pr{A->ref_slot, A->ref_aff, A->tgt_aff, A->tgt_pose, A->tgt_img};
+  BAPairs pr{A->ref_slot, A->ref_aff, A->tgt_aff, A->tgt_pose, A->tgt_img, A->anorm_f32};
   const int b = A->b, n = A->n, m = A->m;
   const int pb = A->pix_begin, pe = (A->pix_end > 0) ? A->pix_end : n;
   if (pb < 0 || pe > n || pb >= pe) return COMO_ERR_ARG;

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void dense_ref_kernel(
     const T* __restrict__ Kt, long kt_slot_stride, const int* __restrict__ pixidx, const T* __restrict__ logzm,
     const T* __restrict__ Twc, const T* __restrict__ Kmat, const T* __restrict__ dlogzm_dTwc, int n, int m, int Wimg,
     T* __restrict__ Pwn, T* __restrict__ dPwn_dTwc, T* __restrict__ uvec, T* __restrict__ zbuf, T* __restrict__ logzn_out,
-    uint32_t* __restrict__ hists) {
+    uint32_t* __restrict__ hists, const int* __restrict__ pixcoord) {
   using KeyT = typename KeyOf<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
   __shared__ T coef[64][8];          // per inducing point: {logz_m, dlogz_m/dT (6), 0}
@@ -79,11 +79,12 @@ __global__ __launch_bounds__(256) void dense_ref_kernel(
     }
     const T logz = acc[0];
     const T z = exp(logz);                                       // depth.py:6-9
+    const int crow = pixcoord ? pixcoord[(long)b * n + i] : row;
     T rx, ry;
     {
 #pragma clang fp contract(off)
-      rx = (T(row % Wimg) - cx) / fx;                            // camera.py:43-47 with p = (col, row)
-      ry = (T(row / Wimg) - cy) / fy;
+      rx = (T(crow % Wimg) - cx) / fx;                           // camera.py:43-47 with p = (col, row)
+      ry = (T(crow / Wimg) - cy) / fy;
     }
     const T Xc = z * rx, Yc = z * ry, Zc = z;                    // P = z * ray
     T Xw, Yw, Zw;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
     const float* __restrict__ Kt, long kt_slot_stride, const int* __restrict__ pixidx, const float* __restrict__ logzm,
     const float* __restrict__ Twc, const float* __restrict__ Kmat, const float* __restrict__ dlogzm_dTwc, int n, int m,
     int Wimg, float* __restrict__ Pwn, float* __restrict__ dPwn_dTwc, float* __restrict__ uvec, float* __restrict__ zbuf,
-    float* __restrict__ logzn_out, uint32_t* __restrict__ hists) {
+    float* __restrict__ logzn_out, uint32_t* __restrict__ hists, const int* __restrict__ pixcoord) {
   using T = float;
   using KeyT = typename KeyOf<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
@@ -201,11 +202,12 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
     const int row = pixidx ? pixidx[(long)b * n + i] : i;
     const T logz = a7[0];
     const T z = exp(logz);                                       // depth.py:6-9
+    const int crow = pixcoord ? pixcoord[(long)b * n + i] : row;
     T rx, ry;
     {
 #pragma clang fp contract(off)
-      rx = (T(row % Wimg) - cx) / fx;                            // camera.py:43-47 with p = (col, row)
-      ry = (T(row / Wimg) - cy) / fy;
+      rx = (T(crow % Wimg) - cx) / fx;                           // camera.py:43-47 with p = (col, row)
+      ry = (T(crow / Wimg) - cy) / fy;
     }
     const T Xc = z * rx, Yc = z * ry, Zc = z;
     T Xw, Yw, Zw;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(256) void ktilde_kernel(const T* __restrict__ cov, 
 template <typename T>
 int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logzm, const T* Twc, const T* Kmat,
               const T* dlogzm_dTwc, int B, int n, int m, int Wimg, T* Pwn, T* dPwn_dTwc, T* uvec, T* zbuf, T* logzn_out,
-              void* hists_v, T* med_out3, hipStream_t s) {
+              void* hists_v, T* med_out3, const int* pixcoord, hipStream_t s) {
   using KeyT = typename KeyOf<T>::type;
   if (!Kt || !logzm || !Twc || !Kmat || !dlogzm_dTwc || !Pwn || !dPwn_dTwc || !uvec || !zbuf || !hists_v || !med_out3 ||
       B <= 0 || n <= 0 || m <= 0 || m > 64 || (m & 3) || Wimg <= 0)
@@ -346,10 +348,10 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
     int gm = ((n + 63) / 64 + 3) / 4;
     if (gm > 256) gm = 256;
     hipLaunchKernelGGL(dense_ref_mfma_kernel, dim3(gm, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
-                       dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists);
+                       dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord);
   } else {
     hipLaunchKernelGGL(dense_ref_kernel<T>, dim3(gx, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
-                       dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists);
+                       dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord);
   }
   COMO_CHECK_LAUNCH();
   for (int p = 1; p < SelCfg<KeyT>::NPASS; ++p) {
@@ -369,18 +371,18 @@ int como_select_finish_f64(const void*, int, double*, como_stream_t);
 int como_dense_ref_f32(const float* Kt, long kt_slot_stride, const int* pixidx, const float* logzm, const float* Twc,
                        const float* K, const float* dlogzm_dTwc, int B, int n, int m, int Wimg, float* Pwn,
                        float* dPwn_dTwc, float* uvec, float* zbuf, float* logzn_out, void* hists, float* med_out3,
-                       como_stream_t stream) {
+                       const int* pixcoord, como_stream_t stream) {
   int rc = como::dense_ref<float>(Kt, kt_slot_stride, pixidx, logzm, Twc, K, dlogzm_dTwc, B, n, m, Wimg, Pwn, dPwn_dTwc, uvec,
-                                  zbuf, logzn_out, hists, med_out3, (hipStream_t)stream);
+                                  zbuf, logzn_out, hists, med_out3, pixcoord, (hipStream_t)stream);
   if (rc) return rc;
   return como_select_finish_f32(hists, B, med_out3, stream);
 }
 int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx, const double* logzm, const double* Twc,
                        const double* K, const double* dlogzm_dTwc, int B, int n, int m, int Wimg, double* Pwn,
                        double* dPwn_dTwc, double* uvec, double* zbuf, double* logzn_out, void* hists, double* med_out3,
-                       como_stream_t stream) {
+                       const int* pixcoord, como_stream_t stream) {
   int rc = como::dense_ref<double>(Kt, kt_slot_stride, pixidx, logzm, Twc, K, dlogzm_dTwc, B, n, m, Wimg, Pwn, dPwn_dTwc, uvec,
-                                   zbuf, logzn_out, hists, med_out3, (hipStream_t)stream);
+                                   zbuf, logzn_out, hists, med_out3, pixcoord, (hipStream_t)stream);
   if (rc) return rc;
   return como_select_finish_f64(hists, B, med_out3, stream);
 }

@@ -42,7 +42,7 @@ def default_chunks(b, n, dtype):
 def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac, poses_all, aff_all, img_base, K,
               ref_slot, ref_aff, tgt_aff, tgt_pose, tgt_img, pose_ref_inds, pose_tgt_inds, landmark_inds, dzdP, H, g,
               err_out, uvec=None, pixidx=None, invz=None, kt_slot_stride=0, chunks=None, phase=0xFF, want_pj=False,
-              want_blocks=False, sigma_out=None, pix_range=None, reduce_hists=None, events=None):
+              want_blocks=False, sigma_out=None, pix_range=None, reduce_hists=None, events=None, anorm_f32=False):
     """Thin marshalling layer over como_ba_linearize_* (see include/como_hip.h for every field).
 
     pix_range=(begin, end): this rank's share of the reference pixels of every pair (multi-GPU shard).
@@ -58,6 +58,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     a = _lib.BAArgs()
     a.b, a.n, a.m, a.H, a.W, a.zmode, a.chunks, a.phase = b, n, m, H_img, W_img, zmode, chunks, phase
     a.pix_begin, a.pix_end = pb, pe
+    a.anorm_f32 = 1 if anorm_f32 else 0
     a.variant = BLOCK_VARIANT
     a.stagger = BLOCK_STAGGER
     a.h_is_f64 = 1 if H.dtype == torch.float64 else 0

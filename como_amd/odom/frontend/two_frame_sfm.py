@@ -1,0 +1,168 @@
+"""Two-frame photometric SfM initialisation on the GPU (reference como/odom/frontend/two_frame_sfm.py).
+
+construct_photo_system (:232-269) is expressed through the SAME HIP kernels as the window BA: with T_wi := Tji and
+T_wj := I the pair (i -> j) of batch_photo_cost has Pw = Tji Pi = Pj, its reference-pose block is d r / d Tji (right
+perturbation) and its depth columns, with invz = 1 and dlogz_m/dT = 0, are d r / d(log-depth codes) = (dI/dPi . ray z) K~.
+The system is assembled into a scratch (6 + 2 + 8 + m + 1) layout and the (6 + m) rows / columns are gathered from it.
+The priors (:115-177), the solve (:288-293) and the update (:296-303) are O(m^2) torch ops on the device.
+"""
+import torch
+
+from como_amd import _lib
+from como_amd.geometry import lie_algebra as lie
+from como_amd.odom.backend import photo
+from como_amd.odom.backend.dense_ref import dense_reference_factored
+
+_tables = {}
+
+
+def _table(m, device):
+    key = (m, str(device))
+    t = _tables.get(key)
+    if t is None:
+        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+        D = 16 + m + 1
+        lm = torch.full((1, 3 * m), D - 1, dtype=torch.long, device=device)       # d-columns -> 16+k; the two unused
+        lm[0, 0::3] = torch.arange(16, 16 + m, device=device)                      # "landmark" axes land in a trash row
+        sel = torch.cat((torch.arange(6, device=device), torch.arange(16, 16 + m, device=device)))
+        t = {"ref_slot": i32([0]), "ref_aff": i32([0]), "tgt_aff": i32([1]), "tgt_pose": i32([1]),
+             "tgt_img": torch.zeros(1, dtype=torch.int64, device=device),
+             "pose_ref": torch.arange(8, device=device).reshape(1, 8), "pose_tgt": torch.arange(8, 16, device=device).reshape(1, 8),
+             "lm": lm, "sel": sel, "D": D}
+        _tables[key] = t
+    return t
+
+
+def construct_photo_system(Tji, sparse_log_depth, aff, test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, intrinsics,
+                           photo_sigma, H, g):
+    """reference two_frame_sfm.py:232-269, same arguments and return tuple
+    (total_err, log_depth_i (1,N,1), coords_j, depths_j, valid_mask (1,N), Pi (1,N,3)); H (6+m,6+m), g (6+m) accumulated.
+    Gray images (c = 1); `aff` and `photo_sigma` are unused there as well."""
+    _lib.require_cuda(Tji, sparse_log_depth, test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, intrinsics, H, g)
+    dt, dev = Knm_Kmminv.dtype, Knm_Kmminv.device
+    N, m = Knm_Kmminv.shape[1], Knm_Kmminv.shape[2]
+    Hh, Ww = img_and_grads_j.shape[-2:]
+    if img_and_grads_j.shape[1] != 3:
+        raise RuntimeError("como_amd two_frame_sfm: gray images (c = 1) only")
+    tb = _table(m, dev)
+    pixcoord = (test_coords_i[..., 0] * Ww + test_coords_i[..., 1]).to(torch.int32).reshape(1, N).contiguous()
+    zeros6 = torch.zeros((1, m, 6), dtype=dt, device=dev)
+    Kt = Knm_Kmminv.contiguous()
+    Pj, dPj_dT, uvec, _, logz = dense_reference_factored(sparse_log_depth.reshape(1, m), Tji.reshape(1, 4, 4), Kt, None,
+                                                         intrinsics, zeros6, Ww, pixcoord=pixcoord)
+    poses = torch.stack((Tji.reshape(4, 4).to(dt), torch.eye(4, dtype=dt, device=dev))).contiguous()
+    aff0 = torch.zeros((2, 2), dtype=dt, device=dev)
+    D = tb["D"]
+    Hs = torch.zeros((D, D), dtype=dt, device=dev)
+    gs = torch.zeros((D,), dtype=dt, device=dev)
+    err = torch.zeros((), dtype=torch.float64, device=dev)
+    ones = torch.ones((1, m), dtype=dt, device=dev)
+    dzdP = torch.tensor([[1.0, 0.0, 0.0]], dtype=dt, device=dev)
+    photo.linearize(dtype=dt, b=1, n=N, m=m, H_img=Hh, W_img=Ww, zmode=1, Pwn=Pj, vals=vals_i.reshape(1, N).to(dt).contiguous(),
+                    dPwn_dTwc=dPj_dT, zjac=Kt, uvec=uvec, pixidx=None, invz=ones, kt_slot_stride=Kt.stride(0), poses_all=poses,
+                    aff_all=aff0, img_base=img_and_grads_j.to(dt).contiguous(), K=intrinsics.to(dt).contiguous(),
+                    ref_slot=tb["ref_slot"], ref_aff=tb["ref_aff"], tgt_aff=tb["tgt_aff"], tgt_pose=tb["tgt_pose"],
+                    tgt_img=tb["tgt_img"], pose_ref_inds=tb["pose_ref"], pose_tgt_inds=tb["pose_tgt"], landmark_inds=tb["lm"],
+                    dzdP=dzdP, H=Hs, g=gs, err_out=err, want_pj=True, anorm_f32=True)
+    sel = tb["sel"]
+    H += Hs[sel][:, sel]
+    g += gs[sel]
+    aux = photo.last_aux
+    valid = aux["valid"].reshape(1, N).bool()
+    # Pi = Tji^-1 Pj is not needed by the kernels; the reference returns it (two_frame_sfm.py:269) -> rebuild from logz
+    z = torch.exp(logz.reshape(1, N, 1))
+    K = intrinsics
+    ray = torch.stack(((test_coords_i[..., 1].to(dt) - K[0, 2]) / K[0, 0], (test_coords_i[..., 0].to(dt) - K[1, 2]) / K[1, 1],
+                       torch.ones((1, N), dtype=dt, device=dev)), dim=-1)
+    Pi = z * ray
+    pj = aux["pj"].reshape(1, N, 2)
+    vm = valid[0]
+    coords_j = torch.stack((pj[0, vm, 1], pj[0, vm, 0]), dim=-1)[None]                   # swap_coords_xy(pj)[valid]
+    depths_j = Pj[0, 2, vm].reshape(1, -1, 1)
+    return err.to(dt), logz.reshape(1, N, 1).clone(), coords_j, depths_j, valid, Pi
+
+
+def linearize_sparse_depth_prior(L_mm):
+    """:115-125"""
+    B, m, _ = L_mm.shape
+    eye = torch.eye(m, device=L_mm.device).unsqueeze(0).repeat(B, 1, 1)
+    dr_dd = torch.linalg.solve_triangular(L_mm, eye.to(L_mm.dtype), upper=False)
+    return dr_dd, torch.einsum("hjk,hjl->hkl", dr_dd, dr_dd)
+
+
+def linearize_mean_log_depth_prior_system(Knm_Kmminv):
+    """:128-134"""
+    N = Knm_Kmminv.shape[1]
+    dr_dd = torch.sum(Knm_Kmminv, dim=1, keepdim=True) / N
+    return dr_dd, torch.einsum("hjk,hjl->hkl", dr_dd, dr_dd)
+
+
+def construct_sparse_depth_prior_system(sparse_log_depth_ref, H, g, dr_dd, H_d_d):
+    """:137-148"""
+    r = torch.matmul(dr_dd, sparse_log_depth_ref)
+    total_err = torch.sum(torch.square(r), dim=(1, 2))
+    g[6:] -= torch.sum(dr_dd * r, dim=1).flatten().squeeze(0)
+    H[6:, 6:] += H_d_d.squeeze(0)
+    return total_err
+
+
+def construct_mean_log_depth_prior_system(log_depth, H, g, dr_dd, H_d_d, sigma):
+    """:151-165"""
+    info_sqrt = 1.0 / sigma
+    r = torch.mean(log_depth, dim=(1, 2), keepdim=True) * info_sqrt
+    total_err = torch.sum(torch.square(r), dim=(1, 2))
+    g[6:] -= torch.sum(info_sqrt * dr_dd * r, dim=1).flatten()
+    H[6:, 6:] += (info_sqrt * info_sqrt) * torch.block_diag(*H_d_d)
+    return total_err
+
+
+def solve_delta(H, g):
+    """:288-293"""
+    L, _ = torch.linalg.cholesky_ex(H, upper=False, check_errors=False)
+    return torch.cholesky_solve(g[:, None], L, upper=False)
+
+
+def update_vars(T, sparse_log_depth, aff, delta):
+    """:296-303"""
+    return lie.batch_se3(T, delta[:6, 0].unsqueeze(0)), sparse_log_depth + delta[6:], aff
+
+
+def two_frame_sfm(Tji_init, sparse_log_depth_init, aff_init, test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, dr_prior_dd,
+                  H_prior_d_d, intrinsics, sigmas, term_criteria, init_cfg):
+    """:306-392 (one host read-back per iteration for the stop test, as the reference)."""
+    dev, dt = Tji_init.device, Tji_init.dtype
+    m = sparse_log_depth_init.shape[1]
+    D = 6 + m
+    Tji, d, aff = Tji_init.clone(), sparse_log_depth_init.clone(), aff_init.clone()
+    dr_mean_dd, H_mean_d_d = linearize_mean_log_depth_prior_system(Knm_Kmminv)
+    it, prev = 0, float("inf")
+    while True:
+        H = torch.zeros((D, D), device=dev, dtype=dt)
+        g = torch.zeros((D,), device=dev, dtype=dt)
+        photo_err, log_depth, coords_j, depths_j, valid, Pi = construct_photo_system(
+            Tji, d, aff, test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, intrinsics, sigmas["photo"], H, g)
+        e_d = construct_sparse_depth_prior_system(d, H, g, dr_prior_dd, H_prior_d_d)
+        e_m = construct_mean_log_depth_prior_system(log_depth, H, g, dr_mean_dd, H_mean_d_d, sigma=1e0)
+        total = float(photo_err + e_d + e_m)
+        delta = solve_delta(H, g)
+        Tji, d, aff = update_vars(Tji, d, aff, delta)
+        it += 1
+        dn = float(torch.norm(delta[:6]))
+        dec = prev - total
+        rel = abs(dec) / prev
+        if it >= init_cfg["max_iter"] or dn < init_cfg["delta_norm"] or (rel < init_cfg["rel_tol"] and dec > 0):
+            break
+        prev = total
+    two_frame_sfm.last_iters = it
+    return Tji, d, aff, coords_j, depths_j, torch.mean(log_depth, dim=(1, 2), keepdim=True)
+
+
+def two_frame_sfm_pyr(Tji_init, sparse_log_depth_init, aff_init, test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j,
+                      dr_prior_dd, H_prior_d_d, intrinsics, sigmas, term_criteria, init_cfg):
+    """:15-52 (lists ordered coarse -> fine)."""
+    Tji, d, aff = Tji_init.clone(), sparse_log_depth_init.clone(), aff_init.clone()
+    for l in range(len(vals_i)):
+        Tji, d, aff, coords_j, depths_j, mld = two_frame_sfm(Tji, d, aff, test_coords_i[l], vals_i[l], Knm_Kmminv[l],
+                                                             img_and_grads_j[l], dr_prior_dd, H_prior_d_d, intrinsics[l],
+                                                             sigmas, term_criteria, init_cfg)
+    return Tji, d, aff, coords_j, depths_j, mld

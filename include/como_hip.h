@@ -81,6 +81,8 @@ typedef struct como_ba_args {
   int stagger;               /* pipelined kernel: start delay (x1024 cycles) of odd hardware wave slots, 0 = none */
   int pix_begin, pix_end;    /* reference-pixel range [begin,end) of every pair handled by this call (multi-GPU shard);
                                 pix_end <= 0 means n.  ws_r / ws_valid / pj_out are then (b, end-begin). */
+  int anorm_f32;             /* 1: the sampling normalisation 1/W, 1/H is rounded to float32 first (two_frame_sfm.py:187-190
+                                builds A_norm from an integer tensor -> float32 even in a float64 run); 0: computed in T */
   const void* Pwn;           /* zmode 0: (slots,n,3) photo.py:86 ; zmode 1: planes (slots,3,n) */
   const void* vals;          /* (slots,n)     photo.py:84 */
   const void* dPwn_dTwc;     /* zmode 0: (slots,n,3,6) photo.py:90 ; zmode 1: planes (slots,18,n) */
@@ -145,15 +147,17 @@ int como_chol_append_obs_info_f32(float* L, float* obs_info, float* var, const f
  * rows of the selected pixels (NULL = identity), logzm (B,m), Twc (B,4,4), K (3,3), dlogzm_dTwc (B,m,6).
  * Outputs (structure-of-arrays planes): Pwn (B,3,n), dPwn_dTwc (B,18,n) [full Jacobian incl. the path through
  * logz_m(T_wc)], uvec (B,3,n) = R_wc ray z_n, zbuf (B,n) = depth, logzn_out (B,n) optional,
- * med_out3 (B,3) = {exact median depth (sparse_map.py:220), 1.4826*median, n}.  hists: B * select workspace. */
+ * med_out3 (B,3) = {exact median depth (sparse_map.py:220), 1.4826*median, n}.  hists: B * select workspace.
+ * pixcoord (B,n) optional: linear pixel index row*W+col of every reference pixel when it differs from its K~ row
+ * (two-frame SfM passes K~ rows of the selected pixels only, two_frame_sfm.py:246-252); NULL = the K~ row index. */
 int como_dense_ref_f32(const float* Kt, long kt_slot_stride, const int* pixidx, const float* logzm, const float* Twc,
                        const float* K, const float* dlogzm_dTwc, int B, int n, int m, int Wimg, float* Pwn,
                        float* dPwn_dTwc, float* uvec, float* zbuf, float* logzn_out, void* hists, float* med_out3,
-                       como_stream_t stream);
+                       const int* pixcoord, como_stream_t stream);
 int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx, const double* logzm, const double* Twc,
                        const double* K, const double* dlogzm_dTwc, int B, int n, int m, int Wimg, double* Pwn,
                        double* dPwn_dTwc, double* uvec, double* zbuf, double* logzn_out, void* hists, double* med_out3,
-                       como_stream_t stream);
+                       const int* pixcoord, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * DepthCov covariance-kernel assembly, Python-twin formula (python path: depth_cov/core/kernels.py:22-88,

@@ -524,3 +524,32 @@ def test_precalc_jacobians_vs_golden():
         ref = otrk.ic_jacobians(dI[0, :, 0].to(dt), P[0].to(dt), vals[0, :, 0].to(dt), K.to(dt))
         assert tuple(J.shape) == (1, N, 1, 8)
         assert rel_err(J[0, :, 0], ref) < tol
+
+
+# ------------------------------------------------------------------------------------------------
+# Two-frame SfM system (a28/a29) through the BA kernels vs the reference's construct_photo_system
+def test_two_frame_sfm_system_vs_golden():
+    from como_amd.odom.frontend import two_frame_sfm as sfm
+    S = load_golden("sfm_f64.npz")
+    m = S["logz_m"].shape[1]
+    D = 6 + m
+    H = torch.zeros((D, D), dtype=torch.float64, device=DEV)
+    g = torch.zeros((D,), dtype=torch.float64, device=DEV)
+    aff = torch.zeros((1, 2, 1), dtype=torch.float64, device=DEV)
+    err, log_depth, coords_j, depths_j, valid, Pi = sfm.construct_photo_system(
+        dev(S["Tji"]), dev(S["logz_m"]), aff, dev(S["coords_i"]), dev(S["vals_i"]), dev(S["Kt"]), dev(S["img_and_grads_j"]),
+        dev(S["K"]), 0.1, H, g)
+    mism = (valid.cpu() != S["valid"]).sum().item()
+    eH, eg = rel_err(H, S["H"]), rel_err(g, S["g"])
+    ee = abs(err.item() - S["err"].item()) / S["err"].item()
+    report("sfm_system", mask_mismatch=mism, H_rel=eH, g_rel=eg, err_rel=ee, logz_rel=rel_err(log_depth, S["log_depth"]))
+    assert mism == 0                                            # validity mask bit-exact
+    assert rel_err(log_depth, S["log_depth"]) < 1e-13 and rel_err(Pi, S["Pi"]) < 1e-13
+    assert eH < 1e-10 and eg < 1e-10 and ee < 1e-10            # float64; same float32 A_norm as the reference
+    assert coords_j.shape[1] == int(S["valid"].sum()) and depths_j.shape[1] == coords_j.shape[1]
+    # a GN step reduces the cost and the loop terminates
+    dr, Hd = sfm.linearize_sparse_depth_prior(torch.eye(m, dtype=torch.float64, device=DEV)[None])
+    T, d, _, _, _, mld = sfm.two_frame_sfm(dev(S["Tji"]), dev(S["logz_m"]), aff, dev(S["coords_i"]), dev(S["vals_i"]), dev(S["Kt"]),
+                                          dev(S["img_and_grads_j"]), dr, Hd, dev(S["K"]), {"photo": 0.1}, {},
+                                          {"max_iter": 6, "delta_norm": 1e-9, "rel_tol": 1e-9})
+    assert torch.isfinite(T).all() and torch.isfinite(d).all() and sfm.two_frame_sfm.last_iters <= 6
