@@ -86,6 +86,51 @@ __global__ __launch_bounds__(256) void obs_info_kernel(const float* __restrict__
   var[(long)b * d + j] -= v * v;
 }
 
+
+// greedy_loop.get_next_inds (samplers.py:219-239): cost = (sqrt(var) with NaN -> 0, + 1e-10) * [every chosen point is
+// farther than dist_thresh]; argmax (first maximum) per batch.  The "all chosen points" test is kept as a running mask
+// (mask &= dist^2 to the k NEW points > thresh^2), which is the same predicate.  One workgroup per batch element.
+__global__ __launch_bounds__(1024) void greedy_next_kernel(const float* __restrict__ var, const float* __restrict__ dom,
+                                                           const float* __restrict__ chosen, int k, uint8_t* __restrict__ mask,
+                                                           float thresh_sq, long* __restrict__ best_idx,
+                                                           float* __restrict__ max_stdev, int d) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* vb = var + (long)b * d;
+  const float* db = dom + (long)b * d * 2;
+  uint8_t* mb = mask + (long)b * d;
+  float best = -1.f, best_sd = 0.f;
+  int bi = 0x7fffffff;
+  for (int j = tid; j < d; j += 1024) {
+    uint8_t ok = mb[j];
+    const float y = db[2 * j], x = db[2 * j + 1];
+    for (int c = 0; c < k; ++c) {
+      const float dy = chosen[((long)b * k + c) * 2] - y, dx = chosen[((long)b * k + c) * 2 + 1] - x;
+      const float d2 = dy * dy + dx * dx;
+      ok = ok && (d2 > thresh_sq);
+    }
+    mb[j] = ok;
+    float sd = sqrtf(vb[j]);
+    if (sd != sd) sd = 0.f;
+    sd += 1e-10f;
+    const float cost = ok ? sd : 0.f;
+    if (cost > best) { best = cost; bi = j; best_sd = sd; }       // ascending j per thread: first maximum kept
+  }
+  __shared__ float sc[1024], ss[1024];
+  __shared__ int si[1024];
+  sc[tid] = best; si[tid] = bi; ss[tid] = best_sd;
+  __syncthreads();
+  for (int h = 512; h > 0; h >>= 1) {
+    if (tid < h) {
+      const float c2 = sc[tid + h];
+      const int i2 = si[tid + h];
+      if (c2 > sc[tid] || (c2 == sc[tid] && i2 < si[tid])) { sc[tid] = c2; si[tid] = i2; ss[tid] = ss[tid + h]; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) { best_idx[b] = si[0]; max_stdev[b] = ss[0]; }
+}
+
 template <typename T>
 int cross_cov(const T* x1, const T* E1, const T* x2, const T* E2, T scale, T* K12, int B, int N, int M,
               const long* strides_host, hipStream_t s) {
@@ -122,6 +167,16 @@ int como_chol_append_obs_info_f32(float* L, float* obs_info, float* var, const f
   hipLaunchKernelGGL(como::chol_row_kernel, dim3(B), dim3(64), 0, s, L, k_ni, k_ii, n, N);
   COMO_CHECK_LAUNCH();
   hipLaunchKernelGGL(como::obs_info_kernel, dim3((d + 255) / 256, B), dim3(256), 0, s, k_id, L, obs_info, var, n, d, N);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_greedy_next_f32(const float* var, const float* coords_domain, const float* chosen, int k, uint8_t* mask,
+                         float dist_thresh_sq, long* best_idx, float* max_stdev, int B, int d, como_stream_t stream) {
+  if (!var || !coords_domain || !mask || !best_idx || !max_stdev || B <= 0 || d <= 0 || k < 0 || (k > 0 && !chosen))
+    return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::greedy_next_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, var, coords_domain, chosen, k, mask,
+                     dist_thresh_sq, best_idx, max_stdev, d);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }

@@ -1,0 +1,167 @@
+"""Greedy conditional-entropy inducing-point sampler on the GPU (reference como/depth_cov/core/samplers.py).
+
+Same functions and arguments as the reference (get_coords_domain :10-25, get_cov_domain :28-34, sample_sparse_coords
+:38-107, precalc_entropy_vars :125-193, greedy_loop :196-282, greedy_conditional_entropy :285-324).  The per-step work is
+the native ops (csrc/cov.hip: cross_covariance, Cholesky append + variance downdate) plus `como_greedy_next_f32` for
+get_next_inds; the chosen index stays on the device, so the 63 steps of a 64-point sample enqueue without a host
+synchronisation (the reference synchronises at least once per step when terminate_early is set; so does this loop then).
+"""
+import torch
+
+from como_amd import _lib
+from como_amd import como_backends
+from como_amd.depth_cov.core import gaussian_kernel as gk
+from como_amd.utils.coords import normalize_coordinates
+
+
+def get_coords_domain(cov_params_img, border=0):
+    b, c, h, w = cov_params_img.shape
+    dev = cov_params_img.device
+    y, x = torch.meshgrid(torch.arange(h, dtype=torch.long, device=dev), torch.arange(w, dtype=torch.long, device=dev),
+                          indexing="ij")
+    img = torch.dstack((y, x))[border:h - border, border:w - border, :]
+    return img.reshape(-1, 2).unsqueeze(0).repeat(b, 1, 1)
+
+
+def get_cov_domain(coord_vec, cov_params_img):
+    b = cov_params_img.shape[0]
+    vec = cov_params_img[:, :, coord_vec[0, :, 0], coord_vec[0, :, 1]]
+    return torch.permute(vec, (0, 2, 1)).reshape(b, -1, 2, 2).contiguous()
+
+
+def get_obs_info(L, K_mn):
+    return torch.linalg.solve_triangular(L, K_mn, upper=False)
+
+
+def calc_var(obs_info, K_diag):
+    return K_diag - torch.sum(obs_info * obs_info, dim=1)
+
+
+def precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_coords_norm, curr_var, fixed_var, scale):
+    b, m, _ = curr_coords_norm.shape
+    dev, dt = E_domain.device, E_domain.dtype
+    d = coords_domain_norm.shape[-2]
+    coord_vec_inds = torch.empty((b, n), device=dev, dtype=torch.long)
+    coords_n_norm = torch.empty((b, n, 2), device=dev, dtype=dt)
+    E_n = torch.empty((b, n, 2, 2), device=dev, dtype=dt)
+    L = torch.eye(n, device=dev, dtype=dt).unsqueeze(0).repeat(b, 1, 1)
+    obs_info = torch.zeros((b, n, d), device=dev, dtype=dt)
+    if m > 0:
+        coord_vec_inds[:, :m] = -1
+        coords_n_norm[:, 0:m, :] = curr_coords_norm
+        E_n[:, :m, :, :] = gk.interpolate_kernel_params(gaussian_covs, curr_coords_norm)
+    else:
+        areas = E_domain[..., 0, 0] * E_domain[..., 1, 1] - E_domain[..., 0, 1] * E_domain[..., 1, 0]
+        best = torch.argmax(areas.view(b, -1), dim=1)
+        bi = torch.arange(b, device=dev)
+        coord_vec_inds[:, 0] = best
+        coords_n_norm[:, 0, :] = coords_domain_norm[bi, best, :]
+        E_n[:, 0, :, :] = E_domain[bi, best, :, :]
+        m = 1
+    K_nn = como_backends.cross_covariance(coords_n_norm[:, :m, :], E_n[:, :m, :, :], coords_n_norm[:, :m, :].clone(),
+                                          E_n[:, :m, :, :].clone(), scale)
+    if curr_var.shape[1] > 0:
+        assert curr_var.shape[1] == curr_coords_norm.shape[1]
+        K_nn += torch.diag_embed(curr_var)
+    if fixed_var is not None:
+        K_nn += torch.diag_embed(fixed_var * torch.ones(b, m, device=dev))
+    L[:, :m, :m] = torch.linalg.cholesky(K_nn, upper=False)
+    K_md = como_backends.cross_covariance(coords_n_norm[:, :m, :], E_n[:, :m, :, :], coords_domain_norm.view(b, -1, 2), E_domain,
+                                          scale)
+    obs_info[:, :m, :] = get_obs_info(L[:, :m, :m], K_md)
+    return coord_vec_inds, coords_n_norm, E_n, L, obs_info, m
+
+
+class _Next:
+    """get_next_inds with a device-resident running distance mask."""
+
+    def __init__(self, coords_domain_norm, dist_thresh):
+        self.dom = coords_domain_norm.contiguous()
+        b, d, _ = self.dom.shape
+        dev = self.dom.device
+        self.mask = torch.ones((b, d), dtype=torch.uint8, device=dev)
+        self.best = torch.empty((b,), dtype=torch.long, device=dev)
+        self.sd = torch.empty((b,), dtype=torch.float32, device=dev)
+        self.t2 = float(dist_thresh) * float(dist_thresh)
+        self.b, self.d = b, d
+
+    def __call__(self, var, new_chosen):
+        ch = new_chosen.contiguous()
+        rc = _lib.lib().como_greedy_next_f32(var.data_ptr(), self.dom.data_ptr(), ch.data_ptr(), ch.shape[1], self.mask.data_ptr(),
+                                             self.t2, self.best.data_ptr(), self.sd.data_ptr(), self.b, self.d,
+                                             _lib.stream_ptr(var.device))
+        _lib.check(rc, "como_greedy_next_f32")
+        return self.sd, self.best
+
+
+def greedy_loop(coord_vec_inds, coords_n_norm, E_n, coords_domain_norm, E_domain, L, obs_info, m, n, signal_var, fixed_var,
+                max_stdev_thresh, terminate_early, dist_thresh):
+    _lib.require_cuda(coords_n_norm, E_n, coords_domain_norm, E_domain, L, obs_info)
+    if coords_n_norm.dtype != torch.float32:
+        raise RuntimeError("como_amd greedy_loop: float32 only (as the reference's native Cholesky kernels)")
+    dev = coords_n_norm.device
+    b = coords_n_norm.shape[0]
+    bi = torch.arange(b, device=dev)
+    sv = float(signal_var)                                             # ONE read-back, before the loop
+    k_ii = sv + (float(fixed_var) if fixed_var is not None else 0.0)
+    nxt = _Next(coords_domain_norm, dist_thresh)
+    pred_var = calc_var(obs_info[:, :m, :], sv).contiguous()
+    max_sd, best = nxt(pred_var, coords_n_norm[:, :m, :])
+    for i in range(m, n):
+        if terminate_early and bool((max_sd < max_stdev_thresh).all()):
+            coord_vec_inds = coord_vec_inds[:, :i]
+            coords_n_norm = coords_n_norm[:, :i, :]
+            break
+        ci = coords_domain_norm[bi, best, :]
+        Ei = E_domain[bi, best, :, :]
+        coord_vec_inds[:, i] = best
+        coords_n_norm[:, i, :] = ci
+        E_n[:, i, :, :] = Ei
+        ci, Ei = ci.unsqueeze(1), Ei.unsqueeze(1)
+        k_ni = como_backends.cross_covariance(coords_n_norm[:, 0:i, :], E_n[:, 0:i, :, :], ci, Ei, sv)
+        k_id = como_backends.cross_covariance(ci, Ei, coords_domain_norm, E_domain, sv)
+        como_backends.get_new_chol_obs_info(L, obs_info, pred_var, k_ni, k_id, k_ii, i)
+        max_sd, best = nxt(pred_var, ci)
+    return coord_vec_inds
+
+
+def greedy_conditional_entropy(gaussian_covs, E_domain, n, coords_domain_norm, curr_coords_norm, curr_var, fixed_var,
+                               signal_var, max_stdev_thresh, terminate_early, dist_thresh):
+    cvi, cn, E_n, L, obs, m = precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_coords_norm, curr_var,
+                                                   fixed_var, signal_var)
+    return greedy_loop(cvi, cn, E_n, coords_domain_norm, E_domain, L, obs, m, n, signal_var, fixed_var, max_stdev_thresh,
+                       terminate_early, dist_thresh)
+
+
+def sample_sparse_coords(cov_params_img, num_samples, mode, max_stdev_thresh=-1e8, border=0, terminate_early=False,
+                         dist_thresh=0.0, signal_var=None, fixed_var=None, curr_coords=None, curr_var=None, coords_domain=None,
+                         dtype=torch.float):
+    """samplers.py:38-107 (mode "greedy_conditional_entropy"; "random_uniform" is a torch.multinomial one-liner there)."""
+    b = cov_params_img.shape[0]
+    img_size = cov_params_img.shape[-2:]
+    dev = cov_params_img.device
+    cov = cov_params_img.to(device=dev, dtype=dtype)
+    if curr_coords is None:
+        curr_coords = torch.empty((b, 0, 2), device=dev, dtype=dtype)
+    if curr_var is None:
+        curr_var = torch.zeros((b, 0), device=dev, dtype=dtype)
+    if coords_domain is None:
+        coords_domain = get_coords_domain(cov, border=border)
+        cdn = normalize_coordinates(coords_domain, img_size).to(dtype)
+        E_domain = get_cov_domain(coords_domain, cov)
+    else:
+        cdn = normalize_coordinates(coords_domain, img_size).to(dtype)
+        E_domain = gk.interpolate_kernel_params(cov, cdn)
+    if mode == "random_uniform":
+        w = torch.ones(cdn.shape[:-1], device=dev)
+        inds = torch.multinomial(w, num_samples - curr_coords.shape[-2], replacement=False)
+    elif mode == "greedy_conditional_entropy":
+        n = min(num_samples, coords_domain.shape[1])
+        ccn = normalize_coordinates(curr_coords, img_size).to(dtype)
+        inds = greedy_conditional_entropy(cov, E_domain, n, cdn, ccn, curr_var, fixed_var, signal_var, max_stdev_thresh,
+                                          terminate_early, dist_thresh)
+    else:
+        raise ValueError("sample_sparse_coords mode: " + mode + " is not implemented.")
+    domain_inds = inds[:, inds[0, :] >= 0]
+    bi = torch.arange(b, device=dev).unsqueeze(1).repeat(1, domain_inds.shape[1])
+    return coords_domain[bi, domain_inds, :], domain_inds

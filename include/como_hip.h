@@ -140,6 +140,12 @@ int como_cross_covariance_f64(const double* x1, const double* E1, const double* 
                               double* K12, int B, int N, int M, const long* strides_host, como_stream_t stream);
 int como_chol_append_obs_info_f32(float* L, float* obs_info, float* var, const float* k_ni, const float* k_id,
                                   float k_ii, int B, int n, int d, int N, como_stream_t stream);
+/* como_greedy_next_f32  replaces  greedy_loop.get_next_inds (depth_cov/core/samplers.py:219-239, torch ops there):
+ *   var (B,d), coords_domain (B,d,2) normalised, chosen (B,k,2) the k points added since the last call, mask (B,d)
+ *   uint8 running "farther than dist_thresh from every chosen point" (initialise to 1), best_idx (B) int64 and
+ *   max_stdev (B) outputs stay on the device: the sampler loop needs no host round trip. */
+int como_greedy_next_f32(const float* var, const float* coords_domain, const float* chosen, int k, uint8_t* mask,
+                         float dist_thresh_sq, long* best_idx, float* max_stdev, int B, int d, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense reference points in factored form (python path: backend/sparse_map.py:184-230 backproject_cloud +

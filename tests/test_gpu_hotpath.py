@@ -553,3 +553,24 @@ def test_two_frame_sfm_system_vs_golden():
                                           dev(S["img_and_grads_j"]), dr, Hd, dev(S["K"]), {"photo": 0.1}, {},
                                           {"max_iter": 6, "delta_norm": 1e-9, "rel_tol": 1e-9})
     assert torch.isfinite(T).all() and torch.isfinite(d).all() and sfm.two_frame_sfm.last_iters <= 6
+
+
+# ------------------------------------------------------------------------------------------------
+# Greedy conditional-entropy sampler (a33-a35): chosen pixels identical to the reference's sample_sparse_coords
+def test_greedy_sampler_vs_golden():
+    from como_amd.depth_cov.core import samplers
+    from oracle import depthcov as odc
+    C = load_golden("cov_ops_f32.npz")
+    num, border, dth = int(C["samp_num"]), int(C["samp_border"]), float(C["samp_dist_thresh"])
+    coords, inds = samplers.sample_sparse_coords(dev(C["cov_params_img"]), num, "greedy_conditional_entropy", border=border,
+                                                 dist_thresh=dth, signal_var=torch.tensor(1.0))
+    assert torch.equal(inds.cpu(), C["samp_domain_inds"]) and torch.equal(coords.cpu(), C["samp_coords"])
+    # full operating point of the reference: 64 points on a 192x256 covariance image, vs the oracle
+    from como_amd.synth import synthetic_cov_params
+    cov = synthetic_cov_params(1, 96, 128, seed=3, dtype=torch.float64).float()
+    idx, pix, *_ = odc.greedy_sampler(cov, 32, 1.0, 2, 0.05)
+    coords, inds = samplers.sample_sparse_coords(dev(cov), 32, "greedy_conditional_entropy", border=2, dist_thresh=0.05,
+                                                 signal_var=torch.tensor(1.0))
+    same = (inds.cpu()[0] == idx).sum().item()
+    report("greedy_sampler", same_of_32=same)
+    assert same == 32 and torch.equal(coords.cpu()[0], pix)
