@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--eager", action="store_true", help="do not capture the iteration into a hipGraph")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the window-4 (reference default sub-selection) line")
     args = ap.parse_args()
 
     shard, device = cdist.init_from_env()
@@ -163,6 +164,36 @@ def main():
     pose_err = (wb.kf_poses - state["poses_gt"]).abs().max().item()
     pose_err0 = (pose0 - state["poses_gt"]).abs().max().item()
 
+    # HBM traffic of the dominant kernel: rocprofv3 PMC passes of THIS command, committed under profiles/
+    # (scripts/collect_profiles.sh); FETCH_SIZE doubled per the gfx950 note of guides/MI355X_MICROARCH.md, WRITE_SIZE as is.
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r1_bench_pmc_summary.json")
+    if os.path.exists(pmc_path) and args.gpus == 1 and args.window == 1 and args.dtype == "f32":
+        try:
+            pm = json.load(open(pmc_path))
+            key = [k for k in pm if "ba_blocks" in k][0]
+            traffic = (2.0 * pm[key]["FETCH_SIZE"]["avg_per_launch"] + pm[key]["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
+        except Exception:                                   # noqa: BLE001  (a malformed summary just leaves traffic null)
+            traffic = None
+
+    secondary = None
+    if args.window == 1 and not args.no_secondary and args.gpus == 1:
+        # the reference's default sub-selection (config/como.yml: nonmax_suppression_window 4, n = 19,200 px / keyframe)
+        cfg4 = copy.deepcopy(DEFAULT_CFG)
+        cfg4["photo_construction"]["nonmax_suppression_window"] = 4
+        wb4 = WindowBA(build_state(args, device, pix_dtype), cfg=cfg4, pix_dtype=pix_dtype, window_full=True)
+        for _ in range(args.warmup):
+            wb4.iterate()
+        g4 = (not args.eager) and wb4.capture()
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        for _ in range(args.steps):
+            wb4.step()
+        torch.cuda.synchronize()
+        e4 = time.perf_counter() - t4
+        secondary = {"workload": f"same window, nonmax_suppression_window=4 (n={wb4.n} reference px/KF, the reference's default)",
+                     "value": args.steps / e4, "unit": "GN iters/s", "ms_per_step": e4 / args.steps * 1e3, "hip_graph": bool(g4)}
+
     if shard.rank == 0:
         out = {
             "metric": "GN iters/sec, 8-keyframe 640x480 photometric BA",
@@ -175,10 +206,12 @@ def main():
                        "pixel_pairs_per_iter": npairs * wb.n, "system_dim": wb.dim, "pix_dtype": args.dtype,
                        "system_dtype": "f64", "hip_graph": bool(graphed), "parallelism": f"dp{args.gpus} (reference-pixel shards of every pair)"},
             "roofline": {"bound": "hbm", "kernel": "ba_blocks_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None, "kernel_ms": blk_ms,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel_ms": blk_ms,
                          "algorithmic_bytes_per_launch": pixel_pairs_rank * bytes_per},
             "solution": {"cholesky_info": info, "max_pose_abs_err_vs_gt_start": pose_err0, "max_pose_abs_err_vs_gt_end": pose_err},
         }
+        if secondary is not None:
+            out["secondary"] = secondary
         if not args.no_cpu and args.gpus == 1:
             st_cpu = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in state.items()}
             st_cpu["Knm_Kmminv"] = st_cpu["Knm_Kmminv"]
