@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(
       valid_out[oi] = w.ok ? 1 : 0;
       if (pj_out) { pj_out[2 * oi] = w.u; pj_out[2 * oi + 1] = w.v; }
     }
-    sel_lds_add_aggregated(lh, sel_digit<KeyT>(abs_key(r), 0), inr && w.ok);
+    sel_lds_add(lh, sel_digit<KeyT>(abs_key(r), 0), inr && w.ok);
   }
   __syncthreads();
   sel_flush(lh, hists);

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void dense_ref_kernel(
       zbuf[(long)b * n + i] = Zc;
       if (logzn_out) logzn_out[(long)b * n + i] = logz;
     }
-    sel_lds_add_aggregated(lh, sel_digit<KeyT>(abs_key(Zc), 0), inr);
+    sel_lds_add(lh, sel_digit<KeyT>(abs_key(Zc), 0), inr);
   }
   __syncthreads();
   sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
       zbuf[(long)b * n + i] = Zc;
       if (logzn_out) logzn_out[(long)b * n + i] = logz;
     }
-    sel_lds_add_aggregated(lh, sel_digit<KeyT>(abs_key(Zc), 0), inr);
+    sel_lds_add(lh, sel_digit<KeyT>(abs_key(Zc), 0), inr);
   }
   __syncthreads();
   sel_flush(lh, hists + (long)b * 6 * SEL_BINS);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void track_residual_kernel(
       if (pj_out) { pj_out[2 * i] = u; pj_out[2 * i + 1] = v; }
       if (depth_out) depth_out[i] = hz;
     }
-    sel_lds_add_aggregated(lh, sel_digit<KeyT>(abs_key(r), 0), inr && ok);
+    sel_lds_add(lh, sel_digit<KeyT>(abs_key(r), 0), inr && ok);
   }
   __syncthreads();
   sel_flush(lh, hists);
