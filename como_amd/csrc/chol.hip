@@ -266,6 +266,9 @@ __global__ __launch_bounds__(512) void chol_panel_kernel(double* __restrict__ W,
 }
 
 // L^T delta = y with y = row D of L (columns 0..D-1).  One workgroup of 1024 threads.
+// Bound by what ONE compute unit can pull through the fabric (~10 B/clk: 2.3 MB of L at D = 760 -> ~65 us; a version
+// that prefetched every panel a step ahead into registers measured the same 69 us).  Spreading the panel products over
+// many workgroups needs a device-wide hand-off per panel (~4 us each, 24 of them): no better.
 // Per 32-block (right to left): x_k = L_kk^-T y_k is a 32x32 mat-vec with the pre-inverted diagonal block, then
 // y_j -= L[k rows, j]^T x_k for the columns to the left (coalesced along j).
 __global__ __launch_bounds__(1024) void chol_backsub_kernel(const double* __restrict__ Lw, const double* __restrict__ Iw,
