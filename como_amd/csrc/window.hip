@@ -164,8 +164,9 @@ struct PriorArgs {
 
 __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int m) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* M = sm;                 // m x m
-  double* MG = M + m * m;         // m x 6
+  const int MS = m + 1;           // padded row stride: column walks of M are conflict-free
+  double* M = sm;                 // m x (m + 1)
+  double* MG = M + m * MS;        // m x 6
   double* w = MG + m * 6;         // m
   double* r0 = w + m;             // m
   double* G = r0 + m;             // m x 6
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
         const int i = e / m, j = e % m;
         double v = kin[u] * i_gp;
         if (i == j && A.first_mask[(long)b * m + i]) v += i_ld;
-        M[e] = v;
+        M[i * MS + j] = v;
       }
     }
   }
@@ -203,13 +204,13 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
   __syncthreads();
   for (int e = tid; e < m; e += 256) {
     double s = 0;
-    for (int k = 0; k < m; ++k) s += M[e * m + k] * r0[k];
+    for (int k = 0; k < m; ++k) s += M[e * MS + k] * r0[k];
     w[e] = s;
   }
   for (int e = tid; e < m * 6; e += 256) {
     const int i = e / 6, a = e % 6;
     double s = 0;
-    for (int k = 0; k < m; ++k) s += M[i * m + k] * G[k * 6 + a];
+    for (int k = 0; k < m; ++k) s += M[i * MS + k] * G[k * 6 + a];
     MG[e] = s;
   }
   __syncthreads();
@@ -240,12 +241,11 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
   // H_PP
   for (int e = tid + 256 * slice; e < 9 * m * m; e += 256 * nsl) {
     const int q1 = e / (3 * m), q2 = e % (3 * m);
-    const double v = M[(q1 / 3) * m + (q2 / 3)] * dP[q1] * dP[q2];
+    const double v = M[(q1 / 3) * MS + (q2 / 3)] * dP[q1] * dP[q2];
     atomicAdd(&A.H[li[q1] * D + li[q2]], v);
   }
   // errors: gp = r0^T (Kinv/s^2) r0, ld = sum first r0^2 / s^2
-  if (!lead) return;
-  if (tid < 64) {
+  if (lead && tid < 64) {
     double egp = 0, eld = 0;
     for (int i = tid; i < m; i += 64) {
       const double fi = A.first_mask[(long)b * m + i] ? i_ld : 0.0;
@@ -255,45 +255,68 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
     egp = wave_sum(egp); eld = wave_sum(eld);
     if (tid == 0) { atomicAdd(&A.err[0], egp); atomicAdd(&A.err[1], eld); }
   }
-  // pixel prior, mode "first": one lane per first-observed landmark of this keyframe.  Landmark rows / columns are
-  // private to the lane; the pose block and pose gradient are shared by all lanes, so they are wave-reduced first
-  // (64 same-address fp64 atomics per entry serialise at ~45 ns each: that was 80% of this kernel).
-  if (tid < 64) {
-    const int j = tid;
-    const bool act = j < m && A.first_mask[(long)b * m + (j < m ? j : 0)];
-    const long bj = (long)b * m + (act ? j : 0);
-    const double r[2] = {A.pm[2 * bj] - A.pm_first[2 * bj], A.pm[2 * bj + 1] - A.pm_first[2 * bj + 1]};
-    const double* JP = A.dp_dP + 6 * bj;     // 2x3
-    const double* JT = A.dp_dT + 12 * bj;    // 2x6
-    double jp[6], jt[12];
+  // pixel prior, mode "first".  A wave-level fp64 atomic instruction costs ~180 ns whether 2 or 64 lanes are active, so
+  // every scatter below is laid out with one ITEM per lane (never a per-lane serial loop of atomics): the 48 landmark-side
+  // entries of each first-observed landmark are items q = 48 j + t spread over threads and slices; the 36 + 6 pose-side
+  // entries shared by all landmarks are summed by 42 threads (one output each) and added with a single instruction.
+  double* px = red + 64;                           // m x 21 {JP 6, JT 12, r 2, act}
+  for (int j = tid; j < m; j += 256) {
+    const long bj = (long)b * m + j;
+    const bool act = A.first_mask[bj];
+    double* o = px + 21 * j;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) jp[k] = JP[k];
+    for (int k = 0; k < 6; ++k) o[k] = A.dp_dP[6 * bj + k];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) jt[k] = JT[k];
-    if (act) {
-      for (int d = 0; d < 3; ++d) {
-        for (int d2 = 0; d2 < 3; ++d2) atomicAdd(&A.H[li[3 * j + d] * D + li[3 * j + d2]], i_px * (jp[d] * jp[d2] + jp[3 + d] * jp[3 + d2]));
-        atomicAdd(&A.g[li[3 * j + d]], -i_px * (jp[d] * r[0] + jp[3 + d] * r[1]));
-        for (int a = 0; a < 6; ++a) {
-          const double v = i_px * (jt[a] * jp[d] + jt[6 + a] * jp[3 + d]);
-          atomicAdd(&A.H[pi[a] * D + li[3 * j + d]], v);
-          atomicAdd(&A.H[li[3 * j + d] * D + pi[a]], v);
-        }
-      }
+    for (int k = 0; k < 12; ++k) o[6 + k] = A.dp_dT[12 * bj + k];
+    o[18] = A.pm[2 * bj] - A.pm_first[2 * bj];
+    o[19] = A.pm[2 * bj + 1] - A.pm_first[2 * bj + 1];
+    o[20] = act ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  for (int q = tid + 256 * slice; q < 48 * m; q += 256 * nsl) {
+    const int j = q / 48, t = q % 48;
+    const double* o = px + 21 * j;
+    if (o[20] == 0.0) continue;
+    const double* jp = o;
+    const double* jt = o + 6;
+    if (t < 9) {
+      const int d = t / 3, d2 = t % 3;
+      atomicAdd(&A.H[li[3 * j + d] * D + li[3 * j + d2]], i_px * (jp[d] * jp[d2] + jp[3 + d] * jp[3 + d2]));
+    } else if (t < 12) {
+      const int d = t - 9;
+      atomicAdd(&A.g[li[3 * j + d]], -i_px * (jp[d] * o[18] + jp[3 + d] * o[19]));
+    } else {
+      const int u = t - 12, d = u / 12, a = (u % 12) >> 1;
+      const double v = i_px * (jt[a] * jp[d] + jt[6 + a] * jp[3 + d]);
+      if (u & 1) atomicAdd(&A.H[li[3 * j + d] * D + pi[a]], v);
+      else atomicAdd(&A.H[pi[a] * D + li[3 * j + d]], v);
     }
-    const double on = act ? i_px : 0.0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const double v = wave_sum(on * (jt[a] * jt[c] + jt[6 + a] * jt[6 + c]));
-        if (tid == 0) atomicAdd(&A.H[pi[a] * D + pi[c]], v);
+  }
+  if (!lead) return;
+  if (tid < 42) {
+    double acc = 0.0;
+    if (tid < 36) {
+      const int a = tid / 6, c = tid % 6;
+      for (int j = 0; j < m; ++j) {
+        const double* o = px + 21 * j;
+        acc += o[20] * (o[6 + a] * o[6 + c] + o[12 + a] * o[12 + c]);
       }
-      const double gv = wave_sum(on * (jt[a] * r[0] + jt[6 + a] * r[1]));
-      if (tid == 0) atomicAdd(&A.g[pi[a]], -gv);
+      atomicAdd(&A.H[pi[a] * D + pi[c]], i_px * acc);
+    } else {
+      const int a = tid - 36;
+      for (int j = 0; j < m; ++j) {
+        const double* o = px + 21 * j;
+        acc += o[20] * (o[6 + a] * o[18] + o[12 + a] * o[19]);
+      }
+      atomicAdd(&A.g[pi[a]], -i_px * acc);
     }
-    const double epx = wave_sum(on * (r[0] * r[0] + r[1] * r[1]));
-    if (tid == 0) atomicAdd(&A.err[2], epx);
+  } else if (tid >= 64 && tid < 128) {
+    const int j = tid - 64;
+    double e = 0.0;
+    if (j < m) { const double* o = px + 21 * j; e = o[20] * (o[18] * o[18] + o[19] * o[19]); }
+    for (int jj = j + 64; jj < m; jj += 64) { const double* o = px + 21 * jj; e += o[20] * (o[18] * o[18] + o[19] * o[19]); }
+    e = wave_sum(e);
+    if (j == 0) atomicAdd(&A.err[2], i_px * e);
   }
   // anchors on keyframe 0 (Mapping.py:855-900)
   if (b == 0 && tid == 0) {
@@ -317,27 +340,23 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
     const double wxt[3] = {wn[1] * tt[2] - wn[2] * tt[1], wn[2] * tt[0] - wn[0] * tt[2], wn[0] * tt[1] - wn[1] * tt[0]};
     const double wxwxt[3] = {wn[1] * wxt[2] - wn[2] * wxt[1], wn[2] * wxt[0] - wn[0] * wxt[2], wn[0] * wxt[1] - wn[1] * wxt[0]};
     const double cf = 1.0 - th / (2.0 * tan(0.5 * th));
-    double xi[6];
-    for (int i = 0; i < 3; ++i) { xi[i] = -wv[i]; xi[3 + i] = -(tt[i] - (0.5 * tt[i]) * wxt[i] + cf * wxwxt[i]); }
+    for (int i = 0; i < 3; ++i) { red[i] = -wv[i]; red[3 + i] = -(tt[i] - (0.5 * tt[i]) * wxt[i] + cf * wxwxt[i]); }
+  }
+  __syncthreads();
+  if (b == 0 && tid < 8) {                           // 6 pose + 2 affine anchor entries: one lane each
+    const bool isp = tid < 6;
+    const int q = isp ? 0 : tid - 6;
     const double isq = 1.0 / A.s_pose;
     const double jtj = (double)((float)isq * (float)isq);          // float32 J^T J of the reference (torch.eye default dtype)
-    double ep = 0;
-    for (int a = 0; a < 6; ++a) {
-      atomicAdd(&A.H[pi[a] * D + pi[a]], jtj);
-      atomicAdd(&A.g[pi[a]], -(isq * (isq * xi[a])));
-      ep += (isq * xi[a]) * (isq * xi[a]);
-    }
-    // affine anchors
     const double ia = (1.0 / A.s_aff) * (1.0 / A.s_aff);
-    double ea = 0;
-    for (int q = 0; q < 2; ++q) {
-      const double r = A.aff[q] - A.aff_anchor[q];
-      atomicAdd(&A.H[pi[6 + q] * D + pi[6 + q]], ia);
-      atomicAdd(&A.g[pi[6 + q]], -ia * r);
-      ea += ia * r * r;
-    }
-    atomicAdd(&A.err[3], ep);
-    atomicAdd(&A.err[4], ea);
+    const double xi = red[isp ? tid : 0];
+    const double r = A.aff[q] - A.aff_anchor[q];
+    atomicAdd(&A.H[pi[tid] * D + pi[tid]], isp ? jtj : ia);
+    atomicAdd(&A.g[pi[tid]], isp ? -(isq * (isq * xi)) : -ia * r);
+    double ep = isp ? (isq * xi) * (isq * xi) : 0.0;
+    double ea = isp ? 0.0 : ia * r * r;
+    for (int o = 1; o < 8; o <<= 1) { ep += __shfl_xor(ep, o, 8); ea += __shfl_xor(ea, o, 8); }
+    if (tid == 0) { atomicAdd(&A.err[3], ep); atomicAdd(&A.err[4], ea); }
   }
   if (b == 0 && A.nfix > 0) {
     const double il = (1.0 / A.s_lm) * (1.0 / A.s_lm);
@@ -420,8 +439,8 @@ int como_win_priors(const como_win_args* a, como_stream_t stream) {
   A.s_gp = a->s_gp; A.s_ld = a->s_ld; A.s_px = a->s_px; A.s_pose = a->s_pose; A.s_aff = a->s_aff; A.s_lm = a->s_lm;
   A.H = a->H; A.g = a->g; A.D = a->D; A.err = a->err;
   const int m = a->m;
-  const size_t lds = (size_t)(m * m + m * 6 + m + m + m * 6 + m * 3 + 64) * sizeof(double);
-  hipLaunchKernelGGL(win_priors_kernel, dim3(a->B, 16), dim3(256), lds, s, A, a->B, m);
+  const size_t lds = (size_t)(m * (m + 1) + m * 6 + m + m + m * 6 + m * 3 + 64 + m * 21) * sizeof(double);
+  hipLaunchKernelGGL(win_priors_kernel, dim3(a->B, 32), dim3(256), lds, s, A, a->B, m);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }
