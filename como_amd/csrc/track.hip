@@ -107,11 +107,20 @@ __global__ __launch_bounds__(256) void track_reduce_kernel(const T* __restrict__
     }
     acc[44] += w * wr * wr;                                // total_err
   }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // block reduction through LDS in a fixed order: column k of the 256 x 46 tile is summed by 4 threads (64 rows each, fp64),
+  // then combined.  (46 wave_sum() calls on doubles cost ~11 us per block: cross-lane f64 moves are two ds_bpermute each.)
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  T* tile = reinterpret_cast<T*>(dyn_lds);                 // [256][TRK_ACC + 1]
 #pragma unroll
-  for (int k = 0; k < TRK_ACC; ++k) {
-    double s = wave_sum((double)acc[k]);
-    if (lane == 0) red[wv][k] = s;
+  for (int k = 0; k < TRK_ACC; ++k) tile[threadIdx.x * (TRK_ACC + 1) + k] = acc[k];
+  __syncthreads();
+  {
+    const int k = threadIdx.x & 63, pp = threadIdx.x >> 6;
+    if (k < TRK_ACC) {
+      double s = 0;
+      for (int rr = 0; rr < 64; ++rr) s += (double)tile[(pp * 64 + rr) * (TRK_ACC + 1) + k];
+      red[pp][k] = s;
+    }
   }
   __syncthreads();
   if (threadIdx.x < TRK_ACC)
@@ -159,10 +168,26 @@ __global__ __launch_bounds__(256) void track_finish_kernel(const double* __restr
   __shared__ double tot[TRK_ACC];
   KeyT prefix; uint32_t k_rem, nv;
   sel_resolve<KeyT>(hists, SelCfg<KeyT>::NPASS, &sc, prefix, k_rem, nv);
-  if (threadIdx.x < TRK_ACC) {
+  {
+    // fixed-order sum of the block partials, 4 interleaved parts x 8 loads in flight (one dependent load per partial made
+    // this single-workgroup kernel 250 us at 1200 partials)
+    __shared__ double part[4][64];
+    const int a = threadIdx.x & 63, pp = threadIdx.x >> 6;
     double s = 0;
-    for (int b = 0; b < nblocks; ++b) s += partials[(long)b * TRK_ACC + threadIdx.x];   // fixed order
-    tot[threadIdx.x] = s;
+    if (a < TRK_ACC) {
+      int b = pp;
+      for (; b + 28 < nblocks; b += 32) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = partials[(long)(b + 4 * q) * TRK_ACC + a];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += v[q];
+      }
+      for (; b < nblocks; b += 4) s += partials[(long)b * TRK_ACC + a];
+    }
+    part[pp][a] = s;
+    __syncthreads();
+    if (threadIdx.x < TRK_ACC) tot[threadIdx.x] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -233,9 +258,12 @@ int track_iter(const T* Tji, const T* Kmat, const T* aff, const T* P, const T* v
     int rc = select_hist<T>(r_ws, valid_out, N, 1, hists, p, s);
     if (rc) return rc;
   }
-  int rblocks = (int)((N + 255) / 256);
+  // ~4 pixels per thread: the 46-value block reduction (shuffles + LDS) is amortised, and track_finish sums fewer partials
+  int rblocks = (int)((N + 1023) / 1024);
+  if (rblocks < 1) rblocks = 1;
   if (rblocks > TRK_MAX_BLOCKS) rblocks = TRK_MAX_BLOCKS;
-  hipLaunchKernelGGL(track_reduce_kernel<T>, dim3(rblocks), dim3(256), 0, s, J8, r_ws, valid_out, N, hists, partials);
+  hipLaunchKernelGGL(track_reduce_kernel<T>, dim3(rblocks), dim3(256), 256 * (TRK_ACC + 1) * sizeof(T), s, J8, r_ws, valid_out, N, hists,
+                     partials);
   COMO_CHECK_LAUNCH();
   hipLaunchKernelGGL(track_finish_kernel<T>, dim3(1), dim3(256), 0, s, partials, rblocks, hists, Tji, aff, out);
   COMO_CHECK_LAUNCH();
