@@ -18,15 +18,22 @@ namespace como {
 
 typedef float nf4 __attribute__((ext_vector_type(4)));
 
-template <int KS, int MT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt,
-                                                        const float* __restrict__ bias, float* __restrict__ out, int Cin,
-                                                        int CinP, int Cout, int H, int W, int out_ctot, int out_coff) {
+// WV waves per workgroup share one output tile (64 pixels x 16*MT channels) and split the input channels between them
+// (split-K): the deep levels have 48..768 pixels and up to 512 x 9 reduction steps, far too few tiles to fill 1024 SIMDs
+// otherwise (one wave did 1152 dependent load->MFMA steps: 430 us for a 226 MFLOP layer).  WV = 1 is the plain mapping
+// for the wide levels.  Loads are unconditional on clamped addresses and the channel loop is unrolled so that several
+// steps' loads are in flight per wave.  Optional epilogue: per-channel sum / sum of squares of the outputs accumulated
+// into gn_sums (N, G, 2) doubles -- the GroupNorm statistics of the next layer, without a separate pass over the tensor.
+template <int KS, int MT, int WV>
+__global__ __launch_bounds__(64 * WV) void conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt,
+                                                            const float* __restrict__ bias, float* __restrict__ out, int Cin,
+                                                            int CinP, int Cout, int H, int W, int out_ctot, int out_coff,
+                                                            double* __restrict__ gn_sums, int gn_groups) {
+  constexpr int GN_SLOTS = 32;
   constexpr int PAD = KS / 2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
   const int HW = H * W;
-  const int p0 = (blockIdx.x * 4 + wv) * 64;
-  if (p0 >= HW) return;
+  const int p0 = blockIdx.x * 64;
   const int co0 = blockIdx.y * 16 * MT;
   const int n = blockIdx.z;
   const float* inb = in + (long)n * Cin * HW;
@@ -45,35 +52,82 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[mt][t] = nf4{0.f, 0.f, 0.f, 0.f};
-  for (int ky = 0; ky < KS; ++ky) {
-    for (int kx = 0; kx < KS; ++kx) {
-      int off[4];
-      bool ok[4];
+  // this wave's channel slice [cbeg, cend) in steps of 4
+  const int steps = CinP >> 2;
+  const int per = (steps + WV - 1) / WV;
+  const int cbeg = 4 * min(steps, wv * per), cend = 4 * min(steps, (wv + 1) * per);
+  int wco[MT];
+  float wokm[MT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int yy = py[t] + ky - PAD, xx = px[t] + kx - PAD;
-        ok[t] = pv[t] && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        off[t] = ok[t] ? yy * W + xx : 0;
+  for (int mt = 0; mt < MT; ++mt) { const int co = co0 + 16 * mt + c; wokm[mt] = co < Cout ? 1.f : 0.f; wco[mt] = co < Cout ? co : 0; }
+#pragma unroll 1
+  for (int kk = 0; kk < KS * KS; ++kk) {
+    const int ky = kk / KS, kx = kk - ky * KS;
+    // padding / tail handling by MULTIPLYING with a 0/1 mask: with a select the compiler sinks every load into its own
+    // exec-masked branch followed by s_waitcnt vmcnt(0) -- one exposed memory latency per load (1.6 us per step)
+    int off[4];
+    float okm[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int yy = py[t] + ky - PAD, xx = px[t] + kx - PAD;
+      const bool ok = pv[t] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      okm[t] = ok ? 1.f : 0.f;
+      off[t] = ok ? yy * W + xx : 0;
+    }
+    const float* wk = wt + (long)kk * CinP * Cout;
+    constexpr int U = 4;                                   // reduction steps whose loads are in flight together
+    int ci0 = cbeg;
+    for (; ci0 + 4 * U <= cend; ci0 += 4 * U) {
+      float a[U][MT], b[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int ci = ci0 + 4 * u + q;                    // ci < CinP: weight rows exist (zero rows beyond Cin)
+        const float* ip = inb + (long)min(ci, Cin - 1) * HW;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[u][mt] = wk[(long)ci * Cout + wco[mt]];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) b[u][t] = ip[off[t]];
       }
-      const float* wk = wt + (long)(ky * KS + kx) * CinP * Cout;
-      for (int ci0 = 0; ci0 < CinP; ci0 += 4) {
-        const int ci = ci0 + q;
-        float a[MT], b[4];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int co = co0 + 16 * mt + c;
-          a[mt] = (co < Cout) ? wk[(long)ci * Cout + co] : 0.f;
-        }
-        const bool cv = ci < Cin;
-        const float* ip = inb + (long)(cv ? ci : 0) * HW;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = (cv && ok[t]) ? ip[off[t]] : 0.f;
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], b[t], acc[mt][t], 0, 0, 0);
+          for (int t = 0; t < 4; ++t)
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt] * wokm[mt], b[u][t] * okm[t], acc[mt][t], 0, 0, 0);
+    }
+    for (; ci0 < cend; ci0 += 4) {
+      const int ci = ci0 + q;
+      const float* ip = inb + (long)min(ci, Cin - 1) * HW;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float av = wk[(long)ci * Cout + wco[mt]] * wokm[mt];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ip[off[t]] * okm[t], acc[mt][t], 0, 0, 0);
       }
     }
+  }
+  if constexpr (WV > 1) {
+    // fixed-order cross-wave reduction through LDS (wave 0 adds the slices of waves 1..WV-1 in order)
+    __shared__ float red[(WV - 1) * MT * 4 * 4 * 64];
+    if (wv > 0) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) red[((((wv - 1) * MT + mt) * 4 + t) * 4 + r) * 64 + lane] = acc[mt][t][r];
+    }
+    __syncthreads();
+    if (wv > 0) return;
+#pragma unroll 1
+    for (int w2 = 0; w2 < WV - 1; ++w2)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][t][r] += red[(((w2 * MT + mt) * 4 + t) * 4 + r) * 64 + lane];
   }
   float* ob = out + ((long)n * out_ctot + out_coff) * HW;
 #pragma unroll
@@ -81,12 +135,31 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const float* __restrict_
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int co = co0 + 16 * mt + 4 * q + r;
-      if (co >= Cout) continue;
-      const float bv = bias ? bias[co] : 0.f;
+      const bool cok = co < Cout;
+      const float bv = (bias && cok) ? bias[co] : 0.f;
+      double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int p = p0 + 16 * t + c;
-        if (p < HW) ob[(long)co * HW + p] = acc[mt][t][r] + bv;
+        if (cok && p < HW) {
+          const float v = acc[mt][t][r] + bv;
+          ob[(long)co * HW + p] = v;
+          s1 += (double)v;
+          s2 += (double)v * (double)v;
+        }
+      }
+      if (gn_sums) {
+        // 16 lanes (c) hold the same channel: reduce them, one atomic pair per (wave, channel)
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 16); s2 += __shfl_xor(s2, o, 16); }
+        if (c == 0 && cok) {
+          // 32 slots per statistic: thousands of waves adding to the same 2 x G addresses serialise at the memory side
+          const int g = co / (Cout / gn_groups);
+          const int slot = (blockIdx.x + blockIdx.y) % GN_SLOTS;
+          double* dst = gn_sums + (((long)slot * gridDim.z + n) * gn_groups + g) * 2;
+          atomicAdd(dst, s1);
+          atomicAdd(dst + 1, s2);
+        }
       }
     }
 }
@@ -120,17 +193,38 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 }
 
 // y = GroupNorm(x) (affine), then  act == 1: y = LeakyReLU(y);  act == 2: y = LeakyReLU(residual + y)   (layers.py:23-27)
+// stats: from gn_stats_kernel (float mean, rstd) or, when sums != nullptr, the (sum, sum of squares) the producing
+// convolution accumulated (biased variance, as nn.GroupNorm).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, const float* __restrict__ stats,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                       const float* __restrict__ residual, float* __restrict__ out, int C,
-                                                       int G, int HW, float slope, int act, long total) {
+                                                       const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ residual,
+                                                       float* __restrict__ out, int N, int C, int G, int HW, float eps,
+                                                       float slope, int act, long total) {
+  __shared__ float sm[2 * 256];
+  if (sums) {                                            // N * G <= 256 (checked by the launcher)
+    for (int idx = threadIdx.x; idx < N * G; idx += 256) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int sl = 0; sl < 32; ++sl) {
+        s1 += sums[((long)sl * N * G + idx) * 2];
+        s2 += sums[((long)sl * N * G + idx) * 2 + 1];
+      }
+      const double cnt = (double)(C / G) * (double)HW;
+      const double m = s1 / cnt;
+      double var = s2 / cnt - m * m;
+      if (var < 0.0) var = 0.0;
+      sm[2 * idx] = (float)m;
+      sm[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+  }
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const long nc = i / HW;
   const int ch = (int)(nc % C);
   const int n = (int)(nc / C);
   const int g = ch / (C / G);
-  const float mean = stats[2 * (n * G + g)], rstd = stats[2 * (n * G + g) + 1];
+  const float mean = sums ? sm[2 * (n * G + g)] : stats[2 * (n * G + g)];
+  const float rstd = sums ? sm[2 * (n * G + g) + 1] : stats[2 * (n * G + g) + 1];
   float y = (x[i] - mean) * rstd * gamma[ch] + beta[ch];
   if (act == 2) y += residual[i];
   if (act) y = y > 0.f ? y : y * slope;
@@ -236,39 +330,66 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(const T* __restrict__ in
 
 }  // namespace como
 
+namespace como {
+template <int KS, int MT, int WV>
+static void launch_conv(dim3 grid, hipStream_t s, const float* in, const float* wt, const float* bias, float* out, int Cin, int CinP,
+                        int Cout, int H, int W, int out_ctot, int out_coff, double* gn_sums, int gn_groups) {
+  hipLaunchKernelGGL((conv_mfma_kernel<KS, MT, WV>), grid, dim3(64 * WV), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W,
+                     out_ctot, out_coff, gn_sums, gn_groups);
+}
+
+}  // namespace como
+
 extern "C" {
 
 int como_nn_conv2d_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
-                       int H, int W, int ks, int out_ctot, int out_coff, como_stream_t stream) {
-  using namespace como;
+                       int H, int W, int ks, int out_ctot, int out_coff, double* gn_sums, int gn_groups,
+                       como_stream_t stream) {
   if (!in || !wt || !out || N <= 0 || Cin <= 0 || CinP < Cin || (CinP & 3) || Cout <= 0 || H <= 0 || W <= 0 ||
-      (ks != 1 && ks != 3) || out_ctot < out_coff + Cout)
+      (ks != 1 && ks != 3) || out_ctot < out_coff + Cout || (gn_sums && (gn_groups <= 0 || Cout % gn_groups)))
     return COMO_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int HW = H * W;
-  const unsigned gx = (unsigned)((HW + 255) / 256);
-  const int mt = (Cout >= 32) ? 2 : 1;
-  const dim3 grid(gx, (unsigned)((Cout + 16 * mt - 1) / (16 * mt)), (unsigned)N);
-  if (ks == 3 && mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<3, 2>), grid, dim3(256), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff);
-  else if (ks == 3) hipLaunchKernelGGL((conv_mfma_kernel<3, 1>), grid, dim3(256), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff);
-  else if (mt == 2) hipLaunchKernelGGL((conv_mfma_kernel<1, 2>), grid, dim3(256), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff);
-  else hipLaunchKernelGGL((conv_mfma_kernel<1, 1>), grid, dim3(256), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff);
+  const int tiles_px = (HW + 63) / 64;
+  const long ksteps = (long)ks * ks * (CinP / 4);
+  // channel-tile height and split-K width: enough waves to fill the chip, at least ~16 reduction steps per wave
+  int mt = (Cout >= 32) ? 2 : 1;
+  long waves = (long)tiles_px * ((Cout + 16 * mt - 1) / (16 * mt)) * N;
+  if (mt == 2 && waves < 2048) { mt = 1; waves = (long)tiles_px * ((Cout + 15) / 16) * N; }
+  int wvs = 1;
+  while (wvs < 16 && waves * wvs < 2048 && (CinP / 4) / (wvs * 2) >= 4) wvs *= 2;
+  (void)ksteps;
+  const dim3 grid((unsigned)tiles_px, (unsigned)((Cout + 16 * mt - 1) / (16 * mt)), (unsigned)N);
+#define COMO_CONV(KS_, MT_, WV_) como::launch_conv<KS_, MT_, WV_>(grid, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff, gn_sums, gn_groups)
+#define COMO_CONV_W(KS_, MT_)                                                                         \
+  switch (wvs) { case 1: COMO_CONV(KS_, MT_, 1); break; case 2: COMO_CONV(KS_, MT_, 2); break;        \
+                 case 4: COMO_CONV(KS_, MT_, 4); break; case 8: COMO_CONV(KS_, MT_, 8); break;        \
+                 default: COMO_CONV(KS_, MT_, 16); break; }
+  if (ks == 3 && mt == 2) { COMO_CONV_W(3, 2) }
+  else if (ks == 3) { COMO_CONV_W(3, 1) }
+  else if (mt == 2) { COMO_CONV_W(1, 2) }
+  else { COMO_CONV_W(1, 1) }
+#undef COMO_CONV_W
+#undef COMO_CONV
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }
 
 int como_nn_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* residual, float* out,
-                          float* stats, int N, int C, int G, int HW, float eps, float slope, int act, como_stream_t stream) {
+                          float* stats, const double* sums, int N, int C, int G, int HW, float eps, float slope, int act,
+                          como_stream_t stream) {
   using namespace como;
-  if (!x || !gamma || !beta || !out || !stats || N <= 0 || C <= 0 || G <= 0 || (C % G) || HW <= 0 || act < 0 || act > 2 ||
-      (act == 2 && !residual))
+  if (!x || !gamma || !beta || !out || (!stats && !sums) || N <= 0 || C <= 0 || G <= 0 || (C % G) || HW <= 0 || act < 0 ||
+      act > 2 || (act == 2 && !residual) || (sums && N * G > 256))
     return COMO_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)(N * G)), dim3(256), 0, s, x, C, G, HW, eps, stats);
-  COMO_CHECK_LAUNCH();
+  if (!sums) {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)(N * G)), dim3(256), 0, s, x, C, G, HW, eps, stats);
+    COMO_CHECK_LAUNCH();
+  }
   const long total = (long)N * C * HW;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, stats, gamma, beta, residual,
-                     out, C, G, HW, slope, act, total);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, stats, sums, gamma, beta,
+                     residual, out, N, C, G, HW, eps, slope, act, total);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }

@@ -30,26 +30,30 @@ class _Conv:
         self.wt, self.cin, self.cinp, self.cout, self.k = _relayout(weight.float())
         self.bias = bias.float().contiguous()
 
-    def __call__(self, x, out=None, coff=0):
+    def __call__(self, x, out=None, coff=0, gn_sums=None):
+        """gn_sums: optional zeroed (32, N, 16, 2) float64 tensor receiving the GroupNorm statistics of the output."""
         N, C, H, W = x.shape
         assert C == self.cin and x.dtype == torch.float32 and x.is_contiguous()
         if out is None:
             out = torch.empty((N, self.cout, H, W), dtype=torch.float32, device=x.device)
         rc = _lib.lib().como_nn_conv2d_f32(x.data_ptr(), self.wt.data_ptr(), self.bias.data_ptr(), out.data_ptr(), N,
                                            self.cin, self.cinp, self.cout, H, W, self.k, out.shape[1], coff,
+                                           gn_sums.data_ptr() if gn_sums is not None else None, GN_GROUPS,
                                            _lib.stream_ptr(x.device))
         _lib.check(rc, "como_nn_conv2d_f32")
         return out
 
 
-def _groupnorm(x, gamma, beta, act, residual=None):
+def _groupnorm(x, gamma, beta, act, residual=None, sums=None):
+    """sums: the (32,N,16,2) float64 statistics a convolution accumulated for x; None = compute them here."""
     N, C, H, W = x.shape
     out = torch.empty_like(x)
-    stats = torch.empty((N * GN_GROUPS * 2,), dtype=torch.float32, device=x.device)
+    stats = torch.empty((N * GN_GROUPS * 2,), dtype=torch.float32, device=x.device) if sums is None else None
     rc = _lib.lib().como_nn_groupnorm_f32(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                           residual.data_ptr() if residual is not None else None, out.data_ptr(),
-                                          stats.data_ptr(), N, C, GN_GROUPS, H * W, GN_EPS, LEAKY_SLOPE, act,
-                                          _lib.stream_ptr(x.device))
+                                          stats.data_ptr() if stats is not None else None,
+                                          sums.data_ptr() if sums is not None else None, N, C, GN_GROUPS, H * W, GN_EPS,
+                                          LEAKY_SLOPE, act, _lib.stream_ptr(x.device))
     _lib.check(rc, "como_nn_groupnorm_f32")
     return out
 
@@ -64,11 +68,13 @@ class ResidualConv:
         self.gamma = sd[prefix + "norm.weight"].float().contiguous()
         self.beta = sd[prefix + "norm.bias"].float().contiguous()
 
-    def __call__(self, x):
-        y = _groupnorm(self.conv1(x), self.gamma, self.beta, 1)
-        y2 = self.conv2(y)
+    def __call__(self, x, sums=None):
+        """sums: (2, 32, N, 16, 2) zeroed float64 scratch for the two GroupNorm statistics (None: separate stats passes)."""
+        s1, s2 = (sums[0], sums[1]) if sums is not None else (None, None)
+        y = _groupnorm(self.conv1(x, gn_sums=s1), self.gamma, self.beta, 1, sums=s1)
+        y2 = self.conv2(y, gn_sums=s2)
         skip = self.conv3(x)
-        return _groupnorm(y2, self.gamma, self.beta, 2, residual=skip)
+        return _groupnorm(y2, self.gamma, self.beta, 2, residual=skip, sums=s2)
 
 
 def maxpool2(x):
@@ -140,9 +146,12 @@ class UNet:
     def forward(self, x):
         _lib.require_cuda(x)
         x = normalize_imagenet(x.float().contiguous())
-        enc = [self.base(x)]
+        # GroupNorm statistics of all 2 * (1 + 2 * levels) normalisations: one zero-fill, accumulated by the convolutions
+        nres = 1 + 2 * self.num_levels
+        sums = torch.zeros((nres, 2, 32, x.shape[0], GN_GROUPS, 2), dtype=torch.float64, device=x.device)   # 32 slots
+        enc = [self.base(x, sums[0])]
         for i in range(self.num_levels):
-            enc.append(self.down[i](maxpool2(enc[-1])))                     # DownConv (layers.py:30-43)
+            enc.append(self.down[i](maxpool2(enc[-1]), sums[1 + i]))        # DownConv (layers.py:30-43)
         out = []
         dec = enc[-1]
         for i in range(self.num_levels - 1, -1, -1):                         # UpConv (layers.py:46-75)
@@ -151,7 +160,7 @@ class UNet:
             cat = torch.empty((N, 2 * c, H, W), dtype=torch.float32, device=x.device)
             self.up_conv[i](upsample2x(dec), out=cat, coff=0)
             cat[:, c:].copy_(skip)
-            dec = self.up_block[i](cat)
+            dec = self.up_block[i](cat, sums[1 + self.num_levels + i])
             if i < self.num_levels - 1:
                 f = self.feature[i](dec)
                 out.append(self.feature_act(f) if self.feature_act else f)

@@ -237,17 +237,22 @@ int como_win_update(const double* delta, double* poses, double* aff, const long*
  * All tensors NCHW contiguous.
  *  conv2d   : stride 1, zero "same" padding, ks in {1,3}; wt is the torch weight (Cout,Cin,ks,ks) re-laid as
  *             [ks*ks][CinP][Cout] with CinP = Cin rounded up to 4 (zero rows); bias may be NULL; the result is written
- *             to channels [out_coff, out_coff+Cout) of an (N,out_ctot,H,W) tensor (torch.cat of UpConv, layers.py:72).
+ *             to channels [out_coff, out_coff+Cout) of an (N,out_ctot,H,W) tensor (torch.cat of UpConv, layers.py:72);
+ *             gn_sums (32,N,gn_groups,2) doubles (32 contention slots), optional, pre-zeroed: per-group sum / sum of
+ *             squares of the outputs are ADDED (the statistics of the GroupNorm that follows, without another pass over the tensor).
  *  groupnorm: nn.GroupNorm(G, C) (biased variance, eps) followed by act: 0 none, 1 LeakyReLU(slope),
- *             2 LeakyReLU(residual + y) (ResidualConv.forward, layers.py:23-27); stats: (N*G*2) float scratch.
+ *             2 LeakyReLU(residual + y) (ResidualConv.forward, layers.py:23-27); statistics either from `sums` (as
+ *             accumulated by conv2d) or, when sums is NULL, computed here into stats (N*G*2 float scratch).
  *  maxpool2 : nn.MaxPool2d(2); upsample2x: nn.Upsample(scale 2, bilinear, align_corners=False);
  *  normalize: torchvision Normalize(mean, std) on 3 channels (mean3/std3 are HOST pointers);
  *  cov_act  : normalize_params_cov + kernel_params_to_covariance, (N,3,HW) -> (N,4,HW) = [x, s, s, z];
  *  resize_aa: F.interpolate(mode="bilinear", antialias=True, align_corners=False). */
 int como_nn_conv2d_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
-                       int H, int W, int ks, int out_ctot, int out_coff, como_stream_t stream);
+                       int H, int W, int ks, int out_ctot, int out_coff, double* gn_sums, int gn_groups,
+                       como_stream_t stream);
 int como_nn_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* residual, float* out,
-                          float* stats, int N, int C, int G, int HW, float eps, float slope, int act, como_stream_t stream);
+                          float* stats, const double* sums, int N, int C, int G, int HW, float eps, float slope, int act,
+                          como_stream_t stream);
 int como_nn_maxpool2_f32(const float* in, float* out, int NC, int H, int W, como_stream_t stream);
 int como_nn_upsample2x_f32(const float* in, float* out, int NC, int H, int W, como_stream_t stream);
 int como_nn_normalize_f32(const float* in, float* out, int N, int HW, const float* mean3, const float* std3,

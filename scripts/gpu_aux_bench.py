@@ -66,7 +66,8 @@ def main():
     rgb = torch.rand(1, 3, 480, 640, device=DEV)
     out["depthcov_run_model_ms"] = timeit(lambda: run_model(model, rgb), n=10)
     rgb_r = torch.rand(1, 3, 192, 256, device=DEV)
-    out["depthcov_forward_192x256_ms"] = timeit(lambda: model(rgb_r), n=10)
+    out["depthcov_forward_192x256_eager_ms"] = timeit(lambda: model(rgb_r), n=10)
+    out["depthcov_forward_192x256_graph_ms"] = timeit(lambda: model.forward_graphed(rgb_r), n=10)
     # greedy sampler: 64 points on the 192x256 covariance image (domain 49,152 pixels)
     cov = synth.synthetic_cov_params(1, 192, 256, seed=2, dtype=torch.float64).float().to(DEV)
     sv = torch.tensor(1.0)
