@@ -57,5 +57,6 @@ def test_sharded_window_ba_matches_single_process():
         assert np.abs(Hd - Hs).max() / np.abs(Hs).max() < 2e-6
         assert abs(ed - es) / abs(es) < 3e-4            # cost: float32 running sum per workgroup, regrouped by the shards
         assert np.abs(pd - ps).max() < 1e-6
-    # both ranks hold the SAME result (identical all-reduced system, redundant solve)
-    assert np.array_equal(res[0]["sharded"][0], res[1]["sharded"][0])
+    # both ranks hold the same result: identical all-reduced photometric system, priors added and solved redundantly
+    # (fp64 atomics of the prior scatter are unordered: agreement to round-off, not bitwise)
+    assert np.abs(res[0]["sharded"][0] - res[1]["sharded"][0]).max() < 1e-12
