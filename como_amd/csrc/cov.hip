@@ -17,6 +17,25 @@ __device__ __forceinline__ float ref_matern(float Q) {
   return (1.0f + tmp) * expf(-tmp);
 }
 
+
+// k(x_a, E_a; x_b, E_b) * scale with exactly the float arithmetic of cross_cov_kernel<float> (E row-major 2x2)
+__device__ __forceinline__ float cov_value_f32(float xa0, float xa1, const float* Ea, float xb0, float xb1, const float* Eb,
+                                               float scale) {
+  const float a00 = Ea[0], a01 = Ea[1], a10 = Ea[2], a11 = Ea[3];
+  const float b00 = Eb[0], b01 = Eb[1], b10 = Eb[2], b11 = Eb[3];
+  const float dx = xa0 - xb0;
+  const float dy = xa1 - xb1;
+  const float e00 = a00 + b00, e01 = a01 + b01, e11 = a11 + b11;
+  const float det_inv = (float)(1.0 / (double)(e00 * e11 - e01 * e01));
+  float Q = (e11 * dx * dx) - 2.f * (e01 * dx * dy) + (e00 * dy * dy);
+  Q = (float)((double)Q * (0.5 * (double)det_inv));
+  const float d1 = a00 * a11 - a01 * a10;
+  const float d2 = b00 * b11 - b01 * b10;
+  const float pw = powf(d1 * d2, 0.25f);
+  const float C = (float)(2.0 * (double)pw * (double)ref_safe_sqrt(det_inv));
+  return scale * C * ref_matern(Q);
+}
+
 struct CovStrides {
   long x1[3], E1[4], x2[3], E2[4];
 };
@@ -131,6 +150,105 @@ __global__ __launch_bounds__(1024) void greedy_next_kernel(const float* __restri
   if (tid == 0) { best_idx[b] = si[0]; max_stdev[b] = ss[0]; }
 }
 
+
+// ---- the whole greedy loop on the device (samplers.py:196-282 without early termination): per step two launches ----
+// greedy_pick: get_next_inds (running distance mask, first maximum) and the gather of the chosen point into slot `slot`.
+__global__ __launch_bounds__(1024) void greedy_pick_kernel(const float* __restrict__ var, const float* __restrict__ dom,
+                                                           const float* __restrict__ Edom, float* __restrict__ coords_n,
+                                                           float* __restrict__ E_n, long* __restrict__ inds, int n, int k0,
+                                                           int k, uint8_t* __restrict__ mask, float thresh_sq, int slot,
+                                                           long* __restrict__ best_idx, float* __restrict__ max_stdev, int d) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* vb = var + (long)b * d;
+  const float* db = dom + (long)b * d * 2;
+  uint8_t* mb = mask + (long)b * d;
+  const float* chosen = coords_n + ((long)b * n + k0) * 2;      // the k points added since the last call
+  float best = -1.f, best_sd = 0.f;
+  int bi = 0x7fffffff;
+  for (int j = tid; j < d; j += 1024) {
+    uint8_t ok = mb[j];
+    const float y = db[2 * j], x = db[2 * j + 1];
+    for (int c = 0; c < k; ++c) {
+      const float dy = chosen[2 * c] - y, dx = chosen[2 * c + 1] - x;
+      const float d2 = dy * dy + dx * dx;
+      ok = ok && (d2 > thresh_sq);
+    }
+    mb[j] = ok;
+    float sd = sqrtf(vb[j]);
+    if (sd != sd) sd = 0.f;
+    sd += 1e-10f;
+    const float cost = ok ? sd : 0.f;
+    if (cost > best) { best = cost; bi = j; best_sd = sd; }
+  }
+  __shared__ float sc[1024], ss[1024];
+  __shared__ int si[1024];
+  sc[tid] = best; si[tid] = bi; ss[tid] = best_sd;
+  __syncthreads();
+  for (int h = 512; h > 0; h >>= 1) {
+    if (tid < h) {
+      const float c2 = sc[tid + h];
+      const int i2 = si[tid + h];
+      if (c2 > sc[tid] || (c2 == sc[tid] && i2 < si[tid])) { sc[tid] = c2; si[tid] = i2; ss[tid] = ss[tid + h]; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int w = si[0];
+    best_idx[b] = w;
+    max_stdev[b] = ss[0];
+    if (slot < n) {
+      inds[(long)b * n + slot] = w;
+      coords_n[((long)b * n + slot) * 2] = db[2 * w];
+      coords_n[((long)b * n + slot) * 2 + 1] = db[2 * w + 1];
+      for (int e = 0; e < 4; ++e) E_n[((long)b * n + slot) * 4 + e] = Edom[((long)b * d + w) * 4 + e];
+    }
+  }
+}
+
+// greedy_append: k_ni, the new Cholesky row (every workgroup redoes the tiny forward substitution from an LDS copy of L;
+// workgroup 0 stores it), then k_id, the obs_info row and the variance downdate of this workgroup's 256 domain pixels.
+// Arithmetic = cross_cov_kernel<float> + chol_row_kernel + obs_info_kernel.
+__global__ __launch_bounds__(256) void greedy_append_kernel(const float* __restrict__ coords_n, const float* __restrict__ E_n,
+                                                            const float* __restrict__ dom, const float* __restrict__ Edom,
+                                                            float* __restrict__ L, float* __restrict__ obs_info,
+                                                            float* __restrict__ var, float scale, float k_ii, int n, int d,
+                                                            int N) {
+  __shared__ float sx[64 * 2], sE[64 * 4], sL[64 * 65], lrow[64];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  float* Lb = L + (long)b * n * n;
+  for (int e = tid; e < (N + 1) * 2; e += 256) sx[e] = coords_n[(long)b * n * 2 + e];
+  for (int e = tid; e < (N + 1) * 4; e += 256) sE[e] = E_n[(long)b * n * 4 + e];
+  for (int e = tid; e < N * N; e += 256) { const int r = e / N, c = e % N; sL[r * 65 + c] = Lb[(long)r * n + c]; }
+  __syncthreads();
+  if (tid < 64) {
+    const int lane = tid;
+    float sum = 0.f;
+    if (lane < N) sum = cov_value_f32(sx[2 * lane], sx[2 * lane + 1], sE + 4 * lane, sx[2 * N], sx[2 * N + 1], sE + 4 * N, scale);
+    float sumsq = 0.f;
+    for (int i = 0; i < N; ++i) {
+      float li = 0.f;
+      if (lane == i) li = sum / sL[i * 65 + i];
+      li = __shfl(li, i, 64);
+      sumsq += li * li;
+      if (lane == i) lrow[i] = li;
+      if (lane > i && lane < N) sum -= sL[lane * 65 + i] * li;
+    }
+    if (lane == 0) lrow[N] = sqrtf(k_ii - sumsq);
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid <= N) Lb[(long)N * n + tid] = lrow[tid];
+  const int j = blockIdx.x * 256 + tid;
+  if (j >= d) return;
+  const float* xd = dom + ((long)b * d + j) * 2;
+  float sum = cov_value_f32(sx[2 * N], sx[2 * N + 1], sE + 4 * N, xd[0], xd[1], Edom + ((long)b * d + j) * 4, scale);
+  float* ob = obs_info + (long)b * n * d;
+  for (int i = 0; i < N; ++i) sum -= ob[(long)i * d + j] * lrow[i];
+  const float v = sum / lrow[N];
+  ob[(long)N * d + j] = v;
+  var[(long)b * d + j] -= v * v;
+}
+
 template <typename T>
 int cross_cov(const T* x1, const T* E1, const T* x2, const T* E2, T scale, T* K12, int B, int N, int M,
               const long* strides_host, hipStream_t s) {
@@ -178,6 +296,28 @@ int como_greedy_next_f32(const float* var, const float* coords_domain, const flo
   hipLaunchKernelGGL(como::greedy_next_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, var, coords_domain, chosen, k, mask,
                      dist_thresh_sq, best_idx, max_stdev, d);
   COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,
+                         float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
+                         float k_ii, float dist_thresh_sq, int B, int n, int d, int m, como_stream_t stream) {
+  using namespace como;
+  if (!coords_n || !E_n || !coord_vec_inds || !coords_domain || !E_domain || !L || !obs_info || !var || !mask || !best_idx ||
+      !max_stdev || B <= 0 || n <= 0 || n > 64 || d <= 0 || m < 1 || m > n)
+    return COMO_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(1024), 0, s, var, coords_domain, E_domain, coords_n, E_n, coord_vec_inds,
+                     n, 0, m, mask, dist_thresh_sq, m, best_idx, max_stdev, d);
+  COMO_CHECK_LAUNCH();
+  for (int i = m; i < n; ++i) {
+    hipLaunchKernelGGL(greedy_append_kernel, dim3((d + 255) / 256, B), dim3(256), 0, s, coords_n, E_n, coords_domain, E_domain, L,
+                       obs_info, var, scale, k_ii, n, d, i);
+    COMO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(1024), 0, s, var, coords_domain, E_domain, coords_n, E_n,
+                       coord_vec_inds, n, i, 1, mask, dist_thresh_sq, i + 1, best_idx, max_stdev, d);
+    COMO_CHECK_LAUNCH();
+  }
   return COMO_OK;
 }
 

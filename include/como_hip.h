@@ -146,6 +146,14 @@ int como_chol_append_obs_info_f32(float* L, float* obs_info, float* var, const f
  *   max_stdev (B) outputs stay on the device: the sampler loop needs no host round trip. */
 int como_greedy_next_f32(const float* var, const float* coords_domain, const float* chosen, int k, uint8_t* mask,
                          float dist_thresh_sq, long* best_idx, float* max_stdev, int B, int d, como_stream_t stream);
+/* como_greedy_loop_f32  replaces  the whole greedy_loop (samplers.py:196-282, terminate_early = False): two launches per
+ *   added point (append: k_ni, Cholesky row, k_id, obs_info row, variance downdate; pick: distance mask, argmax, gather
+ *   of the chosen point), no host involvement.  State as precalc_entropy_vars leaves it: the first m slots of
+ *   coords_n (B,n,2) / E_n (B,n,2,2) / L (B,n,n) / obs_info (B,n,d) filled, var (B,d) = calc_var(...), mask (B,d) ones;
+ *   on return slots m..n-1 and coord_vec_inds (B,n) int64 are filled.  n <= 64; contiguous float32. */
+int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,
+                         float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
+                         float k_ii, float dist_thresh_sq, int B, int n, int d, int m, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense reference points in factored form (python path: backend/sparse_map.py:184-230 backproject_cloud +

@@ -565,6 +565,11 @@ def test_greedy_sampler_vs_golden():
     coords, inds = samplers.sample_sparse_coords(dev(C["cov_params_img"]), num, "greedy_conditional_entropy", border=border,
                                                  dist_thresh=dth, signal_var=torch.tensor(1.0))
     assert torch.equal(inds.cpu(), C["samp_domain_inds"]) and torch.equal(coords.cpu(), C["samp_coords"])
+    # the step-by-step host loop (taken when early termination is requested; never triggered with this threshold)
+    coords2, inds2 = samplers.sample_sparse_coords(dev(C["cov_params_img"]), num, "greedy_conditional_entropy", border=border,
+                                                   dist_thresh=dth, signal_var=torch.tensor(1.0), terminate_early=True,
+                                                   max_stdev_thresh=-1.0)
+    assert torch.equal(inds2.cpu(), C["samp_domain_inds"])
     # full operating point of the reference: 64 points on a 192x256 covariance image, vs the oracle
     from como_amd.synth import synthetic_cov_params
     cov = synthetic_cov_params(1, 96, 128, seed=3, dtype=torch.float64).float()
