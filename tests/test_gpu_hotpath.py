@@ -579,3 +579,60 @@ def test_greedy_sampler_vs_golden():
     same = (inds.cpu()[0] == idx).sum().item()
     report("greedy_sampler", same_of_32=same)
     assert same == 32 and torch.equal(coords.cpu()[0], pix)
+
+
+# ------------------------------------------------------------------------------------------------
+# Full-size window (the bench workload: 8 keyframes, 640x480, m = 64): size-independent properties
+def _full_window(pix_dtype, window, seed=0):
+    from como_amd import synth
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    import copy
+
+    def predictor(cov, cm):
+        Kinv, L, Kt = prep_predictor(cov.double(), cm.double(), 1.0)
+        return Kinv, L, Kt.to(pix_dtype)
+    st = synth.make_window(B=8, H=480, W=640, m=64, dtype=torch.float64, device=DEV, seed=seed, predictor=predictor)
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = window
+    return WindowBA(st, cfg=cfg, pix_dtype=pix_dtype, window_full=True), st
+
+
+@pytest.mark.parametrize("window", [4, 1])
+def test_fullsize_window_properties(window):
+    """(1) the float32 pixel path agrees with the float64 (reference mapping dtype) pixel path: first-iteration system and
+    pose update within the stated 1e-4; (2) H symmetric; (3) Gauss-Newton converges to the ground-truth poses and the
+    cost settles below its starting value; (4) the captured-graph replay equals the eager iteration."""
+    w32, st = _full_window(torch.float32, window)
+    w64, _ = _full_window(torch.float64, window)
+    H32, g32 = w32.linearize()
+    H64, g64 = w64.linearize()
+    eH, eg = rel_err(H32, H64), rel_err(g32, g64)
+    sym = ((H64 - H64.T).abs().max() / H64.abs().max()).item()
+    d32, d64 = w32.iterate(), w64.iterate()                      # (re-linearises; same state)
+    upd = (w32.kf_poses - w64.kf_poses).abs().max().item()
+    report("fullsize_window", window=window, H_rel_f32_vs_f64=eH, g_rel=eg, sym=sym, pose_update_diff=upd,
+           n=w32.n, D=w32.dim)
+    assert eH < 2e-5 and eg < 2e-4 and sym < 1e-12
+    assert upd < 1e-4
+    gt = st["poses_gt"]
+    e0 = (w32.kf_poses - gt).abs().max().item()
+    errs = []
+    for _ in range(8):
+        w32.iterate()
+        errs.append(float(w32.err))
+    e1 = (w32.kf_poses - gt).abs().max().item()
+    report("fullsize_window_convergence", window=window, pose_err_after_1=e0, pose_err_after_9=e1, cost=errs)
+    assert e1 < 5e-4 and e1 < e0
+    # the robust scale is re-estimated every iteration and the cost is a float32 running sum: settled = flat to 1e-3
+    assert errs[-1] < errs[0] and all(abs(e - errs[-1]) <= 1e-3 * errs[-1] for e in errs[2:])
+    # graph replay == eager: two identical copies of the state, one stepped through the captured graph
+    wa, _ = _full_window(torch.float32, window, seed=1)
+    wb, _ = _full_window(torch.float32, window, seed=1)
+    assert wa.capture(warmup=2)                                  # runs 2 real iterations before recording
+    for _ in range(2):
+        wb.iterate()
+    for _ in range(3):
+        wa.step()
+        wb.iterate()
+    assert (wa.kf_poses - wb.kf_poses).abs().max().item() < 1e-8  # unordered fp64 atomics only
