@@ -29,7 +29,8 @@ class BAArgs(ctypes.Structure):
         ("pose_tgt_inds", c_void_p), ("landmark_inds", c_void_p), ("dzdP", c_void_p), ("Hmat", c_void_p),
         ("gvec", c_void_p), ("D", c_long), ("err_out", c_void_p), ("sigma_out", c_void_p), ("pj_out", c_void_p),
         ("pair_blocks_out", c_void_p), ("ws_r", c_void_p), ("ws_valid", c_void_p), ("ws_hists", c_void_p),
-        ("ws_pair", c_void_p), ("ws_partials", c_void_p),
+        ("ws_pair", c_void_p), ("ws_partials", c_void_p), ("grp_pairs", c_void_p), ("single_pairs", c_void_p),
+        ("ngrp", c_int), ("nsingle", c_int),
     ]
 
 

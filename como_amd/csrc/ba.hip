@@ -410,7 +410,8 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
     const T* __restrict__ uvec, const int* __restrict__ pixidx, const T* __restrict__ invz, long kt_slot_stride,
     BAPairs pr, const T* __restrict__ pair_T, const T* __restrict__ pair_aff, const T* __restrict__ img_base,
     const T* __restrict__ Kmat, int H, int W, int n, int m, int pix_begin, int pix_end, int chunk_len,
-    const uint32_t* __restrict__ hists, T* __restrict__ partials, T* __restrict__ sigma_out, int stagger) {
+    const uint32_t* __restrict__ hists, T* __restrict__ partials, T* __restrict__ sigma_out, int stagger,
+    const int* __restrict__ pair_map) {
   using KeyT = typename KeyOf<T>::type;
   using Cfg = BACfg;
   using acc_t = typename Acc4<T>::type;
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
   const T info_sqrt = T(1) / sigma;
   if (sigma_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sigma_out[0] = sigma; sigma_out[1] = (T)nv; }
 
-  const int p = blockIdx.y;
+  const int p = pair_map ? pair_map[blockIdx.y] : blockIdx.y;
   const int slot = pr.ref_slot[p];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int q = lane >> 4, c = lane & 15;
@@ -636,6 +637,278 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
   }
 }
 
+// ---------------------------------------- pass 2, two pairs sharing their reference keyframe ---------------------------
+// Consecutive-keyframe graphs give every inner keyframe TWO pairs with the same reference (i -> i+1, i -> i-1).  Both
+// rows of a reference pixel carry the SAME K~ row, scaled by their own s_g: the depth x depth block of the normal
+// equations only needs  sum_g s_g^2 K~ K~^T  -- one weighted Gram instead of two.  One workgroup walks the reference
+// pixels ONCE for both pairs: P_w, dPwn_dTwc, uvec, vals and the K~ ring are loaded once (45 % fewer HBM bytes), the
+// matrix work per pixel is 10 (zz, weight sqrt(s_0^2 + s_1^2)) + 2 x 5 (pose x pose, pose x depth with the pose row
+// rescaled by s_g / sqrt(s_0^2 + s_1^2)) = 20 tile-steps instead of 30.  Records: pair 0 carries the zz tiles and the
+// depth gradient, pair 1's are zero -- the assembly kernel is unchanged.  float32 only.
+template <int WPS, int PF>
+__global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
+    const float* __restrict__ Pwn, const float* __restrict__ vals, const float* __restrict__ dPwn_dTwc,
+    const float* __restrict__ Kt, const float* __restrict__ uvec, const int* __restrict__ pixidx,
+    const float* __restrict__ invz, long kt_slot_stride, BAPairs pr, const float* __restrict__ pair_T,
+    const float* __restrict__ pair_aff, const float* __restrict__ img_base, const float* __restrict__ Kmat, int H, int W, int n,
+    int m, int pix_begin, int pix_end, int chunk_len, const uint32_t* __restrict__ hists, float* __restrict__ partials,
+    float* __restrict__ sigma_out, const int* __restrict__ grp_pairs) {
+  using T = float;
+  using KeyT = typename KeyOf<T>::type;
+  using Cfg = BACfg;
+  using acc_t = typename Acc4<T>::type;
+  constexpr int G = 2;
+  __shared__ SelScratch sc;
+  constexpr int STG1 = 16 * JP_STRIDE + 64 * 2;
+  constexpr int STG = G * STG1;
+  constexpr int LDS_ELEMS = (4 * STG > 2 * Cfg::REC) ? 4 * STG : 2 * Cfg::REC;
+  __shared__ T lds[LDS_ELEMS];
+
+  KeyT prefix; uint32_t k_rem, nv;
+  sel_resolve<KeyT>(hists, SelCfg<KeyT>::NPASS, &sc, prefix, k_rem, nv);
+  const T sigma = T(1.4826) * key_value(prefix);
+  const T info_sqrt = T(1) / sigma;
+  if (sigma_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sigma_out[0] = sigma; sigma_out[1] = (T)nv; }
+
+  // a row {p, -1} is a reference keyframe with a single pair: its second lane set is masked off (rows of zeros)
+  const int pg0 = grp_pairs[2 * blockIdx.y], pg1 = grp_pairs[2 * blockIdx.y + 1];
+  const bool has1 = pg1 >= 0;
+  const int pg[G] = {pg0, has1 ? pg1 : pg0};
+  const int slot = pr.ref_slot[pg[0]];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int q = lane >> 4, c = lane & 15;
+  T* Jp[G];
+  T* Sv[G];
+  T Mr[G][12], scale[G], bias[G];
+  const T* img[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    Jp[g] = lds + wv * STG + g * STG1;
+    Sv[g] = Jp[g] + 16 * JP_STRIDE;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) Mr[g][k] = pair_T[12 * (long)pg[g] + k];
+    scale[g] = pair_aff[2 * pg[g]];
+    bias[g] = pair_aff[2 * pg[g] + 1];
+    img[g] = img_base + pr.tgt_img[pg[g]];
+  }
+  const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
+  const long HW = (long)H * W;
+  T invz4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
+  const T* KtS = Kt + (long)slot * kt_slot_stride + ((4 * c < m) ? 4 * c : 0);
+
+  acc_t azz[10], aTT[G], aTz[G][4];
+#pragma unroll
+  for (int t = 0; t < 10; ++t) azz[t] = acc_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    aTT[g] = acc_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) aTz[g][e] = acc_t{0.f, 0.f, 0.f, 0.f};
+  }
+  T gT[G] = {0.f, 0.f}, gz[4] = {0.f, 0.f, 0.f, 0.f}, err[G] = {0.f, 0.f};
+
+  const int begin = pix_begin + blockIdx.x * chunk_len;
+  const int end = min(pix_end, begin + chunk_len);
+  V4<T> kq[PF];
+
+  // ---- pipeline registers (shared: P_w, Dv, Uv, valv, rows; per pair: warp state + taps) ----
+  T pw0, pw1, pw2;
+  T Dv[18], Uv[3], valv;
+  T tv[G][12];
+  T wX[G], wY[G], wZ[G], w00[G], w01[G], w10[G], w11[G];
+  bool wok[G];
+  int row_cur = 0, row_nxt = 0;
+
+  auto s0_load = [&](int tile) {
+    const int ic = min(tile + lane, end - 1);
+    pw0 = Pwn[((long)slot * 3 + 0) * n + ic]; pw1 = Pwn[((long)slot * 3 + 1) * n + ic]; pw2 = Pwn[((long)slot * 3 + 2) * n + ic];
+  };
+  auto s1_issue = [&](int tile) {
+    const int i = tile + lane;
+    const bool inr = i < end;
+    const int ic = inr ? i : (end - 1);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      Warp<T> w = warp_point(Mr[g], fx, fy, cx, cy, pw0, pw1, pw2, H, W);
+      Taps<T> tp = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
+      wX[g] = w.X; wY[g] = w.Y; wZ[g] = w.Z; wok[g] = inr && w.ok && (g == 0 || has1);
+      w00[g] = tp.w00; w01[g] = tp.w01; w10[g] = tp.w10; w11[g] = tp.w11;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const T* P = img[g] + pl * HW;
+        tv[g][4 * pl + 0] = P[tp.i00]; tv[g][4 * pl + 1] = P[tp.i01]; tv[g][4 * pl + 2] = P[tp.i10]; tv[g][4 * pl + 3] = P[tp.i11];
+      }
+    }
+    const T* D = dPwn_dTwc + (long)slot * 18 * n + ic;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) Dv[k] = D[(long)k * n];
+    const T* U = uvec + (long)slot * 3 * n + ic;
+    Uv[0] = U[0]; Uv[1] = U[n]; Uv[2] = U[2 * (long)n];
+    valv = vals[(long)slot * n + ic];
+    row_nxt = pixidx ? pixidx[(long)slot * n + ic] : ic;
+  };
+  auto s2_rows = [&]() {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const T It = w00[g] * tv[g][0] + w01[g] * tv[g][1] + w10[g] * tv[g][2] + w11[g] * tv[g][3];
+      const T gx = w00[g] * tv[g][4] + w01[g] * tv[g][5] + w10[g] * tv[g][6] + w11[g] * tv[g][7];
+      const T gy = w00[g] * tv[g][8] + w01[g] * tv[g][9] + w10[g] * tv[g][10] + w11[g] * tv[g][11];
+      const T Iref_s = scale[g] * valv;
+      const T r = It - Iref_s + bias[g];
+      const bool ok = wok[g];
+      const T wr = r * info_sqrt;
+      const T wgt = ok ? huber(wr) : T(0);
+      const T ws = sqrt(wgt);
+      const T s = ok ? info_sqrt * ws : T(0);
+      err[g] += ok ? (ws * wr) * (ws * wr) : T(0);
+      const T iz = ok ? T(1) / wZ[g] : T(0);
+      const T a0 = gx * fx * iz, a1 = gy * fy * iz;
+      const T a2 = -(a0 * wX[g] + a1 * wY[g]) * iz;
+      const T b0 = a0 * Mr[g][0] + a1 * Mr[g][4] + a2 * Mr[g][8];
+      const T b1 = a0 * Mr[g][1] + a1 * Mr[g][5] + a2 * Mr[g][9];
+      const T b2 = a0 * Mr[g][2] + a1 * Mr[g][6] + a2 * Mr[g][10];
+      T* J = Jp[g];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) J[k * JP_STRIDE + lane] = s * (b0 * Dv[k] + b1 * Dv[6 + k] + b2 * Dv[12 + k]);
+      J[6 * JP_STRIDE + lane] = s * Iref_s;
+      J[7 * JP_STRIDE + lane] = -s;
+      const T Xc = ok ? wX[g] : T(0), Yc = ok ? wY[g] : T(0), Zc = ok ? wZ[g] : T(0);
+      J[8 * JP_STRIDE + lane] = s * (a1 * Zc - a2 * Yc);
+      J[9 * JP_STRIDE + lane] = s * (a2 * Xc - a0 * Zc);
+      J[10 * JP_STRIDE + lane] = s * (a0 * Yc - a1 * Xc);
+      J[11 * JP_STRIDE + lane] = -s * a0;
+      J[12 * JP_STRIDE + lane] = -s * a1;
+      J[13 * JP_STRIDE + lane] = -s * a2;
+      J[14 * JP_STRIDE + lane] = -s * Iref_s;
+      J[15 * JP_STRIDE + lane] = s;
+      Sv[g][lane] = s * r;
+      Sv[g][64 + lane] = s * (b0 * Uv[0] + b1 * Uv[1] + b2 * Uv[2]);
+    }
+  };
+
+  const int tile0 = begin + wv * 64;
+  if (tile0 < end) {
+    s0_load(tile0);
+    s1_issue(tile0);
+    row_cur = row_nxt;
+    static_for<PF>([&](auto ic_) {
+      constexpr int st = decltype(ic_)::value;
+      const int row = __shfl(row_cur, 4 * st + q, 64);
+      kq[st] = load4(KtS + (long)row * m);
+    });
+    s0_load(tile0 + 256);
+  }
+  for (int tile = tile0; tile < end; tile += 256) {
+    s2_rows();
+    s1_issue(tile + 256);
+    s0_load(tile + 512);
+    __builtin_amdgcn_wave_barrier();
+    for (int half = 0; half < 16 / PF; ++half) {
+      static_for<PF>([&](auto ic_) {
+        constexpr int sl = decltype(ic_)::value;
+        const int st = half * PF + sl;
+        const int px = 4 * st + q;
+        const T a00 = Jp[0][c * JP_STRIDE + px], a01 = Jp[1][c * JP_STRIDE + px];
+        const T rt0 = Sv[0][px], rt1 = Sv[1][px];
+        const T sz0 = Sv[0][64 + px], sz1 = Sv[1][64 + px];
+        const V4<T> k4 = kq[sl];
+        {
+          const int nst = st + PF;
+          const bool same = nst < 16;
+          const int row = __shfl(same ? row_cur : row_nxt, 4 * (same ? nst : nst - 16) + q, 64);
+          kq[sl] = load4(KtS + (long)row * m);
+        }
+        const T cs = sz0 * sz0 + sz1 * sz1;
+        const T rs = cs > T(0) ? __builtin_amdgcn_rsqf(cs) : T(0);
+        const T sc2 = cs * rs;                                   // sqrt(s_0^2 + s_1^2)
+        T zq[4];
+        zq[0] = sc2 * (k4.x * invz4[0]); zq[1] = sc2 * (k4.y * invz4[1]); zq[2] = sc2 * (k4.z * invz4[2]); zq[3] = sc2 * (k4.w * invz4[3]);
+        const T p0 = a00 * (sz0 * rs), p1 = a01 * (sz1 * rs);    // pose rows rescaled for the pose x depth tiles
+        const T gzs = (sz0 * rt0 + sz1 * rt1) * rs;
+        gT[0] += a00 * rt0;
+        gT[1] += a01 * rt1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gz[e] += zq[e] * gzs;
+        aTT[0] = mfma16(a00, a00, aTT[0]);
+        aTT[1] = mfma16(a01, a01, aTT[1]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          aTz[0][e] = mfma16(p0, zq[e], aTz[0][e]);
+          aTz[1][e] = mfma16(p1, zq[e], aTz[1][e]);
+        }
+        static_for<10>([&](auto it) {
+          constexpr int tt = decltype(it)::value + 5;          // tiles 5..14 of the 15-tile enumeration = depth x depth
+          constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
+          azz[tt - 5] = mfma16(zq[ti - 1], zq[tj - 1], azz[tt - 5]);
+        });
+      });
+    }
+    __builtin_amdgcn_wave_barrier();
+    row_cur = row_nxt;
+  }
+
+  // ---- epilogue: one record per pair, ordered cross-wave reduction (record layout of ba_blocks_kernel) ----
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    gT[g] += __shfl_xor(gT[g], 16, 64);
+    gT[g] += __shfl_xor(gT[g], 32, 64);
+    err[g] = wave_sum(err[g]);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    gz[e] += __shfl_xor(gz[e], 16, 64);
+    gz[e] += __shfl_xor(gz[e], 32, 64);
+  }
+  static_for<G>([&](auto ig) {
+    constexpr int g = decltype(ig)::value;
+    acc_t acc[Cfg::NT];
+    T gacc[Cfg::NB];
+    acc[0] = aTT[g];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[1 + e] = aTz[g][e];
+#pragma unroll
+    for (int t = 0; t < 10; ++t) acc[5 + t] = (g == 0) ? azz[t] : acc_t{0.f, 0.f, 0.f, 0.f};
+    gacc[0] = gT[g];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gacc[1 + e] = (g == 0) ? gz[e] : T(0);
+    T er = err[g];
+    auto put = [&](T* dst) {
+#pragma unroll
+      for (int t = 0; t < Cfg::NT; ++t)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) dst[t * 256 + rg * 64 + lane] = acc[t][rg];
+      if (lane < 16) {
+#pragma unroll
+        for (int t = 0; t < Cfg::NB; ++t) dst[Cfg::NT * 256 + t * 16 + lane] = gacc[t];
+      }
+      if (lane == 0) dst[Cfg::NT * 256 + Cfg::NB * 16] = er;
+    };
+    auto add = [&](const T* src) {
+#pragma unroll
+      for (int t = 0; t < Cfg::NT; ++t)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) acc[t][rg] += src[t * 256 + rg * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < Cfg::NB; ++t) gacc[t] += src[Cfg::NT * 256 + t * 16 + (lane & 15)];
+      er += src[Cfg::NT * 256 + Cfg::NB * 16];
+    };
+    __syncthreads();
+    if (wv >= 2) put(lds + (wv - 2) * Cfg::REC);
+    __syncthreads();
+    if (wv < 2) add(lds + wv * Cfg::REC);
+    __syncthreads();
+    if (wv == 1) put(lds);
+    __syncthreads();
+    if (wv == 0 && (g == 0 || has1)) {
+      add(lds);
+      put(partials + (long)(pg[g] * gridDim.x + blockIdx.x) * Cfg::REC);
+    }
+  });
+}
+
 // ---------------------------------------- stage 2 ------------------------------------------------
 // One thread per record element: fixed-order fp64 sum over the pair's wave partials, then the
 // landmark expansion (photo.py:169-182) and accumulation into H / g (photo.py:184-231).
@@ -789,17 +1062,35 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
                      (const float*)A->dPwn_dTwc, (const float*)A->zjac, (const float*)A->uvec, A->pixidx,             \
                      (const float*)A->invz, A->kt_slot_stride, pr, (const float*)pair_T, (const float*)pair_aff,      \
                      (const float*)A->img_base, (const float*)A->K, A->H, A->W, n, m, pb, pe, chunk_len, hists,       \
-                     (float*)A->ws_partials, (float*)A->sigma_out, A->stagger)
+                     (float*)A->ws_partials, (float*)A->sigma_out, A->stagger, (const int*)nullptr)
 #define LAUNCH_PIPE_ABL(AB)                                                                                           \
   hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2, AB>), grid, blk, 0, s, (const float*)A->Pwn, (const float*)A->vals, \
                      (const float*)A->dPwn_dTwc, (const float*)A->zjac, (const float*)A->uvec, A->pixidx,             \
                      (const float*)A->invz, A->kt_slot_stride, pr, (const float*)pair_T, (const float*)pair_aff,      \
                      (const float*)A->img_base, (const float*)A->K, A->H, A->W, n, m, pb, pe, chunk_len, hists,       \
-                     (float*)A->ws_partials, (float*)A->sigma_out, A->stagger)
+                     (float*)A->ws_partials, (float*)A->sigma_out, A->stagger, (const int*)nullptr)
       if constexpr (sizeof(T) == 4) {
         if (A->variant == 3) { LAUNCH_PIPE(1); }
         else if (A->variant == 11) { LAUNCH_PIPE_ABL(1); }
         else if (A->variant == 12) { LAUNCH_PIPE_ABL(2); }
+        else if (A->variant != 2 && A->grp_pairs && A->ngrp > 0 && (A->nsingle == 0 || A->single_pairs)) {
+          // pairs that share their reference keyframe go through the two-pair kernel, the rest through the one-pair kernel
+          // two waves per SIMD and a 4-deep K~ ring (256 VGPRs): 329 us; one wave per SIMD with an 8-deep ring: 371 us
+          hipLaunchKernelGGL((ba_blocks_pair2_kernel<2, 4>), dim3(chunks, A->ngrp), blk, 0, s, (const float*)A->Pwn,
+                             (const float*)A->vals, (const float*)A->dPwn_dTwc, (const float*)A->zjac, (const float*)A->uvec,
+                             A->pixidx, (const float*)A->invz, A->kt_slot_stride, pr, (const float*)pair_T,
+                             (const float*)pair_aff, (const float*)A->img_base, (const float*)A->K, A->H, A->W, n, m, pb, pe,
+                             chunk_len, hists, (float*)A->ws_partials, (float*)A->sigma_out, A->grp_pairs);
+          if (A->nsingle > 0) {
+            COMO_CHECK_LAUNCH();
+            hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2>), dim3(chunks, A->nsingle), blk, 0, s, (const float*)A->Pwn,
+                               (const float*)A->vals, (const float*)A->dPwn_dTwc, (const float*)A->zjac,
+                               (const float*)A->uvec, A->pixidx, (const float*)A->invz, A->kt_slot_stride, pr,
+                               (const float*)pair_T, (const float*)pair_aff, (const float*)A->img_base, (const float*)A->K,
+                               A->H, A->W, n, m, pb, pe, chunk_len, hists, (float*)A->ws_partials, (float*)A->sigma_out,
+                               A->stagger, A->single_pairs);
+          }
+        }
         else { LAUNCH_PIPE(2); }
       } else {
         LAUNCH_BLOCKS(1);

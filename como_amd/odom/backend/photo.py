@@ -32,9 +32,10 @@ def _buf(name, shape, dtype, device):
     return t[:numel].view(*shape)
 
 
-def default_chunks(b, n, dtype):
-    """Pixel chunks per pair: about two resident rounds of 256-thread workgroups on 256 CUs."""
-    per_cu = 3 if dtype == torch.float32 else 1
+def default_chunks(b, n, dtype, per_cu=None):
+    """Pixel chunks per pair (or per pair group): about two resident rounds of 256-thread workgroups on 256 CUs."""
+    if per_cu is None:
+        per_cu = 3 if dtype == torch.float32 else 1
     want = max(1, (2 * 256 * per_cu + b - 1) // b)
     return int(max(1, min(want, (n + 255) // 256)))
 
@@ -42,7 +43,8 @@ def default_chunks(b, n, dtype):
 def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac, poses_all, aff_all, img_base, K,
               ref_slot, ref_aff, tgt_aff, tgt_pose, tgt_img, pose_ref_inds, pose_tgt_inds, landmark_inds, dzdP, H, g,
               err_out, uvec=None, pixidx=None, invz=None, kt_slot_stride=0, chunks=None, phase=0xFF, want_pj=False,
-              want_blocks=False, sigma_out=None, pix_range=None, reduce_hists=None, events=None, anorm_f32=False):
+              want_blocks=False, sigma_out=None, pix_range=None, reduce_hists=None, events=None, anorm_f32=False,
+              grp_pairs=None, single_pairs=None):
     """Thin marshalling layer over como_ba_linearize_* (see include/como_hip.h for every field).
 
     pix_range=(begin, end): this rank's share of the reference pixels of every pair (multi-GPU shard).
@@ -54,11 +56,18 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     pb, pe = pix_range if pix_range is not None else (0, n)
     nl = pe - pb
     if chunks is None:
-        chunks = default_chunks(b, nl, dtype)
+        if grp_pairs is not None and grp_pairs.numel() > 0 and dtype == torch.float32 and zmode == 1 and BLOCK_VARIANT == 0:
+            chunks = default_chunks(grp_pairs.shape[0], nl, dtype, per_cu=2)     # two-pair kernel: 2 workgroups per CU resident
+        else:
+            chunks = default_chunks(b, nl, dtype)
     a = _lib.BAArgs()
     a.b, a.n, a.m, a.H, a.W, a.zmode, a.chunks, a.phase = b, n, m, H_img, W_img, zmode, chunks, phase
     a.pix_begin, a.pix_end = pb, pe
     a.anorm_f32 = 1 if anorm_f32 else 0
+    if grp_pairs is not None and grp_pairs.numel() > 0:
+        a.grp_pairs, a.ngrp = _lib.ptr(grp_pairs), grp_pairs.shape[0]
+        a.single_pairs = _lib.ptr(single_pairs) if single_pairs is not None and single_pairs.numel() > 0 else None
+        a.nsingle = single_pairs.numel() if single_pairs is not None else 0
     a.variant = BLOCK_VARIANT
     a.stagger = BLOCK_STAGGER
     a.h_is_f64 = 1 if H.dtype == torch.float64 else 0
@@ -202,6 +211,19 @@ class PairTable:
             rows.append(recent_inds[t] if r else kf_inds[t])
         self.pose_tgt_inds = torch.stack(rows).contiguous()
         self.landmark_inds = landmark_inds[rid].contiguous()
+        # pairs sharing their reference keyframe, two at a time (csrc/ba.hip ba_blocks_pair2_kernel); the rest one by one
+        by_ref = {}
+        for p_, r_ in enumerate(ref_ids):
+            by_ref.setdefault(int(r_), []).append(p_)
+        grp = []
+        for lst in by_ref.values():
+            while len(lst) >= 2:
+                grp.append([lst.pop(0), lst.pop(0)])
+            if lst:
+                grp.append([lst[0], -1])                   # a lone pair rides the same kernel with its second half masked
+        self.grp_pairs = torch.tensor(grp, dtype=torch.int32, device=device).reshape(-1, 2)
+        self.single_pairs = torch.zeros(0, dtype=torch.int32, device=device)
+        self.ngroups = len(grp)
 
 
 def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uvec, Kt, pixidx, invz, dzdP, img_base, K,
@@ -218,4 +240,5 @@ def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uv
                      ref_slot=table.ref_slot, ref_aff=table.ref_aff, tgt_aff=table.tgt_aff, tgt_pose=table.tgt_pose,
                      tgt_img=table.tgt_img, pose_ref_inds=table.pose_ref_inds, pose_tgt_inds=table.pose_tgt_inds,
                      landmark_inds=table.landmark_inds, dzdP=dzdP, H=H, g=g, err_out=err_out, chunks=chunks,
-                     phase=phase, sigma_out=sigma_out, pix_range=pix_range, reduce_hists=reduce_hists, events=events)
+                     phase=phase, sigma_out=sigma_out, pix_range=pix_range, reduce_hists=reduce_hists, events=events,
+                     grp_pairs=(table.grp_pairs if vals.dtype == torch.float32 else None), single_pairs=table.single_pairs)

@@ -77,7 +77,8 @@ typedef struct como_ba_args {
   int chunks;                /* pixel chunks per pair (grid.x of the block kernel); partial records = b*chunks */
   int phase;                 /* bit mask: 1 setup+residual(+hist pass 0), 2<<(p-1) hist pass p>=1, 64 blocks, 128 reduce+assemble */
   int h_is_f64;              /* element type of Hmat / gvec: 1 = double, 0 = float */
-  int variant;               /* zmode 1 only: 0 = software-pipelined block kernel (float32; default), 1 = straightforward one */
+  int variant;               /* zmode 1 only: 0 = software-pipelined block kernels (float32; default; two-pair kernel where
+                                grp_pairs lists pairs), 1 = straightforward one, 2 = pipelined one-pair kernel only */
   int stagger;               /* pipelined kernel: start delay (x1024 cycles) of odd hardware wave slots, 0 = none */
   int pix_begin, pix_end;    /* reference-pixel range [begin,end) of every pair handled by this call (multi-GPU shard);
                                 pix_end <= 0 means n.  ws_r / ws_valid / pj_out are then (b, end-begin). */
@@ -116,6 +117,10 @@ typedef struct como_ba_args {
   void* ws_hists;            /* como_select_workspace_bytes() */
   void* ws_pair;             /* b*14 elements */
   void* ws_partials;         /* como_ba_partials_elems(b, chunks, m) elements */
+  const int* grp_pairs;      /* optional (ngrp,2): pairs of this batch that share their reference slot, two per row (zmode 1,
+                                float32): the depth x depth block and the K~ reads are shared inside a row */
+  const int* single_pairs;   /* (nsingle): the pairs not listed in grp_pairs */
+  int ngrp, nsingle;         /* every pair appears exactly once in grp_pairs U single_pairs; ngrp = 0 / NULL: one pair at a time */
 } como_ba_args;
 
 long como_ba_partials_elems(int b, int chunks, int m);
