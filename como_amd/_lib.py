@@ -44,7 +44,9 @@ class WinArgs(ctypes.Structure):
                                           "dlogz_dT", "dlogz_dP", "dp_dP", "dp_dT", "init_Pm", "reinit_flag", "px_logzm",
                                           "px_invz", "px_dzdP", "px_dlogz_dT", "px_poses", "px_aff")]
                 + [(n, c_double) for n in ("s_gp", "s_ld", "s_px", "s_pose", "s_aff", "s_lm")]
-                + [(n, c_void_p) for n in ("H", "g", "err")])
+                + [(n, c_void_p) for n in ("H", "g", "err")]
+                + [("zero_a", c_void_p), ("zero_a_bytes", c_long), ("zero_b", c_void_p), ("zero_b_bytes", c_long),
+                   ("median_out", c_void_p)])
 
 
 # name -> (restype, argtypes); every symbol include/como_hip.h declares
@@ -69,8 +71,8 @@ SIGNATURES = {
     "como_chol_append_obs_info_f32": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "como_greedy_loop_f32": (c_int, [c_void_p] * 11 + [c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "como_greedy_next_f32": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "como_dense_ref_f32": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 9),
-    "como_dense_ref_f64": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 9),
+    "como_dense_ref_f32": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8 + [c_int, c_void_p]),
+    "como_dense_ref_f64": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8 + [c_int, c_void_p]),
     "como_kernel_matrix_f32": (c_int, [c_void_p] * 4 + [c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "como_kernel_matrix_f64": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int, c_int, c_int, c_void_p]),
     "como_ktilde_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,

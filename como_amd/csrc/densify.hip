@@ -335,13 +335,14 @@ __global__ __launch_bounds__(256) void ktilde_kernel(const T* __restrict__ cov, 
 template <typename T>
 int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logzm, const T* Twc, const T* Kmat,
               const T* dlogzm_dTwc, int B, int n, int m, int Wimg, T* Pwn, T* dPwn_dTwc, T* uvec, T* zbuf, T* logzn_out,
-              void* hists_v, T* med_out3, const int* pixcoord, hipStream_t s) {
+              void* hists_v, T* med_out3, const int* pixcoord, int flags, hipStream_t s) {
   using KeyT = typename KeyOf<T>::type;
   if (!Kt || !logzm || !Twc || !Kmat || !dlogzm_dTwc || !Pwn || !dPwn_dTwc || !uvec || !zbuf || !hists_v || !med_out3 ||
       B <= 0 || n <= 0 || m <= 0 || m > 64 || (m & 3) || Wimg <= 0)
     return COMO_ERR_ARG;
   uint32_t* hists = (uint32_t*)hists_v;
-  if (hipMemsetAsync(hists, 0, (size_t)B * 6 * SEL_BINS * sizeof(uint32_t), s) != hipSuccess) return COMO_ERR_LAUNCH;
+  if (!(flags & 1) && hipMemsetAsync(hists, 0, (size_t)B * 6 * SEL_BINS * sizeof(uint32_t), s) != hipSuccess)
+    return COMO_ERR_LAUNCH;
   int gx = (n + 255) / 256;
   if (gx > 512) gx = 512;
   if constexpr (sizeof(T) == 4) {
@@ -371,18 +372,18 @@ int como_select_finish_f64(const void*, int, double*, como_stream_t);
 int como_dense_ref_f32(const float* Kt, long kt_slot_stride, const int* pixidx, const float* logzm, const float* Twc,
                        const float* K, const float* dlogzm_dTwc, int B, int n, int m, int Wimg, float* Pwn,
                        float* dPwn_dTwc, float* uvec, float* zbuf, float* logzn_out, void* hists, float* med_out3,
-                       const int* pixcoord, como_stream_t stream) {
+                       const int* pixcoord, int flags, como_stream_t stream) {
   int rc = como::dense_ref<float>(Kt, kt_slot_stride, pixidx, logzm, Twc, K, dlogzm_dTwc, B, n, m, Wimg, Pwn, dPwn_dTwc, uvec,
-                                  zbuf, logzn_out, hists, med_out3, pixcoord, (hipStream_t)stream);
+                                  zbuf, logzn_out, hists, med_out3, pixcoord, flags, (hipStream_t)stream);
   if (rc) return rc;
   return como_select_finish_f32(hists, B, med_out3, stream);
 }
 int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx, const double* logzm, const double* Twc,
                        const double* K, const double* dlogzm_dTwc, int B, int n, int m, int Wimg, double* Pwn,
                        double* dPwn_dTwc, double* uvec, double* zbuf, double* logzn_out, void* hists, double* med_out3,
-                       const int* pixcoord, como_stream_t stream) {
+                       const int* pixcoord, int flags, como_stream_t stream) {
   int rc = como::dense_ref<double>(Kt, kt_slot_stride, pixidx, logzm, Twc, K, dlogzm_dTwc, B, n, m, Wimg, Pwn, dPwn_dTwc, uvec,
-                                   zbuf, logzn_out, hists, med_out3, pixcoord, (hipStream_t)stream);
+                                   zbuf, logzn_out, hists, med_out3, pixcoord, flags, (hipStream_t)stream);
   if (rc) return rc;
   return como_select_finish_f64(hists, B, med_out3, stream);
 }

@@ -75,8 +75,13 @@ __global__ __launch_bounds__(64) void win_scaffold_kernel(
     const double* __restrict__ poses, const double* __restrict__ aff, int F, const double* __restrict__ P_m,
     const int* __restrict__ lm_ids, const int* __restrict__ first_frame, const int* __restrict__ first_slot,
     const double* __restrict__ Kmat, const double* __restrict__ median, const double* __restrict__ pm_first, int B, int m,
-    ScaffoldOut o, ScaffoldPix<TP> px) {
+    ScaffoldOut o, ScaffoldPix<TP> px, uint4* __restrict__ za, long za16, uint4* __restrict__ zb, long zb16,
+    double* __restrict__ err8) {
   const int b = blockIdx.x, j = threadIdx.x;
+  // this iteration's accumulators that would otherwise each need a fill launch (~4.5 us apiece)
+  for (long e = (long)b * 64 + j; e < za16; e += (long)gridDim.x * 64) za[e] = uint4{0u, 0u, 0u, 0u};
+  for (long e = (long)b * 64 + j; e < zb16; e += (long)gridDim.x * 64) zb[e] = uint4{0u, 0u, 0u, 0u};
+  if (err8 && b == 0 && j < 8) err8[j] = 0.0;
   // pix-dtype copies of ALL frame poses / affine params (keyframes then recent frames)
   for (int e = b * 64 + j; e < F * 16; e += gridDim.x * 64) px.poses[e] = (TP)poses[e];
   for (int e = b * 64 + j; e < F * 2; e += gridDim.x * 64) px.aff[e] = (TP)aff[e];
@@ -160,6 +165,7 @@ struct PriorArgs {
   const int* fix_lm; int nfix;
   double s_gp, s_ld, s_px, s_pose, s_aff, s_lm;   // sigmas
   double* H; double* g; long D; double* err;      // err: 8 doubles
+  double* median_out;
 };
 
 __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int m) {
@@ -178,6 +184,7 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
   const bool lead = slice == 0;
   const double med = A.median_is_f32 ? (double)((const float*)A.median)[(long)b * A.median_stride]
                                      : ((const double*)A.median)[(long)b * A.median_stride];
+  if (A.median_out && lead && tid == 0) A.median_out[b] = med;      // the next iteration's re-initialisation depth
   const double logmed = log(med);
   const double i_gp = 1.0 / (A.s_gp * A.s_gp), i_ld = 1.0 / (A.s_ld * A.s_ld), i_px = 1.0 / (A.s_px * A.s_px);
   {
@@ -407,17 +414,23 @@ int como_win_scaffold(const como_win_args* a, como_stream_t stream) {
   if (!a || a->B <= 0 || a->m <= 0 || a->m > 64 || a->F < a->B) return COMO_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   ScaffoldOut o{a->pm, a->logzm, a->invz, a->dzdP, a->dlogz_dT, a->dlogz_dP, a->dp_dP, a->dp_dT, a->init_Pm, a->reinit_flag};
-  const int grid = a->B > (a->F * 16 + 63) / 64 ? a->B : (a->F * 16 + 63) / 64;
+  int grid = a->B > (a->F * 16 + 63) / 64 ? a->B : (a->F * 16 + 63) / 64;
+  const long za16 = a->zero_a ? a->zero_a_bytes / 16 : 0, zb16 = a->zero_b ? a->zero_b_bytes / 16 : 0;
+  if ((a->zero_a && (a->zero_a_bytes & 15)) || (a->zero_b && (a->zero_b_bytes & 15))) return COMO_ERR_ARG;
+  if (za16 + zb16 > 0 && grid < 64) grid = 64;             // enough threads for the clears
+  double* zerr = (a->zero_a || a->zero_b) ? a->err : nullptr;
   if (a->pix_is_f64) {
     ScaffoldPix<double> px{(double*)a->px_logzm, (double*)a->px_invz, (double*)a->px_dzdP, (double*)a->px_dlogz_dT,
                            (double*)a->px_poses, (double*)a->px_aff};
     hipLaunchKernelGGL(win_scaffold_kernel<double>, dim3(grid), dim3(64), 0, s, a->poses, a->aff, a->F, a->P_m, a->lm_ids,
-                       a->first_frame, a->first_slot, a->K, a->median, a->pm_first, a->B, a->m, o, px);
+                       a->first_frame, a->first_slot, a->K, a->median, a->pm_first, a->B, a->m, o, px, (uint4*)a->zero_a, za16,
+                       (uint4*)a->zero_b, zb16, zerr);
   } else {
     ScaffoldPix<float> px{(float*)a->px_logzm, (float*)a->px_invz, (float*)a->px_dzdP, (float*)a->px_dlogz_dT,
                           (float*)a->px_poses, (float*)a->px_aff};
     hipLaunchKernelGGL(win_scaffold_kernel<float>, dim3(grid), dim3(64), 0, s, a->poses, a->aff, a->F, a->P_m, a->lm_ids,
-                       a->first_frame, a->first_slot, a->K, a->median, a->pm_first, a->B, a->m, o, px);
+                       a->first_frame, a->first_slot, a->K, a->median, a->pm_first, a->B, a->m, o, px, (uint4*)a->zero_a, za16,
+                       (uint4*)a->zero_b, zb16, zerr);
   }
   COMO_CHECK_LAUNCH();
   hipLaunchKernelGGL(win_apply_reinit_kernel, dim3((a->L + 255) / 256), dim3(256), 0, s, a->P_m, a->init_Pm, a->reinit_flag, a->L);
@@ -438,6 +451,7 @@ int como_win_priors(const como_win_args* a, como_stream_t stream) {
   A.fix_inds = a->fix_inds; A.fix_lm = a->fix_lm; A.nfix = a->nfix;
   A.s_gp = a->s_gp; A.s_ld = a->s_ld; A.s_px = a->s_px; A.s_pose = a->s_pose; A.s_aff = a->s_aff; A.s_lm = a->s_lm;
   A.H = a->H; A.g = a->g; A.D = a->D; A.err = a->err;
+  A.median_out = a->median_out;
   const int m = a->m;
   const size_t lds = (size_t)(m * (m + 1) + m * 6 + m + m + m * 6 + m * 3 + 64 + m * 21) * sizeof(double);
   hipLaunchKernelGGL(win_priors_kernel, dim3(a->B, 32), dim3(256), lds, s, A, a->B, m);

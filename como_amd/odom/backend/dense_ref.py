@@ -11,9 +11,11 @@ from como_amd import _lib
 _ws = {}
 
 
-def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_logz=True, med_out=None, pixcoord=None):
+def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_logz=True, med_out=None, pixcoord=None,
+                             hists=None):
     """logzm (B,m[,1]) Twc (B,4,4) Kt (B,rows,m) pixidx (B,n) int32 or None K (3,3) dlogzm_dTwc (B,m[,1],6).
     pixcoord: optional (B,n) int32 linear pixel index (row*W+col) when it differs from the K~ row index.
+    hists: optional caller-owned, ALREADY ZEROED select workspace (B * como_select_workspace_bytes()): skips the clear.
     med_out: optional caller-owned (B,3) buffer for {median depth, 1.4826*median, n} (fixed address for fused chains).
     Returns Pwn (B,3,n), dPwn_dTwc (B,18,n), uvec (B,3,n), median depth (B,), logzn (B,n)."""
     _lib.require_cuda(logzm, Twc, Kt, K, dlogzm_dTwc)
@@ -38,7 +40,7 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
     fn = getattr(L, "como_dense_ref_" + _lib.suffix(dt))
     rc = fn(Kt.data_ptr(), Kt.stride(0), _lib.ptr(pixidx), lz.data_ptr(), Tw.data_ptr(), Kc.data_ptr(), dl.data_ptr(), B, n, m,
             int(Wimg), ws["Pwn"].data_ptr(), ws["dT"].data_ptr(), ws["uvec"].data_ptr(), ws["z"].data_ptr(),
-            ws["logz"].data_ptr() if want_logz else None, ws["hists"].data_ptr(), med.data_ptr(), _lib.ptr(pixcoord),
-            _lib.stream_ptr(dev))
+            ws["logz"].data_ptr() if want_logz else None, (hists if hists is not None else ws["hists"]).data_ptr(), med.data_ptr(),
+            _lib.ptr(pixcoord), 1 if hists is not None else 0, _lib.stream_ptr(dev))
     _lib.check(rc, "como_dense_ref")
     return ws["Pwn"], ws["dT"], ws["uvec"], med[:, 0], ws["logz"]

@@ -44,7 +44,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
               ref_slot, ref_aff, tgt_aff, tgt_pose, tgt_img, pose_ref_inds, pose_tgt_inds, landmark_inds, dzdP, H, g,
               err_out, uvec=None, pixidx=None, invz=None, kt_slot_stride=0, chunks=None, phase=0xFF, want_pj=False,
               want_blocks=False, sigma_out=None, pix_range=None, reduce_hists=None, events=None, anorm_f32=False,
-              grp_pairs=None, single_pairs=None):
+              grp_pairs=None, single_pairs=None, zeroed_hists=None):
     """Thin marshalling layer over como_ba_linearize_* (see include/como_hip.h for every field).
 
     pix_range=(begin, end): this rank's share of the reference pixels of every pair (multi-GPU shard).
@@ -73,7 +73,8 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     a.h_is_f64 = 1 if H.dtype == torch.float64 else 0
     ws_r = _buf("r", (b, nl), dtype, dev)
     ws_valid = _buf("valid", (b, nl), torch.uint8, dev)
-    ws_hists = _buf("hists", (L.como_select_workspace_bytes() // 4,), torch.int32, dev)
+    # zeroed_hists: caller-owned select workspace that is ALREADY zero (the fused window path clears it elsewhere)
+    ws_hists = zeroed_hists if zeroed_hists is not None else _buf("hists", (L.como_select_workspace_bytes() // 4,), torch.int32, dev)
     ws_pair = _buf("pair", (b * 14,), dtype, dev)
     ws_part = _buf("partials", (L.como_ba_partials_elems(b, chunks, m),), dtype, dev)
     if sigma_out is None:
@@ -101,7 +102,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     stream = _lib.stream_ptr(dev)
 
     def run(ph):
-        a.phase = ph
+        a.phase = ph | (256 if zeroed_hists is not None else 0)
         _lib.check(fn(ctypes.byref(a), stream), "como_ba_linearize")
 
     if reduce_hists is None and events is None:
@@ -228,7 +229,7 @@ class PairTable:
 
 def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uvec, Kt, pixidx, invz, dzdP, img_base, K,
                           H_img, W_img, H, g, err_out, chunks=None, phase=0xFF, sigma_out=None, pix_range=None,
-                          reduce_hists=None, events=None):
+                          reduce_hists=None, events=None, zeroed_hists=None):
     """Fast path: same normal equations as batch_photo_cost from the rank-1 factors of dPwn_dzm.
     Per-keyframe arrays (slots = keyframes): Pwn (B,n,3) vals (B,n) dPwn_dTwc (B,n,3,6) uvec (B,n,3) invz (B,m)
     Kt (B,rows,m) dense predictor, pixidx (B,n) int32 rows of Kt (None = identity), dzdP (B,3)."""
@@ -241,4 +242,5 @@ def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uv
                      tgt_img=table.tgt_img, pose_ref_inds=table.pose_ref_inds, pose_tgt_inds=table.pose_tgt_inds,
                      landmark_inds=table.landmark_inds, dzdP=dzdP, H=H, g=g, err_out=err_out, chunks=chunks,
                      phase=phase, sigma_out=sigma_out, pix_range=pix_range, reduce_hists=reduce_hists, events=events,
-                     grp_pairs=(table.grp_pairs if vals.dtype == torch.float32 else None), single_pairs=table.single_pairs)
+                     grp_pairs=(table.grp_pairs if vals.dtype == torch.float32 else None), single_pairs=table.single_pairs,
+                     zeroed_hists=zeroed_hists)

@@ -174,6 +174,13 @@ class WindowBA:
         sg = self.cfg["sigmas"]
         a.s_gp, a.s_ld, a.s_px, a.s_pose, a.s_aff, a.s_lm = 1.0, 1.0, 1e-2, sg["pose_prior"], sg["scale_prior"], sg["scale_prior"]
         a.H, a.g, a.err = ptr(self.H), ptr(self.g), ptr(self.prior_err)
+        # the two radix-select workspaces of an iteration are cleared by the scaffold kernel (no fill launches)
+        hb = _lib.lib().como_select_workspace_bytes()
+        self.w["hist_dr"] = torch.zeros(B * hb // 4, dtype=torch.int32, device=self.dev)
+        self.w["hist_ba"] = torch.zeros(hb // 4, dtype=torch.int32, device=self.dev)
+        a.zero_a, a.zero_a_bytes = ptr(self.w["hist_dr"]), B * hb
+        a.zero_b, a.zero_b_bytes = ptr(self.w["hist_ba"]), hb
+        a.median_out = ptr(self.median_depths)
         self.win_args = a
 
     # ---- fused HIP chain -----------------------------------------------------------------------------------------
@@ -182,19 +189,18 @@ class WindowBA:
         s = _lib.stream_ptr(dev)
         _lib.check(L.como_win_scaffold(ctypes.byref(a), s), "como_win_scaffold")
         Pwn, dT, uvec, med, _ = dense_reference_factored(w["px_logzm"], w["px_poses"][:self.B], self.Kt, self.pixidx, self.K_pix,
-                                                         w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"])
+                                                         w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"],
+                                                         hists=w["hist_dr"])
         self.sys.zero_()
-        self.prior_err.zero_()
         photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=Pwn, vals=self.vals_n,
                                     dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],
                                     img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=self.H, g=self.g,
                                     err_out=self.err, sigma_out=self.sigma, pix_range=self.pix_range,
                                     reduce_hists=(self.shard.all_reduce_sum if self.shard is not None else None),
-                                    events=self.events)
+                                    events=self.events, zeroed_hists=w["hist_ba"])
         if self.shard is not None:
             self.shard.all_reduce_sum(self.sys)          # normal equations of all shards: H | g | err in one collective
-        _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")
-        self.median_depths.copy_(med)
+        _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")   # also stores the new median depths
         return self.H, self.g
 
     def iterate_fused(self):

@@ -75,7 +75,8 @@ typedef struct como_ba_args {
   int zmode;                 /* 0: zjac = dPwn_dzm (slots,n,3,m) as photo.py:92 receives it
                                 1: factored: zjac = K~ rows (slot, row, m); dPwn_dzm[n,:,k] = uvec[n,:] K~[pix(n),k] invz[k] */
   int chunks;                /* pixel chunks per pair (grid.x of the block kernel); partial records = b*chunks */
-  int phase;                 /* bit mask: 1 setup+residual(+hist pass 0), 2<<(p-1) hist pass p>=1, 64 blocks, 128 reduce+assemble */
+  int phase;                 /* bit mask: 1 setup+residual(+hist pass 0), 2<<(p-1) hist pass p>=1, 64 blocks, 128 reduce+assemble,
+                                256 = ws_hists is already zero (skip the clear) */
   int h_is_f64;              /* element type of Hmat / gvec: 1 = double, 0 = float */
   int variant;               /* zmode 1 only: 0 = software-pipelined block kernels (float32; default; two-pair kernel where
                                 grp_pairs lists pairs), 1 = straightforward one, 2 = pipelined one-pair kernel only */
@@ -168,15 +169,16 @@ int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, cons
  * logz_m(T_wc)], uvec (B,3,n) = R_wc ray z_n, zbuf (B,n) = depth, logzn_out (B,n) optional,
  * med_out3 (B,3) = {exact median depth (sparse_map.py:220), 1.4826*median, n}.  hists: B * select workspace.
  * pixcoord (B,n) optional: linear pixel index row*W+col of every reference pixel when it differs from its K~ row
- * (two-frame SfM passes K~ rows of the selected pixels only, two_frame_sfm.py:246-252); NULL = the K~ row index. */
+ * (two-frame SfM passes K~ rows of the selected pixels only, two_frame_sfm.py:246-252); NULL = the K~ row index.
+ * flags bit 0: hists is already zero (skip the clear). */
 int como_dense_ref_f32(const float* Kt, long kt_slot_stride, const int* pixidx, const float* logzm, const float* Twc,
                        const float* K, const float* dlogzm_dTwc, int B, int n, int m, int Wimg, float* Pwn,
                        float* dPwn_dTwc, float* uvec, float* zbuf, float* logzn_out, void* hists, float* med_out3,
-                       const int* pixcoord, como_stream_t stream);
+                       const int* pixcoord, int flags, como_stream_t stream);
 int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx, const double* logzm, const double* Twc,
                        const double* K, const double* dlogzm_dTwc, int B, int n, int m, int Wimg, double* Pwn,
                        double* dPwn_dTwc, double* uvec, double* zbuf, double* logzn_out, void* hists, double* med_out3,
-                       const int* pixcoord, como_stream_t stream);
+                       const int* pixcoord, int flags, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * DepthCov covariance-kernel assembly, Python-twin formula (python path: depth_cov/core/kernels.py:22-88,
@@ -236,6 +238,9 @@ typedef struct como_win_args {
   void* px_logzm; void* px_invz; void* px_dzdP; void* px_dlogz_dT; void* px_poses; void* px_aff;
   double s_gp, s_ld, s_px, s_pose, s_aff, s_lm;   /* sigmas: 1, 1, 1e-2, cfg pose_prior, cfg scale_prior, cfg scale_prior */
   double* H; double* g; double* err;              /* err: 8 doubles {gp, log-depth, pixel, pose, affine, landmarks, -, -} */
+  void* zero_a; long zero_a_bytes;                /* optional: two buffers (multiples of 16 bytes) that como_win_scaffold clears */
+  void* zero_b; long zero_b_bytes;                /*   together with err -- the radix-select histograms of this iteration */
+  double* median_out;                             /* optional (B): como_win_priors stores median_new here (next iteration's `median`) */
 } como_win_args;
 
 int como_win_scaffold(const como_win_args* args_host, como_stream_t stream);
