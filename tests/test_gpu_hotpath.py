@@ -636,3 +636,102 @@ def test_fullsize_window_properties(window):
         wa.step()
         wb.iterate()
     assert (wa.kf_poses - wb.kf_poses).abs().max().item() < 1e-8  # unordered fp64 atomics only
+
+
+# ------------------------------------------------------------------------------------------------
+# Ragged and degenerate shapes: batch_photo_cost against the oracle on seeded random inputs
+def _random_ba_case(seed, B, b_pairs, n, m, H, W, dt, behind=None):
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64)
+    yy, xx = torch.meshgrid(torch.linspace(0, 3.1, H, dtype=torch.float64), torch.linspace(0, 4.2, W, dtype=torch.float64), indexing="ij")
+    imgs = []
+    for k in range(B):
+        I = 0.5 + 0.3 * torch.sin(2.0 * xx + 0.7 * k) * torch.cos(1.5 * yy - 0.3 * k) + 0.1 * torch.sin(5 * xx * yy / 4)
+        gx = torch.zeros_like(I); gy = torch.zeros_like(I)
+        gx[:, 1:-1] = 0.5 * (I[:, 2:] - I[:, :-2]); gy[1:-1] = 0.5 * (I[2:] - I[:-2])
+        imgs.append(torch.stack((I, gx, gy)))
+    iag = torch.stack(imgs)
+    K = torch.tensor([[0.9 * W, 0, (W - 1) / 2], [0, 0.9 * W, (H - 1) / 2], [0, 0, 1]], dtype=torch.float64)
+    poses = torch.eye(4, dtype=torch.float64).repeat(B, 1, 1)
+    poses[:, :3, 3] = 0.02 * rnd(B, 3)
+    u = torch.rand(B, n, generator=g, dtype=torch.float64) * (W - 1)
+    v = torch.rand(B, n, generator=g, dtype=torch.float64) * (H - 1)
+    z = 1.0 + 0.3 * torch.rand(B, n, generator=g, dtype=torch.float64)
+    Pw = torch.stack(((u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z), -1)
+    if behind is not None:
+        Pw[behind] = Pw[behind] * torch.tensor([1.0, 1.0, -1.0], dtype=torch.float64)      # a whole keyframe behind every camera
+    ref = torch.arange(b_pairs) % B
+    tgt = (ref + 1 + (torch.arange(b_pairs) // B)) % B
+    D = 8 * B + 3 * m * B
+    kf_inds = torch.arange(8 * B).reshape(B, 8)
+    lm = 8 * B + torch.arange(3 * m * B).reshape(B, 3 * m)
+    c = lambda t: t.to(dt)
+    return {"vals": c(torch.rand(B, n, 1, generator=g, dtype=torch.float64)), "aff": c(0.05 * rnd(B, 2, 1)), "Pwn": c(Pw), "poses": c(poses),
+            "iag": c(iag), "dT": c(rnd(B, n, 3, 6)), "dz": c(0.3 * rnd(B, n, 3, m, 1)), "dzdP": c(rnd(B, 1, 1, 3)), "K": c(K),
+            "kf_inds": kf_inds, "lm": lm, "ref": ref, "tgt": tgt, "D": D}
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, b_pairs=1, n=1, m=4, H=9, W=11),                     # one pixel, one pair, smallest m
+    dict(B=3, b_pairs=4, n=1003, m=12, H=37, W=53),                # nothing a multiple of 64 / 256
+    dict(B=3, b_pairs=6, n=257, m=64, H=16, W=24),                 # full m, a target visited twice
+    dict(B=3, b_pairs=4, n=300, m=8, H=20, W=31, behind=1),        # every pixel of keyframe 1 invalid in its pairs
+])
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_batch_photo_cost_ragged_vs_oracle(case, dt):
+    import como_amd.odom.backend.photo as photo
+    from oracle import photo_ba
+    case = dict(case)
+    C = _random_ba_case(17, dt=dt, **case)
+    r, t = C["ref"], C["tgt"]
+    args = lambda f: (f(C["vals"][r]), f(C["aff"][r]), f(C["Pwn"][r]), f(C["poses"][t]), f(C["aff"][t]), f(C["iag"][t]), f(C["dT"][r]),
+                      f(C["dz"][r]), f(C["dzdP"][r]), f(C["kf_inds"][r]), f(C["kf_inds"][t]), f(C["lm"][r]), f(C["K"]))
+    D = C["D"]
+    Ho, go = torch.zeros((D, D), dtype=dt), torch.zeros(D, dtype=dt)
+    eo, aux_o = photo_ba.batch_photo_cost(*args(lambda x: x), Ho, go, return_aux=True)
+    H, g = torch.zeros((D, D), dtype=dt, device=DEV), torch.zeros(D, dtype=dt, device=DEV)
+    e = photo.batch_photo_cost(*args(dev), H, g)
+    valid = photo.last_aux["valid"].cpu().bool()
+    nvalid = int(aux_o["valid"].sum())
+    report("ba_ragged", case=str(case), dtype=str(dt), nvalid=nvalid, mask_mismatch=int((valid != aux_o["valid"]).sum()),
+           H_rel=rel_err(H, Ho) if nvalid else 0.0)
+    assert torch.equal(valid, aux_o["valid"])                          # masks bit-exact, whatever the shape
+    assert torch.isfinite(H).all() and torch.isfinite(g).all()
+    if nvalid == 0:
+        assert H.abs().max().item() == 0.0 and g.abs().max().item() == 0.0
+    else:
+        tol = 1e-9 if dt == torch.float64 else 3e-4
+        assert rel_err(H, Ho) < tol and rel_err(g, go) < tol
+        assert abs(float(e) - float(eo)) <= tol * abs(float(eo))
+
+
+@pytest.mark.parametrize("N,H,W", [(1, 9, 11), (63, 20, 31), (1003, 37, 53), (4099, 48, 64)])
+def test_tracking_iter_ragged_vs_oracle(N, H, W):
+    """tracking_iter on odd pixel counts / image sizes against the oracle (float32): mask bit-exact, delta within 2e-4."""
+    import como_amd.odom.frontend.photo_tracking as pt
+    from oracle import tracking as otrk
+    g = torch.Generator().manual_seed(N)
+    yy, xx = torch.meshgrid(torch.linspace(0, 3.1, H), torch.linspace(0, 4.2, W), indexing="ij")
+    img = (0.5 + 0.3 * torch.sin(2.0 * xx) * torch.cos(1.5 * yy) + 0.1 * torch.sin(5 * xx * yy / 4)).float()
+    K = torch.tensor([[0.9 * W, 0, (W - 1) / 2], [0, 0.9 * W, (H - 1) / 2], [0, 0, 1]])
+    u = torch.rand(N, generator=g) * (W + 4) - 2                     # some points project outside the image
+    v = torch.rand(N, generator=g) * (H + 4) - 2
+    z = 1.0 + 0.3 * torch.rand(N, generator=g)
+    P = torch.stack(((u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z), -1)
+    if N > 2:
+        P[1, 2] = -P[1, 2]                                           # one point behind the camera
+    vals = torch.rand(N, generator=g)
+    J = torch.randn(N, 8, generator=g)
+    T = torch.eye(4)
+    T[:3, 3] = torch.tensor([0.01, -0.02, 0.005])
+    o = otrk.tracking_iter(T, P, K, img, torch.tensor([0.02, -0.01]), vals, J.clone())
+    if not bool(o["valid"].any()):
+        pytest.skip("no valid pixel in this draw")
+    out = pt.tracking_iter(dev(T[None]), dev(P[None]), dev(K), dev(img[None, None]), dev(torch.tensor([0.02, -0.01]).reshape(1, 2, 1)),
+                           dev(vals[None, :, None]), dev(J[None, :, None, :].clone()), 0.1, None)
+    Tn, an, delta, mse, gn, pj, valid, depth = out
+    assert torch.equal(valid[0].cpu(), o["valid"])
+    nv = int(o["valid"].sum())
+    if nv >= 8 and torch.isfinite(o["delta"]).all():                 # fewer valid rows than unknowns: singular in the reference too
+        assert rel_err(delta[0, :, 0], o["delta"]) < 2e-3
+        assert abs(float(mse) - float(o["mse"])) <= 1e-4 * abs(float(o["mse"])) + 1e-7
