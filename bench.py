@@ -134,8 +134,8 @@ def main():
     for _ in range(args.warmup):
         wb.iterate()
     graphed = (not args.eager) and wb.capture()
-    if not graphed and not args.eager and shard.rank == 0:
-        print("hipGraph capture failed:", getattr(wb, "capture_error", "multi-GPU path is eager"), file=sys.stderr)
+    if not graphed and not args.eager and shard.rank == 0 and shard.world == 1:
+        print("hipGraph capture failed:", getattr(wb, "capture_error", "?"), file=sys.stderr)
     shard.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -52,6 +52,9 @@ def init_from_env(backend=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     use_cuda = torch.cuda.is_available()
+    if os.environ.get("COMO_SINGLE_DEVICE") == "1":       # test rigs with one GPU: every rank on device 0 (needs gloo)
+        local = 0
+    backend = backend or os.environ.get("COMO_DIST_BACKEND") or None
     device = torch.device(f"cuda:{local}") if use_cuda else torch.device("cpu")
     if use_cuda:
         torch.cuda.set_device(device)
