@@ -293,23 +293,44 @@ __global__ __launch_bounds__(256) void kernel_matrix_py_kernel(const T* __restri
       kernel_py(a[0], a[1], E1 + ((long)b * N + i) * 4, c[0], c[1], E2 + ((long)b * M + j) * 4) * scale;
 }
 
-// K~ rows for every photo pixel: thread = pixel; k_nm (m values) in registers, then the m x m product with
-// K_mm^-1 staged in LDS.  m <= 64.
+// K~ rows for every photo pixel on the matrix cores.  One wave owns 16 pixels per trip: lane (px = l & 15, kq = l >> 4)
+// evaluates the 16 kernel values k(pixel px, inducing point 4 s + kq), s = 0..15 -- which is exactly the A-operand layout of
+// the 16x16x4 MFMA (row = l & 15, k = l >> 4) -- and multiplies by K_mm^-1 (B operand from LDS: one ds_read per MFMA
+// instead of one per FMA: the thread-per-pixel version issued 4096 broadcast LDS reads per pixel and was LDS-bound).
+// m <= 64; float32 and float64 (v_mfma_f64_16x16x4_f64).
+template <typename T> struct KAcc { typedef T type __attribute__((ext_vector_type(4))); };
+__device__ __forceinline__ typename KAcc<float>::type k_mfma(float a, float b, typename KAcc<float>::type c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ typename KAcc<double>::type k_mfma(double a, double b, typename KAcc<double>::type c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+template <typename T> __device__ __forceinline__ int k_mfma_row(int lane, int reg);          // C/D row of (lane, register)
+template <> __device__ __forceinline__ int k_mfma_row<float>(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+template <> __device__ __forceinline__ int k_mfma_row<double>(int lane, int reg) { return (lane >> 4) + 4 * reg; }
+
 template <typename T>
 __global__ __launch_bounds__(256) void ktilde_kernel(const T* __restrict__ cov, int Hc, int Wc, const T* __restrict__ xm,
                                                      const T* __restrict__ Em, const T* __restrict__ Kinv, T scale,
                                                      int Hp, int Wp, int m, T* __restrict__ out) {
-  __shared__ T sK[64 * 64];
+  using acc_t = typename KAcc<T>::type;
+  __shared__ T sK[64 * 65];                                // K_mm^-1, row stride 65 (zero-padded to 64 x 64)
   __shared__ T sx[64 * 2];
   __shared__ T sE[64 * 4];
   const int b = blockIdx.y;
-  for (int k = threadIdx.x; k < m * m; k += 256) sK[k] = Kinv[(long)b * m * m + k];
-  for (int k = threadIdx.x; k < m * 2; k += 256) sx[k] = xm[(long)b * m * 2 + k];
-  for (int k = threadIdx.x; k < m * 4; k += 256) sE[k] = Em[(long)b * m * 4 + k];
+  for (int k = threadIdx.x; k < 64 * 64; k += 256) {
+    const int r = k >> 6, c = k & 63;
+    sK[r * 65 + c] = (r < m && c < m) ? Kinv[(long)b * m * m + (long)r * m + c] : T(0);
+  }
+  for (int k = threadIdx.x; k < 64 * 2; k += 256) sx[k] = (k < m * 2) ? xm[(long)b * m * 2 + k] : T(0);
+  for (int k = threadIdx.x; k < 64 * 4; k += 256) sE[k] = (k < m * 4) ? Em[(long)b * m * 4 + k] : ((k & 3) == 0 || (k & 3) == 3 ? T(1) : T(0));
   __syncthreads();
   const long np = (long)Hp * Wp;
   const T ar = T(1) / T(Hc), ac = T(1) / T(Wc);
-  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < np; p += (long)gridDim.x * 256) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, px = lane & 15, kq = lane >> 4;
+  const long groups = (np + 15) / 16;
+  for (long grp = (long)blockIdx.x * 4 + wv; grp < groups; grp += (long)gridDim.x * 4) {
+    const long p = min(grp * 16 + px, np - 1);
     const int row = (int)(p / Wp), col = (int)(p % Wp);
     T rn, cn;
     {
@@ -319,15 +340,25 @@ __global__ __launch_bounds__(256) void ktilde_kernel(const T* __restrict__ cov, 
     }
     T En[4];
     cov_lookup(cov + (long)b * 4 * Hc * Wc, Hc, Wc, rn, cn, En);
-    T kn[64];
-#pragma unroll 4
-    for (int j = 0; j < 64; ++j) kn[j] = (j < m) ? kernel_py(rn, cn, En, sx[2 * j], sx[2 * j + 1], sE + 4 * j) * scale : T(0);
-    T* o = out + ((long)b * np + p) * m;
-    for (int j = 0; j < m; ++j) {
-      T s = T(0);
+    T a[16];
 #pragma unroll
-      for (int k = 0; k < 64; ++k) s += kn[k] * ((k < m) ? sK[k * m + j] : T(0));
-      o[j] = s;
+    for (int s2 = 0; s2 < 16; ++s2) {
+      const int k = 4 * s2 + kq;
+      const T v = kernel_py(rn, cn, En, sx[2 * k], sx[2 * k + 1], sE + 4 * k) * scale;
+      a[s2] = (k < m) ? v : T(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (16 * t >= m) break;
+      acc_t acc = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+      for (int s2 = 0; s2 < 16; ++s2) acc = k_mfma(a[s2], sK[(4 * s2 + kq) * 65 + 16 * t + px], acc);
+      const int j = 16 * t + px;                        // here l & 15 is the output column
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long pr = grp * 16 + k_mfma_row<T>(lane, r);
+        if (pr < np && j < m) out[((long)b * np + pr) * m + j] = acc[r];
+      }
     }
   }
 }
@@ -401,8 +432,8 @@ int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx,
   int como_ktilde_##SFX(const T* cov, int Hc, int Wc, const T* xm, const T* Em, const T* Kinv, T scale, int B, int Hp,   \
                         int Wp, int m, T* out, como_stream_t stream) {                                                 \
     if (!cov || !xm || !Em || !Kinv || !out || B <= 0 || m <= 0 || m > 64 || Hp <= 0 || Wp <= 0) return COMO_ERR_ARG;  \
-    long blocks = ((long)Hp * Wp + 255) / 256;                                                                         \
-    if (blocks > 1024) blocks = 1024;                                                                                  \
+    long blocks = ((long)Hp * Wp + 63) / 64;                                                                           \
+    if (blocks > 2048) blocks = 2048;                                                                                  \
     hipLaunchKernelGGL(como::ktilde_kernel<T>, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, cov, Hc,   \
                        Wc, xm, Em, Kinv, scale, Hp, Wp, m, out);                                                       \
     COMO_CHECK_LAUNCH();                                                                                               \
