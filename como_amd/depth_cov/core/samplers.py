@@ -29,6 +29,12 @@ def get_cov_domain(coord_vec, cov_params_img):
     return torch.permute(vec, (0, 2, 1)).reshape(b, -1, 2, 2).contiguous()
 
 
+def random_uniform(n, coords_domain_norm):
+    """samplers.py:110-114"""
+    weights = torch.ones(coords_domain_norm.shape[:-1], device=coords_domain_norm.device)
+    return torch.multinomial(weights, n, replacement=False)
+
+
 def get_obs_info(L, K_mn):
     return torch.linalg.solve_triangular(L, K_mn, upper=False)
 
@@ -161,8 +167,7 @@ def sample_sparse_coords(cov_params_img, num_samples, mode, max_stdev_thresh=-1e
         cdn = normalize_coordinates(coords_domain, img_size).to(dtype)
         E_domain = gk.interpolate_kernel_params(cov, cdn)
     if mode == "random_uniform":
-        w = torch.ones(cdn.shape[:-1], device=dev)
-        inds = torch.multinomial(w, num_samples - curr_coords.shape[-2], replacement=False)
+        inds = random_uniform(num_samples - curr_coords.shape[-2], cdn)
     elif mode == "greedy_conditional_entropy":
         n = min(num_samples, coords_domain.shape[1])
         ccn = normalize_coordinates(curr_coords, img_size).to(dtype)
