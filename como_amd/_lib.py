@@ -94,6 +94,10 @@ SIGNATURES = {
     "como_img_grads_f64": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "como_img_blur_down_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
     "como_img_blur_down_f64": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
+    "como_img_blur_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
+    "como_img_blur_f64": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
+    "como_depth_pool2_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
+    "como_depth_pool2_f64": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "como_subselect_pixels_f32": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p] * 3),
     "como_subselect_pixels_f64": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p] * 3),
     "como_track_precalc_jac_f32": (c_int, [c_void_p] * 5 + [c_long, c_void_p]),

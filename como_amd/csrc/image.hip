@@ -53,6 +53,56 @@ __global__ __launch_bounds__(256) void blur_down_kernel(const T* __restrict__ im
            k2 * (p[(long)ym * W + x] + p[(long)y * W + xm] + p[(long)y * W + xp] + p[(long)yp * W + x]) + k4 * p[(long)y * W + x];
 }
 
+
+// [1 2 1]^2/16 blur, reflect padding, no decimation (GaussianBlurModule.forward, image_processing.py:60-65)
+template <typename T>
+__global__ __launch_bounds__(256) void blur_kernel(const T* __restrict__ img, T* __restrict__ out, int H, int W, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % W), y = (int)((i / W) % H);
+  const long nc = i / ((long)W * H);
+  const T* p = img + nc * H * W;
+  const int xm = reflect1(x - 1, W), xp = reflect1(x + 1, W), ym = reflect1(y - 1, H), yp = reflect1(y + 1, H);
+  const T k1 = T(1) / T(16), k2 = T(2) / T(16), k4 = T(4) / T(16);
+  out[i] = k1 * (p[(long)ym * W + xm] + p[(long)ym * W + xp] + p[(long)yp * W + xm] + p[(long)yp * W + xp]) +
+           k2 * (p[(long)ym * W + x] + p[(long)y * W + xm] + p[(long)y * W + xp] + p[(long)yp * W + x]) + k4 * p[(long)y * W + x];
+}
+
+// pyr_depth (como/data/depth_resize.py:6-36), kernel_size = stride = 2: mode 0 bilinear (2x2 mean), 1 nearest_neighbor,
+// 2 max, 3 min, 4 masked_bilinear (mean over the non-NaN entries, 0 if there are none)
+template <typename T>
+__global__ __launch_bounds__(256) void depth_pool2_kernel(const T* __restrict__ in, T* __restrict__ out, int H, int W, int mode,
+                                                          long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int Ho = (mode == 1) ? (H + 1) / 2 : H / 2, Wo = (mode == 1) ? (W + 1) / 2 : W / 2;
+  const int x = (int)(i % Wo), y = (int)((i / Wo) % Ho);
+  const long nc = i / ((long)Wo * Ho);
+  const T* p = in + nc * H * W + (long)(2 * y) * W + 2 * x;
+  if (mode == 1) { out[i] = p[0]; return; }
+  const T a = p[0], b = p[1], c = p[W], d = p[W + 1];
+  T v;
+  if (mode == 0) v = (((a + b) + c) + d) / T(4);
+  else if (mode == 2 || mode == 3) {                       // max_pool2d semantics: a NaN in the window wins
+    const T sgn = (mode == 2) ? T(1) : T(-1);
+    const T e[4] = {sgn * a, sgn * b, sgn * c, sgn * d};
+    T mx = e[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+      if (e[k] > mx || e[k] != e[k]) mx = e[k];
+    v = sgn * mx;
+  }
+  else {
+    const T e[4] = {a, b, c, d};
+    T sum = T(0), cnt = T(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (e[k] == e[k]) { sum += e[k]; cnt += T(1); }
+    v = cnt > T(0) ? sum / cnt : T(0);
+  }
+  out[i] = v;
+}
+
 // One thread per window cell: first maximum of sqrt(gx^2 + gy^2) in row-major scan (max_pool2d semantics).
 // img_and_grads (B, 3, H, W) gray; coords (B, n, 2) int64 (row, col); pixidx (B, n) int32 = row*W + col (may be NULL).
 template <typename T>
@@ -124,6 +174,23 @@ extern "C" {
     const long total = (long)NC * Ho * Wo;                                                                             \
     hipLaunchKernelGGL(como::blur_down_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,                 \
                        (hipStream_t)stream, img, out, H, W, Ho, Wo, total);                                            \
+    COMO_CHECK_LAUNCH();                                                                                               \
+    return COMO_OK;                                                                                                    \
+  }                                                                                                                    \
+  int como_img_blur_##SFX(const T* img, T* out, int NC, int H, int W, como_stream_t stream) {                          \
+    if (!img || !out || NC <= 0 || H < 2 || W < 2) return COMO_ERR_ARG;                                                \
+    const long total = (long)NC * H * W;                                                                               \
+    hipLaunchKernelGGL(como::blur_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,  \
+                       img, out, H, W, total);                                                                         \
+    COMO_CHECK_LAUNCH();                                                                                               \
+    return COMO_OK;                                                                                                    \
+  }                                                                                                                    \
+  int como_depth_pool2_##SFX(const T* in, T* out, int NC, int H, int W, int mode, como_stream_t stream) {              \
+    if (!in || !out || NC <= 0 || H < 2 || W < 2 || mode < 0 || mode > 4) return COMO_ERR_ARG;                         \
+    const int Ho = (mode == 1) ? (H + 1) / 2 : H / 2, Wo = (mode == 1) ? (W + 1) / 2 : W / 2;                          \
+    const long total = (long)NC * Ho * Wo;                                                                             \
+    hipLaunchKernelGGL(como::depth_pool2_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,               \
+                       (hipStream_t)stream, in, out, H, W, mode, total);                                               \
     COMO_CHECK_LAUNCH();                                                                                               \
     return COMO_OK;                                                                                                    \
   }                                                                                                                    \

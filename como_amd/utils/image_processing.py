@@ -1,7 +1,7 @@
 """Image gradients and pyramids on the HIP kernels of csrc/image.hip.
 
 Mirror of como/utils/image_processing.py (ImageGradientModule :8-44, GaussianBlurModule :47-65, ImagePyramidModule :68-87,
-IntrinsicsPyramidModule :109-123): same class names, constructor arguments and call results.  GPU tensors only.
+IntrinsicsPyramidModule :109-123, DepthPyramidModule :90-106 with pyr_depth of como/data/depth_resize.py): same class names, constructor arguments and call results.  GPU tensors only.
 """
 import torch
 
@@ -29,6 +29,64 @@ def blur_down(img):
     fn = getattr(_lib.lib(), "como_img_blur_down_" + _lib.suffix(img.dtype))
     _lib.check(fn(img.data_ptr(), out.data_ptr(), N * C, H, W, _lib.stream_ptr(img.device)), "como_img_blur_down")
     return out
+
+
+def blur(img):
+    """GaussianBlurModule.forward (image_processing.py:60-65)."""
+    _lib.require_cuda(img)
+    img = img.contiguous()
+    N, C, H, W = img.shape
+    out = torch.empty_like(img)
+    fn = getattr(_lib.lib(), "como_img_blur_" + _lib.suffix(img.dtype))
+    _lib.check(fn(img.data_ptr(), out.data_ptr(), N * C, H, W, _lib.stream_ptr(img.device)), "como_img_blur")
+    return out
+
+
+_DEPTH_MODES = {"bilinear": 0, "nearest_neighbor": 1, "max": 2, "min": 3, "masked_bilinear": 4}
+
+
+def pyr_depth(depth, mode, kernel_size=2):
+    """como/data/depth_resize.py:6-36 (factors of 2 only, as the reference notes)."""
+    if kernel_size != 2:
+        raise ValueError("pyr_depth: kernel_size 2 only")
+    if mode not in _DEPTH_MODES:
+        raise ValueError("pyr_depth mode: " + mode + " is not implemented.")
+    _lib.require_cuda(depth)
+    depth = depth.contiguous()
+    N, C, H, W = depth.shape
+    md = _DEPTH_MODES[mode]
+    Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if md == 1 else (H // 2, W // 2)
+    out = torch.empty((N, C, Ho, Wo), dtype=depth.dtype, device=depth.device)
+    fn = getattr(_lib.lib(), "como_depth_pool2_" + _lib.suffix(depth.dtype))
+    _lib.check(fn(depth.data_ptr(), out.data_ptr(), N * C, H, W, md, _lib.stream_ptr(depth.device)), "como_depth_pool2")
+    return out
+
+
+class GaussianBlurModule:
+    def __init__(self, channels, device, dtype):
+        self.channels = channels
+
+    def __call__(self, x):
+        return blur(x)
+
+    forward = __call__
+
+
+class DepthPyramidModule:
+    def __init__(self, start_level, end_level, mode, device):
+        self.start_level, self.end_level, self.mode = start_level, end_level, mode
+
+    def __call__(self, x):
+        pyr = []
+        lvl = x
+        for i in range(self.end_level - 1):
+            if i >= self.start_level:
+                pyr.insert(0, lvl)
+            lvl = pyr_depth(lvl, self.mode, kernel_size=2)
+        pyr.insert(0, lvl)
+        return pyr
+
+    forward = __call__
 
 
 class ImageGradientModule:

@@ -294,6 +294,12 @@ int como_img_grads_f32(const float* img, float* out, int N, int C, int H, int W,
 int como_img_grads_f64(const double* img, double* out, int N, int C, int H, int W, como_stream_t stream);
 int como_img_blur_down_f32(const float* img, float* out, int NC, int H, int W, como_stream_t stream);
 int como_img_blur_down_f64(const double* img, double* out, int NC, int H, int W, como_stream_t stream);
+/* img_blur: the same blur without decimation (GaussianBlurModule); depth_pool2: pyr_depth (como/data/depth_resize.py:6-36)
+ * with kernel_size 2, mode 0 bilinear, 1 nearest_neighbor, 2 max, 3 min, 4 masked_bilinear. */
+int como_img_blur_f32(const float* img, float* out, int NC, int H, int W, como_stream_t stream);
+int como_img_blur_f64(const double* img, double* out, int NC, int H, int W, como_stream_t stream);
+int como_depth_pool2_f32(const float* in, float* out, int NC, int H, int W, int mode, como_stream_t stream);
+int como_depth_pool2_f64(const double* in, double* out, int NC, int H, int W, int mode, como_stream_t stream);
 int como_subselect_pixels_f32(const float* img_and_grads, int B, int H, int W, int window, long* coords, int* pixidx,
                               como_stream_t stream);
 int como_subselect_pixels_f64(const double* img_and_grads, int B, int H, int W, int window, long* coords, int* pixidx,

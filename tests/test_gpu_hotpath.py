@@ -735,3 +735,33 @@ def test_tracking_iter_ragged_vs_oracle(N, H, W):
     if nv >= 8 and torch.isfinite(o["delta"]).all():                 # fewer valid rows than unknowns: singular in the reference too
         assert rel_err(delta[0, :, 0], o["delta"]) < 2e-3
         assert abs(float(mse) - float(o["mse"])) <= 1e-4 * abs(float(o["mse"])) + 1e-7
+
+
+def test_blur_and_depth_pyramid_vs_torch():
+    """GaussianBlurModule / DepthPyramidModule (pyr_depth, every mode) against the torch formulas of the reference."""
+    import torch.nn.functional as F
+    from como_amd.utils import image_processing as ip
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(2, 1, 37, 52, generator=g, dtype=torch.float64)
+    k = (1.0 / 16.0) * torch.tensor([[1.0, 2.0, 1.0], [2.0, 4.0, 2.0], [1.0, 2.0, 1.0]], dtype=torch.float64).view(1, 1, 3, 3)
+    ref = F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), k)
+    assert rel_err(ip.GaussianBlurModule(1, DEV, torch.float64)(dev(x)), ref) < 1e-14
+    assert rel_err(ip.blur(dev(x.float())), ref) < 2e-6
+    d = torch.rand(1, 1, 48, 64, generator=g) * 3 + 0.5
+    d[0, 0, 10:20, 5:9] = float("nan")
+    d[0, 0, 30:32, 40:42] = float("nan")                         # a fully-NaN 2x2 cell
+    refs = {"nearest_neighbor": d[:, :, 0::2, 0::2], "max": F.max_pool2d(d, 2), "min": -F.max_pool2d(-d, 2)}
+    mask = ~d.isnan()
+    dm = torch.where(mask, d, torch.zeros_like(d))
+    s_ = F.avg_pool2d(dm, 2, 2, divisor_override=1)
+    c_ = F.avg_pool2d(mask.float(), 2, 2, divisor_override=1)
+    refs["masked_bilinear"] = torch.where(c_ > 0, s_ / c_, torch.tensor(0.0))
+    clean = torch.nan_to_num(d, nan=1.0)
+    for mode, ref in refs.items():
+        got = ip.pyr_depth(dev(d), mode).cpu()
+        both_nan = got.isnan() & ref.isnan()
+        assert torch.equal(got.isnan(), ref.isnan()), mode
+        assert ((got - ref).abs()[~both_nan].max() if (~both_nan).any() else 0) < 1e-6, mode
+    assert rel_err(ip.pyr_depth(dev(clean), "bilinear"), F.avg_pool2d(clean, 2, 2)) < 1e-6
+    pyr = ip.DepthPyramidModule(0, 3, "nearest_neighbor", DEV)(dev(clean))
+    assert [tuple(p.shape[-2:]) for p in pyr] == [(12, 16), (24, 32), (48, 64)]
