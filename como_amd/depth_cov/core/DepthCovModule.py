@@ -8,6 +8,7 @@ import math
 
 import torch
 
+from como_amd.depth_cov.core import covariance as cv
 from como_amd.depth_cov.nn import UNet as unet
 
 
@@ -21,12 +22,22 @@ class DepthCovModule:
         n = self.num_levels - 1
         self.scale_params = [float(state_dict.get(f"cov_modules.{i}.scale_param", 0.0)) for i in range(n)]
         self.log_depth_var_scales = [float(state_dict.get(f"log_depth_var_scales.{i}", 0.0)) for i in range(n)]
+        # the per-level module lists Mapping.prep_predictor / the sampler index (`model.cov_modules[level](...)`)
+        self.cov_modules = [cv.CovarianceModule(self.get_scale(i)) for i in range(n)]
+        self.cross_cov_modules = [cv.CrossCovarianceModule(self.get_scale(i)) for i in range(n)]
+        self.diagonal_cov_modules = [cv.DiagonalCovarianceModule(self.get_scale(i)) for i in range(n)]
 
     def get_var(self, level):
         return self.depth_var_prior * math.exp(self.log_depth_var_scales[level])
 
     def get_scale(self, level):
         return self.kernel_scale_prior * math.exp(self.scale_params[level])
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
 
     def forward(self, rgb):
         """(N,3,H,W) float in [0,1] -> list of 4 covariance images (N,4,h,w), coarse to fine (DepthCovModule.py:80-87)."""

@@ -29,6 +29,46 @@ def covariance(coords, E, scale):
     return kernel_matrix(coords, E, coords, E, scale)
 
 
+class CovarianceModule:
+    """covariance.py:10-26 with the scale resolved to a float: `module(coords, E)` -> (B,N,N)."""
+
+    def __init__(self, scale):
+        self.scale = float(scale)
+
+    def get_scale(self):
+        return self.scale
+
+    def __call__(self, coords, E):
+        return covariance(coords, E, self.scale)
+
+    forward = __call__
+
+
+class CrossCovarianceModule(CovarianceModule):
+    """covariance.py:28-39: `module(coords_train, E_train, coords_test, E_test)` -> (B,N,M)."""
+
+    def __call__(self, coords_train, E_train, coords_test, E_test):
+        return kernel_matrix(coords_train, E_train, coords_test, E_test, self.scale)
+
+    forward = __call__
+
+
+class DiagonalCovarianceModule(CovarianceModule):
+    """covariance.py:42-50 + kernels.py:69-88 (Q = 0): K_ii = scale * 2 sqrt(det E) / safe_sqrt(det 2E) * matern(0); O(n)
+    elementwise torch ops."""
+
+    def __call__(self, coords, E):
+        det = E[..., 0, 0] * E[..., 1, 1] - E[..., 0, 1] * E[..., 1, 0]
+        E2 = 2 * E
+        det2 = E2[..., 0, 0] * E2[..., 1, 1] - E2[..., 0, 1] * E2[..., 1, 0]
+        C = 2.0 * torch.sqrt(det) / torch.sqrt(det2 + 1e-8)
+        q = torch.sqrt(torch.zeros_like(C) + 1e-8)                          # safe_sqrt(0)
+        tmp = (3.0 ** 0.5) * q
+        return C * ((1 + tmp) * torch.exp(-tmp)) * self.scale
+
+    forward = __call__
+
+
 def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None):
     """Mapping.prep_predictor (Mapping.py:430-468): returns (K_mm_inv (B,m,m), L_mm (B,m,m), Knm_Kmminv (B,H,W,m)).
     K_nm (H*W x m per keyframe) is never materialised."""

@@ -765,3 +765,18 @@ def test_blur_and_depth_pyramid_vs_torch():
     assert rel_err(ip.pyr_depth(dev(clean), "bilinear"), F.avg_pool2d(clean, 2, 2)) < 1e-6
     pyr = ip.DepthPyramidModule(0, 3, "nearest_neighbor", DEV)(dev(clean))
     assert [tuple(p.shape[-2:]) for p in pyr] == [(12, 16), (24, 32), (48, 64)]
+
+
+def test_covariance_modules_vs_golden():
+    """model.cov_modules / cross_cov_modules / diagonal_cov_modules (the objects Mapping.prep_predictor indexes) against the
+    reference modules' float64 outputs."""
+    from como_amd.depth_cov.core.DepthCovModule import DepthCovModule
+    from como_amd.synth import depthcov_state_dict
+    C = load_golden("cov_ops_f32.npz")
+    model = DepthCovModule({k: dev(v) for k, v in depthcov_state_dict(0).items()})
+    x1, E1, x2, E2 = (dev(C[k].double()) for k in ("x1", "E1", "x2", "E2"))
+    K11 = model.cov_modules[-1](x1, E1)
+    K12 = model.cross_cov_modules[-1](x1, E1, x2, E2)
+    assert rel_err(K11, C["K11_py64"]) < 1e-7 and rel_err(K12, C["K12_py64"]) < 1e-7   # the twin casts coordinate differences to float32
+    kd = model.diagonal_cov_modules[-1](x1, E1)
+    assert rel_err(kd, torch.diagonal(C["K11_py64"], dim1=-2, dim2=-1)) < 1e-6      # k(x,x): Q = 0, safe_sqrt's 1e-8
