@@ -17,6 +17,7 @@ _DROPIN = {
     "como.odom.backend.robust_loss": "como_amd.odom.backend.robust_loss",
     "como.odom.frontend.photo_tracking": "como_amd.odom.frontend.photo_tracking",
     "como.depth_cov.core.samplers": "como_amd.depth_cov.core.samplers",
+    "como.depth_cov.core.distill_depth": "como_amd.depth_cov.core.distill_depth",
     "como.utils.image_processing": "como_amd.utils.image_processing",
     "como.odom.factors.gp_priors": "como_amd.odom.factors.gp_priors",
     "como.odom.factors.depth_prior": "como_amd.odom.factors.depth_prior",

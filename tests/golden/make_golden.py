@@ -418,9 +418,40 @@ def net_case(seed=0):
     return out
 
 
+def distill_case(seed=7):
+    """distill_depth_from_scratch / distill_conditional_depth_from_scratch of the reference (distill_depth.py:88-175) on a
+    synthetic covariance image and a smooth depth map, float32 as the tracker calls them."""
+    import como.depth_cov.core.distill_depth as rdd
+    from como.utils.coords import get_test_coords
+    H, W, m = 24, 32, 12
+    model = ref_model()
+    cov = synth.synthetic_cov_params(1, H, W, seed=seed, dtype=torch.float64).float()
+    g = torch.Generator().manual_seed(seed)
+    coords_n = get_test_coords((H, W), device="cpu", batch_size=1).float()
+    yy, xx = coords_n[0, :, 0], coords_n[0, :, 1]
+    z = (1.5 + 0.4 * torch.sin(xx / 7.0) * torch.cos(yy / 5.0)).reshape(1, -1, 1)
+    z[0, :5, 0] = 0.0                                              # a few invalid depths (below min_depth)
+    perm = torch.randperm(H * W, generator=g)[:m]
+    coords_m = coords_n[:, perm, :].clone() + 0.37                # off the pixel grid: the conditional variance stays > 0
+    out = {"cov": cov, "coords_m": coords_m, "coords_n": coords_n, "z_obs": z}
+    with torch.no_grad():
+        K_mm, K_nm, K_d = rdd.calc_kernel_matrices(coords_m, coords_n, cov, model)
+        Kt, L_mm, sinv = rdd.get_predictor(K_mm, K_nm, K_d)
+        out.update({"K_mm": K_mm, "K_nm": K_nm, "K_nn_diag": K_d, "Kt": Kt, "L_mm": L_mm, "stdev_inv": sinv})
+        for wp in (False, True):
+            lz, res = rdd.distill_depth_from_scratch(coords_m, coords_n, z, cov, model, wp, 0.1)
+            out[f"logz_m_prior{int(wp)}"] = lz
+            out[f"resid_prior{int(wp)}"] = res
+        z1 = torch.exp(out["logz_m_prior1"][:, :5, :])
+        out["logz_m2_cond"] = rdd.distill_conditional_depth_from_scratch(coords_m, z1, coords_n, cov, z, model, 0.1, 0.05)
+    return out
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net"]
+    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net", "distill"]
+    if "distill" in which:
+        save("distill_f32.npz", distill_case())
     if "net" in which:
         save("depthcov_net.npz", net_case(seed=0))
     if "ba" in which:

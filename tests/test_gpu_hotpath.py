@@ -780,3 +780,26 @@ def test_covariance_modules_vs_golden():
     assert rel_err(K11, C["K11_py64"]) < 1e-7 and rel_err(K12, C["K12_py64"]) < 1e-7   # the twin casts coordinate differences to float32
     kd = model.diagonal_cov_modules[-1](x1, E1)
     assert rel_err(kd, torch.diagonal(C["K11_py64"], dim1=-2, dim2=-1)) < 1e-6      # k(x,x): Q = 0, safe_sqrt's 1e-8
+
+
+def test_distill_depth_vs_golden():
+    """distill_depth.py mirror (kernel matrices from the HIP covariance modules) against the reference's outputs, float32."""
+    from como_amd.depth_cov.core import distill_depth as dd
+    from como_amd.depth_cov.core.DepthCovModule import DepthCovModule
+    from como_amd.synth import depthcov_state_dict
+    G = load_golden("distill_f32.npz")
+    model = DepthCovModule({k: dev(v) for k, v in depthcov_state_dict(0).items()})     # scales default to 1 as in ref_model()
+    cov, cm, cn, z = dev(G["cov"]), dev(G["coords_m"]), dev(G["coords_n"]), dev(G["z_obs"])
+    K_mm, K_nm, K_d = dd.calc_kernel_matrices(cm, cn, cov, model)
+    assert rel_err(K_mm, G["K_mm"]) < 2e-6 and rel_err(K_nm, G["K_nm"]) < 2e-6 and rel_err(K_d, G["K_nn_diag"]) < 2e-6
+    Kt, L_mm, sinv = dd.get_predictor(K_mm, K_nm, K_d)
+    assert rel_err(L_mm, G["L_mm"]) < 1e-4 and rel_err(Kt, G["Kt"]) < 2e-3          # K_mm^-1 in float32: conditioning
+    for wp in (0, 1):
+        lz, res = dd.distill_depth_from_scratch(cm, cn, z, cov, model, bool(wp), 0.1)
+        e = (lz.cpu() - G[f"logz_m_prior{wp}"]).abs().max().item()
+        report("distill", prior=wp, logz_abs_err=e)
+        assert e < (5e-3 if wp else 5e-2)                                           # un-regularised fit is ill-conditioned
+        assert tuple(res.shape) == tuple(G[f"resid_prior{wp}"].shape)
+    z1 = torch.exp(dev(G["logz_m_prior1"])[:, :5, :])
+    lz2 = dd.distill_conditional_depth_from_scratch(cm, z1, cn, cov, z, model, 0.1, 0.05)
+    assert (lz2.cpu() - G["logz_m2_cond"]).abs().max().item() < 5e-3
