@@ -77,7 +77,7 @@ __device__ __forceinline__ double rsq_refined(double d) {      // hardware estim
 // oC, oS: CB x CB doubles each; sq: CB doubles.
 __device__ __forceinline__ void factor_invert_tile(double (&v)[2][2], double* oC, double* oS, double* sq,
                                                    double* __restrict__ Lw, double* __restrict__ Iw, int Dp, int k, int D,
-                                                   int* __restrict__ info) {
+                                                   int* __restrict__ info, double* ldsInv = nullptr) {
   const int tid = threadIdx.x, role = tid >> 8, lt = tid & 255, tx = lt & 15, ty = lt >> 4;
   const long kk = (long)k * CB;
   if (role == 0) {
@@ -142,127 +142,254 @@ __device__ __forceinline__ void factor_invert_tile(double (&v)[2][2], double* oC
   for (int e = tid; e < CB * CB; e += 512) {
     const int r = e / CB, c = e % CB;
     if (c <= r) Lw[(kk + r) * Dp + kk + c] = oC[c * CB + r] * sq[c];
-    Iw[(long)k * CB * CB + e] = (c <= r) ? oS[e] * sq[r] : 0.0;
+    const double iv = (c <= r) ? oS[e] * sq[r] : 0.0;
+    Iw[(long)k * CB * CB + e] = iv;
+    if (ldsInv) ldsInv[r * CLD + c] = iv;                 // kept on chip for the second column of a column pair
   }
 }
 
-// Look-ahead blocked Cholesky.  chol_first: L_00, L_00^-1.  chol_panel(k), k = 0..nb-2, one launch each, one workgroup
-// per trailing tile (i, j), k < j <= i:  L_ik = A_ik L_kk^-T as a 32^3 GEMM against the PRE-INVERTED diagonal block
-// (no serial triangular solve), A_ij -= L_ik L_jk^T, and the workgroup that owns tile (k+1, k+1) immediately factors and
-// inverts it for the next launch -- the only serial work left on the critical path of a panel.
-// W: working copy (trailing tiles updated in place); Lw: the factor (a SEPARATE matrix: other workgroups of the launch
-// still read the un-factored panel blocks from W); Iw: inverses of the diagonal blocks of L (nb x CB x CB).
-__global__ __launch_bounds__(512) void chol_first_kernel(const double* __restrict__ W, double* __restrict__ Lw,
-                                                         double* __restrict__ Iw, int Dp, int D, int* __restrict__ info) {
-  __shared__ double oC[CB * CB];
-  __shared__ double oS[CB * CB];
-  __shared__ double sq[CB];
-  const int tx = threadIdx.x & 15, ty = (threadIdx.x & 255) >> 4;
-  double v[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-  if (threadIdx.x < 256) {
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// 32x32x32 product X Y^T of two LDS tiles (leading dimension CLD) on the f64 matrix cores: 4 waves, wave w owns the
+// 16x16 quadrant (w >> 1, w & 1) and issues 8 v_mfma_f64_16x16x4_f64 on 16 LDS reads (the VALU version -- 128 reads and
+// 128 FMAs per thread -- cost ~1.4 us per product, all of it on the serial chain of a panel step).
+// Lane l feeds A[row = l & 15][k] and B[k][col = l & 15] with k-group q = l >> 4; the k values of group q are
+// 16 (q & 1) + 8 (q >> 1) + s, s = 0..7, which makes the 64-bit LDS reads of each half-wave bank-conflict free.
+__device__ __forceinline__ void tile_nt_mfma(const double* X, const double* Y, int w, int l, d4_t& acc) {
+  const int r = l & 15, q = l >> 4, ko = 16 * (q & 1) + 8 * (q >> 1);
+  const double* x = X + (16 * (w >> 1) + r) * CLD + ko;
+  const double* y = Y + (16 * (w & 1) + r) * CLD + ko;
+  double xa[8], ya[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { xa[s] = x[s]; ya[s] = y[s]; }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s], ya[s], acc, 0, 0, 0);
+}
+// element (row, col) of accumulator register i of lane l of wave w
+__device__ __forceinline__ int mrow(int w, int l, int i) { return 16 * (w >> 1) + (l >> 4) + 4 * i; }
+__device__ __forceinline__ int mcol(int w, int l) { return 16 * (w & 1) + (l & 15); }
+
+__device__ __forceinline__ void tile_store_mfma(double* dst, int w, int l, const d4_t& acc) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[mrow(w, l, i) * CLD + mcol(w, l)] = acc[i];
+}
+
+constexpr int TSZ = CB * CLD;      // one LDS tile
+constexpr int NT2 = 7;             // tiles of LDS used by the column-pair kernels (59 KB)
+
+// Factor the 2x2 block of tiles [T00 . ; T10 T11] (all already updated by every earlier column): T00 and T11 arrive in
+// the registers of threads 0..255 (thread (ty, tx) owns (ty+16a, tx+16b)), T10 in LDS tile 0.  Publishes L_d0d0, L_d1d0,
+// L_d1d1 and the two inverted diagonal blocks.  Tiles 1..6 of `sm` are scratch.
+__device__ __forceinline__ void factor_pair_tail(double (&v)[2][2], double (&v2)[2][2], double* sm, bool has1, int d0,
+                                                 double* __restrict__ Lw, double* __restrict__ Iw, int Dp, int D,
+                                                 int* __restrict__ info) {
+  const int tid = threadIdx.x, half = tid >> 8, lt = tid & 255, tx = lt & 15, ty = lt >> 4;
+  const int w = (tid >> 6) & 3, l = tid & 63;
+  double* T10 = sm;
+  double* Vn = sm + 1 * TSZ;
+  double* Ln = sm + 2 * TSZ;
+  double* Up = sm + 6 * TSZ;
+  factor_invert_tile(v, sm + 3 * TSZ, sm + 4 * TSZ, sm + 5 * TSZ, Lw, Iw, Dp, d0, D, info, Vn);
+  if (!has1) return;
+  __syncthreads();
+  if (half == 0) {                                       // L_d1d0 = T10 L_d0d0^-T
+    d4_t r = {0.0, 0.0, 0.0, 0.0};
+    tile_nt_mfma(T10, Vn, w, l, r);
+    tile_store_mfma(Ln, w, l, r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      Lw[((long)(d0 + 1) * CB + mrow(w, l, i)) * Dp + (long)d0 * CB + mcol(w, l)] = r[i];
+  }
+  __syncthreads();
+  if (half == 0) {                                       // T11 -= L_d1d0 L_d1d0^T
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    tile_nt_mfma(Ln, Ln, w, l, acc);
+    tile_store_mfma(Up, w, l, acc);
+  }
+  __syncthreads();
+  if (half == 0) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int r = ty + 16 * a, c = tx + 16 * b;
+        v2[a][b] = (c <= r) ? v2[a][b] - Up[r * CLD + c] : 0.0;
+      }
+  }
+  factor_invert_tile(v2, sm + 3 * TSZ, sm + 4 * TSZ, sm + 5 * TSZ, Lw, Iw, Dp, d0 + 1, D, info);
+}
+
+// Column-pair start: factors block columns 0 and 1 (their 2x2 block of diagonal tiles).
+__global__ __launch_bounds__(512) void chol_first2_kernel(const double* __restrict__ W, double* __restrict__ Lw,
+                                                          double* __restrict__ Iw, int Dp, int D, int nb,
+                                                          int* __restrict__ info) {
+  __shared__ double sm[NT2 * TSZ];
+  const int tid = threadIdx.x, lt = tid & 255, tx = lt & 15, ty = lt >> 4;
+  const bool has1 = nb > 1;
+  double v[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, v2[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  if (tid < 256) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const int r = ty + 16 * a, c = tx + 16 * b;
         v[a][b] = (c <= r) ? W[(long)r * Dp + c] : 0.0;
+        if (has1) v2[a][b] = (c <= r) ? W[(long)(CB + r) * Dp + CB + c] : 0.0;
       }
   }
-  factor_invert_tile(v, oC, oS, sq, Lw, Iw, Dp, 0, D, info);
+  if (has1)
+    for (int e = tid; e < CB * CB; e += 512) {
+      const int r = e / CB, c = e % CB;
+      sm[r * CLD + c] = W[(long)(CB + r) * Dp + c];
+    }
+  __syncthreads();
+  factor_pair_tail(v, v2, sm, has1, 0, Lw, Iw, Dp, D, info);
 }
 
-__global__ __launch_bounds__(512) void chol_panel_kernel(double* __restrict__ W, double* __restrict__ Lw,
-                                                         double* __restrict__ Iw, int Dp, int D, int k, int nb,
-                                                         int* __restrict__ info) {
-  __shared__ double sV[CB * CLD];      // L_kk^-1
-  __shared__ double sA[CB * CLD];      // A_ik   (later: raw columns of the next diagonal tile)
-  __shared__ double sB[CB * CLD];      // A_jk   (later: raw rows of its inverse)
-  __shared__ double sI[CB * CLD];      // L_ik   (later: 1/sqrt(pivots))
-  __shared__ double sJ[CB * CLD];      // L_jk
-  const int tid = threadIdx.x, half = tid >> 8, lt = tid & 255;
+// Look-ahead blocked Cholesky, two block columns per launch.  The serial chain of a panel step -- launch gap, tile
+// loads, the in-tile factorisation of the next diagonal block -- bounds this solver (D = 760: 24 block columns, at most
+// 276 trailing tiles), so columns c0 and c1 = c0 + 1 are eliminated by ONE launch and the extra products run on the
+// matrix cores.  Needs L_c0c0^-1, L_c1c0 and L_c1c1^-1, published by the previous launch's chain workgroup.
+// One workgroup per trailing tile (i, j), c1 < j <= i:
+//   L_i0 = A_i0 V0^T, A_i1 -= L_i0 L_10^T, L_i1 = A_i1 V1^T  (waves 0..3; the same for block-row j on waves 4..7),
+//   A_ij -= L_i0 L_j0^T + L_i1 L_j1^T.
+// L_ik = A_ik L_kk^-T is a product against the PRE-INVERTED diagonal block: no serial triangular solve anywhere.
+// The chain workgroup is tile (d1, d0) with d0 = c0 + 2, d1 = d0 + 1: from the same four L blocks it also forms the
+// updated diagonal tiles (d0, d0) and (d1, d1), keeps all three on chip, and factors + inverts the pair for the next
+// launch (factor_pair_tail).
+// W: working copy (trailing tiles updated in place); Lw: the factor (a SEPARATE matrix: other workgroups of the launch
+// still read the un-factored panel blocks from W); Iw: inverses of the diagonal blocks of L (nb x CB x CB).
+__global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W, double* __restrict__ Lw,
+                                                          double* __restrict__ Iw, int Dp, int D, int c0, int nb,
+                                                          int* __restrict__ info) {
+  __shared__ double sm[NT2 * TSZ];
+  double* sV0 = sm;
+  double* sV1 = sm + 1 * TSZ;
+  double* sL10 = sm + 2 * TSZ;
+  double* sI0 = sm + 3 * TSZ;      // A_i,c0 -> L_i,c0
+  double* sJ0 = sm + 4 * TSZ;
+  double* sI1 = sm + 5 * TSZ;      // A_i,c1 -> L_i,c1
+  double* sJ1 = sm + 6 * TSZ;
+  const int tid = threadIdx.x, half = tid >> 8, lt = tid & 255, tx = lt & 15, ty = lt >> 4;
+  const int w = (tid >> 6) & 3, l = tid & 63;
+  const int c1 = c0 + 1, d0 = c0 + 2, d1 = c0 + 3;
+  const bool has1 = d1 < nb;
   int ti = -1, tj = -1;
   {
     int t = blockIdx.x;
-    for (int i = k + 1; i < nb; ++i) {
-      const int cnt = i - k;                 // j = k+1 .. i
-      if (t < cnt) { ti = i; tj = k + 1 + t; break; }
+    for (int i = d0; i < nb; ++i) {
+      const int cnt = i - d0 + 1;            // j = d0 .. i
+      if (t < cnt) { ti = i; tj = d0 + t; break; }
       t -= cnt;
     }
   }
-  const long kk = (long)k * CB;
+  if (has1 && ti == tj && ti <= d1) return;  // tiles (d0,d0), (d1,d1) belong to the chain workgroup
+  const bool chain = has1 ? (ti == d1 && tj == d0) : (ti == d0);
+  const long k0 = (long)c0 * CB, k1 = (long)c1 * CB;
   for (int e = tid; e < CB * CB; e += 512) {
-    const int r = e / CB, c = e % CB;
-    sV[r * CLD + c] = Iw[((long)k * CB + r) * CB + c];
-    sA[r * CLD + c] = W[((long)ti * CB + r) * Dp + kk + c];
-    sB[r * CLD + c] = W[((long)tj * CB + r) * Dp + kk + c];
+    const int r = e / CB, c = e % CB, o = r * CLD + c;
+    sV0[o] = Iw[((long)c0 * CB + r) * CB + c];
+    sV1[o] = Iw[((long)c1 * CB + r) * CB + c];
+    sL10[o] = Lw[(k1 + r) * Dp + k0 + c];
+    sI0[o] = W[((long)ti * CB + r) * Dp + k0 + c];
+    sJ0[o] = W[((long)tj * CB + r) * Dp + k0 + c];
+    sI1[o] = W[((long)ti * CB + r) * Dp + k1 + c];
+    sJ1[o] = W[((long)tj * CB + r) * Dp + k1 + c];
   }
   __syncthreads();
-  const int tx = lt & 15, ty = lt >> 4;
-  constexpr int RT = CB / 16;
-  // L_ik[r][c] = sum_t A_ik[r][t] Linv[c][t]  (threads 0..255), the same for L_jk (threads 256..511)
+  double* s0 = half ? sJ0 : sI0;
+  double* s1 = half ? sJ1 : sI1;
   {
-    const double* src = half ? sB : sA;
-    double* dst = half ? sJ : sI;
-    double ai[RT][RT];
-#pragma unroll
-    for (int a = 0; a < RT; ++a)
-#pragma unroll
-      for (int b = 0; b < RT; ++b) ai[a][b] = 0.0;
-#pragma unroll 8
-    for (int t = 0; t < CB; ++t) {
-      double xi[RT], vv[RT];
-#pragma unroll
-      for (int a = 0; a < RT; ++a) { xi[a] = src[(ty + 16 * a) * CLD + t]; vv[a] = sV[(tx + 16 * a) * CLD + t]; }
-#pragma unroll
-      for (int a = 0; a < RT; ++a)
-#pragma unroll
-        for (int b = 0; b < RT; ++b) ai[a][b] += xi[a] * vv[b];
-    }
-#pragma unroll
-    for (int a = 0; a < RT; ++a)
-#pragma unroll
-      for (int b = 0; b < RT; ++b) dst[(ty + 16 * a) * CLD + tx + 16 * b] = ai[a][b];
+    d4_t r = {0.0, 0.0, 0.0, 0.0};
+    tile_nt_mfma(s0, sV0, w, l, r);                       // L_x0 = A_x0 V0^T
+    __syncthreads();
+    tile_store_mfma(s0, w, l, r);
   }
   __syncthreads();
-  if (tj == ti) {   // the diagonal-tile workgroup of block-row i publishes L_ik
+  {
+    d4_t r = {0.0, 0.0, 0.0, 0.0};
+    tile_nt_mfma(s0, sL10, w, l, r);                      // A_x1 -= L_x0 L_10^T  (own elements only: no barrier before)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s1[mrow(w, l, i) * CLD + mcol(w, l)] -= r[i];
+  }
+  __syncthreads();
+  {
+    d4_t r = {0.0, 0.0, 0.0, 0.0};
+    tile_nt_mfma(s1, sV1, w, l, r);                       // L_x1 = A_x1 V1^T
+    __syncthreads();
+    tile_store_mfma(s1, w, l, r);
+  }
+  __syncthreads();
+  if (ti == tj || chain) {                                // publish the L blocks of block-row i (and of row j: chain)
     for (int e = tid; e < CB * CB; e += 512) {
-      const int r = e / CB, c = e % CB;
-      Lw[((long)ti * CB + r) * Dp + kk + c] = sI[r * CLD + c];
+      const int r = e / CB, c = e % CB, o = r * CLD + c;
+      Lw[((long)ti * CB + r) * Dp + k0 + c] = sI0[o];
+      Lw[((long)ti * CB + r) * Dp + k1 + c] = sI1[o];
+      if (chain && has1) {
+        Lw[((long)tj * CB + r) * Dp + k0 + c] = sJ0[o];
+        Lw[((long)tj * CB + r) * Dp + k1 + c] = sJ1[o];
+      }
     }
   }
-  const bool next_diag = (ti == k + 1) && (tj == k + 1);
-  // A_ij -= L_ik L_jk^T : 16x16 threads, (CB/16)^2 outputs each (threads 0..255)
-  double v[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-  if (half == 0) {
-    double acc[RT][RT];
+  if (!chain) {
+    if (half == 0) {
+      d4_t acc = {0.0, 0.0, 0.0, 0.0};
+      tile_nt_mfma(sI0, sJ0, w, l, acc);
+      tile_nt_mfma(sI1, sJ1, w, l, acc);
 #pragma unroll
-    for (int a = 0; a < RT; ++a)
-#pragma unroll
-      for (int b = 0; b < RT; ++b) acc[a][b] = 0.0;
-#pragma unroll 8
-    for (int t = 0; t < CB; ++t) {
-      double xi[RT], xj[RT];
-#pragma unroll
-      for (int a = 0; a < RT; ++a) { xi[a] = sI[(ty + 16 * a) * CLD + t]; xj[a] = sJ[(tx + 16 * a) * CLD + t]; }
-#pragma unroll
-      for (int a = 0; a < RT; ++a)
-#pragma unroll
-        for (int b = 0; b < RT; ++b) acc[a][b] += xi[a] * xj[b];
+      for (int i = 0; i < 4; ++i) {
+        const int r = mrow(w, l, i), c = mcol(w, l);
+        if (ti != tj || c <= r) W[((long)ti * CB + r) * Dp + (long)tj * CB + c] -= acc[i];
+      }
     }
+    return;
+  }
+  // chain workgroup: the updated tiles stay on chip (tiles 0..2 -- V0, V1, L10 -- are dead by now)
+  if (half == 0) {                                        // T00 from the row-j blocks (row i when there is no d1)
+    const double* a0 = has1 ? sJ0 : sI0;
+    const double* a1 = has1 ? sJ1 : sI1;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    tile_nt_mfma(a0, a0, w, l, acc);
+    tile_nt_mfma(a1, a1, w, l, acc);
 #pragma unroll
-    for (int a = 0; a < RT; ++a)
+    for (int i = 0; i < 4; ++i) {
+      const int r = mrow(w, l, i), c = mcol(w, l);
+      sm[1 * TSZ + r * CLD + c] = W[((long)d0 * CB + r) * Dp + (long)d0 * CB + c] - acc[i];
+    }
+    if (has1) {                                           // T11 from the row-i blocks
+      d4_t a11 = {0.0, 0.0, 0.0, 0.0};
+      tile_nt_mfma(sI0, sI0, w, l, a11);
+      tile_nt_mfma(sI1, sI1, w, l, a11);
 #pragma unroll
-      for (int b = 0; b < RT; ++b) {
+      for (int i = 0; i < 4; ++i) {
+        const int r = mrow(w, l, i), c = mcol(w, l);
+        sm[2 * TSZ + r * CLD + c] = W[((long)d1 * CB + r) * Dp + (long)d1 * CB + c] - a11[i];
+      }
+    }
+  } else if (has1) {                                      // T10
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+    tile_nt_mfma(sI0, sJ0, w, l, acc);
+    tile_nt_mfma(sI1, sJ1, w, l, acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = mrow(w, l, i), c = mcol(w, l);
+      sm[r * CLD + c] = W[((long)d1 * CB + r) * Dp + (long)d0 * CB + c] - acc[i];
+    }
+  }
+  __syncthreads();
+  double v[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, v2[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+  if (half == 0) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
         const int r = ty + 16 * a, c = tx + 16 * b;
-        double* w = W + ((long)ti * CB + r) * Dp + (long)tj * CB + c;
-        if (next_diag) v[a][b] = (c <= r) ? *w - acc[a][b] : 0.0;   // stays on chip: factored + inverted right below
-        else if (ti != tj || c <= r) *w -= acc[a][b];
+        v[a][b] = (c <= r) ? sm[1 * TSZ + r * CLD + c] : 0.0;
+        if (has1) v2[a][b] = (c <= r) ? sm[2 * TSZ + r * CLD + c] : 0.0;
       }
   }
-  if (next_diag) {
-    __syncthreads();                                   // sA / sB / sI are dead now
-    factor_invert_tile(v, sA, sB, sI, Lw, Iw, Dp, k + 1, D, info);
-  }
+  __syncthreads();
+  factor_pair_tail(v, v2, sm, has1, d0, Lw, Iw, Dp, D, info);
 }
 
 // L^T delta = y with y = row D of L (columns 0..D-1).  One workgroup of 1024 threads.
@@ -327,12 +454,12 @@ int como_chol_solve_f64(const double* H, const double* g, double* delta, void* w
   hipLaunchKernelGGL(chol_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, H, g, W, D, Dp, info);
   COMO_CHECK_LAUNCH();
   if (Dp > 4096) return COMO_ERR_ARG;
-  hipLaunchKernelGGL(chol_first_kernel, dim3(1), dim3(512), 0, s, W, Lw, Iw, Dp, D, info);
+  hipLaunchKernelGGL(chol_first2_kernel, dim3(1), dim3(512), 0, s, W, Lw, Iw, Dp, D, nb, info);
   COMO_CHECK_LAUNCH();
-  for (int k = 0; k + 1 < nb; ++k) {
-    const int r = nb - 1 - k;
+  for (int c0 = 0; c0 + 2 < nb; c0 += 2) {               // two block columns per launch
+    const int r = nb - (c0 + 2);
     const int tiles = r * (r + 1) / 2;
-    hipLaunchKernelGGL(chol_panel_kernel, dim3(tiles), dim3(512), 0, s, W, Lw, Iw, Dp, D, k, nb, info);
+    hipLaunchKernelGGL(chol_panel2_kernel, dim3(tiles), dim3(512), 0, s, W, Lw, Iw, Dp, D, c0, nb, info);
     COMO_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(1024), 0, s, Lw, Iw, Dp, D, nb, delta);
