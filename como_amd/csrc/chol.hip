@@ -286,15 +286,39 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
   if (has1 && ti == tj && ti <= d1) return;  // tiles (d0,d0), (d1,d1) belong to the chain workgroup
   const bool chain = has1 ? (ti == d1 && tj == d0) : (ti == d0);
   const long k0 = (long)c0 * CB, k1 = (long)c1 * CB;
-  for (int e = tid; e < CB * CB; e += 512) {
-    const int r = e / CB, c = e % CB, o = r * CLD + c;
-    sV0[o] = Iw[((long)c0 * CB + r) * CB + c];
-    sV1[o] = Iw[((long)c1 * CB + r) * CB + c];
-    sL10[o] = Lw[(k1 + r) * Dp + k0 + c];
-    sI0[o] = W[((long)ti * CB + r) * Dp + k0 + c];
-    sJ0[o] = W[((long)tj * CB + r) * Dp + k0 + c];
-    sI1[o] = W[((long)ti * CB + r) * Dp + k1 + c];
-    sJ1[o] = W[((long)tj * CB + r) * Dp + k1 + c];
+  {                                                       // all 14 tile loads of a thread in flight at once
+    double t[2][7];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 512 * u, r = e / CB, c = e % CB;
+      t[u][0] = Iw[((long)c0 * CB + r) * CB + c];
+      t[u][1] = Iw[((long)c1 * CB + r) * CB + c];
+      t[u][2] = Lw[(k1 + r) * Dp + k0 + c];
+      t[u][3] = W[((long)ti * CB + r) * Dp + k0 + c];
+      t[u][4] = W[((long)tj * CB + r) * Dp + k0 + c];
+      t[u][5] = W[((long)ti * CB + r) * Dp + k1 + c];
+      t[u][6] = W[((long)tj * CB + r) * Dp + k1 + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 512 * u, o = (e / CB) * CLD + e % CB;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) sm[q * TSZ + o] = t[u][q];
+    }
+  }
+  // the chain workgroup's own trailing tiles, fetched now so that their latency hides behind the products
+  double wpre[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  if (chain) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long r = mrow(w, l, i), c = mcol(w, l);
+      if (half == 0) {
+        wpre[0][i] = W[((long)d0 * CB + r) * Dp + (long)d0 * CB + c];
+        if (has1) wpre[1][i] = W[((long)d1 * CB + r) * Dp + (long)d1 * CB + c];
+      } else if (has1) {
+        wpre[0][i] = W[((long)d1 * CB + r) * Dp + (long)d0 * CB + c];
+      }
+    }
   }
   __syncthreads();
   double* s0 = half ? sJ0 : sI0;
@@ -354,7 +378,7 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = mrow(w, l, i), c = mcol(w, l);
-      sm[1 * TSZ + r * CLD + c] = W[((long)d0 * CB + r) * Dp + (long)d0 * CB + c] - acc[i];
+      sm[1 * TSZ + r * CLD + c] = wpre[0][i] - acc[i];
     }
     if (has1) {                                           // T11 from the row-i blocks
       d4_t a11 = {0.0, 0.0, 0.0, 0.0};
@@ -363,7 +387,7 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = mrow(w, l, i), c = mcol(w, l);
-        sm[2 * TSZ + r * CLD + c] = W[((long)d1 * CB + r) * Dp + (long)d1 * CB + c] - a11[i];
+        sm[2 * TSZ + r * CLD + c] = wpre[1][i] - a11[i];
       }
     }
   } else if (has1) {                                      // T10
@@ -373,7 +397,7 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = mrow(w, l, i), c = mcol(w, l);
-      sm[r * CLD + c] = W[((long)d1 * CB + r) * Dp + (long)d0 * CB + c] - acc[i];
+      sm[r * CLD + c] = wpre[0][i] - acc[i];
     }
   }
   __syncthreads();
