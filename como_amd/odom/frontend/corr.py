@@ -1,0 +1,138 @@
+"""Sparse-point correspondence and initialisation for a new keyframe (reference como/odom/frontend/corr.py).
+
+`track_and_init` keeps the reference's signature and return values.  What runs where:
+  * reprojection of the m inducing points and of the dense depth image of the previous keyframe: elementwise torch ops on
+    the device (O(N) once per keyframe),
+  * latent log-depths in the new frame: `distill_depth_from_scratch` / `distill_conditional_depth_from_scratch`
+    (kernel matrices from the HIP covariance modules),
+  * pruning of the tracked points and sampling of new ones: `sample_sparse_coords` (HIP greedy sampler, csrc/cov.hip),
+  * Scharr gradient of the reference log-depth: `ImageGradientModule` (csrc/image.hip).
+"""
+import torch
+import torch.nn.functional as F
+
+from como_amd.depth_cov.core.distill_depth import distill_conditional_depth_from_scratch, distill_depth_from_scratch
+from como_amd.depth_cov.core.samplers import sample_sparse_coords
+from como_amd.geometry.camera import backprojection, projection
+from como_amd.geometry.lie_algebra import invertSE3
+from como_amd.geometry.transforms import transform_points
+from como_amd.utils.coords import get_test_coords, normalize_coordinates, swap_coords_xy
+from como_amd.utils.image_processing import ImageGradientModule
+
+
+def filter_reproj_coords(coords, P, img_size, min_depth):
+    """Keep points at least one pixel inside the image and deeper than min_depth (corr.py:17-29).  coords (1,n,2) row/col."""
+    r, c = coords[0, :, 0], coords[0, :, 1]
+    keep = (c >= 1) & (c < img_size[-1] - 1) & (r >= 1) & (r < img_size[-2] - 1) & (P[0, :, 2] > min_depth)
+    return coords[:, keep, :], P[:, keep, :], keep
+
+
+def condition_depth(logz_m, Knm_Kmminv):
+    return Knm_Kmminv @ logz_m
+
+
+def reproject_points(coords_i, zi, Tji, K):
+    """Row/col coords + depths of frame i -> row/col coords and camera points in frame j (corr.py:37-43)."""
+    Pi, _ = backprojection(K[0], swap_coords_xy(coords_i), zi)
+    Pj, _, _ = transform_points(Tji, Pi)
+    pj, _ = projection(K[0], Pj)
+    return swap_coords_xy(pj), Pj
+
+
+def get_correspondence_errors(P_reproj, P_new, mode):
+    """corr.py:47-59"""
+    if mode == "z":
+        return torch.abs(P_reproj[..., 2:3] - P_new[..., 2:3])
+    if mode in ("logz", "logr"):
+        return torch.abs(torch.log(P_reproj[..., 2:3]) - torch.log(P_new[..., 2:3]))
+    if mode == "3d":
+        return torch.linalg.norm(P_reproj - P_new, dim=-1, keepdim=True)
+    raise ValueError(f"unknown correspondence mode {mode!r}")
+
+
+def _sample_at(img, coords, size):
+    """Bilinear look-up of a (1,1,h,w) image at row/col coords (1,k,2) -> (1,k,1) (zeros outside, align_corners=False)."""
+    grid = swap_coords_xy(normalize_coordinates(coords, size)).unsqueeze(1)
+    out = F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+    return out.reshape(1, 1, coords.shape[1]).permute(0, 2, 1)
+
+
+def track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, cov_params_img2, K, model, corr_params, sampling_params,
+                   rgb_img_size, rgb1=None, rgb2=None):
+    """corr.py:62-242.  Returns (coords_2, z2, corr_mask, coords_all, z_all):
+    the newly sampled points and their depths, which of the m previous points are kept as correspondences, and the full
+    inducing set of the new keyframe (kept correspondences first)."""
+    dev = coords_m1.device
+    b, _, h, w = cov_params_img2.shape
+    if b != 1:
+        raise RuntimeError("track_and_init: batch 1 only")
+    N = rgb_img_size[0] * rgb_img_size[1]
+    cov_size = (h, w)
+    min_d = corr_params["min_obs_depth"]
+
+    # previous keyframe (1) -> new frame (2): the sparse points and the whole depth image
+    Tji = invertSE3(pose2) @ pose1
+    coords_n1 = get_test_coords(z_img1.shape[-2:], device=dev, batch_size=b)
+    z_n1 = z_img1.reshape(b, 1, N).permute(0, 2, 1)
+    cj_m, Pj_m = reproject_points(coords_m1, z_m1, Tji, K)
+    cj_n, Pj_n = reproject_points(coords_n1, z_n1, Tji, K)
+    cj_m, Pj_m, keep_m = filter_reproj_coords(cj_m, Pj_m, cov_size, min_d)
+    cj_n, Pj_n, _ = filter_reproj_coords(cj_n, Pj_n, cov_size, min_d)
+    zj_n = Pj_n[:, :, 2:3]
+
+    # latent depths of the reprojected sparse points under the NEW frame's covariance, from the reprojected dense depths
+    logz_m, logz_res = distill_depth_from_scratch(cj_m, cj_n, zj_n, cov_params_img2, model,
+                                                  distill_with_prior=corr_params["distill_with_prior"], min_depth=min_d)
+    z_m = torch.exp(logz_m)
+    P_m, _ = backprojection(K[0], swap_coords_xy(cj_m), z_m)
+
+    # back into frame 1: compare with the interpolated reference depth there
+    ci_m, Pi_m = reproject_points(cj_m, z_m, invertSE3(Tji), K)
+    P_proj, _ = backprojection(K[0], swap_coords_xy(ci_m), _sample_at(z_img1, ci_m, cov_size))
+
+    # depth discontinuities of the reference: |grad log z| at the original sparse coordinates
+    gx, gy = ImageGradientModule(channels=1, device=dev, dtype=z_img1.dtype)(torch.log(z_img1))
+    grad_ref = _sample_at(torch.sqrt(gx * gx + gy * gy), coords_m1[:, keep_m, :], cov_size)
+
+    mode = corr_params["corr_mode"]
+    err = torch.maximum(get_correspondence_errors(P_proj, Pi_m, mode), get_correspondence_errors(Pj_m, P_m, mode))
+    good = ((err < corr_params["corr_thresh"]) & (grad_ref < corr_params["logz_grad_mag_thresh"]))[0, :, 0]
+
+    coords_1 = cj_m[:, good, :]
+    z1 = Pj_m[:, good, 2:3]
+    n_max = sampling_params["max_num_coords"]
+    if coords_1.shape[1] > 0:
+        # thin the tracked points with the same greedy criterion (the sampler reorders: only its index set is used)
+        with torch.no_grad():
+            _, picked = sample_sparse_coords(cov_params_img2, n_max, "greedy_conditional_entropy",
+                                             sampling_params["max_stdev_thresh"], border=sampling_params["border"],
+                                             terminate_early=True, dist_thresh=sampling_params["dist_thresh"],
+                                             signal_var=model.get_scale(-1), fixed_var=sampling_params["fixed_var"],
+                                             coords_domain=coords_1)
+        sel = torch.zeros(coords_1.shape[1], device=dev, dtype=torch.bool)
+        sel[picked[0, :]] = True
+        coords_1 = coords_1[:, sel, :]
+        z1 = z1[:, sel, :]
+        good[good.clone()] = sel
+    corr_mask = keep_m.clone()
+    corr_mask[keep_m] = good
+
+    if coords_1.shape[1] < n_max:
+        with torch.no_grad():
+            coords_2, _ = sample_sparse_coords(cov_params_img2, n_max, sampling_params["mode"],
+                                               sampling_params["max_stdev_thresh"], border=sampling_params["border"],
+                                               terminate_early=False, dist_thresh=sampling_params["dist_thresh"],
+                                               signal_var=model.get_scale(-1), fixed_var=sampling_params["fixed_var"],
+                                               curr_coords=coords_1)
+            coords_2 = coords_2.to(dtype=coords_1.dtype)
+        coords_all = torch.cat((coords_1, coords_2), dim=1)
+        # depths of the new points conditioned on the tracked ones; observation noise = spread of the first fit
+        logz_2 = distill_conditional_depth_from_scratch(coords_all, z1, cj_n, cov_params_img2, zj_n, model, min_depth=0.0,
+                                                        stdev_obs=torch.std(logz_res))
+        z2 = torch.exp(logz_2)
+        z_all = torch.cat((z1, z2), dim=1)
+    else:
+        coords_all, z_all = coords_1.clone(), z1.clone()
+        coords_2 = torch.empty((1, 0, 2), device=dev, dtype=coords_1.dtype)
+        z2 = torch.empty((1, 0, 1), device=dev, dtype=z1.dtype)
+    return coords_2, z2, corr_mask, coords_all, z_all

@@ -31,3 +31,19 @@ def get_coord_img(img_size, device, batch_size=1):
     h, w = img_size
     r, c = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
     return torch.stack((r, c), dim=-1).unsqueeze(0).repeat(batch_size, 1, 1, 1)
+
+
+def fill_image(coords, vals, img_size, default_val=float("nan")):
+    """Scatter vals (n,1) to the integer-truncated coords (n,2) of a (1,h,w) image pre-filled with default_val
+    (coords.py:50-56).  Where several points land on one pixel the LAST one wins -- the order torch's CPU index_put
+    applies them in, made explicit here so the GPU result is deterministic and equal to the reference's."""
+    h, w = int(img_size[0]), int(img_size[1])
+    c = coords.long()
+    flat = c[..., 0] * w + c[..., 1]
+    n = flat.numel()
+    order = torch.full((h * w,), -1, device=coords.device, dtype=torch.long)
+    order.scatter_reduce_(0, flat.reshape(-1), torch.arange(n, device=coords.device), reduce="amax", include_self=True)
+    img = torch.full((h * w,), default_val, device=coords.device, dtype=vals.dtype)
+    hit = order >= 0
+    img[hit] = vals.reshape(-1)[order[hit]]
+    return img.view(1, h, w)

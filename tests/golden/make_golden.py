@@ -447,9 +447,41 @@ def distill_case(seed=7):
     return out
 
 
+CORR_PARAMS = {"corr_mode": "logz", "corr_thresh": 3.0e-2, "distill_with_prior": True, "min_obs_depth": 0.0,
+               "logz_grad_mag_thresh": 7.0e-2}                     # config/como.yml mapping.corr
+
+
+def corr_case(seed=11, H=48, W=64, m=12, nmax=16):
+    """track_and_init of the reference (corr.py:62-242) between two rendered keyframes of the synthetic plane scene, mapping
+    dtype (float64), with the sampling / correspondence parameters of config/como.yml (max_num_coords reduced to 16).
+    One sparse depth is corrupted by 20 % so that at least one point is rejected as a correspondence."""
+    import como.odom.frontend.corr as rcorr
+    dtype = torch.float64
+    model = ref_model()
+    st = synth.make_window(B=2, H=H, W=W, m=m, dtype=dtype, seed=seed)
+    cov2 = synth.synthetic_cov_params(1, H, W, seed=seed + 1, dtype=dtype)
+    g = torch.Generator().manual_seed(seed)
+    pose1, pose2 = st["poses_gt"][0:1].clone(), st["poses_gt"][1:2].clone()
+    coords_m1 = st["coords_m"][0:1].clone()
+    z_img1 = st["depth_gt"][0:1, None].clone()
+    cm = coords_m1[0].long()
+    z_m1 = z_img1[0, 0][cm[:, 0], cm[:, 1]].reshape(1, m, 1) * (1 + 0.002 * torch.randn((1, m, 1), generator=g, dtype=dtype))
+    z_m1[0, 3, 0] *= 1.2
+    sampling = {"mode": "greedy_conditional_entropy", "max_num_coords": nmax, "max_stdev_thresh": 1.0e-2, "border": 3,
+                "fixed_var": 0.0, "dist_thresh": 1.0e-1}
+    with torch.no_grad():
+        coords_2, z2, corr_mask, coords_all, z_all = rcorr.track_and_init(
+            pose1, pose2, coords_m1, z_m1, z_img1, cov2, st["intrinsics"], model, CORR_PARAMS, sampling, (H, W))
+    return {"pose1": pose1, "pose2": pose2, "coords_m1": coords_m1, "z_m1": z_m1, "z_img1": z_img1, "cov2": cov2,
+            "K": st["intrinsics"], "nmax": nmax, "coords_2": coords_2, "z2": z2, "corr_mask": corr_mask,
+            "coords_all": coords_all, "z_all": z_all}
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net", "distill"]
+    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net", "distill", "corr"]
+    if "corr" in which:
+        save("corr_f64.npz", corr_case())
     if "distill" in which:
         save("distill_f32.npz", distill_case())
     if "net" in which:

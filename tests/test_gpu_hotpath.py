@@ -803,3 +803,29 @@ def test_distill_depth_vs_golden():
     z1 = torch.exp(dev(G["logz_m_prior1"])[:, :5, :])
     lz2 = dd.distill_conditional_depth_from_scratch(cm, z1, cn, cov, z, model, 0.1, 0.05)
     assert (lz2.cpu() - G["logz_m2_cond"]).abs().max().item() < 5e-3
+
+
+def test_track_and_init_vs_golden():
+    """corr.py mirror: correspondences, newly sampled inducing points and their depths for a new keyframe, against the
+    reference's track_and_init on the same inputs (mapping dtype float64).  The correspondence mask and the sampled pixel
+    set must be identical; depths agree to the conditioning of the m x m float64 solves."""
+    from como_amd.depth_cov.core.DepthCovModule import DepthCovModule
+    from como_amd.odom.frontend.corr import track_and_init
+    from como_amd.synth import depthcov_state_dict
+    G = load_golden("corr_f64.npz")
+    model = DepthCovModule({k: dev(v) for k, v in depthcov_state_dict(0).items()})
+    corr_params = {"corr_mode": "logz", "corr_thresh": 3.0e-2, "distill_with_prior": True, "min_obs_depth": 0.0,
+                   "logz_grad_mag_thresh": 7.0e-2}
+    sampling = {"mode": "greedy_conditional_entropy", "max_num_coords": int(G["nmax"]), "max_stdev_thresh": 1.0e-2,
+                "border": 3, "fixed_var": 0.0, "dist_thresh": 1.0e-1}
+    H, W = G["z_img1"].shape[-2:]
+    c2, z2, mask, call, zall = track_and_init(dev(G["pose1"]), dev(G["pose2"]), dev(G["coords_m1"]), dev(G["z_m1"]),
+                                              dev(G["z_img1"]), dev(G["cov2"]), dev(G["K"]), model, corr_params, sampling,
+                                              (H, W))
+    assert torch.equal(mask.cpu(), G["corr_mask"])
+    assert tuple(c2.shape) == tuple(G["coords_2"].shape) and torch.equal(c2.cpu().to(G["coords_2"].dtype), G["coords_2"])
+    assert (call.cpu() - G["coords_all"]).abs().max().item() < 1e-9
+    ez2 = (z2.cpu() - G["z2"]).abs().max().item()
+    ezall = (zall.cpu() - G["z_all"]).abs().max().item()
+    report("track_and_init", kept=int(mask.sum()), new=int(c2.shape[1]), z2_abs_err=ez2, z_all_abs_err=ezall)
+    assert ezall < 1e-4 and ez2 < 1e-4
