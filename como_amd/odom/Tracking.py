@@ -1,0 +1,194 @@
+"""Headless frame tracker: the state machine of the reference's `Tracking` (como/odom/Tracking.py:21-379) without the process
+/ queue plumbing.  Same method names, arguments and return tuples, so the caller code of the reference (Odometry / the
+multiprocessing wrappers) can drive it unchanged.
+
+Per frame (`handle_frame`): image pyramid -> `photo_tracking_pyr` (HIP, csrc/track.hip, one captured graph per pyramid level)
+-> reprojection of the last keyframe's points -> keyframe / one-way-frame decision.  Per new keyframe
+(`update_kf_reference`): pyramids of the keyframe image(s) and depth(s), back-projection into the last keyframe's frame and
+the inverse-compositional Jacobians (`precalc_jacobians`, HIP, csrc/image.hip).  The O(N) glue between the kernels is torch
+elementwise work on the device.
+"""
+import torch
+
+from como_amd.geometry.affine_brightness import get_aff_w_curr, get_rel_aff
+from como_amd.geometry.camera import backprojection, projection
+from como_amd.geometry.lie_algebra import invertSE3
+from como_amd.geometry.transforms import get_rel_pose, get_T_w_curr, transform_points
+from como_amd.odom.frontend.photo_tracking import photo_tracking_pyr, precalc_jacobians
+from como_amd.utils.coords import fill_image, get_test_coords, swap_coords_xy
+from como_amd.utils.image_processing import (DepthPyramidModule, ImageGradientModule, ImagePyramidModule,
+                                             IntrinsicsPyramidModule, rgb_to_grayscale)
+
+_DTYPES = {"float": torch.float32, "double": torch.float64, "half": torch.float16}
+
+
+def _in_image(p, depth, img_size, border, depth_thresh, strict):
+    """Projected pixel p (.., 2) as (x, y) inside the image grown by `border`, and depth above the threshold."""
+    x, y = p[..., 0], p[..., 1]
+    if strict:                      # Tracking.py:173-178 (open interval)
+        ok = (x > -border) & (x < img_size[-1] - 1 + border) & (y > -border) & (y < img_size[-2] - 1 + border)
+    else:                           # Tracking.py:265-281 (closed interval)
+        ok = (x >= -border) & (x <= img_size[-1] - 1 + border) & (y >= -border) & (y <= img_size[-2] - 1 + border)
+    return ok & (depth[..., 0] > depth_thresh)
+
+
+class Tracking:
+    def __init__(self, cfg, intrinsics, img_size):
+        self.cfg = cfg
+        self.device = cfg["device"]
+        self.dtype = _DTYPES[cfg["dtype"]] if isinstance(cfg["dtype"], str) else cfg["dtype"]
+        self.intrinsics = intrinsics
+        self.img_size = img_size
+        self.mapping_init = False
+
+    def track(self, data):
+        raise NotImplementedError
+
+    def setup(self):
+        self.init_basic_vars()
+        self.init_kf_vars()
+        self.reset_one_way_vars()
+        self.T_w_rec_last = None
+
+    # ---- construction ----------------------------------------------------------------------------------------------
+    def init_basic_vars(self):
+        """Tracking.py:46-72"""
+        self.intrinsics = self.intrinsics.to(device=self.device, dtype=self.dtype)
+        pyr = self.cfg["pyr"]
+        s, e = pyr["start_level"], pyr["end_level"]
+        self.intrinsics_pyr = IntrinsicsPyramidModule(s, e, self.device)(self.intrinsics, [1.0, 1.0])
+        c = {"gray": 1, "rgb": 3}[self.cfg["color"]]
+        self.gradient_module = ImageGradientModule(channels=c, device=self.device, dtype=self.dtype)
+        self.img_pyr_module = ImagePyramidModule(c, s, e, self.device, dtype=self.dtype)
+        self.depth_pyr_module = DepthPyramidModule(s, e, pyr["depth_interp_mode"], self.device)
+
+    def reset_one_way_vars(self):
+        self.num_one_way_since_kf = 0
+        self.last_one_way_empty_pixels = 0
+        self.last_flow_rmse = 0.0
+        self.last_flow_wo_rot_rmse = 0.0
+
+    def init_kf_vars(self):
+        self.T_curr_kf = torch.eye(4, device=self.device, dtype=self.dtype).unsqueeze(0)
+        self.aff_curr_kf = torch.zeros((1, 2, 1), device=self.device, dtype=self.dtype)
+        self.last_one_way_num_pixels = self.img_size[-1] * self.img_size[-2]
+        self.last_kf_sent_ts = torch.zeros(1, device=self.device, dtype=self.dtype)
+        self.kf_received_ts = torch.zeros(1, device=self.device, dtype=self.dtype)
+
+    # ---- small accessors -------------------------------------------------------------------------------------------
+    def get_curr_world_pose(self):
+        return get_T_w_curr(self.T_w_kf, self.T_curr_kf)
+
+    def get_curr_world_aff(self):
+        return get_aff_w_curr(self.aff_w_kf, self.aff_curr_kf)
+
+    def prep_tracking_img(self, rgb):
+        img = rgb_to_grayscale(rgb) if self.cfg["color"] == "gray" else rgb.clone()
+        return self.img_pyr_module(img)
+
+    def get_img_gradients(self, img_pyr):
+        out = []
+        for lvl in img_pyr:
+            gx, gy = self.gradient_module(lvl)
+            out.append(torch.cat((lvl, gx, gy), dim=1))
+        return out
+
+    # ---- keyframe / one-way decisions (Tracking.py:110-161) ----------------------------------------------------------
+    def check_keyframe(self, median_depth, num_reproj_depth, T_curr_kf):
+        if not bool(self.last_kf_sent_ts <= self.kf_received_ts):
+            return False                                   # a keyframe request is still in flight
+        kfg = self.cfg["keyframing"]
+        n_px = self.vals_pyr[-1].shape[1]
+        if torch.linalg.norm(T_curr_kf[:, :3, 3]) > kfg["kf_depth_motion_ratio"] * median_depth:
+            return True
+        return bool(kfg["kf_num_pixels_frac"] > num_reproj_depth / n_px)
+
+    def check_one_way_frame(self, median_depth, num_reproj_depth, T_curr_kf, T_w_curr):
+        kfg = self.cfg["keyframing"]
+        pending = 1 if bool(self.last_kf_sent_ts > self.kf_received_ts) else 0
+        scale = (1.0 + self.num_one_way_since_kf + pending) / (1.0 + kfg["one_way_freq"])
+        n_px = self.vals_pyr[-1].shape[1]
+        empty = n_px - num_reproj_depth
+        moved = torch.linalg.norm(T_curr_kf[:, :3, 3]) > scale * kfg["kf_depth_motion_ratio"] * median_depth
+        new = bool(moved) or bool(empty > scale * (1 - kfg["kf_num_pixels_frac"]) * n_px)
+        if new:
+            self.last_one_way_empty_pixels = empty
+            self.T_w_rec_last = T_w_curr
+        return new
+
+    def get_reproj_last_kf(self, T_curr_kf):
+        """Depth image of the newest keyframe's finest-level points seen from the current frame, NaN where nothing lands
+        (Tracking.py:163-185)."""
+        P_curr, _, _ = transform_points(T_curr_kf, self.P_pyr[-1][None, -1, :, :])
+        p, _ = projection(self.intrinsics_pyr[-1], P_curr)
+        depth = P_curr[:, :, 2:3]
+        ok = _in_image(p, depth, self.img_size, 0, 0.0, strict=True)
+        return fill_image(swap_coords_xy(p)[ok, :], depth[ok, :], self.img_size)
+
+    # ---- new reference keyframe(s) from mapping (Tracking.py:187-313) ------------------------------------------------
+    def update_kf_reference(self, kf_data):
+        timestamps, kf_rgb, kf_pose, kf_aff, depth = kf_data
+        nk = kf_pose.shape[0]
+        if timestamps[-1] > self.kf_received_ts and self.mapping_init:
+            # re-base the current frame's relative pose / affine parameters on the new last keyframe
+            self.T_w_f = get_T_w_curr(self.T_w_kf, self.T_curr_kf)
+            self.T_curr_kf = get_rel_pose(self.T_w_f, kf_pose[nk - 1:nk])
+            self.aff_w_f = get_aff_w_curr(self.aff_w_kf, self.aff_curr_kf)
+            self.aff_curr_kf = get_rel_aff(self.aff_w_f, kf_aff[nk - 1:nk])
+            self.reset_one_way_vars()
+        elif not self.mapping_init:
+            self.mapping_init = True
+            self.last_kf_sent_ts = timestamps[-1]
+
+        if timestamps[-1] != self.kf_received_ts:          # new image(s): intensities and gradients at every pixel
+            self.coords_pyr, self.vals_pyr, self.img_grads_pyr = [], [], []
+            for lvl in self.prep_tracking_img(kf_rgb):
+                gx, gy = self.gradient_module(lvl)
+                b, c, h, w = lvl.shape
+                flat = lambda t: t.reshape(b, c, h * w).permute(0, 2, 1)       # (B,N,C), row-major pixel order
+                self.vals_pyr.append(flat(lvl).contiguous())
+                self.img_grads_pyr.append(torch.stack((flat(gx), flat(gy)), dim=-1).contiguous())
+                self.coords_pyr.append(get_test_coords((h, w), device=self.device, batch_size=b))
+
+        self.P_pyr, self.dI_dT_pyr, self.mask_pyr = [], [], []
+        rel = invertSE3(kf_pose[nk - 1:nk]) @ kf_pose       # every keyframe -> the last keyframe's frame
+        for i, d in enumerate(self.depth_pyr_module(depth)):
+            coords = self.coords_pyr[i]
+            b, _, h, w = d.shape
+            z = d[:, 0].reshape(b, h * w, 1)
+            P, _ = backprojection(self.intrinsics_pyr[i], swap_coords_xy(coords), z)
+            P_all, _, _ = transform_points(rel, P)
+            p_all, _ = projection(self.intrinsics_pyr[i], P_all)
+            self.mask_pyr.append(_in_image(p_all, P_all[:, :, 2:3], (h, w), 50, 1e-4, strict=False))
+            self.dI_dT_pyr.append(precalc_jacobians(self.img_grads_pyr[i], P_all, self.vals_pyr[i], self.intrinsics_pyr[i]))
+            self.P_pyr.append(P_all)
+
+        self.kf_received_ts = timestamps[-1]
+        self.T_w_kf = kf_pose[nk - 1:nk]
+        self.aff_w_kf = kf_aff[nk - 1:nk]
+
+    # ---- one frame (Tracking.py:315-379) -----------------------------------------------------------------------------
+    def handle_frame(self, data):
+        timestamp, rgb = data
+        img_pyr = self.prep_tracking_img(rgb)
+        self.T_curr_kf, self.aff_curr_kf = photo_tracking_pyr(self.T_curr_kf, self.aff_curr_kf, self.vals_pyr, self.P_pyr,
+                                                              self.dI_dT_pyr, self.mask_pyr, self.intrinsics_pyr, img_pyr,
+                                                              self.cfg["sigmas"]["photo"], self.cfg["term_criteria"])
+        T_w_curr = self.get_curr_world_pose()
+        track_data_viz = (timestamp, T_w_curr.clone())
+        track_data_map = None
+
+        reproj = self.get_reproj_last_kf(self.T_curr_kf)
+        seen = ~torch.isnan(reproj)
+        n_seen = torch.count_nonzero(seen)
+        median_depth = torch.median(reproj[seen])
+        self.last_reproj_stats = (n_seen, median_depth)
+
+        if self.check_keyframe(median_depth, n_seen, self.T_curr_kf):
+            track_data_map = ("keyframe", rgb.clone(), self.T_curr_kf, self.aff_curr_kf, self.kf_received_ts, timestamp)
+            self.last_kf_sent_ts = timestamp
+        elif self.check_one_way_frame(median_depth, n_seen, self.T_curr_kf, T_w_curr):
+            track_data_map = ("one-way", rgb.clone(), self.T_curr_kf, self.aff_curr_kf, self.kf_received_ts, timestamp)
+            self.last_rec_sent_ts = timestamp
+            self.num_one_way_since_kf += 1
+        return track_data_viz, track_data_map

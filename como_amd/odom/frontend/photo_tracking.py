@@ -190,9 +190,13 @@ def photo_tracking_pyr(Tji_init, aff_init, vals_i, Pi, dI_dT, masks, intrinsics,
     The masked reference arrays of a keyframe are gathered once and kept (the reference re-gathers them every frame); the
     current frame's pyramid levels and intrinsics are copied into persistent buffers so that every level replays its
     captured iteration graph."""
-    key = tuple(t.data_ptr() for t in vals_i) + tuple(t.data_ptr() for t in masks)
-    lv = _pyr_cache.get(key)
-    if lv is None:
+    # keyed by the IDENTITY of every reference-side tensor; the entry keeps them alive, so neither an id nor a device
+    # address can be recycled for different data while the entry exists (a refined depth map = new P / dI_dT / mask
+    # tensors = a new entry)
+    src = tuple(vals_i) + tuple(Pi) + tuple(dI_dT) + tuple(masks)
+    key = tuple(id(t) for t in src)
+    ent = _pyr_cache.get(key)
+    if ent is None:
         if len(_pyr_cache) > 4:
             _pyr_cache.clear()
             _level_graphs.clear()
@@ -202,7 +206,9 @@ def photo_tracking_pyr(Tji_init, aff_init, vals_i, Pi, dI_dT, masks, intrinsics,
             lv.append({"vals": vals_i[l][None, mk, :].contiguous(), "P": Pi[l][None, mk, :].contiguous(),
                        "dI": dI_dT[l][None, mk, :, :].contiguous(), "img": torch.empty_like(img_j[l]),
                        "K": torch.empty_like(intrinsics[l])})
-        _pyr_cache[key] = lv
+        ent = (lv, src)
+        _pyr_cache[key] = ent
+    lv = ent[0]
     Tji = Tji_init.clone()
     aff = aff_init.clone()
     for l in range(len(vals_i)):

@@ -129,3 +129,10 @@ class IntrinsicsPyramidModule:
         return pyr
 
     forward = __call__
+
+
+def rgb_to_grayscale(rgb):
+    """ITU-R 601-2 luma of a (..,3,H,W) image, the weights torchvision's functional.rgb_to_grayscale applies (the reference
+    calls it in Mapping.get_img_and_grads / Tracking.prep_tracking_img)."""
+    r, g, b = rgb.unbind(dim=-3)
+    return (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(-3)

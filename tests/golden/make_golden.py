@@ -447,6 +447,58 @@ def distill_case(seed=7):
     return out
 
 
+TRACK_CFG = {"device": "cpu", "dtype": "float", "color": "gray",
+             "pyr": {"start_level": 0, "end_level": 3, "depth_interp_mode": "nearest_neighbor"},
+             "term_criteria": {"max_iter": 50, "delta_norm": 1.0e-3, "rel_tol": 1.0e-3, "grad_norm": 1.0},
+             "sigmas": {"photo": 1.0e-1},
+             "keyframing": {"kf_depth_motion_ratio": 0.03, "kf_num_pixels_frac": 0.75, "one_way_freq": 3}}
+
+
+def tracker_case(seed=3, H=96, W=128, nframes=6):
+    """The reference's Tracking state machine (Tracking.py:187-379) on a rendered sequence: one keyframe with GT depth, then
+    frames moving away from it until a one-way frame and a keyframe are requested; then a second keyframe arrives from
+    'mapping' (GT pose / depth) and one more frame is tracked against it.  config/como.yml tracking section with
+    kf_depth_motion_ratio lowered to 0.03 so that the requests happen within a few frames."""
+    import como.odom.Tracking as rtr
+    dtype = torch.float32
+    scene = synth.PlaneScene(seed=seed, freq_scale=W / 640.0)
+    K = synth.intrinsics_for(H, W)
+    T = synth.gt_poses(nframes + 1, step=0.012, deg=0.5)
+    g = torch.Generator().manual_seed(seed)
+    rgbs, depths = [], []
+    for k in range(nframes + 1):
+        I, z = scene.render(T[k], K, H, W)
+        I = I + 0.002 * torch.randn(I.shape, generator=g, dtype=torch.float64)
+        rgbs.append(I[None, None].repeat(1, 3, 1, 1).to(dtype))
+        depths.append(z[None, None].to(dtype))
+    trk = rtr.Tracking(TRACK_CFG, K.to(dtype), (H, W))
+    trk.init_basic_vars(); trk.init_kf_vars(); trk.reset_one_way_vars(); trk.T_w_rec_last = None   # setup() minus init_gpu
+    out = {"K": K.to(dtype), "rgb": torch.cat(rgbs), "depth": torch.cat(depths), "poses_gt": T.to(dtype)}
+    aff0 = torch.zeros((1, 2, 1), dtype=dtype)
+    trk.update_kf_reference(([1.0], rgbs[0], T[0:1].to(dtype), aff0, depths[0]))
+    kinds, second_kf_at = [], -1
+    for k in range(1, nframes + 1):
+        if second_kf_at < 0 and kinds and kinds[-1] == 1:
+            # mapping answers the keyframe request: the previous frame becomes keyframe 2 (GT pose and depth)
+            second_kf_at = k - 1
+            trk.update_kf_reference(([1.0 + second_kf_at], rgbs[second_kf_at], T[second_kf_at:second_kf_at + 1].to(dtype), aff0,
+                                     depths[second_kf_at]))
+            out["rebased_T_curr_kf"] = trk.T_curr_kf.clone()
+            out["rebased_aff_curr_kf"] = trk.aff_curr_kf.clone()
+        viz, mp = trk.handle_frame((1.0 + k, rgbs[k]))
+        kinds.append(0 if mp is None else (1 if mp[0] == "keyframe" else 2))
+        rd = trk.get_reproj_last_kf(trk.T_curr_kf)
+        ok = ~torch.isnan(rd)
+        out[f"T_curr_kf_{k}"] = trk.T_curr_kf.clone()
+        out[f"aff_curr_kf_{k}"] = trk.aff_curr_kf.clone()
+        out[f"T_w_curr_{k}"] = viz[1]
+        out[f"n_reproj_{k}"] = torch.count_nonzero(ok)
+        out[f"median_depth_{k}"] = torch.median(rd[ok])
+    out["kinds"] = np.array(kinds)                       # 0 none, 1 keyframe, 2 one-way
+    out["second_kf_at"] = second_kf_at
+    return out
+
+
 CORR_PARAMS = {"corr_mode": "logz", "corr_thresh": 3.0e-2, "distill_with_prior": True, "min_obs_depth": 0.0,
                "logz_grad_mag_thresh": 7.0e-2}                     # config/como.yml mapping.corr
 
@@ -479,7 +531,9 @@ def corr_case(seed=11, H=48, W=64, m=12, nmax=16):
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net", "distill", "corr"]
+    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net", "distill", "corr", "tracker"]
+    if "tracker" in which:
+        save("tracker_f32.npz", tracker_case())
     if "corr" in which:
         save("corr_f64.npz", corr_case())
     if "distill" in which:

@@ -829,3 +829,41 @@ def test_track_and_init_vs_golden():
     ezall = (zall.cpu() - G["z_all"]).abs().max().item()
     report("track_and_init", kept=int(mask.sum()), new=int(c2.shape[1]), z2_abs_err=ez2, z_all_abs_err=ezall)
     assert ezall < 1e-4 and ez2 < 1e-4
+
+
+def test_tracking_state_machine_vs_golden():
+    """Tracking mirror (como_amd/odom/Tracking.py) driven through the reference's sequence: keyframe reference set-up,
+    six tracked frames, the keyframe / one-way requests they raise, and the re-basing on a second keyframe.  The decisions
+    must be identical; poses agree to the float32 tracking tolerance."""
+    from como_amd.odom.Tracking import Tracking
+    G = load_golden("tracker_f32.npz")
+    cfg = {"device": DEV, "dtype": "float", "color": "gray",
+           "pyr": {"start_level": 0, "end_level": 3, "depth_interp_mode": "nearest_neighbor"},
+           "term_criteria": {"max_iter": 50, "delta_norm": 1.0e-3, "rel_tol": 1.0e-3, "grad_norm": 1.0},
+           "sigmas": {"photo": 1.0e-1},
+           "keyframing": {"kf_depth_motion_ratio": 0.03, "kf_num_pixels_frac": 0.75, "one_way_freq": 3}}
+    rgb, depth, T = dev(G["rgb"]), dev(G["depth"]), dev(G["poses_gt"])
+    H, W = rgb.shape[-2:]
+    trk = Tracking(cfg, G["K"].clone(), (H, W))
+    trk.setup()
+    aff0 = torch.zeros((1, 2, 1), device=DEV, dtype=torch.float32)
+    trk.update_kf_reference(([1.0], rgb[0:1], T[0:1], aff0, depth[0:1]))
+    kinds, second = [], int(G["second_kf_at"])
+    worst_T = worst_med = 0.0
+    worst_n = 0
+    for k in range(1, rgb.shape[0]):
+        if k - 1 == second:
+            trk.update_kf_reference(([1.0 + second], rgb[second:second + 1], T[second:second + 1], aff0, depth[second:second + 1]))
+            assert (trk.T_curr_kf.cpu() - G["rebased_T_curr_kf"]).abs().max().item() < 5e-6
+            assert (trk.aff_curr_kf.cpu() - G["rebased_aff_curr_kf"]).abs().max().item() < 5e-6
+        viz, mp = trk.handle_frame((1.0 + k, rgb[k:k + 1]))
+        kinds.append(0 if mp is None else (1 if mp[0] == "keyframe" else 2))
+        n_seen, med = trk.last_reproj_stats
+        worst_T = max(worst_T, (trk.T_curr_kf.cpu() - G[f"T_curr_kf_{k}"]).abs().max().item(),
+                      (viz[1].cpu() - G[f"T_w_curr_{k}"]).abs().max().item())
+        worst_n = max(worst_n, abs(int(n_seen) - int(G[f"n_reproj_{k}"])))
+        worst_med = max(worst_med, abs(float(med) - float(G[f"median_depth_{k}"])))
+        assert (trk.aff_curr_kf.cpu() - G[f"aff_curr_kf_{k}"]).abs().max().item() < 5e-5
+    report("tracker", kinds=kinds, pose_abs_err=worst_T, n_reproj_diff=worst_n, median_depth_err=worst_med)
+    assert kinds == [int(x) for x in G["kinds"]]
+    assert worst_T < 5e-6 and worst_n <= 3 and worst_med < 1e-5
