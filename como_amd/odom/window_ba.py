@@ -55,7 +55,8 @@ class WindowBA:
         B, _, self.Himg, self.Wimg = state["kf_img_and_grads"].shape
         self.B = B
         self.m = state["coords_m"].shape[1]
-        nrec = 0
+        rec_poses = state.get("recent_poses")
+        nrec = int(rec_poses.shape[0]) if rec_poses is not None else 0      # one-way frames (Mapping.add_one_way_frame)
         self.F = B + nrec
         self.intrinsics = f64(state["intrinsics"])
         # all frame poses / affine params in ONE buffer each (keyframes first): the views below alias it
@@ -67,7 +68,12 @@ class WindowBA:
         self.kf_aff_params = self.aff_all[:B].view(B, 2, 1)
         self.recent_poses = self.poses_all[B:]
         self.recent_aff_params = self.aff_all[B:].view(nrec, 2, 1)
-        self.recent_timestamps = torch.empty((0,), device=dev, dtype=self.dt)
+        if nrec:
+            self.poses_all[B:] = f64(rec_poses)
+            self.aff_all[B:] = f64(state["recent_aff_params"]).reshape(nrec, 2)
+            self.recent_timestamps = state["recent_timestamps"]
+        else:
+            self.recent_timestamps = torch.empty((0,), device=dev, dtype=self.dt)
         self.P_m = f64(state["P_m"])
         self.correspondence_mask = state["correspondence_mask"]
         self.obs_ref_mask = state["obs_ref_mask"].contiguous()
@@ -76,7 +82,10 @@ class WindowBA:
         self.K_mm_inv = f64(state["K_mm_inv"])
         self.kf_timestamps = state["kf_timestamps"]
         # per-pixel data in pix_dtype
-        self.img = state["kf_img_and_grads"].to(pix_dtype).contiguous()
+        # keyframe image stacks followed by the one-way frames' in ONE buffer (targets are addressed by element offset)
+        imgs = state["kf_img_and_grads"] if not nrec else torch.cat((state["kf_img_and_grads"],
+                                                                      state["recent_img_and_grads"].to(state["kf_img_and_grads"].dtype)))
+        self.img = imgs.to(pix_dtype).contiguous()
         self.Kt = state["Knm_Kmminv"].to(pix_dtype).reshape(B, self.Himg * self.Wimg, self.m).contiguous()
         self.K_pix = self.intrinsics[0].to(pix_dtype).contiguous()
         self.median_depths = (f64(state["median_depth_init"]) if "median_depth_init" in state
@@ -92,11 +101,11 @@ class WindowBA:
     def _prepare_topology(self):
         B, dev, m = self.B, self.dev, self.m
         w = self.cfg["photo_construction"]["nonmax_suppression_window"]
-        coords_n, _ = smap.subselect_pixels(self.img, w)                       # Mapping.py:665-668
+        coords_n, _ = smap.subselect_pixels(self.img[:B], w)                   # Mapping.py:665-668
         self.coords_n = coords_n
         self.n = coords_n.shape[1]
         self.pixidx = (coords_n[..., 0] * self.Wimg + coords_n[..., 1]).to(torch.int32).contiguous()
-        self.vals_n = torch.gather(self.img[:, 0].reshape(B, -1), 1, self.pixidx.long()).contiguous()
+        self.vals_n = torch.gather(self.img[:B, 0].reshape(B, -1), 1, self.pixidx.long()).contiguous()
         self.remap, paired = smap.get_batch_remap_function(self.correspondence_mask)
         landmark_ids, _ = paired
         self.point_inds = lin_sys.landmark_to_batched_3d_point_inds(landmark_ids, B)
@@ -129,7 +138,8 @@ class WindowBA:
                                                         self.cfg["photo_construction"])
         self.kf_pairs, self.one_way_pairs = [ref, tgt], [ow_kf, ow_t]
         self.table = photo.PairTable(ref + ow_kf, tgt + ow_t, [False] * len(ref) + [True] * len(ow_kf), B, self.kf_inds,
-                                     self.recent_inds, self.landmark_inds, 3 * self.Himg * self.Wimg, 0, dev)
+                                     self.recent_inds, self.landmark_inds, 3 * self.Himg * self.Wimg,
+                                     B * 3 * self.Himg * self.Wimg, dev)
         # H | g | err packed in ONE buffer: the multi-GPU exchange of the normal equations is a single all-reduce
         D = self.dim
         self.sys = torch.zeros((D * D + D + 1,), device=dev, dtype=self.dt)
@@ -289,6 +299,9 @@ class WindowBA:
                                                  self.recent_aff_params, self.recent_inds, self.P_m, self.lm_start)
         self.kf_poses.copy_(kp)
         self.kf_aff_params.copy_(ka)
+        if self.F > self.B:
+            self.recent_poses.copy_(rp)
+            self.recent_aff_params.copy_(ra)
         self.P_m.copy_(Pn)
         self.delta = delta
         return delta

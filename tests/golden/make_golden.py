@@ -545,6 +545,8 @@ if __name__ == "__main__":
         save("ba_window_f32.npz", window_case(torch.float32, 3, 48, 64, 8, 2, seed=1, with_recent=False))
         save("ba_window_recent_f64.npz", window_case(torch.float64, 4, 48, 64, 8, 2, seed=2, with_recent=True, save_dense=False,
                                                      window_full=False))
+        save("ba_window_recent_full_f64.npz", window_case(torch.float64, 4, 48, 64, 8, 2, seed=3, with_recent=True, save_dense=False,
+                                                          window_full=True))
     if "track" in which:
         save("tracking_f32.npz", tracking_case(96, 128, 3, seed=0))
     if "sfm" in which:

@@ -867,3 +867,35 @@ def test_tracking_state_machine_vs_golden():
     report("tracker", kinds=kinds, pose_abs_err=worst_T, n_reproj_diff=worst_n, median_depth_err=worst_med)
     assert kinds == [int(x) for x in G["kinds"]]
     assert worst_T < 5e-6 and worst_n <= 3 and worst_med < 1e-5
+
+
+@pytest.mark.parametrize("name,full", [("ba_window_recent_f64.npz", False), ("ba_window_recent_full_f64.npz", True)])
+def test_window_iterate_with_one_way_frames_vs_golden(name, full):
+    """Mapping.iterate()-equivalent with one-way (recent) frames in the window: before the window is full (mean-log-depth
+    scale prior, reference-signature path) and with a full window (anchors; fused HIP chain).  float64 pixel path."""
+    import copy
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    G = load_golden(name)
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = 2
+    st = {k: dev(G[k]) for k in ("intrinsics", "kf_poses", "kf_aff_params", "kf_img_and_grads", "coords_m", "correspondence_mask",
+                                 "P_m", "kf_timestamps", "obs_ref_mask", "pm_first_obs", "L_mm", "K_mm_inv", "pose_anchor",
+                                 "recent_poses", "recent_aff_params", "recent_img_and_grads", "recent_timestamps")}
+    st["Knm_Kmminv"] = prep_predictor(dev(G["cov_params_img"]), dev(G["coords_m"]), 1.0)[2]
+    if full:
+        st["P_anchor"] = dev(G["P_anchor"])
+    else:
+        st["init_scale_anchor"] = dev(G["init_scale_anchor"])
+    wb = WindowBA(st, cfg=cfg, pix_dtype=torch.float64, window_full=full)
+    assert wb.fused == full and wb.F == wb.B + G["recent_poses"].shape[0]
+    wb.median_depths.copy_(dev(G["median_depths_in"]))
+    delta = wb.iterate()
+    perr = (wb.kf_poses.cpu() - G["kf_poses_new"]).abs().max().item()
+    rerr = (wb.recent_poses.cpu() - G["recent_poses_new"]).abs().max().item()
+    aerr = (wb.recent_aff_params.cpu().reshape(-1) - G["recent_aff_new"].reshape(-1)).abs().max().item()
+    report("window_iterate_recent", full=full, H_rel=rel_err(wb.H, G["H_full"]), delta_rel=rel_err(delta, G["delta"]), kf_pose_err=perr,
+           recent_pose_err=rerr, recent_aff_err=aerr)
+    assert rel_err(wb.H, G["H_full"]) < 1e-8 and rel_err(wb.g, G["g_full"]) < 1e-8
+    assert perr < 1e-9 and rerr < 1e-9 and aerr < 1e-9
+    assert (wb.P_m.cpu() - G["P_new"]).abs().max().item() < 1e-8
