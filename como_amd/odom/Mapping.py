@@ -1,0 +1,359 @@
+"""Headless keyframe-window mapper: the state machine of the reference's `Mapping` (como/odom/Mapping.py:42-968) without the
+GUI / process / queue plumbing.  Same method names, arguments and state attributes (`kf_poses`, `P_m`,
+`correspondence_mask`, `recent_poses`, ...), so the reference's caller code can drive it unchanged.
+
+What runs where:
+  * `iterate()`                 -> `WindowBA` (odom/window_ba.py): the fused HIP chain (scaffold, dense reference, photometric
+                                   system, priors, Cholesky, update), hipGraph-replayed once the window is full; the
+                                   reference-signature path while it fills.  The WindowBA object is rebuilt whenever the
+                                   window's topology changes (new keyframe / one-way frame) and owns the iteration state in
+                                   between; this class's attributes are refreshed from it after every iteration.
+  * `add_keyframe()`            -> Scharr gradients (csrc/image.hip), DepthCov network (csrc/nn.hip), `track_and_init`
+                                   (frontend/corr.py: HIP sampler + covariance kernels), K~ predictor (csrc/densify.hip).
+  * window bookkeeping (correspondence mask, anchors, pruning): small torch ops on the device, as in the reference.
+
+Deviations, documented: (1) no checkpoint loader -- `setup(model)` takes a `DepthCovModule` mirror (or a state dict);
+(2) `depth_imgs` is evaluated on demand from the stored log-depths instead of on every iteration (the reference recomputes
+B x H x W x m products per GN iteration only to keep this cache warm); (3) between topology changes the scaffold's
+re-initialisation depth uses the median of the sub-selected reference pixels (the reference: median of the full depth image
+of the previous iteration) -- it only matters for landmarks that fall behind a camera.
+"""
+import torch
+
+from como_amd.depth_cov.core.covariance import prep_predictor as _prep_predictor
+from como_amd.depth_cov.core.DepthCovModule import DepthCovModule, run_model as _run_model
+from como_amd.geometry.affine_brightness import get_aff_w_curr
+from como_amd.geometry.camera import backprojection
+from como_amd.geometry.transforms import get_T_w_curr, transform_points
+from como_amd.odom.frontend.corr import track_and_init
+from como_amd.odom.window_ba import WindowBA
+from como_amd.utils.coords import swap_coords_xy
+from como_amd.depth_cov.nn.UNet import resize_aa
+from como_amd.utils.image_processing import ImageGradientModule, rgb_to_grayscale
+
+_DTYPES = {"float": torch.float32, "double": torch.float64}
+
+
+def normalizeSE3_inplace(T):
+    """Project the rotation block onto SO(3) (reference geometry/lie_algebra.py:98-101)."""
+    U, _, Vh = torch.linalg.svd(T[..., :3, :3])
+    T[..., :3, :3] = U @ Vh
+
+
+class Mapping:
+    def __init__(self, cfg, intrinsics):
+        self.cfg = cfg
+        self.device = cfg["device"]
+        self.dtype = _DTYPES[cfg["dtype"]] if isinstance(cfg["dtype"], str) else cfg["dtype"]
+        self.pix_dtype = _DTYPES[cfg.get("pix_dtype", "float")]      # element type of the per-pixel kernels
+        self.intrinsics = intrinsics.unsqueeze(0)
+        self.is_init = False
+        self._ba = None
+
+    def setup(self, model=None):
+        self.init_basic_vars()
+        self.load_model(model)
+        self.init_keyframe_vars()
+        self.init_prior_vals()
+        self.reset_iteration_vars(new_kf=True, converged=True)
+
+    # ---- construction (Mapping.py:70-136) -----------------------------------------------------------------------------
+    def init_basic_vars(self):
+        c = {"gray": 1, "rgb": 3}[self.cfg["color"]]
+        self.intrinsics = self.intrinsics.to(device=self.device, dtype=self.dtype)
+        self.gradient_module = ImageGradientModule(channels=c, device=self.device, dtype=self.dtype)
+        self.last_kf_send_time = 0.0
+
+    def init_keyframe_vars(self):
+        e = lambda dt=None: torch.empty((0), device=self.device, dtype=dt or self.dtype)
+        self.kf_timestamps = []
+        self.rgb, self.kf_img_and_grads, self.cov_params_img = e(), e(), e()
+        self.kf_poses, self.kf_aff_params = e(), e()
+        self.depth_dims = []
+        self.pm_first_obs, self.pm, self.logzm = e(), e(), e()
+        self.L_mm, self.Kmm_inv, self.Knm_Kmminv = e(), e(), e()
+        self.correspondence_mask = e()
+        self.P_m = e()
+        self.obs_ref_mask = e(torch.bool)
+        self.recent_timestamps = []
+        self.recent_img_and_grads, self.recent_poses, self.recent_aff_params = e(), e(), e()
+        self._depth_cache = None
+
+    def init_prior_vals(self):
+        self.window_full = False
+        self.pose_anchor = torch.empty((0), device=self.device, dtype=self.dtype)
+        self.aff_anchor = torch.empty((0), device=self.device, dtype=self.dtype)
+        self.sparse_log_depth_anchor = torch.empty((0), device=self.device, dtype=self.dtype)
+        self.init_scale_anchor = None
+
+    def load_model(self, model=None):
+        """Mapping.py:397-407.  model: DepthCovModule mirror, a state dict, or None (then cfg['model_path'] must point to a
+        torch-saved state dict)."""
+        self.cov_level = -1
+        self.network_size_list = list(self.cfg.get("network_size", [192, 256]))
+        self.network_size = torch.tensor(self.network_size_list, device=self.device)
+        if model is None:
+            model = torch.load(self.cfg["model_path"], map_location=self.device)
+        if isinstance(model, dict):
+            sd = model.get("state_dict", model)
+            model = DepthCovModule({k: v.to(self.device) for k, v in sd.items()})
+        self.model = model
+
+    # ---- window helpers (Mapping.py:470-497) ----------------------------------------------------------------------------
+    def _cat(self, name, new_var, i):
+        old = getattr(self, name)
+        setattr(self, name, new_var.clone() if old.numel() == 0 and old.dim() == 1 else torch.cat((old[i:, ...], new_var), dim=0))
+
+    def window_cat_helper_list(self, var, new_var, i):
+        del var[:i]
+        var.append(new_var)
+
+    def get_kf_start_window_ind(self):
+        return -self.cfg["graph"]["num_keyframes"] + 1
+
+    def get_recent_start_window_ind(self):
+        return -self.cfg["graph"]["num_one_way_frames"] + 1
+
+    def reset_iteration_vars(self, new_kf, converged=False):
+        self.converged = converged
+        self._ba = None                                   # topology (or a frame's initial values) changed
+        if new_kf:
+            self.iter = 0
+            self.total_err_prev = float("inf")
+
+    def get_safe_ind(self, ind):
+        n = self.kf_poses.shape[0]
+        return n - 1 if ind == -1 or ind >= n else ind
+
+    # ---- images / network / predictor ------------------------------------------------------------------------------------
+    def get_img_and_grads(self, rgb):
+        img = rgb_to_grayscale(rgb) if self.cfg["color"] == "gray" else rgb.clone()
+        gx, gy = self.gradient_module(img)
+        return torch.cat((img, gx, gy), dim=1)
+
+    def run_model(self, rgb):
+        """Mapping.py:409-428 on the HIP network."""
+        return _run_model(self.model, rgb, network_size=self.network_size_list, dtype=self.dtype,
+                          graphed=self.cfg.get("graph_network", True))
+
+    def prep_predictor(self, cov_params_img, coords_m):
+        """Mapping.py:430-468 -> (K_mm_inv, L_mm, Knm_Kmminv (b,H,W,m)); K_nm is never materialised (csrc/densify.hip)."""
+        size = tuple(self.kf_img_and_grads.shape[-2:]) if self.kf_img_and_grads.numel() else tuple(cov_params_img.shape[-2:])
+        return _prep_predictor(cov_params_img, coords_m.to(cov_params_img.dtype), self.model.get_scale(-1), photo_img_size=size)
+
+    # ---- tracker-facing accessors ----------------------------------------------------------------------------------------
+    def find_kf_from_timestamp(self, kf_timestamp):
+        for i in range(len(self.kf_timestamps) - 1, -1, -1):
+            if kf_timestamp == self.kf_timestamps[i]:
+                return i
+        return None
+
+    def get_curr_world_pose(self, pose_curr_kf, kf_ind):
+        return get_T_w_curr(self.kf_poses[kf_ind:kf_ind + 1, ...], pose_curr_kf)
+
+    def get_curr_world_aff(self, aff_curr_kf, kf_ind):
+        return get_aff_w_curr(self.kf_aff_params[kf_ind:kf_ind + 1, ...], aff_curr_kf)
+
+    @property
+    def depth_imgs(self):
+        """(B,1,H,W) depth images exp(K~ logz_m) of the stored log-depths (Mapping.store_vars :753-755), cached until the
+        log-depths change."""
+        if self._depth_cache is None and self.logzm.numel():
+            b, h, w, m = self.Knm_Kmminv.shape
+            logz = (self.Knm_Kmminv.reshape(b, h * w, m) @ self.logzm.reshape(b, m, 1)).reshape(b, 1, h, w)
+            self._depth_cache = torch.exp(logz)
+        return self._depth_cache
+
+    def get_kf_ref_data(self, ind=-1):
+        """Mapping.py:499-512: the newest `track_ref.num_keyframes` keyframes for the tracker."""
+        end = self.kf_poses.shape[0]
+        ind = max(0, end - self.cfg["track_ref"]["num_keyframes"])
+        return (self.kf_timestamps[ind:end], self.rgb[ind:end], self.kf_poses[ind:end], self.kf_aff_params[ind:end],
+                self.depth_imgs[ind:end])
+
+    def store_vars(self, pm, logzm, Knm_Kmminv):
+        """Mapping.py:749-758"""
+        self.pm, self.logzm = pm, logzm
+        self._depth_cache = None
+        d = self.depth_imgs
+        self.median_depths = torch.median(d.reshape(d.shape[0], -1), dim=1).values
+
+    # ---- keyframe insertion (Mapping.py:138-229) -------------------------------------------------------------------------
+    def init_keyframe(self, rgb, cov_params_img, coords_m, pose_init, logz_m, aff_init, timestamp):
+        """First keyframe with given inducing points and log-depths (from the two-frame initialisation)."""
+        img_and_grads = self.get_img_and_grads(rgb)
+        cov_params_img = resize_aa(cov_params_img, rgb.shape[-2:])
+        self.initialize_pose_vars(pose_init, aff_init)
+        self.initialize_kf_img_vars_vars(rgb, img_and_grads, cov_params_img)
+        Kmm_inv, L_mm, Knm_Kmminv = self.prep_predictor(cov_params_img, coords_m)
+        depth_dim = coords_m.shape[1]
+        pm = swap_coords_xy(coords_m)
+        z_m = torch.exp(logz_m)
+        self.initialize_sparse_pixel_vars(pm, z_m, depth_dim, Kmm_inv, L_mm, Knm_Kmminv)
+        Pc_m, _ = backprojection(self.intrinsics[0], pm, z_m)
+        Pw_m, _, _ = transform_points(pose_init, Pc_m)
+        self.initialize_sparse_landmark_vars(torch.ones((1, depth_dim), device=self.device, dtype=torch.bool), Pw_m.squeeze(0))
+        self.kf_timestamps = [timestamp]
+        self.store_vars(pm, logz_m, Knm_Kmminv)
+
+    def add_keyframe(self, rgb, kf_pose_init, kf_aff_init, timestamp):
+        img_and_grads = self.get_img_and_grads(rgb)
+        cov_params_img = self.run_model(rgb)
+        coords_m_last = swap_coords_xy(self.pm[-1:, ...])
+        zm_last = torch.exp(self.logzm[-1:, ...])
+        coords_m_new, z_m_new, corr_mask, coords_m, zm_first_obs = track_and_init(
+            self.kf_poses[-1:, ...], kf_pose_init, coords_m_last, zm_last, self.depth_imgs[-1:, ...], cov_params_img,
+            self.intrinsics, self.model, self.cfg["corr"], self.cfg["sampling"], self.kf_img_and_grads.shape[-2:])
+        p_m_new = swap_coords_xy(coords_m_new).to(dtype=z_m_new.dtype)
+        Pc_new, _ = backprojection(self.intrinsics[0], p_m_new, z_m_new)
+        Pw_new, _, _ = transform_points(kf_pose_init, Pc_new)
+        Kmm_inv, L_mm, Knm_Kmminv = self.prep_predictor(cov_params_img, coords_m)
+        pm_first_obs = swap_coords_xy(coords_m)
+        self.window_cat_helper_list(self.kf_timestamps, timestamp, self.get_kf_start_window_ind())
+        self.initialize_pose_vars(kf_pose_init, kf_aff_init)
+        self.initialize_kf_img_vars_vars(rgb, img_and_grads, cov_params_img)
+        self.initialize_sparse_pixel_vars(pm_first_obs, zm_first_obs, coords_m_new.shape[1], Kmm_inv, L_mm, Knm_Kmminv)
+        self.initialize_sparse_landmark_vars(corr_mask, Pw_new.squeeze(0))
+        self.reset_iteration_vars(new_kf=True)
+        self.store_vars(self.pm, self.logzm, self.Knm_Kmminv)
+        self.prune_one_way()
+
+    def prune_one_way(self):
+        """Drop one-way frames older than the oldest keyframe (Mapping.py:231-245)."""
+        oldest = self.kf_timestamps[0]
+        r = 0
+        for i, ts in enumerate(self.recent_timestamps):
+            if ts < oldest:
+                r = i + 1
+        if r:
+            self.recent_timestamps = self.recent_timestamps[r:]
+            self.recent_img_and_grads = self.recent_img_and_grads[r:]
+            self.recent_poses = self.recent_poses[r:]
+            self.recent_aff_params = self.recent_aff_params[r:]
+            self._ba = None
+
+    def add_one_way_frame(self, rgb, pose_init, aff_init, timestamp):
+        img_and_grads = self.get_img_and_grads(rgb)
+        i = self.get_recent_start_window_ind()
+        self.window_cat_helper_list(self.recent_timestamps, timestamp, i)
+        self._cat("recent_img_and_grads", img_and_grads, i)
+        self._cat("recent_poses", pose_init, i)
+        self._cat("recent_aff_params", aff_init, i)
+        self.reset_iteration_vars(new_kf=False)
+
+    # ---- per-keyframe state (Mapping.py:262-367) -------------------------------------------------------------------------
+    def initialize_pose_vars(self, pose_init, aff_init):
+        num_kf = self.kf_poses.shape[0] if self.kf_poses.dim() > 1 else 0
+        window_empty = num_kf == 0
+        self.window_full = num_kf >= self.cfg["graph"]["num_keyframes"]
+        i = self.get_kf_start_window_ind()
+        pose_init = pose_init.clone()
+        normalizeSE3_inplace(pose_init)
+        self._cat("kf_poses", pose_init, i)
+        self._cat("kf_aff_params", aff_init, i)
+        if window_empty or self.window_full:
+            # gauge anchors: oldest keyframe's pose; affine parameters re-expressed relative to it
+            self.pose_anchor = self.kf_poses[0:1, ...].clone()
+            self.kf_aff_params = self.kf_aff_params - self.kf_aff_params[0:1, ...]
+            self.aff_anchor = torch.zeros_like(self.kf_aff_params[0:1, ...])
+
+    def initialize_kf_img_vars_vars(self, rgb, img_and_grads, cov_params_img):
+        i = self.get_kf_start_window_ind()
+        self._cat("rgb", rgb, i)
+        self._cat("kf_img_and_grads", img_and_grads, i)
+        self._cat("cov_params_img", cov_params_img, i)
+
+    def initialize_sparse_pixel_vars(self, pm_first_obs, zm_first_obs, new_depth_dim, Kmm_inv, L_mm, Knm_Kmminv):
+        i = self.get_kf_start_window_ind()
+        self.window_cat_helper_list(self.depth_dims, new_depth_dim, i)
+        self._cat("pm_first_obs", pm_first_obs, i)
+        self._cat("pm", pm_first_obs, i)
+        self._cat("logzm", torch.log(zm_first_obs), i)
+        self._depth_cache = None
+        # which of a keyframe's inducing points were first observed in it (the newly sampled ones sit at the end)
+        first = torch.zeros((1, self.cfg["sampling"]["max_num_coords"]), device=self.device, dtype=torch.bool)
+        first[:, -new_depth_dim:] = True       # as the reference: with 0 new points the slice [-0:] marks ALL (Mapping.py:312)
+        self._cat("obs_ref_mask", first, i)
+        self._cat("Kmm_inv", Kmm_inv, i)
+        self._cat("L_mm", L_mm, i)
+        self._cat("Knm_Kmminv", Knm_Kmminv, i)
+
+    def initialize_sparse_landmark_vars(self, corr_mask, P):
+        """Correspondence mask (num_kf x num_landmarks) and landmark list after inserting a keyframe (Mapping.py:321-367)."""
+        i = self.get_kf_start_window_ind()
+        num_kf = self.correspondence_mask.shape[0] if self.correspondence_mask.dim() > 1 else 0
+        self.window_full = num_kf >= self.cfg["graph"]["num_keyframes"]
+        n_new = P.shape[0]
+        if num_kf == 0:
+            self.correspondence_mask = corr_mask
+            self.P_m = P
+        else:
+            old = self.correspondence_mask
+            alive = old[i:, :].any(dim=0)                          # landmarks still seen by a keyframe that stays
+            tracked = torch.zeros_like(old[0, :])
+            tracked[torch.nonzero(old[-1, :])[:, 0]] = corr_mask   # the last keyframe's landmarks that were tracked on
+            kept = torch.cat((old[i:, alive], tracked[None, alive]), dim=0)
+            fresh = torch.zeros((kept.shape[0], n_new), device=self.device, dtype=torch.bool)
+            fresh[-1, :] = True
+            self.correspondence_mask = torch.cat((kept, fresh), dim=1)
+            self.P_m = torch.cat((self.P_m[alive, :], P), dim=0)
+        if self.window_full:
+            # landmarks of the (new) oldest keyframe carry what left the window: pin them
+            self.P_m_anchors = self.P_m[self.correspondence_mask[0, :], :]
+
+    # ---- tracker messages (Mapping.py:580-601) ---------------------------------------------------------------------------
+    def handle_tracking_data(self, data):
+        kf_viz_data, kf_updated = None, False
+        if data[0] in ("one-way", "keyframe"):
+            rgb, pose_curr_kf, aff_curr_kf, kf_timestamp, timestamp = data[1:]
+            k = self.find_kf_from_timestamp(kf_timestamp)
+            pose_w = self.get_curr_world_pose(pose_curr_kf.to(self.dtype), k)
+            aff_w = self.get_curr_world_aff(aff_curr_kf.to(self.dtype), k)
+            if data[0] == "one-way":
+                self.add_one_way_frame(rgb.to(self.dtype), pose_w, aff_w, timestamp)
+            else:
+                self.add_keyframe(rgb.to(self.dtype), pose_w, aff_w, timestamp)
+                kf_updated = True
+        return kf_viz_data, kf_updated
+
+    # ---- one Gauss-Newton iteration over the window (Mapping.py:760-968) -------------------------------------------------
+    def _window_state(self):
+        ts = lambda lst: torch.as_tensor([float(t) for t in lst], device=self.device, dtype=self.dtype)
+        st = {"intrinsics": self.intrinsics, "kf_poses": self.kf_poses, "kf_aff_params": self.kf_aff_params,
+              "kf_img_and_grads": self.kf_img_and_grads, "coords_m": self.pm, "P_m": self.P_m,
+              "correspondence_mask": self.correspondence_mask, "obs_ref_mask": self.obs_ref_mask,
+              "pm_first_obs": self.pm_first_obs, "L_mm": self.L_mm, "K_mm_inv": self.Kmm_inv, "Knm_Kmminv": self.Knm_Kmminv,
+              "kf_timestamps": ts(self.kf_timestamps), "median_depth_init": self.median_depths,
+              "pose_anchor": self.pose_anchor, "init_scale_anchor": self.init_scale_anchor}
+        if self.window_full:
+            st["P_anchor"] = self.P_m_anchors
+        if len(self.recent_timestamps):
+            st.update({"recent_poses": self.recent_poses, "recent_aff_params": self.recent_aff_params,
+                       "recent_img_and_grads": self.recent_img_and_grads, "recent_timestamps": ts(self.recent_timestamps)})
+        return st
+
+    def iterate(self):
+        if self._ba is None:
+            cfg = {"photo_construction": self.cfg["photo_construction"], "sigmas": self.cfg["sigmas"]}
+            self._ba = WindowBA(self._window_state(), cfg=cfg, pix_dtype=self.pix_dtype, window_full=self.window_full)
+            if self._ba.fused and self.cfg.get("graph_iterate", False):
+                self._ba.capture(warmup=0)
+        ba = self._ba
+        ba.step()
+        # refresh the public state from the solver's buffers
+        self.kf_poses = ba.kf_poses.to(self.dtype).clone()
+        self.kf_aff_params = ba.kf_aff_params.to(self.dtype).clone()
+        if ba.F > ba.B:
+            self.recent_poses = ba.recent_poses.to(self.dtype).clone()
+            self.recent_aff_params = ba.recent_aff_params.to(self.dtype).clone()
+        self.P_m = ba.P_m.to(self.dtype).clone()
+        self.kf_pairs, self.one_way_pairs = ba.kf_pairs, ba.one_way_pairs
+        if ba.fused:
+            pm, logzm = ba.w["pm"], ba.w["logzm"].unsqueeze(-1)
+        else:
+            pm, logzm = ba.pm, ba.logzm
+        self.pm, self.logzm = pm.to(self.dtype).clone(), logzm.to(self.dtype).clone()
+        self._depth_cache = None
+        self.median_depths = ba.median_depths.to(self.dtype).clone()
+        self.iter += 1
+        return self.converged

@@ -20,7 +20,7 @@ def load_golden(name):
     out = {}
     for k in d.files:
         a = d[k]
-        out[k] = torch.from_numpy(a) if a.dtype != object else a
+        out[k] = torch.from_numpy(a) if a.dtype.kind in "fiub" else a        # strings (tags) stay numpy
     return out
 
 

@@ -529,9 +529,113 @@ def corr_case(seed=11, H=48, W=64, m=12, nmax=16):
             "coords_all": coords_all, "z_all": z_all}
 
 
+MAP_CFG = {"device": "cpu", "dtype": "double", "color": "gray", "model_path": None, "track_ref": {"num_keyframes": 1},
+           "graph": {"num_keyframes": 3, "num_one_way_frames": 4},
+           "photo_construction": {"nonmax_suppression_window": 2, "pairwise_batch_size": 128, "radius_thresh": 0.0,
+                                  "degrees_thresh": 0.0},
+           "term_criteria": {"max_iter": 20, "delta_norm": 1.0e-8, "abs_tol": 1.0e-6, "rel_tol": 1.0e-6},
+           "sigmas": {"photo": 1.0e-1, "mean_depth_prior": 1.0e-2, "scale_prior": 1.0e-4, "pose_prior": 1.0e-6},
+           "sampling": {"mode": "greedy_conditional_entropy", "max_num_coords": 12, "max_stdev_thresh": 1.0e-2, "border": 3,
+                        "fixed_var": 0.0, "dist_thresh": 1.0e-1},
+           "corr": CORR_PARAMS}
+MAP_NET_SIZE = [32, 64]
+MAP_SNAP = ("kf_poses", "kf_aff_params", "P_m", "correspondence_mask", "obs_ref_mask", "pm_first_obs", "pm", "logzm",
+            "recent_poses", "recent_aff_params", "pose_anchor", "median_depths")
+
+
+def mapping_case(seed=5, H=48, W=64):
+    """The reference's Mapping state machine (Mapping.py:138-367, 760-968) driven headless on CPU: first keyframe from given
+    inducing points, a second keyframe, a one-way frame, a third keyframe, and a fourth that makes the window (3 keyframes)
+    slide -- two GN iterations after every insertion.  config/como.yml mapping section with a 3-keyframe window, 12
+    inducing points, 48x64 images and a 32x64 network input; the DepthCov weights are the seeded ones of
+    synth.depthcov_state_dict."""
+    import como.odom.Mapping as rmap
+    import torchvision.transforms.functional as TF
+    dtype = torch.float64
+    model = DepthCovModule()
+    missing, unexpected = model.load_state_dict(synth.depthcov_state_dict(0), strict=False)
+    assert not unexpected
+    model.eval()
+    scene = synth.PlaneScene(seed=seed, freq_scale=W / 640.0)
+    K = synth.intrinsics_for(H, W)
+    T = synth.gt_poses(6, step=0.02, deg=0.8)
+    g = torch.Generator().manual_seed(seed)
+    rgbs, depths = [], []
+    for k in range(6):
+        I, z = scene.render(T[k], K, H, W)
+        I = I + 0.002 * torch.randn(I.shape, generator=g, dtype=torch.float64)
+        rgbs.append(I[None, None].repeat(1, 3, 1, 1).to(dtype))
+        depths.append(z)
+    mp = rmap.Mapping(MAP_CFG, K.to(dtype))
+    mp.init_basic_vars()                                            # setup() minus init_gpu / checkpoint loading
+    mp.cov_level = -1
+    mp.network_size = torch.tensor(MAP_NET_SIZE)
+    mp.network_size_list = list(MAP_NET_SIZE)
+    mp.model = model
+    mp.init_keyframe_vars()
+    mp.init_prior_vals()
+    mp.reset_iteration_vars(new_kf=True, converged=True)
+    out = {"K": K.to(dtype), "rgb": torch.cat(rgbs), "poses_gt": T.to(dtype)}
+    snaps = []
+
+    def snap(tag):
+        i = len(snaps)
+        snaps.append(tag)
+        for name in MAP_SNAP:
+            v = getattr(mp, name)
+            out[f"s{i}_{name}"] = v.clone() if torch.is_tensor(v) else torch.as_tensor(v)
+        out[f"s{i}_kf_timestamps"] = torch.tensor(mp.kf_timestamps, dtype=dtype)
+        out[f"s{i}_recent_timestamps"] = torch.tensor(mp.recent_timestamps, dtype=dtype)
+        out[f"s{i}_depth_dims"] = torch.tensor(mp.depth_dims)
+        out[f"s{i}_window_full"] = torch.tensor(mp.window_full)
+        if hasattr(mp, "P_m_anchors"):
+            out[f"s{i}_P_m_anchors"] = mp.P_m_anchors.clone()
+
+    def perturbed(k, s):
+        xi = s * torch.randn((1, 6), generator=g, dtype=dtype)
+        return (T[k:k + 1] @ synth.se3_exp(xi)).to(dtype)
+
+    with torch.no_grad():
+        # keyframe 0: covariance image at network resolution, inducing points sampled on the image-size covariance image
+        rgb_r = TF.resize(rgbs[0], MAP_NET_SIZE, interpolation=TF.InterpolationMode.BILINEAR, antialias=True).float()
+        cov_net = model(rgb_r)[-1].to(dtype)
+        cov_img = TF.resize(cov_net, (H, W), interpolation=TF.InterpolationMode.BILINEAR, antialias=True)
+        sp = MAP_CFG["sampling"]
+        coords_m0, _ = rsamp.sample_sparse_coords(cov_img, sp["max_num_coords"], sp["mode"], sp["max_stdev_thresh"],
+                                                  border=sp["border"], terminate_early=False, dist_thresh=sp["dist_thresh"],
+                                                  signal_var=model.get_scale(-1), fixed_var=sp["fixed_var"])
+        coords_m0 = coords_m0.to(dtype)
+        cm = coords_m0[0].long()
+        logz0 = torch.log(depths[0][cm[:, 0], cm[:, 1]]).reshape(1, -1, 1) + 0.01 * torch.randn((1, cm.shape[0], 1), generator=g,
+                                                                                               dtype=dtype)
+        aff0 = torch.zeros((1, 2, 1), dtype=dtype)
+        out.update({"cov_net0": cov_net.clone(), "coords_m0": coords_m0.clone(), "logz_m0": logz0.clone()})   # the reference set_()s its state tensors in place
+        mp.init_keyframe(rgbs[0], cov_net, coords_m0, T[0:1].to(dtype).clone(), logz0, aff0.clone(), 1.0)
+        mp.init_scale_anchor = torch.mean(logz0)
+        out["init_scale_anchor"] = mp.init_scale_anchor
+        snap("init_keyframe")
+        inits = {}
+        for k, ts, kind in ((1, 2.0, "kf"), (2, 2.5, "ow"), (3, 3.0, "kf"), (4, 4.0, "kf")):
+            Tin, ain = perturbed(k, 2e-3), 0.01 * torch.randn((1, 2, 1), generator=g, dtype=dtype)
+            inits[f"pose_init_{k}"], inits[f"aff_init_{k}"] = Tin.clone(), ain.clone()
+            if kind == "kf":
+                mp.add_keyframe(rgbs[k], Tin, ain, ts)
+            else:
+                mp.add_one_way_frame(rgbs[k], Tin, ain, ts)
+            snap(f"add_{kind}_{k}")
+            mp.iterate()
+            mp.iterate()
+            snap(f"iterate2_after_{k}")
+        out.update(inits)
+    out["snap_tags"] = np.array(snaps)
+    return out
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net", "distill", "corr", "tracker"]
+    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net", "distill", "corr", "tracker", "mapping"]
+    if "mapping" in which:
+        save("mapping_f64.npz", mapping_case())
     if "tracker" in which:
         save("tracker_f32.npz", tracker_case())
     if "corr" in which:

@@ -899,3 +899,72 @@ def test_window_iterate_with_one_way_frames_vs_golden(name, full):
     assert rel_err(wb.H, G["H_full"]) < 1e-8 and rel_err(wb.g, G["g_full"]) < 1e-8
     assert perr < 1e-9 and rerr < 1e-9 and aerr < 1e-9
     assert (wb.P_m.cpu() - G["P_new"]).abs().max().item() < 1e-8
+
+
+def test_mapping_state_machine_vs_golden():
+    """Mapping mirror (como_amd/odom/Mapping.py) driven through the reference's sequence: first keyframe, second keyframe,
+    one-way frame, third keyframe, and a fourth that makes the 3-keyframe window slide, two GN iterations after every
+    insertion (float64 pixel path).  Window bookkeeping (correspondence mask, first-observation masks, timestamps,
+    landmark counts) must be identical; poses, landmarks and log-depths agree to what the float32 DepthCov network leaves
+    (its covariance image feeds the sampler and the depth distillation of every new keyframe)."""
+    from como_amd.depth_cov.core.DepthCovModule import DepthCovModule
+    from como_amd.odom.Mapping import Mapping
+    from como_amd.synth import depthcov_state_dict
+    G = load_golden("mapping_f64.npz")
+    cfg = {"device": DEV, "dtype": "double", "pix_dtype": "double", "color": "gray", "track_ref": {"num_keyframes": 1},
+           "graph": {"num_keyframes": 3, "num_one_way_frames": 4}, "network_size": [32, 64], "graph_network": False,
+           "photo_construction": {"nonmax_suppression_window": 2, "pairwise_batch_size": 128, "radius_thresh": 0.0,
+                                  "degrees_thresh": 0.0},
+           "sigmas": {"photo": 1.0e-1, "mean_depth_prior": 1.0e-2, "scale_prior": 1.0e-4, "pose_prior": 1.0e-6},
+           "sampling": {"mode": "greedy_conditional_entropy", "max_num_coords": 12, "max_stdev_thresh": 1.0e-2, "border": 3,
+                        "fixed_var": 0.0, "dist_thresh": 1.0e-1},
+           "corr": {"corr_mode": "logz", "corr_thresh": 3.0e-2, "distill_with_prior": True, "min_obs_depth": 0.0,
+                    "logz_grad_mag_thresh": 7.0e-2}}
+    mp = Mapping(cfg, G["K"].clone())
+    mp.setup(DepthCovModule({k: dev(v) for k, v in depthcov_state_dict(0).items()}))
+    rgb = dev(G["rgb"])
+    tags = [str(t) for t in G["snap_tags"]]
+    worst = {"pose": 0.0, "P": 0.0, "logz": 0.0, "aff": 0.0, "med": 0.0}
+
+    def check(i):
+        g = lambda n: G[f"s{i}_{n}"]
+        assert torch.equal(mp.correspondence_mask.cpu(), g("correspondence_mask")), tags[i]
+        assert torch.equal(mp.obs_ref_mask.cpu(), g("obs_ref_mask")), tags[i]
+        assert [float(t) for t in mp.kf_timestamps] == g("kf_timestamps").tolist(), tags[i]
+        assert [float(t) for t in mp.recent_timestamps] == g("recent_timestamps").tolist(), tags[i]
+        assert list(mp.depth_dims) == g("depth_dims").tolist() and bool(mp.window_full) == bool(g("window_full")), tags[i]
+        want = g("pm_first_obs")
+        got = mp.pm_first_obs.cpu()
+        sampled = (want == want.round()).all(dim=-1)                      # freshly sampled points sit on integer pixels
+        assert torch.equal(got[sampled], want[sampled]), tags[i]          # same sampled pixels
+        assert (got - want).abs().max().item() < 1e-4, tags[i]            # tracked ones: reprojections through estimated poses
+        worst["pose"] = max(worst["pose"], (mp.kf_poses.cpu() - g("kf_poses")).abs().max().item())
+        worst["aff"] = max(worst["aff"], (mp.kf_aff_params.cpu() - g("kf_aff_params")).abs().max().item())
+        worst["P"] = max(worst["P"], (mp.P_m.cpu() - g("P_m")).abs().max().item())
+        worst["logz"] = max(worst["logz"], (mp.logzm.cpu() - g("logzm")).abs().max().item())
+        worst["med"] = max(worst["med"], (mp.median_depths.cpu() - g("median_depths")).abs().max().item())
+        if g("recent_poses").numel():
+            worst["pose"] = max(worst["pose"], (mp.recent_poses.cpu() - g("recent_poses")).abs().max().item())
+        assert (mp.pose_anchor.cpu() - g("pose_anchor")).abs().max().item() < 1e-4, tags[i]
+        if f"s{i}_P_m_anchors" in G:
+            assert (mp.P_m_anchors.cpu() - G[f"s{i}_P_m_anchors"]).abs().max().item() < 1e-3, tags[i]
+
+    T0 = dev(G["poses_gt"])[0:1].clone()
+    mp.init_keyframe(rgb[0:1], dev(G["cov_net0"]), dev(G["coords_m0"]), T0, dev(G["logz_m0"]),
+                     torch.zeros((1, 2, 1), device=DEV, dtype=torch.float64), 1.0)
+    mp.init_scale_anchor = dev(G["init_scale_anchor"])
+    check(0)
+    i = 1
+    for k, ts, kind in ((1, 2.0, "kf"), (2, 2.5, "ow"), (3, 3.0, "kf"), (4, 4.0, "kf")):
+        Tin, ain = dev(G[f"pose_init_{k}"]).clone(), dev(G[f"aff_init_{k}"]).clone()
+        if kind == "kf":
+            mp.add_keyframe(rgb[k:k + 1], Tin, ain, ts)
+        else:
+            mp.add_one_way_frame(rgb[k:k + 1], Tin, ain, ts)
+        check(i)
+        mp.iterate()
+        mp.iterate()
+        check(i + 1)
+        i += 2
+    report("mapping", snapshots=len(tags), landmarks=int(mp.P_m.shape[0]), **{k + "_abs_err": v for k, v in worst.items()})
+    assert worst["pose"] < 1e-5 and worst["aff"] < 1e-4 and worst["P"] < 1e-3 and worst["logz"] < 1e-3 and worst["med"] < 2e-2
