@@ -166,3 +166,33 @@ def two_frame_sfm_pyr(Tji_init, sparse_log_depth_init, aff_init, test_coords_i, 
                                                              img_and_grads_j[l], dr_prior_dd, H_prior_d_d, intrinsics[l],
                                                              sigmas, term_criteria, init_cfg)
     return Tji, d, aff, coords_j, depths_j, mld
+
+
+def setup_reference(img_and_grads, sparse_coords_norm, model, cov_params_img, intrinsics):
+    """:55-112.  Per pyramid level (coarse -> fine) of the reference frame: intensities, test coordinates, the predictor
+    K~ = K_nm K_mm^-1 of the inducing points (kernel matrices from the HIP covariance modules; no jitter on K_mm here, as
+    the reference), plus the level intrinsics and the sparse-depth prior.  Test coordinates are ALL pixels in row-major
+    order (the reference draws the same set in a random order -- `torch.multinomial` without replacement over a mask of
+    ones -- which only permutes the terms of the sums)."""
+    from como_amd.depth_cov.core.gaussian_kernel import interpolate_kernel_params
+    from como_amd.utils.coords import get_test_coords, normalize_coordinates
+    from como_amd.utils.image_processing import IntrinsicsPyramidModule
+    c = img_and_grads[-1].shape[-3] // 3
+    dev, dt = img_and_grads[-1].device, img_and_grads[-1].dtype
+    intrinsics_pyr = IntrinsicsPyramidModule(0, len(img_and_grads), dev)(intrinsics, [1.0, 1.0])
+    E_m = interpolate_kernel_params(cov_params_img, sparse_coords_norm)
+    K_mm = model.cov_modules[-1](sparse_coords_norm, E_m)
+    L_mm, _ = torch.linalg.cholesky_ex(K_mm, upper=False)
+    dr_prior_dd, H_prior_d_d = linearize_sparse_depth_prior(L_mm)
+    vals_pyr, coords_pyr, Kt_pyr, sizes = [], [], [], []
+    for lvl in img_and_grads:
+        h, w = lvl.shape[-2:]
+        coords = get_test_coords((h, w), device=dev, batch_size=1)
+        cn = normalize_coordinates(coords.to(dt), (h, w))
+        E_n = interpolate_kernel_params(cov_params_img, cn)
+        K_nm = model.cross_cov_modules[-1](cn, E_n, sparse_coords_norm, E_m)
+        Kt_pyr.append(torch.cholesky_solve(K_nm.transpose(-2, -1), L_mm, upper=False).transpose(-2, -1).contiguous())
+        vals_pyr.append(lvl[:, :c].reshape(lvl.shape[0], c, h * w).contiguous())
+        coords_pyr.append(coords)
+        sizes.append((h, w))
+    return vals_pyr, coords_pyr, Kt_pyr, sizes, intrinsics_pyr, dr_prior_dd, H_prior_d_d

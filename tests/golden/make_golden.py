@@ -631,9 +631,78 @@ def mapping_case(seed=5, H=48, W=64):
     return out
 
 
+INIT_CFG = {"start_level": 0, "end_level": 3, "max_iter": 50, "delta_norm": 1.0e-4, "rel_tol": 1.0e-4,
+            "kf_depth_motion_ratio": 0.04, "kf_num_pixels_frac": 0.75}                       # config/como.yml mapping.init
+
+
+def sfm_init_case(seed=9, H=48, W=64, nframes=5):
+    """Two-frame initialisation through the reference's Mapping.attempt_two_frame_init (Mapping.py:546-578) and
+    TwoFrameSfm.handle_frame (TwoFrameSfm.py:28-79): the first frame becomes the reference, the following ones are aligned
+    until the baseline suffices; then keyframes 0 and 1 are created from the SfM result.  Same reduced configuration as
+    mapping_case."""
+    import como.odom.Mapping as rmap
+    from como.odom.frontend.TwoFrameSfm import TwoFrameSfm
+    dtype = torch.float64
+    torch.manual_seed(seed)                                # the reference permutes its test pixels with torch.multinomial
+    model = DepthCovModule()
+    model.load_state_dict(synth.depthcov_state_dict(0), strict=False)
+    model.eval()
+    cfg = dict(MAP_CFG)
+    cfg["init"] = INIT_CFG
+    scene = synth.PlaneScene(seed=seed, freq_scale=W / 640.0)
+    K = synth.intrinsics_for(H, W)
+    T = synth.gt_poses(nframes, step=0.025, deg=0.6)
+    g = torch.Generator().manual_seed(seed)
+    rgbs = []
+    for k in range(nframes):
+        I, _ = scene.render(T[k], K, H, W)
+        I = I + 0.002 * torch.randn(I.shape, generator=g, dtype=torch.float64)
+        rgbs.append(I[None, None].repeat(1, 3, 1, 1).to(dtype))
+    mp = rmap.Mapping(cfg, K.to(dtype))
+    mp.init_basic_vars()
+    mp.cov_level = -1
+    mp.network_size = torch.tensor(MAP_NET_SIZE)
+    mp.network_size_list = list(MAP_NET_SIZE)
+    mp.model = model
+    mp.init_keyframe_vars()
+    mp.init_prior_vals()
+    mp.reset_iteration_vars(new_kf=True, converged=True)
+    mp.two_frame_sfm = TwoFrameSfm(cfg, mp.intrinsics[0, :, :], model, -1, mp.network_size)
+    out = {"K": K.to(dtype), "rgb": torch.cat(rgbs)}
+    # the initialiser alone, frame by frame, on a second instance
+    sfm = TwoFrameSfm(cfg, mp.intrinsics[0, :, :], model, -1, mp.network_size)
+    flags = []
+    with torch.no_grad():
+        for k in range(nframes):
+            r = sfm.handle_frame(rgbs[k], 1.0 + k)
+            flags.append(bool(r[0]))
+            if k == 0:
+                out["coords_m"] = sfm.coords_m.clone()
+                out["cov_params_img"] = sfm.cov_params_img.clone()
+            else:
+                out[f"T_curr_kf_{k}"], out[f"aff_curr_kf_{k}"], out[f"logd_{k}"], out[f"mean_log_depth_{k}"] = r[1], r[2], r[3], r[6]
+                out[f"median_depth_curr_{k}"] = torch.median(r[5])
+            if r[0]:
+                break
+        out["is_init_flags"] = np.array(flags)
+        done_at = -1
+        for k in range(nframes):
+            if mp.attempt_two_frame_init(1.0 + k, rgbs[k]):
+                done_at = k
+                break
+    out["init_done_at"] = done_at
+    for name in ("kf_poses", "kf_aff_params", "P_m", "correspondence_mask", "obs_ref_mask", "pm_first_obs", "logzm",
+                 "pose_anchor", "median_depths", "init_scale_anchor"):
+        out["m_" + name] = getattr(mp, name).clone()
+    out["m_kf_timestamps"] = torch.tensor(mp.kf_timestamps, dtype=dtype)
+    return out
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net", "distill", "corr", "tracker", "mapping"]
+    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net", "distill", "corr", "tracker", "mapping", "sfm_init"]
+    if "sfm_init" in which:
+        save("sfm_init_f64.npz", sfm_init_case())
     if "mapping" in which:
         save("mapping_f64.npz", mapping_case())
     if "tracker" in which:

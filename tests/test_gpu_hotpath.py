@@ -968,3 +968,61 @@ def test_mapping_state_machine_vs_golden():
         i += 2
     report("mapping", snapshots=len(tags), landmarks=int(mp.P_m.shape[0]), **{k + "_abs_err": v for k, v in worst.items()})
     assert worst["pose"] < 1e-5 and worst["aff"] < 1e-4 and worst["P"] < 1e-3 and worst["logz"] < 1e-3 and worst["med"] < 2e-2
+
+
+def test_two_frame_init_state_machine_vs_golden():
+    """TwoFrameSfm.handle_frame and Mapping.attempt_two_frame_init mirrors against the reference on the same frames: same
+    frame at which initialisation succeeds, same inducing pixels, relative pose / log-depth codes of the SfM within the
+    tolerance left by the float32 network, and the two keyframes created from it."""
+    from como_amd.depth_cov.core.DepthCovModule import DepthCovModule
+    from como_amd.odom.frontend.TwoFrameSfm import TwoFrameSfm
+    from como_amd.odom.Mapping import Mapping
+    from como_amd.synth import depthcov_state_dict
+    G = load_golden("sfm_init_f64.npz")
+    cfg = {"device": DEV, "dtype": "double", "pix_dtype": "double", "color": "gray", "track_ref": {"num_keyframes": 1},
+           "graph": {"num_keyframes": 3, "num_one_way_frames": 4}, "network_size": [32, 64], "graph_network": False,
+           "photo_construction": {"nonmax_suppression_window": 2, "pairwise_batch_size": 128, "radius_thresh": 0.0,
+                                  "degrees_thresh": 0.0},
+           "term_criteria": {"max_iter": 20, "delta_norm": 1.0e-8, "abs_tol": 1.0e-6, "rel_tol": 1.0e-6},
+           "sigmas": {"photo": 1.0e-1, "mean_depth_prior": 1.0e-2, "scale_prior": 1.0e-4, "pose_prior": 1.0e-6},
+           "sampling": {"mode": "greedy_conditional_entropy", "max_num_coords": 12, "max_stdev_thresh": 1.0e-2, "border": 3,
+                        "fixed_var": 0.0, "dist_thresh": 1.0e-1},
+           "corr": {"corr_mode": "logz", "corr_thresh": 3.0e-2, "distill_with_prior": True, "min_obs_depth": 0.0,
+                    "logz_grad_mag_thresh": 7.0e-2},
+           "init": {"start_level": 0, "end_level": 3, "max_iter": 50, "delta_norm": 1.0e-4, "rel_tol": 1.0e-4,
+                    "kf_depth_motion_ratio": 0.04, "kf_num_pixels_frac": 0.75}}
+    model = DepthCovModule({k: dev(v) for k, v in depthcov_state_dict(0).items()})
+    rgb = dev(G["rgb"])
+    K = dev(G["K"])
+    sfm = TwoFrameSfm(cfg, K, model, -1, [32, 64])
+    flags = []
+    worst_T = worst_d = 0.0
+    for k in range(len(G["is_init_flags"])):
+        r = sfm.handle_frame(rgb[k:k + 1], 1.0 + k)
+        flags.append(bool(r[0]))
+        if k == 0:
+            assert torch.equal(sfm.coords_m.cpu(), G["coords_m"])                      # same inducing pixels
+            assert rel_err(sfm.cov_params_img, G["cov_params_img"]) < 2e-4              # float32 network, 30 layers
+        else:
+            worst_T = max(worst_T, (r[1].cpu() - G[f"T_curr_kf_{k}"]).abs().max().item())
+            worst_d = max(worst_d, (r[3].cpu() - G[f"logd_{k}"]).abs().max().item(),
+                          (r[6].cpu() - G[f"mean_log_depth_{k}"]).abs().max().item())
+    assert flags == [bool(x) for x in G["is_init_flags"]]
+    mp = Mapping(cfg, G["K"].clone())
+    mp.setup(model)
+    done = -1
+    for k in range(rgb.shape[0]):
+        if mp.attempt_two_frame_init(1.0 + k, rgb[k:k + 1]):
+            done = k
+            break
+    assert done == int(G["init_done_at"]) and [float(t) for t in mp.kf_timestamps] == G["m_kf_timestamps"].tolist()
+    assert torch.equal(mp.correspondence_mask.cpu(), G["m_correspondence_mask"])
+    assert torch.equal(mp.obs_ref_mask.cpu(), G["m_obs_ref_mask"])
+    e_pose = (mp.kf_poses.cpu() - G["m_kf_poses"]).abs().max().item()
+    e_P = (mp.P_m.cpu() - G["m_P_m"]).abs().max().item()
+    e_lz = (mp.logzm.cpu() - G["m_logzm"]).abs().max().item()
+    e_anchor = (mp.init_scale_anchor.cpu() - G["m_init_scale_anchor"]).abs().max().item()
+    report("two_frame_init", init_at=done, sfm_pose_err=worst_T, sfm_logd_err=worst_d, kf_pose_err=e_pose, P_err=e_P, logz_err=e_lz,
+           scale_anchor_err=e_anchor)
+    assert worst_T < 2e-5 and worst_d < 2e-3
+    assert e_pose < 2e-5 and e_P < 2e-3 and e_lz < 2e-3 and e_anchor < 2e-4
