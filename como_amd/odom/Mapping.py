@@ -173,6 +173,14 @@ class Mapping:
         return (self.kf_timestamps[ind:end], self.rgb[ind:end], self.kf_poses[ind:end], self.kf_aff_params[ind:end],
                 self.depth_imgs[ind:end])
 
+    def get_kf_viz_data(self, ind=-1):
+        """Mapping.py:514-544: cloned snapshot for a viewer."""
+        import time
+        self.last_kf_send_time = time.time()
+        return (self.kf_timestamps.copy(), self.rgb.clone(), self.kf_poses.clone(), self.depth_imgs.clone(),
+                swap_coords_xy(self.pm).clone(), self.P_m.clone(), self.obs_ref_mask.clone(), self.recent_poses.clone(),
+                list(getattr(self, "kf_pairs", [])), list(getattr(self, "one_way_pairs", [])))
+
     def store_vars(self, pm, logzm, Knm_Kmminv):
         """Mapping.py:749-758"""
         self.pm, self.logzm = pm, logzm
@@ -329,6 +337,7 @@ class Mapping:
             if data[0] == "one-way":
                 self.add_one_way_frame(rgb.to(self.dtype), pose_w, aff_w, timestamp)
             else:
+                kf_viz_data = self.get_kf_viz_data()          # snapshot BEFORE the insertion, as the reference
                 self.add_keyframe(rgb.to(self.dtype), pose_w, aff_w, timestamp)
                 kf_updated = True
         return kf_viz_data, kf_updated

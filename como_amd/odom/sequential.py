@@ -1,0 +1,71 @@
+"""Single-process odometry loop: the reference's sequential mode (como/odom/sequential/{ComoSeq,MappingSeq,TrackingSeq}.py)
+without the GUI.  Per frame: track against the newest keyframe (once mapping is initialised), hand the tracker's request
+(keyframe / one-way frame / initialisation frame) to the mapper, run ONE mapping GN iteration, and give the tracker the
+refreshed keyframe reference (pose, affine parameters, dense depth) -- the order of ComoSeq.iter (ComoSeq.py:41-71)."""
+import time
+
+import torch
+
+from como_amd.odom.Mapping import Mapping
+from como_amd.odom.Tracking import Tracking
+
+
+def transfer_data(data, device, dtype):
+    """Tensors of a message tuple to the receiver's device / dtype (como/utils/multiprocessing.py:16-21)."""
+    return tuple(d.to(device=device, dtype=dtype, copy=False) if torch.is_tensor(d) else d for d in data)
+
+
+class TrackingSeq(Tracking):
+    def track(self, data):
+        return self.handle_frame(data)
+
+
+class MappingSeq(Mapping):
+    def map(self, data):
+        """MappingSeq.py:11-47 -> (kf_viz_data, kf_ref_data)"""
+        kf_viz_data = kf_ref_data = None
+        kf_updated = False
+        if data is not None:
+            data = transfer_data(data, self.device, self.dtype)
+            if not self.is_init:
+                if data[0] == "init":
+                    kf_updated = self.attempt_two_frame_init(data[1], data[2])
+            else:
+                kf_viz_data, kf_updated = self.handle_tracking_data(data)
+        if self.is_init and not self.converged:
+            self.converged = self.iterate()
+            kf_updated = True
+        if self.is_init and (time.time() - self.last_kf_send_time > 1.0):
+            kf_viz_data = self.get_kf_viz_data()
+        if data is not None and data[0] == "keyframe":
+            kf_viz_data = self.get_kf_viz_data()
+        if kf_updated:
+            kf_ref_data = self.get_kf_ref_data()
+        return kf_viz_data, kf_ref_data
+
+
+class ComoSeq:
+    """Headless ComoSeq: `iter(timestamp, rgb)` per frame; the tracked world poses accumulate in `timestamps` / `est_poses`."""
+
+    def __init__(self, slam_cfg, intrinsics, img_size, model=None):
+        self.tracking = TrackingSeq(slam_cfg["tracking"], intrinsics.clone(), img_size)
+        self.mapping = MappingSeq(slam_cfg["mapping"], intrinsics.clone())
+        self.tracking.setup()
+        self.mapping.setup(model)
+        self.timestamps, self.est_poses = [], []
+        self.last_kf_viz = None
+
+    def iter(self, timestamp, rgb):
+        trk, mp = self.tracking, self.mapping
+        if mp.is_init:
+            viz, to_map = trk.track(transfer_data((timestamp, rgb.clone()), trk.device, trk.dtype))
+            self.timestamps.append(viz[0])
+            self.est_poses.append(viz[1])
+        else:
+            to_map = ("init", timestamp, rgb.clone())
+        kf_viz, kf_ref = mp.map(to_map)
+        if kf_ref is not None:
+            trk.update_kf_reference(transfer_data(kf_ref, trk.device, trk.dtype))
+        if kf_viz is not None:
+            self.last_kf_viz = kf_viz
+        return to_map[0] if to_map is not None else None

@@ -698,9 +698,73 @@ def sfm_init_case(seed=9, H=48, W=64, nframes=5):
     return out
 
 
+def odometry_case(seed=13, H=48, W=64, nframes=16):
+    """The reference's sequential odometry loop (sequential/ComoSeq.py:41-71 without the GUI, MappingSeq.map,
+    TrackingSeq.track) on a rendered sequence: two-frame initialisation, then per frame tracking (float32) -> keyframe /
+    one-way requests -> one mapping iteration (float64) -> refreshed tracker reference.  Reduced configuration of
+    mapping_case / tracker_case (kf_depth_motion_ratio 0.05)."""
+    from como.odom.sequential.MappingSeq import MappingSeq
+    from como.odom.sequential.TrackingSeq import TrackingSeq
+    from como.odom.frontend.TwoFrameSfm import TwoFrameSfm
+    from como.utils.multiprocessing import transfer_data
+    torch.manual_seed(seed)
+    model = DepthCovModule()
+    model.load_state_dict(synth.depthcov_state_dict(0), strict=False)
+    model.eval()
+    mcfg = dict(MAP_CFG)
+    mcfg["init"] = INIT_CFG
+    tcfg = {k: (dict(v) if isinstance(v, dict) else v) for k, v in TRACK_CFG.items()}
+    tcfg["keyframing"]["kf_depth_motion_ratio"] = 0.05
+    scene = synth.PlaneScene(seed=seed, freq_scale=W / 640.0)
+    K = synth.intrinsics_for(H, W)
+    T = synth.gt_poses(nframes, step=0.012, deg=0.4)
+    g = torch.Generator().manual_seed(seed)
+    rgbs = []
+    for k in range(nframes):
+        I, _ = scene.render(T[k], K, H, W)
+        I = I + 0.002 * torch.randn(I.shape, generator=g, dtype=torch.float64)
+        rgbs.append(I[None, None].repeat(1, 3, 1, 1))
+    trk = TrackingSeq(tcfg, K.clone(), (H, W))
+    trk.init_basic_vars(); trk.init_kf_vars(); trk.reset_one_way_vars(); trk.T_w_rec_last = None
+    mp = MappingSeq(mcfg, K.clone())
+    mp.init_basic_vars()
+    mp.cov_level = -1
+    mp.network_size = torch.tensor(MAP_NET_SIZE)
+    mp.network_size_list = list(MAP_NET_SIZE)
+    mp.model = model
+    mp.init_keyframe_vars()
+    mp.init_prior_vals()
+    mp.reset_iteration_vars(new_kf=True, converged=True)
+    mp.two_frame_sfm = TwoFrameSfm(mcfg, mp.intrinsics[0, :, :], model, -1, mp.network_size)
+    out = {"K": K, "rgb": torch.cat(rgbs), "poses_gt": T}
+    kinds = []
+    code = {None: 0, "init": 3, "keyframe": 1, "one-way": 2}
+    with torch.no_grad():
+        for k in range(nframes):
+            ts, rgb = 1.0 + k, rgbs[k]
+            if mp.is_init:
+                viz, to_map = trk.track(transfer_data((ts, rgb.clone()), trk.device, trk.dtype))
+                out[f"T_w_curr_{k}"] = viz[1].clone()
+            else:
+                to_map = ("init", ts, rgb.clone())
+            kinds.append(code[to_map[0] if to_map is not None else None])
+            _, kf_ref = mp.map(to_map)
+            if kf_ref is not None:
+                trk.update_kf_reference(transfer_data(kf_ref, trk.device, trk.dtype))
+            out[f"n_kf_{k}"] = torch.tensor(mp.kf_poses.shape[0] if mp.kf_poses.dim() > 1 else 0)
+    out["kinds"] = np.array(kinds)
+    for name in ("kf_poses", "kf_aff_params", "P_m", "correspondence_mask", "obs_ref_mask", "recent_poses"):
+        out["m_" + name] = getattr(mp, name).clone()
+    out["m_kf_timestamps"] = torch.tensor(mp.kf_timestamps, dtype=torch.float64)
+    out["m_recent_timestamps"] = torch.tensor(mp.recent_timestamps, dtype=torch.float64)
+    return out
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net", "distill", "corr", "tracker", "mapping", "sfm_init"]
+    which = sys.argv[1:] or ["ba", "track", "sfm", "cov", "image", "full", "net", "distill", "corr", "tracker", "mapping", "sfm_init", "odometry"]
+    if "odometry" in which:
+        save("odometry_seq.npz", odometry_case())
     if "sfm_init" in which:
         save("sfm_init_f64.npz", sfm_init_case())
     if "mapping" in which:

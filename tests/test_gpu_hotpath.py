@@ -1026,3 +1026,52 @@ def test_two_frame_init_state_machine_vs_golden():
            scale_anchor_err=e_anchor)
     assert worst_T < 2e-5 and worst_d < 2e-3
     assert e_pose < 2e-5 and e_P < 2e-3 and e_lz < 2e-3 and e_anchor < 2e-4
+
+
+def test_sequential_odometry_vs_golden():
+    """The whole headless odometry loop (como_amd/odom/sequential.py: two-frame initialisation, float32 tracking, keyframe
+    / one-way requests, one float64 mapping iteration per frame, tracker reference refresh) against the reference's
+    sequential mode on the same 16 rendered frames: the same request for every frame, the same keyframe / one-way
+    timestamps and correspondence mask at the end, tracked world poses within 1e-4."""
+    from como_amd.depth_cov.core.DepthCovModule import DepthCovModule
+    from como_amd.odom.sequential import ComoSeq
+    from como_amd.synth import depthcov_state_dict
+    G = load_golden("odometry_seq.npz")
+    mcfg = {"device": DEV, "dtype": "double", "pix_dtype": "double", "color": "gray", "track_ref": {"num_keyframes": 1},
+            "graph": {"num_keyframes": 3, "num_one_way_frames": 4}, "network_size": [32, 64], "graph_network": False,
+            "photo_construction": {"nonmax_suppression_window": 2, "pairwise_batch_size": 128, "radius_thresh": 0.0,
+                                   "degrees_thresh": 0.0},
+            "term_criteria": {"max_iter": 20, "delta_norm": 1.0e-8, "abs_tol": 1.0e-6, "rel_tol": 1.0e-6},
+            "sigmas": {"photo": 1.0e-1, "mean_depth_prior": 1.0e-2, "scale_prior": 1.0e-4, "pose_prior": 1.0e-6},
+            "sampling": {"mode": "greedy_conditional_entropy", "max_num_coords": 12, "max_stdev_thresh": 1.0e-2, "border": 3,
+                         "fixed_var": 0.0, "dist_thresh": 1.0e-1},
+            "corr": {"corr_mode": "logz", "corr_thresh": 3.0e-2, "distill_with_prior": True, "min_obs_depth": 0.0,
+                     "logz_grad_mag_thresh": 7.0e-2},
+            "init": {"start_level": 0, "end_level": 3, "max_iter": 50, "delta_norm": 1.0e-4, "rel_tol": 1.0e-4,
+                     "kf_depth_motion_ratio": 0.04, "kf_num_pixels_frac": 0.75}}
+    tcfg = {"device": DEV, "dtype": "float", "color": "gray",
+            "pyr": {"start_level": 0, "end_level": 3, "depth_interp_mode": "nearest_neighbor"},
+            "term_criteria": {"max_iter": 50, "delta_norm": 1.0e-3, "rel_tol": 1.0e-3, "grad_norm": 1.0},
+            "sigmas": {"photo": 1.0e-1},
+            "keyframing": {"kf_depth_motion_ratio": 0.05, "kf_num_pixels_frac": 0.75, "one_way_freq": 3}}
+    model = DepthCovModule({k: dev(v) for k, v in depthcov_state_dict(0).items()})
+    rgb = dev(G["rgb"])
+    H, W = rgb.shape[-2:]
+    odo = ComoSeq({"tracking": tcfg, "mapping": mcfg}, G["K"].clone(), (H, W), model)
+    code = {None: 0, "init": 3, "keyframe": 1, "one-way": 2}
+    kinds, worst = [], 0.0
+    for k in range(rgb.shape[0]):
+        n_before = len(odo.est_poses)
+        kinds.append(code[odo.iter(1.0 + k, rgb[k:k + 1])])
+        if len(odo.est_poses) > n_before:
+            worst = max(worst, (odo.est_poses[-1].cpu().double() - G[f"T_w_curr_{k}"].double()).abs().max().item())
+        nk = odo.mapping.kf_poses.shape[0] if odo.mapping.kf_poses.dim() > 1 else 0
+        assert nk == int(G[f"n_kf_{k}"]), k
+    mp = odo.mapping
+    report("odometry_seq", kinds=kinds, tracked_pose_abs_err=worst, kf_pose_err=(mp.kf_poses.cpu() - G["m_kf_poses"]).abs().max().item(),
+           P_err=(mp.P_m.cpu() - G["m_P_m"]).abs().max().item())
+    assert kinds == [int(x) for x in G["kinds"]]
+    assert [float(t) for t in mp.kf_timestamps] == G["m_kf_timestamps"].tolist()
+    assert [float(t) for t in mp.recent_timestamps] == G["m_recent_timestamps"].tolist()
+    assert torch.equal(mp.correspondence_mask.cpu(), G["m_correspondence_mask"])
+    assert worst < 1e-4 and (mp.kf_poses.cpu() - G["m_kf_poses"]).abs().max().item() < 1e-4
