@@ -61,6 +61,8 @@ SIGNATURES = {
     "como_track_partials_bytes": (c_long, []),
     "como_track_iter_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 9),
     "como_track_iter_f64": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 9),
+    "como_track_iter_masked_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 10),
+    "como_track_iter_masked_f64": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 10),
     "como_ba_partials_elems": (c_long, [c_int, c_int, c_int]),
     "como_ba_linearize_f32": (c_int, [ctypes.POINTER(BAArgs), c_void_p]),
     "como_ba_linearize_f64": (c_int, [ctypes.POINTER(BAArgs), c_void_p]),

@@ -1012,7 +1012,7 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
   uint32_t* hists = (uint32_t*)A->ws_hists;
 
   if (A->phase & 1) {
-    if (!(A->phase & 256) && hipMemsetAsync(hists, 0, 6 * SEL_BINS * sizeof(uint32_t), s) != hipSuccess) return COMO_ERR_LAUNCH;
+    if (!(A->phase & 256) && !zero_words(hists, 6 * SEL_BINS, s)) return COMO_ERR_LAUNCH;
     hipLaunchKernelGGL(ba_pair_setup_kernel<T>, dim3((b + 63) / 64), dim3(64), 0, s, (const T*)A->poses_all,
                        (const T*)A->aff_all, pr, b, pair_T, pair_aff);
     COMO_CHECK_LAUNCH();

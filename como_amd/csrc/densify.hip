@@ -372,7 +372,7 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
       B <= 0 || n <= 0 || m <= 0 || m > 64 || (m & 3) || Wimg <= 0)
     return COMO_ERR_ARG;
   uint32_t* hists = (uint32_t*)hists_v;
-  if (!(flags & 1) && hipMemsetAsync(hists, 0, (size_t)B * 6 * SEL_BINS * sizeof(uint32_t), s) != hipSuccess)
+  if (!(flags & 1) && !zero_words(hists, (size_t)B * 6 * SEL_BINS, s))
     return COMO_ERR_LAUNCH;
   int gx = (n + 255) / 256;
   if (gx > 512) gx = 512;

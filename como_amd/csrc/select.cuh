@@ -122,4 +122,25 @@ __device__ __forceinline__ void sel_flush(const uint32_t* lds_hist, uint32_t* __
   }
 }
 
+// Workspace clears are KERNELS, never hipMemsetAsync: a memset node captured into a hipGraph was observed (ROCm 7.2, gfx950)
+// to fill with a stale 64-bit pattern on later replays once unrelated eager work had run in between -- the node's fill
+// parameters are not pinned with the graph.  A kernel node carries its arguments by value.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void sel_zero_kernel(uint32_t* __restrict__ p, size_t nwords) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < nwords) {
+    *reinterpret_cast<uint4*>(p + i) = make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    for (size_t k = i; k < nwords; ++k) p[k] = 0u;
+  }
+}
+
+// p must be 16-byte aligned (every workspace here is a whole allocation or a multiple of 6 * SEL_BINS words into one)
+inline bool zero_words(void* p, size_t nwords, hipStream_t s) {
+  if (nwords == 0) return true;
+  const unsigned blocks = (unsigned)((nwords + 1023) / 1024);
+  hipLaunchKernelGGL(sel_zero_kernel<0>, dim3(blocks), dim3(256), 0, s, (uint32_t*)p, nwords);
+  return hipGetLastError() == hipSuccess;
+}
+
 }  // namespace como

@@ -91,7 +91,7 @@ int como_select_workspace_bytes(void) { return 6 * como::SEL_BINS * (int)sizeof(
 
 int como_select_begin(void* hists, int nseg, como_stream_t stream_) {
   if (!hists || nseg < 1) return COMO_ERR_ARG;
-  if (hipMemsetAsync(hists, 0, (size_t)nseg * como_select_workspace_bytes(), (hipStream_t)stream_) != hipSuccess) return COMO_ERR_LAUNCH;
+  if (!como::zero_words(hists, (size_t)nseg * 6 * como::SEL_BINS, (hipStream_t)stream_)) return COMO_ERR_LAUNCH;
   return COMO_OK;
 }
 

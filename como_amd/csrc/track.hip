@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void track_residual_kernel(
     const T* __restrict__ Tji, const T* __restrict__ Kmat, const T* __restrict__ aff, const T* __restrict__ P,
     const T* __restrict__ vals_i, const T* __restrict__ img, int H, int W, long N, T* __restrict__ J8,
     T* __restrict__ r_out, uint8_t* __restrict__ valid_out, T* __restrict__ pj_out, T* __restrict__ depth_out,
-    uint32_t* __restrict__ hists) {
+    uint32_t* __restrict__ hists, const uint8_t* __restrict__ in_mask) {
   using KeyT = typename KeyOf<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
   for (int b = threadIdx.x; b < SEL_BINS; b += 256) lh[b] = 0;
@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void track_residual_kernel(
     T hx, hy, hz;
     rigid_apply(Pm, X, Y, Z, hx, hy, hz);          // p_h = A P + b
     const T u = hx / hz, v = hy / hz;              // coords = p_h[:2] / depth
-    const bool ok = in_image(u, v, H, W) && (hz > T(0));
+    // in_mask: the caller's reference-side selection (photo_tracking.py:20-26 gathers vals/P/dI_dT with it); a point that
+    // is masked out behaves exactly like one that projects outside the image
+    const bool ok = in_image(u, v, H, W) && (hz > T(0)) && (in_mask == nullptr || in_mask[i] != 0);
     Taps<T> t = make_taps(grid_position(u, W, ax), grid_position(v, H, ay), H, W);
     const T It = tap_sum(img, t);
     const T tmp = ea * It;                          // photo_tracking.py:124
@@ -85,9 +87,11 @@ __global__ __launch_bounds__(256) void track_reduce_kernel(const T* __restrict__
 #pragma unroll
   for (int k = 0; k < TRK_ACC; ++k) acc[k] = T(0);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < N; i += (long)gridDim.x * 256) {
+    if (!valid[i]) continue;                        // weight[invalid] = 0 (photo_tracking.py:80-81): contributes exactly
+                                                    // zero, also when a masked-out point carries non-finite J / r
     const T r = r_in[i];
     const T wr = r * info_sqrt;
-    const T w = valid[i] ? huber(wr) : T(0);        // weight[invalid] = 0, photo_tracking.py:80-81
+    const T w = huber(wr);
     T J[8];
     if (sizeof(T) == 4) {
       const float4 a = *reinterpret_cast<const float4*>(&J8[8 * i]);
@@ -242,17 +246,17 @@ __global__ __launch_bounds__(256) void track_finish_kernel(const double* __restr
 template <typename T>
 int track_iter(const T* Tji, const T* Kmat, const T* aff, const T* P, const T* vals_i, const T* img, int H, int W,
                long N, T* J8, T* r_ws, uint8_t* valid_out, T* pj_out, T* depth_out, void* hists_v, double* partials,
-               T* out, hipStream_t s) {
+               T* out, const uint8_t* in_mask, hipStream_t s) {
   using KeyT = typename KeyOf<T>::type;
   if (!Tji || !Kmat || !aff || !P || !vals_i || !img || !J8 || !r_ws || !valid_out || !hists_v || !partials || !out ||
       N <= 0 || H < 3 || W < 3)
     return COMO_ERR_ARG;
   uint32_t* hists = (uint32_t*)hists_v;
-  if (hipMemsetAsync(hists, 0, 6 * SEL_BINS * sizeof(uint32_t), s) != hipSuccess) return COMO_ERR_LAUNCH;
+  if (!zero_words(hists, 6 * SEL_BINS, s)) return COMO_ERR_LAUNCH;
   long blocks = (N + 255) / 256;
   if (blocks > 1024) blocks = 1024;   // bounded: the digit-0 flush serialises per hot bin at the memory-side atomics
   hipLaunchKernelGGL(track_residual_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, Tji, Kmat, aff, P, vals_i, img,
-                     H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists);
+                     H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists, in_mask);
   COMO_CHECK_LAUNCH();
   for (int p = 1; p < SelCfg<KeyT>::NPASS; ++p) {
     int rc = select_hist<T>(r_ws, valid_out, N, 1, hists, p, s);
@@ -280,7 +284,23 @@ int como_track_iter_f32(const float* Tji, const float* K, const float* aff, cons
                         const float* img, int H, int W, long N, float* J8, float* r_ws, uint8_t* valid_out,
                         float* pj_out, float* depth_out, void* hists, void* partials, float* out, como_stream_t stream) {
   return como::track_iter<float>(Tji, K, aff, P, vals_i, img, H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists,
-                                 (double*)partials, out, (hipStream_t)stream);
+                                 (double*)partials, out, nullptr, (hipStream_t)stream);
+}
+
+int como_track_iter_masked_f32(const float* Tji, const float* K, const float* aff, const float* P, const float* vals_i,
+                               const float* img, int H, int W, long N, float* J8, float* r_ws, uint8_t* valid_out,
+                               float* pj_out, float* depth_out, void* hists, void* partials, float* out,
+                               const uint8_t* in_mask, como_stream_t stream) {
+  return como::track_iter<float>(Tji, K, aff, P, vals_i, img, H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists,
+                                 (double*)partials, out, in_mask, (hipStream_t)stream);
+}
+
+int como_track_iter_masked_f64(const double* Tji, const double* K, const double* aff, const double* P, const double* vals_i,
+                               const double* img, int H, int W, long N, double* J8, double* r_ws, uint8_t* valid_out,
+                               double* pj_out, double* depth_out, void* hists, void* partials, double* out,
+                               const uint8_t* in_mask, como_stream_t stream) {
+  return como::track_iter<double>(Tji, K, aff, P, vals_i, img, H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists,
+                                  (double*)partials, out, in_mask, (hipStream_t)stream);
 }
 
 int como_track_iter_f64(const double* Tji, const double* K, const double* aff, const double* P, const double* vals_i,
@@ -288,7 +308,7 @@ int como_track_iter_f64(const double* Tji, const double* K, const double* aff, c
                         double* pj_out, double* depth_out, void* hists, void* partials, double* out,
                         como_stream_t stream) {
   return como::track_iter<double>(Tji, K, aff, P, vals_i, img, H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists,
-                                  (double*)partials, out, (hipStream_t)stream);
+                                  (double*)partials, out, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

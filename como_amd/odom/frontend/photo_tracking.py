@@ -13,17 +13,22 @@ from como_amd.geometry.lie_algebra import skew_symmetric
 _ws_cache = {}
 
 
+def _new_workspace(device, dtype, N):
+    L = _lib.lib()
+    return {"r": torch.empty(N, device=device, dtype=dtype),
+            "hists": torch.empty(L.como_select_workspace_bytes() // 4, device=device, dtype=torch.int32),
+            "partials": torch.empty(L.como_track_partials_bytes() // 8, device=device, dtype=torch.float64)}
+
+
 def _workspace(device, dtype, N):
+    """Scratch of the eager entry points (one per size, a few kept).  Captured graphs own theirs (_LevelGraph.ws): a graph
+    records raw addresses, so its scratch must live exactly as long as the graph."""
     key = (str(device), dtype, N)
     ws = _ws_cache.get(key)
     if ws is None:
-        L = _lib.lib()
-        ws = {
-            "r": torch.empty(N, device=device, dtype=dtype),
-            "hists": torch.empty(L.como_select_workspace_bytes() // 4, device=device, dtype=torch.int32),
-            "partials": torch.empty(L.como_track_partials_bytes() // 8, device=device, dtype=torch.float64),
-        }
-        _ws_cache.clear()
+        if len(_ws_cache) > 8:
+            _ws_cache.clear()
+        ws = _new_workspace(device, dtype, N)
         _ws_cache[key] = ws
     return ws
 
@@ -51,8 +56,9 @@ def precalc_jacobians(dI_dw, P, vals, intrinsics):
     return torch.cat((dI_dT, vals.unsqueeze(-1), torch.ones_like(vals).unsqueeze(-1)), dim=-1)
 
 
-def tracking_iter_raw(Tji, Pi, intrinsics, img_j, aff, vals_i, dI_dT, want_proj=True):
-    """Enqueue one GN iteration; returns (out[105], valid u8 (N,), pj (N,2) or None, depth (N,) or None)."""
+def tracking_iter_raw(Tji, Pi, intrinsics, img_j, aff, vals_i, dI_dT, want_proj=True, in_mask=None, ws=None):
+    """Enqueue one GN iteration; returns (out[105], valid u8 (N,), pj (N,2) or None, depth (N,) or None).
+    in_mask (N,) uint8: reference-side selection applied in the kernel (0 = ignore the point)."""
     _lib.require_cuda(Tji, Pi, intrinsics, img_j, aff, vals_i, dI_dT)
     if img_j.shape[0] != 1 or img_j.shape[1] != 1 or Pi.shape[0] != 1:
         raise RuntimeError("como_amd tracking: batch 1, gray (c = 1) only")
@@ -62,16 +68,22 @@ def tracking_iter_raw(Tji, Pi, intrinsics, img_j, aff, vals_i, dI_dT, want_proj=
     for t in (Tji, Pi, intrinsics, img_j, aff, vals_i, dI_dT):
         if not t.is_contiguous() or t.dtype != dt:
             raise RuntimeError("como_amd tracking: inputs must be contiguous and share one dtype")
-    ws = _workspace(dev, dt, N)
+    ws = ws if ws is not None else _workspace(dev, dt, N)
     out = torch.empty(105, device=dev, dtype=dt)
     valid = torch.empty(N, device=dev, dtype=torch.uint8)
     pj = torch.empty((N, 2), device=dev, dtype=dt) if want_proj else None
     depth = torch.empty(N, device=dev, dtype=dt) if want_proj else None
-    fn = getattr(_lib.lib(), "como_track_iter_" + _lib.suffix(dt))
-    rc = fn(_lib.ptr(Tji), _lib.ptr(intrinsics), _lib.ptr(aff), _lib.ptr(Pi), _lib.ptr(vals_i), _lib.ptr(img_j), H, W, N,
+    args = [_lib.ptr(Tji), _lib.ptr(intrinsics), _lib.ptr(aff), _lib.ptr(Pi), _lib.ptr(vals_i), _lib.ptr(img_j), H, W, N,
             _lib.ptr(dI_dT), _lib.ptr(ws["r"]), _lib.ptr(valid), _lib.ptr(pj), _lib.ptr(depth), _lib.ptr(ws["hists"]),
-            _lib.ptr(ws["partials"]), _lib.ptr(out), _lib.stream_ptr(dev))
-    _lib.check(rc, "como_track_iter")
+            _lib.ptr(ws["partials"]), _lib.ptr(out)]
+    if in_mask is None:
+        fn = getattr(_lib.lib(), "como_track_iter_" + _lib.suffix(dt))
+    else:
+        if in_mask.dtype != torch.uint8 or in_mask.numel() != N or not in_mask.is_contiguous():
+            raise RuntimeError("como_amd tracking: in_mask must be a contiguous uint8 tensor of N elements")
+        fn = getattr(_lib.lib(), "como_track_iter_masked_" + _lib.suffix(dt))
+        args.append(_lib.ptr(in_mask))
+    _lib.check(fn(*args, _lib.stream_ptr(dev)), "como_track_iter")
     return out, valid, pj, depth
 
 
@@ -85,24 +97,30 @@ def tracking_iter(Tji, Pi, intrinsics, img_j, aff, vals_i, dI_dT, photo_sigma, A
             pj[None], valid[None].bool(), depth[None, :, None])
 
 
+LOOKAHEAD = 4      # GN iterations enqueued per host read-back of the stop-test scalars
+
+
 class _LevelGraph:
     """One tracking GN iteration (memset + residual + 2 select passes + reduce + finish + state write-back) captured in a
     hipGraph over FIXED buffers: the pose / affine state lives in `self.T`, `self.aff` and is advanced in place, so the
-    host only replays the graph and reads 3 scalars back for the reference's stop test (~35 us per iteration instead of
-    ~300 us of Python + 7 launches)."""
+    host only replays the graph (~35 us per iteration instead of ~300 us of Python + 7 launches)."""
 
-    def __init__(self, vals_i, Pi, dI_dT, img_j, intrinsics):
+    def __init__(self, vals_i, Pi, dI_dT, img_j, intrinsics, in_mask=None):
         dev, dt = Pi.device, Pi.dtype
         self.args = (Pi, intrinsics, img_j, vals_i, dI_dT)
+        self.in_mask = in_mask
         self.T = torch.zeros((1, 4, 4), device=dev, dtype=dt)
         self.aff = torch.zeros((1, 2, 1), device=dev, dtype=dt)
+        self.ring = torch.zeros((LOOKAHEAD, 105), device=dev, dtype=dt)      # per-iteration results between read-backs
+        self.ws = _new_workspace(dev, dt, Pi.shape[1])                       # owned: the graph records its addresses
         self.out = None
         self.graph = None
         self.dev = dev
 
     def _iter(self):
         Pi, K, img_j, vals_i, dI_dT = self.args
-        out, _, _, _ = tracking_iter_raw(self.T, Pi, K, img_j, self.aff, vals_i, dI_dT, want_proj=False)
+        out, _, _, _ = tracking_iter_raw(self.T, Pi, K, img_j, self.aff, vals_i, dI_dT, want_proj=False, in_mask=self.in_mask,
+                                         ws=self.ws)
         self.T.copy_(out[80:96].reshape(1, 4, 4))
         self.aff.copy_(out[96:98].reshape(1, 2, 1))
         return out
@@ -142,78 +160,107 @@ class _LevelGraph:
 _level_graphs = {}
 
 
-def _level_graph(vals_i, Pi, dI_dT, img_j, intrinsics):
-    """Graphs are keyed by the buffer addresses: a new keyframe (new reference arrays) builds a new one, successive frames
-    tracked against the same keyframe WITH THE SAME target-image buffer reuse it."""
+def _level_graph(vals_i, Pi, dI_dT, img_j, intrinsics, in_mask=None):
+    """Graphs are keyed by the buffer addresses: they are meant for PERSISTENT buffers (photo_tracking_pyr copies every new
+    reference / frame into the same ones); a caller passing its own tensors must keep them alive and unmodified."""
     key = (vals_i.data_ptr(), Pi.data_ptr(), dI_dT.data_ptr(), img_j.data_ptr(), intrinsics.data_ptr(), Pi.shape[1],
-           tuple(img_j.shape), Pi.dtype)
+           tuple(img_j.shape), Pi.dtype, in_mask.data_ptr() if in_mask is not None else 0)
     lg = _level_graphs.get(key)
     if lg is None:
         if len(_level_graphs) > 16:
             _level_graphs.clear()
-        lg = _LevelGraph(vals_i, Pi, dI_dT, img_j, intrinsics)
+        lg = _LevelGraph(vals_i, Pi, dI_dT, img_j, intrinsics, in_mask)
         lg.capture()
         _level_graphs[key] = lg
     return lg
 
 
-def photo_level_tracking(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, intrinsics, photo_sigma, term_criteria, use_graph=True):
-    """reference photo_tracking.py:147-185 (one host read-back of 3 scalars per iteration for the stop test).
+def photo_level_tracking(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, intrinsics, photo_sigma, term_criteria, use_graph=True,
+                         in_mask=None):
+    """reference photo_tracking.py:147-185.  The stop test needs 3 scalars of every iteration on the host: LOOKAHEAD
+    iterations are enqueued per read-back, their results kept in a small ring; when the test fires at iteration j the state
+    of iteration j is restored, so the result is the reference's, at the price of at most LOOKAHEAD-1 surplus iterations.
     use_graph: replay each iteration from a hipGraph over fixed buffers (inputs must stay alive and unmodified)."""
     if use_graph:
-        lg = _level_graph(vals_i, Pi, dI_dT, img_j, intrinsics)
+        lg = _level_graph(vals_i, Pi, dI_dT, img_j, intrinsics, in_mask)
     else:
-        lg = _LevelGraph(vals_i, Pi, dI_dT, img_j, intrinsics)
+        lg = _LevelGraph(vals_i, Pi, dI_dT, img_j, intrinsics, in_mask)
     lg.T.copy_(Tji_init.reshape(1, 4, 4))
     lg.aff.copy_(aff_init.reshape(1, 2, 1))
     it = 0
     prev = float("inf")
-    while True:
-        out = lg.step()
-        sc = out[98:104].tolist()                              # one small D2H copy: mse, grad_norm, ., ., ., delta_norm
-        mse, gnorm, dnorm = sc[0], sc[1], sc[5]
-        it += 1
-        rel = abs((prev - mse) / prev) if prev != float("inf") else float("nan")
-        if (it >= term_criteria["max_iter"] or dnorm < term_criteria["delta_norm"] or rel < term_criteria["rel_tol"]
-                or gnorm < term_criteria["grad_norm"]):
-            break
-        prev = mse
+    done = False
+    while not done:
+        for j in range(LOOKAHEAD):
+            lg.ring[j].copy_(lg.step())
+        rows = lg.ring.tolist()                                # ONE device->host copy per LOOKAHEAD iterations
+        for j in range(LOOKAHEAD):
+            mse, gnorm, dnorm = rows[j][98], rows[j][99], rows[j][103]
+            it += 1
+            rel = abs((prev - mse) / prev) if prev != float("inf") else float("nan")
+            if (it >= term_criteria["max_iter"] or dnorm < term_criteria["delta_norm"] or rel < term_criteria["rel_tol"]
+                    or gnorm < term_criteria["grad_norm"]):
+                if j + 1 < LOOKAHEAD:                          # roll the state back to iteration j
+                    lg.T.copy_(lg.ring[j, 80:96].reshape(1, 4, 4))
+                    lg.aff.copy_(lg.ring[j, 96:98].reshape(1, 2, 1))
+                done = True
+                break
+            prev = mse
     photo_level_tracking.last_iters = it
     return lg.T.clone(), lg.aff.clone()
 
 
-_pyr_cache = {}
+class _PyrBuffers:
+    """Persistent device buffers of one pyramid shape: reference arrays (all B*N points of every level, never gathered), the
+    selection masks, the current frame's levels and intrinsics.  Their addresses never change, so each level's captured
+    iteration graph is built once and serves every keyframe and every frame of the run."""
+
+    def __init__(self, vals_i, Pi, dI_dT, img_j, intrinsics):
+        self.levels = []
+        for l in range(len(vals_i)):
+            n = vals_i[l].shape[0] * vals_i[l].shape[1]
+            dev, dt = Pi[l].device, Pi[l].dtype
+            self.levels.append({"vals": torch.empty((1, n, vals_i[l].shape[2]), device=dev, dtype=dt),
+                                "P": torch.empty((1, n, 3), device=dev, dtype=dt),
+                                "dI": torch.empty((1, n) + tuple(dI_dT[l].shape[2:]), device=dev, dtype=dt),
+                                "mask": torch.empty((n,), device=dev, dtype=torch.uint8),
+                                "img": torch.empty_like(img_j[l]), "K": torch.empty_like(intrinsics[l])})
+        self.src = None
+
+    def load_reference(self, vals_i, Pi, dI_dT, masks):
+        src = tuple(vals_i) + tuple(Pi) + tuple(dI_dT) + tuple(masks)
+        if self.src is not None and len(src) == len(self.src) and all(a is b for a, b in zip(src, self.src)):
+            return
+        for l, c in enumerate(self.levels):
+            c["vals"].copy_(vals_i[l].reshape(c["vals"].shape))
+            c["P"].copy_(Pi[l].reshape(c["P"].shape))
+            c["dI"].copy_(dI_dT[l].reshape(c["dI"].shape))
+            c["mask"].copy_(masks[l].reshape(-1))
+        self.src = src                                         # held: an id cannot be recycled while it is remembered
+
+
+_pyr_buffers = {}
 
 
 def photo_tracking_pyr(Tji_init, aff_init, vals_i, Pi, dI_dT, masks, intrinsics, img_j, photo_sigma, term_criteria):
     """reference photo_tracking.py:10-42 (lists ordered coarse -> fine).
-    The masked reference arrays of a keyframe are gathered once and kept (the reference re-gathers them every frame); the
-    current frame's pyramid levels and intrinsics are copied into persistent buffers so that every level replays its
-    captured iteration graph."""
-    # keyed by the IDENTITY of every reference-side tensor; the entry keeps them alive, so neither an id nor a device
-    # address can be recycled for different data while the entry exists (a refined depth map = new P / dI_dT / mask
-    # tensors = a new entry)
-    src = tuple(vals_i) + tuple(Pi) + tuple(dI_dT) + tuple(masks)
-    key = tuple(id(t) for t in src)
-    ent = _pyr_cache.get(key)
-    if ent is None:
-        if len(_pyr_cache) > 4:
-            _pyr_cache.clear()
+    The reference gathers the masked subset of vals / P / dI_dT on every frame; here the full arrays are copied into
+    persistent buffers when (and only when) the reference tensors change, the masks go to the kernel
+    (`como_track_iter_masked_*`), and every level replays one iteration graph captured once per pyramid shape."""
+    key = (str(Pi[0].device), Pi[0].dtype) + tuple((v.shape[0] * v.shape[1],) + tuple(i.shape[-2:]) for v, i in zip(vals_i, img_j))
+    pb = _pyr_buffers.get(key)
+    if pb is None:
+        if len(_pyr_buffers) > 2:
+            _pyr_buffers.clear()
             _level_graphs.clear()
-        lv = []
-        for l in range(len(vals_i)):
-            mk = masks[l]
-            lv.append({"vals": vals_i[l][None, mk, :].contiguous(), "P": Pi[l][None, mk, :].contiguous(),
-                       "dI": dI_dT[l][None, mk, :, :].contiguous(), "img": torch.empty_like(img_j[l]),
-                       "K": torch.empty_like(intrinsics[l])})
-        ent = (lv, src)
-        _pyr_cache[key] = ent
-    lv = ent[0]
+        pb = _PyrBuffers(vals_i, Pi, dI_dT, img_j, intrinsics)
+        _pyr_buffers[key] = pb
+    pb.load_reference(vals_i, Pi, dI_dT, masks)
     Tji = Tji_init.clone()
     aff = aff_init.clone()
-    for l in range(len(vals_i)):
-        c = lv[l]
+    for l, c in enumerate(pb.levels):
         c["img"].copy_(img_j[l])
         c["K"].copy_(intrinsics[l])
-        Tji, aff = photo_level_tracking(Tji, aff, c["vals"], c["P"], c["dI"], c["img"], c["K"], photo_sigma, term_criteria)
+        Tji, aff = photo_level_tracking(Tji, aff, c["vals"], c["P"], c["dI"], c["img"], c["K"], photo_sigma, term_criteria,
+                                        in_mask=c["mask"])
     return Tji, aff

@@ -62,6 +62,18 @@ int como_track_iter_f64(const double* Tji, const double* K, const double* aff, c
                         const double* img, int H, int W, long N, double* J8, double* r_ws, uint8_t* valid_out,
                         double* pj_out, double* depth_out, void* hists, void* partials, double* out,
                         como_stream_t stream);
+/* Same iteration over a FIXED-size reference set with a selection mask instead of a gathered subset (the reference gathers
+ * vals / P / dI_dT with the keyframe's validity mask on every frame, photo_tracking.py:20-26): in_mask (N) u8, 0 = the point
+ * is ignored exactly like one that projects outside the image (it may carry non-finite P / J8).  Buffer sizes never change
+ * between keyframes, so one captured hipGraph per pyramid level serves the whole run. */
+int como_track_iter_masked_f32(const float* Tji, const float* K, const float* aff, const float* P, const float* vals_i,
+                               const float* img, int H, int W, long N, float* J8, float* r_ws, uint8_t* valid_out,
+                               float* pj_out, float* depth_out, void* hists, void* partials, float* out,
+                               const uint8_t* in_mask, como_stream_t stream);
+int como_track_iter_masked_f64(const double* Tji, const double* K, const double* aff, const double* P, const double* vals_i,
+                               const double* img, int H, int W, long N, double* J8, double* r_ws, uint8_t* valid_out,
+                               double* pj_out, double* depth_out, void* hists, void* partials, double* out,
+                               const uint8_t* in_mask, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Window BA linearisation (python path: backend/photo.py:83-233 batch_photo_cost).

@@ -1,0 +1,118 @@
+"""End-to-end timing of the headless sequential odometry loop (como_amd/odom/sequential.py) on a rendered 640x480 sequence
+with the parameters of the reference's config/como.yml (9 keyframes, 24 one-way frames, 64 inducing points, network input
+192x256, sub-selection window 4; tracking float32, mapping float64 system with float32 pixel kernels).
+
+    python scripts/gpu_odometry_bench.py [--frames 80] [--H 480 --W 640]
+
+Prints one JSON line: frames/s of the whole loop and the mean cost of its parts (tracked frame, mapping iteration, keyframe
+insertion, one-way insertion, tracker reference refresh).  Run on the GPU box through gpurun.
+"""
+import argparse
+import json
+import sys
+import time
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from como_amd import synth  # noqa: E402
+from como_amd.depth_cov.core.DepthCovModule import DepthCovModule  # noqa: E402
+from como_amd.odom.sequential import ComoSeq  # noqa: E402
+
+
+def cfgs(dev, args):
+    tracking = {"device": dev, "dtype": "float", "color": "gray",
+                "pyr": {"start_level": 0, "end_level": 3, "depth_interp_mode": "nearest_neighbor"},
+                "term_criteria": {"max_iter": 50, "delta_norm": 1.0e-3, "rel_tol": 1.0e-3, "grad_norm": 1.0},
+                "sigmas": {"photo": 1.0e-1},
+                "keyframing": {"kf_depth_motion_ratio": 0.12, "kf_num_pixels_frac": 0.75, "one_way_freq": 3}}
+    mapping = {"device": dev, "dtype": "double", "pix_dtype": args.pix, "color": "gray", "track_ref": {"num_keyframes": 1},
+               "graph": {"num_keyframes": 9, "num_one_way_frames": 24}, "network_size": [192, 256],
+               "photo_construction": {"nonmax_suppression_window": 4, "pairwise_batch_size": 128, "radius_thresh": 0.0,
+                                      "degrees_thresh": 0.0},
+               "term_criteria": {"max_iter": 20, "delta_norm": 1.0e-8, "abs_tol": 1.0e-6, "rel_tol": 1.0e-6},
+               "sigmas": {"photo": 1.0e-1, "mean_depth_prior": 1.0e-2, "scale_prior": 1.0e-4, "pose_prior": 1.0e-6},
+               "sampling": {"mode": "greedy_conditional_entropy", "max_num_coords": 64, "max_stdev_thresh": 1.0e-2, "border": 3,
+                            "fixed_var": 0.0, "dist_thresh": 1.0e-1},
+               "corr": {"corr_mode": "logz", "corr_thresh": 3.0e-2, "distill_with_prior": True, "min_obs_depth": 0.0,
+                        "logz_grad_mag_thresh": 7.0e-2},
+               "init": {"start_level": 0, "end_level": 3, "max_iter": 50, "delta_norm": 1.0e-4, "rel_tol": 1.0e-4,
+                        "kf_depth_motion_ratio": 0.04, "kf_num_pixels_frac": 0.75}}
+    return {"tracking": tracking, "mapping": mapping}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=80)
+    ap.add_argument("--H", type=int, default=480)
+    ap.add_argument("--W", type=int, default=640)
+    ap.add_argument("--step", type=float, default=0.01)
+    ap.add_argument("--pix", default="float")
+    args = ap.parse_args()
+    dev = "cuda:0"
+    H, W = args.H, args.W
+    scene = synth.PlaneScene(seed=1, freq_scale=W / 640.0)
+    K = synth.intrinsics_for(H, W)
+    T = synth.gt_poses(args.frames, step=args.step, deg=0.3)
+    g = torch.Generator().manual_seed(1)
+    rgbs = []
+    for k in range(args.frames):
+        I, _ = scene.render(T[k], K, H, W)
+        I = I + 0.002 * torch.randn(I.shape, generator=g, dtype=torch.float64)
+        rgbs.append(I[None, None].repeat(1, 3, 1, 1).to(dev))
+    model = DepthCovModule({k: v.to(dev) for k, v in synth.depthcov_state_dict(0).items()})
+    odo = ComoSeq(cfgs(dev, args), K.clone(), (H, W), model)
+
+    # instrument the parts (synchronising timers: this is a breakdown, the loop total below is measured without them)
+    parts = {}
+
+    def timed(obj, name, label):
+        fn = getattr(obj, name)
+
+        def wrap(*a, **k):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn(*a, **k)
+            torch.cuda.synchronize()
+            parts.setdefault(label, []).append(time.perf_counter() - t0)
+            return r
+        setattr(obj, name, wrap)
+
+    if os.environ.get("COMO_ODO_BREAKDOWN", "1") == "1":
+        timed(odo.tracking, "handle_frame", "track_frame")
+        timed(odo.tracking, "update_kf_reference", "tracker_reference_refresh")
+        timed(odo.mapping, "iterate", "mapping_iterate")
+        timed(odo.mapping, "add_keyframe", "add_keyframe")
+        timed(odo.mapping, "add_one_way_frame", "add_one_way_frame")
+        timed(odo.mapping, "attempt_two_frame_init", "two_frame_init_attempt")
+    kinds = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    t_first_tracked = None
+    for k in range(args.frames):
+        kinds.append(odo.iter(1.0 + 0.033 * k, rgbs[k]))
+        if t_first_tracked is None and odo.mapping.is_init:
+            torch.cuda.synchronize()
+            t_first_tracked = (k, time.perf_counter())
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    n_tracked = args.frames - 1 - t_first_tracked[0]
+    # trajectory error against GT after a similarity alignment of the translations (monocular: scale is a gauge)
+    est = torch.stack([p[0, :3, 3].double().cpu() for p in odo.est_poses])
+    gt = T[args.frames - len(odo.est_poses):, :3, 3]
+    s = (est * gt).sum() / (est * est).sum() if (est * est).sum() > 0 else 1.0
+    out = {"frames": args.frames, "size": [H, W], "loop_fps_after_init": n_tracked / (t1 - t_first_tracked[1]),
+           "loop_ms_per_frame_after_init": 1e3 * (t1 - t_first_tracked[1]) / max(n_tracked, 1),
+           "init_done_at_frame": t_first_tracked[0],
+           "requests": {str(k): kinds.count(k) for k in set(kinds)},
+           "keyframes": len(odo.mapping.kf_timestamps), "one_way_frames": len(odo.mapping.recent_timestamps),
+           "landmarks": int(odo.mapping.P_m.shape[0]), "window_full": bool(odo.mapping.window_full),
+           "parts_ms": {k: {"mean": 1e3 * sum(v) / len(v), "max": 1e3 * max(v), "n": len(v)} for k, v in parts.items()},
+           "traj_scale": float(s), "traj_rmse_after_scale": float(((s * est - gt) ** 2).sum(1).mean().sqrt())}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
