@@ -10,10 +10,28 @@ from como_amd.depth_cov.core.gaussian_kernel import interpolate_kernel_params
 from como_amd.utils.coords import normalize_coordinates
 
 
+def _gram(A, b, chunks=256):
+    """A^T A and A^T b for a tall A (B,n,m), n >> m.  As one GEMM the m x m output is a single tile -- one workgroup walking
+    the whole K = n dimension (20 ms at n = 300k in float64) -- so the rows are split into `chunks` slabs whose partial
+    products run as a batched GEMM and are summed."""
+    B, n, m = A.shape
+    if n < 16 * chunks:
+        return A.mT @ A, A.mT @ b
+    per = -(-n // chunks)
+    pad = per * chunks - n
+    if pad:
+        A = torch.cat((A, A.new_zeros((B, pad, m))), dim=1)
+        b = torch.cat((b, b.new_zeros((B, pad, b.shape[2]))), dim=1)
+    Ac = A.reshape(B * chunks, per, m)
+    bc = b.reshape(B * chunks, per, b.shape[2])
+    return ((Ac.mT @ Ac).reshape(B, chunks, m, m).sum(1), (Ac.mT @ bc).reshape(B, chunks, m, b.shape[2]).sum(1))
+
+
 def lstsq_chol(A, b):
     """como/utils/lin_alg.py:82-87: normal equations + Cholesky."""
-    L, _ = torch.linalg.cholesky_ex(A.mT @ A, upper=False)
-    return torch.cholesky_solve(A.mT @ b, L, upper=False)
+    AtA, Atb = _gram(A, b)
+    L, _ = torch.linalg.cholesky_ex(AtA, upper=False)
+    return torch.cholesky_solve(Atb, L, upper=False)
 
 
 def calc_kernel_matrices(coords_m, coords_n, cov_params_img, model):
@@ -57,8 +75,9 @@ def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model,
     Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model))
     if stdev_obs is not None:
         sinv = (1.0 / stdev_obs) * torch.ones_like(sinv)
-    ok = z_obs[0, :, 0] > min_depth
-    return distill_depth(Kt[:, ok, :], z_obs[:, ok, :], distill_with_prior, L_mm=L_mm, stdev_inv_obs=sinv[:, ok, :])
+    ok = torch.nonzero(z_obs[0, :, 0] > min_depth)[:, 0]
+    return distill_depth(Kt.index_select(1, ok), z_obs.index_select(1, ok), distill_with_prior, L_mm=L_mm,
+                         stdev_inv_obs=sinv.index_select(1, ok))
 
 
 def distill_conditional_depth_with_scale_prior(Knm_Kmminv, z_obs, z1, stdev_inv_obs):
@@ -81,5 +100,6 @@ def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_
     assert coords_m.shape[0] == 1
     Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model))
     sinv = (1.0 / stdev_obs) * torch.ones_like(sinv)
-    ok = z_obs[0, :, 0] > min_depth
-    return distill_conditional_depth_with_scale_prior(Kt[:, ok, :], z_obs[:, ok, :], z_m1, sinv[:, ok, :])
+    ok = torch.nonzero(z_obs[0, :, 0] > min_depth)[:, 0]
+    return distill_conditional_depth_with_scale_prior(Kt.index_select(1, ok), z_obs.index_select(1, ok), z_m1,
+                                                      sinv.index_select(1, ok))

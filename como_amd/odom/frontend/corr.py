@@ -24,7 +24,8 @@ def filter_reproj_coords(coords, P, img_size, min_depth):
     """Keep points at least one pixel inside the image and deeper than min_depth (corr.py:17-29).  coords (1,n,2) row/col."""
     r, c = coords[0, :, 0], coords[0, :, 1]
     keep = (c >= 1) & (c < img_size[-1] - 1) & (r >= 1) & (r < img_size[-2] - 1) & (P[0, :, 2] > min_depth)
-    return coords[:, keep, :], P[:, keep, :], keep
+    idx = torch.nonzero(keep)[:, 0]                      # index_select: far faster than boolean indexing of a middle dimension
+    return coords.index_select(1, idx), P.index_select(1, idx), keep
 
 
 def condition_depth(logz_m, Knm_Kmminv):

@@ -59,6 +59,10 @@ def main():
     timed(map_mod, "track_and_init", "kf.track_and_init")
     timed(map_mod, "_run_model", "kf.run_model")
     timed(map_mod, "_prep_predictor", "kf.prep_predictor")
+    import como_amd.odom.frontend.corr as corr
+    for nm in ("reproject_points", "distill_depth_from_scratch", "distill_conditional_depth_from_scratch", "sample_sparse_coords",
+               "filter_reproj_coords", "_sample_at"):
+        timed(corr, nm, "kf.corr." + nm)
     odo = seq_mod.ComoSeq(ob.cfgs(dev, args), K.clone(), (480, 640), model)
     timed(odo.tracking, "prep_tracking_img", "trk.prep_tracking_img")
     timed(odo.tracking, "get_reproj_last_kf", "trk.get_reproj_last_kf")
