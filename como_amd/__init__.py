@@ -19,6 +19,13 @@ _DROPIN = {
     "como.depth_cov.core.samplers": "como_amd.depth_cov.core.samplers",
     "como.depth_cov.core.distill_depth": "como_amd.depth_cov.core.distill_depth",
     "como.utils.image_processing": "como_amd.utils.image_processing",
+    "como.odom.frontend.corr": "como_amd.odom.frontend.corr",
+    "como.odom.frontend.two_frame_sfm": "como_amd.odom.frontend.two_frame_sfm",
+    "como.odom.frontend.TwoFrameSfm": "como_amd.odom.frontend.TwoFrameSfm",
+    "como.odom.Mapping": "como_amd.odom.Mapping",
+    "como.odom.Tracking": "como_amd.odom.Tracking",
+    "como.geometry.transforms": "como_amd.geometry.transforms",
+    "como.geometry.affine_brightness": "como_amd.geometry.affine_brightness",
     "como.odom.factors.gp_priors": "como_amd.odom.factors.gp_priors",
     "como.odom.factors.depth_prior": "como_amd.odom.factors.depth_prior",
     "como.odom.factors.pixel_prior": "como_amd.odom.factors.pixel_prior",

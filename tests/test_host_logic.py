@@ -99,3 +99,97 @@ def test_cpu_tensors_are_rejected_loudly():
     E = torch.eye(2).expand(1, 2, 2, 2).contiguous()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         cb.cross_covariance(x, E, x, E, 1.0)
+
+
+def _cpu_mapping(num_kf=3, m=12):
+    from como_amd.odom.Mapping import Mapping
+    cfg = {"device": "cpu", "dtype": "double", "color": "gray", "graph": {"num_keyframes": num_kf, "num_one_way_frames": 4},
+           "sampling": {"max_num_coords": m}}
+    mp = Mapping(cfg, torch.eye(3, dtype=torch.float64))
+    mp.init_keyframe_vars()
+    mp.init_prior_vals()
+    return mp
+
+
+def test_mapping_window_bookkeeping_vs_reference_snapshots():
+    """Correspondence-mask / landmark-list / anchor bookkeeping of Mapping (pure torch) replayed on CPU between consecutive
+    snapshots of the reference's run (mapping_f64.npz): every keyframe insertion must reproduce the reference's mask."""
+    G = load_golden("mapping_f64.npz")
+    tags = [str(t) for t in G["snap_tags"]]
+    N = 3
+    for i in range(1, len(tags)):
+        if not tags[i].startswith("add_kf"):
+            continue
+        prev, new = G[f"s{i - 1}_correspondence_mask"], G[f"s{i}_correspondence_mask"]
+        P_prev, P_new = G[f"s{i - 1}_P_m"], G[f"s{i}_P_m"]
+        start = -N + 1
+        alive = prev[start:, :].any(dim=0)
+        n_alive = int(alive.sum())
+        tracked_full = torch.zeros(prev.shape[1], dtype=torch.bool)
+        tracked_full[alive] = new[-1, :n_alive]
+        corr_mask = tracked_full[prev[-1]]
+        mp = _cpu_mapping(N)
+        mp.correspondence_mask, mp.P_m = prev.clone(), P_prev.clone()
+        mp.initialize_sparse_landmark_vars(corr_mask, P_new[n_alive:])
+        assert torch.equal(mp.correspondence_mask, new), tags[i]
+        assert torch.equal(mp.P_m, torch.cat((P_prev[alive], P_new[n_alive:]))), tags[i]
+        assert bool(mp.window_full) == bool(G[f"s{i}_window_full"]), tags[i]
+        if mp.window_full:
+            assert torch.equal(mp.P_m_anchors, mp.P_m[new[0]])
+    # pose / affine anchors when the window slides: the oldest remaining keyframe becomes the gauge
+    mp = _cpu_mapping(N)
+    g = torch.Generator().manual_seed(0)
+    for k in range(4):
+        T = torch.eye(4, dtype=torch.float64)[None].clone()
+        T[0, :3, 3] = torch.randn(3, generator=g, dtype=torch.float64)
+        mp.initialize_pose_vars(T, torch.randn((1, 2, 1), generator=g, dtype=torch.float64))
+    assert mp.kf_poses.shape[0] == N and mp.window_full
+    assert torch.equal(mp.pose_anchor, mp.kf_poses[0:1]) and float(mp.kf_aff_params[0].abs().max()) == 0.0
+    # one-way frames older than the oldest keyframe are pruned
+    mp.kf_timestamps = [5.0, 6.0, 7.0]
+    mp.recent_timestamps = [4.0, 4.5, 5.5, 6.5]
+    mp.recent_poses = torch.arange(4, dtype=torch.float64).reshape(4, 1, 1).expand(4, 4, 4).clone()
+    mp.recent_aff_params = torch.zeros((4, 2, 1), dtype=torch.float64)
+    mp.recent_img_and_grads = torch.zeros((4, 3, 2, 2), dtype=torch.float64)
+    mp.prune_one_way()
+    assert mp.recent_timestamps == [5.5, 6.5] and mp.recent_poses[:, 0, 0].tolist() == [2.0, 3.0]
+
+
+def test_fill_image_last_point_wins_like_torch_cpu():
+    """fill_image's explicit last-wins rule equals what the reference's `img[:, r, c] = vals` does on the CPU."""
+    from como_amd.utils.coords import fill_image
+    g = torch.Generator().manual_seed(1)
+    coords = torch.rand((500, 2), generator=g) * torch.tensor([7.0, 9.0])
+    vals = torch.rand((500, 1), generator=g)
+    want = float("nan") * torch.ones((1, 7, 9))
+    cl = coords.long()
+    want[:, cl[..., 0], cl[..., 1]] = vals[..., 0]
+    got = fill_image(coords, vals, (7, 9))
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(torch.nan_to_num(got), torch.nan_to_num(want))
+
+
+def test_tracking_request_rules():
+    """Keyframe / one-way request rules of Tracking (Tracking.py:110-161) on hand-made statistics."""
+    from como_amd.odom.Tracking import Tracking
+    cfg = {"device": "cpu", "dtype": "float", "color": "gray",
+           "keyframing": {"kf_depth_motion_ratio": 0.1, "kf_num_pixels_frac": 0.75, "one_way_freq": 3}}
+    trk = Tracking(cfg, torch.eye(3), (10, 10))
+    trk.init_kf_vars()
+    trk.reset_one_way_vars()
+    trk.vals_pyr = [torch.zeros((1, 100, 1))]
+    T = torch.eye(4)[None].clone()
+    med = torch.tensor(2.0)
+    T[0, 0, 3] = 0.19
+    assert not trk.check_keyframe(med, torch.tensor(90), T)          # 0.19 < 0.1 * 2, 90 % of the pixels still seen
+    T[0, 0, 3] = 0.21
+    assert trk.check_keyframe(med, torch.tensor(90), T)              # moved far enough
+    T[0, 0, 3] = 0.0
+    assert trk.check_keyframe(med, torch.tensor(70), T)              # too few pixels re-observed
+    trk.last_kf_sent_ts = 5.0                                        # a keyframe request is in flight: no second one
+    assert not trk.check_keyframe(med, torch.tensor(10), T)
+    # one-way frames: thresholds scaled by (1 + sent + pending) / (1 + freq) = 2/4 while the keyframe is pending
+    T[0, 0, 3] = 0.11
+    assert trk.check_one_way_frame(med, torch.tensor(100), T, T)     # 0.11 > 0.5 * 0.2
+    T[0, 0, 3] = 0.09
+    assert not trk.check_one_way_frame(med, torch.tensor(100), T, T)
+    assert trk.check_one_way_frame(med, torch.tensor(80), T, T)      # 20 empty pixels > 0.5 * 25
