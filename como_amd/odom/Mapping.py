@@ -4,7 +4,7 @@ GUI / process / queue plumbing.  Same method names, arguments and state attribut
 
 What runs where:
   * `iterate()`                 -> `WindowBA` (odom/window_ba.py): the fused HIP chain (scaffold, dense reference, photometric
-                                   system, priors, Cholesky, update), hipGraph-replayed once the window is full; the
+                                   system, priors, Cholesky, update) once the window is full; the
                                    reference-signature path while it fills.  The WindowBA object is rebuilt whenever the
                                    window's topology changes (new keyframe / one-way frame) and owns the iteration state in
                                    between; this class's attributes are refreshed from it after every iteration.
@@ -361,9 +361,8 @@ class Mapping:
     def iterate(self):
         if self._ba is None:
             cfg = {"photo_construction": self.cfg["photo_construction"], "sigmas": self.cfg["sigmas"]}
+            # (eager launches: a topology lives for ~2-3 iterations in the sequential loop, less than a graph capture costs)
             self._ba = WindowBA(self._window_state(), cfg=cfg, pix_dtype=self.pix_dtype, window_full=self.window_full)
-            if self._ba.fused and self.cfg.get("graph_iterate", False):
-                self._ba.capture(warmup=0)
         ba = self._ba
         ba.step()
         # refresh the public state from the solver's buffers
