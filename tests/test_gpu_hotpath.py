@@ -901,7 +901,8 @@ def test_window_iterate_with_one_way_frames_vs_golden(name, full):
     assert (wb.P_m.cpu() - G["P_new"]).abs().max().item() < 1e-8
 
 
-def test_mapping_state_machine_vs_golden():
+@pytest.mark.parametrize("pix", ["double", "float"])
+def test_mapping_state_machine_vs_golden(pix):
     """Mapping mirror (como_amd/odom/Mapping.py) driven through the reference's sequence: first keyframe, second keyframe,
     one-way frame, third keyframe, and a fourth that makes the 3-keyframe window slide, two GN iterations after every
     insertion (float64 pixel path).  Window bookkeeping (correspondence mask, first-observation masks, timestamps,
@@ -911,7 +912,7 @@ def test_mapping_state_machine_vs_golden():
     from como_amd.odom.Mapping import Mapping
     from como_amd.synth import depthcov_state_dict
     G = load_golden("mapping_f64.npz")
-    cfg = {"device": DEV, "dtype": "double", "pix_dtype": "double", "color": "gray", "track_ref": {"num_keyframes": 1},
+    cfg = {"device": DEV, "dtype": "double", "pix_dtype": pix, "color": "gray", "track_ref": {"num_keyframes": 1},
            "graph": {"num_keyframes": 3, "num_one_way_frames": 4}, "network_size": [32, 64], "graph_network": False,
            "photo_construction": {"nonmax_suppression_window": 2, "pairwise_batch_size": 128, "radius_thresh": 0.0,
                                   "degrees_thresh": 0.0},
@@ -920,6 +921,8 @@ def test_mapping_state_machine_vs_golden():
                         "fixed_var": 0.0, "dist_thresh": 1.0e-1},
            "corr": {"corr_mode": "logz", "corr_thresh": 3.0e-2, "distill_with_prior": True, "min_obs_depth": 0.0,
                     "logz_grad_mag_thresh": 7.0e-2}}
+    # "float": the production configuration (float32 per-pixel kernels, float64 system) -- same decisions, looser values
+    loose = pix == "float"
     mp = Mapping(cfg, G["K"].clone())
     mp.setup(DepthCovModule({k: dev(v) for k, v in depthcov_state_dict(0).items()}))
     rgb = dev(G["rgb"])
@@ -937,7 +940,7 @@ def test_mapping_state_machine_vs_golden():
         got = mp.pm_first_obs.cpu()
         sampled = (want == want.round()).all(dim=-1)                      # freshly sampled points sit on integer pixels
         assert torch.equal(got[sampled], want[sampled]), tags[i]          # same sampled pixels
-        assert (got - want).abs().max().item() < 1e-4, tags[i]            # tracked ones: reprojections through estimated poses
+        assert (got - want).abs().max().item() < (2e-2 if loose else 1e-4), tags[i]   # tracked: reprojections through estimated poses
         worst["pose"] = max(worst["pose"], (mp.kf_poses.cpu() - g("kf_poses")).abs().max().item())
         worst["aff"] = max(worst["aff"], (mp.kf_aff_params.cpu() - g("kf_aff_params")).abs().max().item())
         worst["P"] = max(worst["P"], (mp.P_m.cpu() - g("P_m")).abs().max().item())
@@ -945,9 +948,9 @@ def test_mapping_state_machine_vs_golden():
         worst["med"] = max(worst["med"], (mp.median_depths.cpu() - g("median_depths")).abs().max().item())
         if g("recent_poses").numel():
             worst["pose"] = max(worst["pose"], (mp.recent_poses.cpu() - g("recent_poses")).abs().max().item())
-        assert (mp.pose_anchor.cpu() - g("pose_anchor")).abs().max().item() < 1e-4, tags[i]
+        assert (mp.pose_anchor.cpu() - g("pose_anchor")).abs().max().item() < (1e-3 if loose else 1e-4), tags[i]
         if f"s{i}_P_m_anchors" in G:
-            assert (mp.P_m_anchors.cpu() - G[f"s{i}_P_m_anchors"]).abs().max().item() < 1e-3, tags[i]
+            assert (mp.P_m_anchors.cpu() - G[f"s{i}_P_m_anchors"]).abs().max().item() < (1e-2 if loose else 1e-3), tags[i]
 
     T0 = dev(G["poses_gt"])[0:1].clone()
     mp.init_keyframe(rgb[0:1], dev(G["cov_net0"]), dev(G["coords_m0"]), T0, dev(G["logz_m0"]),
@@ -966,8 +969,11 @@ def test_mapping_state_machine_vs_golden():
         mp.iterate()
         check(i + 1)
         i += 2
-    report("mapping", snapshots=len(tags), landmarks=int(mp.P_m.shape[0]), **{k + "_abs_err": v for k, v in worst.items()})
-    assert worst["pose"] < 1e-5 and worst["aff"] < 1e-4 and worst["P"] < 1e-3 and worst["logz"] < 1e-3 and worst["med"] < 2e-2
+    report("mapping", pix=pix, snapshots=len(tags), landmarks=int(mp.P_m.shape[0]), **{k + "_abs_err": v for k, v in worst.items()})
+    if loose:
+        assert worst["pose"] < 1e-4 and worst["aff"] < 1e-3 and worst["P"] < 1e-2 and worst["logz"] < 1e-2 and worst["med"] < 2e-2
+    else:
+        assert worst["pose"] < 1e-5 and worst["aff"] < 1e-4 and worst["P"] < 1e-3 and worst["logz"] < 1e-3 and worst["med"] < 2e-2
 
 
 def test_two_frame_init_state_machine_vs_golden():
