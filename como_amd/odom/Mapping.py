@@ -166,12 +166,21 @@ class Mapping:
             self._depth_cache = torch.exp(logz)
         return self._depth_cache
 
+    def depth_imgs_of(self, lo, hi):
+        """Depth images of keyframes lo..hi-1 only (one 157 MB predictor each at 640x480: the tracker asks for the newest one
+        on every frame, `depth_imgs` would evaluate all nine)."""
+        if self._depth_cache is not None:
+            return self._depth_cache[lo:hi]
+        Kt = self.Knm_Kmminv[lo:hi]
+        b, h, w, m = Kt.shape
+        return torch.exp((Kt.reshape(b, h * w, m) @ self.logzm[lo:hi].reshape(b, m, 1)).reshape(b, 1, h, w))
+
     def get_kf_ref_data(self, ind=-1):
         """Mapping.py:499-512: the newest `track_ref.num_keyframes` keyframes for the tracker."""
         end = self.kf_poses.shape[0]
         ind = max(0, end - self.cfg["track_ref"]["num_keyframes"])
         return (self.kf_timestamps[ind:end], self.rgb[ind:end], self.kf_poses[ind:end], self.kf_aff_params[ind:end],
-                self.depth_imgs[ind:end])
+                self.depth_imgs_of(ind, end))
 
     def get_kf_viz_data(self, ind=-1):
         """Mapping.py:514-544: cloned snapshot for a viewer."""
@@ -212,7 +221,8 @@ class Mapping:
         coords_m_last = swap_coords_xy(self.pm[-1:, ...])
         zm_last = torch.exp(self.logzm[-1:, ...])
         coords_m_new, z_m_new, corr_mask, coords_m, zm_first_obs = track_and_init(
-            self.kf_poses[-1:, ...], kf_pose_init, coords_m_last, zm_last, self.depth_imgs[-1:, ...], cov_params_img,
+            self.kf_poses[-1:, ...], kf_pose_init, coords_m_last, zm_last, self.depth_imgs_of(self.kf_poses.shape[0] - 1,
+                                                                                             self.kf_poses.shape[0]), cov_params_img,
             self.intrinsics, self.model, self.cfg["corr"], self.cfg["sampling"], self.kf_img_and_grads.shape[-2:])
         p_m_new = swap_coords_xy(coords_m_new).to(dtype=z_m_new.dtype)
         Pc_new, _ = backprojection(self.intrinsics[0], p_m_new, z_m_new)
