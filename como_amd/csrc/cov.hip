@@ -301,21 +301,22 @@ int como_greedy_next_f32(const float* var, const float* coords_domain, const flo
 
 int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,
                          float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
-                         float k_ii, float dist_thresh_sq, int B, int n, int d, int m, como_stream_t stream) {
+                         float k_ii, float dist_thresh_sq, int B, int n, int d, int m, float* sd_trace, como_stream_t stream) {
   using namespace como;
   if (!coords_n || !E_n || !coord_vec_inds || !coords_domain || !E_domain || !L || !obs_info || !var || !mask || !best_idx ||
       !max_stdev || B <= 0 || n <= 0 || n > 64 || d <= 0 || m < 1 || m > n)
     return COMO_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(1024), 0, s, var, coords_domain, E_domain, coords_n, E_n, coord_vec_inds,
-                     n, 0, m, mask, dist_thresh_sq, m, best_idx, max_stdev, d);
+                     n, 0, m, mask, dist_thresh_sq, m, best_idx, sd_trace ? sd_trace + (long)m * B : max_stdev, d);
   COMO_CHECK_LAUNCH();
   for (int i = m; i < n; ++i) {
     hipLaunchKernelGGL(greedy_append_kernel, dim3((d + 255) / 256, B), dim3(256), 0, s, coords_n, E_n, coords_domain, E_domain, L,
                        obs_info, var, scale, k_ii, n, d, i);
     COMO_CHECK_LAUNCH();
     hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(1024), 0, s, var, coords_domain, E_domain, coords_n, E_n,
-                       coord_vec_inds, n, i, 1, mask, dist_thresh_sq, i + 1, best_idx, max_stdev, d);
+                       coord_vec_inds, n, i, 1, mask, dist_thresh_sq, i + 1, best_idx,
+                       sd_trace ? sd_trace + (long)(i + 1) * B : max_stdev, d);
     COMO_CHECK_LAUNCH();
   }
   return COMO_OK;

@@ -112,13 +112,21 @@ def greedy_loop(coord_vec_inds, coords_n_norm, E_n, coords_domain_norm, E_domain
     k_ii = sv + (float(fixed_var) if fixed_var is not None else 0.0)
     nxt = _Next(coords_domain_norm, dist_thresh)
     pred_var = calc_var(obs_info[:, :m, :], sv).contiguous()
-    if not terminate_early and all(t.is_contiguous() for t in (coords_n_norm, E_n, L, obs_info, coord_vec_inds, E_domain)):
-        # the whole loop on the device: two launches per added point, nothing read back
+    if all(t.is_contiguous() for t in (coords_n_norm, E_n, L, obs_info, coord_vec_inds, E_domain)):
+        # the whole loop on the device: two launches per added point.  Early termination (samplers.py:255-259) is decided
+        # afterwards from the per-step trace of the largest remaining standard deviation -- the greedy sequence does not
+        # depend on where it is cut -- with ONE read-back instead of one per step.
+        trace = torch.zeros((n + 1, b), device=dev, dtype=torch.float32) if terminate_early else None
         rc = _lib.lib().como_greedy_loop_f32(coords_n_norm.data_ptr(), E_n.data_ptr(), coord_vec_inds.data_ptr(),
                                              nxt.dom.data_ptr(), E_domain.data_ptr(), L.data_ptr(), obs_info.data_ptr(),
                                              pred_var.data_ptr(), nxt.mask.data_ptr(), nxt.best.data_ptr(), nxt.sd.data_ptr(),
-                                             sv, k_ii, nxt.t2, b, n, nxt.d, m, _lib.stream_ptr(dev))
+                                             sv, k_ii, nxt.t2, b, n, nxt.d, m, _lib.ptr(trace), _lib.stream_ptr(dev))
         _lib.check(rc, "como_greedy_loop_f32")
+        if terminate_early:
+            below = (trace[m:n] < max_stdev_thresh).all(dim=1).tolist()
+            for k, stop in enumerate(below):
+                if stop:
+                    return coord_vec_inds[:, :m + k]
         return coord_vec_inds
     max_sd, best = nxt(pred_var, coords_n_norm[:, :m, :])
     for i in range(m, n):
