@@ -25,6 +25,7 @@ _DROPIN = {
     "como.odom.Mapping": "como_amd.odom.Mapping",
     "como.odom.Tracking": "como_amd.odom.Tracking",
     "como.geometry.transforms": "como_amd.geometry.transforms",
+    "como.utils.io": "como_amd.utils.io",
     "como.geometry.affine_brightness": "como_amd.geometry.affine_brightness",
     "como.odom.factors.gp_priors": "como_amd.odom.factors.gp_priors",
     "como.odom.factors.depth_prior": "como_amd.odom.factors.depth_prior",

@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--W", type=int, default=640)
     ap.add_argument("--step", type=float, default=0.01)
     ap.add_argument("--pix", default="float")
+    ap.add_argument("--save-traj", default=None, help="write the tracked trajectory in TUM format")
     args = ap.parse_args()
     dev = "cuda:0"
     H, W = args.H, args.W
@@ -111,6 +112,9 @@ def main():
            "landmarks": int(odo.mapping.P_m.shape[0]), "window_full": bool(odo.mapping.window_full),
            "parts_ms": {k: {"mean": 1e3 * sum(v) / len(v), "max": 1e3 * max(v), "n": len(v)} for k, v in parts.items()},
            "traj_scale": float(s), "traj_rmse_after_scale": float(((s * est - gt) ** 2).sum(1).mean().sqrt())}
+    if args.save_traj:
+        from como_amd.utils.io import save_traj
+        save_traj(args.save_traj, odo.timestamps, torch.cat([p.double().cpu() for p in odo.est_poses]))
     print(json.dumps(out))
 
 

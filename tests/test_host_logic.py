@@ -193,3 +193,21 @@ def test_tracking_request_rules():
     T[0, 0, 3] = 0.09
     assert not trk.check_one_way_frame(med, torch.tensor(100), T, T)
     assert trk.check_one_way_frame(med, torch.tensor(80), T, T)      # 20 empty pixels > 0.5 * 25
+
+
+def test_trajectory_io_roundtrip(tmp_path):
+    """save_traj writes TUM lines (timestamp tx ty tz qx qy qz qw, 4 decimals) that read back to the poses."""
+    import numpy as np
+    from como_amd.geometry.lie_algebra import se3_exp
+    from como_amd.utils.io import pose_to_tq, save_traj, tq_to_pose
+    g = torch.Generator().manual_seed(3)
+    T = se3_exp(0.3 * torch.randn((5, 6), generator=g, dtype=torch.float64))
+    tq = pose_to_tq(T)
+    assert tq.shape == (5, 7) and np.allclose(np.linalg.norm(tq[:, 3:], axis=1), 1.0)
+    assert np.allclose(tq_to_pose(tq), T.numpy(), atol=1e-12)
+    assert pose_to_tq(T[0]).shape == (7,)
+    p = tmp_path / "traj.txt"
+    save_traj(str(p), [0.5 * k for k in range(5)], T)
+    rows = np.loadtxt(str(p))
+    assert rows.shape == (5, 8) and np.allclose(rows[:, 0], [0.0, 0.5, 1.0, 1.5, 2.0])
+    assert np.allclose(tq_to_pose(rows[:, 1:]), T.numpy(), atol=2e-4)              # 4 decimals
