@@ -354,7 +354,7 @@ class Mapping:
 
     # ---- one Gauss-Newton iteration over the window (Mapping.py:760-968) -------------------------------------------------
     def _window_state(self):
-        ts = lambda lst: torch.as_tensor([float(t) for t in lst], device=self.device, dtype=self.dtype)
+        ts = lambda lst: torch.as_tensor([float(t) for t in lst], dtype=torch.float64)     # host: only the pair graph reads them
         st = {"intrinsics": self.intrinsics, "kf_poses": self.kf_poses, "kf_aff_params": self.kf_aff_params,
               "kf_img_and_grads": self.kf_img_and_grads, "coords_m": self.pm, "P_m": self.P_m,
               "correspondence_mask": self.correspondence_mask, "obs_ref_mask": self.obs_ref_mask,

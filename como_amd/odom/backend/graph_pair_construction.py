@@ -38,8 +38,8 @@ def get_kf_edges(poses, median_depths, cfg):
 def get_one_way_temporal_neighbors(kf_timestamps, recent_timestamps):
     """Each recent frame is linked to the keyframe before and after it; frames newer than the newest
     keyframe only to that keyframe (reference :97-133)."""
-    kf_ts = [float(t) for t in kf_timestamps]
-    rc_ts = [float(t) for t in recent_timestamps]
+    as_list = lambda ts: [float(t) for t in (ts.tolist() if torch.is_tensor(ts) else ts)]   # ONE read-back for a tensor
+    kf_ts, rc_ts = as_list(kf_timestamps), as_list(recent_timestamps)
     nk, nr = len(kf_ts), len(rc_ts)
     kf_ids, r_ids = [], []
     k = -1

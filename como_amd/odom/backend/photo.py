@@ -207,10 +207,9 @@ class PairTable:
         self.tgt_img = torch.as_tensor(off, dtype=torch.int64, device=device)
         rid = torch.as_tensor(ref_ids, dtype=torch.long, device=device)
         self.pose_ref_inds = kf_inds[rid].contiguous()
-        rows = []
-        for t, r in zip(tgt_ids, tgt_is_recent):
-            rows.append(recent_inds[t] if r else kf_inds[t])
-        self.pose_tgt_inds = torch.stack(rows).contiguous()
+        # system rows of every target frame with ONE gather (keyframes first, then the one-way frames)
+        frame_rows = torch.cat((kf_inds, recent_inds), dim=0) if any(tgt_is_recent) else kf_inds
+        self.pose_tgt_inds = frame_rows[torch.as_tensor(tgt_frame, dtype=torch.long, device=device)].contiguous()
         self.landmark_inds = landmark_inds[rid].contiguous()
         # pairs sharing their reference keyframe, two at a time (csrc/ba.hip ba_blocks_pair2_kernel); the rest one by one
         by_ref = {}
