@@ -62,93 +62,134 @@ __device__ __forceinline__ double rsq_refined(double d) {      // hardware estim
   return r;
 }
 
-// Factor a CBxCB tile and invert the factor with 512 threads in ONE rolled loop, one barrier per pivot.
-// Measured cost model on MI355X (scripts/micro): one wave issues ~1 VALU instruction per 6 cycles, an LDS store ->
-// barrier -> load hop is ~150 cycles, f64 FMAs are not the problem.  The pivot loop is therefore bound by the
-// INSTRUCTIONS each wave executes per pivot, so the work is split by role:
-//   threads   0..255 (F): thread (ty, tx) owns A[ty+16a][tx+16b]; step c: load raw column c, 1/d, rank-1 update,
-//                         owners of column c+1 store it raw (oC[c+1][:]) for the next step
-//   threads 256..511 (I): thread (ty, tx) owns S[ty+16a][tx+16b] (S = I initially); step c handles pivot t = c-1:
-//                         load raw column t and raw row t of S, 1/sqrt(d) -> sq[t], S[i][:] -= L[i][t] X[t][:],
-//                         owners of row t+1 store it raw (oS[t+1][:])
-// Nothing is scaled inside the loop: L[r][c] = oC[c][r] * sq[c] and L^-1[t][j] = oS[t][j] * sq[t] are formed by
-// the copy-out.  (Earlier versions: a fully unrolled single-wave register kernel was instruction-fetch bound -- 40 KB
-// of straight-line code executed once; 256 threads doing both roles took 1100 cycles per pivot.)
-// oC, oS: CB x CB doubles each; sq: CB doubles.
-__device__ __forceinline__ void factor_invert_tile(double (&v)[2][2], double* oC, double* oS, double* sq,
-                                                   double* __restrict__ Lw, double* __restrict__ Iw, int Dp, int k, int D,
-                                                   int* __restrict__ info, double* ldsInv = nullptr) {
-  const int tid = threadIdx.x, role = tid >> 8, lt = tid & 255, tx = lt & 15, ty = lt >> 4;
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double rsq_cubic(double d) {        // hardware estimate (24 bits) + one third-order correction
+  const double r = __builtin_amdgcn_rsq(d);
+  const double e = __builtin_fma(-(d * r), r, 1.0);
+  return __builtin_fma(r, e * __builtin_fma(0.375, e, 0.5), r);
+}
+
+// Factor a 32x32 tile (lower part of the LDS tile At, leading dimension CLD) and invert the factor, 512 threads, FOUR
+// pivots per barrier.  Measured cost model on MI355X (scripts/micro): a wave issues ~1 VALU instruction per 4-6 cycles, an
+// LDS store -> barrier -> load hop is ~150 cycles, dependent f64 ops ~6 cycles: a pivot-by-pivot loop (one barrier per
+// pivot, 32 of them) cost ~500 cycles per pivot = 6.7 us per tile, all of it on the serial chain of a panel step.
+// Blocked by 4, the per-pivot work becomes
+//   * a 4x4 Cholesky + inverse W of the diagonal micro-block, computed REDUNDANTLY by every lane of the four factor waves
+//     from ten LDS reads (no hand-off, ~45 dependent operations),
+//   * the panel P[r][0..3] = A[r][p0..p0+3] W^T and the rank-4 trailing update A -= P P^T as ONE v_mfma_f64_16x16x4_f64 per
+//     16x16 quadrant: waves 0..3 keep the quadrants of A in the MFMA accumulator layout, lane l supplies P[row l&15][k l>>4],
+//   * waves 4..7 run the inverse ONE block behind with the same shape: X_B = W S_B, S -= P X_B, reading W and P from LDS.
+// One barrier per block step, 9 in all.  Rows / columns are published raw to small ping-pong buffers; L and L^-1 go to
+// global memory (and L^-1 to `ldsInv` when the caller needs it on chip) as they are produced.
+// scratch: 800 doubles.  At may alias ldsInv (At is consumed before the first barrier, L^-1 is written after the second).
+__device__ __forceinline__ void factor_invert_tile(const double* At, double* scratch, double* __restrict__ Lw,
+                                                   double* __restrict__ Iw, int Dp, int k, int D, int* __restrict__ info,
+                                                   double* ldsInv = nullptr) {
+  const int tid = threadIdx.x, role = tid >> 8, w = (tid >> 6) & 3, l = tid & 63;
+  const int qa = w >> 1, qb = w & 1, lr = l & 15, kq = l >> 4;
   const long kk = (long)k * CB;
+  double* colbuf = scratch;             // [2][4][32] raw columns of the current block: colbuf[t][r] = A[r][p0 + t]
+  double* rowbuf = scratch + 256;       // [2][4][32] raw rows of S
+  double* Pbuf = scratch + 512;         // [2][4][32] panel of the block the inverse works on: P[t][r] (0 for r < p0 + 4)
+  double* Wbuf = scratch + 768;         // [2][16]    its micro-inverse W (row-major)
+  const int rowA = 16 * qa + lr, rowB = 16 * qb + lr;
+  d4_t acc;
   if (role == 0) {
-    if (tx == 0) { oC[ty] = v[0][0]; oC[ty + 16] = v[1][0]; }
-    for (int c = 0; c <= CB; ++c) {
-      __syncthreads();
-      if (c == CB) break;
-      const double* col = oC + c * CB;
-      double d = col[c];
-      const double c0 = col[tx], c1 = col[tx + 16], r0 = col[ty], r1 = col[ty + 16];
-      if (!(d > 0.0)) {
-        if (tid == 0 && kk + c < D) atomicCAS(info, 0, (int)kk + c + 1);
-        d = 1.0;
-      }
-      const double rinv = rcp_refined(d);
-      const double w0 = r0 * rinv, w1 = r1 * rinv;
-      const double m0 = (tx > c) ? c0 : 0.0, m1 = (tx + 16 > c) ? c1 : 0.0;
-      v[0][0] -= w0 * m0;
-      v[0][1] -= w0 * m1;
-      v[1][0] -= w1 * m0;
-      v[1][1] -= w1 * m1;
-      if (c + 1 < CB && tx == ((c + 1) & 15)) {
-        const bool hi = c + 1 >= 16;
-        double* nxt = oC + (c + 1) * CB;
-        nxt[ty] = hi ? v[0][1] : v[0][0];
-        nxt[ty + 16] = hi ? v[1][1] : v[1][0];
-      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 16 * qa + kq + 4 * i, c = 16 * qb + lr;
+      acc[i] = (c <= r) ? At[r * CLD + c] : 0.0;
+    }
+    if (qb == 0 && lr < 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) colbuf[lr * 32 + 16 * qa + kq + 4 * i] = acc[i];
     }
   } else {
-    double S[2][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int i = 0; i < 4; ++i) acc[i] = (16 * qa + kq + 4 * i == 16 * qb + lr) ? 1.0 : 0.0;
+    if (tid < 256 + 128) { const int t = (tid - 256) >> 5, j = (tid - 256) & 31; rowbuf[t * 32 + j] = (t == j) ? 1.0 : 0.0; }
+  }
+  for (int s = 0; s <= CB / 4; ++s) {
+    __syncthreads();
+    if (role == 0) {
+      if (s == CB / 4) continue;
+      const int p0 = 4 * s;
+      const double* cb = colbuf + (s & 1) * 128;
+      // ---- 4x4 micro-block: M = L L^T, W = L^-1
+      const double m00 = cb[p0], m10 = cb[p0 + 1], m20 = cb[p0 + 2], m30 = cb[p0 + 3];
+      const double m11 = cb[32 + p0 + 1], m21 = cb[32 + p0 + 2], m31 = cb[32 + p0 + 3];
+      const double m22 = cb[64 + p0 + 2], m32 = cb[64 + p0 + 3], m33 = cb[96 + p0 + 3];
+      int bad = 0;
+      double d0 = m00;
+      if (!(d0 > 0.0)) { bad = bad ? bad : 1; d0 = 1.0; }
+      const double i0 = rsq_cubic(d0);
+      const double l10 = m10 * i0, l20 = m20 * i0, l30 = m30 * i0;
+      double d1 = __builtin_fma(-l10, l10, m11);
+      if (!(d1 > 0.0)) { bad = bad ? bad : 2; d1 = 1.0; }
+      const double i1 = rsq_cubic(d1);
+      const double l21 = __builtin_fma(-l20, l10, m21) * i1, l31 = __builtin_fma(-l30, l10, m31) * i1;
+      double d2 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, m22));
+      if (!(d2 > 0.0)) { bad = bad ? bad : 3; d2 = 1.0; }
+      const double i2 = rsq_cubic(d2);
+      const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, m32)) * i2;
+      double d3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, m33)));
+      if (!(d3 > 0.0)) { bad = bad ? bad : 4; d3 = 1.0; }
+      const double i3 = rsq_cubic(d3);
+      if (bad && tid == 0 && kk + p0 + bad - 1 < D) atomicCAS(info, 0, (int)kk + p0 + bad);
+      const double w10 = -i1 * (l10 * i0);
+      const double w21 = -i2 * (l21 * i1);
+      const double w32 = -i3 * (l32 * i2);
+      const double w20 = -i2 * __builtin_fma(l21, w10, l20 * i0);
+      const double w31 = -i3 * __builtin_fma(l32, w21, l31 * i1);
+      const double w30 = -i3 * __builtin_fma(l32, w20, __builtin_fma(l31, w10, l30 * i0));
+      // row kq of W
+      const double wk0 = kq == 0 ? i0 : (kq == 1 ? w10 : (kq == 2 ? w20 : w30));
+      const double wk1 = kq == 0 ? 0.0 : (kq == 1 ? i1 : (kq == 2 ? w21 : w31));
+      const double wk2 = kq < 2 ? 0.0 : (kq == 2 ? i2 : w32);
+      const double wk3 = kq == 3 ? i3 : 0.0;
+      // ---- panel entries this lane feeds to the matrix core: P[rowA][kq], P[rowB][kq]
+      const double pA = __builtin_fma(cb[96 + rowA], wk3, __builtin_fma(cb[64 + rowA], wk2, __builtin_fma(cb[32 + rowA], wk1, cb[rowA] * wk0)));
+      const double pB = __builtin_fma(cb[96 + rowB], wk3, __builtin_fma(cb[64 + rowB], wk2, __builtin_fma(cb[32 + rowB], wk1, cb[rowB] * wk0)));
+      const double pAu = rowA >= p0 + 4 ? pA : 0.0;     // rows of the block itself (and above) take no part in the update
+      const double pBu = rowB >= p0 + 4 ? pB : 0.0;
+      if (w != 1) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pAu, pBu, acc, 0, 0, 0);   // quadrant (0,1) is above the diagonal
+      if (qb == 0) {                                    // waves 0 and 2 hold P for rows 0..31 once each
+        if (p0 + kq <= rowA) Lw[(kk + rowA) * Dp + kk + p0 + kq] = pA;
+        Pbuf[(s & 1) * 128 + kq * 32 + rowA] = pAu;
+      }
+      if (w == 0 && lr == 0) {
+        double* wb = Wbuf + (s & 1) * 16 + 4 * kq;
+        wb[0] = wk0; wb[1] = wk1; wb[2] = wk2; wb[3] = wk3;
+      }
+      const int c = 16 * qb + lr;
+      if (s + 1 < CB / 4 && w != 1 && c >= p0 + 4 && c < p0 + 8) {
+        double* nb = colbuf + ((s + 1) & 1) * 128 + (c - (p0 + 4)) * 32 + 16 * qa + kq;
 #pragma unroll
-      for (int b = 0; b < 2; ++b) S[a][b] = (ty + 16 * a == tx + 16 * b) ? 1.0 : 0.0;
-    if (ty == 0) { oS[tx] = S[0][0]; oS[tx + 16] = S[0][1]; }
-    for (int c = 0; c <= CB; ++c) {
-      __syncthreads();
-      if (c == 0) continue;
-      const int t = c - 1;
-      const double* col = oC + t * CB;
-      const double* row = oS + t * CB;
-      double d = col[t];
-      const double p0 = col[ty], p1 = col[ty + 16], x0 = row[tx], x1 = row[tx + 16];
-      if (!(d > 0.0)) d = 1.0;
-      const double isq = rsq_refined(d);
-      if (lt == 0) sq[t] = isq;
-      const double xs0 = x0 * isq, xs1 = x1 * isq;                 // X[t][:]
-      const double l0 = (ty > t) ? p0 * isq : 0.0, l1 = (ty + 16 > t) ? p1 * isq : 0.0;
-      S[0][0] -= l0 * xs0;
-      S[0][1] -= l0 * xs1;
-      S[1][0] -= l1 * xs0;
-      S[1][1] -= l1 * xs1;
-      if (t + 1 < CB && ty == ((t + 1) & 15)) {
-        const bool hi = t + 1 >= 16;
-        double* nxt = oS + (t + 1) * CB;
-        nxt[tx] = hi ? S[1][0] : S[0][0];
-        nxt[tx + 16] = hi ? S[1][1] : S[0][1];
+        for (int i = 0; i < 4; ++i) nb[4 * i] = acc[i];
+      }
+    } else {
+      if (s == 0) continue;
+      const int sb = s - 1, p0 = 4 * sb, prv = sb & 1;
+      const double* wb = Wbuf + prv * 16 + 4 * kq;
+      const double* rb = rowbuf + prv * 128;
+      const double pA = Pbuf[prv * 128 + kq * 32 + rowA];
+      const double x = __builtin_fma(wb[3], rb[96 + rowB], __builtin_fma(wb[2], rb[64 + rowB], __builtin_fma(wb[1], rb[32 + rowB], wb[0] * rb[rowB])));
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pA, x, acc, 0, 0, 0);
+      if (qa == 0) {                                    // waves 4 and 5 hold X[p0 + kq][0..31] once each
+        Iw[(long)k * CB * CB + (p0 + kq) * CB + rowB] = x;
+        if (ldsInv) ldsInv[(p0 + kq) * CLD + rowB] = x;
+      }
+      if (sb + 1 < CB / 4 && qa == ((p0 + 4) >> 4)) {   // rows p0+4 .. p0+7 of S are final: publish them raw
+        const int isel = ((p0 + 4) & 15) >> 2;
+        const double v = isel == 0 ? acc[0] : (isel == 1 ? acc[1] : (isel == 2 ? acc[2] : acc[3]));
+        rowbuf[(s & 1) * 128 + kq * 32 + rowB] = v;
       }
     }
-  }
-  __syncthreads();
-  for (int e = tid; e < CB * CB; e += 512) {
-    const int r = e / CB, c = e % CB;
-    if (c <= r) Lw[(kk + r) * Dp + kk + c] = oC[c * CB + r] * sq[c];
-    const double iv = (c <= r) ? oS[e] * sq[r] : 0.0;
-    Iw[(long)k * CB * CB + e] = iv;
-    if (ldsInv) ldsInv[r * CLD + c] = iv;                 // kept on chip for the second column of a column pair
   }
 }
 
-typedef double d4_t __attribute__((ext_vector_type(4)));
+
 
 // 32x32x32 product X Y^T of two LDS tiles (leading dimension CLD) on the f64 matrix cores: 4 waves, wave w owns the
 // 16x16 quadrant (w >> 1, w & 1) and issues 8 v_mfma_f64_16x16x4_f64 on 16 LDS reads (the VALU version -- 128 reads and
@@ -177,19 +218,19 @@ __device__ __forceinline__ void tile_store_mfma(double* dst, int w, int l, const
 constexpr int TSZ = CB * CLD;      // one LDS tile
 constexpr int NT2 = 7;             // tiles of LDS used by the column-pair kernels (59 KB)
 
-// Factor the 2x2 block of tiles [T00 . ; T10 T11] (all already updated by every earlier column): T00 and T11 arrive in
-// the registers of threads 0..255 (thread (ty, tx) owns (ty+16a, tx+16b)), T10 in LDS tile 0.  Publishes L_d0d0, L_d1d0,
-// L_d1d1 and the two inverted diagonal blocks.  Tiles 1..6 of `sm` are scratch.
-__device__ __forceinline__ void factor_pair_tail(double (&v)[2][2], double (&v2)[2][2], double* sm, bool has1, int d0,
-                                                 double* __restrict__ Lw, double* __restrict__ Iw, int Dp, int D,
-                                                 int* __restrict__ info) {
-  const int tid = threadIdx.x, half = tid >> 8, lt = tid & 255, tx = lt & 15, ty = lt >> 4;
+// Factor the 2x2 block of tiles [T00 . ; T10 T11] (all already updated by every earlier column), given in LDS: T10 in tile
+// 0, T00 in tile 1, T11 in tile 2 (lower parts valid).  Publishes L_d0d0, L_d1d0, L_d1d1 and the two inverted diagonal
+// blocks.  Tiles 3 and 5 are scratch; tile 1 receives L_d0d0^-1.
+__device__ __forceinline__ void factor_pair_tail(double* sm, bool has1, int d0, double* __restrict__ Lw,
+                                                 double* __restrict__ Iw, int Dp, int D, int* __restrict__ info) {
+  const int tid = threadIdx.x, half = tid >> 8;
   const int w = (tid >> 6) & 3, l = tid & 63;
   double* T10 = sm;
   double* Vn = sm + 1 * TSZ;
-  double* Ln = sm + 2 * TSZ;
-  double* Up = sm + 6 * TSZ;
-  factor_invert_tile(v, sm + 3 * TSZ, sm + 4 * TSZ, sm + 5 * TSZ, Lw, Iw, Dp, d0, D, info, Vn);
+  double* T11 = sm + 2 * TSZ;
+  double* Ln = sm + 3 * TSZ;
+  double* scratch = sm + 5 * TSZ;
+  factor_invert_tile(Vn, scratch, Lw, Iw, Dp, d0, D, info, Vn);
   if (!has1) return;
   __syncthreads();
   if (half == 0) {                                       // L_d1d0 = T10 L_d0d0^-T
@@ -201,22 +242,14 @@ __device__ __forceinline__ void factor_pair_tail(double (&v)[2][2], double (&v2)
       Lw[((long)(d0 + 1) * CB + mrow(w, l, i)) * Dp + (long)d0 * CB + mcol(w, l)] = r[i];
   }
   __syncthreads();
-  if (half == 0) {                                       // T11 -= L_d1d0 L_d1d0^T
+  if (half == 0) {                                       // T11 -= L_d1d0 L_d1d0^T, in place (each lane its own elements)
     d4_t acc = {0.0, 0.0, 0.0, 0.0};
     tile_nt_mfma(Ln, Ln, w, l, acc);
-    tile_store_mfma(Up, w, l, acc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) T11[mrow(w, l, i) * CLD + mcol(w, l)] -= acc[i];
   }
   __syncthreads();
-  if (half == 0) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int r = ty + 16 * a, c = tx + 16 * b;
-        v2[a][b] = (c <= r) ? v2[a][b] - Up[r * CLD + c] : 0.0;
-      }
-  }
-  factor_invert_tile(v2, sm + 3 * TSZ, sm + 4 * TSZ, sm + 5 * TSZ, Lw, Iw, Dp, d0 + 1, D, info);
+  factor_invert_tile(T11, scratch, Lw, Iw, Dp, d0 + 1, D, info);
 }
 
 // Column-pair start: factors block columns 0 and 1 (their 2x2 block of diagonal tiles).
@@ -224,26 +257,18 @@ __global__ __launch_bounds__(512) void chol_first2_kernel(const double* __restri
                                                           double* __restrict__ Iw, int Dp, int D, int nb,
                                                           int* __restrict__ info) {
   __shared__ double sm[NT2 * TSZ];
-  const int tid = threadIdx.x, lt = tid & 255, tx = lt & 15, ty = lt >> 4;
+  const int tid = threadIdx.x;
   const bool has1 = nb > 1;
-  double v[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, v2[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-  if (tid < 256) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int r = ty + 16 * a, c = tx + 16 * b;
-        v[a][b] = (c <= r) ? W[(long)r * Dp + c] : 0.0;
-        if (has1) v2[a][b] = (c <= r) ? W[(long)(CB + r) * Dp + CB + c] : 0.0;
-      }
-  }
-  if (has1)
-    for (int e = tid; e < CB * CB; e += 512) {
-      const int r = e / CB, c = e % CB;
-      sm[r * CLD + c] = W[(long)(CB + r) * Dp + c];
+  for (int e = tid; e < CB * CB; e += 512) {
+    const int r = e / CB, c = e % CB, o = r * CLD + c;
+    sm[1 * TSZ + o] = W[(long)r * Dp + c];
+    if (has1) {
+      sm[o] = W[(long)(CB + r) * Dp + c];
+      sm[2 * TSZ + o] = W[(long)(CB + r) * Dp + CB + c];
     }
+  }
   __syncthreads();
-  factor_pair_tail(v, v2, sm, has1, 0, Lw, Iw, Dp, D, info);
+  factor_pair_tail(sm, has1, 0, Lw, Iw, Dp, D, info);
 }
 
 // Look-ahead blocked Cholesky, two block columns per launch.  The serial chain of a panel step -- launch gap, tile
@@ -401,19 +426,7 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
     }
   }
   __syncthreads();
-  double v[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, v2[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
-  if (half == 0) {
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int r = ty + 16 * a, c = tx + 16 * b;
-        v[a][b] = (c <= r) ? sm[1 * TSZ + r * CLD + c] : 0.0;
-        if (has1) v2[a][b] = (c <= r) ? sm[2 * TSZ + r * CLD + c] : 0.0;
-      }
-  }
-  __syncthreads();
-  factor_pair_tail(v, v2, sm, has1, d0, Lw, Iw, Dp, D, info);
+  factor_pair_tail(sm, has1, d0, Lw, Iw, Dp, D, info);
 }
 
 // L^T delta = y with y = row D of L (columns 0..D-1).  One workgroup of 1024 threads.
