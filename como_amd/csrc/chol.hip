@@ -429,42 +429,90 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
   factor_pair_tail(sm, has1, d0, Lw, Iw, Dp, D, info);
 }
 
-// L^T delta = y with y = row D of L (columns 0..D-1).  One workgroup of 1024 threads.
-// Bound by what ONE compute unit can pull through the fabric (~10 B/clk: 2.3 MB of L at D = 760 -> ~65 us; a version
-// that prefetched every panel a step ahead into registers measured the same 69 us).  Spreading the panel products over
-// many workgroups needs a device-wide hand-off per panel (~4 us each, 24 of them): no better.
+// L^T delta = y with y = row D of L (columns 0..D-1).
+// One workgroup walking the whole factor is bound by what ONE compute unit can pull through the fabric (~10-14 B/clk: 2.3 MB
+// of L at D = 760 -> 68 us; a version that prefetched every panel a step ahead into registers measured the same), and
+// spreading the panel products of every step over many workgroups needs a device-wide hand-off per panel (~4 us each, 24
+// of them): no better.  So the solve is split ONCE, with launch boundaries as the only synchronisation:
+//   chol_backsub(blocks h..nb-1)  one workgroup, the lower-right triangle (1/4 of the bytes)
+//   chol_backsub_rect             many workgroups: y_j -= L[h*32.., j]^T x for the columns left of the split (1/2 of the bytes)
+//   chol_backsub(blocks 0..h-1)   one workgroup, the upper-left triangle (1/4 of the bytes)
 // Per 32-block (right to left): x_k = L_kk^-T y_k is a 32x32 mat-vec with the pre-inverted diagonal block, then
-// y_j -= L[k rows, j]^T x_k for the columns to the left (coalesced along j).
-__global__ __launch_bounds__(1024) void chol_backsub_kernel(const double* __restrict__ Lw, const double* __restrict__ Iw,
-                                                            int Dp, int D, int nb, double* __restrict__ delta) {
+// y_j -= L[k rows, j]^T x_k for the columns to the left within the range (coalesced along j).
+// ysrc: right-hand side of the range (NULL = row D of L); yinit: when not NULL, receives row D of L for the columns left
+// of the range (the rect kernel subtracts from it).
+constexpr int BS_THREADS = 512;
+__global__ __launch_bounds__(BS_THREADS) void chol_backsub_kernel(const double* __restrict__ Lw, const double* __restrict__ Iw,
+                                                                  int Dp, int D, int k_lo, int k_hi,
+                                                                  const double* __restrict__ ysrc, double* __restrict__ yinit,
+                                                                  double* __restrict__ delta) {
   __shared__ double y[4096];
   __shared__ double xb[CB];
   const int tid = threadIdx.x;
-  for (int j = tid; j < Dp; j += 1024) y[j] = (j < D) ? Lw[(long)D * Dp + j] : 0.0;
+  const int j_lo = k_lo * CB, j_hi = k_hi * CB;
+  for (int j = j_lo + tid; j < j_hi; j += BS_THREADS) y[j] = (j < D) ? (ysrc ? ysrc[j] : Lw[(long)D * Dp + j]) : 0.0;
+  if (yinit)
+    for (int j = tid; j < j_lo; j += BS_THREADS) yinit[j] = Lw[(long)D * Dp + j];
+  // a step is two dependent global-load latencies (inverse block, then the panel rows) unless they are taken off the chain:
+  // the inverse block of the NEXT step is staged in LDS during the current one, the first panel slab is fetched before x
+  // is known
+  __shared__ double sInv[2][CB * CB];
+  for (int e = tid; e < CB * CB; e += BS_THREADS) sInv[(k_hi - 1) & 1][e] = Iw[(long)(k_hi - 1) * CB * CB + e];
   __syncthreads();
-  for (int k = nb - 1; k >= 0; --k) {
+  for (int k = k_hi - 1; k >= k_lo; --k) {
     const long kk = (long)k * CB;
+    const int j0 = j_lo + tid;
+    double v0[CB];
+    if (j0 < kk) {
+#pragma unroll
+      for (int r = 0; r < CB; ++r) v0[r] = Lw[(kk + r) * Dp + j0];
+    }
+    double nx[CB * CB / BS_THREADS];
+    if (k > k_lo) {
+#pragma unroll
+      for (int u = 0; u < CB * CB / BS_THREADS; ++u) nx[u] = Iw[(long)(k - 1) * CB * CB + tid + u * BS_THREADS];
+    }
     if (tid < CB) {                                       // x_c = sum_r inv[r][c] y_r
+      const double* inv = sInv[k & 1];
       double s = 0.0;
-      const double* inv = Iw + (long)k * CB * CB;
 #pragma unroll 8
       for (int r = 0; r < CB; ++r) s += inv[r * CB + tid] * y[kk + r];
       if (kk + tid >= D) s = 0.0;                         // appended row / pad rows carry no unknowns
       xb[tid] = s;
       if (kk + tid < D) delta[kk + tid] = s;
     }
-    __syncthreads();
-    for (int j = tid; j < kk; j += 1024) {
-      double v[CB];
+    if (k > k_lo) {
 #pragma unroll
-      for (int r = 0; r < CB; ++r) v[r] = Lw[(kk + r) * Dp + j];
+      for (int u = 0; u < CB * CB / BS_THREADS; ++u) sInv[(k - 1) & 1][tid + u * BS_THREADS] = nx[u];
+    }
+    __syncthreads();
+    if (j0 < kk) {
       double s = 0.0;
 #pragma unroll
-      for (int r = 0; r < CB; ++r) s += v[r] * xb[r];
+      for (int r = 0; r < CB; ++r) s += v0[r] * xb[r];
+      y[j0] -= s;
+    }
+    for (int j = j0 + BS_THREADS; j < kk; j += BS_THREADS) {
+      double s = 0.0;
+#pragma unroll 8
+      for (int r = 0; r < CB; ++r) s += Lw[(kk + r) * Dp + j] * xb[r];
       y[j] -= s;
     }
     __syncthreads();
   }
+}
+
+// ybuf[j] -= sum_{r in [r_lo, D)} L[r][j] x[r] for j < ncols: blockIdx.x = 128-column chunk, blockIdx.y = row slab.
+__global__ __launch_bounds__(128) void chol_backsub_rect_kernel(const double* __restrict__ Lw, int Dp, int D, int r_lo, int ncols,
+                                                                const double* __restrict__ x, double* __restrict__ ybuf) {
+  const int j = blockIdx.x * 128 + threadIdx.x;
+  const int rows = D - r_lo, per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = r_lo + blockIdx.y * per, r1 = min(r0 + per, D);
+  if (j >= ncols || r0 >= r1) return;
+  double s = 0.0;
+#pragma unroll 4
+  for (int r = r0; r < r1; ++r) s += Lw[(long)r * Dp + j] * x[r];
+  atomicAdd(&ybuf[j], -s);
 }
 
 }  // namespace como
@@ -499,8 +547,22 @@ int como_chol_solve_f64(const double* H, const double* g, double* delta, void* w
     hipLaunchKernelGGL(chol_panel2_kernel, dim3(tiles), dim3(512), 0, s, W, Lw, Iw, Dp, D, c0, nb, info);
     COMO_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(1024), 0, s, Lw, Iw, Dp, D, nb, delta);
-  COMO_CHECK_LAUNCH();
+  const int h = nb / 2;
+  if (nb < 6) {
+    hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, 0, nb, (const double*)nullptr,
+                       (double*)nullptr, delta);
+    COMO_CHECK_LAUNCH();
+  } else {
+    double* ybuf = W;                                     // the working copy is dead once the factor is complete
+    hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, h, nb, (const double*)nullptr, ybuf, delta);
+    COMO_CHECK_LAUNCH();
+    const int ncols = h * CB, r_lo = h * CB;
+    hipLaunchKernelGGL(chol_backsub_rect_kernel, dim3((ncols + 127) / 128, 32), dim3(128), 0, s, Lw, Dp, D, r_lo, ncols, delta, ybuf);
+    COMO_CHECK_LAUNCH();
+    hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, 0, h, (const double*)ybuf, (double*)nullptr,
+                       delta);
+    COMO_CHECK_LAUNCH();
+  }
   return COMO_OK;
 }
 
