@@ -430,8 +430,8 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
 }
 
 // L^T delta = y with y = row D of L (columns 0..D-1).
-// One workgroup walking the whole factor is bound by what ONE compute unit can pull through the fabric (~10-14 B/clk: 2.3 MB
-// of L at D = 760 -> 68 us; a version that prefetched every panel a step ahead into registers measured the same), and
+// One workgroup walking the whole factor is bound by what ONE compute unit can pull through the fabric (~12 B/clk: 2.3 MB
+// of L at D = 760 -> 68 us; prefetching panels / inverse blocks one or two steps ahead changes nothing at that size), and
 // spreading the panel products of every step over many workgroups needs a device-wide hand-off per panel (~4 us each, 24
 // of them): no better.  So the solve is split ONCE, with launch boundaries as the only synchronisation:
 //   chol_backsub(blocks h..nb-1)  one workgroup, the lower-right triangle (1/4 of the bytes)
@@ -458,19 +458,32 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsub_kernel(const double* 
   // is known
   __shared__ double sInv[2][CB * CB];
   for (int e = tid; e < CB * CB; e += BS_THREADS) sInv[(k_hi - 1) & 1][e] = Iw[(long)(k_hi - 1) * CB * CB + e];
-  __syncthreads();
-  for (int k = k_hi - 1; k >= k_lo; --k) {
-    const long kk = (long)k * CB;
-    const int j0 = j_lo + tid;
-    double v0[CB];
+  // workgroup barrier that waits for LDS traffic only: the panel loads issued for the NEXT step stay in flight across it
+  // (__syncthreads() drains the vector-memory counter too)
+  auto lds_barrier = []() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  const int j0 = j_lo + tid;
+  double vc[CB];                                          // panel slab of the current step, fetched one step ahead
+  {
+    const long kk = (long)(k_hi - 1) * CB;
     if (j0 < kk) {
 #pragma unroll
-      for (int r = 0; r < CB; ++r) v0[r] = Lw[(kk + r) * Dp + j0];
+      for (int r = 0; r < CB; ++r) vc[r] = Lw[(kk + r) * Dp + j0];
     }
-    double nx[CB * CB / BS_THREADS];
+  }
+  __syncthreads();
+  // one step; `cur` was fetched during the previous step, `nxt` is fetched now and consumed by the next one (two register
+  // sets used alternately: no copies, the wait for a slab falls a whole step after its issue)
+  constexpr int NU = CB * CB / BS_THREADS;
+  auto step = [&](int k, double (&cur)[CB], double (&nxt)[CB]) {
+    const long kk = (long)k * CB;
+    double nx[NU];
     if (k > k_lo) {
+      if (j0 < kk - CB) {
 #pragma unroll
-      for (int u = 0; u < CB * CB / BS_THREADS; ++u) nx[u] = Iw[(long)(k - 1) * CB * CB + tid + u * BS_THREADS];
+        for (int r = 0; r < CB; ++r) nxt[r] = Lw[(kk - CB + r) * Dp + j0];
+      }
+#pragma unroll
+      for (int u = 0; u < NU; ++u) nx[u] = Iw[(long)(k - 1) * CB * CB + tid + u * BS_THREADS];
     }
     if (tid < CB) {                                       // x_c = sum_r inv[r][c] y_r
       const double* inv = sInv[k & 1];
@@ -481,15 +494,11 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsub_kernel(const double* 
       xb[tid] = s;
       if (kk + tid < D) delta[kk + tid] = s;
     }
-    if (k > k_lo) {
-#pragma unroll
-      for (int u = 0; u < CB * CB / BS_THREADS; ++u) sInv[(k - 1) & 1][tid + u * BS_THREADS] = nx[u];
-    }
-    __syncthreads();
+    lds_barrier();
     if (j0 < kk) {
       double s = 0.0;
 #pragma unroll
-      for (int r = 0; r < CB; ++r) s += v0[r] * xb[r];
+      for (int r = 0; r < CB; ++r) s += cur[r] * xb[r];
       y[j0] -= s;
     }
     for (int j = j0 + BS_THREADS; j < kk; j += BS_THREADS) {
@@ -498,7 +507,16 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsub_kernel(const double* 
       for (int r = 0; r < CB; ++r) s += Lw[(kk + r) * Dp + j] * xb[r];
       y[j] -= s;
     }
-    __syncthreads();
+    if (k > k_lo) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) sInv[(k - 1) & 1][tid + u * BS_THREADS] = nx[u];
+    }
+    lds_barrier();
+  };
+  double vd[CB];
+  for (int k = k_hi - 1; k >= k_lo; k -= 2) {
+    step(k, vc, vd);
+    if (k - 1 >= k_lo) step(k - 1, vd, vc);
   }
 }
 
