@@ -372,6 +372,7 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
       B <= 0 || n <= 0 || m <= 0 || m > 64 || (m & 3) || Wimg <= 0)
     return COMO_ERR_ARG;
   uint32_t* hists = (uint32_t*)hists_v;
+  if (!(flags & 4)) {
   if (!(flags & 1) && !zero_words(hists, (size_t)B * 6 * SEL_BINS, s))
     return COMO_ERR_LAUNCH;
   int gx = (n + 255) / 256;
@@ -386,6 +387,8 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
                        dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord);
   }
   COMO_CHECK_LAUNCH();
+  }
+  if (flags & 2) return COMO_OK;                          // points only: the median passes run elsewhere (flags & 4)
   for (int p = 1; p < SelCfg<KeyT>::NPASS; ++p) {
     int rc = select_hist<T>(zbuf, nullptr, n, B, hists, p, s);
     if (rc) return rc;
@@ -406,7 +409,7 @@ int como_dense_ref_f32(const float* Kt, long kt_slot_stride, const int* pixidx, 
                        const int* pixcoord, int flags, como_stream_t stream) {
   int rc = como::dense_ref<float>(Kt, kt_slot_stride, pixidx, logzm, Twc, K, dlogzm_dTwc, B, n, m, Wimg, Pwn, dPwn_dTwc, uvec,
                                   zbuf, logzn_out, hists, med_out3, pixcoord, flags, (hipStream_t)stream);
-  if (rc) return rc;
+  if (rc || (flags & 2)) return rc;
   return como_select_finish_f32(hists, B, med_out3, stream);
 }
 int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx, const double* logzm, const double* Twc,
@@ -415,7 +418,7 @@ int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx,
                        const int* pixcoord, int flags, como_stream_t stream) {
   int rc = como::dense_ref<double>(Kt, kt_slot_stride, pixidx, logzm, Twc, K, dlogzm_dTwc, B, n, m, Wimg, Pwn, dPwn_dTwc, uvec,
                                    zbuf, logzn_out, hists, med_out3, pixcoord, flags, (hipStream_t)stream);
-  if (rc) return rc;
+  if (rc || (flags & 2)) return rc;
   return como_select_finish_f64(hists, B, med_out3, stream);
 }
 

@@ -192,25 +192,44 @@ class WindowBA:
         a.zero_b, a.zero_b_bytes = ptr(self.w["hist_ba"]), hb
         a.median_out = ptr(self.median_depths)
         self.win_args = a
+        self.w["dr_ws"] = {}                               # dense-reference planes: owned here (captured graphs record them)
+        self.overlap_priors = True
+        self._side_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
 
     # ---- fused HIP chain -----------------------------------------------------------------------------------------
     def linearize_fused(self):
         L, a, w, dev = _lib.lib(), self.win_args, self.w, self.dev
         s = _lib.stream_ptr(dev)
         _lib.check(L.como_win_scaffold(ctypes.byref(a), s), "como_win_scaffold")
-        Pwn, dT, uvec, med, _ = dense_reference_factored(w["px_logzm"], w["px_poses"][:self.B], self.Kt, self.pixidx, self.K_pix,
-                                                         w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"],
-                                                         hists=w["hist_dr"])
         self.sys.zero_()
+        dr = lambda part: dense_reference_factored(w["px_logzm"], w["px_poses"][:self.B], self.Kt, self.pixidx, self.K_pix,
+                                                   w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"],
+                                                   hists=w["hist_dr"], ws=w["dr_ws"], part=part)
+        fork = self.shard is None and self.overlap_priors
+        Pwn, dT, uvec, med, _ = dr("points" if fork else "all")
+        if fork:
+            # Nothing between the reference points and the solve needs the median depths except the priors, and the priors
+            # only ADD into H / g (atomics): the median's select passes and the prior kernel run on a second stream (a
+            # parallel branch of the captured graph) beside the residual / block / assembly kernels -- ~50 us of small
+            # launches off the critical path.
+            main = torch.cuda.current_stream(dev)
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dr("median")
+                _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
         photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=Pwn, vals=self.vals_n,
                                     dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],
                                     img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=self.H, g=self.g,
                                     err_out=self.err, sigma_out=self.sigma, pix_range=self.pix_range,
                                     reduce_hists=(self.shard.all_reduce_sum if self.shard is not None else None),
                                     events=self.events, zeroed_hists=w["hist_ba"])
-        if self.shard is not None:
-            self.shard.all_reduce_sum(self.sys)          # normal equations of all shards: H | g | err in one collective
-        _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")   # also stores the new median depths
+        if fork:
+            torch.cuda.current_stream(dev).wait_stream(side)
+        else:
+            if self.shard is not None:
+                self.shard.all_reduce_sum(self.sys)      # normal equations of all shards: H | g | err in one collective
+            _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")   # also stores the new median depths
         return self.H, self.g
 
     def iterate_fused(self):

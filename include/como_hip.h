@@ -185,7 +185,9 @@ int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, cons
  * med_out3 (B,3) = {exact median depth (sparse_map.py:220), 1.4826*median, n}.  hists: B * select workspace.
  * pixcoord (B,n) optional: linear pixel index row*W+col of every reference pixel when it differs from its K~ row
  * (two-frame SfM passes K~ rows of the selected pixels only, two_frame_sfm.py:246-252); NULL = the K~ row index.
- * flags bit 0: hists is already zero (skip the clear). */
+ * flags bit 0: hists is already zero (skip the clear); bit 1: points only -- the kernel and its pass-0 depth histogram,
+ * no median; bit 2: median only -- the remaining select passes + finish on the zbuf / hists a bit-1 call left (the two halves
+ * may run on different streams: nothing between the reference points and the priors needs the median). */
 int como_dense_ref_f32(const float* Kt, long kt_slot_stride, const int* pixidx, const float* logzm, const float* Twc,
                        const float* K, const float* dlogzm_dTwc, int B, int n, int m, int Wimg, float* Pwn,
                        float* dPwn_dTwc, float* uvec, float* zbuf, float* logzn_out, void* hists, float* med_out3,
