@@ -100,6 +100,40 @@ def cpu_baseline(args, state_cpu):
                       f"solve {sol * 1e3:.0f} ms; linearisation time scaled x{scale:g} to this workload's pixel count"}
 
 
+def odometry_loop(device, frames=100):
+    """Informational: the whole headless sequential odometry loop (tracking + keyframe management + one mapping iteration
+    per frame, como_amd/odom/sequential.py) on a rendered 640x480 sequence with the parameters of the reference's
+    config/como.yml; frames/s after the two-frame initialisation.  Never fails the bench line."""
+    try:
+        import argparse
+        from como_amd import synth
+        from como_amd.depth_cov.core.DepthCovModule import DepthCovModule
+        from como_amd.odom.sequential import ComoSeq
+        from scripts.gpu_odometry_bench import cfgs
+        H, W = 480, 640
+        scene = synth.PlaneScene(seed=1, freq_scale=1.0, device=device)
+        K = synth.intrinsics_for(H, W, device=device)
+        T = synth.gt_poses(frames, step=0.01, deg=0.3, device=device)
+        rgbs = [scene.render(T[k], K, H, W)[0][None, None].repeat(1, 3, 1, 1) for k in range(frames)]
+        model = DepthCovModule({k: v.to(device) for k, v in synth.depthcov_state_dict(0).items()})
+        odo = ComoSeq(cfgs(str(device), argparse.Namespace(pix="float")), K.cpu().clone(), (H, W), model)
+        t0, k0, kinds = None, None, []
+        for k in range(frames):
+            kinds.append(odo.iter(1.0 + 0.033 * k, rgbs[k]))
+            if t0 is None and odo.mapping.is_init:
+                torch.cuda.synchronize()
+                t0, k0 = time.perf_counter(), k
+        torch.cuda.synchronize()
+        n = frames - 1 - k0
+        el = time.perf_counter() - t0
+        return {"workload": "sequential odometry loop, rendered 640x480 sequence, config/como.yml parameters (9 keyframes, 24 one-way "
+                            "frames, m=64, window 4, float32 tracking, float64 mapping system / float32 pixel kernels)",
+                "value": n / el, "unit": "frames/s", "ms_per_frame": 1e3 * el / n, "frames": n,
+                "keyframes_inserted": kinds.count("keyframe"), "one_way_inserted": kinds.count("one-way")}
+    except Exception as e:                                  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +228,10 @@ def main():
         secondary = {"workload": f"same window, nonmax_suppression_window=4 (n={wb4.n} reference px/KF, the reference's default)",
                      "value": args.steps / e4, "unit": "GN iters/s", "ms_per_step": e4 / args.steps * 1e3, "hip_graph": bool(g4)}
 
+    odometry = None
+    if args.window == 1 and not args.no_secondary and args.gpus == 1:
+        odometry = odometry_loop(device)
+
     if shard.rank == 0:
         out = {
             "metric": "GN iters/sec, 8-keyframe 640x480 photometric BA",
@@ -212,6 +250,8 @@ def main():
         }
         if secondary is not None:
             out["secondary"] = secondary
+        if odometry is not None:
+            out["odometry_loop"] = odometry
         if not args.no_cpu and args.gpus == 1:
             st_cpu = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in state.items()}
             st_cpu["Knm_Kmminv"] = st_cpu["Knm_Kmminv"]
