@@ -2,15 +2,16 @@
 //
 // Reference: como/odom/backend/linear_system.py:101-112 (`solve_system`: cholesky_ex(check_errors=False) +
 // cholesky_solve).  hipSOLVER needs ~2.5 ms for D = 760 (dozens of tiny launches, not graph-capturable); here the
-// factorisation is a right-looking blocked Cholesky with ONE launch per 32-column panel, no host synchronisation:
+// factorisation is a right-looking blocked Cholesky with ONE launch per PAIR of 32-column panels, no host synchronisation:
 //
 //   chol_pack      : W (Dp x Dp workspace) <- lower(H), with g appended as row D (so the forward substitution
-//                    L y = g falls out of the factorisation: row D of L is y^T) and an identity pad up to Dp = 64 * nb.
-//   chol_first / chol_panel(k): look-ahead panels (see the kernels): one launch per 32-column panel, the panel solve is
-//                    a GEMM against the pre-inverted diagonal block, the next diagonal block is factored and inverted
-//                    by the workgroup that just updated it.  A non-positive pivot is reported in `info` (1-based, first failure)
-//                    instead of being swallowed; the factorisation then continues with pivot 1 as a defined value.
-//   chol_backsub   : one workgroup, L^T delta = y, right-to-left over the 64-blocks.
+//                    L y = g falls out of the factorisation: row D of L is y^T) and an identity pad up to Dp = 32 * nb.
+//   chol_first2 / chol_panel2(c0): look-ahead column pairs (see the kernels): the panel solve is a product against the
+//                    pre-inverted diagonal blocks on the f64 matrix cores, the next pair of diagonal blocks is factored and
+//                    inverted by the workgroup that just updated it (factor_invert_tile: four pivots per barrier, rank-4
+//                    MFMA updates).  A non-positive pivot is reported in `info` (1-based, first failure) instead of being
+//                    swallowed; the factorisation then continues with pivot 1 as a defined value.
+//   chol_backsub x2 + chol_backsub_rect: L^T delta = y, split once into triangle / rectangle / triangle launches.
 #include "common.cuh"
 #include "../../include/como_hip.h"
 #include <type_traits>
@@ -19,7 +20,6 @@
 namespace como {
 
 constexpr int CB = 32;        // panel / tile width (in-tile factor/solve latency grows as CB^2 per panel: 32 beats 64)
-constexpr int TPR = 256 / CB; // threads per row in the tile triangular solve
 constexpr int CLD = CB + 1;   // padded LDS leading dimension
 
 __global__ __launch_bounds__(256) void chol_pack_kernel(const double* __restrict__ H, const double* __restrict__ g,
@@ -34,32 +34,6 @@ __global__ __launch_bounds__(256) void chol_pack_kernel(const double* __restrict
   else if (i == D && j == D) v = 1e300;          // pivot of the appended row: irrelevant, just positive
   else if (i == j) v = 1.0;                      // identity pad
   W[idx] = v;
-}
-
-// ---- register-resident 32x32 tile kernels: lane r of wave 0 owns row r, every loop is unrolled at compile time.
-// reciprocal: hardware estimate + two Newton steps (double accuracy)
-__device__ __forceinline__ double fast_rcp(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  r = r * (2.0 - d * r);
-  r = r * (2.0 - d * r);
-  return r;
-}
-
-template <typename F, int... I>
-__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, typename F>
-__device__ __forceinline__ void sfor(F&& f) { sfor_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{}); }
-
-__device__ __forceinline__ double rcp_refined(double d) {      // hardware estimate (24 bits) + one cubic correction
-  const double r = __builtin_amdgcn_rcp(d);
-  const double e = __builtin_fma(-d, r, 1.0);
-  return __builtin_fma(r, __builtin_fma(e, e, e), r);
-}
-__device__ __forceinline__ double rsq_refined(double d) {      // hardware estimate + two Newton steps
-  double r = __builtin_amdgcn_rsq(d);
-  r = r * (1.5 - 0.5 * d * r * r);
-  r = r * (1.5 - 0.5 * d * r * r);
-  return r;
 }
 
 typedef double d4_t __attribute__((ext_vector_type(4)));

@@ -8,7 +8,7 @@
     solve                                 lin_sys.solve_system  linear_system.py:101-112   HIP chol_*   (csrc/chol.hip)
     update                                lin_sys.update_vars   linear_system.py:115-152   HIP win_update
 
-`fused=True` (default) runs the ~45-launch HIP chain above; `fused=False` runs the same iteration through the
+`fused=True` (default) runs the 31-launch HIP chain above (two stream branches, see linearize_fused); `fused=False` runs the same iteration through the
 reference-signature mirrors (torch ops for the O(B m) parts) -- both are checked against the golden vectors.
 State tensors live on one GPU and are updated in place (fixed addresses: the iteration is hipGraph-capturable).
 `pix_dtype` is the element type of the per-pixel path (float32 = mixed precision, float64 = config/como.yml:28);
