@@ -84,6 +84,8 @@ __device__ __forceinline__ void factor_invert_tile(const double* At, double* scr
     for (int i = 0; i < 4; ++i) acc[i] = (16 * qa + kq + 4 * i == 16 * qb + lr) ? 1.0 : 0.0;
     if (tid < 256 + 128) { const int t = (tid - 256) >> 5, j = (tid - 256) & 31; rowbuf[t * 32 + j] = (t == j) ? 1.0 : 0.0; }
   }
+  // ROLLED on purpose: unrolled, the nine steps are ~2000 instructions executed once each -- instruction-fetch bound
+#pragma unroll 1
   for (int s = 0; s <= CB / 4; ++s) {
     __syncthreads();
     if (role == 0) {
