@@ -26,6 +26,8 @@ def cross_covariance(x1, E1, x2, E2, scale):
         raise RuntimeError("cross_covariance: float32 / float64 tensors of one dtype expected")
     B, N, M = x1.shape[0], x1.shape[1], x2.shape[1]
     K12 = torch.empty((B, N, M), dtype=dt, device=x1.device)
+    if K12.numel() == 0:                                   # no points on one side: an empty matrix, as the torch-side callers expect
+        return K12
     strides = (ctypes.c_long * 14)(*x1.stride(), *E1.stride(), *x2.stride(), *E2.stride())
     fn = getattr(_lib.lib(), "como_cross_covariance_" + _lib.suffix(dt))
     rc = fn(x1.data_ptr(), E1.data_ptr(), x2.data_ptr(), E2.data_ptr(), float(scale), K12.data_ptr(), B, N, M, strides,

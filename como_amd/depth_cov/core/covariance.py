@@ -17,6 +17,8 @@ def kernel_matrix(x1, E1, x2, E2, scale):
     dt = E1.dtype
     B, N, M = x1.shape[0], x1.shape[1], x2.shape[1]
     out = torch.empty((B, N, M), dtype=dt, device=x1.device)
+    if out.numel() == 0:                                   # e.g. no sparse point of the previous keyframe reprojects into the new one
+        return out
     fn = getattr(_lib.lib(), "como_kernel_matrix_" + _lib.suffix(dt))
     rc = fn(x1.to(dt).contiguous().data_ptr(), E1.contiguous().data_ptr(), x2.to(dt).contiguous().data_ptr(),
             E2.contiguous().data_ptr(), float(scale), out.data_ptr(), B, N, M, _lib.stream_ptr(x1.device))
