@@ -211,3 +211,16 @@ def test_trajectory_io_roundtrip(tmp_path):
     rows = np.loadtxt(str(p))
     assert rows.shape == (5, 8) and np.allclose(rows[:, 0], [0.0, 0.5, 1.0, 1.5, 2.0])
     assert np.allclose(tq_to_pose(rows[:, 1:]), T.numpy(), atol=2e-4)              # 4 decimals
+
+
+def test_slabwise_gram_equals_direct():
+    """distill_depth._gram (256-slab batched GEMM for tall least-squares systems) == A^T A, A^T b."""
+    from como_amd.depth_cov.core.distill_depth import _gram, lstsq_chol
+    g = torch.Generator().manual_seed(5)
+    for n in (100, 4096, 10007):
+        A = torch.randn((1, n, 7), generator=g, dtype=torch.float64)
+        b = torch.randn((1, n, 1), generator=g, dtype=torch.float64)
+        AtA, Atb = _gram(A, b)
+        assert rel(AtA, A.mT @ A) < 1e-13 and rel(Atb, A.mT @ b) < 1e-12
+        x = lstsq_chol(A, b)
+        assert rel(x, torch.linalg.lstsq(A, b).solution) < 1e-9
