@@ -206,6 +206,91 @@ __global__ __launch_bounds__(1024) void greedy_pick_kernel(const float* __restri
   }
 }
 
+// Two-stage form of greedy_pick for large domains (one workgroup walking 300k candidates took 250 us per added point):
+// greedy_scan updates the distance mask and finds the best candidate of its slice, greedy_pick2 reduces the slices and gathers
+// the chosen point.  Same ordering rule at every level (largest cost, then smallest index), so the result is the one of the
+// single-workgroup kernel.
+__global__ __launch_bounds__(256) void greedy_scan_kernel(const float* __restrict__ var, const float* __restrict__ dom,
+                                                          const float* __restrict__ coords_n, int n, int k0, int k,
+                                                          uint8_t* __restrict__ mask, float thresh_sq, int d,
+                                                          float4* __restrict__ part) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.y, g = blockIdx.x, G = gridDim.x, tid = threadIdx.x;
+  const float* vb = var + (long)b * d;
+  const float* db = dom + (long)b * d * 2;
+  uint8_t* mb = mask + (long)b * d;
+  const float* chosen = coords_n + ((long)b * n + k0) * 2;
+  const int per = (d + G - 1) / G, j0 = g * per, j1 = min(d, j0 + per);
+  float best = -1.f, best_sd = 0.f;
+  int bi = 0x7fffffff;
+  for (int j = j0 + tid; j < j1; j += 256) {
+    uint8_t ok = mb[j];
+    const float y = db[2 * j], x = db[2 * j + 1];
+    for (int c = 0; c < k; ++c) {
+      const float dy = chosen[2 * c] - y, dx = chosen[2 * c + 1] - x;
+      const float d2 = dy * dy + dx * dx;
+      ok = ok && (d2 > thresh_sq);
+    }
+    mb[j] = ok;
+    float sd = sqrtf(vb[j]);
+    if (sd != sd) sd = 0.f;
+    sd += 1e-10f;
+    const float cost = ok ? sd : 0.f;
+    if (cost > best) { best = cost; bi = j; best_sd = sd; }
+  }
+  __shared__ float sc[256], ss[256];
+  __shared__ int si[256];
+  sc[tid] = best; si[tid] = bi; ss[tid] = best_sd;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (tid < h) {
+      const float c2 = sc[tid + h];
+      const int i2 = si[tid + h];
+      if (c2 > sc[tid] || (c2 == sc[tid] && i2 < si[tid])) { sc[tid] = c2; si[tid] = i2; ss[tid] = ss[tid + h]; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) part[(long)b * G + g] = make_float4(sc[0], __int_as_float(si[0]), ss[0], 0.f);
+}
+
+__global__ __launch_bounds__(256) void greedy_pick2_kernel(const float4* __restrict__ part, int G, const float* __restrict__ dom,
+                                                           const float* __restrict__ Edom, float* __restrict__ coords_n,
+                                                           float* __restrict__ E_n, long* __restrict__ inds, int n, int slot,
+                                                           long* __restrict__ best_idx, float* __restrict__ max_stdev, int d) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* db = dom + (long)b * d * 2;
+  float best = -1.f, best_sd = 0.f;
+  int bi = 0x7fffffff;
+  for (int g = tid; g < G; g += 256) {
+    const float4 p = part[(long)b * G + g];
+    const int i2 = __float_as_int(p.y);
+    if (p.x > best || (p.x == best && i2 < bi)) { best = p.x; bi = i2; best_sd = p.z; }
+  }
+  __shared__ float sc[256], ss[256];
+  __shared__ int si[256];
+  sc[tid] = best; si[tid] = bi; ss[tid] = best_sd;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (tid < h) {
+      const float c2 = sc[tid + h];
+      const int i2 = si[tid + h];
+      if (c2 > sc[tid] || (c2 == sc[tid] && i2 < si[tid])) { sc[tid] = c2; si[tid] = i2; ss[tid] = ss[tid + h]; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int w = si[0];
+    best_idx[b] = w;
+    max_stdev[b] = ss[0];
+    if (slot < n) {
+      inds[(long)b * n + slot] = w;
+      coords_n[((long)b * n + slot) * 2] = db[2 * w];
+      coords_n[((long)b * n + slot) * 2 + 1] = db[2 * w + 1];
+      for (int e = 0; e < 4; ++e) E_n[((long)b * n + slot) * 4 + e] = Edom[((long)b * d + w) * 4 + e];
+    }
+  }
+}
+
 // greedy_append: k_ni, the new Cholesky row (every workgroup redoes the tiny forward substitution from an LDS copy of L;
 // workgroup 0 stores it), then k_id, the obs_info row and the variance downdate of this workgroup's 256 domain pixels.
 // Arithmetic = cross_cov_kernel<float> + chol_row_kernel + obs_info_kernel.
@@ -301,22 +386,34 @@ int como_greedy_next_f32(const float* var, const float* coords_domain, const flo
 
 int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,
                          float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
-                         float k_ii, float dist_thresh_sq, int B, int n, int d, int m, float* sd_trace, como_stream_t stream) {
+                         float k_ii, float dist_thresh_sq, int B, int n, int d, int m, float* sd_trace, void* scratch,
+                         como_stream_t stream) {
   using namespace como;
   if (!coords_n || !E_n || !coord_vec_inds || !coords_domain || !E_domain || !L || !obs_info || !var || !mask || !best_idx ||
       !max_stdev || B <= 0 || n <= 0 || n > 64 || d <= 0 || m < 1 || m > n)
     return COMO_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(1024), 0, s, var, coords_domain, E_domain, coords_n, E_n, coord_vec_inds,
-                     n, 0, m, mask, dist_thresh_sq, m, best_idx, sd_trace ? sd_trace + (long)m * B : max_stdev, d);
+  int G = (d + 1023) / 1024;
+  if (G > 1024) G = 1024;
+  const bool two_stage = scratch != nullptr && G > 1;
+  auto pick = [&](int k0, int k, int slot, float* sd_out) {
+    if (two_stage) {
+      hipLaunchKernelGGL(greedy_scan_kernel, dim3(G, B), dim3(256), 0, s, var, coords_domain, coords_n, n, k0, k, mask,
+                         dist_thresh_sq, d, (float4*)scratch);
+      hipLaunchKernelGGL(greedy_pick2_kernel, dim3(B), dim3(256), 0, s, (const float4*)scratch, G, coords_domain, E_domain,
+                         coords_n, E_n, coord_vec_inds, n, slot, best_idx, sd_out, d);
+    } else {
+      hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(1024), 0, s, var, coords_domain, E_domain, coords_n, E_n,
+                         coord_vec_inds, n, k0, k, mask, dist_thresh_sq, slot, best_idx, sd_out, d);
+    }
+  };
+  pick(0, m, m, sd_trace ? sd_trace + (long)m * B : max_stdev);
   COMO_CHECK_LAUNCH();
   for (int i = m; i < n; ++i) {
     hipLaunchKernelGGL(greedy_append_kernel, dim3((d + 255) / 256, B), dim3(256), 0, s, coords_n, E_n, coords_domain, E_domain, L,
                        obs_info, var, scale, k_ii, n, d, i);
     COMO_CHECK_LAUNCH();
-    hipLaunchKernelGGL(greedy_pick_kernel, dim3(B), dim3(1024), 0, s, var, coords_domain, E_domain, coords_n, E_n,
-                       coord_vec_inds, n, i, 1, mask, dist_thresh_sq, i + 1, best_idx,
-                       sd_trace ? sd_trace + (long)(i + 1) * B : max_stdev, d);
+    pick(i, 1, i + 1, sd_trace ? sd_trace + (long)(i + 1) * B : max_stdev);
     COMO_CHECK_LAUNCH();
   }
   return COMO_OK;

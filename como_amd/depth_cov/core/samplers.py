@@ -117,10 +117,12 @@ def greedy_loop(coord_vec_inds, coords_n_norm, E_n, coords_domain_norm, E_domain
         # afterwards from the per-step trace of the largest remaining standard deviation -- the greedy sequence does not
         # depend on where it is cut -- with ONE read-back instead of one per step.
         trace = torch.zeros((n + 1, b), device=dev, dtype=torch.float32) if terminate_early else None
+        scratch = torch.empty((b * 4096,), device=dev, dtype=torch.float32)      # per-slice argmax partials (two-stage pick)
         rc = _lib.lib().como_greedy_loop_f32(coords_n_norm.data_ptr(), E_n.data_ptr(), coord_vec_inds.data_ptr(),
                                              nxt.dom.data_ptr(), E_domain.data_ptr(), L.data_ptr(), obs_info.data_ptr(),
                                              pred_var.data_ptr(), nxt.mask.data_ptr(), nxt.best.data_ptr(), nxt.sd.data_ptr(),
-                                             sv, k_ii, nxt.t2, b, n, nxt.d, m, _lib.ptr(trace), _lib.stream_ptr(dev))
+                                             sv, k_ii, nxt.t2, b, n, nxt.d, m, _lib.ptr(trace), scratch.data_ptr(),
+                                             _lib.stream_ptr(dev))
         _lib.check(rc, "como_greedy_loop_f32")
         if terminate_early:
             below = (trace[m:n] < max_stdev_thresh).all(dim=1).tolist()
