@@ -131,4 +131,38 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// ---- SE(3) exponential ------------------------------------------------------------------------
+// T = Exp(xi) for COMO's tangent ordering xi = [omega (0:3), v (3:6)] (rotation first):
+//   R = I + a [w]x + b [w]x^2,  t = (I + b [w]x + c [w]x^2) v,  a = sin(th)/th, b = (1-cos th)/th^2, c = (th-sin th)/th^3.
+// The reference delegates to lietorch's SE3.exp with the vector REORDERED to [tau = v, phi = omega]
+// (lie_algebra.py:45-56) -- lietorch is an unpinned third-party dependency, so this closed form is pinned against
+// scipy.linalg.expm of the 4x4 twist matrix instead (tests/golden/se3_expm.npz, make_golden_r2.py::se3_case).
+// ONE definition: win_update (T <- T Exp(delta)) and track_finish (T <- T Exp(-delta)) both call it.
+__device__ inline void se3_exp_f64(const double* xi, double* Tm) {
+  const double wx = xi[0], wy = xi[1], wz = xi[2];
+  const double th2 = wx * wx + wy * wy + wz * wz;
+  double a, b, c;
+  if (th2 < 1e-12) {
+    a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0;
+  } else {
+    const double th = sqrt(th2);
+    a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = (th - sin(th)) / (th2 * th);
+  }
+  const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+  double W2[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) W2[i * 3 + j] = W[i * 3] * W[j] + W[i * 3 + 1] * W[3 + j] + W[i * 3 + 2] * W[6 + j];
+  for (int i = 0; i < 3; ++i) {
+    double t = 0;
+    for (int j = 0; j < 3; ++j) {
+      const double e = (i == j) ? 1.0 : 0.0;
+      Tm[i * 4 + j] = e + a * W[i * 3 + j] + b * W2[i * 3 + j];
+      t += (e + b * W[i * 3 + j] + c * W2[i * 3 + j]) * xi[3 + j];
+    }
+    Tm[i * 4 + 3] = t;
+  }
+  Tm[12] = Tm[13] = Tm[14] = 0.0;
+  Tm[15] = 1.0;
+}
+
 }  // namespace como

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void dense_ref_kernel(
     const T u0 = Tm[0] * Xc + Tm[1] * Yc + Tm[2] * Zc;           // uvec = R (ray z)
     const T u1 = Tm[4] * Xc + Tm[5] * Yc + Tm[6] * Zc;
     const T u2 = Tm[8] * Xc + Tm[9] * Yc + Tm[10] * Zc;
-    if (inr) {
+    if (inr && Pwn) {                                              // Pwn == nullptr: depth-only pass (full-image median)
       const long base3 = (long)b * 3 * n + i, base18 = (long)b * 18 * n + i;
       Pwn[base3] = Xw; Pwn[base3 + n] = Yw; Pwn[base3 + 2 * (long)n] = Zw;
       uvec[base3] = u0; uvec[base3 + n] = u1; uvec[base3 + 2 * (long)n] = u2;
@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256) void dense_ref_kernel(
         dPwn_dTwc[base18 + (long)(r * 6 + 4) * n] = r1 + uu[r] * acc[5];
         dPwn_dTwc[base18 + (long)(r * 6 + 5) * n] = r2 + uu[r] * acc[6];
       }
+    }
+    if (inr) {
       zbuf[(long)b * n + i] = Zc;
       if (logzn_out) logzn_out[(long)b * n + i] = logz;
     }
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
     const T u0 = Tm[0] * Xc + Tm[1] * Yc + Tm[2] * Zc;
     const T u1 = Tm[4] * Xc + Tm[5] * Yc + Tm[6] * Zc;
     const T u2 = Tm[8] * Xc + Tm[9] * Yc + Tm[10] * Zc;
-    if (inr) {
+    if (inr && Pwn) {
       const long base3 = (long)b * 3 * n + i, base18 = (long)b * 18 * n + i;
       Pwn[base3] = Xw; Pwn[base3 + n] = Yw; Pwn[base3 + 2 * (long)n] = Zw;
       uvec[base3] = u0; uvec[base3 + n] = u1; uvec[base3 + 2 * (long)n] = u2;
@@ -231,6 +233,8 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
         dPwn_dTwc[base18 + (long)(r * 6 + 4) * n] = r1 + uu[r] * a7[5];
         dPwn_dTwc[base18 + (long)(r * 6 + 5) * n] = r2 + uu[r] * a7[6];
       }
+    }
+    if (inr) {
       zbuf[(long)b * n + i] = Zc;
       if (logzn_out) logzn_out[(long)b * n + i] = logz;
     }
@@ -368,9 +372,12 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
               const T* dlogzm_dTwc, int B, int n, int m, int Wimg, T* Pwn, T* dPwn_dTwc, T* uvec, T* zbuf, T* logzn_out,
               void* hists_v, T* med_out3, const int* pixcoord, int flags, hipStream_t s) {
   using KeyT = typename KeyOf<T>::type;
-  if (!Kt || !logzm || !Twc || !Kmat || !dlogzm_dTwc || !Pwn || !dPwn_dTwc || !uvec || !zbuf || !hists_v || !med_out3 ||
+  const bool depth_only = (flags & 8) != 0;   // z_n = exp(K~ logz_m) of every row + its exact median: Mapping.store_vars (Mapping.py:749-758)
+  if (!Kt || !logzm || !Twc || !Kmat || !dlogzm_dTwc || !zbuf || !hists_v || !med_out3 ||
       B <= 0 || n <= 0 || m <= 0 || m > 64 || (m & 3) || Wimg <= 0)
     return COMO_ERR_ARG;
+  if (depth_only) { Pwn = nullptr; dPwn_dTwc = nullptr; uvec = nullptr; }
+  else if (!Pwn || !dPwn_dTwc || !uvec) return COMO_ERR_ARG;
   uint32_t* hists = (uint32_t*)hists_v;
   if (!(flags & 4)) {
   if (!(flags & 1) && !zero_words(hists, (size_t)B * 6 * SEL_BINS, s))

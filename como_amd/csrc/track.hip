@@ -132,34 +132,6 @@ __global__ __launch_bounds__(256) void track_reduce_kernel(const T* __restrict__
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-// closed-form SE3 exp of xi = [omega, v] (COMO order), double precision
-__device__ inline void se3_exp_d(const double* xi, double* Tm) {
-  const double wx = xi[0], wy = xi[1], wz = xi[2];
-  const double th2 = wx * wx + wy * wy + wz * wz;
-  double a, b, c;
-  if (th2 < 1e-12) {
-    a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0;
-  } else {
-    const double th = sqrt(th2);
-    a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = (th - sin(th)) / (th2 * th);
-  }
-  const double W[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-  double W2[9];
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j) W2[i * 3 + j] = W[i * 3] * W[j] + W[i * 3 + 1] * W[3 + j] + W[i * 3 + 2] * W[6 + j];
-  for (int i = 0; i < 3; ++i) {
-    double t = 0;
-    for (int j = 0; j < 3; ++j) {
-      const double e = (i == j) ? 1.0 : 0.0;
-      Tm[i * 4 + j] = e + a * W[i * 3 + j] + b * W2[i * 3 + j];
-      t += (e + b * W[i * 3 + j] + c * W2[i * 3 + j]) * xi[3 + j];
-    }
-    Tm[i * 4 + 3] = t;
-  }
-  Tm[12] = Tm[13] = Tm[14] = 0.0;
-  Tm[15] = 1.0;
-}
-
 // out layout (T): [0:64) H | [64:72) g | [72:80) delta | [80:96) T_new | [96:98) aff_new |
 //                 98 mse | 99 grad_norm | 100 total_err | 101 sigma | 102 nvalid | 103 delta_norm | 104 chol_info
 template <typename T>
@@ -221,7 +193,7 @@ __global__ __launch_bounds__(256) void track_finish_kernel(const double* __restr
     double xi[6], E[16], Tn[16], dn = 0;
     for (int i = 0; i < 6; ++i) xi[i] = -d[i];
     for (int i = 0; i < 8; ++i) dn += d[i] * d[i];
-    se3_exp_d(xi, E);
+    se3_exp_f64(xi, E);
     for (int i = 0; i < 4; ++i)
       for (int j = 0; j < 4; ++j) {
         double t = 0;

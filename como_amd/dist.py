@@ -26,9 +26,7 @@ class Shard:
         per = ((per + 63) // 64) * 64                      # whole 64-pixel wave tiles
         b = min(n, self.rank * per)
         e = min(n, b + per)
-        if e <= b:                                         # degenerate tiny problems: give the last pixel to idle ranks
-            b, e = n - 1, n
-        return b, e
+        return b, max(b, e)                                # b == e: an idle rank (more ranks than 64-pixel tiles) owns nothing
 
     def all_reduce_sum(self, t):
         if self.world > 1:

@@ -14,9 +14,8 @@ What runs where:
 
 Deviations, documented: (1) no checkpoint loader -- `setup(model)` takes a `DepthCovModule` mirror (or a state dict);
 (2) `depth_imgs` is evaluated on demand from the stored log-depths instead of on every iteration (the reference recomputes
-B x H x W x m products per GN iteration only to keep this cache warm); (3) between topology changes the scaffold's
-re-initialisation depth uses the median of the sub-selected reference pixels (the reference: median of the full depth image
-of the previous iteration) -- it only matters for landmarks that fall behind a camera.
+B x H x W x m products per GN iteration only to keep this cache warm; the per-keyframe median of that image, which the
+priors and the landmark re-initialisation read, IS computed every iteration -- WindowBA's full-image median pass).
 """
 import torch
 

@@ -52,3 +52,32 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
             _lib.stream_ptr(dev))
     _lib.check(rc, "como_dense_ref")
     return ws["Pwn"], ws["dT"], ws["uvec"], med[:, 0], ws["logz"]
+
+
+def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all"):
+    """Mapping.store_vars (Mapping.py:749-758): per keyframe the exact median of exp(K~ logz_m) over ALL rows of K~
+    (the full depth image).  logzm (B,m), Kt (B,rows,m); med_out (B,3) caller-owned {median, 1.4826 median, n};
+    ws: caller-owned dict (depth plane + select histograms; a captured graph records the addresses).
+    part: "all", or "points" (kernel + pass-0 histogram) then "median" (remaining select passes + finish)."""
+    _lib.require_cuda(logzm, Kt)
+    dt, dev = Kt.dtype, Kt.device
+    B, rows, m = Kt.shape
+    L = _lib.lib()
+    key = ("full", str(dev), dt, B, rows)
+    w = ws.get(key)
+    if w is None:
+        w = {"z": torch.empty((B, rows), device=dev, dtype=dt),
+             "hists": torch.zeros((B * L.como_select_workspace_bytes() // 4,), device=dev, dtype=torch.int32),
+             "eye": torch.eye(4, device=dev, dtype=dt).repeat(B, 1, 1).contiguous(),
+             "K": torch.eye(3, device=dev, dtype=dt), "dl": torch.zeros((B, m, 6), device=dev, dtype=dt)}
+        ws[key] = w
+    lz = logzm.reshape(B, m)
+    if lz.dtype != dt or not lz.is_contiguous():
+        lz = lz.to(dt).contiguous()
+    fn = getattr(L, "como_dense_ref_" + _lib.suffix(dt))
+    h = hists if hists is not None else w["hists"]
+    rc = fn(Kt.data_ptr(), Kt.stride(0), None, lz.data_ptr(), w["eye"].data_ptr(), w["K"].data_ptr(), w["dl"].data_ptr(), B, rows, m,
+            1, None, None, None, w["z"].data_ptr(), None, h.data_ptr(), med_out.data_ptr(), None,
+            8 | (1 if hists is not None else 0) | {"all": 0, "points": 2, "median": 4}[part], _lib.stream_ptr(dev))
+    _lib.check(rc, "como_dense_ref (depth only)")
+    return med_out[:, 0]

@@ -43,8 +43,9 @@ def landmark_to_batched_3d_point_inds(landmark_inds, num_kf):
 _chol_ws = {}
 
 
-def solve_system(H, g):
-    """delta (D,1) = H^-1 g by dense Cholesky (reference :101-112).  float64 systems on the GPU run the blocked HIP
+def solve_system(H, g, ws=None):
+    """ws: caller-owned dict for the factorisation workspace (a captured graph records its address; None: process-wide).
+    delta (D,1) = H^-1 g by dense Cholesky (reference :101-112).  float64 systems on the GPU run the blocked HIP
     factorisation of csrc/chol.hip (graph-capturable, ~10x hipSOLVER at D = 760); float32 systems (the reference-signature
     path with a float32 H) go through torch.linalg.  `solve_system.last_info` holds the factorisation status (device int)."""
     if H.is_cuda and H.dtype == torch.float64:
@@ -52,12 +53,14 @@ def solve_system(H, g):
         L = _lib.lib()
         D = H.shape[0]
         key = (str(H.device), D)
-        ws = _chol_ws.get(key)
+        store = _chol_ws if ws is None else ws
+        ws = store.get(key)
         if ws is None:
             ws = (torch.empty(L.como_chol_workspace_bytes(D) // 8, dtype=torch.float64, device=H.device),
-                  torch.zeros(1, dtype=torch.int32, device=H.device))
-            _chol_ws[key] = ws
-        delta = torch.empty((D, 1), dtype=torch.float64, device=H.device)
+                  torch.zeros(1, dtype=torch.int32, device=H.device),
+                  torch.empty((D, 1), dtype=torch.float64, device=H.device))
+            store[key] = ws
+        delta = ws[2] if store is not _chol_ws else torch.empty((D, 1), dtype=torch.float64, device=H.device)
         Hc = H if H.is_contiguous() else H.contiguous()
         rc = L.como_chol_solve_f64(Hc.data_ptr(), g.contiguous().data_ptr(), delta.data_ptr(), ws[0].data_ptr(), D,
                                    ws[1].data_ptr(), _lib.stream_ptr(H.device))

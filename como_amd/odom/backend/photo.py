@@ -20,15 +20,19 @@ BLOCK_STAGGER = int(__import__("os").environ.get("COMO_BA_STAGGER", "0"))
 last_aux = {}   # diagnostics of the most recent call: valid mask, sigma, nvalid (tests / callers that want them)
 
 
-def _buf(name, shape, dtype, device):
+def _buf(name, shape, dtype, device, ws=None):
+    """Scratch tensor `name` from the workspace dict `ws` (None: the process-wide one, for one-shot eager calls only --
+    whoever captures a graph or keeps several windows alive passes its OWN dict: a graph records raw addresses, and a
+    shared buffer that grows on a later, larger request would be freed under it)."""
+    ws = _ws if ws is None else ws
     key = (name, str(device))
-    t = _ws.get(key)
+    t = ws.get(key)
     numel = 1
     for s in shape:
         numel *= int(s)
     if t is None or t.dtype != dtype or t.numel() < numel:
         t = torch.empty(max(numel, 1), device=device, dtype=dtype)
-        _ws[key] = t
+        ws[key] = t
     return t[:numel].view(*shape)
 
 
@@ -44,17 +48,28 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
               ref_slot, ref_aff, tgt_aff, tgt_pose, tgt_img, pose_ref_inds, pose_tgt_inds, landmark_inds, dzdP, H, g,
               err_out, uvec=None, pixidx=None, invz=None, kt_slot_stride=0, chunks=None, phase=0xFF, want_pj=False,
               want_blocks=False, sigma_out=None, pix_range=None, reduce_hists=None, events=None, anorm_f32=False,
-              grp_pairs=None, single_pairs=None, zeroed_hists=None):
+              grp_pairs=None, single_pairs=None, zeroed_hists=None, ws=None):
     """Thin marshalling layer over como_ba_linearize_* (see include/como_hip.h for every field).
 
     pix_range=(begin, end): this rank's share of the reference pixels of every pair (multi-GPU shard).
     reduce_hists(view): called on the (2048,) int32 histogram of each radix-select digit pass right after it is produced
         (multi-GPU: an all-reduce(sum), so every rank resolves the same exact median); splits the chain into phases.
-    events: optional dict filled with (start, end) torch.cuda.Event pairs around the block kernel ("blocks")."""
+    events: optional dict filled with (start, end) torch.cuda.Event pairs around the block kernel ("blocks").
+    ws: caller-owned workspace dict (residuals, validity, pair tables, partials, ...); see _buf."""
     dev = Pwn.device
     L = _lib.lib()
     pb, pe = pix_range if pix_range is not None else (0, n)
     nl = pe - pb
+    if nl <= 0:
+        # an idle shard (more ranks than 64-pixel tiles): contributes nothing -- but it must still take part in the
+        # histogram all-reduces of the distributed median
+        if reduce_hists is not None:
+            zh = zeroed_hists if zeroed_hists is not None else _buf("hists", (L.como_select_workspace_bytes() // 4,), torch.int32, dev, ws)
+            if zeroed_hists is None:
+                zh.zero_()
+            for ps in range(3 if dtype == torch.float32 else 6):
+                reduce_hists(zh[ps * 2048:(ps + 1) * 2048])
+        return sigma_out
     if chunks is None:
         if grp_pairs is not None and grp_pairs.numel() > 0 and dtype == torch.float32 and zmode == 1 and BLOCK_VARIANT == 0:
             chunks = default_chunks(grp_pairs.shape[0], nl, dtype, per_cu=2)     # two-pair kernel: 2 workgroups per CU resident
@@ -71,16 +86,16 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     a.variant = BLOCK_VARIANT
     a.stagger = BLOCK_STAGGER
     a.h_is_f64 = 1 if H.dtype == torch.float64 else 0
-    ws_r = _buf("r", (b, nl), dtype, dev)
-    ws_valid = _buf("valid", (b, nl), torch.uint8, dev)
+    ws_r = _buf("r", (b, nl), dtype, dev, ws)
+    ws_valid = _buf("valid", (b, nl), torch.uint8, dev, ws)
     # zeroed_hists: caller-owned select workspace that is ALREADY zero (the fused window path clears it elsewhere)
-    ws_hists = zeroed_hists if zeroed_hists is not None else _buf("hists", (L.como_select_workspace_bytes() // 4,), torch.int32, dev)
-    ws_pair = _buf("pair", (b * 14,), dtype, dev)
-    ws_part = _buf("partials", (L.como_ba_partials_elems(b, chunks, m),), dtype, dev)
+    ws_hists = zeroed_hists if zeroed_hists is not None else _buf("hists", (L.como_select_workspace_bytes() // 4,), torch.int32, dev, ws)
+    ws_pair = _buf("pair", (b * 14,), dtype, dev, ws)
+    ws_part = _buf("partials", (L.como_ba_partials_elems(b, chunks, m),), dtype, dev, ws)
     if sigma_out is None:
-        sigma_out = _buf("sigma", (2,), dtype, dev)
-    pj = _buf("pj", (b, nl, 2), dtype, dev) if want_pj else None
-    blocks = _buf("blocks", (b, 3936), torch.float64, dev) if want_blocks else None
+        sigma_out = _buf("sigma", (2,), dtype, dev, ws)
+    pj = _buf("pj", (b, nl, 2), dtype, dev, ws) if want_pj else None
+    blocks = _buf("blocks", (b, 3936), torch.float64, dev, ws) if want_blocks else None
     keep = [Pwn, vals, dPwn_dTwc, zjac, uvec, pixidx, invz, poses_all, aff_all, img_base, K, ref_slot, ref_aff, tgt_aff,
             tgt_pose, tgt_img, pose_ref_inds, pose_tgt_inds, landmark_inds, dzdP, H, g, err_out]
     _lib.require_cuda(*keep)
@@ -228,7 +243,7 @@ class PairTable:
 
 def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uvec, Kt, pixidx, invz, dzdP, img_base, K,
                           H_img, W_img, H, g, err_out, chunks=None, phase=0xFF, sigma_out=None, pix_range=None,
-                          reduce_hists=None, events=None, zeroed_hists=None):
+                          reduce_hists=None, events=None, zeroed_hists=None, ws=None):
     """Fast path: same normal equations as batch_photo_cost from the rank-1 factors of dPwn_dzm.
     Per-keyframe arrays (slots = keyframes): Pwn (B,n,3) vals (B,n) dPwn_dTwc (B,n,3,6) uvec (B,n,3) invz (B,m)
     Kt (B,rows,m) dense predictor, pixidx (B,n) int32 rows of Kt (None = identity), dzdP (B,3)."""
@@ -242,4 +257,4 @@ def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uv
                      landmark_inds=table.landmark_inds, dzdP=dzdP, H=H, g=g, err_out=err_out, chunks=chunks,
                      phase=phase, sigma_out=sigma_out, pix_range=pix_range, reduce_hists=reduce_hists, events=events,
                      grp_pairs=(table.grp_pairs if vals.dtype == torch.float32 else None), single_pairs=table.single_pairs,
-                     zeroed_hists=zeroed_hists)
+                     zeroed_hists=zeroed_hists, ws=ws)

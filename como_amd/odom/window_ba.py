@@ -23,7 +23,7 @@ import como_amd.odom.backend.photo as photo
 import como_amd.odom.backend.sparse_map as smap
 from como_amd import _lib
 from como_amd.geometry.camera import backprojection
-from como_amd.odom.backend.dense_ref import dense_reference_factored
+from como_amd.odom.backend.dense_ref import dense_reference_factored, full_image_median
 from como_amd.odom.backend.graph_pair_construction import setup_photometric_pairs
 from como_amd.odom.factors.depth_prior import log_depth_prior
 from como_amd.odom.factors.gp_priors import gp_ml_cost, mean_log_depth_cost
@@ -160,7 +160,12 @@ class WindowBA:
                   "reinit_flag": torch.zeros(L, device=dev, dtype=torch.int32),
                   "px_logzm": zp(B, m), "px_invz": zp(B, m), "px_dzdP": zp(B, 3), "px_dlogz_dT": zp(B, m, 6),
                   "px_poses": zp(F, 4, 4), "px_aff": zp(F, 2),
-                  "med3": zp(B, 3)}
+                  "med3": zp(B, 3), "med3_full": zp(B, 3)}
+        # The reference keeps TWO medians per keyframe: the one of the sub-selected reference pixels (setup_test_points,
+        # sparse_map.py:220 -- only the pair graph reads it) and `self.median_depths` = the median of the FULL depth image
+        # exp(K~ logz_m) (store_vars, Mapping.py:749-758), which the priors and the landmark re-initialisation use.  With
+        # every pixel a reference pixel (window 1) the two coincide and the dense-reference median serves both.
+        self.full_median = self.n != self.Himg * self.Wimg
         self.first_mask_u8 = self.obs_ref_mask.to(torch.uint8).contiguous()
         self.fix_lm = self.fix_idx.to(torch.int32).contiguous()
         self.aff_anchor2 = self.aff_anchor.reshape(2).contiguous()
@@ -177,7 +182,7 @@ class WindowBA:
         a.lm_ids, a.first_frame, a.first_slot, a.fix_lm = ptr(self.lm_ids), ptr(self.first_frame), ptr(self.first_slot), ptr(self.fix_lm)
         a.first_mask, a.pose_inds, a.landmark_inds, a.fix_inds = (ptr(self.first_mask_u8), ptr(self.kf_inds), ptr(self.landmark_inds),
                                                                   ptr(self.fix_inds_flat))
-        a.median_new = ptr(self.w["med3"])
+        a.median_new = ptr(self.w["med3_full"] if self.full_median else self.w["med3"])
         for k in ("pm", "logzm", "invz", "dzdP", "dlogz_dT", "dlogz_dP", "dp_dP", "dp_dT", "init_Pm", "reinit_flag", "px_logzm",
                   "px_invz", "px_dzdP", "px_dlogz_dT", "px_poses", "px_aff"):
             setattr(a, k, ptr(self.w[k]))
@@ -186,13 +191,18 @@ class WindowBA:
         a.H, a.g, a.err = ptr(self.H), ptr(self.g), ptr(self.prior_err)
         # the two radix-select workspaces of an iteration are cleared by the scaffold kernel (no fill launches)
         hb = _lib.lib().como_select_workspace_bytes()
-        self.w["hist_dr"] = torch.zeros(B * hb // 4, dtype=torch.int32, device=self.dev)
+        self.w["hist_dr2"] = torch.zeros(2 * B * hb // 4, dtype=torch.int32, device=self.dev)   # dense-ref median | full-image median
+        self.w["hist_dr"] = self.w["hist_dr2"][:B * hb // 4]
+        self.w["hist_full"] = self.w["hist_dr2"][B * hb // 4:]
         self.w["hist_ba"] = torch.zeros(hb // 4, dtype=torch.int32, device=self.dev)
-        a.zero_a, a.zero_a_bytes = ptr(self.w["hist_dr"]), B * hb
+        a.zero_a, a.zero_a_bytes = ptr(self.w["hist_dr2"]), 2 * B * hb
         a.zero_b, a.zero_b_bytes = ptr(self.w["hist_ba"]), hb
         a.median_out = ptr(self.median_depths)
         self.win_args = a
         self.w["dr_ws"] = {}                               # dense-reference planes: owned here (captured graphs record them)
+        self.w["ba_ws"] = {}                               # residual / validity / pair / partial-Gram scratch of the BA chain
+        self.w["chol_ws"] = {}                             # Cholesky workspace + delta
+        self.with_priors = True                            # tests: False leaves H = the photometric system alone
         self.overlap_priors = True
         self._side_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
 
@@ -206,8 +216,19 @@ class WindowBA:
                                                    w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"],
                                                    hists=w["hist_dr"], ws=w["dr_ws"], part=part)
         fork = self.shard is None and self.overlap_priors
+        fm = lambda part: full_image_median(w["px_logzm"], self.Kt, w["med3_full"], w["dr_ws"], hists=w["hist_full"], part=part)
+        if fork and self.full_median:
+            # the full-image median needs only the scaffold's log-depths: its whole branch (depth image, select passes,
+            # priors) runs beside the dense reference points and the photometric system
+            main = torch.cuda.current_stream(dev)
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                fm("all")
+                if self.with_priors:
+                    _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
         Pwn, dT, uvec, med, _ = dr("points" if fork else "all")
-        if fork:
+        if fork and not self.full_median:
             # Nothing between the reference points and the solve needs the median depths except the priors, and the priors
             # only ADD into H / g (atomics): the median's select passes and the prior kernel run on a second stream (a
             # parallel branch of the captured graph) beside the residual / block / assembly kernels -- ~50 us of small
@@ -217,24 +238,28 @@ class WindowBA:
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 dr("median")
-                _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
+                if self.with_priors:
+                    _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
         photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=Pwn, vals=self.vals_n,
                                     dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],
                                     img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=self.H, g=self.g,
                                     err_out=self.err, sigma_out=self.sigma, pix_range=self.pix_range,
                                     reduce_hists=(self.shard.all_reduce_sum if self.shard is not None else None),
-                                    events=self.events, zeroed_hists=w["hist_ba"])
+                                    events=self.events, zeroed_hists=w["hist_ba"], ws=w["ba_ws"])
         if fork:
             torch.cuda.current_stream(dev).wait_stream(side)
         else:
             if self.shard is not None:
                 self.shard.all_reduce_sum(self.sys)      # normal equations of all shards: H | g | err in one collective
-            _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")   # also stores the new median depths
+            if self.full_median:
+                fm("all")
+            if self.with_priors:
+                _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")   # also stores the new median depths
         return self.H, self.g
 
     def iterate_fused(self):
         H, g = self.linearize_fused()
-        delta = lin_sys.solve_system(H, g)
+        delta = lin_sys.solve_system(H, g, ws=self.w["chol_ws"])
         rc = _lib.lib().como_win_update(delta.data_ptr(), self.poses_all.data_ptr(), self.aff_all.data_ptr(),
                                         self.frame_inds.data_ptr(), self.F, self.P_m.data_ptr(), self.L, self.lm_start,
                                         _lib.stream_ptr(self.dev))
@@ -271,6 +296,11 @@ class WindowBA:
         p = self.pix_dtype
         Pwn, dPwn_dTwc, uvec, med, _ = dense_reference_factored(logzm.to(p), self.kf_poses.to(p), self.Kt, self.pixidx, self.K_pix,
                                                                 dlogzm_dTwc.to(p), self.Wimg, want_logz=False)
+        self.median_subset = med
+        if self.full_median:                                 # Mapping.store_vars: median of the full depth image
+            if not hasattr(self, "_fm_ws"):
+                self._fm_ws = ({}, torch.zeros((self.B, 3), device=self.dev, dtype=p))
+            med = full_image_median(logzm.to(p), self.Kt, self._fm_ws[1], self._fm_ws[0])
         self.median_depths.copy_(med)
         self.pm, self.logzm = pm, logzm
         H, g = self.H, self.g
@@ -283,7 +313,7 @@ class WindowBA:
                                     img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=H, g=g,
                                     err_out=self.err, sigma_out=self.sigma, pix_range=self.pix_range,
                                     reduce_hists=(self.shard.all_reduce_sum if self.shard is not None else None),
-                                    events=self.events)
+                                    events=self.events, ws=self.w["ba_ws"])
         if self.shard is not None:
             self.shard.all_reduce_sum(self.sys)
         kf_pose_inds = self.kf_inds[:, :6]

@@ -190,7 +190,10 @@ int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, cons
  * (two-frame SfM passes K~ rows of the selected pixels only, two_frame_sfm.py:246-252); NULL = the K~ row index.
  * flags bit 0: hists is already zero (skip the clear); bit 1: points only -- the kernel and its pass-0 depth histogram,
  * no median; bit 2: median only -- the remaining select passes + finish on the zbuf / hists a bit-1 call left (the two halves
- * may run on different streams: nothing between the reference points and the priors needs the median). */
+ * may run on different streams: nothing between the reference points and the priors needs the median);
+ * bit 3: depth only -- z_n = exp(K~[n,:] logz_m) of every row into zbuf and its exact per-keyframe median, no planes
+ * (Pwn / dPwn_dTwc / uvec may be NULL): Mapping.store_vars' full-image median depth (Mapping.py:749-758), the value
+ * the priors and the landmark re-initialisation use. */
 int como_dense_ref_f32(const float* Kt, long kt_slot_stride, const int* pixidx, const float* logzm, const float* Twc,
                        const float* K, const float* dlogzm_dTwc, int B, int n, int m, int Wimg, float* Pwn,
                        float* dPwn_dTwc, float* uvec, float* zbuf, float* logzn_out, void* hists, float* med_out3,

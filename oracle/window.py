@@ -35,10 +35,27 @@ class OracleWindow:
     def iterate(self):
         c, K, B = self.c, self.K, self.B
         Pb = self.P[self.ids]
-        pm, logz, zmask, dlogz_dz, dz_dPw, dz_dTwc, dp_dPw, dp_dTwc = odr.project_landmarks(self.poses, Pb, K, Pb, self.med)
+        # re-initialisation point of every landmark: its first-observation pixel back-projected from its FIRST observer at
+        # that keyframe's (full-image) median depth (Mapping.py:612-634); used where z < 0.1 median (sparse_map.py:26-41)
+        L = self.P.shape[0]
+        first = torch.argmax(self.corr.int(), dim=0)
+        slot = (self.ids[first] == torch.arange(L)[:, None]).int().argmax(dim=1)
+        px = c["pm_first_obs"][first, slot]                                       # (L,2) (x, y)
+        ray = torch.stack(((px[:, 0] - K[0, 2]) / K[0, 0], (px[:, 1] - K[1, 2]) / K[1, 1], torch.ones(L, dtype=torch.float64)), -1)
+        Tf = self.poses[first]
+        init_P = torch.einsum("lij,lj->li", Tf[:, :3, :3], ray * self.med[first][:, None]) + Tf[:, :3, 3]
+        pm, logz, zmask, dlogz_dz, dz_dPw, dz_dTwc, dp_dPw, dp_dTwc = odr.project_landmarks(self.poses, Pb, K, init_P[self.ids],
+                                                                                            self.med)
+        moved = zmask[first, slot]                                                # re-initialised by the first observer: for good
+        self.P = torch.where(moved[:, None], init_P, self.P)                      # Mapping.py:645-648
+        self.zmask, self.moved = zmask, moved
         dlogz_dT = dlogz_dz @ dz_dTwc
         dlogz_dP = dlogz_dz @ dz_dPw
-        Pw, dT, dz, med, _ = odr.dense_reference(logz, self.poses, self.Kt_rows, self.cn, K, dlogz_dT, dlogz_dz)
+        Pw, dT, dz, med_sub, _ = odr.dense_reference(logz, self.poses, self.Kt_rows, self.cn, K, dlogz_dT, dlogz_dz)
+        self.med_subset = med_sub                                                 # setup_test_points: pair graph only
+        # Mapping.store_vars (Mapping.py:749-758): median of the full depth image -> priors, next iteration's re-init
+        Kt = c["Knm_Kmminv"].reshape(B, -1, self.m)
+        med = torch.median(torch.exp(Kt @ logz.reshape(B, self.m, 1))[..., 0], dim=1).values
         self.med = med
         H = torch.zeros((self.D, self.D), dtype=torch.float64)
         g = torch.zeros(self.D, dtype=torch.float64)

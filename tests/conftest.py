@@ -61,3 +61,14 @@ def pytest_sessionfinish(session, exitstatus):
 def rel_err(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-300)).item()
+
+
+def scaled_err(H, Href):
+    """Scale-aware matrix error: max |D^-1/2 (H - Href) D^-1/2| with D = diag(Href) (rows with a zero diagonal are compared
+    unscaled).  The Jacobi-scaled reference has a unit diagonal whatever the 1e12 pose anchor does to max|H|, so this
+    measures every block -- photometric, prior, anchor -- relative to its own magnitude (a max-norm relative error of the
+    full system only ever sees the anchor)."""
+    H, Href = H.detach().double().cpu(), Href.detach().double().cpu()
+    d = torch.sqrt(torch.diagonal(Href).abs())
+    d = torch.where(d > 0, d, torch.ones_like(d))
+    return ((H - Href).abs() / d[:, None] / d[None, :]).max().item()

@@ -197,7 +197,12 @@ def window_case(dtype, B, H, W, m, window, seed, with_recent, aff_noise=0.02, sa
     # --- priors exactly as reference Mapping.iterate applies them (Mapping.py:809-917)
     kf_pose_inds, kf_aff_inds = kf_inds[:, :6], kf_inds[:, 6:]
     dlogzm_dPwm = dlogzm_dzm @ dzm_dPwm
-    log_med = torch.log(med[:, None, None])
+    # Mapping.store_vars (Mapping.py:749-758): the priors use the median of the FULL depth image exp(K~ logz_m), not the
+    # sub-selected pixels' median that setup_test_points returned (that one only feeds the pair graph)
+    depth_imgs = torch.exp(torch.permute(st["Knm_Kmminv"] @ logzm[:, None, :, :], (0, 3, 1, 2)))
+    med_full = torch.median(depth_imgs.view(B, H * W), dim=1).values
+    out["median_depths_full"] = med_full
+    log_med = torch.log(med_full[:, None, None])
     e_gp = gp_ml_cost(logzm, log_med, st["L_mm"], dlogzm_dPwm, dlogzm_dTwc, landmark_inds, kf_pose_inds, Hm, gv, sigma=1e0)
     out.update({"H_gp": Hm.clone(), "g_gp": gv.clone()})
     e_ld = log_depth_prior(logzm, log_med, dlogzm_dPwm, dlogzm_dTwc, st["obs_ref_mask"], landmark_inds, kf_pose_inds,

@@ -1,0 +1,306 @@
+"""Round-2 golden vectors: every case here drives the reference's OWN `Mapping.iterate` (como/odom/Mapping.py:760-968)
+on a real `como.odom.Mapping.Mapping` object whose state attributes are filled from a seeded synthetic window, and records
+what the reference computed (hooks around `create_photo_system` and `solve_system` keep the intermediate H / g).
+
+    python tests/golden/make_golden_r2.py [fullwin4] [fullwin1] [reinit] [win32] [se3]
+
+Cases
+  fullwin4 / fullwin1 : the METRIC configuration -- 8 keyframes, 640x480, m = 64, nonmax window 4 (reference default) and
+                        window 1 (dense: every pixel a reference pixel, the bench workload).  Inputs are NOT stored: the
+                        tests regenerate them from the same seeds (synth.make_window(seed=0)); stored are the reference's
+                        scalars / small vectors (valid counts, sigma_r, err, g, diag H, H v probes, delta, new poses...).
+  reinit              : a small window in which landmarks fall behind a camera / below 0.1 x median depth, through the
+                        reference's prep_geometry_scaffold (Mapping.py:603-659, sparse_map.py:26-41).
+  win32               : config 4 -- a 32-keyframe window (62 pairs, D ~ 2.4 k) at reduced resolution.
+  se3                 : SE(3) exponential pinned INDEPENDENTLY of any hand-written closed form: scipy.linalg.expm of the
+                        4x4 twist matrix, for the [tau, phi] ordering lietorch documents (the reference reorders COMO's
+                        [omega, v] to it, lie_algebra.py:45-56).
+Runs only in the build container (needs /root/reference).  Fixtures are data only.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (sets up sys.path, shims, como_backends)
+
+import como.odom.Mapping as rmap  # noqa: E402
+import como.odom.backend.photo as rphoto  # noqa: E402
+import como.odom.backend.linear_system as rlin  # noqa: E402
+from como.geometry.lie_algebra import invertSE3_J  # noqa: E402
+from como.geometry.transforms import transform_points  # noqa: E402
+from como.geometry.camera import projection  # noqa: E402
+
+from como_amd import synth  # noqa: E402
+
+
+def ref_mapping_from_state(st, window, dtype=torch.float64, window_full=True, recent=None):
+    """A reference Mapping object holding the window `st` (synth.make_window with the reference predictor)."""
+    cfg = dict(mg.MAP_CFG)
+    cfg["dtype"] = "double" if dtype == torch.float64 else "float"
+    cfg["photo_construction"] = {"nonmax_suppression_window": window, "pairwise_batch_size": 128, "radius_thresh": 0.0,
+                                 "degrees_thresh": 0.0}
+    mp = rmap.Mapping(cfg, st["intrinsics"][0].clone())
+    mp.init_basic_vars()
+    mp.init_keyframe_vars()
+    mp.init_prior_vals()
+    mp.reset_iteration_vars(new_kf=True, converged=True)
+    B = st["kf_poses"].shape[0]
+    mp.kf_timestamps = st["kf_timestamps"].tolist()
+    mp.kf_img_and_grads = st["kf_img_and_grads"]
+    mp.kf_poses = st["kf_poses"].clone()
+    mp.kf_aff_params = st["kf_aff_params"].clone()
+    mp.pm_first_obs = st["pm_first_obs"].clone()
+    mp.logzm = torch.zeros((B, st["coords_m"].shape[1], 1), dtype=dtype)     # only its shape is read before the scaffold
+    mp.L_mm = st["L_mm"]
+    mp.Kmm_inv = st["K_mm_inv"]
+    mp.Knm_Kmminv = st["Knm_Kmminv"]
+    mp.correspondence_mask = st["correspondence_mask"].clone()
+    mp.P_m = st["P_m"].clone()
+    mp.obs_ref_mask = st["obs_ref_mask"].clone()
+    mp.median_depths = st["median_depth_init"].clone()
+    if recent is not None:
+        mp.recent_timestamps = recent["recent_timestamps"].tolist()
+        mp.recent_img_and_grads = recent["recent_img_and_grads"]
+        mp.recent_poses = recent["recent_poses"].clone()
+        mp.recent_aff_params = recent["recent_aff_params"].clone()
+    mp.window_full = window_full
+    mp.pose_anchor = st["pose_anchor"].clone()
+    mp.aff_anchor = torch.zeros((1, 2, 1), dtype=dtype)
+    mp.P_m_anchors = st["P_anchor"].clone()
+    mp.is_init = True
+    return mp
+
+
+class Hooks:
+    """Record what the reference's iterate passes to / gets from create_photo_system and solve_system."""
+
+    def __init__(self):
+        self.rec = {}
+        self._cps, self._solve = rmap.create_photo_system, rlin.solve_system
+
+    def __enter__(self):
+        rec = self.rec
+
+        def cps(*a):
+            out = self._cps(*a)
+            (kf_poses, kf_aff, rp, ra, Pwn, dPwn_dTwc, dPwn_dzm, dzm_dPwm, med, vals_n, imgs, rimgs, kts, rts, K, H, g, cfg,
+             kf_inds, recent_inds, landmark_inds) = a
+            rec.update({"H_photo": H.clone(), "g_photo": g.clone(), "photo_err": torch.as_tensor(out[0]).clone(),
+                        "kf_ref_ids": torch.tensor(out[1][0]), "kf_target_ids": torch.tensor(out[1][1]),
+                        "ow_kf_ids": torch.tensor(out[2][0], dtype=torch.long), "ow_target_ids": torch.tensor(out[2][1], dtype=torch.long),
+                        "median_depths_subset": med.clone(), "landmark_inds": landmark_inds.clone(), "kf_inds": kf_inds.clone(),
+                        "dzm_dPwm": dzm_dPwm.clone()})
+            # per-pair validity / residual through the reference's own functions (photo.py:104-128), keyframe pairs only
+            rid, tid = rec["kf_ref_ids"], rec["kf_target_ids"]
+            Tcw_t, _ = invertSE3_J(kf_poses[tid])
+            Pcj, _, _ = transform_points(Tcw_t, Pwn[rid])
+            vals_t, _, valid = rphoto.interp_img(imgs[tid], Pcj, K[0])
+            vis = torch.exp(kf_aff[tid][:, 0:1, :] - kf_aff[rid][:, 0:1, :]) * vals_n[rid]
+            r = vals_t - vis + (kf_aff[tid][:, 1:2, :] - kf_aff[rid][:, 1:2, :])
+            rec["pair_nvalid"] = valid.sum(dim=1)
+            rec["pair_abs_r_sum"] = (r[..., 0].abs() * valid).sum(dim=1)
+            if len(out[2][0]) == 0:
+                rec["sigma_r"] = 1.4826 * torch.median(torch.abs(r[valid]))
+            rec["_full"] = {"Pwn": Pwn, "dPwn_dTwc": dPwn_dTwc, "vals_n": vals_n, "valid": valid, "r": r[..., 0], "Pcj": Pcj}
+            return out
+
+        def solve(H, g):
+            rec["H_full"], rec["g_full"] = H.clone(), g.clone()
+            d = self._solve(H, g)
+            rec["delta"] = d.clone()
+            rec["chol_info"] = torch.linalg.cholesky_ex(H)[1].clone()
+            return d
+        rmap.create_photo_system = cps
+        rlin.solve_system = solve
+        return self
+
+    def __exit__(self, *exc):
+        rmap.create_photo_system = self._cps
+        rlin.solve_system = self._solve
+
+
+from tests.golden_probes import probes  # noqa: E402  (one definition, shared with the tests)
+
+
+def jacobi_scale(H):
+    d = torch.sqrt(torch.diagonal(H).clamp_min(1e-300))
+    return H / d[:, None] / d[None, :]
+
+
+def summarise(rec, mp, st0, keep_full_H):
+    """Small reference outputs of one iterate: scalars, D-vectors, diag, Jacobi-scaled probe products, new state."""
+    out = {}
+    for k in ("photo_err", "kf_ref_ids", "kf_target_ids", "median_depths_subset", "pair_nvalid", "pair_abs_r_sum", "g_photo",
+              "g_full", "delta", "chol_info", "landmark_inds", "kf_inds"):
+        out[k] = rec[k]
+    if "sigma_r" in rec:
+        out["sigma_r"] = rec["sigma_r"]
+    D = rec["H_photo"].shape[0]
+    V = probes(D)
+    for name in ("H_photo", "H_full"):
+        H = rec[name]
+        out[name + "_diag"] = torch.diagonal(H).clone()
+        # scale-aware check data: S = D^-1/2 H D^-1/2 has unit diagonal whatever the 1e12 pose anchor does to max|H|
+        dd = torch.sqrt(torch.diagonal(H))
+        nz = dd > 0
+        S = torch.zeros_like(H)
+        S[nz[:, None] & nz[None, :]] = (H / dd[:, None].clamp_min(1e-300) / dd[None, :].clamp_min(1e-300))[nz[:, None] & nz[None, :]]
+        out[name + "_scaled_probe"] = S @ V
+        out[name + "_scaled_fro"] = torch.linalg.norm(S)
+        out[name + "_pose_block"] = H[:8 * mp.kf_poses.shape[0], :8 * mp.kf_poses.shape[0]].clone()
+        if keep_full_H:
+            out[name] = H
+    out["median_depths_full"] = mp.median_depths.clone()          # store_vars: full-image median (Mapping.py:749-758)
+    out["kf_poses_new"], out["kf_aff_new"], out["P_new"] = mp.kf_poses.clone(), mp.kf_aff_params.clone(), mp.P_m.clone()
+    out["logzm"], out["pm"] = mp.logzm.clone(), mp.pm.clone()
+    out["total_err"] = torch.as_tensor(mp.total_err_prev).clone()
+    out["kf_poses_in"], out["P_in"] = st0["kf_poses"], st0["P_m"]
+    return out
+
+
+def fullwin_case(window, B=8, H=480, W=640, m=64, seed=0, iters=3):
+    dtype = torch.float64
+    t0 = time.time()
+    model = mg.ref_model()
+    pred = lambda cov, cm: mg.ref_prep_predictor(model, cov, cm, (H, W), dtype)[:3]
+    st = synth.make_window(B=B, H=H, W=W, m=m, dtype=dtype, seed=seed, predictor=pred)
+    print(f"  window state built in {time.time() - t0:.0f} s")
+    mp = ref_mapping_from_state(st, window)
+    out = {}
+    with Hooks() as hk:
+        for it in range(iters):
+            t1 = time.time()
+            mp.iterate()
+            print(f"  reference iterate {it}: {time.time() - t1:.1f} s, err {float(mp.total_err_prev):.6e}")
+            s = summarise(hk.rec, mp, st, keep_full_H=(it == 0 and window == 4))
+            for k, v in s.items():
+                out[f"it{it}_{k}"] = v
+            if it == 0:
+                full = hk.rec["_full"]
+                # a deterministic sample of per-pixel values of the first iteration (pair p, pixel index i)
+                g = torch.Generator().manual_seed(7)
+                b, n = full["valid"].shape
+                pi = torch.randint(0, b, (4096,), generator=g)
+                ii = torch.randint(0, n, (4096,), generator=g)
+                out.update({"sample_pair": pi, "sample_pix": ii, "sample_valid": full["valid"][pi, ii], "sample_r": full["r"][pi, ii],
+                            "sample_Pwn": full["Pwn"][hk.rec["kf_ref_ids"][pi], ii]})
+    out.update({"window": window, "B": B, "H": H, "W": W, "m": m, "seed": seed, "K_mm_inv": st["K_mm_inv"],
+                "coords_m": st["coords_m"], "P_m": st["P_m"]})
+    return out
+
+
+def reinit_case(seed=21, B=3, H=48, W=64, m=8, window=2):
+    """Landmarks behind a camera / closer than 0.1 x the keyframe's median depth (sparse_map.py:26-41): one landmark first
+    observed by keyframe 0 is mirrored behind it (-> re-initialised for good, Mapping.py:645-648), and keyframe 1's median
+    depth is set so that 0.1 x median splits its landmarks (-> their camera-frame point is replaced for this iteration; the
+    ones keyframe 1 observed first are moved for good)."""
+    dtype = torch.float64
+    model = mg.ref_model()
+    pred = lambda cov, cm: mg.ref_prep_predictor(model, cov, cm, (H, W), dtype)[:3]
+    st = synth.make_window(B=B, H=H, W=W, m=m, dtype=dtype, seed=seed, predictor=pred, aff_noise=0.02)
+    corr = st["correspondence_mask"]
+    ids0 = torch.nonzero(corr[0])[:, 0]
+    l_behind = int(ids0[2])
+    T0 = st["kf_poses"][0]
+    Pc = T0[:3, :3].T @ (st["P_m"][l_behind] - T0[:3, 3])
+    Pc[2] = -Pc[2]
+    st["P_m"][l_behind] = T0[:3, :3] @ Pc + T0[:3, 3]
+    # depths of keyframe 1's landmarks -> pick the median so that 0.1 * median falls between them
+    T1 = st["kf_poses"][1]
+    ids1 = torch.nonzero(corr[1])[:, 0]
+    z1 = ((st["P_m"][ids1] - T1[:3, 3]) @ T1[:3, :3])[:, 2]
+    zf = torch.sort(z1[st["obs_ref_mask"][1]]).values              # depths of the landmarks keyframe 1 observed first
+    st["median_depth_init"][1] = 10.0 * 0.5 * (zf[-2] + zf[-1])      # 0.1 x median flags all of them but the farthest
+    st["median_depth_init"][0] = 1.07
+    st["median_depth_init"][2] = 0.93
+    mp = ref_mapping_from_state(st, window)
+    out = {k: st[k] for k in ("intrinsics", "kf_poses", "kf_aff_params", "kf_img_and_grads", "cov_params_img", "coords_m",
+                              "correspondence_mask", "P_m", "kf_timestamps", "K_mm_inv", "L_mm", "Knm_Kmminv", "obs_ref_mask",
+                              "pm_first_obs", "pose_anchor", "P_anchor")}
+    out["median_depths_in"] = st["median_depth_init"].clone()
+    # scaffold alone first (on a copy): z_mask and the re-initialised landmarks
+    import copy
+    mp_s = copy.copy(mp)
+    mp_s.P_m = mp.P_m.clone()
+    sc = mp_s.prep_geometry_scaffold()
+    out.update({"sc_pm": sc[0], "sc_dpm_dTwc": sc[1], "sc_dpm_dPwm": sc[2], "sc_logzm": sc[3], "sc_dzm_dTwc": sc[4],
+                "sc_dlogzm_dzm": sc[5], "sc_dzm_dPwm": sc[6], "sc_P_m_after": mp_s.P_m.clone()})
+    n_moved = int((mp_s.P_m != st["P_m"]).any(dim=1).sum())
+    print(f"  reinit: {n_moved} landmarks moved for good (behind: {l_behind})")
+    assert n_moved >= 2
+    with Hooks() as hk:
+        mp.iterate()
+        s = summarise(hk.rec, mp, st, keep_full_H=True)
+    for k, v in s.items():
+        out[f"it0_{k}"] = v
+    out["n_moved"] = n_moved
+    return out
+
+
+def win32_case(B=32, H=60, W=80, m=24, window=2, seed=31):
+    """Config 4 at reduced resolution: a 32-keyframe window (62 consecutive pairs), D = 8 B + 3 L."""
+    dtype = torch.float64
+    model = mg.ref_model()
+    pred = lambda cov, cm: mg.ref_prep_predictor(model, cov, cm, (H, W), dtype)[:3]
+    # the synthetic trajectory is one degree per keyframe: 32 keyframes of a 80-pixel-wide camera would leave the plane
+    st = synth.make_window(B=B, H=H, W=W, m=m, dtype=dtype, seed=seed, predictor=pred, aff_noise=0.01)
+    mp = ref_mapping_from_state(st, window)
+    # inputs are regenerated by the tests from the same seed (synth.make_window); only small arrays are stored
+    out = {k: st[k] for k in ("kf_poses", "coords_m", "correspondence_mask", "P_m", "K_mm_inv")}
+    out.update({"B": B, "H": H, "W": W, "m": m, "window": window, "seed": seed, "aff_noise": 0.01})
+    out["median_depths_in"] = st["median_depth_init"].clone()
+    with Hooks() as hk:
+        for it in range(2):
+            mp.iterate()
+            s = summarise(hk.rec, mp, st, keep_full_H=False)
+            for k, v in s.items():
+                out[f"it{it}_{k}"] = v
+            print(f"  win32 iterate {it}: D = {hk.rec['H_full'].shape[0]}, pairs = {len(hk.rec['kf_ref_ids'])}, "
+                  f"err {float(mp.total_err_prev):.6e}, chol info {int(hk.rec['chol_info'])}")
+    return out
+
+
+def se3_case(seed=5):
+    """T = expm([[phi]x, tau],[0, 0]) by scipy for twists [tau, phi] (lietorch's documented ordering); COMO's update
+    vector is [omega (0:3), v (3:6)] and batch_se3 / se3_exp feed lietorch [v, omega] (lie_algebra.py:45-56)."""
+    from scipy.linalg import expm
+    rs = np.random.RandomState(seed)
+    xi = np.concatenate((rs.randn(24, 6) * 0.3, rs.randn(8, 6) * 1e-7, rs.randn(8, 6) * 1e-3,
+                         rs.randn(8, 6) * np.array([3.0, 3.0, 3.0, 1.0, 1.0, 1.0]), np.zeros((1, 6))))
+    # rows here are COMO ordering [omega, v]
+    T = np.zeros((xi.shape[0], 4, 4))
+    for i, x in enumerate(xi):
+        w, v = x[:3], x[3:]
+        A = np.zeros((4, 4))
+        A[:3, :3] = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        A[:3, 3] = v
+        T[i] = expm(A)
+    T0 = np.zeros((xi.shape[0], 4, 4))
+    for i in range(xi.shape[0]):
+        a = rs.randn(6) * 0.5
+        A = np.zeros((4, 4))
+        A[:3, :3] = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        A[:3, 3] = a[3:]
+        T0[i] = expm(A)
+    return {"xi_omega_v": torch.from_numpy(xi), "expm": torch.from_numpy(T), "T0": torch.from_numpy(T0),
+            "T0_expm": torch.from_numpy(T0 @ T)}
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["se3", "reinit", "win32", "fullwin4"]
+    if "se3" in which:
+        mg.save("se3_expm.npz", se3_case())
+    if "reinit" in which:
+        mg.save("ba_window_reinit_f64.npz", reinit_case())
+    if "win32" in which:
+        mg.save("ba_window32_f64.npz", win32_case())
+    if "fullwin4" in which:
+        mg.save("fullsize_window4.npz", fullwin_case(4))
+    if "fullwin1" in which:
+        mg.save("fullsize_window1.npz", fullwin_case(1, iters=1))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.conftest import load_golden, rel_err, report
+from tests.conftest import load_golden, rel_err, report, scaled_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -150,6 +150,7 @@ def test_batch_photo_cost_vs_golden(name, tol):
     assert abs(sig[0].item() - G["sigma_r"].item()) <= (1e-12 if tol < 1e-6 else 2e-6)
     assert int(sig[1].item()) == int(G["kfpair_valid"].sum())
     assert rel_err(H, G["H_photo"]) < tol and rel_err(g, G["g_photo"]) < tol
+    assert scaled_err(H, G["H_photo"]) < tol * 10                      # every block relative to its own scale
     assert abs(err.item() - G["photo_err"].item()) / G["photo_err"].item() < tol
 
 
@@ -278,7 +279,7 @@ def test_mixed_precision_f32_pixels_f64_system():
     G64 = load_golden("ba_window_f64.npz")
     H, g, err, _ = _ba_call(G32, dt_h=torch.float64)
     report("ba_mixed", H_rel=rel_err(H, G64["H_photo"]), g_rel=rel_err(g, G64["g_photo"]))
-    assert rel_err(H, G64["H_photo"]) < 3e-4 and rel_err(g, G64["g_photo"]) < 3e-4
+    assert scaled_err(H, G64["H_photo"]) < 3e-4 and rel_err(g, G64["g_photo"]) < 3e-4
 
 
 # ------------------------------------------------------------------------------------------------
@@ -359,14 +360,14 @@ def test_window_iterate_vs_golden(pix, fused):
     wb = WindowBA(_window_state(G), cfg=cfg, pix_dtype=pix, window_full=True, fused=fused)
     wb.median_depths.copy_(dev(G["median_depths_in"]))
     H, g = wb.linearize()
-    Hrel, grel = rel_err(H, G["H_full"]), rel_err(g, G["g_full"])
+    Hrel, grel = scaled_err(H, G["H_full"]), rel_err(g, G["g_full"])    # Jacobi-scaled: every block relative to its own magnitude
     wb2 = WindowBA(_window_state(G), cfg=cfg, pix_dtype=pix, window_full=True, fused=fused)
     wb2.median_depths.copy_(dev(G["median_depths_in"]))
     delta = wb2.iterate()
     perr = (wb2.kf_poses.cpu() - G["kf_poses_new"]).abs().max().item()
     report("window_iterate", pix=str(pix), fused=fused, H_rel=Hrel, g_rel=grel, delta_rel=rel_err(delta, G["delta"]), pose_err=perr,
            P_err=(wb2.P_m.cpu() - G["P_new"]).abs().max(), info=int(lin_info()))
-    tol = 1e-8 if pix == torch.float64 else 2e-3
+    tol = 1e-8 if pix == torch.float64 else 3e-4
     assert Hrel < tol and grel < tol
     assert perr < (1e-9 if pix == torch.float64 else 1e-4)           # poses within 1e-4 of the reference
     assert (wb2.P_m.cpu() - G["P_new"]).abs().max() < (1e-8 if pix == torch.float64 else 5e-3)
@@ -894,9 +895,9 @@ def test_window_iterate_with_one_way_frames_vs_golden(name, full):
     perr = (wb.kf_poses.cpu() - G["kf_poses_new"]).abs().max().item()
     rerr = (wb.recent_poses.cpu() - G["recent_poses_new"]).abs().max().item()
     aerr = (wb.recent_aff_params.cpu().reshape(-1) - G["recent_aff_new"].reshape(-1)).abs().max().item()
-    report("window_iterate_recent", full=full, H_rel=rel_err(wb.H, G["H_full"]), delta_rel=rel_err(delta, G["delta"]), kf_pose_err=perr,
+    report("window_iterate_recent", full=full, H_scaled=scaled_err(wb.H, G["H_full"]), delta_rel=rel_err(delta, G["delta"]), kf_pose_err=perr,
            recent_pose_err=rerr, recent_aff_err=aerr)
-    assert rel_err(wb.H, G["H_full"]) < 1e-8 and rel_err(wb.g, G["g_full"]) < 1e-8
+    assert scaled_err(wb.H, G["H_full"]) < 1e-8 and rel_err(wb.g, G["g_full"]) < 1e-8
     assert perr < 1e-9 and rerr < 1e-9 and aerr < 1e-9
     assert (wb.P_m.cpu() - G["P_new"]).abs().max().item() < 1e-8
 
@@ -971,9 +972,10 @@ def test_mapping_state_machine_vs_golden(pix):
         i += 2
     report("mapping", pix=pix, snapshots=len(tags), landmarks=int(mp.P_m.shape[0]), **{k + "_abs_err": v for k, v in worst.items()})
     if loose:
-        assert worst["pose"] < 1e-4 and worst["aff"] < 1e-3 and worst["P"] < 1e-2 and worst["logz"] < 1e-2 and worst["med"] < 2e-2
+        assert worst["pose"] < 1e-4 and worst["aff"] < 1e-3 and worst["P"] < 1e-2 and worst["logz"] < 1e-2 and worst["med"] < 5e-3
     else:
-        assert worst["pose"] < 1e-5 and worst["aff"] < 1e-4 and worst["P"] < 1e-3 and worst["logz"] < 1e-3 and worst["med"] < 2e-2
+        # median_depths is the reference's store_vars value (full depth image) at every snapshot
+        assert worst["pose"] < 1e-5 and worst["aff"] < 1e-4 and worst["P"] < 1e-3 and worst["logz"] < 1e-3 and worst["med"] < 5e-4
 
 
 def test_two_frame_init_state_machine_vs_golden():

@@ -1,0 +1,224 @@
+"""Round-2 parity pins of the HIP path (through the C ABI) against values the REFERENCE's own Mapping.iterate produced
+(tests/golden/make_golden_r2.py): the metric configuration at full size (8 keyframes, 640x480, m = 64; nonmax window 4 =
+the reference default and window 1 = the bench workload), landmark re-initialisation, the 32-keyframe window (config 4),
+SE(3) exp against scipy's expm, Cholesky at D ~ 2.4 k.  Matrix comparisons use the scale-aware `scaled_err`
+(Jacobi-scaled by the reference diagonal), never a max-norm of the full system (dominated by the 1e12 pose anchor).
+Run with `-m gpu` on an MI355X."""
+import copy
+
+import pytest
+import torch
+
+from tests.conftest import load_golden, rel_err, report, scaled_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+def _hip_predictor(pix_dtype):
+    from como_amd.depth_cov.core.covariance import prep_predictor
+
+    def predictor(cov, cm):
+        Kinv, L, Kt = prep_predictor(cov.double(), cm.double(), 1.0)          # conditioning in float64 (Mapping dtype)
+        return Kinv, L, Kt.to(pix_dtype)
+    return predictor
+
+
+def _window_from_seed(G, pix_dtype, window, fused=True):
+    from como_amd import synth
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    st = synth.make_window(B=int(G["B"]), H=int(G["H"]), W=int(G["W"]), m=int(G["m"]), dtype=torch.float64, device=DEV,
+                           seed=int(G["seed"]), predictor=_hip_predictor(pix_dtype),
+                           aff_noise=float(G["aff_noise"]) if "aff_noise" in G else 0.0)
+    assert torch.equal(st["P_m"].cpu(), G["P_m"]) and torch.equal(st["coords_m"].cpu(), G["coords_m"])   # same seeds, same inputs
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = window
+    return WindowBA(st, cfg=cfg, pix_dtype=pix_dtype, window_full=True, fused=fused), st
+
+
+def _pair_counts(wb):
+    import como_amd.odom.backend.photo as photo
+    return photo.last_aux["valid"].view(wb.table.b, -1).sum(dim=1).cpu()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("window", [4, 1])
+@pytest.mark.parametrize("pix", [torch.float32, torch.float64])
+def test_fullsize_metric_window_vs_reference(pix, window):
+    """THE metric configuration against the reference: first the photometric system alone (the block kernels: f32 =
+    ba_blocks_pair2, f64 = the f64 block kernel), then whole iterations.
+    Bars: per-pair valid counts exact (f64) / within 3 pixels of 268,800+ (f32: P_w is computed in float32); sigma_r 1e-9
+    relative (f64) / 2e-7 absolute (f32: sigma_r is 1.4826 x ONE residual of float32 image values ~0.5, ulp 6e-8); H_photo / H_full scale-aware 1e-9 (f64) / 2e-4 (f32); poses within 1e-8 (f64) / 1e-4 (f32) of the reference
+    after every one of its iterations."""
+    import como_amd.odom.backend.photo as photo
+    G = load_golden(f"fullsize_window{window}.npz")
+    f64 = pix == torch.float64
+    g0 = lambda k: G[f"it0_{k}"]
+    # -- photometric system only
+    wb, st = _window_from_seed(G, pix, window)
+    assert wb.dim == 760 and wb.table.b == 14
+    wb.with_priors = False
+    H, g = wb.linearize()
+    torch.cuda.synchronize()
+    counts = _pair_counts(wb)
+    dcount = (counts - g0("pair_nvalid")).abs().max().item()
+    sig, nv = float(wb.sigma[0]), int(wb.sigma[1])
+    sig_rel = abs(sig - float(g0("sigma_r"))) / float(g0("sigma_r"))
+    eH = scaled_err(H, g0("H_photo")) if "it0_H_photo" in G else None
+    eHd = rel_err(torch.diagonal(H), g0("H_photo_diag"))
+    ePB = scaled_err(H[:64, :64], g0("H_photo_pose_block"))
+    eg = rel_err(g, g0("g_photo"))
+    eerr = abs(float(wb.err) - float(g0("photo_err"))) / float(g0("photo_err"))
+    # Jacobi-scaled probe products S v (S = D^-1/2 H D^-1/2): every entry of H enters, each relative to its own scale
+    d = torch.sqrt(g0("H_photo_diag")).to(DEV)
+    ok = d > 0
+    dinv = torch.where(ok, 1.0 / d.clamp_min(1e-300), torch.zeros_like(d))
+    from tests.golden_probes import probes
+    V = probes(760).to(DEV)
+    Sv = (dinv[:, None] * H * dinv[None, :]) @ V
+    eprobe = ((Sv.cpu() - g0("H_photo_scaled_probe")).abs().max() / g0("H_photo_scaled_probe").abs().max()).item()
+    pi, ii = G["sample_pair"], G["sample_pix"]
+    valid = photo.last_aux["valid"].view(wb.table.b, -1).cpu().bool()
+    r = photo.last_aux["r"].view(wb.table.b, -1).cpu().double()
+    samp_mis = int((valid[pi, ii] != G["sample_valid"]).sum())
+    both = valid[pi, ii] & G["sample_valid"]
+    samp_r = (r[pi, ii] - G["sample_r"])[both].abs().max().item()
+    report("fullsize_vs_reference_photo", pix=str(pix), window=window, count_diff=dcount, nvalid=nv, nvalid_ref=int(g0("pair_nvalid").sum()),
+           sigma_rel=sig_rel, H_photo_scaled=eH, H_diag_rel=eHd, pose_block_scaled=ePB, g_rel=eg, err_rel=eerr, probe_rel=eprobe,
+           sample_mask_mismatch=samp_mis, sample_r_err=samp_r)
+    assert dcount <= (0 if f64 else 3) and abs(nv - int(g0("pair_nvalid").sum())) <= (0 if f64 else 6)
+    assert samp_mis <= (0 if f64 else 1) and samp_r < (1e-9 if f64 else 2e-6)
+    assert sig_rel < 1e-9 if f64 else abs(sig - float(g0("sigma_r"))) < 2e-7
+    tolH = 1e-9 if f64 else 2e-4
+    if eH is not None:
+        assert eH < tolH
+    assert eHd < tolH and ePB < tolH and eprobe < tolH and eg < tolH and eerr < (1e-9 if f64 else 1e-5)
+    # -- whole iterations (fresh state)
+    wb, st = _window_from_seed(G, pix, window)
+    iters = sum(1 for k in G if k.endswith("_delta"))
+    worst = {"pose": 0.0, "P": 0.0, "aff": 0.0, "med": 0.0, "H_full": 0.0, "delta": 0.0}
+    for it in range(iters):
+        gi = lambda k: G[f"it{it}_{k}"]
+        wb.iterate()
+        torch.cuda.synchronize()
+        if it == 0 and f"it{it}_H_full" in G:
+            worst["H_full"] = scaled_err(wb.H, gi("H_full"))
+        worst["delta"] = max(worst["delta"], rel_err(wb.delta, gi("delta")))
+        worst["pose"] = max(worst["pose"], (wb.kf_poses.cpu() - gi("kf_poses_new")).abs().max().item())
+        worst["aff"] = max(worst["aff"], (wb.kf_aff_params.cpu() - gi("kf_aff_new")).abs().max().item())
+        worst["P"] = max(worst["P"], (wb.P_m.cpu() - gi("P_new")).abs().max().item())
+        worst["med"] = max(worst["med"], ((wb.median_depths.cpu() - gi("median_depths_full")).abs() / gi("median_depths_full")).max().item())
+    import como_amd.odom.backend.linear_system as ls
+    report("fullsize_vs_reference_iterate", pix=str(pix), window=window, iters=iters, info=int(ls.solve_system.last_info), **worst)
+    assert int(ls.solve_system.last_info) == 0
+    assert worst["pose"] < (1e-8 if f64 else 1e-4)                    # solved poses within 1e-4 of the reference (north star)
+    assert worst["aff"] < (1e-8 if f64 else 1e-4) and worst["P"] < (1e-7 if f64 else 2e-3)
+    assert worst["med"] < (1e-9 if f64 else 2e-6)                     # the full-image median (Mapping.store_vars)
+    assert worst["H_full"] < (1e-8 if f64 else 2e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _state_from_fixture(G):
+    st = {k: dev(G[k]) for k in ("intrinsics", "kf_poses", "kf_aff_params", "kf_img_and_grads", "coords_m", "correspondence_mask",
+                                 "P_m", "kf_timestamps", "obs_ref_mask", "pm_first_obs", "L_mm", "K_mm_inv", "Knm_Kmminv", "pose_anchor",
+                                 "P_anchor")}
+    st["median_depth_init"] = dev(G["median_depths_in"])
+    return st
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_landmark_reinit_vs_reference(fused):
+    """Landmarks behind a camera / closer than 0.1 x the keyframe's median depth (sparse_map.py:26-41, Mapping.py:625-648):
+    win_scaffold + win_apply_reinit (fused) and the mirror path, against the reference's scaffold and whole iteration."""
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    G = load_golden("ba_window_reinit_f64.npz")
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = 2
+    wb = WindowBA(_state_from_fixture(G), cfg=cfg, pix_dtype=torch.float64, window_full=True, fused=fused)
+    H, g = wb.linearize()
+    torch.cuda.synchronize()
+    moved_ref = (G["sc_P_m_after"] != G["P_m"]).any(dim=1)
+    P_after = wb.P_m.cpu()
+    moved = (P_after != G["P_m"]).any(dim=1)
+    if fused:
+        pm, logzm = wb.w["pm"].cpu(), wb.w["logzm"].cpu()[..., None]
+    else:
+        pm, logzm = wb.pm.cpu(), wb.logzm.cpu()
+    report("reinit", fused=fused, n_moved=int(moved.sum()), n_moved_ref=int(moved_ref.sum()), P_err=(P_after - G["sc_P_m_after"]).abs().max(),
+           pm_err=(pm - G["sc_pm"]).abs().max(), logz_err=(logzm - G["sc_logzm"]).abs().max(), H_scaled=scaled_err(H, G["it0_H_full"]),
+           g_rel=rel_err(g, G["it0_g_full"]))
+    assert int(moved_ref.sum()) >= 2 and torch.equal(moved, moved_ref)
+    assert (P_after - G["sc_P_m_after"]).abs().max() < 1e-12
+    assert (pm - G["sc_pm"]).abs().max() < 1e-9 and (logzm - G["sc_logzm"]).abs().max() < 1e-12
+    assert scaled_err(H, G["it0_H_full"]) < 1e-8 and rel_err(g, G["it0_g_full"]) < 1e-8
+    wb2 = WindowBA(_state_from_fixture(G), cfg=cfg, pix_dtype=torch.float64, window_full=True, fused=fused)
+    wb2.iterate()
+    assert (wb2.kf_poses.cpu() - G["it0_kf_poses_new"]).abs().max() < 1e-9
+    assert (wb2.P_m.cpu() - G["it0_P_new"]).abs().max() < 1e-8
+    assert ((wb2.median_depths.cpu() - G["it0_median_depths_full"]).abs() / G["it0_median_depths_full"]).max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pix", [torch.float64, torch.float32])
+def test_window32_vs_reference(pix):
+    """Config 4 at reduced resolution: 32 keyframes, 62 pairs, two reference iterations (fused chain, one and two-pair groups)."""
+    G = load_golden("ba_window32_f64.npz")
+    f64 = pix == torch.float64
+    wb, st = _window_from_seed(G, pix, int(G["window"]))
+    assert wb.table.b == 62 and wb.dim == G["it0_g_full"].shape[0]
+    worst = {"pose": 0.0, "P": 0.0, "diag": 0.0, "count": 0}
+    for it in range(2):
+        gi = lambda k: G[f"it{it}_{k}"]
+        wb.iterate()
+        torch.cuda.synchronize()
+        worst["count"] = max(worst["count"], int((_pair_counts(wb) - gi("pair_nvalid")).abs().max()))
+        worst["diag"] = max(worst["diag"], rel_err(torch.diagonal(wb.H), gi("H_full_diag")))
+        worst["pose"] = max(worst["pose"], (wb.kf_poses.cpu() - gi("kf_poses_new")).abs().max().item())
+        worst["P"] = max(worst["P"], (wb.P_m.cpu() - gi("P_new")).abs().max().item())
+    report("window32", pix=str(pix), D=wb.dim, **worst)
+    assert worst["count"] <= (0 if f64 else 2)
+    assert worst["pose"] < (1e-8 if f64 else 1e-4) and worst["P"] < (1e-6 if f64 else 5e-3)
+
+
+@pytest.mark.parametrize("D", [2399, 2400, 2440, 3200])
+def test_cholesky_solve_config4_sizes(D):
+    """The dense solve at the 32-keyframe system size (D = 8 B + 3 L ~ 2.4 k, linear_system.py:101-112) and above."""
+    import como_amd.odom.backend.linear_system as ls
+    g0 = torch.Generator().manual_seed(D)
+    A = torch.randn((D, D + 8), generator=g0, dtype=torch.float64)
+    H = A @ A.T + 1e-3 * torch.eye(D, dtype=torch.float64)
+    H[0, 0] += 1e12
+    g = torch.randn(D, generator=g0, dtype=torch.float64)
+    Hd, gd = dev(H), dev(g)
+    ref = torch.cholesky_solve(gd[:, None], torch.linalg.cholesky(Hd)).cpu()
+    d = ls.solve_system(Hd, gd).cpu()
+    resid = ((H @ d - g[:, None]).abs().max() / g.abs().max()).item()
+    report("chol_large", D=D, rel=rel_err(d, ref), resid=resid, info=int(ls.solve_system.last_info))
+    assert int(ls.solve_system.last_info) == 0
+    assert rel_err(d, ref) < 1e-7 and resid < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_se3_exp_kernels_vs_scipy_expm():
+    """The device SE(3) exponential (csrc/common.cuh se3_exp_f64: ONE definition shared by win_update and track_finish)
+    through the C ABI entry como_win_update, against scipy.linalg.expm of the twist matrix."""
+    from como_amd import _lib
+    G = load_golden("se3_expm.npz")
+    xi, T0, want = G["xi_omega_v"], G["T0"], G["T0_expm"]
+    F = xi.shape[0]
+    delta = torch.zeros(8 * F + 3, dtype=torch.float64)
+    delta[:8 * F].view(F, 8)[:, :6] = xi
+    poses, aff = dev(T0.clone()), torch.zeros((F, 2), dtype=torch.float64, device=DEV)
+    frame_inds = torch.arange(8 * F, device=DEV).reshape(F, 8).contiguous()
+    P = torch.zeros((1, 3), dtype=torch.float64, device=DEV)
+    rc = _lib.lib().como_win_update(dev(delta).data_ptr(), poses.data_ptr(), aff.data_ptr(), frame_inds.data_ptr(), F, P.data_ptr(), 1,
+                                    8 * F, _lib.stream_ptr(torch.device(DEV)))
+    assert rc == 0
+    torch.cuda.synchronize()
+    e = (poses.cpu() - want).abs().max().item()
+    report("se3_expm", win_update_err=e)
+    assert e < 1e-12

@@ -23,7 +23,7 @@ def test_prior_factors_match_reference():
         kpi = G["kf_inds"][:, :6]
         lmk = G["landmark_inds"]
         dP, dT = G["dlogzm_dzm"] @ G["dzm_dPwm"], G["dlogzm_dzm"] @ G["dzm_dTwc"]
-        lm = torch.log(G["median_depths"])[:, None, None]
+        lm = torch.log(G["median_depths_full"])[:, None, None]
         e = [gp_ml_cost(G["logzm"], lm, G["L_mm"], dP, dT, lmk, kpi, H, g, 1.0)]
         assert rel(H, G["H_gp"]) < 1e-12 and rel(g, G["g_gp"]) < 1e-12
         e.append(log_depth_prior(G["logzm"], lm, dP, dT, G["obs_ref_mask"], lmk, kpi, H, g, "first_mean", 1.0, 1.0))

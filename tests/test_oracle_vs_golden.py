@@ -82,7 +82,7 @@ def test_priors_solve_update(golden, name):
     lmk = G["landmark_inds"]
     dlogzm_dPw = G["dlogzm_dzm"] @ G["dzm_dPwm"]
     dlogzm_dTwc = G["dlogzm_dzm"] @ G["dzm_dTwc"]
-    log_med = torch.log(G["median_depths"])[:, None, None]
+    log_med = torch.log(G["median_depths_full"])[:, None, None]       # Mapping.store_vars median (full depth image)
     e = [priors.gp_ml_cost(G["logzm"], log_med, G["L_mm"], dlogzm_dPw, dlogzm_dTwc, lmk, kf_pose_inds, H, g, 1.0)]
     assert rel(H, G["H_gp"]) < tol and rel(g, G["g_gp"]) < tol
     e.append(priors.log_depth_prior_first_mean(G["logzm"], log_med, dlogzm_dPw, dlogzm_dTwc, G["obs_ref_mask"], lmk,
