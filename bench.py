@@ -1,6 +1,6 @@
 """bench.py -- GN iterations / second of the 8-keyframe 640x480 photometric window BA on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--window 1|4] [--dtype f32|f64] [--no-cpu]
+    python bench.py --gpus N --steps K --warmup W [--window 1|4] [--dtype f32|f64] [--keyframes B] [--replicas] [--no-cpu]
     (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
 One "step" = one Gauss-Newton iteration of the window BA, exactly the reference's Mapping.iterate sequence
@@ -9,9 +9,18 @@ One "step" = one Gauss-Newton iteration of the window BA, exactly the reference'
 Cholesky solve -> pose / affine / landmark update.  Inputs (images, K~, landmarks) are resident in HBM before the
 timed region.  Synthetic seeded scene (como_amd/synth.py); no datasets or checkpoints exist in this image.
 
-Workloads: --window 1 (default) = every pixel is a reference pixel (n = 307,200 per keyframe, 4.3 M pixel-pairs per
-iteration); --window 4 = the reference's default sub-selection (config/como.yml:37, n = 19,200).  The per-pixel path
-runs in --dtype (f32 default, mixed precision: the normal equations, priors, solve and state are float64 always).
+Headline workload: --window 1 = every pixel is a reference pixel (n = 307,200 per keyframe, 4.3 M pixel-pairs per
+iteration), per-pixel path in --dtype (f32 default: mixed precision, the normal equations / priors / solve / state are
+float64 always).  The same JSON line also carries (N = 1 only):
+  reference_dtype : the same dense window with the per-pixel path in float64 = the reference's mapping dtype
+                    (config/como.yml:28), with its own roofline (784 B per pixel-pair);
+  secondary       : the window at the reference's default sub-selection (nonmax_suppression_window 4, n = 19,200), f32 and f64;
+  tracking        : config 2 -- the 2-frame 640x480 tracking GN iteration (unit A: 53 B per pixel);
+  odometry_loop   : the whole headless sequential loop (frames / s);
+  cpu_baseline    : the oracle (CPU restatement of the reference algorithm) timed on this box's host cores on the
+                    window-4 workload EXACTLY as `secondary` runs it (full iteration incl. priors, >= 5 repetitions).
+--keyframes 32 runs config 4's window (62 pairs, D ~ 2.9 k); --replicas runs config 5's mode: one independent window per
+GPU, no collective ("scaling": "weak", value = sum over ranks).
 """
 import argparse
 import json
@@ -42,62 +51,49 @@ def build_state(args, device, pix_dtype):
                              seed=args.seed, predictor=predictor)
 
 
-def cpu_baseline(args, state_cpu):
-    """The oracle ("port") timed on the host cores: same algorithmic structure as the reference's CPU path
-    (materialised Jacobian rows, batched Gram products, index_add assembly, cholesky_ex + cholesky_solve)."""
-    from oracle import dense_ref as odr, photo_ba as oba
-    st = state_cpu
-    K = st["intrinsics"][0]
-    B = st["kf_poses"].shape[0]
-    H, W = st["kf_img_and_grads"].shape[-2:]
-    m = st["coords_m"].shape[1]
-    Pb, ids = odr.batched_landmarks(st["P_m"], st["correspondence_mask"])
-    med0 = st["median_depth_init"].double()
-    L = st["P_m"].shape[0]
-    D = 8 * B + 3 * L
-    kf_inds = torch.arange(8 * B).reshape(B, 8)
-    lm = (3 * ids.repeat_interleave(3, dim=1) + torch.arange(3).repeat(m)[None]) + 8 * B
-    cn = odr.subselect_pixels(st["kf_img_and_grads"], 4)            # bounded sample: the window-4 sub-selection
-    bi = torch.arange(B)[:, None].expand(-1, cn.shape[1])
-    Kt_rows = st["Knm_Kmminv"][bi, cn[..., 0], cn[..., 1], :].double()
-    vals = st["kf_img_and_grads"][bi, :1, cn[..., 0], cn[..., 1]]
-    ref, tgt = oba.consecutive_pairs(B)
-    rid, tid = torch.tensor(ref), torch.tensor(tgt)
-
-    def one_iter():
-        t0 = time.perf_counter()
-        p, logz, zm, dlogz_dz, dz_dPw, dz_dTwc, dp_dPw, dp_dTwc = odr.project_landmarks(st["kf_poses"], Pb, K, Pb, med0)
-        Pw, dT, dz, med, _ = odr.dense_reference(logz, st["kf_poses"], Kt_rows, cn, K, dlogz_dz @ dz_dTwc, dlogz_dz)
-        Hm = torch.zeros((D, D), dtype=torch.float64)
-        g = torch.zeros(D, dtype=torch.float64)
-        oba.batch_photo_cost(vals[rid], st["kf_aff_params"][rid], Pw[rid], st["kf_poses"][tid], st["kf_aff_params"][tid],
-                             st["kf_img_and_grads"][tid], dT[rid], dz[rid], dz_dPw[rid], kf_inds[rid], kf_inds[tid], lm[rid], K, Hm, g)
-        t1 = time.perf_counter()
-        Hm += 1e3 * torch.eye(D, dtype=torch.float64)               # stand-in for the O(B m^2) priors: keeps H PD for the solve
-        oba.solve_system(Hm, g)
-        t2 = time.perf_counter()
-        return t1 - t0, t2 - t1
-
-    # pick the fastest thread count for these small-tensor ops (256 threads on a 256-core host is ~100x slower than 16)
+def cpu_baseline(args, state_cpu, window=4, reps=5):
+    """The oracle ("port": oracle/window.py OracleWindow.iterate = the reference's Mapping.iterate sequence with
+    materialised Jacobian rows, batched Gram products, index_add assembly, the real prior factors, cholesky_ex +
+    cholesky_solve) timed on the host cores on the window-`window` workload exactly -- no scaling, no stand-ins."""
+    from oracle.window import OracleWindow
+    ncpu = os.cpu_count() or 8
+    # these are many small/medium tensor ops: torch with every core of a 100+ core host is far slower than with 16-32
     best = None
-    for nt in sorted({8, 16, 32, min(64, os.cpu_count() or 8)}):
-        if nt > (os.cpu_count() or 8):
+    for nt in sorted({8, 16, 32, min(64, ncpu)}):
+        if nt > ncpu:
             continue
         torch.set_num_threads(nt)
-        a, b2 = one_iter()
-        if best is None or a + b2 < best[0]:
-            best = (a + b2, nt)
+        ow = OracleWindow(state_cpu, window=window)
+        t0 = time.perf_counter()
+        ow.iterate()
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nt)
     torch.set_num_threads(best[1])
-    one_iter()
-    reps = 3
-    lin, sol = zip(*[one_iter() for _ in range(reps)])
-    lin, sol = sorted(lin)[reps // 2], sorted(sol)[reps // 2]
-    scale = (args.height * args.width) / cn.shape[1] if args.window == 1 else 16.0 / (args.window ** 2)
-    t_iter = lin * scale + sol
-    return {"value": 1.0 / t_iter, "unit": "GN iters/s", "cores": best[1], "kind": "port",
-            "sample": f"oracle (torch-CPU, float64) GN iteration on the window-4 sub-selection of the same window "
-                      f"(n={cn.shape[1]} px/KF, {len(ref)} pairs, D={D}), median of {reps}: linearise {lin * 1e3:.0f} ms, "
-                      f"solve {sol * 1e3:.0f} ms; linearisation time scaled x{scale:g} to this workload's pixel count"}
+    ow = OracleWindow(state_cpu, window=window)
+    ow.iterate()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ow.iterate()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    n = ow.cn.shape[1]
+    out = {"value": 1.0 / med, "unit": "GN iters/s", "cores": best[1], "host_cores": ncpu, "kind": "port",
+           "workload": f"window={window}",
+           "sample": f"oracle/window.py (torch-CPU, float64) full GN iteration incl. priors + solve on the window-{window} workload "
+                     f"exactly (n={n} px/KF, {ow.aux['valid'].shape[0]} pairs, D={ow.D}): median of {reps} after 1 warm-up = "
+                     f"{med * 1e3:.0f} ms (min {ts[0] * 1e3:.0f}, max {ts[-1] * 1e3:.0f}); {best[1]} torch threads (fastest of "
+                     f"8/16/32/64) on a {ncpu}-core host; compare with `secondary` (same workload on the GPU), not with `value`"}
+    if args.cpu_dense:
+        torch.set_num_threads(best[1])
+        owd = OracleWindow(state_cpu, window=1)
+        t0 = time.perf_counter()
+        owd.iterate()
+        out["dense_once_s"] = time.perf_counter() - t0
+        out["dense_value"] = 1.0 / out["dense_once_s"]
+    return out
 
 
 def odometry_loop(device, frames=100):
@@ -134,6 +130,129 @@ def odometry_loop(device, frames=100):
         return {"error": repr(e)[:300]}
 
 
+ALGO_SCALARS_PER_TRACKING_PIXEL = 53.0 / 4.0   # SURVEY.md section 8(d) unit A: 53 B per pixel-iteration in float32
+
+
+def git_sha():
+    try:
+        import subprocess
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:                                       # noqa: BLE001  (the GPU box snapshot has no .git)
+        return None
+
+
+def committed_traffic(kernel_substr, summary="r2_bench_pmc_summary.json"):
+    """HBM bytes per launch of a kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled per the
+    gfx950 note of guides/MI355X_MICROARCH.md, WRITE_SIZE as is).  NOT measured by this run: counters need rocprofv3
+    around the process (scripts/collect_profiles.sh); the value is labelled with its source file."""
+    path = os.path.join(ROOT, "profiles", summary)
+    try:
+        pm = json.load(open(path))
+        key = [k for k in pm if kernel_substr in k][0]
+        val = (2.0 * pm[key]["FETCH_SIZE"]["avg_per_launch"] + pm[key]["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
+        return val, f"committed_profile:profiles/{summary}:{key[:60]}"
+    except Exception:                                       # noqa: BLE001
+        return None, None
+
+
+def run_window(args, device, pix_dtype, window, shard=None, seed=None, state=None):
+    """Build the window, warm up, capture, time exactly args.steps iterations; returns (wb, state, elapsed, graphed)."""
+    import copy
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = window
+    if state is None:
+        a2 = argparse.Namespace(**vars(args))
+        if seed is not None:
+            a2.seed = seed
+        state = build_state(a2, device, pix_dtype)
+    wb = WindowBA(state, cfg=cfg, pix_dtype=pix_dtype, window_full=True, shard=shard)
+    for _ in range(args.warmup):
+        wb.iterate()
+    graphed = (not args.eager) and wb.capture()
+    return wb, state, graphed
+
+
+def timed_steps(wb, steps, barrier=None):
+    if barrier is not None:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wb.step()
+    torch.cuda.synchronize()
+    if barrier is not None:
+        barrier()
+    return time.perf_counter() - t0
+
+
+def block_kernel_roofline(wb, dtype_name, reps=5):
+    """Dominant kernel (the pair-block kernel): duration from HIP events on the launch stream (events cannot sit inside a
+    captured graph, so the same kernel on the same data is timed in eager iterations right after the timed region;
+    profiles/ holds the rocprofv3 --kernel-trace --stats summary of the same command for cross-checking)."""
+    wb.events = {}
+    for _ in range(reps):
+        wb.iterate()
+    torch.cuda.synchronize()
+    ev = wb.events.get("blocks", [])
+    wb.events = None
+    blk_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    pb, pe = wb.pix_range if wb.pix_range is not None else (0, wb.n)
+    pixel_pairs = wb.table.b * (pe - pb)
+    bytes_per = ALGO_SCALARS_PER_PIXEL_PAIR * (4 if dtype_name == "f32" else 8)
+    achieved = pixel_pairs * bytes_per / (blk_ms * 1e-3) / 1e9 if blk_ms > 0 else 0.0
+    kname = "ba_blocks_pair2_kernel<2,4>" if dtype_name == "f32" else "ba_blocks_pair2_f64_kernel"
+    traffic, src = committed_traffic("ba_blocks_pair2_kernel" if dtype_name == "f32" else "ba_blocks_pair2_f64")
+    return {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src, "kernel_ms": blk_ms,
+            "algorithmic_bytes_per_launch": pixel_pairs * bytes_per,
+            "algorithmic_bytes_per_pixel_pair": bytes_per}
+
+
+def tracking_leg(device, steps=200):
+    """Config 2: the tracking GN iteration on a synthetic 640x480 pair, level 0 (N = 307,200 reference pixels): the captured
+    iteration graph of como_amd/odom/frontend/photo_tracking.py replayed `steps` times (float32 = the reference's tracking
+    dtype).  Unit A: 53 B per pixel-iteration."""
+    try:
+        import como_amd.odom.frontend.photo_tracking as pt
+        from como_amd.utils import image_processing as ip
+        tp = synth.make_tracking_pair(H=480, W=640, dtype=torch.float32, device=device, seed=3, levels=1)
+        K = tp["intrinsics"]
+        stack = ip.img_and_grads(tp["img_ref"])
+        v, u = torch.meshgrid(torch.arange(480., device=device), torch.arange(640., device=device), indexing="ij")
+        ray = torch.stack(((u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], torch.ones_like(u)), -1).reshape(-1, 3)
+        P = (tp["depth_ref"][0, 0].reshape(-1, 1) * ray)[None].contiguous()
+        vals = tp["img_ref"].reshape(1, -1, 1).contiguous()
+        dI = torch.stack((stack[0, 1].reshape(-1), stack[0, 2].reshape(-1)), -1)[None, :, None, :].contiguous()
+        J = pt.precalc_jacobians(dI, P, vals, K)
+        lg = pt._LevelGraph(vals, P, J, tp["img_cur"], K)
+        graphed = lg.capture()
+        lg.T.copy_(tp["Tji_init"].reshape(1, 4, 4))
+        for _ in range(10):
+            lg.step()
+        torch.cuda.synchronize()
+        lg.T.copy_(tp["Tji_init"].reshape(1, 4, 4))
+        lg.aff.zero_()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            lg.step()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        us = el / steps * 1e6
+        N = P.shape[1]
+        algo = N * 53.0
+        terr = (lg.T - tp["Tji_gt"]).abs().max().item()
+        ach = algo / (us * 1e-6) / 1e9
+        return {"workload": f"config 2: 2-frame 640x480 photometric tracking GN iteration, level 0, N={N} reference pixels, float32",
+                "value": steps / el, "unit": "GN iters/s", "us_per_iter": us, "steps": steps, "hip_graph": bool(graphed),
+                "pixels_per_s": N * steps / el, "max_pose_abs_err_vs_gt_end": terr,
+                "roofline": {"bound": "hbm", "kernel": "track iteration (whole chain)", "achieved": ach, "peak": HBM_PEAK_GBPS,
+                             "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                             "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_per_pixel": 53.0}}
+    except Exception as e:                                  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,8 +265,10 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-dense", action="store_true", help="also time ONE dense (window 1) oracle iteration on the host (~1 min, ~30 GB)")
     ap.add_argument("--eager", action="store_true", help="do not capture the iteration into a hipGraph")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the window-4 (reference default sub-selection) line")
+    ap.add_argument("--no-secondary", action="store_true", help="only the headline leg (no f64 / window-4 / tracking / odometry legs)")
+    ap.add_argument("--replicas", action="store_true", help="config 5: one independent window per GPU, no collective (weak scaling)")
     args = ap.parse_args()
 
     shard, device = cdist.init_from_env()
@@ -156,108 +277,89 @@ def main():
     if shard.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={shard.world}")
     pix_dtype = torch.float32 if args.dtype == "f32" else torch.float64
+    sharded = shard.world > 1 and not args.replicas
 
-    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
-    import copy
-    cfg = copy.deepcopy(DEFAULT_CFG)
-    cfg["photo_construction"]["nonmax_suppression_window"] = args.window
-    state = build_state(args, device, pix_dtype)
-    wb = WindowBA(state, cfg=cfg, pix_dtype=pix_dtype, window_full=True, shard=(shard if shard.world > 1 else None))
-    pose0 = wb.kf_poses.clone()
-
-    for _ in range(args.warmup):
-        wb.iterate()
-    graphed = (not args.eager) and wb.capture()
-    if not graphed and not args.eager and shard.rank == 0 and shard.world == 1:
+    # ---- headline leg ----
+    wb, state, graphed = run_window(args, device, pix_dtype, args.window, shard=(shard if sharded else None),
+                                    seed=(args.seed + shard.rank if args.replicas else None))
+    if not graphed and not args.eager and shard.rank == 0 and not sharded:
         print("hipGraph capture failed:", getattr(wb, "capture_error", "?"), file=sys.stderr)
-    shard.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wb.step()
-    torch.cuda.synchronize()
-    shard.barrier()
-    elapsed = shard.max_scalar(time.perf_counter() - t0, device)
-
-    # roofline probe: the dominant kernel's duration from HIP events on the launch stream (events cannot sit inside a
-    # captured graph, so the same kernel on the same data is timed in eager iterations right after the timed region;
-    # profiles/ holds the rocprofv3 --kernel-trace --stats summary of this command for cross-checking)
-    wb.events = {}
-    for _ in range(5):
-        wb.iterate()
-    torch.cuda.synchronize()
+    pose0_err = None
+    elapsed = shard.max_scalar(timed_steps(wb, args.steps, barrier=shard.barrier), device)
     ms_step = elapsed / args.steps * 1e3
-    ev = wb.events.get("blocks", [])
-    blk_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
-    npairs = wb.table.b
-    pb, pe = wb.pix_range if wb.pix_range is not None else (0, wb.n)
-    pixel_pairs_rank = npairs * (pe - pb)
-    bytes_per = ALGO_SCALARS_PER_PIXEL_PAIR * (4 if args.dtype == "f32" else 8)
-    achieved = pixel_pairs_rank * bytes_per / (blk_ms * 1e-3) / 1e9 if blk_ms > 0 else 0.0
-    info = int(__import__("como_amd.odom.backend.linear_system", fromlist=["x"]).solve_system.last_info)
+    total_iters = args.steps * (shard.world if args.replicas else 1)
+    roof = block_kernel_roofline(wb, args.dtype)
+    import como_amd.odom.backend.linear_system as lin_sys
+    info = int(lin_sys.solve_system.last_info)
     pose_err = (wb.kf_poses - state["poses_gt"]).abs().max().item()
-    pose_err0 = (pose0 - state["poses_gt"]).abs().max().item()
+    pose_err0 = (state["kf_poses"] - state["poses_gt"]).abs().max().item()
+    npairs = wb.table.b
 
-    # HBM traffic of the dominant kernel: rocprofv3 PMC passes of THIS command, committed under profiles/
-    # (scripts/collect_profiles.sh); FETCH_SIZE doubled per the gfx950 note of guides/MI355X_MICROARCH.md, WRITE_SIZE as is.
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r1_bench_pmc_summary.json")
-    if os.path.exists(pmc_path) and args.gpus == 1 and args.window == 1 and args.dtype == "f32":
-        try:
-            pm = json.load(open(pmc_path))
-            key = [k for k in pm if "ba_blocks" in k][0]
-            traffic = (2.0 * pm[key]["FETCH_SIZE"]["avg_per_launch"] + pm[key]["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
-        except Exception:                                   # noqa: BLE001  (a malformed summary just leaves traffic null)
-            traffic = None
-
-    secondary = None
-    if args.window == 1 and not args.no_secondary and args.gpus == 1:
+    legs = {}
+    single = args.gpus == 1 and not args.no_secondary and args.window == 1 and args.keyframes == 8
+    if single:
+        # the reference's mapping dtype: float64 per-pixel path on the same dense window
+        other = "f64" if args.dtype == "f32" else "f32"
+        odt = torch.float64 if other == "f64" else torch.float32
+        del wb
+        torch.cuda.empty_cache()
+        wbo, sto, go = run_window(args, device, odt, args.window)
+        eo = timed_steps(wbo, args.steps)
+        ro = block_kernel_roofline(wbo, other)
+        legs["reference_dtype" if other == "f64" else "mixed_precision"] = {
+            "workload": f"same window, per-pixel path in {other}" + (" (config/como.yml:28 mapping dtype double)" if other == "f64" else ""),
+            "dtype": other, "value": args.steps / eo, "unit": "GN iters/s", "ms_per_step": eo / args.steps * 1e3, "steps": args.steps,
+            "hip_graph": bool(go), "roofline": ro,
+            "max_pose_abs_err_vs_gt_end": (wbo.kf_poses - sto["poses_gt"]).abs().max().item()}
+        del wbo, sto
+        torch.cuda.empty_cache()
         # the reference's default sub-selection (config/como.yml: nonmax_suppression_window 4, n = 19,200 px / keyframe)
-        cfg4 = copy.deepcopy(DEFAULT_CFG)
-        cfg4["photo_construction"]["nonmax_suppression_window"] = 4
-        wb4 = WindowBA(build_state(args, device, pix_dtype), cfg=cfg4, pix_dtype=pix_dtype, window_full=True)
-        for _ in range(args.warmup):
-            wb4.iterate()
-        g4 = (not args.eager) and wb4.capture()
-        torch.cuda.synchronize()
-        t4 = time.perf_counter()
-        for _ in range(args.steps):
-            wb4.step()
-        torch.cuda.synchronize()
-        e4 = time.perf_counter() - t4
-        secondary = {"workload": f"same window, nonmax_suppression_window=4 (n={wb4.n} reference px/KF, the reference's default)",
-                     "value": args.steps / e4, "unit": "GN iters/s", "ms_per_step": e4 / args.steps * 1e3, "hip_graph": bool(g4)}
-
-    odometry = None
-    if args.window == 1 and not args.no_secondary and args.gpus == 1:
-        odometry = odometry_loop(device)
+        sec = {}
+        for nm, dt_ in (("f32", torch.float32), ("f64", torch.float64)):
+            wb4, st4, g4 = run_window(args, device, dt_, 4)
+            e4 = timed_steps(wb4, args.steps)
+            sec[nm] = {"value": args.steps / e4, "ms_per_step": e4 / args.steps * 1e3, "hip_graph": bool(g4)}
+            n4 = wb4.n
+            del wb4, st4
+        legs["secondary"] = {"workload": f"same window, nonmax_suppression_window=4 (n={n4} reference px/KF, the reference's default)",
+                             "unit": "GN iters/s", "value": sec["f32"]["value"], "ms_per_step": sec["f32"]["ms_per_step"],
+                             "hip_graph": sec["f32"]["hip_graph"], "dtype": "f32", "f64": sec["f64"]}
+        torch.cuda.empty_cache()
+        legs["tracking"] = tracking_leg(device)
+        legs["odometry_loop"] = odometry_loop(device)
 
     if shard.rank == 0:
+        mode = "replicas" if args.replicas else ("dp%d (reference-pixel shards of every pair)" % args.gpus)
         out = {
-            "metric": "GN iters/sec, 8-keyframe 640x480 photometric BA",
-            "value": args.steps / elapsed, "unit": "GN iters/s", "n_gpus": args.gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong",
+            "metric": "GN iters/sec, 8-keyframe 640x480 photometric BA" if args.keyframes == 8 else
+                      f"GN iters/sec, {args.keyframes}-keyframe {args.width}x{args.height} photometric BA",
+            "value": total_iters / elapsed, "unit": "GN iters/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": "weak" if args.replicas else "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.keyframes}-keyframe {args.width}x{args.height} window BA, {npairs} keyframe pairs, "
-                                   f"n={wb.n} reference px/KF (window={args.window}), m=64, D={wb.dim}; one step = full GN "
-                                   f"iteration (scaffold, dense ref, photometric system, priors, Cholesky solve, update)",
-                       "pixel_pairs_per_iter": npairs * wb.n, "system_dim": wb.dim, "pix_dtype": args.dtype,
-                       "system_dtype": "f64", "hip_graph": bool(graphed), "parallelism": f"dp{args.gpus} (reference-pixel shards of every pair)"},
-            "roofline": {"bound": "hbm", "kernel": "ba_blocks_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel_ms": blk_ms,
-                         "algorithmic_bytes_per_launch": pixel_pairs_rank * bytes_per},
+                                   f"n={wb_n(state, args)} reference px/KF (window={args.window}), m=64, D={roof_dim(state, args)}; one step = "
+                                   f"full GN iteration (scaffold, dense ref, photometric system, priors, Cholesky solve, update)",
+                       "pixel_pairs_per_iter": npairs * wb_n(state, args), "system_dim": roof_dim(state, args), "pix_dtype": args.dtype,
+                       "system_dtype": "f64", "hip_graph": bool(graphed), "parallelism": mode},
+            "roofline": roof,
             "solution": {"cholesky_info": info, "max_pose_abs_err_vs_gt_start": pose_err0, "max_pose_abs_err_vs_gt_end": pose_err},
+            "git": git_sha(),
         }
-        if secondary is not None:
-            out["secondary"] = secondary
-        if odometry is not None:
-            out["odometry_loop"] = odometry
-        if not args.no_cpu and args.gpus == 1:
+        out.update(legs)
+        if not args.no_cpu and args.gpus == 1 and args.keyframes == 8:
             st_cpu = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in state.items()}
-            st_cpu["Knm_Kmminv"] = st_cpu["Knm_Kmminv"]
             out["cpu_baseline"] = cpu_baseline(args, st_cpu)
         print(json.dumps(out))
     shard.barrier()
+
+
+def wb_n(state, args):
+    return (args.height // args.window) * (args.width // args.window)
+
+
+def roof_dim(state, args):
+    return 8 * args.keyframes + 3 * int(state["P_m"].shape[0])
 
 
 if __name__ == "__main__":

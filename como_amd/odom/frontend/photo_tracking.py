@@ -197,7 +197,12 @@ def photo_level_tracking(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, intrinsic
         for j in range(LOOKAHEAD):
             mse, gnorm, dnorm = rows[j][98], rows[j][99], rows[j][103]
             it += 1
-            rel = abs((prev - mse) / prev) if prev != float("inf") else float("nan")
+            if prev == float("inf"):
+                rel = float("nan")
+            elif prev == 0.0:                                  # torch: 0/0 -> nan, x/0 -> inf (a Python float division raises)
+                rel = float("nan") if mse == 0.0 else float("inf")
+            else:
+                rel = abs((prev - mse) / prev)
             if (it >= term_criteria["max_iter"] or dnorm < term_criteria["delta_norm"] or rel < term_criteria["rel_tol"]
                     or gnorm < term_criteria["grad_norm"]):
                 if j + 1 < LOOKAHEAD:                          # roll the state back to iteration j

@@ -64,8 +64,9 @@ def _regenerated_window(G, predictor):
     from como_amd import synth
     st = synth.make_window(B=int(G["B"]), H=int(G["H"]), W=int(G["W"]), m=int(G["m"]), dtype=torch.float64, seed=int(G["seed"]),
                            predictor=predictor, aff_noise=float(G["aff_noise"]) if "aff_noise" in G else 0.0)
-    assert torch.equal(st["kf_poses"], G["kf_poses"] if "kf_poses" in G else G["it0_kf_poses_in"])     # same seeds -> same inputs
-    assert torch.equal(st["P_m"], G["P_m"]) and torch.equal(st["coords_m"], G["coords_m"])
+    # same seeds -> same inputs (discrete choices identical; values to the last bits: CPU sin / exp / BLAS depend on the host ISA)
+    assert (st["kf_poses"] - (G["kf_poses"] if "kf_poses" in G else G["it0_kf_poses_in"])).abs().max() < 1e-12
+    assert torch.equal(st["coords_m"], G["coords_m"]) and (st["P_m"] - G["P_m"]).abs().max() < 1e-12
     return st
 
 
