@@ -36,8 +36,8 @@ def _window_from_seed(G, pix_dtype, window, fused=True):
                            aff_noise=float(G["aff_noise"]) if "aff_noise" in G else 0.0)
     # same seeds -> same inputs: discrete choices identical; floating-point values to the last bits only (the synthetic scene
     # goes through CPU sin / exp / BLAS, whose last bit depends on the host CPU's vector ISA)
-    assert torch.equal(st["coords_m"].cpu(), G["coords_m"]) and st["P_m"].shape == G["P_m"].shape
-    assert (st["P_m"].cpu() - G["P_m"]).abs().max() < 1e-12
+    assert st["P_m"].shape == G["P_m"].shape and torch.equal(st["correspondence_mask"].cpu().sum(1), torch.full((int(G["B"]),), int(G["m"])))
+    assert (st["coords_m"].cpu() - G["coords_m"]).abs().max() < 1e-9 and (st["P_m"].cpu() - G["P_m"]).abs().max() < 1e-12
     cfg = copy.deepcopy(DEFAULT_CFG)
     cfg["photo_construction"]["nonmax_suppression_window"] = window
     return WindowBA(st, cfg=cfg, pix_dtype=pix_dtype, window_full=True, fused=fused), st

@@ -66,7 +66,7 @@ def _regenerated_window(G, predictor):
                            predictor=predictor, aff_noise=float(G["aff_noise"]) if "aff_noise" in G else 0.0)
     # same seeds -> same inputs (discrete choices identical; values to the last bits: CPU sin / exp / BLAS depend on the host ISA)
     assert (st["kf_poses"] - (G["kf_poses"] if "kf_poses" in G else G["it0_kf_poses_in"])).abs().max() < 1e-12
-    assert torch.equal(st["coords_m"], G["coords_m"]) and (st["P_m"] - G["P_m"]).abs().max() < 1e-12
+    assert (st["coords_m"] - G["coords_m"]).abs().max() < 1e-9 and (st["P_m"] - G["P_m"]).abs().max() < 1e-12
     return st
 
 
