@@ -24,6 +24,10 @@
 #include <type_traits>
 #include <utility>
 
+#ifndef COMO_F64_PF
+#define COMO_F64_PF 4      // depth of the K~ register ring of the float64 two-pair kernel
+#endif
+
 namespace como {
 
 // compile-time loop: f(std::integral_constant<int, I>{}) for I = 0..N-1 (guarantees static register indexing)
@@ -909,6 +913,248 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
   });
 }
 
+// ---------------------------------------- pass 2, float64: two pairs, role-specialised wave pair -------------------------
+// The reference's mapping dtype is double (config/como.yml:28).  In double the 20 accumulator tiles of the two-pair kernel
+// are 160 registers and its pipeline state another ~130: more than one wave can hold without spilling.  Here a workgroup
+// is TWO waves that walk the same 64-pixel tiles of one reference keyframe and split the work by ROLE:
+//   wave 0: warp / taps / Jacobian row of pair 0 (stages S1, S2)  +  the 10 depth x depth tiles (weight sqrt(s0^2 + s1^2))
+//   wave 1: warp / taps / Jacobian row of pair 1                  +  the 2 pose x pose and 8 pose x depth tiles
+// = 10 v_mfma_f64_16x16x4_f64 per 4-pixel step and 80 accumulator registers per wave.  The staged rows go through LDS in
+// two buffers (one workgroup barrier per tile); P_w / dPwn_dTwc / uvec and the K~ quads are loaded by both waves (the
+// second read of a line is an L1 / L2 hit -- HBM sees each byte once, 784 B per pixel-pair is shared as in float32).
+// Every accumulator element is owned by exactly one wave, so there is no cross-wave reduction: each wave writes its part
+// of the two per-pair records.
+template <int PF>
+__global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
+    const double* __restrict__ Pwn, const double* __restrict__ vals, const double* __restrict__ dPwn_dTwc,
+    const double* __restrict__ Kt, const double* __restrict__ uvec, const int* __restrict__ pixidx,
+    const double* __restrict__ invz, long kt_slot_stride, BAPairs pr, const double* __restrict__ pair_T,
+    const double* __restrict__ pair_aff, const double* __restrict__ img_base, const double* __restrict__ Kmat, int H, int W,
+    int n, int m, int pix_begin, int pix_end, int chunk_len, const uint32_t* __restrict__ hists,
+    double* __restrict__ partials, double* __restrict__ sigma_out, const int* __restrict__ grp_pairs) {
+  using T = double;
+  using KeyT = typename KeyOf<T>::type;
+  using Cfg = BACfg;
+  using acc_t = typename Acc4<T>::type;
+  __shared__ SelScratch sc;
+  constexpr int STG1 = 16 * JP_STRIDE + 64 * 2;       // one pair's staged tile: 16 pose/affine rows + r~ + depth scale
+  __shared__ T lds[2 * 2 * STG1];                      // [buffer][pair]: 37.9 KB
+
+  // robust scale from the finished histograms; sel_resolve is written for 256-thread blocks: feed it 128 threads x 2 rounds
+  KeyT prefix; uint32_t k_rem, nv;
+  sel_resolve_n<KeyT, 128>(hists, SelCfg<KeyT>::NPASS, &sc, prefix, k_rem, nv);
+  const T sigma = T(1.4826) * key_value(prefix);
+  const T info_sqrt = T(1) / sigma;
+  if (sigma_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sigma_out[0] = sigma; sigma_out[1] = (T)nv; }
+
+  const int pg0 = grp_pairs[2 * blockIdx.y], pg1 = grp_pairs[2 * blockIdx.y + 1];
+  const bool has1 = pg1 >= 0;
+  const int lane = threadIdx.x & 63;
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // wave-uniform
+  const int q = lane >> 4, c = lane & 15;
+  const int pgm = (role == 0 || !has1) ? pg0 : pg1;                       // the pair whose rows this wave produces
+  const bool live = role == 0 || has1;
+  const int slot = pr.ref_slot[pg0];
+  T Mr[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Mr[k] = pair_T[12 * (long)pgm + k];
+  const T scale = pair_aff[2 * pgm], bias = pair_aff[2 * pgm + 1];
+  const T* img = img_base + pr.tgt_img[pgm];
+  const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
+  const long HW = (long)H * W;
+  T invz4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
+  const T* KtS = Kt + (long)slot * kt_slot_stride + ((4 * c < m) ? 4 * c : 0);
+
+  acc_t acc[10];      // role 0: the 10 depth x depth tiles; role 1: {TT_0, TT_1, Tz_0[4], Tz_1[4]}
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = acc_t{T(0), T(0), T(0), T(0)};
+  T gv[4] = {T(0), T(0), T(0), T(0)};    // role 0: depth gradient of this lane's quad; role 1: gv[0], gv[1] = pose gradients
+  T err = T(0);
+
+  const int begin = pix_begin + blockIdx.x * chunk_len;
+  const int end = min(pix_end, begin + chunk_len);
+  V4<T> kq[PF];
+  T pw0, pw1, pw2;
+  T Dv[18], Uv[3], valv, tv[12];
+  T wX = 0, wY = 0, wZ = 0, w00 = 0, w01 = 0, w10 = 0, w11 = 0;
+  bool wok = false;
+  int row_cur = 0, row_nxt = 0;
+
+  auto s0_load = [&](int tile) {
+    const int ic = min(tile + lane, end - 1);
+    pw0 = Pwn[((long)slot * 3 + 0) * n + ic]; pw1 = Pwn[((long)slot * 3 + 1) * n + ic]; pw2 = Pwn[((long)slot * 3 + 2) * n + ic];
+  };
+  auto s1_issue = [&](int tile) {
+    const int i = tile + lane;
+    const bool inr = i < end;
+    const int ic = inr ? i : (end - 1);
+    Warp<T> w = warp_point(Mr, fx, fy, cx, cy, pw0, pw1, pw2, H, W);
+    Taps<T> tp = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
+    wX = w.X; wY = w.Y; wZ = w.Z; wok = inr && w.ok && live;
+    w00 = tp.w00; w01 = tp.w01; w10 = tp.w10; w11 = tp.w11;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const T* P = img + pl * HW;
+      tv[4 * pl + 0] = P[tp.i00]; tv[4 * pl + 1] = P[tp.i01]; tv[4 * pl + 2] = P[tp.i10]; tv[4 * pl + 3] = P[tp.i11];
+    }
+    const T* D = dPwn_dTwc + (long)slot * 18 * n + ic;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) Dv[k] = D[(long)k * n];
+    const T* U = uvec + (long)slot * 3 * n + ic;
+    Uv[0] = U[0]; Uv[1] = U[n]; Uv[2] = U[2 * (long)n];
+    valv = vals[(long)slot * n + ic];
+    row_nxt = pixidx ? pixidx[(long)slot * n + ic] : ic;
+  };
+  auto s2_rows = [&](T* J, T* S) {     // this wave's pair: 16 rows + r~ + depth scale of the tile loaded one stage ago
+    const T It = w00 * tv[0] + w01 * tv[1] + w10 * tv[2] + w11 * tv[3];
+    const T gx = w00 * tv[4] + w01 * tv[5] + w10 * tv[6] + w11 * tv[7];
+    const T gy = w00 * tv[8] + w01 * tv[9] + w10 * tv[10] + w11 * tv[11];
+    const T Iref_s = scale * valv;
+    const T r = It - Iref_s + bias;
+    const bool ok = wok;
+    const T wr = r * info_sqrt;
+    const T wgt = ok ? huber(wr) : T(0);
+    const T ws = sqrt(wgt);
+    const T s = ok ? info_sqrt * ws : T(0);
+    err += ok ? (ws * wr) * (ws * wr) : T(0);
+    const T iz = ok ? T(1) / wZ : T(0);
+    const T a0 = gx * fx * iz, a1 = gy * fy * iz;
+    const T a2 = -(a0 * wX + a1 * wY) * iz;
+    const T b0 = a0 * Mr[0] + a1 * Mr[4] + a2 * Mr[8];
+    const T b1 = a0 * Mr[1] + a1 * Mr[5] + a2 * Mr[9];
+    const T b2 = a0 * Mr[2] + a1 * Mr[6] + a2 * Mr[10];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) J[k * JP_STRIDE + lane] = s * (b0 * Dv[k] + b1 * Dv[6 + k] + b2 * Dv[12 + k]);
+    J[6 * JP_STRIDE + lane] = s * Iref_s;
+    J[7 * JP_STRIDE + lane] = -s;
+    const T Xc = ok ? wX : T(0), Yc = ok ? wY : T(0), Zc = ok ? wZ : T(0);
+    J[8 * JP_STRIDE + lane] = s * (a1 * Zc - a2 * Yc);
+    J[9 * JP_STRIDE + lane] = s * (a2 * Xc - a0 * Zc);
+    J[10 * JP_STRIDE + lane] = s * (a0 * Yc - a1 * Xc);
+    J[11 * JP_STRIDE + lane] = -s * a0;
+    J[12 * JP_STRIDE + lane] = -s * a1;
+    J[13 * JP_STRIDE + lane] = -s * a2;
+    J[14 * JP_STRIDE + lane] = -s * Iref_s;
+    J[15 * JP_STRIDE + lane] = s;
+    S[lane] = s * r;
+    S[64 + lane] = s * (b0 * Uv[0] + b1 * Uv[1] + b2 * Uv[2]);
+  };
+
+  if (begin < end) {
+    s0_load(begin);
+    s1_issue(begin);
+    row_cur = row_nxt;
+    static_for<PF>([&](auto ic_) {
+      constexpr int st = decltype(ic_)::value;
+      const int row = __shfl(row_cur, 4 * st + q, 64);
+      kq[st] = load4(KtS + (long)row * m);
+    });
+    s0_load(begin + 64);
+  }
+  int buf = 0;
+  for (int tile = begin; tile < end; tile += 64) {
+    T* stage = lds + buf * (2 * STG1);
+    s2_rows(stage + role * STG1, stage + role * STG1 + 16 * JP_STRIDE);
+    __syncthreads();                               // both pairs' rows of this tile are staged (the other buffer is free again)
+    s1_issue(tile + 64);
+    s0_load(tile + 128);
+    const T* J0 = stage;
+    const T* J1 = stage + STG1;
+    const T* S0 = J0 + 16 * JP_STRIDE;
+    const T* S1 = J1 + 16 * JP_STRIDE;
+    for (int half = 0; half < 16 / PF; ++half) {
+      static_for<PF>([&](auto ic_) {
+        constexpr int sl = decltype(ic_)::value;
+        const int st = half * PF + sl;
+        const int px = 4 * st + q;
+        const T rt0 = S0[px], rt1 = S1[px];
+        const T sz0 = S0[64 + px], sz1 = S1[64 + px];
+        const V4<T> k4 = kq[sl];
+        {
+          const int nst = st + PF;
+          const bool same = nst < 16;
+          const int row = __shfl(same ? row_cur : row_nxt, 4 * (same ? nst : nst - 16) + q, 64);
+          kq[sl] = load4(KtS + (long)row * m);
+        }
+        const T cs = sz0 * sz0 + sz1 * sz1;
+        const T rs = cs > T(0) ? T(1) / sqrt(cs) : T(0);
+        const T sc2 = cs * rs;                                   // sqrt(s_0^2 + s_1^2)
+        T zq[4];
+        zq[0] = sc2 * (k4.x * invz4[0]); zq[1] = sc2 * (k4.y * invz4[1]); zq[2] = sc2 * (k4.z * invz4[2]); zq[3] = sc2 * (k4.w * invz4[3]);
+        if (role == 0) {
+          const T gzs = (sz0 * rt0 + sz1 * rt1) * rs;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) gv[e] += zq[e] * gzs;
+          static_for<10>([&](auto it) {
+            constexpr int tt = decltype(it)::value + 5;          // tiles 5..14 of the 15-tile enumeration = depth x depth
+            constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
+            acc[tt - 5] = mfma16(zq[ti - 1], zq[tj - 1], acc[tt - 5]);
+          });
+        } else {
+          const T a00 = J0[c * JP_STRIDE + px], a01 = J1[c * JP_STRIDE + px];
+          const T p0 = a00 * (sz0 * rs), p1 = a01 * (sz1 * rs);  // pose rows rescaled for the pose x depth tiles
+          gv[0] += a00 * rt0;
+          gv[1] += a01 * rt1;
+          acc[0] = mfma16(a00, a00, acc[0]);
+          acc[1] = mfma16(a01, a01, acc[1]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[2 + e] = mfma16(p0, zq[e], acc[2 + e]);
+            acc[6 + e] = mfma16(p1, zq[e], acc[6 + e]);
+          }
+        }
+      });
+    }
+    row_cur = row_nxt;
+    buf ^= 1;
+  }
+
+  // ---- epilogue: every element has one owner; record layout of ba_blocks_kernel (15 tiles | 5 x 16 gradient | err) ----
+  err = wave_sum(err);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    gv[e] += __shfl_xor(gv[e], 16, 64);
+    gv[e] += __shfl_xor(gv[e], 32, 64);
+  }
+  T* rec0 = partials + (long)(pg0 * gridDim.x + blockIdx.x) * Cfg::REC;
+  T* rec1 = has1 ? partials + (long)(pg1 * gridDim.x + blockIdx.x) * Cfg::REC : nullptr;
+  auto put_tile = [&](T* rec, int tt, const acc_t& a) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) rec[tt * 256 + rg * 64 + lane] = a[rg];
+  };
+  const acc_t zero4 = acc_t{T(0), T(0), T(0), T(0)};
+  if (role == 0) {
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      put_tile(rec0, 5 + t, acc[t]);
+      if (rec1) put_tile(rec1, 5 + t, zero4);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        rec0[Cfg::NT * 256 + (1 + e) * 16 + lane] = gv[e];
+        if (rec1) rec1[Cfg::NT * 256 + (1 + e) * 16 + lane] = T(0);
+      }
+    }
+    if (lane == 0) rec0[Cfg::NT * 256 + Cfg::NB * 16] = err;
+  } else {
+    put_tile(rec0, 0, acc[0]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) put_tile(rec0, 1 + e, acc[2 + e]);
+    if (lane < 16) rec0[Cfg::NT * 256 + lane] = gv[0];
+    if (rec1) {
+      put_tile(rec1, 0, acc[1]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) put_tile(rec1, 1 + e, acc[6 + e]);
+      if (lane < 16) rec1[Cfg::NT * 256 + lane] = gv[1];
+      if (lane == 0) rec1[Cfg::NT * 256 + Cfg::NB * 16] = err;
+    }
+  }
+}
+
 // ---------------------------------------- stage 2 ------------------------------------------------
 // One thread per record element: fixed-order fp64 sum over the pair's wave partials, then the
 // landmark expansion (photo.py:169-182) and accumulation into H / g (photo.py:184-231).
@@ -1093,7 +1339,17 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
         }
         else { LAUNCH_PIPE(2); }
       } else {
-        LAUNCH_BLOCKS(1);
+        // float64 = the reference's mapping dtype: role-specialised two-pair kernel (variant 1 keeps the plain kernel for A/B runs)
+        if (A->variant != 2 && A->variant != 1 && A->grp_pairs && A->ngrp > 0 && A->nsingle == 0) {
+          hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF>), dim3(chunks, A->ngrp), dim3(128), 0, s,
+                             (const double*)A->Pwn, (const double*)A->vals, (const double*)A->dPwn_dTwc, (const double*)A->zjac,
+                             (const double*)A->uvec, A->pixidx, (const double*)A->invz, A->kt_slot_stride, pr,
+                             (const double*)pair_T, (const double*)pair_aff, (const double*)A->img_base, (const double*)A->K,
+                             A->H, A->W, n, m, pb, pe, chunk_len, hists, (double*)A->ws_partials, (double*)A->sigma_out,
+                             A->grp_pairs);
+        } else {
+          LAUNCH_BLOCKS(1);
+        }
       }
 #undef LAUNCH_PIPE
 #undef LAUNCH_PIPE_ABL

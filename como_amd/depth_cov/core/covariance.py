@@ -71,9 +71,11 @@ class DiagonalCovarianceModule(CovarianceModule):
     forward = __call__
 
 
-def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None):
+def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None, K_mm_inv=None):
     """Mapping.prep_predictor (Mapping.py:430-468): returns (K_mm_inv (B,m,m), L_mm (B,m,m), Knm_Kmminv (B,H,W,m)).
-    K_nm (H*W x m per keyframe) is never materialised."""
+    K_nm (H*W x m per keyframe) is never materialised.  K_mm_inv: optional precomputed inverse (then L_mm is returned as
+    None and only K~ = K_nm K_mm^-1 is formed) -- K_mm is ill-conditioned (~1e8), so two float64 LAPACKs agree on its
+    inverse to ~1e-8 only; parity tests of the kernels DOWNSTREAM of K~ pass the reference's own inverse."""
     _lib.require_cuda(cov_params_img, coords_m)
     B, _, Hc, Wc = cov_params_img.shape
     dt, dev = cov_params_img.dtype, cov_params_img.device
@@ -81,10 +83,14 @@ def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None):
     m = coords_m.shape[1]
     cm = normalize_coordinates(coords_m.to(dt), (Hc, Wc))
     Em = interpolate_kernel_params(cov_params_img, cm)
-    K_mm = covariance(cm, Em, scale)
-    K_mm = K_mm + torch.diag_embed((1e-6 * torch.ones(B, m, device=dev)).to(dt))      # float32 jitter as Mapping.py:450
-    L_mm, _ = torch.linalg.cholesky_ex(K_mm, upper=False)
-    K_mm_inv = torch.cholesky_solve(torch.eye(m, dtype=dt, device=dev).expand(B, m, m), L_mm, upper=False).contiguous()
+    if K_mm_inv is None:
+        K_mm = covariance(cm, Em, scale)
+        K_mm = K_mm + torch.diag_embed((1e-6 * torch.ones(B, m, device=dev)).to(dt))      # float32 jitter as Mapping.py:450
+        L_mm, _ = torch.linalg.cholesky_ex(K_mm, upper=False)
+        K_mm_inv = torch.cholesky_solve(torch.eye(m, dtype=dt, device=dev).expand(B, m, m), L_mm, upper=False).contiguous()
+    else:
+        L_mm = None
+        K_mm_inv = K_mm_inv.to(device=dev, dtype=dt).contiguous()
     out = torch.empty((B, Hp, Wp, m), dtype=dt, device=dev)
     fn = getattr(_lib.lib(), "como_ktilde_" + _lib.suffix(dt))
     rc = fn(cov_params_img.contiguous().data_ptr(), Hc, Wc, cm.contiguous().data_ptr(), Em.contiguous().data_ptr(),

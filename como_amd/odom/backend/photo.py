@@ -71,8 +71,9 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
                 reduce_hists(zh[ps * 2048:(ps + 1) * 2048])
         return sigma_out
     if chunks is None:
-        if grp_pairs is not None and grp_pairs.numel() > 0 and dtype == torch.float32 and zmode == 1 and BLOCK_VARIANT == 0:
-            chunks = default_chunks(grp_pairs.shape[0], nl, dtype, per_cu=2)     # two-pair kernel: 2 workgroups per CU resident
+        if grp_pairs is not None and grp_pairs.numel() > 0 and zmode == 1 and BLOCK_VARIANT == 0:
+            # two-pair kernels: 2 workgroups per CU resident (f32: 256 threads, 2 waves / SIMD; f64: 128 threads, 1 wave / SIMD)
+            chunks = default_chunks(grp_pairs.shape[0], nl, dtype, per_cu=2)
         else:
             chunks = default_chunks(b, nl, dtype)
     a = _lib.BAArgs()
@@ -256,5 +257,5 @@ def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uv
                      tgt_img=table.tgt_img, pose_ref_inds=table.pose_ref_inds, pose_tgt_inds=table.pose_tgt_inds,
                      landmark_inds=table.landmark_inds, dzdP=dzdP, H=H, g=g, err_out=err_out, chunks=chunks,
                      phase=phase, sigma_out=sigma_out, pix_range=pix_range, reduce_hists=reduce_hists, events=events,
-                     grp_pairs=(table.grp_pairs if vals.dtype == torch.float32 else None), single_pairs=table.single_pairs,
+                     grp_pairs=table.grp_pairs, single_pairs=table.single_pairs,
                      zeroed_hists=zeroed_hists, ws=ws)
