@@ -51,6 +51,23 @@ __device__ __forceinline__ typename Acc4<float>::type mfma16(float a, float b, t
 __device__ __forceinline__ typename Acc4<double>::type mfma16(double a, double b, typename Acc4<double>::type c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
+// LDS written by this wave is visible to this wave's later reads (no other wave involved)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// 1/x and 1/sqrt(x) in double from the hardware seed + one Newton step (second / third order): ~1 ulp, 4-6 instructions
+// instead of the ~25 of an IEEE division or sqrt.  Only used for Jacobian WEIGHTS (never for what feeds a validity mask).
+__device__ __forceinline__ double fast_rcp(double x) {
+  const double y = __builtin_amdgcn_rcp(x);
+  return fma(y, fma(-x, y, 1.0), y);
+}
+__device__ __forceinline__ double fast_rsq(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);
+  return fma(y, e * fma(0.375, e, 0.5), y);
+}
 // C/D register layout of the 16x16x4 MFMA: row of (lane, reg); column is lane & 15 for both.
 template <typename T> __host__ __device__ constexpr int mfma_row(int lane, int reg);
 template <> __host__ __device__ constexpr int mfma_row<float>(int lane, int reg) { return (lane >> 4) * 4 + reg; }
@@ -663,8 +680,8 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
   using acc_t = typename Acc4<T>::type;
   constexpr int G = 2;
   __shared__ SelScratch sc;
-  constexpr int STG1 = 16 * JP_STRIDE + 64 * 2;
-  constexpr int STG = G * STG1;
+  constexpr int STG1 = 16 * JP_STRIDE + 64 * 2;     // per pair: 16 pose/affine rows, r~, depth scale / joint weight
+  constexpr int STG = G * STG1 + 64 * 2;           // + per pixel of the tile: joint weight sqrt(s0^2 + s1^2), joint whitened residual
   constexpr int LDS_ELEMS = (4 * STG > 2 * Cfg::REC) ? 4 * STG : 2 * Cfg::REC;
   __shared__ T lds[LDS_ELEMS];
 
@@ -683,6 +700,7 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
   const int q = lane >> 4, c = lane & 15;
   T* Jp[G];
   T* Sv[G];
+  T* Px = lds + wv * STG + G * STG1;
   T Mr[G][12], scale[G], bias[G];
   const T* img[G];
 #pragma unroll
@@ -755,6 +773,7 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
     row_nxt = pixidx ? pixidx[(long)slot * n + ic] : ic;
   };
   auto s2_rows = [&]() {
+    T rsv[G], szv[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const T It = w00[g] * tv[g][0] + w01[g] * tv[g][1] + w10[g] * tv[g][2] + w11[g] * tv[g][3];
@@ -788,9 +807,17 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
       J[13 * JP_STRIDE + lane] = -s * a2;
       J[14 * JP_STRIDE + lane] = -s * Iref_s;
       J[15 * JP_STRIDE + lane] = s;
-      Sv[g][lane] = s * r;
-      Sv[g][64 + lane] = s * (b0 * Uv[0] + b1 * Uv[1] + b2 * Uv[2]);
+      rsv[g] = s * r;
+      szv[g] = s * (b0 * Uv[0] + b1 * Uv[1] + b2 * Uv[2]);
+      Sv[g][lane] = rsv[g];
     }
+    // per-PIXEL factors of the joint depth row, once per tile (lane = pixel) instead of in every step of every column lane
+    const T cs = szv[0] * szv[0] + szv[1] * szv[1];
+    const T rs = cs > T(0) ? __builtin_amdgcn_rsqf(cs) : T(0);
+    Px[lane] = cs * rs;                                          // sqrt(s_0^2 + s_1^2)
+    Px[64 + lane] = (szv[0] * rsv[0] + szv[1] * rsv[1]) * rs;    // whitened residual of the joint depth row
+    Sv[0][64 + lane] = szv[0] * rs;                              // pose rows rescaled for the pose x depth tiles
+    Sv[1][64 + lane] = szv[1] * rs;
   };
 
   const int tile0 = begin + wv * 64;
@@ -817,7 +844,7 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
         const int px = 4 * st + q;
         const T a00 = Jp[0][c * JP_STRIDE + px], a01 = Jp[1][c * JP_STRIDE + px];
         const T rt0 = Sv[0][px], rt1 = Sv[1][px];
-        const T sz0 = Sv[0][64 + px], sz1 = Sv[1][64 + px];
+        const T sc2 = Px[px], gzs = Px[64 + px];
         const V4<T> k4 = kq[sl];
         {
           const int nst = st + PF;
@@ -825,13 +852,9 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
           const int row = __shfl(same ? row_cur : row_nxt, 4 * (same ? nst : nst - 16) + q, 64);
           kq[sl] = load4(KtS + (long)row * m);
         }
-        const T cs = sz0 * sz0 + sz1 * sz1;
-        const T rs = cs > T(0) ? __builtin_amdgcn_rsqf(cs) : T(0);
-        const T sc2 = cs * rs;                                   // sqrt(s_0^2 + s_1^2)
-        T zq[4];
-        zq[0] = sc2 * (k4.x * invz4[0]); zq[1] = sc2 * (k4.y * invz4[1]); zq[2] = sc2 * (k4.z * invz4[2]); zq[3] = sc2 * (k4.w * invz4[3]);
-        const T p0 = a00 * (sz0 * rs), p1 = a01 * (sz1 * rs);    // pose rows rescaled for the pose x depth tiles
-        const T gzs = (sz0 * rt0 + sz1 * rt1) * rs;
+        // depth columns WITHOUT the 1 / z_m factor: constant over pixels, applied to the accumulators once in the epilogue
+        const T zq[4] = {sc2 * k4.x, sc2 * k4.y, sc2 * k4.z, sc2 * k4.w};
+        const T p0 = a00 * Sv[0][64 + px], p1 = a01 * Sv[1][64 + px];
         gT[0] += a00 * rt0;
         gT[1] += a01 * rt1;
 #pragma unroll
@@ -854,6 +877,26 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
     row_cur = row_nxt;
   }
 
+  // the 1 / z_m factors of the depth columns (dPwn_dzm = uvec K~ / z_m), once per accumulator: column of depth block t at
+  // lane-column ci is kcol(t, ci); the f32 MFMA row of (lane, reg) is 4 (lane >> 4) + reg
+  static_for<10>([&](auto it) {
+    constexpr int tt = decltype(it)::value + 5;
+    constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int k1 = kcol(ti, mfma_row<T>(lane, rg));
+      const T f1 = (k1 < m) ? invz[(long)slot * m + k1] : T(0);
+      azz[tt - 5][rg] *= f1 * invz4[tj - 1];
+    }
+  });
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    gz[e] *= invz4[e];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) aTz[g][e][rg] *= invz4[e];
+  }
   // ---- epilogue: one record per pair, ordered cross-wave reduction (record layout of ba_blocks_kernel) ----
 #pragma unroll
   for (int g = 0; g < G; ++g) {
@@ -939,6 +982,7 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
   __shared__ SelScratch sc;
   constexpr int STG1 = 16 * JP_STRIDE + 64 * 2;       // one pair's staged tile: 16 pose/affine rows + r~ + depth scale
   __shared__ T lds[2 * 2 * STG1];                      // [buffer][pair]: 37.9 KB
+  __shared__ T pxs[2][4 * 64];                         // per wave, per pixel of the tile: {sqrt(s0^2+s1^2), g-weight | s0/., s1/.}
 
   // robust scale from the finished histograms; sel_resolve is written for 256-thread blocks: feed it 128 threads x 2 rounds
   KeyT prefix; uint32_t k_rem, nv;
@@ -1016,11 +1060,12 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
     const T r = It - Iref_s + bias;
     const bool ok = wok;
     const T wr = r * info_sqrt;
-    const T wgt = ok ? huber(wr) : T(0);
-    const T ws = sqrt(wgt);
+    const T awr = fabs(wr);
+    // sqrt of the Huber weight (robust_loss.py:9-16): 1 inside the band, sqrt(1.345 / |x|) outside
+    const T ws = (awr < T(1.345)) ? T(1) : T(1.1597413504743201) * fast_rsq(awr);
     const T s = ok ? info_sqrt * ws : T(0);
     err += ok ? (ws * wr) * (ws * wr) : T(0);
-    const T iz = ok ? T(1) / wZ : T(0);
+    const T iz = ok ? fast_rcp(wZ) : T(0);
     const T a0 = gx * fx * iz, a1 = gy * fy * iz;
     const T a2 = -(a0 * wX + a1 * wY) * iz;
     const T b0 = a0 * Mr[0] + a1 * Mr[4] + a2 * Mr[8];
@@ -1065,13 +1110,28 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
     const T* J1 = stage + STG1;
     const T* S0 = J0 + 16 * JP_STRIDE;
     const T* S1 = J1 + 16 * JP_STRIDE;
+    // per-PIXEL factors once per tile (lane = pixel) instead of once per (pixel, column lane) in every step: the two rows of a
+    // reference pixel share the K~ row scaled by s_g; weight of the joint depth row = sqrt(s_0^2 + s_1^2)
+    {
+      const T rt0 = S0[lane], rt1 = S1[lane], sz0 = S0[64 + lane], sz1 = S1[64 + lane];
+      const T cs = sz0 * sz0 + sz1 * sz1;
+      const T rs = cs > T(0) ? fast_rsq(cs) : T(0);
+      T* my = pxs[role];
+      my[lane] = cs * rs;                                        // sqrt(s_0^2 + s_1^2)
+      if (role == 0) {
+        my[64 + lane] = (sz0 * rt0 + sz1 * rt1) * rs;            // whitened residual of the joint depth row
+      } else {
+        my[128 + lane] = sz0 * rs;                               // pose rows rescaled for the pose x depth tiles
+        my[192 + lane] = sz1 * rs;
+      }
+      wave_lds_sync();
+    }
+    const T* my = pxs[role];
     for (int half = 0; half < 16 / PF; ++half) {
       static_for<PF>([&](auto ic_) {
         constexpr int sl = decltype(ic_)::value;
         const int st = half * PF + sl;
         const int px = 4 * st + q;
-        const T rt0 = S0[px], rt1 = S1[px];
-        const T sz0 = S0[64 + px], sz1 = S1[64 + px];
         const V4<T> k4 = kq[sl];
         {
           const int nst = st + PF;
@@ -1079,13 +1139,11 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
           const int row = __shfl(same ? row_cur : row_nxt, 4 * (same ? nst : nst - 16) + q, 64);
           kq[sl] = load4(KtS + (long)row * m);
         }
-        const T cs = sz0 * sz0 + sz1 * sz1;
-        const T rs = cs > T(0) ? T(1) / sqrt(cs) : T(0);
-        const T sc2 = cs * rs;                                   // sqrt(s_0^2 + s_1^2)
-        T zq[4];
-        zq[0] = sc2 * (k4.x * invz4[0]); zq[1] = sc2 * (k4.y * invz4[1]); zq[2] = sc2 * (k4.z * invz4[2]); zq[3] = sc2 * (k4.w * invz4[3]);
+        const T sc2 = my[px];
+        // depth columns WITHOUT the 1 / z_m factor: it is constant over pixels and is applied to the accumulators once
+        const T zq[4] = {sc2 * k4.x, sc2 * k4.y, sc2 * k4.z, sc2 * k4.w};
         if (role == 0) {
-          const T gzs = (sz0 * rt0 + sz1 * rt1) * rs;
+          const T gzs = my[64 + px];
 #pragma unroll
           for (int e = 0; e < 4; ++e) gv[e] += zq[e] * gzs;
           static_for<10>([&](auto it) {
@@ -1095,9 +1153,9 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
           });
         } else {
           const T a00 = J0[c * JP_STRIDE + px], a01 = J1[c * JP_STRIDE + px];
-          const T p0 = a00 * (sz0 * rs), p1 = a01 * (sz1 * rs);  // pose rows rescaled for the pose x depth tiles
-          gv[0] += a00 * rt0;
-          gv[1] += a01 * rt1;
+          const T p0 = a00 * my[128 + px], p1 = a01 * my[192 + px];
+          gv[0] += a00 * S0[px];
+          gv[1] += a01 * S1[px];
           acc[0] = mfma16(a00, a00, acc[0]);
           acc[1] = mfma16(a01, a01, acc[1]);
 #pragma unroll
@@ -1114,6 +1172,27 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
 
   // ---- epilogue: every element has one owner; record layout of ba_blocks_kernel (15 tiles | 5 x 16 gradient | err) ----
   err = wave_sum(err);
+  // the 1 / z_m factors of the depth columns (dPwn_dzm = uvec K~ / z_m, sparse_map.py:184-230), once per accumulator:
+  // column k of depth block t at lane-column ci is kcol(t, ci) = 4 ci + t - 1; the f64 MFMA row of (lane, reg) is (lane >> 4) + 4 reg
+  if (role == 0) {
+    static_for<10>([&](auto it) {
+      constexpr int tt = decltype(it)::value + 5;
+      constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int k1 = kcol(ti, mfma_row<T>(lane, rg));
+        const T f1 = (k1 < m) ? invz[(long)slot * m + k1] : T(0);
+        acc[tt - 5][rg] *= f1 * invz4[tj - 1];
+      }
+    });
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gv[e] *= invz4[e];
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) { acc[2 + e][rg] *= invz4[e]; acc[6 + e][rg] *= invz4[e]; }
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     gv[e] += __shfl_xor(gv[e], 16, 64);

@@ -16,6 +16,7 @@ from como_amd.odom.backend.graph_pair_construction import setup_photometric_pair
 
 _ws = {}
 BLOCK_VARIANT = int(__import__("os").environ.get("COMO_BA_VARIANT", "0"))   # 0 = software-pipelined block kernel, 1 = plain
+CHUNKS_OVERRIDE = int(__import__("os").environ.get("COMO_BA_CHUNKS", "0"))   # tuning runs: pixel chunks per pair group
 BLOCK_STAGGER = int(__import__("os").environ.get("COMO_BA_STAGGER", "0"))
 last_aux = {}   # diagnostics of the most recent call: valid mask, sigma, nvalid (tests / callers that want them)
 
@@ -70,10 +71,14 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
             for ps in range(3 if dtype == torch.float32 else 6):
                 reduce_hists(zh[ps * 2048:(ps + 1) * 2048])
         return sigma_out
+    if chunks is None and CHUNKS_OVERRIDE > 0:
+        chunks = min(CHUNKS_OVERRIDE, (nl + 255) // 256)
     if chunks is None:
         if grp_pairs is not None and grp_pairs.numel() > 0 and zmode == 1 and BLOCK_VARIANT == 0:
             # two-pair kernels: 2 workgroups per CU resident (f32: 256 threads, 2 waves / SIMD; f64: 128 threads, 1 wave / SIMD)
-            chunks = default_chunks(grp_pairs.shape[0], nl, dtype, per_cu=2)
+            # -> ONE resident round of 512 workgroups (measured, dense 8-keyframe window: 64 chunks x 8 groups 313 us,
+            # 128 x 8 = two rounds 338 us in float32; 841 vs 882 us in float64)
+            chunks = default_chunks(grp_pairs.shape[0], nl, dtype, per_cu=1)
         else:
             chunks = default_chunks(b, nl, dtype)
     a = _lib.BAArgs()

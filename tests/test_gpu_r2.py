@@ -131,7 +131,7 @@ def test_fullsize_metric_window_vs_reference(pix, window):
     assert int(ls.solve_system.last_info) == 0
     assert worst["pose"] < (1e-7 if f64 else 1e-4)                    # solved poses within 1e-4 of the reference (north star)
     assert worst["aff"] < (1e-7 if f64 else 1e-4) and worst["P"] < (1e-5 if f64 else 2e-3)
-    assert worst["med"] < (1e-8 if f64 else 2e-6)                     # the full-image median (Mapping.store_vars)
+    assert worst["med"] < (1e-7 if f64 else 1e-5)                     # the full-image median (Mapping.store_vars)
     assert worst["H_full"] < (5e-6 if f64 else 2e-3)
 
 
