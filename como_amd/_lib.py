@@ -31,6 +31,7 @@ class BAArgs(ctypes.Structure):
         ("pair_blocks_out", c_void_p), ("ws_r", c_void_p), ("ws_valid", c_void_p), ("ws_hists", c_void_p),
         ("ws_pair", c_void_p), ("ws_partials", c_void_p), ("grp_pairs", c_void_p), ("single_pairs", c_void_p),
         ("ngrp", c_int), ("nsingle", c_int),
+        ("fix_plane", c_long), ("reduce_mode", c_int), ("blocks_fix", c_void_p),
     ]
 
 
@@ -46,7 +47,7 @@ class WinArgs(ctypes.Structure):
                 + [(n, c_double) for n in ("s_gp", "s_ld", "s_px", "s_pose", "s_aff", "s_lm")]
                 + [(n, c_void_p) for n in ("H", "g", "err")]
                 + [("zero_a", c_void_p), ("zero_a_bytes", c_long), ("zero_b", c_void_p), ("zero_b_bytes", c_long),
-                   ("median_out", c_void_p)])
+                   ("median_out", c_void_p), ("sysfix", c_void_p), ("fix_plane", c_long)])
 
 
 # name -> (restype, argtypes); every symbol include/como_hip.h declares
@@ -64,6 +65,8 @@ SIGNATURES = {
     "como_track_iter_masked_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 10),
     "como_track_iter_masked_f64": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 10),
     "como_ba_partials_elems": (c_long, [c_int, c_int, c_int]),
+    "como_sys_fix_plane_elems": (c_long, [c_long]),
+    "como_sys_finalize": (c_int, [c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "como_ba_linearize_f32": (c_int, [ctypes.POINTER(BAArgs), c_void_p]),
     "como_ba_linearize_f64": (c_int, [ctypes.POINTER(BAArgs), c_void_p]),
     "como_cross_covariance_f32": (c_int, [c_void_p] * 4 + [c_float, c_void_p, c_int, c_int, c_int,

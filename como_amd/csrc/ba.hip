@@ -1237,19 +1237,25 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
 // ---------------------------------------- stage 2 ------------------------------------------------
 // One thread per record element: fixed-order fp64 sum over the pair's wave partials, then the
 // landmark expansion (photo.py:169-182) and accumulation into H / g (photo.py:184-231).
-template <typename T, typename TH>
+// TH = float / double: floating-point atomics into the caller's H, both triangles (the reference-signature contract:
+// batch_photo_cost accumulates into whatever H already holds).  TH = long long: ORDER-INDEPENDENT mode -- exact integer
+// atomics into the fixed-point system buffer, lower triangle only (como_sys_finalize mirrors it), see common.cuh fix_add.
+// MODE 0: reduce + expand; 1: reduce only -> blocks_fix; 2: expand from blocks_fix (after the all-reduce of the shards).
+template <typename T, typename TH, int MODE>
 __global__ __launch_bounds__(256) void ba_reduce_assemble_kernel(
     const T* __restrict__ partials, int nrec_per_pair, BAPairs pr, const long* __restrict__ pose_ref_inds,
     const long* __restrict__ pose_tgt_inds, const long* __restrict__ landmark_inds, const T* __restrict__ dzdP,
     int m, TH* __restrict__ Hm, long D, TH* __restrict__ gv, double* __restrict__ err_out,
-    double* __restrict__ pair_blocks) {
+    double* __restrict__ pair_blocks, long fix_plane, long long* __restrict__ blocks_fix) {
   using Cfg = BACfg;
+  constexpr bool FIX = std::is_same<TH, long long>::value;
+  constexpr int NE = Cfg::NT * 256 + Cfg::NB * 16 + 1;
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int p = blockIdx.y;
-  if (e >= Cfg::NT * 256 + Cfg::NB * 16 + 1) return;
-  const T* base = partials + (long)p * nrec_per_pair * Cfg::REC + e;
+  if (e >= NE) return;
   double s = 0;
-  {
+  if constexpr (MODE != 2) {
+    const T* base = partials + (long)p * nrec_per_pair * Cfg::REC + e;
     // fixed summation order, but 8 loads in flight (one dependent 16 KB-strided load per step was 45 us of this kernel)
     int w = 0;
     for (; w + 8 <= nrec_per_pair; w += 8) {
@@ -1261,12 +1267,38 @@ __global__ __launch_bounds__(256) void ba_reduce_assemble_kernel(
     }
     for (; w < nrec_per_pair; ++w) s += (double)base[(long)w * Cfg::REC];
   }
+  if constexpr (MODE == 1) {                       // this rank's share of the pair sums, in fixed point (exact all-reduce)
+    long long hi;
+    unsigned long long lo;
+    if (!(fabs(s) < 4.0e18)) { hi = 0x4000000000000000ll; lo = 0; }   // non-finite: an integer part no sum of finite shares reaches
+    else fix_split(s, hi, lo);
+    blocks_fix[2 * ((long)p * Cfg::REC + e)] = hi;
+    blocks_fix[2 * ((long)p * Cfg::REC + e) + 1] = (long long)lo;
+    return;
+  }
+  if constexpr (MODE == 2) {
+    const long long hi = blocks_fix[2 * ((long)p * Cfg::REC + e)];
+    const unsigned long long lo = (unsigned long long)blocks_fix[2 * ((long)p * Cfg::REC + e) + 1];
+    s = (hi >= 0x2000000000000000ll || hi <= -0x2000000000000000ll) ? __builtin_nan("") : fix_value(hi, lo);
+  }
   if (pair_blocks) pair_blocks[(long)p * Cfg::REC + e] = s;
   const int slot = pr.ref_slot[p];
   const long* pri = pose_ref_inds + 8 * (long)p;
   const long* pti = pose_tgt_inds + 8 * (long)p;
   const long* lmi = landmark_inds + 3 * (long)m * p;
   const T* dz = dzdP + 3 * (long)slot;
+  long long* poison = nullptr;
+  if constexpr (FIX) poison = (long long*)Hm + D * D + D + FIX_POISON;
+  // one symmetric entry pair (ia, ib) / (ib, ia) of H
+  auto add_sym = [&](long ia, long ib, double v, bool both) {
+    if constexpr (FIX) {
+      const long r = ia > ib ? ia : ib, c = ia > ib ? ib : ia;
+      fix_add((long long*)Hm, fix_plane, r * D + c, v, poison);
+    } else {
+      atomicAdd(&Hm[ia * D + ib], (TH)v);
+      if (both) atomicAdd(&Hm[ib * D + ia], (TH)v);
+    }
+  };
   // column id -> (kind, index): block 0 entry i: pose index (i<8 ref, else target); block t>=1: depth kcol(t,i)
   if (e < Cfg::NT * 256) {
     const int tt = e >> 8, rg = (e >> 6) & 3, lane = e & 63;
@@ -1275,45 +1307,68 @@ __global__ __launch_bounds__(256) void ba_reduce_assemble_kernel(
       for (int b = a; b < Cfg::NB; ++b) { if (cnt == tt) { ti = a; tj = b; } ++cnt; }
     const int ri = mfma_row<T>(lane, rg), ci = lane & 15;
     if (ti == 0 && tj == 0) {
+      // the full 16 x 16 tile is present: (ri, ci) and (ci, ri) carry the same bits -- fixed-point mode keeps one of them
       const long ia = ri < 8 ? pri[ri] : pti[ri - 8];
       const long ib = ci < 8 ? pri[ci] : pti[ci - 8];
-      atomicAdd(&Hm[ia * D + ib], (TH)s);
+      if (!FIX || ia >= ib) add_sym(ia, ib, s, false);
     } else if (ti == 0) {
       const int k = kcol(tj, ci);
       if (k < m) {
         const long ia = ri < 8 ? pri[ri] : pti[ri - 8];
-        for (int d = 0; d < 3; ++d) {
-          const TH v = (TH)(s * (double)dz[d]);
-          const long il = lmi[3 * k + d];
-          atomicAdd(&Hm[ia * D + il], v);
-          atomicAdd(&Hm[il * D + ia], v);
-        }
+        for (int d = 0; d < 3; ++d) add_sym(ia, lmi[3 * k + d], s * (double)dz[d], true);
       }
     } else {
       const int k1 = kcol(ti, ri), k2 = kcol(tj, ci);
       if (k1 < m && k2 < m) {
         for (int d1 = 0; d1 < 3; ++d1)
           for (int d2 = 0; d2 < 3; ++d2) {
-            const TH v = (TH)((double)dz[d1] * s * (double)dz[d2]);
+            const double v = (double)dz[d1] * s * (double)dz[d2];
             const long i1 = lmi[3 * k1 + d1], i2 = lmi[3 * k2 + d2];
-            atomicAdd(&Hm[i1 * D + i2], v);
-            if (ti != tj) atomicAdd(&Hm[i2 * D + i1], v);
+            // diagonal tiles hold both (k1, k2) and (k2, k1): each thread adds its own ordered entry; off-diagonal tiles
+            // hold (k1, k2) once: both triangles (float modes) / the lower one (fixed-point mode)
+            if (ti != tj) add_sym(i1, i2, v, true);
+            else if (!FIX || i1 >= i2) add_sym(i1, i2, v, false);
           }
       }
     }
   } else if (e < Cfg::NT * 256 + Cfg::NB * 16) {
     const int t = (e - Cfg::NT * 256) >> 4, ci = e & 15;
     const double gval = -s;                                  // get_gradient: g = -sum J r (linear_system.py:24-26)
+    auto add_g = [&](long ia, double v) {
+      if constexpr (FIX) fix_add((long long*)Hm, fix_plane, D * D + ia, v, poison);
+      else atomicAdd(&gv[ia], (TH)v);
+    };
     if (t == 0) {
-      const long ia = ci < 8 ? pri[ci] : pti[ci - 8];
-      atomicAdd(&gv[ia], (TH)gval);
+      add_g(ci < 8 ? pri[ci] : pti[ci - 8], gval);
     } else {
       const int k = kcol(t, ci);
       if (k < m)
-        for (int d = 0; d < 3; ++d) atomicAdd(&gv[lmi[3 * k + d]], (TH)(gval * (double)dz[d]));
+        for (int d = 0; d < 3; ++d) add_g(lmi[3 * k + d], gval * (double)dz[d]);
     }
   } else {
-    atomicAdd(err_out, s);
+    if constexpr (FIX) fix_add((long long*)Hm, fix_plane, D * D + D, s, poison);
+    else atomicAdd(err_out, s);
+  }
+}
+
+// fixed-point system buffer -> float64 H (both triangles, exactly symmetric), g, errors
+__global__ __launch_bounds__(256) void sys_finalize_kernel(const long long* __restrict__ fix, long plane, long D,
+                                                           double* __restrict__ H, double* __restrict__ g,
+                                                           double* __restrict__ err8) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  const bool poisoned = fix[D * D + D + FIX_POISON] != 0;
+  if (t < D * D) {
+    const long i = t / D, j = t - i * D;
+    if (j <= i) {
+      double v = fix_value(fix[t], (unsigned long long)fix[plane + t]);
+      if (poisoned && t == 0) v = __builtin_nan("");
+      H[t] = v;
+      if (j < i) H[j * D + i] = v;
+    }
+  } else if (t < D * D + D) {
+    g[t - D * D] = fix_value(fix[t], (unsigned long long)fix[plane + t]);
+  } else if (t < D * D + D + FIX_ERR_SLOTS && err8) {
+    err8[t - D * D - D] = fix_value(fix[t], (unsigned long long)fix[plane + t]);
   }
 }
 
@@ -1437,15 +1492,22 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
     COMO_CHECK_LAUNCH();
   }
   if (A->phase & 128) {
-    if (!A->pose_ref_inds || !A->pose_tgt_inds || !A->landmark_inds || !A->dzdP || !A->Hmat || !A->gvec || !A->err_out)
+    if (!A->pose_ref_inds || !A->pose_tgt_inds || !A->landmark_inds || !A->dzdP || !A->Hmat ||
+        (A->h_is_f64 != 2 && (!A->gvec || !A->err_out)))
       return COMO_ERR_ARG;
     const int nrec = A->chunks;
-#define LAUNCH_ASM(TH)                                                                                               \
-  hipLaunchKernelGGL((ba_reduce_assemble_kernel<T, TH>), dim3((BACfg::REC + 255) / 256, b), dim3(256), 0, s,          \
+#define LAUNCH_ASM(TH, MODE)                                                                                         \
+  hipLaunchKernelGGL((ba_reduce_assemble_kernel<T, TH, MODE>), dim3((BACfg::REC + 255) / 256, b), dim3(256), 0, s,    \
                      (const T*)A->ws_partials, nrec, pr, A->pose_ref_inds, A->pose_tgt_inds, A->landmark_inds,        \
                      (const T*)A->dzdP, m, (TH*)A->Hmat, A->D, (TH*)A->gvec, (double*)A->err_out,                     \
-                     (double*)A->pair_blocks_out)
-    if (A->h_is_f64) { LAUNCH_ASM(double); } else { LAUNCH_ASM(float); }
+                     (double*)A->pair_blocks_out, A->fix_plane, (long long*)A->blocks_fix)
+    if (A->h_is_f64 == 2) {
+      if (A->fix_plane < A->D * A->D + A->D + FIX_ERR_SLOTS) return COMO_ERR_ARG;
+      if (A->reduce_mode != 0 && !A->blocks_fix) return COMO_ERR_ARG;
+      if (A->reduce_mode == 1) { LAUNCH_ASM(long long, 1); }
+      else if (A->reduce_mode == 2) { LAUNCH_ASM(long long, 2); }
+      else { LAUNCH_ASM(long long, 0); }
+    } else if (A->h_is_f64) { LAUNCH_ASM(double, 0); } else { LAUNCH_ASM(float, 0); }
 #undef LAUNCH_ASM
     COMO_CHECK_LAUNCH();
   }
@@ -1459,6 +1521,17 @@ extern "C" {
 long como_ba_partials_elems(int b, int chunks, int m) {
   (void)m;
   return (long)b * chunks * como::BACfg::REC;
+}
+
+long como_sys_fix_plane_elems(long D) { return D * D + D + como::FIX_ERR_SLOTS; }
+
+int como_sys_finalize(const void* sysfix, long fix_plane, long D, double* H, double* g, double* err8, como_stream_t stream) {
+  if (!sysfix || !H || !g || D <= 0 || fix_plane < D * D + D + como::FIX_ERR_SLOTS) return COMO_ERR_ARG;
+  const long total = D * D + D + como::FIX_ERR_SLOTS;
+  hipLaunchKernelGGL(como::sys_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)sysfix, fix_plane, D, H, g, err8);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
 }
 
 int como_ba_linearize_f32(const como_ba_args* a, como_stream_t stream) { return como::ba_linearize<float>(a, (hipStream_t)stream); }

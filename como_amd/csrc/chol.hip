@@ -421,12 +421,19 @@ constexpr int BS_THREADS = 512;
 __global__ __launch_bounds__(BS_THREADS) void chol_backsub_kernel(const double* __restrict__ Lw, const double* __restrict__ Iw,
                                                                   int Dp, int D, int k_lo, int k_hi,
                                                                   const double* __restrict__ ysrc, double* __restrict__ yinit,
-                                                                  double* __restrict__ delta) {
+                                                                  double* __restrict__ delta,
+                                                                  const double* __restrict__ ypart, int nslab, int pstride) {
   __shared__ double y[4096];
   __shared__ double xb[CB];
   const int tid = threadIdx.x;
   const int j_lo = k_lo * CB, j_hi = k_hi * CB;
-  for (int j = j_lo + tid; j < j_hi; j += BS_THREADS) y[j] = (j < D) ? (ysrc ? ysrc[j] : Lw[(long)D * Dp + j]) : 0.0;
+  for (int j = j_lo + tid; j < j_hi; j += BS_THREADS) {
+    double v = (j < D) ? (ysrc ? ysrc[j] : Lw[(long)D * Dp + j]) : 0.0;
+    // the rectangle's row slabs, subtracted in slab order (no floating-point atomics: the solve is bit-reproducible)
+    if (ypart && j < D)
+      for (int sl = 0; sl < nslab; ++sl) v -= ypart[(long)sl * pstride + j];
+    y[j] = v;
+  }
   if (yinit)
     for (int j = tid; j < j_lo; j += BS_THREADS) yinit[j] = Lw[(long)D * Dp + j];
   // a step is two dependent global-load latencies (inverse block, then the panel rows) unless they are taken off the chain:
@@ -496,17 +503,19 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsub_kernel(const double* 
   }
 }
 
-// ybuf[j] -= sum_{r in [r_lo, D)} L[r][j] x[r] for j < ncols: blockIdx.x = 128-column chunk, blockIdx.y = row slab.
+// ypart[slab][j] = sum_{r in slab of [r_lo, D)} L[r][j] x[r] for j < ncols: blockIdx.x = 128-column chunk, blockIdx.y = row slab.
+// One partial per (slab, column), summed in slab order by the consumer (atomics would make the solve order-dependent).
 __global__ __launch_bounds__(128) void chol_backsub_rect_kernel(const double* __restrict__ Lw, int Dp, int D, int r_lo, int ncols,
-                                                                const double* __restrict__ x, double* __restrict__ ybuf) {
+                                                                const double* __restrict__ x, double* __restrict__ ypart,
+                                                                int pstride) {
   const int j = blockIdx.x * 128 + threadIdx.x;
   const int rows = D - r_lo, per = (rows + gridDim.y - 1) / gridDim.y;
   const int r0 = r_lo + blockIdx.y * per, r1 = min(r0 + per, D);
-  if (j >= ncols || r0 >= r1) return;
+  if (j >= ncols) return;
   double s = 0.0;
 #pragma unroll 4
   for (int r = r0; r < r1; ++r) s += Lw[(long)r * Dp + j] * x[r];
-  atomicAdd(&ybuf[j], -s);
+  ypart[(long)blockIdx.y * pstride + j] = s;
 }
 
 }  // namespace como
@@ -544,17 +553,21 @@ int como_chol_solve_f64(const double* H, const double* g, double* delta, void* w
   const int h = nb / 2;
   if (nb < 6) {
     hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, 0, nb, (const double*)nullptr,
-                       (double*)nullptr, delta);
+                       (double*)nullptr, delta, (const double*)nullptr, 0, 0);
     COMO_CHECK_LAUNCH();
   } else {
     double* ybuf = W;                                     // the working copy is dead once the factor is complete
-    hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, h, nb, (const double*)nullptr, ybuf, delta);
+    double* ypart = W + Dp;                               // 32 row-slab partials of the rectangle, Dp apart (Dp >= 192 > 33 rows)
+    constexpr int NSLAB = 32;
+    hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, h, nb, (const double*)nullptr, ybuf, delta,
+                       (const double*)nullptr, 0, 0);
     COMO_CHECK_LAUNCH();
     const int ncols = h * CB, r_lo = h * CB;
-    hipLaunchKernelGGL(chol_backsub_rect_kernel, dim3((ncols + 127) / 128, 32), dim3(128), 0, s, Lw, Dp, D, r_lo, ncols, delta, ybuf);
+    hipLaunchKernelGGL(chol_backsub_rect_kernel, dim3((ncols + 127) / 128, NSLAB), dim3(128), 0, s, Lw, Dp, D, r_lo, ncols, delta,
+                       ypart, Dp);
     COMO_CHECK_LAUNCH();
     hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, 0, h, (const double*)ybuf, (double*)nullptr,
-                       delta);
+                       delta, (const double*)ypart, NSLAB, Dp);
     COMO_CHECK_LAUNCH();
   }
   return COMO_OK;

@@ -131,6 +131,36 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// ---- exact, order-independent accumulation ------------------------------------------------------
+// A double v is split into floor(v) (int64) and (v - floor(v)) * 2^56 (uint64) and the two parts are added with integer
+// atomics: integer addition is associative, so the sum does not depend on the order in which workgroups, streams or ranks
+// deliver their contributions (floating-point atomics do).  Range |v| < 2^62, resolution 2^-56 = 1.4e-17 absolute (the
+// entries of the normal equations are >> 1e-10); up to 256 contributions per entry before the fraction word could wrap.
+constexpr double FIX_SCALE = 72057594037927936.0;            // 2^56
+constexpr int FIX_ERR_SLOTS = 8;
+constexpr int FIX_POISON = 7;                                // err slot counting non-finite contributions
+
+__device__ __forceinline__ void fix_split(double v, long long& hi, unsigned long long& lo) {
+  const double f = floor(v);
+  hi = (long long)f;
+  lo = (unsigned long long)((v - f) * FIX_SCALE);            // v - f in [0, 1] exactly; scaling by 2^56 is exact
+}
+__device__ __forceinline__ double fix_value(long long hi, unsigned long long lo) {
+  return (double)hi + (double)lo * (1.0 / FIX_SCALE);
+}
+// planes: fix[idx] (integer parts), fix[plane + idx] (fractions); poison = &fix[D*D + D + FIX_POISON]
+__device__ __forceinline__ void fix_add(long long* __restrict__ fix, long plane, long idx, double v, long long* __restrict__ poison) {
+  if (!(fabs(v) < 4.0e18)) {                                 // NaN / inf / overflow: flag it, the finalize pass poisons H
+    atomicAdd((unsigned long long*)poison, 1ull);
+    return;
+  }
+  long long hi;
+  unsigned long long lo;
+  fix_split(v, hi, lo);
+  if (hi) atomicAdd((unsigned long long*)&fix[idx], (unsigned long long)hi);
+  if (lo) atomicAdd((unsigned long long*)&fix[plane + idx], lo);
+}
+
 // ---- SE(3) exponential ------------------------------------------------------------------------
 // T = Exp(xi) for COMO's tangent ordering xi = [omega (0:3), v (3:6)] (rotation first):
 //   R = I + a [w]x + b [w]x^2,  t = (I + b [w]x + c [w]x^2) v,  a = sin(th)/th, b = (1-cos th)/th^2, c = (th-sin th)/th^3.

@@ -139,6 +139,7 @@ struct PriorArgs {
   double s_gp, s_ld, s_px, s_pose, s_aff, s_lm;   // sigmas
   double* H; double* g; long D; double* err;      // err: 8 doubles
   double* median_out;
+  long long* fix; long plane;                     // order-independent mode: fixed-point system buffer (common.cuh fix_add)
 };
 
 __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int m) {
@@ -197,32 +198,48 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
   const long* pi = A.pose_inds + 8 * (long)b;
   const long* li = A.landmark_inds + 3 * (long)m * b;
   const long D = A.D;
+  // Accumulation.  Floating-point mode: fp64 atomics into H (both triangles), g, err.  Fixed-point mode (A.fix): exact integer
+  // atomics, LOWER triangle only (como_sys_finalize mirrors it) -- every symmetric entry pair is added exactly once.
+  const bool FX = A.fix != nullptr;
+  long long* poison = FX ? A.fix + D * D + D + FIX_POISON : nullptr;
+  auto addH = [&](long r, long c, double v) {                 // floating mode: entry (r, c); fixed mode: entry (max, min)
+    if (FX) { const long rr = r > c ? r : c, cc = r > c ? c : r; fix_add(A.fix, A.plane, rr * D + cc, v, poison); }
+    else atomicAdd(&A.H[r * D + c], v);
+  };
+  auto addG = [&](long i, double v) {
+    if (FX) fix_add(A.fix, A.plane, D * D + i, v, poison);
+    else atomicAdd(&A.g[i], v);
+  };
+  auto addE = [&](int k, double v) {                          // prior errors: slots 1..6 of the fixed-point err block
+    if (FX) fix_add(A.fix, A.plane, D * D + D + 1 + k, v, poison);
+    else atomicAdd(&A.err[k], v);
+  };
   // H_TT, g_T  (log-depth-space priors)
   if (lead && tid < 36) {
     const int a = tid / 6, c = tid % 6;
     double s = 0;
     for (int k = 0; k < m; ++k) s += G[k * 6 + a] * MG[k * 6 + c];
-    atomicAdd(&A.H[pi[a] * D + pi[c]], s);
+    if (!FX || a >= c) addH(pi[a], pi[c], s);
   } else if (lead && tid < 42) {
     const int a = tid - 36;
     double s = 0;
     for (int k = 0; k < m; ++k) s += G[k * 6 + a] * w[k];
-    atomicAdd(&A.g[pi[a]], -s);
+    addG(pi[a], -s);
   }
   // H_TP (both triangles), g_P
   for (int e = tid + 256 * slice; e < 6 * m * 3; e += 256 * nsl) {
     const int a = e / (3 * m), q = e % (3 * m), j = q / 3, d = q % 3;
     const double v = MG[j * 6 + a] * dP[j * 3 + d];
-    atomicAdd(&A.H[pi[a] * D + li[q]], v);
-    atomicAdd(&A.H[li[q] * D + pi[a]], v);
+    addH(li[q], pi[a], v);
+    if (!FX) addH(pi[a], li[q], v);
   }
   if (lead)
-    for (int q = tid; q < 3 * m; q += 256) atomicAdd(&A.g[li[q]], -w[q / 3] * dP[q]);
+    for (int q = tid; q < 3 * m; q += 256) addG(li[q], -w[q / 3] * dP[q]);
   // H_PP
   for (int e = tid + 256 * slice; e < 9 * m * m; e += 256 * nsl) {
     const int q1 = e / (3 * m), q2 = e % (3 * m);
     const double v = M[(q1 / 3) * MS + (q2 / 3)] * dP[q1] * dP[q2];
-    atomicAdd(&A.H[li[q1] * D + li[q2]], v);
+    if (!FX || li[q1] >= li[q2]) addH(li[q1], li[q2], v);
   }
   // errors: gp = r0^T (Kinv/s^2) r0, ld = sum first r0^2 / s^2
   if (lead && tid < 64) {
@@ -233,7 +250,7 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
       egp += r0[i] * (w[i] - fi * r0[i]);
     }
     egp = wave_sum(egp); eld = wave_sum(eld);
-    if (tid == 0) { atomicAdd(&A.err[0], egp); atomicAdd(&A.err[1], eld); }
+    if (tid == 0) { addE(0, egp); addE(1, eld); }
   }
   // pixel prior, mode "first".  A wave-level fp64 atomic instruction costs ~180 ns whether 2 or 64 lanes are active, so
   // every scatter below is laid out with one ITEM per lane (never a per-lane serial loop of atomics): the 48 landmark-side
@@ -261,15 +278,15 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
     const double* jt = o + 6;
     if (t < 9) {
       const int d = t / 3, d2 = t % 3;
-      atomicAdd(&A.H[li[3 * j + d] * D + li[3 * j + d2]], i_px * (jp[d] * jp[d2] + jp[3 + d] * jp[3 + d2]));
+      if (!FX || d >= d2) addH(li[3 * j + d], li[3 * j + d2], i_px * (jp[d] * jp[d2] + jp[3 + d] * jp[3 + d2]));
     } else if (t < 12) {
       const int d = t - 9;
-      atomicAdd(&A.g[li[3 * j + d]], -i_px * (jp[d] * o[18] + jp[3 + d] * o[19]));
+      addG(li[3 * j + d], -i_px * (jp[d] * o[18] + jp[3 + d] * o[19]));
     } else {
       const int u = t - 12, d = u / 12, a = (u % 12) >> 1;
       const double v = i_px * (jt[a] * jp[d] + jt[6 + a] * jp[3 + d]);
-      if (u & 1) atomicAdd(&A.H[li[3 * j + d] * D + pi[a]], v);
-      else atomicAdd(&A.H[pi[a] * D + li[3 * j + d]], v);
+      if (u & 1) addH(li[3 * j + d], pi[a], v);
+      else if (!FX) addH(pi[a], li[3 * j + d], v);
     }
   }
   if (!lead) return;
@@ -281,14 +298,14 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
         const double* o = px + 21 * j;
         acc += o[20] * (o[6 + a] * o[6 + c] + o[12 + a] * o[12 + c]);
       }
-      atomicAdd(&A.H[pi[a] * D + pi[c]], i_px * acc);
+      if (!FX || a >= c) addH(pi[a], pi[c], i_px * acc);
     } else {
       const int a = tid - 36;
       for (int j = 0; j < m; ++j) {
         const double* o = px + 21 * j;
         acc += o[20] * (o[6 + a] * o[18] + o[12 + a] * o[19]);
       }
-      atomicAdd(&A.g[pi[a]], -i_px * acc);
+      addG(pi[a], -i_px * acc);
     }
   } else if (tid >= 64 && tid < 128) {
     const int j = tid - 64;
@@ -296,7 +313,7 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
     if (j < m) { const double* o = px + 21 * j; e = o[20] * (o[18] * o[18] + o[19] * o[19]); }
     for (int jj = j + 64; jj < m; jj += 64) { const double* o = px + 21 * jj; e += o[20] * (o[18] * o[18] + o[19] * o[19]); }
     e = wave_sum(e);
-    if (j == 0) atomicAdd(&A.err[2], i_px * e);
+    if (j == 0) addE(2, i_px * e);
   }
   // anchors on keyframe 0 (Mapping.py:855-900)
   if (b == 0 && tid == 0) {
@@ -331,12 +348,12 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
     const double ia = (1.0 / A.s_aff) * (1.0 / A.s_aff);
     const double xi = red[isp ? tid : 0];
     const double r = A.aff[q] - A.aff_anchor[q];
-    atomicAdd(&A.H[pi[tid] * D + pi[tid]], isp ? jtj : ia);
-    atomicAdd(&A.g[pi[tid]], isp ? -(isq * (isq * xi)) : -ia * r);
+    addH(pi[tid], pi[tid], isp ? jtj : ia);
+    addG(pi[tid], isp ? -(isq * (isq * xi)) : -ia * r);
     double ep = isp ? (isq * xi) * (isq * xi) : 0.0;
     double ea = isp ? 0.0 : ia * r * r;
     for (int o = 1; o < 8; o <<= 1) { ep += __shfl_xor(ep, o, 8); ea += __shfl_xor(ea, o, 8); }
-    if (tid == 0) { atomicAdd(&A.err[3], ep); atomicAdd(&A.err[4], ea); }
+    if (tid == 0) { addE(3, ep); addE(4, ea); }
   }
   if (b == 0 && A.nfix > 0) {
     const double il = (1.0 / A.s_lm) * (1.0 / A.s_lm);
@@ -345,13 +362,13 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
       const int f = e / 3, d = e % 3;
       const double r = A.P_m[3 * (long)A.fix_lm[f] + d] - A.P_anchor[e];
       const long ii = A.fix_inds[e];
-      atomicAdd(&A.H[ii * D + ii], il);
-      atomicAdd(&A.g[ii], -il * r);
+      addH(ii, ii, il);
+      addG(ii, -il * r);
       el += il * r * r;
     }
     red[tid & 63] = 0;
     el = wave_sum(el);
-    if ((tid & 63) == 0) atomicAdd(&A.err[5], el);
+    if ((tid & 63) == 0) addE(5, el);
   }
 }
 
@@ -413,7 +430,7 @@ int como_win_scaffold(const como_win_args* a, como_stream_t stream) {
 
 int como_win_priors(const como_win_args* a, como_stream_t stream) {
   using namespace como;
-  if (!a || a->B <= 0 || a->m <= 0 || a->m > 64 || !a->H || !a->g || !a->err) return COMO_ERR_ARG;
+  if (!a || a->B <= 0 || a->m <= 0 || a->m > 64 || (!a->sysfix && (!a->H || !a->g || !a->err))) return COMO_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   PriorArgs A;
   A.logzm = a->logzm; A.dlogz_dT = a->dlogz_dT; A.dlogz_dP = a->dlogz_dP; A.pm = a->pm; A.pm_first = a->pm_first;
@@ -425,6 +442,8 @@ int como_win_priors(const como_win_args* a, como_stream_t stream) {
   A.s_gp = a->s_gp; A.s_ld = a->s_ld; A.s_px = a->s_px; A.s_pose = a->s_pose; A.s_aff = a->s_aff; A.s_lm = a->s_lm;
   A.H = a->H; A.g = a->g; A.D = a->D; A.err = a->err;
   A.median_out = a->median_out;
+  A.fix = (long long*)a->sysfix; A.plane = a->fix_plane;
+  if (A.fix && A.plane < a->D * a->D + a->D + FIX_ERR_SLOTS) return COMO_ERR_ARG;
   const int m = a->m;
   const size_t lds = (size_t)(m * (m + 1) + m * 6 + m + m + m * 6 + m * 3 + 64 + m * 21) * sizeof(double);
   hipLaunchKernelGGL(win_priors_kernel, dim3(a->B, 32), dim3(256), lds, s, A, a->B, m);

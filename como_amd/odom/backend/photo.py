@@ -49,28 +49,26 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
               ref_slot, ref_aff, tgt_aff, tgt_pose, tgt_img, pose_ref_inds, pose_tgt_inds, landmark_inds, dzdP, H, g,
               err_out, uvec=None, pixidx=None, invz=None, kt_slot_stride=0, chunks=None, phase=0xFF, want_pj=False,
               want_blocks=False, sigma_out=None, pix_range=None, reduce_hists=None, events=None, anorm_f32=False,
-              grp_pairs=None, single_pairs=None, zeroed_hists=None, ws=None):
+              grp_pairs=None, single_pairs=None, zeroed_hists=None, ws=None, sysfix=None, fix_plane=0, D=None,
+              reduce_blocks=None):
     """Thin marshalling layer over como_ba_linearize_* (see include/como_hip.h for every field).
 
     pix_range=(begin, end): this rank's share of the reference pixels of every pair (multi-GPU shard).
     reduce_hists(view): called on the (2048,) int32 histogram of each radix-select digit pass right after it is produced
         (multi-GPU: an all-reduce(sum), so every rank resolves the same exact median); splits the chain into phases.
     events: optional dict filled with (start, end) torch.cuda.Event pairs around the block kernel ("blocks").
-    ws: caller-owned workspace dict (residuals, validity, pair tables, partials, ...); see _buf."""
+    ws: caller-owned workspace dict (residuals, validity, pair tables, partials, ...); see _buf.
+    sysfix / fix_plane / D: ORDER-INDEPENDENT assembly into the fixed-point system buffer (include/como_hip.h,
+        como_sys_finalize) instead of floating-point atomics into H / g / err_out (which may then be None).
+    reduce_blocks(t): multi-GPU with sysfix: called on the (b, 3936, 2) int64 fixed-point per-pair sums between the
+        reduce and the expand stage (an integer all-reduce(sum): exact, so every rank continues with identical bits)."""
     dev = Pwn.device
     L = _lib.lib()
     pb, pe = pix_range if pix_range is not None else (0, n)
     nl = pe - pb
-    if nl <= 0:
-        # an idle shard (more ranks than 64-pixel tiles): contributes nothing -- but it must still take part in the
-        # histogram all-reduces of the distributed median
-        if reduce_hists is not None:
-            zh = zeroed_hists if zeroed_hists is not None else _buf("hists", (L.como_select_workspace_bytes() // 4,), torch.int32, dev, ws)
-            if zeroed_hists is None:
-                zh.zero_()
-            for ps in range(3 if dtype == torch.float32 else 6):
-                reduce_hists(zh[ps * 2048:(ps + 1) * 2048])
-        return sigma_out
+    idle = nl <= 0          # an idle shard (more ranks than 64-pixel tiles) owns nothing but takes part in every collective
+    if idle:
+        pb, pe, nl = 0, 1, 1                       # placeholder geometry for the argument struct; no pixel kernel is launched
     if chunks is None and CHUNKS_OVERRIDE > 0:
         chunks = min(CHUNKS_OVERRIDE, (nl + 255) // 256)
     if chunks is None:
@@ -91,7 +89,12 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
         a.nsingle = single_pairs.numel() if single_pairs is not None else 0
     a.variant = BLOCK_VARIANT
     a.stagger = BLOCK_STAGGER
-    a.h_is_f64 = 1 if H.dtype == torch.float64 else 0
+    if sysfix is not None:
+        a.h_is_f64, a.fix_plane = 2, int(fix_plane)
+    else:
+        a.h_is_f64 = 1 if H.dtype == torch.float64 else 0
+    blocks_fix = _buf("blocks_fix", (b, 3936, 2), torch.int64, dev, ws) if reduce_blocks is not None else None
+    a.blocks_fix = _lib.ptr(blocks_fix)
     ws_r = _buf("r", (b, nl), dtype, dev, ws)
     ws_valid = _buf("valid", (b, nl), torch.uint8, dev, ws)
     # zeroed_hists: caller-owned select workspace that is ALREADY zero (the fused window path clears it elsewhere)
@@ -104,7 +107,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     blocks = _buf("blocks", (b, 3936), torch.float64, dev, ws) if want_blocks else None
     keep = [Pwn, vals, dPwn_dTwc, zjac, uvec, pixidx, invz, poses_all, aff_all, img_base, K, ref_slot, ref_aff, tgt_aff,
             tgt_pose, tgt_img, pose_ref_inds, pose_tgt_inds, landmark_inds, dzdP, H, g, err_out]
-    _lib.require_cuda(*keep)
+    _lib.require_cuda(*[t for t in keep if t is not None])
     for name, t in (("Pwn", Pwn), ("vals", vals), ("dPwn_dTwc", dPwn_dTwc), ("zjac", zjac), ("uvec", uvec),
                     ("pixidx", pixidx), ("invz", invz), ("poses_all", poses_all), ("aff_all", aff_all), ("K", K),
                     ("ref_slot", ref_slot), ("ref_aff", ref_aff), ("tgt_aff", tgt_aff), ("tgt_pose", tgt_pose),
@@ -115,28 +118,49 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
         setattr(a, name, _lib.ptr(t))
     a.img_base = img_base if isinstance(img_base, int) else _lib.ptr(img_base)
     a.kt_slot_stride = int(kt_slot_stride)
-    a.D = H.shape[1]
+    a.D = int(D) if D is not None else H.shape[1]
+    if sysfix is not None:
+        _lib.require_cuda(sysfix)
+        a.Hmat = _lib.ptr(sysfix)
     a.sigma_out, a.pj_out, a.pair_blocks_out = _lib.ptr(sigma_out), _lib.ptr(pj), _lib.ptr(blocks)
     a.ws_r, a.ws_valid, a.ws_hists, a.ws_pair, a.ws_partials = (_lib.ptr(ws_r), _lib.ptr(ws_valid), _lib.ptr(ws_hists),
                                                                  _lib.ptr(ws_pair), _lib.ptr(ws_part))
     fn = getattr(L, "como_ba_linearize_" + _lib.suffix(dtype))
     stream = _lib.stream_ptr(dev)
 
-    def run(ph):
+    def run(ph, mode=0):
         a.phase = ph | (256 if zeroed_hists is not None else 0)
+        a.reduce_mode = mode
         _lib.check(fn(ctypes.byref(a), stream), "como_ba_linearize")
 
-    if reduce_hists is None and events is None:
+    def assemble():
+        if reduce_blocks is None:
+            if not idle:
+                run(128)
+            return
+        if idle:
+            blocks_fix.zero_()
+        else:
+            run(128, 1)                            # this shard's per-pair sums, fixed point
+        reduce_blocks(blocks_fix)                  # exact integer all-reduce
+        run(128, 2)                                # every rank expands / scatters the same bits
+
+    if reduce_hists is None and events is None and reduce_blocks is None:
         run(phase)
     else:
         npass = 3 if dtype == torch.float32 else 6
-        run(1)
+        if idle and zeroed_hists is None:
+            ws_hists.zero_()
+        if not idle:
+            run(1)
         for ps in range(npass):
             if reduce_hists is not None:
                 reduce_hists(ws_hists[ps * 2048:(ps + 1) * 2048])
-            if ps + 1 < npass:
+            if ps + 1 < npass and not idle:
                 run(2 << ps)
-        if events is not None:
+        if idle:
+            pass
+        elif events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             run(64)
@@ -144,7 +168,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
             events.setdefault("blocks", []).append((e0, e1))
         else:
             run(64)
-        run(128)
+        assemble()
     last_aux.clear()
     last_aux.update({"valid": ws_valid, "r": ws_r, "sigma": sigma_out, "pj": pj, "blocks": blocks, "hists": ws_hists,
                      "chunks": chunks})
@@ -249,7 +273,8 @@ class PairTable:
 
 def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uvec, Kt, pixidx, invz, dzdP, img_base, K,
                           H_img, W_img, H, g, err_out, chunks=None, phase=0xFF, sigma_out=None, pix_range=None,
-                          reduce_hists=None, events=None, zeroed_hists=None, ws=None):
+                          reduce_hists=None, events=None, zeroed_hists=None, ws=None, sysfix=None, fix_plane=0, D=None,
+                          reduce_blocks=None):
     """Fast path: same normal equations as batch_photo_cost from the rank-1 factors of dPwn_dzm.
     Per-keyframe arrays (slots = keyframes): Pwn (B,n,3) vals (B,n) dPwn_dTwc (B,n,3,6) uvec (B,n,3) invz (B,m)
     Kt (B,rows,m) dense predictor, pixidx (B,n) int32 rows of Kt (None = identity), dzdP (B,3)."""
@@ -263,4 +288,4 @@ def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uv
                      landmark_inds=table.landmark_inds, dzdP=dzdP, H=H, g=g, err_out=err_out, chunks=chunks,
                      phase=phase, sigma_out=sigma_out, pix_range=pix_range, reduce_hists=reduce_hists, events=events,
                      grp_pairs=table.grp_pairs, single_pairs=table.single_pairs,
-                     zeroed_hists=zeroed_hists, ws=ws)
+                     zeroed_hists=zeroed_hists, ws=ws, sysfix=sysfix, fix_plane=fix_plane, D=D, reduce_blocks=reduce_blocks)

@@ -140,13 +140,21 @@ class WindowBA:
         self.table = photo.PairTable(ref + ow_kf, tgt + ow_t, [False] * len(ref) + [True] * len(ow_kf), B, self.kf_inds,
                                      self.recent_inds, self.landmark_inds, 3 * self.Himg * self.Wimg,
                                      B * 3 * self.Himg * self.Wimg, dev)
-        # H | g | err packed in ONE buffer: the multi-GPU exchange of the normal equations is a single all-reduce
+        # H | g | err(8) in ONE float64 buffer.  The fused chain does not accumulate into it: every contribution (pair blocks,
+        # priors) goes through exact integer atomics into the fixed-point buffer `sysfix` (order-independent: the normal
+        # equations are bit-identical from run to run, eager or graph replay, whatever order workgroups and streams finish
+        # in) and como_sys_finalize converts once per iteration.  err block: [0] photometric, [1..6] the prior factors.
         D = self.dim
-        self.sys = torch.zeros((D * D + D + 1,), device=dev, dtype=self.dt)
+        self.sys = torch.zeros((D * D + D + 8,), device=dev, dtype=self.dt)
         self.H = self.sys[:D * D].view(D, D)
         self.g = self.sys[D * D:D * D + D]
-        self.err = self.sys[D * D + D:].view(())
-        self.prior_err = torch.zeros(8, device=dev, dtype=self.dt)
+        self.err8 = self.sys[D * D + D:]
+        self.err = self.err8[0]
+        self.prior_err = self.err8[1:7] if (self.fused and dev.type == "cuda") else torch.zeros(8, device=dev, dtype=self.dt)
+        self.sysfix, self.fix_plane = None, 0
+        if self.fused and dev.type == "cuda":
+            self.fix_plane = int(_lib.lib().como_sys_fix_plane_elems(D))
+            self.sysfix = torch.zeros((2 * self.fix_plane,), device=dev, dtype=torch.int64)
         self.sigma = torch.zeros(2, device=dev, dtype=self.pix_dtype)
         self.pix_range = self.shard.pixel_range(self.n) if self.shard is not None else None
         self._prepare_fused()
@@ -188,7 +196,9 @@ class WindowBA:
             setattr(a, k, ptr(self.w[k]))
         sg = self.cfg["sigmas"]
         a.s_gp, a.s_ld, a.s_px, a.s_pose, a.s_aff, a.s_lm = 1.0, 1.0, 1e-2, sg["pose_prior"], sg["scale_prior"], sg["scale_prior"]
-        a.H, a.g, a.err = ptr(self.H), ptr(self.g), ptr(self.prior_err)
+        self._scratch_err = torch.zeros(8, device=dev, dtype=self.dt)
+        a.H, a.g, a.err = ptr(self.H), ptr(self.g), ptr(self._scratch_err)
+        a.sysfix, a.fix_plane = ptr(self.sysfix), self.fix_plane
         # the two radix-select workspaces of an iteration are cleared by the scaffold kernel (no fill launches)
         hb = _lib.lib().como_select_workspace_bytes()
         self.w["hist_dr2"] = torch.zeros(2 * B * hb // 4, dtype=torch.int32, device=self.dev)   # dense-ref median | full-image median
@@ -211,7 +221,7 @@ class WindowBA:
         L, a, w, dev = _lib.lib(), self.win_args, self.w, self.dev
         s = _lib.stream_ptr(dev)
         _lib.check(L.como_win_scaffold(ctypes.byref(a), s), "como_win_scaffold")
-        self.sys.zero_()
+        self.sysfix.zero_()
         dr = lambda part: dense_reference_factored(w["px_logzm"], w["px_poses"][:self.B], self.Kt, self.pixidx, self.K_pix,
                                                    w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"],
                                                    hists=w["hist_dr"], ws=w["dr_ws"], part=part)
@@ -242,19 +252,23 @@ class WindowBA:
                     _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
         photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=Pwn, vals=self.vals_n,
                                     dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],
-                                    img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=self.H, g=self.g,
-                                    err_out=self.err, sigma_out=self.sigma, pix_range=self.pix_range,
+                                    img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=None, g=None,
+                                    err_out=None, sigma_out=self.sigma, pix_range=self.pix_range,
                                     reduce_hists=(self.shard.all_reduce_sum if self.shard is not None else None),
-                                    events=self.events, zeroed_hists=w["hist_ba"], ws=w["ba_ws"])
+                                    events=self.events, zeroed_hists=w["hist_ba"], ws=w["ba_ws"], sysfix=self.sysfix,
+                                    fix_plane=self.fix_plane, D=self.dim,
+                                    # multi-GPU: the shards' per-pair sums (b x 3936 fixed-point values, 0.9 MB at 14 pairs)
+                                    # are all-reduced as integers -- exact -- and every rank expands the same bits
+                                    reduce_blocks=(self.shard.all_reduce_sum if self.shard is not None else None))
         if fork:
             torch.cuda.current_stream(dev).wait_stream(side)
         else:
-            if self.shard is not None:
-                self.shard.all_reduce_sum(self.sys)      # normal equations of all shards: H | g | err in one collective
             if self.full_median:
                 fm("all")
             if self.with_priors:
                 _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")   # also stores the new median depths
+        _lib.check(L.como_sys_finalize(self.sysfix.data_ptr(), self.fix_plane, self.dim, self.H.data_ptr(), self.g.data_ptr(),
+                                       self.err8.data_ptr(), s), "como_sys_finalize")
         return self.H, self.g
 
     def iterate_fused(self):

@@ -134,6 +134,16 @@ typedef struct como_ba_args {
                                 float32): the depth x depth block and the K~ reads are shared inside a row */
   const int* single_pairs;   /* (nsingle): the pairs not listed in grp_pairs */
   int ngrp, nsingle;         /* every pair appears exactly once in grp_pairs U single_pairs; ngrp = 0 / NULL: one pair at a time */
+  /* h_is_f64 == 2: ORDER-INDEPENDENT assembly.  Hmat points at a fixed-point system buffer (see como_sys_finalize): two
+     planes of `fix_plane` int64 each, {H lower triangle (D*D, row-major, row >= col) | g (D) | err + spare (8)}; every
+     contribution is added with exact integer atomics (associative -> the result does not depend on the order in which
+     workgroups, streams or ranks deliver it).  gvec / err_out are ignored. */
+  long fix_plane;
+  /* reduce_mode (phase 128): 0 = reduce the per-workgroup records of every pair and expand / scatter them (single GPU);
+     1 = reduce only: blocks_fix (b, 3952, 2) int64 receives the per-pair sums in fixed point (all-reduce them with an
+     integer SUM -- exact, so every rank ends with identical bits); 2 = expand / scatter from blocks_fix. */
+  int reduce_mode;
+  void* blocks_fix;
 } como_ba_args;
 
 long como_ba_partials_elems(int b, int chunks, int m);
@@ -264,10 +274,20 @@ typedef struct como_win_args {
   void* zero_a; long zero_a_bytes;                /* optional: two buffers (multiples of 16 bytes) that como_win_scaffold clears */
   void* zero_b; long zero_b_bytes;                /*   together with err -- the radix-select histograms of this iteration */
   double* median_out;                             /* optional (B): como_win_priors stores median_new here (next iteration's `median`) */
+  void* sysfix; long fix_plane;                   /* optional: fixed-point system buffer (como_sys_finalize); then the priors are added
+                                                     there (lower triangle, exact integer atomics) and H / g / err are not touched;
+                                                     the 6 prior errors go to slots 1..6 of the err block */
 } como_win_args;
 
 int como_win_scaffold(const como_win_args* args_host, como_stream_t stream);
 int como_win_priors(const como_win_args* args_host, como_stream_t stream);
+/* Order-independent normal equations.  sysfix = 2 planes x fix_plane int64 (fix_plane >= D*D + D + 8): plane 0 holds
+ * floor(v) sums, plane 1 the fractional parts in units of 2^-56, of {H[i][j] for i >= j at i*D+j | g at D*D | errors at
+ * D*D+D (slot 0 photometric, 1..6 priors, 7 = count of non-finite contributions)}.  como_sys_finalize converts to float64:
+ * H (D,D) BOTH triangles (exactly symmetric), g (D), err8 (8); a non-finite contribution anywhere poisons H[0][0] with NaN
+ * so that the factorisation reports it.  The buffer must be zeroed before the first contribution of an iteration. */
+long como_sys_fix_plane_elems(long D);
+int como_sys_finalize(const void* sysfix, long fix_plane, long D, double* H, double* g, double* err8, como_stream_t stream);
 int como_win_update(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
                     long lm_start, como_stream_t stream);
 

@@ -636,7 +636,9 @@ def test_fullsize_window_properties(window):
     for _ in range(3):
         wa.step()
         wb.iterate()
-    assert (wa.kf_poses - wb.kf_poses).abs().max().item() < 1e-7  # (tightened to bitwise once the assembly is order-independent)
+    # order-independent (exact fixed-point) assembly: replay and eager launches give the same BITS, whatever order the
+    # workgroups and the two stream branches finish in
+    assert torch.equal(wa.kf_poses, wb.kf_poses) and torch.equal(wa.H, wb.H)
 
 
 # ------------------------------------------------------------------------------------------------
