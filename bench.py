@@ -197,8 +197,7 @@ def block_kernel_roofline(wb, dtype_name, reps=5):
     ev = wb.events.get("blocks", [])
     wb.events = None
     blk_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
-    pb, pe = wb.pix_range if wb.pix_range is not None else (0, wb.n)
-    pixel_pairs = wb.table.b * (pe - pb)
+    pixel_pairs = wb.table.b * (0 if wb.idle else wb.n)          # wb.n = this rank's reference pixels per keyframe
     bytes_per = ALGO_SCALARS_PER_PIXEL_PAIR * (4 if dtype_name == "f32" else 8)
     achieved = pixel_pairs * bytes_per / (blk_ms * 1e-3) / 1e9 if blk_ms > 0 else 0.0
     kname = "ba_blocks_pair2_kernel<2,4>" if dtype_name == "f32" else "ba_blocks_pair2_f64_kernel"
@@ -269,6 +268,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not capture the iteration into a hipGraph")
     ap.add_argument("--no-secondary", action="store_true", help="only the headline leg (no f64 / window-4 / tracking / odometry legs)")
     ap.add_argument("--replicas", action="store_true", help="config 5: one independent window per GPU, no collective (weak scaling)")
+    ap.add_argument("--force-shard", action="store_true", help="testing on a one-GPU box: run the multi-GPU code path (RCCL "
+                    "collectives, sharded medians, fixed-point exchange) through a single-rank process group")
     args = ap.parse_args()
 
     shard, device = cdist.init_from_env()
@@ -278,6 +279,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={shard.world}")
     pix_dtype = torch.float32 if args.dtype == "f32" else torch.float64
     sharded = shard.world > 1 and not args.replicas
+    if args.force_shard and shard.world == 1:
+        import torch.distributed as tdist
+        if not tdist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            tdist.init_process_group("nccl", rank=0, world_size=1)
+        shard = cdist.Shard(0, 1, force_collectives=True)
+        sharded = True
 
     # ---- headline leg ----
     wb, state, graphed = run_window(args, device, pix_dtype, args.window, shard=(shard if sharded else None),
@@ -350,8 +359,18 @@ def main():
         if not args.no_cpu and args.gpus == 1 and args.keyframes == 8:
             st_cpu = {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in state.items()}
             out["cpu_baseline"] = cpu_baseline(args, st_cpu)
-        print(json.dumps(out))
+        # RCCL writes its version banner through C stdio (flushed at exit): push it out first so that the JSON line is last
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                   # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     shard.barrier()
+    import torch.distributed as tdist
+    if tdist.is_initialized():
+        tdist.destroy_process_group()
 
 
 def wb_n(state, args):

@@ -7,8 +7,11 @@ linearises its own contiguous share of the reference pixels of EVERY keyframe pa
   * the robust scale is a GLOBAL exact median (photo.py:124-128): the 2048-bin histogram of each radix-select digit
     pass is summed across ranks (8 KiB all-reduce, 3 for float keys / 6 for double) -- every rank then resolves the
     same k-th key, bit for bit;
-  * the normal equations: H | g | err packed in one buffer, ONE all-reduce(sum) (D^2 + D + 1 doubles, 4.6 MB at
-    D = 760), after which every rank adds the priors and solves redundantly (no broadcast of delta).
+  * the normal equations: the shards' per-pair Gram sums (b x 3936 values as fixed-point integer pairs: 0.9 MB at 14
+    pairs, 3.9 MB at 62) in ONE integer all-reduce(sum) -- exact, so every rank continues with identical bits -- after
+    which every rank expands them into H, adds the priors and solves redundantly (no broadcast of delta);
+  * the per-keyframe median depth of the dense reference / the full depth image (Mapping.store_vars): each rank evaluates its
+    pixel / row range, the digit histograms of all keyframes are all-reduced per pass (3 x 64 KiB for float keys).
 Payloads are latency-bound on xGMI (tens of microseconds); see DESIGN.md for the accounting.
 """
 import os
@@ -18,8 +21,11 @@ import torch.distributed as dist
 
 
 class Shard:
-    def __init__(self, rank, world, group=None):
+    def __init__(self, rank, world, group=None, force_collectives=False):
+        """force_collectives: issue the collectives even with world == 1 (tests: a single-rank `nccl` group exercises the
+        RCCL path -- dtypes, stream semantics, graph capture -- on a one-GPU box)."""
         self.rank, self.world, self.group = rank, world, group
+        self.force = force_collectives
 
     def pixel_range(self, n):
         per = (n + self.world - 1) // self.world
@@ -28,8 +34,14 @@ class Shard:
         e = min(n, b + per)
         return b, max(b, e)                                # b == e: an idle rank (more ranks than 64-pixel tiles) owns nothing
 
+    def row_range(self, rows):
+        """This rank's share of `rows` items (any granularity), contiguous, covering [0, rows) exactly once over the ranks."""
+        per = (rows + self.world - 1) // self.world
+        b = min(rows, self.rank * per)
+        return b, min(rows, b + per)
+
     def all_reduce_sum(self, t):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 

@@ -54,11 +54,13 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
     return ws["Pwn"], ws["dT"], ws["uvec"], med[:, 0], ws["logz"]
 
 
-def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all"):
+def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=None):
     """Mapping.store_vars (Mapping.py:749-758): per keyframe the exact median of exp(K~ logz_m) over ALL rows of K~
     (the full depth image).  logzm (B,m), Kt (B,rows,m); med_out (B,3) caller-owned {median, 1.4826 median, n};
     ws: caller-owned dict (depth plane + select histograms; a captured graph records the addresses).
-    part: "all", or "points" (kernel + pass-0 histogram) then "median" (remaining select passes + finish)."""
+    part: "all", or "points" (kernel + pass-0 histogram) then "median" (remaining select passes + finish).
+    reduce: multi-GPU -- Kt is then this rank's ROW RANGE of every keyframe's predictor (a view) and the digit histograms
+    are all-reduced between the passes (median_passes), so every rank gets the median of the whole image."""
     _lib.require_cuda(logzm, Kt)
     dt, dev = Kt.dtype, Kt.device
     B, rows, m = Kt.shape
@@ -76,8 +78,39 @@ def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all"):
         lz = lz.to(dt).contiguous()
     fn = getattr(L, "como_dense_ref_" + _lib.suffix(dt))
     h = hists if hists is not None else w["hists"]
+    if reduce is not None:
+        part_flag = 2                                    # kernel + pass-0 histogram here, the passes below
+    else:
+        part_flag = {"all": 0, "points": 2, "median": 4}[part]
     rc = fn(Kt.data_ptr(), Kt.stride(0), None, lz.data_ptr(), w["eye"].data_ptr(), w["K"].data_ptr(), w["dl"].data_ptr(), B, rows, m,
             1, None, None, None, w["z"].data_ptr(), None, h.data_ptr(), med_out.data_ptr(), None,
-            8 | (1 if hists is not None else 0) | {"all": 0, "points": 2, "median": 4}[part], _lib.stream_ptr(dev))
+            8 | (1 if hists is not None else 0) | part_flag, _lib.stream_ptr(dev))
     _lib.check(rc, "como_dense_ref (depth only)")
+    if reduce is not None:
+        if hists is None:
+            raise RuntimeError("como_amd: the sharded full-image median needs a caller-zeroed histogram workspace")
+        median_passes(w["z"], h, med_out, reduce)
+    return med_out[:, 0]
+
+
+def median_passes(z, hists, med_out, reduce=None, idle=False):
+    """The select passes after a `part="points"` call, one at a time, with `reduce(t)` (an all-reduce(sum) across the ranks
+    that share the keyframes' pixels) applied to every digit histogram right after it is complete: every rank then resolves
+    the same exact per-keyframe median of the UNION of the shards.  z (B,n_local) depths written by the points kernel,
+    hists its select workspace (pass 0 already accumulated), med_out (B,3)."""
+    L = _lib.lib()
+    B, n = z.shape
+    dt = z.dtype
+    sfx = _lib.suffix(dt)
+    npass = 3 if dt == torch.float32 else 6
+    hv = hists.view(B, 6, 2048)
+    s = _lib.stream_ptr(z.device)
+    for p in range(npass):
+        if reduce is not None:
+            stage = hv[:, p].contiguous()
+            reduce(stage)
+            hv[:, p].copy_(stage)
+        if p + 1 < npass and not idle:                       # an idle rank (no pixels) only takes part in the collectives
+            _lib.check(getattr(L, "como_select_hist_" + sfx)(z.data_ptr(), None, n, B, hists.data_ptr(), p + 1, s), "como_select_hist")
+    _lib.check(getattr(L, "como_select_finish_" + sfx)(hists.data_ptr(), B, med_out.data_ptr(), s), "como_select_finish")
     return med_out[:, 0]

@@ -23,7 +23,7 @@ import como_amd.odom.backend.photo as photo
 import como_amd.odom.backend.sparse_map as smap
 from como_amd import _lib
 from como_amd.geometry.camera import backprojection
-from como_amd.odom.backend.dense_ref import dense_reference_factored, full_image_median
+from como_amd.odom.backend.dense_ref import dense_reference_factored, full_image_median, median_passes
 from como_amd.odom.backend.graph_pair_construction import setup_photometric_pairs
 from como_amd.odom.factors.depth_prior import log_depth_prior
 from como_amd.odom.factors.gp_priors import gp_ml_cost, mean_log_depth_cost
@@ -43,6 +43,8 @@ class WindowBA:
         """state: dict as produced by como_amd.synth.make_window (plus K_mm_inv / L_mm / Knm_Kmminv).
         shard: como_amd.dist.Shard for the one-process-per-GPU data-parallel mode (None = single GPU)."""
         self.shard = shard
+        if shard is not None and not (fused and window_full):
+            raise RuntimeError("como_amd: the multi-GPU window BA runs the fused chain (full window) only")
         self.events = None
         self.graph = None
         self.cfg = cfg or DEFAULT_CFG
@@ -103,9 +105,22 @@ class WindowBA:
         w = self.cfg["photo_construction"]["nonmax_suppression_window"]
         coords_n, _ = smap.subselect_pixels(self.img[:B], w)                   # Mapping.py:665-668
         self.coords_n = coords_n
-        self.n = coords_n.shape[1]
+        self.n_total = coords_n.shape[1]
         self.pixidx = (coords_n[..., 0] * self.Wimg + coords_n[..., 1]).to(torch.int32).contiguous()
         self.vals_n = torch.gather(self.img[:B, 0].reshape(B, -1), 1, self.pixidx.long()).contiguous()
+        self.idle = False
+        if self.shard is not None:
+            # One process per GPU: this rank owns a contiguous range of the reference pixels of EVERY keyframe -- to all
+            # per-pixel kernels (dense reference, residual, blocks) it simply is a window with fewer reference pixels; only
+            # the collectives (median histograms, per-pair sums) know about the other ranks.
+            pb, pe = self.shard.pixel_range(self.n_total)
+            self.idle = pe <= pb                           # more ranks than 64-pixel tiles: takes part in the collectives only
+            if self.idle:
+                pb, pe = 0, 1                              # placeholder arrays of one pixel; no pixel kernel is launched
+            self.pixidx = self.pixidx[:, pb:pe].contiguous()
+            self.vals_n = self.vals_n[:, pb:pe].contiguous()
+            self.row_range = self.shard.row_range(self.Himg * self.Wimg)
+        self.n = self.pixidx.shape[1]
         self.remap, paired = smap.get_batch_remap_function(self.correspondence_mask)
         landmark_ids, _ = paired
         self.point_inds = lin_sys.landmark_to_batched_3d_point_inds(landmark_ids, B)
@@ -156,7 +171,7 @@ class WindowBA:
             self.fix_plane = int(_lib.lib().como_sys_fix_plane_elems(D))
             self.sysfix = torch.zeros((2 * self.fix_plane,), device=dev, dtype=torch.int64)
         self.sigma = torch.zeros(2, device=dev, dtype=self.pix_dtype)
-        self.pix_range = self.shard.pixel_range(self.n) if self.shard is not None else None
+        self.pix_range = (0, 0) if self.idle else None     # (the shard is already cut out of pixidx / vals_n)
         self._prepare_fused()
 
     def _prepare_fused(self):
@@ -173,7 +188,7 @@ class WindowBA:
         # sparse_map.py:220 -- only the pair graph reads it) and `self.median_depths` = the median of the FULL depth image
         # exp(K~ logz_m) (store_vars, Mapping.py:749-758), which the priors and the landmark re-initialisation use.  With
         # every pixel a reference pixel (window 1) the two coincide and the dense-reference median serves both.
-        self.full_median = self.n != self.Himg * self.Wimg
+        self.full_median = self.n_total != self.Himg * self.Wimg
         self.first_mask_u8 = self.obs_ref_mask.to(torch.uint8).contiguous()
         self.fix_lm = self.fix_idx.to(torch.int32).contiguous()
         self.aff_anchor2 = self.aff_anchor.reshape(2).contiguous()
@@ -227,6 +242,8 @@ class WindowBA:
                                                    hists=w["hist_dr"], ws=w["dr_ws"], part=part)
         fork = self.shard is None and self.overlap_priors
         fm = lambda part: full_image_median(w["px_logzm"], self.Kt, w["med3_full"], w["dr_ws"], hists=w["hist_full"], part=part)
+        if self.shard is not None:
+            return self._linearize_sharded(dr)
         if fork and self.full_median:
             # the full-image median needs only the scaffold's log-depths: its whole branch (depth image, select passes,
             # priors) runs beside the dense reference points and the photometric system
@@ -253,13 +270,8 @@ class WindowBA:
         photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=Pwn, vals=self.vals_n,
                                     dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],
                                     img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=None, g=None,
-                                    err_out=None, sigma_out=self.sigma, pix_range=self.pix_range,
-                                    reduce_hists=(self.shard.all_reduce_sum if self.shard is not None else None),
-                                    events=self.events, zeroed_hists=w["hist_ba"], ws=w["ba_ws"], sysfix=self.sysfix,
-                                    fix_plane=self.fix_plane, D=self.dim,
-                                    # multi-GPU: the shards' per-pair sums (b x 3936 fixed-point values, 0.9 MB at 14 pairs)
-                                    # are all-reduced as integers -- exact -- and every rank expands the same bits
-                                    reduce_blocks=(self.shard.all_reduce_sum if self.shard is not None else None))
+                                    err_out=None, sigma_out=self.sigma, events=self.events, zeroed_hists=w["hist_ba"],
+                                    ws=w["ba_ws"], sysfix=self.sysfix, fix_plane=self.fix_plane, D=self.dim)
         if fork:
             torch.cuda.current_stream(dev).wait_stream(side)
         else:
@@ -267,6 +279,38 @@ class WindowBA:
                 fm("all")
             if self.with_priors:
                 _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")   # also stores the new median depths
+        _lib.check(L.como_sys_finalize(self.sysfix.data_ptr(), self.fix_plane, self.dim, self.H.data_ptr(), self.g.data_ptr(),
+                                       self.err8.data_ptr(), s), "como_sys_finalize")
+        return self.H, self.g
+
+    def _linearize_sharded(self, dr):
+        """The multi-GPU iteration: the same kernels on this rank's pixel range, plus three kinds of collectives (all
+        `Shard.all_reduce_sum`, RCCL on the GPU): the digit histograms of the per-keyframe median depth, those of the
+        global robust scale, and the fixed-point per-pair sums.  Everything after them is replicated and bit-identical."""
+        L, a, w, dev = _lib.lib(), self.win_args, self.w, self.dev
+        s = _lib.stream_ptr(dev)
+        red = self.shard.all_reduce_sum
+        if self.full_median:
+            rb, re = self.row_range
+            full_image_median(w["px_logzm"], self.Kt[:, rb:re], w["med3_full"], w["dr_ws"], hists=w["hist_full"], reduce=red)
+        Pwn = dT = uvec = None
+        if not self.idle:
+            Pwn, dT, uvec, _, _ = dr("points")
+        else:
+            z1 = torch.zeros((self.B, 1), device=dev, dtype=self.pix_dtype)
+            Pwn, dT, uvec = z1.new_zeros((self.B, 3, 1)), z1.new_zeros((self.B, 18, 1)), z1.new_zeros((self.B, 3, 1))
+        if not self.full_median:
+            key = (str(dev), self.Kt.dtype, self.B, self.n)
+            z = w["dr_ws"][key]["z"] if not self.idle else z1
+            median_passes(z, w["hist_dr"], w["med3"], red, idle=self.idle)
+        photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=Pwn, vals=self.vals_n,
+                                    dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],
+                                    img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=None, g=None,
+                                    err_out=None, sigma_out=self.sigma, pix_range=self.pix_range, reduce_hists=red,
+                                    events=self.events, zeroed_hists=w["hist_ba"], ws=w["ba_ws"], sysfix=self.sysfix,
+                                    fix_plane=self.fix_plane, D=self.dim, reduce_blocks=red)
+        if self.with_priors:
+            _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")
         _lib.check(L.como_sys_finalize(self.sysfix.data_ptr(), self.fix_plane, self.dim, self.H.data_ptr(), self.g.data_ptr(),
                                        self.err8.data_ptr(), s), "como_sys_finalize")
         return self.H, self.g
@@ -373,8 +417,8 @@ class WindowBA:
     def capture(self, warmup=3):
         """Capture one GN iteration into a hipGraph (torch.cuda.CUDAGraph).  Returns True on success; on failure the
         object stays usable in eager mode (the reason is kept in self.capture_error)."""
-        if self.shard is not None:
-            return False                      # collectives between kernels: the multi-GPU path stays eager
+        # multi-GPU: the collectives are captured with the kernels (RCCL supports stream capture); if the runtime refuses,
+        # the except branch below leaves the object in eager mode
         self.graph = None
         try:
             side = torch.cuda.Stream(device=self.dev)
@@ -387,7 +431,8 @@ class WindowBA:
             ev = self.events
             self.events = None
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # (thread_local: the process group's watchdog thread may query events while this thread captures)
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if self.shard is not None else "global"):
                 self.iterate()
             self.events = ev
             self.graph = g

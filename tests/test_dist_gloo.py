@@ -1,5 +1,5 @@
 """The N > 1 protocol of como_amd/dist.py with world_size 2 on gloo (CPU): pixel-range shards, the distributed EXACT
-median (per-digit histogram all-reduce) and the single all-reduce of the packed normal equations.
+median (per-digit histogram all-reduce) and the single all-reduce of the fixed-point per-pair sums.
 
 The HIP kernels cannot run here; each rank emulates its kernel phases with the CPU oracle / numpy on ITS pixel range and
 drives the real `Shard` collectives -- the result must equal the single-process result."""
@@ -88,16 +88,26 @@ def _worker(rank, world, port, q):
         med, nv = _distributed_median(shard, r.numpy().reshape(-1), valid.numpy().reshape(-1))
         sigma = torch.tensor(1.4826, dtype=torch.float64) * float(med)
         Gm, gv, err = photo_ba.pair_blocks(r, valid, J, sigma)
+        # the exchange of the product (csrc/ba.hip ba_reduce_assemble MODE 1 / 2): this rank's per-pair sums are split into
+        # floor(v) and (v - floor(v)) 2^56, all-reduced as INTEGERS (exact, order-independent), and every rank expands the
+        # same bits into the normal equations
+        nb = Gm.shape[0]
+        vec = torch.cat((Gm.reshape(nb, -1), gv.reshape(nb, -1)), dim=1).reshape(-1)
+        vec = torch.cat((vec, err.reshape(1).double()))
+        hi = torch.floor(vec)
+        fix = torch.stack((hi.to(torch.int64), ((vec - hi) * 2.0 ** 56).to(torch.int64)), dim=1).contiguous()
+        shard.all_reduce_sum(fix)
+        tot = fix[:, 0].double() + fix[:, 1].double() * 2.0 ** -56
+        Gm_t = tot[:-1].reshape(nb, -1)[:, :Gm[0].numel()].reshape(Gm.shape)
+        gv_t = tot[:-1].reshape(nb, -1)[:, Gm[0].numel():].reshape(gv.shape)
         D = G["H_photo"].shape[0]
-        sysbuf = torch.zeros(D * D + D + 1, dtype=torch.float64)
-        H, gg = sysbuf[:D * D].view(D, D), sysbuf[D * D:D * D + D]
-        photo_ba.assemble(Gm, gv, G["dzm_dPwm"][rid], G["kf_inds"][rid], G["kf_inds"][tid], G["landmark_inds"][rid], H, gg)
-        sysbuf[-1] = err
-        shard.all_reduce_sum(sysbuf)
+        H, gg = torch.zeros((D, D), dtype=torch.float64), torch.zeros(D, dtype=torch.float64)
+        photo_ba.assemble(Gm_t, gv_t, G["dzm_dPwm"][rid], G["kf_inds"][rid], G["kf_inds"][tid], G["landmark_inds"][rid], H, gg)
         out["sigma"] = (float(sigma), float(G["sigma_r"]))
         out["H_rel"] = float((H - G["H_photo"]).abs().max() / G["H_photo"].abs().max())
         out["g_rel"] = float((gg - G["g_photo"]).abs().max() / G["g_photo"].abs().max())
-        out["err"] = (float(sysbuf[-1]), float(G["photo_err"]))
+        out["err"] = (float(tot[-1]), float(G["photo_err"]))
+        out["H_bits"] = H.numpy().tobytes()
         out["range"] = (b, e, n)
         q.put((rank, out))
     finally:
@@ -136,3 +146,4 @@ def test_two_rank_protocol_matches_single_process():
         assert o["H_rel"] < 1e-12 and o["g_rel"] < 1e-12
         assert o["err"][0] == pytest.approx(o["err"][1], rel=1e-12)
     assert res[0]["range"][1] == res[1]["range"][0]          # contiguous shards
+    assert res[0]["H_bits"] == res[1]["H_bits"]              # integer all-reduce: both ranks hold the same bits

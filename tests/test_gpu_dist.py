@@ -63,3 +63,51 @@ def test_sharded_window_ba_matches_single_process():
     assert np.array_equal(res[0]["sharded"][0], res[1]["sharded"][0])          # poses after two iterations
     # ... and the single-process result is bit-identical on both ranks too (no order-dependent accumulation anywhere)
     assert np.array_equal(res[0]["single"][1], res[1]["single"][1]) and np.array_equal(res[0]["single"][0], res[1]["single"][0])
+
+
+def _nccl_worker(port, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    import torch.distributed as dist
+    from como_amd import synth
+    from como_amd.dist import Shard
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    from como_amd.odom.window_ba import WindowBA
+    device = torch.device("cuda:0")
+    torch.cuda.set_device(device)
+    dist.init_process_group("nccl", rank=0, world_size=1)            # backend "nccl" IS RCCL on ROCm
+    try:
+        def predictor(cov, cm):
+            Kinv, L, Kt = prep_predictor(cov.double(), cm.double(), 1.0)
+            return Kinv, L, Kt.float()
+        out = {}
+        for name, sh in (("single", None), ("rccl", Shard(0, 1, force_collectives=True))):
+            st = synth.make_window(B=4, H=96, W=128, m=16, dtype=torch.float64, device=device, seed=3, predictor=predictor)
+            wb = WindowBA(st, pix_dtype=torch.float32, window_full=True, shard=sh)
+            wb.iterate()
+            wb.iterate()
+            graphed = wb.capture(warmup=1)
+            for _ in range(2):
+                wb.step()
+            torch.cuda.synchronize()
+            out[name] = (wb.kf_poses.cpu().numpy().copy(), wb.H.cpu().numpy().copy(), bool(graphed),
+                         getattr(wb, "capture_error", "")[-400:])
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_single_rank_group():
+    """The sharded iteration through a real `nccl` (= RCCL) process group of ONE rank (the test box has one GPU; RCCL refuses
+    two ranks on a device): int32 histogram and int64 fixed-point all-reduces on the GPU, issued eagerly and inside a
+    captured hipGraph.  With one rank the shard is the whole window, so the result must equal the unsharded one BITWISE."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(29900 + (os.getpid() % 90), q))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    from tests.conftest import report
+    report("rccl_single_rank", graph_single=out["single"][2], graph_rccl=out["rccl"][2], capture_error=out["rccl"][3])
+    assert np.array_equal(out["single"][0], out["rccl"][0]) and np.array_equal(out["single"][1], out["rccl"][1])
+    assert out["single"][2]                                             # the unsharded iteration always captures
