@@ -64,6 +64,11 @@ SIGNATURES = {
     "como_track_iter_f64": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 9),
     "como_track_iter_masked_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 10),
     "como_track_iter_masked_f64": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 10),
+    "como_track_level_workspace_bytes": (c_long, []),
+    "como_track_level_workspace_create": (c_void_p, []),
+    "como_track_level_workspace_destroy": (None, [c_void_p]),
+    "como_track_level_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
+                                     c_void_p, c_int, c_void_p, c_void_p]),
     "como_ba_partials_elems": (c_long, [c_int, c_int, c_int]),
     "como_sys_fix_plane_elems": (c_long, [c_long]),
     "como_sys_finalize": (c_int, [c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -172,8 +172,16 @@ __device__ inline void se3_exp_f64(const double* xi, double* Tm) {
   const double wx = xi[0], wy = xi[1], wz = xi[2];
   const double th2 = wx * wx + wy * wy + wz * wz;
   double a, b, c;
-  if (th2 < 1e-12) {
-    a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0;
+  if (th2 < 0.25) {
+    // |omega| < 0.5 (every Gauss-Newton update): the power series in th^2 to th^18 -- truncation < 1e-20, no cancellation
+    // (the closed forms (1 - cos th) / th^2 and (th - sin th) / th^3 lose digits for small th) and no f64 sin / cos
+    const double x = th2;
+    a = 1.0 + x * (-1.0 / 6 + x * (1.0 / 120 + x * (-1.0 / 5040 + x * (1.0 / 362880 + x * (-1.0 / 39916800 + x * (1.0 / 6227020800.0
+        + x * (-1.0 / 1307674368000.0 + x * (1.0 / 355687428096000.0))))))));
+    b = 0.5 + x * (-1.0 / 24 + x * (1.0 / 720 + x * (-1.0 / 40320 + x * (1.0 / 3628800 + x * (-1.0 / 479001600 + x * (1.0 / 87178291200.0
+        + x * (-1.0 / 20922789888000.0 + x * (1.0 / 6402373705728000.0))))))));
+    c = 1.0 / 6 + x * (-1.0 / 120 + x * (1.0 / 5040 + x * (-1.0 / 362880 + x * (1.0 / 39916800 + x * (-1.0 / 6227020800.0
+        + x * (1.0 / 1307674368000.0 + x * (-1.0 / 355687428096000.0 + x * (1.0 / 121645100408832000.0))))))));
   } else {
     const double th = sqrt(th2);
     a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = (th - sin(th)) / (th2 * th);

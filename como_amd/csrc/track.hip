@@ -246,9 +246,438 @@ int track_iter(const T* Tji, const T* Kmat, const T* aff, const T* P, const T* v
   return COMO_OK;
 }
 
+
+// ---------------------------------------- one pyramid level in ONE launch ------------------------------------------
+// photo_level_tracking (photo_tracking.py:147-185): the whole Gauss-Newton loop of a level -- every iteration's warp /
+// residual / exact median / Huber-weighted 8x8 system / solve / pose update AND the stop test -- in one persistent kernel.
+// The chain above is 6 launches + a host read-back of three scalars per iteration (62 us per iteration at 640x480, all of
+// it launch / dependency latency: an iteration moves 16 MB).  Here:
+//   * every thread keeps its (up to TL_MAXP) reference pixels -- P, I_ref, the 7 constant Jacobian entries, the mask bit --
+//     in REGISTERS for the whole level: from the second iteration on only the target image (L2-resident) is read;
+//   * the four dependency points of an iteration (three radix-select digit histograms, the 46 sums) are device-wide
+//     barriers instead of kernel boundaries;
+//   * everything that crosses workgroups travels through device-scope ATOMICS (histogram bins, exact fixed-point sums,
+//     barrier counters) and is read back with device-scope atomic loads; the 46 sums are order-independent, so every
+//     workgroup reads the same bits; one wave per workgroup brackets the barrier with a release / acquire fence (L2 drain /
+//     invalidate: measured necessary -- the XCD-private L2 posts atomics and keeps copies of device-scope loads);
+//   * the 8x8 solve, the pose update and the stop test are computed by EVERY workgroup redundantly from those sums, so all
+//     workgroups take the same exit without another exchange.
+// MI355X: the 8 XCDs have private L2s; device-scope traffic is served by the memory-side cache, ~1.5 us per round trip --
+// the barrier is one non-returning atomic per workgroup (8 counters, one per XCD-aligned residue class) + one polling round.
+// All workgroups must be co-resident: the host launches at most one workgroup per compute unit.
+constexpr int TL_MAXP = 5;          // reference pixels per thread
+constexpr int TL_NC = 8;            // arrival counters of the device-wide barrier (workgroup b -> counter b % 8)
+constexpr int TL_BAR_WORDS = 32 * (TL_NC + 1);       // counters 128 B apart, then the error flag
+constexpr int TL_SUM_WORDS = 2 * 2 * 64;             // two parities x {integer parts, fractions} x 64 (46 used) 64-bit sums
+
+template <typename U>
+__device__ __forceinline__ U ld_dev(const U* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename U>
+__device__ __forceinline__ void st_dev(U* p, U v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct TLBarrier {
+  unsigned* bar;       // [32 c] arrival counter c, [32 TL_NC] error flag
+  unsigned epoch;
+  int G;
+  int cached;          // the workspace lives in ordinary (L2-cacheable) device memory: bracket the barrier with an L2 invalidate
+};
+
+// returns false if the barrier timed out (a workgroup never arrived: not co-resident, or the device is wedged)
+__device__ __forceinline__ bool tl_barrier(TLBarrier& B) {
+  __shared__ int ok_s;
+  __syncthreads();                    // every wave's atomics / stores of this phase are issued and acknowledged (vmcnt(0))
+  B.epoch += 1;
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    // (No release fence: every cross-workgroup write of a phase is a RETURNING atomic whose value the issuing wave has
+    // already received -- see `flush` -- i.e. it is performed at the memory side before this arrival is issued.  Measured:
+    // a release fence = L2 write-back costs 3.7 us per barrier, waiting for the returns 2 us.)
+    if (lane == 0) __hip_atomic_fetch_add(&B.bar[32 * (blockIdx.x % TL_NC)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned target = (unsigned)B.G * B.epoch;
+    unsigned* errf = B.bar + 32 * TL_NC;
+    int ok = 1;
+    for (long spin = 0;; ++spin) {
+      unsigned v = (lane < TL_NC) ? ld_dev(&B.bar[32 * lane]) : 0u;
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+      v = __shfl(v, 0, 64);
+      if (v >= target) break;
+      if ((spin & 255) == 255 && ld_dev(errf)) { ok = 0; break; }
+      if (spin > 400000) { if (lane == 0) atomicExch(errf, 1u); ok = 0; break; }      // ~0.4 s
+      __builtin_amdgcn_s_sleep(1);
+    }
+    // acquire (cacheable workspace only): drop this XCD's L2 copies of the words other XCDs have updated since (device-scope
+    // loads allocate in L2; a recycled histogram would be read stale).  1.7 us per barrier; an UNCACHED workspace
+    // (como_track_level_workspace_create) does not need it.
+    if (B.cached) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (lane == 0) ok_s = ok;
+  }
+  __syncthreads();
+  return ok_s != 0;
+}
+
+struct TLCriteria { int max_iter; float delta_norm, rel_tol, grad_norm; };
+
+// -DCOMO_TL_PROFILE: workgroup 0 stamps the phases of iteration 3 (100 MHz wall clock) into the tail of the workspace
+#ifdef COMO_TL_PROFILE
+#define TL_STAMP(k) do { if (blockIdx.x == 0 && tid == 0 && it == 3) stamps[k] = (long long)wall_clock64(); } while (0)
+#else
+#define TL_STAMP(k) do { } while (0)
+#endif
+
+// one more digit of the exact k-th key: `hist` (2048 device-scope counters) is the histogram of this digit among the keys
+// that match the digits resolved so far; returns the digit and lowers k_rem to the rank inside that bin
+__device__ __forceinline__ uint32_t tl_resolve_digit(const uint32_t* hist, uint32_t& k_rem, uint32_t* total, SelScratch* sc) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint32_t c[8], local = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { c[j] = ld_dev(&hist[tid * 8 + j]); local += c[j]; }
+  uint32_t incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) sc->wave_tot[wv] = incl;
+  if (tid == 0) { sc->found_bin = 0; sc->found_below = 0; }
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wv; ++w) base += sc->wave_tot[w];
+  const uint32_t tot = sc->wave_tot[0] + sc->wave_tot[1] + sc->wave_tot[2] + sc->wave_tot[3];
+  if (total) { *total = tot; k_rem = tot ? (tot - 1) / 2 : 0; }        // first digit: lower median of all valid keys
+  const uint32_t excl = base + incl - local;
+  if (local > 0 && k_rem >= excl && k_rem < excl + local) {
+    uint32_t run = excl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (k_rem >= run && k_rem < run + c[j]) { sc->found_bin = tid * 8 + j; sc->found_below = run; }
+      run += c[j];
+    }
+  }
+  __syncthreads();
+  const uint32_t bin = sc->found_bin;
+  k_rem -= sc->found_below;
+  __syncthreads();
+  return bin;
+}
+
+__global__ __launch_bounds__(256) void track_level_kernel(
+    const float* __restrict__ Tji_init, const float* __restrict__ Kmat, const float* __restrict__ aff_init,
+    const float* __restrict__ P, const float* __restrict__ vals_i, const float* __restrict__ img, int H, int W, long N,
+    const float* __restrict__ J8, const uint8_t* __restrict__ in_mask, TLCriteria crit, unsigned* __restrict__ bar,
+    uint32_t* __restrict__ hists2, long long* __restrict__ sums2, long long* __restrict__ stamps, float* __restrict__ out,
+    int ppt, int ws_cached) {
+  using T = float;
+  using KeyT = uint32_t;
+  __shared__ uint32_t lh[SEL_BINS];
+  __shared__ SelScratch sc;
+  __shared__ float tile[128][TRK_ACC + 1];
+  __shared__ double red[4][TRK_ACC];
+  __shared__ double tot[TRK_ACC];
+  __shared__ float state[24];          // 16 T | 2 aff | mse | gnorm | dnorm
+  const int tid = threadIdx.x, G = gridDim.x;
+  TLBarrier B{bar, 0u, G, ws_cached};
+
+  // ---- this thread's reference pixels, register-resident for the whole level ----
+  T pX[TL_MAXP], pY[TL_MAXP], pZ[TL_MAXP], vref[TL_MAXP], Jc[TL_MAXP][7];
+  bool sel[TL_MAXP];
+#pragma unroll
+  for (int k = 0; k < TL_MAXP; ++k) {
+    const long i = ((long)k * G + blockIdx.x) * 256 + tid;
+    sel[k] = (k < ppt) && (i < N);
+    const long ic = sel[k] ? i : 0;
+    pX[k] = P[3 * ic]; pY[k] = P[3 * ic + 1]; pZ[k] = P[3 * ic + 2];
+    vref[k] = vals_i[ic];
+    const float4 a = *reinterpret_cast<const float4*>(&J8[8 * ic]);
+    const float4 b = *reinterpret_cast<const float4*>(&J8[8 * ic + 4]);
+    Jc[k][0] = a.x; Jc[k][1] = a.y; Jc[k][2] = a.z; Jc[k][3] = a.w; Jc[k][4] = b.x; Jc[k][5] = b.y; Jc[k][6] = b.w;   // [6] = J7
+    if (sel[k] && in_mask) sel[k] = in_mask[ic] != 0;
+  }
+  T Tc[16], a0 = aff_init[0], a1 = aff_init[1];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) Tc[k] = Tji_init[k];
+  T Kr[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) Kr[k] = Kmat[k];
+  const T ax = T(1) / T(W), ay = T(1) / T(H);
+  T mse_prev = __builtin_inff();
+  int it = 0;
+  bool alive = true;
+
+  // RETURNING atomics: the returned value comes from where the read-modify-write was performed (the memory side), so once
+  // the wave has it (s_waitcnt in the barrier's __syncthreads) the update is globally performed -- a non-returning atomic is
+  // acknowledged by the XCD's L2 before that, and the barrier arrival (another address, another channel) can overtake it
+  auto flush = [&](uint32_t* gh) {
+    uint32_t sink = 0;
+    for (int b = tid; b < SEL_BINS; b += 256) {
+      const uint32_t v = lh[b];
+      if (v) sink += __hip_atomic_fetch_add(&gh[b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("" ::"v"(sink));
+  };
+
+  while (true) {
+    uint32_t* hs = hists2 + (it & 1) * 6 * SEL_BINS;          // this iteration's digit histograms / sums
+    uint32_t* hother = hists2 + ((it + 1) & 1) * 6 * SEL_BINS;
+    long long* sm = sums2 + (it & 1) * 128;
+    long long* smother = sums2 + ((it + 1) & 1) * 128;
+    TL_STAMP(0);
+    // ---- phase A: warp, sample, residual, validity, digit-0 histogram ----
+    for (int b = tid; b < SEL_BINS; b += 256) lh[b] = 0;
+    T Pm[12];
+    {
+#pragma clang fp contract(off)
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j)
+          Pm[i * 4 + j] = dot3_seq(Kr[i * 3 + 0], Kr[i * 3 + 1], Kr[i * 3 + 2], Tc[0 * 4 + j], Tc[1 * 4 + j], Tc[2 * 4 + j]);
+    }
+    const T ea = exp(-a0), bb = a1;
+    __syncthreads();
+    T rk[TL_MAXP], j6[TL_MAXP];
+    bool ok[TL_MAXP];
+#pragma unroll
+    for (int k = 0; k < TL_MAXP; ++k) {
+      T hx, hy, hz;
+      rigid_apply(Pm, pX[k], pY[k], pZ[k], hx, hy, hz);
+      const T u = hx / hz, v = hy / hz;
+      ok[k] = sel[k] && in_image(u, v, H, W) && (hz > T(0));
+      Taps<T> t = make_taps(grid_position(u, W, ax), grid_position(v, H, ay), H, W);
+      const T It = tap_sum(img, t);
+      const T tmp = ea * It;
+      j6[k] = -tmp;
+      rk[k] = (tmp + bb) - vref[k];
+      if (ok[k]) atomicAdd(&lh[sel_digit<KeyT>(abs_key(rk[k]), 0)], 1u);
+    }
+    __syncthreads();
+    TL_STAMP(1);
+    flush(hs);
+    TL_STAMP(2);
+    if (!tl_barrier(B)) { alive = false; break; }
+    TL_STAMP(3);
+    // ---- phases B, C: digits 1 and 2 of the exact median (keys come from registers: no memory pass) ----
+    KeyT prefix = 0;
+    uint32_t k_rem = 0, nv = 0;
+    for (int ps = 1; ps < 3; ++ps) {
+      for (int b = tid; b < SEL_BINS; b += 256) lh[b] = 0;
+      if (ps == 1) {   // the other parity's histograms / sums: free since the last barrier, used by the next iteration
+        // cleared with read-modify-write atomics (performed at the memory side like the adds that follow): a device-scope
+        // STORE may linger in this XCD's write-back L2 and land after other workgroups' atomic adds, wiping them
+        uint32_t sink = 0;
+        for (int e = blockIdx.x * 256 + tid; e < 3 * SEL_BINS; e += G * 256)
+          sink += __hip_atomic_fetch_and(&hother[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x == G - 1 && tid < 128)
+          sink += (uint32_t)__hip_atomic_fetch_and((unsigned long long*)&smother[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(sink));
+      }
+      const uint32_t bin = tl_resolve_digit(hs + (ps - 1) * SEL_BINS, k_rem, ps == 1 ? &nv : nullptr, &sc);   // (orders the lh clear)
+      prefix |= ((KeyT)bin) << SelCfg<KeyT>::shift(ps - 1);
+#pragma unroll
+      for (int k = 0; k < TL_MAXP; ++k) {
+        const KeyT key = abs_key(rk[k]);
+        if (ok[k] && sel_match<KeyT>(key, prefix, ps)) atomicAdd(&lh[sel_digit<KeyT>(key, ps)], 1u);
+      }
+      __syncthreads();
+      TL_STAMP(4 + 3 * (ps - 1));
+      flush(hs + ps * SEL_BINS);
+      TL_STAMP(5 + 3 * (ps - 1));
+      if (!tl_barrier(B)) { alive = false; break; }
+      TL_STAMP(6 + 3 * (ps - 1));
+    }
+    if (!alive) break;
+    // ---- phase D: robust weights, 8x8 system sums ----
+    {
+      const uint32_t bin = tl_resolve_digit(hs + 2 * SEL_BINS, k_rem, nullptr, &sc);
+      prefix |= ((KeyT)bin) << SelCfg<KeyT>::shift(2);
+    }
+    const T sigma = T(1.4826) * key_value(prefix);
+    const T info_sqrt = T(1) / sigma;
+    T acc[TRK_ACC];
+#pragma unroll
+    for (int k = 0; k < TRK_ACC; ++k) acc[k] = T(0);
+#pragma unroll
+    for (int k = 0; k < TL_MAXP; ++k) {
+      if (!ok[k]) continue;
+      const T r = rk[k];
+      const T wr = r * info_sqrt;
+      const T w = huber(wr);
+      const T J[8] = {Jc[k][0], Jc[k][1], Jc[k][2], Jc[k][3], Jc[k][4], Jc[k][5], j6[k], Jc[k][6]};
+      int q = 0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const T wa = w * J[a];
+#pragma unroll
+        for (int b = a; b < 8; ++b) acc[q++] += wa * J[b];
+        acc[36 + a] += wa * r;
+      }
+      acc[44] += w * wr * wr;
+    }
+    TL_STAMP(10);
+    // fixed-order block reduction: upper half of the block folds into the lower half, then 4 x 32-row column sums in fp64
+    if (tid >= 128) {
+#pragma unroll
+      for (int k = 0; k < TRK_ACC; ++k) tile[tid - 128][k] = acc[k];
+    }
+    __syncthreads();
+    if (tid < 128) {
+#pragma unroll
+      for (int k = 0; k < TRK_ACC; ++k) acc[k] += tile[tid][k];
+    }
+    __syncthreads();
+    if (tid < 128) {
+#pragma unroll
+      for (int k = 0; k < TRK_ACC; ++k) tile[tid][k] = acc[k];
+    }
+    __syncthreads();
+    {
+      const int k = tid & 63, pp = tid >> 6;
+      if (k < TRK_ACC) {
+        double s = 0;
+        for (int rr = 0; rr < 32; ++rr) s += (double)tile[pp * 32 + rr][k];
+        red[pp][k] = s;
+      }
+    }
+    __syncthreads();
+    if (tid < TRK_ACC) {
+      // this workgroup's share into the device-wide sums, exact fixed point (common.cuh fix_split): order-independent
+      const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+      long long hi;
+      unsigned long long lo;
+      if (!(fabs(v) < 4.0e18)) { hi = 0x2000000000000000ll; lo = 0; }      // non-finite: poisons the sum
+      else fix_split(v, hi, lo);
+      unsigned long long sink = 0;
+      if (hi) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[tid], (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lo) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[64 + tid], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(sink));
+    }
+    TL_STAMP(11);
+    if (!tl_barrier(B)) { alive = false; break; }
+    TL_STAMP(12);
+    // ---- phase E (every workgroup, identically): totals, 8x8 Cholesky, T <- T Exp(-delta), stop test ----
+    if (tid < TRK_ACC) {
+      const long long hi = ld_dev(&sm[tid]);
+      const unsigned long long lo = (unsigned long long)ld_dev(&sm[64 + tid]);
+      tot[tid] = (hi >= 0x1000000000000000ll) ? __builtin_nan("") : fix_value(hi, lo);
+    }
+    __syncthreads();
+    TL_STAMP(13);
+    if (tid == 0) {
+      double Hm[64], g[8], L[64], y[8], d[8];
+      int q = 0;
+      for (int a = 0; a < 8; ++a)
+        for (int b = a; b < 8; ++b) { Hm[a * 8 + b] = tot[q]; Hm[b * 8 + a] = tot[q]; ++q; }
+      double gn = 0;
+      for (int a = 0; a < 8; ++a) { g[a] = tot[36 + a]; gn += g[a] * g[a]; }
+      int info = 0;
+      for (int i = 0; i < 64; ++i) L[i] = 0;
+      for (int j = 0; j < 8; ++j) {
+        double s = Hm[j * 8 + j];
+        for (int k = 0; k < j; ++k) s -= L[j * 8 + k] * L[j * 8 + k];
+        if (!(s > 0) && info == 0) info = j + 1;
+        const double dj = sqrt(s);
+        L[j * 8 + j] = dj;
+        for (int i = j + 1; i < 8; ++i) {
+          double t = Hm[i * 8 + j];
+          for (int k = 0; k < j; ++k) t -= L[i * 8 + k] * L[j * 8 + k];
+          L[i * 8 + j] = t / dj;
+        }
+      }
+      for (int i = 0; i < 8; ++i) { double t = g[i]; for (int k = 0; k < i; ++k) t -= L[i * 8 + k] * y[k]; y[i] = t / L[i * 8 + i]; }
+      for (int i = 7; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < 8; ++k) t -= L[k * 8 + i] * d[k]; d[i] = t / L[i * 8 + i]; }
+      TL_STAMP(14);
+      double xi[6], E[16], dn = 0;
+      for (int i = 0; i < 6; ++i) xi[i] = -d[i];
+      for (int i = 0; i < 8; ++i) dn += d[i] * d[i];
+      se3_exp_f64(xi, E);
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+          double t = 0;
+          for (int k = 0; k < 4; ++k) t += (double)Tc[i * 4 + k] * E[k * 4 + j];
+          state[i * 4 + j] = (T)t;
+        }
+      TL_STAMP(15);
+      state[16] = (T)((double)a0 - d[6]);
+      state[17] = (T)((double)a1 - d[7]);
+      state[18] = (T)(tot[44] / (double)nv);
+      state[19] = (T)sqrt(gn);
+      state[20] = (T)sqrt(dn);
+      if (blockIdx.x == 0) {                                   // the record of this iteration, layout of como_track_iter_*
+        for (int i = 0; i < 64; ++i) out[i] = (T)Hm[i];
+        for (int i = 0; i < 8; ++i) { out[64 + i] = (T)g[i]; out[72 + i] = (T)d[i]; }
+        for (int i = 0; i < 16; ++i) out[80 + i] = state[i];
+        out[96] = state[16]; out[97] = state[17];
+        out[98] = state[18]; out[99] = state[19]; out[100] = (T)tot[44];
+        out[101] = sigma; out[102] = (T)nv; out[103] = state[20]; out[104] = (T)info;
+        out[105] = (T)(it + 1);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Tc[k] = state[k];
+    a0 = state[16]; a1 = state[17];
+    const T mse = state[18], gnorm = state[19], dnorm = state[20];
+    TL_STAMP(16);
+    ++it;
+    // photo_tracking.py:166-180, float32 arithmetic as the reference's 0-dim tensors
+    const T rel = fabsf((mse_prev - mse) / mse_prev);
+    mse_prev = mse;
+    __syncthreads();                                           // `state` / `tot` are rewritten next iteration
+    if (it >= crit.max_iter || dnorm < crit.delta_norm || rel < crit.rel_tol || gnorm < crit.grad_norm) break;
+  }
+  if (!alive && blockIdx.x == 0 && tid == 0) out[104] = T(-1);  // a barrier timed out
+}
+
 }  // namespace como
 
 extern "C" {
+
+long como_track_level_workspace_bytes(void);
+
+/* Optional: a workspace in UNCACHED device memory (hipDeviceMallocUncached: not held in the XCD-private L2s), created once
+ * outside any stream capture.  NULL if the runtime refuses. */
+void* como_track_level_workspace_create(void) {
+  void* p = nullptr;
+  const size_t bytes = (size_t)como_track_level_workspace_bytes();
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemset(p, 0, bytes) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return nullptr; }
+  return p;
+}
+void como_track_level_workspace_destroy(void* p) { if (p) (void)hipFree(p); }
+
+long como_track_level_workspace_bytes(void) {
+  return (long)como::TL_BAR_WORDS * 4 + 2L * 6 * como::SEL_BINS * 4 + (long)como::TL_SUM_WORDS * 8 + 32 * 8;   // (+ profile stamps)
+}
+
+int como_track_level_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P, const float* vals_i,
+                         const float* img, int H, int W, long N, const float* J8, const uint8_t* in_mask, int max_iter,
+                         float delta_norm, float rel_tol, float grad_norm, void* workspace, int workspace_uncached, float* out,
+                         como_stream_t stream) {
+  using namespace como;
+  if (!Tji_init || !K || !aff_init || !P || !vals_i || !img || !J8 || !workspace || !out || N <= 0 || H < 3 || W < 3 ||
+      max_iter < 1)
+    return COMO_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return COMO_ERR_LAUNCH;
+    ncu = prop.multiProcessorCount;
+  }
+  long G = (N + 255) / 256;
+  if (G > ncu) G = ncu;                       // one workgroup per compute unit: all co-resident (the barrier needs that)
+  if (G > 512) G = 512;
+  const long ppt = (N + G * 256 - 1) / (G * 256);
+  if (ppt > TL_MAXP) return COMO_ERR_ARG;     // larger than TL_MAXP x 256 x #CU pixels: use the como_track_iter_* chain
+  unsigned* bar = (unsigned*)workspace;
+  uint32_t* hists2 = (uint32_t*)workspace + TL_BAR_WORDS;
+  long long* sums2 = (long long*)(hists2 + 2 * 6 * SEL_BINS);
+  long long* stamps = sums2 + TL_SUM_WORDS;
+  if (!zero_words(workspace, TL_BAR_WORDS + 2 * 6 * SEL_BINS + 2 * TL_SUM_WORDS, s)) return COMO_ERR_LAUNCH;
+  TLCriteria crit{max_iter, delta_norm, rel_tol, grad_norm};
+  hipLaunchKernelGGL(track_level_kernel, dim3((unsigned)G), dim3(256), 0, s, Tji_init, K, aff_init, P, vals_i, img, H, W, N, J8,
+                     in_mask, crit, bar, hists2, sums2, stamps, out, (int)ppt, workspace_uncached ? 0 : 1);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
 
 long como_track_partials_bytes(void) { return (long)como::TRK_MAX_BLOCKS * como::TRK_ACC * (long)sizeof(double); }
 

@@ -175,12 +175,65 @@ def _level_graph(vals_i, Pi, dI_dT, img_j, intrinsics, in_mask=None):
     return lg
 
 
+FUSED_LEVEL = __import__("os").environ.get("COMO_TRACK_FUSED", "1") != "0"
+_level_ws = {}
+UNCACHED_WS = __import__("os").environ.get("COMO_TRACK_UNCACHED_WS", "1") == "1"   # barrier workspace in uncached device memory
+
+
+def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, intrinsics, term_criteria, in_mask=None):
+    """The whole level in ONE launch (csrc/track.hip track_level_kernel): Gauss-Newton loop + stop test on the device, no
+    host read-back.  Returns (Tji (1,4,4), aff (1,2,1), out (106,)) -- all device tensors; out[105] = iterations run.
+    None if the level does not fit the persistent kernel (then the per-iteration chain runs)."""
+    dev, dt = Pi.device, Pi.dtype
+    if dt != torch.float32 or not Pi.is_cuda or img_j.shape[0] != 1 or img_j.shape[1] != 1 or Pi.shape[0] != 1:
+        return None
+    L = _lib.lib()
+    N = Pi.shape[1]
+    H, W = img_j.shape[-2:]
+    for t in (Tji_init, Pi, intrinsics, img_j, aff_init, vals_i, dI_dT):
+        if not t.is_contiguous() or t.dtype != dt:
+            raise RuntimeError("como_amd tracking: inputs must be contiguous and share one dtype")
+    key = str(dev)
+    ws = _level_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(L.como_track_level_workspace_bytes() // 4, device=dev, dtype=torch.int32)
+        _level_ws[key] = ws
+    uncached = 0
+    ws_ptr = _lib.ptr(ws)
+    if UNCACHED_WS and not torch.cuda.is_current_stream_capturing():
+        wsp = _level_ws.get(key + ":uc")
+        if wsp is None:
+            with torch.cuda.device(dev):
+                wsp = L.como_track_level_workspace_create()          # uncached device memory, once per device
+            _level_ws[key + ":uc"] = wsp or 0
+        if wsp:
+            ws_ptr, uncached = wsp, 1
+    out = torch.empty(106, device=dev, dtype=dt)
+    rc = L.como_track_level_f32(_lib.ptr(Tji_init), _lib.ptr(intrinsics), _lib.ptr(aff_init), _lib.ptr(Pi), _lib.ptr(vals_i),
+                                _lib.ptr(img_j), H, W, N, _lib.ptr(dI_dT), _lib.ptr(in_mask), int(term_criteria["max_iter"]),
+                                float(term_criteria["delta_norm"]), float(term_criteria["rel_tol"]), float(term_criteria["grad_norm"]),
+                                ws_ptr, uncached, _lib.ptr(out), _lib.stream_ptr(dev))
+    if rc == 1:                                            # COMO_ERR_ARG: more pixels than the persistent kernel holds
+        return None
+    _lib.check(rc, "como_track_level")
+    return out[80:96].reshape(1, 4, 4), out[96:98].reshape(1, 2, 1), out
+
+
 def photo_level_tracking(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, intrinsics, photo_sigma, term_criteria, use_graph=True,
-                         in_mask=None):
-    """reference photo_tracking.py:147-185.  The stop test needs 3 scalars of every iteration on the host: LOOKAHEAD
+                         in_mask=None, fused=None):
+    """reference photo_tracking.py:147-185.  Default: the persistent one-launch kernel (photo_level_tracking_fused);
+    fused=False (or COMO_TRACK_FUSED=0) runs the per-iteration chain described next.  The stop test needs 3 scalars of every iteration on the host: LOOKAHEAD
     iterations are enqueued per read-back, their results kept in a small ring; when the test fires at iteration j the state
     of iteration j is restored, so the result is the reference's, at the price of at most LOOKAHEAD-1 surplus iterations.
     use_graph: replay each iteration from a hipGraph over fixed buffers (inputs must stay alive and unmodified)."""
+    if (FUSED_LEVEL if fused is None else fused):
+        if in_mask is not None and (in_mask.dtype != torch.uint8 or in_mask.numel() != Pi.shape[1] or not in_mask.is_contiguous()):
+            raise RuntimeError("como_amd tracking: in_mask must be a contiguous uint8 tensor of N elements")
+        res = photo_level_tracking_fused(Tji_init.reshape(1, 4, 4).contiguous(), aff_init.reshape(1, 2, 1).contiguous(), vals_i, Pi,
+                                         dI_dT, img_j, intrinsics, term_criteria, in_mask)
+        if res is not None:
+            photo_level_tracking.last_out = res[2]             # device tensor: [105] = iterations, [104] = status
+            return res[0].clone(), res[1].clone()
     if use_graph:
         lg = _level_graph(vals_i, Pi, dI_dT, img_j, intrinsics, in_mask)
     else:

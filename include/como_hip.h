@@ -75,6 +75,28 @@ int como_track_iter_masked_f64(const double* Tji, const double* K, const double*
                                double* pj_out, double* depth_out, void* hists, void* partials, double* out,
                                const uint8_t* in_mask, como_stream_t stream);
 
+/* One whole pyramid LEVEL -- photo_level_tracking, como/odom/frontend/photo_tracking.py:147-185 -- in one launch: the
+ * Gauss-Newton loop (tracking_iter :117-143 per iteration) with the stop test (:166-180: iter >= max_iter or |delta| <
+ * delta_norm or |(mse_prev - mse) / mse_prev| < rel_tol or |g| < grad_norm, float32 arithmetic) evaluated on the device.
+ * A persistent kernel: reference pixels stay in registers across iterations, device-wide barriers replace the kernel
+ * boundaries of the como_track_iter_* chain, no host round trip.  float32 (the reference's tracking dtype), c = 1.
+ *   J8 (N,8) is read only (column 6 is recomputed every iteration, not written back); in_mask (N) u8 or NULL.
+ *   workspace: como_track_level_workspace_bytes() bytes (cleared by the call); workspace_uncached = 1 if it came from
+ *   como_track_level_workspace_create() (uncached device memory: the device-wide barriers then need no L2 invalidate,
+ *   40 instead of 50 us per iteration at 640x480), 0 for ordinary device memory.
+ *   out (106): the como_track_iter_* record of the LAST iteration run (T at [80:96), aff at [96:98)), [104] = cholesky
+ *   info or -1 if the device-wide barrier timed out, [105] = number of iterations run.
+ * Returns COMO_ERR_ARG when N exceeds 5 x 256 x (number of compute units) pixels (use the chain then). */
+long como_track_level_workspace_bytes(void);
+/* allocator of such a workspace in UNCACHED device memory (hipDeviceMallocUncached; call outside stream capture); NULL if the
+ * runtime refuses -- pass ordinary device memory and workspace_uncached = 0 then */
+void* como_track_level_workspace_create(void);
+void como_track_level_workspace_destroy(void* ws);
+int como_track_level_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P, const float* vals_i,
+                         const float* img, int H, int W, long N, const float* J8, const uint8_t* in_mask, int max_iter,
+                         float delta_norm, float rel_tol, float grad_norm, void* workspace, int workspace_uncached, float* out,
+                         como_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Window BA linearisation (python path: backend/photo.py:83-233 batch_photo_cost).
  * All scalar tensors have the element type of the entry point (f32 / f64) except H, g (see h_is_f64).
