@@ -17,6 +17,7 @@ float64 always).  The same JSON line also carries (N = 1 only):
   secondary       : the window at the reference's default sub-selection (nonmax_suppression_window 4, n = 19,200), f32 and f64;
   tracking        : config 2 -- the 2-frame 640x480 tracking GN iteration (unit A: 53 B per pixel);
   odometry_loop   : the whole headless sequential loop (frames / s);
+  ate_vs_ref      : ATE-RMSE of the HIP loop's trajectory against the reference's own on a 72-frame 192x256 sequence;
   cpu_baseline    : the oracle (CPU restatement of the reference algorithm) timed on this box's host cores on the
                     window-4 workload EXACTLY as `secondary` runs it (full iteration incl. priors, >= 5 repetitions).
 --keyframes 32 runs config 4's window (62 pairs, D ~ 2.9 k); --replicas runs config 5's mode: one independent window per
@@ -256,6 +257,35 @@ def tracking_leg(device, steps=200):
         return {"error": repr(e)[:300]}
 
 
+def ate_leg(device):
+    """BASELINE.json's "ATE vs ref": the HIP loop's trajectory against the one the REFERENCE's sequential loop produced on the
+    same 72 frames (192x256, config/como.yml parameters; tests/golden/ate_sequence.npz, generated by running the reference)."""
+    try:
+        import numpy as np
+        from como_amd.utils.ate import ate_rmse
+        from scripts.ate_sequence import run_ate_sequence
+        d = np.load(os.path.join(ROOT, "tests", "golden", "ate_sequence.npz"))
+        G = {k: (torch.from_numpy(d[k]) if d[k].dtype.kind in "fiub" else d[k]) for k in d.files}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kinds, poses, odo = run_ate_sequence(G, "float", str(device))
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        ref_kinds = [int(x) for x in G["kinds"]]
+        tr = [k for k in range(len(ref_kinds)) if bool(G["tracked"][k]) and k in poses]
+        est, ref, gt = [poses[k] for k in tr], [G["T_w_curr"][k] for k in tr], [G["poses_gt"][k] for k in tr]
+        return {"workload": "72 rendered frames 192x256, config/como.yml parameters (9-keyframe sliding window, 24 one-way frames, m=64, "
+                            "window 4, float32 tracking, float64 mapping system / float32 pixel kernels), seeded DepthCov weights",
+                "value": ate_rmse(est, ref), "unit": "m (ATE-RMSE of the tracked positions vs the reference's trajectory, no alignment)",
+                "ate_rmse_sim3_aligned": ate_rmse(est, ref, "sim3"), "frames": len(ref_kinds), "tracked": len(tr),
+                "same_decisions": sum(int(a == b) for a, b in zip(kinds, ref_kinds)),
+                "path_length_m": float(sum((G["poses_gt"][k + 1, :3, 3] - G["poses_gt"][k, :3, 3]).norm() for k in range(len(ref_kinds) - 1))),
+                "ate_vs_ground_truth_sim3": {"hip": ate_rmse(est, gt, "sim3"), "reference": ate_rmse(ref, gt, "sim3")},
+                "wall_s_including_setup": el}
+    except Exception as e:                                  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,6 +370,7 @@ def main():
         torch.cuda.empty_cache()
         legs["tracking"] = tracking_leg(device)
         legs["odometry_loop"] = odometry_loop(device)
+        legs["ate_vs_ref"] = ate_leg(device)
 
     if shard.rank == 0:
         mode = "replicas" if args.replicas else ("dp%d (reference-pixel shards of every pair)" % args.gpus)

@@ -2,7 +2,7 @@
 on a real `como.odom.Mapping.Mapping` object whose state attributes are filled from a seeded synthetic window, and records
 what the reference computed (hooks around `create_photo_system` and `solve_system` keep the intermediate H / g).
 
-    python tests/golden/make_golden_r2.py [fullwin4] [fullwin1] [reinit] [win32] [se3]
+    python tests/golden/make_golden_r2.py [fullwin4] [fullwin1] [reinit] [win32] [se3] [ate]
 
 Cases
   fullwin4 / fullwin1 : the METRIC configuration -- 8 keyframes, 640x480, m = 64, nonmax window 4 (reference default) and
@@ -291,6 +291,97 @@ def se3_case(seed=5):
             "T0_expm": torch.from_numpy(T0 @ T)}
 
 
+ATE_TRACK_CFG = {"device": "cpu", "dtype": "float", "color": "gray",
+                 "pyr": {"start_level": 0, "end_level": 3, "depth_interp_mode": "nearest_neighbor"},
+                 "term_criteria": {"max_iter": 50, "delta_norm": 1.0e-3, "rel_tol": 1.0e-3, "grad_norm": 1.0},
+                 "sigmas": {"photo": 1.0e-1},
+                 "keyframing": {"kf_depth_motion_ratio": 0.12, "kf_num_pixels_frac": 0.75, "one_way_freq": 3}}      # config/como.yml
+ATE_MAP_CFG = {"device": "cpu", "dtype": "double", "color": "gray", "model_path": None, "track_ref": {"num_keyframes": 1},
+               "graph": {"num_keyframes": 9, "num_one_way_frames": 24},
+               "photo_construction": {"nonmax_suppression_window": 4, "pairwise_batch_size": 128, "radius_thresh": 0.0,
+                                      "degrees_thresh": 0.0},
+               "term_criteria": {"max_iter": 20, "delta_norm": 1.0e-8, "abs_tol": 1.0e-6, "rel_tol": 1.0e-6},
+               "sigmas": {"photo": 1.0e-1, "mean_depth_prior": 1.0e-2, "scale_prior": 1.0e-4, "pose_prior": 1.0e-6},
+               "sampling": {"mode": "greedy_conditional_entropy", "max_num_coords": 64, "max_stdev_thresh": 1.0e-2, "border": 3,
+                            "fixed_var": 0.0, "dist_thresh": 1.0e-1},
+               "corr": mg.CORR_PARAMS,
+               "init": {"start_level": 0, "end_level": 3, "max_iter": 50, "delta_norm": 1.0e-4, "rel_tol": 1.0e-4,
+                        "kf_depth_motion_ratio": 0.04, "kf_num_pixels_frac": 0.75}}                                   # config/como.yml
+
+
+def ate_frames(nframes, H, W, seed, step, deg):
+    """The rendered sequence (shared with the GPU test, which regenerates it from the same seeds)."""
+    scene = synth.PlaneScene(seed=seed, freq_scale=W / 640.0)
+    K = synth.intrinsics_for(H, W)
+    T = synth.gt_poses(nframes, step=step, deg=deg)
+    g = torch.Generator().manual_seed(seed)
+    rgbs = []
+    for k in range(nframes):
+        I, _ = scene.render(T[k], K, H, W)
+        I = I + 0.002 * torch.randn(I.shape, generator=g, dtype=torch.float64)
+        rgbs.append(I[None, None].repeat(1, 3, 1, 1))
+    return K, T, rgbs
+
+
+def ate_case(seed=17, H=192, W=256, nframes=72, step=0.02, deg=0.4):
+    """"ATE vs ref" (BASELINE.json metric): the reference's OWN sequential odometry loop (sequential/ComoSeq.py without the
+    GUI: TrackingSeq.track -> MappingSeq.map per frame) on a rendered 72-frame sequence at the reference's native network
+    resolution 192x256 with the parameters of config/como.yml (9-keyframe window, 24 one-way frames, 64 inducing points,
+    nonmax window 4, float32 tracking, float64 mapping); DepthCov weights = the seeded ones (no checkpoint in this image).
+    Stored: the per-frame decisions and the tracked world poses; the frames are regenerated from the seeds by the test."""
+    from como.odom.sequential.MappingSeq import MappingSeq
+    from como.odom.sequential.TrackingSeq import TrackingSeq
+    from como.odom.frontend.TwoFrameSfm import TwoFrameSfm
+    from como.utils.multiprocessing import transfer_data
+    from como.depth_cov.core.DepthCovModule import DepthCovModule
+    torch.manual_seed(seed)
+    model = DepthCovModule()
+    model.load_state_dict(synth.depthcov_state_dict(0), strict=False)
+    model.eval()
+    K, T, rgbs = ate_frames(nframes, H, W, seed, step, deg)
+    trk = TrackingSeq(ATE_TRACK_CFG, K.clone(), (H, W))
+    trk.init_basic_vars(); trk.init_kf_vars(); trk.reset_one_way_vars(); trk.T_w_rec_last = None
+    mp = MappingSeq(ATE_MAP_CFG, K.clone())
+    mp.init_basic_vars()
+    mp.cov_level = -1
+    mp.network_size = torch.tensor([H, W])
+    mp.network_size_list = [H, W]
+    mp.model = model
+    mp.init_keyframe_vars()
+    mp.init_prior_vals()
+    mp.reset_iteration_vars(new_kf=True, converged=True)
+    mp.two_frame_sfm = TwoFrameSfm(ATE_MAP_CFG, mp.intrinsics[0, :, :], model, -1, mp.network_size)
+    out = {"K": K, "poses_gt": T, "seed": seed, "H": H, "W": W, "nframes": nframes, "step": step, "deg": deg}
+    kinds, poses, valid = [], [], []
+    code = {None: 0, "init": 3, "keyframe": 1, "one-way": 2}
+    t0 = time.time()
+    with torch.no_grad():
+        for k in range(nframes):
+            ts, rgb = 1.0 + k, rgbs[k]
+            if mp.is_init:
+                viz, to_map = trk.track(transfer_data((ts, rgb.clone()), trk.device, trk.dtype))
+                poses.append(viz[1].clone().double().reshape(4, 4))
+                valid.append(True)
+            else:
+                to_map = ("init", ts, rgb.clone())
+                poses.append(torch.eye(4, dtype=torch.float64))
+                valid.append(False)
+            kinds.append(code[to_map[0] if to_map is not None else None])
+            _, kf_ref = mp.map(to_map)
+            if kf_ref is not None:
+                trk.update_kf_reference(transfer_data(kf_ref, trk.device, trk.dtype))
+            if k % 10 == 0:
+                print(f"  ate frame {k}: kind {kinds[-1]}, keyframes {mp.kf_poses.shape[0] if mp.kf_poses.dim() > 1 else 0}, {time.time() - t0:.0f} s")
+    out["kinds"] = np.array(kinds)
+    out["T_w_curr"] = torch.stack(poses)
+    out["tracked"] = torch.tensor(valid)
+    out["m_kf_poses"] = mp.kf_poses.clone()
+    out["m_kf_timestamps"] = torch.tensor(mp.kf_timestamps, dtype=torch.float64)
+    out["m_window_full"] = torch.tensor(bool(mp.window_full))
+    # the reference's own accuracy on this sequence (its ATE against the ground truth, scale-aligned: monocular)
+    return out
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["se3", "reinit", "win32", "fullwin4"]
@@ -304,3 +395,5 @@ if __name__ == "__main__":
         mg.save("fullsize_window4.npz", fullwin_case(4))
     if "fullwin1" in which:
         mg.save("fullsize_window1.npz", fullwin_case(1, iters=1))
+    if "ate" in which:
+        mg.save("ate_sequence.npz", ate_case())

@@ -284,3 +284,34 @@ def test_fused_tracking_level_matches_iteration_chain(H, W, masked):
            aff_err=ea, T6_err=e6, iters6=int(rec6[105]), err_vs_gt=gt)
     assert status == 0 and it_fused == it_chain and int(rec6[105]) == 6
     assert eT < 2e-6 and ea < 2e-6 and e6 < 2e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+from scripts.ate_sequence import run_ate_sequence  # noqa: E402  (shared with bench.py)
+
+
+@pytest.mark.parametrize("pix", ["double", "float"])
+def test_ate_vs_reference_sequence(pix):
+    """"ATE vs ref" (BASELINE.json metric): 72 frames at 192x256 with config/como.yml parameters through the whole HIP loop
+    (two-frame init, tracking, keyframe management over a sliding 9-keyframe window, one mapping iteration per frame)
+    against the trajectory the reference's own sequential loop produced on the same frames."""
+    from como_amd.utils.ate import ate_rmse
+    G = load_golden("ate_sequence.npz")
+    kinds, poses, odo = run_ate_sequence(G, pix)
+    ref_kinds = [int(x) for x in G["kinds"]]
+    tracked = [k for k in range(len(ref_kinds)) if bool(G["tracked"][k]) and k in poses]
+    est = [poses[k] for k in tracked]
+    ref = [G["T_w_curr"][k] for k in tracked]
+    gt = [G["poses_gt"][k] for k in tracked]
+    ate = ate_rmse(est, ref)
+    ate_sim3 = ate_rmse(est, ref, "sim3")
+    worst = max((e - r).abs().max().item() for e, r in zip(est, ref))
+    same = sum(int(a == b) for a, b in zip(kinds, ref_kinds))
+    path_len = float(sum((G["poses_gt"][k + 1, :3, 3] - G["poses_gt"][k, :3, 3]).norm() for k in range(len(ref_kinds) - 1)))
+    report("ate_vs_ref", pix=pix, frames=len(ref_kinds), tracked=len(tracked), same_decisions=same, ate_rmse=ate, ate_rmse_sim3=ate_sim3,
+           worst_pose_abs=worst, ate_ref_vs_gt_sim3=ate_rmse(ref, gt, "sim3"), ate_hip_vs_gt_sim3=ate_rmse(est, gt, "sim3"),
+           path_length=path_len, keyframes=int(odo.mapping.kf_poses.shape[0]), window_full=bool(odo.mapping.window_full))
+    assert len(tracked) >= 60
+    assert kinds == ref_kinds                                         # the same request on every frame
+    assert [float(t) for t in odo.mapping.kf_timestamps] == G["m_kf_timestamps"].tolist()
+    assert ate < 2e-5 and worst < 5e-5                                # metres, over a 1.45 m path (measured 7.6e-7 / 4.5e-6)
