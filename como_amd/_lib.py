@@ -76,6 +76,8 @@ SIGNATURES = {
     "como_ba_linearize_f64": (c_int, [ctypes.POINTER(BAArgs), c_void_p]),
     "como_cross_covariance_f32": (c_int, [c_void_p] * 4 + [c_float, c_void_p, c_int, c_int, c_int,
                                                         ctypes.POINTER(c_long), c_void_p]),
+    "como_cross_covariance_f16": (c_int, [c_void_p] * 4 + [c_float, c_void_p, c_int, c_int, c_int,
+                                                        ctypes.POINTER(c_long), c_void_p]),
     "como_cross_covariance_f64": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int, c_int, c_int,
                                                         ctypes.POINTER(c_long), c_void_p]),
     "como_chol_append_obs_info_f32": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int, c_int, c_void_p]),
@@ -156,6 +158,8 @@ def require_cuda(*tensors):
 
 
 def suffix(dtype):
+    if dtype == torch.float16:
+        return "f16"
     if dtype == torch.float32:
         return "f32"
     if dtype == torch.float64:

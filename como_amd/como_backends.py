@@ -22,8 +22,8 @@ def cross_covariance(x1, E1, x2, E2, scale):
             raise RuntimeError("como_amd.como_backends: CPU tensors are not supported (HIP build, no CPU fallback)")
         raise RuntimeError("All variables must be on same device.")
     dt = x1.dtype
-    if any(t.dtype != dt for t in ts) or dt not in (torch.float32, torch.float64):
-        raise RuntimeError("cross_covariance: float32 / float64 tensors of one dtype expected")
+    if any(t.dtype != dt for t in ts) or dt not in (torch.float16, torch.float32, torch.float64):
+        raise RuntimeError("cross_covariance: float16 / float32 / float64 tensors of one dtype expected")
     B, N, M = x1.shape[0], x1.shape[1], x2.shape[1]
     K12 = torch.empty((B, N, M), dtype=dt, device=x1.device)
     if K12.numel() == 0:                                   # no points on one side: an empty matrix, as the torch-side callers expect

@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void cross_cov_kernel(const T* __restrict__ x1
   const T d1 = a00 * a11 - a01 * a10;
   const T d2 = b00 * b11 - b01 * b10;
   T pw;
-  if constexpr (sizeof(T) == 4) pw = powf(d1 * d2, 0.25f); else pw = pow(d1 * d2, 0.25);
+  if constexpr (sizeof(T) == 8) pw = pow(d1 * d2, 0.25);
+  else pw = (T)powf((float)(d1 * d2), 0.25f);              // float, and half (c10::Half pow = float powf rounded to half)
   const T C = (T)(2.0 * (double)pw * (double)ref_safe_sqrt((float)det_inv));
   K12[((long)b * N + i) * M + j] = scale * C * (T)ref_matern((float)Q);
 }
@@ -360,6 +361,14 @@ int como_cross_covariance_f32(const float* x1, const float* E1, const float* x2,
 int como_cross_covariance_f64(const double* x1, const double* E1, const double* x2, const double* E2, double scale,
                               double* K12, int B, int N, int M, const long* strides_host, como_stream_t stream) {
   return como::cross_cov<double>(x1, E1, x2, E2, scale, K12, B, N, M, strides_host, (hipStream_t)stream);
+}
+
+/* half: the reference dispatches cross_covariance for at::Half too (AT_DISPATCH_FLOATING_TYPES_AND_HALF, cov_gpu.cu:73).
+ * c10::Half arithmetic = every operation computed in float and rounded to half: exactly what _Float16 arithmetic gives. */
+int como_cross_covariance_f16(const void* x1, const void* E1, const void* x2, const void* E2, float scale, void* K12, int B,
+                              int N, int M, const long* strides_host, como_stream_t stream) {
+  return como::cross_cov<_Float16>((const _Float16*)x1, (const _Float16*)E1, (const _Float16*)x2, (const _Float16*)E2,
+                                   (_Float16)scale, (_Float16*)K12, B, N, M, strides_host, (hipStream_t)stream);
 }
 
 int como_chol_append_obs_info_f32(float* L, float* obs_info, float* var, const float* k_ni, const float* k_id,

@@ -148,13 +148,14 @@ class WindowBA:
         slot_of.scatter_(1, self.lm_ids.long(), torch.arange(m, device=dev, dtype=torch.int32)[None].expand(B, m).contiguous())
         self.first_frame = first_obs.to(torch.int32).contiguous()
         self.first_slot = slot_of[first_obs, torch.arange(L, device=dev)].contiguous()
-        ref, tgt, ow_kf, ow_t = setup_photometric_pairs(self.kf_poses, self.recent_poses, self.kf_timestamps,
-                                                        self.recent_timestamps, self.median_depths,
-                                                        self.cfg["photo_construction"])
-        self.kf_pairs, self.one_way_pairs = [ref, tgt], [ow_kf, ow_t]
-        self.table = photo.PairTable(ref + ow_kf, tgt + ow_t, [False] * len(ref) + [True] * len(ow_kf), B, self.kf_inds,
-                                     self.recent_inds, self.landmark_inds, 3 * self.Himg * self.Wimg,
-                                     B * 3 * self.Himg * self.Wimg, dev)
+        pc = self.cfg["photo_construction"]
+        if self.fused and pc.get("radius_thresh", 0.0) > 0.0 and pc.get("degrees_thresh", 0.0) > 0.0:
+            # The reference rebuilds the pair graph on every iterate from the CURRENT poses and median depths
+            # (create_photo_system, photo.py:259-262).  With purely temporal edges (the shipped thresholds, 0) the graph only
+            # depends on the topology; pose-dependent radius edges would go stale inside the fused / captured iteration.
+            raise RuntimeError("como_amd: radius / degree pair edges need the pair graph rebuilt every iteration: use "
+                               "WindowBA(fused=False) (it re-evaluates the pairs in linearize()) for radius_thresh, degrees_thresh > 0")
+        self._build_pair_table()
         # H | g | err(8) in ONE float64 buffer.  The fused chain does not accumulate into it: every contribution (pair blocks,
         # priors) goes through exact integer atomics into the fixed-point buffer `sysfix` (order-independent: the normal
         # equations are bit-identical from run to run, eager or graph replay, whatever order workgroups and streams finish
@@ -173,6 +174,20 @@ class WindowBA:
         self.sigma = torch.zeros(2, device=dev, dtype=self.pix_dtype)
         self.pix_range = (0, 0) if self.idle else None     # (the shard is already cut out of pixidx / vals_n)
         self._prepare_fused()
+
+    def _build_pair_table(self):
+        """Pair graph from the current poses / median depths (graph_pair_construction.py:155-182) -> device-resident PairTable."""
+        B, dev = self.B, self.dev
+        ref, tgt, ow_kf, ow_t = setup_photometric_pairs(self.kf_poses, self.recent_poses, self.kf_timestamps,
+                                                        self.recent_timestamps, self.median_depths,
+                                                        self.cfg["photo_construction"])
+        pairs = ([ref, tgt], [ow_kf, ow_t])
+        if getattr(self, "table", None) is not None and pairs == (self.kf_pairs, self.one_way_pairs):
+            return
+        self.kf_pairs, self.one_way_pairs = pairs
+        self.table = photo.PairTable(ref + ow_kf, tgt + ow_t, [False] * len(ref) + [True] * len(ow_kf), B, self.kf_inds,
+                                     self.recent_inds, self.landmark_inds, 3 * self.Himg * self.Wimg,
+                                     B * 3 * self.Himg * self.Wimg, dev)
 
     def _prepare_fused(self):
         B, m, L, F, dev, p = self.B, self.m, self.L, self.F, self.dev, self.pix_dtype
@@ -348,6 +363,9 @@ class WindowBA:
     def linearize(self):
         if self.fused:
             return self.linearize_fused()
+        pc = self.cfg["photo_construction"]
+        if pc.get("radius_thresh", 0.0) > 0.0 and pc.get("degrees_thresh", 0.0) > 0.0:
+            self._build_pair_table()          # pose-dependent edges: rebuilt every iteration, as create_photo_system does
         pm, logzm, z_mask, dlogzm_dzm, dzm_dPwm, dzm_dTwc, dpm_dPwm, dpm_dTwc = self.scaffold()
         dlogzm_dTwc = dlogzm_dzm @ dzm_dTwc
         dlogzm_dPwm = dlogzm_dzm @ dzm_dPwm

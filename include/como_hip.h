@@ -186,6 +186,10 @@ int como_ba_linearize_f64(const como_ba_args* args_host, como_stream_t stream);
  *   obs_info and all of var are updated in place.  n <= 64. */
 int como_cross_covariance_f32(const float* x1, const float* E1, const float* x2, const float* E2, float scale,
                               float* K12, int B, int N, int M, const long* strides_host, como_stream_t stream);
+/* half precision (the reference's dispatch includes at::Half, cov_gpu.cu:73): IEEE binary16 storage and per-operation
+ * rounding, scale passed as float */
+int como_cross_covariance_f16(const void* x1, const void* E1, const void* x2, const void* E2, float scale, void* K12, int B,
+                              int N, int M, const long* strides_host, como_stream_t stream);
 int como_cross_covariance_f64(const double* x1, const double* E1, const double* x2, const double* E2, double scale,
                               double* K12, int B, int N, int M, const long* strides_host, como_stream_t stream);
 int como_chol_append_obs_info_f32(float* L, float* obs_info, float* var, const float* k_ni, const float* k_id,

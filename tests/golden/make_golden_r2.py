@@ -291,6 +291,29 @@ def se3_case(seed=5):
             "T0_expm": torch.from_numpy(T0 @ T)}
 
 
+def pair_graph_case(seed=41):
+    """setup_photometric_pairs of the reference (graph_pair_construction.py:155-182) with POSITIVE radius / degree thresholds:
+    keyframe radius edges (:53-94 mode "radius", non-consecutive only) and pose-based one-way edges (nearest + radius)."""
+    import como.odom.backend.graph_pair_construction as rgp
+    g = torch.Generator().manual_seed(seed)
+    B, R = 7, 5
+    T = synth.gt_poses(B, step=0.05, deg=3.0)
+    T[:, :3, 3] += 0.02 * torch.randn((B, 3), generator=g, dtype=torch.float64)
+    Tr = synth.gt_poses(12, step=0.03, deg=1.7)[torch.tensor([1, 3, 4, 8, 11])].clone()
+    Tr[:, :3, 3] += 0.01 * torch.randn((R, 3), generator=g, dtype=torch.float64)
+    med = 0.9 + 0.3 * torch.rand((B,), generator=g, dtype=torch.float64)
+    kts = torch.arange(B, dtype=torch.float64) * 2.0
+    rts = torch.tensor([0.5, 1.5, 3.5, 8.5, 12.5], dtype=torch.float64)
+    out = {"kf_poses": T, "recent_poses": Tr, "median_depths": med, "kf_timestamps": kts, "recent_timestamps": rts}
+    for i, (rad, deg) in enumerate(((0.12, 8.0), (0.25, 12.0), (0.0, 0.0), (0.12, 0.0))):
+        cfg = {"radius_thresh": rad, "degrees_thresh": deg}
+        a, b, c, d = rgp.setup_photometric_pairs(T, Tr, kts.tolist(), rts.tolist(), med, cfg)
+        out.update({f"c{i}_cfg": torch.tensor([rad, deg]), f"c{i}_kf_ref": torch.tensor(a), f"c{i}_kf_tgt": torch.tensor(b),
+                    f"c{i}_ow_kf": torch.tensor(c, dtype=torch.long), f"c{i}_ow_tgt": torch.tensor(d, dtype=torch.long)})
+        print(f"  pair graph cfg {cfg}: {len(a)} keyframe pairs, {len(c)} one-way pairs")
+    return out
+
+
 ATE_TRACK_CFG = {"device": "cpu", "dtype": "float", "color": "gray",
                  "pyr": {"start_level": 0, "end_level": 3, "depth_interp_mode": "nearest_neighbor"},
                  "term_criteria": {"max_iter": 50, "delta_norm": 1.0e-3, "rel_tol": 1.0e-3, "grad_norm": 1.0},
@@ -395,5 +418,7 @@ if __name__ == "__main__":
         mg.save("fullsize_window4.npz", fullwin_case(4))
     if "fullwin1" in which:
         mg.save("fullsize_window1.npz", fullwin_case(1, iters=1))
+    if "pairs" in which:
+        mg.save("pair_graph.npz", pair_graph_case())
     if "ate" in which:
         mg.save("ate_sequence.npz", ate_case())

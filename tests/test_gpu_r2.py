@@ -315,3 +315,35 @@ def test_ate_vs_reference_sequence(pix):
     assert kinds == ref_kinds                                         # the same request on every frame
     assert [float(t) for t in odo.mapping.kf_timestamps] == G["m_kf_timestamps"].tolist()
     assert ate < 2e-5 and worst < 5e-5                                # metres, over a 1.45 m path (measured 7.6e-7 / 4.5e-6)
+
+
+def test_cross_covariance_half_dispatch():
+    """The reference dispatches cross_covariance for at::Half as well (cov_gpu.cu:73).  como_cross_covariance_f16 against (a) an
+    emulation of the kernel's operation sequence in torch float16 arithmetic (every operation rounded to half, like
+    c10::Half) and (b) the float32 kernel on the same half-rounded inputs."""
+    import como_amd.como_backends as cb
+    C = load_golden("cov_ops_f32.npz")
+    x1, E1, x2, E2 = (C[k].half() for k in ("x1", "E1", "x2", "E2"))
+    K16 = cb.cross_covariance(dev(x1), dev(E1), dev(x2), dev(E2), 0.8)
+    assert K16.dtype == torch.float16 and K16.shape == (x1.shape[0], x1.shape[1], x2.shape[1])
+    K32 = cb.cross_covariance(dev(x1.float()), dev(E1.float()), dev(x2.float()), dev(E2.float()), 0.8)
+    h = lambda t: t.half()
+    a, b = E1[:, :, None], E2[:, None, :]
+    dx = x1[:, :, None, 0] - x2[:, None, :, 0]
+    dy = x1[:, :, None, 1] - x2[:, None, :, 1]
+    e00, e01, e11 = a[..., 0, 0] + b[..., 0, 0], a[..., 0, 1] + b[..., 0, 1], a[..., 1, 1] + b[..., 1, 1]
+    det_inv = h(1.0 / (e00 * e11 - e01 * e01).double())
+    Q = (e11 * dx * dx) - h(torch.tensor(2.0)) * (e01 * dx * dy) + (e00 * dy * dy)
+    Q = h(Q.double() * (0.5 * det_inv.double()))
+    d1 = a[..., 0, 0] * a[..., 1, 1] - a[..., 0, 1] * a[..., 1, 0]
+    d2 = b[..., 0, 0] * b[..., 1, 1] - b[..., 0, 1] * b[..., 1, 0]
+    pw = h(torch.pow((d1 * d2).float(), 0.25))
+    ssq = lambda t: torch.sqrt(t.float().double() + 1e-8).float()                     # ref_safe_sqrt: float in, float out
+    Cc = h(2.0 * pw.double() * ssq(det_inv).double())
+    tmp = (1.73205080757 * ssq(Q).double()).float()
+    mat = (1.0 + tmp) * torch.exp(-tmp)
+    emu = h(torch.tensor(0.8)) * Cc * h(mat)
+    e_emu = ((K16.cpu().float() - emu.float()).abs().max() / emu.float().abs().max()).item()
+    e_f32 = ((K16.cpu().float() - K32.cpu()).abs().max() / K32.cpu().abs().max()).item()
+    report("cross_cov_half", vs_half_emulation=e_emu, vs_float32_kernel=e_f32)
+    assert e_emu < 2e-3 and e_f32 < 1e-2

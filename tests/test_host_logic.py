@@ -224,3 +224,19 @@ def test_slabwise_gram_equals_direct():
         assert rel(AtA, A.mT @ A) < 1e-13 and rel(Atb, A.mT @ b) < 1e-12
         x = lstsq_chol(A, b)
         assert rel(x, torch.linalg.lstsq(A, b).solution) < 1e-9
+
+
+def test_pair_graph_radius_and_degree_edges_vs_reference():
+    """setup_photometric_pairs with positive radius / degree thresholds (graph_pair_construction.py:21-94,155-182): keyframe
+    radius edges and pose-based one-way edges, against pair lists the reference produced (make_golden_r2.py::pair_graph_case)."""
+    from como_amd.odom.backend.graph_pair_construction import setup_photometric_pairs
+    G = load_golden("pair_graph.npz")
+    n_extra = 0
+    for i in range(4):
+        rad, deg = (float(x) for x in G[f"c{i}_cfg"])
+        a, b, c, d = setup_photometric_pairs(G["kf_poses"], G["recent_poses"], G["kf_timestamps"], G["recent_timestamps"],
+                                             G["median_depths"], {"radius_thresh": rad, "degrees_thresh": deg})
+        assert a == G[f"c{i}_kf_ref"].tolist() and b == G[f"c{i}_kf_tgt"].tolist(), i
+        assert c == G[f"c{i}_ow_kf"].tolist() and d == G[f"c{i}_ow_tgt"].tolist(), i
+        n_extra += len(a) - 12
+    assert n_extra > 0                                                # the radius edges are actually exercised
