@@ -86,6 +86,8 @@ def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=Non
             1, None, None, None, w["z"].data_ptr(), None, h.data_ptr(), med_out.data_ptr(), None,
             8 | (1 if hists is not None else 0) | part_flag, _lib.stream_ptr(dev))
     _lib.check(rc, "como_dense_ref (depth only)")
+    if reduce == "defer":
+        return w["z"]                                    # the caller drives the select passes (shared all-reduces)
     if reduce is not None:
         if hists is None:
             raise RuntimeError("como_amd: the sharded full-image median needs a caller-zeroed histogram workspace")

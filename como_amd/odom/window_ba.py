@@ -299,31 +299,53 @@ class WindowBA:
         return self.H, self.g
 
     def _linearize_sharded(self, dr):
-        """The multi-GPU iteration: the same kernels on this rank's pixel range, plus three kinds of collectives (all
-        `Shard.all_reduce_sum`, RCCL on the GPU): the digit histograms of the per-keyframe median depth, those of the
-        global robust scale, and the fixed-point per-pair sums.  Everything after them is replicated and bit-identical."""
+        """The multi-GPU iteration: the same kernels on this rank's pixel range, plus two kinds of collectives (all
+        `Shard.all_reduce_sum`, RCCL on the GPU): per radix-select digit pass ONE all-reduce carrying the histogram of the global
+        robust scale together with the per-keyframe histograms of the median depth (3 for float keys, 6 for double), and one
+        all-reduce of the fixed-point per-pair sums.  Everything after them is replicated and bit-identical."""
         L, a, w, dev = _lib.lib(), self.win_args, self.w, self.dev
         s = _lib.stream_ptr(dev)
         red = self.shard.all_reduce_sum
+        B = self.B
+        sfx = _lib.suffix(self.pix_dtype)
+        npass = 3 if self.pix_dtype == torch.float32 else 6
+        # --- the depth whose per-keyframe median the priors need: the full depth image (sub-selected windows) or the dense
+        #     reference itself (every pixel a reference pixel); its select passes ride on the residual median's all-reduces
         if self.full_median:
             rb, re = self.row_range
-            full_image_median(w["px_logzm"], self.Kt[:, rb:re], w["med3_full"], w["dr_ws"], hists=w["hist_full"], reduce=red)
-        Pwn = dT = uvec = None
+            zmed = full_image_median(w["px_logzm"], self.Kt[:, rb:re], w["med3_full"], w["dr_ws"], hists=w["hist_full"], reduce="defer")
+            hmed, med_out, z_idle = w["hist_full"], w["med3_full"], False
         if not self.idle:
             Pwn, dT, uvec, _, _ = dr("points")
         else:
-            z1 = torch.zeros((self.B, 1), device=dev, dtype=self.pix_dtype)
-            Pwn, dT, uvec = z1.new_zeros((self.B, 3, 1)), z1.new_zeros((self.B, 18, 1)), z1.new_zeros((self.B, 3, 1))
+            z1 = torch.zeros((B, 1), device=dev, dtype=self.pix_dtype)
+            Pwn, dT, uvec = z1.new_zeros((B, 3, 1)), z1.new_zeros((B, 18, 1)), z1.new_zeros((B, 3, 1))
         if not self.full_median:
-            key = (str(dev), self.Kt.dtype, self.B, self.n)
-            z = w["dr_ws"][key]["z"] if not self.idle else z1
-            median_passes(z, w["hist_dr"], w["med3"], red, idle=self.idle)
+            key = (str(dev), self.Kt.dtype, B, self.n)
+            zmed = w["dr_ws"][key]["z"] if not self.idle else z1
+            hmed, med_out, z_idle = w["hist_dr"], w["med3"], self.idle
+        hv = hmed.view(B, 6, 2048)
+        state = {"p": 0}
+
+        def reduce_both(h_ba):
+            p = state["p"]
+            stage = torch.cat((h_ba, hv[:, p].reshape(-1)))
+            red(stage)                                     # ONE collective per digit pass for both exact medians
+            h_ba.copy_(stage[:2048])
+            hv[:, p].copy_(stage[2048:].view(B, 2048))
+            if p + 1 < npass and not z_idle:
+                _lib.check(getattr(L, "como_select_hist_" + sfx)(zmed.data_ptr(), None, zmed.shape[1], B, hmed.data_ptr(), p + 1, s),
+                           "como_select_hist")
+            state["p"] = p + 1
+
         photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=Pwn, vals=self.vals_n,
                                     dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],
                                     img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=None, g=None,
-                                    err_out=None, sigma_out=self.sigma, pix_range=self.pix_range, reduce_hists=red,
+                                    err_out=None, sigma_out=self.sigma, pix_range=self.pix_range, reduce_hists=reduce_both,
                                     events=self.events, zeroed_hists=w["hist_ba"], ws=w["ba_ws"], sysfix=self.sysfix,
                                     fix_plane=self.fix_plane, D=self.dim, reduce_blocks=red)
+        assert state["p"] == npass
+        _lib.check(getattr(L, "como_select_finish_" + sfx)(hmed.data_ptr(), B, med_out.data_ptr(), s), "como_select_finish")
         if self.with_priors:
             _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")
         _lib.check(L.como_sys_finalize(self.sysfix.data_ptr(), self.fix_plane, self.dim, self.H.data_ptr(), self.g.data_ptr(),
