@@ -967,8 +967,12 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
 // second read of a line is an L1 / L2 hit -- HBM sees each byte once, 784 B per pixel-pair is shared as in float32).
 // Every accumulator element is owned by exactly one wave, so there is no cross-wave reduction: each wave writes its part
 // of the two per-pair records.
-template <int PF>
-__global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
+// PIPE = true : one wave per SIMD (512-register budget), the four-stage software pipeline hides the load latencies.
+// PIPE = false: two waves per SIMD (<= 256 registers: nothing of the NEXT tile is held across the matrix phase), load ->
+//               warp -> rows -> matrix phase per tile, the co-resident wave fills the gaps (MFMA and VALU time of one wave
+//               add up on a SIMD; with a single wave the matrix pipe idles 61 % of the time).
+template <int PF, bool PIPE>
+__global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
     const double* __restrict__ Pwn, const double* __restrict__ vals, const double* __restrict__ dPwn_dTwc,
     const double* __restrict__ Kt, const double* __restrict__ uvec, const int* __restrict__ pixidx,
     const double* __restrict__ invz, long kt_slot_stride, BAPairs pr, const double* __restrict__ pair_T,
@@ -981,7 +985,7 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
   using acc_t = typename Acc4<T>::type;
   __shared__ SelScratch sc;
   constexpr int STG1 = 16 * JP_STRIDE + 64 * 2;       // one pair's staged tile: 16 pose/affine rows + r~ + depth scale
-  __shared__ T lds[2 * 2 * STG1];                      // [buffer][pair]: 37.9 KB
+  __shared__ T lds[(PIPE ? 2 : 1) * 2 * STG1];         // [buffer][pair]: 37.9 KB pipelined (two buffers), 18.9 KB otherwise
   __shared__ T pxs[2][4 * 64];                         // per wave, per pixel of the tile: {sqrt(s0^2+s1^2), g-weight | s0/., s1/.}
 
   // robust scale from the finished histograms; sel_resolve is written for 256-thread blocks: feed it 128 threads x 2 rounds
@@ -1088,7 +1092,7 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
     S[64 + lane] = s * (b0 * Uv[0] + b1 * Uv[1] + b2 * Uv[2]);
   };
 
-  if (begin < end) {
+  if (PIPE && begin < end) {
     s0_load(begin);
     s1_issue(begin);
     row_cur = row_nxt;
@@ -1101,11 +1105,24 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
   }
   int buf = 0;
   for (int tile = begin; tile < end; tile += 64) {
-    T* stage = lds + buf * (2 * STG1);
+    T* stage = lds + (PIPE ? buf : 0) * (2 * STG1);
+    if constexpr (!PIPE) {
+      s0_load(tile);
+      s1_issue(tile);
+      row_cur = row_nxt;
+      static_for<PF>([&](auto ic_) {
+        constexpr int st = decltype(ic_)::value;
+        const int row = __shfl(row_cur, 4 * st + q, 64);
+        kq[st] = load4(KtS + (long)row * m);
+      });
+      __syncthreads();                             // the other wave is done reading the previous tile's rows
+    }
     s2_rows(stage + role * STG1, stage + role * STG1 + 16 * JP_STRIDE);
     __syncthreads();                               // both pairs' rows of this tile are staged (the other buffer is free again)
-    s1_issue(tile + 64);
-    s0_load(tile + 128);
+    if constexpr (PIPE) {
+      s1_issue(tile + 64);
+      s0_load(tile + 128);
+    }
     const T* J0 = stage;
     const T* J1 = stage + STG1;
     const T* S0 = J0 + 16 * JP_STRIDE;
@@ -1136,8 +1153,10 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
         {
           const int nst = st + PF;
           const bool same = nst < 16;
-          const int row = __shfl(same ? row_cur : row_nxt, 4 * (same ? nst : nst - 16) + q, 64);
-          kq[sl] = load4(KtS + (long)row * m);
+          if (PIPE || same) {
+            const int row = __shfl(same ? row_cur : row_nxt, 4 * (same ? nst : nst - 16) + q, 64);
+            kq[sl] = load4(KtS + (long)row * m);
+          }
         }
         const T sc2 = my[px];
         // depth columns WITHOUT the 1 / z_m factor: it is constant over pixels and is applied to the accumulators once
@@ -1166,7 +1185,7 @@ __global__ __launch_bounds__(128, 1) void ba_blocks_pair2_f64_kernel(
         }
       });
     }
-    row_cur = row_nxt;
+    if constexpr (PIPE) row_cur = row_nxt;
     buf ^= 1;
   }
 
@@ -1474,8 +1493,17 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
         else { LAUNCH_PIPE(2); }
       } else {
         // float64 = the reference's mapping dtype: role-specialised two-pair kernel (variant 1 keeps the plain kernel for A/B runs)
-        if (A->variant != 2 && A->variant != 1 && A->grp_pairs && A->ngrp > 0 && A->nsingle == 0) {
-          hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF>), dim3(chunks, A->ngrp), dim3(128), 0, s,
+        // default: two waves per SIMD, no software pipeline (774 us on the dense 8-keyframe window; variant 3: one wave per
+        // SIMD with the four-stage pipeline, 824 us)
+        if (A->variant != 3 && A->variant != 2 && A->variant != 1 && A->grp_pairs && A->ngrp > 0 && A->nsingle == 0) {
+          hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, false>), dim3(chunks, A->ngrp), dim3(128), 0, s,
+                             (const double*)A->Pwn, (const double*)A->vals, (const double*)A->dPwn_dTwc, (const double*)A->zjac,
+                             (const double*)A->uvec, A->pixidx, (const double*)A->invz, A->kt_slot_stride, pr,
+                             (const double*)pair_T, (const double*)pair_aff, (const double*)A->img_base, (const double*)A->K,
+                             A->H, A->W, n, m, pb, pe, chunk_len, hists, (double*)A->ws_partials, (double*)A->sigma_out,
+                             A->grp_pairs);
+        } else if (A->variant != 2 && A->variant != 1 && A->grp_pairs && A->ngrp > 0 && A->nsingle == 0) {
+          hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, true>), dim3(chunks, A->ngrp), dim3(128), 0, s,
                              (const double*)A->Pwn, (const double*)A->vals, (const double*)A->dPwn_dTwc, (const double*)A->zjac,
                              (const double*)A->uvec, A->pixidx, (const double*)A->invz, A->kt_slot_stride, pr,
                              (const double*)pair_T, (const double*)pair_aff, (const double*)A->img_base, (const double*)A->K,

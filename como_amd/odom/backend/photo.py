@@ -72,7 +72,10 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     if chunks is None and CHUNKS_OVERRIDE > 0:
         chunks = min(CHUNKS_OVERRIDE, (nl + 255) // 256)
     if chunks is None:
-        if grp_pairs is not None and grp_pairs.numel() > 0 and zmode == 1 and BLOCK_VARIANT == 0:
+        if grp_pairs is not None and grp_pairs.numel() > 0 and zmode == 1 and BLOCK_VARIANT == 0 and dtype == torch.float64:
+            # float64 two-pair kernel: 128-thread workgroups, two waves per SIMD = 4 workgroups per CU: one resident round of 1024
+            chunks = default_chunks(grp_pairs.shape[0], nl, dtype, per_cu=2)
+        elif grp_pairs is not None and grp_pairs.numel() > 0 and zmode == 1 and BLOCK_VARIANT in (0, 3):
             # two-pair kernels: 2 workgroups per CU resident (f32: 256 threads, 2 waves / SIMD; f64: 128 threads, 1 wave / SIMD)
             # -> ONE resident round of 512 workgroups (measured, dense 8-keyframe window: 64 chunks x 8 groups 313 us,
             # 128 x 8 = two rounds 338 us in float32; 841 vs 882 us in float64)
