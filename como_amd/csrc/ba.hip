@@ -136,25 +136,43 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(
   const int stride = gridDim.x * 256;
   const int nl = pix_end - pix_begin;                   // this rank's pixel range [pix_begin, pix_end) of every pair
   const int iters = (nl + stride - 1) / stride;         // uniform trip count (whole waves for the aggregated histogram)
-  for (int it = 0; it < iters; ++it) {
-    const int i0 = pix_begin + it * stride + blockIdx.x * 256 + threadIdx.x;
-    const bool inr = i0 < pix_end;
-    const int i = inr ? i0 : pix_end - 1;
-    const long ri = (long)slot * n + i;
-    T Px, Py, Pz;
-    if constexpr (SOA) { Px = Pwn[((long)slot * 3 + 0) * n + i]; Py = Pwn[((long)slot * 3 + 1) * n + i]; Pz = Pwn[((long)slot * 3 + 2) * n + i]; }
-    else { Px = Pwn[3 * ri]; Py = Pwn[3 * ri + 1]; Pz = Pwn[3 * ri + 2]; }
-    Warp<T> w = warp_point(Mr, fx, fy, cx, cy, Px, Py, Pz, H, W);
-    Taps<T> t = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
-    const T It = tap_sum(img, t);
-    const T r = It - scale * vals[ri] + bias;           // photo.py:114-118
-    if (inr) {
-      const long oi = (long)p * nl + (i - pix_begin);
-      r_out[oi] = r;
-      valid_out[oi] = w.ok ? 1 : 0;
-      if (pj_out) { pj_out[2 * oi] = w.u; pj_out[2 * oi + 1] = w.v; }
+  // UN pixels per trip: their P_w / I_ref loads, then their tap loads, are in flight together (one pixel per trip left the
+  // kernel latency-bound: 124 MB in 45 us)
+  constexpr int UN = 4;
+  for (int it0 = 0; it0 < iters; it0 += UN) {
+    int idx[UN];
+    bool inr[UN];
+    T Px[UN], Py[UN], Pz[UN], vr[UN];
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const int i0 = pix_begin + (it0 + k) * stride + blockIdx.x * 256 + threadIdx.x;
+      inr[k] = (it0 + k < iters) && (i0 < pix_end);
+      idx[k] = inr[k] ? i0 : pix_end - 1;
+      const long ri = (long)slot * n + idx[k];
+      if constexpr (SOA) {
+        Px[k] = Pwn[((long)slot * 3 + 0) * n + idx[k]]; Py[k] = Pwn[((long)slot * 3 + 1) * n + idx[k]]; Pz[k] = Pwn[((long)slot * 3 + 2) * n + idx[k]];
+      } else { Px[k] = Pwn[3 * ri]; Py[k] = Pwn[3 * ri + 1]; Pz[k] = Pwn[3 * ri + 2]; }
+      vr[k] = vals[ri];
     }
-    sel_lds_add(lh, sel_digit<KeyT>(abs_key(r), 0), inr && w.ok);
+    Warp<T> w[UN];
+    T It[UN];
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      w[k] = warp_point(Mr, fx, fy, cx, cy, Px[k], Py[k], Pz[k], H, W);
+      Taps<T> t = make_taps(grid_position(w[k].u, W, ax), grid_position(w[k].v, H, ay), H, W);
+      It[k] = tap_sum(img, t);
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const T r = It[k] - scale * vr[k] + bias;         // photo.py:114-118
+      if (inr[k]) {
+        const long oi = (long)p * nl + (idx[k] - pix_begin);
+        r_out[oi] = r;
+        valid_out[oi] = w[k].ok ? 1 : 0;
+        if (pj_out) { pj_out[2 * oi] = w[k].u; pj_out[2 * oi + 1] = w[k].v; }
+      }
+      sel_lds_add(lh, sel_digit<KeyT>(abs_key(r), 0), inr[k] && w[k].ok);
+    }
   }
   __syncthreads();
   sel_flush(lh, hists);

@@ -37,10 +37,26 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const T* __restrict__ 
       }
     }
   } else {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-      if (!valid || valid[i]) {
-        KeyT key = abs_key(r[i]);
-        if (sel_match<KeyT>(key, prefix, pass)) atomicAdd(&lh[sel_digit<KeyT>(key, pass)], 1u);
+    // four independent elements per trip (their loads in flight together): with one element per trip the double-precision
+    // pass streamed 34 MB in 32 us
+    const long stride = (long)gridDim.x * 256;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+      T e[4];
+      bool ok[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long i = i0 + k * stride;
+        ok[k] = i < n;
+        const long ic = ok[k] ? i : i0;
+        e[k] = r[ic];
+        if (valid) ok[k] = ok[k] && valid[ic];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (ok[k]) {
+          KeyT key = abs_key(e[k]);
+          if (sel_match<KeyT>(key, prefix, pass)) atomicAdd(&lh[sel_digit<KeyT>(key, pass)], 1u);
+        }
       }
     }
   }
