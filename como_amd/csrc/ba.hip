@@ -1451,7 +1451,10 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
   // digit passes 1..P-1 (multi-GPU: the caller all-reduces hists between phases 1, 2a.. and 4)
   for (int ps = 1; ps < SelCfg<KeyT>::NPASS; ++ps) {
     if (A->phase & (2 << (ps - 1))) {
-      int rc = select_hist<T>((const T*)A->ws_r, (const uint8_t*)A->ws_valid, (long)b * nl, 1, hists, ps, s);
+      // all later passes in this one call (single GPU): a double select may finish digits 4, 5 from collected candidates
+      // (select.hip); the multi-GPU protocol runs one pass per call with a histogram all-reduce in between -> plain passes
+      const int collect = ((A->phase & 0x3E) == 0x3E) ? 0x100 : 0;
+      int rc = select_hist<T>((const T*)A->ws_r, (const uint8_t*)A->ws_valid, (long)b * nl, 1, hists, ps | collect, s);
       if (rc) return rc;
     }
   }

@@ -397,7 +397,7 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
   }
   if (flags & 2) return COMO_OK;                          // points only: the median passes run elsewhere (flags & 4)
   for (int p = 1; p < SelCfg<KeyT>::NPASS; ++p) {
-    int rc = select_hist<T>(zbuf, nullptr, n, B, hists, p, s);
+    int rc = select_hist<T>(zbuf, nullptr, n, B, hists, p | 0x100, s);     // (all remaining passes here: candidates allowed)
     if (rc) return rc;
   }
   return COMO_OK;

@@ -4,16 +4,32 @@
 
 namespace como {
 
+// Double keys need six digit passes, but after four of them (43 of 64 bits) the candidate set is a handful of keys: the
+// pass-3 kernel also COLLECTS the keys that match the 33 bits resolved so far, a one-workgroup tail kernel finishes digits
+// 4 and 5 from that list (writing the same histograms the full passes would) and passes 4, 5 return at once.  Scratch lives
+// in the part of the workspace no pass uses: digits 4 and 5 are 10 bits wide, so the upper 1024 words of their slots are free
+// -- slot 4: [1024] candidate count, [1025] "done"; slot 5: [1024, 2048) = up to 512 keys.  The tail clears count and keys
+// again (consumers scan whole slots); "done" = 1 in an unused bin is harmless.  More candidates than fit (massive ties):
+// the tail only cleans up and the full passes run.
+constexpr int SEL_COLLECT = 0x100;          // flag or-ed into `pass` (pass 3 of a double select)
+constexpr int SEL_CAND_CAP = 512;
+__device__ __forceinline__ uint32_t* sel_cand_count(uint32_t* h) { return h + 4 * SEL_BINS + 1024; }
+__device__ __forceinline__ uint32_t* sel_cand_done(uint32_t* h) { return h + 4 * SEL_BINS + 1025; }
+__device__ __forceinline__ uint64_t* sel_cand_keys(uint32_t* h) { return reinterpret_cast<uint64_t*>(h + 5 * SEL_BINS + 1024); }
+
 template <typename T>
 __global__ __launch_bounds__(256) void select_hist_kernel(const T* __restrict__ r, const uint8_t* __restrict__ valid,
-                                                          long n, uint32_t* __restrict__ hists, int pass) {
+                                                          long n, uint32_t* __restrict__ hists, int pass_flags) {
   using KeyT = typename KeyOf<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
   __shared__ SelScratch sc;
+  const int pass = pass_flags & 0xff;
+  const bool collect = (sizeof(T) == 8) && (pass_flags & SEL_COLLECT) && pass == 3;
   // blockIdx.y = segment: independent selects over consecutive length-n slices (e.g. one median per keyframe)
   r += (long)blockIdx.y * n;
   if (valid) valid += (long)blockIdx.y * n;
   hists += (long)blockIdx.y * 6 * SEL_BINS;
+  if (sizeof(T) == 8 && pass >= 4 && *sel_cand_done(hists)) return;      // the tail kernel already produced this digit
   for (int b = threadIdx.x; b < SEL_BINS; b += 256) lh[b] = 0;
   KeyT prefix; uint32_t k_rem, nv;
   sel_resolve<KeyT>(hists, pass, &sc, prefix, k_rem, nv);   // contains __syncthreads (also orders the lh init)
@@ -55,13 +71,78 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const T* __restrict__ 
       for (int k = 0; k < 4; ++k) {
         if (ok[k]) {
           KeyT key = abs_key(e[k]);
-          if (sel_match<KeyT>(key, prefix, pass)) atomicAdd(&lh[sel_digit<KeyT>(key, pass)], 1u);
+          if (sel_match<KeyT>(key, prefix, pass)) {
+            atomicAdd(&lh[sel_digit<KeyT>(key, pass)], 1u);
+            if constexpr (sizeof(T) == 8) {
+              if (collect) {
+                const uint32_t slot = atomicAdd(sel_cand_count(hists), 1u);
+                if (slot < (uint32_t)SEL_CAND_CAP) sel_cand_keys(hists)[slot] = (uint64_t)key;
+              }
+            }
+          }
         }
       }
     }
   }
   __syncthreads();
   sel_flush(lh, hists + pass * SEL_BINS);
+}
+
+// digits 4 and 5 of a double select from the collected candidates (one workgroup per segment)
+__global__ __launch_bounds__(256) void select_tail_kernel(uint32_t* __restrict__ hists) {
+  using KeyT = uint64_t;
+  __shared__ SelScratch sc;
+  __shared__ uint64_t keys[SEL_CAND_CAP];
+  __shared__ uint32_t lh[1024];
+  __shared__ uint32_t part[64];
+  __shared__ uint32_t found[2];
+  hists += (long)blockIdx.x * 6 * SEL_BINS;
+  const int tid = threadIdx.x;
+  const uint32_t cnt = *sel_cand_count(hists);
+  const bool fits = cnt <= (uint32_t)SEL_CAND_CAP;
+  const uint32_t nk = fits ? cnt : (uint32_t)SEL_CAND_CAP;
+  for (uint32_t i = tid; i < nk; i += 256) keys[i] = sel_cand_keys(hists)[i];
+  __syncthreads();
+  // clean the scratch: consumers scan whole slots
+  for (int i = tid; i < 1024; i += 256) hists[5 * SEL_BINS + 1024 + i] = 0u;
+  if (tid == 0) *sel_cand_count(hists) = 0u;
+  if (!fits) return;                                   // massive ties: the full passes 4, 5 run
+  KeyT prefix; uint32_t k_rem, nv;
+  sel_resolve<KeyT>(hists, 4, &sc, prefix, k_rem, nv);
+  for (int p = 4; p < 6; ++p) {
+    for (int b = tid; b < 1024; b += 256) lh[b] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < cnt; i += 256)
+      if (sel_match<KeyT>(keys[i], prefix, p)) atomicAdd(&lh[sel_digit<KeyT>(keys[i], p)], 1u);
+    __syncthreads();
+    for (int b = tid; b < 1024; b += 256) hists[p * SEL_BINS + b] = lh[b];     // what the full pass would have accumulated
+    // the bin holding rank k_rem: 64 threads x 16 bins, prefix over the 64 partial sums by one thread
+    if (tid < 64) {
+      uint32_t s16 = 0;
+      for (int j = 0; j < 16; ++j) s16 += lh[tid * 16 + j];
+      part[tid] = s16;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t run = 0;
+      int t = 0;
+      for (; t < 64; ++t) { if (k_rem < run + part[t]) break; run += part[t]; }
+      uint32_t bin = 0, below = run;
+      if (t < 64) {
+        for (int j = 0; j < 16; ++j) {
+          const uint32_t c = lh[t * 16 + j];
+          if (k_rem < below + c) { bin = t * 16 + j; break; }
+          below += c;
+        }
+      } else below = 0;
+      found[0] = bin; found[1] = below;
+    }
+    __syncthreads();
+    prefix |= ((KeyT)found[0]) << SelCfg<KeyT>::shift(p);
+    k_rem -= found[1];
+    __syncthreads();
+  }
+  if (tid == 0) *sel_cand_done(hists) = 1u;
 }
 
 template <typename T>
@@ -83,6 +164,8 @@ __global__ __launch_bounds__(256) void select_finish_kernel(const uint32_t* __re
 template <typename T>
 int select_hist(const T* r, const uint8_t* valid, long n, int nseg, uint32_t* hists, int pass, hipStream_t s) {
   using KeyT = typename KeyOf<T>::type;
+  const int pass_flags = pass;
+  pass &= 0xff;
   if (!r || !hists || n < 0 || nseg < 1 || pass < 0 || pass >= SelCfg<KeyT>::NPASS) return COMO_ERR_ARG;
   long blocks = (n + 255) / 256;
   if (blocks < 1) blocks = 1;
@@ -92,8 +175,12 @@ int select_hist(const T* r, const uint8_t* valid, long n, int nseg, uint32_t* hi
   blocks = (blocks + 3) / 4;                         // 4 elements per thread on the vector path
   if (blocks < 1) blocks = 1;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(select_hist_kernel<T>, dim3((unsigned)blocks, nseg), dim3(256), 0, s, r, valid, n, hists, pass);
+  hipLaunchKernelGGL(select_hist_kernel<T>, dim3((unsigned)blocks, nseg), dim3(256), 0, s, r, valid, n, hists, pass_flags);
   COMO_CHECK_LAUNCH();
+  if (sizeof(T) == 8 && (pass_flags & SEL_COLLECT) && pass == 3) {
+    hipLaunchKernelGGL(select_tail_kernel, dim3(nseg), dim3(256), 0, s, hists);
+    COMO_CHECK_LAUNCH();
+  }
   return COMO_OK;
 }
 

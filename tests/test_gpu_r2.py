@@ -347,3 +347,43 @@ def test_cross_covariance_half_dispatch():
     e_f32 = ((K16.cpu().float() - K32.cpu()).abs().max() / K32.cpu().abs().max()).item()
     report("cross_cov_half", vs_half_emulation=e_emu, vs_float32_kernel=e_f32)
     assert e_emu < 2e-3 and e_f32 < 1e-2
+
+
+@pytest.mark.parametrize("case", ["random", "ties_overflow", "all_equal", "two_values", "tiny"])
+def test_double_select_with_candidate_tail(case):
+    """The double-precision exact median with the pass-3 candidate collection + one-workgroup tail (csrc/select.hip) against
+    torch.median: ordinary data (the tail finishes digits 4, 5), more tied keys than the candidate buffer holds (the tail backs
+    off and the full passes run), degenerate inputs.  Several segments at once, scratch words cleaned up afterwards."""
+    from como_amd import _lib
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(17)
+    nseg, n = 3, 60_000
+    if case == "random":
+        r = torch.randn((nseg, n), generator=g, dtype=torch.float64) * torch.exp(2 * torch.randn((nseg, n), generator=g, dtype=torch.float64))
+    elif case == "ties_overflow":
+        r = torch.randn((nseg, n), generator=g, dtype=torch.float64)
+        r[:, ::2] = 0.3125                                   # 30,000 identical keys: far more than the 512-key buffer
+    elif case == "all_equal":
+        r = torch.full((nseg, n), -2.5, dtype=torch.float64)
+    elif case == "two_values":
+        r = torch.where(torch.rand((nseg, n), generator=g) < 0.5, 1.0, 1.0 + 2.0 ** -40).double()      # differ in digit 4 only
+    else:
+        n = 5
+        r = torch.randn((nseg, n), generator=g, dtype=torch.float64)
+    rd = dev(r)
+    hb = L.como_select_workspace_bytes() // 4
+    hists = torch.empty(nseg * hb, dtype=torch.int32, device=DEV)
+    out = torch.empty((nseg, 3), dtype=torch.float64, device=DEV)
+    s = _lib.stream_ptr()
+    _lib.check(L.como_select_begin(hists.data_ptr(), nseg, s), "begin")
+    for p in range(6):
+        _lib.check(L.como_select_hist_f64(rd.data_ptr(), None, n, nseg, hists.data_ptr(), p | (0x100 if p == 3 else 0), s), "hist")
+    _lib.check(L.como_select_finish_f64(hists.data_ptr(), nseg, out.data_ptr(), s), "finish")
+    ref = torch.median(r.abs(), dim=1).values
+    hv = hists.view(nseg, 6, 2048).cpu()
+    done = hv[:, 4, 1025].tolist()
+    report("select_tail", case=case, done=done, got=out[:, 0].cpu(), want=ref)
+    assert torch.equal(out[:, 0].cpu(), ref)
+    assert (hv[:, 4, 1024] == 0).all() and (hv[:, 5, 1024:] == 0).all()          # scratch cleaned
+    # (two_values: all 60,000 keys agree on the first 33 bits -> more candidates than the buffer holds -> full passes)
+    assert done == ([0] * nseg if case in ("ties_overflow", "all_equal", "two_values") else [1] * nseg)
