@@ -32,6 +32,7 @@ class BAArgs(ctypes.Structure):
         ("ws_pair", c_void_p), ("ws_partials", c_void_p), ("grp_pairs", c_void_p), ("single_pairs", c_void_p),
         ("ngrp", c_int), ("nsingle", c_int),
         ("fix_plane", c_long), ("reduce_mode", c_int), ("blocks_fix", c_void_p),
+        ("channels", c_int), ("pair_chan", c_void_p),
     ]
 
 
@@ -69,6 +70,10 @@ SIGNATURES = {
     "como_track_level_workspace_destroy": (None, [c_void_p]),
     "como_track_level_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_void_p, c_void_p, c_int, c_float, c_float, c_float,
                                      c_void_p, c_int, c_void_p, c_void_p]),
+    "como_track_iter_channels_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int] + [c_void_p] * 10),
+    "como_track_iter_channels_f64": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int] + [c_void_p] * 10),
+    "como_track_level_channels_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_int, c_float,
+                                              c_float, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "como_ba_partials_elems": (c_long, [c_int, c_int, c_int]),
     "como_sys_fix_plane_elems": (c_long, [c_long]),
     "como_sys_finalize": (c_int, [c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -80,7 +80,11 @@ struct BAPairs {
   const int* tgt_pose;     // [b] index into poses_all of the target pose
   const long* tgt_img;     // [b] element offset of the target [I,gx,gy] stack relative to img_base
   int anorm_f32;           // sampling normalisation rounded to float32 first (two_frame_sfm.py:187-190)
+  const int* chan;         // [b] image channel of each pair (NULL: 0).  A c-channel image (`color: rgb`) is linearised as c
+  int C;                   //     pairs per keyframe pair, one per channel: photo.py:112-128 treats (pixel, channel) residuals alike
 };
+// channel ch of the target stack [I_0..I_C-1 | gx_0.. | gy_0..] (photo.py:24-27, 44-52) and of the reference values (slots,n,C)
+__device__ __forceinline__ int pair_chan(const BAPairs& pr, int p) { return pr.chan ? pr.chan[p] : 0; }
 
 template <typename T>
 __global__ void ba_pair_setup_kernel(const T* __restrict__ poses_all, const T* __restrict__ aff_all, BAPairs pr, int b,
@@ -130,8 +134,9 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(
   const T scale = pair_aff[2 * p], bias = pair_aff[2 * p + 1];
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
   const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
-  const T* img = img_base + pr.tgt_img[p];
-  const long HW = (long)H * W;
+  const int ch = pair_chan(pr, p);
+  const T* img = img_base + pr.tgt_img[p] + (long)ch * H * W;
+  const long HW = (long)pr.C * H * W;
   __syncthreads();
   const int stride = gridDim.x * 256;
   const int nl = pix_end - pix_begin;                   // this rank's pixel range [pix_begin, pix_end) of every pair
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256) void ba_residual_kernel(
       if constexpr (SOA) {
         Px[k] = Pwn[((long)slot * 3 + 0) * n + idx[k]]; Py[k] = Pwn[((long)slot * 3 + 1) * n + idx[k]]; Pz[k] = Pwn[((long)slot * 3 + 2) * n + idx[k]];
       } else { Px[k] = Pwn[3 * ri]; Py[k] = Pwn[3 * ri + 1]; Pz[k] = Pwn[3 * ri + 2]; }
-      vr[k] = vals[ri];
+      vr[k] = vals[ri * pr.C + ch];
     }
     Warp<T> w[UN];
     T It[UN];
@@ -255,8 +260,9 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
   const T scale = pair_aff[2 * p], bias = pair_aff[2 * p + 1];
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
   const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
-  const T* img = img_base + pr.tgt_img[p];
-  const long HW = (long)H * W;
+  const int ch = pair_chan(pr, p);
+  const T* img = img_base + pr.tgt_img[p] + (long)ch * H * W;
+  const long HW = (long)pr.C * H * W;
 
   T invz4[4] = {T(0), T(0), T(0), T(0)};
   if constexpr (ZMODE == 1) {
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
       Warp<T> w = warp_point(Mr, fx, fy, cx, cy, Px, Py, Pz, H, W);
       Taps<T> tp = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
       const T It = tap_sum(img, tp), gx = tap_sum(img + HW, tp), gy = tap_sum(img + 2 * HW, tp);
-      const T Iref_s = scale * vals[ri];
+      const T Iref_s = scale * vals[ri * pr.C + ch];
       const T r = It - Iref_s + bias;
       const bool ok = inr && w.ok;
       const T wr = r * info_sqrt;
@@ -477,8 +483,9 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
   const T scale = pair_aff[2 * p], bias = pair_aff[2 * p + 1];
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
   const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
-  const T* img = img_base + pr.tgt_img[p];
-  const long HW = (long)H * W;
+  const int ch = pair_chan(pr, p);
+  const T* img = img_base + pr.tgt_img[p] + (long)ch * H * W;
+  const long HW = (long)pr.C * H * W;
   T invz4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
@@ -528,7 +535,7 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
     for (int k = 0; k < 18; ++k) Dv[k] = D[(long)k * n];
     const T* U = uvec + (long)slot * 3 * n + ic;
     Uv[0] = U[0]; Uv[1] = U[n]; Uv[2] = U[2 * (long)n];
-    valv = vals[(long)slot * n + ic];
+    valv = vals[((long)slot * n + ic) * pr.C + ch];
     row_nxt = pixidx ? pixidx[(long)slot * n + ic] : ic;
   };
   auto s2_rows = [&]() {
@@ -729,11 +736,12 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
     for (int k = 0; k < 12; ++k) Mr[g][k] = pair_T[12 * (long)pg[g] + k];
     scale[g] = pair_aff[2 * pg[g]];
     bias[g] = pair_aff[2 * pg[g] + 1];
-    img[g] = img_base + pr.tgt_img[pg[g]];
+    img[g] = img_base + pr.tgt_img[pg[g]] + (long)pair_chan(pr, pg[g]) * H * W;
   }
+  const int ch = pair_chan(pr, pg[0]);              // both pairs of a group share reference slot AND channel (one I_ref load)
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
   const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
-  const long HW = (long)H * W;
+  const long HW = (long)pr.C * H * W;
   T invz4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
@@ -787,7 +795,7 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
     for (int k = 0; k < 18; ++k) Dv[k] = D[(long)k * n];
     const T* U = uvec + (long)slot * 3 * n + ic;
     Uv[0] = U[0]; Uv[1] = U[n]; Uv[2] = U[2 * (long)n];
-    valv = vals[(long)slot * n + ic];
+    valv = vals[((long)slot * n + ic) * pr.C + ch];
     row_nxt = pixidx ? pixidx[(long)slot * n + ic] : ic;
   };
   auto s2_rows = [&]() {
@@ -1025,10 +1033,11 @@ __global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
 #pragma unroll
   for (int k = 0; k < 12; ++k) Mr[k] = pair_T[12 * (long)pgm + k];
   const T scale = pair_aff[2 * pgm], bias = pair_aff[2 * pgm + 1];
-  const T* img = img_base + pr.tgt_img[pgm];
+  const int ch = pair_chan(pr, pg0);                // both pairs of a group share reference slot AND channel
+  const T* img = img_base + pr.tgt_img[pgm] + (long)pair_chan(pr, pgm) * H * W;
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
   const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
-  const long HW = (long)H * W;
+  const long HW = (long)pr.C * H * W;
   T invz4[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
@@ -1071,7 +1080,7 @@ __global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
     for (int k = 0; k < 18; ++k) Dv[k] = D[(long)k * n];
     const T* U = uvec + (long)slot * 3 * n + ic;
     Uv[0] = U[0]; Uv[1] = U[n]; Uv[2] = U[2 * (long)n];
-    valv = vals[(long)slot * n + ic];
+    valv = vals[((long)slot * n + ic) * pr.C + ch];
     row_nxt = pixidx ? pixidx[(long)slot * n + ic] : ic;
   };
   auto s2_rows = [&](T* J, T* S) {     // this wave's pair: 16 rows + r~ + depth scale of the tile loaded one stage ago
@@ -1419,7 +1428,9 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
       !A->ws_hists || !A->ws_pair || !A->ws_partials)
     return COMO_ERR_ARG;
   if (A->zmode == 1 && (!A->uvec || !A->invz)) return COMO_ERR_ARG;
-  BAPairs pr{A->ref_slot, A->ref_aff, A->tgt_aff, A->tgt_pose, A->tgt_img, A->anorm_f32};
+  if (A->channels < 0 || (A->channels > 1 && !A->pair_chan)) return COMO_ERR_ARG;
+  BAPairs pr{A->ref_slot, A->ref_aff, A->tgt_aff, A->tgt_pose, A->tgt_img, A->anorm_f32, A->channels > 1 ? A->pair_chan : nullptr,
+             A->channels > 1 ? A->channels : 1};
   const int b = A->b, n = A->n, m = A->m;
   const int pb = A->pix_begin, pe = (A->pix_end > 0) ? A->pix_end : n;
   if (pb < 0 || pe > n || pb >= pe) return COMO_ERR_ARG;

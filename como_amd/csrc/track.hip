@@ -26,7 +26,9 @@ __global__ __launch_bounds__(256) void track_residual_kernel(
     const T* __restrict__ Tji, const T* __restrict__ Kmat, const T* __restrict__ aff, const T* __restrict__ P,
     const T* __restrict__ vals_i, const T* __restrict__ img, int H, int W, long N, T* __restrict__ J8,
     T* __restrict__ r_out, uint8_t* __restrict__ valid_out, T* __restrict__ pj_out, T* __restrict__ depth_out,
-    uint32_t* __restrict__ hists, const uint8_t* __restrict__ in_mask) {
+    uint32_t* __restrict__ hists, const uint8_t* __restrict__ in_mask, int C) {
+  // C image channels (`color: rgb`): element e = pixel * C + channel of vals_i (N,C), J8 (N,C,8), r_out / valid_out (N,C);
+  // every (pixel, channel) residual is one entry of the median and of the sums (photo_tracking.py:117-143, 77-93)
   using KeyT = typename KeyOf<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
   for (int b = threadIdx.x; b < SEL_BINS; b += 256) lh[b] = 0;
@@ -42,11 +44,14 @@ __global__ __launch_bounds__(256) void track_residual_kernel(
   const T ea = exp(-aff[0]), bb = aff[1];
   __syncthreads();
   const long stride = (long)gridDim.x * 256;
-  const long iters = (N + stride - 1) / stride;               // uniform trip count (the aggregated histogram needs whole waves)
+  const long NE = N * C;
+  const long iters = (NE + stride - 1) / stride;              // uniform trip count (the aggregated histogram needs whole waves)
   for (long it = 0; it < iters; ++it) {
     const long i0 = it * stride + (long)blockIdx.x * 256 + threadIdx.x;
-    const bool inr = i0 < N;
-    const long i = inr ? i0 : N - 1;
+    const bool inr = i0 < NE;
+    const long e = inr ? i0 : NE - 1;
+    const long i = C == 1 ? e : (long)((unsigned long)e / (unsigned)C);     // pixel
+    const int ch = (int)(e - i * C);
     const T X = P[3 * i + 0], Y = P[3 * i + 1], Z = P[3 * i + 2];
     T hx, hy, hz;
     rigid_apply(Pm, X, Y, Z, hx, hy, hz);          // p_h = A P + b
@@ -55,15 +60,17 @@ __global__ __launch_bounds__(256) void track_residual_kernel(
     // is masked out behaves exactly like one that projects outside the image
     const bool ok = in_image(u, v, H, W) && (hz > T(0)) && (in_mask == nullptr || in_mask[i] != 0);
     Taps<T> t = make_taps(grid_position(u, W, ax), grid_position(v, H, ay), H, W);
-    const T It = tap_sum(img, t);
+    const T It = tap_sum(img + (long)ch * H * W, t);
     const T tmp = ea * It;                          // photo_tracking.py:124
-    const T r = (tmp + bb) - vals_i[i];
+    const T r = (tmp + bb) - vals_i[e];
     if (inr) {
-      J8[8 * i + 6] = -tmp;                         // dI_dT[..., 6] = -tmp (in-place, photo_tracking.py:125)
-      r_out[i] = r;
-      valid_out[i] = ok ? 1 : 0;
-      if (pj_out) { pj_out[2 * i] = u; pj_out[2 * i + 1] = v; }
-      if (depth_out) depth_out[i] = hz;
+      J8[8 * e + 6] = -tmp;                         // dI_dT[..., 6] = -tmp (in-place, photo_tracking.py:125)
+      r_out[e] = r;
+      valid_out[e] = ok ? 1 : 0;
+      if (ch == 0) {
+        if (pj_out) { pj_out[2 * i] = u; pj_out[2 * i + 1] = v; }
+        if (depth_out) depth_out[i] = hz;
+      }
     }
     sel_lds_add(lh, sel_digit<KeyT>(abs_key(r), 0), inr && ok);
   }
@@ -138,7 +145,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void track_finish_kernel(const double* __restrict__ partials, int nblocks,
                                                            const uint32_t* __restrict__ hists,
                                                            const T* __restrict__ Tji, const T* __restrict__ aff,
-                                                           T* __restrict__ out) {
+                                                           T* __restrict__ out, int C) {
   using KeyT = typename KeyOf<T>::type;
   __shared__ SelScratch sc;
   __shared__ double tot[TRK_ACC];
@@ -205,11 +212,11 @@ __global__ __launch_bounds__(256) void track_finish_kernel(const double* __restr
     for (int i = 0; i < 16; ++i) out[80 + i] = (T)Tn[i];
     out[96] = (T)((double)aff[0] - d[6]);
     out[97] = (T)((double)aff[1] - d[7]);
-    out[98] = (T)(tot[44] / (double)nv);
+    out[98] = (T)(tot[44] / (double)(nv / C));    // mean over the valid PIXELS (photo_tracking.py:83-85), nv counts channels
     out[99] = (T)sqrt(gn);
     out[100] = (T)tot[44];
     out[101] = T(1.4826) * key_value(prefix);
-    out[102] = (T)nv;
+    out[102] = (T)(nv / C);
     out[103] = (T)sqrt(dn);
     out[104] = (T)info;
   }
@@ -218,30 +225,31 @@ __global__ __launch_bounds__(256) void track_finish_kernel(const double* __restr
 template <typename T>
 int track_iter(const T* Tji, const T* Kmat, const T* aff, const T* P, const T* vals_i, const T* img, int H, int W,
                long N, T* J8, T* r_ws, uint8_t* valid_out, T* pj_out, T* depth_out, void* hists_v, double* partials,
-               T* out, const uint8_t* in_mask, hipStream_t s) {
+               T* out, const uint8_t* in_mask, hipStream_t s, int C = 1) {
   using KeyT = typename KeyOf<T>::type;
   if (!Tji || !Kmat || !aff || !P || !vals_i || !img || !J8 || !r_ws || !valid_out || !hists_v || !partials || !out ||
-      N <= 0 || H < 3 || W < 3)
+      N <= 0 || H < 3 || W < 3 || C < 1 || C > 4)
     return COMO_ERR_ARG;
+  const long NE = N * C;                             // (pixel, channel) elements
   uint32_t* hists = (uint32_t*)hists_v;
   if (!zero_words(hists, 6 * SEL_BINS, s)) return COMO_ERR_LAUNCH;
-  long blocks = (N + 255) / 256;
+  long blocks = (NE + 255) / 256;
   if (blocks > 1024) blocks = 1024;   // bounded: the digit-0 flush serialises per hot bin at the memory-side atomics
   hipLaunchKernelGGL(track_residual_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, s, Tji, Kmat, aff, P, vals_i, img,
-                     H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists, in_mask);
+                     H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists, in_mask, C);
   COMO_CHECK_LAUNCH();
   for (int p = 1; p < SelCfg<KeyT>::NPASS; ++p) {
-    int rc = select_hist<T>(r_ws, valid_out, N, 1, hists, p, s);
+    int rc = select_hist<T>(r_ws, valid_out, NE, 1, hists, p, s);
     if (rc) return rc;
   }
   // ~4 pixels per thread: the 46-value block reduction (shuffles + LDS) is amortised, and track_finish sums fewer partials
-  int rblocks = (int)((N + 1023) / 1024);
+  int rblocks = (int)((NE + 1023) / 1024);
   if (rblocks < 1) rblocks = 1;
   if (rblocks > TRK_MAX_BLOCKS) rblocks = TRK_MAX_BLOCKS;
-  hipLaunchKernelGGL(track_reduce_kernel<T>, dim3(rblocks), dim3(256), 256 * (TRK_ACC + 1) * sizeof(T), s, J8, r_ws, valid_out, N, hists,
+  hipLaunchKernelGGL(track_reduce_kernel<T>, dim3(rblocks), dim3(256), 256 * (TRK_ACC + 1) * sizeof(T), s, J8, r_ws, valid_out, NE, hists,
                      partials);
   COMO_CHECK_LAUNCH();
-  hipLaunchKernelGGL(track_finish_kernel<T>, dim3(1), dim3(256), 0, s, partials, rblocks, hists, Tji, aff, out);
+  hipLaunchKernelGGL(track_finish_kernel<T>, dim3(1), dim3(256), 0, s, partials, rblocks, hists, Tji, aff, out, C);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
     const float* __restrict__ P, const float* __restrict__ vals_i, const float* __restrict__ img, int H, int W, long N,
     const float* __restrict__ J8, const uint8_t* __restrict__ in_mask, TLCriteria crit, unsigned* __restrict__ bar,
     uint32_t* __restrict__ hists2, long long* __restrict__ sums2, long long* __restrict__ stamps, float* __restrict__ out,
-    int ppt, int ws_cached) {
+    int ppt, int ws_cached, int C) {
   using T = float;
   using KeyT = uint32_t;
   __shared__ uint32_t lh[SEL_BINS];
@@ -378,19 +386,23 @@ __global__ __launch_bounds__(256) void track_level_kernel(
   TLBarrier B{bar, 0u, G, ws_cached};
 
   // ---- this thread's reference pixels, register-resident for the whole level ----
+  // (C channels: an element = (pixel, channel) of vals_i (N,C) / J8 (N,C,8); its target plane is img + channel * H * W)
   T pX[TL_MAXP], pY[TL_MAXP], pZ[TL_MAXP], vref[TL_MAXP], Jc[TL_MAXP][7];
+  int choff[TL_MAXP];
   bool sel[TL_MAXP];
 #pragma unroll
   for (int k = 0; k < TL_MAXP; ++k) {
     const long i = ((long)k * G + blockIdx.x) * 256 + tid;
-    sel[k] = (k < ppt) && (i < N);
+    sel[k] = (k < ppt) && (i < N * C);
     const long ic = sel[k] ? i : 0;
-    pX[k] = P[3 * ic]; pY[k] = P[3 * ic + 1]; pZ[k] = P[3 * ic + 2];
+    const long ip = C == 1 ? ic : (long)((unsigned)ic / (unsigned)C);
+    choff[k] = (int)(ic - ip * C) * H * W;
+    pX[k] = P[3 * ip]; pY[k] = P[3 * ip + 1]; pZ[k] = P[3 * ip + 2];
     vref[k] = vals_i[ic];
     const float4 a = *reinterpret_cast<const float4*>(&J8[8 * ic]);
     const float4 b = *reinterpret_cast<const float4*>(&J8[8 * ic + 4]);
     Jc[k][0] = a.x; Jc[k][1] = a.y; Jc[k][2] = a.z; Jc[k][3] = a.w; Jc[k][4] = b.x; Jc[k][5] = b.y; Jc[k][6] = b.w;   // [6] = J7
-    if (sel[k] && in_mask) sel[k] = in_mask[ic] != 0;
+    if (sel[k] && in_mask) sel[k] = in_mask[ip] != 0;
   }
   T Tc[16], a0 = aff_init[0], a1 = aff_init[1];
 #pragma unroll
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
       const T u = hx / hz, v = hy / hz;
       ok[k] = sel[k] && in_image(u, v, H, W) && (hz > T(0));
       Taps<T> t = make_taps(grid_position(u, W, ax), grid_position(v, H, ay), H, W);
-      const T It = tap_sum(img, t);
+      const T It = tap_sum(img + choff[k], t);
       const T tmp = ea * It;
       j6[k] = -tmp;
       rk[k] = (tmp + bb) - vref[k];
@@ -596,7 +608,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
       TL_STAMP(15);
       state[16] = (T)((double)a0 - d[6]);
       state[17] = (T)((double)a1 - d[7]);
-      state[18] = (T)(tot[44] / (double)nv);
+      state[18] = (T)(tot[44] / (double)(nv / C));    // mean over valid pixels
       state[19] = (T)sqrt(gn);
       state[20] = (T)sqrt(dn);
       if (blockIdx.x == 0) {                                   // the record of this iteration, layout of como_track_iter_*
@@ -605,7 +617,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
         for (int i = 0; i < 16; ++i) out[80 + i] = state[i];
         out[96] = state[16]; out[97] = state[17];
         out[98] = state[18]; out[99] = state[19]; out[100] = (T)tot[44];
-        out[101] = sigma; out[102] = (T)nv; out[103] = state[20]; out[104] = (T)info;
+        out[101] = sigma; out[102] = (T)(nv / C); out[103] = state[20]; out[104] = (T)info;
         out[105] = (T)(it + 1);
       }
     }
@@ -646,14 +658,15 @@ long como_track_level_workspace_bytes(void) {
   return (long)como::TL_BAR_WORDS * 4 + 2L * 6 * como::SEL_BINS * 4 + (long)como::TL_SUM_WORDS * 8 + 32 * 8;   // (+ profile stamps)
 }
 
-int como_track_level_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P, const float* vals_i,
-                         const float* img, int H, int W, long N, const float* J8, const uint8_t* in_mask, int max_iter,
-                         float delta_norm, float rel_tol, float grad_norm, void* workspace, int workspace_uncached, float* out,
-                         como_stream_t stream) {
+int como_track_level_channels_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P,
+                                  const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
+                                  const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
+                                  void* workspace, int workspace_uncached, float* out, como_stream_t stream) {
   using namespace como;
   if (!Tji_init || !K || !aff_init || !P || !vals_i || !img || !J8 || !workspace || !out || N <= 0 || H < 3 || W < 3 ||
-      max_iter < 1)
+      max_iter < 1 || channels < 1 || channels > 4)
     return COMO_ERR_ARG;
+  const long NE = N * channels;
   hipStream_t s = (hipStream_t)stream;
   static int ncu = 0;
   if (ncu == 0) {
@@ -662,10 +675,10 @@ int como_track_level_f32(const float* Tji_init, const float* K, const float* aff
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return COMO_ERR_LAUNCH;
     ncu = prop.multiProcessorCount;
   }
-  long G = (N + 255) / 256;
+  long G = (NE + 255) / 256;
   if (G > ncu) G = ncu;                       // one workgroup per compute unit: all co-resident (the barrier needs that)
   if (G > 512) G = 512;
-  const long ppt = (N + G * 256 - 1) / (G * 256);
+  const long ppt = (NE + G * 256 - 1) / (G * 256);
   if (ppt > TL_MAXP) return COMO_ERR_ARG;     // larger than TL_MAXP x 256 x #CU pixels: use the como_track_iter_* chain
   unsigned* bar = (unsigned*)workspace;
   uint32_t* hists2 = (uint32_t*)workspace + TL_BAR_WORDS;
@@ -674,9 +687,33 @@ int como_track_level_f32(const float* Tji_init, const float* K, const float* aff
   if (!zero_words(workspace, TL_BAR_WORDS + 2 * 6 * SEL_BINS + 2 * TL_SUM_WORDS, s)) return COMO_ERR_LAUNCH;
   TLCriteria crit{max_iter, delta_norm, rel_tol, grad_norm};
   hipLaunchKernelGGL(track_level_kernel, dim3((unsigned)G), dim3(256), 0, s, Tji_init, K, aff_init, P, vals_i, img, H, W, N, J8,
-                     in_mask, crit, bar, hists2, sums2, stamps, out, (int)ppt, workspace_uncached ? 0 : 1);
+                     in_mask, crit, bar, hists2, sums2, stamps, out, (int)ppt, workspace_uncached ? 0 : 1, channels);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
+}
+
+int como_track_level_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P, const float* vals_i,
+                         const float* img, int H, int W, long N, const float* J8, const uint8_t* in_mask, int max_iter,
+                         float delta_norm, float rel_tol, float grad_norm, void* workspace, int workspace_uncached, float* out,
+                         como_stream_t stream) {
+  return como_track_level_channels_f32(Tji_init, K, aff_init, P, vals_i, img, H, W, N, 1, J8, in_mask, max_iter, delta_norm,
+                                       rel_tol, grad_norm, workspace, workspace_uncached, out, stream);
+}
+
+int como_track_iter_channels_f32(const float* Tji, const float* K, const float* aff, const float* P, const float* vals_i,
+                                 const float* img, int H, int W, long N, int channels, float* J8, float* r_ws,
+                                 uint8_t* valid_out, float* pj_out, float* depth_out, void* hists, void* partials, float* out,
+                                 const uint8_t* in_mask, como_stream_t stream) {
+  return como::track_iter<float>(Tji, K, aff, P, vals_i, img, H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists,
+                                 (double*)partials, out, in_mask, (hipStream_t)stream, channels);
+}
+
+int como_track_iter_channels_f64(const double* Tji, const double* K, const double* aff, const double* P, const double* vals_i,
+                                 const double* img, int H, int W, long N, int channels, double* J8, double* r_ws,
+                                 uint8_t* valid_out, double* pj_out, double* depth_out, void* hists, void* partials,
+                                 double* out, const uint8_t* in_mask, como_stream_t stream) {
+  return como::track_iter<double>(Tji, K, aff, P, vals_i, img, H, W, N, J8, r_ws, valid_out, pj_out, depth_out, hists,
+                                  (double*)partials, out, in_mask, (hipStream_t)stream, channels);
 }
 
 long como_track_partials_bytes(void) { return (long)como::TRK_MAX_BLOCKS * como::TRK_ACC * (long)sizeof(double); }

@@ -50,7 +50,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
               err_out, uvec=None, pixidx=None, invz=None, kt_slot_stride=0, chunks=None, phase=0xFF, want_pj=False,
               want_blocks=False, sigma_out=None, pix_range=None, reduce_hists=None, events=None, anorm_f32=False,
               grp_pairs=None, single_pairs=None, zeroed_hists=None, ws=None, sysfix=None, fix_plane=0, D=None,
-              reduce_blocks=None):
+              reduce_blocks=None, channels=1, pair_chan=None):
     """Thin marshalling layer over como_ba_linearize_* (see include/como_hip.h for every field).
 
     pix_range=(begin, end): this rank's share of the reference pixels of every pair (multi-GPU shard).
@@ -61,7 +61,9 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     sysfix / fix_plane / D: ORDER-INDEPENDENT assembly into the fixed-point system buffer (include/como_hip.h,
         como_sys_finalize) instead of floating-point atomics into H / g / err_out (which may then be None).
     reduce_blocks(t): multi-GPU with sysfix: called on the (b, 3936, 2) int64 fixed-point per-pair sums between the
-        reduce and the expand stage (an integer all-reduce(sum): exact, so every rank continues with identical bits)."""
+        reduce and the expand stage (an integer all-reduce(sum): exact, so every rank continues with identical bits).
+    channels / pair_chan: colour images (`color: rgb`): vals is (slots,n,c), the image stacks are (3c,H,W) and every keyframe
+        pair appears c times in the pair arrays, once per channel (`expand_channels`); b counts those entries."""
     dev = Pwn.device
     L = _lib.lib()
     pb, pe = pix_range if pix_range is not None else (0, n)
@@ -92,6 +94,12 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
         a.nsingle = single_pairs.numel() if single_pairs is not None else 0
     a.variant = BLOCK_VARIANT
     a.stagger = BLOCK_STAGGER
+    a.channels = int(channels)
+    if channels > 1:
+        if pair_chan is None or pair_chan.numel() != b or pair_chan.dtype != torch.int32 or not pair_chan.is_contiguous():
+            raise RuntimeError("como_amd: pair_chan must be a contiguous int32 tensor with one channel per pair entry")
+        _lib.require_cuda(pair_chan)
+        a.pair_chan = _lib.ptr(pair_chan)
     if sysfix is not None:
         a.h_is_f64, a.fix_plane = 2, int(fix_plane)
     else:
@@ -182,13 +190,23 @@ def _i32(x, device):
     return torch.as_tensor(x, dtype=torch.int32, device=device).contiguous()
 
 
+def expand_channels(c, *per_pair):
+    """A c-channel keyframe pair is c entries of the pair arrays (include/como_hip.h, como_ba_args.channels): entry p * c + ch
+    = pair p, channel ch.  Returns the repeated per-pair tensors and the (b * c) int32 channel of every entry."""
+    out = [t.repeat_interleave(c, dim=0).contiguous() for t in per_pair]
+    b = per_pair[0].shape[0]
+    chan = torch.arange(c, dtype=torch.int32, device=per_pair[0].device).repeat(b).contiguous()
+    return out, chan
+
+
 def batch_photo_cost(vals_i, aff_params_i, Pwn, Twcj, aff_params_j, img_and_grads_j, dPwn_dTwci, dPwn_dzm, dzm_dPwm,
                      pose_ref_inds, pose_target_inds, landmark_inds, intrinsics, H, g):
     """reference photo.py:83-233: accumulates the photometric normal equations of b pairs into H, g; returns the
-    robustified total error (0-dim tensor).  Gray images only (c = 1)."""
+    robustified total error (0-dim tensor).  c = vals_i.shape[2] image channels (gray 1, rgb 3)."""
     b, n, _, m, _ = dPwn_dzm.shape
-    if vals_i.shape[2] != 1:
-        raise RuntimeError("como_amd: gray images (c = 1) only")
+    c = vals_i.shape[2]
+    if img_and_grads_j.shape[1] != 3 * c:
+        raise RuntimeError("como_amd: img_and_grads_j must hold 3 c channels [I | dI/dx | dI/dy] for vals_i of c channels")
     if m % 4 != 0 or m > 64:
         raise RuntimeError("como_amd: m must be a multiple of 4 and <= 64")
     dev, dt = vals_i.device, vals_i.dtype
@@ -197,14 +215,21 @@ def batch_photo_cost(vals_i, aff_params_i, Pwn, Twcj, aff_params_j, img_and_grad
     aff_all = torch.cat((aff_params_i.reshape(b, 2), aff_params_j.reshape(b, 2)), dim=0).contiguous()
     img = img_and_grads_j.contiguous()
     err = torch.zeros((), dtype=torch.float64, device=dev)
-    linearize(dtype=dt, b=b, n=n, m=m, H_img=Hh, W_img=Ww, zmode=0, Pwn=Pwn.contiguous(), vals=vals_i.reshape(b, n).contiguous(),
+    tgt_img = torch.arange(b, dtype=torch.int64, device=dev) * (3 * c * Hh * Ww)
+    pri, pti, lmi, chan = pose_ref_inds, pose_target_inds, landmark_inds, None
+    if c > 1:
+        (ar, tgt_img, pri, pti, lmi), chan = expand_channels(c, ar, tgt_img, pri, pti, lmi)
+    linearize(dtype=dt, b=b * c, n=n, m=m, H_img=Hh, W_img=Ww, zmode=0, Pwn=Pwn.contiguous(), vals=vals_i.contiguous(),
               dPwn_dTwc=dPwn_dTwci.contiguous(), zjac=dPwn_dzm.contiguous(), poses_all=Twcj.contiguous(), aff_all=aff_all,
               img_base=img, K=intrinsics.contiguous(), ref_slot=ar, ref_aff=ar, tgt_aff=(ar + b).contiguous(), tgt_pose=ar,
-              tgt_img=(torch.arange(b, dtype=torch.int64, device=dev) * (3 * Hh * Ww)).contiguous(),
-              pose_ref_inds=pose_ref_inds.contiguous(), pose_tgt_inds=pose_target_inds.contiguous(),
-              landmark_inds=landmark_inds.contiguous(), dzdP=dzm_dPwm[:, 0, 0, :].contiguous(), H=H, g=g, err_out=err,
-              want_pj=True)
-    last_aux["valid"] = last_aux["valid"].bool()
+              tgt_img=tgt_img.contiguous(), pose_ref_inds=pri.contiguous(), pose_tgt_inds=pti.contiguous(),
+              landmark_inds=lmi.contiguous(), dzdP=dzm_dPwm[:, 0, 0, :].contiguous(), H=H, g=g, err_out=err,
+              want_pj=True, channels=c, pair_chan=chan)
+    # per keyframe pair as the reference returns them: the mask / projection do not depend on the channel; r is (b,n,c)
+    last_aux["valid"] = last_aux["valid"][::c].bool()
+    if c > 1:
+        last_aux["pj"] = last_aux["pj"][::c]
+        last_aux["r"] = last_aux["r"].view(b, c, -1).transpose(1, 2)
     return err.to(dt)
 
 
@@ -243,9 +268,18 @@ class PairTable:
     reused by every GN iteration: no per-iteration host->device traffic)."""
 
     def __init__(self, ref_ids, tgt_ids, tgt_is_recent, num_kf, kf_inds, recent_inds, landmark_inds, img_stride,
-                 recent_img_offset, device):
+                 recent_img_offset, device, channels=1):
+        # colour images: every keyframe pair becomes `channels` consecutive entries, one per channel (como_ba_args.channels);
+        # img_stride is the size of a frame's whole (3c,H,W) stack
+        self.channels = c = int(channels)
+        self.npairs = len(ref_ids)
+        if c > 1:
+            ref_ids = [r for r in ref_ids for _ in range(c)]
+            tgt_ids = [t for t in tgt_ids for _ in range(c)]
+            tgt_is_recent = [r for r in tgt_is_recent for _ in range(c)]
         b = len(ref_ids)
         self.b = b
+        self.pair_chan = _i32([p_ % c for p_ in range(b)], device) if c > 1 else None
         self.ref_slot = _i32(ref_ids, device)
         self.ref_aff = _i32(ref_ids, device)
         tgt_frame = [t + (num_kf if r else 0) for t, r in zip(tgt_ids, tgt_is_recent)]
@@ -262,7 +296,7 @@ class PairTable:
         # pairs sharing their reference keyframe, two at a time (csrc/ba.hip ba_blocks_pair2_kernel); the rest one by one
         by_ref = {}
         for p_, r_ in enumerate(ref_ids):
-            by_ref.setdefault(int(r_), []).append(p_)
+            by_ref.setdefault((int(r_), p_ % c), []).append(p_)     # same reference keyframe AND channel
         grp = []
         for lst in by_ref.values():
             while len(lst) >= 2:
@@ -281,9 +315,11 @@ def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uv
     """Fast path: same normal equations as batch_photo_cost from the rank-1 factors of dPwn_dzm.
     Per-keyframe arrays (slots = keyframes): Pwn (B,n,3) vals (B,n) dPwn_dTwc (B,n,3,6) uvec (B,n,3) invz (B,m)
     Kt (B,rows,m) dense predictor, pixidx (B,n) int32 rows of Kt (None = identity), dzdP (B,3)."""
-    B, n = vals.shape
+    B, n = vals.shape[:2]                                  # (B,n) gray or (B,n,c)
+    if (vals.shape[2] if vals.dim() == 3 else 1) != table.channels:
+        raise RuntimeError("como_amd: vals must be (B,n,c) with the pair table's channel count")
     m = Kt.shape[-1]
-    return linearize(dtype=vals.dtype, b=table.b, n=n, m=m, H_img=H_img, W_img=W_img, zmode=1, Pwn=Pwn, vals=vals,
+    return linearize(dtype=vals.dtype, b=table.b, channels=table.channels, pair_chan=table.pair_chan, n=n, m=m, H_img=H_img, W_img=W_img, zmode=1, Pwn=Pwn, vals=vals,
                      dPwn_dTwc=dPwn_dTwc, zjac=Kt, uvec=uvec, pixidx=pixidx, invz=invz,
                      kt_slot_stride=Kt.stride(0), poses_all=poses_all, aff_all=aff_all, img_base=img_base, K=K,
                      ref_slot=table.ref_slot, ref_aff=table.ref_aff, tgt_aff=table.tgt_aff, tgt_pose=table.tgt_pose,

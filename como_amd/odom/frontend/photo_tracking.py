@@ -3,7 +3,7 @@
 Same names, argument meaning and return values as the reference functions; the per-pixel work of
 `tracking_iter` (warp, sampling, residual, validity mask, exact median, Huber-weighted 8x8 normal
 equations, solve, pose update) runs in the HIP kernel chain of csrc/track.hip through the C ABI
-(`como_track_iter_*`).  Gray images (c = 1) only; no CPU fallback.
+(`como_track_iter_*`; `como_track_*_channels_*` for colour images, c = 3).  No CPU fallback.
 """
 import torch
 
@@ -14,6 +14,7 @@ _ws_cache = {}
 
 
 def _new_workspace(device, dtype, N):
+    """N = residual entries = pixels x image channels."""
     L = _lib.lib()
     return {"r": torch.empty(N, device=device, dtype=dtype),
             "hists": torch.empty(L.como_select_workspace_bytes() // 4, device=device, dtype=torch.int32),
@@ -58,33 +59,41 @@ def precalc_jacobians(dI_dw, P, vals, intrinsics):
 
 def tracking_iter_raw(Tji, Pi, intrinsics, img_j, aff, vals_i, dI_dT, want_proj=True, in_mask=None, ws=None):
     """Enqueue one GN iteration; returns (out[105], valid u8 (N,), pj (N,2) or None, depth (N,) or None).
-    in_mask (N,) uint8: reference-side selection applied in the kernel (0 = ignore the point)."""
+    in_mask (N,) uint8: reference-side selection applied in the kernel (0 = ignore the point).
+    c = img_j.shape[1] image channels: vals_i (1,N,c), dI_dT (1,N,c,8) (column 6 is overwritten in place as the reference does)."""
     _lib.require_cuda(Tji, Pi, intrinsics, img_j, aff, vals_i, dI_dT)
-    if img_j.shape[0] != 1 or img_j.shape[1] != 1 or Pi.shape[0] != 1:
-        raise RuntimeError("como_amd tracking: batch 1, gray (c = 1) only")
+    if img_j.shape[0] != 1 or Pi.shape[0] != 1:
+        raise RuntimeError("como_amd tracking: batch 1 only")
     dt, dev = Pi.dtype, Pi.device
     N = Pi.shape[1]
+    c = img_j.shape[1]
+    if vals_i.numel() != N * c or dI_dT.numel() != N * c * 8:
+        raise RuntimeError("como_amd tracking: vals_i must be (1,N,c) and dI_dT (1,N,c,8) for an image of c channels")
     H, W = img_j.shape[-2:]
     for t in (Tji, Pi, intrinsics, img_j, aff, vals_i, dI_dT):
         if not t.is_contiguous() or t.dtype != dt:
             raise RuntimeError("como_amd tracking: inputs must be contiguous and share one dtype")
-    ws = ws if ws is not None else _workspace(dev, dt, N)
+    ws = ws if ws is not None else _workspace(dev, dt, N * c)
     out = torch.empty(105, device=dev, dtype=dt)
-    valid = torch.empty(N, device=dev, dtype=torch.uint8)
+    valid = torch.empty(N * c, device=dev, dtype=torch.uint8)
     pj = torch.empty((N, 2), device=dev, dtype=dt) if want_proj else None
     depth = torch.empty(N, device=dev, dtype=dt) if want_proj else None
     args = [_lib.ptr(Tji), _lib.ptr(intrinsics), _lib.ptr(aff), _lib.ptr(Pi), _lib.ptr(vals_i), _lib.ptr(img_j), H, W, N,
             _lib.ptr(dI_dT), _lib.ptr(ws["r"]), _lib.ptr(valid), _lib.ptr(pj), _lib.ptr(depth), _lib.ptr(ws["hists"]),
             _lib.ptr(ws["partials"]), _lib.ptr(out)]
-    if in_mask is None:
+    if in_mask is not None and (in_mask.dtype != torch.uint8 or in_mask.numel() != N or not in_mask.is_contiguous()):
+        raise RuntimeError("como_amd tracking: in_mask must be a contiguous uint8 tensor of N elements")
+    if c > 1:
+        fn = getattr(_lib.lib(), "como_track_iter_channels_" + _lib.suffix(dt))
+        args.insert(9, c)
+        args.append(_lib.ptr(in_mask))
+    elif in_mask is None:
         fn = getattr(_lib.lib(), "como_track_iter_" + _lib.suffix(dt))
     else:
-        if in_mask.dtype != torch.uint8 or in_mask.numel() != N or not in_mask.is_contiguous():
-            raise RuntimeError("como_amd tracking: in_mask must be a contiguous uint8 tensor of N elements")
         fn = getattr(_lib.lib(), "como_track_iter_masked_" + _lib.suffix(dt))
         args.append(_lib.ptr(in_mask))
     _lib.check(fn(*args, _lib.stream_ptr(dev)), "como_track_iter")
-    return out, valid, pj, depth
+    return out, (valid if c == 1 else valid.view(N, c)[:, 0]), pj, depth
 
 
 def tracking_iter(Tji, Pi, intrinsics, img_j, aff, vals_i, dI_dT, photo_sigma, A_norm):
@@ -112,7 +121,7 @@ class _LevelGraph:
         self.T = torch.zeros((1, 4, 4), device=dev, dtype=dt)
         self.aff = torch.zeros((1, 2, 1), device=dev, dtype=dt)
         self.ring = torch.zeros((LOOKAHEAD, 105), device=dev, dtype=dt)      # per-iteration results between read-backs
-        self.ws = _new_workspace(dev, dt, Pi.shape[1])                       # owned: the graph records its addresses
+        self.ws = _new_workspace(dev, dt, Pi.shape[1] * img_j.shape[1])      # owned: the graph records its addresses
         self.out = None
         self.graph = None
         self.dev = dev
@@ -185,10 +194,13 @@ def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, int
     host read-back.  Returns (Tji (1,4,4), aff (1,2,1), out (106,)) -- all device tensors; out[105] = iterations run.
     None if the level does not fit the persistent kernel (then the per-iteration chain runs)."""
     dev, dt = Pi.device, Pi.dtype
-    if dt != torch.float32 or not Pi.is_cuda or img_j.shape[0] != 1 or img_j.shape[1] != 1 or Pi.shape[0] != 1:
+    if dt != torch.float32 or not Pi.is_cuda or img_j.shape[0] != 1 or Pi.shape[0] != 1:
         return None
     L = _lib.lib()
     N = Pi.shape[1]
+    c = img_j.shape[1]
+    if vals_i.numel() != N * c or dI_dT.numel() != N * c * 8:
+        raise RuntimeError("como_amd tracking: vals_i must be (1,N,c) and dI_dT (1,N,c,8) for an image of c channels")
     H, W = img_j.shape[-2:]
     for t in (Tji_init, Pi, intrinsics, img_j, aff_init, vals_i, dI_dT):
         if not t.is_contiguous() or t.dtype != dt:
@@ -209,10 +221,11 @@ def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, int
         if wsp:
             ws_ptr, uncached = wsp, 1
     out = torch.empty(106, device=dev, dtype=dt)
-    rc = L.como_track_level_f32(_lib.ptr(Tji_init), _lib.ptr(intrinsics), _lib.ptr(aff_init), _lib.ptr(Pi), _lib.ptr(vals_i),
-                                _lib.ptr(img_j), H, W, N, _lib.ptr(dI_dT), _lib.ptr(in_mask), int(term_criteria["max_iter"]),
-                                float(term_criteria["delta_norm"]), float(term_criteria["rel_tol"]), float(term_criteria["grad_norm"]),
-                                ws_ptr, uncached, _lib.ptr(out), _lib.stream_ptr(dev))
+    rc = L.como_track_level_channels_f32(_lib.ptr(Tji_init), _lib.ptr(intrinsics), _lib.ptr(aff_init), _lib.ptr(Pi),
+                                         _lib.ptr(vals_i), _lib.ptr(img_j), H, W, N, c, _lib.ptr(dI_dT), _lib.ptr(in_mask),
+                                         int(term_criteria["max_iter"]), float(term_criteria["delta_norm"]),
+                                         float(term_criteria["rel_tol"]), float(term_criteria["grad_norm"]), ws_ptr, uncached,
+                                         _lib.ptr(out), _lib.stream_ptr(dev))
     if rc == 1:                                            # COMO_ERR_ARG: more pixels than the persistent kernel holds
         return None
     _lib.check(rc, "como_track_level")

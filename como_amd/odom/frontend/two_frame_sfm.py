@@ -16,19 +16,22 @@ from como_amd.odom.backend.dense_ref import dense_reference_factored
 _tables = {}
 
 
-def _table(m, device):
-    key = (m, str(device))
+def _table(m, device, c=1):
+    """Pair arrays of the one (i -> j) pair; c image channels = c entries, one per channel (como_ba_args.channels)."""
+    key = (m, str(device), c)
     t = _tables.get(key)
     if t is None:
-        i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)
+        i32 = lambda v: torch.tensor(v * c, dtype=torch.int32, device=device)
         D = 16 + m + 1
         lm = torch.full((1, 3 * m), D - 1, dtype=torch.long, device=device)       # d-columns -> 16+k; the two unused
         lm[0, 0::3] = torch.arange(16, 16 + m, device=device)                      # "landmark" axes land in a trash row
         sel = torch.cat((torch.arange(6, device=device), torch.arange(16, 16 + m, device=device)))
         t = {"ref_slot": i32([0]), "ref_aff": i32([0]), "tgt_aff": i32([1]), "tgt_pose": i32([1]),
-             "tgt_img": torch.zeros(1, dtype=torch.int64, device=device),
-             "pose_ref": torch.arange(8, device=device).reshape(1, 8), "pose_tgt": torch.arange(8, 16, device=device).reshape(1, 8),
-             "lm": lm, "sel": sel, "D": D}
+             "tgt_img": torch.zeros(c, dtype=torch.int64, device=device),
+             "pose_ref": torch.arange(8, device=device).reshape(1, 8).repeat(c, 1),
+             "pose_tgt": torch.arange(8, 16, device=device).reshape(1, 8).repeat(c, 1),
+             "lm": lm.repeat(c, 1), "sel": sel, "D": D,
+             "chan": torch.arange(c, dtype=torch.int32, device=device) if c > 1 else None}
         _tables[key] = t
     return t
 
@@ -37,14 +40,16 @@ def construct_photo_system(Tji, sparse_log_depth, aff, test_coords_i, vals_i, Kn
                            photo_sigma, H, g):
     """reference two_frame_sfm.py:232-269, same arguments and return tuple
     (total_err, log_depth_i (1,N,1), coords_j, depths_j, valid_mask (1,N), Pi (1,N,3)); H (6+m,6+m), g (6+m) accumulated.
-    Gray images (c = 1); `aff` and `photo_sigma` are unused there as well."""
+    vals_i (1,c,N) and img_and_grads_j (1,3c,H,W) as the reference passes them (c = 1 gray, 3 rgb: linearize_photo :180-200);
+    `aff` and `photo_sigma` are unused there as well."""
     _lib.require_cuda(Tji, sparse_log_depth, test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, intrinsics, H, g)
     dt, dev = Knm_Kmminv.dtype, Knm_Kmminv.device
     N, m = Knm_Kmminv.shape[1], Knm_Kmminv.shape[2]
     Hh, Ww = img_and_grads_j.shape[-2:]
-    if img_and_grads_j.shape[1] != 3:
-        raise RuntimeError("como_amd two_frame_sfm: gray images (c = 1) only")
-    tb = _table(m, dev)
+    c = img_and_grads_j.shape[1] // 3
+    if img_and_grads_j.shape[1] != 3 * c or vals_i.numel() != c * N:
+        raise RuntimeError("como_amd two_frame_sfm: img_and_grads_j must be (1,3c,H,W) and vals_i (1,c,N)")
+    tb = _table(m, dev, c)
     pixcoord = (test_coords_i[..., 0] * Ww + test_coords_i[..., 1]).to(torch.int32).reshape(1, N).contiguous()
     zeros6 = torch.zeros((1, m, 6), dtype=dt, device=dev)
     Kt = Knm_Kmminv.contiguous()
@@ -58,7 +63,8 @@ def construct_photo_system(Tji, sparse_log_depth, aff, test_coords_i, vals_i, Kn
     err = torch.zeros((), dtype=torch.float64, device=dev)
     ones = torch.ones((1, m), dtype=dt, device=dev)
     dzdP = torch.tensor([[1.0, 0.0, 0.0]], dtype=dt, device=dev)
-    photo.linearize(dtype=dt, b=1, n=N, m=m, H_img=Hh, W_img=Ww, zmode=1, Pwn=Pj, vals=vals_i.reshape(1, N).to(dt).contiguous(),
+    vals = vals_i.reshape(1, c, N).transpose(1, 2).to(dt).contiguous()        # (1,N,c): the kernels' (slots,n,c) layout
+    photo.linearize(dtype=dt, b=c, n=N, m=m, H_img=Hh, W_img=Ww, zmode=1, Pwn=Pj, vals=vals, channels=c, pair_chan=tb["chan"],
                     dPwn_dTwc=dPj_dT, zjac=Kt, uvec=uvec, pixidx=None, invz=ones, kt_slot_stride=Kt.stride(0), poses_all=poses,
                     aff_all=aff0, img_base=img_and_grads_j.to(dt).contiguous(), K=intrinsics.to(dt).contiguous(),
                     ref_slot=tb["ref_slot"], ref_aff=tb["ref_aff"], tgt_aff=tb["tgt_aff"], tgt_pose=tb["tgt_pose"],
@@ -68,14 +74,14 @@ def construct_photo_system(Tji, sparse_log_depth, aff, test_coords_i, vals_i, Kn
     H += Hs[sel][:, sel]
     g += gs[sel]
     aux = photo.last_aux
-    valid = aux["valid"].reshape(1, N).bool()
+    valid = aux["valid"].reshape(c, N)[:1].bool()              # the mask does not depend on the channel
     # Pi = Tji^-1 Pj is not needed by the kernels; the reference returns it (two_frame_sfm.py:269) -> rebuild from logz
     z = torch.exp(logz.reshape(1, N, 1))
     K = intrinsics
     ray = torch.stack(((test_coords_i[..., 1].to(dt) - K[0, 2]) / K[0, 0], (test_coords_i[..., 0].to(dt) - K[1, 2]) / K[1, 1],
                        torch.ones((1, N), dtype=dt, device=dev)), dim=-1)
     Pi = z * ray
-    pj = aux["pj"].reshape(1, N, 2)
+    pj = aux["pj"].reshape(c, N, 2)[:1]
     vm = valid[0]
     coords_j = torch.stack((pj[0, vm, 1], pj[0, vm, 0]), dim=-1)[None]                   # swap_coords_xy(pj)[valid]
     depths_j = Pj[0, 2, vm].reshape(1, -1, 1)

@@ -107,7 +107,10 @@ class WindowBA:
         self.coords_n = coords_n
         self.n_total = coords_n.shape[1]
         self.pixidx = (coords_n[..., 0] * self.Wimg + coords_n[..., 1]).to(torch.int32).contiguous()
-        self.vals_n = torch.gather(self.img[:B, 0].reshape(B, -1), 1, self.pixidx.long()).contiguous()
+        # vals_n (B,n) gray / (B,n,c) colour = kf_img_and_grads[b, :c, row, col] (Mapping.py:677-681)
+        c = self.channels = self.img.shape[1] // 3
+        vals = torch.gather(self.img[:B, :c].reshape(B, c, -1), 2, self.pixidx.long()[:, None].expand(-1, c, -1))
+        self.vals_n = (vals[:, 0] if c == 1 else vals.transpose(1, 2)).contiguous()
         self.idle = False
         if self.shard is not None:
             # One process per GPU: this rank owns a contiguous range of the reference pixels of EVERY keyframe -- to all
@@ -185,9 +188,9 @@ class WindowBA:
         if getattr(self, "table", None) is not None and pairs == (self.kf_pairs, self.one_way_pairs):
             return
         self.kf_pairs, self.one_way_pairs = pairs
+        stack = 3 * self.channels * self.Himg * self.Wimg          # one frame's [I | dI/dx | dI/dy] stack
         self.table = photo.PairTable(ref + ow_kf, tgt + ow_t, [False] * len(ref) + [True] * len(ow_kf), B, self.kf_inds,
-                                     self.recent_inds, self.landmark_inds, 3 * self.Himg * self.Wimg,
-                                     B * 3 * self.Himg * self.Wimg, dev)
+                                     self.recent_inds, self.landmark_inds, stack, B * stack, dev, channels=self.channels)
 
     def _prepare_fused(self):
         B, m, L, F, dev, p = self.B, self.m, self.L, self.F, self.dev, self.pix_dtype

@@ -80,7 +80,7 @@ class PlaneScene:
 
 
 def scharr_and_stack(img):
-    """(B,1,H,W) -> (B,3,H,W) [I, gx, gy]: Scharr/32 with reflect padding.
+    """(B,c,H,W) -> (B,3c,H,W) [I | gx | gy] (each c channels): Scharr/32 with reflect padding.
 
     Same filter as reference como/utils/image_processing.py:8-44 (test/bench
     input construction only; the product kernel is como_amd.utils.image_processing).
@@ -88,8 +88,9 @@ def scharr_and_stack(img):
     kx = torch.tensor([[-3.0, 0.0, 3.0], [-10.0, 0.0, 10.0], [-3.0, 0.0, 3.0]],
                       dtype=img.dtype, device=img.device) / 32.0
     p = torch.nn.functional.pad(img, (1, 1, 1, 1), mode="reflect")
-    gx = torch.nn.functional.conv2d(p, kx.view(1, 1, 3, 3))
-    gy = torch.nn.functional.conv2d(p, kx.T.contiguous().view(1, 1, 3, 3))
+    c = img.shape[1]
+    gx = torch.nn.functional.conv2d(p, kx.view(1, 1, 3, 3).repeat(c, 1, 1, 1), groups=c)
+    gy = torch.nn.functional.conv2d(p, kx.T.contiguous().view(1, 1, 3, 3).repeat(c, 1, 1, 1), groups=c)
     return torch.cat((img, gx, gy), dim=1)
 
 
@@ -205,9 +206,32 @@ def build_landmarks(scene, T_gt, K, H, W, m, seed=0, reuse_frac=0.625, border=4)
     return torch.stack(coords_sorted), corr, torch.stack(P_all)
 
 
+def make_recent(ts, H, W, seed, dtype=torch.float64, device="cpu", channels=1, pose_noise=1e-3, aff_noise=0.02):
+    """One-way frames at (fractional) keyframe times `ts` of the make_window(seed) scene: images (same textures, channel for
+    channel), perturbed poses and affine parameters -- what the reference Mapping holds in its recent_* members."""
+    g = torch.Generator().manual_seed(seed + 5)
+    K64 = intrinsics_for(H, W, torch.float64)
+    scenes = [PlaneScene(seed=seed + 1000 * ch, dtype=torch.float64, device="cpu", freq_scale=W / 640.0) for ch in range(channels)]
+    imgs, poses = [], []
+    for t in ts:
+        xi = torch.zeros(1, 6, dtype=torch.float64)
+        xi[0, 1] = t * math.pi / 180.0
+        Tr = se3_exp(xi)[0]
+        Tr[0, 3] = 0.02 * t
+        Tr[1, 3] = 0.004 * t
+        imgs.append(torch.stack([sc.render(Tr, K64, H, W)[0] for sc in scenes]))
+        poses.append(Tr @ se3_exp(pose_noise * torch.randn((1, 6), generator=g, dtype=torch.float64))[0])
+    aff = aff_noise * torch.randn((len(ts), 2, 1), generator=g, dtype=torch.float64)
+    return {"recent_img_and_grads": scharr_and_stack(torch.stack(imgs).to(dtype)).to(device),
+            "recent_poses": torch.stack(poses).to(dtype).to(device), "recent_aff_params": aff.to(dtype).to(device),
+            "recent_timestamps": torch.tensor(list(ts), dtype=dtype, device=device)}
+
+
 def make_window(B=8, H=480, W=640, m=64, dtype=torch.float64, device="cpu", seed=0,
-                predictor=None, pose_noise=1e-3, depth_noise=0.02, aff_noise=0.0):
+                predictor=None, pose_noise=1e-3, depth_noise=0.02, aff_noise=0.0, channels=1):
     """Build one keyframe-window state (what reference Mapping holds before iterate()).
+    channels = 3: colour images (`color: rgb`): channel 0 is the gray scene's texture, channels 1 and 2 are two more
+    textures on the same plane.
 
     predictor(cov_params_img (B,4,H,W), coords_m (B,m,2)) -> (K_mm_inv, L_mm, Knm_Kmminv (B,H,W,m))
     """
@@ -221,6 +245,9 @@ def make_window(B=8, H=480, W=640, m=64, dtype=torch.float64, device="cpu", seed
         imgs.append(I)
         depths.append(z)
     img = torch.stack(imgs)[:, None]
+    for ch in range(1, channels):
+        tex = PlaneScene(seed=seed + 1000 * ch, dtype=torch.float64, device="cpu", freq_scale=W / 640.0)
+        img = torch.cat((img, torch.stack([tex.render(T_gt[k], K64, H, W)[0] for k in range(B)])[:, None]), dim=1)
     img = img + 0.002 * torch.randn(img.shape, generator=g, dtype=torch.float64)
     depth_gt = torch.stack(depths)
     img_and_grads = scharr_and_stack(img.to(dtype))
@@ -266,23 +293,28 @@ def make_window(B=8, H=480, W=640, m=64, dtype=torch.float64, device="cpu", seed
 
 
 def make_tracking_pair(H=480, W=640, dtype=torch.float32, device="cpu", seed=0, levels=3,
-                       pose_noise=1e-3):
-    """Reference keyframe (image, GT depth) + a second frame, for 2-frame tracking (config 2)."""
+                       pose_noise=1e-3, channels=1):
+    """Reference keyframe (image, GT depth) + a second frame, for 2-frame tracking (config 2).
+    channels = 3: colour images (the gray texture + two more textures on the same plane)."""
     g = torch.Generator().manual_seed(seed)
     scene = PlaneScene(seed=seed, freq_scale=W / 640.0)
     K = intrinsics_for(H, W)
     T = gt_poses(2, step=0.012, deg=0.7)
     I0, z0 = scene.render(T[0], K, H, W)
     I1, _ = scene.render(T[1], K, H, W)
+    if channels > 1:
+        tex = [PlaneScene(seed=seed + 1000 * ch, freq_scale=W / 640.0) for ch in range(1, channels)]
+        I0 = torch.stack([I0] + [t.render(T[0], K, H, W)[0] for t in tex])
+        I1 = torch.stack([I1] + [t.render(T[1], K, H, W)[0] for t in tex])
     I0 = I0 + 0.002 * torch.randn(I0.shape, generator=g, dtype=torch.float64)
     I1 = 0.97 * (I1 + 0.002 * torch.randn(I1.shape, generator=g, dtype=torch.float64)) + 0.01
     T10_gt = torch.linalg.inv(T[1]) @ T[0]  # T_ji: i = ref (0), j = current (1)
     xi = pose_noise * torch.randn((1, 6), generator=g, dtype=torch.float64)
     T10_init = T10_gt[None] @ se3_exp(xi)
     return {
-        "img_ref": I0[None, None].to(dtype).to(device),
+        "img_ref": (I0[None, None] if channels == 1 else I0[None]).to(dtype).to(device),
         "depth_ref": z0[None, None].to(dtype).to(device),
-        "img_cur": I1[None, None].to(dtype).to(device),
+        "img_cur": (I1[None, None] if channels == 1 else I1[None]).to(dtype).to(device),
         "intrinsics": K.to(dtype).to(device),
         "Tji_gt": T10_gt[None].to(dtype).to(device),
         "Tji_init": T10_init.to(dtype).to(device),

@@ -97,6 +97,25 @@ int como_track_level_f32(const float* Tji_init, const float* K, const float* aff
                          float delta_norm, float rel_tol, float grad_norm, void* workspace, int workspace_uncached, float* out,
                          como_stream_t stream);
 
+/* Colour images (`color: rgb`, config/como.yml:7; photo_tracking.py works on (1,N,c) values and (1,N,c,8) Jacobians): the
+ * same iteration / level with `channels` = c image channels.  vals_i (N,c), J8 (N,c,8), img (c,H,W) planes, r_ws (N,c),
+ * valid_out (N,c) u8 workspace (every channel of a pixel carries the pixel's mask; the reference's (1,N) mask is column 0),
+ * pj_out (N,2), depth_out (N), in_mask (N).  Every (pixel, channel) residual is one entry of the median and of the sums;
+ * mean_sq_err divides by the number of valid PIXELS (photo_tracking.py:83-85); out[102] = valid pixels.  channels in 1..4;
+ * como_track_level_channels_f32 returns COMO_ERR_ARG when N * channels exceeds the persistent kernel's capacity. */
+int como_track_iter_channels_f32(const float* Tji, const float* K, const float* aff, const float* P, const float* vals_i,
+                                 const float* img, int H, int W, long N, int channels, float* J8, float* r_ws,
+                                 uint8_t* valid_out, float* pj_out, float* depth_out, void* hists, void* partials, float* out,
+                                 const uint8_t* in_mask, como_stream_t stream);
+int como_track_iter_channels_f64(const double* Tji, const double* K, const double* aff, const double* P, const double* vals_i,
+                                 const double* img, int H, int W, long N, int channels, double* J8, double* r_ws,
+                                 uint8_t* valid_out, double* pj_out, double* depth_out, void* hists, void* partials,
+                                 double* out, const uint8_t* in_mask, como_stream_t stream);
+int como_track_level_channels_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P,
+                                  const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
+                                  const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
+                                  void* workspace, int workspace_uncached, float* out, como_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Window BA linearisation (python path: backend/photo.py:83-233 batch_photo_cost).
  * All scalar tensors have the element type of the entry point (f32 / f64) except H, g (see h_is_f64).
@@ -120,7 +139,7 @@ typedef struct como_ba_args {
   int anorm_f32;             /* 1: the sampling normalisation 1/W, 1/H is rounded to float32 first (two_frame_sfm.py:187-190
                                 builds A_norm from an integer tensor -> float32 even in a float64 run); 0: computed in T */
   const void* Pwn;           /* zmode 0: (slots,n,3) photo.py:86 ; zmode 1: planes (slots,3,n) */
-  const void* vals;          /* (slots,n)     photo.py:84 */
+  const void* vals;          /* (slots,n,c)   photo.py:84 (c = channels) */
   const void* dPwn_dTwc;     /* zmode 0: (slots,n,3,6) photo.py:90 ; zmode 1: planes (slots,18,n) */
   const void* zjac;          /* see zmode */
   const void* uvec;          /* zmode 1: planes (slots,3,n) */
@@ -129,7 +148,7 @@ typedef struct como_ba_args {
   long kt_slot_stride;       /* zmode 1: elements between slots of K~ */
   const void* poses_all;     /* (F,4,4) target poses T_wc */
   const void* aff_all;       /* (A,2) affine brightness params */
-  const void* img_base;      /* base pointer of the [I,gx,gy] (3,H,W) stacks */
+  const void* img_base;      /* base pointer of the [I,gx,gy] (3c,H,W) stacks */
   const void* K;             /* (3,3) intrinsics */
   const int* ref_slot;       /* [b] */
   const int* ref_aff;        /* [b] index into aff_all */
@@ -166,6 +185,13 @@ typedef struct como_ba_args {
      integer SUM -- exact, so every rank ends with identical bits); 2 = expand / scatter from blocks_fix. */
   int reduce_mode;
   void* blocks_fix;
+  /* Colour images (`color: rgb`, config/como.yml:7,29; photo.py:24-27): channels = c of the [I_0..I_c-1 | gx_0.. | gy_0..]
+     (3c,H,W) stacks and of vals (slots,n,c).  photo.py:112-128 treats every (pixel, channel) residual alike (one global
+     median, one Huber weight each, Gram summed over n AND c), so a c-channel keyframe pair is passed as c entries of the
+     pair arrays that differ only in pair_chan[p] (their blocks land on the same rows of H).  Pairs listed together in
+     grp_pairs must share slot and channel.  channels <= 1: gray, pair_chan ignored. */
+  int channels;
+  const int* pair_chan;      /* [b] */
 } como_ba_args;
 
 long como_ba_partials_elems(int b, int chunks, int m);

@@ -53,8 +53,9 @@ def project_landmarks(Twc, Pw, K, reinit_P, median_depths):
 def subselect_pixels(img_and_grads, window):
     """Pixel of max gradient magnitude per window x window cell; reference sparse_map.py:116-142.
     Returns coords (B, n, 2) long (row, col).  Ties: first in row-major scan (max_pool2d)."""
-    B, _, H, W = img_and_grads.shape
-    gn = torch.sqrt(img_and_grads[:, 1] ** 2 + img_and_grads[:, 2] ** 2)
+    B, c3, H, W = img_and_grads.shape
+    c = c3 // 3                                        # gradient norm over all channels, sparse_map.py:127-132
+    gn = torch.sqrt(torch.sum(img_and_grads[:, c:2 * c] ** 2 + img_and_grads[:, 2 * c:] ** 2, dim=1))
     _, idx = torch.nn.functional.max_pool2d(gn[:, None], kernel_size=window, return_indices=True)
     idx = idx.reshape(B, -1)
     return torch.stack((idx // W, idx % W), dim=-1)

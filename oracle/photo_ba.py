@@ -13,11 +13,12 @@ from . import geom
 def pair_rows(vals_i, aff_i, Pwn, Twcj, aff_j, img_and_grads_j, dPwn_dTwci, dPwn_dzm, K):
     """Un-robustified residuals and Jacobian rows of every (pair, ref pixel).
 
-    Follows reference photo.py:104-149 (gray images, c = 1).
-    Shapes: vals_i (b,n,1) aff (b,2,1) Pwn (b,n,3) Twcj (b,4,4) img (b,3,H,W)
+    Follows reference photo.py:104-149; c image channels (gray 1, rgb 3: photo.py:24-27, 44-52).
+    Shapes: vals_i (b,n,c) aff (b,2,1) Pwn (b,n,3) Twcj (b,4,4) img (b,3c,H,W) = [I | dI/dx | dI/dy]
             dPwn_dTwci (b,n,3,6) dPwn_dzm (b,n,3,m,1).
-    Returns r (b,n), valid (b,n) bool, J (b,n,16+m) with column order
-            [ref pose 6, ref aff 2 | target pose 6, target aff 2 | m log-depth cols].
+    Returns r (b,n,c), valid (b,n) bool, J (b,n,c,16+m) with column order
+            [ref pose 6, ref aff 2 | target pose 6, target aff 2 | m log-depth cols]; for c = 1 the channel axis is dropped
+            (r (b,n), J (b,n,16+m)).
     """
     b, n = vals_i.shape[:2]
     m = dPwn_dzm.shape[3]
@@ -26,35 +27,38 @@ def pair_rows(vals_i, aff_i, Pwn, Twcj, aff_j, img_and_grads_j, dPwn_dTwci, dPwn
     Pc = geom.rigid_apply(Tcw, Pwn)                   # photo.py:106, transforms.py:17-23
     u, v = geom.project(K, Pc)                        # photo.py:30, camera.py:20-26
     valid = geom.in_image(u, v, H, W) & (Pc[..., 2] > 0)   # photo.py:15-21
-    samp = torch.stack([geom.bilinear_zeros(img_and_grads_j[k], u[k], v[k]) for k in range(b)])  # (b,3,n)
-    I_t, gx, gy = samp[:, 0], samp[:, 1], samp[:, 2]
-    # residual, photo.py:114-118
-    scale = torch.exp(aff_j[:, 0:1, 0] - aff_i[:, 0:1, 0])            # (b,1)
-    Iref_s = scale * vals_i[..., 0]
-    r = I_t - Iref_s + (aff_j[:, 1:2, 0] - aff_i[:, 1:2, 0])
+    c = vals_i.shape[2]
+    samp = torch.stack([geom.bilinear_zeros(img_and_grads_j[k], u[k], v[k]) for k in range(b)])  # (b,3c,n)
+    I_t, gx, gy = (samp[:, k * c:(k + 1) * c].transpose(1, 2) for k in range(3))                 # (b,n,c) each, photo.py:44-52
+    # residual, photo.py:114-118 (one affine pair per frame, shared by the channels)
+    scale = torch.exp(aff_j[:, 0:1, :] - aff_i[:, 0:1, :])            # (b,1,1)
+    Iref_s = scale * vals_i
+    r = I_t - Iref_s + (aff_j[:, 1:2, :] - aff_i[:, 1:2, :])
     # dI/dPc = [gx gy] dp/dPc, camera.py:28-35
-    X, Y, Z = Pc[..., 0], Pc[..., 1], Pc[..., 2]
+    X, Y, Z = Pc[..., 0:1], Pc[..., 1:2], Pc[..., 2:3]                # (b,n,1)
     fx, fy = K[0, 0], K[1, 1]
-    dI_dPc = torch.stack((gx * fx / Z, gy * fy / Z, -(gx * fx * X / Z + gy * fy * Y / Z) / Z), dim=-1)  # (b,n,3)
+    dI_dPc = torch.stack((gx * fx / Z, gy * fy / Z, -(gx * fx * X / Z + gy * fy * Y / Z) / Z), dim=-1)  # (b,n,c,3)
     Rcw = Tcw[:, :3, :3]
-    dI_dPw = torch.einsum("bnk,bkl->bnl", dI_dPc, Rcw)               # photo.py:135
+    dI_dPw = torch.einsum("bnck,bkl->bncl", dI_dPc, Rcw)             # photo.py:135
     # target pose: dPc/dTcw = [-Rcw [Pw]x, Rcw]; dTcw/dTwc = -Ad(Twc)  (photo.py:107, transforms.py:25-29)
     dPc_dTcw = torch.cat((-torch.einsum("bij,bnjk->bnik", Rcw, geom.skew(Pwn)),
                           Rcw[:, None].expand(b, n, 3, 3)), dim=-1)  # (b,n,3,6)
     dPc_dTwc = torch.einsum("bnij,bjk->bnik", dPc_dTcw, -geom.adjoint(Twcj))
-    J = torch.empty((b, n, 16 + m), dtype=vals_i.dtype)
-    J[..., 0:6] = torch.einsum("bnk,bnkl->bnl", dI_dPw, dPwn_dTwci)  # photo.py:145
-    J[..., 6] = Iref_s                                               # photo.py:121
+    J = torch.empty((b, n, c, 16 + m), dtype=vals_i.dtype)
+    J[..., 0:6] = torch.einsum("bnck,bnkl->bncl", dI_dPw, dPwn_dTwci)  # photo.py:145
+    J[..., 6] = Iref_s                                                 # photo.py:121
     J[..., 7] = -1.0
-    J[..., 8:14] = torch.einsum("bnk,bnkl->bnl", dI_dPc, dPc_dTwc)   # photo.py:146
+    J[..., 8:14] = torch.einsum("bnck,bnkl->bncl", dI_dPc, dPc_dTwc)   # photo.py:146
     J[..., 14] = -Iref_s
     J[..., 15] = 1.0
-    J[..., 16:] = torch.einsum("bnk,bnkm->bnm", dI_dPw, dPwn_dzm[..., 0])  # photo.py:137-139
+    J[..., 16:] = torch.einsum("bnck,bnkm->bncm", dI_dPw, dPwn_dzm[..., 0])  # photo.py:137-139
+    if c == 1:
+        return r[..., 0], valid, J[:, :, 0]
     return r, valid, J
 
 
 def robust_scale(r, valid):
-    """sigma = 1.4826 * lower-median(|r| over valid), photo.py:124-128."""
+    """sigma = 1.4826 * lower-median(|r| over the valid pixels, all channels of them), photo.py:124-128."""
     return 1.4826 * torch.median(r[valid].abs())
 
 
@@ -63,14 +67,16 @@ def pair_blocks(r, valid, J, sigma):
 
     photo.py:66-80 (robustify) + linear_system.py:24-38 (blocks).
     """
+    if r.dim() == 2:                                   # c = 1 without the channel axis
+        r, J = r[..., None], J[:, :, None]
     wr = r * (1.0 / sigma)
     w = geom.huber_weight(wr)
-    w = torch.where(valid, w, torch.zeros_like(w))
+    w = torch.where(valid[..., None], w, torch.zeros_like(w))        # one weight per (pixel, channel); photo.py:71-73
     s = torch.sqrt(w) * (1.0 / sigma)
     Jt = J * s[..., None]
     rt = r * s
-    G = torch.einsum("bnk,bnl->bkl", Jt, Jt)
-    gv = -torch.einsum("bnk,bn->bk", Jt, rt)
+    G = torch.einsum("bnck,bncl->bkl", Jt, Jt)         # linear_system.py:31-38: summed over pixels AND channels
+    gv = -torch.einsum("bnck,bnc->bk", Jt, rt)
     err = torch.sum(torch.square(torch.sqrt(w) * wr))
     return G, gv, err
 

@@ -1,6 +1,6 @@
 """Oracle: inverse-compositional photometric tracking GN
 (reference como/odom/frontend/photo_tracking.py).  TEST INFRASTRUCTURE (see oracle/__init__.py).
-Gray images (c = 1).
+Gray images (vals (N,), J (N,8), img (H,W)) or c channels (vals (N,c), J (N,c,8), img (c,H,W)).
 """
 import torch
 
@@ -9,7 +9,9 @@ from . import geom
 
 def ic_jacobians(dI_dw, P, vals, K):
     """Reference-side Jacobians at theta = 0, photo_tracking.py:46-74.
-    dI_dw (N,2) = image gradient at ref pixels, P (N,3), vals (N,) -> (N,8)."""
+    dI_dw (N,2) = image gradient at ref pixels, P (N,3), vals (N,) -> (N,8); c channels: dI_dw (N,c,2), vals (N,c) -> (N,c,8)."""
+    if vals.dim() == 2:
+        return torch.stack([ic_jacobians(dI_dw[:, ch], P, vals[:, ch], K) for ch in range(vals.shape[1])], dim=1)
     X, Y, Z = P[:, 0], P[:, 1], P[:, 2]
     fx, fy = K[0, 0], K[1, 1]
     zero = torch.zeros_like(Z)
@@ -33,23 +35,30 @@ def project_ic(K, Tji, Pi):
 def tracking_iter(Tji, Pi, K, img_j, aff, vals_i, J8):
     """One GN iteration, photo_tracking.py:117-143.
     Tji (4,4), Pi (N,3), img_j (H,W), aff (2,), vals_i (N,), J8 (N,8) (column 6 is overwritten).
+    c channels: img_j (c,H,W), vals_i (N,c), J8 (N,c,8); every (pixel, channel) residual enters the median and the sums,
+    the mean error divides by the valid PIXELS (photo_tracking.py:83-85).
     Returns dict with T_new, aff_new, delta, mse, grad_norm, u, v, valid, depth, sigma, H, g."""
-    H_, W_ = img_j.shape
+    gray = img_j.dim() == 2
+    if gray:
+        img_j, vals_i, J8 = img_j[None], vals_i[:, None], J8[:, None]
+    H_, W_ = img_j.shape[-2:]
     u, v, depth = project_ic(K, Tji, Pi)
     valid = geom.in_image(u, v, H_, W_) & (depth > 0)
-    It = geom.bilinear_zeros(img_j[None], u, v)[0]
+    It = geom.bilinear_zeros(img_j, u, v).T                                  # (N,c)
     tmp = torch.exp(-aff[0]) * It
     J = J8.clone()
-    J[:, 6] = -tmp
+    J[..., 6] = -tmp
     r = (tmp + aff[1]) - vals_i
     sigma = 1.4826 * torch.median(r[valid].abs())
     wr = r * (1.0 / sigma)
-    w = torch.where(valid, geom.huber_weight(wr), torch.zeros_like(wr))     # photo_tracking.py:77-81
+    w = torch.where(valid[:, None], geom.huber_weight(wr), torch.zeros_like(wr))     # photo_tracking.py:77-81
     total = torch.sum(w * wr * wr)
     mse = total / valid.sum()
-    JW = J * w[:, None]
-    g = (JW * r[:, None]).sum(0)
-    Hm = JW.T @ J
+    JW = J * w[..., None]
+    g = (JW * r[..., None]).sum((0, 1))
+    Hm = torch.einsum("nck,ncl->kl", JW, J)
+    if gray:
+        r = r[:, 0]
     L, _ = torch.linalg.cholesky_ex(Hm, check_errors=False)
     delta = torch.cholesky_solve(g[:, None], L)[:, 0]
     T_new = Tji @ geom.se3_exp(-delta[:6])

@@ -26,7 +26,8 @@ class OracleWindow:
         self.cn = odr.subselect_pixels(c["kf_img_and_grads"], window)
         bi = torch.arange(self.B)[:, None].expand(-1, self.cn.shape[1])
         self.Kt_rows = c["Knm_Kmminv"][bi, self.cn[..., 0], self.cn[..., 1], :]
-        self.vals = c["kf_img_and_grads"][bi, :1, self.cn[..., 0], self.cn[..., 1]]
+        nch = c["kf_img_and_grads"].shape[1] // 3                                 # image channels (gray 1, rgb 3)
+        self.vals = c["kf_img_and_grads"][:, :nch].permute(0, 2, 3, 1)[bi, self.cn[..., 0], self.cn[..., 1]]   # (B,n,c), Mapping.py:677-681
         self.med = c["median_depth_init"].clone() if "median_depth_init" in c else torch.full((self.B,), 1.0, dtype=torch.float64)
         self.pose_anchor = c.get("pose_anchor", self.poses[0:1].clone())
         self.P_anchor = c.get("P_anchor", self.P[self.corr[0]].clone())

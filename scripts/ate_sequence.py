@@ -11,16 +11,17 @@ def run_ate_sequence(G, pix="float", dev="cuda:0"):
     from como_amd.depth_cov.core.DepthCovModule import DepthCovModule
     from como_amd.odom.sequential import ComoSeq
     H, W, n, seed = int(G["H"]), int(G["W"]), int(G["nframes"]), int(G["seed"])
-    scene = synth.PlaneScene(seed=seed, freq_scale=W / 640.0)
+    colour = bool(int(G["colour"])) if "colour" in G else False       # `color: rgb`: one texture per channel
+    scenes = [synth.PlaneScene(seed=seed + 1000 * ch, freq_scale=W / 640.0) for ch in range(3 if colour else 1)]
     K = synth.intrinsics_for(H, W)
     T = synth.gt_poses(n, step=float(G["step"]), deg=float(G["deg"]))
     g = torch.Generator().manual_seed(seed)
-    tcfg = {"device": dev, "dtype": "float", "color": "gray",
+    tcfg = {"device": dev, "dtype": "float", "color": "rgb" if colour else "gray",
             "pyr": {"start_level": 0, "end_level": 3, "depth_interp_mode": "nearest_neighbor"},
             "term_criteria": {"max_iter": 50, "delta_norm": 1.0e-3, "rel_tol": 1.0e-3, "grad_norm": 1.0},
             "sigmas": {"photo": 1.0e-1},
             "keyframing": {"kf_depth_motion_ratio": 0.12, "kf_num_pixels_frac": 0.75, "one_way_freq": 3}}
-    mcfg = {"device": dev, "dtype": "double", "pix_dtype": pix, "color": "gray", "track_ref": {"num_keyframes": 1},
+    mcfg = {"device": dev, "dtype": "double", "pix_dtype": pix, "color": "rgb" if colour else "gray", "track_ref": {"num_keyframes": 1},
             "graph": {"num_keyframes": 9, "num_one_way_frames": 24}, "network_size": [H, W], "graph_network": False,
             "photo_construction": {"nonmax_suppression_window": 4, "pairwise_batch_size": 128, "radius_thresh": 0.0,
                                    "degrees_thresh": 0.0},
@@ -37,9 +38,9 @@ def run_ate_sequence(G, pix="float", dev="cuda:0"):
     code = {None: 0, "init": 3, "keyframe": 1, "one-way": 2}
     kinds, poses = [], {}
     for k in range(n):
-        I, _ = scene.render(T[k], K, H, W)
+        I = torch.stack([sc.render(T[k], K, H, W)[0] for sc in scenes])
         I = I + 0.002 * torch.randn(I.shape, generator=g, dtype=torch.float64)
-        rgb = I[None, None].repeat(1, 3, 1, 1).to(dev)
+        rgb = (I[None] if colour else I[None].repeat(1, 3, 1, 1)).to(dev)
         nb = len(odo.est_poses)
         kinds.append(code[odo.iter(1.0 + k, rgb)])
         if len(odo.est_poses) > nb:

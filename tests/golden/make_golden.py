@@ -243,11 +243,12 @@ def window_case(dtype, B, H, W, m, window, seed, with_recent, aff_noise=0.02, sa
     return out
 
 
-def tracking_case(H, W, levels, seed, dtype=torch.float32):
-    tp = synth.make_tracking_pair(H=H, W=W, dtype=dtype, seed=seed, levels=levels)
+def tracking_case(H, W, levels, seed, dtype=torch.float32, channels=1):
+    """channels = 3: `color: rgb` (vals (1,N,3), dI_dT (1,N,3,8), one median over all (pixel, channel) residuals)."""
+    tp = synth.make_tracking_pair(H=H, W=W, dtype=dtype, seed=seed, levels=levels, channels=channels)
     K = tp["intrinsics"]
-    grad = ImageGradientModule(1, "cpu", dtype)
-    pyr = ImagePyramidModule(1, 0, levels, "cpu", dtype)
+    grad = ImageGradientModule(channels, "cpu", dtype)
+    pyr = ImagePyramidModule(channels, 0, levels, "cpu", dtype)
     ipyr = IntrinsicsPyramidModule(0, levels, "cpu")
     dpyr = DepthPyramidModule(0, levels, "nearest_neighbor", "cpu")
     K_pyr = ipyr(K, [1.0, 1.0])
@@ -288,13 +289,13 @@ def tracking_case(H, W, levels, seed, dtype=torch.float32):
     return out
 
 
-def sfm_case(H, W, m, seed, dtype=torch.float64):
+def sfm_case(H, W, m, seed, dtype=torch.float64, channels=1):
     model = ref_model()
-    st = synth.make_window(B=2, H=H, W=W, m=m, dtype=dtype, seed=seed,
+    st = synth.make_window(B=2, H=H, W=W, m=m, dtype=dtype, seed=seed, channels=channels,
                            predictor=lambda cov, cm: ref_prep_predictor(model, cov, cm, (H, W), dtype)[:3])
     K = st["intrinsics"][0]
     tc = get_test_coords((H, W), device="cpu", batch_size=1)
-    vals_i = st["kf_img_and_grads"][0:1, 0:1].reshape(1, 1, -1)
+    vals_i = st["kf_img_and_grads"][0:1, 0:channels].reshape(1, channels, -1)          # (1,c,N), two_frame_sfm.py:80-86
     Kt = st["Knm_Kmminv"][0:1].reshape(1, H * W, m)
     Tji = invertSE3(st["kf_poses"][1:2]) @ st["kf_poses"][0:1]
     # log-depths of KF0's inducing points from GT depth
@@ -791,8 +792,12 @@ if __name__ == "__main__":
                                                           window_full=True))
     if "track" in which:
         save("tracking_f32.npz", tracking_case(96, 128, 3, seed=0))
+    if "tracking_rgb" in which:
+        save("tracking_rgb_f32.npz", tracking_case(72, 96, 3, seed=4, channels=3))
     if "sfm" in which:
         save("sfm_f64.npz", sfm_case(48, 64, 8, seed=4))
+    if "sfm_rgb" in which:
+        save("sfm_rgb_f64.npz", sfm_case(48, 64, 8, seed=6, channels=3))
     if "cov" in which:
         save("cov_ops_f32.npz", cov_case(48, 64, seed=5))
     if "image" in which:

@@ -103,7 +103,7 @@ class Hooks:
             vis = torch.exp(kf_aff[tid][:, 0:1, :] - kf_aff[rid][:, 0:1, :]) * vals_n[rid]
             r = vals_t - vis + (kf_aff[tid][:, 1:2, :] - kf_aff[rid][:, 1:2, :])
             rec["pair_nvalid"] = valid.sum(dim=1)
-            rec["pair_abs_r_sum"] = (r[..., 0].abs() * valid).sum(dim=1)
+            rec["pair_abs_r_sum"] = (r.abs() * valid[..., None]).sum(dim=(1, 2))     # all channels of the valid pixels
             if len(out[2][0]) == 0:
                 rec["sigma_r"] = 1.4826 * torch.median(torch.abs(r[valid]))
             rec["_full"] = {"Pwn": Pwn, "dPwn_dTwc": dPwn_dTwc, "vals_n": vals_n, "valid": valid, "r": r[..., 0], "Pcj": Pcj}
@@ -265,6 +265,37 @@ def win32_case(B=32, H=60, W=80, m=24, window=2, seed=31):
     return out
 
 
+def rgb_window_case(B=4, H=48, W=64, m=16, window=2, seed=51, with_recent=True):
+    """`color: rgb` (config/como.yml:7,29): a window of 3-channel keyframes (and one-way frames) through the reference's
+    Mapping.iterate -- (pixel, channel) residuals share one median, one affine pair per frame (photo.py:24-52, 112-128)."""
+    dtype = torch.float64
+    model = mg.ref_model()
+    pred = lambda cov, cm: mg.ref_prep_predictor(model, cov, cm, (H, W), dtype)[:3]
+    st = synth.make_window(B=B, H=H, W=W, m=m, dtype=dtype, seed=seed, predictor=pred, aff_noise=0.02, channels=3)
+    recent = None
+    if with_recent:                                    # two one-way frames between keyframes 1 | 2 and 2 | 3 (3 channels)
+        recent = synth.make_recent([1.5, 2.5], H, W, seed, dtype=dtype, channels=3)
+    mp = ref_mapping_from_state(st, window, recent=recent)
+    mp.cfg["color"] = "rgb"
+    out = {k: st[k] for k in ("kf_poses", "coords_m", "correspondence_mask", "P_m", "K_mm_inv", "kf_aff_params")}
+    out.update({"B": B, "H": H, "W": W, "m": m, "window": window, "seed": seed, "aff_noise": 0.02, "channels": 3})
+    if recent is not None:
+        out.update({k: recent[k] for k in ("recent_timestamps", "recent_poses", "recent_aff_params")})
+    out["median_depths_in"] = st["median_depth_init"].clone()
+    with Hooks() as hk:
+        for it in range(2):
+            mp.iterate()
+            s = summarise(hk.rec, mp, st, keep_full_H=(it == 0))
+            for k, v in s.items():
+                out[f"it{it}_{k}"] = v
+            if recent is not None:
+                out[f"it{it}_recent_poses_new"] = mp.recent_poses.clone()
+                out[f"it{it}_recent_aff_new"] = mp.recent_aff_params.clone()
+            print(f"  rgb iterate {it}: D = {hk.rec['H_full'].shape[0]}, pairs = {len(hk.rec['kf_ref_ids'])} + "
+                  f"{len(hk.rec['ow_kf_ids'])} one-way, err {float(mp.total_err_prev):.6e}, chol info {int(hk.rec['chol_info'])}")
+    return out
+
+
 def se3_case(seed=5):
     """T = expm([[phi]x, tau],[0, 0]) by scipy for twists [tau, phi] (lietorch's documented ordering); COMO's update
     vector is [omega (0:3), v (3:6)] and batch_se3 / se3_exp feed lietorch [v, omega] (lie_algebra.py:45-56)."""
@@ -332,21 +363,22 @@ ATE_MAP_CFG = {"device": "cpu", "dtype": "double", "color": "gray", "model_path"
                         "kf_depth_motion_ratio": 0.04, "kf_num_pixels_frac": 0.75}}                                   # config/como.yml
 
 
-def ate_frames(nframes, H, W, seed, step, deg):
-    """The rendered sequence (shared with the GPU test, which regenerates it from the same seeds)."""
-    scene = synth.PlaneScene(seed=seed, freq_scale=W / 640.0)
+def ate_frames(nframes, H, W, seed, step, deg, colour=False):
+    """The rendered sequence (shared with the GPU test, which regenerates it from the same seeds).  colour: three different
+    textures on the plane, one per channel (otherwise the gray texture replicated)."""
+    scenes = [synth.PlaneScene(seed=seed + 1000 * ch, freq_scale=W / 640.0) for ch in range(3 if colour else 1)]
     K = synth.intrinsics_for(H, W)
     T = synth.gt_poses(nframes, step=step, deg=deg)
     g = torch.Generator().manual_seed(seed)
     rgbs = []
     for k in range(nframes):
-        I, _ = scene.render(T[k], K, H, W)
+        I = torch.stack([sc.render(T[k], K, H, W)[0] for sc in scenes])
         I = I + 0.002 * torch.randn(I.shape, generator=g, dtype=torch.float64)
-        rgbs.append(I[None, None].repeat(1, 3, 1, 1))
+        rgbs.append(I[None] if colour else I[None].repeat(1, 3, 1, 1))
     return K, T, rgbs
 
 
-def ate_case(seed=17, H=192, W=256, nframes=72, step=0.02, deg=0.4):
+def ate_case(seed=17, H=192, W=256, nframes=72, step=0.02, deg=0.4, colour=False):
     """"ATE vs ref" (BASELINE.json metric): the reference's OWN sequential odometry loop (sequential/ComoSeq.py without the
     GUI: TrackingSeq.track -> MappingSeq.map per frame) on a rendered 72-frame sequence at the reference's native network
     resolution 192x256 with the parameters of config/como.yml (9-keyframe window, 24 one-way frames, 64 inducing points,
@@ -361,10 +393,13 @@ def ate_case(seed=17, H=192, W=256, nframes=72, step=0.02, deg=0.4):
     model = DepthCovModule()
     model.load_state_dict(synth.depthcov_state_dict(0), strict=False)
     model.eval()
-    K, T, rgbs = ate_frames(nframes, H, W, seed, step, deg)
-    trk = TrackingSeq(ATE_TRACK_CFG, K.clone(), (H, W))
+    K, T, rgbs = ate_frames(nframes, H, W, seed, step, deg, colour)
+    tcfg, mcfg = dict(ATE_TRACK_CFG), dict(ATE_MAP_CFG)
+    if colour:                                         # config/como.yml:7,29 `color: rgb`
+        tcfg["color"] = mcfg["color"] = "rgb"
+    trk = TrackingSeq(tcfg, K.clone(), (H, W))
     trk.init_basic_vars(); trk.init_kf_vars(); trk.reset_one_way_vars(); trk.T_w_rec_last = None
-    mp = MappingSeq(ATE_MAP_CFG, K.clone())
+    mp = MappingSeq(mcfg, K.clone())
     mp.init_basic_vars()
     mp.cov_level = -1
     mp.network_size = torch.tensor([H, W])
@@ -373,8 +408,9 @@ def ate_case(seed=17, H=192, W=256, nframes=72, step=0.02, deg=0.4):
     mp.init_keyframe_vars()
     mp.init_prior_vals()
     mp.reset_iteration_vars(new_kf=True, converged=True)
-    mp.two_frame_sfm = TwoFrameSfm(ATE_MAP_CFG, mp.intrinsics[0, :, :], model, -1, mp.network_size)
-    out = {"K": K, "poses_gt": T, "seed": seed, "H": H, "W": W, "nframes": nframes, "step": step, "deg": deg}
+    mp.two_frame_sfm = TwoFrameSfm(mcfg, mp.intrinsics[0, :, :], model, -1, mp.network_size)
+    out = {"K": K, "poses_gt": T, "seed": seed, "H": H, "W": W, "nframes": nframes, "step": step, "deg": deg,
+           "colour": int(colour)}
     kinds, poses, valid = [], [], []
     code = {None: 0, "init": 3, "keyframe": 1, "one-way": 2}
     t0 = time.time()
@@ -422,3 +458,8 @@ if __name__ == "__main__":
         mg.save("pair_graph.npz", pair_graph_case())
     if "ate" in which:
         mg.save("ate_sequence.npz", ate_case())
+    if "ate_rgb" in which:
+        mg.save("ate_sequence_rgb.npz", ate_case(seed=23, H=96, W=128, nframes=40, colour=True))
+    if "rgb" in which:
+        mg.save("ba_window_rgb_f64.npz", rgb_window_case())
+        mg.save("ba_window_rgb_kf_f64.npz", rgb_window_case(with_recent=False))     # keyframe pairs only: the oracle's window

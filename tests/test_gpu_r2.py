@@ -37,9 +37,14 @@ def _hip_predictor(pix_dtype, kinv=None):
 def _window_from_seed(G, pix_dtype, window, fused=True):
     from como_amd import synth
     from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    ch = int(G["channels"]) if "channels" in G else 1
     st = synth.make_window(B=int(G["B"]), H=int(G["H"]), W=int(G["W"]), m=int(G["m"]), dtype=torch.float64, device=DEV,
                            seed=int(G["seed"]), predictor=_hip_predictor(pix_dtype, G["K_mm_inv"]),
-                           aff_noise=float(G["aff_noise"]) if "aff_noise" in G else 0.0)
+                           aff_noise=float(G["aff_noise"]) if "aff_noise" in G else 0.0, channels=ch)
+    if "recent_timestamps" in G:                       # one-way frames of the same scene (synth.make_recent, same seed)
+        rec = synth.make_recent(G["recent_timestamps"].tolist(), int(G["H"]), int(G["W"]), int(G["seed"]), device=DEV, channels=ch)
+        assert (rec["recent_poses"].cpu() - G["recent_poses"]).abs().max() < 1e-12
+        st.update(rec)
     # same seeds -> same inputs: discrete choices identical; floating-point values to the last bits only (the synthetic scene
     # goes through CPU sin / exp / BLAS, whose last bit depends on the host CPU's vector ISA)
     assert st["P_m"].shape == G["P_m"].shape and torch.equal(st["correspondence_mask"].cpu().sum(1), torch.full((int(G["B"]),), int(G["m"])))
@@ -174,6 +179,111 @@ def test_landmark_reinit_vs_reference(fused):
     assert (wb2.kf_poses.cpu() - G["it0_kf_poses_new"]).abs().max() < 1e-9
     assert (wb2.P_m.cpu() - G["it0_P_new"]).abs().max() < 1e-6      # a landmark re-initialised at depth ~10 is barely constrained
     assert ((wb2.median_depths.cpu() - G["it0_median_depths_full"]).abs() / G["it0_median_depths_full"]).max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_rgb_two_frame_sfm_system_vs_reference():
+    """construct_photo_system with c = 3 (vals_i (1,3,N), a 9-plane target stack): mask bit-exact, H / g / err to 1e-10."""
+    from como_amd.odom.frontend import two_frame_sfm as sfm
+    S = load_golden("sfm_rgb_f64.npz")
+    dev = lambda t: t.to(DEV).contiguous()
+    m = S["logz_m"].shape[1]
+    D = 6 + m
+    H = torch.zeros((D, D), dtype=torch.float64, device=DEV)
+    g = torch.zeros((D,), dtype=torch.float64, device=DEV)
+    aff = torch.zeros((1, 2, 1), dtype=torch.float64, device=DEV)
+    err, log_depth, coords_j, depths_j, valid, Pi = sfm.construct_photo_system(
+        dev(S["Tji"]), dev(S["logz_m"]), aff, dev(S["coords_i"]), dev(S["vals_i"]), dev(S["Kt"]), dev(S["img_and_grads_j"]),
+        dev(S["K"]), 0.1, H, g)
+    eH, eg = rel_err(H, S["H"]), rel_err(g, S["g"])
+    ee = abs(err.item() - S["err"].item()) / S["err"].item()
+    report("sfm_system_rgb", mask_mismatch=(valid.cpu() != S["valid"]).sum(), H_rel=eH, g_rel=eg, err_rel=ee)
+    assert torch.equal(valid.cpu(), S["valid"])
+    assert eH < 1e-10 and eg < 1e-10 and ee < 1e-10
+    assert coords_j.shape[1] == int(S["valid"].sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_rgb_tracking_vs_reference():
+    """`color: rgb` tracking (photo_tracking.py with c = 3): one iteration (mask / projection bit-exact), the in-place column 6
+    of dI_dT, the pyramid through the persistent level kernel AND through the per-iteration chain, float64 chain too."""
+    import como_amd.odom.frontend.photo_tracking as pt
+    T = load_golden("tracking_rgb_f32.npz")
+    dev = lambda t: t.to(DEV).contiguous()
+    l = 2
+    J = dev(T[f"J_l{l}"].clone())
+    img = dev(T[f"cur_l{l}"])
+    aff0 = torch.zeros((1, 2, 1), device=DEV)
+    Tn, an, delta, mse, gn, pj, valid, depth = pt.tracking_iter(dev(T["Tji_init"]), dev(T[f"P_l{l}"]), dev(T[f"K_l{l}"]), img, aff0,
+                                                                dev(T[f"vals_l{l}"]), J, 0.1, None)
+    report("rgb_tracking_iter", mask_mismatch=(valid.cpu() != T["it_valid"]).sum(), delta_rel=rel_err(delta, T["it_delta"]),
+           T_err=(Tn.cpu() - T["it_T"]).abs().max(), mse=mse, mse_ref=T["it_mse"])
+    assert torch.equal(valid.cpu(), T["it_valid"]) and torch.equal(pj.cpu(), T["it_pj"]) and torch.equal(depth.cpu(), T["it_depth"])
+    assert rel_err(delta, T["it_delta"]) < 2e-4 and (Tn.cpu() - T["it_T"]).abs().max() < 1e-5
+    assert (an.cpu() - T["it_aff"]).abs().max() < 1e-5
+    assert abs(mse.item() - T["it_mse"].item()) < 1e-4 * T["it_mse"].item()            # mean over valid PIXELS, not entries
+    assert abs(gn.item() - T["it_grad_norm"].item()) < 1e-4 * T["it_grad_norm"].item()
+    # dI_dT[..., 6] = -e^{-a} I_j per channel (photo_tracking.py:124-125), a = 0: the sampled target image
+    from oracle import geom
+    It = geom.bilinear_zeros(T[f"cur_l{l}"][0], T["it_pj"][0, :, 0], T["it_pj"][0, :, 1]).T
+    assert (J[0, :, :, 6].cpu() + It)[T["it_valid"][0]].abs().max() < 1e-6
+    # float64 chain on the same data
+    d64 = lambda t: t.to(DEV).double().contiguous()
+    out64 = pt.tracking_iter(d64(T["Tji_init"]), d64(T[f"P_l{l}"]), d64(T[f"K_l{l}"]), d64(T[f"cur_l{l}"]), aff0.double(),
+                             d64(T[f"vals_l{l}"]), d64(T[f"J_l{l}"].clone()), 0.1, None)
+    assert (out64[0].cpu().float() - T["it_T"]).abs().max() < 1e-5 and int((out64[6].cpu() != T["it_valid"]).sum()) <= 1
+    term = {"max_iter": 50, "delta_norm": 1e-3, "rel_tol": 1e-3, "grad_norm": 1.0}
+    for fused in (True, False):
+        keep = pt.FUSED_LEVEL
+        pt.FUSED_LEVEL = fused
+        try:
+            Tf, af = pt.photo_tracking_pyr(dev(T["Tji_init"]), aff0, [dev(T[f"vals_l{i}"]) for i in range(3)],
+                                           [dev(T[f"P_l{i}"]) for i in range(3)], [dev(T[f"J_l{i}"].clone()) for i in range(3)],
+                                           [dev(T[f"mask_l{i}"]) for i in range(3)], [dev(T[f"K_l{i}"]) for i in range(3)],
+                                           [dev(T[f"cur_l{i}"]) for i in range(3)], 0.1, term)
+        finally:
+            pt.FUSED_LEVEL = keep
+        report("rgb_tracking_pyr", fused=fused, T_err=(Tf.cpu() - T["pyr_T"]).abs().max(), aff_err=(af.cpu() - T["pyr_aff"]).abs().max())
+        assert (Tf.cpu() - T["pyr_T"]).abs().max() < 1e-4 and (af.cpu() - T["pyr_aff"]).abs().max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("pix", [torch.float64, torch.float32])
+@pytest.mark.parametrize("fixture", ["ba_window_rgb_kf_f64.npz", "ba_window_rgb_f64.npz"])
+def test_rgb_window_vs_reference(fixture, pix, fused):
+    """`color: rgb` (config/como.yml:7,29): 3-channel keyframes and one-way frames against two iterations of the reference's
+    Mapping.iterate.  Every keyframe pair is three entries of the pair table (one per channel; photo.py:24-52, 112-128):
+    one global median over all (pixel, channel) residuals, per-pair valid counts identical for the three channels."""
+    G = load_golden(fixture)
+    f64 = pix == torch.float64
+    wb, st = _window_from_seed(G, pix, int(G["window"]), fused=fused)
+    nkf = len(G["it0_kf_ref_ids"])
+    nall = nkf + (len(G["recent_timestamps"]) * 2 if "recent_timestamps" in G else 0)
+    assert wb.channels == 3 and wb.table.b == 3 * nall and wb.dim == G["it0_g_full"].shape[0]
+    worst = {"pose": 0.0, "P": 0.0, "H": 0.0, "count": 0, "sigma": 0.0, "rec": 0.0}
+    for it in range(2):
+        gi = lambda k: G[f"it{it}_{k}"]
+        wb.iterate()
+        torch.cuda.synchronize()
+        cnt = _pair_counts(wb).view(nall, 3)
+        assert torch.equal(cnt[:, 0], cnt[:, 1]) and torch.equal(cnt[:, 0], cnt[:, 2])      # the mask does not depend on the channel
+        worst["count"] = max(worst["count"], int((cnt[:nkf, 0] - gi("pair_nvalid")).abs().max()))
+        if f"it{it}_sigma_r" in G:
+            worst["sigma"] = max(worst["sigma"], abs(float(wb.sigma[0]) - float(gi("sigma_r"))) / float(gi("sigma_r")))
+            assert int(wb.sigma[1]) == 3 * int(gi("pair_nvalid").sum())                     # median over ALL channels
+        if it == 0:
+            worst["H"] = scaled_err(wb.H.cpu(), gi("H_full"))
+        worst["pose"] = max(worst["pose"], (wb.kf_poses.cpu() - gi("kf_poses_new")).abs().max().item())
+        worst["P"] = max(worst["P"], (wb.P_m.cpu() - gi("P_new")).abs().max().item())
+        if "recent_timestamps" in G:
+            worst["rec"] = max(worst["rec"], (wb.recent_poses.cpu() - gi("recent_poses_new")).abs().max().item(),
+                               (wb.recent_aff_params.cpu() - gi("recent_aff_new")).abs().max().item())
+    report("rgb_window", fixture=fixture, pix=str(pix), fused=fused, D=wb.dim, **worst)
+    assert worst["count"] <= (0 if f64 else 2)
+    assert worst["sigma"] < (2e-7 if f64 else 5e-5)            # as the gray windows: K~ from the device predictor (cond(K_mm) ~ 1e8)
+    assert worst["H"] < (1e-8 if f64 else 5e-4)
+    assert worst["pose"] < (1e-8 if f64 else 1e-4) and worst["P"] < (1e-6 if f64 else 5e-3) and worst["rec"] < (1e-8 if f64 else 1e-4)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -315,6 +425,30 @@ def test_ate_vs_reference_sequence(pix):
     assert kinds == ref_kinds                                         # the same request on every frame
     assert [float(t) for t in odo.mapping.kf_timestamps] == G["m_kf_timestamps"].tolist()
     assert ate < 2e-5 and worst < 5e-5                                # metres, over a 1.45 m path (measured 7.6e-7 / 4.5e-6)
+
+
+def test_ate_rgb_vs_reference_sequence():
+    """`color: rgb` end to end: 40 colour frames (one texture per channel) at 96x128 through the whole HIP loop -- two-frame
+    init (gray, as the reference: TwoFrameSfm.py:79), 3-channel tracking, keyframe management, 3-channel window BA --
+    against the reference's own sequential loop run with `color: rgb` in both config sections."""
+    from como_amd.utils.ate import ate_rmse
+    G = load_golden("ate_sequence_rgb.npz")
+    assert int(G["colour"]) == 1
+    kinds, poses, odo = run_ate_sequence(G, "double")
+    ref_kinds = [int(x) for x in G["kinds"]]
+    tracked = [k for k in range(len(ref_kinds)) if bool(G["tracked"][k]) and k in poses]
+    est = [poses[k] for k in tracked]
+    ref = [G["T_w_curr"][k] for k in tracked]
+    ate = ate_rmse(est, ref)
+    worst = max((e - r).abs().max().item() for e, r in zip(est, ref))
+    report("ate_vs_ref_rgb", frames=len(ref_kinds), tracked=len(tracked), same_decisions=sum(int(a == b) for a, b in zip(kinds, ref_kinds)),
+           ate_rmse=ate, worst_pose_abs=worst, keyframes=int(odo.mapping.kf_poses.shape[0]),
+           channels=int(odo.mapping.kf_img_and_grads.shape[1]) // 3)
+    assert odo.mapping.kf_img_and_grads.shape[1] == 9               # [I | dI/dx | dI/dy] x 3 channels
+    assert len(tracked) >= 30
+    assert kinds == ref_kinds
+    assert [float(t) for t in odo.mapping.kf_timestamps] == G["m_kf_timestamps"].tolist()
+    assert ate < 2e-5 and worst < 5e-5
 
 
 def test_cross_covariance_half_dispatch():

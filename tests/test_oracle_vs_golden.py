@@ -163,12 +163,49 @@ def test_tracking(golden):
     assert (Tf - T["pyr_T"][0]).abs().max() < 1e-5 and (af - T["pyr_aff"][0, :, 0]).abs().max() < 1e-5
 
 
+def test_tracking_rgb(golden):
+    """`color: rgb`: vals (1,N,3), dI_dT (1,N,3,8), img (1,3,H,W) -- photo_tracking.py:46-74, 117-143 with c = 3."""
+    T = golden("tracking_rgb_f32.npz")
+    l = 2
+    assert T[f"cur_l{l}"].shape[1] == 3 and T[f"J_l{l}"].shape[2:] == (3, 8)
+    o = tracking.tracking_iter(T["Tji_init"][0], T[f"P_l{l}"][0], T[f"K_l{l}"], T[f"cur_l{l}"][0], torch.zeros(2),
+                               T[f"vals_l{l}"][0], T[f"J_l{l}"][0])
+    assert torch.equal(o["valid"], T["it_valid"][0])
+    assert torch.equal(torch.stack((o["u"], o["v"]), -1), T["it_pj"][0])
+    assert rel(o["delta"], T["it_delta"][0, :, 0]) < 1e-4
+    assert abs(o["mse"].item() - T["it_mse"].item()) < 1e-5 * max(1.0, T["it_mse"].item())
+    assert rel(o["T"], T["it_T"][0]) < 1e-6
+    gxy = torch.stack((T[f"gx_l{l}"][0].reshape(3, -1).T, T[f"gy_l{l}"][0].reshape(3, -1).T), -1)       # (N,3,2)
+    J = tracking.ic_jacobians(gxy, T[f"P_l{l}"][0], T[f"vals_l{l}"][0], T[f"K_l{l}"])
+    assert rel(J, T[f"J_l{l}"][0]) < 1e-6
+    term = {"max_iter": 50, "delta_norm": 1e-3, "rel_tol": 1e-3, "grad_norm": 1.0}
+    Tf, af, its = tracking.pyramid_tracking(
+        T["Tji_init"][0], torch.zeros(2), [T[f"vals_l{i}"][0] for i in range(3)], [T[f"P_l{i}"][0] for i in range(3)],
+        [T[f"J_l{i}"][0] for i in range(3)], [T[f"mask_l{i}"][0] for i in range(3)],
+        [T[f"K_l{i}"] for i in range(3)], [T[f"cur_l{i}"][0] for i in range(3)], term)
+    assert (Tf - T["pyr_T"][0]).abs().max() < 1e-5 and (af - T["pyr_aff"][0, :, 0]).abs().max() < 1e-5
+
+
 def test_two_frame_sfm(golden):
     S = golden("sfm_f64.npz")
     D = S["H"].shape[0]
     H = torch.zeros((D, D), dtype=torch.float64)
     g = torch.zeros(D, dtype=torch.float64)
     o = sfm.construct_photo_system(S["Tji"][0], S["logz_m"][0, :, 0], S["coords_i"][0], S["vals_i"][0, 0], S["Kt"][0],
+                                   S["img_and_grads_j"][0], S["K"], H, g)
+    assert torch.equal(o["valid"], S["valid"][0])
+    assert rel(H, S["H"]) < 1e-9 and rel(g, S["g"]) < 1e-9
+    assert abs(o["err"].item() - S["err"].item()) / S["err"].item() < 1e-9
+
+
+def test_two_frame_sfm_rgb(golden):
+    """c = 3: vals_i (1,3,N), img_and_grads_j (1,9,H,W) (linearize_photo, two_frame_sfm.py:180-216)."""
+    S = golden("sfm_rgb_f64.npz")
+    assert S["vals_i"].shape[1] == 3 and S["img_and_grads_j"].shape[1] == 9
+    D = S["H"].shape[0]
+    H = torch.zeros((D, D), dtype=torch.float64)
+    g = torch.zeros(D, dtype=torch.float64)
+    o = sfm.construct_photo_system(S["Tji"][0], S["logz_m"][0, :, 0], S["coords_i"][0], S["vals_i"][0], S["Kt"][0],
                                    S["img_and_grads_j"][0], S["K"], H, g)
     assert torch.equal(o["valid"], S["valid"][0])
     assert rel(H, S["H"]) < 1e-9 and rel(g, S["g"]) < 1e-9

@@ -63,7 +63,8 @@ def test_oracle_reinit_vs_reference():
 def _regenerated_window(G, predictor):
     from como_amd import synth
     st = synth.make_window(B=int(G["B"]), H=int(G["H"]), W=int(G["W"]), m=int(G["m"]), dtype=torch.float64, seed=int(G["seed"]),
-                           predictor=predictor, aff_noise=float(G["aff_noise"]) if "aff_noise" in G else 0.0)
+                           predictor=predictor, aff_noise=float(G["aff_noise"]) if "aff_noise" in G else 0.0,
+                           channels=int(G["channels"]) if "channels" in G else 1)
     # same seeds -> same inputs (discrete choices identical; values to the last bits: CPU sin / exp / BLAS depend on the host ISA)
     assert (st["kf_poses"] - (G["kf_poses"] if "kf_poses" in G else G["it0_kf_poses_in"])).abs().max() < 1e-12
     assert (st["coords_m"] - G["coords_m"]).abs().max() < 1e-9 and (st["P_m"] - G["P_m"]).abs().max() < 1e-12
@@ -94,6 +95,18 @@ def test_oracle_window32_vs_reference():
     ow = OracleWindow(st, window=int(G["window"]))
     assert ow.D == G["it0_g_full"].shape[0] == 8 * 32 + 3 * st["P_m"].shape[0]
     _check_iterations(ow, G, 2, 1e-8)
+
+
+def test_oracle_rgb_window_vs_reference():
+    """`color: rgb`: 3-channel keyframes through the reference's Mapping.iterate (one median over all (pixel, channel)
+    residuals, one affine pair per frame, Gram summed over pixels and channels: photo.py:24-52, 112-128)."""
+    G = load_golden("ba_window_rgb_kf_f64.npz")
+    st = _regenerated_window(G, lambda cov, cm: depthcov.prep_predictor(cov, cm, 1.0))
+    assert st["kf_img_and_grads"].shape[1] == 9
+    ow = OracleWindow(st, window=int(G["window"]))
+    assert ow.vals.shape[2] == 3
+    _check_iterations(ow, G, 2, 1e-8)
+    assert scaled_err(ow.H, G["it1_H_full"]) < 1e-7 if "it1_H_full" in G else True
 
 
 def test_oracle_fullsize_window4_vs_reference():
