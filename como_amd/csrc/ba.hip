@@ -1,6 +1,7 @@
 // Window bundle adjustment: photometric linearisation of all keyframe pairs on the device.
 //
-// Reference path: como/odom/backend/photo.py:83-233 (`batch_photo_cost`), gray images (c = 1):
+// Reference path: como/odom/backend/photo.py:83-233 (`batch_photo_cost`); written out for gray images (c = 1) -- a colour
+// pair is c entries of the pair arrays, one per channel (BAPairs::chan, include/como_hip.h como_ba_args.channels):
 //   per pair (i -> j) and reference pixel n:  P_cj = T_wcj^-1 P_wn ; sample [I, gx, gy]_j ;
 //   r = I_j - e^{a_j - a_i} I_i + (b_j - b_i) ; GLOBAL sigma = 1.4826 median|r| over all valid
 //   pixels of all pairs ; Huber ; row = [J_i (8) | J_j (8) | J_z (m)] ; blocks J^T J, J^T r ;

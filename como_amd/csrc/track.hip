@@ -1,6 +1,7 @@
 // Inverse-compositional photometric tracking: one Gauss-Newton iteration on the device.
 //
-// Reference path (gray, c = 1): como/odom/frontend/photo_tracking.py:117-143 (`tracking_iter`)
+// Reference path: como/odom/frontend/photo_tracking.py:117-143 (`tracking_iter`); c image channels = c residual entries per
+// pixel (element = pixel * c + channel of vals_i / J8), gray is c = 1
 //   transform_project (geometry/camera.py:57-68) -> img_interp (frontend/photo_utils.py:9-31)
 //   -> affine residual, sigma = 1.4826 median|r| -> robustify_photo (:77-93) -> solve_delta (:96-99)
 //   -> update_pose_ic (:103-114).

@@ -79,7 +79,7 @@ int como_track_iter_masked_f64(const double* Tji, const double* K, const double*
  * Gauss-Newton loop (tracking_iter :117-143 per iteration) with the stop test (:166-180: iter >= max_iter or |delta| <
  * delta_norm or |(mse_prev - mse) / mse_prev| < rel_tol or |g| < grad_norm, float32 arithmetic) evaluated on the device.
  * A persistent kernel: reference pixels stay in registers across iterations, device-wide barriers replace the kernel
- * boundaries of the como_track_iter_* chain, no host round trip.  float32 (the reference's tracking dtype), c = 1.
+ * boundaries of the como_track_iter_* chain, no host round trip.  float32 (the reference's tracking dtype); gray (colour: como_track_level_channels_f32).
  *   J8 (N,8) is read only (column 6 is recomputed every iteration, not written back); in_mask (N) u8 or NULL.
  *   workspace: como_track_level_workspace_bytes() bytes (cleared by the call); workspace_uncached = 1 if it came from
  *   como_track_level_workspace_create() (uncached device memory: the device-wide barriers then need no L2 invalidate,
