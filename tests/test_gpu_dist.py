@@ -65,6 +65,74 @@ def test_sharded_window_ba_matches_single_process():
     assert np.array_equal(res[0]["single"][1], res[1]["single"][1]) and np.array_equal(res[0]["single"][0], res[1]["single"][0])
 
 
+def _config4_worker(rank, world, port, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": "0"})
+    import copy
+    import torch.distributed as dist
+    from como_amd import dist as cdist
+    from como_amd import synth
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    from tests.conftest import load_golden
+    shard, device = cdist.init_from_env(backend="gloo")
+    try:
+        G = load_golden("ba_window32_f64.npz")
+
+        def predictor(cov, cm):                      # the reference's K_mm^-1 (cond ~ 1e8), as tests/test_gpu_r2.py
+            Kinv, L, Kt = prep_predictor(cov.double(), cm.double(), 1.0, K_mm_inv=G["K_mm_inv"])
+            if L is None:
+                L = torch.linalg.cholesky(torch.linalg.inv(Kinv))
+            return Kinv, L, Kt
+        st = synth.make_window(B=int(G["B"]), H=int(G["H"]), W=int(G["W"]), m=int(G["m"]), dtype=torch.float64, device=device,
+                               seed=int(G["seed"]), predictor=predictor, aff_noise=float(G["aff_noise"]))
+        cfg = copy.deepcopy(DEFAULT_CFG)
+        cfg["photo_construction"]["nonmax_suppression_window"] = int(G["window"])
+        wb = WindowBA(st, cfg=cfg, pix_dtype=torch.float64, window_full=True, shard=shard)
+        out = []
+        for it in range(2):
+            wb.iterate()
+            torch.cuda.synchronize()
+            out.append((wb.kf_poses.cpu().numpy().copy(), wb.P_m.cpu().numpy().copy(), int(wb.sigma[1]), wb.H.cpu().numpy().copy()))
+        q.put((rank, out, wb.table.b, wb.dim, wb.n, wb.n_total))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_config4_window_vs_reference(world):
+    """Config 4's shape (a 32-keyframe window, 62 pairs, D = 8 B + 3 L) in the one-process-per-GPU mode: `world` ranks, each
+    with its pixel range of every pair, exchange the median histograms and the fixed-point per-pair sums; every rank must end
+    with the reference's Mapping.iterate result (tests/golden/ba_window32_f64.npz) and all ranks with identical bits."""
+    from tests.conftest import load_golden, report
+    G = load_golden("ba_window32_f64.npz")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 300) + world
+    procs = [ctx.Process(target=_config4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, out, b, dim, n, n_total = q.get(timeout=600)
+        res[rank] = out
+        assert b == 62 and dim == G["it0_g_full"].shape[0] and 0 < n < n_total          # a proper share of the pixels
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    worst = {"pose": 0.0, "P": 0.0}
+    for it in range(2):
+        poses, P, nvalid, H = res[0][it]
+        assert nvalid == int(G[f"it{it}_pair_nvalid"].sum())                             # the global valid count: exact
+        worst["pose"] = max(worst["pose"], float(np.abs(poses - G[f"it{it}_kf_poses_new"].numpy()).max()))
+        worst["P"] = max(worst["P"], float(np.abs(P - G[f"it{it}_P_new"].numpy()).max()))
+        for r in range(1, world):                                                        # every rank: the same bits
+            assert np.array_equal(res[r][it][0], poses) and np.array_equal(res[r][it][3], H)
+    report("sharded_config4", world=world, **worst)
+    assert worst["pose"] < 1e-8 and worst["P"] < 1e-6
+
+
 def _nccl_worker(port, q):
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     import torch.distributed as dist
