@@ -54,6 +54,8 @@ class WinArgs(ctypes.Structure):
 # name -> (restype, argtypes); every symbol include/como_hip.h declares
 SIGNATURES = {
     "como_abi_version": (c_int, []),
+    "como_clear_last_error": (c_int, []),
+    "como_abort_capture": (c_int, [c_void_p]),
     "como_select_workspace_bytes": (c_int, []),
     "como_select_begin": (c_int, [c_void_p, c_int, c_void_p]),
     "como_select_hist_f32": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
@@ -154,6 +156,41 @@ def ptr(t):
 
 def stream_ptr(device=None):
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def capture_graph(fn, device, thread_local=False):
+    """Capture `fn()` into a hipGraph (torch.cuda.CUDAGraph).  Returns (graph, fn's result) or (None, error text): a capture
+    that an operation inside invalidates leaves the capture stream in capture mode and torch's current stream pointing at it;
+    both are undone here (como_abort_capture, stream restored), so the caller can go on launching eagerly.  After one such
+    failure every later call returns (None, reason) at once."""
+    global _capture_broken
+    if _capture_broken:                        # torch's capture machinery does not survive an aborted capture (a second
+        return None, _capture_broken           # attempt aborts the process): stay eager for the rest of the process
+    prev = torch.cuda.current_stream(device)
+    g = torch.cuda.CUDAGraph()
+    ctx = torch.cuda.graph(g, capture_error_mode="thread_local" if thread_local else "global")
+    try:
+        with ctx:
+            out = fn()
+        return g, out
+    except Exception:   # noqa: BLE001
+        import traceback
+        err = traceback.format_exc()[-1500:]
+        cap = getattr(ctx, "capture_stream", None)
+        for st in (cap, torch.cuda.current_stream(device)):
+            if st is not None:
+                lib().como_abort_capture(st.cuda_stream)
+        torch.cuda.set_stream(prev)
+        try:
+            torch.cuda.synchronize(device)
+        except Exception:   # noqa: BLE001
+            pass
+        lib().como_clear_last_error()
+        _capture_broken = "graph capture disabled after an earlier capture failed: " + err[-300:]
+        return None, err
+
+
+_capture_broken = ""
 
 
 def require_cuda(*tensors):

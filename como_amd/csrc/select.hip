@@ -188,7 +188,27 @@ int select_hist(const T* r, const uint8_t* valid, long n, int nseg, uint32_t* hi
 
 extern "C" {
 
-int como_abi_version(void) { return 1; }
+int como_abi_version(void) { return 2; }
+
+// A failed stream capture (or any failed runtime call of the caller) leaves its code in the thread's "last error"; the
+// launch check of the next como_* call would report it as that call's launch failure.  Returns the code it cleared.
+int como_clear_last_error(void) { return (int)hipGetLastError(); }
+
+// End a stream capture that went wrong (an operation the capture does not allow invalidates it, but the stream stays in
+// capture mode -- and every later launch on it fails -- until hipStreamEndCapture is called).  Returns 1 if the stream was
+// capturing, 0 if not; the partial graph, if any, is destroyed and the last error cleared.
+int como_abort_capture(como_stream_t stream) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing((hipStream_t)stream, &st) != hipSuccess) st = hipStreamCaptureStatusNone;
+  int was = st != hipStreamCaptureStatusNone;
+  if (was) {
+    hipGraph_t g = nullptr;
+    (void)hipStreamEndCapture((hipStream_t)stream, &g);
+    if (g) (void)hipGraphDestroy(g);
+  }
+  (void)hipGetLastError();
+  return was;
+}
 
 int como_select_workspace_bytes(void) { return 6 * como::SEL_BINS * (int)sizeof(uint32_t); }   /* per segment */
 

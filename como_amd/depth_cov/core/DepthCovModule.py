@@ -8,6 +8,7 @@ import math
 
 import torch
 
+from como_amd import _lib
 from como_amd.depth_cov.core import covariance as cv
 from como_amd.depth_cov.nn import UNet as unet
 
@@ -55,20 +56,14 @@ class DepthCovModule:
                 self._graphs = {}
             x = torch.empty(rgb.shape, dtype=torch.float32, device=rgb.device)
             x.copy_(rgb)
-            try:
-                side = torch.cuda.Stream(device=rgb.device)
-                side.wait_stream(torch.cuda.current_stream(rgb.device))
-                with torch.cuda.stream(side):
-                    self.forward(x)
-                torch.cuda.current_stream(rgb.device).wait_stream(side)
-                torch.cuda.synchronize(rgb.device)
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    outs = self.forward(x)
-                ent = (g, x, outs)
-            except Exception:                               # noqa: BLE001  (eager path keeps working)
-                torch.cuda.synchronize(rgb.device)
-                ent = (None, x, None)
+            side = torch.cuda.Stream(device=rgb.device)
+            side.wait_stream(torch.cuda.current_stream(rgb.device))
+            with torch.cuda.stream(side):
+                self.forward(x)
+            torch.cuda.current_stream(rgb.device).wait_stream(side)
+            torch.cuda.synchronize(rgb.device)
+            g, outs = _lib.capture_graph(lambda: self.forward(x), rgb.device)     # (on failure the eager path keeps working)
+            ent = (g, x, outs if g is not None else None)
             self._graphs[key] = ent
         g, x, outs = ent
         if g is None:

@@ -40,6 +40,17 @@ class Shard:
         b = min(rows, self.rank * per)
         return b, min(rows, b + per)
 
+    @property
+    def collectives(self):
+        return self.world > 1 or self.force
+
+    def capturable(self):
+        """Can the collectives go into a hipGraph?  RCCL ("nccl") supports stream capture; gloo stages through the host."""
+        try:
+            return dist.is_initialized() and "nccl" in str(dist.get_backend(self.group)).lower()
+        except Exception:   # noqa: BLE001
+            return False
+
     def all_reduce_sum(self, t):
         if self.world > 1 or self.force:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

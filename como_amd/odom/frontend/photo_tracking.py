@@ -135,28 +135,19 @@ class _LevelGraph:
         return out
 
     def capture(self):
-        try:
-            keepT, keepA = self.T.clone(), self.aff.clone()
-            side = torch.cuda.Stream(device=self.dev)
-            side.wait_stream(torch.cuda.current_stream(self.dev))
-            with torch.cuda.stream(side):
-                self._iter()                                   # warm-up outside capture (workspace allocation)
-            torch.cuda.current_stream(self.dev).wait_stream(side)
-            torch.cuda.synchronize(self.dev)
-            self.T.copy_(keepT)
-            self.aff.copy_(keepA)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.out = self._iter()
-            self.T.copy_(keepT)                                # the capture itself does not execute; keep the state exact
-            self.aff.copy_(keepA)
-            self.graph = g
-        except Exception:                                      # noqa: BLE001  (eager fallback keeps working)
-            self.graph = None
-            try:
-                torch.cuda.synchronize(self.dev)
-            except Exception:                                  # noqa: BLE001
-                pass
+        keepT, keepA = self.T.clone(), self.aff.clone()
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            self._iter()                                       # warm-up outside capture (workspace allocation)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        self.T.copy_(keepT)
+        self.aff.copy_(keepA)
+        g, out = _lib.capture_graph(self._iter, self.dev)      # (on failure the eager path keeps working)
+        self.T.copy_(keepT)                                    # the capture itself does not execute; keep the state exact
+        self.aff.copy_(keepA)
+        self.graph, self.out = (g, out) if g is not None else (None, None)
         return self.graph is not None
 
     def step(self):

@@ -463,32 +463,28 @@ class WindowBA:
         # multi-GPU: the collectives are captured with the kernels (RCCL supports stream capture); if the runtime refuses,
         # the except branch below leaves the object in eager mode
         self.graph = None
-        try:
-            side = torch.cuda.Stream(device=self.dev)
-            side.wait_stream(torch.cuda.current_stream(self.dev))
-            with torch.cuda.stream(side):
-                for _ in range(warmup):
-                    self.iterate()
-            torch.cuda.current_stream(self.dev).wait_stream(side)
-            torch.cuda.synchronize(self.dev)
-            ev = self.events
-            self.events = None
-            g = torch.cuda.CUDAGraph()
-            # (thread_local: the process group's watchdog thread may query events while this thread captures)
-            with torch.cuda.graph(g, capture_error_mode="thread_local" if self.shard is not None else "global"):
-                self.iterate()
-            self.events = ev
-            self.graph = g
-            return True
-        except Exception:   # noqa: BLE001
-            import traceback
-            self.graph = None
-            self.capture_error = traceback.format_exc()[-1500:]
-            try:
-                torch.cuda.synchronize(self.dev)
-            except Exception:   # noqa: BLE001
-                pass
+        if self.shard is not None and self.shard.collectives and not self.shard.capturable():
+            # (a gloo group -- the single-GPU test rigs -- stages through the host: nothing to capture, and an aborted
+            # capture leaves gloo's own streams in a state that crashed later collectives)
+            self.capture_error = "process group backend cannot be captured into a hipGraph"
             return False
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.iterate()
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        ev = self.events
+        self.events = None
+        # (thread_local: the process group's watchdog thread may query events while this thread captures)
+        g, out = _lib.capture_graph(self.iterate, self.dev, thread_local=self.shard is not None)
+        self.events = ev
+        if g is None:
+            self.capture_error = out
+            return False
+        self.graph = g
+        return True
 
     def step(self):
         """One GN iteration: graph replay when captured, eager otherwise."""

@@ -28,6 +28,12 @@ extern "C" {
 typedef void* como_stream_t;
 
 int como_abi_version(void);
+/* Read and clear the HIP runtime's per-thread last error (returns its code, 0 = none).  Every como_* call checks the last error
+ * after its launches, so a caller whose own runtime call failed (e.g. an aborted stream capture) clears it before going on. */
+int como_clear_last_error(void);
+/* End a stream capture that was invalidated (the stream stays in capture mode, and every launch on it fails, until
+ * hipStreamEndCapture is called); destroys the partial graph and clears the last error.  Returns 1 if `stream` was capturing. */
+int como_abort_capture(como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Exact k-th select (lower median of |r| over valid entries; torch.median semantics).

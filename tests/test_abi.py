@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, n), f"{n} declared in include/como_hip.h but not exported"
         assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in como_amd/_lib.py"
     assert set(_lib.SIGNATURES) == set(names)
-    assert L.como_abi_version() == 1
+    assert L.como_abi_version() == 2
     assert L.como_select_workspace_bytes() == 6 * 2048 * 4
     assert L.como_ba_partials_elems(14, 55, 64) == 14 * 55 * 3936
 

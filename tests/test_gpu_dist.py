@@ -179,3 +179,26 @@ def test_rccl_collectives_single_rank_group():
     report("rccl_single_rank", graph_single=out["single"][2], graph_rccl=out["rccl"][2], capture_error=out["rccl"][3])
     assert np.array_equal(out["single"][0], out["rccl"][0]) and np.array_equal(out["single"][1], out["rccl"][1])
     assert out["single"][2]                                             # the unsharded iteration always captures
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """bench.py exactly as the driver launches it for N = 2 (torch.distributed.run, one process per rank), on the one-GPU test
+    rig: both ranks on device 0, gloo instead of RCCL (COMO_SINGLE_DEVICE / COMO_DIST_BACKEND).  Checks the whole multi-rank
+    flow -- sharded window, collectives, eager fallback where the backend cannot be captured, max-over-ranks timing, ONE JSON
+    line from rank 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, COMO_SINGLE_DEVICE="1", COMO_DIST_BACKEND="gloo")
+    port = 29700 + (os.getpid() % 200)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["metric"] and d["roofline"]["kernel_ms"] > 0 and d["solution"]["cholesky_info"] == 0
+    assert d["solution"]["max_pose_abs_err_vs_gt_end"] < d["solution"]["max_pose_abs_err_vs_gt_start"]

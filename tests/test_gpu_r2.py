@@ -451,6 +451,46 @@ def test_ate_rgb_vs_reference_sequence():
     assert ate < 2e-5 and worst < 5e-5
 
 
+_RECOVERY_SCRIPT = r"""
+import torch
+from como_amd import _lib
+import como_amd.como_backends as cb
+DEV = torch.device("cuda:0")
+g = torch.Generator().manual_seed(1)
+x1 = (torch.rand((2, 7, 2), generator=g) * 2 - 1).to(DEV); x2 = (torch.rand((2, 33, 2), generator=g) * 2 - 1).to(DEV)
+E = lambda n: (torch.eye(2)[None, None] * 0.05 + 0.01).expand(2, n, 2, 2).contiguous().to(DEV)
+E1, E2 = E(7), E(33)
+want = cb.cross_covariance(x1, E1, x2, E2, 0.8).clone()
+def bad():
+    k = cb.cross_covariance(x1, E1, x2, E2, 0.8)
+    return float(k.sum().item())                       # a synchronising read-back: illegal while capturing
+cur = torch.cuda.current_stream(DEV)
+gr, err = _lib.capture_graph(bad, DEV)
+assert gr is None and isinstance(err, str) and len(err) > 0
+assert not torch.cuda.is_current_stream_capturing() and torch.cuda.current_stream(DEV) == cur
+got = cb.cross_covariance(x1, E1, x2, E2, 0.8)         # the launch check of the next call sees no stale error
+torch.cuda.synchronize()
+assert torch.equal(got, want)
+g2, why = _lib.capture_graph(lambda: cb.cross_covariance(x1, E1, x2, E2, 0.8), DEV)
+assert g2 is None and "disabled" in why                # later requests are declined, not attempted
+assert torch.equal(cb.cross_covariance(x1, E1, x2, E2, 0.8), want)
+print("RECOVERED")
+"""
+
+
+def test_recovery_after_invalidated_capture():
+    """A capture that an operation inside invalidates (here: a host read-back) must leave the process able to launch eagerly:
+    _lib.capture_graph ends the capture (como_abort_capture), restores the stream, clears the runtime's last error and declines
+    later capture requests (torch's capture machinery does not survive an aborted capture).  Own process: it poisons capture."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _RECOVERY_SCRIPT], cwd=root, env=dict(os.environ, PYTHONPATH=root), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "RECOVERED" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_cross_covariance_half_dispatch():
     """The reference dispatches cross_covariance for at::Half as well (cov_gpu.cu:73).  como_cross_covariance_f16 against (a) an
     emulation of the kernel's operation sequence in torch float16 arithmetic (every operation rounded to half, like
