@@ -58,6 +58,10 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+__device__ __forceinline__ float fast_rcpf(float x) {              // hardware reciprocal + one Newton step (~0.5 ulp)
+  const float y = __builtin_amdgcn_rcpf(x);
+  return fmaf(y, fmaf(-x, y, 1.0f), y);
+}
 // 1/x and 1/sqrt(x) in double from the hardware seed + one Newton step (second / third order): ~1 ulp, 4-6 instructions
 // instead of the ~25 of an IEEE division or sqrt.  Only used for Jacobian WEIGHTS (never for what feeds a validity mask).
 __device__ __forceinline__ double fast_rcp(double x) {
@@ -810,11 +814,14 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
       const T r = It - Iref_s + bias[g];
       const bool ok = wok[g];
       const T wr = r * info_sqrt;
-      const T wgt = ok ? huber(wr) : T(0);
-      const T ws = sqrt(wgt);
-      const T s = ok ? info_sqrt * ws : T(0);
-      err[g] += ok ? (ws * wr) * (ws * wr) : T(0);
-      const T iz = ok ? T(1) / wZ[g] : T(0);
+      // WEIGHTS of the Jacobian rows (never what feeds a validity mask): hardware reciprocal + one Newton step and the
+      // hardware square root (1 ulp) instead of the IEEE division / sqrt expansions (~30 instructions per pair and pixel)
+      const T awr = fabsf(wr);
+      const T hub = (awr < T(1.345)) ? T(1) : T(1.345) * fast_rcpf(awr);          // robust_loss.py:9-16
+      const T ws = ok ? __builtin_amdgcn_sqrtf(hub) : T(0);
+      const T s = info_sqrt * ws;
+      err[g] += (ws * wr) * (ws * wr);
+      const T iz = ok ? fast_rcpf(wZ[g]) : T(0);
       const T a0 = gx * fx * iz, a1 = gy * fy * iz;
       const T a2 = -(a0 * wX[g] + a1 * wY[g]) * iz;
       const T b0 = a0 * Mr[g][0] + a1 * Mr[g][4] + a2 * Mr[g][8];
@@ -864,6 +871,8 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
     s1_issue(tile + 256);
     s0_load(tile + 512);
     __builtin_amdgcn_wave_barrier();
+    // (rolled on purpose, and the K~ rows come through the row table even when it is the identity: the fully unrolled
+    //  matrix phase, or a computed row index, doubles the kernel's time -- the register allocation has no slack)
     for (int half = 0; half < 16 / PF; ++half) {
       static_for<PF>([&](auto ic_) {
         constexpr int sl = decltype(ic_)::value;
