@@ -309,7 +309,8 @@ def photo_tracking_pyr(Tji_init, aff_init, vals_i, Pi, dI_dT, masks, intrinsics,
     The reference gathers the masked subset of vals / P / dI_dT on every frame; here the full arrays are copied into
     persistent buffers when (and only when) the reference tensors change, the masks go to the kernel
     (`como_track_iter_masked_*`), and every level replays one iteration graph captured once per pyramid shape."""
-    key = (str(Pi[0].device), Pi[0].dtype) + tuple((v.shape[0] * v.shape[1],) + tuple(i.shape[-2:]) for v, i in zip(vals_i, img_j))
+    key = (str(Pi[0].device), Pi[0].dtype) + tuple((v.shape[0] * v.shape[1], v.shape[2]) + tuple(i.shape[-2:])
+                                                   for v, i in zip(vals_i, img_j))          # (points, channels, H, W) per level
     pb = _pyr_buffers.get(key)
     if pb is None:
         if len(_pyr_buffers) > 2:

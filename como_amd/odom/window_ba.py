@@ -99,6 +99,24 @@ class WindowBA:
         self.init_scale_anchor = state.get("init_scale_anchor")
         self._prepare_topology()
 
+    @staticmethod
+    def _fixed_remap(mask, m):
+        """sparse_map.get_batch_remap_function (reference sparse_map.py:73-112) for a window in which every keyframe observes
+        exactly m landmarks -- what the reference's own `landmark_to_batched_3d_point_inds` (.view(num_kf, -1)) requires --
+        WITHOUT the host synchronisations of torch.nonzero / .item(): the window is rebuilt on every one-way frame and every
+        keyframe of the sequential loop, and each synchronisation stalls the host behind the whole queued GPU work.
+        Returns (remap, landmark_ids (B*m,2) as the reference's list, lm_of (B,m) landmark index per slot, ascending)."""
+        B = mask.shape[0]
+        lm_of = torch.argsort((~mask).to(torch.uint8), dim=1, stable=True)[:, :m].contiguous()     # the m True columns, in order
+        rows = torch.arange(B, device=mask.device).repeat_interleave(m)
+        landmark_ids = torch.stack((rows, lm_of.reshape(-1)), dim=1)
+
+        def remap(variable, default_val=-1):           # variable (B,L,...) -> (B,m,...); every slot is filled
+            idx = lm_of.reshape((B, m) + (1,) * (variable.dim() - 2)).expand((B, m) + tuple(variable.shape[2:]))
+            return torch.gather(variable, 1, idx)
+
+        return remap, landmark_ids, lm_of
+
     # ---- things that change only when the keyframe set changes ---------------------------------------------------
     def _prepare_topology(self):
         B, dev, m = self.B, self.dev, self.m
@@ -124,8 +142,7 @@ class WindowBA:
             self.vals_n = self.vals_n[:, pb:pe].contiguous()
             self.row_range = self.shard.row_range(self.Himg * self.Wimg)
         self.n = self.pixidx.shape[1]
-        self.remap, paired = smap.get_batch_remap_function(self.correspondence_mask)
-        landmark_ids, _ = paired
+        self.remap, landmark_ids, lm_of = self._fixed_remap(self.correspondence_mask, m)
         self.point_inds = lin_sys.landmark_to_batched_3d_point_inds(landmark_ids, B)
         L = self.P_m.shape[0]
         self.L = L
@@ -140,7 +157,7 @@ class WindowBA:
         self.landmark_inds_flat = torch.arange(3 * L, device=dev).reshape(L, 3) + self.lm_start
         # index lists of the oldest keyframe's landmarks (their anchors, Mapping.py:884-898): precomputed -- boolean-mask
         # indexing inside the iteration would synchronise with the host (and cannot be captured in a hipGraph)
-        self.fix_idx = torch.nonzero(self.correspondence_mask[0])[:, 0]
+        self.fix_idx = lm_of[0]
         self.fix_inds_flat = self.landmark_inds_flat[self.fix_idx].flatten().contiguous()
         self.lm_ids = (self.point_inds[:, ::3] // 3).to(torch.int32).contiguous()          # (B,m)
         first_obs = torch.argmax(self.correspondence_mask.int(), dim=0)                    # first observer keyframe

@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--step", type=float, default=0.01)
     ap.add_argument("--pix", default="float")
     ap.add_argument("--save-traj", default=None, help="write the tracked trajectory in TUM format")
+    ap.add_argument("--cprofile-after", type=int, default=-1, help="cProfile the loop from this frame on (host-side breakdown)")
     args = ap.parse_args()
     dev = "cuda:0"
     H, W = args.H, args.W
@@ -92,13 +93,28 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     t_first_tracked = None
+    prof = None
     for k in range(args.frames):
+        if k == args.cprofile_after:
+            import cProfile
+            prof = cProfile.Profile()
+            prof.enable()
         kinds.append(odo.iter(1.0 + 0.033 * k, rgbs[k]))
         if t_first_tracked is None and odo.mapping.is_init:
             torch.cuda.synchronize()
             t_first_tracked = (k, time.perf_counter())
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    if prof is not None:
+        import io
+        import pstats
+        prof.disable()
+        buf = io.StringIO()
+        pstats.Stats(prof, stream=buf).sort_stats("cumulative").print_stats(60)
+        buf.write("\n==== by own time ====\n")
+        pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(40)
+        os.makedirs("gpurun_out", exist_ok=True)
+        open("gpurun_out/odo_cprofile.txt", "w").write(buf.getvalue())
     n_tracked = args.frames - 1 - t_first_tracked[0]
     # trajectory error against GT after a similarity alignment of the translations (monocular: scale is a gauge)
     est = torch.stack([p[0, :3, 3].double().cpu() for p in odo.est_poses])
