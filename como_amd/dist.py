@@ -16,8 +16,10 @@ Payloads are latency-bound on xGMI (tens of microseconds); see DESIGN.md for the
 """
 import os
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver stack
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 class Shard:
