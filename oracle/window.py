@@ -66,6 +66,9 @@ class OracleWindow:
                                         c["kf_img_and_grads"][tid], dT[rid], dz[rid], dz_dPw[rid], self.kf_inds[rid],
                                         self.kf_inds[tid], self.lm[rid], K, H, g, return_aux=True)
         self.aux = aux
+        # the arguments batch_photo_cost just received (photo.py:83-99), for tests that drive another implementation with them
+        self.last_photo_args = (self.vals[rid], self.aff[rid], Pw[rid], self.poses[tid], self.aff[tid], c["kf_img_and_grads"][tid],
+                                dT[rid], dz[rid], dz_dPw[rid], self.kf_inds[rid], self.kf_inds[tid], self.lm[rid], K)
         kpi = self.kf_inds[:, :6]
         log_med = torch.log(med)[:, None, None]
         opr.gp_ml_cost(logz, log_med, c["L_mm"], dlogz_dP, dlogz_dT, self.lm, kpi, H, g, 1.0)

@@ -182,6 +182,43 @@ def test_landmark_reinit_vs_reference(fused):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("pix", [torch.float64, torch.float32])
+def test_rgb_batch_photo_cost_signature_path(pix):
+    """The reference-signature entry `batch_photo_cost` (photo.py:83-233) with 3-channel inputs -- vals_i (b,n,3), a 9-plane
+    target stack, the materialised dPwn_dzm -- against the oracle on the SAME arguments (the oracle's c = 3 path is pinned to the
+    reference by test_oracle_rgb_window_vs_reference; the arguments are what its window iteration passes)."""
+    import como_amd.odom.backend.photo as photo
+    from oracle import depthcov
+    from oracle.window import OracleWindow
+    from como_amd import synth
+    G = load_golden("ba_window_rgb_kf_f64.npz")
+    st = synth.make_window(B=int(G["B"]), H=int(G["H"]), W=int(G["W"]), m=int(G["m"]), dtype=torch.float64, seed=int(G["seed"]),
+                           predictor=lambda cov, cm: depthcov.prep_predictor(cov, cm, 1.0), aff_noise=float(G["aff_noise"]), channels=3)
+    ow = OracleWindow(st, window=int(G["window"]))
+    ow.iterate()
+    args = ow.last_photo_args
+    D = ow.D
+    Ho, go = torch.zeros((D, D), dtype=torch.float64), torch.zeros(D, dtype=torch.float64)
+    from oracle import photo_ba as oba
+    eo, aux = oba.batch_photo_cost(*args, Ho, go, return_aux=True)
+    dev_args = [a.to(DEV).to(pix).contiguous() if a.is_floating_point() else a.to(DEV).contiguous() for a in args]
+    Hh = torch.zeros((D, D), dtype=torch.float64, device=DEV)
+    gh = torch.zeros(D, dtype=torch.float64, device=DEV)
+    eh = photo.batch_photo_cost(*dev_args, Hh, gh)
+    f64 = pix == torch.float64
+    valid = photo.last_aux["valid"].cpu()
+    sig = photo.last_aux["sigma"].cpu()
+    report("rgb_batch_photo_cost", pix=str(pix), mask_mismatch=(valid != aux["valid"]).sum(), H=scaled_err(Hh.cpu(), Ho), g=rel_err(gh, go),
+           err=abs(float(eh) - float(eo)) / float(eo), sigma=abs(float(sig[0]) - float(aux["sigma"])) / float(aux["sigma"]))
+    assert int((valid != aux["valid"]).sum()) <= (0 if f64 else 2)
+    assert int(sig[1]) == 3 * int(aux["valid"].sum()) or not f64                       # (pixel, channel) entries of the median
+    assert abs(float(sig[0]) - float(aux["sigma"])) < (1e-12 if f64 else 1e-5) * float(aux["sigma"])
+    assert scaled_err(Hh.cpu(), Ho) < (1e-10 if f64 else 5e-4) and rel_err(gh, go) < (1e-10 if f64 else 5e-4)
+    assert abs(float(eh) - float(eo)) < (1e-10 if f64 else 1e-4) * float(eo)
+    assert tuple(photo.last_aux["r"].shape) == tuple(args[0].shape)                    # (b,n,3) as the reference's r_photo
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def test_rgb_two_frame_sfm_system_vs_reference():
     """construct_photo_system with c = 3 (vals_i (1,3,N), a 9-plane target stack): mask bit-exact, H / g / err to 1e-10."""
     from como_amd.odom.frontend import two_frame_sfm as sfm
