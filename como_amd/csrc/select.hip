@@ -39,16 +39,29 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const T* __restrict__ 
   const bool vec = (sizeof(T) == 4) && ((n & 3) == 0) && ((reinterpret_cast<uintptr_t>(r) & 15) == 0) &&
                    (!valid || (reinterpret_cast<uintptr_t>(valid) & 3) == 0);
   if (vec) {
+    // four independent 16-byte loads per thread and trip: with one, 256 workgroups keep 1 MB in flight and the pass is
+    // latency-bound (21 MB in 17 us)
     const long n4 = n >> 2;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-      const float4 rv = reinterpret_cast<const float4*>(r)[i];
-      const uint32_t vv = valid ? reinterpret_cast<const uint32_t*>(valid)[i] : 0x01010101u;
-      const float e[4] = {rv.x, rv.y, rv.z, rv.w};
+    const long stride = (long)gridDim.x * 256;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+      float4 rv[4];
+      uint32_t vv[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if ((vv >> (8 * k)) & 0xffu) {
-          KeyT key = abs_key((T)e[k]);
-          if (sel_match<KeyT>(key, prefix, pass)) atomicAdd(&lh[sel_digit<KeyT>(key, pass)], 1u);
+      for (int u = 0; u < 4; ++u) {
+        const long i = i0 + u * stride;
+        const bool in = i < n4;
+        rv[u] = reinterpret_cast<const float4*>(r)[in ? i : i0];
+        vv[u] = !in ? 0u : (valid ? reinterpret_cast<const uint32_t*>(valid)[i] : 0x01010101u);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float e[4] = {rv[u].x, rv[u].y, rv[u].z, rv[u].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if ((vv[u] >> (8 * k)) & 0xffu) {
+            KeyT key = abs_key((T)e[k]);
+            if (sel_match<KeyT>(key, prefix, pass)) atomicAdd(&lh[sel_digit<KeyT>(key, pass)], 1u);
+          }
         }
       }
     }
