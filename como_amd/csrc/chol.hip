@@ -11,7 +11,7 @@
 //                    inverted by the workgroup that just updated it (factor_invert_tile: four pivots per barrier, rank-4
 //                    MFMA updates).  A non-positive pivot is reported in `info` (1-based, first failure) instead of being
 //                    swallowed; the factorisation then continues with pivot 1 as a defined value.
-//   chol_backsub x2 + chol_backsub_rect: L^T delta = y, split once into triangle / rectangle / triangle launches.
+//   chol_backsub + chol_backsub_rect: L^T delta = y, split into 2 or 4 block ranges: triangle / rectangle / triangle ... launches.
 #include "common.cuh"
 #include "../../include/como_hip.h"
 #include <type_traits>
@@ -409,10 +409,11 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
 // One workgroup walking the whole factor is bound by what ONE compute unit can pull through the fabric (~12 B/clk: 2.3 MB
 // of L at D = 760 -> 68 us; prefetching panels / inverse blocks one or two steps ahead changes nothing at that size), and
 // spreading the panel products of every step over many workgroups needs a device-wide hand-off per panel (~4 us each, 24
-// of them): no better.  So the solve is split ONCE, with launch boundaries as the only synchronisation:
-//   chol_backsub(blocks h..nb-1)  one workgroup, the lower-right triangle (1/4 of the bytes)
-//   chol_backsub_rect             many workgroups: y_j -= L[h*32.., j]^T x for the columns left of the split (1/2 of the bytes)
-//   chol_backsub(blocks 0..h-1)   one workgroup, the upper-left triangle (1/4 of the bytes)
+// of them): no better.  So the solve is split into P block ranges (2, or 4 from 48 blocks on), right to left, with launch
+// boundaries as the only synchronisation:
+//   chol_backsub(range p)       one workgroup, the triangle of the range (1 / P^2 of the bytes)
+//   chol_backsub_rect(range p)  many workgroups: y_j -= L[rows of range p, j]^T x for ALL columns left of the range
+//   chol_backsub(range p - 1)   ... (its right-hand side = row D minus the partials of every rectangle to its right)
 // Per 32-block (right to left): x_k = L_kk^-T y_k is a 32x32 mat-vec with the pre-inverted diagonal block, then
 // y_j -= L[k rows, j]^T x_k for the columns to the left within the range (coalesced along j).
 // ysrc: right-hand side of the range (NULL = row D of L); yinit: when not NULL, receives row D of L for the columns left
@@ -430,8 +431,15 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsub_kernel(const double* 
   for (int j = j_lo + tid; j < j_hi; j += BS_THREADS) {
     double v = (j < D) ? (ysrc ? ysrc[j] : Lw[(long)D * Dp + j]) : 0.0;
     // the rectangle's row slabs, subtracted in slab order (no floating-point atomics: the solve is bit-reproducible)
-    if (ypart && j < D)
-      for (int sl = 0; sl < nslab; ++sl) v -= ypart[(long)sl * pstride + j];
+    if (ypart && j < D) {                             // (nslab is a multiple of 8; eight loads in flight, fixed order of the sum)
+      for (int sl = 0; sl < nslab; sl += 8) {
+        double pv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pv[u] = ypart[(long)(sl + u) * pstride + j];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v -= pv[u];
+      }
+    }
     y[j] = v;
   }
   if (yinit)
@@ -503,14 +511,14 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsub_kernel(const double* 
   }
 }
 
-// ypart[slab][j] = sum_{r in slab of [r_lo, D)} L[r][j] x[r] for j < ncols: blockIdx.x = 128-column chunk, blockIdx.y = row slab.
+// ypart[slab][j] = sum_{r in slab of [r_lo, r_hi)} L[r][j] x[r] for j < ncols: blockIdx.x = 128-column chunk, blockIdx.y = row slab.
 // One partial per (slab, column), summed in slab order by the consumer (atomics would make the solve order-dependent).
-__global__ __launch_bounds__(128) void chol_backsub_rect_kernel(const double* __restrict__ Lw, int Dp, int D, int r_lo, int ncols,
+__global__ __launch_bounds__(128) void chol_backsub_rect_kernel(const double* __restrict__ Lw, int Dp, int r_lo, int r_hi, int ncols,
                                                                 const double* __restrict__ x, double* __restrict__ ypart,
                                                                 int pstride) {
   const int j = blockIdx.x * 128 + threadIdx.x;
-  const int rows = D - r_lo, per = (rows + gridDim.y - 1) / gridDim.y;
-  const int r0 = r_lo + blockIdx.y * per, r1 = min(r0 + per, D);
+  const int rows = r_hi - r_lo, per = (rows + gridDim.y - 1) / gridDim.y;
+  const int r0 = r_lo + blockIdx.y * per, r1 = min(r0 + per, r_hi);
   if (j >= ncols) return;
   double s = 0.0;
 #pragma unroll 4
@@ -550,25 +558,34 @@ int como_chol_solve_f64(const double* H, const double* g, double* delta, void* w
     hipLaunchKernelGGL(chol_panel2_kernel, dim3(tiles), dim3(512), 0, s, W, Lw, Iw, Dp, D, c0, nb, info);
     COMO_CHECK_LAUNCH();
   }
-  const int h = nb / 2;
   if (nb < 6) {
     hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, 0, nb, (const double*)nullptr,
                        (double*)nullptr, delta, (const double*)nullptr, 0, 0);
     COMO_CHECK_LAUNCH();
   } else {
+    // P block ranges, right to left: triangle(range p) -> rectangle(rows of range p x ALL columns left of it) -> triangle(p-1) ...
+    // Each triangle is walked by one workgroup (1 / P^2 of the factor's bytes each), the rectangles by many; a column receives
+    // the partials of every rectangle to its right, summed in a fixed order.  A triangle launch has ~10 us of fixed cost
+    // (right-hand side, first inverse block and panel slab): D = 760 (24 blocks) is fastest with 2 ranges (55 us; 4 ranges:
+    // 75 us), D = 2680 (84 blocks) with 4 (two 157 us triangles -> the iteration 4.08 -> 3.87 ms).
+    const int P = nb >= 48 ? 4 : 2;
+    const int NSLAB = nb >= 48 ? 32 : 8;                  // row slabs per rectangle (a multiple of 8: the consumer's unroll)
     double* ybuf = W;                                     // the working copy is dead once the factor is complete
-    double* ypart = W + Dp;                               // 32 row-slab partials of the rectangle, Dp apart (Dp >= 192 > 33 rows)
-    constexpr int NSLAB = 32;
-    hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, h, nb, (const double*)nullptr, ybuf, delta,
-                       (const double*)nullptr, 0, 0);
-    COMO_CHECK_LAUNCH();
-    const int ncols = h * CB, r_lo = h * CB;
-    hipLaunchKernelGGL(chol_backsub_rect_kernel, dim3((ncols + 127) / 128, NSLAB), dim3(128), 0, s, Lw, Dp, D, r_lo, ncols, delta,
-                       ypart, Dp);
-    COMO_CHECK_LAUNCH();
-    hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, 0, h, (const double*)ybuf, (double*)nullptr,
-                       delta, (const double*)ypart, NSLAB, Dp);
-    COMO_CHECK_LAUNCH();
+    double* ypart = W + Dp;                               // (P - 1) x NSLAB row-slab partials, Dp apart (Dp >= 192 rows)
+    for (int p = P - 1; p >= 0; --p) {
+      const int k_lo = (int)((long)nb * p / P), k_hi = (int)((long)nb * (p + 1) / P);
+      const bool first = p == P - 1;
+      hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, k_lo, k_hi,
+                         first ? (const double*)nullptr : (const double*)ybuf, first ? ybuf : (double*)nullptr, delta,
+                         first ? (const double*)nullptr : (const double*)ypart, NSLAB * (P - 1 - p), Dp);
+      COMO_CHECK_LAUNCH();
+      if (p > 0) {
+        const int ncols = k_lo * CB, r_lo = k_lo * CB, r_hi = min(k_hi * CB, D);
+        hipLaunchKernelGGL(chol_backsub_rect_kernel, dim3((ncols + 127) / 128, NSLAB), dim3(128), 0, s, Lw, Dp, r_lo, r_hi, ncols,
+                           delta, ypart + (long)(P - 1 - p) * NSLAB * Dp, Dp);
+        COMO_CHECK_LAUNCH();
+      }
+    }
   }
   return COMO_OK;
 }
