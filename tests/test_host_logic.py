@@ -240,3 +240,41 @@ def test_pair_graph_radius_and_degree_edges_vs_reference():
         assert c == G[f"c{i}_ow_kf"].tolist() and d == G[f"c{i}_ow_tgt"].tolist(), i
         n_extra += len(a) - 12
     assert n_extra > 0                                                # the radius edges are actually exercised
+
+
+def test_pair_table_colour_expansion():
+    """`color: rgb`: every keyframe pair becomes c consecutive entries of the pair table, one per channel, with the same system
+    rows; two-pair groups never mix reference keyframes or channels (the block kernel loads I_ref once per group)."""
+    import torch
+    from como_amd.odom.backend.photo import PairTable
+    B, m, L, HW = 4, 8, 20, 48 * 64
+    kf_inds = torch.arange(8 * B).reshape(B, 8)
+    recent_inds = torch.arange(8 * 2).reshape(2, 8) + 8 * B
+    lm = torch.arange(3 * m * B).reshape(B, 3 * m) + 100
+    ref = [0, 1, 2, 1, 2, 3, 1, 2]
+    tgt = [1, 2, 3, 0, 1, 2, 0, 1]
+    rec = [False] * 6 + [True, True]
+    for c in (1, 3):
+        stack = 3 * c * HW
+        t = PairTable(ref, tgt, rec, B, kf_inds, recent_inds, lm, stack, B * stack, torch.device("cpu"), channels=c)
+        assert t.b == len(ref) * c and t.npairs == len(ref) and t.channels == c
+        if c == 1:
+            assert t.pair_chan is None
+        else:
+            assert t.pair_chan.tolist() == [0, 1, 2] * len(ref)
+        for p in range(len(ref)):
+            for ch in range(c):
+                e = p * c + ch
+                assert int(t.ref_slot[e]) == ref[p]
+                frame = tgt[p] + (B if rec[p] else 0)
+                assert int(t.tgt_pose[e]) == frame and int(t.tgt_aff[e]) == frame
+                assert int(t.tgt_img[e]) == (B * stack + tgt[p] * stack if rec[p] else tgt[p] * stack)   # the FRAME's stack
+                assert torch.equal(t.pose_ref_inds[e], kf_inds[ref[p]]) and torch.equal(t.landmark_inds[e], lm[ref[p]])
+                assert torch.equal(t.pose_tgt_inds[e], (recent_inds[tgt[p]] if rec[p] else kf_inds[tgt[p]]))
+        seen = []
+        for a, b_ in t.grp_pairs.tolist():
+            seen.append(a)
+            if b_ >= 0:
+                seen.append(b_)
+                assert int(t.ref_slot[a]) == int(t.ref_slot[b_]) and a % c == b_ % c       # same keyframe, same channel
+        assert sorted(seen) == list(range(t.b))                                          # every entry exactly once
