@@ -378,6 +378,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
   using T = float;
   using KeyT = uint32_t;
   __shared__ uint32_t lh[SEL_BINS];
+  __shared__ uint32_t lh1[SEL_BINS];   // speculative digit-1 histogram (see `spec_bin`)
   __shared__ SelScratch sc;
   __shared__ float tile[128][TRK_ACC + 1];
   __shared__ double red[4][TRK_ACC];
@@ -419,15 +420,22 @@ __global__ __launch_bounds__(256) void track_level_kernel(
   // RETURNING atomics: the returned value comes from where the read-modify-write was performed (the memory side), so once
   // the wave has it (s_waitcnt in the barrier's __syncthreads) the update is globally performed -- a non-returning atomic is
   // acknowledged by the XCD's L2 before that, and the barrier arrival (another address, another channel) can overtake it
-  auto flush = [&](uint32_t* gh) {
+  auto flush = [&](uint32_t* gh, const uint32_t* src = nullptr) {
+    if (!src) src = lh;
     uint32_t sink = 0;
     for (int b = tid; b < SEL_BINS; b += 256) {
-      const uint32_t v = lh[b];
+      const uint32_t v = src[b];
       if (v) sink += __hip_atomic_fetch_add(&gh[b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     asm volatile("" ::"v"(sink));
   };
 
+  // SPECULATION on the first digit of the median: the robust scale moves little between iterations, so phase A also counts
+  // the SECOND digit of the keys whose first digit equals the previous iteration's (`spec_bin`), into region 3 of the
+  // histograms.  If the first digit resolves to that bin again, the second digit's histogram is already complete and one of
+  // the four device-wide synchronisations of the iteration (phase B: histogram, flush, barrier) is skipped; if not, region 3
+  // is ignored and phase B runs as always -- the result is the exact median either way.
+  int spec_bin = -1;
   while (true) {
     uint32_t* hs = hists2 + (it & 1) * 6 * SEL_BINS;          // this iteration's digit histograms / sums
     uint32_t* hother = hists2 + ((it + 1) & 1) * 6 * SEL_BINS;
@@ -435,7 +443,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
     long long* smother = sums2 + ((it + 1) & 1) * 128;
     TL_STAMP(0);
     // ---- phase A: warp, sample, residual, validity, digit-0 histogram ----
-    for (int b = tid; b < SEL_BINS; b += 256) lh[b] = 0;
+    for (int b = tid; b < SEL_BINS; b += 256) { lh[b] = 0; lh1[b] = 0; }
     T Pm[12];
     {
 #pragma clang fp contract(off)
@@ -458,31 +466,45 @@ __global__ __launch_bounds__(256) void track_level_kernel(
       const T tmp = ea * It;
       j6[k] = -tmp;
       rk[k] = (tmp + bb) - vref[k];
-      if (ok[k]) atomicAdd(&lh[sel_digit<KeyT>(abs_key(rk[k]), 0)], 1u);
+      if (ok[k]) {
+        const KeyT key = abs_key(rk[k]);
+        const uint32_t d0 = sel_digit<KeyT>(key, 0);
+        atomicAdd(&lh[d0], 1u);
+        if ((int)d0 == spec_bin) atomicAdd(&lh1[sel_digit<KeyT>(key, 1)], 1u);
+      }
     }
     __syncthreads();
     TL_STAMP(1);
     flush(hs);
+    if (spec_bin >= 0) flush(hs + 3 * SEL_BINS, lh1);
     TL_STAMP(2);
     if (!tl_barrier(B)) { alive = false; break; }
     TL_STAMP(3);
     // ---- phases B, C: digits 1 and 2 of the exact median (keys come from registers: no memory pass) ----
     KeyT prefix = 0;
     uint32_t k_rem = 0, nv = 0;
+    bool spec_hit = false;
     for (int ps = 1; ps < 3; ++ps) {
       for (int b = tid; b < SEL_BINS; b += 256) lh[b] = 0;
       if (ps == 1) {   // the other parity's histograms / sums: free since the last barrier, used by the next iteration
         // cleared with read-modify-write atomics (performed at the memory side like the adds that follow): a device-scope
         // STORE may linger in this XCD's write-back L2 and land after other workgroups' atomic adds, wiping them
         uint32_t sink = 0;
-        for (int e = blockIdx.x * 256 + tid; e < 3 * SEL_BINS; e += G * 256)
+        for (int e = blockIdx.x * 256 + tid; e < 4 * SEL_BINS; e += G * 256)
           sink += __hip_atomic_fetch_and(&hother[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (blockIdx.x == G - 1 && tid < 128)
           sink += (uint32_t)__hip_atomic_fetch_and((unsigned long long*)&smother[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("" ::"v"(sink));
       }
-      const uint32_t bin = tl_resolve_digit(hs + (ps - 1) * SEL_BINS, k_rem, ps == 1 ? &nv : nullptr, &sc);   // (orders the lh clear)
+      // digit ps - 1 from its finished histogram; after a successful speculation digit 1 sits in region 3
+      const uint32_t bin = tl_resolve_digit(hs + ((ps == 2 && spec_hit) ? 3 : ps - 1) * SEL_BINS, k_rem, ps == 1 ? &nv : nullptr,
+                                            &sc);                                        // (orders the lh clear)
       prefix |= ((KeyT)bin) << SelCfg<KeyT>::shift(ps - 1);
+      if (ps == 1) {
+        spec_hit = (int)bin == spec_bin;              // uniform over the grid: every workgroup resolves the same histogram
+        spec_bin = (int)bin;
+        if (spec_hit) continue;                       // phase B is already done: no histogram, no flush, no barrier
+      }
 #pragma unroll
       for (int k = 0; k < TL_MAXP; ++k) {
         const KeyT key = abs_key(rk[k]);
