@@ -2,7 +2,7 @@
 on a real `como.odom.Mapping.Mapping` object whose state attributes are filled from a seeded synthetic window, and records
 what the reference computed (hooks around `create_photo_system` and `solve_system` keep the intermediate H / g).
 
-    python tests/golden/make_golden_r2.py [fullwin4] [fullwin1] [reinit] [win32] [se3] [ate]
+    python tests/golden/make_golden_r2.py [fullwin4] [fullwin1] [reinit] [win32] [se3] [pairs] [ate] [ate_rgb] [rgb] [datasets]
 
 Cases
   fullwin4 / fullwin1 : the METRIC configuration -- 8 keyframes, 640x480, m = 64, nonmax window 4 (reference default) and
@@ -441,6 +441,27 @@ def ate_case(seed=17, H=192, W=256, nframes=72, step=0.02, deg=0.4, colour=False
     return out
 
 
+def dataset_intrinsics_case(img_size=(192, 256), crop_size=10):
+    """Intrinsics of the dataset readers at the network size, computed with the reference's own `resize_intrinsics`
+    (como/geometry/camera.py:4-15) from the constants / the header values the reference readers use
+    (como/data/odom_datasets.py:58-111 TUM freiburg3 -- no distortion --, :180-206 ScanNet with its crop, :278-289 Replica).
+    The readers themselves need cv2 and real sequences; only this arithmetic is pinned."""
+    from como.geometry.camera import resize_intrinsics
+    size = torch.tensor(list(img_size))
+    out = {}
+    K = torch.tensor([[600.0, 0.0, 599.5], [0.0, 600.0, 339.5], [0.0, 0.0, 1.0]])
+    out["replica"] = resize_intrinsics(K, size / torch.tensor([680, 1200]))
+    K = torch.tensor([[535.4, 0.0, 320.1], [0.0, 539.2, 247.6], [0.0, 0.0, 1.0]])
+    out["tum3"] = resize_intrinsics(K, size / torch.tensor([480, 640]))
+    # ScanNet scene header of tests/test_data_io.py: colour 1296 x 968, fx = fy = 1170.187988, (mx, my) = (647.75, 483.75)
+    K = torch.tensor([[1170.187988, 0.0, 647.75], [0.0, 1170.187988, 483.75], [0.0, 0.0, 1.0]])
+    K = resize_intrinsics(K, torch.tensor([480, 640]) / torch.tensor([968.0, 1296.0]))
+    K[0, 2] -= crop_size
+    K[1, 2] -= crop_size
+    out["scannet"] = resize_intrinsics(K, size / torch.tensor([480 - 2 * crop_size, 640 - 2 * crop_size]))
+    return out
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     which = sys.argv[1:] or ["se3", "reinit", "win32", "fullwin4"]
@@ -458,6 +479,8 @@ if __name__ == "__main__":
         mg.save("pair_graph.npz", pair_graph_case())
     if "ate" in which:
         mg.save("ate_sequence.npz", ate_case())
+    if "datasets" in which:
+        mg.save("dataset_intrinsics.npz", dataset_intrinsics_case())
     if "ate_rgb" in which:
         mg.save("ate_sequence_rgb.npz", ate_case(seed=23, H=96, W=128, nframes=40, colour=True))
     if "rgb" in which:
