@@ -32,7 +32,7 @@ class BAArgs(ctypes.Structure):
         ("ws_pair", c_void_p), ("ws_partials", c_void_p), ("grp_pairs", c_void_p), ("single_pairs", c_void_p),
         ("ngrp", c_int), ("nsingle", c_int),
         ("fix_plane", c_long), ("reduce_mode", c_int), ("blocks_fix", c_void_p),
-        ("channels", c_int), ("pair_chan", c_void_p),
+        ("channels", c_int), ("pair_chan", c_void_p), ("ref_pose", c_void_p),
     ]
 
 

@@ -87,16 +87,21 @@ struct BAPairs {
   int anorm_f32;           // sampling normalisation rounded to float32 first (two_frame_sfm.py:187-190)
   const int* chan;         // [b] image channel of each pair (NULL: 0).  A c-channel image (`color: rgb`) is linearised as c
   int C;                   //     pairs per keyframe pair, one per channel: photo.py:112-128 treats (pixel, channel) residuals alike
+  const int* ref_pose;     // [b] index into poses_all of the REFERENCE keyframe's pose T_wc (zmode 2 only, else NULL)
 };
 // channel ch of the target stack [I_0..I_C-1 | gx_0.. | gy_0..] (photo.py:24-27, 44-52) and of the reference values (slots,n,C)
 __device__ __forceinline__ int pair_chan(const BAPairs& pr, int p) { return pr.chan ? pr.chan[p] : 0; }
 
 template <typename T>
 __global__ void ba_pair_setup_kernel(const T* __restrict__ poses_all, const T* __restrict__ aff_all, BAPairs pr, int b,
-                                     T* __restrict__ pair_T, T* __restrict__ pair_aff) {
+                                     T* __restrict__ pair_T, T* __restrict__ pair_aff, T* __restrict__ pair_ref) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= b) return;
   invert_pose34(poses_all + 16 * (long)pr.tgt_pose[p], pair_T + 12 * (long)p);   // photo.py:105
+  if (pr.ref_pose) {                                                             // zmode 2: [R_wc | t_wc] of the reference keyframe
+#pragma unroll
+    for (int k = 0; k < 12; ++k) pair_ref[12 * (long)p + k] = poses_all[16 * (long)pr.ref_pose[p] + k];
+  }
   const T* ai = aff_all + 2 * (long)pr.ref_aff[p];
   const T* aj = aff_all + 2 * (long)pr.tgt_aff[p];
   pair_aff[2 * p + 0] = exp(aj[0] - ai[0]);                                      // photo.py:115
@@ -118,6 +123,24 @@ __device__ __forceinline__ Warp<T> warp_point(const T* __restrict__ M, T fx, T f
   w.v = project1(fy, w.Y, w.Z, cy);
   w.ok = in_image(w.u, w.v, H, W) && (w.Z > T(0));      // photo.py:15-21
   return w;
+}
+
+// zmode 2 (compact dense reference): the block kernels rebuild the reference-pose block from P_w, the reference pose
+// [R | t] = T_wc and the six dot products dl = K~[n,:] dlogz_m/dT_wc instead of loading 18 + 3 planes:
+//   dP_w/dT_wc = [-[u]x R , R] + u (x) dl   with u = R ray z_n = P_w - t   (densify.hip dense_ref: -(R [P_c]x) = -[u]x R)
+//   b^T dP_w/dT_wc = [ R^T (u x b) , R^T b ] + (b . u) dl
+// Returns u . b (the depth scale before the row weight) and the six geometric entries jr[0..5]; the caller adds
+// (s b.u) dl[k].  Only Jacobian VALUES depend on this (never a validity mask).
+template <typename T>
+__device__ __forceinline__ T ref_pose_geom(const T* __restrict__ Rf, T Px, T Py, T Pz, T b0, T b1, T b2, T* __restrict__ jr) {
+  const T u0 = Px - Rf[3], u1 = Py - Rf[7], u2 = Pz - Rf[11];
+  const T w0 = u1 * b2 - u2 * b1, w1 = u2 * b0 - u0 * b2, w2 = u0 * b1 - u1 * b0;      // u x b
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    jr[j] = Rf[j] * w0 + Rf[4 + j] * w1 + Rf[8 + j] * w2;
+    jr[3 + j] = Rf[j] * b0 + Rf[4 + j] * b1 + Rf[8 + j] * b2;
+  }
+  return b0 * u0 + b1 * u1 + b2 * u2;
 }
 
 // ---------------------------------------- pass 1 -------------------------------------------------
@@ -235,9 +258,9 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
     const int* __restrict__ pixidx,  // ZMODE 1: (slots, n) row index into K~ of that slot (nullptr -> identity)
     const T* __restrict__ invz,      // ZMODE 1: (slots, m)
     long kt_slot_stride,             // ZMODE 1: elements between consecutive slots of K~
-    BAPairs pr, const T* __restrict__ pair_T, const T* __restrict__ pair_aff, const T* __restrict__ img_base,
-    const T* __restrict__ Kmat, int H, int W, int n, int m, int pix_begin, int pix_end, int chunk_len,
-    const uint32_t* __restrict__ hists, T* __restrict__ partials, T* __restrict__ sigma_out) {
+    BAPairs pr, const T* __restrict__ pair_T, const T* __restrict__ pair_aff, const T* __restrict__ pair_ref,
+    const T* __restrict__ img_base, const T* __restrict__ Kmat, int H, int W, int n, int m, int pix_begin, int pix_end,
+    int chunk_len, const uint32_t* __restrict__ hists, T* __restrict__ partials, T* __restrict__ sigma_out) {
   using KeyT = typename KeyOf<T>::type;
   using Cfg = BACfg;
   using acc_t = typename Acc4<T>::type;
@@ -269,8 +292,11 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
   const T* img = img_base + pr.tgt_img[p] + (long)ch * H * W;
   const long HW = (long)pr.C * H * W;
 
+  T Rf[12];                                 // ZMODE 2: [R | t] of the reference keyframe's pose
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Rf[k] = (ZMODE == 2) ? pair_ref[12 * (long)p + k] : T(0);
   T invz4[4] = {T(0), T(0), T(0), T(0)};
-  if constexpr (ZMODE == 1) {
+  if constexpr (ZMODE >= 1) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
   }
@@ -291,7 +317,7 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
   V4<T> kq[PF];
   for (int tile = begin + wv * 64; tile < end; tile += 256) {
     int myrow = 0;
-    if constexpr (ZMODE == 1) {
+    if constexpr (ZMODE >= 1) {
       const int i = min(tile + lane, end - 1);
       myrow = pixidx ? pixidx[(long)slot * n + i] : i;
       static_for<PF>([&](auto ic) {
@@ -308,7 +334,7 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
       const int ic = inr ? i : (end - 1);
       const long ri = (long)slot * n + ic;
       T Px, Py, Pz;
-      if constexpr (ZMODE == 1) {       // fast path: structure-of-arrays planes (slot, component, n)
+      if constexpr (ZMODE >= 1) {       // fast path: structure-of-arrays planes (slot, component, n)
         Px = Pwn[((long)slot * 3 + 0) * n + ic]; Py = Pwn[((long)slot * 3 + 1) * n + ic]; Pz = Pwn[((long)slot * 3 + 2) * n + ic];
       } else {
         Px = Pwn[3 * ri]; Py = Pwn[3 * ri + 1]; Pz = Pwn[3 * ri + 2];
@@ -333,7 +359,14 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
       const T b1 = a0 * Mr[1] + a1 * Mr[5] + a2 * Mr[9];
       const T b2 = a0 * Mr[2] + a1 * Mr[6] + a2 * Mr[10];
       // reference-pose block: dI/dP_w dP_w/dT_wci (photo.py:145)
-      if constexpr (ZMODE == 1) {
+      T bu = T(0);                        // ZMODE 2: b . u
+      if constexpr (ZMODE == 2) {
+        T jr[6];
+        bu = ref_pose_geom(Rf, Px, Py, Pz, b0, b1, b2, jr);
+        const T* D = dPwn_dTwc + (long)slot * 6 * n + ic;            // planes dlogz_n/dT_wc
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Jp[k * JP_STRIDE + lane] = s * (jr[k] + bu * D[(long)k * n]);
+      } else if constexpr (ZMODE == 1) {
         const T* D = dPwn_dTwc + (long)slot * 18 * n + ic;
 #pragma unroll
         for (int k = 0; k < 6; ++k)
@@ -358,6 +391,8 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
       Sv[0 * 64 + lane] = s * r;                           // whitened residual r~
       if constexpr (ZMODE == 0) {
         Sv[1 * 64 + lane] = s * b0; Sv[2 * 64 + lane] = s * b1; Sv[3 * 64 + lane] = s * b2;
+      } else if constexpr (ZMODE == 2) {
+        Sv[1 * 64 + lane] = s * bu;
       } else {
         const T* U = uvec + (long)slot * 3 * n + ic;
         Sv[1 * 64 + lane] = s * (b0 * U[0] + b1 * U[n] + b2 * U[2 * (long)n]);
@@ -450,15 +485,16 @@ __global__ __launch_bounds__(256) void ba_blocks_kernel(
 // of a wave (PMC on the straightforward version: MFMA pipe 44 % busy, 20 k of 28 k wave-cycles per tile spent
 // outside phase B, mostly waiting on the two dependent load rounds of phase A).  Per wave and tile t:
 //     S2(t)   consume the loads issued one tile ago -> 16 pose/affine entries + depth scale + r~ -> LDS
-//     S1(t+1) warp the NEXT tile's points (loaded two stages ago), issue its 12 tap loads + 22 plane loads
+//     S1(t+1) warp the NEXT tile's points (loaded two stages ago), issue its 12 tap loads + 7 plane loads
 //     S0(t+2) issue the P_w loads of the tile after that
 //     S3(t)   16 MFMA steps; after consuming K~ quad `st` the same register is re-loaded for tile t+1
-// so every load has a full matrix phase (~7.7 k cycles) to land.
+// so every load has a full matrix phase (~7.7 k cycles) to land.  Compact dense reference (zmode 2): `dlz` holds the six
+// planes dlogz_n/dT_wc; the reference-pose block is rebuilt from P_w and the reference pose (ref_pose_geom).
 template <typename T, int WPS, int ABL = 0>   // ABL (ablation, timing only): 1 = no MFMA, 2 = no S2 arithmetic, 3 = no loads in S1
 __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
-    const T* __restrict__ Pwn, const T* __restrict__ vals, const T* __restrict__ dPwn_dTwc, const T* __restrict__ Kt,
-    const T* __restrict__ uvec, const int* __restrict__ pixidx, const T* __restrict__ invz, long kt_slot_stride,
-    BAPairs pr, const T* __restrict__ pair_T, const T* __restrict__ pair_aff, const T* __restrict__ img_base,
+    const T* __restrict__ Pwn, const T* __restrict__ vals, const T* __restrict__ dlz, const T* __restrict__ Kt,
+    const int* __restrict__ pixidx, const T* __restrict__ invz, long kt_slot_stride,
+    BAPairs pr, const T* __restrict__ pair_T, const T* __restrict__ pair_aff, const T* __restrict__ pair_ref, const T* __restrict__ img_base,
     const T* __restrict__ Kmat, int H, int W, int n, int m, int pix_begin, int pix_end, int chunk_len,
     const uint32_t* __restrict__ hists, T* __restrict__ partials, T* __restrict__ sigma_out, int stagger,
     const int* __restrict__ pair_map) {
@@ -482,9 +518,9 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
   const int q = lane >> 4, c = lane & 15;
   T* Jp = lds + wv * STG;
   T* Sv = Jp + 16 * JP_STRIDE;              // [0] r~, [1] s (dI/dPw . u)
-  T Mr[12];
+  T Mr[12], Rf[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) Mr[k] = pair_T[12 * (long)p + k];
+  for (int k = 0; k < 12; ++k) { Mr[k] = pair_T[12 * (long)p + k]; Rf[k] = pair_ref[12 * (long)p + k]; }
   const T scale = pair_aff[2 * p], bias = pair_aff[2 * p + 1];
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
   const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
@@ -513,7 +549,7 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
 
   // ---- pipeline registers ----
   T pw0, pw1, pw2;                     // S0: P_w of the tile that S1 will warp next
-  T tv[12], Dv[18], Uv[3], valv;       // S1: loaded values of the tile S2 will consume
+  T tv[12], Dv[6], pq0 = 0, pq1 = 0, pq2 = 0, valv;   // S1: loaded values (+ the warped tile's P_w) of the tile S2 will consume
   T wX = 0, wY = 0, wZ = 0, w00 = 0, w01 = 0, w10 = 0, w11 = 0;
   bool wok = false;
   int row_cur = 0, row_nxt = 0;
@@ -529,17 +565,16 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
     Warp<T> w = warp_point(Mr, fx, fy, cx, cy, pw0, pw1, pw2, H, W);
     Taps<T> tp = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
     wX = w.X; wY = w.Y; wZ = w.Z; wok = inr && w.ok;
+    pq0 = pw0; pq1 = pw1; pq2 = pw2;
     w00 = tp.w00; w01 = tp.w01; w10 = tp.w10; w11 = tp.w11;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
       const T* P = img + pl * HW;
       tv[4 * pl + 0] = P[tp.i00]; tv[4 * pl + 1] = P[tp.i01]; tv[4 * pl + 2] = P[tp.i10]; tv[4 * pl + 3] = P[tp.i11];
     }
-    const T* D = dPwn_dTwc + (long)slot * 18 * n + ic;
+    const T* D = dlz + (long)slot * 6 * n + ic;
 #pragma unroll
-    for (int k = 0; k < 18; ++k) Dv[k] = D[(long)k * n];
-    const T* U = uvec + (long)slot * 3 * n + ic;
-    Uv[0] = U[0]; Uv[1] = U[n]; Uv[2] = U[2 * (long)n];
+    for (int k = 0; k < 6; ++k) Dv[k] = D[(long)k * n];
     valv = vals[((long)slot * n + ic) * pr.C + ch];
     row_nxt = pixidx ? pixidx[(long)slot * n + ic] : ic;
   };
@@ -548,8 +583,8 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
 #pragma unroll
       for (int k2 = 0; k2 < 12; ++k2) asm volatile("" ::"v"(tv[k2]));
 #pragma unroll
-      for (int k2 = 0; k2 < 18; ++k2) asm volatile("" ::"v"(Dv[k2]));
-      asm volatile("" ::"v"(Uv[0]), "v"(Uv[1]), "v"(Uv[2]), "v"(valv));
+      for (int k2 = 0; k2 < 6; ++k2) asm volatile("" ::"v"(Dv[k2]));
+      asm volatile("" ::"v"(valv));
 #pragma unroll
       for (int k2 = 0; k2 < 16; ++k2) Jp[k2 * JP_STRIDE + lane] = T(0.001) * T(k2 + lane);
       Sv[lane] = T(0.01); Sv[64 + lane] = T(0.02);
@@ -572,8 +607,10 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
     const T b0 = a0 * Mr[0] + a1 * Mr[4] + a2 * Mr[8];
     const T b1 = a0 * Mr[1] + a1 * Mr[5] + a2 * Mr[9];
     const T b2 = a0 * Mr[2] + a1 * Mr[6] + a2 * Mr[10];
+    T jr[6];
+    const T bu = ref_pose_geom(Rf, pq0, pq1, pq2, b0, b1, b2, jr);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) Jp[k * JP_STRIDE + lane] = s * (b0 * Dv[k] + b1 * Dv[6 + k] + b2 * Dv[12 + k]);
+    for (int k = 0; k < 6; ++k) Jp[k * JP_STRIDE + lane] = s * (jr[k] + bu * Dv[k]);
     Jp[6 * JP_STRIDE + lane] = s * Iref_s;
     Jp[7 * JP_STRIDE + lane] = -s;
     const T Xc = ok ? wX : T(0), Yc = ok ? wY : T(0), Zc = ok ? wZ : T(0);
@@ -586,7 +623,7 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
     Jp[14 * JP_STRIDE + lane] = -s * Iref_s;
     Jp[15 * JP_STRIDE + lane] = s;
     Sv[lane] = s * r;
-    Sv[64 + lane] = s * (b0 * Uv[0] + b1 * Uv[1] + b2 * Uv[2]);
+    Sv[64 + lane] = s * bu;
   };
 
   // Phase stagger: the two waves that share a SIMD (one from each co-resident workgroup) would otherwise run in
@@ -692,16 +729,16 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pipe_kernel(
 // Consecutive-keyframe graphs give every inner keyframe TWO pairs with the same reference (i -> i+1, i -> i-1).  Both
 // rows of a reference pixel carry the SAME K~ row, scaled by their own s_g: the depth x depth block of the normal
 // equations only needs  sum_g s_g^2 K~ K~^T  -- one weighted Gram instead of two.  One workgroup walks the reference
-// pixels ONCE for both pairs: P_w, dPwn_dTwc, uvec, vals and the K~ ring are loaded once (45 % fewer HBM bytes), the
+// pixels ONCE for both pairs: P_w, dlogz_n/dT_wc (compact dense reference, zmode 2), vals and the K~ ring are loaded once, the
 // matrix work per pixel is 10 (zz, weight sqrt(s_0^2 + s_1^2)) + 2 x 5 (pose x pose, pose x depth with the pose row
 // rescaled by s_g / sqrt(s_0^2 + s_1^2)) = 20 tile-steps instead of 30.  Records: pair 0 carries the zz tiles and the
 // depth gradient, pair 1's are zero -- the assembly kernel is unchanged.  float32 only.
 template <int WPS, int PF>
 __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
-    const float* __restrict__ Pwn, const float* __restrict__ vals, const float* __restrict__ dPwn_dTwc,
-    const float* __restrict__ Kt, const float* __restrict__ uvec, const int* __restrict__ pixidx,
+    const float* __restrict__ Pwn, const float* __restrict__ vals, const float* __restrict__ dlz,
+    const float* __restrict__ Kt, const int* __restrict__ pixidx,
     const float* __restrict__ invz, long kt_slot_stride, BAPairs pr, const float* __restrict__ pair_T,
-    const float* __restrict__ pair_aff, const float* __restrict__ img_base, const float* __restrict__ Kmat, int H, int W, int n,
+    const float* __restrict__ pair_aff, const float* __restrict__ pair_ref, const float* __restrict__ img_base, const float* __restrict__ Kmat, int H, int W, int n,
     int m, int pix_begin, int pix_end, int chunk_len, const uint32_t* __restrict__ hists, float* __restrict__ partials,
     float* __restrict__ sigma_out, const int* __restrict__ grp_pairs) {
   using T = float;
@@ -743,6 +780,9 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
     bias[g] = pair_aff[2 * pg[g] + 1];
     img[g] = img_base + pr.tgt_img[pg[g]] + (long)pair_chan(pr, pg[g]) * H * W;
   }
+  T Rf[12];                                         // [R | t] of the shared reference keyframe
+#pragma unroll
+  for (int k = 0; k < 12; ++k) Rf[k] = pair_ref[12 * (long)pg[0] + k];
   const int ch = pair_chan(pr, pg[0]);              // both pairs of a group share reference slot AND channel (one I_ref load)
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
   const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
@@ -767,9 +807,9 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
   const int end = min(pix_end, begin + chunk_len);
   V4<T> kq[PF];
 
-  // ---- pipeline registers (shared: P_w, Dv, Uv, valv, rows; per pair: warp state + taps) ----
-  T pw0, pw1, pw2;
-  T Dv[18], Uv[3], valv;
+  // ---- pipeline registers (shared: P_w, Dv, valv, rows; per pair: warp state + taps) ----
+  T pw0, pw1, pw2, pq0 = 0.f, pq1 = 0.f, pq2 = 0.f;
+  T Dv[6], valv;
   T tv[G][12];
   T wX[G], wY[G], wZ[G], w00[G], w01[G], w10[G], w11[G];
   bool wok[G];
@@ -795,11 +835,10 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
         tv[g][4 * pl + 0] = P[tp.i00]; tv[g][4 * pl + 1] = P[tp.i01]; tv[g][4 * pl + 2] = P[tp.i10]; tv[g][4 * pl + 3] = P[tp.i11];
       }
     }
-    const T* D = dPwn_dTwc + (long)slot * 18 * n + ic;
+    pq0 = pw0; pq1 = pw1; pq2 = pw2;
+    const T* D = dlz + (long)slot * 6 * n + ic;
 #pragma unroll
-    for (int k = 0; k < 18; ++k) Dv[k] = D[(long)k * n];
-    const T* U = uvec + (long)slot * 3 * n + ic;
-    Uv[0] = U[0]; Uv[1] = U[n]; Uv[2] = U[2 * (long)n];
+    for (int k = 0; k < 6; ++k) Dv[k] = D[(long)k * n];
     valv = vals[((long)slot * n + ic) * pr.C + ch];
     row_nxt = pixidx ? pixidx[(long)slot * n + ic] : ic;
   };
@@ -828,8 +867,10 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
       const T b1 = a0 * Mr[g][1] + a1 * Mr[g][5] + a2 * Mr[g][9];
       const T b2 = a0 * Mr[g][2] + a1 * Mr[g][6] + a2 * Mr[g][10];
       T* J = Jp[g];
+      T jr[6];
+      const T bu = ref_pose_geom(Rf, pq0, pq1, pq2, b0, b1, b2, jr);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) J[k * JP_STRIDE + lane] = s * (b0 * Dv[k] + b1 * Dv[6 + k] + b2 * Dv[12 + k]);
+      for (int k = 0; k < 6; ++k) J[k * JP_STRIDE + lane] = s * (jr[k] + bu * Dv[k]);
       J[6 * JP_STRIDE + lane] = s * Iref_s;
       J[7 * JP_STRIDE + lane] = -s;
       const T Xc = ok ? wX[g] : T(0), Yc = ok ? wY[g] : T(0), Zc = ok ? wZ[g] : T(0);
@@ -842,7 +883,7 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
       J[14 * JP_STRIDE + lane] = -s * Iref_s;
       J[15 * JP_STRIDE + lane] = s;
       rsv[g] = s * r;
-      szv[g] = s * (b0 * Uv[0] + b1 * Uv[1] + b2 * Uv[2]);
+      szv[g] = s * bu;
       Sv[g][lane] = rsv[g];
     }
     // per-PIXEL factors of the joint depth row, once per tile (lane = pixel) instead of in every step of every column lane
@@ -913,7 +954,7 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
     row_cur = row_nxt;
   }
 
-  // the 1 / z_m factors of the depth columns (dPwn_dzm = uvec K~ / z_m), once per accumulator: column of depth block t at
+  // the 1 / z_m factors of the depth columns (dPwn_dzm = u K~ / z_m), once per accumulator: column of depth block t at
   // lane-column ci is kcol(t, ci); the f32 MFMA row of (lane, reg) is 4 (lane >> 4) + reg
   static_for<10>([&](auto it) {
     constexpr int tt = decltype(it)::value + 5;
@@ -994,34 +1035,42 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
 
 // ---------------------------------------- pass 2, float64: two pairs, role-specialised wave pair -------------------------
 // The reference's mapping dtype is double (config/como.yml:28).  In double the 20 accumulator tiles of the two-pair kernel
-// are 160 registers and its pipeline state another ~130: more than one wave can hold without spilling.  Here a workgroup
+// are 160 registers and its pipeline state another ~100: more than one wave can hold without spilling.  Here a workgroup
 // is TWO waves that walk the same 64-pixel tiles of one reference keyframe and split the work by ROLE:
 //   wave 0: warp / taps / Jacobian row of pair 0 (stages S1, S2)  +  the 10 depth x depth tiles (weight sqrt(s0^2 + s1^2))
 //   wave 1: warp / taps / Jacobian row of pair 1                  +  the 2 pose x pose and 8 pose x depth tiles
-// = 10 v_mfma_f64_16x16x4_f64 per 4-pixel step and 80 accumulator registers per wave.  The staged rows go through LDS in
-// two buffers (one workgroup barrier per tile); P_w / dPwn_dTwc / uvec and the K~ quads are loaded by both waves (the
-// second read of a line is an L1 / L2 hit -- HBM sees each byte once, 784 B per pixel-pair is shared as in float32).
+// = 10 v_mfma_f64_16x16x4_f64 per 4-pixel step and 80 accumulator registers per wave.  The staged rows go through ONE LDS
+// buffer (two workgroup barriers per tile: 23 KB per workgroup, so four workgroups fit a CU); P_w / dlogz_n/dT_wc and the
+// K~ quads are loaded by both waves (the second read of a line is an L1 / L2 hit -- HBM sees each byte once).
 // Every accumulator element is owned by exactly one wave, so there is no cross-wave reduction: each wave writes its part
 // of the two per-pair records.
-// PIPE = true : one wave per SIMD (512-register budget), the four-stage software pipeline hides the load latencies.
-// PIPE = false: two waves per SIMD (<= 256 registers: nothing of the NEXT tile is held across the matrix phase), load ->
-//               warp -> rows -> matrix phase per tile, the co-resident wave fills the gaps (MFMA and VALU time of one wave
-//               add up on a SIMD; with a single wave the matrix pipe idles 61 % of the time).
-template <int PF, bool PIPE>
-__global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
-    const double* __restrict__ Pwn, const double* __restrict__ vals, const double* __restrict__ dPwn_dTwc,
-    const double* __restrict__ Kt, const double* __restrict__ uvec, const int* __restrict__ pixidx,
-    const double* __restrict__ invz, long kt_slot_stride, BAPairs pr, const double* __restrict__ pair_T,
-    const double* __restrict__ pair_aff, const double* __restrict__ img_base, const double* __restrict__ Kmat, int H, int W,
-    int n, int m, int pix_begin, int pix_end, int chunk_len, const uint32_t* __restrict__ hists,
-    double* __restrict__ partials, double* __restrict__ sigma_out, const int* __restrict__ grp_pairs) {
+// Compact dense reference (zmode 2): the reference-pose block is rebuilt from P_w, the reference pose and the six planes
+// dlogz_n/dT_wc (ref_pose_geom) -- 10 planes per pixel instead of 25, which is what lets the software pipeline (the NEXT
+// tile's taps / planes in registers across the matrix phase) fit the 256-register budget of TWO waves per SIMD.
+// PIPE = true : four-stage software pipeline, no load latency between two matrix phases of a wave.
+// PIPE = false: load -> warp -> rows -> matrix phase per tile, the co-resident wave fills the gaps.
+// K~ rows are addressed by 32-bit byte offsets from the (uniform) slot base: the host checks kt_slot_stride * 8 < 4 GiB.
+__device__ __forceinline__ V4<double> load4_off(const char* __restrict__ base, uint32_t off) {
+  const double2 a = *reinterpret_cast<const double2*>(base + off);
+  const double2 b = *reinterpret_cast<const double2*>(base + off + 16);
+  return V4<double>{a.x, a.y, b.x, b.y};
+}
+
+template <int PF, bool PIPE, int WPS>
+__global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
+    const double* __restrict__ Pwn, const double* __restrict__ vals, const double* __restrict__ dlz,
+    const double* __restrict__ Kt, const int* __restrict__ pixidx, const double* __restrict__ invz, long kt_slot_stride,
+    BAPairs pr, const double* __restrict__ pair_T, const double* __restrict__ pair_aff, const double* __restrict__ pair_ref,
+    const double* __restrict__ img_base, const double* __restrict__ Kmat, int H, int W, int n, int m, int pix_begin,
+    int pix_end, int chunk_len, const uint32_t* __restrict__ hists, double* __restrict__ partials,
+    double* __restrict__ sigma_out, const int* __restrict__ grp_pairs) {
   using T = double;
   using KeyT = typename KeyOf<T>::type;
   using Cfg = BACfg;
   using acc_t = typename Acc4<T>::type;
   __shared__ SelScratch sc;
   constexpr int STG1 = 16 * JP_STRIDE + 64 * 2;       // one pair's staged tile: 16 pose/affine rows + r~ + depth scale
-  __shared__ T lds[(PIPE ? 2 : 1) * 2 * STG1];         // [buffer][pair]: 37.9 KB pipelined (two buffers), 18.9 KB otherwise
+  __shared__ T lds[2 * STG1];                          // [pair]
   __shared__ T pxs[2][4 * 64];                         // per wave, per pixel of the tile: {sqrt(s0^2+s1^2), g-weight | s0/., s1/.}
 
   // robust scale from the finished histograms; sel_resolve is written for 256-thread blocks: feed it 128 threads x 2 rounds
@@ -1039,19 +1088,23 @@ __global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
   const int pgm = (role == 0 || !has1) ? pg0 : pg1;                       // the pair whose rows this wave produces
   const bool live = role == 0 || has1;
   const int slot = pr.ref_slot[pg0];
-  T Mr[12];
+  T Mr[12], Rf[12];
 #pragma unroll
-  for (int k = 0; k < 12; ++k) Mr[k] = pair_T[12 * (long)pgm + k];
+  for (int k = 0; k < 12; ++k) { Mr[k] = pair_T[12 * (long)pgm + k]; Rf[k] = pair_ref[12 * (long)pg0 + k]; }
   const T scale = pair_aff[2 * pgm], bias = pair_aff[2 * pgm + 1];
   const int ch = pair_chan(pr, pg0);                // both pairs of a group share reference slot AND channel
   const T* img = img_base + pr.tgt_img[pgm] + (long)pair_chan(pr, pgm) * H * W;
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
   const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
   const long HW = (long)pr.C * H * W;
-  T invz4[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
-  const T* KtS = Kt + (long)slot * kt_slot_stride + ((4 * c < m) ? 4 * c : 0);
+  // lanes whose quad lies beyond m read quad 0 instead (finite values); their columns are nulled by invz = 0 in the epilogue
+  const char* KtB = reinterpret_cast<const char*>(Kt + (long)slot * kt_slot_stride);
+  const uint32_t cbyte = (uint32_t)(((4 * c < m) ? 4 * c : 0) * sizeof(T));
+  const uint32_t row_bytes = (uint32_t)(m * sizeof(T));
+  const T* PwS = Pwn + (long)slot * 3 * n;
+  const T* DlS = dlz + (long)slot * 6 * n;
+  const T* VaS = vals + (long)slot * n * pr.C + ch;
+  const int* PiS = pixidx ? pixidx + (long)slot * n : nullptr;
 
   acc_t acc[10];      // role 0: the 10 depth x depth tiles; role 1: {TT_0, TT_1, Tz_0[4], Tz_1[4]}
 #pragma unroll
@@ -1062,15 +1115,15 @@ __global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
   const int begin = pix_begin + blockIdx.x * chunk_len;
   const int end = min(pix_end, begin + chunk_len);
   V4<T> kq[PF];
-  T pw0, pw1, pw2;
-  T Dv[18], Uv[3], valv, tv[12];
+  T pw0, pw1, pw2, pq0 = 0, pq1 = 0, pq2 = 0;
+  T Dv[6], valv, tv[12];
   T wX = 0, wY = 0, wZ = 0, w00 = 0, w01 = 0, w10 = 0, w11 = 0;
   bool wok = false;
-  int row_cur = 0, row_nxt = 0;
+  uint32_t roff_cur = 0, roff_nxt = 0;   // byte offset of this lane's pixel's K~ row inside the slot
 
   auto s0_load = [&](int tile) {
     const int ic = min(tile + lane, end - 1);
-    pw0 = Pwn[((long)slot * 3 + 0) * n + ic]; pw1 = Pwn[((long)slot * 3 + 1) * n + ic]; pw2 = Pwn[((long)slot * 3 + 2) * n + ic];
+    pw0 = PwS[ic]; pw1 = PwS[(long)n + ic]; pw2 = PwS[2 * (long)n + ic];
   };
   auto s1_issue = [&](int tile) {
     const int i = tile + lane;
@@ -1079,19 +1132,23 @@ __global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
     Warp<T> w = warp_point(Mr, fx, fy, cx, cy, pw0, pw1, pw2, H, W);
     Taps<T> tp = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
     wX = w.X; wY = w.Y; wZ = w.Z; wok = inr && w.ok && live;
+    pq0 = pw0; pq1 = pw1; pq2 = pw2;
     w00 = tp.w00; w01 = tp.w01; w10 = tp.w10; w11 = tp.w11;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
       const T* P = img + pl * HW;
       tv[4 * pl + 0] = P[tp.i00]; tv[4 * pl + 1] = P[tp.i01]; tv[4 * pl + 2] = P[tp.i10]; tv[4 * pl + 3] = P[tp.i11];
     }
-    const T* D = dPwn_dTwc + (long)slot * 18 * n + ic;
 #pragma unroll
-    for (int k = 0; k < 18; ++k) Dv[k] = D[(long)k * n];
-    const T* U = uvec + (long)slot * 3 * n + ic;
-    Uv[0] = U[0]; Uv[1] = U[n]; Uv[2] = U[2 * (long)n];
-    valv = vals[((long)slot * n + ic) * pr.C + ch];
-    row_nxt = pixidx ? pixidx[(long)slot * n + ic] : ic;
+    for (int k = 0; k < 6; ++k) Dv[k] = DlS[(long)k * n + ic];
+    valv = VaS[(long)ic * pr.C];
+    roff_nxt = (uint32_t)(PiS ? PiS[ic] : ic) * row_bytes;
+  };
+  auto kq_prefetch = [&]() {
+    static_for<PF>([&](auto ic_) {
+      constexpr int st = decltype(ic_)::value;
+      kq[st] = load4_off(KtB, (uint32_t)__shfl((int)roff_cur, 4 * st + q, 64) + cbyte);
+    });
   };
   auto s2_rows = [&](T* J, T* S) {     // this wave's pair: 16 rows + r~ + depth scale of the tile loaded one stage ago
     const T It = w00 * tv[0] + w01 * tv[1] + w10 * tv[2] + w11 * tv[3];
@@ -1112,8 +1169,11 @@ __global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
     const T b0 = a0 * Mr[0] + a1 * Mr[4] + a2 * Mr[8];
     const T b1 = a0 * Mr[1] + a1 * Mr[5] + a2 * Mr[9];
     const T b2 = a0 * Mr[2] + a1 * Mr[6] + a2 * Mr[10];
+    T jr[6];
+    const T bu = ref_pose_geom(Rf, pq0, pq1, pq2, b0, b1, b2, jr);
+    const T sbu = s * bu;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) J[k * JP_STRIDE + lane] = s * (b0 * Dv[k] + b1 * Dv[6 + k] + b2 * Dv[12 + k]);
+    for (int k = 0; k < 6; ++k) J[k * JP_STRIDE + lane] = s * jr[k] + sbu * Dv[k];
     J[6 * JP_STRIDE + lane] = s * Iref_s;
     J[7 * JP_STRIDE + lane] = -s;
     const T Xc = ok ? wX : T(0), Yc = ok ? wY : T(0), Zc = ok ? wZ : T(0);
@@ -1126,51 +1186,42 @@ __global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
     J[14 * JP_STRIDE + lane] = -s * Iref_s;
     J[15 * JP_STRIDE + lane] = s;
     S[lane] = s * r;
-    S[64 + lane] = s * (b0 * Uv[0] + b1 * Uv[1] + b2 * Uv[2]);
+    S[64 + lane] = sbu;
   };
 
   if (PIPE && begin < end) {
     s0_load(begin);
     s1_issue(begin);
-    row_cur = row_nxt;
-    static_for<PF>([&](auto ic_) {
-      constexpr int st = decltype(ic_)::value;
-      const int row = __shfl(row_cur, 4 * st + q, 64);
-      kq[st] = load4(KtS + (long)row * m);
-    });
+    roff_cur = roff_nxt;
+    kq_prefetch();
     s0_load(begin + 64);
   }
-  int buf = 0;
+  T* const Jmine = lds + role * STG1;
+  const T* const J0 = lds;
+  const T* const J1 = lds + STG1;
+  const T* const S0 = J0 + 16 * JP_STRIDE;
+  const T* const S1 = J1 + 16 * JP_STRIDE;
+  T* const my = pxs[role];
   for (int tile = begin; tile < end; tile += 64) {
-    T* stage = lds + (PIPE ? buf : 0) * (2 * STG1);
     if constexpr (!PIPE) {
       s0_load(tile);
       s1_issue(tile);
-      row_cur = row_nxt;
-      static_for<PF>([&](auto ic_) {
-        constexpr int st = decltype(ic_)::value;
-        const int row = __shfl(row_cur, 4 * st + q, 64);
-        kq[st] = load4(KtS + (long)row * m);
-      });
-      __syncthreads();                             // the other wave is done reading the previous tile's rows
+      roff_cur = roff_nxt;
+      kq_prefetch();
     }
-    s2_rows(stage + role * STG1, stage + role * STG1 + 16 * JP_STRIDE);
-    __syncthreads();                               // both pairs' rows of this tile are staged (the other buffer is free again)
+    __syncthreads();                               // the other wave is done reading the previous tile's rows
+    s2_rows(Jmine, Jmine + 16 * JP_STRIDE);
+    __syncthreads();                               // both pairs' rows of this tile are staged
     if constexpr (PIPE) {
-      s1_issue(tile + 64);
+      s1_issue(tile + 64);                         // (clamped past the end: harmless re-reads, masked by `inr`)
       s0_load(tile + 128);
     }
-    const T* J0 = stage;
-    const T* J1 = stage + STG1;
-    const T* S0 = J0 + 16 * JP_STRIDE;
-    const T* S1 = J1 + 16 * JP_STRIDE;
     // per-PIXEL factors once per tile (lane = pixel) instead of once per (pixel, column lane) in every step: the two rows of a
     // reference pixel share the K~ row scaled by s_g; weight of the joint depth row = sqrt(s_0^2 + s_1^2)
     {
       const T rt0 = S0[lane], rt1 = S1[lane], sz0 = S0[64 + lane], sz1 = S1[64 + lane];
       const T cs = sz0 * sz0 + sz1 * sz1;
       const T rs = cs > T(0) ? fast_rsq(cs) : T(0);
-      T* my = pxs[role];
       my[lane] = cs * rs;                                        // sqrt(s_0^2 + s_1^2)
       if (role == 0) {
         my[64 + lane] = (sz0 * rt0 + sz1 * rt1) * rs;            // whitened residual of the joint depth row
@@ -1180,26 +1231,27 @@ __global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
       }
       wave_lds_sync();
     }
-    const T* my = pxs[role];
-    for (int half = 0; half < 16 / PF; ++half) {
-      static_for<PF>([&](auto ic_) {
-        constexpr int sl = decltype(ic_)::value;
-        const int st = half * PF + sl;
-        const int px = 4 * st + q;
-        const V4<T> k4 = kq[sl];
-        {
-          const int nst = st + PF;
-          const bool same = nst < 16;
-          if (PIPE || same) {
-            const int row = __shfl(same ? row_cur : row_nxt, 4 * (same ? nst : nst - 16) + q, 64);
-            kq[sl] = load4(KtS + (long)row * m);
-          }
-        }
-        const T sc2 = my[px];
-        // depth columns WITHOUT the 1 / z_m factor: it is constant over pixels and is applied to the accumulators once
-        const T zq[4] = {sc2 * k4.x, sc2 * k4.y, sc2 * k4.z, sc2 * k4.w};
-        if (role == 0) {
+    // ring refill of slot sl at step st: the quad of step st + PF of this tile, or (pipelined) of step st + PF - 16 of the next
+    auto refill = [&](int sl, int st) {
+      const int nst = st + PF;
+      const bool same = nst < 16;
+      if (PIPE || same) {
+        const uint32_t off = (uint32_t)__shfl((int)(same ? roff_cur : roff_nxt), 4 * (same ? nst : nst - 16) + q, 64);
+        kq[sl] = load4_off(KtB, off + cbyte);
+      }
+    };
+    if (role == 0) {
+      for (int half = 0; half < 16 / PF; ++half) {
+        static_for<PF>([&](auto ic_) {
+          constexpr int sl = decltype(ic_)::value;
+          const int st = half * PF + sl;
+          const int px = 4 * st + q;
+          const V4<T> k4 = kq[sl];
+          refill(sl, st);
+          const T sc2 = my[px];
           const T gzs = my[64 + px];
+          // depth columns WITHOUT the 1 / z_m factor: it is constant over pixels and is applied to the accumulators once
+          const T zq[4] = {sc2 * k4.x, sc2 * k4.y, sc2 * k4.z, sc2 * k4.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) gv[e] += zq[e] * gzs;
           static_for<10>([&](auto it) {
@@ -1207,7 +1259,18 @@ __global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
             constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
             acc[tt - 5] = mfma16(zq[ti - 1], zq[tj - 1], acc[tt - 5]);
           });
-        } else {
+        });
+      }
+    } else {
+      for (int half = 0; half < 16 / PF; ++half) {
+        static_for<PF>([&](auto ic_) {
+          constexpr int sl = decltype(ic_)::value;
+          const int st = half * PF + sl;
+          const int px = 4 * st + q;
+          const V4<T> k4 = kq[sl];
+          refill(sl, st);
+          const T sc2 = my[px];
+          const T zq[4] = {sc2 * k4.x, sc2 * k4.y, sc2 * k4.z, sc2 * k4.w};
           const T a00 = J0[c * JP_STRIDE + px], a01 = J1[c * JP_STRIDE + px];
           const T p0 = a00 * my[128 + px], p1 = a01 * my[192 + px];
           gv[0] += a00 * S0[px];
@@ -1219,16 +1282,18 @@ __global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
             acc[2 + e] = mfma16(p0, zq[e], acc[2 + e]);
             acc[6 + e] = mfma16(p1, zq[e], acc[6 + e]);
           }
-        }
-      });
+        });
+      }
     }
-    if constexpr (PIPE) row_cur = row_nxt;
-    buf ^= 1;
+    if constexpr (PIPE) roff_cur = roff_nxt;
   }
 
   // ---- epilogue: every element has one owner; record layout of ba_blocks_kernel (15 tiles | 5 x 16 gradient | err) ----
   err = wave_sum(err);
-  // the 1 / z_m factors of the depth columns (dPwn_dzm = uvec K~ / z_m, sparse_map.py:184-230), once per accumulator:
+  T invz4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
+  // the 1 / z_m factors of the depth columns (dPwn_dzm = u K~ / z_m, sparse_map.py:184-230), once per accumulator:
   // column k of depth block t at lane-column ci is kcol(t, ci) = 4 ci + t - 1; the f64 MFMA row of (lane, reg) is (lane >> 4) + 4 reg
   if (role == 0) {
     static_for<10>([&](auto it) {
@@ -1286,6 +1351,372 @@ __global__ __launch_bounds__(128, PIPE ? 1 : 2) void ba_blocks_pair2_f64_kernel(
       for (int e = 0; e < 4; ++e) put_tile(rec1, 1 + e, acc[6 + e]);
       if (lane < 16) rec1[Cfg::NT * 256 + lane] = gv[1];
       if (lane == 0) rec1[Cfg::NT * 256 + Cfg::NB * 16] = err;
+    }
+  }
+}
+
+// ---------------------------------------- pass 2, float64: WAVE-SPECIALISED two-pair kernel ----------------------------
+// The role-split kernel above makes every wave both a producer (warp, taps, Jacobian rows: ~25 dependent global loads per
+// pixel) and a consumer (160 v_mfma_f64 per tile): the matrix pipe waits whenever a tile's loads are late, and hiding them
+// with a software pipeline costs more registers than two waves per SIMD have (147 spilled VGPRs at 256).  Here the two jobs
+// are different WAVES of a 192-thread workgroup that meet once per 64-pixel tile at an LDS-only barrier:
+//   producer  (no accumulators): both pairs' warp / taps / rows of tile t+1 -> LDS buffer (t+1) & 1 while the consumers
+//             multiply tile t; it runs one tile ahead, its load latencies are nobody's critical path;
+//   consumer Z: the 10 depth x depth tiles  (A = B = sqrt(s0^2 + s1^2) K~ quad), depth gradient;
+//   consumer T: the 2 pose x pose + 8 pose x depth tiles (A = pose row x depth scale, B = the raw K~ quad), pose gradients.
+// A consumer's only global loads are its K~ quads (a register ring PF steps deep, addressed by pixel index alone, so they
+// run ahead across tile boundaries) -- between two barriers it issues 160 MFMAs and ~8 other instructions per step.
+// Three waves per SIMD (<= 168 registers each): four workgroups per CU, 39.9 KB of LDS each (two stage buffers).  Roles
+// rotate with the workgroup index so that every SIMD hosts a mix of producers and consumers whatever the dispatcher's
+// wave -> SIMD assignment is.  Records as in the role-split kernel: every element has exactly one owner.
+// 12 consecutive doubles at a wave-uniform address through the scalar cache, into SGPRs, NOT hoisted out of loops (volatile):
+// the producer's pose constants are re-read where they are used instead of occupying 72 SGPRs across its whole loop.
+typedef int sgpr8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void sload12(const double* __restrict__ p, double* __restrict__ out) {
+  sgpr8_t a, b, c;
+  asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x20\n\ts_load_dwordx8 %2, %3, 0x40\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(a), "=&s"(b), "=&s"(c)
+               : "s"(p)
+               : "memory");
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    out[k] = __hiloint2double(a[2 * k + 1], a[2 * k]);
+    out[4 + k] = __hiloint2double(b[2 * k + 1], b[2 * k]);
+    out[8 + k] = __hiloint2double(c[2 * k + 1], c[2 * k]);
+  }
+}
+
+__device__ __forceinline__ void lds_barrier() {      // this wave's LDS traffic is complete; global loads stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <int PFZ, int PFT, int WPS>   // depth of the K~ register ring of consumer Z / T (steps of 4 pixels; divides 16), waves / SIMD
+__global__ __launch_bounds__(192, WPS) void ba_blocks_ws_f64_kernel(
+    const double* __restrict__ Pwn, const double* __restrict__ vals, const double* __restrict__ dlz,
+    const double* __restrict__ Kt, const int* __restrict__ pixidx, const double* __restrict__ invz, long kt_slot_stride,
+    BAPairs pr, const double* __restrict__ pair_T, const double* __restrict__ pair_aff, const double* __restrict__ pair_ref,
+    const double* __restrict__ img_base, const double* __restrict__ Kmat, int H, int W, int n, int m, int pix_begin,
+    int pix_end, int chunk_len, const uint32_t* __restrict__ hists, double* __restrict__ partials,
+    double* __restrict__ sigma_out, const int* __restrict__ grp_pairs) {
+  using T = double;
+  using KeyT = typename KeyOf<T>::type;
+  using Cfg = BACfg;
+  using acc_t = typename Acc4<T>::type;
+  constexpr int ROWS = 16 * JP_STRIDE;               // one pair's 16 pose / affine rows of a tile
+  constexpr int PXA = 2 * ROWS;                      // per pixel {sqrt(s0^2 + s1^2), joint whitened residual}
+  constexpr int PXB = PXA + 64 * 2;                  // per pixel {depth scale 0, depth scale 1, r~0, r~1}
+  constexpr int BUF = PXB + 64 * 4;                  // 2496 doubles
+  __shared__ T lds[2 * BUF];                         // two stage buffers: 39,936 B (four workgroups per CU)
+  static_assert(sizeof(SelScratch) <= sizeof(T) * BUF, "resolve scratch aliases the first stage buffer");
+
+  KeyT prefix; uint32_t k_rem, nv;
+  sel_resolve_part<KeyT, 128, 3>(hists, SelCfg<KeyT>::NPASS, reinterpret_cast<SelScratch*>(lds), prefix, k_rem, nv);
+  const T sigma = T(1.4826) * key_value(prefix);
+  const T info_sqrt = T(1) / sigma;
+  if (sigma_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { sigma_out[0] = sigma; sigma_out[1] = (T)nv; }
+
+  const int pg0 = grp_pairs[2 * blockIdx.y], pg1r = grp_pairs[2 * blockIdx.y + 1];
+  const bool has1 = pg1r >= 0;
+  const int pg1 = has1 ? pg1r : pg0;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef COMO_WS_FORCE_ROLE                                                  // (register-budget analysis builds only)
+  const int role = COMO_WS_FORCE_ROLE;
+#else
+  const int role = (wv + (int)blockIdx.x + (int)blockIdx.y) % 3;         // wave-uniform: 0 producer, 1 consumer Z, 2 consumer T
+#endif
+  const int q = lane >> 4, c = lane & 15;
+  const int slot = pr.ref_slot[pg0];
+  const int begin = pix_begin + blockIdx.x * chunk_len;
+  const int end = min(pix_end, begin + chunk_len);
+  T* rec0 = partials + (long)(pg0 * gridDim.x + blockIdx.x) * Cfg::REC;
+  T* rec1 = has1 ? partials + (long)(pg1 * gridDim.x + blockIdx.x) * Cfg::REC : nullptr;
+  const int* PiS = pixidx ? pixidx + (long)slot * n : nullptr;
+  const uint32_t row_bytes = (uint32_t)(m * sizeof(T));
+
+  if (role == 0) {
+    // =========================================== producer ===========================================
+    // The pose constants of BOTH pairs ([R | t] of two targets and of the reference: 36 doubles = 72 SGPRs) do not fit the
+    // scalar register file next to everything else; kept live across the loop the compiler parks them in VGPRs and spills.
+    // They are (re)read through the scalar cache where they are used instead (sload12).
+    constexpr int G = 2;
+    const int pg[G] = {pg0, pg1};
+    T scale[G], bias[G];
+    const T* img[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      scale[g] = pair_aff[2 * pg[g]];
+      bias[g] = pair_aff[2 * pg[g] + 1];
+      img[g] = img_base + pr.tgt_img[pg[g]] + (long)pair_chan(pr, pg[g]) * H * W;
+    }
+    const int ch = pair_chan(pr, pg0);              // both pairs of a group share reference slot AND channel
+    const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+    const T ax = pr.anorm_f32 ? (T)(1.0f / (float)W) : T(1) / T(W), ay = pr.anorm_f32 ? (T)(1.0f / (float)H) : T(1) / T(H);
+    const long HW = (long)pr.C * H * W;
+    const T* PwS = Pwn + (long)slot * 3 * n;
+    const T* DlS = dlz + (long)slot * 6 * n;
+    const T* VaS = vals + (long)slot * n * pr.C + ch;
+    T err[G] = {T(0), T(0)};
+    T pw0, pw1, pw2;
+    {
+      const int ic = min(begin + lane, end - 1);
+      pw0 = PwS[ic]; pw1 = PwS[(long)n + ic]; pw2 = PwS[2 * (long)n + ic];
+    }
+    int buf = 0;
+    for (int tile = begin; tile < end; tile += 64, buf ^= 1) {
+      const int i = tile + lane;
+      const bool inr = i < end;
+      const int ic = inr ? i : (end - 1);
+      // ---- S1: warp the tile's points into both targets, issue every load of the tile
+      const T Px = pw0, Py = pw1, Pz = pw2;
+      T tv[G][12], wX[G], wY[G], wZ[G], w00[G], w01[G], w10[G], w11[G];
+      bool wok[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        T M[12];
+        sload12(pair_T + 12 * (long)pg[g], M);
+        Warp<T> w = warp_point(M, fx, fy, cx, cy, Px, Py, Pz, H, W);
+        Taps<T> tp = make_taps(grid_position(w.u, W, ax), grid_position(w.v, H, ay), H, W);
+        wX[g] = w.X; wY[g] = w.Y; wZ[g] = w.Z; wok[g] = inr && w.ok && (g == 0 || has1);
+        w00[g] = tp.w00; w01[g] = tp.w01; w10[g] = tp.w10; w11[g] = tp.w11;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const T* P = img[g] + pl * HW;
+          tv[g][4 * pl + 0] = P[tp.i00]; tv[g][4 * pl + 1] = P[tp.i01]; tv[g][4 * pl + 2] = P[tp.i10]; tv[g][4 * pl + 3] = P[tp.i11];
+        }
+      }
+      T Dv[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Dv[k] = DlS[(long)k * n + ic];
+      const T valv = VaS[(long)ic * pr.C];
+      {   // next tile's points (clamped past the end)
+        const int ic2 = min(tile + 64 + lane, end - 1);
+        pw0 = PwS[ic2]; pw1 = PwS[(long)n + ic2]; pw2 = PwS[2 * (long)n + ic2];
+      }
+      // ---- S2: rows of both pairs -> stage buffer
+      T* B = lds + buf * BUF;
+      T rsv[G], szv[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const T It = w00[g] * tv[g][0] + w01[g] * tv[g][1] + w10[g] * tv[g][2] + w11[g] * tv[g][3];
+        const T gx = w00[g] * tv[g][4] + w01[g] * tv[g][5] + w10[g] * tv[g][6] + w11[g] * tv[g][7];
+        const T gy = w00[g] * tv[g][8] + w01[g] * tv[g][9] + w10[g] * tv[g][10] + w11[g] * tv[g][11];
+        const T Iref_s = scale[g] * valv;
+        const T r = It - Iref_s + bias[g];
+        const bool ok = wok[g];
+        const T wr = r * info_sqrt;
+        const T awr = fabs(wr);
+        // sqrt of the Huber weight (robust_loss.py:9-16): 1 inside the band, sqrt(1.345 / |x|) outside
+        const T ws = (awr < T(1.345)) ? T(1) : T(1.1597413504743201) * fast_rsq(awr);
+        const T s = ok ? info_sqrt * ws : T(0);
+        err[g] += ok ? (ws * wr) * (ws * wr) : T(0);
+        const T iz = ok ? fast_rcp(wZ[g]) : T(0);
+        const T a0 = gx * fx * iz, a1 = gy * fy * iz;
+        const T a2 = -(a0 * wX[g] + a1 * wY[g]) * iz;
+        T b0, b1, b2;
+        {
+          T Mg[12];
+          sload12(pair_T + 12 * (long)pg[g], Mg);
+          b0 = a0 * Mg[0] + a1 * Mg[4] + a2 * Mg[8];
+          b1 = a0 * Mg[1] + a1 * Mg[5] + a2 * Mg[9];
+          b2 = a0 * Mg[2] + a1 * Mg[6] + a2 * Mg[10];
+        }
+        T jr[6], bu;
+        {
+          T Rf[12];
+          sload12(pair_ref + 12 * (long)pg0, Rf);
+          bu = ref_pose_geom(Rf, Px, Py, Pz, b0, b1, b2, jr);
+        }
+        const T sbu = s * bu;
+        T* J = B + g * ROWS;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) J[k * JP_STRIDE + lane] = s * jr[k] + sbu * Dv[k];
+        J[6 * JP_STRIDE + lane] = s * Iref_s;
+        J[7 * JP_STRIDE + lane] = -s;
+        const T Xc = ok ? wX[g] : T(0), Yc = ok ? wY[g] : T(0), Zc = ok ? wZ[g] : T(0);
+        J[8 * JP_STRIDE + lane] = s * (a1 * Zc - a2 * Yc);
+        J[9 * JP_STRIDE + lane] = s * (a2 * Xc - a0 * Zc);
+        J[10 * JP_STRIDE + lane] = s * (a0 * Yc - a1 * Xc);
+        J[11 * JP_STRIDE + lane] = -s * a0;
+        J[12 * JP_STRIDE + lane] = -s * a1;
+        J[13 * JP_STRIDE + lane] = -s * a2;
+        J[14 * JP_STRIDE + lane] = -s * Iref_s;
+        J[15 * JP_STRIDE + lane] = s;
+        rsv[g] = s * r;
+        szv[g] = sbu;
+      }
+      // per-PIXEL factors of the joint depth row (both rows of a reference pixel share the K~ row scaled by their own depth
+      // scale): weight sqrt(s0^2 + s1^2) and its whitened residual
+      const T cs = szv[0] * szv[0] + szv[1] * szv[1];
+      const T rs = cs > T(0) ? fast_rsq(cs) : T(0);
+      B[PXA + 2 * lane] = cs * rs;
+      B[PXA + 2 * lane + 1] = (szv[0] * rsv[0] + szv[1] * rsv[1]) * rs;
+      B[PXB + 4 * lane] = szv[0];
+      B[PXB + 4 * lane + 1] = szv[1];
+      B[PXB + 4 * lane + 2] = rsv[0];
+      B[PXB + 4 * lane + 3] = rsv[1];
+      lds_barrier();                               // tile staged; the consumers are done with the other buffer
+    }
+    err[0] = wave_sum(err[0]);
+    err[1] = wave_sum(err[1]);
+    if (lane == 0) {
+      rec0[Cfg::NT * 256 + Cfg::NB * 16] = err[0];
+      if (rec1) rec1[Cfg::NT * 256 + Cfg::NB * 16] = err[1];
+    }
+    return;
+  }
+
+  // ============================================== consumers ==============================================
+  // lanes whose quad lies beyond m read quad 0 instead (finite values); their columns are nulled by invz = 0 in the epilogue
+  const char* KtB = reinterpret_cast<const char*>(Kt + (long)slot * kt_slot_stride);
+  const uint32_t cbyte = (uint32_t)(((4 * c < m) ? 4 * c : 0) * sizeof(T));
+  acc_t acc[10];      // Z: the 10 depth x depth tiles; T: {TT_0, TT_1, Tz_0[4], Tz_1[4]}
+#pragma unroll
+  for (int t = 0; t < 10; ++t) acc[t] = acc_t{T(0), T(0), T(0), T(0)};
+  T gv[4] = {T(0), T(0), T(0), T(0)};    // Z: depth gradient of this lane's quad; T: gv[0], gv[1] = pose gradients
+  static_assert(16 % PFZ == 0 && 16 % PFT == 0, "the ring slot of a step must be the same in every tile");
+  constexpr int PFM = PFZ > PFT ? PFZ : PFT;
+  V4<T> kq[PFM];
+  // K~ row index of this lane's pixel of a tile, fetched TWO tiles ahead: by the time it is multiplied into a byte offset
+  // the load has long landed (its wait must not drain the K~ ring that was issued after it)
+  auto row_idx = [&](int tile) -> uint32_t {
+    const int ic = min(tile + lane, end - 1);
+    return (uint32_t)(PiS ? PiS[ic] : ic);
+  };
+  uint32_t roff_cur = row_idx(begin) * row_bytes, roff_nxt = 0;
+  uint32_t pix_n1 = row_idx(begin + 64), pix_n2 = 0;
+  static_for<PFM>([&](auto ic_) {
+    constexpr int st = decltype(ic_)::value;
+    if (st < (role == 1 ? PFZ : PFT))
+      kq[st] = load4_off(KtB, (uint32_t)__builtin_amdgcn_ds_bpermute(4 * q + 16 * st, (int)roff_cur) + cbyte);
+  });
+  // Every per-step address is ONE per-tile base register + a compile-time offset (the instruction's offset field): written
+  // out with explicit byte arithmetic -- indexed by the step, the compiler hoisted 16 steps x 3 loop-invariant address
+  // vectors out of the tile loop and spilled them (scratch reloads + vmcnt(0) drains of the K~ ring inside the loop).
+  const int qsel = q * 4;                                      // ds_bpermute byte address of lane q (+ 16 per step)
+  // refill ring slot sl after step st: the quad of step st + PF of this tile, or of step st + PF - 16 of the next one
+  auto refill = [&](auto pf_, auto sl_, auto st_) {
+    constexpr int sl = decltype(sl_)::value, nst = decltype(st_)::value + decltype(pf_)::value;
+    constexpr bool same = nst < 16;
+    const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(qsel + 16 * (same ? nst : nst - 16), (int)(same ? roff_cur : roff_nxt));
+    kq[sl] = load4_off(KtB, off + cbyte);
+  };
+  int buf = 0;
+  if (role == 1) {
+    for (int tile = begin; tile < end; tile += 64, buf ^= 1) {
+      pix_n2 = row_idx(tile + 128);
+      roff_nxt = pix_n1 * row_bytes;
+      lds_barrier();                               // the producer has staged this tile
+      const char* Bq = reinterpret_cast<const char*>(lds + buf * BUF + PXA) + q * 16;      // {sqrt(s0^2 + s1^2), joint r~} of pixel q
+      static_for<16>([&](auto ic_) {
+        constexpr int st = decltype(ic_)::value;
+        constexpr int sl = st % PFZ;
+        const double2 pa = *reinterpret_cast<const double2*>(Bq + st * 64);
+        // depth columns WITHOUT the 1 / z_m factor: it is constant over pixels and is applied to the accumulators once
+        const T zq[4] = {pa.x * kq[sl].x, pa.x * kq[sl].y, pa.x * kq[sl].z, pa.x * kq[sl].w};
+        refill(std::integral_constant<int, PFZ>{}, std::integral_constant<int, sl>{}, ic_);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gv[e] += zq[e] * pa.y;
+        static_for<10>([&](auto it) {
+          constexpr int tt = decltype(it)::value + 5;          // tiles 5..14 of the 15-tile enumeration = depth x depth
+          constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
+          acc[tt - 5] = mfma16(zq[ti - 1], zq[tj - 1], acc[tt - 5]);
+        });
+      });
+      roff_cur = roff_nxt;
+      pix_n1 = pix_n2;
+    }
+  } else {
+    for (int tile = begin; tile < end; tile += 64, buf ^= 1) {
+      pix_n2 = row_idx(tile + 128);
+      roff_nxt = pix_n1 * row_bytes;
+      lds_barrier();
+      const char* Bc = reinterpret_cast<const char*>(lds + buf * BUF) + (c * JP_STRIDE + q) * 8;   // pose row c, pixel q
+      const char* Bq = reinterpret_cast<const char*>(lds + buf * BUF + PXB) + q * 32;              // {sz0, sz1, r~0, r~1} of pixel q
+      static_for<16>([&](auto ic_) {
+        constexpr int st = decltype(ic_)::value;
+        constexpr int sl = st % PFT;
+        const T a00 = *reinterpret_cast<const T*>(Bc + st * 32);
+        const T a01 = *reinterpret_cast<const T*>(Bc + ROWS * 8 + st * 32);
+        const double2 sz = *reinterpret_cast<const double2*>(Bq + st * 128);          // depth scales of the two rows
+        const double2 rr = *reinterpret_cast<const double2*>(Bq + st * 128 + 16);     // their whitened residuals
+        const T p0 = a00 * sz.x, p1 = a01 * sz.y;              // pose row x depth scale; the B operand is the raw K~ quad
+        gv[0] += a00 * rr.x;
+        gv[1] += a01 * rr.y;
+        acc[0] = mfma16(a00, a00, acc[0]);
+        acc[1] = mfma16(a01, a01, acc[1]);
+        const T kk[4] = {kq[sl].x, kq[sl].y, kq[sl].z, kq[sl].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[2 + e] = mfma16(p0, kk[e], acc[2 + e]);
+          acc[6 + e] = mfma16(p1, kk[e], acc[6 + e]);
+        }
+        refill(std::integral_constant<int, PFT>{}, std::integral_constant<int, sl>{}, ic_);
+      });
+      roff_cur = roff_nxt;
+      pix_n1 = pix_n2;
+    }
+  }
+
+  // ---- epilogue: record layout of ba_blocks_kernel (15 tiles | 5 x 16 gradient | err) ----
+  T invz4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
+  auto put_tile = [&](T* rec, int tt, const acc_t& a) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) rec[tt * 256 + rg * 64 + lane] = a[rg];
+  };
+  const acc_t zero4 = acc_t{T(0), T(0), T(0), T(0)};
+  if (role == 1) {
+    // the 1 / z_m factors of the depth columns (dPwn_dzm = u K~ / z_m, sparse_map.py:184-230), once per accumulator: column k
+    // of depth block t at lane-column ci is kcol(t, ci) = 4 ci + t - 1; the f64 MFMA row of (lane, reg) is (lane >> 4) + 4 reg
+    static_for<10>([&](auto it) {
+      constexpr int tt = decltype(it)::value + 5;
+      constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int k1 = kcol(ti, mfma_row<T>(lane, rg));
+        const T f1 = (k1 < m) ? invz[(long)slot * m + k1] : T(0);
+        acc[tt - 5][rg] *= f1 * invz4[tj - 1];
+      }
+    });
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      gv[e] *= invz4[e];
+      gv[e] += __shfl_xor(gv[e], 16, 64);
+      gv[e] += __shfl_xor(gv[e], 32, 64);
+    }
+#pragma unroll
+    for (int t = 0; t < 10; ++t) {
+      put_tile(rec0, 5 + t, acc[t]);
+      if (rec1) put_tile(rec1, 5 + t, zero4);
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        rec0[Cfg::NT * 256 + (1 + e) * 16 + lane] = gv[e];
+        if (rec1) rec1[Cfg::NT * 256 + (1 + e) * 16 + lane] = T(0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) { acc[2 + e][rg] *= invz4[e]; acc[6 + e][rg] *= invz4[e]; }
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      gv[e] += __shfl_xor(gv[e], 16, 64);
+      gv[e] += __shfl_xor(gv[e], 32, 64);
+    }
+    put_tile(rec0, 0, acc[0]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) put_tile(rec0, 1 + e, acc[2 + e]);
+    if (lane < 16) rec0[Cfg::NT * 256 + lane] = gv[0];
+    if (rec1) {
+      put_tile(rec1, 0, acc[1]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) put_tile(rec1, 1 + e, acc[6 + e]);
+      if (lane < 16) rec1[Cfg::NT * 256 + lane] = gv[1];
     }
   }
 }
@@ -1437,29 +1868,32 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
       !A->ref_slot || !A->ref_aff || !A->tgt_aff || !A->tgt_pose || !A->tgt_img || !A->ws_r || !A->ws_valid ||
       !A->ws_hists || !A->ws_pair || !A->ws_partials)
     return COMO_ERR_ARG;
+  if (A->zmode < 0 || A->zmode > 2) return COMO_ERR_ARG;
   if (A->zmode == 1 && (!A->uvec || !A->invz)) return COMO_ERR_ARG;
+  if (A->zmode == 2 && (!A->invz || !A->ref_pose)) return COMO_ERR_ARG;
   if (A->channels < 0 || (A->channels > 1 && !A->pair_chan)) return COMO_ERR_ARG;
   BAPairs pr{A->ref_slot, A->ref_aff, A->tgt_aff, A->tgt_pose, A->tgt_img, A->anorm_f32, A->channels > 1 ? A->pair_chan : nullptr,
-             A->channels > 1 ? A->channels : 1};
+             A->channels > 1 ? A->channels : 1, A->zmode == 2 ? A->ref_pose : nullptr};
   const int b = A->b, n = A->n, m = A->m;
   const int pb = A->pix_begin, pe = (A->pix_end > 0) ? A->pix_end : n;
   if (pb < 0 || pe > n || pb >= pe) return COMO_ERR_ARG;
   const int nl = pe - pb;
-  T* pair_T = (T*)A->ws_pair;
+  T* pair_T = (T*)A->ws_pair;                       // ws_pair: [12 b] target inverse poses | [2 b] affine | [12 b] reference poses
   T* pair_aff = pair_T + 12 * (long)b;
+  T* pair_ref = pair_aff + 2 * (long)b;
   uint32_t* hists = (uint32_t*)A->ws_hists;
 
   if (A->phase & 1) {
     if (!(A->phase & 256) && !zero_words(hists, 6 * SEL_BINS, s)) return COMO_ERR_LAUNCH;
     hipLaunchKernelGGL(ba_pair_setup_kernel<T>, dim3((b + 63) / 64), dim3(64), 0, s, (const T*)A->poses_all,
-                       (const T*)A->aff_all, pr, b, pair_T, pair_aff);
+                       (const T*)A->aff_all, pr, b, pair_T, pair_aff, pair_ref);
     COMO_CHECK_LAUNCH();
     // ~1024 workgroups in total: every workgroup ends with global atomics on the few hot digit-0 bins, which
     // serialise per address at the memory side (~15 ns each) -- 14k workgroups cost > 200 us there.
     int gx = (nl + 255) / 256;
     const int cap = (1024 + b - 1) / b;
     if (gx > cap) gx = cap;
-    if (A->zmode == 1)
+    if (A->zmode >= 1)
       hipLaunchKernelGGL((ba_residual_kernel<T, true>), dim3(gx, b), dim3(256), 0, s, (const T*)A->Pwn, (const T*)A->vals, pr,
                          pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, pb, pe, (T*)A->ws_r,
                          (uint8_t*)A->ws_valid, (T*)A->pj_out, hists);
@@ -1489,74 +1923,77 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
 #define LAUNCH_BLOCKS(ZM)                                                                                            \
   hipLaunchKernelGGL((ba_blocks_kernel<T, ZM>), grid, blk, 0, s, (const T*)A->Pwn, (const T*)A->vals,                 \
                      (const T*)A->dPwn_dTwc, (const T*)A->zjac, (const T*)A->uvec, A->pixidx, (const T*)A->invz,      \
-                     A->kt_slot_stride, pr, pair_T, pair_aff, (const T*)A->img_base, (const T*)A->K, A->H, A->W, n, m, \
-                     pb, pe, chunk_len, hists, (T*)A->ws_partials, (T*)A->sigma_out)
+                     A->kt_slot_stride, pr, pair_T, pair_aff, pair_ref, (const T*)A->img_base, (const T*)A->K, A->H,  \
+                     A->W, n, m, pb, pe, chunk_len, hists, (T*)A->ws_partials, (T*)A->sigma_out)
+    // zmode 0 (the reference's materialised dPwn_dzm) and zmode 1 (materialised dPwn_dTwc / uvec planes) run the plain
+    // kernel; the tuned kernels below take the compact dense reference (zmode 2).  variant 1 = plain kernel for A/B runs.
+    const bool grouped = A->grp_pairs && A->ngrp > 0;
     if (A->zmode == 0) {
       LAUNCH_BLOCKS(0);
+    } else if (A->zmode == 1) {
+      LAUNCH_BLOCKS(1);
     } else if (A->variant == 1) {
-      LAUNCH_BLOCKS(1);                                    // straightforward fused version (kept for A/B runs)
+      LAUNCH_BLOCKS(2);
     } else {
-      // float32 only: the double build of the pipelined kernel needs > 512 registers (spills) -- the float64 pixel
-      // path keeps the straightforward kernel.  variant 0: two waves per SIMD (244 VGPRs, no spills); 3: one wave.
-#define LAUNCH_PIPE(WPS)                                                                                             \
-  hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, WPS>), grid, blk, 0, s, (const float*)A->Pwn, (const float*)A->vals, \
-                     (const float*)A->dPwn_dTwc, (const float*)A->zjac, (const float*)A->uvec, A->pixidx,             \
-                     (const float*)A->invz, A->kt_slot_stride, pr, (const float*)pair_T, (const float*)pair_aff,      \
-                     (const float*)A->img_base, (const float*)A->K, A->H, A->W, n, m, pb, pe, chunk_len, hists,       \
-                     (float*)A->ws_partials, (float*)A->sigma_out, A->stagger, (const int*)nullptr)
-#define LAUNCH_PIPE_ABL(AB)                                                                                           \
-  hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2, AB>), grid, blk, 0, s, (const float*)A->Pwn, (const float*)A->vals, \
-                     (const float*)A->dPwn_dTwc, (const float*)A->zjac, (const float*)A->uvec, A->pixidx,             \
-                     (const float*)A->invz, A->kt_slot_stride, pr, (const float*)pair_T, (const float*)pair_aff,      \
-                     (const float*)A->img_base, (const float*)A->K, A->H, A->W, n, m, pb, pe, chunk_len, hists,       \
-                     (float*)A->ws_partials, (float*)A->sigma_out, A->stagger, (const int*)nullptr)
+#define PIPE_ARGS(NPAIR_ROWS, MAP)                                                                                     \
+  dim3(chunks, NPAIR_ROWS), blk, 0, s, (const float*)A->Pwn, (const float*)A->vals, (const float*)A->dPwn_dTwc,        \
+      (const float*)A->zjac, A->pixidx, (const float*)A->invz, A->kt_slot_stride, pr, (const float*)pair_T,            \
+      (const float*)pair_aff, (const float*)pair_ref, (const float*)A->img_base, (const float*)A->K, A->H, A->W, n, m,  \
+      pb, pe, chunk_len, hists, (float*)A->ws_partials, (float*)A->sigma_out, A->stagger, MAP
       if constexpr (sizeof(T) == 4) {
-        if (A->variant == 3) { LAUNCH_PIPE(1); }
-        else if (A->variant == 11) { LAUNCH_PIPE_ABL(1); }
-        else if (A->variant == 12) { LAUNCH_PIPE_ABL(2); }
-        else if (A->variant != 2 && A->grp_pairs && A->ngrp > 0 && (A->nsingle == 0 || A->single_pairs)) {
+        // variant 0: two waves per SIMD (no spills); 3: one wave per SIMD; 11 / 12: timing ablations; 2: one pair at a time
+        if (A->variant == 3) { hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 1>), PIPE_ARGS(b, (const int*)nullptr)); }
+        else if (A->variant == 11) { hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2, 1>), PIPE_ARGS(b, (const int*)nullptr)); }
+        else if (A->variant == 12) { hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2, 2>), PIPE_ARGS(b, (const int*)nullptr)); }
+        else if (A->variant != 2 && grouped && (A->nsingle == 0 || A->single_pairs)) {
           // pairs that share their reference keyframe go through the two-pair kernel, the rest through the one-pair kernel
           // two waves per SIMD and a 4-deep K~ ring (256 VGPRs): 329 us; one wave per SIMD with an 8-deep ring: 371 us
           hipLaunchKernelGGL((ba_blocks_pair2_kernel<2, 4>), dim3(chunks, A->ngrp), blk, 0, s, (const float*)A->Pwn,
-                             (const float*)A->vals, (const float*)A->dPwn_dTwc, (const float*)A->zjac, (const float*)A->uvec,
+                             (const float*)A->vals, (const float*)A->dPwn_dTwc, (const float*)A->zjac,
                              A->pixidx, (const float*)A->invz, A->kt_slot_stride, pr, (const float*)pair_T,
-                             (const float*)pair_aff, (const float*)A->img_base, (const float*)A->K, A->H, A->W, n, m, pb, pe,
-                             chunk_len, hists, (float*)A->ws_partials, (float*)A->sigma_out, A->grp_pairs);
+                             (const float*)pair_aff, (const float*)pair_ref, (const float*)A->img_base, (const float*)A->K,
+                             A->H, A->W, n, m, pb, pe, chunk_len, hists, (float*)A->ws_partials, (float*)A->sigma_out,
+                             A->grp_pairs);
           if (A->nsingle > 0) {
             COMO_CHECK_LAUNCH();
-            hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2>), dim3(chunks, A->nsingle), blk, 0, s, (const float*)A->Pwn,
-                               (const float*)A->vals, (const float*)A->dPwn_dTwc, (const float*)A->zjac,
-                               (const float*)A->uvec, A->pixidx, (const float*)A->invz, A->kt_slot_stride, pr,
-                               (const float*)pair_T, (const float*)pair_aff, (const float*)A->img_base, (const float*)A->K,
-                               A->H, A->W, n, m, pb, pe, chunk_len, hists, (float*)A->ws_partials, (float*)A->sigma_out,
-                               A->stagger, A->single_pairs);
+            hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2>), PIPE_ARGS(A->nsingle, A->single_pairs));
           }
         }
-        else { LAUNCH_PIPE(2); }
+        else { hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2>), PIPE_ARGS(b, (const int*)nullptr)); }
       } else {
-        // float64 = the reference's mapping dtype: role-specialised two-pair kernel (variant 1 keeps the plain kernel for A/B runs)
-        // default: two waves per SIMD, no software pipeline (774 us on the dense 8-keyframe window; variant 3: one wave per
-        // SIMD with the four-stage pipeline, 824 us)
-        if (A->variant != 3 && A->variant != 2 && A->variant != 1 && A->grp_pairs && A->ngrp > 0 && A->nsingle == 0) {
-          hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, false>), dim3(chunks, A->ngrp), dim3(128), 0, s,
-                             (const double*)A->Pwn, (const double*)A->vals, (const double*)A->dPwn_dTwc, (const double*)A->zjac,
-                             (const double*)A->uvec, A->pixidx, (const double*)A->invz, A->kt_slot_stride, pr,
-                             (const double*)pair_T, (const double*)pair_aff, (const double*)A->img_base, (const double*)A->K,
-                             A->H, A->W, n, m, pb, pe, chunk_len, hists, (double*)A->ws_partials, (double*)A->sigma_out,
-                             A->grp_pairs);
-        } else if (A->variant != 2 && A->variant != 1 && A->grp_pairs && A->ngrp > 0 && A->nsingle == 0) {
-          hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, true>), dim3(chunks, A->ngrp), dim3(128), 0, s,
-                             (const double*)A->Pwn, (const double*)A->vals, (const double*)A->dPwn_dTwc, (const double*)A->zjac,
-                             (const double*)A->uvec, A->pixidx, (const double*)A->invz, A->kt_slot_stride, pr,
-                             (const double*)pair_T, (const double*)pair_aff, (const double*)A->img_base, (const double*)A->K,
-                             A->H, A->W, n, m, pb, pe, chunk_len, hists, (double*)A->ws_partials, (double*)A->sigma_out,
-                             A->grp_pairs);
+        // float64 = the reference's mapping dtype.  Default (variant 0): the wave-specialised two-pair kernel (producer / two
+        // consumer waves); the role-split kernel for A/B runs: 5 = software pipeline at two waves per SIMD, 4 = two waves per
+        // SIMD without the pipeline, 3 = pipeline, one wave per SIMD.
+        // (32-bit K~ row offsets: a slot of the predictor must stay below 4 GiB, else the plain kernel)
+        const bool fits32 = (unsigned long)A->kt_slot_stride * sizeof(T) < (1ul << 32) && (unsigned long)n * m * sizeof(T) < (1ul << 32);
+#define F64_ARGS                                                                                                      \
+  dim3(chunks, A->ngrp), dim3(128), 0, s, (const double*)A->Pwn, (const double*)A->vals, (const double*)A->dPwn_dTwc,   \
+      (const double*)A->zjac, A->pixidx, (const double*)A->invz, A->kt_slot_stride, pr, (const double*)pair_T,          \
+      (const double*)pair_aff, (const double*)pair_ref, (const double*)A->img_base, (const double*)A->K, A->H, A->W, n,  \
+      m, pb, pe, chunk_len, hists, (double*)A->ws_partials, (double*)A->sigma_out, A->grp_pairs
+        if (A->variant != 2 && grouped && A->nsingle == 0 && fits32) {
+          if (A->variant == 3) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, true, 1>), F64_ARGS); }
+          else if (A->variant == 4) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, false, 2>), F64_ARGS); }
+          else if (A->variant == 5) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, true, 2>), F64_ARGS); }
+          else {
+#define WS_ARGS                                                                                                       \
+  dim3(chunks, A->ngrp), dim3(192), 0, s, (const double*)A->Pwn, (const double*)A->vals, (const double*)A->dPwn_dTwc,   \
+      (const double*)A->zjac, A->pixidx, (const double*)A->invz, A->kt_slot_stride, pr, (const double*)pair_T,          \
+      (const double*)pair_aff, (const double*)pair_ref, (const double*)A->img_base, (const double*)A->K, A->H, A->W, n,  \
+      m, pb, pe, chunk_len, hists, (double*)A->ws_partials, (double*)A->sigma_out, A->grp_pairs
+            // K~ ring depths (Z, T) and waves per SIMD; 6 / 7 / 8: tuning runs
+            if (A->variant == 6) { hipLaunchKernelGGL((ba_blocks_ws_f64_kernel<4, 4, 3>), WS_ARGS); }
+            else if (A->variant == 7) { hipLaunchKernelGGL((ba_blocks_ws_f64_kernel<2, 2, 3>), WS_ARGS); }
+            else if (A->variant == 8) { hipLaunchKernelGGL((ba_blocks_ws_f64_kernel<8, 8, 2>), WS_ARGS); }
+            else { hipLaunchKernelGGL((ba_blocks_ws_f64_kernel<4, 2, 3>), WS_ARGS); }
+#undef WS_ARGS
+          }
         } else {
-          LAUNCH_BLOCKS(1);
+          LAUNCH_BLOCKS(2);
         }
+#undef F64_ARGS
       }
-#undef LAUNCH_PIPE
-#undef LAUNCH_PIPE_ABL
+#undef PIPE_ARGS
     }
 #undef LAUNCH_BLOCKS
     COMO_CHECK_LAUNCH();

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void dense_ref_kernel(
     const T* __restrict__ Kt, long kt_slot_stride, const int* __restrict__ pixidx, const T* __restrict__ logzm,
     const T* __restrict__ Twc, const T* __restrict__ Kmat, const T* __restrict__ dlogzm_dTwc, int n, int m, int Wimg,
     T* __restrict__ Pwn, T* __restrict__ dPwn_dTwc, T* __restrict__ uvec, T* __restrict__ zbuf, T* __restrict__ logzn_out,
-    uint32_t* __restrict__ hists, const int* __restrict__ pixcoord) {
+    uint32_t* __restrict__ hists, const int* __restrict__ pixcoord, int compact) {
   using KeyT = typename KeyOf<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
   __shared__ T coef[64][8];          // per inducing point: {logz_m, dlogz_m/dT (6), 0}
@@ -92,7 +92,14 @@ __global__ __launch_bounds__(256) void dense_ref_kernel(
     const T u0 = Tm[0] * Xc + Tm[1] * Yc + Tm[2] * Zc;           // uvec = R (ray z)
     const T u1 = Tm[4] * Xc + Tm[5] * Yc + Tm[6] * Zc;
     const T u2 = Tm[8] * Xc + Tm[9] * Yc + Tm[10] * Zc;
-    if (inr && Pwn) {                                              // Pwn == nullptr: depth-only pass (full-image median)
+    if (inr && Pwn && compact) {
+      // compact form: the block kernels rebuild dPwn_dTwc = [-[u]x R, R] + u (x) dlogz_n/dT_wc from P_w, the pose and these
+      // six dot products (u = P_w - t_wc): 9 planes written instead of 24
+      const long base3 = (long)b * 3 * n + i, base6 = (long)b * 6 * n + i;
+      Pwn[base3] = Xw; Pwn[base3 + n] = Yw; Pwn[base3 + 2 * (long)n] = Zw;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dPwn_dTwc[base6 + (long)k * n] = acc[1 + k];
+    } else if (inr && Pwn) {                                       // Pwn == nullptr: depth-only pass (full-image median)
       const long base3 = (long)b * 3 * n + i, base18 = (long)b * 18 * n + i;
       Pwn[base3] = Xw; Pwn[base3 + n] = Yw; Pwn[base3 + 2 * (long)n] = Zw;
       uvec[base3] = u0; uvec[base3 + n] = u1; uvec[base3 + 2 * (long)n] = u2;
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
     const float* __restrict__ Kt, long kt_slot_stride, const int* __restrict__ pixidx, const float* __restrict__ logzm,
     const float* __restrict__ Twc, const float* __restrict__ Kmat, const float* __restrict__ dlogzm_dTwc, int n, int m,
     int Wimg, float* __restrict__ Pwn, float* __restrict__ dPwn_dTwc, float* __restrict__ uvec, float* __restrict__ zbuf,
-    float* __restrict__ logzn_out, uint32_t* __restrict__ hists, const int* __restrict__ pixcoord) {
+    float* __restrict__ logzn_out, uint32_t* __restrict__ hists, const int* __restrict__ pixcoord, int compact) {
   using T = float;
   using KeyT = typename KeyOf<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
@@ -217,7 +224,12 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
     const T u0 = Tm[0] * Xc + Tm[1] * Yc + Tm[2] * Zc;
     const T u1 = Tm[4] * Xc + Tm[5] * Yc + Tm[6] * Zc;
     const T u2 = Tm[8] * Xc + Tm[9] * Yc + Tm[10] * Zc;
-    if (inr && Pwn) {
+    if (inr && Pwn && compact) {
+      const long base3 = (long)b * 3 * n + i, base6 = (long)b * 6 * n + i;
+      Pwn[base3] = Xw; Pwn[base3 + n] = Yw; Pwn[base3 + 2 * (long)n] = Zw;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dPwn_dTwc[base6 + (long)k * n] = a7[1 + k];
+    } else if (inr && Pwn) {
       const long base3 = (long)b * 3 * n + i, base18 = (long)b * 18 * n + i;
       Pwn[base3] = Xw; Pwn[base3 + n] = Yw; Pwn[base3 + 2 * (long)n] = Zw;
       uvec[base3] = u0; uvec[base3 + n] = u1; uvec[base3 + 2 * (long)n] = u2;
@@ -372,12 +384,13 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
               const T* dlogzm_dTwc, int B, int n, int m, int Wimg, T* Pwn, T* dPwn_dTwc, T* uvec, T* zbuf, T* logzn_out,
               void* hists_v, T* med_out3, const int* pixcoord, int flags, hipStream_t s) {
   using KeyT = typename KeyOf<T>::type;
+  const int compact = (flags & 16) ? 1 : 0;   // dPwn_dTwc receives the 6 planes dlogz_n/dT_wc only, uvec is not written
   const bool depth_only = (flags & 8) != 0;   // z_n = exp(K~ logz_m) of every row + its exact median: Mapping.store_vars (Mapping.py:749-758)
   if (!Kt || !logzm || !Twc || !Kmat || !dlogzm_dTwc || !zbuf || !hists_v || !med_out3 ||
       B <= 0 || n <= 0 || m <= 0 || m > 64 || (m & 3) || Wimg <= 0)
     return COMO_ERR_ARG;
   if (depth_only) { Pwn = nullptr; dPwn_dTwc = nullptr; uvec = nullptr; }
-  else if (!Pwn || !dPwn_dTwc || !uvec) return COMO_ERR_ARG;
+  else if (!Pwn || !dPwn_dTwc || (!uvec && !compact)) return COMO_ERR_ARG;
   uint32_t* hists = (uint32_t*)hists_v;
   if (!(flags & 4)) {
   if (!(flags & 1) && !zero_words(hists, (size_t)B * 6 * SEL_BINS, s))
@@ -388,10 +401,10 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
     int gm = ((n + 63) / 64 + 3) / 4;
     if (gm > 256) gm = 256;
     hipLaunchKernelGGL(dense_ref_mfma_kernel, dim3(gm, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
-                       dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord);
+                       dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord, compact);
   } else {
     hipLaunchKernelGGL(dense_ref_kernel<T>, dim3(gx, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
-                       dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord);
+                       dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord, compact);
   }
   COMO_CHECK_LAUNCH();
   }

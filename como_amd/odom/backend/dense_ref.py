@@ -12,7 +12,7 @@ _ws = {}
 
 
 def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_logz=True, med_out=None, pixcoord=None,
-                             hists=None, ws=None, part="all"):
+                             hists=None, ws=None, part="all", compact=False):
     """logzm (B,m[,1]) Twc (B,4,4) Kt (B,rows,m) pixidx (B,n) int32 or None K (3,3) dlogzm_dTwc (B,m[,1],6).
     pixcoord: optional (B,n) int32 linear pixel index (row*W+col) when it differs from the K~ row index.
     hists: optional caller-owned, ALREADY ZEROED select workspace (B * como_select_workspace_bytes()): skips the clear.
@@ -20,18 +20,24 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
     ws: optional caller-owned dict that receives / holds the output planes (a captured graph records their addresses, so
     whoever owns the graph must own them).  part: "all", or "points" then "median" as two calls (the median half -- select
     passes + finish -- can run on another stream; only the priors read it).
-    Returns Pwn (B,3,n), dPwn_dTwc (B,18,n), uvec (B,3,n), median depth (B,), logzn (B,n)."""
+    compact: the form the tuned block kernels consume (como_ba_args.zmode 2): instead of the 18 + 3 planes of dPwn_dTwc and
+    uvec only the six planes dlogz_n/dT_wc = K~[n,:] dlogz_m/dT_wc are written -- the kernels rebuild
+    dP_w/dT_wc = [-[u]x R, R] + u (x) dlogz_n/dT_wc with u = P_w - t_wc from the reference pose.
+    Returns Pwn (B,3,n), dPwn_dTwc (B,18,n) [compact: dlogzn_dTwc (B,6,n)], uvec (B,3,n) [compact: None], median depth (B,),
+    logzn (B,n)."""
     _lib.require_cuda(logzm, Twc, Kt, K, dlogzm_dTwc)
     dt, dev = Kt.dtype, Kt.device
     B, rows, m = Kt.shape
     n = pixidx.shape[1] if pixidx is not None else rows
     L = _lib.lib()
-    key = (str(dev), dt, B, n)
+    key = (str(dev), dt, B, n) if not compact else (str(dev), dt, B, n, "compact")
     own = ws
     ws = own.get(key) if own is not None else _ws.get(key)
     if ws is None:
-        ws = {"Pwn": torch.empty((B, 3, n), device=dev, dtype=dt), "dT": torch.empty((B, 18, n), device=dev, dtype=dt),
-              "uvec": torch.empty((B, 3, n), device=dev, dtype=dt), "z": torch.empty((B, n), device=dev, dtype=dt),
+        ws = {"Pwn": torch.empty((B, 3, n), device=dev, dtype=dt),
+              "dT": torch.empty((B, 6 if compact else 18, n), device=dev, dtype=dt),
+              "uvec": None if compact else torch.empty((B, 3, n), device=dev, dtype=dt),
+              "z": torch.empty((B, n), device=dev, dtype=dt),
               "logz": torch.empty((B, n), device=dev, dtype=dt), "med": torch.empty((B, 3), device=dev, dtype=dt),
               "hists": torch.empty((B * L.como_select_workspace_bytes() // 4,), device=dev, dtype=torch.int32)}
         if own is not None:
@@ -46,9 +52,9 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
     Kc = K.to(dt).contiguous()
     fn = getattr(L, "como_dense_ref_" + _lib.suffix(dt))
     rc = fn(Kt.data_ptr(), Kt.stride(0), _lib.ptr(pixidx), lz.data_ptr(), Tw.data_ptr(), Kc.data_ptr(), dl.data_ptr(), B, n, m,
-            int(Wimg), ws["Pwn"].data_ptr(), ws["dT"].data_ptr(), ws["uvec"].data_ptr(), ws["z"].data_ptr(),
+            int(Wimg), ws["Pwn"].data_ptr(), ws["dT"].data_ptr(), _lib.ptr(ws["uvec"]), ws["z"].data_ptr(),
             ws["logz"].data_ptr() if want_logz else None, (hists if hists is not None else ws["hists"]).data_ptr(), med.data_ptr(),
-            _lib.ptr(pixcoord), (1 if hists is not None else 0) | {"all": 0, "points": 2, "median": 4}[part],
+            _lib.ptr(pixcoord), (1 if hists is not None else 0) | {"all": 0, "points": 2, "median": 4}[part] | (16 if compact else 0),
             _lib.stream_ptr(dev))
     _lib.check(rc, "como_dense_ref")
     return ws["Pwn"], ws["dT"], ws["uvec"], med[:, 0], ws["logz"]

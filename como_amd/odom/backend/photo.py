@@ -50,7 +50,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
               err_out, uvec=None, pixidx=None, invz=None, kt_slot_stride=0, chunks=None, phase=0xFF, want_pj=False,
               want_blocks=False, sigma_out=None, pix_range=None, reduce_hists=None, events=None, anorm_f32=False,
               grp_pairs=None, single_pairs=None, zeroed_hists=None, ws=None, sysfix=None, fix_plane=0, D=None,
-              reduce_blocks=None, channels=1, pair_chan=None):
+              reduce_blocks=None, channels=1, pair_chan=None, ref_pose=None):
     """Thin marshalling layer over como_ba_linearize_* (see include/como_hip.h for every field).
 
     pix_range=(begin, end): this rank's share of the reference pixels of every pair (multi-GPU shard).
@@ -62,6 +62,8 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
         como_sys_finalize) instead of floating-point atomics into H / g / err_out (which may then be None).
     reduce_blocks(t): multi-GPU with sysfix: called on the (b, 3936, 2) int64 fixed-point per-pair sums between the
         reduce and the expand stage (an integer all-reduce(sum): exact, so every rank continues with identical bits).
+    ref_pose: zmode 2 (compact dense reference: dPwn_dTwc = the six planes dlogz_n/dT_wc, no uvec): (b,) int32 index into
+        poses_all of every pair's REFERENCE keyframe pose.
     channels / pair_chan: colour images (`color: rgb`): vals is (slots,n,c), the image stacks are (3c,H,W) and every keyframe
         pair appears c times in the pair arrays, once per channel (`expand_channels`); b counts those entries."""
     dev = Pwn.device
@@ -74,10 +76,11 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     if chunks is None and CHUNKS_OVERRIDE > 0:
         chunks = min(CHUNKS_OVERRIDE, (nl + 255) // 256)
     if chunks is None:
-        if grp_pairs is not None and grp_pairs.numel() > 0 and zmode == 1 and BLOCK_VARIANT == 0 and dtype == torch.float64:
-            # float64 two-pair kernel: 128-thread workgroups, two waves per SIMD = 4 workgroups per CU: one resident round of 1024
+        if grp_pairs is not None and grp_pairs.numel() > 0 and zmode == 2 and BLOCK_VARIANT not in (1, 2, 3, 8) and dtype == torch.float64:
+            # float64 two-pair kernels (wave-specialised: 192 threads, three waves per SIMD; role-split: 128 threads, two waves
+            # per SIMD): 4 workgroups per CU = one resident round of 1024
             chunks = default_chunks(grp_pairs.shape[0], nl, dtype, per_cu=2)
-        elif grp_pairs is not None and grp_pairs.numel() > 0 and zmode == 1 and BLOCK_VARIANT in (0, 3):
+        elif grp_pairs is not None and grp_pairs.numel() > 0 and zmode == 2 and BLOCK_VARIANT in (0, 3, 8):
             # two-pair kernels: 2 workgroups per CU resident (f32: 256 threads, 2 waves / SIMD; f64: 128 threads, 1 wave / SIMD)
             # -> ONE resident round of 512 workgroups (measured, dense 8-keyframe window: 64 chunks x 8 groups 313 us,
             # 128 x 8 = two rounds 338 us in float32; 841 vs 882 us in float64)
@@ -95,6 +98,11 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     a.variant = BLOCK_VARIANT
     a.stagger = BLOCK_STAGGER
     a.channels = int(channels)
+    if zmode == 2:
+        if ref_pose is None or ref_pose.numel() != b or ref_pose.dtype != torch.int32 or not ref_pose.is_contiguous():
+            raise RuntimeError("como_amd: zmode 2 needs ref_pose, a contiguous int32 tensor with one pose index per pair entry")
+        _lib.require_cuda(ref_pose)
+        a.ref_pose = _lib.ptr(ref_pose)
     if channels > 1:
         if pair_chan is None or pair_chan.numel() != b or pair_chan.dtype != torch.int32 or not pair_chan.is_contiguous():
             raise RuntimeError("como_amd: pair_chan must be a contiguous int32 tensor with one channel per pair entry")
@@ -110,7 +118,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
     ws_valid = _buf("valid", (b, nl), torch.uint8, dev, ws)
     # zeroed_hists: caller-owned select workspace that is ALREADY zero (the fused window path clears it elsewhere)
     ws_hists = zeroed_hists if zeroed_hists is not None else _buf("hists", (L.como_select_workspace_bytes() // 4,), torch.int32, dev, ws)
-    ws_pair = _buf("pair", (b * 14,), dtype, dev, ws)
+    ws_pair = _buf("pair", (b * 26,), dtype, dev, ws)
     ws_part = _buf("partials", (L.como_ba_partials_elems(b, chunks, m),), dtype, dev, ws)
     if sigma_out is None:
         sigma_out = _buf("sigma", (2,), dtype, dev, ws)
@@ -281,6 +289,7 @@ class PairTable:
         self.b = b
         self.pair_chan = _i32([p_ % c for p_ in range(b)], device) if c > 1 else None
         self.ref_slot = _i32(ref_ids, device)
+        self.ref_pose = self.ref_slot                       # keyframes come first in the pose buffer: slot b = pose b
         self.ref_aff = _i32(ref_ids, device)
         tgt_frame = [t + (num_kf if r else 0) for t, r in zip(tgt_ids, tgt_is_recent)]
         self.tgt_aff = _i32(tgt_frame, device)
@@ -313,13 +322,17 @@ def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uv
                           reduce_hists=None, events=None, zeroed_hists=None, ws=None, sysfix=None, fix_plane=0, D=None,
                           reduce_blocks=None):
     """Fast path: same normal equations as batch_photo_cost from the rank-1 factors of dPwn_dzm.
-    Per-keyframe arrays (slots = keyframes): Pwn (B,n,3) vals (B,n) dPwn_dTwc (B,n,3,6) uvec (B,n,3) invz (B,m)
-    Kt (B,rows,m) dense predictor, pixidx (B,n) int32 rows of Kt (None = identity), dzdP (B,3)."""
+    Per-keyframe arrays (slots = keyframes), structure-of-arrays planes: Pwn (B,3,n) vals (B,n[,c]) invz (B,m)
+    Kt (B,rows,m) dense predictor, pixidx (B,n) int32 rows of Kt (None = identity), dzdP (B,3), and either
+      uvec (B,3,n) + dPwn_dTwc (B,18,n): materialised pose Jacobian (como_ba_args.zmode 1, plain kernel), or
+      uvec None + dPwn_dTwc (B,6,n) = dlogz_n/dT_wc: the compact dense reference (zmode 2, the tuned kernels; the
+      reference poses are poses_all[table.ref_pose])."""
     B, n = vals.shape[:2]                                  # (B,n) gray or (B,n,c)
     if (vals.shape[2] if vals.dim() == 3 else 1) != table.channels:
         raise RuntimeError("como_amd: vals must be (B,n,c) with the pair table's channel count")
     m = Kt.shape[-1]
-    return linearize(dtype=vals.dtype, b=table.b, channels=table.channels, pair_chan=table.pair_chan, n=n, m=m, H_img=H_img, W_img=W_img, zmode=1, Pwn=Pwn, vals=vals,
+    return linearize(dtype=vals.dtype, b=table.b, channels=table.channels, pair_chan=table.pair_chan, n=n, m=m, H_img=H_img, W_img=W_img,
+                     zmode=(2 if uvec is None else 1), ref_pose=(table.ref_pose if uvec is None else None), Pwn=Pwn, vals=vals,
                      dPwn_dTwc=dPwn_dTwc, zjac=Kt, uvec=uvec, pixidx=pixidx, invz=invz,
                      kt_slot_stride=Kt.stride(0), poses_all=poses_all, aff_all=aff_all, img_base=img_base, K=K,
                      ref_slot=table.ref_slot, ref_aff=table.ref_aff, tgt_aff=table.tgt_aff, tgt_pose=table.tgt_pose,

@@ -54,7 +54,7 @@ def construct_photo_system(Tji, sparse_log_depth, aff, test_coords_i, vals_i, Kn
     zeros6 = torch.zeros((1, m, 6), dtype=dt, device=dev)
     Kt = Knm_Kmminv.contiguous()
     Pj, dPj_dT, uvec, _, logz = dense_reference_factored(sparse_log_depth.reshape(1, m), Tji.reshape(1, 4, 4), Kt, None,
-                                                         intrinsics, zeros6, Ww, pixcoord=pixcoord)
+                                                         intrinsics, zeros6, Ww, pixcoord=pixcoord, compact=True)
     poses = torch.stack((Tji.reshape(4, 4).to(dt), torch.eye(4, dtype=dt, device=dev))).contiguous()
     aff0 = torch.zeros((2, 2), dtype=dt, device=dev)
     D = tb["D"]
@@ -64,7 +64,8 @@ def construct_photo_system(Tji, sparse_log_depth, aff, test_coords_i, vals_i, Kn
     ones = torch.ones((1, m), dtype=dt, device=dev)
     dzdP = torch.tensor([[1.0, 0.0, 0.0]], dtype=dt, device=dev)
     vals = vals_i.reshape(1, c, N).transpose(1, 2).to(dt).contiguous()        # (1,N,c): the kernels' (slots,n,c) layout
-    photo.linearize(dtype=dt, b=c, n=N, m=m, H_img=Hh, W_img=Ww, zmode=1, Pwn=Pj, vals=vals, channels=c, pair_chan=tb["chan"],
+    photo.linearize(dtype=dt, b=c, n=N, m=m, H_img=Hh, W_img=Ww, zmode=2, ref_pose=tb["ref_slot"], Pwn=Pj, vals=vals, channels=c,
+                    pair_chan=tb["chan"],
                     dPwn_dTwc=dPj_dT, zjac=Kt, uvec=uvec, pixidx=None, invz=ones, kt_slot_stride=Kt.stride(0), poses_all=poses,
                     aff_all=aff0, img_base=img_and_grads_j.to(dt).contiguous(), K=intrinsics.to(dt).contiguous(),
                     ref_slot=tb["ref_slot"], ref_aff=tb["ref_aff"], tgt_aff=tb["tgt_aff"], tgt_pose=tb["tgt_pose"],

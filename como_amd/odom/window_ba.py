@@ -274,7 +274,7 @@ class WindowBA:
         self.sysfix.zero_()
         dr = lambda part: dense_reference_factored(w["px_logzm"], w["px_poses"][:self.B], self.Kt, self.pixidx, self.K_pix,
                                                    w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"],
-                                                   hists=w["hist_dr"], ws=w["dr_ws"], part=part)
+                                                   hists=w["hist_dr"], ws=w["dr_ws"], part=part, compact=True)
         fork = self.shard is None and self.overlap_priors
         fm = lambda part: full_image_median(w["px_logzm"], self.Kt, w["med3_full"], w["dr_ws"], hists=w["hist_full"], part=part)
         if self.shard is not None:
@@ -339,9 +339,9 @@ class WindowBA:
             Pwn, dT, uvec, _, _ = dr("points")
         else:
             z1 = torch.zeros((B, 1), device=dev, dtype=self.pix_dtype)
-            Pwn, dT, uvec = z1.new_zeros((B, 3, 1)), z1.new_zeros((B, 18, 1)), z1.new_zeros((B, 3, 1))
+            Pwn, dT, uvec = z1.new_zeros((B, 3, 1)), z1.new_zeros((B, 6, 1)), None
         if not self.full_median:
-            key = (str(dev), self.Kt.dtype, B, self.n)
+            key = (str(dev), self.Kt.dtype, B, self.n, "compact")
             zmed = w["dr_ws"][key]["z"] if not self.idle else z1
             hmed, med_out, z_idle = w["hist_dr"], w["med3"], self.idle
         hv = hmed.view(B, 6, 2048)
@@ -413,7 +413,7 @@ class WindowBA:
         dlogzm_dPwm = dlogzm_dzm @ dzm_dPwm
         p = self.pix_dtype
         Pwn, dPwn_dTwc, uvec, med, _ = dense_reference_factored(logzm.to(p), self.kf_poses.to(p), self.Kt, self.pixidx, self.K_pix,
-                                                                dlogzm_dTwc.to(p), self.Wimg, want_logz=False)
+                                                                dlogzm_dTwc.to(p), self.Wimg, want_logz=False, compact=True)
         self.median_subset = med
         if self.full_median:                                 # Mapping.store_vars: median of the full depth image
             if not hasattr(self, "_fm_ws"):

@@ -132,26 +132,31 @@ typedef struct como_ba_args {
   int m;                     /* inducing points per keyframe: multiple of 4, <= 64 */
   int H, W;                  /* target image size */
   int zmode;                 /* 0: zjac = dPwn_dzm (slots,n,3,m) as photo.py:92 receives it
-                                1: factored: zjac = K~ rows (slot, row, m); dPwn_dzm[n,:,k] = uvec[n,:] K~[pix(n),k] invz[k] */
+                                1: factored: zjac = K~ rows (slot, row, m); dPwn_dzm[n,:,k] = uvec[n,:] K~[pix(n),k] invz[k]
+                                2: factored AND compact (the tuned kernels): as 1, but dPwn_dTwc holds only the six planes
+                                   dlogz_n/dT_wc = K~[n,:] dlogz_m/dT_wc (como_dense_ref_* flag 16) and uvec is not read: the
+                                   kernels rebuild dP_w/dT_wc = [-[u]x R, R] + u (x) dlogz_n/dT_wc with u = P_w - t_wc from the
+                                   reference keyframe's pose poses_all[ref_pose[p]] (sparse_map.py:184-230) */
   int chunks;                /* pixel chunks per pair (grid.x of the block kernel); partial records = b*chunks */
   int phase;                 /* bit mask: 1 setup+residual(+hist pass 0), 2<<(p-1) hist pass p>=1, 64 blocks, 128 reduce+assemble,
                                 256 = ws_hists is already zero (skip the clear) */
   int h_is_f64;              /* element type of Hmat / gvec: 1 = double, 0 = float */
-  int variant;               /* zmode 1 only: 0 = software-pipelined block kernels (float32; default; two-pair kernel where
-                                grp_pairs lists pairs), 1 = straightforward one, 2 = pipelined one-pair kernel only */
+  int variant;               /* zmode 2 only: 0 = software-pipelined block kernels (default; the two-pair kernels where
+                                grp_pairs lists pairs), 1 = straightforward one, 2 = pipelined one-pair kernel only (float32),
+                                3 = one wave per SIMD, 4 = float64 two-pair kernel without the software pipeline */
   int stagger;               /* pipelined kernel: start delay (x1024 cycles) of odd hardware wave slots, 0 = none */
   int pix_begin, pix_end;    /* reference-pixel range [begin,end) of every pair handled by this call (multi-GPU shard);
                                 pix_end <= 0 means n.  ws_r / ws_valid / pj_out are then (b, end-begin). */
   int anorm_f32;             /* 1: the sampling normalisation 1/W, 1/H is rounded to float32 first (two_frame_sfm.py:187-190
                                 builds A_norm from an integer tensor -> float32 even in a float64 run); 0: computed in T */
-  const void* Pwn;           /* zmode 0: (slots,n,3) photo.py:86 ; zmode 1: planes (slots,3,n) */
+  const void* Pwn;           /* zmode 0: (slots,n,3) photo.py:86 ; zmode 1, 2: planes (slots,3,n) */
   const void* vals;          /* (slots,n,c)   photo.py:84 (c = channels) */
-  const void* dPwn_dTwc;     /* zmode 0: (slots,n,3,6) photo.py:90 ; zmode 1: planes (slots,18,n) */
+  const void* dPwn_dTwc;     /* zmode 0: (slots,n,3,6) photo.py:90 ; zmode 1: planes (slots,18,n) ; zmode 2: planes (slots,6,n) */
   const void* zjac;          /* see zmode */
   const void* uvec;          /* zmode 1: planes (slots,3,n) */
-  const int* pixidx;         /* zmode 1: (slots,n) row of K~ per reference pixel, NULL = identity */
-  const void* invz;          /* zmode 1: (slots,m) = dlogz_m/dz_m = 1/z_m */
-  long kt_slot_stride;       /* zmode 1: elements between slots of K~ */
+  const int* pixidx;         /* zmode 1, 2: (slots,n) row of K~ per reference pixel, NULL = identity */
+  const void* invz;          /* zmode 1, 2: (slots,m) = dlogz_m/dz_m = 1/z_m */
+  long kt_slot_stride;       /* zmode 1, 2: elements between slots of K~ */
   const void* poses_all;     /* (F,4,4) target poses T_wc */
   const void* aff_all;       /* (A,2) affine brightness params */
   const void* img_base;      /* base pointer of the [I,gx,gy] (3c,H,W) stacks */
@@ -175,7 +180,7 @@ typedef struct como_ba_args {
   void* ws_r;                /* (b,n_local) residual workspace */
   uint8_t* ws_valid;         /* (b,n_local) validity mask (an OUTPUT as well: bit-exact vs photo.py:15-21) */
   void* ws_hists;            /* como_select_workspace_bytes() */
-  void* ws_pair;             /* b*14 elements */
+  void* ws_pair;             /* b*26 elements */
   void* ws_partials;         /* como_ba_partials_elems(b, chunks, m) elements */
   const int* grp_pairs;      /* optional (ngrp,2): pairs of this batch that share their reference slot, two per row (zmode 1,
                                 float32): the depth x depth block and the K~ reads are shared inside a row */
@@ -187,7 +192,7 @@ typedef struct como_ba_args {
      workgroups, streams or ranks deliver it).  gvec / err_out are ignored. */
   long fix_plane;
   /* reduce_mode (phase 128): 0 = reduce the per-workgroup records of every pair and expand / scatter them (single GPU);
-     1 = reduce only: blocks_fix (b, 3952, 2) int64 receives the per-pair sums in fixed point (all-reduce them with an
+     1 = reduce only: blocks_fix (b, 3936, 2) int64 receives the per-pair sums in fixed point (all-reduce them with an
      integer SUM -- exact, so every rank ends with identical bits); 2 = expand / scatter from blocks_fix. */
   int reduce_mode;
   void* blocks_fix;
@@ -198,6 +203,7 @@ typedef struct como_ba_args {
      grp_pairs must share slot and channel.  channels <= 1: gray, pair_chan ignored. */
   int channels;
   const int* pair_chan;      /* [b] */
+  const int* ref_pose;       /* zmode 2: [b] index into poses_all of the REFERENCE keyframe's pose T_wc */
 } como_ba_args;
 
 long como_ba_partials_elems(int b, int chunks, int m);
@@ -261,7 +267,9 @@ int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, cons
  * may run on different streams: nothing between the reference points and the priors needs the median);
  * bit 3: depth only -- z_n = exp(K~[n,:] logz_m) of every row into zbuf and its exact per-keyframe median, no planes
  * (Pwn / dPwn_dTwc / uvec may be NULL): Mapping.store_vars' full-image median depth (Mapping.py:749-758), the value
- * the priors and the landmark re-initialisation use. */
+ * the priors and the landmark re-initialisation use;
+ * bit 4: compact -- dPwn_dTwc receives only the six planes (B,6,n) dlogz_n/dT_wc = K~[n,:] dlogz_m/dT_wc and uvec is not
+ * written (may be NULL): what como_ba_args.zmode 2 consumes (9 planes written per pixel instead of 24). */
 int como_dense_ref_f32(const float* Kt, long kt_slot_stride, const int* pixidx, const float* logzm, const float* Twc,
                        const float* K, const float* dlogzm_dTwc, int B, int n, int m, int Wimg, float* Pwn,
                        float* dPwn_dTwc, float* uvec, float* zbuf, float* logzn_out, void* hists, float* med_out3,
