@@ -1,6 +1,6 @@
 """bench.py -- GN iterations / second of the 8-keyframe 640x480 photometric window BA on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--window 1|4] [--dtype f32|f64] [--keyframes B] [--replicas] [--no-cpu]
+    python bench.py --gpus N --steps K --warmup W [--window 1|4] [--dtype f64|f32] [--keyframes B] [--replicas] [--no-cpu]
     (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
 
 One "step" = one Gauss-Newton iteration of the window BA, exactly the reference's Mapping.iterate sequence
@@ -10,18 +10,22 @@ Cholesky solve -> pose / affine / landmark update.  Inputs (images, K~, landmark
 timed region.  Synthetic seeded scene (como_amd/synth.py); no datasets or checkpoints exist in this image.
 
 Headline workload: --window 1 = every pixel is a reference pixel (n = 307,200 per keyframe, 4.3 M pixel-pairs per
-iteration), per-pixel path in --dtype (f32 default: mixed precision, the normal equations / priors / solve / state are
-float64 always).  The same JSON line also carries (N = 1 only):
-  reference_dtype : the same dense window with the per-pixel path in float64 = the reference's mapping dtype
-                    (config/como.yml:28), with its own roofline (784 B per pixel-pair);
-  secondary       : the window at the reference's default sub-selection (nonmax_suppression_window 4, n = 19,200), f32 and f64;
+iteration), per-pixel path in --dtype: **f64 by default = the reference's mapping dtype** (config/como.yml:28 `dtype: double`);
+the normal equations / priors / solve / state are float64 always.  `value`, `dtype`, `roofline` (784 B per pixel-pair) and the
+top-level `cpu_baseline` (the oracle on the SAME dense workload) all describe that leg.  The same JSON line also carries (N = 1):
+  mixed_precision : the same dense window with the per-pixel path in float32 (392 B per pixel-pair), own roofline;
+  secondary       : the window at the reference's default sub-selection (nonmax_suppression_window 4, n = 19,200), f64 and f32
+                    -- the reference's operating point; its numbers are repeated as flat keys of `config` (window4_*);
   tracking        : config 2 -- the 2-frame 640x480 tracking GN iteration (unit A: 53 B per pixel);
   odometry_loop   : the whole headless sequential loop (frames / s);
   ate_vs_ref      : ATE-RMSE of the HIP loop's trajectory against the reference's own on a 72-frame 192x256 sequence;
-  cpu_baseline    : the oracle (CPU restatement of the reference algorithm) timed on this box's host cores on the
-                    window-4 workload EXACTLY as `secondary` runs it (full iteration incl. priors, >= 5 repetitions).
---keyframes 32 runs config 4's window (62 pairs, D ~ 2.9 k); --replicas runs config 5's mode: one independent window per
-GPU, no collective ("scaling": "weak", value = sum over ranks).
+  cpu_baseline    : the oracle (CPU restatement of the reference algorithm) timed on this box's host cores: the dense headline
+                    workload (bounded: two iterations) and, nested under `window4`, the window-4 workload.
+--keyframes 32 runs config 4's window (62 pairs, D ~ 2.9 k).
+--replicas runs config 5's mode: ONE SEQUENCE PER GPU -- every rank drives its own rendered 640x480 sequence through the whole
+odometry loop (tracking + keyframe management + DepthCov network + window BA, como_amd/odom/sequential.py <-> the reference's
+como/odom/sequential/ComoSeq.py:42-127), no collective; K = frames timed per rank after the two-frame initialisation and W
+warm-up frames; value = sum over ranks of frames / s ("scaling": "weak").
 """
 import argparse
 import json
@@ -55,10 +59,12 @@ def build_state(args, device, pix_dtype):
                              seed=args.seed, predictor=predictor)
 
 
-def cpu_baseline(args, state_cpu, window=4, reps=5):
+def cpu_baseline(args, state_cpu, reps=5):
     """The oracle ("port": oracle/window.py OracleWindow.iterate = the reference's Mapping.iterate sequence with
     materialised Jacobian rows, batched Gram products, index_add assembly, the real prior factors, cholesky_ex +
-    cholesky_solve) timed on the host cores on the window-`window` workload exactly -- no scaling, no stand-ins."""
+    cholesky_solve) timed on the host cores -- no scaling, no stand-ins.  Top level = the SAME workload as `value` (the dense
+    window, bounded to two iterations: ~10 s each and ~30 GB of materialised Jacobians); `window4` = the reference's default
+    sub-selection (compare with `secondary`)."""
     from oracle.window import OracleWindow
     ncpu = os.cpu_count() or 8
     # these are many small/medium tensor ops: torch with every core of a 100+ core host is far slower than with 16-32
@@ -67,14 +73,14 @@ def cpu_baseline(args, state_cpu, window=4, reps=5):
         if nt > ncpu:
             continue
         torch.set_num_threads(nt)
-        ow = OracleWindow(state_cpu, window=window)
+        ow = OracleWindow(state_cpu, window=4)
         t0 = time.perf_counter()
         ow.iterate()
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
             best = (dt, nt)
     torch.set_num_threads(best[1])
-    ow = OracleWindow(state_cpu, window=window)
+    ow = OracleWindow(state_cpu, window=4)
     ow.iterate()
     ts = []
     for _ in range(reps):
@@ -84,36 +90,50 @@ def cpu_baseline(args, state_cpu, window=4, reps=5):
     ts.sort()
     med = ts[len(ts) // 2]
     n = ow.cn.shape[1]
-    out = {"value": 1.0 / med, "unit": "GN iters/s", "cores": best[1], "host_cores": ncpu, "kind": "port",
-           "workload": f"window={window}",
-           "sample": f"oracle/window.py (torch-CPU, float64) full GN iteration incl. priors + solve on the window-{window} workload "
-                     f"exactly (n={n} px/KF, {ow.aux['valid'].shape[0]} pairs, D={ow.D}): median of {reps} after 1 warm-up = "
-                     f"{med * 1e3:.0f} ms (min {ts[0] * 1e3:.0f}, max {ts[-1] * 1e3:.0f}); {best[1]} torch threads (fastest of "
-                     f"8/16/32/64) on a {ncpu}-core host; compare with `secondary` (same workload on the GPU), not with `value`"}
-    # the headline (dense, window 1) workload: ONE oracle iteration, not extrapolated (16x the pixel-pairs, ~30 GB of
-    # materialised Jacobians on the host): only where the host has the memory for it
+    w4 = {"value": 1.0 / med, "unit": "GN iters/s", "cores": best[1], "host_cores": ncpu, "kind": "port", "workload": "window=4",
+          "sample": f"oracle/window.py (torch-CPU, float64) full GN iteration incl. priors + solve on the window-4 workload "
+                    f"exactly (n={n} px/KF, {ow.aux['valid'].shape[0]} pairs, D={ow.D}): median of {reps} after 1 warm-up = "
+                    f"{med * 1e3:.0f} ms (min {ts[0] * 1e3:.0f}, max {ts[-1] * 1e3:.0f}); {best[1]} torch threads (fastest of "
+                    f"8/16/32/64) on a {ncpu}-core host; compare with `secondary` (same workload on the GPU)"}
+    del ow
+    # the headline (dense) workload, not extrapolated: only where the host has the memory for it
     try:
         import psutil
         avail = psutil.virtual_memory().available
     except Exception:                                       # noqa: BLE001
         avail = 0
-    if not args.no_cpu_dense and avail > 96e9:
-        torch.set_num_threads(best[1])
-        owd = OracleWindow(state_cpu, window=1)
+    dense_ok = args.window == 1 and not args.no_cpu_dense and avail > 96e9
+    if not dense_ok:
+        out = dict(w4)
+        out["note"] = ("the dense (window 1) oracle iteration was skipped (host memory / --no-cpu-dense / --window): this is the "
+                       "window-4 workload -- compare with `secondary`, not with `value`")
+        out["window4"] = w4
+        return out
+    torch.set_num_threads(best[1])
+    owd = OracleWindow(state_cpu, window=args.window)
+    td = []
+    for _ in range(2):
         t0 = time.perf_counter()
         owd.iterate()
-        out["dense"] = {"value": 1.0 / (time.perf_counter() - t0), "unit": "GN iters/s", "workload": "window=1 (the headline workload), one iteration",
-                        "seconds": time.perf_counter() - t0, "cores": best[1]}
-        del owd
-    else:
-        out["dense"] = None
-    return out
+        td.append(time.perf_counter() - t0)
+    nd, pairs, D = owd.cn.shape[1], owd.aux["valid"].shape[0], owd.D
+    del owd
+    return {"value": 1.0 / min(td), "unit": "GN iters/s", "cores": best[1], "host_cores": ncpu, "kind": "port",
+            "workload": f"window={args.window} (the workload of `value`)",
+            "sample": f"oracle/window.py (torch-CPU, float64) full GN iteration incl. priors + solve on the headline workload exactly "
+                      f"(n={nd} px/KF, {pairs} pairs, D={D}): two iterations, {td[0]:.1f} s and {td[1]:.1f} s, value = 1 / the faster; "
+                      f"{best[1]} torch threads (fastest of 8/16/32/64 on the window-4 workload) on a {ncpu}-core host",
+            "seconds": td, "window4": w4}
 
 
-def odometry_loop(device, frames=100):
-    """Informational: the whole headless sequential odometry loop (tracking + keyframe management + one mapping iteration
-    per frame, como_amd/odom/sequential.py) on a rendered 640x480 sequence with the parameters of the reference's
-    config/como.yml; frames/s after the two-frame initialisation.  Never fails the bench line."""
+def odometry_loop(device, frames=100, seed=1, pix="float", warm=0, barrier=None, timed_frames=None):
+    """The whole headless sequential odometry loop (tracking + keyframe management + DepthCov network on every new keyframe +
+    one mapping iteration per frame, como_amd/odom/sequential.py <-> como/odom/sequential/ComoSeq.py:42-127) on a rendered
+    640x480 sequence with the parameters of the reference's config/como.yml; frames/s after the two-frame initialisation
+    (+ `warm` further untimed frames).  `seed` picks the scene texture and the camera path (--replicas: one sequence per rank);
+    pix = "float" (mixed precision) / "double" (the reference's mapping dtype) per-pixel kernels of the window BA.
+    timed_frames: time EXACTLY that many frames (the sequence is rendered long enough); barrier: called right before / after
+    the timed region (multi-rank).  Never fails the bench line: returns {"error": ...} instead."""
     try:
         import argparse
         from como_amd import synth
@@ -121,25 +141,42 @@ def odometry_loop(device, frames=100):
         from como_amd.odom.sequential import ComoSeq
         from scripts.gpu_odometry_bench import cfgs
         H, W = 480, 640
-        scene = synth.PlaneScene(seed=1, freq_scale=1.0, device=device)
+        if timed_frames is not None:
+            frames = timed_frames + warm + 24               # the two-frame initialisation succeeds within the first ~10 frames
+        scene = synth.PlaneScene(seed=seed, freq_scale=1.0, device=device)
         K = synth.intrinsics_for(H, W, device=device)
-        T = synth.gt_poses(frames, step=0.01, deg=0.3, device=device)
+        T = synth.gt_poses(frames, step=0.01, deg=0.3 + 0.02 * ((seed - 1) % 5), device=device)
         rgbs = [scene.render(T[k], K, H, W)[0][None, None].repeat(1, 3, 1, 1) for k in range(frames)]
         model = DepthCovModule({k: v.to(device) for k, v in synth.depthcov_state_dict(0).items()})
-        odo = ComoSeq(cfgs(str(device), argparse.Namespace(pix="float")), K.cpu().clone(), (H, W), model)
-        t0, k0, kinds = None, None, []
+        odo = ComoSeq(cfgs(str(device), argparse.Namespace(pix=pix)), K.cpu().clone(), (H, W), model)
+        t0, k0, kinds, k_end = None, None, [], frames
+        k_init = None
         for k in range(frames):
-            kinds.append(odo.iter(1.0 + 0.033 * k, rgbs[k]))
-            if t0 is None and odo.mapping.is_init:
+            if k_init is None and odo.mapping.is_init:
+                k_init = k
+            if t0 is None and k_init is not None and k >= k_init + warm:
+                if barrier is not None:
+                    barrier()
                 torch.cuda.synchronize()
                 t0, k0 = time.perf_counter(), k
+                if timed_frames is not None:
+                    k_end = k + timed_frames
+            if k >= k_end:
+                break
+            kinds.append(odo.iter(1.0 + 0.033 * k, rgbs[k]))
         torch.cuda.synchronize()
-        n = frames - 1 - k0
         el = time.perf_counter() - t0
-        return {"workload": "sequential odometry loop, rendered 640x480 sequence, config/como.yml parameters (9 keyframes, 24 one-way "
-                            "frames, m=64, window 4, float32 tracking, float64 mapping system / float32 pixel kernels)",
-                "value": n / el, "unit": "frames/s", "ms_per_frame": 1e3 * el / n, "frames": n,
-                "keyframes_inserted": kinds.count("keyframe"), "one_way_inserted": kinds.count("one-way")}
+        if barrier is not None:
+            barrier()
+        n = min(k_end, frames) - k0
+        if timed_frames is not None and n != timed_frames:
+            return {"error": f"only {n} of {timed_frames} frames could be timed (initialisation at frame {k_init})"}
+        from como_amd.odom.frontend.photo_tracking import photo_tracking_pyr
+        return {"workload": f"sequential odometry loop, rendered 640x480 sequence (seed {seed}), config/como.yml parameters (9 keyframes, "
+                            f"24 one-way frames, m=64, window 4, float32 tracking, float64 mapping system / {pix} pixel kernels)",
+                "value": n / el, "unit": "frames/s", "ms_per_frame": 1e3 * el / n, "frames": n, "elapsed_s": el,
+                "keyframes_inserted": kinds.count("keyframe"), "one_way_inserted": kinds.count("one-way"),
+                "tracking_chain_fallbacks": int(getattr(photo_tracking_pyr, "fallbacks", 0))}
     except Exception as e:                                  # noqa: BLE001
         return {"error": repr(e)[:300]}
 
@@ -155,18 +192,20 @@ def git_sha():
         return None
 
 
-def committed_traffic(kernel_substr, summary="r2_bench_pmc_summary.json"):
+def committed_traffic(kernel_substr, summaries=("r3_bench_pmc_summary.json", "r2_bench_pmc_summary.json")):
     """HBM bytes per launch of a kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled per the
     gfx950 note of guides/MI355X_MICROARCH.md, WRITE_SIZE as is).  NOT measured by this run: counters need rocprofv3
     around the process (scripts/collect_profiles.sh); the value is labelled with its source file."""
-    path = os.path.join(ROOT, "profiles", summary)
-    try:
-        pm = json.load(open(path))
-        key = [k for k in pm if kernel_substr in k][0]
-        val = (2.0 * pm[key]["FETCH_SIZE"]["avg_per_launch"] + pm[key]["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
-        return val, f"committed_profile:profiles/{summary}:{key[:60]}"
-    except Exception:                                       # noqa: BLE001
-        return None, None
+    for summary in summaries:
+        path = os.path.join(ROOT, "profiles", summary)
+        try:
+            pm = json.load(open(path))
+            key = [k for k in pm if kernel_substr in k][0]
+            val = (2.0 * pm[key]["FETCH_SIZE"]["avg_per_launch"] + pm[key]["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
+            return val, f"committed_profile:profiles/{summary}:{key[:60]}"
+        except Exception:                                   # noqa: BLE001
+            continue
+    return None, None
 
 
 def run_window(args, device, pix_dtype, window, shard=None, seed=None, state=None):
@@ -214,8 +253,10 @@ def block_kernel_roofline(wb, dtype_name, reps=5):
     pixel_pairs = wb.table.b * (0 if wb.idle else wb.n)          # wb.n = this rank's reference pixels per keyframe
     bytes_per = ALGO_SCALARS_PER_PIXEL_PAIR * (4 if dtype_name == "f32" else 8)
     achieved = pixel_pairs * bytes_per / (blk_ms * 1e-3) / 1e9 if blk_ms > 0 else 0.0
-    kname = "ba_blocks_pair2_kernel<2,4>" if dtype_name == "f32" else "ba_blocks_pair2_f64_kernel"
-    traffic, src = committed_traffic("ba_blocks_pair2_kernel" if dtype_name == "f32" else "ba_blocks_pair2_f64")
+    kname = "ba_blocks_pair2_kernel<2,4>" if dtype_name == "f32" else "ba_blocks_ws_f64_kernel"
+    traffic, src = committed_traffic("ba_blocks_pair2_kernel" if dtype_name == "f32" else "ba_blocks_ws_f64")
+    if traffic is None and dtype_name == "f64":
+        traffic, src = committed_traffic("ba_blocks_pair2_f64")
     return {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src, "kernel_ms": blk_ms,
             "algorithmic_bytes_per_launch": pixel_pairs * bytes_per,
@@ -259,12 +300,23 @@ def tracking_leg(device, steps=200):
         algo = N * 53.0
         terr = (lg.T - tp["Tji_gt"]).abs().max().item()
         ach = algo / (us * 1e-6) / 1e9
+        # HBM bytes per ITERATION from the committed counter pass of scripts/track_profile.py (one launch = `iterations_per_launch`
+        # iterations of the same 640x480 level; FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is)
+        tr_iter, tr_src = None, None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r3_track_pmc_summary.json")))
+            key = [k for k in pm if "track_level_kernel" in k][0]
+            per_launch = (2.0 * pm[key]["FETCH_SIZE"]["avg_per_launch"] + pm[key]["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
+            tr_iter = per_launch / float(pm["_meta"]["track_iterations_per_launch"])
+            tr_src = "committed_profile:profiles/r3_track_pmc_summary.json:" + key[:40]
+        except Exception:                                   # noqa: BLE001
+            pass
         return {"workload": f"config 2: 2-frame 640x480 photometric tracking GN iteration, level 0, N={N} reference pixels, float32",
                 "value": steps / el, "unit": "GN iters/s", "us_per_iter": us, "steps": steps, "hip_graph": bool(graphed),
                 "persistent_level_kernel": bool(fused),
                 "pixels_per_s": N * steps / el, "max_pose_abs_err_vs_gt_end": terr,
                 "roofline": {"bound": "hbm", "kernel": "track_level_kernel (per iteration)", "achieved": ach, "peak": HBM_PEAK_GBPS,
-                             "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": None,
+                             "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": tr_iter, "traffic_source": tr_src,
                              "algorithmic_bytes_per_launch": algo, "algorithmic_bytes_per_pixel": 53.0}}
     except Exception as e:                                  # noqa: BLE001
         return {"error": repr(e)[:300]}
@@ -299,22 +351,52 @@ def ate_leg(device):
         return {"error": repr(e)[:300]}
 
 
+def replicas_main(args, shard, device):
+    """Config 5: one sequence per GPU (throughput mode).  Every rank runs its OWN rendered sequence through the whole odometry
+    loop; no collective touches the data path (the barrier / max only bracket the timed region)."""
+    pix = "double" if args.dtype == "f64" else "float"
+    # warm-up run on a short sequence: library load, kernel code objects, the allocator's pools
+    r = odometry_loop(device, seed=1 + shard.rank, pix=pix, warm=args.warmup, barrier=shard.barrier, timed_frames=args.steps)
+    if "error" in r:
+        raise SystemExit("replica sequence failed on rank %d: %s" % (shard.rank, r["error"]))
+    elapsed = shard.max_scalar(r["elapsed_s"], device)
+    per_rank = shard.gather_scalars(r["value"], device)
+    if shard.rank == 0:
+        out = {"metric": "frames/sec, one 640x480 sequence per GPU through the whole odometry loop (config 5, throughput mode)",
+               "value": shard.world * args.steps / elapsed, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": r["workload"] + "; one step = one frame (tracking, keyframe management, DepthCov network + "
+                                      "sampler on every new keyframe, one window-BA GN iteration)",
+                          "parallelism": "replicas: one sequence per GPU, no collective", "frames_per_rank": args.steps,
+                          "keyframes_inserted_rank0": r["keyframes_inserted"], "one_way_inserted_rank0": r["one_way_inserted"],
+                          "tracking_chain_fallbacks_rank0": r["tracking_chain_fallbacks"]},
+               "per_rank_frames_per_s": per_rank, "git": git_sha()}
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
+    shard.barrier()
+    import torch.distributed as tdist
+    if tdist.is_initialized():
+        tdist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--window", type=int, default=1, choices=[1, 2, 4, 8])
-    ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--dtype", default="f64", choices=["f32", "f64"],
+                    help="per-pixel path: f64 = the reference's mapping dtype (config/como.yml:28), f32 = mixed precision")
     ap.add_argument("--keyframes", type=int, default=8)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--no-cpu-dense", action="store_true", help="skip the ONE dense (window 1) oracle iteration of cpu_baseline (~40 s, ~30 GB of host memory)")
+    ap.add_argument("--no-cpu-dense", action="store_true", help="cpu_baseline on the window-4 workload only (skips the two dense oracle iterations: ~20 s, ~30 GB of host memory)")
     ap.add_argument("--eager", action="store_true", help="do not capture the iteration into a hipGraph")
-    ap.add_argument("--no-secondary", action="store_true", help="only the headline leg (no f64 / window-4 / tracking / odometry legs)")
-    ap.add_argument("--replicas", action="store_true", help="config 5: one independent window per GPU, no collective (weak scaling)")
+    ap.add_argument("--no-secondary", action="store_true", help="only the headline leg (no f32 / window-4 / tracking / odometry legs)")
+    ap.add_argument("--replicas", action="store_true", help="config 5: one SEQUENCE per GPU through the whole odometry loop, no collective (weak scaling)")
     ap.add_argument("--force-shard", action="store_true", help="testing on a one-GPU box: run the multi-GPU code path (RCCL "
                     "collectives, sharded medians, fixed-point exchange) through a single-rank process group")
     args = ap.parse_args()
@@ -324,8 +406,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     if shard.world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={shard.world}")
+    if args.replicas:
+        return replicas_main(args, shard, device)
     pix_dtype = torch.float32 if args.dtype == "f32" else torch.float64
-    sharded = shard.world > 1 and not args.replicas
+    sharded = shard.world > 1
     if args.force_shard and shard.world == 1:
         import torch.distributed as tdist
         if not tdist.is_initialized():
@@ -336,14 +420,11 @@ def main():
         sharded = True
 
     # ---- headline leg ----
-    wb, state, graphed = run_window(args, device, pix_dtype, args.window, shard=(shard if sharded else None),
-                                    seed=(args.seed + shard.rank if args.replicas else None))
+    wb, state, graphed = run_window(args, device, pix_dtype, args.window, shard=(shard if sharded else None))
     if not graphed and not args.eager and shard.rank == 0 and not sharded:
         print("hipGraph capture failed:", getattr(wb, "capture_error", "?"), file=sys.stderr)
-    pose0_err = None
     elapsed = shard.max_scalar(timed_steps(wb, args.steps, barrier=shard.barrier), device)
     ms_step = elapsed / args.steps * 1e3
-    total_iters = args.steps * (shard.world if args.replicas else 1)
     roof = block_kernel_roofline(wb, args.dtype)
     import como_amd.odom.backend.linear_system as lin_sys
     info = int(lin_sys.solve_system.last_info)
@@ -351,54 +432,69 @@ def main():
     pose_err0 = (state["kf_poses"] - state["poses_gt"]).abs().max().item()
     npairs = wb.table.b
 
-    legs = {}
+    legs, flat = {}, {}
     single = args.gpus == 1 and not args.no_secondary and args.window == 1 and args.keyframes == 8
     if single:
-        # the reference's mapping dtype: float64 per-pixel path on the same dense window
-        other = "f64" if args.dtype == "f32" else "f32"
+        # the other per-pixel dtype on the same dense window
+        other = "f32" if args.dtype == "f64" else "f64"
         odt = torch.float64 if other == "f64" else torch.float32
         del wb
         torch.cuda.empty_cache()
         wbo, sto, go = run_window(args, device, odt, args.window)
         eo = timed_steps(wbo, args.steps)
         ro = block_kernel_roofline(wbo, other)
-        legs["reference_dtype" if other == "f64" else "mixed_precision"] = {
-            "workload": f"same window, per-pixel path in {other}" + (" (config/como.yml:28 mapping dtype double)" if other == "f64" else ""),
+        name = "mixed_precision" if other == "f32" else "reference_dtype"
+        legs[name] = {
+            "workload": f"same window, per-pixel path in {other}" + (" (config/como.yml:28 mapping dtype double)" if other == "f64"
+                                                                     else " (mixed precision: system / priors / solve / state stay float64)"),
             "dtype": other, "value": args.steps / eo, "unit": "GN iters/s", "ms_per_step": eo / args.steps * 1e3, "steps": args.steps,
             "hip_graph": bool(go), "roofline": ro,
             "max_pose_abs_err_vs_gt_end": (wbo.kf_poses - sto["poses_gt"]).abs().max().item()}
+        flat[f"{name}_{other}_gn_iters_per_s"] = args.steps / eo
+        flat[f"{name}_{other}_ms_per_step"] = eo / args.steps * 1e3
         del wbo, sto
         torch.cuda.empty_cache()
         # the reference's default sub-selection (config/como.yml: nonmax_suppression_window 4, n = 19,200 px / keyframe)
         sec = {}
-        for nm, dt_ in (("f32", torch.float32), ("f64", torch.float64)):
+        for nm, dt_ in (("f64", torch.float64), ("f32", torch.float32)):
             wb4, st4, g4 = run_window(args, device, dt_, 4)
             e4 = timed_steps(wb4, args.steps)
             sec[nm] = {"value": args.steps / e4, "ms_per_step": e4 / args.steps * 1e3, "hip_graph": bool(g4)}
             n4 = wb4.n
             del wb4, st4
-        legs["secondary"] = {"workload": f"same window, nonmax_suppression_window=4 (n={n4} reference px/KF, the reference's default)",
-                             "unit": "GN iters/s", "value": sec["f32"]["value"], "ms_per_step": sec["f32"]["ms_per_step"],
-                             "hip_graph": sec["f32"]["hip_graph"], "dtype": "f32", "f64": sec["f64"]}
+            flat[f"window4_{nm}_gn_iters_per_s"] = sec[nm]["value"]
+            flat[f"window4_{nm}_ms_per_step"] = sec[nm]["ms_per_step"]
+        legs["secondary"] = {"workload": f"same window, nonmax_suppression_window=4 (n={n4} reference px/KF, the reference's default "
+                                         f"= its operating point: config/como.yml:28,37)",
+                             "unit": "GN iters/s", "value": sec["f64"]["value"], "ms_per_step": sec["f64"]["ms_per_step"],
+                             "hip_graph": sec["f64"]["hip_graph"], "dtype": "f64", "f32": sec["f32"]}
         torch.cuda.empty_cache()
         legs["tracking"] = tracking_leg(device)
         legs["odometry_loop"] = odometry_loop(device)
+        if "value" in legs["odometry_loop"]:
+            flat["odometry_loop_frames_per_s"] = legs["odometry_loop"]["value"]
+        if "value" in legs["tracking"]:
+            flat["tracking_us_per_iter"] = legs["tracking"]["us_per_iter"]
         legs["ate_vs_ref"] = ate_leg(device)
+        if "value" in legs["ate_vs_ref"]:
+            flat["ate_vs_ref_rmse_m"] = legs["ate_vs_ref"]["value"]
 
     if shard.rank == 0:
-        mode = "replicas" if args.replicas else ("dp%d (reference-pixel shards of every pair)" % args.gpus)
+        mode = "dp%d (reference-pixel shards of every pair)" % args.gpus
+        cfg = {"workload": f"{args.keyframes}-keyframe {args.width}x{args.height} window BA, {npairs} keyframe pairs, "
+                           f"n={wb_n(state, args)} reference px/KF (window={args.window}), m=64, D={roof_dim(state, args)}; one step = "
+                           f"full GN iteration (scaffold, dense ref, photometric system, priors, Cholesky solve, update)",
+               "pixel_pairs_per_iter": npairs * wb_n(state, args), "system_dim": roof_dim(state, args), "pix_dtype": args.dtype,
+               "system_dtype": "f64", "hip_graph": bool(graphed), "parallelism": mode}
+        cfg.update(flat)
         out = {
             "metric": "GN iters/sec, 8-keyframe 640x480 photometric BA" if args.keyframes == 8 else
                       f"GN iters/sec, {args.keyframes}-keyframe {args.width}x{args.height} photometric BA",
-            "value": total_iters / elapsed, "unit": "GN iters/s", "n_gpus": args.gpus, "steps": args.steps,
+            "value": args.steps / elapsed, "unit": "GN iters/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak" if args.replicas else "strong",
+            "scaling": "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.keyframes}-keyframe {args.width}x{args.height} window BA, {npairs} keyframe pairs, "
-                                   f"n={wb_n(state, args)} reference px/KF (window={args.window}), m=64, D={roof_dim(state, args)}; one step = "
-                                   f"full GN iteration (scaffold, dense ref, photometric system, priors, Cholesky solve, update)",
-                       "pixel_pairs_per_iter": npairs * wb_n(state, args), "system_dim": roof_dim(state, args), "pix_dtype": args.dtype,
-                       "system_dtype": "f64", "hip_graph": bool(graphed), "parallelism": mode},
+            "config": cfg,
             "roofline": roof,
             "solution": {"cholesky_info": info, "max_pose_abs_err_vs_gt_start": pose_err0, "max_pose_abs_err_vs_gt_end": pose_err},
             "git": git_sha(),

@@ -100,6 +100,10 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "como_chol_workspace_bytes": (c_long, [c_int]),
     "como_chol_solve_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "como_chol_small_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "como_chol_small_f64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "como_trsm_lower_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),
+    "como_trsm_lower_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),
     "como_nn_conv2d_f32": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_int, c_void_p]),
     "como_nn_groupnorm_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_float, c_int, c_void_p]),
     "como_nn_maxpool2_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
   __shared__ SelScratch sc;
   constexpr int STG1 = 16 * JP_STRIDE + 64 * 2;       // one pair's staged tile: 16 pose/affine rows + r~ + depth scale
   __shared__ T lds[2 * STG1];                          // [pair]
-  __shared__ T pxs[2][4 * 64];                         // per wave, per pixel of the tile: {sqrt(s0^2+s1^2), g-weight | s0/., s1/.}
+  __shared__ T pxs[2][2 * 64];                         // per wave, per pixel of the tile: {sqrt(s0^2 + s1^2), joint whitened residual}
 
   // robust scale from the finished histograms; sel_resolve is written for 256-thread blocks: feed it 128 threads x 2 rounds
   KeyT prefix; uint32_t k_rem, nv;
@@ -1121,9 +1121,11 @@ __global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
   bool wok = false;
   uint32_t roff_cur = 0, roff_nxt = 0;   // byte offset of this lane's pixel's K~ row inside the slot
 
+  uint32_t pix_s0 = 0;                   // K~ row index of the pixel whose P_w the S0 stage holds (fetched with it, two tiles ahead)
   auto s0_load = [&](int tile) {
     const int ic = min(tile + lane, end - 1);
     pw0 = PwS[ic]; pw1 = PwS[(long)n + ic]; pw2 = PwS[2 * (long)n + ic];
+    pix_s0 = (uint32_t)(PiS ? PiS[ic] : ic);
   };
   auto s1_issue = [&](int tile) {
     const int i = tile + lane;
@@ -1142,12 +1144,12 @@ __global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
 #pragma unroll
     for (int k = 0; k < 6; ++k) Dv[k] = DlS[(long)k * n + ic];
     valv = VaS[(long)ic * pr.C];
-    roff_nxt = (uint32_t)(PiS ? PiS[ic] : ic) * row_bytes;
+    roff_nxt = pix_s0 * row_bytes;
   };
   auto kq_prefetch = [&]() {
     static_for<PF>([&](auto ic_) {
       constexpr int st = decltype(ic_)::value;
-      kq[st] = load4_off(KtB, (uint32_t)__shfl((int)roff_cur, 4 * st + q, 64) + cbyte);
+      kq[st] = load4_off(KtB, (uint32_t)__builtin_amdgcn_ds_bpermute(4 * q + 16 * st, (int)roff_cur) + cbyte);
     });
   };
   auto s2_rows = [&](T* J, T* S) {     // this wave's pair: 16 rows + r~ + depth scale of the tile loaded one stage ago
@@ -1197,11 +1199,24 @@ __global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
     s0_load(begin + 64);
   }
   T* const Jmine = lds + role * STG1;
-  const T* const J0 = lds;
-  const T* const J1 = lds + STG1;
-  const T* const S0 = J0 + 16 * JP_STRIDE;
-  const T* const S1 = J1 + 16 * JP_STRIDE;
+  const T* const S0 = lds + 16 * JP_STRIDE;
+  const T* const S1 = lds + STG1 + 16 * JP_STRIDE;
   T* const my = pxs[role];
+  // Every per-step address of the matrix phase is ONE base register + a compile-time offset (the instruction's offset field);
+  // the 16 steps are fully unrolled with static ring slots, so the compiler counts outstanding loads exactly (a rolled loop
+  // over ring rounds made it wait for vmcnt(0) -- i.e. for K~ quads issued a few hundred cycles earlier -- once per round).
+  const char* const Jc = reinterpret_cast<const char*>(lds) + (c * JP_STRIDE + q) * 8;       // pose row c, pixel q of pair 0
+  const char* const Sq = reinterpret_cast<const char*>(lds + 16 * JP_STRIDE) + q * 8;        // {r~, depth scale} of pixel q, pair 0
+  const char* const Mq = reinterpret_cast<const char*>(my) + q * 16;                         // role 0: {joint weight, joint r~}
+  const int qsel = q * 4;                                                                     // ds_bpermute address of lane q
+  auto refill = [&](auto sl_, auto st_) {
+    constexpr int sl = decltype(sl_)::value, nst = decltype(st_)::value + PF;
+    constexpr bool same = nst < 16;
+    if constexpr (PIPE || same) {
+      const uint32_t off = (uint32_t)__builtin_amdgcn_ds_bpermute(qsel + 16 * (same ? nst : nst - 16), (int)(same ? roff_cur : roff_nxt));
+      kq[sl] = load4_off(KtB, off + cbyte);
+    }
+  };
   for (int tile = begin; tile < end; tile += 64) {
     if constexpr (!PIPE) {
       s0_load(tile);
@@ -1216,74 +1231,52 @@ __global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
       s1_issue(tile + 64);                         // (clamped past the end: harmless re-reads, masked by `inr`)
       s0_load(tile + 128);
     }
-    // per-PIXEL factors once per tile (lane = pixel) instead of once per (pixel, column lane) in every step: the two rows of a
-    // reference pixel share the K~ row scaled by s_g; weight of the joint depth row = sqrt(s_0^2 + s_1^2)
-    {
+    if (role == 0) {
+      // per-PIXEL factors of the joint depth row once per tile (lane = pixel): the two rows of a reference pixel share the K~ row
+      // scaled by their depth scales s_g; weight of the joint row = sqrt(s_0^2 + s_1^2), and its whitened residual
       const T rt0 = S0[lane], rt1 = S1[lane], sz0 = S0[64 + lane], sz1 = S1[64 + lane];
       const T cs = sz0 * sz0 + sz1 * sz1;
       const T rs = cs > T(0) ? fast_rsq(cs) : T(0);
-      my[lane] = cs * rs;                                        // sqrt(s_0^2 + s_1^2)
-      if (role == 0) {
-        my[64 + lane] = (sz0 * rt0 + sz1 * rt1) * rs;            // whitened residual of the joint depth row
-      } else {
-        my[128 + lane] = sz0 * rs;                               // pose rows rescaled for the pose x depth tiles
-        my[192 + lane] = sz1 * rs;
-      }
+      my[2 * lane] = cs * rs;
+      my[2 * lane + 1] = (sz0 * rt0 + sz1 * rt1) * rs;
       wave_lds_sync();
-    }
-    // ring refill of slot sl at step st: the quad of step st + PF of this tile, or (pipelined) of step st + PF - 16 of the next
-    auto refill = [&](int sl, int st) {
-      const int nst = st + PF;
-      const bool same = nst < 16;
-      if (PIPE || same) {
-        const uint32_t off = (uint32_t)__shfl((int)(same ? roff_cur : roff_nxt), 4 * (same ? nst : nst - 16) + q, 64);
-        kq[sl] = load4_off(KtB, off + cbyte);
-      }
-    };
-    if (role == 0) {
-      for (int half = 0; half < 16 / PF; ++half) {
-        static_for<PF>([&](auto ic_) {
-          constexpr int sl = decltype(ic_)::value;
-          const int st = half * PF + sl;
-          const int px = 4 * st + q;
-          const V4<T> k4 = kq[sl];
-          refill(sl, st);
-          const T sc2 = my[px];
-          const T gzs = my[64 + px];
-          // depth columns WITHOUT the 1 / z_m factor: it is constant over pixels and is applied to the accumulators once
-          const T zq[4] = {sc2 * k4.x, sc2 * k4.y, sc2 * k4.z, sc2 * k4.w};
+      static_for<16>([&](auto ic_) {
+        constexpr int st = decltype(ic_)::value;
+        constexpr int sl = st % PF;
+        const double2 pa = *reinterpret_cast<const double2*>(Mq + st * 64);
+        // depth columns WITHOUT the 1 / z_m factor: it is constant over pixels and is applied to the accumulators once
+        const T zq[4] = {pa.x * kq[sl].x, pa.x * kq[sl].y, pa.x * kq[sl].z, pa.x * kq[sl].w};
+        refill(std::integral_constant<int, sl>{}, ic_);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) gv[e] += zq[e] * gzs;
-          static_for<10>([&](auto it) {
-            constexpr int tt = decltype(it)::value + 5;          // tiles 5..14 of the 15-tile enumeration = depth x depth
-            constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
-            acc[tt - 5] = mfma16(zq[ti - 1], zq[tj - 1], acc[tt - 5]);
-          });
+        for (int e = 0; e < 4; ++e) gv[e] += zq[e] * pa.y;
+        static_for<10>([&](auto it) {
+          constexpr int tt = decltype(it)::value + 5;          // tiles 5..14 of the 15-tile enumeration = depth x depth
+          constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
+          acc[tt - 5] = mfma16(zq[ti - 1], zq[tj - 1], acc[tt - 5]);
         });
-      }
+      });
     } else {
-      for (int half = 0; half < 16 / PF; ++half) {
-        static_for<PF>([&](auto ic_) {
-          constexpr int sl = decltype(ic_)::value;
-          const int st = half * PF + sl;
-          const int px = 4 * st + q;
-          const V4<T> k4 = kq[sl];
-          refill(sl, st);
-          const T sc2 = my[px];
-          const T zq[4] = {sc2 * k4.x, sc2 * k4.y, sc2 * k4.z, sc2 * k4.w};
-          const T a00 = J0[c * JP_STRIDE + px], a01 = J1[c * JP_STRIDE + px];
-          const T p0 = a00 * my[128 + px], p1 = a01 * my[192 + px];
-          gv[0] += a00 * S0[px];
-          gv[1] += a01 * S1[px];
-          acc[0] = mfma16(a00, a00, acc[0]);
-          acc[1] = mfma16(a01, a01, acc[1]);
+      static_for<16>([&](auto ic_) {
+        constexpr int st = decltype(ic_)::value;
+        constexpr int sl = st % PF;
+        const T a00 = *reinterpret_cast<const T*>(Jc + st * 32);
+        const T a01 = *reinterpret_cast<const T*>(Jc + STG1 * 8 + st * 32);
+        const T r0 = *reinterpret_cast<const T*>(Sq + st * 32), sz0 = *reinterpret_cast<const T*>(Sq + 64 * 8 + st * 32);
+        const T r1 = *reinterpret_cast<const T*>(Sq + STG1 * 8 + st * 32), sz1 = *reinterpret_cast<const T*>(Sq + STG1 * 8 + 64 * 8 + st * 32);
+        // pose x depth tiles: (pose row x its depth scale) (x) the raw K~ quad (the joint weight cancels: a s/|s| . |s| k)
+        const T p0 = a00 * sz0, p1 = a01 * sz1;
+        gv[0] += a00 * r0;
+        gv[1] += a01 * r1;
+        acc[0] = mfma16(a00, a00, acc[0]);
+        acc[1] = mfma16(a01, a01, acc[1]);
+        const T kk[4] = {kq[sl].x, kq[sl].y, kq[sl].z, kq[sl].w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            acc[2 + e] = mfma16(p0, zq[e], acc[2 + e]);
-            acc[6 + e] = mfma16(p1, zq[e], acc[6 + e]);
-          }
-        });
-      }
+        for (int e = 0; e < 4; ++e) {
+          acc[2 + e] = mfma16(p0, kk[e], acc[2 + e]);
+          acc[6 + e] = mfma16(p1, kk[e], acc[6 + e]);
+        }
+        refill(std::integral_constant<int, sl>{}, ic_);
+      });
     }
     if constexpr (PIPE) roff_cur = roff_nxt;
   }
@@ -1737,36 +1730,58 @@ __global__ __launch_bounds__(256) void ba_reduce_assemble_kernel(
   using Cfg = BACfg;
   constexpr bool FIX = std::is_same<TH, long long>::value;
   constexpr int NE = Cfg::NT * 256 + Cfg::NB * 16 + 1;
+  // Non-finite sums of the sharded (MODE 1 -> all-reduce -> MODE 2) path travel as COUNTS, never as a magic value inside the
+  // summed number (an additive sentinel wraps: 4 ranks x 2^62 = 0): workgroup k of a pair stores its "saw a non-finite sum"
+  // flag into plane (k & 1) of padding slot NE + (k >> 1) of the pair's record -- plain stores, every padding word of the
+  // record is written (the all-reduced buffers are bit-identical from run to run); MODE 2 poisons when any count is nonzero.
+  constexpr int NFLAG_BLOCKS = (Cfg::REC + 255) / 256;
+  static_assert((NFLAG_BLOCKS + 1) / 2 <= Cfg::REC - NE, "one flag word per workgroup fits the record padding");
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int p = blockIdx.y;
-  if (e >= NE) return;
+  if constexpr (MODE == 0) {
+    if (e >= NE) return;
+  }
   double s = 0;
   if constexpr (MODE != 2) {
-    const T* base = partials + (long)p * nrec_per_pair * Cfg::REC + e;
-    // fixed summation order, but 8 loads in flight (one dependent 16 KB-strided load per step was 45 us of this kernel)
-    int w = 0;
-    for (; w + 8 <= nrec_per_pair; w += 8) {
-      T v[8];
+    if (e < NE) {
+      const T* base = partials + (long)p * nrec_per_pair * Cfg::REC + e;
+      // fixed summation order, but 8 loads in flight (one dependent 16 KB-strided load per step was 45 us of this kernel)
+      int w = 0;
+      for (; w + 8 <= nrec_per_pair; w += 8) {
+        T v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = base[(long)(w + q) * Cfg::REC];
+        for (int q = 0; q < 8; ++q) v[q] = base[(long)(w + q) * Cfg::REC];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s += (double)v[q];
+        for (int q = 0; q < 8; ++q) s += (double)v[q];
+      }
+      for (; w < nrec_per_pair; ++w) s += (double)base[(long)w * Cfg::REC];
     }
-    for (; w < nrec_per_pair; ++w) s += (double)base[(long)w * Cfg::REC];
   }
   if constexpr (MODE == 1) {                       // this rank's share of the pair sums, in fixed point (exact all-reduce)
-    long long hi;
-    unsigned long long lo;
-    if (!(fabs(s) < 4.0e18)) { hi = 0x4000000000000000ll; lo = 0; }   // non-finite: an integer part no sum of finite shares reaches
-    else fix_split(s, hi, lo);
-    blocks_fix[2 * ((long)p * Cfg::REC + e)] = hi;
-    blocks_fix[2 * ((long)p * Cfg::REC + e) + 1] = (long long)lo;
+    long long* rec = blocks_fix + 2 * (long)p * Cfg::REC;
+    const bool bad = (e < NE) && !(fabs(s) < 4.0e18);
+    if (e < NE) {
+      long long hi = 0;
+      unsigned long long lo = 0;
+      if (!bad) fix_split(s, hi, lo);
+      rec[2 * e] = hi;
+      rec[2 * e + 1] = (long long)lo;
+    } else if (e < Cfg::REC && e >= NE + (NFLAG_BLOCKS + 1) / 2) {
+      rec[2 * e] = 0;                              // padding beyond the flag words
+      rec[2 * e + 1] = 0;
+    }
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (threadIdx.x == 0) rec[2 * (NE + ((int)blockIdx.x >> 1)) + ((int)blockIdx.x & 1)] = any_bad ? 1 : 0;
+    if ((NFLAG_BLOCKS & 1) && blockIdx.x == 0 && threadIdx.x == 1) rec[2 * (NE + (NFLAG_BLOCKS >> 1)) + 1] = 0;   // the unpaired flag word
     return;
   }
   if constexpr (MODE == 2) {
-    const long long hi = blocks_fix[2 * ((long)p * Cfg::REC + e)];
-    const unsigned long long lo = (unsigned long long)blocks_fix[2 * ((long)p * Cfg::REC + e) + 1];
-    s = (hi >= 0x2000000000000000ll || hi <= -0x2000000000000000ll) ? __builtin_nan("") : fix_value(hi, lo);
+    if (e >= NE) return;
+    const long long* rec = blocks_fix + 2 * (long)p * Cfg::REC;
+    long long nbad = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * ((NFLAG_BLOCKS + 1) / 2); ++k) nbad |= rec[2 * NE + k];
+    s = nbad ? __builtin_nan("") : fix_value(rec[2 * e], (unsigned long long)rec[2 * e + 1]);
   }
   if (pair_blocks) pair_blocks[(long)p * Cfg::REC + e] = s;
   const int slot = pr.ref_slot[p];
@@ -1961,9 +1976,12 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
         }
         else { hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2>), PIPE_ARGS(b, (const int*)nullptr)); }
       } else {
-        // float64 = the reference's mapping dtype.  Default (variant 0): the wave-specialised two-pair kernel (producer / two
-        // consumer waves); the role-split kernel for A/B runs: 5 = software pipeline at two waves per SIMD, 4 = two waves per
-        // SIMD without the pipeline, 3 = pipeline, one wave per SIMD.
+        // float64 = the reference's mapping dtype.  Default (variant 0 = 3): the role-split two-pair kernel, software-pipelined,
+        // ONE wave per SIMD with an 8-deep K~ ring (measured on the dense 8-keyframe window: 601 us with a 4-deep ring; two
+        // waves per SIMD without the pipeline 694 us, with it -- 147 spilled registers -- 1169 us).  A/B variants: 9 = 4-deep
+        // ring, 4 / 5 = two waves per SIMD without / with the pipeline; 6 / 7 / 8 / 10 = the wave-specialised kernel (one
+        // producer + two consumer waves per workgroup: 754 ... 786 us whatever the ring depth -- the dispatcher spreads the
+        // waves over the SIMDs without regard to their role, so some SIMDs host three consumers and others none).
         // (32-bit K~ row offsets: a slot of the predictor must stay below 4 GiB, else the plain kernel)
         const bool fits32 = (unsigned long)A->kt_slot_stride * sizeof(T) < (1ul << 32) && (unsigned long)n * m * sizeof(T) < (1ul << 32);
 #define F64_ARGS                                                                                                      \
@@ -1972,7 +1990,8 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
       (const double*)pair_aff, (const double*)pair_ref, (const double*)A->img_base, (const double*)A->K, A->H, A->W, n,  \
       m, pb, pe, chunk_len, hists, (double*)A->ws_partials, (double*)A->sigma_out, A->grp_pairs
         if (A->variant != 2 && grouped && A->nsingle == 0 && fits32) {
-          if (A->variant == 3) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, true, 1>), F64_ARGS); }
+          if (A->variant == 3 || A->variant == 0) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<8, true, 1>), F64_ARGS); }
+          else if (A->variant == 9) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<4, true, 1>), F64_ARGS); }
           else if (A->variant == 4) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, false, 2>), F64_ARGS); }
           else if (A->variant == 5) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, true, 2>), F64_ARGS); }
           else {
@@ -1985,7 +2004,8 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
             if (A->variant == 6) { hipLaunchKernelGGL((ba_blocks_ws_f64_kernel<4, 4, 3>), WS_ARGS); }
             else if (A->variant == 7) { hipLaunchKernelGGL((ba_blocks_ws_f64_kernel<2, 2, 3>), WS_ARGS); }
             else if (A->variant == 8) { hipLaunchKernelGGL((ba_blocks_ws_f64_kernel<8, 8, 2>), WS_ARGS); }
-            else { hipLaunchKernelGGL((ba_blocks_ws_f64_kernel<4, 2, 3>), WS_ARGS); }
+            else if (A->variant == 10) { hipLaunchKernelGGL((ba_blocks_ws_f64_kernel<4, 2, 3>), WS_ARGS); }
+            else return COMO_ERR_ARG;
 #undef WS_ARGS
           }
         } else {

@@ -275,6 +275,7 @@ int track_iter(const T* Tji, const T* Kmat, const T* aff, const T* P, const T* v
 // the barrier is one non-returning atomic per workgroup (8 counters, one per XCD-aligned residue class) + one polling round.
 // All workgroups must be co-resident: the host launches at most one workgroup per compute unit.
 constexpr int TL_MAXP = 5;          // reference pixels per thread
+constexpr int TL_POISON = 63;       // word of the 64-entry integer plane of the device-wide sums that counts non-finite shares (TRK_ACC <= 63)
 constexpr int TL_NC = 8;            // arrival counters of the device-wide barrier (workgroup b -> counter b % 8)
 constexpr int TL_BAR_WORDS = 32 * (TL_NC + 1);       // counters 128 B apart, then the error flag
 constexpr int TL_SUM_WORDS = 2 * 2 * 64;             // two parities x {integer parts, fractions} x 64 (46 used) 64-bit sums
@@ -416,6 +417,14 @@ __global__ __launch_bounds__(256) void track_level_kernel(
   T mse_prev = __builtin_inff();
   int it = 0;
   bool alive = true;
+  // the result record starts as "no iteration done": the initial pose / affine parameters -- a barrier time-out in the
+  // first iteration (workgroups not co-resident) must not hand uninitialised memory to the caller as the tracked pose
+  if (blockIdx.x == 0 && tid < 24) {
+    if (tid < 16) out[80 + tid] = Tji_init[tid];
+    else if (tid < 18) out[96 + (tid - 16)] = aff_init[tid - 16];
+    else if (tid == 18) out[104] = T(0);
+    else if (tid == 19) out[105] = T(0);
+  }
 
   // RETURNING atomics: the returned value comes from where the read-modify-write was performed (the memory side), so once
   // the wave has it (s_waitcnt in the barrier's __syncthreads) the update is globally performed -- a non-returning atomic is
@@ -574,11 +583,13 @@ __global__ __launch_bounds__(256) void track_level_kernel(
     if (tid < TRK_ACC) {
       // this workgroup's share into the device-wide sums, exact fixed point (common.cuh fix_split): order-independent
       const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-      long long hi;
-      unsigned long long lo;
-      if (!(fabs(v) < 4.0e18)) { hi = 0x2000000000000000ll; lo = 0; }      // non-finite: poisons the sum
-      else fix_split(v, hi, lo);
+      long long hi = 0;
+      unsigned long long lo = 0;
       unsigned long long sink = 0;
+      // non-finite: counted in a dedicated word (sm[63], cleared with the rest of the buffer), never encoded in the summed
+      // value -- an additive sentinel wraps once enough workgroups add it (8 x 2^61 = 0)
+      if (!(fabs(v) < 4.0e18)) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[TL_POISON], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else fix_split(v, hi, lo);
       if (hi) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[tid], (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (lo) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[64 + tid], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       asm volatile("" ::"v"(sink));
@@ -590,7 +601,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
     if (tid < TRK_ACC) {
       const long long hi = ld_dev(&sm[tid]);
       const unsigned long long lo = (unsigned long long)ld_dev(&sm[64 + tid]);
-      tot[tid] = (hi >= 0x1000000000000000ll) ? __builtin_nan("") : fix_value(hi, lo);
+      tot[tid] = (ld_dev(&sm[TL_POISON]) != 0) ? __builtin_nan("") : fix_value(hi, lo);
     }
     __syncthreads();
     TL_STAMP(13);

@@ -7,6 +7,7 @@ fused K~ = K_nm K_mm^-1 run in csrc/densify.hip.  `scale` = scale_prior * exp(sc
 import torch
 
 from como_amd import _lib
+from como_amd.utils.lin_alg import chol_small
 from como_amd.depth_cov.core.gaussian_kernel import interpolate_kernel_params
 from como_amd.utils.coords import normalize_coordinates
 
@@ -86,8 +87,9 @@ def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None, K_mm_in
     if K_mm_inv is None:
         K_mm = covariance(cm, Em, scale)
         K_mm = K_mm + torch.diag_embed((1e-6 * torch.ones(B, m, device=dev)).to(dt))      # float32 jitter as Mapping.py:450
-        L_mm, _ = torch.linalg.cholesky_ex(K_mm, upper=False)
-        K_mm_inv = torch.cholesky_solve(torch.eye(m, dtype=dt, device=dev).expand(B, m, m), L_mm, upper=False).contiguous()
+        # conditioning on the device in ONE launch (csrc/smallsolve.hip): L_mm and K_mm^-1 = L^-T L^-1
+        f = chol_small(K_mm, want_L=True, want_inv=True)
+        L_mm, K_mm_inv = f["L"], f["inv"].contiguous()
     else:
         L_mm = None
         K_mm_inv = K_mm_inv.to(device=dev, dtype=dt).contiguous()

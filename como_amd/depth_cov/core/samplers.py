@@ -12,6 +12,7 @@ from como_amd import _lib
 from como_amd import como_backends
 from como_amd.depth_cov.core import gaussian_kernel as gk
 from como_amd.utils.coords import normalize_coordinates
+from como_amd.utils.lin_alg import chol_small, trsm_lower
 
 
 def get_coords_domain(cov_params_img, border=0):
@@ -36,7 +37,8 @@ def random_uniform(n, coords_domain_norm):
 
 
 def get_obs_info(L, K_mn):
-    return torch.linalg.solve_triangular(L, K_mn, upper=False)
+    """L^-1 K_mn (samplers.py:117-118): forward substitution, one thread per pixel of the domain (csrc/smallsolve.hip)."""
+    return trsm_lower(L, K_mn)
 
 
 def calc_var(obs_info, K_diag):
@@ -71,7 +73,7 @@ def precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_co
         K_nn += torch.diag_embed(curr_var)
     if fixed_var is not None:
         K_nn += torch.diag_embed(fixed_var * torch.ones(b, m, device=dev))
-    L[:, :m, :m] = torch.linalg.cholesky(K_nn, upper=False)
+    L[:, :m, :m] = chol_small(K_nn, want_L=True)["L"]          # the initial factor (torch.linalg.cholesky in the reference)
     K_md = como_backends.cross_covariance(coords_n_norm[:, :m, :], E_n[:, :m, :, :], coords_domain_norm.view(b, -1, 2), E_domain,
                                           scale)
     obs_info[:, :m, :] = get_obs_info(L[:, :m, :m], K_md)

@@ -64,6 +64,14 @@ class Shard:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
+    def gather_scalars(self, v, device):
+        """The value of every rank, in rank order (reporting only: e.g. per-replica throughput)."""
+        t = torch.zeros(self.world, dtype=torch.float64, device=device)
+        t[self.rank] = float(v)
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return [float(x) for x in t.tolist()]
+
     def barrier(self):
         if self.world > 1:
             dist.barrier(group=self.group)

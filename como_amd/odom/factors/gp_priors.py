@@ -2,6 +2,7 @@
 import torch
 
 from como_amd.odom.factors.prior_accumulate import accumulate, logz_chain
+from como_amd.utils.lin_alg import trsm_lower
 
 
 _linv_cache = {}
@@ -16,7 +17,7 @@ def _linv(L_mm):
         return hit[1]
     B, m, _ = L_mm.shape
     eye = torch.eye(m, dtype=L_mm.dtype, device=L_mm.device).expand(B, m, m)
-    Linv = torch.linalg.solve_triangular(L_mm, eye, upper=False)
+    Linv = trsm_lower(L_mm, eye.contiguous()) if L_mm.is_cuda else torch.linalg.solve_triangular(L_mm, eye, upper=False)
     _linv_cache["k"] = (key, Linv)
     return Linv
 

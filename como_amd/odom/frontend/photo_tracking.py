@@ -196,7 +196,9 @@ def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, int
     for t in (Tji_init, Pi, intrinsics, img_j, aff_init, vals_i, dI_dT):
         if not t.is_contiguous() or t.dtype != dt:
             raise RuntimeError("como_amd tracking: inputs must be contiguous and share one dtype")
-    key = str(dev)
+    # one barrier workspace per (device, stream): two level launches running concurrently on different streams must not share
+    # the barrier counters / recycled histograms
+    key = f"{dev}:{torch.cuda.current_stream(dev).cuda_stream}"
     ws = _level_ws.get(key)
     if ws is None:
         ws = torch.zeros(L.como_track_level_workspace_bytes() // 4, device=dev, dtype=torch.int32)
@@ -319,11 +321,27 @@ def photo_tracking_pyr(Tji_init, aff_init, vals_i, Pi, dI_dT, masks, intrinsics,
         pb = _PyrBuffers(vals_i, Pi, dI_dT, img_j, intrinsics)
         _pyr_buffers[key] = pb
     pb.load_reference(vals_i, Pi, dI_dT, masks)
-    Tji = Tji_init.clone()
-    aff = aff_init.clone()
     for l, c in enumerate(pb.levels):
         c["img"].copy_(img_j[l])
         c["K"].copy_(intrinsics[l])
-        Tji, aff = photo_level_tracking(Tji, aff, c["vals"], c["P"], c["dI"], c["img"], c["K"], photo_sigma, term_criteria,
-                                        in_mask=c["mask"])
+
+    def run(fused):
+        Tji, aff, bad = Tji_init.clone(), aff_init.clone(), None
+        for c in pb.levels:
+            photo_level_tracking.last_out = None
+            Tji, aff = photo_level_tracking(Tji, aff, c["vals"], c["P"], c["dI"], c["img"], c["K"], photo_sigma, term_criteria,
+                                            in_mask=c["mask"], fused=fused)
+            rec = photo_level_tracking.last_out
+            if rec is not None:                                # the persistent level kernel ran: [104] < 0 = barrier time-out
+                bad = (rec[104] < 0) if bad is None else (bad | (rec[104] < 0))
+        return Tji, aff, bad
+
+    Tji, aff, bad = run(None)
+    # The persistent kernel's device-wide barrier gives up (instead of hanging) when its workgroups are not co-resident --
+    # another process or concurrent kernels on the GPU; the level's result is then the last completed iteration's state, not
+    # the converged one.  ONE scalar per frame decides (the caller synchronises right after tracking anyway for its keyframe
+    # tests): on a time-out the frame is tracked again by the per-iteration chain.
+    if bad is not None and bool(bad):
+        photo_tracking_pyr.fallbacks = getattr(photo_tracking_pyr, "fallbacks", 0) + 1
+        Tji, aff, _ = run(False)
     return Tji, aff

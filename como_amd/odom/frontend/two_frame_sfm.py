@@ -12,6 +12,7 @@ from como_amd import _lib
 from como_amd.geometry import lie_algebra as lie
 from como_amd.odom.backend import photo
 from como_amd.odom.backend.dense_ref import dense_reference_factored
+from como_amd.utils.lin_alg import chol_small, cholesky_solve_many, trsm_lower
 
 _tables = {}
 
@@ -93,7 +94,7 @@ def linearize_sparse_depth_prior(L_mm):
     """:115-125"""
     B, m, _ = L_mm.shape
     eye = torch.eye(m, device=L_mm.device).unsqueeze(0).repeat(B, 1, 1)
-    dr_dd = torch.linalg.solve_triangular(L_mm, eye.to(L_mm.dtype), upper=False)
+    dr_dd = trsm_lower(L_mm, eye.to(L_mm.dtype))                   # L_mm^-1 (csrc/smallsolve.hip)
     return dr_dd, torch.einsum("hjk,hjl->hkl", dr_dd, dr_dd)
 
 
@@ -125,8 +126,7 @@ def construct_mean_log_depth_prior_system(log_depth, H, g, dr_dd, H_d_d, sigma):
 
 def solve_delta(H, g):
     """:288-293"""
-    L, _ = torch.linalg.cholesky_ex(H, upper=False, check_errors=False)
-    return torch.cholesky_solve(g[:, None], L, upper=False)
+    return chol_small(H, want_L=False, rhs=g[:, None])["X"]        # (6 + m) system: factor + substitutions in one launch
 
 
 def update_vars(T, sparse_log_depth, aff, delta):
@@ -189,7 +189,7 @@ def setup_reference(img_and_grads, sparse_coords_norm, model, cov_params_img, in
     intrinsics_pyr = IntrinsicsPyramidModule(0, len(img_and_grads), dev)(intrinsics, [1.0, 1.0])
     E_m = interpolate_kernel_params(cov_params_img, sparse_coords_norm)
     K_mm = model.cov_modules[-1](sparse_coords_norm, E_m)
-    L_mm, _ = torch.linalg.cholesky_ex(K_mm, upper=False)
+    L_mm = chol_small(K_mm, want_L=True)["L"]
     dr_prior_dd, H_prior_d_d = linearize_sparse_depth_prior(L_mm)
     vals_pyr, coords_pyr, Kt_pyr, sizes = [], [], [], []
     for lvl in img_and_grads:
@@ -198,7 +198,7 @@ def setup_reference(img_and_grads, sparse_coords_norm, model, cov_params_img, in
         cn = normalize_coordinates(coords.to(dt), (h, w))
         E_n = interpolate_kernel_params(cov_params_img, cn)
         K_nm = model.cross_cov_modules[-1](cn, E_n, sparse_coords_norm, E_m)
-        Kt_pyr.append(torch.cholesky_solve(K_nm.transpose(-2, -1), L_mm, upper=False).transpose(-2, -1).contiguous())
+        Kt_pyr.append(cholesky_solve_many(K_nm.transpose(-2, -1).contiguous(), L_mm).transpose(-2, -1).contiguous())
         vals_pyr.append(lvl[:, :c].reshape(lvl.shape[0], c, h * w).contiguous())
         coords_pyr.append(coords)
         sizes.append((h, w))

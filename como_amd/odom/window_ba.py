@@ -346,10 +346,18 @@ class WindowBA:
             hmed, med_out, z_idle = w["hist_dr"], w["med3"], self.idle
         hv = hmed.view(B, 6, 2048)
         state = {"p": 0}
+        # staging buffer of the ONE collective per digit pass (global residual histogram | B median-depth histograms): owned by
+        # the window (a captured graph records its address; nothing is allocated inside the iteration)
+        stage = w.get("hist_stage")
+        if stage is None:
+            stage = w["hist_stage"] = torch.empty((1 + B) * 2048, dtype=torch.int32, device=dev)
+        fork = self.overlap_priors and self._side_stream is not None
+        side = self._side_stream
 
         def reduce_both(h_ba):
             p = state["p"]
-            stage = torch.cat((h_ba, hv[:, p].reshape(-1)))
+            stage[:2048].copy_(h_ba)
+            stage[2048:].view(B, 2048).copy_(hv[:, p])
             red(stage)                                     # ONE collective per digit pass for both exact medians
             h_ba.copy_(stage[:2048])
             hv[:, p].copy_(stage[2048:].view(B, 2048))
@@ -357,6 +365,17 @@ class WindowBA:
                 _lib.check(getattr(L, "como_select_hist_" + sfx)(zmed.data_ptr(), None, zmed.shape[1], B, hmed.data_ptr(), p + 1, s),
                            "como_select_hist")
             state["p"] = p + 1
+            if p + 1 == npass and fork:
+                # every digit of the median depths is resolved: their finish + the prior factors (which only ADD into the
+                # fixed-point system) run on the side stream beside the block kernel, the exchange of the pair sums and
+                # their expansion -- the same two-branch shape as the single-GPU chain
+                main = torch.cuda.current_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    ss = _lib.stream_ptr(dev)
+                    _lib.check(getattr(L, "como_select_finish_" + sfx)(hmed.data_ptr(), B, med_out.data_ptr(), ss), "como_select_finish")
+                    if self.with_priors:
+                        _lib.check(L.como_win_priors(ctypes.byref(a), ss), "como_win_priors")
 
         photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=Pwn, vals=self.vals_n,
                                     dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],
@@ -365,9 +384,12 @@ class WindowBA:
                                     events=self.events, zeroed_hists=w["hist_ba"], ws=w["ba_ws"], sysfix=self.sysfix,
                                     fix_plane=self.fix_plane, D=self.dim, reduce_blocks=red)
         assert state["p"] == npass
-        _lib.check(getattr(L, "como_select_finish_" + sfx)(hmed.data_ptr(), B, med_out.data_ptr(), s), "como_select_finish")
-        if self.with_priors:
-            _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")
+        if fork:
+            torch.cuda.current_stream(dev).wait_stream(side)
+        else:
+            _lib.check(getattr(L, "como_select_finish_" + sfx)(hmed.data_ptr(), B, med_out.data_ptr(), s), "como_select_finish")
+            if self.with_priors:
+                _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")
         _lib.check(L.como_sys_finalize(self.sysfix.data_ptr(), self.fix_plane, self.dim, self.H.data_ptr(), self.g.data_ptr(),
                                        self.err8.data_ptr(), s), "como_sys_finalize")
         return self.H, self.g

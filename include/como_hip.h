@@ -304,6 +304,26 @@ int como_chol_solve_f64(const double* H, const double* g, double* delta, void* w
                         como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Conditioning of the small SPD systems of the DepthCov path (n <= 80), batched: ONE launch, one workgroup per matrix, float32
+ * or float64.  Replaces torch.linalg.cholesky(_ex) + torch.cholesky_solve where the reference conditions m x m systems:
+ * K_mm + 1e-6 I -> L_mm, K_mm^-1 (como/odom/Mapping.py:450-458); get_predictor and the distillation's normal equations
+ * (depth_cov/core/distill_depth.py:30-48, utils/lin_alg.py:82-87); the sampler's initial factor (depth_cov/core/samplers.py:
+ * 110-165); the (6 + m) two-frame solve (odom/frontend/two_frame_sfm.py:288-293).
+ * A (B,n,n) row-major, lower triangle read.  Optional outputs (NULL = not wanted): L (B,n,n) lower factor (upper triangle
+ * zero), Ainv (B,n,n) = A^-1 (symmetric, both triangles), X (B,n,k) = A^-1 rhs for rhs (B,n,k) (rhs and X go together);
+ * info (B) = 0 or the order of the first non-positive leading minor (torch.linalg.cholesky_ex's info; nothing is raised). */
+int como_chol_small_f32(const float* A, int B, int n, float* L, float* Ainv, const float* rhs, int k, float* X, int* info,
+                        como_stream_t stream);
+int como_chol_small_f64(const double* A, int B, int n, double* L, double* Ainv, const double* rhs, int k, double* X, int* info,
+                        como_stream_t stream);
+/* X (B,n,d) = L^-1 Bm: forward substitution with a lower-triangular L (B,n,n), n <= 64, for MANY right-hand sides Bm (B,n,d)
+ * (torch.linalg.solve_triangular(L, K, upper=False): samplers.py:117-118 get_obs_info with d = the whole pixel domain;
+ * two_frame_sfm.py:115-125 with Bm = I).  trans != 0: X = L^-T Bm (backward substitution) -- the two calls in sequence are
+ * torch.cholesky_solve(Bm, L) for many columns (two_frame_sfm.py:363-366: K_mm^-1 K_mn over every pixel).  X may alias Bm. */
+int como_trsm_lower_f32(const float* L, const float* Bm, float* X, int B, int n, long d, int trans, como_stream_t stream);
+int como_trsm_lower_f64(const double* L, const double* Bm, double* X, int B, int n, long d, int trans, como_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused O(B*m) bookkeeping of one window GN iteration (python path: Mapping.prep_geometry_scaffold
  * Mapping.py:603-659 + sparse_map.py:18-60; the prior factors of Mapping.iterate :809-917 = odom/factors/*.py;
  * linear_system.update_vars :115-152).  All state is float64; px_* are mirrors in the per-pixel dtype. */

@@ -202,3 +202,57 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
     assert d["metric"] and d["roofline"]["kernel_ms"] > 0 and d["solution"]["cholesky_info"] == 0
     assert d["solution"]["max_pose_abs_err_vs_gt_end"] < d["solution"]["max_pose_abs_err_vs_gt_start"]
+
+
+def test_bench_replicas_one_sequence_per_rank():
+    """BASELINE config 5 (one SEQUENCE per GPU, throughput mode) as `bench.py --replicas` runs it: every rank drives its own
+    rendered 640x480 sequence through the whole odometry loop (tracking, keyframe management, DepthCov network + sampler on
+    every new keyframe, one window-BA iteration per frame), no data-path collective.  One-GPU test rig: both ranks on device 0
+    (their kernels interleave), gloo for the bracketing barrier / max."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, COMO_SINGLE_DEVICE="1", COMO_DIST_BACKEND="gloo")
+    port = 29400 + (os.getpid() % 200)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--replicas", "--gpus", "2",
+                        "--steps", "30", "--warmup", "2"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 30 and d["scaling"] == "weak" and d["unit"] == "frames/s"
+    assert len(d["per_rank_frames_per_s"]) == 2 and min(d["per_rank_frames_per_s"]) > 0
+    assert d["value"] > 0 and abs(d["value"] - 2 * 30 / (d["ms_per_step"] * 30 / 1e3)) < 1e-6 * d["value"]
+    assert d["config"]["frames_per_rank"] == 30
+
+
+def test_replica_sequences_share_one_gpu():
+    """Config 5's correctness: two replica PROCESSES on the one GPU, started 0 s and 1.5 s after their contexts are up so that
+    their phases (two-frame initialisation, keyframe insertions, persistent tracking launches) collide differently, each running
+    the 72-frame sequence of tests/golden/ate_sequence.npz through the whole loop.  Each trajectory must match the REFERENCE's own
+    (same request on every frame, ATE-RMSE < 2e-5 m) -- in particular when another process's kernels keep the persistent tracking
+    kernel's workgroups from being co-resident (its barrier then gives up and the frame falls back to the per-iteration chain)."""
+    import json
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tmp = tempfile.mkdtemp()
+    procs = []
+    for rank, delay in ((0, 0.0), (1, 1.5)):
+        out = os.path.join(tmp, f"replica{rank}.json")
+        procs.append((out, subprocess.Popen([sys.executable, os.path.join(root, "scripts", "replica_ate_check.py"), "--rank", str(rank),
+                                             "--delay", str(delay), "--out", out], cwd=root, stdout=subprocess.PIPE,
+                                            stderr=subprocess.PIPE, text=True)))
+    res = []
+    for out, p in procs:
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, se[-2000:]
+        res.append(json.load(open(out)))
+    for r in res:
+        assert r["tracked"] >= 60 and r["same_decisions"] == r["frames"] and r["kf_timestamps_equal"], r
+        assert r["ate_rmse"] < 2e-5 and r["worst_pose_abs"] < 5e-5, r
+    # the two runs really overlapped in time
+    assert res[1]["delay"] < res[0]["seconds"], res

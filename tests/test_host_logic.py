@@ -215,15 +215,14 @@ def test_trajectory_io_roundtrip(tmp_path):
 
 def test_slabwise_gram_equals_direct():
     """distill_depth._gram (256-slab batched GEMM for tall least-squares systems) == A^T A, A^T b."""
-    from como_amd.depth_cov.core.distill_depth import _gram, lstsq_chol
+    from como_amd.depth_cov.core.distill_depth import _gram
     g = torch.Generator().manual_seed(5)
     for n in (100, 4096, 10007):
         A = torch.randn((1, n, 7), generator=g, dtype=torch.float64)
         b = torch.randn((1, n, 1), generator=g, dtype=torch.float64)
         AtA, Atb = _gram(A, b)
         assert rel(AtA, A.mT @ A) < 1e-13 and rel(Atb, A.mT @ b) < 1e-12
-        x = lstsq_chol(A, b)
-        assert rel(x, torch.linalg.lstsq(A, b).solution) < 1e-9
+    # (the solve of the normal equations runs in csrc/smallsolve.hip: tests/test_gpu_r3.py::test_small_spd_conditioning)
 
 
 def test_pair_graph_radius_and_degree_edges_vs_reference():
