@@ -253,10 +253,8 @@ def block_kernel_roofline(wb, dtype_name, reps=5):
     pixel_pairs = wb.table.b * (0 if wb.idle else wb.n)          # wb.n = this rank's reference pixels per keyframe
     bytes_per = ALGO_SCALARS_PER_PIXEL_PAIR * (4 if dtype_name == "f32" else 8)
     achieved = pixel_pairs * bytes_per / (blk_ms * 1e-3) / 1e9 if blk_ms > 0 else 0.0
-    kname = "ba_blocks_pair2_kernel<2,4>" if dtype_name == "f32" else "ba_blocks_ws_f64_kernel"
-    traffic, src = committed_traffic("ba_blocks_pair2_kernel" if dtype_name == "f32" else "ba_blocks_ws_f64")
-    if traffic is None and dtype_name == "f64":
-        traffic, src = committed_traffic("ba_blocks_pair2_f64")
+    kname = "ba_blocks_pair2_kernel<2,4>" if dtype_name == "f32" else "ba_blocks_pair2_f64_kernel<4,true,1>"
+    traffic, src = committed_traffic("ba_blocks_pair2_kernel" if dtype_name == "f32" else "ba_blocks_pair2_f64")
     return {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src, "kernel_ms": blk_ms,
             "algorithmic_bytes_per_launch": pixel_pairs * bytes_per,

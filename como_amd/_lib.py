@@ -92,6 +92,8 @@ SIGNATURES = {
     "como_greedy_next_f32": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "como_dense_ref_f32": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8 + [c_int, c_void_p]),
     "como_dense_ref_f64": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8 + [c_int, c_void_p]),
+    "como_depth_band_f32": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, c_void_p]),
+    "como_depth_band_f64": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, c_void_p]),
     "como_kernel_matrix_f32": (c_int, [c_void_p] * 4 + [c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "como_kernel_matrix_f64": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int, c_int, c_int, c_void_p]),
     "como_ktilde_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,

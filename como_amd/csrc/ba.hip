@@ -1976,10 +1976,10 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
         }
         else { hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2>), PIPE_ARGS(b, (const int*)nullptr)); }
       } else {
-        // float64 = the reference's mapping dtype.  Default (variant 0 = 3): the role-split two-pair kernel, software-pipelined,
-        // ONE wave per SIMD with an 8-deep K~ ring (measured on the dense 8-keyframe window: 601 us with a 4-deep ring; two
-        // waves per SIMD without the pipeline 694 us, with it -- 147 spilled registers -- 1169 us).  A/B variants: 9 = 4-deep
-        // ring, 4 / 5 = two waves per SIMD without / with the pipeline; 6 / 7 / 8 / 10 = the wave-specialised kernel (one
+        // float64 = the reference's mapping dtype.  Default (variant 0): the role-split two-pair kernel, software-pipelined,
+        // ONE wave per SIMD with a 4-deep K~ ring: 580 us on the dense 8-keyframe window (8-deep ring, variant 3: 615 us; two
+        // waves per SIMD without the pipeline, variant 4: 679 us; with it -- 147 spilled registers --, variant 5: 1169 us).
+        // 9 = 2-deep ring; 6 / 7 / 8 / 10 = the wave-specialised kernel (one
         // producer + two consumer waves per workgroup: 754 ... 786 us whatever the ring depth -- the dispatcher spreads the
         // waves over the SIMDs without regard to their role, so some SIMDs host three consumers and others none).
         // (32-bit K~ row offsets: a slot of the predictor must stay below 4 GiB, else the plain kernel)
@@ -1990,8 +1990,9 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
       (const double*)pair_aff, (const double*)pair_ref, (const double*)A->img_base, (const double*)A->K, A->H, A->W, n,  \
       m, pb, pe, chunk_len, hists, (double*)A->ws_partials, (double*)A->sigma_out, A->grp_pairs
         if (A->variant != 2 && grouped && A->nsingle == 0 && fits32) {
-          if (A->variant == 3 || A->variant == 0) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<8, true, 1>), F64_ARGS); }
-          else if (A->variant == 9) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<4, true, 1>), F64_ARGS); }
+          if (A->variant == 0) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<4, true, 1>), F64_ARGS); }
+          else if (A->variant == 3) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<8, true, 1>), F64_ARGS); }
+          else if (A->variant == 9) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<2, true, 1>), F64_ARGS); }
           else if (A->variant == 4) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, false, 2>), F64_ARGS); }
           else if (A->variant == 5) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, true, 2>), F64_ARGS); }
           else {

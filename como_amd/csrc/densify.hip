@@ -256,6 +256,106 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
   sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
 }
 
+template <typename T>
+__global__ void copy_elems_kernel(const T* __restrict__ src, T* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+// ---- full-image median depth without re-reading K~ (Mapping.store_vars, Mapping.py:749-758) ---------------------------
+// With sub-selected reference pixels (nonmax window > 1) the priors and the landmark re-initialisation still need the exact
+// per-keyframe median of the FULL depth image z_n = exp(K~[n,:] logz_m): a depth-only pass over all H W rows of K~ per GN
+// iteration (630 MB at 8 x 640x480 in float32), only to find ONE order statistic.  Between two iterations logz_m moves by a
+// small step, and |delta logz_n| <= ||K~[n,:]||_1 max_k |delta logz_m,k|: a pixel whose cached log-depth interval
+// [lref - err, lref + err] lies wholly on one side of where the new median can be is counted without being evaluated.
+//   state per pixel : lref (log-depth at its last exact evaluation), err (bound on its drift since then), l1 (||K~ row||_1)
+//   per keyframe    : logzm_prev (log-depths at the previous call), l1max, the previous exact median (med_prev3[b][0])
+//   new median in   : [log med_prev - l1max delta, log med_prev + l1max delta]      (every pixel moves by at most l1max delta)
+// A pixel below that interval writes depth 0, one above it +inf, a CANDIDATE is evaluated exactly (and its state refreshed):
+// the median of the resulting plane IS the exact median of the full image as long as the true median is a candidate's value,
+// which the interval guarantees.  The usual select passes run on the plane unchanged.  init != 0: every pixel is a candidate
+// (builds the state).  Cost: 3 state planes read (+ rewritten where they change) + the candidates' K~ rows.
+template <typename T>
+__global__ __launch_bounds__(256) void depth_band_kernel(
+    const T* __restrict__ Kt, long kt_slot_stride, const T* __restrict__ logzm, const T* __restrict__ logzm_prev, int rows, int m,
+    T* __restrict__ lref, T* __restrict__ err, T* __restrict__ l1, float* __restrict__ l1max, const T* __restrict__ med_prev3,
+    T* __restrict__ zbuf, uint32_t* __restrict__ hists, unsigned* __restrict__ ncand, int init) {
+  using KeyT = typename KeyOf<T>::type;
+  __shared__ uint32_t lh[SEL_BINS];
+  __shared__ T coef[64];
+  __shared__ T sdelta, sabs;
+  const int b = blockIdx.y;
+  for (int k = threadIdx.x; k < SEL_BINS; k += 256) lh[k] = 0;
+  if (threadIdx.x < 64) {
+    const int k = threadIdx.x;
+    const T cur = (k < m) ? logzm[(long)b * m + k] : T(0);
+    const T prv = (k < m && !init) ? logzm_prev[(long)b * m + k] : cur;
+    coef[k] = cur;
+    T d = fabs(cur - prv), a = fabs(cur);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { d = fmax(d, __shfl_xor(d, off, 64)); a = fmax(a, __shfl_xor(a, off, 64)); }
+    if (k == 0) { sdelta = d; sabs = a; }
+  }
+  __syncthreads();
+  // rounding head-room of one evaluated dot product (m terms) relative to ||row||_1 max|logz_m|
+  const T eps = (sizeof(T) == 4) ? T(4e-6) : T(4e-15);
+  const T delta = sdelta * (T(1) + T(64) * eps) + (sdelta > T(0) ? eps : T(0));
+  const T mp = init ? T(0) : log(med_prev3[3 * b]);
+  const T band = init ? T(0) : (T)l1max[b] * delta + eps * (fabs(mp) + T(1));
+  const T inf = (T)__builtin_inff();
+  const int stride = gridDim.x * 256;
+  unsigned mycand = 0;
+  float myl1max = 0.f;
+  for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 - (int)threadIdx.x < rows; i0 += stride) {
+    const bool inr = i0 < rows;
+    const int i = inr ? i0 : rows - 1;
+    const long si = (long)b * rows + i;
+    bool cand = init != 0;
+    T e = T(0), lr = T(0), rl1 = T(0);
+    if (!init) {
+      rl1 = l1[si];
+      lr = lref[si];
+      e = err[si] + rl1 * delta;
+      cand = !((lr + e < mp - band) || (lr - e > mp + band));            // (NaN anywhere -> candidate)
+    }
+    T z;
+    if (cand) {
+      const T* Kr = Kt + (long)b * kt_slot_stride + (long)i * m;
+      T acc = T(0), s1 = T(0);
+      for (int j = 0; j < m; j += 4) {
+        const Q4<T> kv = ld4(Kr + j);
+        const T kk[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc += kk[q] * coef[j + q]; s1 += fabs(kk[q]); }
+      }
+      z = exp(acc);                                                       // depth.py:6-9
+      if (inr) {
+        lref[si] = acc;
+        err[si] = eps * (s1 * sabs + T(1));
+        if (init) { l1[si] = s1; myl1max = fmaxf(myl1max, (float)s1 * 1.000001f); }
+        ++mycand;
+      }
+    } else {
+      z = (lr < mp) ? T(0) : inf;
+      if (inr) err[si] = e;
+    }
+    if (inr) zbuf[si] = z;
+    sel_lds_add(lh, sel_digit<KeyT>(abs_key(z), 0), inr);
+  }
+  if (init) {                                                             // positive floats order like their bit patterns
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) myl1max = fmaxf(myl1max, __shfl_xor(myl1max, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax((unsigned*)&l1max[b], __float_as_uint(myl1max));
+  }
+  if (ncand) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mycand += __shfl_xor(mycand, off, 64);
+    if ((threadIdx.x & 63) == 0 && mycand) atomicAdd(&ncand[b], mycand);
+  }
+  __syncthreads();
+  sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
+}
+
 // ---- K~ --------------------------------------------------------------------------------------------------------
 // bilinear lookup with border padding at normalised (row, col) coordinates (grid_sample align_corners=False)
 template <typename T>
@@ -441,6 +541,28 @@ int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx,
   if (rc || (flags & 2)) return rc;
   return como_select_finish_f64(hists, B, med_out3, stream);
 }
+
+#define COMO_DEF_BAND(SFX, T)                                                                                          \
+  int como_depth_band_##SFX(const T* Kt, long kt_slot_stride, const T* logzm, T* logzm_prev, int B, int rows, int m, T* lref,  \
+                            T* err, T* l1, float* l1max, const T* med_prev3, T* zbuf, void* hists, unsigned* ncand, int init,  \
+                            como_stream_t stream) {                                                                            \
+    if (!Kt || !logzm || !logzm_prev || !lref || !err || !l1 || !l1max || !med_prev3 || !zbuf || !hists || B <= 0 ||          \
+        rows <= 0 || m <= 0 || m > 64 || (m & 3))                                                                             \
+      return COMO_ERR_ARG;                                                                                                    \
+    int gx = (rows + 255) / 256;                                                                                              \
+    if (gx > 512) gx = 512;                                                                                                   \
+    hipLaunchKernelGGL(como::depth_band_kernel<T>, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, Kt, kt_slot_stride, logzm,  \
+                       (const T*)logzm_prev, rows, m, lref, err, l1, l1max, med_prev3, zbuf, (uint32_t*)hists, ncand, init);   \
+    COMO_CHECK_LAUNCH();                                                                                                      \
+    /* the log-depths this call was evaluated at become the next call's reference: a KERNEL node (select.cuh: captured  */    \
+    /* memset / memcpy nodes are avoided in replayed graphs), after the band kernel on the same stream                   */    \
+    hipLaunchKernelGGL(como::copy_elems_kernel<T>, dim3((B * m + 255) / 256), dim3(256), 0, (hipStream_t)stream, logzm,        \
+                       logzm_prev, B * m);                                                                                    \
+    COMO_CHECK_LAUNCH();                                                                                                      \
+    return COMO_OK;                                                                                                           \
+  }
+COMO_DEF_BAND(f32, float)
+COMO_DEF_BAND(f64, double)
 
 #define COMO_DEF_KMAT(SFX, T)                                                                                          \
   int como_kernel_matrix_##SFX(const T* x1, const T* E1, const T* x2, const T* E2, T scale, T* out, int B, int N, int M, \

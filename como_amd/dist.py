@@ -58,6 +58,11 @@ class Shard:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def all_reduce_max(self, t):
+        if self.world > 1 or self.force:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
     def max_scalar(self, v, device):
         t = torch.tensor([v], dtype=torch.float64, device=device)
         if self.world > 1:

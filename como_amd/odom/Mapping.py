@@ -28,6 +28,7 @@ from como_amd.odom.frontend.corr import track_and_init
 from como_amd.odom.frontend.TwoFrameSfm import TwoFrameSfm
 from como_amd.odom.window_ba import WindowBA
 from como_amd.utils.coords import swap_coords_xy
+from como_amd.utils.select import masked_median
 from como_amd.depth_cov.nn.UNet import resize_aa
 from como_amd.utils.image_processing import ImageGradientModule, rgb_to_grayscale
 
@@ -194,7 +195,9 @@ class Mapping:
         self.pm, self.logzm = pm, logzm
         self._depth_cache = None
         d = self.depth_imgs
-        self.median_depths = torch.median(d.reshape(d.shape[0], -1), dim=1).values
+        d2 = d.reshape(d.shape[0], -1)
+        # per-keyframe exact median of the full depth image: one segmented device select instead of B sorts
+        self.median_depths = masked_median(d2).to(d2.dtype) if d2.is_cuda else torch.median(d2, dim=1).values
 
     # ---- keyframe insertion (Mapping.py:138-229) -------------------------------------------------------------------------
     def init_keyframe(self, rgb, cov_params_img, coords_m, pose_init, logz_m, aff_init, timestamp):

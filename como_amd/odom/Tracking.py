@@ -16,6 +16,7 @@ from como_amd.geometry.lie_algebra import invertSE3
 from como_amd.geometry.transforms import get_rel_pose, get_T_w_curr
 from como_amd.odom.frontend.photo_tracking import photo_tracking_pyr, precalc_jacobians
 from como_amd.utils.coords import fill_image, get_test_coords, swap_coords_xy
+from como_amd.utils.select import masked_median
 from como_amd.utils.image_processing import (DepthPyramidModule, ImageGradientModule, ImagePyramidModule,
                                              IntrinsicsPyramidModule, rgb_to_grayscale)
 
@@ -192,7 +193,9 @@ class Tracking:
         reproj = self.get_reproj_last_kf(self.T_curr_kf)
         seen = ~torch.isnan(reproj)
         n_seen = torch.count_nonzero(seen)
-        median_depth = torch.median(reproj[seen])
+        # exact median of the seen depths (all positive: in front of the camera) by the device select -- no boolean-mask gather,
+        # no sort, no synchronisation (Tracking.py:345 torch.median(reproj[seen]))
+        median_depth = masked_median(reproj.reshape(-1), seen.reshape(-1)) if reproj.is_cuda else torch.median(reproj[seen])
         self.last_reproj_stats = (n_seen, median_depth)
 
         if self.check_keyframe(median_depth, n_seen, self.T_curr_kf):

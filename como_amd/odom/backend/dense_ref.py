@@ -60,10 +60,18 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
     return ws["Pwn"], ws["dT"], ws["uvec"], med[:, 0], ws["logz"]
 
 
-def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=None):
+BAND_MEDIAN = __import__("os").environ.get("COMO_BAND_MEDIAN", "1") != "0"
+
+
+def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=None, band=None, reduce_max=None):
     """Mapping.store_vars (Mapping.py:749-758): per keyframe the exact median of exp(K~ logz_m) over ALL rows of K~
     (the full depth image).  logzm (B,m), Kt (B,rows,m); med_out (B,3) caller-owned {median, 1.4826 median, n};
     ws: caller-owned dict (depth plane + select histograms; a captured graph records the addresses).
+    band (default: on, COMO_BAND_MEDIAN=0 disables): `como_depth_band_*` instead of the depth-only pass -- only the pixels whose
+    cached log-depth interval can straddle the new median are re-evaluated (state kept in `ws`; med_out must then be the SAME
+    buffer on every call: it holds the previous median); the first call with a given `ws` builds the state.  Exact either way.
+    reduce_max(t): multi-GPU (Kt = this rank's rows): all-reduce(MAX) applied ONCE, to the per-keyframe largest row norm when the
+    state is built -- the bound on how far the GLOBAL median can move must cover every rank's rows.
     part: "all", or "points" (kernel + pass-0 histogram) then "median" (remaining select passes + finish).
     reduce: multi-GPU -- Kt is then this rank's ROW RANGE of every keyframe's predictor (a view) and the digit histograms
     are all-reduced between the passes (median_passes), so every rank gets the median of the whole image."""
@@ -88,10 +96,37 @@ def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=Non
         part_flag = 2                                    # kernel + pass-0 histogram here, the passes below
     else:
         part_flag = {"all": 0, "points": 2, "median": 4}[part]
-    rc = fn(Kt.data_ptr(), Kt.stride(0), None, lz.data_ptr(), w["eye"].data_ptr(), w["K"].data_ptr(), w["dl"].data_ptr(), B, rows, m,
-            1, None, None, None, w["z"].data_ptr(), None, h.data_ptr(), med_out.data_ptr(), None,
-            8 | (1 if hists is not None else 0) | part_flag, _lib.stream_ptr(dev))
-    _lib.check(rc, "como_dense_ref (depth only)")
+    use_band = (BAND_MEDIAN if band is None else band) and hists is not None and part_flag != 4
+    if use_band:
+        st = w.get("band")
+        init = st is None
+        if init:
+            st = w["band"] = {"lref": torch.zeros((B, rows), device=dev, dtype=dt), "err": torch.zeros((B, rows), device=dev, dtype=dt),
+                              "l1": torch.zeros((B, rows), device=dev, dtype=dt), "l1max": torch.zeros(B, device=dev, dtype=torch.float32),
+                              "prev": torch.zeros((B, m), device=dev, dtype=dt), "ncand": torch.zeros(B, device=dev, dtype=torch.int32),
+                              "calls": 0, "med": med_out.data_ptr()}
+        if st["med"] != med_out.data_ptr():
+            raise RuntimeError("como_amd full_image_median: the band state belongs to another med_out buffer (it carries the previous median)")
+        st["calls"] += 1
+        if not lz.is_contiguous():
+            lz = lz.contiguous()
+        rc = getattr(L, "como_depth_band_" + _lib.suffix(dt))(
+            Kt.data_ptr(), Kt.stride(0), lz.data_ptr(), st["prev"].data_ptr(), B, rows, m, st["lref"].data_ptr(), st["err"].data_ptr(),
+            st["l1"].data_ptr(), st["l1max"].data_ptr(), med_out.data_ptr(), w["z"].data_ptr(), h.data_ptr(), st["ncand"].data_ptr(),
+            1 if init else 0, _lib.stream_ptr(dev))
+        _lib.check(rc, "como_depth_band")
+        if init and reduce_max is not None:
+            reduce_max(st["l1max"])
+        if part_flag == 0:                               # "all": the remaining select passes + finish right away
+            rc = fn(Kt.data_ptr(), Kt.stride(0), None, lz.data_ptr(), w["eye"].data_ptr(), w["K"].data_ptr(), w["dl"].data_ptr(), B,
+                    rows, m, 1, None, None, None, w["z"].data_ptr(), None, h.data_ptr(), med_out.data_ptr(), None, 8 | 1 | 4,
+                    _lib.stream_ptr(dev))
+            _lib.check(rc, "como_dense_ref (median of the band plane)")
+    else:
+        rc = fn(Kt.data_ptr(), Kt.stride(0), None, lz.data_ptr(), w["eye"].data_ptr(), w["K"].data_ptr(), w["dl"].data_ptr(), B, rows,
+                m, 1, None, None, None, w["z"].data_ptr(), None, h.data_ptr(), med_out.data_ptr(), None,
+                8 | (1 if hists is not None else 0) | part_flag, _lib.stream_ptr(dev))
+        _lib.check(rc, "como_dense_ref (depth only)")
     if reduce == "defer":
         return w["z"]                                    # the caller drives the select passes (shared all-reduces)
     if reduce is not None:

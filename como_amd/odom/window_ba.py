@@ -333,7 +333,8 @@ class WindowBA:
         #     reference itself (every pixel a reference pixel); its select passes ride on the residual median's all-reduces
         if self.full_median:
             rb, re = self.row_range
-            zmed = full_image_median(w["px_logzm"], self.Kt[:, rb:re], w["med3_full"], w["dr_ws"], hists=w["hist_full"], reduce="defer")
+            zmed = full_image_median(w["px_logzm"], self.Kt[:, rb:re], w["med3_full"], w["dr_ws"], hists=w["hist_full"], reduce="defer",
+                                     reduce_max=self.shard.all_reduce_max)
             hmed, med_out, z_idle = w["hist_full"], w["med3_full"], False
         if not self.idle:
             Pwn, dT, uvec, _, _ = dr("points")

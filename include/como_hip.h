@@ -279,6 +279,22 @@ int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx,
                        double* dPwn_dTwc, double* uvec, double* zbuf, double* logzn_out, void* hists, double* med_out3,
                        const int* pixcoord, int flags, como_stream_t stream);
 
+/* Mapping.store_vars' full-image median depth (Mapping.py:749-758) WITHOUT re-reading all of K~ every GN iteration: instead of
+ * the depth-only pass of como_dense_ref_* (flag 8) this evaluates z_n = exp(K~[n,:] logz_m) only for the pixels whose cached
+ * log-depth interval can still straddle the new median (|delta logz_n| <= ||K~[n,:]||_1 max_k |delta logz_m,k|); the others
+ * write 0 / +inf according to their side, so the exact select on zbuf returns the exact median of the full image.
+ * State (caller-owned, one per keyframe set): lref / err / l1 (B,rows), l1max (B) float, logzm_prev (B,m) (updated by the call),
+ * med_prev3 (B,3) = the {median, ., .} the PREVIOUS call's select wrote (read before this call's select overwrites it).
+ * init != 0: builds the state (every pixel evaluated: the cost of the depth-only pass).  zbuf (B,rows) and hists as for
+ * como_dense_ref_* with flags 2|8 (pass-0 histogram accumulated into an already zeroed workspace); continue with
+ * como_dense_ref_*(flags 4|8) for the remaining select passes + finish.  ncand (B) optional: candidates counted (+=). */
+int como_depth_band_f32(const float* Kt, long kt_slot_stride, const float* logzm, float* logzm_prev, int B, int rows, int m,
+                        float* lref, float* err, float* l1, float* l1max, const float* med_prev3, float* zbuf, void* hists,
+                        unsigned* ncand, int init, como_stream_t stream);
+int como_depth_band_f64(const double* Kt, long kt_slot_stride, const double* logzm, double* logzm_prev, int B, int rows, int m,
+                        double* lref, double* err, double* l1, float* l1max, const double* med_prev3, double* zbuf, void* hists,
+                        unsigned* ncand, int init, como_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * DepthCov covariance-kernel assembly, Python-twin formula (python path: depth_cov/core/kernels.py:22-88,
  * covariance.py:10-39) and conditioning (Mapping.py:430-468 prep_predictor).

@@ -216,3 +216,47 @@ def test_tracking_level_record_starts_as_initial_pose():
     # the same launch again must give the same bits (the record is fully written by the kernel, nothing stale)
     res2 = pt.photo_level_tracking_fused(tp["Tji_init"].reshape(1, 4, 4).contiguous(), aff0, vals, P, J, tp["img_cur"], K, term, None)
     assert torch.equal(res[0], res2[0]) and torch.equal(res[1], res2[1])
+
+
+@pytest.mark.parametrize("pix", [torch.float64, torch.float32])
+def test_band_median_equals_full_depth_pass(pix):
+    """Mapping.store_vars' full-image median through `como_depth_band_*` (only the pixels that can still straddle the median are
+    re-evaluated) against the depth-only pass over every row of K~, over several GN iterations of the same window (nonmax
+    window 4: the reference's operating point): identical medians (float64: the same bits -- both evaluate a candidate with the
+    same scalar loop; float32: the full pass forms the dot products on the matrix cores), and most pixels are NOT re-evaluated."""
+    import copy
+    from como_amd import synth
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    from como_amd.odom.backend import dense_ref
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+
+    def predictor(cov, cm):
+        Kinv, L, Kt = prep_predictor(cov.double(), cm.double(), 1.0)
+        return Kinv, L, Kt.to(pix)
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = 4
+    meds = {}
+    for band in (True, False):
+        st = synth.make_window(B=4, H=192, W=256, m=64, dtype=torch.float64, device=DEV, seed=5, predictor=predictor)
+        old = dense_ref.BAND_MEDIAN
+        dense_ref.BAND_MEDIAN = band
+        try:
+            wb = WindowBA(st, cfg=cfg, pix_dtype=pix, window_full=True)
+            seq = []
+            for _ in range(6):
+                wb.iterate()
+                seq.append(wb.median_depths.clone())
+            if band:
+                key = [k for k in wb.w["dr_ws"] if k[0] == "full"][0]
+                bs = wb.w["dr_ws"][key]["band"]
+                frac = float(bs["ncand"].sum()) / (bs["calls"] * 4 * 192 * 256)
+        finally:
+            dense_ref.BAND_MEDIAN = old
+        meds[band] = torch.stack(seq).cpu()
+    d = (meds[True] - meds[False]).abs().max().item()
+    report("band_median", pix=str(pix), max_abs_diff=d, candidate_fraction=frac, medians=meds[True][-1])
+    if pix == torch.float64:
+        assert torch.equal(meds[True], meds[False])
+    else:
+        assert d < 2e-6 * float(meds[False].abs().max())
+    assert frac < 0.6                                    # (1/6 of the calls build the state: every pixel a candidate there)
