@@ -134,7 +134,17 @@ __global__ __launch_bounds__(256) void dense_ref_kernel(
 // operands of v_mfma_f32_16x16x4_f32 (row = l & 15, k = l >> 4; the k permutation k = 16 s + 4 q + e is applied to the
 // coefficient operand too); D (rows 4 q + r, column l & 15) goes through a 2 KB LDS transpose so that the epilogue
 // (exp, ray, pose Jacobian, 27 coalesced plane stores) runs one pixel per lane.
-typedef float mf4 __attribute__((ext_vector_type(4)));
+template <typename T> struct DAcc { typedef T type __attribute__((ext_vector_type(4))); };
+__device__ __forceinline__ typename DAcc<float>::type d_mfma(float a, float b, typename DAcc<float>::type c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ typename DAcc<double>::type d_mfma(double a, double b, typename DAcc<double>::type c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+// C/D row of (lane, register) of the 16x16x4 MFMA: float32 4 (lane >> 4) + reg, float64 (lane >> 4) + 4 reg
+template <typename T> __device__ __forceinline__ int d_mfma_row(int lane, int reg);
+template <> __device__ __forceinline__ int d_mfma_row<float>(int lane, int reg) { return (lane >> 4) * 4 + reg; }
+template <> __device__ __forceinline__ int d_mfma_row<double>(int lane, int reg) { return (lane >> 4) + 4 * reg; }
 
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -142,22 +152,23 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
-    const float* __restrict__ Kt, long kt_slot_stride, const int* __restrict__ pixidx, const float* __restrict__ logzm,
-    const float* __restrict__ Twc, const float* __restrict__ Kmat, const float* __restrict__ dlogzm_dTwc, int n, int m,
-    int Wimg, float* __restrict__ Pwn, float* __restrict__ dPwn_dTwc, float* __restrict__ uvec, float* __restrict__ zbuf,
-    float* __restrict__ logzn_out, uint32_t* __restrict__ hists, const int* __restrict__ pixcoord, int compact) {
-  using T = float;
+    const T* __restrict__ Kt, long kt_slot_stride, const int* __restrict__ pixidx, const T* __restrict__ logzm,
+    const T* __restrict__ Twc, const T* __restrict__ Kmat, const T* __restrict__ dlogzm_dTwc, int n, int m,
+    int Wimg, T* __restrict__ Pwn, T* __restrict__ dPwn_dTwc, T* __restrict__ uvec, T* __restrict__ zbuf,
+    T* __restrict__ logzn_out, uint32_t* __restrict__ hists, const int* __restrict__ pixcoord, int compact) {
   using KeyT = typename KeyOf<T>::type;
+  using acc_t = typename DAcc<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
-  __shared__ float sD[4][64 * 9];
+  __shared__ T sD[4][64 * 9];
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
   for (int k = tid; k < SEL_BINS; k += 256) lh[k] = 0;
-  float bop[16];                      // coefficient operand: column c of {logz_m, dlogz_m/dT (6), 0...}, k = 16 s + 4 q + e
+  T bop[16];                          // coefficient operand: column c of {logz_m, dlogz_m/dT (6), 0...}, k = 16 s + 4 q + e
 #pragma unroll
   for (int se = 0; se < 16; ++se) {
     const int k = 16 * (se >> 2) + 4 * q + (se & 3);
-    float v = 0.f;
+    T v = T(0);
     if (k < m) {
       if (c == 0) v = logzm[(long)b * m + k];
       else if (c < 7) v = dlogzm_dTwc[((long)b * m + k) * 6 + (c - 1)];
@@ -169,35 +180,35 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
   for (int k = 0; k < 12; ++k) Tm[k] = Twc[16 * (long)b + k];
   const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
   __syncthreads();
-  float* myD = sD[wv];
+  T* myD = sD[wv];
   const int tiles = (n + 63) >> 6;
   for (int tile = blockIdx.x * 4 + wv; tile < tiles; tile += gridDim.x * 4) {
     const int px0 = tile << 6;
-    float4 kv[4][4];
+    Q4<T> kv[4][4];                     // (float64: 32 B per lane and load -- 16 rows x 128 contiguous bytes per wave load)
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int ii = min(px0 + 16 * it + c, n - 1);
       const int rw = pixidx ? pixidx[(long)b * n + ii] : ii;
-      const float* Kr = Kt + (long)b * kt_slot_stride + (long)rw * m;
+      const T* Kr = Kt + (long)b * kt_slot_stride + (long)rw * m;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int kk = min(16 * s + 4 * q, m - 4);           // clamped: the matching coefficients are zero
-        kv[it][s] = *reinterpret_cast<const float4*>(Kr + kk);
+        kv[it][s] = ld4(Kr + kk);
       }
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-      mf4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc_t acc = {T(0), T(0), T(0), T(0)};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[it][s].x, bop[4 * s + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[it][s].y, bop[4 * s + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[it][s].z, bop[4 * s + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kv[it][s].w, bop[4 * s + 3], acc, 0, 0, 0);
+        acc = d_mfma(kv[it][s].x, bop[4 * s + 0], acc);
+        acc = d_mfma(kv[it][s].y, bop[4 * s + 1], acc);
+        acc = d_mfma(kv[it][s].z, bop[4 * s + 2], acc);
+        acc = d_mfma(kv[it][s].w, bop[4 * s + 3], acc);
       }
       if (c < 8) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) myD[(16 * it + 4 * q + r) * 9 + c] = acc[r];
+        for (int r = 0; r < 4; ++r) myD[(16 * it + d_mfma_row<T>(lane, r)) * 9 + c] = acc[r];
       }
     }
     wave_lds_fence();
@@ -497,10 +508,13 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
     return COMO_ERR_LAUNCH;
   int gx = (n + 255) / 256;
   if (gx > 512) gx = 512;
-  if constexpr (sizeof(T) == 4) {
+  // float32: always the matrix-core kernel.  float64: the matrix-core kernel for the dense reference POINTS (row-major tile
+  // loads: 16 rows x 128 contiguous bytes per wave load instead of 64 rows x 32 bytes); the depth-only pass keeps the
+  // thread-per-pixel kernel, whose summation order the band median (depth_band_kernel) reproduces bit for bit.
+  if (sizeof(T) == 4 || (!depth_only && !(flags & 32))) {
     int gm = ((n + 63) / 64 + 3) / 4;
     if (gm > 256) gm = 256;
-    hipLaunchKernelGGL(dense_ref_mfma_kernel, dim3(gm, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
+    hipLaunchKernelGGL(dense_ref_mfma_kernel<T>, dim3(gm, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
                        dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord, compact);
   } else {
     hipLaunchKernelGGL(dense_ref_kernel<T>, dim3(gx, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,

@@ -9,8 +9,9 @@ namespace como {
 // 4 and 5 from that list (writing the same histograms the full passes would) and passes 4, 5 return at once.  Scratch lives
 // in the part of the workspace no pass uses: digits 4 and 5 are 10 bits wide, so the upper 1024 words of their slots are free
 // -- slot 4: [1024] candidate count, [1025] "done"; slot 5: [1024, 2048) = up to 512 keys.  The tail clears count and keys
-// again (consumers scan whole slots); "done" = 1 in an unused bin is harmless.  More candidates than fit (massive ties):
-// the tail only cleans up and the full passes run.
+// again (consumers scan whole slots); "done" = 1 in an unused bin is harmless.  More candidates than fit (massive ties, e.g.
+// constant images): the tail workgroup streams the data itself for digits 4 and 5 -- slow (one workgroup), but it keeps the
+// two always-enqueued fallback launches (4.5 us each, every iteration) out of the common path.
 constexpr int SEL_COLLECT = 0x100;          // flag or-ed into `pass` (pass 3 of a double select)
 constexpr int SEL_CAND_CAP = 512;
 __device__ __forceinline__ uint32_t* sel_cand_count(uint32_t* h) { return h + 4 * SEL_BINS + 1024; }
@@ -30,6 +31,7 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const T* __restrict__ 
   if (valid) valid += (long)blockIdx.y * n;
   hists += (long)blockIdx.y * 6 * SEL_BINS;
   if (sizeof(T) == 8 && pass >= 4 && *sel_cand_done(hists)) return;      // the tail kernel already produced this digit
+                                                                        // (plain passes 4, 5 after a collecting pass 3)
   for (int b = threadIdx.x; b < SEL_BINS; b += 256) lh[b] = 0;
   KeyT prefix; uint32_t k_rem, nv;
   sel_resolve<KeyT>(hists, pass, &sc, prefix, k_rem, nv);   // contains __syncthreads (also orders the lh init)
@@ -102,7 +104,8 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const T* __restrict__ 
 }
 
 // digits 4 and 5 of a double select from the collected candidates (one workgroup per segment)
-__global__ __launch_bounds__(256) void select_tail_kernel(uint32_t* __restrict__ hists) {
+__global__ __launch_bounds__(256) void select_tail_kernel(uint32_t* __restrict__ hists, const double* __restrict__ r,
+                                                          const uint8_t* __restrict__ valid, long n) {
   using KeyT = uint64_t;
   __shared__ SelScratch sc;
   __shared__ uint64_t keys[SEL_CAND_CAP];
@@ -110,6 +113,8 @@ __global__ __launch_bounds__(256) void select_tail_kernel(uint32_t* __restrict__
   __shared__ uint32_t part[64];
   __shared__ uint32_t found[2];
   hists += (long)blockIdx.x * 6 * SEL_BINS;
+  r += (long)blockIdx.x * n;
+  if (valid) valid += (long)blockIdx.x * n;
   const int tid = threadIdx.x;
   const uint32_t cnt = *sel_cand_count(hists);
   const bool fits = cnt <= (uint32_t)SEL_CAND_CAP;
@@ -119,14 +124,21 @@ __global__ __launch_bounds__(256) void select_tail_kernel(uint32_t* __restrict__
   // clean the scratch: consumers scan whole slots
   for (int i = tid; i < 1024; i += 256) hists[5 * SEL_BINS + 1024 + i] = 0u;
   if (tid == 0) *sel_cand_count(hists) = 0u;
-  if (!fits) return;                                   // massive ties: the full passes 4, 5 run
   KeyT prefix; uint32_t k_rem, nv;
   sel_resolve<KeyT>(hists, 4, &sc, prefix, k_rem, nv);
   for (int p = 4; p < 6; ++p) {
     for (int b = tid; b < 1024; b += 256) lh[b] = 0;
     __syncthreads();
-    for (uint32_t i = tid; i < cnt; i += 256)
-      if (sel_match<KeyT>(keys[i], prefix, p)) atomicAdd(&lh[sel_digit<KeyT>(keys[i], p)], 1u);
+    if (fits) {
+      for (uint32_t i = tid; i < cnt; i += 256)
+        if (sel_match<KeyT>(keys[i], prefix, p)) atomicAdd(&lh[sel_digit<KeyT>(keys[i], p)], 1u);
+    } else {                                           // massive ties: this workgroup streams the whole slice
+      for (long i = tid; i < n; i += 256) {
+        if (valid && !valid[i]) continue;
+        const KeyT key = abs_key(r[i]);
+        if (sel_match<KeyT>(key, prefix, p)) atomicAdd(&lh[sel_digit<KeyT>(key, p)], 1u);
+      }
+    }
     __syncthreads();
     for (int b = tid; b < 1024; b += 256) hists[p * SEL_BINS + b] = lh[b];     // what the full pass would have accumulated
     // the bin holding rank k_rem: 64 threads x 16 bins, prefix over the 64 partial sums by one thread
@@ -180,6 +192,8 @@ int select_hist(const T* r, const uint8_t* valid, long n, int nseg, uint32_t* hi
   const int pass_flags = pass;
   pass &= 0xff;
   if (!r || !hists || n < 0 || nseg < 1 || pass < 0 || pass >= SelCfg<KeyT>::NPASS) return COMO_ERR_ARG;
+  // double keys with the collecting protocol (flag on every pass): the tail launched with pass 3 produces digits 4 and 5
+  if (sizeof(T) == 8 && (pass_flags & SEL_COLLECT) && pass >= 4) return COMO_OK;
   long blocks = (n + 255) / 256;
   if (blocks < 1) blocks = 1;
   // Few, fat workgroups: every workgroup ends with up to 2048 global atomics on the SAME histogram, which serialise per
@@ -191,7 +205,7 @@ int select_hist(const T* r, const uint8_t* valid, long n, int nseg, uint32_t* hi
   hipLaunchKernelGGL(select_hist_kernel<T>, dim3((unsigned)blocks, nseg), dim3(256), 0, s, r, valid, n, hists, pass_flags);
   COMO_CHECK_LAUNCH();
   if (sizeof(T) == 8 && (pass_flags & SEL_COLLECT) && pass == 3) {
-    hipLaunchKernelGGL(select_tail_kernel, dim3(nseg), dim3(256), 0, s, hists);
+    hipLaunchKernelGGL(select_tail_kernel, dim3(nseg), dim3(256), 0, s, hists, (const double*)r, valid, n);
     COMO_CHECK_LAUNCH();
   }
   return COMO_OK;
