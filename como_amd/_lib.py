@@ -48,7 +48,8 @@ class WinArgs(ctypes.Structure):
                 + [(n, c_double) for n in ("s_gp", "s_ld", "s_px", "s_pose", "s_aff", "s_lm")]
                 + [(n, c_void_p) for n in ("H", "g", "err")]
                 + [("zero_a", c_void_p), ("zero_a_bytes", c_long), ("zero_b", c_void_p), ("zero_b_bytes", c_long),
-                   ("median_out", c_void_p), ("sysfix", c_void_p), ("fix_plane", c_long)])
+                   ("median_out", c_void_p), ("sysfix", c_void_p), ("fix_plane", c_long),
+                   ("mld_J", c_void_p), ("mld_anchor", c_void_p), ("s_mld", c_double)])
 
 
 # name -> (restype, argtypes); every symbol include/como_hip.h declares

@@ -140,6 +140,7 @@ struct PriorArgs {
   double* H; double* g; long D; double* err;      // err: 8 doubles
   double* median_out;
   long long* fix; long plane;                     // order-independent mode: fixed-point system buffer (common.cuh fix_add)
+  const double* mld_J; const double* mld_anchor; double s_mld;   // filling window: mean-log-depth scale prior on keyframe 0
 };
 
 __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int m) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
   double* r0 = w + m;             // m
   double* G = r0 + m;             // m x 6
   double* dP = G + m * 6;         // m x 3
-  double* red = dP + m * 3;       // 64 scratch
+  double* red = dP + m * 3;       // 64 scratch (+ m x 21 pixel-prior rows behind it, then 6 + 3m mean-log-depth row)
   // grid (B, S): every slice rebuilds the small m x m prologue in LDS and scatters 1/S of H_TP / H_PP (the 9 m^2
   // fp64 atomics per keyframe were the whole cost with one workgroup per keyframe); slice 0 adds everything else
   const int b = blockIdx.x, tid = threadIdx.x, slice = blockIdx.y, nsl = gridDim.y;
@@ -287,6 +288,35 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
       const double v = i_px * (jt[a] * jp[d] + jt[6 + a] * jp[3 + d]);
       if (u & 1) addH(li[3 * j + d], pi[a], v);
       else if (!FX) addH(pi[a], li[3 * j + d], v);
+    }
+  }
+  // mean-log-depth scale prior on keyframe 0 while the window fills (Mapping.py:900-917, gp_priors.py:84-150): ONE residual
+  // r = J . logz_m - anchor with the row v = [J G (6) | J_k dlogz_k/dP (3m)]: H += v v^T / s^2 -- (6 + 3m)^2 / 2 entries, one
+  // item per lane over all slices of keyframe 0's workgroups
+  if (b == 0 && A.mld_J && A.nfix == 0) {
+    double* vrow = red + 64 + 21 * m;               // 6 + 3m
+    const double im = 1.0 / (A.s_mld * A.s_mld);
+    if (tid < 6) {
+      double s = 0;
+      for (int k = 0; k < m; ++k) s += A.mld_J[k] * G[k * 6 + tid];
+      vrow[tid] = s;
+    }
+    for (int q = tid; q < 3 * m; q += 256) vrow[6 + q] = A.mld_J[q / 3] * dP[q];
+    __syncthreads();
+    double rr = 0;
+    for (int k = 0; k < m; ++k) rr += A.mld_J[k] * A.logzm[k];
+    rr -= A.mld_anchor[0];
+    const int nv = 6 + 3 * m;
+    auto vidx = [&](int i) -> long { return i < 6 ? pi[i] : li[i - 6]; };
+    for (int e = tid + 256 * slice; e < nv * nv; e += 256 * nsl) {
+      const int i = e / nv, j = e % nv;
+      const long ri = vidx(i), rj = vidx(j);
+      // (distinct variables of one keyframe have distinct rows, so ri >= rj keeps each symmetric pair exactly once)
+      if (!FX || ri >= rj) addH(ri, rj, im * vrow[i] * vrow[j]);
+    }
+    if (lead) {
+      for (int i = tid; i < nv; i += 256) addG(vidx(i), -im * rr * vrow[i]);
+      if (tid == 0) addE(5, im * rr * rr);
     }
   }
   if (!lead) return;
@@ -443,9 +473,11 @@ int como_win_priors(const como_win_args* a, como_stream_t stream) {
   A.H = a->H; A.g = a->g; A.D = a->D; A.err = a->err;
   A.median_out = a->median_out;
   A.fix = (long long*)a->sysfix; A.plane = a->fix_plane;
+  A.mld_J = a->mld_J; A.mld_anchor = a->mld_anchor; A.s_mld = a->s_mld;
+  if (A.mld_J && (!A.mld_anchor || !(A.s_mld > 0.0) || a->nfix != 0)) return COMO_ERR_ARG;
   if (A.fix && A.plane < a->D * a->D + a->D + FIX_ERR_SLOTS) return COMO_ERR_ARG;
   const int m = a->m;
-  const size_t lds = (size_t)(m * (m + 1) + m * 6 + m + m + m * 6 + m * 3 + 64 + m * 21) * sizeof(double);
+  const size_t lds = (size_t)(m * (m + 1) + m * 6 + m + m + m * 6 + m * 3 + 64 + m * 21 + 6 + 3 * m) * sizeof(double);
   hipLaunchKernelGGL(win_priors_kernel, dim3(a->B, 32), dim3(256), lds, s, A, a->B, m);
   COMO_CHECK_LAUNCH();
   return COMO_OK;

@@ -43,15 +43,17 @@ class WindowBA:
         """state: dict as produced by como_amd.synth.make_window (plus K_mm_inv / L_mm / Knm_Kmminv).
         shard: como_amd.dist.Shard for the one-process-per-GPU data-parallel mode (None = single GPU)."""
         self.shard = shard
-        if shard is not None and not (fused and window_full):
-            raise RuntimeError("como_amd: the multi-GPU window BA runs the fused chain (full window) only")
+        if shard is not None and not fused:
+            raise RuntimeError("como_amd: the multi-GPU window BA runs the fused chain only")
         self.events = None
         self.graph = None
         self.cfg = cfg or DEFAULT_CFG
         self.dev = state["kf_poses"].device
         self.dt = torch.float64
         self.pix_dtype = pix_dtype
-        self.fused = fused and window_full
+        # the fused chain also serves the FILLING window (fewer keyframes than the graph holds): its only difference is the
+        # scale prior -- mean predicted log-depth of keyframe 0 instead of landmark anchors (Mapping.py:884-917)
+        self.fused = fused and (window_full or state.get("init_scale_anchor") is not None)
         f64 = lambda t: t.to(self.dt).contiguous()
         dev = self.dev
         B, _, self.Himg, self.Wimg = state["kf_img_and_grads"].shape
@@ -228,7 +230,7 @@ class WindowBA:
         self.fix_lm = self.fix_idx.to(torch.int32).contiguous()
         self.aff_anchor2 = self.aff_anchor.reshape(2).contiguous()
         a = _lib.WinArgs()
-        a.B, a.F, a.m, a.L, a.nfix = B, F, m, L, int(self.fix_lm.numel())
+        a.B, a.F, a.m, a.L, a.nfix = B, F, m, L, (int(self.fix_lm.numel()) if self.window_full else 0)
         a.pix_is_f64 = 1 if p == torch.float64 else 0
         a.median_new_is_f32 = 1 if p == torch.float32 else 0
         a.median_new_stride = 3
@@ -258,6 +260,12 @@ class WindowBA:
         a.zero_a, a.zero_a_bytes = ptr(self.w["hist_dr2"]), 2 * B * hb
         a.zero_b, a.zero_b_bytes = ptr(self.w["hist_ba"]), hb
         a.median_out = ptr(self.median_depths)
+        if not self.window_full:
+            # mean_log_depth_cost (gp_priors.py:84-150): J = column means of keyframe 0's K~ (float64 sum of the pix-dtype rows, as the
+            # mirror path forms it), anchor = the initial scale, sigma = cfg mean_depth_prior; constant for this topology
+            self.mld_J = (self.Kt[0].to(self.dt).sum(0) / self.Kt.shape[1]).contiguous()
+            self.mld_anchor = torch.as_tensor(self.init_scale_anchor, dtype=self.dt, device=dev).reshape(-1)[:1].contiguous()
+            a.mld_J, a.mld_anchor, a.s_mld = ptr(self.mld_J), ptr(self.mld_anchor), float(sg["mean_depth_prior"])
         self.win_args = a
         self.w["dr_ws"] = {}                               # dense-reference planes: owned here (captured graphs record them)
         self.w["ba_ws"] = {}                               # residual / validity / pair / partial-Gram scratch of the BA chain

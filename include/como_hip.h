@@ -379,6 +379,12 @@ typedef struct como_win_args {
   void* sysfix; long fix_plane;                   /* optional: fixed-point system buffer (como_sys_finalize); then the priors are added
                                                      there (lower triangle, exact integer atomics) and H / g / err are not touched;
                                                      the 6 prior errors go to slots 1..6 of the err block */
+  /* While the window is filling (fewer keyframes than the graph holds) the reference replaces the landmark anchors of
+     keyframe 0 by a scale prior on its MEAN predicted log-depth (Mapping.py:900-917, factors/gp_priors.py:84-150):
+     r = mld_J . logz_m[0] - *mld_anchor, information 1 / s_mld^2, with mld_J (m) = the column means of keyframe 0's K~
+     (constant for a topology).  mld_J != NULL (and nfix == 0) selects it; its error goes to slot 6 of the err block like the
+     anchors' (the two are alternatives). */
+  const double* mld_J; const double* mld_anchor; double s_mld;
 } como_win_args;
 
 int como_win_scaffold(const como_win_args* args_host, como_stream_t stream);

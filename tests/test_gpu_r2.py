@@ -34,12 +34,13 @@ def _hip_predictor(pix_dtype, kinv=None):
     return predictor
 
 
-def _window_from_seed(G, pix_dtype, window, fused=True):
+def _window_from_seed(G, pix_dtype, window, fused=True, own_inverse=False):
+    """own_inverse: K_mm^-1 from the HIP conditioning kernel (csrc/smallsolve.hip) instead of the fixture's (the reference's)."""
     from como_amd import synth
     from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
     ch = int(G["channels"]) if "channels" in G else 1
     st = synth.make_window(B=int(G["B"]), H=int(G["H"]), W=int(G["W"]), m=int(G["m"]), dtype=torch.float64, device=DEV,
-                           seed=int(G["seed"]), predictor=_hip_predictor(pix_dtype, G["K_mm_inv"]),
+                           seed=int(G["seed"]), predictor=_hip_predictor(pix_dtype, None if own_inverse else G["K_mm_inv"]),
                            aff_noise=float(G["aff_noise"]) if "aff_noise" in G else 0.0, channels=ch)
     if "recent_timestamps" in G:                       # one-way frames of the same scene (synth.make_recent, same seed)
         rec = synth.make_recent(G["recent_timestamps"].tolist(), int(G["H"]), int(G["W"]), int(G["seed"]), device=DEV, channels=ch)
@@ -138,6 +139,45 @@ def test_fullsize_metric_window_vs_reference(pix, window):
     assert worst["aff"] < (1e-7 if f64 else 1e-4) and worst["P"] < (1e-5 if f64 else 2e-3)
     assert worst["med"] < (1e-7 if f64 else 1e-5)                     # the full-image median (Mapping.store_vars)
     assert worst["H_full"] < (5e-6 if f64 else 2e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_fullsize_window_with_own_conditioning():
+    """The metric window at full size with NOTHING of the reference's in the path: K_mm + 1e-6 I is factored and inverted by the
+    HIP conditioning kernel (csrc/smallsolve.hip, round 3) instead of taking the fixture's K_mm^-1 as the other full-size tests
+    do.  K_mm has a condition number of ~1e8, so two correct float64 inverses differ by ~1e-8 relative and K~ = K_nm K_mm^-1
+    with them; this test BOUNDS what that does to the result: the own inverse against the reference's, K~ against K~, and the
+    solved poses after every reference iteration against the reference's -- still three orders inside the north star's 1e-4."""
+    G = load_golden("fullsize_window4.npz")
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    wb_ref, st_ref = _window_from_seed(G, torch.float64, 4)
+    wb, st = _window_from_seed(G, torch.float64, 4, own_inverse=True)
+    e_inv = rel_err(st["K_mm_inv"], G["K_mm_inv"])
+    # residual of the own inverse against K_mm itself (what an inverse is judged by): |K_mm Kinv - I|
+    from como_amd.depth_cov.core.covariance import covariance
+    from como_amd.depth_cov.core.gaussian_kernel import interpolate_kernel_params
+    from como_amd.utils.coords import normalize_coordinates
+    cov = st["cov_params_img"].double()
+    cm = normalize_coordinates(st["coords_m"].double(), cov.shape[-2:])
+    K_mm = covariance(cm, interpolate_kernel_params(cov, cm), 1.0)
+    K_mm = K_mm + torch.diag_embed((1e-6 * torch.ones(K_mm.shape[:2], device=DEV)).double())
+    eye = torch.eye(K_mm.shape[-1], dtype=torch.float64, device=DEV)
+    res_own = (K_mm @ st["K_mm_inv"].double() - eye).abs().max().item()
+    res_ref = (K_mm @ dev(G["K_mm_inv"]).double() - eye).abs().max().item()
+    e_kt = rel_err(st["Knm_Kmminv"], st_ref["Knm_Kmminv"])
+    iters = sum(1 for k in G if k.endswith("_delta"))
+    worst = {"pose": 0.0, "aff": 0.0, "P": 0.0, "med": 0.0}
+    for it in range(iters):
+        gi = lambda k: G[f"it{it}_{k}"]
+        wb.iterate()
+        worst["pose"] = max(worst["pose"], (wb.kf_poses.cpu() - gi("kf_poses_new")).abs().max().item())
+        worst["aff"] = max(worst["aff"], (wb.kf_aff_params.cpu() - gi("kf_aff_new")).abs().max().item())
+        worst["P"] = max(worst["P"], (wb.P_m.cpu() - gi("P_new")).abs().max().item())
+        worst["med"] = max(worst["med"], ((wb.median_depths.cpu() - gi("median_depths_full")).abs() / gi("median_depths_full")).max().item())
+    report("fullsize_own_conditioning", Kinv_rel_vs_reference=e_inv, residual_own=res_own, residual_reference=res_ref, Kt_rel=e_kt, **worst)
+    assert res_own < 1e-6 and res_own < 20 * res_ref + 1e-9          # as good an inverse as the reference's LAPACK gives
+    assert e_kt < 1e-5                                               # cond(K_mm) ~ 1e8 x float64 round-off
+    assert worst["pose"] < 1e-7 and worst["aff"] < 1e-7 and worst["P"] < 1e-4 and worst["med"] < 1e-6
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -563,8 +603,10 @@ def test_cross_covariance_half_dispatch():
 @pytest.mark.parametrize("case", ["random", "ties_overflow", "all_equal", "two_values", "tiny"])
 def test_double_select_with_candidate_tail(case):
     """The double-precision exact median with the pass-3 candidate collection + one-workgroup tail (csrc/select.hip) against
-    torch.median: ordinary data (the tail finishes digits 4, 5), more tied keys than the candidate buffer holds (the tail backs
-    off and the full passes run), degenerate inputs.  Several segments at once, scratch words cleaned up afterwards."""
+    torch.median: ordinary data (the tail finishes digits 4, 5 from the candidate list), more tied keys than the candidate buffer
+    holds (round 3: the tail workgroup streams the slice itself -- the two fallback launches are gone from the product's chain),
+    degenerate inputs.  Several segments at once, scratch words cleaned up afterwards.  Both protocols: the collect flag on
+    pass 3 only (passes 4, 5 are launched and return at once) and on every pass (the product: passes 4, 5 are not launched)."""
     from como_amd import _lib
     L = _lib.lib()
     g = torch.Generator().manual_seed(17)
@@ -586,15 +628,17 @@ def test_double_select_with_candidate_tail(case):
     hists = torch.empty(nseg * hb, dtype=torch.int32, device=DEV)
     out = torch.empty((nseg, 3), dtype=torch.float64, device=DEV)
     s = _lib.stream_ptr()
-    _lib.check(L.como_select_begin(hists.data_ptr(), nseg, s), "begin")
-    for p in range(6):
-        _lib.check(L.como_select_hist_f64(rd.data_ptr(), None, n, nseg, hists.data_ptr(), p | (0x100 if p == 3 else 0), s), "hist")
-    _lib.check(L.como_select_finish_f64(hists.data_ptr(), nseg, out.data_ptr(), s), "finish")
     ref = torch.median(r.abs(), dim=1).values
-    hv = hists.view(nseg, 6, 2048).cpu()
-    done = hv[:, 4, 1025].tolist()
-    report("select_tail", case=case, done=done, got=out[:, 0].cpu(), want=ref)
-    assert torch.equal(out[:, 0].cpu(), ref)
-    assert (hv[:, 4, 1024] == 0).all() and (hv[:, 5, 1024:] == 0).all()          # scratch cleaned
-    # (two_values: all 60,000 keys agree on the first 33 bits -> more candidates than the buffer holds -> full passes)
-    assert done == ([0] * nseg if case in ("ties_overflow", "all_equal", "two_values") else [1] * nseg)
+    for every_pass in (False, True):
+        _lib.check(L.como_select_begin(hists.data_ptr(), nseg, s), "begin")
+        for p in range(6):
+            flag = 0x100 if (p == 3 or (every_pass and p >= 1)) else 0
+            _lib.check(L.como_select_hist_f64(rd.data_ptr(), None, n, nseg, hists.data_ptr(), p | flag, s), "hist")
+        _lib.check(L.como_select_finish_f64(hists.data_ptr(), nseg, out.data_ptr(), s), "finish")
+        hv = hists.view(nseg, 6, 2048).cpu()
+        done = hv[:, 4, 1025].tolist()
+        report("select_tail", case=case, every_pass=every_pass, done=done, got=out[:, 0].cpu(), want=ref)
+        assert torch.equal(out[:, 0].cpu(), ref)
+        assert (hv[:, 4, 1024] == 0).all() and (hv[:, 5, 1024:] == 0).all()          # scratch cleaned
+        # (two_values / ties: far more keys agree on the first 33 bits than the buffer holds -> the tail streams the slice itself)
+        assert done == [1] * nseg
