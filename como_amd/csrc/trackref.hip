@@ -1,0 +1,143 @@
+// Per-frame glue of the tracker around the GN kernels, fused (each was 10-25 tiny torch launches, i.e. pure host time in the
+// sequential loop: 1.3 ms + 0.5 ms per frame at 640x480):
+//
+//   track_reference : a keyframe's reference arrays for one pyramid level from its depth map -- back-projection, transform into
+//                     the newest keyframe's frame, projection there, validity mask, inverse-compositional Jacobians.
+//                     reference: como/odom/Tracking.py:255-300 (update_kf_reference: backprojection camera.py:43-54,
+//                     transform_points transforms.py:17-23, projection camera.py:20-26, the in-image test :265-281,
+//                     precalc_jacobians photo_tracking.py:46-74).
+//   reproject_depth : the newest keyframe's finest-level points seen from the current frame as a depth image (NaN where nothing
+//                     lands; where several points land on one pixel the LAST one wins, the order torch's CPU index_put applies),
+//                     plus the number of pixels hit.  reference: como/odom/Tracking.py:163-185 (get_reproj_last_kf) and
+//                     como/utils/coords.py:50-56 (fill_image).
+// Element-wise, HBM-bound, a few MB per call.  Mask-feeding arithmetic keeps the reference's operation order (no contraction).
+#include "common.cuh"
+#include "../../include/como_hip.h"
+
+namespace como {
+
+// depth (b, h*w) of level (h, w); rel (b,4,4) = T_lastkf^-1 T_kf; K (3,3) of the level; dI_dw (b,n,1,2); vals (b,n,1)
+template <typename T>
+__global__ __launch_bounds__(256) void track_reference_kernel(const T* __restrict__ depth, const T* __restrict__ rel,
+                                                              const T* __restrict__ Kmat, const T* __restrict__ dI_dw,
+                                                              const T* __restrict__ vals, int h, int w, T border, T depth_thresh,
+                                                              T* __restrict__ P_out, uint8_t* __restrict__ mask_out,
+                                                              T* __restrict__ J_out) {
+  const long n = (long)h * w;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= n) return;
+  const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  const T* M = rel + 16 * (long)b;
+  const long bi = (long)b * n + i;
+  const T z = depth[bi];
+  T X, Y, Z, u, v;
+  {
+#pragma clang fp contract(off)
+    const T rx = (T((int)(i % w)) - cx) / fx;              // camera.py:43-47 with p = (col, row)
+    const T ry = (T((int)(i / w)) - cy) / fy;
+    const T px = z * rx, py = z * ry, pz = z * T(1);
+    // P @ R^T + t (Tracking.py _rigid: one small GEMM per pose; accumulated in k order like the library's K = 3 product)
+    X = ((px * M[0] + py * M[1]) + pz * M[2]) + M[3];
+    Y = ((px * M[4] + py * M[5]) + pz * M[6]) + M[7];
+    Z = ((px * M[8] + py * M[9]) + pz * M[10]) + M[11];
+    u = fx * X / Z + cx;                                   // camera.py:20-26
+    v = fy * Y / Z + cy;
+  }
+  P_out[3 * bi] = X; P_out[3 * bi + 1] = Y; P_out[3 * bi + 2] = Z;
+  // closed interval grown by `border` and a minimum depth (Tracking.py:265-281)
+  const bool ok = (u >= -border) && (u <= T(w - 1) + border) && (v >= -border) && (v <= T(h - 1) + border) && (Z > depth_thresh);
+  mask_out[bi] = ok ? 1 : 0;
+  // inverse-compositional Jacobian at theta = 0 (photo_tracking.py:46-74), same expressions as precalc_jac_kernel (image.hip)
+  const T gx = dI_dw[2 * bi], gy = dI_dw[2 * bi + 1];
+  const T a = gx * (fx / Z), bb = gy * (fy / Z);
+  const T c = gx * (-(fx * X / Z) / Z) + gy * (-(fy * Y / Z) / Z);
+  T* o = J_out + 8 * bi;
+  o[0] = bb * (-Z) + c * Y;
+  o[1] = a * Z + c * (-X);
+  o[2] = a * (-Y) + bb * X;
+  o[3] = a;
+  o[4] = bb;
+  o[5] = c;
+  o[6] = vals[bi];
+  o[7] = T(1);
+}
+
+// pass 1: every point that projects strictly inside the image with positive depth claims its (truncated) pixel with its index
+template <typename T>
+__global__ __launch_bounds__(256) void reproject_claim_kernel(const T* __restrict__ Tck, const T* __restrict__ Kmat,
+                                                              const T* __restrict__ P, long n, int h, int w,
+                                                              long long* __restrict__ order, T* __restrict__ zbuf,
+                                                              int* __restrict__ nseen) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i == 0) *nseen = 0;
+  if (i >= n) return;
+  const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  T X, Y, Z, u, v;
+  {
+#pragma clang fp contract(off)
+    const T px = P[3 * i], py = P[3 * i + 1], pz = P[3 * i + 2];
+    X = ((px * Tck[0] + py * Tck[1]) + pz * Tck[2]) + Tck[3];
+    Y = ((px * Tck[4] + py * Tck[5]) + pz * Tck[6]) + Tck[7];
+    Z = ((px * Tck[8] + py * Tck[9]) + pz * Tck[10]) + Tck[11];
+    u = fx * X / Z + cx;
+    v = fy * Y / Z + cy;
+  }
+  zbuf[i] = Z;
+  // open interval, depth > 0 (Tracking.py:173-178)
+  const bool ok = (u > T(0)) && (u < T(w - 1)) && (v > T(0)) && (v < T(h - 1)) && (Z > T(0));
+  if (ok) {
+    const long tgt = (long)((long long)v) * w + (long)((long long)u);      // .long(): truncation
+    atomicMax((unsigned long long*)&order[tgt], (unsigned long long)(i + 1));   // 0 = empty; the LAST point wins
+  }
+}
+
+// pass 2: the winners' depths, NaN elsewhere; the claim table is left cleared for the next call
+template <typename T>
+__global__ __launch_bounds__(256) void reproject_gather_kernel(long long* __restrict__ order, const T* __restrict__ zbuf, long hw,
+                                                               T* __restrict__ img, uint8_t* __restrict__ seen,
+                                                               int* __restrict__ nseen) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  bool hit = false;
+  if (i < hw) {
+    const long long o = order[i];
+    hit = o > 0;
+    img[i] = hit ? zbuf[o - 1] : (T)__builtin_nanf("");
+    seen[i] = hit ? 1 : 0;
+    if (hit) order[i] = 0;
+  }
+  const unsigned long long bal = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(nseen, __popcll(bal));
+}
+
+}  // namespace como
+
+extern "C" {
+
+#define COMO_DEF_TRACKREF(SFX, T)                                                                                              \
+  int como_track_reference_##SFX(const T* depth, const T* rel, const T* K, const T* dI_dw, const T* vals, int b, int h, int w,    \
+                                 T border, T depth_thresh, T* P_out, uint8_t* mask_out, T* J_out, como_stream_t stream) {         \
+    if (!depth || !rel || !K || !dI_dw || !vals || !P_out || !mask_out || !J_out || b <= 0 || h <= 0 || w <= 0)                 \
+      return COMO_ERR_ARG;                                                                                                      \
+    const long n = (long)h * w;                                                                                                 \
+    hipLaunchKernelGGL(como::track_reference_kernel<T>, dim3((unsigned)((n + 255) / 256), b), dim3(256), 0, (hipStream_t)stream, \
+                       depth, rel, K, dI_dw, vals, h, w, border, depth_thresh, P_out, mask_out, J_out);                          \
+    COMO_CHECK_LAUNCH();                                                                                                        \
+    return COMO_OK;                                                                                                             \
+  }                                                                                                                             \
+  int como_reproject_depth_##SFX(const T* Tck, const T* K, const T* P, long n, int h, int w, void* order_ws, T* zbuf, T* img,     \
+                                 uint8_t* seen, int* nseen, como_stream_t stream) {                                             \
+    if (!Tck || !K || !P || !order_ws || !zbuf || !img || !seen || !nseen || n <= 0 || h <= 0 || w <= 0) return COMO_ERR_ARG;   \
+    const long hw = (long)h * w;                                                                                                \
+    hipLaunchKernelGGL(como::reproject_claim_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,    \
+                       Tck, K, P, n, h, w, (long long*)order_ws, zbuf, nseen);                                                  \
+    COMO_CHECK_LAUNCH();                                                                                                        \
+    hipLaunchKernelGGL(como::reproject_gather_kernel<T>, dim3((unsigned)((hw + 255) / 256)), dim3(256), 0, (hipStream_t)stream,  \
+                       (long long*)order_ws, (const T*)zbuf, hw, img, seen, nseen);                                              \
+    COMO_CHECK_LAUNCH();                                                                                                        \
+    return COMO_OK;                                                                                                             \
+  }
+COMO_DEF_TRACKREF(f32, float)
+COMO_DEF_TRACKREF(f64, double)
+
+}  // extern "C"

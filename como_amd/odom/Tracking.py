@@ -16,6 +16,7 @@ from como_amd.geometry.lie_algebra import invertSE3
 from como_amd.geometry.transforms import get_rel_pose, get_T_w_curr
 from como_amd.odom.frontend.photo_tracking import photo_tracking_pyr, precalc_jacobians
 from como_amd.utils.coords import fill_image, get_test_coords, swap_coords_xy
+from como_amd import _lib
 from como_amd.utils.select import masked_median
 from como_amd.utils.image_processing import (DepthPyramidModule, ImageGradientModule, ImagePyramidModule,
                                              IntrinsicsPyramidModule, rgb_to_grayscale)
@@ -128,6 +129,30 @@ class Tracking:
             self.T_w_rec_last = T_w_curr
         return new
 
+    def reproj_stats_last_kf(self, T_curr_kf):
+        """(reprojected depth image (1,h,w), seen mask, number of pixels seen, their exact median depth) of the newest keyframe's
+        finest-level points in the current frame (Tracking.py:163-185 get_reproj_last_kf + :341-345): two launches
+        (csrc/trackref.hip `como_reproject_depth_*`) + the device select -- no boolean-mask gathers, no host synchronisation."""
+        P = self.P_pyr[-1][-1]                                                   # (n,3) of the newest keyframe
+        if not P.is_cuda:
+            reproj = self.get_reproj_last_kf(T_curr_kf)
+            seen = ~torch.isnan(reproj)
+            return reproj, seen, torch.count_nonzero(seen), torch.median(reproj[seen])
+        h, w = int(self.img_size[-2]), int(self.img_size[-1])
+        n, dt, dev = P.shape[0], P.dtype, P.device
+        ws = getattr(self, "_reproj_ws", None)
+        if ws is None or ws["key"] != (n, h, w, dt):
+            ws = self._reproj_ws = {"key": (n, h, w, dt), "order": torch.zeros(h * w, dtype=torch.int64, device=dev),
+                                    "z": torch.empty(n, dtype=dt, device=dev), "img": torch.empty(h * w, dtype=dt, device=dev),
+                                    "seen": torch.empty(h * w, dtype=torch.uint8, device=dev),
+                                    "nseen": torch.zeros(1, dtype=torch.int32, device=dev)}
+        fn = getattr(_lib.lib(), "como_reproject_depth_" + _lib.suffix(dt))
+        _lib.check(fn(T_curr_kf.reshape(4, 4).contiguous().data_ptr(), self.intrinsics_pyr[-1].contiguous().data_ptr(),
+                      P.contiguous().data_ptr(), n, h, w, ws["order"].data_ptr(), ws["z"].data_ptr(), ws["img"].data_ptr(),
+                      ws["seen"].data_ptr(), ws["nseen"].data_ptr(), _lib.stream_ptr(dev)), "como_reproject_depth")
+        med = masked_median(ws["img"], ws["seen"])
+        return ws["img"].view(1, h, w), ws["seen"].view(1, h, w), ws["nseen"][0].clone(), med
+
     def get_reproj_last_kf(self, T_curr_kf):
         """Depth image of the newest keyframe's finest-level points seen from the current frame, NaN where nothing lands
         (Tracking.py:163-185)."""
@@ -167,6 +192,20 @@ class Tracking:
         for i, d in enumerate(self.depth_pyr_module(depth)):
             coords = self.coords_pyr[i]
             b, _, h, w = d.shape
+            if d.is_cuda and self.vals_pyr[i].shape[2] == 1:
+                # one launch per level (csrc/trackref.hip): back-projection, transform, projection mask, Jacobians
+                dt, dev = d.dtype, d.device
+                P_all = torch.empty((b, h * w, 3), dtype=dt, device=dev)
+                mask = torch.empty((b, h * w), dtype=torch.uint8, device=dev)
+                J = torch.empty((b, h * w, 1, 8), dtype=dt, device=dev)
+                fn = getattr(_lib.lib(), "como_track_reference_" + _lib.suffix(dt))
+                _lib.check(fn(d.contiguous().data_ptr(), rel.to(dt).contiguous().data_ptr(), self.intrinsics_pyr[i].to(dt).contiguous().data_ptr(),
+                              self.img_grads_pyr[i].to(dt).contiguous().data_ptr(), self.vals_pyr[i].to(dt).contiguous().data_ptr(), b, h, w,
+                              50.0, 1e-4, P_all.data_ptr(), mask.data_ptr(), J.data_ptr(), _lib.stream_ptr(dev)), "como_track_reference")
+                self.mask_pyr.append(mask.view(torch.bool))
+                self.dI_dT_pyr.append(J)
+                self.P_pyr.append(P_all)
+                continue
             z = d[:, 0].reshape(b, h * w, 1)
             P, _ = backprojection(self.intrinsics_pyr[i], swap_coords_xy(coords), z)
             P_all = _rigid(rel, P)
@@ -190,12 +229,7 @@ class Tracking:
         track_data_viz = (timestamp, T_w_curr.clone())
         track_data_map = None
 
-        reproj = self.get_reproj_last_kf(self.T_curr_kf)
-        seen = ~torch.isnan(reproj)
-        n_seen = torch.count_nonzero(seen)
-        # exact median of the seen depths (all positive: in front of the camera) by the device select -- no boolean-mask gather,
-        # no sort, no synchronisation (Tracking.py:345 torch.median(reproj[seen]))
-        median_depth = masked_median(reproj.reshape(-1), seen.reshape(-1)) if reproj.is_cuda else torch.median(reproj[seen])
+        reproj, seen, n_seen, median_depth = self.reproj_stats_last_kf(self.T_curr_kf)
         self.last_reproj_stats = (n_seen, median_depth)
 
         if self.check_keyframe(median_depth, n_seen, self.T_curr_kf):

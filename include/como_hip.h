@@ -103,6 +103,27 @@ int como_track_level_f32(const float* Tji_init, const float* K, const float* aff
                          float delta_norm, float rel_tol, float grad_norm, void* workspace, int workspace_uncached, float* out,
                          como_stream_t stream);
 
+/* Per-frame glue of the tracker, fused (csrc/trackref.hip).
+ * como_track_reference_*: a keyframe's reference arrays of ONE pyramid level from its depth map (Tracking.py:255-300
+ *   update_kf_reference): depth (b,h*w), rel (b,4,4) = T_lastkf^-1 T_kf, K (3,3) of the level, dI_dw (b,n,1,2) image gradients,
+ *   vals (b,n,1) intensities (n = h*w, gray) -> P_out (b,n,3) points in the newest keyframe's frame, mask_out (b,n) u8 =
+ *   projects into the image grown by `border` with depth > depth_thresh (closed interval, :265-281), J_out (b,n,1,8)
+ *   inverse-compositional Jacobians (photo_tracking.py:46-74).
+ * como_reproject_depth_*: the newest keyframe's finest-level points P (n,3) seen from the current frame Tck (4,4) = T_curr_kf as a
+ *   depth image img (h*w) (NaN where nothing lands; several points on a pixel: the LAST one wins, utils/coords.py:50-56), seen
+ *   (h*w) u8, *nseen = pixels hit (Tracking.py:163-185 get_reproj_last_kf + :341-344).  order_ws: h*w int64, ZERO on entry, left
+ *   zero; zbuf: n elements of scratch. */
+int como_track_reference_f32(const float* depth, const float* rel, const float* K, const float* dI_dw, const float* vals, int b,
+                             int h, int w, float border, float depth_thresh, float* P_out, uint8_t* mask_out, float* J_out,
+                             como_stream_t stream);
+int como_track_reference_f64(const double* depth, const double* rel, const double* K, const double* dI_dw, const double* vals,
+                             int b, int h, int w, double border, double depth_thresh, double* P_out, uint8_t* mask_out,
+                             double* J_out, como_stream_t stream);
+int como_reproject_depth_f32(const float* Tck, const float* K, const float* P, long n, int h, int w, void* order_ws, float* zbuf,
+                             float* img, uint8_t* seen, int* nseen, como_stream_t stream);
+int como_reproject_depth_f64(const double* Tck, const double* K, const double* P, long n, int h, int w, void* order_ws,
+                             double* zbuf, double* img, uint8_t* seen, int* nseen, como_stream_t stream);
+
 /* Colour images (`color: rgb`, config/como.yml:7; photo_tracking.py works on (1,N,c) values and (1,N,c,8) Jacobians): the
  * same iteration / level with `channels` = c image channels.  vals_i (N,c), J8 (N,c,8), img (c,H,W) planes, r_ws (N,c),
  * valid_out (N,c) u8 workspace (every channel of a pixel carries the pixel's mask; the reference's (1,N) mask is column 0),

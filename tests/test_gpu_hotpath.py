@@ -872,10 +872,12 @@ def test_tracking_state_machine_vs_golden():
     assert worst_T < 5e-6 and worst_n <= 3 and worst_med < 1e-5
 
 
-@pytest.mark.parametrize("name,full", [("ba_window_recent_f64.npz", False), ("ba_window_recent_full_f64.npz", True)])
-def test_window_iterate_with_one_way_frames_vs_golden(name, full):
+@pytest.mark.parametrize("name,full,fused", [("ba_window_recent_f64.npz", False, True), ("ba_window_recent_f64.npz", False, False),
+                                             ("ba_window_recent_full_f64.npz", True, True)])
+def test_window_iterate_with_one_way_frames_vs_golden(name, full, fused):
     """Mapping.iterate()-equivalent with one-way (recent) frames in the window: before the window is full (mean-log-depth
-    scale prior, reference-signature path) and with a full window (anchors; fused HIP chain).  float64 pixel path."""
+    scale prior on keyframe 0: the fused HIP chain -- round 3: win_priors carries that prior -- and the reference-signature
+    mirror path) and with a full window (landmark anchors; fused chain).  float64 pixel path."""
     import copy
     from como_amd.depth_cov.core.covariance import prep_predictor
     from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
@@ -890,14 +892,14 @@ def test_window_iterate_with_one_way_frames_vs_golden(name, full):
         st["P_anchor"] = dev(G["P_anchor"])
     else:
         st["init_scale_anchor"] = dev(G["init_scale_anchor"])
-    wb = WindowBA(st, cfg=cfg, pix_dtype=torch.float64, window_full=full)
-    assert wb.fused == full and wb.F == wb.B + G["recent_poses"].shape[0]
+    wb = WindowBA(st, cfg=cfg, pix_dtype=torch.float64, window_full=full, fused=fused)
+    assert wb.fused == fused and wb.F == wb.B + G["recent_poses"].shape[0]
     wb.median_depths.copy_(dev(G["median_depths_in"]))
     delta = wb.iterate()
     perr = (wb.kf_poses.cpu() - G["kf_poses_new"]).abs().max().item()
     rerr = (wb.recent_poses.cpu() - G["recent_poses_new"]).abs().max().item()
     aerr = (wb.recent_aff_params.cpu().reshape(-1) - G["recent_aff_new"].reshape(-1)).abs().max().item()
-    report("window_iterate_recent", full=full, H_scaled=scaled_err(wb.H, G["H_full"]), delta_rel=rel_err(delta, G["delta"]), kf_pose_err=perr,
+    report("window_iterate_recent", full=full, fused=fused, H_scaled=scaled_err(wb.H, G["H_full"]), delta_rel=rel_err(delta, G["delta"]), kf_pose_err=perr,
            recent_pose_err=rerr, recent_aff_err=aerr)
     assert scaled_err(wb.H, G["H_full"]) < 1e-8 and rel_err(wb.g, G["g_full"]) < 1e-8
     assert perr < 1e-9 and rerr < 1e-9 and aerr < 1e-9

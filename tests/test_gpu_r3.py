@@ -260,3 +260,72 @@ def test_band_median_equals_full_depth_pass(pix):
     else:
         assert d < 2e-6 * float(meds[False].abs().max())
     assert frac < 0.6                                    # (1/6 of the calls build the state: every pixel a candidate there)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_tracker_glue_kernels_vs_torch_formulas(dt):
+    """csrc/trackref.hip against the torch formulas they replace (como_amd/odom/Tracking.py mirrors of the reference's
+    update_kf_reference / get_reproj_last_kf): reference points, validity masks, inverse-compositional Jacobians of a pyramid
+    level; reprojected depth image with the last-point-wins rule, its hit count and exact median."""
+    from como_amd import _lib
+    from como_amd.geometry.camera import backprojection
+    from como_amd.geometry.lie_algebra import se3_exp
+    from como_amd.odom.Tracking import _in_image, _project, _rigid
+    from como_amd.odom.frontend.photo_tracking import precalc_jacobians
+    from como_amd.utils.coords import fill_image, get_test_coords, swap_coords_xy
+    from como_amd.utils.select import masked_median
+    g = torch.Generator().manual_seed(11)
+    b, h, w = 2, 60, 80
+    n = h * w
+    K = torch.tensor([[70.0, 0, 39.5], [0, 70.0, 29.5], [0, 0, 1]], dtype=dt)
+    depth = (1.0 + torch.rand((b, 1, h, w), generator=g, dtype=torch.float64)).to(dt)
+    depth[0, 0, 5, 7] = 1e-5                                                      # below the depth threshold
+    xi = torch.tensor([[0.02, -0.03, 0.01, 0.4, -0.2, 0.1], [0.0, 0.0, 0.0, 0.0, 0.0, 0.0]], dtype=torch.float64)
+    rel = se3_exp(xi).to(dt)
+    dI = torch.randn((b, n, 1, 2), generator=g, dtype=torch.float64).to(dt)
+    vals = torch.rand((b, n, 1), generator=g, dtype=torch.float64).to(dt)
+    # ---- torch formulas (the mirror path)
+    coords = get_test_coords((h, w), device="cpu", batch_size=b)
+    P, _ = backprojection(K, swap_coords_xy(coords), depth[:, 0].reshape(b, n, 1))
+    P_all = _rigid(rel, P)
+    p_all = _project(K, P_all)
+    mask_ref = _in_image(p_all, P_all[:, :, 2:3], (h, w), 50, 1e-4, strict=False)
+    J_ref = precalc_jacobians(dI, P_all, vals, K)
+    # ---- kernel
+    L = _lib.lib()
+    Po = torch.empty((b, n, 3), dtype=dt, device=DEV)
+    mo = torch.empty((b, n), dtype=torch.uint8, device=DEV)
+    Jo = torch.empty((b, n, 1, 8), dtype=dt, device=DEV)
+    fn = getattr(L, "como_track_reference_" + _lib.suffix(dt))
+    _lib.check(fn(dev(depth).data_ptr(), dev(rel).data_ptr(), dev(K).data_ptr(), dev(dI).data_ptr(), dev(vals).data_ptr(), b, h, w, 50.0, 1e-4,
+                  Po.data_ptr(), mo.data_ptr(), Jo.data_ptr(), _lib.stream_ptr(torch.device(DEV))), "como_track_reference")
+    tol = 1e-12 if dt == torch.float64 else 2e-6
+    mm = int((mo.cpu().bool() != mask_ref).sum())
+    report("track_reference", dtype=str(dt), P=rel_err(Po, P_all), J=rel_err(Jo, J_ref), mask_mismatch=mm, masked=int((~mask_ref).sum()))
+    assert rel_err(Po, P_all) < tol and rel_err(Jo, J_ref) < tol * 20 and mm == 0 and int((~mask_ref).sum()) >= 1
+    # ---- reprojection of the newest keyframe's points into a moved frame
+    Tck = se3_exp(torch.tensor([[0.01, 0.02, -0.015, 0.08, -0.05, 0.03]], dtype=torch.float64)).to(dt)
+    Plast = P_all[-1]
+    Pc = _rigid(Tck, Plast[None])
+    pc = _project(K, Pc)
+    ok = _in_image(pc, Pc[:, :, 2:3], (h, w), 0, 0.0, strict=True)
+    img_ref = fill_image(swap_coords_xy(pc)[ok, :], Pc[:, :, 2:3][ok, :], (h, w))
+    seen_ref = ~torch.isnan(img_ref)
+    order = torch.zeros(h * w, dtype=torch.int64, device=DEV)
+    zb = torch.empty(n, dtype=dt, device=DEV)
+    img = torch.empty(h * w, dtype=dt, device=DEV)
+    seen = torch.empty(h * w, dtype=torch.uint8, device=DEV)
+    ns = torch.zeros(1, dtype=torch.int32, device=DEV)
+    fr = getattr(L, "como_reproject_depth_" + _lib.suffix(dt))
+    for _ in range(2):                                                           # twice: the claim table must come back clean
+        _lib.check(fr(dev(Tck.reshape(4, 4)).data_ptr(), dev(K).data_ptr(), dev(Plast.contiguous()).data_ptr(), n, h, w, order.data_ptr(),
+                      zb.data_ptr(), img.data_ptr(), seen.data_ptr(), ns.data_ptr(), _lib.stream_ptr(torch.device(DEV))), "como_reproject_depth")
+    sm = int((seen.cpu().bool().view(1, h, w) != seen_ref).sum())
+    both = seen.cpu().bool().view(1, h, w) & seen_ref
+    dv = (img.cpu().view(1, h, w)[both] - img_ref[both]).abs().max().item()
+    med = masked_median(img, seen)
+    report("reproject_depth", dtype=str(dt), seen=int(ns[0]), seen_ref=int(seen_ref.sum()), seen_mismatch=sm, value_diff=dv, median=med)
+    assert int(order.abs().sum()) == 0 and int(ns[0]) == int(seen.sum())
+    assert sm <= (0 if dt == torch.float64 else 2) and dv < tol * 10 and int(seen_ref.sum()) > 1000
+    if sm == 0:
+        assert abs(float(med) - float(torch.median(img_ref[seen_ref]))) < tol * 10
