@@ -255,10 +255,30 @@ def block_kernel_roofline(wb, dtype_name, reps=5):
     achieved = pixel_pairs * bytes_per / (blk_ms * 1e-3) / 1e9 if blk_ms > 0 else 0.0
     kname = "ba_blocks_pair2_kernel<2,4>" if dtype_name == "f32" else "ba_blocks_pair2_f64_kernel<4,true,1>"
     traffic, src = committed_traffic("ba_blocks_pair2_kernel" if dtype_name == "f32" else "ba_blocks_pair2_f64")
-    return {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src, "kernel_ms": blk_ms,
-            "algorithmic_bytes_per_launch": pixel_pairs * bytes_per,
-            "algorithmic_bytes_per_pixel_pair": bytes_per}
+    # the same launch priced on the matrix pipe: 320 v_mfma_*_16x16x4 (2048 flop each) per 64-pixel tile of a reference-keyframe
+    # group (two pairs share the 10 depth x depth tiles); data-sheet dense peaks of guides/MI355X_MICROARCH.md, and -- float64 --
+    # the rate scripts/micro/mfma_f64_rate.hip sustained on this part with every CU busy (profiles/r3_mfma_f64_rate.txt)
+    ngrp = int(getattr(wb.table, "ngroups", 0) or 0)
+    tiles = 0 if wb.idle else (wb.n + 63) // 64
+    flops = ngrp * tiles * 320 * 2048.0
+    peak_tf = 78.6 if dtype_name == "f64" else 157.3
+    tf = flops / (blk_ms * 1e-3) / 1e12 if blk_ms > 0 else 0.0
+    out = {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": src, "kernel_ms": blk_ms,
+           "algorithmic_bytes_per_launch": pixel_pairs * bytes_per,
+           "algorithmic_bytes_per_pixel_pair": bytes_per,
+           "mfma_flop_per_launch": flops, "mfma_tflops": tf, "mfma_peak_tflops": peak_tf, "mfma_frac": tf / peak_tf}
+    if dtype_name == "f64":
+        try:
+            for ln in open(os.path.join(ROOT, "profiles", "r3_mfma_f64_rate.txt")):
+                if ln.startswith("f64 mfma 16x16x4 only") and "blocks= 512" in ln:
+                    sus = float(ln.split("MFMA")[1].split("TFLOP/s")[0])
+                    out["mfma_sustained_probe_tflops"] = sus
+                    out["mfma_frac_of_sustained"] = tf / sus
+                    out["mfma_probe_source"] = "committed_profile:profiles/r3_mfma_f64_rate.txt (scripts/micro/mfma_f64_rate.hip, two waves per SIMD)"
+        except Exception:                                   # noqa: BLE001
+            pass
+    return out
 
 
 def tracking_leg(device, steps=200):

@@ -297,7 +297,8 @@ def test_tracker_glue_kernels_vs_torch_formulas(dt):
     mo = torch.empty((b, n), dtype=torch.uint8, device=DEV)
     Jo = torch.empty((b, n, 1, 8), dtype=dt, device=DEV)
     fn = getattr(L, "como_track_reference_" + _lib.suffix(dt))
-    _lib.check(fn(dev(depth).data_ptr(), dev(rel).data_ptr(), dev(K).data_ptr(), dev(dI).data_ptr(), dev(vals).data_ptr(), b, h, w, 50.0, 1e-4,
+    d_depth, d_rel, d_K, d_dI, d_vals = dev(depth), dev(rel).contiguous(), dev(K), dev(dI), dev(vals)     # (held: raw pointers below)
+    _lib.check(fn(d_depth.data_ptr(), d_rel.data_ptr(), d_K.data_ptr(), d_dI.data_ptr(), d_vals.data_ptr(), b, h, w, 50.0, 1e-4,
                   Po.data_ptr(), mo.data_ptr(), Jo.data_ptr(), _lib.stream_ptr(torch.device(DEV))), "como_track_reference")
     tol = 1e-12 if dt == torch.float64 else 2e-6
     mm = int((mo.cpu().bool() != mask_ref).sum())
@@ -317,8 +318,9 @@ def test_tracker_glue_kernels_vs_torch_formulas(dt):
     seen = torch.empty(h * w, dtype=torch.uint8, device=DEV)
     ns = torch.zeros(1, dtype=torch.int32, device=DEV)
     fr = getattr(L, "como_reproject_depth_" + _lib.suffix(dt))
+    d_Tck, d_P = dev(Tck.reshape(4, 4).contiguous()), dev(Plast.contiguous())
     for _ in range(2):                                                           # twice: the claim table must come back clean
-        _lib.check(fr(dev(Tck.reshape(4, 4)).data_ptr(), dev(K).data_ptr(), dev(Plast.contiguous()).data_ptr(), n, h, w, order.data_ptr(),
+        _lib.check(fr(d_Tck.data_ptr(), d_K.data_ptr(), d_P.data_ptr(), n, h, w, order.data_ptr(),
                       zb.data_ptr(), img.data_ptr(), seen.data_ptr(), ns.data_ptr(), _lib.stream_ptr(torch.device(DEV))), "como_reproject_depth")
     sm = int((seen.cpu().bool().view(1, h, w) != seen_ref).sum())
     both = seen.cpu().bool().view(1, h, w) & seen_ref
