@@ -104,7 +104,31 @@ class Mapping:
     # ---- window helpers (Mapping.py:470-497) ----------------------------------------------------------------------------
     def _cat(self, name, new_var, i):
         old = getattr(self, name)
+        if name == "Knm_Kmminv" and new_var.is_cuda:
+            return self._cat_pingpong(name, old, new_var, i)
         setattr(self, name, new_var.clone() if old.numel() == 0 and old.dim() == 1 else torch.cat((old[i:, ...], new_var), dim=0))
+
+    def _cat_pingpong(self, name, old, new_var, i):
+        """The dense predictors K~ are 157 MB per keyframe at 640x480 (float64): `torch.cat` of a growing window asks the allocator
+        for a new, larger block on every keyframe (a hipMalloc of > 1 GB: ~12 ms each while the window fills).  Two buffers of
+        the window's full capacity, allocated once, alternate instead; the window is a view of the current one."""
+        cap = self.cfg["graph"]["num_keyframes"]
+        pp = getattr(self, "_kt_pingpong", None)
+        if pp is None or pp[0].shape[1:] != new_var.shape[1:] or pp[0].dtype != new_var.dtype or pp[0].shape[0] != cap:
+            pp = self._kt_pingpong = [torch.empty((cap,) + tuple(new_var.shape[1:]), dtype=new_var.dtype, device=new_var.device)
+                                      for _ in range(2)]
+            self._kt_cur = 0
+        empty = old.numel() == 0 and old.dim() == 1
+        keep = old[0:0] if empty else old[i:, ...]
+        k = keep.shape[0]
+        if k + new_var.shape[0] > cap:
+            raise RuntimeError("como_amd Mapping: more keyframes than graph.num_keyframes")
+        self._kt_cur ^= 1
+        dst = pp[self._kt_cur]
+        if k:
+            dst[:k].copy_(keep)
+        dst[k:k + new_var.shape[0]].copy_(new_var)
+        setattr(self, name, dst[:k + new_var.shape[0]])
 
     def window_cat_helper_list(self, var, new_var, i):
         del var[:i]
