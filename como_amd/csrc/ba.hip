@@ -2031,6 +2031,10 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
                      (double*)A->pair_blocks_out, A->fix_plane, (long long*)A->blocks_fix)
     if (A->h_is_f64 == 2) {
       if (A->fix_plane < A->D * A->D + A->D + FIX_ERR_SLOTS) return COMO_ERR_ARG;
+      // fix_add's fraction plane holds 2^-56 units in 64 bits: 256 contributions to ONE entry are safe, more could lose a carry
+      // silently.  An entry receives at most one contribution per pair entry (the error slot, shared landmark diagonals) plus
+      // the <= 6 prior terms: refuse a batch that could exceed it instead of returning wrong normal equations.
+      if (b > 240) return COMO_ERR_ARG;
       if (A->reduce_mode != 0 && !A->blocks_fix) return COMO_ERR_ARG;
       if (A->reduce_mode == 1) { LAUNCH_ASM(long long, 1); }
       else if (A->reduce_mode == 2) { LAUNCH_ASM(long long, 2); }

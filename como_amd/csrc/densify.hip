@@ -182,35 +182,50 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
   __syncthreads();
   T* myD = sD[wv];
   const int tiles = (n + 63) >> 6;
-  for (int tile = blockIdx.x * 4 + wv; tile < tiles; tile += gridDim.x * 4) {
-    const int px0 = tile << 6;
-    Q4<T> kv[4][4];                     // (float64: 32 B per lane and load -- 16 rows x 128 contiguous bytes per wave load)
+  // Two half-tile register buffers (2 x 16 pixels each): the second half's K~ rows and the NEXT tile's first half are in flight
+  // while the matrix cores work on the other buffer and while the per-pixel epilogue runs -- one buffer of the whole tile made
+  // every wave wait for its 16 loads, multiply, then write, with nothing in flight in between (float64: 327 -> 288 us with the
+  // matrix-core kernel alone).
+  Q4<T> kA[2][4], kB[2][4];           // (float64: 32 B per lane and load -- 16 rows x 128 contiguous bytes per wave load)
+  auto load_half = [&](Q4<T> (&dst)[2][4], int tile_, int half) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int ii = min(px0 + 16 * it + c, n - 1);
+    for (int h2 = 0; h2 < 2; ++h2) {
+      const int ii = min((tile_ << 6) + 16 * (2 * half + h2) + c, n - 1);
       const int rw = pixidx ? pixidx[(long)b * n + ii] : ii;
       const T* Kr = Kt + (long)b * kt_slot_stride + (long)rw * m;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int kk = min(16 * s + 4 * q, m - 4);           // clamped: the matching coefficients are zero
-        kv[it][s] = ld4(Kr + kk);
+        dst[h2][s] = ld4(Kr + kk);
       }
     }
+  };
+  auto mma_half = [&](const Q4<T> (&src)[2][4], int half) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int h2 = 0; h2 < 2; ++h2) {
       acc_t acc = {T(0), T(0), T(0), T(0)};
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        acc = d_mfma(kv[it][s].x, bop[4 * s + 0], acc);
-        acc = d_mfma(kv[it][s].y, bop[4 * s + 1], acc);
-        acc = d_mfma(kv[it][s].z, bop[4 * s + 2], acc);
-        acc = d_mfma(kv[it][s].w, bop[4 * s + 3], acc);
+        acc = d_mfma(src[h2][s].x, bop[4 * s + 0], acc);
+        acc = d_mfma(src[h2][s].y, bop[4 * s + 1], acc);
+        acc = d_mfma(src[h2][s].z, bop[4 * s + 2], acc);
+        acc = d_mfma(src[h2][s].w, bop[4 * s + 3], acc);
       }
       if (c < 8) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) myD[(16 * it + d_mfma_row<T>(lane, r)) * 9 + c] = acc[r];
+        for (int r = 0; r < 4; ++r) myD[(16 * (2 * half + h2) + d_mfma_row<T>(lane, r)) * 9 + c] = acc[r];
       }
     }
+  };
+  const int tstride = gridDim.x * 4;
+  int tile = blockIdx.x * 4 + wv;
+  if (tile < tiles) load_half(kA, tile, 0);
+  for (; tile < tiles; tile += tstride) {
+    const int px0 = tile << 6;
+    load_half(kB, tile, 1);
+    mma_half(kA, 0);
+    if (tile + tstride < tiles) load_half(kA, tile + tstride, 0);     // (wave-uniform)
+    mma_half(kB, 1);
     wave_lds_fence();
     T a7[7];
 #pragma unroll

@@ -210,7 +210,8 @@ typedef struct como_ba_args {
   /* h_is_f64 == 2: ORDER-INDEPENDENT assembly.  Hmat points at a fixed-point system buffer (see como_sys_finalize): two
      planes of `fix_plane` int64 each, {H lower triangle (D*D, row-major, row >= col) | g (D) | err + spare (8)}; every
      contribution is added with exact integer atomics (associative -> the result does not depend on the order in which
-     workgroups, streams or ranks deliver it).  gvec / err_out are ignored. */
+     workgroups, streams or ranks deliver it).  gvec / err_out are ignored.  At most 240 pair entries (b) per call: the fraction
+     word of an entry holds 256 contributions before a carry could be lost (COMO_ERR_ARG beyond). */
   long fix_plane;
   /* reduce_mode (phase 128): 0 = reduce the per-workgroup records of every pair and expand / scatter them (single GPU);
      1 = reduce only: blocks_fix (b, 3936, 2) int64 receives the per-pair sums in fixed point (all-reduce them with an
