@@ -49,7 +49,8 @@ class WinArgs(ctypes.Structure):
                 + [(n, c_void_p) for n in ("H", "g", "err")]
                 + [("zero_a", c_void_p), ("zero_a_bytes", c_long), ("zero_b", c_void_p), ("zero_b_bytes", c_long),
                    ("median_out", c_void_p), ("sysfix", c_void_p), ("fix_plane", c_long),
-                   ("mld_J", c_void_p), ("mld_anchor", c_void_p), ("s_mld", c_double)])
+                   ("mld_J", c_void_p), ("mld_anchor", c_void_p), ("s_mld", c_double),
+                   ("zero_c", c_void_p), ("zero_c_bytes", c_long)])
 
 
 # name -> (restype, argtypes); every symbol include/como_hip.h declares
@@ -107,6 +108,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "como_chol_workspace_bytes": (c_long, [c_int]),
     "como_chol_solve_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "como_chol_solve_packed_f64": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "como_sys_finalize_pack": (c_int, [c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "como_chol_small_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "como_chol_small_f64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "como_trsm_lower_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),

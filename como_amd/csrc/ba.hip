@@ -1874,6 +1874,39 @@ __global__ __launch_bounds__(256) void sys_finalize_kernel(const long long* __re
   }
 }
 
+// sys_finalize + the packing step of the Cholesky solve in ONE launch: besides H / g / err8 it writes the solver's working copy
+// W (Dp x Dp, Dp = the dimension padded to whole 32-wide block columns incl. the appended right-hand-side row -- the layout of
+// chol_pack_kernel, csrc/chol.hip) and resets the factorisation status.  One thread per element of W.
+__global__ __launch_bounds__(256) void sys_finalize_pack_kernel(const long long* __restrict__ fix, long plane, long D,
+                                                                double* __restrict__ H, double* __restrict__ g,
+                                                                double* __restrict__ err8, double* __restrict__ W, long Dp,
+                                                                int* __restrict__ info) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx == 0) *info = 0;
+  if (idx < FIX_ERR_SLOTS && err8) err8[idx] = fix_value(fix[D * D + D + idx], (unsigned long long)fix[plane + D * D + D + idx]);
+  if (idx >= Dp * Dp) return;
+  const long i = idx / Dp, j = idx - i * Dp;
+  const bool poisoned = fix[D * D + D + FIX_POISON] != 0;
+  double v = 0.0;
+  if (i < D && j < D) {
+    if (j <= i) {
+      const long t = i * D + j;
+      v = fix_value(fix[t], (unsigned long long)fix[plane + t]);
+      if (poisoned && t == 0) v = __builtin_nan("");
+      H[t] = v;
+      if (j < i) H[j * D + i] = v;
+    }
+  } else if (i == D && j < D) {
+    v = fix_value(fix[D * D + j], (unsigned long long)fix[plane + D * D + j]);
+    g[j] = v;
+  } else if (i == D && j == D) {
+    v = 1e300;                                     // pivot of the appended row: irrelevant, just positive
+  } else if (i == j) {
+    v = 1.0;                                       // identity pad
+  }
+  W[idx] = v;
+}
+
 // ---------------------------------------- host side ----------------------------------------------
 template <typename T>
 int ba_linearize(const como_ba_args* A, hipStream_t s) {
@@ -2062,6 +2095,18 @@ int como_sys_finalize(const void* sysfix, long fix_plane, long D, double* H, dou
   const long total = D * D + D + como::FIX_ERR_SLOTS;
   hipLaunchKernelGGL(como::sys_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const long long*)sysfix, fix_plane, D, H, g, err8);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_sys_finalize_pack(const void* sysfix, long fix_plane, long D, double* H, double* g, double* err8, void* chol_workspace,
+                           int* info, como_stream_t stream) {
+  if (!sysfix || !H || !g || !chol_workspace || !info || D <= 0 || D > 4000 || fix_plane < D * D + D + como::FIX_ERR_SLOTS)
+    return COMO_ERR_ARG;
+  const long Dp = ((D + 1 + 31) / 32) * 32;        // como_chol_workspace_bytes' padding: whole 32-wide block columns
+  const long total = Dp * Dp;
+  hipLaunchKernelGGL(como::sys_finalize_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)sysfix, fix_plane, D, H, g, err8, (double*)chol_workspace, Dp, info);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }

@@ -536,10 +536,10 @@ long como_chol_workspace_bytes(int D) {
   return (2 * Dp * Dp + nb * como::CB * como::CB) * (long)sizeof(double);
 }
 
-int como_chol_solve_f64(const double* H, const double* g, double* delta, void* workspace, int D, int* info,
-                        como_stream_t stream) {
+static int chol_solve_impl(const double* H, const double* g, double* delta, void* workspace, int D, int* info,
+                           como_stream_t stream, bool packed) {
   using namespace como;
-  if (!H || !g || !delta || !workspace || !info || D <= 0 || D > 4000) return COMO_ERR_ARG;
+  if ((!packed && (!H || !g)) || !delta || !workspace || !info || D <= 0 || D > 4000) return COMO_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const int nb = (D + 1 + CB - 1) / CB;
   const int Dp = nb * CB;
@@ -547,8 +547,10 @@ int como_chol_solve_f64(const double* H, const double* g, double* delta, void* w
   const long tot = (long)Dp * Dp;
   double* Lw = W + tot;
   double* Iw = Lw + tot;
-  hipLaunchKernelGGL(chol_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, H, g, W, D, Dp, info);
-  COMO_CHECK_LAUNCH();
+  if (!packed) {                                      // (packed: como_sys_finalize_pack wrote W and reset info)
+    hipLaunchKernelGGL(chol_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, H, g, W, D, Dp, info);
+    COMO_CHECK_LAUNCH();
+  }
   if (Dp > 4096) return COMO_ERR_ARG;
   hipLaunchKernelGGL(chol_first2_kernel, dim3(1), dim3(512), 0, s, W, Lw, Iw, Dp, D, nb, info);
   COMO_CHECK_LAUNCH();
@@ -588,6 +590,15 @@ int como_chol_solve_f64(const double* H, const double* g, double* delta, void* w
     }
   }
   return COMO_OK;
+}
+
+int como_chol_solve_f64(const double* H, const double* g, double* delta, void* workspace, int D, int* info,
+                        como_stream_t stream) {
+  return chol_solve_impl(H, g, delta, workspace, D, info, stream, false);
+}
+
+int como_chol_solve_packed_f64(double* delta, void* workspace, int D, int* info, como_stream_t stream) {
+  return chol_solve_impl(nullptr, nullptr, delta, workspace, D, info, stream, true);
 }
 
 }  // extern "C"

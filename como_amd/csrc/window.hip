@@ -49,11 +49,12 @@ __global__ __launch_bounds__(64) void win_scaffold_kernel(
     const int* __restrict__ lm_ids, const int* __restrict__ first_frame, const int* __restrict__ first_slot,
     const double* __restrict__ Kmat, const double* __restrict__ median, const double* __restrict__ pm_first, int B, int m,
     ScaffoldOut o, ScaffoldPix<TP> px, uint4* __restrict__ za, long za16, uint4* __restrict__ zb, long zb16,
-    double* __restrict__ err8) {
+    double* __restrict__ err8, uint4* __restrict__ zc, long zc16) {
   const int b = blockIdx.x, j = threadIdx.x;
   // this iteration's accumulators that would otherwise each need a fill launch (~4.5 us apiece)
   for (long e = (long)b * 64 + j; e < za16; e += (long)gridDim.x * 64) za[e] = uint4{0u, 0u, 0u, 0u};
   for (long e = (long)b * 64 + j; e < zb16; e += (long)gridDim.x * 64) zb[e] = uint4{0u, 0u, 0u, 0u};
+  for (long e = (long)b * 64 + j; e < zc16; e += (long)gridDim.x * 64) zc[e] = uint4{0u, 0u, 0u, 0u};
   if (err8 && b == 0 && j < 8) err8[j] = 0.0;
   // pix-dtype copies of ALL frame poses / affine params (keyframes then recent frames)
   for (int e = b * 64 + j; e < F * 16; e += gridDim.x * 64) px.poses[e] = (TP)poses[e];
@@ -436,21 +437,27 @@ int como_win_scaffold(const como_win_args* a, como_stream_t stream) {
   ScaffoldOut o{a->pm, a->logzm, a->invz, a->dzdP, a->dlogz_dT, a->dlogz_dP, a->dp_dP, a->dp_dT, a->init_Pm, a->reinit_flag};
   int grid = a->B > (a->F * 16 + 63) / 64 ? a->B : (a->F * 16 + 63) / 64;
   const long za16 = a->zero_a ? a->zero_a_bytes / 16 : 0, zb16 = a->zero_b ? a->zero_b_bytes / 16 : 0;
-  if ((a->zero_a && (a->zero_a_bytes & 15)) || (a->zero_b && (a->zero_b_bytes & 15))) return COMO_ERR_ARG;
-  if (za16 + zb16 > 0 && grid < 64) grid = 64;             // enough threads for the clears
+  const long zc16 = a->zero_c ? a->zero_c_bytes / 16 : 0;
+  if ((a->zero_a && (a->zero_a_bytes & 15)) || (a->zero_b && (a->zero_b_bytes & 15)) || (a->zero_c && (a->zero_c_bytes & 15)))
+    return COMO_ERR_ARG;
+  if (za16 + zb16 + zc16 > 0 && grid < 64) grid = 64;      // enough threads for the clears
+  if (zc16 > 0) {                                          // megabytes (the fixed-point system): ~4 stores per thread
+    const long want = (zc16 + 64 * 4 - 1) / (64 * 4);
+    if (want > grid) grid = (int)(want > 8192 ? 8192 : want);
+  }
   double* zerr = (a->zero_a || a->zero_b) ? a->err : nullptr;
   if (a->pix_is_f64) {
     ScaffoldPix<double> px{(double*)a->px_logzm, (double*)a->px_invz, (double*)a->px_dzdP, (double*)a->px_dlogz_dT,
                            (double*)a->px_poses, (double*)a->px_aff};
     hipLaunchKernelGGL(win_scaffold_kernel<double>, dim3(grid), dim3(64), 0, s, a->poses, a->aff, a->F, a->P_m, a->lm_ids,
                        a->first_frame, a->first_slot, a->K, a->median, a->pm_first, a->B, a->m, o, px, (uint4*)a->zero_a, za16,
-                       (uint4*)a->zero_b, zb16, zerr);
+                       (uint4*)a->zero_b, zb16, zerr, (uint4*)a->zero_c, zc16);
   } else {
     ScaffoldPix<float> px{(float*)a->px_logzm, (float*)a->px_invz, (float*)a->px_dzdP, (float*)a->px_dlogz_dT,
                           (float*)a->px_poses, (float*)a->px_aff};
     hipLaunchKernelGGL(win_scaffold_kernel<float>, dim3(grid), dim3(64), 0, s, a->poses, a->aff, a->F, a->P_m, a->lm_ids,
                        a->first_frame, a->first_slot, a->K, a->median, a->pm_first, a->B, a->m, o, px, (uint4*)a->zero_a, za16,
-                       (uint4*)a->zero_b, zb16, zerr);
+                       (uint4*)a->zero_b, zb16, zerr, (uint4*)a->zero_c, zc16);
   }
   COMO_CHECK_LAUNCH();
   hipLaunchKernelGGL(win_apply_reinit_kernel, dim3((a->L + 255) / 256), dim3(256), 0, s, a->P_m, a->init_Pm, a->reinit_flag, a->L);

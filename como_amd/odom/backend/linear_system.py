@@ -72,6 +72,30 @@ def solve_system(H, g, ws=None):
     return torch.cholesky_solve(g[:, None], Lf, upper=False)
 
 
+def chol_workspace(D, device, ws):
+    """(workspace, info, delta) of the blocked HIP factorisation for a D x D float64 system, kept in the caller-owned dict `ws`
+    (a captured graph records the addresses)."""
+    from como_amd import _lib
+    key = (str(device), D)
+    w = ws.get(key)
+    if w is None:
+        w = (torch.empty(_lib.lib().como_chol_workspace_bytes(D) // 8, dtype=torch.float64, device=device),
+             torch.zeros(1, dtype=torch.int32, device=device), torch.empty((D, 1), dtype=torch.float64, device=device))
+        ws[key] = w
+    return w
+
+
+def solve_packed(D, device, ws):
+    """delta = H^-1 g for a system `como_sys_finalize_pack` already packed into the solver's working copy (the fused window
+    chain: the packing launch of solve_system is folded into the fixed-point -> float64 conversion)."""
+    from como_amd import _lib
+    w = chol_workspace(D, device, ws)
+    rc = _lib.lib().como_chol_solve_packed_f64(w[2].data_ptr(), w[0].data_ptr(), D, w[1].data_ptr(), _lib.stream_ptr(device))
+    _lib.check(rc, "como_chol_solve_packed")
+    solve_system.last_info = w[1]
+    return w[2]
+
+
 def update_vars(delta, kf_poses, kf_aff_params, kf_inds, recent_poses, recent_aff_params, recent_inds, P,
                 landmark_ind_start):
     d = delta.squeeze(-1)

@@ -259,6 +259,8 @@ class WindowBA:
         self.w["hist_ba"] = torch.zeros(hb // 4, dtype=torch.int32, device=self.dev)
         a.zero_a, a.zero_a_bytes = ptr(self.w["hist_dr2"]), 2 * B * hb
         a.zero_b, a.zero_b_bytes = ptr(self.w["hist_ba"]), hb
+        if self.sysfix is not None and (self.sysfix.numel() * 8) % 16 == 0:
+            a.zero_c, a.zero_c_bytes = ptr(self.sysfix), self.sysfix.numel() * 8      # the scaffold launch clears it (no fill launch)
         a.median_out = ptr(self.median_depths)
         if not self.window_full:
             # mean_log_depth_cost (gp_priors.py:84-150): J = column means of keyframe 0's K~ (float64 sum of the pix-dtype rows, as the
@@ -279,7 +281,8 @@ class WindowBA:
         L, a, w, dev = _lib.lib(), self.win_args, self.w, self.dev
         s = _lib.stream_ptr(dev)
         _lib.check(L.como_win_scaffold(ctypes.byref(a), s), "como_win_scaffold")
-        self.sysfix.zero_()
+        if not a.zero_c:
+            self.sysfix.zero_()
         dr = lambda part: dense_reference_factored(w["px_logzm"], w["px_poses"][:self.B], self.Kt, self.pixidx, self.K_pix,
                                                    w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"],
                                                    hists=w["hist_dr"], ws=w["dr_ws"], part=part, compact=True)
@@ -322,9 +325,15 @@ class WindowBA:
                 fm("all")
             if self.with_priors:
                 _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")   # also stores the new median depths
-        _lib.check(L.como_sys_finalize(self.sysfix.data_ptr(), self.fix_plane, self.dim, self.H.data_ptr(), self.g.data_ptr(),
-                                       self.err8.data_ptr(), s), "como_sys_finalize")
+        self._finalize(s)
         return self.H, self.g
+
+    def _finalize(self, s):
+        """Fixed point -> float64 H / g / err AND the Cholesky solver's packed working copy, one launch."""
+        cw = lin_sys.chol_workspace(self.dim, self.dev, self.w["chol_ws"])
+        _lib.check(_lib.lib().como_sys_finalize_pack(self.sysfix.data_ptr(), self.fix_plane, self.dim, self.H.data_ptr(), self.g.data_ptr(),
+                                                     self.err8.data_ptr(), cw[0].data_ptr(), cw[1].data_ptr(), s), "como_sys_finalize_pack")
+        self._packed = True
 
     def _linearize_sharded(self, dr):
         """The multi-GPU iteration: the same kernels on this rank's pixel range, plus two kinds of collectives (all
@@ -399,13 +408,14 @@ class WindowBA:
             _lib.check(getattr(L, "como_select_finish_" + sfx)(hmed.data_ptr(), B, med_out.data_ptr(), s), "como_select_finish")
             if self.with_priors:
                 _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")
-        _lib.check(L.como_sys_finalize(self.sysfix.data_ptr(), self.fix_plane, self.dim, self.H.data_ptr(), self.g.data_ptr(),
-                                       self.err8.data_ptr(), s), "como_sys_finalize")
+        self._finalize(s)
         return self.H, self.g
 
     def iterate_fused(self):
+        self._packed = False
         H, g = self.linearize_fused()
-        delta = lin_sys.solve_system(H, g, ws=self.w["chol_ws"])
+        delta = (lin_sys.solve_packed(self.dim, self.dev, self.w["chol_ws"]) if self._packed
+                 else lin_sys.solve_system(H, g, ws=self.w["chol_ws"]))
         rc = _lib.lib().como_win_update(delta.data_ptr(), self.poses_all.data_ptr(), self.aff_all.data_ptr(),
                                         self.frame_inds.data_ptr(), self.F, self.P_m.data_ptr(), self.L, self.lm_start,
                                         _lib.stream_ptr(self.dev))

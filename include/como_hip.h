@@ -340,6 +340,8 @@ int como_ktilde_f64(const double* cov, int Hc, int Wc, const double* xm, const d
 long como_chol_workspace_bytes(int D);
 int como_chol_solve_f64(const double* H, const double* g, double* delta, void* workspace, int D, int* info,
                         como_stream_t stream);
+/* the factorisation + substitutions of a system como_sys_finalize_pack already packed into `workspace` */
+int como_chol_solve_packed_f64(double* delta, void* workspace, int D, int* info, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Conditioning of the small SPD systems of the DepthCov path (n <= 80), batched: ONE launch, one workgroup per matrix, float32
@@ -407,6 +409,7 @@ typedef struct como_win_args {
      (constant for a topology).  mld_J != NULL (and nfix == 0) selects it; its error goes to slot 6 of the err block like the
      anchors' (the two are alternatives). */
   const double* mld_J; const double* mld_anchor; double s_mld;
+  void* zero_c; long zero_c_bytes;                /* optional third buffer cleared by como_win_scaffold (the fixed-point system buffer) */
 } como_win_args;
 
 int como_win_scaffold(const como_win_args* args_host, como_stream_t stream);
@@ -418,6 +421,11 @@ int como_win_priors(const como_win_args* args_host, como_stream_t stream);
  * so that the factorisation reports it.  The buffer must be zeroed before the first contribution of an iteration. */
 long como_sys_fix_plane_elems(long D);
 int como_sys_finalize(const void* sysfix, long fix_plane, long D, double* H, double* g, double* err8, como_stream_t stream);
+/* The same conversion fused with the first step of como_chol_solve_f64: also writes the solver's packed working copy into
+ * chol_workspace (como_chol_workspace_bytes(D) bytes) and resets *info; continue with como_chol_solve_packed_f64 (one launch
+ * less on the critical path of every GN iteration). */
+int como_sys_finalize_pack(const void* sysfix, long fix_plane, long D, double* H, double* g, double* err8, void* chol_workspace,
+                           int* info, como_stream_t stream);
 int como_win_update(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
                     long lm_start, como_stream_t stream);
 
