@@ -11,9 +11,12 @@
 //                    inverted by the workgroup that just updated it (factor_invert_tile: four pivots per barrier, rank-4
 //                    MFMA updates).  A non-positive pivot is reported in `info` (1-based, first failure) instead of being
 //                    swallowed; the factorisation then continues with pivot 1 as a defined value.
-//   chol_backsub + chol_backsub_rect: L^T delta = y, split into 2 or 4 block ranges: triangle / rectangle / triangle ... launches.
+//   back-substitution L^T delta = y: up to 40 block columns (D < 1280) it RIDES ALONG with the factorisation (an identity block
+//                    appended under g turns into L^-T tile by tile, delta accumulates in the panel launches; chol_xfinish);
+//                    above that chol_backsub + chol_backsub_rect, 4 block ranges: triangle / rectangle / triangle ... launches.
 #include "common.cuh"
 #include "../../include/como_hip.h"
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(512) void chol_first2_kernel(const double* __restri
 // still read the un-factored panel blocks from W); Iw: inverses of the diagonal blocks of L (nb x CB x CB).
 __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W, double* __restrict__ Lw,
                                                           double* __restrict__ Iw, int Dp, int D, int c0, int nb,
-                                                          int* __restrict__ info) {
+                                                          int* __restrict__ info, double* __restrict__ xacc) {
   __shared__ double sm[NT2 * TSZ];
   double* sV0 = sm;
   double* sV1 = sm + 1 * TSZ;
@@ -276,7 +279,15 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
   const int c1 = c0 + 1, d0 = c0 + 2, d1 = c0 + 3;
   const bool has1 = d1 < nb;
   int ti = -1, tj = -1;
-  {
+  const int ntrail = nb - d0, tiles_reg = ntrail * (ntrail + 1) / 2;
+  const bool app = (int)blockIdx.x >= tiles_reg;   // a tile of the appended identity rows (the ride-along back-substitution)
+  int ar = 0;                                      // its block row among the appended rows
+  if (app) {
+    const int t = blockIdx.x - tiles_reg;
+    ar = t / ntrail;
+    ti = nb + ar;                                  // block row nb + ar of the 2 Dp x Dp working copy
+    tj = d0 + t % ntrail;
+  } else {
     int t = blockIdx.x;
     for (int i = d0; i < nb; ++i) {
       const int cnt = i - d0 + 1;            // j = d0 .. i
@@ -284,6 +295,8 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
       t -= cnt;
     }
   }
+  // an appended row that enters with this column pair has never been written: its tiles are still [.. 0 I 0 ..]
+  const bool virgin = app && ar >= c0;
   if (has1 && ti == tj && ti <= d1) return;  // tiles (d0,d0), (d1,d1) belong to the chain workgroup
   const bool chain = has1 ? (ti == d1 && tj == d0) : (ti == d0);
   const long k0 = (long)c0 * CB, k1 = (long)c1 * CB;
@@ -295,9 +308,9 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
       t[u][0] = Iw[((long)c0 * CB + r) * CB + c];
       t[u][1] = Iw[((long)c1 * CB + r) * CB + c];
       t[u][2] = Lw[(k1 + r) * Dp + k0 + c];
-      t[u][3] = W[((long)ti * CB + r) * Dp + k0 + c];
+      t[u][3] = virgin ? ((ar == c0 && r == c) ? 1.0 : 0.0) : W[((long)ti * CB + r) * Dp + k0 + c];
       t[u][4] = W[((long)tj * CB + r) * Dp + k0 + c];
-      t[u][5] = W[((long)ti * CB + r) * Dp + k1 + c];
+      t[u][5] = virgin ? ((ar == c1 && r == c) ? 1.0 : 0.0) : W[((long)ti * CB + r) * Dp + k1 + c];
       t[u][6] = W[((long)tj * CB + r) * Dp + k1 + c];
     }
 #pragma unroll
@@ -364,8 +377,21 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int r = mrow(w, l, i), c = mcol(w, l);
-        if (ti != tj || c <= r) W[((long)ti * CB + r) * Dp + (long)tj * CB + c] -= acc[i];
+        double* dst = &W[((long)ti * CB + r) * Dp + (long)tj * CB + c];
+        if (ti != tj || c <= r) *dst = (virgin ? 0.0 : *dst) - acc[i];
       }
+    } else if (app && tj == nb - 1 && tid < 256 + CB) {
+      // x_r += (L^-T)_{r,c0} y_c0 + (L^-T)_{r,c1} y_c1: sI0 / sI1 hold the two finished tiles of appended row r, and row
+      // D - 32 (nb - 1) of sJ0 / sJ1 (block row nb - 1 holds the appended right-hand side) is y for these two block columns.
+      // One owner per x_r and launch, launches in stream order: a fixed summation order, no atomics.
+      const int t = tid - 256, gl = D - (nb - 1) * CB;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+      for (int k = 0; k < CB; ++k) {
+        s0 = __builtin_fma(sI0[t * CLD + k], sJ0[gl * CLD + k], s0);
+        s1 = __builtin_fma(sI1[t * CLD + k], sJ1[gl * CLD + k], s1);
+      }
+      xacc[ar * CB + t] = (virgin ? 0.0 : xacc[ar * CB + t]) + (s0 + s1);
     }
     return;
   }
@@ -403,6 +429,78 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
   }
   __syncthreads();
   factor_pair_tail(sm, has1, d0, Lw, Iw, Dp, D, info);
+}
+
+// Ride-along back-substitution (systems of up to RIDE_MAX_NB block columns).  The working copy carries Dp more rows: an
+// identity block B appended under H and g.  The panel operations turn appended row block r into row block r of L^-T (tile (r, c)
+// is final once column c is eliminated, like row D turns g into y = L^-1 g), and delta = L^-T y accumulates tile by tile in the
+// launches that already exist: no pass over the finished factor at all (the two-triangle back-substitution it replaces was
+// 55 us of a 300 us solve at D = 760, on ONE compute unit).  The appended tiles double the trailing updates -- work that is off
+// the serial chain of a launch (it ends long before the chain workgroup does) as long as every workgroup of a launch is
+// co-resident; from RIDE_MAX_NB on the trailing updates are what a launch waits for, and the substitution kernels below are
+// used instead.  Nothing initialises the appended rows: a row block that has not met a column pair yet is known to be
+// [0 .. I .. 0] (`virgin`).
+// chol_xfinish: the last one or two block columns (cf, cf + 1 -- factored by the last chain workgroup, no trailing tiles left)
+// applied to every appended row block r, and delta_r = x_r + (L^-T)_{r,cf} y_cf + (L^-T)_{r,cf+1} y_cf+1.
+constexpr int RIDE_MAX_NB = 40;
+__global__ __launch_bounds__(256) void chol_xfinish_kernel(const double* __restrict__ W, const double* __restrict__ Lw,
+                                                           const double* __restrict__ Iw, int Dp, int D, int nb, int cf,
+                                                           const double* __restrict__ xacc, double* __restrict__ delta) {
+  __shared__ double sm[5 * TSZ];
+  __shared__ double yv[2 * CB];
+  double* sV0 = sm;
+  double* sV1 = sm + 1 * TSZ;
+  double* sL10 = sm + 2 * TSZ;
+  double* sB0 = sm + 3 * TSZ;
+  double* sB1 = sm + 4 * TSZ;
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+  const int r = blockIdx.x, c1 = cf + 1;
+  const bool two = c1 < nb, virgin = r >= cf;
+  for (int e = tid; e < CB * CB; e += 256) {
+    const int rr = e / CB, c = e % CB, o = rr * CLD + c;
+    sV0[o] = Iw[((long)cf * CB + rr) * CB + c];
+    sB0[o] = virgin ? ((r == cf && rr == c) ? 1.0 : 0.0) : W[((long)(nb + r) * CB + rr) * Dp + (long)cf * CB + c];
+    if (two) {
+      sV1[o] = Iw[((long)c1 * CB + rr) * CB + c];
+      sL10[o] = Lw[((long)c1 * CB + rr) * Dp + (long)cf * CB + c];
+      sB1[o] = virgin ? ((r == c1 && rr == c) ? 1.0 : 0.0) : W[((long)(nb + r) * CB + rr) * Dp + (long)c1 * CB + c];
+    }
+  }
+  if (tid < 2 * CB) {                                      // y of the last columns; the appended row's own pivot and the pad are no unknowns
+    const int col = cf * CB + tid;
+    yv[tid] = (col < D && (tid < CB || two)) ? Lw[(long)D * Dp + col] : 0.0;
+  }
+  __syncthreads();
+  {
+    d4_t a = {0.0, 0.0, 0.0, 0.0};
+    tile_nt_mfma(sB0, sV0, w, l, a);                       // (L^-T)_{r,cf} = B_r,cf V0^T
+    __syncthreads();
+    tile_store_mfma(sB0, w, l, a);
+  }
+  __syncthreads();
+  if (two) {
+    d4_t b = {0.0, 0.0, 0.0, 0.0};
+    tile_nt_mfma(sB0, sL10, w, l, b);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sB1[mrow(w, l, i) * CLD + mcol(w, l)] -= b[i];
+    __syncthreads();
+    d4_t c = {0.0, 0.0, 0.0, 0.0};
+    tile_nt_mfma(sB1, sV1, w, l, c);
+    __syncthreads();
+    tile_store_mfma(sB1, w, l, c);
+    __syncthreads();
+  }
+  if (tid < CB) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+    for (int k = 0; k < CB; ++k) s0 = __builtin_fma(sB0[tid * CLD + k], yv[k], s0);
+    if (two) {
+#pragma unroll 8
+      for (int k = 0; k < CB; ++k) s1 = __builtin_fma(sB1[tid * CLD + k], yv[CB + k], s1);
+    }
+    const double x = (virgin ? 0.0 : xacc[r * CB + tid]) + (s0 + s1);
+    if (r * CB + tid < D) delta[r * CB + tid] = x;
+  }
 }
 
 // L^T delta = y with y = row D of L (columns 0..D-1).
@@ -533,7 +631,8 @@ extern "C" {
 long como_chol_workspace_bytes(int D) {
   const long nb = (D + 1 + como::CB - 1) / como::CB;
   const long Dp = nb * como::CB;
-  return (2 * Dp * Dp + nb * como::CB * como::CB) * (long)sizeof(double);
+  // working copy incl. the appended identity rows (2 Dp x Dp) | factor (Dp x Dp) | inverted diagonal blocks | x accumulator
+  return (3 * Dp * Dp + nb * como::CB * como::CB + Dp) * (long)sizeof(double);
 }
 
 static int chol_solve_impl(const double* H, const double* g, double* delta, void* workspace, int D, int* info,
@@ -545,8 +644,14 @@ static int chol_solve_impl(const double* H, const double* g, double* delta, void
   const int Dp = nb * CB;
   double* W = (double*)workspace;
   const long tot = (long)Dp * Dp;
-  double* Lw = W + tot;
+  double* Lw = W + 2 * tot;
   double* Iw = Lw + tot;
+  double* xacc = Iw + (long)nb * CB * CB;
+  static const int ride_max = [] {                       // COMO_CHOL_RIDE_MAX: measurement / test override of the cross-over
+    const char* e = getenv("COMO_CHOL_RIDE_MAX");
+    return e ? atoi(e) : RIDE_MAX_NB;
+  }();
+  const bool ride = nb <= ride_max;
   if (!packed) {                                      // (packed: como_sys_finalize_pack wrote W and reset info)
     hipLaunchKernelGGL(chol_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, H, g, W, D, Dp, info);
     COMO_CHECK_LAUNCH();
@@ -557,10 +662,15 @@ static int chol_solve_impl(const double* H, const double* g, double* delta, void
   for (int c0 = 0; c0 + 2 < nb; c0 += 2) {               // two block columns per launch
     const int r = nb - (c0 + 2);
     const int tiles = r * (r + 1) / 2;
-    hipLaunchKernelGGL(chol_panel2_kernel, dim3(tiles), dim3(512), 0, s, W, Lw, Iw, Dp, D, c0, nb, info);
+    const int app = ride ? (c0 + 2) * r : 0;             // appended rows 0 .. c0 + 1 x the r trailing block columns
+    hipLaunchKernelGGL(chol_panel2_kernel, dim3(tiles + app), dim3(512), 0, s, W, Lw, Iw, Dp, D, c0, nb, info, xacc);
     COMO_CHECK_LAUNCH();
   }
-  if (nb < 6) {
+  if (ride) {
+    hipLaunchKernelGGL(chol_xfinish_kernel, dim3(nb), dim3(256), 0, s, (const double*)W, (const double*)Lw, (const double*)Iw, Dp,
+                       D, nb, ((nb - 1) / 2) * 2, (const double*)xacc, delta);
+    COMO_CHECK_LAUNCH();
+  } else if (nb < 6) {
     hipLaunchKernelGGL(chol_backsub_kernel, dim3(1), dim3(BS_THREADS), 0, s, Lw, Iw, Dp, D, 0, nb, (const double*)nullptr,
                        (double*)nullptr, delta, (const double*)nullptr, 0, 0);
     COMO_CHECK_LAUNCH();
