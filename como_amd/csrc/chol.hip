@@ -47,31 +47,80 @@ __device__ __forceinline__ double rsq_cubic(double d) {        // hardware estim
   return __builtin_fma(r, e * __builtin_fma(0.375, e, 0.5), r);
 }
 
+// 4x4 Cholesky M = L L^T and W = L^-1 (row-major lower), ~45 dependent operations.  A non-positive pivot is replaced by 1 and
+// reported in `bad` (1-based position inside the block, first failure).
+struct Micro4 {
+  double i0, i1, i2, i3, w10, w20, w21, w30, w31, w32;
+  int bad;
+};
+__device__ __forceinline__ Micro4 micro_chol4(double m00, double m10, double m20, double m30, double m11, double m21, double m31,
+                                              double m22, double m32, double m33) {
+  Micro4 o;
+  int bad = 0;
+  double d0 = m00;
+  if (!(d0 > 0.0)) { bad = bad ? bad : 1; d0 = 1.0; }
+  const double i0 = rsq_cubic(d0);
+  const double l10 = m10 * i0, l20 = m20 * i0, l30 = m30 * i0;
+  double d1 = __builtin_fma(-l10, l10, m11);
+  if (!(d1 > 0.0)) { bad = bad ? bad : 2; d1 = 1.0; }
+  const double i1 = rsq_cubic(d1);
+  const double l21 = __builtin_fma(-l20, l10, m21) * i1, l31 = __builtin_fma(-l30, l10, m31) * i1;
+  double d2 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, m22));
+  if (!(d2 > 0.0)) { bad = bad ? bad : 3; d2 = 1.0; }
+  const double i2 = rsq_cubic(d2);
+  const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, m32)) * i2;
+  double d3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, m33)));
+  if (!(d3 > 0.0)) { bad = bad ? bad : 4; d3 = 1.0; }
+  const double i3 = rsq_cubic(d3);
+  o.i0 = i0; o.i1 = i1; o.i2 = i2; o.i3 = i3;
+  o.w10 = -i1 * (l10 * i0);
+  o.w21 = -i2 * (l21 * i1);
+  o.w32 = -i3 * (l32 * i2);
+  o.w20 = -i2 * __builtin_fma(l21, o.w10, l20 * i0);
+  o.w31 = -i3 * __builtin_fma(l32, o.w21, l31 * i1);
+  o.w30 = -i3 * __builtin_fma(l32, o.w20, __builtin_fma(l31, o.w10, l30 * i0));
+  o.bad = bad;
+  return o;
+}
+
 // Factor a 32x32 tile (lower part of the LDS tile At, leading dimension CLD) and invert the factor, 512 threads, FOUR
 // pivots per barrier.  Measured cost model on MI355X (scripts/micro): a wave issues ~1 VALU instruction per 4-6 cycles, an
 // LDS store -> barrier -> load hop is ~150 cycles, dependent f64 ops ~6 cycles: a pivot-by-pivot loop (one barrier per
 // pivot, 32 of them) cost ~500 cycles per pivot = 6.7 us per tile, all of it on the serial chain of a panel step.
-// Blocked by 4, the per-pivot work becomes
-//   * a 4x4 Cholesky + inverse W of the diagonal micro-block, computed REDUNDANTLY by every lane of the four factor waves
-//     from ten LDS reads (no hand-off, ~45 dependent operations),
-//   * the panel P[r][0..3] = A[r][p0..p0+3] W^T and the rank-4 trailing update A -= P P^T as ONE v_mfma_f64_16x16x4_f64 per
-//     16x16 quadrant: waves 0..3 keep the quadrants of A in the MFMA accumulator layout, lane l supplies P[row l&15][k l>>4],
-//   * waves 4..7 run the inverse ONE block behind with the same shape: X_B = W S_B, S -= P X_B, reading W and P from LDS.
-// One barrier per block step, 9 in all.  Rows / columns are published raw to small ping-pong buffers; L and L^-1 go to
-// global memory (and L^-1 to `ldsInv` when the caller needs it on chip) as they are produced.
-// scratch: 800 doubles.  At may alias ldsInv (At is consumed before the first barrier, L^-1 is written after the second).
+// Blocked by 4, with the work of a block step split over three ROLES that run concurrently between two barriers:
+//   * MICRO (wave 5), one block AHEAD: the 4x4 diagonal micro-block of block s + 1 is brought up to date with a private rank-4
+//     look-ahead update (lane (i, j): D'[i][j] = D[i][j] - sum_k Pb[i][k] Pb[j][k], Pb = the four rows of the current panel,
+//     24 FMAs), exchanged inside the wave, then every lane runs the 4x4 Cholesky + inverse W_{s+1} (~45 dependent operations)
+//     and lane 0 publishes W.  This is the serial chain of the tile: ~60 % of a step of round 2's version, where every
+//     update wave ran the micro-block itself BEFORE it could start on its panel (5.4 us per tile).
+//   * UPDATE (waves 0..3): the panel P[r][0..3] = A[r][p0..p0+3] W_s^T (W_s read from LDS, one row per lane) and the rank-4
+//     trailing update A -= P P^T as ONE v_mfma_f64_16x16x4_f64 per 16x16 quadrant: the waves keep the quadrants of A in the MFMA
+//     accumulator layout, lane l supplies P[row l&15][k l>>4].  They publish the next four columns (raw) and the 4x4 diagonal
+//     block after next for the micro wave.
+//   * INVERSE (waves 4, 6, 7: the three non-zero quadrants of the triangular inverse), one block BEHIND: X_B = W S_B,
+//     S -= P X_B, reading W and P from LDS.
+// One barrier per block step, 9 in all.  L and L^-1 go to global memory (and L^-1 to `ldsInv` when the caller needs it on chip)
+// as they are produced.
+// scratch: 880 doubles.  At may alias ldsInv (At is consumed before the first barrier, L^-1 is written after the second).
 __device__ __forceinline__ void factor_invert_tile(const double* At, double* scratch, double* __restrict__ Lw,
                                                    double* __restrict__ Iw, int Dp, int k, int D, int* __restrict__ info,
                                                    double* ldsInv = nullptr) {
-  const int tid = threadIdx.x, role = tid >> 8, w = (tid >> 6) & 3, l = tid & 63;
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+  const int role = wv == 5 ? 2 : (wv >> 2);          // 0 update, 1 inverse, 2 micro
+  const int w = wv & 3;
   const int qa = w >> 1, qb = w & 1, lr = l & 15, kq = l >> 4;
   const long kk = (long)k * CB;
   double* colbuf = scratch;             // [2][4][32] raw columns of the current block: colbuf[t][r] = A[r][p0 + t]
   double* rowbuf = scratch + 256;       // [2][4][32] raw rows of S
   double* Pbuf = scratch + 512;         // [2][4][32] panel of the block the inverse works on: P[t][r] (0 for r < p0 + 4)
-  double* Wbuf = scratch + 768;         // [2][16]    its micro-inverse W (row-major)
+  double* Wbuf = scratch + 768;         // [4][16]    micro-inverses W_s (row-major), block s at slot s & 3
+  double* Dbuf = scratch + 832;         // [2][16]    4x4 diagonal block two blocks ahead (lower part valid)
+  double* Xbuf = scratch + 864;         // [16]       exchange inside the micro wave
   const int rowA = 16 * qa + lr, rowB = 16 * qb + lr;
-  d4_t acc;
+  const int mi = (l >> 2) & 3, mj = l & 3;            // micro wave: lane <-> entry (mi, mj) of the 4x4 block
+  d4_t acc = {0.0, 0.0, 0.0, 0.0};
+  Micro4 mc = {};
+  double draw = 0.0;
   if (role == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -82,10 +131,23 @@ __device__ __forceinline__ void factor_invert_tile(const double* At, double* scr
 #pragma unroll
       for (int i = 0; i < 4; ++i) colbuf[lr * 32 + 16 * qa + kq + 4 * i] = acc[i];
     }
-  } else {
+  } else if (role == 1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = (16 * qa + kq + 4 * i == 16 * qb + lr) ? 1.0 : 0.0;
-    if (tid < 256 + 128) { const int t = (tid - 256) >> 5, j = (tid - 256) & 31; rowbuf[t * 32 + j] = (t == j) ? 1.0 : 0.0; }
+    if (wv != 7) { const int e = (wv == 4 ? 0 : 64) + l, t = e >> 5, j = e & 31; rowbuf[t * 32 + j] = (t == j) ? 1.0 : 0.0; }
+  } else {
+    // block 0 straight from the tile; the raw block 1 entry of this lane for the first look-ahead
+    mc = micro_chol4(At[0], At[CLD], At[2 * CLD], At[3 * CLD], At[CLD + 1], At[2 * CLD + 1], At[3 * CLD + 1], At[2 * CLD + 2],
+                     At[3 * CLD + 2], At[3 * CLD + 3]);
+    draw = At[(4 + mi) * CLD + 4 + mj];
+    if (l == 0) {
+      if (mc.bad && kk + mc.bad - 1 < D) atomicCAS(info, 0, (int)kk + mc.bad);
+      double* wb = Wbuf;
+      wb[0] = mc.i0; wb[1] = 0.0; wb[2] = 0.0; wb[3] = 0.0;
+      wb[4] = mc.w10; wb[5] = mc.i1; wb[6] = 0.0; wb[7] = 0.0;
+      wb[8] = mc.w20; wb[9] = mc.w21; wb[10] = mc.i2; wb[11] = 0.0;
+      wb[12] = mc.w30; wb[13] = mc.w31; wb[14] = mc.w32; wb[15] = mc.i3;
+    }
   }
   // ROLLED on purpose: unrolled, the nine steps are ~2000 instructions executed once each -- instruction-fetch bound
 #pragma unroll 1
@@ -95,38 +157,8 @@ __device__ __forceinline__ void factor_invert_tile(const double* At, double* scr
       if (s == CB / 4) continue;
       const int p0 = 4 * s;
       const double* cb = colbuf + (s & 1) * 128;
-      // ---- 4x4 micro-block: M = L L^T, W = L^-1
-      const double m00 = cb[p0], m10 = cb[p0 + 1], m20 = cb[p0 + 2], m30 = cb[p0 + 3];
-      const double m11 = cb[32 + p0 + 1], m21 = cb[32 + p0 + 2], m31 = cb[32 + p0 + 3];
-      const double m22 = cb[64 + p0 + 2], m32 = cb[64 + p0 + 3], m33 = cb[96 + p0 + 3];
-      int bad = 0;
-      double d0 = m00;
-      if (!(d0 > 0.0)) { bad = bad ? bad : 1; d0 = 1.0; }
-      const double i0 = rsq_cubic(d0);
-      const double l10 = m10 * i0, l20 = m20 * i0, l30 = m30 * i0;
-      double d1 = __builtin_fma(-l10, l10, m11);
-      if (!(d1 > 0.0)) { bad = bad ? bad : 2; d1 = 1.0; }
-      const double i1 = rsq_cubic(d1);
-      const double l21 = __builtin_fma(-l20, l10, m21) * i1, l31 = __builtin_fma(-l30, l10, m31) * i1;
-      double d2 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, m22));
-      if (!(d2 > 0.0)) { bad = bad ? bad : 3; d2 = 1.0; }
-      const double i2 = rsq_cubic(d2);
-      const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, m32)) * i2;
-      double d3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, m33)));
-      if (!(d3 > 0.0)) { bad = bad ? bad : 4; d3 = 1.0; }
-      const double i3 = rsq_cubic(d3);
-      if (bad && tid == 0 && kk + p0 + bad - 1 < D) atomicCAS(info, 0, (int)kk + p0 + bad);
-      const double w10 = -i1 * (l10 * i0);
-      const double w21 = -i2 * (l21 * i1);
-      const double w32 = -i3 * (l32 * i2);
-      const double w20 = -i2 * __builtin_fma(l21, w10, l20 * i0);
-      const double w31 = -i3 * __builtin_fma(l32, w21, l31 * i1);
-      const double w30 = -i3 * __builtin_fma(l32, w20, __builtin_fma(l31, w10, l30 * i0));
-      // row kq of W
-      const double wk0 = kq == 0 ? i0 : (kq == 1 ? w10 : (kq == 2 ? w20 : w30));
-      const double wk1 = kq == 0 ? 0.0 : (kq == 1 ? i1 : (kq == 2 ? w21 : w31));
-      const double wk2 = kq < 2 ? 0.0 : (kq == 2 ? i2 : w32);
-      const double wk3 = kq == 3 ? i3 : 0.0;
+      const double* wr = Wbuf + (s & 3) * 16 + 4 * kq;      // row kq of W_s
+      const double wk0 = wr[0], wk1 = wr[1], wk2 = wr[2], wk3 = wr[3];
       // ---- panel entries this lane feeds to the matrix core: P[rowA][kq], P[rowB][kq]
       const double pA = __builtin_fma(cb[96 + rowA], wk3, __builtin_fma(cb[64 + rowA], wk2, __builtin_fma(cb[32 + rowA], wk1, cb[rowA] * wk0)));
       const double pB = __builtin_fma(cb[96 + rowB], wk3, __builtin_fma(cb[64 + rowB], wk2, __builtin_fma(cb[32 + rowB], wk1, cb[rowB] * wk0)));
@@ -137,32 +169,64 @@ __device__ __forceinline__ void factor_invert_tile(const double* At, double* scr
         if (p0 + kq <= rowA) Lw[(kk + rowA) * Dp + kk + p0 + kq] = pA;
         Pbuf[(s & 1) * 128 + kq * 32 + rowA] = pAu;
       }
-      if (w == 0 && lr == 0) {
-        double* wb = Wbuf + (s & 1) * 16 + 4 * kq;
-        wb[0] = wk0; wb[1] = wk1; wb[2] = wk2; wb[3] = wk3;
-      }
       const int c = 16 * qb + lr;
       if (s + 1 < CB / 4 && w != 1 && c >= p0 + 4 && c < p0 + 8) {
         double* nb = colbuf + ((s + 1) & 1) * 128 + (c - (p0 + 4)) * 32 + 16 * qa + kq;
 #pragma unroll
         for (int i = 0; i < 4; ++i) nb[4 * i] = acc[i];
       }
+      // the diagonal 4x4 block after next, updated through this step: rows p0 + 8 + kq of the diagonal quadrant that holds it
+      if (s + 2 < CB / 4 && qa == qb && qa == ((p0 + 8) >> 4) && c >= p0 + 8 && c < p0 + 12) {
+        const int isel = ((p0 + 8) & 15) >> 2;
+        const double v = isel == 0 ? acc[0] : (isel == 1 ? acc[1] : (isel == 2 ? acc[2] : acc[3]));
+        Dbuf[((s + 1) & 1) * 16 + kq * 4 + (c - (p0 + 8))] = v;
+      }
+    } else if (role == 2) {
+      if (s >= CB / 4 - 1) continue;                     // W_1 .. W_7 at steps 0 .. 6
+      const int p0 = 4 * s;
+      const double* cb = colbuf + (s & 1) * 128 + p0 + 4;  // rows p0 + 4 .. p0 + 7 of the current raw columns
+      const double a0 = cb[mi], a1 = cb[32 + mi], a2 = cb[64 + mi], a3 = cb[96 + mi];
+      const double b0 = cb[mj], b1 = cb[32 + mj], b2 = cb[64 + mj], b3 = cb[96 + mj];
+      const double dr = s == 0 ? draw : Dbuf[(s & 1) * 16 + mi * 4 + mj];
+      // Pb = C W_s^T for rows mi and mj (W lower triangular)
+      const double pa0 = a0 * mc.i0, pb0 = b0 * mc.i0;
+      const double pa1 = __builtin_fma(a1, mc.i1, a0 * mc.w10), pb1 = __builtin_fma(b1, mc.i1, b0 * mc.w10);
+      const double pa2 = __builtin_fma(a2, mc.i2, __builtin_fma(a1, mc.w21, a0 * mc.w20));
+      const double pb2 = __builtin_fma(b2, mc.i2, __builtin_fma(b1, mc.w21, b0 * mc.w20));
+      const double pa3 = __builtin_fma(a3, mc.i3, __builtin_fma(a2, mc.w32, __builtin_fma(a1, mc.w31, a0 * mc.w30)));
+      const double pb3 = __builtin_fma(b3, mc.i3, __builtin_fma(b2, mc.w32, __builtin_fma(b1, mc.w31, b0 * mc.w30)));
+      const double dn = __builtin_fma(-pa3, pb3, __builtin_fma(-pa2, pb2, __builtin_fma(-pa1, pb1, __builtin_fma(-pa0, pb0, dr))));
+      if (l < 16) Xbuf[l] = dn;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // one wave: its LDS accesses complete in order
+      mc = micro_chol4(Xbuf[0], Xbuf[4], Xbuf[8], Xbuf[12], Xbuf[5], Xbuf[9], Xbuf[13], Xbuf[10], Xbuf[14], Xbuf[15]);
+      if (l == 0) {
+        if (mc.bad && kk + p0 + 4 + mc.bad - 1 < D) atomicCAS(info, 0, (int)kk + p0 + 4 + mc.bad);
+        double* wb = Wbuf + ((s + 1) & 3) * 16;
+        wb[0] = mc.i0; wb[1] = 0.0; wb[2] = 0.0; wb[3] = 0.0;
+        wb[4] = mc.w10; wb[5] = mc.i1; wb[6] = 0.0; wb[7] = 0.0;
+        wb[8] = mc.w20; wb[9] = mc.w21; wb[10] = mc.i2; wb[11] = 0.0;
+        wb[12] = mc.w30; wb[13] = mc.w31; wb[14] = mc.w32; wb[15] = mc.i3;
+      }
     } else {
       if (s == 0) continue;
       const int sb = s - 1, p0 = 4 * sb, prv = sb & 1;
-      const double* wb = Wbuf + prv * 16 + 4 * kq;
+      const double* wb = Wbuf + (sb & 3) * 16 + 4 * kq;
       const double* rb = rowbuf + prv * 128;
       const double pA = Pbuf[prv * 128 + kq * 32 + rowA];
       const double x = __builtin_fma(wb[3], rb[96 + rowB], __builtin_fma(wb[2], rb[64 + rowB], __builtin_fma(wb[1], rb[32 + rowB], wb[0] * rb[rowB])));
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-pA, x, acc, 0, 0, 0);
-      if (qa == 0) {                                    // waves 4 and 5 hold X[p0 + kq][0..31] once each
+      if (wv != 6) {                                    // waves 4 and 7 hold X[p0 + kq][0..15] / [16..31]
         Iw[(long)k * CB * CB + (p0 + kq) * CB + rowB] = x;
         if (ldsInv) ldsInv[(p0 + kq) * CLD + rowB] = x;
       }
-      if (sb + 1 < CB / 4 && qa == ((p0 + 4) >> 4)) {   // rows p0+4 .. p0+7 of S are final: publish them raw
-        const int isel = ((p0 + 4) & 15) >> 2;
-        const double v = isel == 0 ? acc[0] : (isel == 1 ? acc[1] : (isel == 2 ? acc[2] : acc[3]));
-        rowbuf[(s & 1) * 128 + kq * 32 + rowB] = v;
+      if (sb + 1 < CB / 4) {                            // rows p0+4 .. p0+7 of S are final: publish them raw
+        if (qa == ((p0 + 4) >> 4)) {
+          const int isel = ((p0 + 4) & 15) >> 2;
+          const double v = isel == 0 ? acc[0] : (isel == 1 ? acc[1] : (isel == 2 ? acc[2] : acc[3]));
+          rowbuf[(s & 1) * 128 + kq * 32 + rowB] = v;
+        } else if (wv == 7) {                           // rows above 16 are zero right of column 15 (no wave holds that quadrant)
+          rowbuf[(s & 1) * 128 + kq * 32 + rowB] = 0.0;
+        }
       }
     }
   }

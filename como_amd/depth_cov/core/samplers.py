@@ -114,7 +114,12 @@ def greedy_loop(coord_vec_inds, coords_n_norm, E_n, coords_domain_norm, E_domain
     k_ii = sv + (float(fixed_var) if fixed_var is not None else 0.0)
     nxt = _Next(coords_domain_norm, dist_thresh)
     pred_var = calc_var(obs_info[:, :m, :], sv).contiguous()
-    if all(t.is_contiguous() for t in (coords_n_norm, E_n, L, obs_info, coord_vec_inds, E_domain)):
+    # (the loop's in / out arrays are this module's own temporaries -- only the returned indices leave it -- so strided views
+    # are simply packed: a strided E_domain used to send every second sampler run of a keyframe through the per-point
+    # fallback below, ~45 points x (6 launches + a host synchronisation))
+    coords_n_norm, E_n, L, obs_info, coord_vec_inds, E_domain = (t.contiguous() for t in (coords_n_norm, E_n, L, obs_info,
+                                                                                          coord_vec_inds, E_domain))
+    if True:
         # the whole loop on the device: two launches per added point.  Early termination (samplers.py:255-259) is decided
         # afterwards from the per-step trace of the largest remaining standard deviation -- the greedy sequence does not
         # depend on where it is cut -- with ONE read-back instead of one per step.

@@ -1,6 +1,8 @@
 """Time the dense SPD solve alone (como_chol_solve_f64) at the window system sizes: graph replay of `reps` solves, HIP events.
 Usage: python scripts/chol_time.py [D ...]   (COMO_CHOL_RIDE_MAX=0 forces the separate back-substitution kernels)"""
+import os
 import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import como_amd.odom.backend.linear_system as ls
 

@@ -52,6 +52,10 @@ def main():
     ap.add_argument("--pix", default="float")
     ap.add_argument("--save-traj", default=None, help="write the tracked trajectory in TUM format")
     ap.add_argument("--cprofile-after", type=int, default=-1, help="cProfile the loop from this frame on (host-side breakdown)")
+    ap.add_argument("--census-after", type=int, default=-1,
+                    help="count torch API calls per como_amd source line from this frame on (TorchFunctionMode)")
+    ap.add_argument("--torch-profile-after", type=int, default=-1,
+                    help="torch.profiler (with python stacks) from this frame on: which source lines launch the small torch kernels")
     args = ap.parse_args()
     dev = "cuda:0"
     H, W = args.H, args.W
@@ -94,17 +98,70 @@ def main():
     t0 = time.perf_counter()
     t_first_tracked = None
     prof = None
+    tprof = None
+    census = None
     for k in range(args.frames):
         if k == args.cprofile_after:
             import cProfile
             prof = cProfile.Profile()
             prof.enable()
+        if k == args.census_after:
+            from torch.overrides import TorchFunctionMode
+
+            class Census(TorchFunctionMode):
+                def __init__(self):
+                    super().__init__()
+                    self.n = {}
+
+                def __torch_function__(self, func, types, a=(), kw=None):
+                    f = sys._getframe(1)
+                    while f is not None and "como_amd" not in f.f_code.co_filename:
+                        f = f.f_back
+                    if f is not None:
+                        name = getattr(func, "__name__", str(func))
+                        key = (f.f_code.co_filename.split("como_amd/")[-1], f.f_lineno, name)
+                        self.n[key] = self.n.get(key, 0) + 1
+                    return func(*a, **(kw or {}))
+            census = Census()
+            census.__enter__()
+        if k == args.torch_profile_after:
+            from torch.profiler import ProfilerActivity, profile
+            tprof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True)
+            tprof.__enter__()
         kinds.append(odo.iter(1.0 + 0.033 * k, rgbs[k]))
         if t_first_tracked is None and odo.mapping.is_init:
             torch.cuda.synchronize()
             t_first_tracked = (k, time.perf_counter())
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    if census is not None:
+        census.__exit__(None, None, None)
+        os.makedirs("gpurun_out", exist_ok=True)
+        skip = {"__get__", "size", "dim", "shape", "is_contiguous", "data_ptr", "stride", "numel", "view", "reshape", "__getitem__",
+                "expand", "unsqueeze", "squeeze", "permute", "transpose", "is_cuda", "device", "dtype", "element_size"}
+        byline = {}
+        for (fn, ln, name), c in census.n.items():
+            if name in skip:
+                continue
+            byline.setdefault((fn, ln), []).append((name, c))
+        with open("gpurun_out/odo_census.txt", "w") as f:
+            nfr = args.frames - args.census_after
+            f.write(f"torch API calls per source line over {nfr} frames (views / metadata excluded)\n")
+            for (fn, ln), v in sorted(byline.items(), key=lambda kv: -sum(c for _, c in kv[1]))[:140]:
+                f.write(f"{sum(c for _, c in v) / nfr:8.2f}/frame  {fn}:{ln}  " + ", ".join(f"{n} x{c}" for n, c in sorted(v, key=lambda t: -t[1])) + "\n")
+    if tprof is not None:
+        tprof.__exit__(None, None, None)
+        os.makedirs("gpurun_out", exist_ok=True)
+        ka = tprof.key_averages(group_by_stack_n=12)
+        rows = []
+        for e in ka:
+            src = [f for f in e.stack if "como_amd" in f]
+            rows.append((e.count, e.self_device_time_total if hasattr(e, "self_device_time_total") else e.self_cuda_time_total,
+                         e.key, " <- ".join(x.strip()[-70:] for x in src[:3])))
+        with open("gpurun_out/odo_torchprof.txt", "w") as f:
+            f.write("count  self_device_us  op  <- como_amd frames (innermost first)\n")
+            for c, t, kname, src in sorted(rows, key=lambda r: -r[0])[:150]:
+                f.write(f"{c:6d} {t:12.0f}  {kname[:40]:40s} {src}\n")
     if prof is not None:
         import io
         import pstats

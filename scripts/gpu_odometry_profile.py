@@ -78,7 +78,9 @@ def main():
         odo.iter(1.0 + 0.033 * k, rgbs[k])
         if hasattr(pt.photo_level_tracking, "last_iters"):
             iters.append(pt.photo_level_tracking.last_iters)
-    out = {k: {"mean_ms": round(1e3 * sum(v) / len(v), 3), "n": len(v)} for k, v in sorted(parts.items())}
+    med = lambda v: sorted(v)[len(v) // 2]
+    out = {k: {"mean_ms": round(1e3 * sum(v) / len(v), 3), "median_ms": round(1e3 * med(v), 3), "total_ms": round(1e3 * sum(v), 1),
+               "n": len(v)} for k, v in sorted(parts.items())}
     out["finest_level_iters_mean"] = sum(iters) / max(len(iters), 1)
     print(json.dumps(out, indent=1))
 

@@ -153,7 +153,10 @@ def summarise(rec, mp, st0, keep_full_H):
         out[name + "_scaled_probe"] = S @ V
         out[name + "_scaled_fro"] = torch.linalg.norm(S)
         out[name + "_pose_block"] = H[:8 * mp.kf_poses.shape[0], :8 * mp.kf_poses.shape[0]].clone()
-        if keep_full_H:
+        if keep_full_H == "tril":                   # the whole matrix as its packed lower triangle (row-major tril_indices order)
+            ti = torch.tril_indices(H.shape[0], H.shape[0])
+            out[name + "_tril"] = H[ti[0], ti[1]].clone()
+        elif keep_full_H:
             out[name] = H
     out["median_depths_full"] = mp.median_depths.clone()          # store_vars: full-image median (Mapping.py:749-758)
     out["kf_poses_new"], out["kf_aff_new"], out["P_new"] = mp.kf_poses.clone(), mp.kf_aff_params.clone(), mp.P_m.clone()
@@ -177,7 +180,7 @@ def fullwin_case(window, B=8, H=480, W=640, m=64, seed=0, iters=3):
             t1 = time.time()
             mp.iterate()
             print(f"  reference iterate {it}: {time.time() - t1:.1f} s, err {float(mp.total_err_prev):.6e}")
-            s = summarise(hk.rec, mp, st, keep_full_H=(it == 0 and window == 4))
+            s = summarise(hk.rec, mp, st, keep_full_H=(False if it else (True if window == 4 else "tril")))
             for k, v in s.items():
                 out[f"it{it}_{k}"] = v
             if it == 0:
