@@ -204,6 +204,55 @@ __device__ void sel_resolve_part(const uint32_t* __restrict__ hists, int npass_d
   }
 }
 
+// The same resolution inside a block of MORE than 256 threads (the 1024-thread streaming passes): the first 256 threads own the
+// bins, every thread takes part in the barriers and returns the same values.
+template <typename KeyT>
+__device__ void sel_resolve_wide(const uint32_t* __restrict__ hists, int npass_done, SelScratch* sc,
+                                 KeyT& prefix, uint32_t& k_rem, uint32_t& nvalid) {
+  constexpr int PER = SEL_BINS / 256;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const bool own = tid < 256;
+  prefix = 0;
+  k_rem = 0;
+  nvalid = 0;
+  for (int p = 0; p < npass_done; ++p) {
+    const uint32_t* h = hists + p * SEL_BINS;
+    uint32_t local = 0;
+    if (own)
+      for (int j = 0; j < PER; ++j) local += h[tid * PER + j];
+    uint32_t incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63 && wv < 4) sc->wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wv) base += sc->wave_tot[w]; tot += sc->wave_tot[w]; }
+    if (p == 0) {
+      nvalid = tot;
+      k_rem = (tot > 0) ? (tot - 1) / 2 : 0;
+    }
+    const uint32_t excl = base + incl - local;
+    if (tid == 0) { sc->found_bin = 0; sc->found_below = 0; }
+    __syncthreads();
+    if (own && local > 0 && k_rem >= excl && k_rem < excl + local) {
+      uint32_t run = excl;
+      for (int j = 0; j < PER; ++j) {
+        const uint32_t cj = h[tid * PER + j];
+        if (k_rem >= run && k_rem < run + cj) { sc->found_bin = tid * PER + j; sc->found_below = run; }
+        run += cj;
+      }
+    }
+    __syncthreads();
+    prefix |= ((KeyT)sc->found_bin) << SelCfg<KeyT>::shift(p);
+    k_rem -= sc->found_below;
+    __syncthreads();
+  }
+}
+
 // LDS histogram increment of the fused digit-0 pass.  Plain ds_add: the keys of a wave fall into ~10-30 exponent bins, the
 // hardware resolves the few-way conflicts in a handful of cycles; a ballot loop that issued one add per DISTINCT bin
 // cost ~150 instructions per wave and was half of the residual kernel (73 -> 43 us).

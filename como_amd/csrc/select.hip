@@ -1,4 +1,5 @@
 // Stand-alone entry points of the exact radix select (see select.cuh).
+#include <cstdlib>
 #include "select.cuh"
 #include "../../include/como_hip.h"
 
@@ -18,9 +19,12 @@ __device__ __forceinline__ uint32_t* sel_cand_count(uint32_t* h) { return h + 4 
 __device__ __forceinline__ uint32_t* sel_cand_done(uint32_t* h) { return h + 4 * SEL_BINS + 1025; }
 __device__ __forceinline__ uint64_t* sel_cand_keys(uint32_t* h) { return reinterpret_cast<uint64_t*>(h + 5 * SEL_BINS + 1024); }
 
-template <typename T>
-__global__ __launch_bounds__(256) void select_hist_kernel(const T* __restrict__ r, const uint8_t* __restrict__ valid,
-                                                          long n, uint32_t* __restrict__ hists, int pass_flags) {
+// NTHR = 256, or 1024 for long slices: the flush at the end of a workgroup (up to 2048 same-address global atomics) caps the
+// number of workgroups at one per compute unit, and four waves per compute unit keep too few loads in flight to stream
+// (34 MB of double keys took 22 us) -- sixteen waves share the same LDS histogram and the same single flush.
+template <typename T, int NTHR>
+__global__ __launch_bounds__(NTHR) void select_hist_kernel(const T* __restrict__ r, const uint8_t* __restrict__ valid,
+                                                           long n, uint32_t* __restrict__ hists, int pass_flags) {
   using KeyT = typename KeyOf<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
   __shared__ SelScratch sc;
@@ -32,9 +36,10 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const T* __restrict__ 
   hists += (long)blockIdx.y * 6 * SEL_BINS;
   if (sizeof(T) == 8 && pass >= 4 && *sel_cand_done(hists)) return;      // the tail kernel already produced this digit
                                                                         // (plain passes 4, 5 after a collecting pass 3)
-  for (int b = threadIdx.x; b < SEL_BINS; b += 256) lh[b] = 0;
+  for (int b = threadIdx.x; b < SEL_BINS; b += NTHR) lh[b] = 0;
   KeyT prefix; uint32_t k_rem, nv;
-  sel_resolve<KeyT>(hists, pass, &sc, prefix, k_rem, nv);   // contains __syncthreads (also orders the lh init)
+  if constexpr (NTHR == 256) sel_resolve<KeyT>(hists, pass, &sc, prefix, k_rem, nv);   // contains __syncthreads (also orders the lh init)
+  else sel_resolve_wide<KeyT>(hists, pass, &sc, prefix, k_rem, nv);
   __syncthreads();
   // 4 elements per thread and iteration (16 B + 4 B loads) when the slice allows it: the pass is pure streaming and
   // was latency-bound with one scalar load per iteration
@@ -44,8 +49,8 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const T* __restrict__ 
     // four independent 16-byte loads per thread and trip: with one, 256 workgroups keep 1 MB in flight and the pass is
     // latency-bound (21 MB in 17 us)
     const long n4 = n >> 2;
-    const long stride = (long)gridDim.x * 256;
-    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n4; i0 += 4 * stride) {
+    const long stride = (long)gridDim.x * NTHR;
+    for (long i0 = (long)blockIdx.x * NTHR + threadIdx.x; i0 < n4; i0 += 4 * stride) {
       float4 rv[4];
       uint32_t vv[4];
 #pragma unroll
@@ -70,8 +75,8 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const T* __restrict__ 
   } else {
     // four independent elements per trip (their loads in flight together): with one element per trip the double-precision
     // pass streamed 34 MB in 32 us
-    const long stride = (long)gridDim.x * 256;
-    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    const long stride = (long)gridDim.x * NTHR;
+    for (long i0 = (long)blockIdx.x * NTHR + threadIdx.x; i0 < n; i0 += 4 * stride) {
       T e[4];
       bool ok[4];
 #pragma unroll
@@ -202,7 +207,14 @@ int select_hist(const T* r, const uint8_t* valid, long n, int nseg, uint32_t* hi
   blocks = (blocks + 3) / 4;                         // 4 elements per thread on the vector path
   if (blocks < 1) blocks = 1;
   if (blocks > cap) blocks = cap;
-  hipLaunchKernelGGL(select_hist_kernel<T>, dim3((unsigned)blocks, nseg), dim3(256), 0, s, r, valid, n, hists, pass_flags);
+  static const bool wide_ok = [] { const char* e = getenv("COMO_SEL_WIDE"); return !e || e[0] != '0'; }();
+  // (long single slices only: the segmented per-keyframe medians run beside other kernels on a side stream, where fat workgroups
+  // measured neutral to slightly negative)
+  if (wide_ok && n >= (1L << 20) && blocks == cap && (n + 4095) / 4096 >= cap) {
+    hipLaunchKernelGGL((select_hist_kernel<T, 1024>), dim3((unsigned)blocks, nseg), dim3(1024), 0, s, r, valid, n, hists, pass_flags);
+  } else {
+    hipLaunchKernelGGL((select_hist_kernel<T, 256>), dim3((unsigned)blocks, nseg), dim3(256), 0, s, r, valid, n, hists, pass_flags);
+  }
   COMO_CHECK_LAUNCH();
   if (sizeof(T) == 8 && (pass_flags & SEL_COLLECT) && pass == 3) {
     hipLaunchKernelGGL(select_tail_kernel, dim3(nseg), dim3(256), 0, s, hists, (const double*)r, valid, n);
