@@ -52,7 +52,7 @@ done
 COMO_SINGLE_DEVICE=1 COMO_DIST_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --replicas --gpus 2 --steps 60 --warmup 5 > $OUT/bench_replicas2_one_gpu.json 2> $OUT/bench_replicas2_one_gpu.err
 timeout 300 python bench.py --replicas --steps 60 --warmup 5 > $OUT/bench_replicas1.json 2> $OUT/bench_replicas1.err
 # the default bench line on the same box
-python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+timeout 900 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 head -8 $OUT/bench_f64_eager_kernel_stats.csv | cut -c1-140
 grep -i "pair2\|dense_ref\|residual\|track_level" $OUT/bench_pmc_summary.txt $OUT/track_pmc_summary.txt | head
 grep -i "pair2" $OUT/bench_mfma_summary.txt | head -3
