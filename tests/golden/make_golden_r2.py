@@ -2,7 +2,7 @@
 on a real `como.odom.Mapping.Mapping` object whose state attributes are filled from a seeded synthetic window, and records
 what the reference computed (hooks around `create_photo_system` and `solve_system` keep the intermediate H / g).
 
-    python tests/golden/make_golden_r2.py [fullwin4] [fullwin1] [reinit] [win32] [se3] [pairs] [ate] [ate_rgb] [rgb] [datasets]
+    python tests/golden/make_golden_r2.py [fullwin4] [fullwin1] [fullwin32] [reinit] [win32] [se3] [pairs] [ate] [ate_rgb] [rgb] [datasets]
 
 Cases
   fullwin4 / fullwin1 : the METRIC configuration -- 8 keyframes, 640x480, m = 64, nonmax window 4 (reference default) and
@@ -180,7 +180,8 @@ def fullwin_case(window, B=8, H=480, W=640, m=64, seed=0, iters=3):
             t1 = time.time()
             mp.iterate()
             print(f"  reference iterate {it}: {time.time() - t1:.1f} s, err {float(mp.total_err_prev):.6e}")
-            s = summarise(hk.rec, mp, st, keep_full_H=(False if it else (True if window == 4 else "tril")))
+            # the whole matrices of iteration 0 where they are small enough to commit (D = 760: 4.6 MB each; packed at window 1)
+            s = summarise(hk.rec, mp, st, keep_full_H=(False if (it or B > 8) else (True if window == 4 else "tril")))
             for k, v in s.items():
                 out[f"it{it}_{k}"] = v
             if it == 0:
@@ -478,6 +479,8 @@ if __name__ == "__main__":
         mg.save("fullsize_window4.npz", fullwin_case(4))
     if "fullwin1" in which:
         mg.save("fullsize_window1.npz", fullwin_case(1, iters=1))
+    if "fullwin32" in which:                     # config 4's window at FULL image size, the reference's default sub-selection
+        mg.save("fullsize_window32.npz", fullwin_case(4, B=32, iters=2, seed=3))
     if "pairs" in which:
         mg.save("pair_graph.npz", pair_graph_case())
     if "ate" in which:

@@ -403,6 +403,63 @@ def test_window32_vs_reference(pix):
     assert worst["pose"] < (1e-8 if f64 else 1e-4) and worst["P"] < (1e-6 if f64 else 5e-3)
 
 
+def test_fullsize_config4_window_vs_reference():
+    """Config 4's window at FULL size -- 32 keyframes, 640x480, m = 64, 62 pairs, the reference's default sub-selection
+    (window 4), D = 8 B + 3 L -- against the reference's own Mapping.iterate (fixture fullsize_window32.npz: scalars, D-vectors,
+    Jacobi-scaled probe products, the new state after each of two iterations), float64 pixel path (the reference's mapping dtype).
+    The reduced-resolution 32-keyframe tests (test_window32_vs_reference, the sharded ones) cover the same code at 60x80."""
+    import como_amd.odom.backend.photo as photo
+    import como_amd.odom.backend.linear_system as ls
+    G = load_golden("fullsize_window32.npz")
+    pix = torch.float64
+    g0 = lambda k: G["it0_" + k]
+    wb, st = _window_from_seed(G, pix, 4)
+    D = int(g0("delta").shape[0])
+    assert wb.dim == D and wb.table.b == 62
+    wb.with_priors = False
+    H, g = wb.linearize()
+    torch.cuda.synchronize()
+    dcount = (_pair_counts(wb) - g0("pair_nvalid")).abs().max().item()
+    sig_rel = abs(float(wb.sigma[0]) - float(g0("sigma_r"))) / float(g0("sigma_r"))
+    eHd = rel_err(torch.diagonal(H), g0("H_photo_diag"))
+    ePB = scaled_err(H[:8 * 32, :8 * 32], g0("H_photo_pose_block"))
+    eg = rel_err(g, g0("g_photo"))
+    eerr = abs(float(wb.err) - float(g0("photo_err"))) / float(g0("photo_err"))
+    d = torch.sqrt(g0("H_photo_diag")).to(DEV)
+    dinv = torch.where(d > 0, 1.0 / d.clamp_min(1e-300), torch.zeros_like(d))
+    from tests.golden_probes import probes
+    Sv = (dinv[:, None] * H * dinv[None, :]) @ probes(D).to(DEV)
+    eprobe = ((Sv.cpu() - g0("H_photo_scaled_probe")).abs().max() / g0("H_photo_scaled_probe").abs().max()).item()
+    pi, ii = G["sample_pair"], G["sample_pix"]
+    valid = photo.last_aux["valid"].view(wb.table.b, -1).cpu().bool()
+    r = photo.last_aux["r"].view(wb.table.b, -1).cpu().double()
+    samp_mis = int((valid[pi, ii] != G["sample_valid"]).sum())
+    both = valid[pi, ii] & G["sample_valid"]
+    samp_r = (r[pi, ii] - G["sample_r"])[both].abs().max().item()
+    # whole iterations (fresh state)
+    del wb, H, g, Sv
+    wb, st = _window_from_seed(G, pix, 4)
+    iters = sum(1 for k in G if k.endswith("_delta"))
+    worst = {"pose": 0.0, "P": 0.0, "aff": 0.0, "med": 0.0, "delta": 0.0}
+    for it in range(iters):
+        gi = lambda k: G[f"it{it}_{k}"]
+        wb.iterate()
+        torch.cuda.synchronize()
+        worst["delta"] = max(worst["delta"], rel_err(wb.delta, gi("delta")))
+        worst["pose"] = max(worst["pose"], (wb.kf_poses.cpu() - gi("kf_poses_new")).abs().max().item())
+        worst["aff"] = max(worst["aff"], (wb.kf_aff_params.cpu() - gi("kf_aff_new")).abs().max().item())
+        worst["P"] = max(worst["P"], (wb.P_m.cpu() - gi("P_new")).abs().max().item())
+        worst["med"] = max(worst["med"], ((wb.median_depths.cpu() - gi("median_depths_full")).abs() / gi("median_depths_full")).max().item())
+    report("fullsize_config4_vs_reference", D=D, count_diff=dcount, sigma_rel=sig_rel, H_diag_rel=eHd, pose_block_scaled=ePB, g_rel=eg,
+           err_rel=eerr, probe_rel=eprobe, sample_mask_mismatch=samp_mis, sample_r_err=samp_r, iters=iters,
+           info=int(ls.solve_system.last_info), **worst)
+    assert dcount == 0 and samp_mis == 0 and samp_r < 2e-7 and sig_rel < 2e-7
+    tolH = 5e-7                                   # the conditioning of K~ (see test_fullsize_metric_window_vs_reference)
+    assert eHd < tolH and ePB < tolH and eprobe < 10 * tolH and eg < tolH and eerr < 5e-7
+    assert int(ls.solve_system.last_info) == 0
+    assert worst["pose"] < 1e-7 and worst["aff"] < 1e-7 and worst["P"] < 1e-5 and worst["med"] < 1e-7
+
+
 @pytest.mark.parametrize("D", [2399, 2400, 2440, 3200])
 def test_cholesky_solve_config4_sizes(D):
     """The dense solve at the 32-keyframe system size (D = 8 B + 3 L ~ 2.4 k, linear_system.py:101-112) and above."""
