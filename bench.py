@@ -223,6 +223,13 @@ def run_window(args, device, pix_dtype, window, shard=None, seed=None, state=Non
     for _ in range(args.warmup):
         wb.iterate()
     graphed = (not args.eager) and wb.capture()
+    if shard is not None and getattr(shard, "world", 1) > 1 and not args.eager:
+        # every rank must take the same path (graph replay or eager launches): if the capture failed on ANY rank, all run eager
+        failed = shard.max_scalar(0.0 if graphed else 1.0, device)
+        if failed > 0.0 and graphed:
+            wb.graph = None
+            wb.capture_error = "hipGraph capture failed on another rank"
+            graphed = False
     return wb, state, graphed
 
 
