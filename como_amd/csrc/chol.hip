@@ -55,23 +55,29 @@ struct Micro4 {
 };
 __device__ __forceinline__ Micro4 micro_chol4(double m00, double m10, double m20, double m30, double m11, double m21, double m31,
                                               double m22, double m32, double m33) {
+  // Two 2x2 blocks, each in closed form: the second pivot of a block is det / first pivot, so rsq(first pivot) and rsq(det) are
+  // INDEPENDENT -- two dependent v_rsq_f64 (+ correction) on the chain instead of four.  (This function is the serial chain of the
+  // tile factorisation: it runs on the look-ahead wave, once per four pivots.)  det = a c - b^2 cancels exactly as c - (b / sqrt a)^2
+  // does; 1 / l11 = sqrt(a) / sqrt(det) = (a rsq(a)) rsq(det).
   Micro4 o;
   int bad = 0;
   double d0 = m00;
   if (!(d0 > 0.0)) { bad = bad ? bad : 1; d0 = 1.0; }
-  const double i0 = rsq_cubic(d0);
+  double detA = __builtin_fma(d0, m11, -(m10 * m10));
+  if (!(detA > 0.0)) { bad = bad ? bad : 2; detA = d0; }            // (second pivot 1, like the pivot-by-pivot form)
+  const double i0 = rsq_cubic(d0), ra = rsq_cubic(detA);
+  const double i1 = ra * (d0 * i0);
   const double l10 = m10 * i0, l20 = m20 * i0, l30 = m30 * i0;
-  double d1 = __builtin_fma(-l10, l10, m11);
-  if (!(d1 > 0.0)) { bad = bad ? bad : 2; d1 = 1.0; }
-  const double i1 = rsq_cubic(d1);
   const double l21 = __builtin_fma(-l20, l10, m21) * i1, l31 = __builtin_fma(-l30, l10, m31) * i1;
-  double d2 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, m22));
-  if (!(d2 > 0.0)) { bad = bad ? bad : 3; d2 = 1.0; }
-  const double i2 = rsq_cubic(d2);
-  const double l32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, m32)) * i2;
-  double d3 = __builtin_fma(-l32, l32, __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, m33)));
-  if (!(d3 > 0.0)) { bad = bad ? bad : 4; d3 = 1.0; }
-  const double i3 = rsq_cubic(d3);
+  double s22 = __builtin_fma(-l21, l21, __builtin_fma(-l20, l20, m22));
+  const double s32 = __builtin_fma(-l31, l21, __builtin_fma(-l30, l20, m32));
+  const double s33 = __builtin_fma(-l31, l31, __builtin_fma(-l30, l30, m33));
+  if (!(s22 > 0.0)) { bad = bad ? bad : 3; s22 = 1.0; }
+  double detS = __builtin_fma(s22, s33, -(s32 * s32));
+  if (!(detS > 0.0)) { bad = bad ? bad : 4; detS = s22; }
+  const double i2 = rsq_cubic(s22), rs = rsq_cubic(detS);
+  const double i3 = rs * (s22 * i2);
+  const double l32 = s32 * i2;
   o.i0 = i0; o.i1 = i1; o.i2 = i2; o.i3 = i3;
   o.w10 = -i1 * (l10 * i0);
   o.w21 = -i2 * (l21 * i1);
