@@ -14,6 +14,11 @@ from como_amd.geometry.affine_brightness import get_aff_w_curr, get_rel_aff
 from como_amd.geometry.camera import backprojection
 from como_amd.geometry.lie_algebra import invertSE3
 from como_amd.geometry.transforms import get_rel_pose, get_T_w_curr
+import os
+
+import numpy as np
+
+import como_amd.odom.frontend.photo_tracking as _pt
 from como_amd.odom.frontend.photo_tracking import photo_tracking_pyr, precalc_jacobians
 from como_amd.utils.coords import fill_image, get_test_coords, swap_coords_xy
 from como_amd import _lib
@@ -129,11 +134,12 @@ class Tracking:
             self.T_w_rec_last = T_w_curr
         return new
 
-    def reproj_stats_last_kf(self, T_curr_kf):
+    def reproj_stats_last_kf(self, T_curr_kf, P=None):
         """(reprojected depth image (1,h,w), seen mask, number of pixels seen, their exact median depth) of the newest keyframe's
         finest-level points in the current frame (Tracking.py:163-185 get_reproj_last_kf + :341-345): two launches
         (csrc/trackref.hip `como_reproject_depth_*`) + the device select -- no boolean-mask gathers, no host synchronisation."""
-        P = self.P_pyr[-1][-1]                                                   # (n,3) of the newest keyframe
+        if P is None:
+            P = self.P_pyr[-1][-1]                                               # (n,3) of the newest keyframe
         if not P.is_cuda:
             reproj = self.get_reproj_last_kf(T_curr_kf)
             seen = ~torch.isnan(reproj)
@@ -218,9 +224,114 @@ class Tracking:
         self.T_w_kf = kf_pose[nk - 1:nk]
         self.aff_w_kf = kf_aff[nk - 1:nk]
 
+    # ---- the same two tests on host scalars (one read-back per frame instead of four synchronising bool()s) ----------------
+    def decide_frame(self, norm_t, median_depth, num_reproj_depth, T_w_curr):
+        """check_keyframe / check_one_way_frame (above) evaluated on the three scalars they look at -- |t| of T_curr_kf, the
+        median reprojected depth, the number of pixels seen -- in the arithmetic the tensor expressions use: float32 products /
+        quotients of float32 operands (a Python scalar meeting a float32 / integer tensor is cast to float32), comparisons in
+        float32.  Returns "keyframe", "one-way" or None; the one-way bookkeeping is updated like check_one_way_frame does."""
+        f32 = np.float32
+        kfg = self.cfg["keyframing"]
+        n_px = self.vals_pyr[-1].shape[1]
+        norm, md, nseen = f32(norm_t), f32(median_depth), int(num_reproj_depth)
+        with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
+            if bool(self.last_kf_sent_ts <= self.kf_received_ts):
+                if norm > f32(kfg["kf_depth_motion_ratio"]) * md:
+                    return "keyframe"
+                if f32(kfg["kf_num_pixels_frac"]) > f32(nseen) / f32(n_px):
+                    return "keyframe"
+            pending = 1 if bool(self.last_kf_sent_ts > self.kf_received_ts) else 0
+            scale = (1.0 + self.num_one_way_since_kf + pending) / (1.0 + kfg["one_way_freq"])
+            empty = n_px - nseen
+            moved = norm > f32(scale * kfg["kf_depth_motion_ratio"]) * md
+            new = bool(moved) or bool(f32(empty) > f32(scale * (1 - kfg["kf_num_pixels_frac"]) * n_px))
+        if new:
+            self.last_one_way_empty_pixels = empty
+            self.T_w_rec_last = T_w_curr
+            return "one-way"
+        return None
+
+    # ---- one frame as ONE hipGraph replay -----------------------------------------------------------------------------------
+    # A tracked frame is a fixed sequence of ~100 small launches (gray image + pyramid, three persistent level kernels, world
+    # pose, reprojection of the keyframe's points, its exact median, the scalars of the keyframe tests): shapes never change, so
+    # the sequence is captured once and replayed on static buffers; the frame's only host synchronisation is the read-back of
+    # eight scalars.  Reference arrays go through the persistent pyramid buffers (copied when the mapper sends new ones).
+    FRAME_GRAPH = os.environ.get("COMO_TRACK_FRAME_GRAPH", "1") != "0"
+
+    def _frame_graph_applies(self, rgb):
+        return (self.FRAME_GRAPH and _pt.FUSED_LEVEL and rgb.is_cuda and self.dtype == torch.float32 and
+                self.cfg["color"] == "gray" and len(self.P_pyr) > 0 and self.P_pyr[-1].shape[0] == 1 and
+                not getattr(self, "_fg_disabled", False))
+
+    def _frame_body(self, fg):
+        img_pyr = self.prep_tracking_img(fg["rgb"])
+        res = _pt.photo_tracking_levels_static(fg["T"], fg["aff"], fg["pb"], img_pyr, self.intrinsics_pyr, self.cfg["term_criteria"],
+                                               fg["ws"])
+        if res is None:
+            return None
+        T, aff, recs = res
+        T_w = get_T_w_curr(fg["T_w_kf"], T)
+        _, _, n_seen, med = self.reproj_stats_last_kf(T, P=fg["pb"].levels[-1]["P"][0])
+        dt = T.dtype
+        sc = torch.cat((torch.linalg.norm(T[:, :3, 3]).reshape(1), med.reshape(1).to(dt), n_seen.reshape(1).to(dt), recs[:, 104]))
+        return T, aff, T_w, sc
+
+    def _track_frame_graph(self, rgb):
+        """(T_curr_kf, aff_curr_kf, T_w_curr, |t|, median depth, pixels seen) or None (the caller then runs the eager path)."""
+        fg = getattr(self, "_fg", None)
+        if fg is None or fg["rgb"].shape != rgb.shape:
+            img_pyr = self.prep_tracking_img(rgb)
+            pb = _pt.pyr_buffers(self.vals_pyr, self.P_pyr, self.dI_dT_pyr, img_pyr, self.intrinsics_pyr)
+            fg = self._fg = {"rgb": torch.empty_like(rgb), "T": torch.empty_like(self.T_curr_kf), "aff": torch.empty_like(self.aff_curr_kf),
+                             "T_w_kf": torch.empty_like(self.T_w_kf), "pb": pb, "ws": _pt.level_workspace_pair(rgb.device),
+                             "graph": None, "out": None, "warm": 0}
+        fg["rgb"].copy_(rgb)
+        fg["T"].copy_(self.T_curr_kf.reshape(1, 4, 4))
+        fg["aff"].copy_(self.aff_curr_kf.reshape(1, 2, 1))
+        fg["T_w_kf"].copy_(self.T_w_kf)
+        fg["pb"].load_reference(self.vals_pyr, self.P_pyr, self.dI_dT_pyr, self.mask_pyr)
+        if fg["graph"] is None and fg["warm"] >= 2:
+            torch.cuda.synchronize(rgb.device)
+            g, out = _lib.capture_graph(lambda: self._frame_body(fg), rgb.device)
+            if g is None or out is None:
+                self._fg_disabled = True               # (capture refused: stay on the eager path for the rest of the run)
+                return None
+            fg["graph"], fg["out"] = g, out
+        if fg["graph"] is not None:
+            fg["graph"].replay()
+            out = fg["out"]
+        else:
+            out = self._frame_body(fg)
+            fg["warm"] += 1
+            if out is None:
+                self._fg_disabled = True
+                return None
+        T, aff, T_w, sc = out
+        v = sc.tolist()                                 # the frame's one host synchronisation
+        if min(v[3:]) < 0:                              # a device-wide barrier of a level kernel timed out: track eagerly
+            _pt.photo_tracking_pyr.fallbacks = getattr(_pt.photo_tracking_pyr, "fallbacks", 0) + 1
+            return None
+        return T.clone(), aff.clone(), T_w.clone(), v[0], v[1], int(v[2])
+
     # ---- one frame (Tracking.py:315-379) -----------------------------------------------------------------------------
     def handle_frame(self, data):
         timestamp, rgb = data
+        if self._frame_graph_applies(rgb):
+            res = self._track_frame_graph(rgb)
+            if res is not None:
+                self.T_curr_kf, self.aff_curr_kf, T_w_curr, norm_t, median_depth, n_seen = res
+                self.last_reproj_stats = (n_seen, median_depth)
+                track_data_viz = (timestamp, T_w_curr)
+                track_data_map = None
+                kind = self.decide_frame(norm_t, median_depth, n_seen, T_w_curr)
+                if kind == "keyframe":
+                    track_data_map = ("keyframe", rgb.clone(), self.T_curr_kf, self.aff_curr_kf, self.kf_received_ts, timestamp)
+                    self.last_kf_sent_ts = timestamp
+                elif kind == "one-way":
+                    track_data_map = ("one-way", rgb.clone(), self.T_curr_kf, self.aff_curr_kf, self.kf_received_ts, timestamp)
+                    self.last_rec_sent_ts = timestamp
+                    self.num_one_way_since_kf += 1
+                return track_data_viz, track_data_map
         img_pyr = self.prep_tracking_img(rgb)
         self.T_curr_kf, self.aff_curr_kf = photo_tracking_pyr(self.T_curr_kf, self.aff_curr_kf, self.vals_pyr, self.P_pyr,
                                                               self.dI_dT_pyr, self.mask_pyr, self.intrinsics_pyr, img_pyr,

@@ -180,7 +180,8 @@ _level_ws = {}
 UNCACHED_WS = __import__("os").environ.get("COMO_TRACK_UNCACHED_WS", "1") == "1"   # barrier workspace in uncached device memory
 
 
-def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, intrinsics, term_criteria, in_mask=None):
+def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, intrinsics, term_criteria, in_mask=None, out=None,
+                               ws_pair=None):
     """The whole level in ONE launch (csrc/track.hip track_level_kernel): Gauss-Newton loop + stop test on the device, no
     host read-back.  Returns (Tji (1,4,4), aff (1,2,1), out (106,)) -- all device tensors; out[105] = iterations run.
     None if the level does not fit the persistent kernel (then the per-iteration chain runs)."""
@@ -198,6 +199,19 @@ def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, int
             raise RuntimeError("como_amd tracking: inputs must be contiguous and share one dtype")
     # one barrier workspace per (device, stream): two level launches running concurrently on different streams must not share
     # the barrier counters / recycled histograms
+    if ws_pair is not None:                                # a caller-owned workspace (the tracker's captured frame graph)
+        ws, wsp = ws_pair
+        if out is None:
+            out = torch.empty(106, device=dev, dtype=dt)
+        rc = L.como_track_level_channels_f32(_lib.ptr(Tji_init), _lib.ptr(intrinsics), _lib.ptr(aff_init), _lib.ptr(Pi),
+                                             _lib.ptr(vals_i), _lib.ptr(img_j), H, W, N, c, _lib.ptr(dI_dT), _lib.ptr(in_mask),
+                                             int(term_criteria["max_iter"]), float(term_criteria["delta_norm"]),
+                                             float(term_criteria["rel_tol"]), float(term_criteria["grad_norm"]),
+                                             wsp if wsp else _lib.ptr(ws), 1 if wsp else 0, _lib.ptr(out), _lib.stream_ptr(dev))
+        if rc == 1:
+            return None
+        _lib.check(rc, "como_track_level")
+        return out[80:96].reshape(1, 4, 4), out[96:98].reshape(1, 2, 1), out
     key = f"{dev}:{torch.cuda.current_stream(dev).cuda_stream}"
     ws = _level_ws.get(key)
     if ws is None:
@@ -213,7 +227,8 @@ def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, int
             _level_ws[key + ":uc"] = wsp or 0
         if wsp:
             ws_ptr, uncached = wsp, 1
-    out = torch.empty(106, device=dev, dtype=dt)
+    if out is None:
+        out = torch.empty(106, device=dev, dtype=dt)
     rc = L.como_track_level_channels_f32(_lib.ptr(Tji_init), _lib.ptr(intrinsics), _lib.ptr(aff_init), _lib.ptr(Pi),
                                          _lib.ptr(vals_i), _lib.ptr(img_j), H, W, N, c, _lib.ptr(dI_dT), _lib.ptr(in_mask),
                                          int(term_criteria["max_iter"]), float(term_criteria["delta_norm"]),
@@ -306,11 +321,8 @@ class _PyrBuffers:
 _pyr_buffers = {}
 
 
-def photo_tracking_pyr(Tji_init, aff_init, vals_i, Pi, dI_dT, masks, intrinsics, img_j, photo_sigma, term_criteria):
-    """reference photo_tracking.py:10-42 (lists ordered coarse -> fine).
-    The reference gathers the masked subset of vals / P / dI_dT on every frame; here the full arrays are copied into
-    persistent buffers when (and only when) the reference tensors change, the masks go to the kernel
-    (`como_track_iter_masked_*`), and every level replays one iteration graph captured once per pyramid shape."""
+def pyr_buffers(vals_i, Pi, dI_dT, img_j, intrinsics):
+    """The persistent buffers of this pyramid shape (created on first use)."""
     key = (str(Pi[0].device), Pi[0].dtype) + tuple((v.shape[0] * v.shape[1], v.shape[2]) + tuple(i.shape[-2:])
                                                    for v, i in zip(vals_i, img_j))          # (points, channels, H, W) per level
     pb = _pyr_buffers.get(key)
@@ -320,6 +332,43 @@ def photo_tracking_pyr(Tji_init, aff_init, vals_i, Pi, dI_dT, masks, intrinsics,
             _level_graphs.clear()
         pb = _PyrBuffers(vals_i, Pi, dI_dT, img_j, intrinsics)
         _pyr_buffers[key] = pb
+    return pb
+
+
+def level_workspace_pair(device):
+    """A private (cached, uncached) barrier workspace pair for persistent level kernels launched from a captured graph."""
+    L = _lib.lib()
+    ws = torch.zeros(L.como_track_level_workspace_bytes() // 4, device=device, dtype=torch.int32)
+    wsp = 0
+    if UNCACHED_WS:
+        with torch.cuda.device(device):
+            wsp = L.como_track_level_workspace_create() or 0
+    return ws, wsp
+
+
+def photo_tracking_levels_static(Tji_init, aff_init, pb, img_j, intrinsics, term_criteria, ws_pair):
+    """Coarse -> fine through the persistent level kernels on the persistent reference buffers `pb`, every level starting from
+    the previous level's result record in place; no host synchronisation, nothing but launches (capturable).  Returns
+    (Tji (1,4,4), aff (1,2,1), records (levels,106): [.,104] < 0 = a device-wide barrier timed out) or None when a level does
+    not fit the persistent kernel."""
+    nl = len(pb.levels)
+    outs = torch.empty((nl, 106), device=Tji_init.device, dtype=Tji_init.dtype)
+    Tji, aff = Tji_init, aff_init
+    for l, c in enumerate(pb.levels):
+        res = photo_level_tracking_fused(Tji, aff, c["vals"], c["P"], c["dI"], img_j[l], intrinsics[l], term_criteria, c["mask"],
+                                         out=outs[l], ws_pair=ws_pair)
+        if res is None:
+            return None
+        Tji, aff = res[0], res[1]
+    return Tji, aff, outs
+
+
+def photo_tracking_pyr(Tji_init, aff_init, vals_i, Pi, dI_dT, masks, intrinsics, img_j, photo_sigma, term_criteria):
+    """reference photo_tracking.py:10-42 (lists ordered coarse -> fine).
+    The reference gathers the masked subset of vals / P / dI_dT on every frame; here the full arrays are copied into
+    persistent buffers when (and only when) the reference tensors change, the masks go to the kernel
+    (`como_track_iter_masked_*`), and every level replays one iteration graph captured once per pyramid shape."""
+    pb = pyr_buffers(vals_i, Pi, dI_dT, img_j, intrinsics)
     pb.load_reference(vals_i, Pi, dI_dT, masks)
     for l, c in enumerate(pb.levels):
         c["img"].copy_(img_j[l])

@@ -195,6 +195,50 @@ def test_tracking_request_rules():
     assert trk.check_one_way_frame(med, torch.tensor(80), T, T)      # 20 empty pixels > 0.5 * 25
 
 
+def test_tracking_requests_on_host_scalars_equal_the_tensor_rules():
+    """Tracking.decide_frame (the frame graph's one-read-back path) makes the decision check_keyframe / check_one_way_frame make
+    on tensors -- random statistics, values ON the thresholds (where the float32 rounding of the products decides), NaN medians."""
+    import copy
+    from como_amd.odom.Tracking import Tracking
+    g = torch.Generator().manual_seed(3)
+    n_px = 307200
+    for case in range(400):
+        ratio = float(torch.rand((), generator=g)) * 0.3 + 0.01
+        frac = float(torch.rand((), generator=g)) * 0.8 + 0.1
+        cfg = {"device": "cpu", "dtype": "float", "color": "gray",
+               "keyframing": {"kf_depth_motion_ratio": ratio, "kf_num_pixels_frac": frac, "one_way_freq": 1 + case % 4}}
+        trk = Tracking(cfg, torch.eye(3), (480, 640))
+        trk.init_kf_vars()
+        trk.reset_one_way_vars()
+        trk.vals_pyr = [torch.zeros((1, n_px, 1))]
+        trk.num_one_way_since_kf = case % 3
+        trk.kf_received_ts = 4.0
+        trk.last_kf_sent_ts = 5.0 if case % 5 == 0 else 3.0
+        md = torch.rand((), generator=g) * 3 + 0.2
+        if case % 37 == 0:
+            md = torch.tensor(float("nan"))
+        t = torch.randn(3, generator=g) * 0.1
+        if case % 3 == 0:                                  # put |t| (almost) exactly on one of the two motion thresholds
+            pending = 1 if trk.last_kf_sent_ts > trk.kf_received_ts else 0
+            sc = 1.0 if case % 2 else (1.0 + trk.num_one_way_since_kf + pending) / (1.0 + cfg["keyframing"]["one_way_freq"])
+            t = t / torch.linalg.norm(t) * (torch.tensor(sc * ratio, dtype=torch.float32) * md)
+        nseen = int(torch.randint(0, n_px + 1, (), generator=g))
+        if case % 4 == 1:                                  # ... or the pixel count on the keyframe threshold
+            nseen = int(frac * n_px) + (case % 3) - 1
+        T = torch.eye(4)[None].clone()
+        T[0, :3, 3] = t
+        ref = copy.copy(trk)
+        if ref.check_keyframe(md, torch.tensor(nseen, dtype=torch.int32), T):
+            want = "keyframe"
+        elif ref.check_one_way_frame(md, torch.tensor(nseen, dtype=torch.int32), T, T):
+            want = "one-way"
+        else:
+            want = None
+        got = trk.decide_frame(float(torch.linalg.norm(T[:, :3, 3])), float(md), nseen, T)
+        assert got == want, (case, got, want)
+        assert int(trk.last_one_way_empty_pixels) == int(ref.last_one_way_empty_pixels)
+
+
 def test_trajectory_io_roundtrip(tmp_path):
     """save_traj writes TUM lines (timestamp tx ty tz qx qy qz qw, 4 decimals) that read back to the poses."""
     import numpy as np
