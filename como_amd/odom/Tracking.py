@@ -195,15 +195,35 @@ class Tracking:
 
         self.P_pyr, self.dI_dT_pyr, self.mask_pyr = [], [], []
         rel = invertSE3(kf_pose[nk - 1:nk]) @ kf_pose       # every keyframe -> the last keyframe's frame
-        for i, d in enumerate(self.depth_pyr_module(depth)):
+        depth_pyr = self.depth_pyr_module(depth)
+        pb = None
+        if (depth.is_cuda and self.vals_pyr[0].shape[2] == 1 and depth.dtype == self.vals_pyr[0].dtype and
+                os.environ.get("COMO_TRACK_DIRECT_REF", "1") != "0"):
+            # this tracker's own persistent reference buffers (the level kernels and the captured frame graph read them): the
+            # reference kernels below write straight into them -- no per-update allocations, no copies before the next frame
+            key = (nk, depth.dtype, tuple(tuple(d.shape[-2:]) for d in depth_pyr))
+            if getattr(self, "_pb_key", None) != key:
+                self._pb = _pt._PyrBuffers.from_shapes(nk, 1, [tuple(d.shape[-2:]) for d in depth_pyr], depth.device, depth.dtype)
+                self._pb_key, self._pb_vals_ts = key, None
+            pb = self._pb
+            if self._pb_vals_ts != timestamps[-1]:          # the keyframe image(s) changed
+                for i, c in enumerate(pb.levels):
+                    c["vals"].copy_(self.vals_pyr[i].reshape(c["vals"].shape))
+                    self.vals_pyr[i] = c["vals"].view(self.vals_pyr[i].shape)
+                self._pb_vals_ts = timestamps[-1]
+        for i, d in enumerate(depth_pyr):
             coords = self.coords_pyr[i]
             b, _, h, w = d.shape
             if d.is_cuda and self.vals_pyr[i].shape[2] == 1:
                 # one launch per level (csrc/trackref.hip): back-projection, transform, projection mask, Jacobians
                 dt, dev = d.dtype, d.device
-                P_all = torch.empty((b, h * w, 3), dtype=dt, device=dev)
-                mask = torch.empty((b, h * w), dtype=torch.uint8, device=dev)
-                J = torch.empty((b, h * w, 1, 8), dtype=dt, device=dev)
+                if pb is not None:
+                    c = pb.levels[i]
+                    P_all, mask, J = c["P"].view(b, h * w, 3), c["mask"].view(b, h * w), c["dI"].view(b, h * w, 1, 8)
+                else:
+                    P_all = torch.empty((b, h * w, 3), dtype=dt, device=dev)
+                    mask = torch.empty((b, h * w), dtype=torch.uint8, device=dev)
+                    J = torch.empty((b, h * w, 1, 8), dtype=dt, device=dev)
                 fn = getattr(_lib.lib(), "como_track_reference_" + _lib.suffix(dt))
                 _lib.check(fn(d.contiguous().data_ptr(), rel.to(dt).contiguous().data_ptr(), self.intrinsics_pyr[i].to(dt).contiguous().data_ptr(),
                               self.img_grads_pyr[i].to(dt).contiguous().data_ptr(), self.vals_pyr[i].to(dt).contiguous().data_ptr(), b, h, w,
@@ -279,9 +299,10 @@ class Tracking:
     def _track_frame_graph(self, rgb):
         """(T_curr_kf, aff_curr_kf, T_w_curr, |t|, median depth, pixels seen) or None (the caller then runs the eager path)."""
         fg = getattr(self, "_fg", None)
-        if fg is None or fg["rgb"].shape != rgb.shape:
-            img_pyr = self.prep_tracking_img(rgb)
-            pb = _pt.pyr_buffers(self.vals_pyr, self.P_pyr, self.dI_dT_pyr, img_pyr, self.intrinsics_pyr)
+        if fg is None or fg["rgb"].shape != rgb.shape or (getattr(self, "_pb", None) is not None and fg["pb"] is not self._pb):
+            pb = getattr(self, "_pb", None)
+            if pb is None:
+                pb = _pt.pyr_buffers(self.vals_pyr, self.P_pyr, self.dI_dT_pyr, self.prep_tracking_img(rgb), self.intrinsics_pyr)
             fg = self._fg = {"rgb": torch.empty_like(rgb), "T": torch.empty_like(self.T_curr_kf), "aff": torch.empty_like(self.aff_curr_kf),
                              "T_w_kf": torch.empty_like(self.T_w_kf), "pb": pb, "ws": _pt.level_workspace_pair(rgb.device),
                              "graph": None, "out": None, "warm": 0}

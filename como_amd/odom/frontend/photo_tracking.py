@@ -306,15 +306,32 @@ class _PyrBuffers:
                                 "img": torch.empty_like(img_j[l]), "K": torch.empty_like(intrinsics[l])})
         self.src = None
 
+    @classmethod
+    def from_shapes(cls, b, c, sizes, device, dtype):
+        """Private buffers for b reference keyframes of c channels at the pyramid levels `sizes` = [(h, w), ...] coarse -> fine."""
+        self = cls.__new__(cls)
+        self.levels = []
+        for h, w in sizes:
+            n = b * h * w
+            self.levels.append({"vals": torch.empty((1, n, c), device=device, dtype=dtype),
+                                "P": torch.empty((1, n, 3), device=device, dtype=dtype),
+                                "dI": torch.empty((1, n, c, 8), device=device, dtype=dtype),
+                                "mask": torch.empty((n,), device=device, dtype=torch.uint8),
+                                "img": torch.empty((1, c, h, w), device=device, dtype=dtype),
+                                "K": torch.empty((3, 3), device=device, dtype=dtype)})
+        self.src = None
+        return self
+
     def load_reference(self, vals_i, Pi, dI_dT, masks):
         src = tuple(vals_i) + tuple(Pi) + tuple(dI_dT) + tuple(masks)
         if self.src is not None and len(src) == len(self.src) and all(a is b for a, b in zip(src, self.src)):
             return
         for l, c in enumerate(self.levels):
-            c["vals"].copy_(vals_i[l].reshape(c["vals"].shape))
-            c["P"].copy_(Pi[l].reshape(c["P"].shape))
-            c["dI"].copy_(dI_dT[l].reshape(c["dI"].shape))
-            c["mask"].copy_(masks[l].reshape(-1))
+            # (a caller that produced its reference arrays IN these buffers -- the tracker's reference kernels write here
+            # directly -- hands views of them back: nothing to copy)
+            for name, t in (("vals", vals_i[l]), ("P", Pi[l]), ("dI", dI_dT[l]), ("mask", masks[l])):
+                if t.data_ptr() != c[name].data_ptr():
+                    c[name].copy_(t.reshape(c[name].shape))
         self.src = src                                         # held: an id cannot be recycled while it is remembered
 
 
