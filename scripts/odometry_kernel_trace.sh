@@ -1,6 +1,6 @@
 #!/bin/bash
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r3c26
-COMO_ODO_BREAKDOWN=0 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_odo2 -- python scripts/gpu_odometry_bench.py --frames 100 > gpurun_out/r3c26/run.log 2>&1
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/ab
+COMO_ODO_BREAKDOWN=0 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_odo2 -- python scripts/gpu_odometry_bench.py --frames 100 > gpurun_out/ab/run.log 2>&1
 F=$(find /tmp/p_odo2 -name "*kernel_trace.csv" | head -1)
 if [ -n "$F" ]; then
 python - "$F" <<'PY'
@@ -16,10 +16,10 @@ for r in rows:
     a = agg[(name, g, wg)]
     a[0] += 1; a[1] += d
 top = sorted(agg.items(), key=lambda kv: -kv[1][1])[:70]
-with open("gpurun_out/r3c26/by_grid.txt", "w") as f:
+with open("gpurun_out/ab/by_grid.txt", "w") as f:
     for (name, g, wg), (c, t) in top:
         f.write(f"{t/1e3:8.2f} ms {c:6d} x {t/c:8.1f} us  grid {g:>9} wg {wg:>5}  {name}\n")
-print(open("gpurun_out/r3c26/by_grid.txt").read()[:6000])
+print(open("gpurun_out/ab/by_grid.txt").read()[:6000])
 PY
 fi
-tail -1 gpurun_out/r3c26/run.log | cut -c1-200
+tail -1 gpurun_out/ab/run.log | cut -c1-200
