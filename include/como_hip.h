@@ -336,7 +336,11 @@ int como_ktilde_f64(const double* cov, int Hc, int Wc, const double* xm, const d
  * Dense SPD solve delta = H^-1 g, float64 (python path: backend/linear_system.py:101-112 solve_system).
  * H (D,D) row-major (lower triangle read), g (D), delta (D) out, workspace of como_chol_workspace_bytes(D) bytes,
  * info (1 int, device): 0 = ok, i > 0 = leading minor i not positive definite (cholesky_ex's info, reported instead
- * of being ignored as the reference does). */
+ * of being ignored as the reference does).
+ * Workspace layout (Dp = D + 1 padded to whole 32-wide block columns): working copy incl. the appended identity rows of the
+ * ride-along back-substitution (2 Dp x Dp) | factor (Dp x Dp) | inverted diagonal blocks (Dp x 32) | x accumulator (Dp);
+ * up to 40 block columns (D < 1280) delta comes out of the factorisation launches themselves, above that from separate
+ * substitution kernels (csrc/chol.hip). */
 long como_chol_workspace_bytes(int D);
 int como_chol_solve_f64(const double* H, const double* g, double* delta, void* workspace, int D, int* info,
                         como_stream_t stream);
