@@ -140,9 +140,16 @@ class Mapping:
     def get_recent_start_window_ind(self):
         return -self.cfg["graph"]["num_one_way_frames"] + 1
 
+    def _retire_ba(self):
+        """The window solver is rebuilt at the next iterate; the old one is kept until then so that the new one can take over
+        what only depends on the keyframe set (WindowBA(prev=...))."""
+        if self._ba is not None:
+            self._ba_prev = self._ba
+        self._ba = None
+
     def reset_iteration_vars(self, new_kf, converged=False):
         self.converged = converged
-        self._ba = None                                   # topology (or a frame's initial values) changed
+        self._retire_ba()                                 # topology (or a frame's initial values) changed
         if new_kf:
             self.iter = 0
             self.total_err_prev = float("inf")
@@ -276,7 +283,7 @@ class Mapping:
             self.recent_img_and_grads = self.recent_img_and_grads[r:]
             self.recent_poses = self.recent_poses[r:]
             self.recent_aff_params = self.recent_aff_params[r:]
-            self._ba = None
+            self._retire_ba()
 
     def add_one_way_frame(self, rgb, pose_init, aff_init, timestamp):
         img_and_grads = self.get_img_and_grads(rgb)
@@ -398,7 +405,9 @@ class Mapping:
         if self._ba is None:
             cfg = {"photo_construction": self.cfg["photo_construction"], "sigmas": self.cfg["sigmas"]}
             # (eager launches: a topology lives for ~2-3 iterations in the sequential loop, less than a graph capture costs)
-            self._ba = WindowBA(self._window_state(), cfg=cfg, pix_dtype=self.pix_dtype, window_full=self.window_full)
+            self._ba = WindowBA(self._window_state(), cfg=cfg, pix_dtype=self.pix_dtype, window_full=self.window_full,
+                                prev=getattr(self, "_ba_prev", None))
+            self._ba_prev = None
         ba = self._ba
         ba.step()
         # refresh the public state from the solver's buffers

@@ -38,11 +38,19 @@ DEFAULT_CFG = {
 }
 
 
+_REUSE_TOPOLOGY = __import__("os").environ.get("COMO_BA_REUSE", "1") != "0"      # (measurement switch)
+
+
 class WindowBA:
-    def __init__(self, state, cfg=None, pix_dtype=torch.float32, window_full=True, shard=None, fused=True):
+    def __init__(self, state, cfg=None, pix_dtype=torch.float32, window_full=True, shard=None, fused=True, prev=None):
         """state: dict as produced by como_amd.synth.make_window (plus K_mm_inv / L_mm / Knm_Kmminv).
-        shard: como_amd.dist.Shard for the one-process-per-GPU data-parallel mode (None = single GPU)."""
+        shard: como_amd.dist.Shard for the one-process-per-GPU data-parallel mode (None = single GPU).
+        prev: the WindowBA this one replaces (the sequential loop rebuilds the window on every one-way frame and keyframe): when
+        the KEYFRAME SET is the same -- the very same image-stack and correspondence-mask tensors -- everything that depends on
+        it only (reference-pixel selection, landmark remap / index tables) is taken over instead of being recomputed."""
         self.shard = shard
+        self._prev = prev
+        self._src_kf_img, self._src_mask = state["kf_img_and_grads"], state["correspondence_mask"]
         if shard is not None and not fused:
             raise RuntimeError("como_amd: the multi-GPU window BA runs the fused chain only")
         self.events = None
@@ -120,8 +128,24 @@ class WindowBA:
         return remap, landmark_ids, lm_of
 
     # ---- things that change only when the keyframe set changes ---------------------------------------------------
+    _KF_SET_ATTRS = ("coords_n", "n_total", "pixidx", "channels", "vals_n", "n", "remap", "point_inds", "L", "kf_inds", "fix_idx",
+                     "lm_ids", "first_obs_mask", "first_frame", "first_slot")
+
+    def _same_keyframe_set(self, prev):
+        return (prev is not None and _REUSE_TOPOLOGY and prev.shard is None and self.shard is None and prev._src_kf_img is self._src_kf_img and
+                prev._src_mask is self._src_mask and prev.B == self.B and prev.m == self.m and prev.pix_dtype == self.pix_dtype and
+                prev.P_m.shape == self.P_m.shape and prev.dev == self.dev and
+                prev.cfg["photo_construction"]["nonmax_suppression_window"] == self.cfg["photo_construction"]["nonmax_suppression_window"])
+
     def _prepare_topology(self):
         B, dev, m = self.B, self.dev, self.m
+        prev, self._prev = self._prev, None                  # (no chain of old windows kept alive)
+        if self._same_keyframe_set(prev):
+            for a in self._KF_SET_ATTRS:
+                setattr(self, a, getattr(prev, a))
+            self.idle = False
+            self._finish_topology()
+            return
         w = self.cfg["photo_construction"]["nonmax_suppression_window"]
         coords_n, _ = smap.subselect_pixels(self.img[:B], w)                   # Mapping.py:665-668
         self.coords_n = coords_n
@@ -148,19 +172,10 @@ class WindowBA:
         self.point_inds = lin_sys.landmark_to_batched_3d_point_inds(landmark_ids, B)
         L = self.P_m.shape[0]
         self.L = L
-        nrec = self.F - B
-        self.dim = 8 * B + 8 * nrec + 3 * L
         self.kf_inds = torch.arange(8 * B, device=dev).reshape(B, 8)
-        self.recent_inds = (torch.arange(8 * nrec, device=dev).reshape(nrec, 8) + 8 * B) if nrec else \
-            torch.empty((0), device=dev, dtype=torch.long)
-        self.frame_inds = torch.arange(8 * self.F, device=dev).reshape(self.F, 8).contiguous()
-        self.lm_start = 8 * B + 8 * nrec
-        self.landmark_inds = (self.point_inds + self.lm_start).contiguous()
-        self.landmark_inds_flat = torch.arange(3 * L, device=dev).reshape(L, 3) + self.lm_start
         # index lists of the oldest keyframe's landmarks (their anchors, Mapping.py:884-898): precomputed -- boolean-mask
         # indexing inside the iteration would synchronise with the host (and cannot be captured in a hipGraph)
         self.fix_idx = lm_of[0]
-        self.fix_inds_flat = self.landmark_inds_flat[self.fix_idx].flatten().contiguous()
         self.lm_ids = (self.point_inds[:, ::3] // 3).to(torch.int32).contiguous()          # (B,m)
         first_obs = torch.argmax(self.correspondence_mask.int(), dim=0)                    # first observer keyframe
         fom = torch.zeros_like(self.correspondence_mask)
@@ -170,6 +185,20 @@ class WindowBA:
         slot_of.scatter_(1, self.lm_ids.long(), torch.arange(m, device=dev, dtype=torch.int32)[None].expand(B, m).contiguous())
         self.first_frame = first_obs.to(torch.int32).contiguous()
         self.first_slot = slot_of[first_obs, torch.arange(L, device=dev)].contiguous()
+        self._finish_topology()
+
+    # ---- ... and what also depends on the number of one-way frames --------------------------------------------------------
+    def _finish_topology(self):
+        B, dev, L = self.B, self.dev, self.L
+        nrec = self.F - B
+        self.dim = 8 * B + 8 * nrec + 3 * L
+        self.recent_inds = (torch.arange(8 * nrec, device=dev).reshape(nrec, 8) + 8 * B) if nrec else \
+            torch.empty((0), device=dev, dtype=torch.long)
+        self.frame_inds = torch.arange(8 * self.F, device=dev).reshape(self.F, 8).contiguous()
+        self.lm_start = 8 * B + 8 * nrec
+        self.landmark_inds = (self.point_inds + self.lm_start).contiguous()
+        self.landmark_inds_flat = torch.arange(3 * L, device=dev).reshape(L, 3) + self.lm_start
+        self.fix_inds_flat = self.landmark_inds_flat[self.fix_idx].flatten().contiguous()
         pc = self.cfg["photo_construction"]
         if self.fused and pc.get("radius_thresh", 0.0) > 0.0 and pc.get("degrees_thresh", 0.0) > 0.0:
             # The reference rebuilds the pair graph on every iterate from the CURRENT poses and median depths
