@@ -239,6 +239,35 @@ def test_tracking_requests_on_host_scalars_equal_the_tensor_rules():
         assert int(trk.last_one_way_empty_pixels) == int(ref.last_one_way_empty_pixels)
 
 
+def test_persistent_pyramid_buffers_skip_copies_of_their_own_views():
+    """_PyrBuffers.load_reference: arrays that already live in the buffers (the tracker's reference kernels write there directly and
+    hand views back) are not copied; foreign arrays are; an unchanged tuple of sources is recognised by identity."""
+    from como_amd.odom.frontend.photo_tracking import _PyrBuffers
+    pb = _PyrBuffers.from_shapes(1, 1, [(3, 4), (6, 8)], "cpu", torch.float32)
+    assert [tuple(c["P"].shape) for c in pb.levels] == [(1, 12, 3), (1, 48, 3)] and pb.levels[1]["dI"].shape == (1, 48, 1, 8)
+    g = torch.Generator().manual_seed(0)
+    for c in pb.levels:
+        for k in ("vals", "P", "dI"):
+            c[k].copy_(torch.rand(c[k].shape, generator=g))
+        c["mask"].fill_(1)
+    before = [{k: c[k].clone() for k in ("vals", "P", "dI", "mask")} for c in pb.levels]
+    views = lambda k, shp: [c[k].view(shp(c[k])) for c in pb.levels]
+    vals = views("vals", lambda t: (1, t.shape[1], 1))
+    P = views("P", lambda t: (1, t.shape[1], 3))
+    dI = views("dI", lambda t: (1, t.shape[1], 1, 8))
+    masks = [c["mask"].view(torch.bool).view(1, -1) for c in pb.levels]
+    pb.load_reference(vals, P, dI, masks)                               # all aliases: nothing may change
+    for c, b in zip(pb.levels, before):
+        assert all(torch.equal(c[k], b[k]) for k in b)
+    P2 = [torch.rand(p.shape, generator=g) for p in P]                  # foreign points: copied in, the rest untouched
+    pb.load_reference(vals, P2, dI, masks)
+    for c, b, p2 in zip(pb.levels, before, P2):
+        assert torch.equal(c["P"], p2.reshape(c["P"].shape)) and torch.equal(c["vals"], b["vals"]) and torch.equal(c["dI"], b["dI"])
+    P2[0].add_(1.0)                                                     # same tensor objects again: recognised, not re-read
+    pb.load_reference(vals, P2, dI, masks)
+    assert not torch.equal(pb.levels[0]["P"], P2[0].reshape(pb.levels[0]["P"].shape))
+
+
 def test_trajectory_io_roundtrip(tmp_path):
     """save_traj writes TUM lines (timestamp tx ty tz qx qy qz qw, 4 decimals) that read back to the poses."""
     import numpy as np
