@@ -1,7 +1,8 @@
 """bench.py -- GN iterations / second of the 8-keyframe 640x480 photometric window BA on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--window 1|4] [--dtype f64|f32] [--keyframes B] [--replicas] [--no-cpu]
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`; a plain
+     `python bench.py --gpus N` with no WORLD_SIZE in the environment starts its N ranks itself, see self_launch)
 
 One "step" = one Gauss-Newton iteration of the window BA, exactly the reference's Mapping.iterate sequence
 (como/odom/Mapping.py:760-968): project landmarks -> dense reference points -> photometric normal equations of all
@@ -405,6 +406,26 @@ def replicas_main(args, shard, device):
         tdist.destroy_process_group()
 
 
+def self_launch(n, argv=None):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: re-run this command line as N ranks under
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free port>` (the same
+    launch the driver's N > 1 command uses) and return its exit status.  The ranks inherit stdout: rank 0 prints the ONE JSON
+    line; the launcher itself only writes to stderr."""
+    import socket
+    import subprocess
+    argv = list(sys.argv[1:] if argv is None else argv)
+    with socket.socket() as s:                               # a port nobody listens on right now
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print("bench.py: no WORLD_SIZE in the environment -- starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -426,11 +447,16 @@ def main():
                     "collectives, sharded medians, fixed-point exchange) through a single-rank process group")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: nobody started the ranks -- start them here (one process per GPU under
+        # torch.distributed.run, rendezvous on 127.0.0.1) and hand rank 0's single JSON line through
+        raise SystemExit(self_launch(args.gpus))
     shard, device = cdist.init_from_env()
     if device.type != "cuda":
         raise SystemExit("bench.py needs an MI355X (the HIP path has no CPU fallback)")
     if shard.world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={shard.world}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={shard.world} (launch with --nproc-per-node {args.gpus}, or without "
+                         f"torch.distributed.run: bench.py then starts its own ranks)")
     if args.replicas:
         return replicas_main(args, shard, device)
     pix_dtype = torch.float32 if args.dtype == "f32" else torch.float64

@@ -147,3 +147,28 @@ def test_two_rank_protocol_matches_single_process():
         assert o["err"][0] == pytest.approx(o["err"][1], rel=1e-12)
     assert res[0]["range"][1] == res[1]["range"][0]          # contiguous shards
     assert res[0]["H_bits"] == res[1]["H_bits"]              # integer all-reduce: both ranks hold the same bits
+
+
+def test_bench_self_launch_builds_the_drivers_command(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE must start its own ranks: the launcher re-runs the same arguments under
+    torch.distributed.run with N processes on 127.0.0.1 (the driver's N > 1 command) -- checked here without a GPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    assert bench.self_launch(8, ["--gpus", "8", "--steps", "5", "--warmup", "2"]) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

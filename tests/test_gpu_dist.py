@@ -206,6 +206,27 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["solution"]["max_pose_abs_err_vs_gt_end"] < d["solution"]["max_pose_abs_err_vs_gt_start"]
 
 
+def test_bench_self_launch_without_world_size():
+    """`python bench.py --gpus 2` with NO WORLD_SIZE / RANK in the environment (the shape of the driver's N = 1 command): bench.py
+    must start its two ranks itself (self_launch -> torch.distributed.run on 127.0.0.1) and still print exactly ONE JSON line.
+    One-GPU test rig as above."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT",
+                                                             "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID")}
+    env.update(COMO_SINGLE_DEVICE="1", COMO_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], cwd=root,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "starting 2 ranks" in r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["solution"]["cholesky_info"] == 0
+
+
 def test_bench_replicas_one_sequence_per_rank():
     """BASELINE config 5 (one SEQUENCE per GPU, throughput mode) as `bench.py --replicas` runs it: every rank drives its own
     rendered 640x480 sequence through the whole odometry loop (tracking, keyframe management, DepthCov network + sampler on
