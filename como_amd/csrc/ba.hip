@@ -1050,13 +1050,44 @@ __global__ __launch_bounds__(256, WPS) void ba_blocks_pair2_kernel(
 // PIPE = true : four-stage software pipeline, no load latency between two matrix phases of a wave.
 // PIPE = false: load -> warp -> rows -> matrix phase per tile, the co-resident wave fills the gaps.
 // K~ rows are addressed by 32-bit byte offsets from the (uniform) slot base: the host checks kt_slot_stride * 8 < 4 GiB.
+// Round 4 (M4 = true, COMO_BA_VARIANT=13: built, parity-green, SLOWER -- 660 us against 585 -- kept as the measured answer to "can the
+// float64 matrix ceiling be moved"): the Gram tiles on v_mfma_f64_4x4x4_4b_f64 instead of v_mfma_f64_16x16x4_f64.  With every CU busy
+// (scripts/micro/mfma_f64_rate.hip, profiles/r4_mfma_f64_rate.txt; sclk stays at 2.39 GHz in both cases): the 16x16x4 shape
+// sustains 36 / 47.5 / 49 TFLOP/s at 1 / 2 / 8 waves per SIMD (62 % of the 78.6 of the data sheet at best: 102 ... 140 cycles per
+// instruction instead of 64), the 4x4x4 shape 74 ... 75 TFLOP/s at ANY occupancy (95 %: 17 cycles per instruction).  Its operand
+// layout (scripts/micro/mfma_f64_4x4_layout.hip): A_blk[i][k] at lane 16 k + 4 blk + i, B_blk[k][j] at lane 16 k + 4 blk + j,
+// D_blk[i][j] at lane 16 i + 4 blk + j (ONE register) -- i.e. with the operands of the 16x16x4 form (lane = 16 k + c) one
+// instruction yields the four DIAGONAL 4x4 blocks of the 16x16 tile; the other twelve blocks come from the same instruction with
+// one operand rotated by 4, 8, 12 lanes inside its row of 16 (two v_mov_b32 row_ror per double).  A tile = four instructions
+// into the four accumulator registers it had before; only the (lane, register) -> (row, column) map of the epilogue changes:
+//   B rotated by 4 d:  register d of lane 16 i + 4 blk + j = element (4 blk + i, 4 ((blk + d) & 3) + j)
+//   A rotated by 4 d:  register d of lane 16 i + 4 blk + j = element (4 ((blk + d) & 3) + i, 4 blk + j)
+// Why it loses inside the kernel (scripts/micro/mfma_f64_gram_step.hip: the bare step is 819 cycles against 1398): a wave-tile of the
+// default kernel costs 18.6 k cycles for 160 16x16x4 instructions = 160 x 64 (the NOMINAL rate) + ~8.4 k cycles of everything else
+// -- interleaved with the warp / Jacobian vector work the 16x16x4 stream does run at its data-sheet rate; it is a bare back-to-back
+// stream that drops to 102 ... 140 cycles.  Both shapes have the same nominal throughput (512 flop / 16 cycles), so the 4x4x4 form
+// only ADDS its 24 ... 36 rotation moves per step to the vector side: the kernel's bound is matrix + vector issue on one pipe.
+// result[lane c of its row] = v[lane (c + 4 D) mod 16 of the row]   (row_ror:n: lane c receives lane (c - n) mod 16)
+template <int D> __device__ __forceinline__ double row_rot4(double v) {
+  if constexpr (D == 0) {
+    return v;
+  } else {
+    constexpr int ctrl = 0x120 + (16 - 4 * D);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, ctrl, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
+}
+__device__ __forceinline__ double mfma4(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+
 __device__ __forceinline__ V4<double> load4_off(const char* __restrict__ base, uint32_t off) {
   const double2 a = *reinterpret_cast<const double2*>(base + off);
   const double2 b = *reinterpret_cast<const double2*>(base + off + 16);
   return V4<double>{a.x, a.y, b.x, b.y};
 }
 
-template <int PF, bool PIPE, int WPS>
+template <int PF, bool PIPE, int WPS, bool M4 = false>
 __global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
     const double* __restrict__ Pwn, const double* __restrict__ vals, const double* __restrict__ dlz,
     const double* __restrict__ Kt, const int* __restrict__ pixidx, const double* __restrict__ invz, long kt_slot_stride,
@@ -1249,11 +1280,25 @@ __global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
         refill(std::integral_constant<int, sl>{}, ic_);
 #pragma unroll
         for (int e = 0; e < 4; ++e) gv[e] += zq[e] * pa.y;
+        if constexpr (M4) {
+          T zr[3][4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { zr[0][e] = row_rot4<1>(zq[e]); zr[1][e] = row_rot4<2>(zq[e]); zr[2][e] = row_rot4<3>(zq[e]); }
+          static_for<10>([&](auto it) {
+            constexpr int tt = decltype(it)::value + 5;
+            constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
+            acc[tt - 5][0] = mfma4(zq[ti - 1], zq[tj - 1], acc[tt - 5][0]);
+            acc[tt - 5][1] = mfma4(zq[ti - 1], zr[0][tj - 1], acc[tt - 5][1]);
+            acc[tt - 5][2] = mfma4(zq[ti - 1], zr[1][tj - 1], acc[tt - 5][2]);
+            acc[tt - 5][3] = mfma4(zq[ti - 1], zr[2][tj - 1], acc[tt - 5][3]);
+          });
+        } else {
         static_for<10>([&](auto it) {
           constexpr int tt = decltype(it)::value + 5;          // tiles 5..14 of the 15-tile enumeration = depth x depth
           constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
           acc[tt - 5] = mfma16(zq[ti - 1], zq[tj - 1], acc[tt - 5]);
         });
+        }
       });
     } else {
       static_for<16>([&](auto ic_) {
@@ -1267,13 +1312,37 @@ __global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
         const T p0 = a00 * sz0, p1 = a01 * sz1;
         gv[0] += a00 * r0;
         gv[1] += a01 * r1;
+        const T kk[4] = {kq[sl].x, kq[sl].y, kq[sl].z, kq[sl].w};
+        if constexpr (M4) {
+          // pose x pose: B rotated; pose x depth: the POSE operand rotated (2 values instead of the 4 of the quad), and
+          // rot(a s) = rot(a) s -- the depth scale is per pixel, i.e. constant along a row of 16 lanes
+          const T a0r[3] = {row_rot4<1>(a00), row_rot4<2>(a00), row_rot4<3>(a00)};
+          const T a1r[3] = {row_rot4<1>(a01), row_rot4<2>(a01), row_rot4<3>(a01)};
+          acc[0][0] = mfma4(a00, a00, acc[0][0]);
+          acc[1][0] = mfma4(a01, a01, acc[1][0]);
+#pragma unroll
+          for (int d = 1; d < 4; ++d) {
+            acc[0][d] = mfma4(a00, a0r[d - 1], acc[0][d]);
+            acc[1][d] = mfma4(a01, a1r[d - 1], acc[1][d]);
+          }
+          const T p0r[4] = {p0, a0r[0] * sz0, a0r[1] * sz0, a0r[2] * sz0};
+          const T p1r[4] = {p1, a1r[0] * sz1, a1r[1] * sz1, a1r[2] * sz1};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+              acc[2 + e][d] = mfma4(p0r[d], kk[e], acc[2 + e][d]);
+              acc[6 + e][d] = mfma4(p1r[d], kk[e], acc[6 + e][d]);
+            }
+          }
+        } else {
         acc[0] = mfma16(a00, a00, acc[0]);
         acc[1] = mfma16(a01, a01, acc[1]);
-        const T kk[4] = {kq[sl].x, kq[sl].y, kq[sl].z, kq[sl].w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           acc[2 + e] = mfma16(p0, kk[e], acc[2 + e]);
           acc[6 + e] = mfma16(p1, kk[e], acc[6 + e]);
+        }
         }
         refill(std::integral_constant<int, sl>{}, ic_);
       });
@@ -1288,24 +1357,34 @@ __global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
   for (int j = 0; j < 4; ++j) invz4[j] = (4 * c + j < m) ? invz[(long)slot * m + 4 * c + j] : T(0);
   // the 1 / z_m factors of the depth columns (dPwn_dzm = u K~ / z_m, sparse_map.py:184-230), once per accumulator:
   // column k of depth block t at lane-column ci is kcol(t, ci) = 4 ci + t - 1; the f64 MFMA row of (lane, reg) is (lane >> 4) + 4 reg
+  // M4: (lane, register d) -> (row, column) of a tile: see row_rot4
+  const int m4_i = lane >> 4, m4_blk = (lane >> 2) & 3, m4_j = lane & 3;
+  auto invz_at = [&](int k) { return (k < m) ? invz[(long)slot * m + k] : T(0); };
   if (role == 0) {
     static_for<10>([&](auto it) {
       constexpr int tt = decltype(it)::value + 5;
       constexpr int ti = tile_row(tt), tj = tt - tile_first(ti) + ti;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
-        const int k1 = kcol(ti, mfma_row<T>(lane, rg));
-        const T f1 = (k1 < m) ? invz[(long)slot * m + k1] : T(0);
-        acc[tt - 5][rg] *= f1 * invz4[tj - 1];
+        if constexpr (M4) {
+          const int row = 4 * m4_blk + m4_i, col = 4 * ((m4_blk + rg) & 3) + m4_j;
+          acc[tt - 5][rg] *= invz_at(kcol(ti, row)) * invz_at(kcol(tj, col));
+        } else {
+          const int k1 = kcol(ti, mfma_row<T>(lane, rg));
+          const T f1 = (k1 < m) ? invz[(long)slot * m + k1] : T(0);
+          acc[tt - 5][rg] *= f1 * invz4[tj - 1];
+        }
       }
     });
 #pragma unroll
     for (int e = 0; e < 4; ++e) gv[e] *= invz4[e];
   } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < 4; ++e) {
+      const T fz = M4 ? invz_at(kcol(e + 1, 4 * m4_blk + m4_j)) : invz4[e];    // (pose operand rotated: column = 4 blk + j)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) { acc[2 + e][rg] *= invz4[e]; acc[6 + e][rg] *= invz4[e]; }
+      for (int rg = 0; rg < 4; ++rg) { acc[2 + e][rg] *= fz; acc[6 + e][rg] *= fz; }
+    }
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -1314,9 +1393,18 @@ __global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
   }
   T* rec0 = partials + (long)(pg0 * gridDim.x + blockIdx.x) * Cfg::REC;
   T* rec1 = has1 ? partials + (long)(pg1 * gridDim.x + blockIdx.x) * Cfg::REC : nullptr;
-  auto put_tile = [&](T* rec, int tt, const acc_t& a) {
+  // rotA: the tile's A operand was the rotated one (pose x depth tiles of role 1)
+  auto put_tile = [&](T* rec, int tt, const acc_t& a, bool rotA = false) {
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) rec[tt * 256 + rg * 64 + lane] = a[rg];
+    for (int rg = 0; rg < 4; ++rg) {
+      if constexpr (M4) {
+        const int o = (m4_blk + rg) & 3;
+        const int row = rotA ? 4 * o + m4_i : 4 * m4_blk + m4_i, col = rotA ? 4 * m4_blk + m4_j : 4 * o + m4_j;
+        rec[tt * 256 + (row >> 2) * 64 + (row & 3) * 16 + col] = a[rg];     // where the 16x16x4 layout keeps (row, col)
+      } else {
+        rec[tt * 256 + rg * 64 + lane] = a[rg];
+      }
+    }
   };
   const acc_t zero4 = acc_t{T(0), T(0), T(0), T(0)};
   if (role == 0) {
@@ -1336,12 +1424,12 @@ __global__ __launch_bounds__(128, WPS) void ba_blocks_pair2_f64_kernel(
   } else {
     put_tile(rec0, 0, acc[0]);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) put_tile(rec0, 1 + e, acc[2 + e]);
+    for (int e = 0; e < 4; ++e) put_tile(rec0, 1 + e, acc[2 + e], true);
     if (lane < 16) rec0[Cfg::NT * 256 + lane] = gv[0];
     if (rec1) {
       put_tile(rec1, 0, acc[1]);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) put_tile(rec1, 1 + e, acc[6 + e]);
+      for (int e = 0; e < 4; ++e) put_tile(rec1, 1 + e, acc[6 + e], true);
       if (lane < 16) rec1[Cfg::NT * 256 + lane] = gv[1];
       if (lane == 0) rec1[Cfg::NT * 256 + Cfg::NB * 16] = err;
     }
@@ -2024,6 +2112,7 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
       m, pb, pe, chunk_len, hists, (double*)A->ws_partials, (double*)A->sigma_out, A->grp_pairs
         if (A->variant != 2 && grouped && A->nsingle == 0 && fits32) {
           if (A->variant == 0) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<4, true, 1>), F64_ARGS); }
+          else if (A->variant == 13) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<4, true, 1, true>), F64_ARGS); }
           else if (A->variant == 3) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<8, true, 1>), F64_ARGS); }
           else if (A->variant == 9) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<2, true, 1>), F64_ARGS); }
           else if (A->variant == 4) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<COMO_F64_PF, false, 2>), F64_ARGS); }

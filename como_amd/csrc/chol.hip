@@ -24,6 +24,8 @@ namespace como {
 
 constexpr int CB = 32;        // panel / tile width (in-tile factor/solve latency grows as CB^2 per panel: 32 beats 64)
 constexpr int CLD = CB + 1;   // padded LDS leading dimension
+constexpr int TSZ = CB * CLD;      // one LDS tile
+constexpr int NT2 = 7;             // tiles of LDS used by the column-pair kernels (59 KB)
 
 __global__ __launch_bounds__(256) void chol_pack_kernel(const double* __restrict__ H, const double* __restrict__ g,
                                                         double* __restrict__ W, int D, int Dp, int* __restrict__ info) {
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(256) void chol_pack_kernel(const double* __restrict
 }
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ double rsq_cubic(double d) {        // hardware estimate (24 bits) + one third-order correction
   const double r = __builtin_amdgcn_rsq(d);
@@ -240,6 +243,269 @@ __device__ __forceinline__ void factor_invert_tile(const double* At, double* scr
 
 
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 4: the 2x2 block of diagonal tiles [T00 . ; T10 T11] factored as ONE continuous 64x64 factorisation (16 four-pivot steps,
+// 17 LDS-only barriers) by FIVE lean waves instead of: tile factor (8 waves, 9 barriers) -> L10 = T10 V0^T -> T11 -= L10 L10^T
+// -> tile factor.  What the in-kernel timestamps of round 3 said: a four-pivot step cost ~0.55 us with eight waves queueing
+// ~150 LDS instructions per step behind one another and draining their global stores at every __syncthreads; the arithmetic of
+// a step is a 4x4 micro-factor (the serial chain) and a handful of rank-4 matrix-core updates.  So:
+//   * the lower triangle of the 64x64 block lives in the MFMA accumulator layout of THREE update waves by quadrant
+//     (16x16 quadrants (R, C) of the 4x4 quadrant grid):  U0: (0,0) (1,0) (1,1) = T00;  U1: (2,0) (2,1) (3,0) (3,1) = T10;
+//     U2: (2,2) (3,2) (3,3) = T11.  Step s (pivots p0 = 4 s .. p0 + 3): every wave forms the panel entries it feeds to the
+//     matrix core itself, P[row][k] = C_s[row][:] . W_s[k][:] (C_s = the raw columns p0..p0+3, W_s = the inverse of the 4x4
+//     micro-factor), one v_mfma_f64_16x16x4_f64 per live quadrant, and the owner of the quadrant column that holds columns
+//     p0+4..p0+7 publishes them (raw, through this step) for step s + 1.  T10 is eliminated by the SAME steps that factor
+//     T00 (its panel rows are L10: no product against V0), T11 receives its rank-4 updates as they are produced, so the
+//     factorisation of T11 simply continues at step 8 -- no hand-over, no ramp;
+//   * MICRO wave, one block ahead (as in round 3): D_{s+1} = raw block - Pb Pb^T with a private rank-4 look-ahead, 4x4 factor +
+//     inverse, publishes W_{s+1};
+//   * INVERSE waves, one block behind: X_B = W S_B, S -= P X_B on the three non-zero quadrants of the 32x32 inverse; one wave
+//     per diagonal tile (a wave that shares its SIMD with the update wave that is idle during its eight steps);
+//   * nothing but LDS between two barriers of the chain: L and L^-1 go to memory as fire-and-forget stores, the barrier waits
+//     for the LDS counter only.
+// has1 = false: a single 32x32 tile (odd block-column count): U0, the micro wave and one inverse wave, 8 steps.
+// scratch (1392 doubles): Cb [2][64][4] raw columns | Pb [2][64][4] masked panel (for the inverse) | Rb [2][4][32] raw rows of S
+// | Wb [4][16] | Db [2][16] diagonal block two ahead | Xb [16].
+#ifdef COMO_FP_PROFILE                                    // scripts/micro/chol_pair.hip: when does each role wave reach / leave a barrier
+__device__ long* fp_prof = nullptr;                      // [wave 0..7][step 0..17][2]: cycle counter after the barrier / when the step's work is done
+#define FP_STAMP(wave, step, which) do { if ((threadIdx.x & 63) == 0 && fp_prof) fp_prof[((wave) * 18 + (step)) * 2 + (which)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FP_STAMP(wave, step, which) do { } while (0)
+#endif
+#ifndef COMO_FP_ABLATE                                   // scripts/micro/chol_pair.hip only: bit 0 / 1 / 2 = the micro / update / inverse
+#define COMO_FP_ABLATE 0                                 // waves skip their work (wrong numbers, the other roles' step time)
+#endif
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+constexpr int FP_PB = 512, FP_RB = 1024, FP_WB = 1280, FP_DB = 1344, FP_XB = 1376;
+
+template <int ROLE> struct FpQuad {
+  static constexpr int NQ = ROLE == 1 ? 4 : 3;
+  static constexpr int R0 = ROLE == 0 ? 0 : 2;
+  static constexpr int C0 = ROLE == 2 ? 2 : 0;
+  __host__ __device__ static constexpr int qr(int q) { return ROLE == 1 ? R0 + (q >> 1) : R0 + (q + 1) / 2; }
+  __host__ __device__ static constexpr int qc(int q) { return ROLE == 1 ? (q & 1) : C0 + (q == 2 ? 1 : 0); }
+  __host__ __device__ static constexpr bool needs(int X) { return ROLE == 1 ? true : (X >= R0 && X < R0 + 2); }
+};
+
+template <int ROLE>
+__device__ __forceinline__ void fp_update_wave(const double* T, double* sc, int nsteps, long kk, double* __restrict__ Lw, int Dp,
+                                               int l) {
+  using Q = FpQuad<ROLE>;
+  const int lr = l & 15, kq = l >> 4;
+  double* Cb = sc;
+  double* Pb = sc + FP_PB;
+  double* Wb = sc + FP_WB;
+  double* Db = sc + FP_DB;
+  d4_t acc[Q::NQ];
+#pragma unroll
+  for (int q = 0; q < Q::NQ; ++q) {
+    const int R = Q::qr(q), C = Q::qc(q);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = 16 * (R - Q::R0) + kq + 4 * i, c = 16 * (C - Q::C0) + lr;
+      double v = T[r * CLD + c];
+      if (ROLE != 1 && R == C && c > r) v = 0.0;
+      acc[q][i] = v;
+    }
+    if (C == 0 && lr < 4) {                               // raw columns 0..3 for step 0
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Cb[(16 * R + kq + 4 * i) * 4 + lr] = acc[q][i];
+    }
+  }
+  const int s_end = ROLE == 2 ? nsteps : 8;               // T00 / T10 are final after step 7
+  const int s_beg = 0;
+#pragma unroll 1
+  for (int s = 0; s <= nsteps; ++s) {
+    FP_STAMP(ROLE, s, 1);
+    lds_only_barrier();
+    FP_STAMP(ROLE, s, 0);
+    if ((COMO_FP_ABLATE & 2) || s < s_beg || s >= s_end) continue;
+    const int p0 = 4 * s;
+    const double* cb = Cb + (s & 1) * 256;
+    const d2_t* wr = (const d2_t*)(Wb + (s & 3) * 16 + 4 * kq);
+    const d2_t w01 = wr[0], w23 = wr[1];
+    // No data-dependent or step-dependent branch around the matrix instructions: a panel entry of a row above the current
+    // block is SELECTED to zero (stale / never-written rows of Cb may hold anything), and a rank-4 update with a zero operand
+    // leaves its quadrant alone -- branches around v_mfma made the compiler shuttle whole accumulators between registers.
+    double p[4] = {0.0, 0.0, 0.0, 0.0}, pm[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int X = 0; X < 4; ++X) {
+      if (!Q::needs(X)) continue;
+      const int row = 16 * X + lr;
+      const d2_t* cr = (const d2_t*)(cb + row * 4);
+      const d2_t c01 = cr[0], c23 = cr[1];
+      p[X] = __builtin_fma(c23[1], w23[1], __builtin_fma(c23[0], w23[0], __builtin_fma(c01[1], w01[1], c01[0] * w01[0])));
+      pm[X] = row >= p0 + 4 ? p[X] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < Q::NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-pm[Q::qr(q)], pm[Q::qc(q)], acc[q], 0, 0, 0);
+    // the factor: rows 0..31 from U0, rows 32..63 from U1 while T00 is eliminated (that is L10), from U2 afterwards (L11)
+    if (ROLE != 2 || p0 >= 32) {
+#pragma unroll
+      for (int X = 0; X < 4; ++X) {
+        if (ROLE == 0 ? X >= 2 : X < 2) continue;
+        const int row = 16 * X + lr;
+        if (row >= p0 + kq) Lw[(kk + row) * Dp + kk + p0 + kq] = p[X];
+        if (ROLE != 1) Pb[(s & 1) * 256 + row * 4 + kq] = pm[X];
+      }
+    }
+    if (p0 + 4 < 4 * nsteps) {                             // raw columns p0+4 .. p0+7, updated through this step
+      const int qcn = (p0 + 4) >> 4, cb0 = (p0 + 4) & 15;
+      double* nb = Cb + ((s + 1) & 1) * 256;
+#pragma unroll
+      for (int q = 0; q < Q::NQ; ++q) {
+        if (Q::qc(q) != qcn) continue;
+        if (lr >= cb0 && lr < cb0 + 4) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) nb[(16 * Q::qr(q) + kq + 4 * i) * 4 + lr - cb0] = acc[q][i];
+        }
+      }
+    }
+    if (p0 + 8 < 4 * nsteps) {                             // the diagonal 4x4 block after next, for the micro wave's look-ahead
+      const int qd = (p0 + 8) >> 4, cbase = (p0 + 8) & 15, isel = cbase >> 2;
+#pragma unroll
+      for (int q = 0; q < Q::NQ; ++q) {
+        if (Q::qr(q) != Q::qc(q) || Q::qr(q) != qd) continue;
+        if (lr >= cbase && lr < cbase + 4) {
+          const double v = isel == 0 ? acc[q][0] : (isel == 1 ? acc[q][1] : (isel == 2 ? acc[q][2] : acc[q][3]));
+          Db[((s + 1) & 1) * 16 + kq * 4 + lr - cbase] = v;
+        }
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void fp_publish_w(double* wb, const Micro4& mc) {
+  d2_t* w = (d2_t*)wb;
+  w[0] = d2_t{mc.i0, 0.0};   w[1] = d2_t{0.0, 0.0};
+  w[2] = d2_t{mc.w10, mc.i1}; w[3] = d2_t{0.0, 0.0};
+  w[4] = d2_t{mc.w20, mc.w21}; w[5] = d2_t{mc.i2, 0.0};
+  w[6] = d2_t{mc.w30, mc.w31}; w[7] = d2_t{mc.w32, mc.i3};
+}
+
+__device__ __forceinline__ void fp_micro_wave(const double* T00, double* sc, int nsteps, long kk, int D, int* __restrict__ info,
+                                              int l) {
+  double* Cb = sc;
+  double* Wb = sc + FP_WB;
+  double* Db = sc + FP_DB;
+  double* Xb = sc + FP_XB;
+  const int mi = (l >> 2) & 3, mj = l & 3;
+  Micro4 mc = micro_chol4(T00[0], T00[CLD], T00[2 * CLD], T00[3 * CLD], T00[CLD + 1], T00[2 * CLD + 1], T00[3 * CLD + 1],
+                          T00[2 * CLD + 2], T00[3 * CLD + 2], T00[3 * CLD + 3]);
+  const double draw = T00[(4 + mi) * CLD + 4 + mj];
+  if (l == 0) {
+    if (mc.bad && kk + mc.bad - 1 < D) atomicCAS(info, 0, (int)kk + mc.bad);
+    fp_publish_w(Wb, mc);
+  }
+#pragma unroll 1
+  for (int s = 0; s <= nsteps; ++s) {
+    FP_STAMP(3, s, 1);
+    lds_only_barrier();
+    FP_STAMP(3, s, 0);
+    if ((COMO_FP_ABLATE & 1) || s >= nsteps - 1) continue;                         // W_1 .. W_{nsteps-1} at steps 0 .. nsteps-2
+    const int p0 = 4 * s;
+    const double* cb = Cb + (s & 1) * 256 + (p0 + 4) * 4;  // rows p0+4 .. p0+7 of the current raw columns
+    const d2_t* ca = (const d2_t*)(cb + mi * 4);
+    const d2_t* cq = (const d2_t*)(cb + mj * 4);
+    const d2_t a01 = ca[0], a23 = ca[1], b01 = cq[0], b23 = cq[1];
+    const double a0 = a01[0], a1 = a01[1], a2 = a23[0], a3 = a23[1];
+    const double b0 = b01[0], b1 = b01[1], b2 = b23[0], b3 = b23[1];
+    const double dr = s == 0 ? draw : Db[(s & 1) * 16 + mi * 4 + mj];
+    const double pa0 = a0 * mc.i0, pb0 = b0 * mc.i0;
+    const double pa1 = __builtin_fma(a1, mc.i1, a0 * mc.w10), pb1 = __builtin_fma(b1, mc.i1, b0 * mc.w10);
+    const double pa2 = __builtin_fma(a2, mc.i2, __builtin_fma(a1, mc.w21, a0 * mc.w20));
+    const double pb2 = __builtin_fma(b2, mc.i2, __builtin_fma(b1, mc.w21, b0 * mc.w20));
+    const double pa3 = __builtin_fma(a3, mc.i3, __builtin_fma(a2, mc.w32, __builtin_fma(a1, mc.w31, a0 * mc.w30)));
+    const double pb3 = __builtin_fma(b3, mc.i3, __builtin_fma(b2, mc.w32, __builtin_fma(b1, mc.w31, b0 * mc.w30)));
+    const double dn = __builtin_fma(-pa3, pb3, __builtin_fma(-pa2, pb2, __builtin_fma(-pa1, pb1, __builtin_fma(-pa0, pb0, dr))));
+    if (l < 16) Xb[l] = dn;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // one wave: its LDS accesses complete in order
+    mc = micro_chol4(Xb[0], Xb[4], Xb[8], Xb[12], Xb[5], Xb[9], Xb[13], Xb[10], Xb[14], Xb[15]);
+    if (l == 0) {
+      if (mc.bad && kk + p0 + 4 + mc.bad - 1 < D) atomicCAS(info, 0, (int)kk + p0 + 4 + mc.bad);
+      fp_publish_w(Wb + ((s + 1) & 3) * 16, mc);
+    }
+  }
+}
+
+// inverse of diagonal tile `itile` (0 / 1): active at steps 8 itile + 1 .. 8 itile + 8, one block behind the update waves
+__device__ __forceinline__ void fp_inverse_wave(double* sc, int nsteps, int itile, double* __restrict__ Iw_tile, int l) {
+  const int lr = l & 15, kq = l >> 4;
+  const double* Pb = sc + FP_PB;
+  double* Rb = sc + FP_RB;
+  const double* Wb = sc + FP_WB;
+  d4_t S00, S10 = {0.0, 0.0, 0.0, 0.0}, S11;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) S00[i] = (kq + 4 * i == lr) ? 1.0 : 0.0;
+  S11 = S00;
+  if (itile == 0) {                                        // rows 0..3 of the identity (tile 1: written during step 8, below)
+    Rb[kq * 32 + lr] = kq == lr ? 1.0 : 0.0;
+    Rb[kq * 32 + 16 + lr] = 0.0;
+  }
+  const int s_first = 8 * itile + 1;
+#pragma unroll 1
+  for (int s = 0; s <= nsteps; ++s) {
+    FP_STAMP(4 + itile, s, 1);
+    lds_only_barrier();
+    FP_STAMP(4 + itile, s, 0);
+    if (itile == 1 && s == 8) {                            // Rb[0] is free during step 8 (tile 0's last inverse step reads Rb[1])
+      Rb[kq * 32 + lr] = kq == lr ? 1.0 : 0.0;
+      Rb[kq * 32 + 16 + lr] = 0.0;
+    }
+    if ((COMO_FP_ABLATE & 4) || s < s_first || s >= s_first + 8) continue;
+    const int sb = s - 1, p0 = 4 * sb, p0l = p0 - 32 * itile, prv = sb & 1;
+    const d2_t* wr = (const d2_t*)(Wb + (sb & 3) * 16 + 4 * kq);
+    const d2_t w01 = wr[0], w23 = wr[1];
+    const double* rb = Rb + prv * 128;
+    const double xLo = __builtin_fma(w23[1], rb[96 + lr], __builtin_fma(w23[0], rb[64 + lr], __builtin_fma(w01[1], rb[32 + lr], w01[0] * rb[lr])));
+    const double xHi = __builtin_fma(w23[1], rb[112 + lr], __builtin_fma(w23[0], rb[80 + lr], __builtin_fma(w01[1], rb[48 + lr], w01[0] * rb[16 + lr])));
+    const double pLo = Pb[prv * 256 + (32 * itile + lr) * 4 + kq], pHi = Pb[prv * 256 + (32 * itile + 16 + lr) * 4 + kq];
+    if (p0l < 12) {                                        // (rows below 16 take part in the update only while p0 + 4 < 16)
+      S00 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pLo, xLo, S00, 0, 0, 0);
+    }
+    S10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pHi, xLo, S10, 0, 0, 0);
+    S11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pHi, xHi, S11, 0, 0, 0);
+    Iw_tile[(p0l + kq) * CB + lr] = xLo;
+    Iw_tile[(p0l + kq) * CB + 16 + lr] = xHi;
+    if (p0l + 4 < CB) {                                    // rows p0l+4 .. p0l+7 of S are final: publish them raw
+      const int qa = (p0l + 4) >> 4, isel = ((p0l + 4) & 15) >> 2;
+      double vlo, vhi;
+      if (qa == 0) {
+        vlo = isel == 0 ? S00[0] : (isel == 1 ? S00[1] : (isel == 2 ? S00[2] : S00[3]));
+        vhi = 0.0;
+      } else {
+        vlo = isel == 0 ? S10[0] : (isel == 1 ? S10[1] : (isel == 2 ? S10[2] : S10[3]));
+        vhi = isel == 0 ? S11[0] : (isel == 1 ? S11[1] : (isel == 2 ? S11[2] : S11[3]));
+      }
+      Rb[(s & 1) * 128 + kq * 32 + lr] = vlo;
+      Rb[(s & 1) * 128 + kq * 32 + 16 + lr] = vhi;
+    }
+  }
+}
+
+// T10 in tile 0, T00 in tile 1, T11 in tile 2 of `sm` (as factor_pair_tail); scratch = tiles 5, 6.
+__device__ __forceinline__ void factor_pair_lean(double* sm, bool has1, int d0, double* __restrict__ Lw, double* __restrict__ Iw,
+                                                 int Dp, int D, int* __restrict__ info) {
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
+  const double* T10 = sm;
+  const double* T00 = sm + 1 * TSZ;
+  const double* T11 = sm + 2 * TSZ;
+  double* sc = sm + 5 * TSZ;
+  const int nsteps = has1 ? 16 : 8;
+  const long kk = (long)d0 * CB;
+  if (wv == 0) fp_update_wave<0>(T00, sc, nsteps, kk, Lw, Dp, l);
+  else if (wv == 1 && has1) fp_update_wave<1>(T10, sc, nsteps, kk, Lw, Dp, l);
+  else if (wv == 2 && has1) fp_update_wave<2>(T11, sc, nsteps, kk, Lw, Dp, l);
+  else if (wv == 3) fp_micro_wave(T00, sc, nsteps, kk, D, info, l);
+  else if (wv == 6) fp_inverse_wave(sc, nsteps, 0, Iw + (long)d0 * CB * CB, l);
+  else if (wv == 4 && has1) fp_inverse_wave(sc, nsteps, 1, Iw + (long)(d0 + 1) * CB * CB, l);
+  else {
+#pragma unroll 1
+    for (int s = 0; s <= nsteps; ++s) lds_only_barrier();
+  }
+}
+
 // 32x32x32 product X Y^T of two LDS tiles (leading dimension CLD) on the f64 matrix cores: 4 waves, wave w owns the
 // 16x16 quadrant (w >> 1, w & 1) and issues 8 v_mfma_f64_16x16x4_f64 on 16 LDS reads (the VALU version -- 128 reads and
 // 128 FMAs per thread -- cost ~1.4 us per product, all of it on the serial chain of a panel step).
@@ -264,8 +530,6 @@ __device__ __forceinline__ void tile_store_mfma(double* dst, int w, int l, const
   for (int i = 0; i < 4; ++i) dst[mrow(w, l, i) * CLD + mcol(w, l)] = acc[i];
 }
 
-constexpr int TSZ = CB * CLD;      // one LDS tile
-constexpr int NT2 = 7;             // tiles of LDS used by the column-pair kernels (59 KB)
 
 // Factor the 2x2 block of tiles [T00 . ; T10 T11] (all already updated by every earlier column), given in LDS: T10 in tile
 // 0, T00 in tile 1, T11 in tile 2 (lower parts valid).  Publishes L_d0d0, L_d1d0, L_d1d1 and the two inverted diagonal
@@ -302,10 +566,11 @@ __device__ __forceinline__ void factor_pair_tail(double* sm, bool has1, int d0, 
 }
 
 // Column-pair start: factors block columns 0 and 1 (their 2x2 block of diagonal tiles).
+template <bool LEAN>
 __global__ __launch_bounds__(512) void chol_first2_kernel(const double* __restrict__ W, double* __restrict__ Lw,
                                                           double* __restrict__ Iw, int Dp, int D, int nb,
                                                           int* __restrict__ info) {
-  __shared__ double sm[NT2 * TSZ];
+  __shared__ __attribute__((aligned(16))) double sm[NT2 * TSZ];
   const int tid = threadIdx.x;
   const bool has1 = nb > 1;
   for (int e = tid; e < CB * CB; e += 512) {
@@ -317,7 +582,8 @@ __global__ __launch_bounds__(512) void chol_first2_kernel(const double* __restri
     }
   }
   __syncthreads();
-  factor_pair_tail(sm, has1, 0, Lw, Iw, Dp, D, info);
+  if (LEAN) factor_pair_lean(sm, has1, 0, Lw, Iw, Dp, D, info);
+  else factor_pair_tail(sm, has1, 0, Lw, Iw, Dp, D, info);
 }
 
 // Look-ahead blocked Cholesky, two block columns per launch.  The serial chain of a panel step -- launch gap, tile
@@ -333,10 +599,11 @@ __global__ __launch_bounds__(512) void chol_first2_kernel(const double* __restri
 // launch (factor_pair_tail).
 // W: working copy (trailing tiles updated in place); Lw: the factor (a SEPARATE matrix: other workgroups of the launch
 // still read the un-factored panel blocks from W); Iw: inverses of the diagonal blocks of L (nb x CB x CB).
+template <bool LEAN>
 __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W, double* __restrict__ Lw,
                                                           double* __restrict__ Iw, int Dp, int D, int c0, int nb,
                                                           int* __restrict__ info, double* __restrict__ xacc) {
-  __shared__ double sm[NT2 * TSZ];
+  __shared__ __attribute__((aligned(16))) double sm[NT2 * TSZ];
   double* sV0 = sm;
   double* sV1 = sm + 1 * TSZ;
   double* sL10 = sm + 2 * TSZ;
@@ -497,8 +764,10 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
       sm[r * CLD + c] = wpre[0][i] - acc[i];
     }
   }
-  __syncthreads();
-  factor_pair_tail(sm, has1, d0, Lw, Iw, Dp, D, info);
+  // (LDS only: the L blocks published above are fire-and-forget stores -- __syncthreads() would wait for their acknowledgement)
+  if (LEAN) lds_only_barrier(); else __syncthreads();
+  if (LEAN) factor_pair_lean(sm, has1, d0, Lw, Iw, Dp, D, info);
+  else factor_pair_tail(sm, has1, d0, Lw, Iw, Dp, D, info);
 }
 
 // Ride-along back-substitution (systems of up to RIDE_MAX_NB block columns).  The working copy carries Dp more rows: an
@@ -722,18 +991,24 @@ static int chol_solve_impl(const double* H, const double* g, double* delta, void
     return e ? atoi(e) : RIDE_MAX_NB;
   }();
   const bool ride = nb <= ride_max;
+  static const bool lean = [] {                           // COMO_CHOL_LEAN=0: round 3's eight-wave tile factorisation (A/B)
+    const char* e = getenv("COMO_CHOL_LEAN");
+    return e ? atoi(e) != 0 : true;
+  }();
   if (!packed) {                                      // (packed: como_sys_finalize_pack wrote W and reset info)
     hipLaunchKernelGGL(chol_pack_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, H, g, W, D, Dp, info);
     COMO_CHECK_LAUNCH();
   }
   if (Dp > 4096) return COMO_ERR_ARG;
-  hipLaunchKernelGGL(chol_first2_kernel, dim3(1), dim3(512), 0, s, W, Lw, Iw, Dp, D, nb, info);
+  if (lean) hipLaunchKernelGGL(chol_first2_kernel<true>, dim3(1), dim3(512), 0, s, W, Lw, Iw, Dp, D, nb, info);
+  else hipLaunchKernelGGL(chol_first2_kernel<false>, dim3(1), dim3(512), 0, s, W, Lw, Iw, Dp, D, nb, info);
   COMO_CHECK_LAUNCH();
   for (int c0 = 0; c0 + 2 < nb; c0 += 2) {               // two block columns per launch
     const int r = nb - (c0 + 2);
     const int tiles = r * (r + 1) / 2;
     const int app = ride ? (c0 + 2) * r : 0;             // appended rows 0 .. c0 + 1 x the r trailing block columns
-    hipLaunchKernelGGL(chol_panel2_kernel, dim3(tiles + app), dim3(512), 0, s, W, Lw, Iw, Dp, D, c0, nb, info, xacc);
+    if (lean) hipLaunchKernelGGL(chol_panel2_kernel<true>, dim3(tiles + app), dim3(512), 0, s, W, Lw, Iw, Dp, D, c0, nb, info, xacc);
+    else hipLaunchKernelGGL(chol_panel2_kernel<false>, dim3(tiles + app), dim3(512), 0, s, W, Lw, Iw, Dp, D, c0, nb, info, xacc);
     COMO_CHECK_LAUNCH();
   }
   if (ride) {
