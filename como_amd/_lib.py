@@ -64,6 +64,9 @@ SIGNATURES = {
     "como_select_hist_f64": (c_int, [c_void_p, c_void_p, c_long, c_int, c_void_p, c_int, c_void_p]),
     "como_select_finish_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "como_select_finish_f64": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "como_select_cand_words": (c_int, []),
+    "como_select_cand_pack": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "como_select_cand_merge": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "como_track_partials_bytes": (c_long, []),
     "como_track_iter_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 9),
     "como_track_iter_f64": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long] + [c_void_p] * 9),

@@ -2044,7 +2044,8 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
     if (A->phase & (2 << (ps - 1))) {
       // all later passes in this one call (single GPU): a double select may finish digits 4, 5 from collected candidates
       // (select.hip); the multi-GPU protocol runs one pass per call with a histogram all-reduce in between -> plain passes
-      const int collect = ((A->phase & 0x3E) == 0x3E) ? 0x100 : 0;
+      // (phase bit 512, multi-GPU double select: pass 3 collects the candidates for ONE exchange, como_select_cand_*: no tail)
+      const int collect = ((A->phase & 0x3E) == 0x3E) ? 0x100 : ((A->phase & 512) && ps == 3 ? 0x300 : 0);
       int rc = select_hist<T>((const T*)A->ws_r, (const uint8_t*)A->ws_valid, (long)b * nl, 1, hists, ps | collect, s);
       if (rc) return rc;
     }

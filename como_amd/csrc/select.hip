@@ -14,7 +14,9 @@ namespace como {
 // constant images): the tail workgroup streams the data itself for digits 4 and 5 -- slow (one workgroup), but it keeps the
 // two always-enqueued fallback launches (4.5 us each, every iteration) out of the common path.
 constexpr int SEL_COLLECT = 0x100;          // flag or-ed into `pass` (pass 3 of a double select)
+constexpr int SEL_NOTAIL = 0x200;           // with SEL_COLLECT on pass 3: collect only, no tail launch (multi-GPU: como_select_cand_*)
 constexpr int SEL_CAND_CAP = 512;
+constexpr int SEL_CAND_WORDS = 2 + 2 * SEL_CAND_CAP;   // packed candidate list of one segment: count | 0 | 512 keys (u64)
 __device__ __forceinline__ uint32_t* sel_cand_count(uint32_t* h) { return h + 4 * SEL_BINS + 1024; }
 __device__ __forceinline__ uint32_t* sel_cand_done(uint32_t* h) { return h + 4 * SEL_BINS + 1025; }
 __device__ __forceinline__ uint64_t* sel_cand_keys(uint32_t* h) { return reinterpret_cast<uint64_t*>(h + 5 * SEL_BINS + 1024); }
@@ -175,6 +177,94 @@ __global__ __launch_bounds__(256) void select_tail_kernel(uint32_t* __restrict__
   if (tid == 0) *sel_cand_done(hists) = 1u;
 }
 
+// ---- multi-GPU double select: ONE exchange instead of three histogram all-reduces for digits 3, 4, 5 --------------------------
+// After digits 0..2 (33 bits) are resolved GLOBALLY (three histogram all-reduces), every rank runs pass 3 with SEL_COLLECT |
+// SEL_NOTAIL on its own slice: the keys that match the 33-bit prefix -- a handful -- land in the candidate scratch of the workspace.
+//   select_cand_pack_kernel : scratch -> a contiguous record per segment (count | 0 | 512 keys), scratch cleared, the rank-LOCAL
+//                             digit-3 histogram cleared (the merge writes the global one);
+//   (the caller all-gathers the records: (world, nseg, SEL_CAND_WORDS) words)
+//   select_cand_merge_kernel: every rank builds, from the union of all ranks' candidates, the histograms of digits 3, 4, 5 that
+//                             three more all-reduced passes would have produced -- consumers resolve exactly as before.
+// A rank with more than 512 candidates (more than 512 keys sharing 33 leading bits: constant images, i.e. sigma = 0 and a
+// non-finite system in the reference as well) cannot be represented: the merge then clears the digit-0 histogram -- zero valid
+// keys: the median reads NaN, the robust scale 0, the system is poisoned and the factorisation reports it.
+__global__ __launch_bounds__(256) void select_cand_pack_kernel(uint32_t* __restrict__ hists, uint32_t* __restrict__ out) {
+  hists += (long)blockIdx.x * 6 * SEL_BINS;
+  out += (long)blockIdx.x * SEL_CAND_WORDS;
+  const int tid = threadIdx.x;
+  const uint32_t cnt = *sel_cand_count(hists);
+  const uint32_t* kw = hists + 5 * SEL_BINS + 1024;
+  for (int i = tid; i < 2 * SEL_CAND_CAP; i += 256) out[2 + i] = (i < 2 * (int)min(cnt, (uint32_t)SEL_CAND_CAP)) ? kw[i] : 0u;
+  __syncthreads();
+  for (int i = tid; i < 1024; i += 256) hists[5 * SEL_BINS + 1024 + i] = 0u;
+  for (int i = tid; i < SEL_BINS; i += 256) hists[3 * SEL_BINS + i] = 0u;
+  if (tid == 0) { out[0] = cnt; out[1] = 0u; *sel_cand_count(hists) = 0u; }
+}
+
+__global__ __launch_bounds__(256) void select_cand_merge_kernel(uint32_t* __restrict__ hists, const uint32_t* __restrict__ gathered,
+                                                                int world, int nseg_total, int seg0) {
+  using KeyT = uint64_t;
+  __shared__ SelScratch sc;
+  __shared__ uint32_t lh[SEL_BINS];
+  __shared__ uint32_t part[64];
+  __shared__ uint32_t found[2];
+  __shared__ uint32_t over;
+  const int seg = blockIdx.x, tid = threadIdx.x;
+  hists += (long)seg * 6 * SEL_BINS;
+  if (tid == 0) over = 0u;
+  __syncthreads();
+  for (int r = tid; r < world; r += 256)
+    if (gathered[((long)r * nseg_total + seg0 + seg) * SEL_CAND_WORDS] > (uint32_t)SEL_CAND_CAP) over = 1u;
+  __syncthreads();
+  if (over) {                                            // not representable: zero valid keys (see above)
+    for (int b = tid; b < SEL_BINS; b += 256) hists[b] = 0u;
+    if (tid == 0) *sel_cand_done(hists) = 1u;
+    return;
+  }
+  KeyT prefix; uint32_t k_rem, nv;
+  sel_resolve<KeyT>(hists, 3, &sc, prefix, k_rem, nv);
+  for (int p = 3; p < 6; ++p) {
+    for (int b = tid; b < SEL_BINS; b += 256) lh[b] = 0;
+    __syncthreads();
+    for (int r = 0; r < world; ++r) {
+      const uint32_t* rec = gathered + ((long)r * nseg_total + seg0 + seg) * SEL_CAND_WORDS;
+      const uint32_t cnt = rec[0];
+      const KeyT* keys = reinterpret_cast<const KeyT*>(rec + 2);
+      for (uint32_t i = tid; i < cnt; i += 256)
+        if (sel_match<KeyT>(keys[i], prefix, p)) atomicAdd(&lh[sel_digit<KeyT>(keys[i], p)], 1u);
+    }
+    __syncthreads();
+    const int nb = 1 << SelCfg<KeyT>::bits(p);
+    for (int b = tid; b < nb; b += 256) hists[p * SEL_BINS + b] = lh[b];
+    // the bin holding rank k_rem: 64 threads x 32 bins, prefix over the 64 partial sums by one thread
+    if (tid < 64) {
+      uint32_t s32 = 0;
+      for (int j = 0; j < 32; ++j) s32 += lh[tid * 32 + j];
+      part[tid] = s32;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t run = 0;
+      int t = 0;
+      for (; t < 64; ++t) { if (k_rem < run + part[t]) break; run += part[t]; }
+      uint32_t bin = 0, below = run;
+      if (t < 64) {
+        for (int j = 0; j < 32; ++j) {
+          const uint32_t c = lh[t * 32 + j];
+          if (k_rem < below + c) { bin = t * 32 + j; break; }
+          below += c;
+        }
+      } else below = 0;
+      found[0] = bin; found[1] = below;
+    }
+    __syncthreads();
+    prefix |= ((KeyT)found[0]) << SelCfg<KeyT>::shift(p);
+    k_rem -= found[1];
+    __syncthreads();
+  }
+  if (tid == 0) *sel_cand_done(hists) = 1u;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void select_finish_kernel(const uint32_t* __restrict__ hists, T* __restrict__ out3) {
   using KeyT = typename KeyOf<T>::type;
@@ -216,7 +306,7 @@ int select_hist(const T* r, const uint8_t* valid, long n, int nseg, uint32_t* hi
     hipLaunchKernelGGL((select_hist_kernel<T, 256>), dim3((unsigned)blocks, nseg), dim3(256), 0, s, r, valid, n, hists, pass_flags);
   }
   COMO_CHECK_LAUNCH();
-  if (sizeof(T) == 8 && (pass_flags & SEL_COLLECT) && pass == 3) {
+  if (sizeof(T) == 8 && (pass_flags & SEL_COLLECT) && !(pass_flags & SEL_NOTAIL) && pass == 3) {
     hipLaunchKernelGGL(select_tail_kernel, dim3(nseg), dim3(256), 0, s, hists, (const double*)r, valid, n);
     COMO_CHECK_LAUNCH();
   }
@@ -262,6 +352,20 @@ int como_select_hist_f32(const float* r, const uint8_t* valid, long n, int nseg,
 }
 int como_select_hist_f64(const double* r, const uint8_t* valid, long n, int nseg, void* hists, int pass, como_stream_t stream) {
   return como::select_hist<double>(r, valid, n, nseg, (uint32_t*)hists, pass, (hipStream_t)stream);
+}
+int como_select_cand_words(void) { return como::SEL_CAND_WORDS; }
+int como_select_cand_pack(void* hists, int nseg, void* out, como_stream_t stream) {
+  if (!hists || !out || nseg < 1) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::select_cand_pack_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, (uint32_t*)hists, (uint32_t*)out);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+int como_select_cand_merge(void* hists, int nseg, const void* gathered, int world, int nseg_total, int seg0, como_stream_t stream) {
+  if (!hists || !gathered || nseg < 1 || world < 1 || seg0 < 0 || seg0 + nseg > nseg_total) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::select_cand_merge_kernel, dim3(nseg), dim3(256), 0, (hipStream_t)stream, (uint32_t*)hists,
+                     (const uint32_t*)gathered, world, nseg_total, seg0);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
 }
 int como_select_finish_f32(const void* hists, int nseg, float* out3, como_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;

@@ -5,8 +5,9 @@ every rank holds the whole window (images 29 MB, K~ 630 MB at 8 x 640x480 -- not
 linearises its own contiguous share of the reference pixels of EVERY keyframe pair (perfect balance, unlike sharding
 14 pairs over 8 ranks).  Two kinds of exchange per GN iteration:
   * the robust scale is a GLOBAL exact median (photo.py:124-128): the 2048-bin histogram of each radix-select digit
-    pass is summed across ranks (8 KiB all-reduce, 3 for float keys / 6 for double) -- every rank then resolves the
-    same k-th key, bit for bit;
+    pass is summed across ranks (8 KiB all-reduce, 3 for float keys) -- every rank then resolves the same k-th key, bit
+    for bit; double keys: three histogram all-reduces (33 bits) + ONE all-gather of the handful of keys that still match
+    (como_select_cand_*: every rank finishes digits 3..5 from the union), not six all-reduces;
   * the normal equations: the shards' per-pair Gram sums (b x 3936 values as fixed-point integer pairs: 0.9 MB at 14
     pairs, 3.9 MB at 62) in ONE integer all-reduce(sum) -- exact, so every rank continues with identical bits -- after
     which every rank expands them into H, adds the priors and solves redundantly (no broadcast of delta);
@@ -62,6 +63,17 @@ class Shard:
         if self.world > 1 or self.force:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
+
+    def all_gather(self, out, inp):
+        """out (world, *inp.shape) <- every rank's inp, in rank order (the candidate exchange of the float64 select)."""
+        if self.world > 1 or self.force:
+            if "nccl" in str(dist.get_backend(self.group)).lower():
+                dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
+            else:                                           # gloo (test rigs): per-rank views of the same buffer
+                dist.all_gather([out[r] for r in range(self.world)], inp, group=self.group)
+        else:
+            out[0].copy_(inp)
+        return out
 
     def max_scalar(self, v, device):
         t = torch.tensor([v], dtype=torch.float64, device=device)

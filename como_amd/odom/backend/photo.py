@@ -172,9 +172,17 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
             ws_hists.zero_()
         if not idle:
             run(1)
+        # float64 keys, multi-GPU: after three all-reduced digits the few keys that still match are exchanged ONCE
+        # (reduce_hists.candidates: pack + all-gather + merge, csrc/select.hip) instead of three more histogram all-reduces
+        cand = getattr(reduce_hists, "candidates", None) if dtype == torch.float64 else None
         for ps in range(npass):
             if reduce_hists is not None:
                 reduce_hists(ws_hists[ps * 2048:(ps + 1) * 2048])
+            if cand is not None and ps == 2:
+                if not idle:
+                    run((2 << 2) | 512)                    # pass 3: collect the candidates, no local tail
+                cand(ws_hists)
+                break
             if ps + 1 < npass and not idle:
                 run(2 << ps)
         if idle:

@@ -15,6 +15,7 @@ State tensors live on one GPU and are updated in place (fixed addresses: the ite
 the system (H, g, poses, landmarks, priors, solve) is always float64.
 """
 import ctypes
+import os
 
 import torch
 
@@ -401,18 +402,8 @@ class WindowBA:
         fork = self.overlap_priors and self._side_stream is not None
         side = self._side_stream
 
-        def reduce_both(h_ba):
-            p = state["p"]
-            stage[:2048].copy_(h_ba)
-            stage[2048:].view(B, 2048).copy_(hv[:, p])
-            red(stage)                                     # ONE collective per digit pass for both exact medians
-            h_ba.copy_(stage[:2048])
-            hv[:, p].copy_(stage[2048:].view(B, 2048))
-            if p + 1 < npass and not z_idle:
-                _lib.check(getattr(L, "como_select_hist_" + sfx)(zmed.data_ptr(), None, zmed.shape[1], B, hmed.data_ptr(), p + 1, s),
-                           "como_select_hist")
-            state["p"] = p + 1
-            if p + 1 == npass and fork:
+        def medians_resolved():
+            if fork:
                 # every digit of the median depths is resolved: their finish + the prior factors (which only ADD into the
                 # fixed-point system) run on the side stream beside the block kernel, the exchange of the pair sums and
                 # their expansion -- the same two-branch shape as the single-GPU chain
@@ -423,6 +414,49 @@ class WindowBA:
                     _lib.check(getattr(L, "como_select_finish_" + sfx)(hmed.data_ptr(), B, med_out.data_ptr(), ss), "como_select_finish")
                     if self.with_priors:
                         _lib.check(L.como_win_priors(ctypes.byref(a), ss), "como_win_priors")
+
+        def reduce_both(h_ba):
+            p = state["p"]
+            stage[:2048].copy_(h_ba)
+            stage[2048:].view(B, 2048).copy_(hv[:, p])
+            red(stage)                                     # ONE collective per digit pass for both exact medians
+            h_ba.copy_(stage[:2048])
+            hv[:, p].copy_(stage[2048:].view(B, 2048))
+            state["p"] = p + 1
+            if exchange and p == 2:
+                return                                     # digits 3..5: reduce_both.candidates
+            if p + 1 < npass and not z_idle:
+                _lib.check(getattr(L, "como_select_hist_" + sfx)(zmed.data_ptr(), None, zmed.shape[1], B, hmed.data_ptr(), p + 1, s),
+                           "como_select_hist")
+            if p + 1 == npass:
+                medians_resolved()
+
+        # float64 keys: three all-reduced digits (33 bits), then ONE all-gather of the keys that still match -- a handful per rank
+        # and median -- from which every rank finishes digits 3..5 itself (csrc/select.hip, como_select_cand_*): 3 + 1 collectives
+        # for both exact medians instead of 6 (+ the per-pair sums = 5 per iteration; `l1max` only when the band state is built)
+        exchange = npass == 6 and os.environ.get("COMO_SEL_EXCHANGE", "1") != "0"
+        if exchange:
+            cw = L.como_select_cand_words()
+            cstage = w.get("cand_stage")
+            if cstage is None:
+                cstage = w["cand_stage"] = (torch.zeros((1 + B, cw), dtype=torch.int32, device=dev),
+                                            torch.zeros((self.shard.world, 1 + B, cw), dtype=torch.int32, device=dev))
+
+            def candidates(h_ba):
+                # (pass 3 of the residual select has just collected its candidates into h_ba's scratch)
+                if not z_idle:
+                    _lib.check(L.como_select_hist_f64(zmed.data_ptr(), None, zmed.shape[1], B, hmed.data_ptr(), 3 | 0x300, s), "como_select_hist")
+                loc, allr = cstage
+                _lib.check(L.como_select_cand_pack(h_ba.data_ptr(), 1, loc.data_ptr(), s), "como_select_cand_pack")
+                _lib.check(L.como_select_cand_pack(hmed.data_ptr(), B, loc[1:].data_ptr(), s), "como_select_cand_pack")
+                self.shard.all_gather(allr, loc)
+                wd = self.shard.world
+                _lib.check(L.como_select_cand_merge(h_ba.data_ptr(), 1, allr.data_ptr(), wd, 1 + B, 0, s), "como_select_cand_merge")
+                _lib.check(L.como_select_cand_merge(hmed.data_ptr(), B, allr.data_ptr(), wd, 1 + B, 1, s), "como_select_cand_merge")
+                state["p"] = npass
+                medians_resolved()
+
+            reduce_both.candidates = candidates
 
         photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=Pwn, vals=self.vals_n,
                                     dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],

@@ -51,6 +51,19 @@ int como_select_hist_f32(const float* r, const uint8_t* valid, long n, int nseg,
 int como_select_hist_f64(const double* r, const uint8_t* valid, long n, int nseg, void* hists, int pass, como_stream_t stream);
 int como_select_finish_f32(const void* hists, int nseg, float* out3, como_stream_t stream);
 int como_select_finish_f64(const void* hists, int nseg, double* out3, como_stream_t stream);
+/* Multi-GPU double select with ONE exchange for digits 3..5 (the reference has no distributed code; this serves the same
+ * global median of photo.py:124-128 across ranks).  After digits 0..2 are all-reduced, run como_select_hist_f64 with
+ * pass = 3 | 0x100 | 0x200 (collect the keys matching the 33-bit prefix, no tail) on every rank, then
+ *   como_select_cand_pack : hists (nseg workspaces) -> out (nseg x como_select_cand_words() uint32: count | 0 | 512 keys), scratch
+ *                           and the rank-local digit-3 histogram cleared;
+ *   all-gather the records over the ranks -> gathered (world, nseg_total, words);
+ *   como_select_cand_merge: writes the digit 3, 4, 5 histograms of the UNION into hists (segments seg0 .. seg0 + nseg of the
+ *                           gathered records) -- consumers and como_select_finish_f64 resolve as after six plain passes.
+ * A rank with more than 512 candidates (> 512 keys sharing 33 leading bits: sigma = 0 inputs) makes the select report zero
+ * valid keys (median NaN, poisoned system). */
+int como_select_cand_words(void);
+int como_select_cand_pack(void* hists, int nseg, void* out, como_stream_t stream);
+int como_select_cand_merge(void* hists, int nseg, const void* gathered, int world, int nseg_total, int seg0, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Tracking: one inverse-compositional GN iteration (python path: frontend/photo_tracking.py:117-143).
@@ -160,7 +173,8 @@ typedef struct como_ba_args {
                                    reference keyframe's pose poses_all[ref_pose[p]] (sparse_map.py:184-230) */
   int chunks;                /* pixel chunks per pair (grid.x of the block kernel); partial records = b*chunks */
   int phase;                 /* bit mask: 1 setup+residual(+hist pass 0), 2<<(p-1) hist pass p>=1, 64 blocks, 128 reduce+assemble,
-                                256 = ws_hists is already zero (skip the clear) */
+                                256 = ws_hists is already zero (skip the clear), 512 = float64 hist pass 3 collects the candidate
+                                keys of the multi-GPU exchange instead of finishing locally (como_select_cand_*) */
   int h_is_f64;              /* element type of Hmat / gvec: 1 = double, 0 = float */
   int variant;               /* zmode 2 only: 0 = software-pipelined block kernels (default; the two-pair kernels where
                                 grp_pairs lists pairs), 1 = straightforward one, 2 = pipelined one-pair kernel only (float32),

@@ -57,6 +57,42 @@ def _distributed_median(shard, r_local, valid_local):
     return arr.view(dt)[0], nv
 
 
+def _distributed_median_exchange(shard, r_local, valid_local, cap=512):
+    """The float64 protocol of como_amd/odom/window_ba.py (csrc/select.hip como_select_cand_*): three all-reduced digit histograms
+    (33 bits), then ONE all-gather of the keys that still match; every rank finishes digits 3..5 from the union."""
+    shifts, bits = SHIFTS[np.float64], BITS[np.float64]
+    keys = _keys(r_local)[valid_local].astype(np.uint64)
+    hists = [None] * 6
+    for p in range(3):
+        prefix, _, _ = _resolve(hists, p, shifts) if p else (0, 0, 0)
+        sel = keys
+        if p > 0:
+            sh = shifts[p - 1]
+            sel = keys[(keys >> np.uint64(sh)) == np.uint64(prefix >> sh)]
+        digit = ((sel >> np.uint64(shifts[p])) & np.uint64((1 << bits[p]) - 1)).astype(np.int64)
+        h = torch.from_numpy(np.bincount(digit, minlength=2048).astype(np.int32))
+        shard.all_reduce_sum(h)
+        hists[p] = h.numpy().astype(np.int64)
+    prefix, _, _ = _resolve(hists, 3, shifts)
+    cand = keys[(keys >> np.uint64(shifts[2])) == np.uint64(prefix >> shifts[2])]
+    assert cand.size <= cap
+    rec = np.zeros(1 + cap, dtype=np.int64)
+    rec[0] = cand.size
+    rec[1:1 + cand.size] = cand.view(np.int64)
+    loc = torch.from_numpy(rec)
+    allr = torch.zeros((shard.world, 1 + cap), dtype=torch.int64)
+    shard.all_gather(allr, loc)                       # the ONE exchange
+    union = np.concatenate([allr[r, 1:1 + int(allr[r, 0])].numpy().view(np.uint64) for r in range(shard.world)])
+    for p in range(3, 6):
+        pfx, _, _ = _resolve(hists, p, shifts)
+        sh = shifts[p - 1]
+        sel = union[(union >> np.uint64(sh)) == np.uint64(pfx >> sh)]
+        digit = ((sel >> np.uint64(shifts[p])) & np.uint64((1 << bits[p]) - 1)).astype(np.int64)
+        hists[p] = np.bincount(digit, minlength=2048).astype(np.int64)
+    prefix, _, nv = _resolve(hists, 6, shifts)
+    return np.array([prefix], dtype=np.uint64).view(np.float64)[0], nv
+
+
 def _worker(rank, world, port, q):
     os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
                        "LOCAL_RANK": str(rank)})
@@ -76,6 +112,9 @@ def _worker(rank, world, port, q):
             med, nv = _distributed_median(shard, r[b:e], valid[b:e])
             ref = torch.median(torch.from_numpy(np.abs(r[valid]))).item()
             out[f"median_{dt.__name__}"] = (float(med), ref, nv, int(valid.sum()))
+            if dt is np.float64:                              # the 3 + 1 protocol gives the same key
+                med2, nv2 = _distributed_median_exchange(shard, r[b:e], valid[b:e])
+                out["median_float64_exchange"] = (float(med2), ref, nv2, int(valid.sum()))
         # 2. sharded normal equations of the golden window: each rank linearises its pixel range, ONE all-reduce
         G = load_golden("ba_window_f64.npz")
         rid, tid = G["kf_ref_ids"].long(), G["kf_target_ids"].long()
@@ -139,7 +178,7 @@ def test_two_rank_protocol_matches_single_process():
         assert p.exitcode == 0
     for rank in (0, 1):
         o = res[rank]
-        for k in ("median_float32", "median_float64"):
+        for k in ("median_float32", "median_float64", "median_float64_exchange"):
             got, ref, nv, nvalid = o[k]
             assert got == ref and nv == nvalid               # exact, on every rank
         assert o["sigma"][0] == pytest.approx(o["sigma"][1], rel=1e-14)

@@ -1,0 +1,75 @@
+"""Round-4 pins of the HIP path (through the C ABI), `-m gpu` on an MI355X:
+  * the float64 select with ONE candidate exchange for digits 3..5 (csrc/select.hip como_select_cand_*): ranks emulated as slices
+    of one array, the histogram all-reduces as sums, the all-gather as a concatenation -- against torch.median, with ties, empty
+    ranks, several segments, and the not-representable case (more than 512 candidates on a rank);
+  * own conditioning (K_mm^-1 from csrc/smallsolve.hip) in the remaining full-size reference pins (float32, window 1, config 4)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _exchange_median(x, valid, world):
+    """x (nseg, n) float64 on the device; `world` ranks own contiguous column ranges.  Returns (nseg,) medians."""
+    from como_amd import _lib
+    L = _lib.lib()
+    nseg, n = x.shape
+    s = _lib.stream_ptr(x.device)
+    words = L.como_select_workspace_bytes() // 4
+    cw = L.como_select_cand_words()
+    per = (n + world - 1) // world
+    sl = [(min(n, r * per), min(n, (r + 1) * per)) for r in range(world)]
+    xs = [x[:, b:e].contiguous() for b, e in sl]
+    vs = [None if valid is None else valid[:, b:e].to(torch.uint8).contiguous() for b, e in sl]
+    hs = [torch.zeros(nseg * words, dtype=torch.int32, device=x.device) for _ in range(world)]
+    for p in range(3):
+        for r in range(world):
+            if xs[r].shape[1] > 0:
+                _lib.check(L.como_select_hist_f64(xs[r].data_ptr(), _lib.ptr(vs[r]), xs[r].shape[1], nseg, hs[r].data_ptr(), p, s), "hist")
+        tot = sum(h.view(nseg, 6, 2048)[:, p] for h in hs)                 # the all-reduce of digit p
+        for h in hs:
+            h.view(nseg, 6, 2048)[:, p] = tot
+    loc = torch.zeros((world, nseg, cw), dtype=torch.int32, device=x.device)
+    for r in range(world):
+        if xs[r].shape[1] > 0:
+            _lib.check(L.como_select_hist_f64(xs[r].data_ptr(), _lib.ptr(vs[r]), xs[r].shape[1], nseg, hs[r].data_ptr(), 3 | 0x300, s), "collect")
+        _lib.check(L.como_select_cand_pack(hs[r].data_ptr(), nseg, loc[r].data_ptr(), s), "pack")
+    outs = []
+    for r in range(world):                                                  # every rank merges the same gathered records
+        _lib.check(L.como_select_cand_merge(hs[r].data_ptr(), nseg, loc.data_ptr(), world, nseg, 0, s), "merge")
+        o = torch.empty((nseg, 3), dtype=torch.float64, device=x.device)
+        _lib.check(L.como_select_finish_f64(hs[r].data_ptr(), nseg, o.data_ptr(), s), "finish")
+        outs.append(o)
+    for o in outs[1:]:
+        assert torch.equal(torch.nan_to_num(o, nan=-1.0), torch.nan_to_num(outs[0], nan=-1.0))   # every rank: the same bits
+    return outs[0][:, 0], outs[0][:, 2], loc[:, :, 0]
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_double_select_candidate_exchange(world):
+    g = torch.Generator().manual_seed(17 + world)
+    nseg, n = 3, 200_003
+    x = (torch.randn((nseg, n), generator=g, dtype=torch.float64) * torch.exp(2 * torch.randn((nseg, n), generator=g, dtype=torch.float64))).abs()
+    x[:, ::7] = 0.125                                           # ties away from the median
+    x[1, ::3] = x[1].median()                                   # and a third of segment 1 tied AT its median (identical keys)
+    valid = torch.rand((nseg, n), generator=g) < 0.8
+    valid[2, n // 3:] = False                                   # the last ranks hold no valid key of segment 2
+    xd, vd = x.to(DEV), valid.to(DEV)
+    med, nv, cnt = _exchange_median(xd, vd, world)
+    for sgm in range(nseg):
+        ref = torch.median(x[sgm][valid[sgm]])
+        if sgm == 1:                                            # ~53 k identical keys: more than 512 candidates on a rank
+            assert int(cnt[:, 1].max()) > 512 and torch.isnan(med[1]) and nv[1] == 0     # reported, not silently wrong
+        else:
+            assert med[sgm].item() == ref.item() and int(nv[sgm]) == int(valid[sgm].sum())
+            assert int(cnt[:, sgm].max()) <= 512
+    report("select_exchange", world=world, cand_max=[int(c) for c in cnt.max(0).values])
+    # no mask, one segment, the plain six-pass select as the second opinion
+    from como_amd.utils.select import masked_median
+    y = xd[0:1].contiguous()
+    m2, _, _ = _exchange_median(y, None, world)
+    assert m2[0].item() == masked_median(y)[0].item() == torch.median(x[0]).item()
