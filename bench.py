@@ -92,6 +92,7 @@ def cpu_baseline(args, state_cpu, reps=5):
     med = ts[len(ts) // 2]
     n = ow.cn.shape[1]
     w4 = {"value": 1.0 / med, "unit": "GN iters/s", "cores": best[1], "host_cores": ncpu, "kind": "port", "workload": "window=4",
+          "protocol": f"median of {reps} after 1 warm-up; threads = fastest of 8/16/32/64 in a one-iteration probe",
           "sample": f"oracle/window.py (torch-CPU, float64) full GN iteration incl. priors + solve on the window-4 workload "
                     f"exactly (n={n} px/KF, {ow.aux['valid'].shape[0]} pairs, D={ow.D}): median of {reps} after 1 warm-up = "
                     f"{med * 1e3:.0f} ms (min {ts[0] * 1e3:.0f}, max {ts[-1] * 1e3:.0f}); {best[1]} torch threads (fastest of "
@@ -120,6 +121,9 @@ def cpu_baseline(args, state_cpu, reps=5):
     nd, pairs, D = owd.cn.shape[1], owd.aux["valid"].shape[0], owd.D
     del owd
     return {"value": 1.0 / min(td), "unit": "GN iters/s", "cores": best[1], "host_cores": ncpu, "kind": "port",
+            "protocol": "best of 2 (no warm-up; ~8-10 s and ~30 GB of materialised Jacobians per iteration keep the default run "
+                        "within minutes -- SURVEY 8(d) asks for the median of >= 5 after 2 warm-ups at os.cpu_count() threads: "
+                        "`window4` below follows the median-of-5 part; threads are the fastest of 8/16/32/64 probed on window 4)",
             "workload": f"window={args.window} (the workload of `value`)",
             "sample": f"oracle/window.py (torch-CPU, float64) full GN iteration incl. priors + solve on the headline workload exactly "
                       f"(n={nd} px/KF, {pairs} pairs, D={D}): two iterations, {td[0]:.1f} s and {td[1]:.1f} s, value = 1 / the faster; "

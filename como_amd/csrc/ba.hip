@@ -131,6 +131,12 @@ __device__ __forceinline__ Warp<T> warp_point(const T* __restrict__ M, T fx, T f
 //   b^T dP_w/dT_wc = [ R^T (u x b) , R^T b ] + (b . u) dl
 // Returns u . b (the depth scale before the row weight) and the six geometric entries jr[0..5]; the caller adds
 // (s b.u) dl[k].  Only Jacobian VALUES depend on this (never a validity mask).
+// Precision of u = P_w - t (the materialised form stored u = R (ray z_n) directly): the subtraction is exact to one rounding of
+// P_w, so u carries a relative error of eps |P_w| / |u|.  In float64 (the reference's mapping dtype, 1.1e-16) that is invisible at
+// any trajectory length; in the float32 mixed-precision path (6e-8) a window |t_wc| = 100 m from the origin looking at 2 m of
+// depth loses a factor 50: 3e-6 relative in the reference-pose block and the depth scale b.u -- still below the float32 bar of
+// the full-size pins (2e-4 on H); beyond ~1 km from the origin use the float64 path (or hand the window over re-centred on its
+// anchor keyframe: the photometric system is invariant under a common rigid shift of poses and landmarks).
 template <typename T>
 __device__ __forceinline__ T ref_pose_geom(const T* __restrict__ Rf, T Px, T Py, T Pz, T b0, T b1, T b2, T* __restrict__ jr) {
   const T u0 = Px - Rf[3], u1 = Py - Rf[7], u2 = Pz - Rf[11];

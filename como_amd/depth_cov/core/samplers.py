@@ -73,7 +73,10 @@ def precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_co
         K_nn += torch.diag_embed(curr_var)
     if fixed_var is not None:
         K_nn += torch.diag_embed(fixed_var * torch.ones(b, m, device=dev))
-    L[:, :m, :m] = chol_small(K_nn, want_L=True)["L"]          # the initial factor (torch.linalg.cholesky in the reference)
+    f = chol_small(K_nn, want_L=True, want_info=True)          # the initial factor (torch.linalg.cholesky in the reference)
+    if int(f["info"].max()) != 0:                              # ... which raises on a non-positive-definite K_nn: so does this
+        raise RuntimeError(f"como_amd precalc_entropy_vars: K_nn is not positive definite (leading minor {int(f['info'].max())})")
+    L[:, :m, :m] = f["L"]
     K_md = como_backends.cross_covariance(coords_n_norm[:, :m, :], E_n[:, :m, :, :], coords_domain_norm.view(b, -1, 2), E_domain,
                                           scale)
     obs_info[:, :m, :] = get_obs_info(L[:, :m, :m], K_md)
@@ -115,44 +118,26 @@ def greedy_loop(coord_vec_inds, coords_n_norm, E_n, coords_domain_norm, E_domain
     nxt = _Next(coords_domain_norm, dist_thresh)
     pred_var = calc_var(obs_info[:, :m, :], sv).contiguous()
     # (the loop's in / out arrays are this module's own temporaries -- only the returned indices leave it -- so strided views
-    # are simply packed: a strided E_domain used to send every second sampler run of a keyframe through the per-point
-    # fallback below, ~45 points x (6 launches + a host synchronisation))
+    # are simply packed)
     coords_n_norm, E_n, L, obs_info, coord_vec_inds, E_domain = (t.contiguous() for t in (coords_n_norm, E_n, L, obs_info,
                                                                                           coord_vec_inds, E_domain))
-    if True:
-        # the whole loop on the device: two launches per added point.  Early termination (samplers.py:255-259) is decided
-        # afterwards from the per-step trace of the largest remaining standard deviation -- the greedy sequence does not
-        # depend on where it is cut -- with ONE read-back instead of one per step.
-        trace = torch.zeros((n + 1, b), device=dev, dtype=torch.float32) if terminate_early else None
-        scratch = torch.empty((b * 4096,), device=dev, dtype=torch.float32)      # per-slice argmax partials (two-stage pick)
-        rc = _lib.lib().como_greedy_loop_f32(coords_n_norm.data_ptr(), E_n.data_ptr(), coord_vec_inds.data_ptr(),
-                                             nxt.dom.data_ptr(), E_domain.data_ptr(), L.data_ptr(), obs_info.data_ptr(),
-                                             pred_var.data_ptr(), nxt.mask.data_ptr(), nxt.best.data_ptr(), nxt.sd.data_ptr(),
-                                             sv, k_ii, nxt.t2, b, n, nxt.d, m, _lib.ptr(trace), scratch.data_ptr(),
-                                             _lib.stream_ptr(dev))
-        _lib.check(rc, "como_greedy_loop_f32")
-        if terminate_early:
-            below = (trace[m:n] < max_stdev_thresh).all(dim=1).tolist()
-            for k, stop in enumerate(below):
-                if stop:
-                    return coord_vec_inds[:, :m + k]
-        return coord_vec_inds
-    max_sd, best = nxt(pred_var, coords_n_norm[:, :m, :])
-    for i in range(m, n):
-        if terminate_early and bool((max_sd < max_stdev_thresh).all()):
-            coord_vec_inds = coord_vec_inds[:, :i]
-            coords_n_norm = coords_n_norm[:, :i, :]
-            break
-        ci = coords_domain_norm[bi, best, :]
-        Ei = E_domain[bi, best, :, :]
-        coord_vec_inds[:, i] = best
-        coords_n_norm[:, i, :] = ci
-        E_n[:, i, :, :] = Ei
-        ci, Ei = ci.unsqueeze(1), Ei.unsqueeze(1)
-        k_ni = como_backends.cross_covariance(coords_n_norm[:, 0:i, :], E_n[:, 0:i, :, :], ci, Ei, sv)
-        k_id = como_backends.cross_covariance(ci, Ei, coords_domain_norm, E_domain, sv)
-        como_backends.get_new_chol_obs_info(L, obs_info, pred_var, k_ni, k_id, k_ii, i)
-        max_sd, best = nxt(pred_var, ci)
+    # the whole loop on the device: two launches per added point.  Early termination (samplers.py:255-259) is decided
+    # afterwards from the per-step trace of the largest remaining standard deviation -- the greedy sequence does not
+    # depend on where it is cut -- with ONE read-back instead of one per step.  (Only the returned indices leave this function:
+    # the packed copies above are NOT written back into strided arguments.)
+    trace = torch.zeros((n + 1, b), device=dev, dtype=torch.float32) if terminate_early else None
+    scratch = torch.empty((b * 4096,), device=dev, dtype=torch.float32)      # per-slice argmax partials (two-stage pick)
+    rc = _lib.lib().como_greedy_loop_f32(coords_n_norm.data_ptr(), E_n.data_ptr(), coord_vec_inds.data_ptr(),
+                                         nxt.dom.data_ptr(), E_domain.data_ptr(), L.data_ptr(), obs_info.data_ptr(),
+                                         pred_var.data_ptr(), nxt.mask.data_ptr(), nxt.best.data_ptr(), nxt.sd.data_ptr(),
+                                         sv, k_ii, nxt.t2, b, n, nxt.d, m, _lib.ptr(trace), scratch.data_ptr(),
+                                         _lib.stream_ptr(dev))
+    _lib.check(rc, "como_greedy_loop_f32")
+    if terminate_early:
+        below = (trace[m:n] < max_stdev_thresh).all(dim=1).tolist()
+        for k, stop in enumerate(below):
+            if stop:
+                return coord_vec_inds[:, :m + k]
     return coord_vec_inds
 
 

@@ -254,6 +254,11 @@ class Tracking:
         kfg = self.cfg["keyframing"]
         n_px = self.vals_pyr[-1].shape[1]
         norm, md, nseen = f32(norm_t), f32(median_depth), int(num_reproj_depth)
+        if nseen == 0:
+            # no pixel of the keyframe is seen: there is no median depth (masked_median reports NaN; the reference's
+            # torch.median of an empty tensor raises).  The motion tests are skipped explicitly -- the pixel-count tests below
+            # then request a keyframe (or, while one is pending, a one-way frame) on their own.
+            md = f32(np.inf)
         with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
             if bool(self.last_kf_sent_ts <= self.kf_received_ts):
                 if norm > f32(kfg["kf_depth_motion_ratio"]) * md:
@@ -303,8 +308,13 @@ class Tracking:
             pb = getattr(self, "_pb", None)
             if pb is None:
                 pb = _pt.pyr_buffers(self.vals_pyr, self.P_pyr, self.dI_dT_pyr, self.prep_tracking_img(rgb), self.intrinsics_pyr)
+            # ONE barrier workspace pair per tracker (the uncached allocation has no destroy entry point): a rebuilt frame graph
+            # -- new pyramid buffers, another image size -- reuses it; the old graph is dropped with the old dict
+            wsp = getattr(self, "_fg_ws", None)
+            if wsp is None or wsp[0].device != rgb.device:
+                wsp = self._fg_ws = _pt.level_workspace_pair(rgb.device)
             fg = self._fg = {"rgb": torch.empty_like(rgb), "T": torch.empty_like(self.T_curr_kf), "aff": torch.empty_like(self.aff_curr_kf),
-                             "T_w_kf": torch.empty_like(self.T_w_kf), "pb": pb, "ws": _pt.level_workspace_pair(rgb.device),
+                             "T_w_kf": torch.empty_like(self.T_w_kf), "pb": pb, "ws": wsp,
                              "graph": None, "out": None, "warm": 0}
         fg["rgb"].copy_(rgb)
         fg["T"].copy_(self.T_curr_kf.reshape(1, 4, 4))

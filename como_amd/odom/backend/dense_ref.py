@@ -99,12 +99,17 @@ def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=Non
     use_band = (BAND_MEDIAN if band is None else band) and hists is not None and part_flag != 4
     if use_band:
         st = w.get("band")
+        # the band bound is only valid for the K~ it was built from: a reused workspace with another predictor (a recycled
+        # ping-pong buffer, another row range) rebuilds the state instead of returning medians of stale row norms
+        ident = (Kt.data_ptr(), Kt.stride(0), B, rows, m)
+        if st is not None and st.get("ident") != ident:
+            st = None
         init = st is None
         if init:
             st = w["band"] = {"lref": torch.zeros((B, rows), device=dev, dtype=dt), "err": torch.zeros((B, rows), device=dev, dtype=dt),
                               "l1": torch.zeros((B, rows), device=dev, dtype=dt), "l1max": torch.zeros(B, device=dev, dtype=torch.float32),
                               "prev": torch.zeros((B, m), device=dev, dtype=dt), "ncand": torch.zeros(B, device=dev, dtype=torch.int32),
-                              "calls": 0, "med": med_out.data_ptr()}
+                              "calls": 0, "med": med_out.data_ptr(), "ident": ident}
         if st["med"] != med_out.data_ptr():
             raise RuntimeError("como_amd full_image_median: the band state belongs to another med_out buffer (it carries the previous median)")
         st["calls"] += 1

@@ -11,7 +11,8 @@ _ws = {}
 def masked_median(x, valid=None):
     """x (nseg, n) or (n,) float32 / float64 CUDA tensor of NON-NEGATIVE values; valid: same shape, bool / uint8, None = all.
     Returns (nseg,) [or a 0-dim tensor for 1-D input]: per segment the lower median of the valid entries (the select orders by
-    |x|), NaN-free as long as the valid entries are.  A segment without valid entries returns 0."""
+    |x|), NaN-free as long as the valid entries are.  A segment WITHOUT valid entries returns NaN (csrc/select.hip
+    select_finish_kernel) -- callers that can meet an empty mask must test the count (Tracking.decide_frame does)."""
     _lib.require_cuda(x)
     one = x.dim() == 1
     x2 = (x[None] if one else x.reshape(x.shape[0], -1)).contiguous()

@@ -73,3 +73,36 @@ def test_double_select_candidate_exchange(world):
     y = xd[0:1].contiguous()
     m2, _, _ = _exchange_median(y, None, world)
     assert m2[0].item() == masked_median(y)[0].item() == torch.median(x[0]).item()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("fixture,pix,window", [("fullsize_window4.npz", torch.float32, 4), ("fullsize_window1.npz", torch.float64, 1),
+                                                ("fullsize_window1.npz", torch.float32, 1), ("fullsize_window32.npz", torch.float64, 4)])
+def test_fullsize_windows_with_own_conditioning(fixture, pix, window):
+    """The full-size reference pins with NOTHING of the reference's in the path (round 3 had this for window 4 / float64 only):
+    K_mm + 1e-6 I factored and inverted by csrc/smallsolve.hip instead of the fixture's K_mm^-1 -- the float32 pixel path, the
+    dense window (window 1 = the bench headline) and config 4 (32 keyframes, D = 2680).  cond(K_mm) ~ 1e8: two correct float64
+    inverses give K~ that differ by ~1e-8 relative; the solved poses must stay within the bars of the pins that take the
+    reference's inverse (1e-7 float64 / 1e-4 float32 -- the north star's 1e-4)."""
+    from tests.conftest import load_golden, rel_err
+    from tests.test_gpu_r2 import _window_from_seed
+    import como_amd.odom.backend.linear_system as ls
+    G = load_golden(fixture)
+    f64 = pix == torch.float64
+    wb, st = _window_from_seed(G, pix, window, own_inverse=True)
+    e_inv = rel_err(st["K_mm_inv"], G["K_mm_inv"])
+    iters = sum(1 for k in G if k.endswith("_delta"))
+    worst = {"pose": 0.0, "aff": 0.0, "P": 0.0, "med": 0.0}
+    for it in range(iters):
+        gi = lambda k: G[f"it{it}_{k}"]
+        wb.iterate()
+        torch.cuda.synchronize()
+        worst["pose"] = max(worst["pose"], (wb.kf_poses.cpu() - gi("kf_poses_new")).abs().max().item())
+        worst["aff"] = max(worst["aff"], (wb.kf_aff_params.cpu() - gi("kf_aff_new")).abs().max().item())
+        worst["P"] = max(worst["P"], (wb.P_m.cpu() - gi("P_new")).abs().max().item())
+        worst["med"] = max(worst["med"], ((wb.median_depths.cpu() - gi("median_depths_full")).abs() / gi("median_depths_full")).max().item())
+    report("fullsize_own_conditioning_r4", fixture=fixture, pix=str(pix), window=window, D=wb.dim, iters=iters, Kinv_rel_vs_reference=e_inv,
+           info=int(ls.solve_system.last_info), **worst)
+    assert int(ls.solve_system.last_info) == 0
+    assert worst["pose"] < (1e-7 if f64 else 1e-4) and worst["aff"] < (1e-7 if f64 else 1e-4)
+    assert worst["P"] < (1e-4 if f64 else 2e-3) and worst["med"] < (1e-6 if f64 else 1e-5)
