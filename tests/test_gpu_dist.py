@@ -106,7 +106,7 @@ def _config4_worker(rank, world, port, q):
             ncoll.append(calls["n"])
             if it < 2:
                 out.append((wb.kf_poses.cpu().numpy().copy(), wb.P_m.cpu().numpy().copy(), int(wb.sigma[1]), wb.H.cpu().numpy().copy()))
-        q.put((rank, out, wb.table.b, wb.dim, wb.n, wb.n_total, ncoll))
+        q.put((rank, out, wb.table.b, wb.dim, 0 if wb.idle else wb.n, wb.n_total, ncoll))    # (an idle rank owns no pixel)
     finally:
         dist.barrier()
         dist.destroy_process_group()
