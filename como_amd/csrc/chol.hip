@@ -288,9 +288,11 @@ template <int ROLE> struct FpQuad {
   __host__ __device__ static constexpr bool needs(int X) { return ROLE == 1 ? true : (X >= R0 && X < R0 + 2); }
 };
 
+// Ls (optional): the factor ALSO goes to the LDS tiles of the pair (tile 1 = L00, tile 0 = L10, tile 2 = L11 -- over the inputs,
+// which are only read before the first barrier); Vs (optional): the inverted diagonal tiles to LDS (Vs = V0, Vs + TSZ = V1).
 template <int ROLE>
 __device__ __forceinline__ void fp_update_wave(const double* T, double* sc, int nsteps, long kk, double* __restrict__ Lw, int Dp,
-                                               int l) {
+                                               int l, double* Ls = nullptr) {
   using Q = FpQuad<ROLE>;
   const int lr = l & 15, kq = l >> 4;
   double* Cb = sc;
@@ -346,7 +348,10 @@ __device__ __forceinline__ void fp_update_wave(const double* T, double* sc, int 
       for (int X = 0; X < 4; ++X) {
         if (ROLE == 0 ? X >= 2 : X < 2) continue;
         const int row = 16 * X + lr;
-        if (row >= p0 + kq) Lw[(kk + row) * Dp + kk + p0 + kq] = p[X];
+        if (row >= p0 + kq) {
+          if (Lw) Lw[(kk + row) * Dp + kk + p0 + kq] = p[X];
+          if (Ls) Ls[(ROLE == 0 ? 1 : (ROLE == 1 ? 0 : 2)) * TSZ + (row & 31) * CLD + ((p0 + kq) & 31)] = p[X];
+        }
         if (ROLE != 1) Pb[(s & 1) * 256 + row * 4 + kq] = pm[X];
       }
     }
@@ -430,7 +435,8 @@ __device__ __forceinline__ void fp_micro_wave(const double* T00, double* sc, int
 }
 
 // inverse of diagonal tile `itile` (0 / 1): active at steps 8 itile + 1 .. 8 itile + 8, one block behind the update waves
-__device__ __forceinline__ void fp_inverse_wave(double* sc, int nsteps, int itile, double* __restrict__ Iw_tile, int l) {
+__device__ __forceinline__ void fp_inverse_wave(double* sc, int nsteps, int itile, double* __restrict__ Iw_tile, int l,
+                                                double* Vs = nullptr) {
   const int lr = l & 15, kq = l >> 4;
   const double* Pb = sc + FP_PB;
   double* Rb = sc + FP_RB;
@@ -466,8 +472,14 @@ __device__ __forceinline__ void fp_inverse_wave(double* sc, int nsteps, int itil
     }
     S10 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pHi, xLo, S10, 0, 0, 0);
     S11 = __builtin_amdgcn_mfma_f64_16x16x4f64(-pHi, xHi, S11, 0, 0, 0);
-    Iw_tile[(p0l + kq) * CB + lr] = xLo;
-    Iw_tile[(p0l + kq) * CB + 16 + lr] = xHi;
+    if (Iw_tile) {
+      Iw_tile[(p0l + kq) * CB + lr] = xLo;
+      Iw_tile[(p0l + kq) * CB + 16 + lr] = xHi;
+    }
+    if (Vs) {
+      Vs[itile * TSZ + (p0l + kq) * CLD + lr] = xLo;
+      Vs[itile * TSZ + (p0l + kq) * CLD + 16 + lr] = xHi;
+    }
     if (p0l + 4 < CB) {                                    // rows p0l+4 .. p0l+7 of S are final: publish them raw
       const int qa = (p0l + 4) >> 4, isel = ((p0l + 4) & 15) >> 2;
       double vlo, vhi;
@@ -486,7 +498,7 @@ __device__ __forceinline__ void fp_inverse_wave(double* sc, int nsteps, int itil
 
 // T10 in tile 0, T00 in tile 1, T11 in tile 2 of `sm` (as factor_pair_tail); scratch = tiles 5, 6.
 __device__ __forceinline__ void factor_pair_lean(double* sm, bool has1, int d0, double* __restrict__ Lw, double* __restrict__ Iw,
-                                                 int Dp, int D, int* __restrict__ info) {
+                                                 int Dp, int D, int* __restrict__ info, double* Ls = nullptr, double* Vs = nullptr) {
   const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
   const double* T10 = sm;
   const double* T00 = sm + 1 * TSZ;
@@ -494,12 +506,12 @@ __device__ __forceinline__ void factor_pair_lean(double* sm, bool has1, int d0, 
   double* sc = sm + 5 * TSZ;
   const int nsteps = has1 ? 16 : 8;
   const long kk = (long)d0 * CB;
-  if (wv == 0) fp_update_wave<0>(T00, sc, nsteps, kk, Lw, Dp, l);
-  else if (wv == 1 && has1) fp_update_wave<1>(T10, sc, nsteps, kk, Lw, Dp, l);
-  else if (wv == 2 && has1) fp_update_wave<2>(T11, sc, nsteps, kk, Lw, Dp, l);
+  if (wv == 0) fp_update_wave<0>(T00, sc, nsteps, kk, Lw, Dp, l, Ls);
+  else if (wv == 1 && has1) fp_update_wave<1>(T10, sc, nsteps, kk, Lw, Dp, l, Ls);
+  else if (wv == 2 && has1) fp_update_wave<2>(T11, sc, nsteps, kk, Lw, Dp, l, Ls);
   else if (wv == 3) fp_micro_wave(T00, sc, nsteps, kk, D, info, l);
-  else if (wv == 6) fp_inverse_wave(sc, nsteps, 0, Iw + (long)d0 * CB * CB, l);
-  else if (wv == 4 && has1) fp_inverse_wave(sc, nsteps, 1, Iw + (long)(d0 + 1) * CB * CB, l);
+  else if (wv == 6) fp_inverse_wave(sc, nsteps, 0, Iw ? Iw + (long)d0 * CB * CB : nullptr, l, Vs);
+  else if (wv == 4 && has1) fp_inverse_wave(sc, nsteps, 1, Iw ? Iw + (long)(d0 + 1) * CB * CB : nullptr, l, Vs);
   else {
 #pragma unroll 1
     for (int s = 0; s <= nsteps; ++s) lds_only_barrier();
@@ -961,6 +973,188 @@ __global__ __launch_bounds__(128) void chol_backsub_rect_kernel(const double* __
 #pragma unroll 4
   for (int r = r0; r < r1; ++r) s += Lw[(long)r * Dp + j] * x[r];
   ypart[(long)blockIdx.y * pstride + j] = s;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Round 4: the small SPD systems of the DepthCov path (n <= 64, float64: K_mm + 1e-6 I -> L_mm, K_mm^-1 once per keyframe, the
+// normal equations of the depth distillation; csrc/smallsolve.hip has the interface and the general kernel) on the machinery
+// above: ONE workgroup per matrix -- the matrix padded with an identity to 32 / 64 and factored by factor_pair_lean with L and the
+// inverted diagonal tiles V0, V1 kept in LDS (~9 us), then
+//   L^-1 = [V0 0; X V1], X = -V1 (L10 V0);  A^-1 = L^-T L^-1 = [V0^T V0 + X^T X, .; V1^T X, V1^T V1]   (six 32^3 matrix-core products)
+//   A^-1 B by block substitution with the inverted diagonal tiles: y0 = V0 b0, y1 = V1 (b1 - L10 y0), x1 = V1^T y1,
+//   x0 = V0^T (y0 - L10^T x1)  -- what the dense solver's ride-along back-substitution does.
+// The pivot-by-pivot LDS kernel it replaces ran 145 ... 224 us per 64 x 64 system (192 barriers for the factor alone).
+template <bool TA, bool TB>      // out = op(X) op(Y): element (i, k) of op(X) is X[i][k] (TA: X[k][i]); (k, j) of op(Y) is Y[k][j] (TB: Y[j][k])
+__device__ __forceinline__ void tile_mm_mfma(const double* X, const double* Y, int w, int l, d4_t& acc) {
+  const int r = l & 15, q = l >> 4;
+  const int i = 16 * (w >> 1) + r, j = 16 * (w & 1) + r;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int k = 4 * s + q;
+    const double a = TA ? X[k * CLD + i] : X[i * CLD + k];
+    const double b = TB ? Y[j * CLD + k] : Y[k * CLD + j];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(512) void chol_small64_kernel(const double* __restrict__ A, int n, double* __restrict__ Lout,
+                                                           double* __restrict__ Ainv, const double* __restrict__ rhs, int k,
+                                                           double* __restrict__ X, int* __restrict__ info) {
+  __shared__ __attribute__((aligned(16))) double sm[NT2 * TSZ];
+  const int b = blockIdx.x, tid = threadIdx.x, w = (tid >> 6) & 3, l = tid & 63, half = tid >> 8;
+  const double* Ab = A + (long)b * n * n;
+  const bool has1 = n > CB;
+  const int np = has1 ? 2 * CB : CB;
+  int* infob = info ? info + b : nullptr;
+  __shared__ int info_s;
+  if (tid == 0) info_s = 0;
+  for (int e = tid; e < np * np; e += 512) {
+    const int i = e / np, j = e % np;
+    const double v = (i < n && j < n) ? (j <= i ? Ab[(long)i * n + j] : 0.0) : (i == j ? 1.0 : 0.0);     // identity pad
+    const int t = i < CB ? 1 : (j < CB ? 0 : 2);           // tile 1 = T00, 0 = T10, 2 = T11
+    if (i >= CB || j < CB) sm[t * TSZ + (i & 31) * CLD + (j & 31)] = v;
+  }
+  __syncthreads();
+  factor_pair_lean(sm, has1, 0, (double*)nullptr, (double*)nullptr, 0, n, &info_s, sm, sm + 3 * TSZ);
+  __syncthreads();
+  if (tid == 0 && infob) *infob = info_s;
+  const double* L10 = sm;
+  const double* L00 = sm + 1 * TSZ;
+  const double* L11 = sm + 2 * TSZ;
+  const double* V0 = sm + 3 * TSZ;
+  const double* V1 = sm + 4 * TSZ;
+  double* S5 = sm + 5 * TSZ;
+  double* S6 = sm + 6 * TSZ;
+  if (Lout) {
+    double* Lb = Lout + (long)b * n * n;
+    for (int e = tid; e < n * n; e += 512) {
+      const int i = e / n, j = e - i * n;
+      const double* t = i < CB ? L00 : (j < CB ? L10 : L11);
+      Lb[e] = (j <= i) ? t[(i & 31) * CLD + (j & 31)] : 0.0;
+    }
+  }
+  if (rhs && X) {
+    // block substitution, 8 right-hand-side columns per sweep; thread (i, c) = (tid >> 3, tid & 7) for tid < 256
+    double* rb = S5;                                        // [64][8] right-hand side -> y -> x
+    double* tb = S5 + 512;                                  // [32][8] temporaries
+    const int i = (tid >> 3) & 31, c = tid & 7;
+    for (int c0 = 0; c0 < k; c0 += 8) {
+      const int kc = min(8, k - c0);
+      for (int e = tid; e < 64 * 8; e += 512) {
+        const int r = e >> 3, cc = e & 7;
+        rb[e] = (r < n && cc < kc) ? rhs[((long)b * n + r) * k + c0 + cc] : 0.0;
+      }
+      __syncthreads();
+      double v = 0.0;
+      if (tid < 256) {                                      // y0 = V0 b0
+#pragma unroll 8
+        for (int q = 0; q < CB; ++q) v = __builtin_fma(V0[i * CLD + q], rb[q * 8 + c], v);
+      }
+      __syncthreads();
+      if (tid < 256) rb[i * 8 + c] = v;
+      __syncthreads();
+      if (has1) {
+        v = 0.0;
+        if (tid < 256) {                                    // t = b1 - L10 y0
+          v = rb[(CB + i) * 8 + c];
+#pragma unroll 8
+          for (int q = 0; q < CB; ++q) v = __builtin_fma(-L10[i * CLD + q], rb[q * 8 + c], v);
+          tb[i * 8 + c] = v;
+        }
+        __syncthreads();
+        v = 0.0;
+        if (tid < 256) {                                    // y1 = V1 t
+#pragma unroll 8
+          for (int q = 0; q < CB; ++q) v = __builtin_fma(V1[i * CLD + q], tb[q * 8 + c], v);
+        }
+        __syncthreads();
+        if (tid < 256) tb[i * 8 + c] = v;
+        __syncthreads();
+        v = 0.0;
+        if (tid < 256) {                                    // x1 = V1^T y1
+#pragma unroll 8
+          for (int q = 0; q < CB; ++q) v = __builtin_fma(V1[q * CLD + i], tb[q * 8 + c], v);
+          rb[(CB + i) * 8 + c] = v;
+        }
+        __syncthreads();
+        v = 0.0;
+        if (tid < 256) {                                    // u = y0 - L10^T x1
+          v = rb[i * 8 + c];
+#pragma unroll 8
+          for (int q = 0; q < CB; ++q) v = __builtin_fma(-L10[q * CLD + i], rb[(CB + q) * 8 + c], v);
+          tb[i * 8 + c] = v;
+        }
+        __syncthreads();
+      } else {
+        if (tid < 256) tb[i * 8 + c] = rb[i * 8 + c];
+        __syncthreads();
+      }
+      v = 0.0;
+      if (tid < 256) {                                      // x0 = V0^T u
+#pragma unroll 8
+        for (int q = 0; q < CB; ++q) v = __builtin_fma(V0[q * CLD + i], tb[q * 8 + c], v);
+        rb[i * 8 + c] = v;
+      }
+      __syncthreads();
+      for (int e = tid; e < 64 * 8; e += 512) {
+        const int r = e >> 3, cc = e & 7;
+        if (r < n && cc < kc) X[((long)b * n + r) * k + c0 + cc] = rb[e];
+      }
+      __syncthreads();
+    }
+  }
+  if (Ainv) {
+    double* Ib = Ainv + (long)b * n * n;
+    auto put = [&](int r0, int c0, const d4_t& a, bool mirror) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = r0 + mrow(w, l, q), cc = c0 + mcol(w, l);
+        if (r < n && cc < n) {
+          Ib[(long)r * n + cc] = a[q];
+          if (mirror) Ib[(long)cc * n + r] = a[q];
+        }
+      }
+    };
+    if (has1) {
+      if (half == 0) {                                      // Y = L10 V0
+        d4_t y = {0.0, 0.0, 0.0, 0.0};
+        tile_mm_mfma<false, false>(L10, V0, w, l, y);
+        tile_store_mfma(S5, w, l, y);
+      }
+      __syncthreads();
+      if (half == 0) {                                      // X = -V1 Y
+        d4_t x = {0.0, 0.0, 0.0, 0.0};
+        tile_mm_mfma<false, false>(V1, S5, w, l, x);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S6[mrow(w, l, q) * CLD + mcol(w, l)] = -x[q];
+      }
+      __syncthreads();
+      if (half == 0) {                                      // A^-1_00 = V0^T V0 + X^T X ; A^-1_11 = V1^T V1
+        d4_t a = {0.0, 0.0, 0.0, 0.0};
+        tile_mm_mfma<true, false>(V0, V0, w, l, a);
+        tile_mm_mfma<true, false>(S6, S6, w, l, a);
+        put(0, 0, a, false);
+      } else {                                              // A^-1_10 = V1^T X (and its mirror), then A^-1_11
+        d4_t a = {0.0, 0.0, 0.0, 0.0};
+        tile_mm_mfma<true, false>(V1, S6, w, l, a);
+        put(CB, 0, a, true);
+        d4_t c = {0.0, 0.0, 0.0, 0.0};
+        tile_mm_mfma<true, false>(V1, V1, w, l, c);
+        put(CB, CB, c, false);
+      }
+    } else if (half == 0) {
+      d4_t a = {0.0, 0.0, 0.0, 0.0};
+      tile_mm_mfma<true, false>(V0, V0, w, l, a);
+      put(0, 0, a, false);
+    }
+  }
+}
+
+int chol_small64_f64(const double* A, int B, int n, double* L, double* Ainv, const double* rhs, int k, double* X, int* info,
+                     hipStream_t s) {
+  hipLaunchKernelGGL(chol_small64_kernel, dim3(B), dim3(512), 0, s, A, n, L, Ainv, rhs, k, X, info);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
 }
 
 }  // namespace como

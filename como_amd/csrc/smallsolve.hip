@@ -16,6 +16,7 @@
 //                        the two-frame initialisation: d = every pixel), one thread per column
 #include "common.cuh"
 #include "../../include/como_hip.h"
+#include <cstdlib>
 
 namespace como {
 
@@ -168,10 +169,18 @@ __global__ __launch_bounds__(256) void trsm_lower_kernel(const T* __restrict__ L
   }
 }
 
+// csrc/chol.hip: n <= 64, float64 on the dense solver's tile machinery (matrix-core tile factorisation, ~15 us per system)
+int chol_small64_f64(const double* A, int B, int n, double* L, double* Ainv, const double* rhs, int k, double* X, int* info,
+                     hipStream_t s);
+
 template <typename T>
 int chol_small(const T* A, int B, int n, T* L, T* Ainv, const T* rhs, int k, T* X, int* info, hipStream_t s) {
   if (!A || B < 0 || n <= 0 || n > SM_MAXN || k < 0 || ((rhs != nullptr) != (X != nullptr)) || (rhs && k <= 0)) return COMO_ERR_ARG;
   if (B == 0) return COMO_OK;
+  if constexpr (sizeof(T) == 8) {
+    static const bool fast = [] { const char* e = getenv("COMO_CHOL_SMALL_FAST"); return !e || e[0] != '0'; }();
+    if (fast && n <= 64 && n >= 8) return chol_small64_f64(A, B, n, L, Ainv, rhs, k, X, info, s);
+  }
   hipLaunchKernelGGL(chol_small_kernel<T>, dim3(B), dim3(256), 0, s, A, n, L, Ainv, rhs, k, X, info);
   COMO_CHECK_LAUNCH();
   return COMO_OK;

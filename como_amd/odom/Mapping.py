@@ -26,6 +26,7 @@ from como_amd.geometry.camera import backprojection
 from como_amd.geometry.transforms import get_T_w_curr, transform_points
 from como_amd.odom.frontend.corr import track_and_init
 from como_amd.odom.frontend.TwoFrameSfm import TwoFrameSfm
+from como_amd.odom.backend.dense_ref import depth_image
 from como_amd.odom.window_ba import WindowBA
 from como_amd.utils.coords import swap_coords_xy
 from como_amd.utils.select import masked_median
@@ -193,8 +194,7 @@ class Mapping:
         log-depths change."""
         if self._depth_cache is None and self.logzm.numel():
             b, h, w, m = self.Knm_Kmminv.shape
-            logz = (self.Knm_Kmminv.reshape(b, h * w, m) @ self.logzm.reshape(b, m, 1)).reshape(b, 1, h, w)
-            self._depth_cache = torch.exp(logz)
+            self._depth_cache = depth_image(self.Knm_Kmminv.reshape(b, h * w, m), self.logzm).reshape(b, 1, h, w)
         return self._depth_cache
 
     def depth_imgs_of(self, lo, hi):
@@ -204,7 +204,7 @@ class Mapping:
             return self._depth_cache[lo:hi]
         Kt = self.Knm_Kmminv[lo:hi]
         b, h, w, m = Kt.shape
-        return torch.exp((Kt.reshape(b, h * w, m) @ self.logzm[lo:hi].reshape(b, m, 1)).reshape(b, 1, h, w))
+        return depth_image(Kt.reshape(b, h * w, m), self.logzm[lo:hi]).reshape(b, 1, h, w)   # one pass over K~ (csrc/densify.hip)
 
     def get_kf_ref_data(self, ind=-1):
         """Mapping.py:499-512: the newest `track_ref.num_keyframes` keyframes for the tracker."""

@@ -60,6 +60,38 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
     return ws["Pwn"], ws["dT"], ws["uvec"], med[:, 0], ws["logz"]
 
 
+_di_ws = {}
+
+
+def depth_image(Kt, logzm, out=None):
+    """exp(K~ logz_m) for every row of K~ (Mapping.store_vars' depth images, Mapping.py:749-758; the tracker asks for the newest
+    keyframe's on every frame): the depth-only pass of `como_dense_ref_*` (flag 8) -- one streaming pass over K~ at HBM rate --
+    instead of a (rows x m) . (m x 1) library GEMM + exp (rocBLAS ran that GEMV shape at 0.7 TB/s: 216 us per 640x480 keyframe).
+    Kt (B,rows,m) (a view with a row stride is fine), logzm (B,m[,1]); returns (B,rows) depths (into `out` when given)."""
+    _lib.require_cuda(Kt, logzm)
+    dt, dev = Kt.dtype, Kt.device
+    B, rows, m = Kt.shape
+    if Kt.stride(2) != 1 or Kt.stride(1) != m:
+        Kt = Kt.contiguous()
+    L = _lib.lib()
+    key = (str(dev), dt, B, m)
+    w = _di_ws.get(key)
+    if w is None:
+        w = _di_ws[key] = {"hists": torch.zeros((B * L.como_select_workspace_bytes() // 4,), device=dev, dtype=torch.int32),
+                           "eye": torch.eye(4, device=dev, dtype=dt).repeat(B, 1, 1).contiguous(),
+                           "K": torch.eye(3, device=dev, dtype=dt), "dl": torch.zeros((B, m, 6), device=dev, dtype=dt),
+                           "med": torch.zeros((B, 3), device=dev, dtype=dt)}
+    z = out if out is not None else torch.empty((B, rows), device=dev, dtype=dt)
+    lz = logzm.reshape(B, m)
+    if lz.dtype != dt or not lz.is_contiguous():
+        lz = lz.to(dt).contiguous()
+    rc = getattr(L, "como_dense_ref_" + _lib.suffix(dt))(
+        Kt.data_ptr(), Kt.stride(0), None, lz.data_ptr(), w["eye"].data_ptr(), w["K"].data_ptr(), w["dl"].data_ptr(), B, rows, m, 1,
+        None, None, None, z.data_ptr(), None, w["hists"].data_ptr(), w["med"].data_ptr(), None, 8 | 2, _lib.stream_ptr(dev))
+    _lib.check(rc, "como_dense_ref (depth image)")
+    return z
+
+
 BAND_MEDIAN = __import__("os").environ.get("COMO_BAND_MEDIAN", "1") != "0"
 
 

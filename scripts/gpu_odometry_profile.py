@@ -24,6 +24,8 @@ def timed(owner, name, label):
     fn = getattr(owner, name)
 
     def wrap(*a, **k):
+        if torch.cuda.is_current_stream_capturing():        # (a wrapped call inside a hipGraph capture: no timers there)
+            return fn(*a, **k)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         r = fn(*a, **k)

@@ -100,7 +100,8 @@ def test_small_spd_conditioning(dt, tol):
     from como_amd.utils.lin_alg import chol_small, cholesky_solve_many, trsm_lower
     g = torch.Generator().manual_seed(3)
     worst = {}
-    for B, n, k in ((1, 5, 1), (3, 16, 3), (2, 64, 11), (1, 70, 1), (1, 80, 9)):
+    # (float64, 8 <= n <= 64: the matrix-core tile kernel of csrc/chol.hip, identity-padded to 32 / 64; otherwise the LDS kernel)
+    for B, n, k in ((1, 5, 1), (3, 16, 3), (1, 32, 2), (2, 33, 9), (2, 48, 1), (2, 64, 11), (1, 70, 1), (1, 80, 9)):
         M = torch.randn((B, n, n + 8), generator=g, dtype=torch.float64)
         A = (M @ M.mT / (n + 8) + 0.05 * torch.eye(n, dtype=torch.float64)).to(dt)
         rhs = torch.randn((B, n, k), generator=g, dtype=torch.float64).to(dt)
@@ -121,6 +122,11 @@ def test_small_spd_conditioning(dt, tol):
     Abad[3, 3] = -1.0
     info = chol_small(dev(Abad[None]), want_L=True, want_info=True)["info"]
     assert info.tolist() == torch.linalg.cholesky_ex(Abad[None].double()).info.tolist() == [4]
+    for n, where in ((40, 3), (40, 35), (64, 64), (20, 9)):                         # both tiles of the padded 64 x 64 block
+        Abad = torch.eye(n, dtype=dt) * 2.0
+        Abad[where - 1, where - 1] = -1.0
+        info = chol_small(dev(Abad[None]), want_L=True, want_info=True)["info"]
+        assert info.tolist() == torch.linalg.cholesky_ex(Abad[None].double()).info.tolist() == [where]
     # many right-hand sides
     for B, n, d in ((1, 64, 3001), (2, 37, 515)):
         M = torch.randn((B, n, n + 8), generator=g, dtype=torch.float64)
