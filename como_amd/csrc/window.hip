@@ -426,6 +426,34 @@ __global__ __launch_bounds__(256) void win_update_kernel(const double* __restric
   for (int e = tid; e < 3 * L; e += gridDim.x * 256) P_m[e] += delta[lm_start + e];
 }
 
+// invertSE3 (lie_algebra.py:83-95 without the Jacobian; also the inverse inside get_T_w_curr / get_rel_pose, transforms.py:6-13):
+// Ti = [R^T | -(R^T t); 0 0 0 1] for n poses, one thread each -- the mirror's torch form is six launches (zeros_like, three slice
+// assignments, a batched matmul, a negation: ~90 us of host time) and runs several times per frame in the tracker / mapper glue.
+// The products are the plain sums a (3x3)(3x1) matmul forms, left to right, without contraction.
+template <typename T>
+__global__ __launch_bounds__(64) void se3_inverse_kernel(const T* __restrict__ in, T* __restrict__ out, int n) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  const T* a = in + 16 * (long)i;
+  T* o = out + 16 * (long)i;
+  T R[9], t[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) R[3 * r + c] = a[4 * r + c];
+    t[r] = a[4 * r + 3];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    T s = R[r] * t[0];                 // row r of R^T = column r of R
+    s = s + R[3 + r] * t[1];
+    s = s + R[6 + r] * t[2];
+    o[4 * r + 0] = R[r]; o[4 * r + 1] = R[3 + r]; o[4 * r + 2] = R[6 + r]; o[4 * r + 3] = -s;
+  }
+  o[12] = T(0); o[13] = T(0); o[14] = T(0); o[15] = T(1);
+}
+
 }  // namespace como
 
 extern "C" {
@@ -497,6 +525,19 @@ int como_win_update(const double* delta, double* poses, double* aff, const long*
   if (blocks < (F + 255) / 256) blocks = (F + 255) / 256;
   hipLaunchKernelGGL(como::win_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, delta, poses, aff, frame_inds, F,
                      P_m, L, lm_start);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_se3_inverse_f32(const float* T, float* out, int n, como_stream_t stream) {
+  if (!T || !out || n <= 0) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::se3_inverse_kernel<float>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, T, out, n);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+int como_se3_inverse_f64(const double* T, double* out, int n, como_stream_t stream) {
+  if (!T || !out || n <= 0) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::se3_inverse_kernel<double>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, T, out, n);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }

@@ -54,6 +54,14 @@ def batch_se3(poses, delta_T):
 
 
 def invertSE3(T):
+    if T.is_cuda and T.dtype in (torch.float32, torch.float64) and T.numel() > 0:
+        # one launch (csrc/window.hip se3_inverse_kernel) instead of six tiny torch ops: this runs several times per frame
+        from como_amd import _lib
+        Tc = T.contiguous()
+        out = torch.empty_like(Tc)
+        fn = getattr(_lib.lib(), "como_se3_inverse_" + _lib.suffix(T.dtype))
+        _lib.check(fn(Tc.data_ptr(), out.data_ptr(), Tc.numel() // 16, _lib.stream_ptr(T.device)), "como_se3_inverse")
+        return out
     Rt = T[..., :3, :3].transpose(-1, -2)
     Ti = torch.zeros_like(T)
     Ti[..., :3, :3] = Rt

@@ -80,6 +80,7 @@ class Mapping:
         self.obs_ref_mask = e(torch.bool)
         self.recent_timestamps = []
         self.recent_img_and_grads, self.recent_poses, self.recent_aff_params = e(), e(), e()
+        self.Knm_Kmminv_pix = self.kf_img_and_grads_pix = self.recent_img_and_grads_pix = None
         self._depth_cache = None
 
     def init_prior_vals(self):
@@ -103,9 +104,20 @@ class Mapping:
         self.model = model
 
     # ---- window helpers (Mapping.py:470-497) ----------------------------------------------------------------------------
+    # Per-pixel data the window solver reads in ITS element type (cfg pix_dtype): with a float32 pixel path and the reference's
+    # float64 mapping state, every rebuild of the window (each keyframe AND each one-way frame) converted the whole K~ window
+    # (1.26 GB at 9 x 640x480) and all image stacks again.  The mirrors below follow the same window operations, so only the
+    # NEW keyframe / frame is converted, once.
+    _PIX_MIRRORED = ("Knm_Kmminv", "kf_img_and_grads", "recent_img_and_grads")
+
     def _cat(self, name, new_var, i):
         old = getattr(self, name)
-        if name == "Knm_Kmminv" and new_var.is_cuda:
+        if name in self._PIX_MIRRORED and new_var.is_cuda and self.pix_dtype != new_var.dtype:
+            pix = name + "_pix"
+            if getattr(self, pix, None) is None or (old.numel() == 0 and old.dim() == 1):
+                setattr(self, pix, torch.empty((0), device=new_var.device, dtype=self.pix_dtype))
+            self._cat(pix, new_var.to(self.pix_dtype), i)
+        if name.startswith("Knm_Kmminv") and new_var.is_cuda:
             return self._cat_pingpong(name, old, new_var, i)
         setattr(self, name, new_var.clone() if old.numel() == 0 and old.dim() == 1 else torch.cat((old[i:, ...], new_var), dim=0))
 
@@ -114,18 +126,19 @@ class Mapping:
         for a new, larger block on every keyframe (a hipMalloc of > 1 GB: ~12 ms each while the window fills).  Two buffers of
         the window's full capacity, allocated once, alternate instead; the window is a view of the current one."""
         cap = self.cfg["graph"]["num_keyframes"]
-        pp = getattr(self, "_kt_pingpong", None)
+        store = self.__dict__.setdefault("_kt_pp", {})              # per window tensor (K~ and its pixel-type mirror)
+        pp, cur = store.get(name, (None, 0))
         if pp is None or pp[0].shape[1:] != new_var.shape[1:] or pp[0].dtype != new_var.dtype or pp[0].shape[0] != cap:
-            pp = self._kt_pingpong = [torch.empty((cap,) + tuple(new_var.shape[1:]), dtype=new_var.dtype, device=new_var.device)
-                                      for _ in range(2)]
-            self._kt_cur = 0
+            pp = [torch.empty((cap,) + tuple(new_var.shape[1:]), dtype=new_var.dtype, device=new_var.device) for _ in range(2)]
+            cur = 0
         empty = old.numel() == 0 and old.dim() == 1
         keep = old[0:0] if empty else old[i:, ...]
         k = keep.shape[0]
         if k + new_var.shape[0] > cap:
             raise RuntimeError("como_amd Mapping: more keyframes than graph.num_keyframes")
-        self._kt_cur ^= 1
-        dst = pp[self._kt_cur]
+        cur ^= 1
+        store[name] = (pp, cur)
+        dst = pp[cur]
         if k:
             dst[:k].copy_(keep)
         dst[k:k + new_var.shape[0]].copy_(new_var)
@@ -281,6 +294,8 @@ class Mapping:
         if r:
             self.recent_timestamps = self.recent_timestamps[r:]
             self.recent_img_and_grads = self.recent_img_and_grads[r:]
+            if getattr(self, "recent_img_and_grads_pix", None) is not None:
+                self.recent_img_and_grads_pix = self.recent_img_and_grads_pix[r:]
             self.recent_poses = self.recent_poses[r:]
             self.recent_aff_params = self.recent_aff_params[r:]
             self._retire_ba()
@@ -399,6 +414,10 @@ class Mapping:
         if len(self.recent_timestamps):
             st.update({"recent_poses": self.recent_poses, "recent_aff_params": self.recent_aff_params,
                        "recent_img_and_grads": self.recent_img_and_grads, "recent_timestamps": ts(self.recent_timestamps)})
+        for name in self._PIX_MIRRORED:                       # already in the solver's per-pixel element type (see _cat)
+            mirror = getattr(self, name + "_pix", None)
+            if mirror is not None and name in st and mirror.shape == st[name].shape:
+                st[name + "_pix"] = mirror
         return st
 
     def iterate(self):

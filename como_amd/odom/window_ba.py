@@ -96,10 +96,15 @@ class WindowBA:
         self.kf_timestamps = state["kf_timestamps"]
         # per-pixel data in pix_dtype
         # keyframe image stacks followed by the one-way frames' in ONE buffer (targets are addressed by element offset)
-        imgs = state["kf_img_and_grads"] if not nrec else torch.cat((state["kf_img_and_grads"],
-                                                                      state["recent_img_and_grads"].to(state["kf_img_and_grads"].dtype)))
+        # (the sequential loop hands over mirrors that are already in pix_dtype -- Mapping._cat -- so that a rebuild does not
+        # convert the whole K~ window and every image stack again)
+        def pix(name):
+            t = state.get(name + "_pix")
+            return t if t is not None and t.dtype == pix_dtype and t.shape == state[name].shape else state[name]
+        kf_img = pix("kf_img_and_grads")
+        imgs = kf_img if not nrec else torch.cat((kf_img, pix("recent_img_and_grads").to(kf_img.dtype)))
         self.img = imgs.to(pix_dtype).contiguous()
-        self.Kt = state["Knm_Kmminv"].to(pix_dtype).reshape(B, self.Himg * self.Wimg, self.m).contiguous()
+        self.Kt = pix("Knm_Kmminv").to(pix_dtype).reshape(B, self.Himg * self.Wimg, self.m).contiguous()
         self.K_pix = self.intrinsics[0].to(pix_dtype).contiguous()
         self.median_depths = (f64(state["median_depth_init"]) if "median_depth_init" in state
                               else torch.full((B,), 1.0, device=dev, dtype=self.dt))

@@ -446,6 +446,10 @@ int como_sys_finalize_pack(const void* sysfix, long fix_plane, long D, double* H
                            int* info, como_stream_t stream);
 int como_win_update(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
                     long lm_start, como_stream_t stream);
+/* invertSE3 (como/geometry/lie_algebra.py:83-95 without the Jacobian; the inverse inside get_T_w_curr / get_rel_pose,
+ * transforms.py:6-13): out[i] = [R^T | -(R^T t); 0 0 0 1] for n row-major 4x4 poses (in and out may not alias). */
+int como_se3_inverse_f32(const float* T, float* out, int n, como_stream_t stream);
+int como_se3_inverse_f64(const double* T, double* out, int n, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * DepthCov covariance network, float32 inference (python path: como/depth_cov/nn/UNet.py:57-78 UNet.forward,
