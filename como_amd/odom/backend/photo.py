@@ -295,21 +295,8 @@ class PairTable:
             tgt_is_recent = [r for r in tgt_is_recent for _ in range(c)]
         b = len(ref_ids)
         self.b = b
-        self.pair_chan = _i32([p_ % c for p_ in range(b)], device) if c > 1 else None
-        self.ref_slot = _i32(ref_ids, device)
-        self.ref_pose = self.ref_slot                       # keyframes come first in the pose buffer: slot b = pose b
-        self.ref_aff = _i32(ref_ids, device)
         tgt_frame = [t + (num_kf if r else 0) for t, r in zip(tgt_ids, tgt_is_recent)]
-        self.tgt_aff = _i32(tgt_frame, device)
-        self.tgt_pose = _i32(tgt_frame, device)
         off = [(recent_img_offset + t * img_stride) if r else t * img_stride for t, r in zip(tgt_ids, tgt_is_recent)]
-        self.tgt_img = torch.as_tensor(off, dtype=torch.int64, device=device)
-        rid = torch.as_tensor(ref_ids, dtype=torch.long, device=device)
-        self.pose_ref_inds = kf_inds[rid].contiguous()
-        # system rows of every target frame with ONE gather (keyframes first, then the one-way frames)
-        frame_rows = torch.cat((kf_inds, recent_inds), dim=0) if any(tgt_is_recent) else kf_inds
-        self.pose_tgt_inds = frame_rows[torch.as_tensor(tgt_frame, dtype=torch.long, device=device)].contiguous()
-        self.landmark_inds = landmark_inds[rid].contiguous()
         # pairs sharing their reference keyframe, two at a time (csrc/ba.hip ba_blocks_pair2_kernel); the rest one by one
         by_ref = {}
         for p_, r_ in enumerate(ref_ids):
@@ -320,7 +307,25 @@ class PairTable:
                 grp.append([lst.pop(0), lst.pop(0)])
             if lst:
                 grp.append([lst[0], -1])                   # a lone pair rides the same kernel with its second half masked
-        self.grp_pairs = torch.tensor(grp, dtype=torch.int32, device=device).reshape(-1, 2)
+        # every host-built index array in TWO host->device copies (int32 | int64) instead of one small pageable copy each: the
+        # window is rebuilt on every keyframe / one-way frame of the sequential loop
+        chan = [p_ % c for p_ in range(b)]
+        i32 = torch.tensor(list(ref_ids) + tgt_frame + chan + [x for g_ in grp for x in g_], dtype=torch.int32).to(device)
+        i64 = torch.tensor(off + list(ref_ids) + tgt_frame, dtype=torch.int64).to(device)
+        self.ref_slot = i32[0:b]
+        self.ref_pose = self.ref_slot                       # keyframes come first in the pose buffer: slot b = pose b
+        self.ref_aff = self.ref_slot
+        self.tgt_aff = i32[b:2 * b]
+        self.tgt_pose = self.tgt_aff
+        self.pair_chan = i32[2 * b:3 * b] if c > 1 else None
+        self.grp_pairs = i32[3 * b:].reshape(-1, 2)
+        self.tgt_img = i64[0:b]
+        rid = i64[b:2 * b]
+        self.pose_ref_inds = kf_inds[rid].contiguous()
+        # system rows of every target frame with ONE gather (keyframes first, then the one-way frames)
+        frame_rows = torch.cat((kf_inds, recent_inds), dim=0) if any(tgt_is_recent) else kf_inds
+        self.pose_tgt_inds = frame_rows[i64[2 * b:3 * b]].contiguous()
+        self.landmark_inds = landmark_inds[rid].contiguous()
         self.single_pairs = torch.zeros(0, dtype=torch.int32, device=device)
         self.ngroups = len(grp)
 

@@ -248,14 +248,21 @@ class WindowBA:
 
     def _prepare_fused(self):
         B, m, L, F, dev, p = self.B, self.m, self.L, self.F, self.dev, self.pix_dtype
-        z64 = lambda *s: torch.zeros(s, device=dev, dtype=self.dt)
-        zp = lambda *s: torch.zeros(s, device=dev, dtype=p)
-        self.w = {"pm": z64(B, m, 2), "logzm": z64(B, m), "invz": z64(B, m), "dzdP": z64(B, 3), "dlogz_dT": z64(B, m, 6),
-                  "dlogz_dP": z64(B, m, 3), "dp_dP": z64(B, m, 6), "dp_dT": z64(B, m, 12), "init_Pm": z64(L, 3),
-                  "reinit_flag": torch.zeros(L, device=dev, dtype=torch.int32),
-                  "px_logzm": zp(B, m), "px_invz": zp(B, m), "px_dzdP": zp(B, 3), "px_dlogz_dT": zp(B, m, 6),
-                  "px_poses": zp(F, 4, 4), "px_aff": zp(F, 2),
-                  "med3": zp(B, 3), "med3_full": zp(B, 3)}
+        # the scaffold's outputs: ONE zeroed allocation per element type, carved into views (the window is rebuilt on every
+        # keyframe and one-way frame of the sequential loop: twenty small zero-fills cost the host more than the kernels they feed)
+        def carve(specs, dtype):
+            sizes = [(k, shp, ((int(torch.Size(shp).numel()) + 3) // 4) * 4) for k, shp in specs]      # 16-byte (f32) / 32-byte steps
+            buf = torch.zeros(sum(n for _, _, n in sizes), device=dev, dtype=dtype)
+            out, o = {}, 0
+            for k, shp, n in sizes:
+                out[k] = buf[o:o + int(torch.Size(shp).numel())].view(shp)
+                o += n
+            return out
+        self.w = carve((("pm", (B, m, 2)), ("logzm", (B, m)), ("invz", (B, m)), ("dzdP", (B, 3)), ("dlogz_dT", (B, m, 6)),
+                        ("dlogz_dP", (B, m, 3)), ("dp_dP", (B, m, 6)), ("dp_dT", (B, m, 12)), ("init_Pm", (L, 3))), self.dt)
+        self.w.update(carve((("px_logzm", (B, m)), ("px_invz", (B, m)), ("px_dzdP", (B, 3)), ("px_dlogz_dT", (B, m, 6)),
+                             ("px_poses", (F, 4, 4)), ("px_aff", (F, 2)), ("med3", (B, 3)), ("med3_full", (B, 3))), p))
+        self.w["reinit_flag"] = torch.zeros(L, device=dev, dtype=torch.int32)
         # The reference keeps TWO medians per keyframe: the one of the sub-selected reference pixels (setup_test_points,
         # sparse_map.py:220 -- only the pair graph reads it) and `self.median_depths` = the median of the FULL depth image
         # exp(K~ logz_m) (store_vars, Mapping.py:749-758), which the priors and the landmark re-initialisation use.  With
@@ -288,10 +295,11 @@ class WindowBA:
         a.sysfix, a.fix_plane = ptr(self.sysfix), self.fix_plane
         # the two radix-select workspaces of an iteration are cleared by the scaffold kernel (no fill launches)
         hb = _lib.lib().como_select_workspace_bytes()
-        self.w["hist_dr2"] = torch.zeros(2 * B * hb // 4, dtype=torch.int32, device=self.dev)   # dense-ref median | full-image median
+        hall = torch.zeros((2 * B + 1) * hb // 4, dtype=torch.int32, device=self.dev)      # one allocation: dense-ref | full-image | BA
+        self.w["hist_dr2"] = hall[:2 * B * hb // 4]
         self.w["hist_dr"] = self.w["hist_dr2"][:B * hb // 4]
         self.w["hist_full"] = self.w["hist_dr2"][B * hb // 4:]
-        self.w["hist_ba"] = torch.zeros(hb // 4, dtype=torch.int32, device=self.dev)
+        self.w["hist_ba"] = hall[2 * B * hb // 4:]
         a.zero_a, a.zero_a_bytes = ptr(self.w["hist_dr2"]), 2 * B * hb
         a.zero_b, a.zero_b_bytes = ptr(self.w["hist_ba"]), hb
         if self.sysfix is not None and (self.sysfix.numel() * 8) % 16 == 0:
