@@ -141,6 +141,8 @@ SIGNATURES = {
     "como_win_scaffold": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
     "como_win_priors": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
     "como_win_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
+    "como_gram_workspace_bytes": (c_long, []),
+    "como_gram_f64": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "como_se3_inverse_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "como_se3_inverse_f64": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
 }

@@ -28,6 +28,41 @@ def _gram(A, b, chunks=256):
     return ((Ac.mT @ Ac).reshape(B, chunks, m, m).sum(1), (Ac.mT @ bc).reshape(B, chunks, m, b.shape[2]).sum(1))
 
 
+_gram_ws = {}
+
+
+def gram_weighted(A, w, y, c=None, want_stats=False):
+    """Weighted normal equations with the rows read in place (csrc/gram.hip `como_gram_f64`): A (1,n,m) float64 on the GPU (a
+    row-strided view is fine), w (1,n[,1]) row weights or None, y (1,n,1), c (1,m[,1]) or None:
+        r = y - A c,   AtA = A^T diag(w) A (1,m,m),   Atb = A^T diag(w) r (1,m,1),   stats = {sum w, sum w r, sum w r^2, #(w != 0)}.
+    Rows with w == 0 contribute nothing whatever they hold (no boolean-mask gather of the valid rows, no concatenation)."""
+    from como_amd import _lib
+    _lib.require_cuda(A, y)
+    B, n, m = A.shape
+    if B != 1 or A.dtype != torch.float64 or m > 64 or m % 4 or A.stride(2) != 1 or A.stride(1) % 2 or A.data_ptr() % 16:
+        raise RuntimeError("como_amd gram_weighted: needs a (1,n,m) float64 tensor with m <= 64, m % 4 == 0 and 16-byte aligned rows")
+    L = _lib.lib()
+    dev = A.device
+    ws = _gram_ws.get(str(dev))
+    if ws is None:
+        ws = _gram_ws[str(dev)] = torch.empty(L.como_gram_workspace_bytes() // 8, dtype=torch.float64, device=dev)
+    AtA = torch.empty((1, m, m), dtype=torch.float64, device=dev)
+    Atb = torch.empty((1, m, 1), dtype=torch.float64, device=dev)
+    stats = torch.empty(4, dtype=torch.float64, device=dev) if want_stats else None
+    wv = None if w is None else w.reshape(n).to(torch.float64).contiguous()
+    yv = y.reshape(n).to(torch.float64).contiguous()
+    cv = None if c is None else c.reshape(m).to(torch.float64).contiguous()
+    rc = L.como_gram_f64(A.data_ptr(), A.stride(1), n, m, _lib.ptr(wv), yv.data_ptr(), _lib.ptr(cv), AtA.data_ptr(), Atb.data_ptr(),
+                         _lib.ptr(stats), ws.data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "como_gram_f64")
+    return (AtA, Atb, stats) if want_stats else (AtA, Atb)
+
+
+def _fast(Kt):
+    return Kt.is_cuda and Kt.dtype == torch.float64 and Kt.shape[0] == 1 and Kt.shape[2] <= 64 and Kt.shape[2] % 4 == 0 and \
+        Kt.stride(2) == 1 and Kt.stride(1) % 2 == 0 and Kt.data_ptr() % 16 == 0
+
+
 def lstsq_chol(A, b):
     """como/utils/lin_alg.py:82-87: normal equations + Cholesky."""
     AtA, Atb = _gram(A, b)
@@ -74,6 +109,22 @@ def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model,
     Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model))
     if stdev_obs is not None:
         sinv = (1.0 / stdev_obs) * torch.ones_like(sinv)
+    if _fast(Kt):
+        # the same normal equations with the rows read in place: the validity test becomes a zero weight (no gather of the
+        # valid rows, no [prior ; observations] concatenation, no library GEMM with a single output tile)
+        okm = z_obs[:, :, 0:1] > min_depth
+        y = torch.log(torch.where(okm, z_obs[:, :, 0:1], torch.ones_like(z_obs[:, :, 0:1])))
+        m = Kt.shape[2]
+        if distill_with_prior:
+            AtA, Atb = gram_weighted(Kt, okm * (sinv * sinv), y)
+            eye = torch.eye(m, device=Kt.device, dtype=Kt.dtype).reshape(1, m, m)
+            Lm1 = trsm_lower(L_mm, eye)                       # the prior rows L_mm^-1 (distill_depth.py:60-63)
+            AtA = AtA + Lm1.mT @ Lm1
+        else:
+            AtA, Atb = gram_weighted(Kt, okm.to(Kt.dtype), y)
+        logz_m = chol_small(AtA, want_L=False, rhs=Atb)["X"]
+        ok = torch.nonzero(okm[0, :, 0])[:, 0]
+        return logz_m, (Kt @ logz_m - y).index_select(1, ok)
     ok = torch.nonzero(z_obs[0, :, 0] > min_depth)[:, 0]
     return distill_depth(Kt.index_select(1, ok), z_obs.index_select(1, ok), distill_with_prior, L_mm=L_mm,
                          stdev_inv_obs=sinv.index_select(1, ok))
@@ -99,6 +150,21 @@ def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_
     assert coords_m.shape[0] == 1
     Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model))
     sinv = (1.0 / stdev_obs) * torch.ones_like(sinv)
+    m, m1 = Kt.shape[2], z_m1.shape[1]
+    if _fast(Kt):
+        # [sp I ; sinv K~[:, m1:]] x = [sp s ; sinv (log z_obs - K~[:, :m1] log z_1)] as weighted normal equations of the rows in place:
+        # the known columns enter through c = [log z_1 ; 0] (r = y - K~ c), the unknown block is the lower-right corner
+        from como_amd.utils.select import masked_median
+        okm = z_obs[:, :, 0:1] > min_depth
+        zs = torch.where(okm, z_obs[:, :, 0:1], torch.ones_like(z_obs[:, :, 0:1]))
+        s_med = torch.log(masked_median(zs[0, :, 0], okm[0, :, 0]))
+        sp2 = (1.0 / 5e-2) ** 2
+        c = torch.cat((torch.log(z_m1).reshape(1, m1, 1), torch.zeros((1, m - m1, 1), device=Kt.device, dtype=Kt.dtype)), dim=1)
+        AtA, Atb = gram_weighted(Kt, okm * (sinv * sinv), torch.log(zs), c=c)
+        m2 = m - m1
+        A22 = AtA[:, m1:, m1:] + sp2 * torch.eye(m2, device=Kt.device, dtype=Kt.dtype)
+        b2 = Atb[:, m1:] + sp2 * s_med
+        return chol_small(A22.contiguous(), want_L=False, rhs=b2.contiguous())["X"]
     ok = torch.nonzero(z_obs[0, :, 0] > min_depth)[:, 0]
     return distill_conditional_depth_with_scale_prior(Kt.index_select(1, ok), z_obs.index_select(1, ok), z_m1,
                                                       sinv.index_select(1, ok))

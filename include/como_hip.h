@@ -347,6 +347,17 @@ int como_ktilde_f64(const double* cov, int Hc, int Wc, const double* xm, const d
                     double scale, int B, int Hp, int Wp, int m, double* out, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Weighted normal equations of the depth distillation (python path: como/utils/lin_alg.py:82-87 lstsq_chol's A^T A / A^T b as
+ * used by depth_cov/core/distill_depth.py:52-84, 122-148), float64, the rows read in place:
+ *   r_i = y_i - sum_k A[i][k] c[k] (c may be NULL);  AtA (m,m) = sum_i w_i A_i A_i^T (both triangles);  Atb (m) = sum_i w_i A_i r_i;
+ *   stats (4, may be NULL) = {sum w, sum w r, sum w r^2, number of rows with w != 0}.
+ * A (n rows, row_stride elements apart, m <= 64 columns, m % 4 == 0, 16-byte aligned), w (n) or NULL (= 1): rows with w == 0
+ * contribute exact zeros whatever they hold; workspace of como_gram_workspace_bytes() bytes.  Deterministic (fixed summation order). */
+long como_gram_workspace_bytes(void);
+int como_gram_f64(const double* A, long row_stride, int n, int m, const double* w, const double* y, const double* c, double* AtA,
+                  double* Atb, double* stats, void* workspace, como_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Dense SPD solve delta = H^-1 g, float64 (python path: backend/linear_system.py:101-112 solve_system).
  * H (D,D) row-major (lower triangle read), g (D), delta (D) out, workspace of como_chol_workspace_bytes(D) bytes,
  * info (1 int, device): 0 = ok, i > 0 = leading minor i not positive definite (cholesky_ex's info, reported instead

@@ -106,3 +106,35 @@ def test_fullsize_windows_with_own_conditioning(fixture, pix, window):
     assert int(ls.solve_system.last_info) == 0
     assert worst["pose"] < (1e-7 if f64 else 1e-4) and worst["aff"] < (1e-7 if f64 else 1e-4)
     assert worst["P"] < (1e-4 if f64 else 2e-3) and worst["med"] < (1e-6 if f64 else 1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_weighted_normal_equations_kernel():
+    """csrc/gram.hip (como_gram_f64) against torch: A^T W A, A^T W (y - A c), the statistics; masked rows hold NaN (they must
+    contribute exact zeros); a row-strided view; sizes that are not multiples of the kernel's row steps; exactly symmetric."""
+    from tests.conftest import rel_err
+    from como_amd.depth_cov.core.distill_depth import gram_weighted
+    g = torch.Generator().manual_seed(5)
+    for n, m, strided in ((49_152, 64, False), (1_003, 64, True), (37, 16, False), (300_001, 48, False)):
+        A = torch.randn((1, n, 64 if strided else m), generator=g, dtype=torch.float64)
+        w = torch.rand((1, n, 1), generator=g, dtype=torch.float64) * (torch.rand((1, n, 1), generator=g) < 0.8)
+        y = torch.randn((1, n, 1), generator=g, dtype=torch.float64)
+        c = torch.randn((1, m, 1), generator=g, dtype=torch.float64)
+        Ad = A.to(DEV)
+        Av = Ad[:, :, :m] if strided else Ad
+        dead = (w == 0)[0, :, 0]
+        Ad[0, dead.to(DEV)] = float("nan")                      # masked rows may hold anything
+        yd = y.clone()
+        yd[0, dead] = float("nan")
+        AtA, Atb, st = gram_weighted(Av, w.to(DEV), yd.to(DEV), c=c.to(DEV), want_stats=True)
+        Ar = A[:, :, :m]
+        r = y - Ar @ c
+        ref_AtA = Ar.mT @ (w * Ar)
+        ref_Atb = Ar.mT @ (w * r)
+        assert rel_err(AtA, ref_AtA) < 1e-12 and rel_err(Atb, ref_Atb) < 1e-12, (n, m)
+        assert torch.equal(AtA, AtA.mT)
+        ref_st = torch.stack((w.sum(), (w * r).sum(), (w * r * r).sum(), (w != 0).sum().double()))
+        assert rel_err(st, ref_st) < 1e-12
+        AtA2, Atb2 = gram_weighted(Av.nan_to_num(0.0), None, y.to(DEV))            # no weights, no c
+        assert rel_err(AtA2, torch.where(dead[None, :, None], torch.zeros_like(Ar), Ar).mT @ torch.where(dead[None, :, None], torch.zeros_like(Ar), Ar)) < 1e-12
+    report("gram_kernel", ok=True)
