@@ -293,6 +293,32 @@ def block_kernel_roofline(wb, dtype_name, reps=5):
     return out
 
 
+def _tracking_level_us(device, H, W, steps=200):
+    """microseconds per GN iteration of ONE persistent level launch at H x W (the pyramid levels of a 640x480 frame)."""
+    import como_amd.odom.frontend.photo_tracking as pt
+    from como_amd.utils import image_processing as ip
+    tp = synth.make_tracking_pair(H=H, W=W, dtype=torch.float32, device=device, seed=3, levels=1)
+    K = tp["intrinsics"]
+    stack = ip.img_and_grads(tp["img_ref"])
+    v, u = torch.meshgrid(torch.arange(float(H), device=device), torch.arange(float(W), device=device), indexing="ij")
+    ray = torch.stack(((u - K[0, 2]) / K[0, 0], (v - K[1, 2]) / K[1, 1], torch.ones_like(u)), -1).reshape(-1, 3)
+    P = (tp["depth_ref"][0, 0].reshape(-1, 1) * ray)[None].contiguous()
+    vals = tp["img_ref"].reshape(1, -1, 1).contiguous()
+    dI = torch.stack((stack[0, 1].reshape(-1), stack[0, 2].reshape(-1)), -1)[None, :, None, :].contiguous()
+    J = pt.precalc_jacobians(dI, P, vals, K)
+    aff0 = torch.zeros((1, 2, 1), device=device)
+    term = {"max_iter": steps, "delta_norm": 0.0, "rel_tol": 0.0, "grad_norm": 0.0}
+    run = lambda: pt.photo_level_tracking(tp["Tji_init"], aff0, vals, P, J, tp["img_cur"], K, 0.1, term)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    rec = pt.photo_level_tracking.last_out.cpu()
+    return el / steps * 1e6, (int(rec[105]) == steps and int(rec[104]) == 0)
+
+
 def tracking_leg(device, steps=200):
     """Config 2: the tracking GN iteration on a synthetic 640x480 pair, level 0 (N = 307,200 reference pixels): the captured
     iteration graph of como_amd/odom/frontend/photo_tracking.py replayed `steps` times (float32 = the reference's tracking
@@ -341,8 +367,16 @@ def tracking_leg(device, steps=200):
             tr_src = "committed_profile:profiles/r3_track_pmc_summary.json:" + key[:40]
         except Exception:                                   # noqa: BLE001
             pass
+        # the coarser pyramid levels of the same frame size (one persistent launch each; a tracked frame runs all three)
+        per_level = {"640x480": us}
+        for (hh, ww) in ((240, 320), (120, 160)):
+            try:
+                per_level[f"{ww}x{hh}"] = _tracking_level_us(device, hh, ww, steps)[0]
+            except Exception as e:                          # noqa: BLE001
+                per_level[f"{ww}x{hh}"] = repr(e)[:120]
         return {"workload": f"config 2: 2-frame 640x480 photometric tracking GN iteration, level 0, N={N} reference pixels, float32",
-                "value": steps / el, "unit": "GN iters/s", "us_per_iter": us, "steps": steps, "hip_graph": bool(graphed),
+                "value": steps / el, "unit": "GN iters/s", "us_per_iter": us, "us_per_iter_by_level": per_level, "steps": steps,
+                "hip_graph": bool(graphed),
                 "persistent_level_kernel": bool(fused),
                 "pixels_per_s": N * steps / el, "max_pose_abs_err_vs_gt_end": terr,
                 "roofline": {"bound": "hbm", "kernel": "track_level_kernel (per iteration)", "achieved": ach, "peak": HBM_PEAK_GBPS,
