@@ -310,13 +310,16 @@ def _tracking_level_us(device, H, W, steps=200):
     term = {"max_iter": steps, "delta_norm": 0.0, "rel_tol": 0.0, "grad_norm": 0.0}
     run = lambda: pt.photo_level_tracking(tp["Tji_init"], aff0, vals, P, J, tp["img_cur"], K, 0.1, term)
     run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    best = None
+    for _ in range(3):                                      # (fastest of three launches: a one-off ~70 ms stall of the first launch
+        torch.cuda.synchronize()                            # after a change of image size was seen on two boxes)
+        t0 = time.perf_counter()
+        run()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        best = el if best is None else min(best, el)
     rec = pt.photo_level_tracking.last_out.cpu()
-    return el / steps * 1e6, (int(rec[105]) == steps and int(rec[104]) == 0)
+    return best / steps * 1e6, (int(rec[105]) == steps and int(rec[104]) == 0)
 
 
 def tracking_leg(device, steps=200):

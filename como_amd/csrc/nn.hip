@@ -60,70 +60,56 @@ __global__ __launch_bounds__(64 * WV) void conv_mfma_kernel(const float* __restr
   float wokm[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) { const int co = co0 + 16 * mt + c; wokm[mt] = co < Cout ? 1.f : 0.f; wco[mt] = co < Cout ? co : 0; }
-  // Round 4: a whole kernel ROW (KS taps) of reduction steps is in flight per batch -- KS x U steps = 12 load groups for a 3x3
-  // kernel instead of 4: the layers are chains of dependent load -> MFMA batches (a 16-channel 3x3 layer at 192x256 was nine
-  // batches of ~2 us of memory latency each for 2 us of matrix work), so the number of batches is what a layer costs.
 #pragma unroll 1
-  for (int ky = 0; ky < KS; ++ky) {
+  for (int kk = 0; kk < KS * KS; ++kk) {
+    const int ky = kk / KS, kx = kk - ky * KS;
     // padding / tail handling by MULTIPLYING with a 0/1 mask: with a select the compiler sinks every load into its own
     // exec-masked branch followed by s_waitcnt vmcnt(0) -- one exposed memory latency per load (1.6 us per step)
-    int off[KS][4];
-    float okm[KS][4];
+    int off[4];
+    float okm[4];
 #pragma unroll
-    for (int kx = 0; kx < KS; ++kx)
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int yy = py[t] + ky - PAD, xx = px[t] + kx - PAD;
-        const bool ok = pv[t] && yy >= 0 && yy < H && xx >= 0 && xx < W;
-        okm[kx][t] = ok ? 1.f : 0.f;
-        off[kx][t] = ok ? yy * W + xx : 0;
-      }
-    const float* wrow = wt + (long)ky * KS * CinP * Cout;
-    // channel steps per tap and batch (KS x U steps of loads in flight); 16-wave workgroups have 128 registers per lane
-    constexpr int U = KS == 1 ? (MT == 1 ? 8 : 4) : (WV >= 16 ? (MT == 1 ? 2 : 1) : (MT == 1 ? 4 : 2));
+    for (int t = 0; t < 4; ++t) {
+      const int yy = py[t] + ky - PAD, xx = px[t] + kx - PAD;
+      const bool ok = pv[t] && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      okm[t] = ok ? 1.f : 0.f;
+      off[t] = ok ? yy * W + xx : 0;
+    }
+    const float* wk = wt + (long)kk * CinP * Cout;
+    // Round 4, measured and NOT adopted (1.04 ms per forward stays): (i) a whole kernel ROW of taps per load batch (12 steps in
+    // flight instead of 4): 0.95 ms, results equal to 4e-7 -- but a different summation order, enough to move the greedy sampler's
+    // picks on the seeded random weights (the two-frame initialisation of one bench sequence went from frame 3 to frame 51:
+    // nothing wrong, but no longer round 3's validated behaviour); (ii) double-buffered batches in THIS order (bit-identical
+    // results): 1.12 ms -- the per-batch tap / offset bookkeeping costs more than the overlap gains.
+    constexpr int U = 4;                                   // reduction steps whose loads are in flight together
     int ci0 = cbeg;
     for (; ci0 + 4 * U <= cend; ci0 += 4 * U) {
-      float a[KS][U][MT], b[KS][U][4];
+      float a[U][MT], b[U][4];
 #pragma unroll
-      for (int kx = 0; kx < KS; ++kx)
+      for (int u = 0; u < U; ++u) {
+        const int ci = ci0 + 4 * u + q;                    // ci < CinP: weight rows exist (zero rows beyond Cin)
+        const float* ip = inb + (long)min(ci, Cin - 1) * HW;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int ci = ci0 + 4 * u + q;                  // ci < CinP: weight rows exist (zero rows beyond Cin)
-          const float* ip = inb + (long)min(ci, Cin - 1) * HW;
-          const float* wk = wrow + (long)kx * CinP * Cout;
+        for (int mt = 0; mt < MT; ++mt) a[u][mt] = wk[(long)ci * Cout + wco[mt]];
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[kx][u][mt] = wk[(long)ci * Cout + wco[mt]];
-#pragma unroll
-          for (int t = 0; t < 4; ++t) b[kx][u][t] = ip[off[kx][t]];
-        }
-#pragma unroll
-      for (int kx = 0; kx < KS; ++kx)
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-              acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kx][u][mt] * wokm[mt], b[kx][u][t] * okm[kx][t], acc[mt][t], 0, 0, 0);
-    }
-    for (; ci0 < cend; ci0 += 4) {                         // channel tail: one step of every tap of the row
-      const int ci = ci0 + q;
-      const float* ip = inb + (long)min(ci, Cin - 1) * HW;
-      float a1[KS][MT], b1[KS][4];
-#pragma unroll
-      for (int kx = 0; kx < KS; ++kx) {
-        const float* wk = wrow + (long)kx * CinP * Cout;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a1[kx][mt] = wk[(long)ci * Cout + wco[mt]] * wokm[mt];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) b1[kx][t] = ip[off[kx][t]] * okm[kx][t];
+        for (int t = 0; t < 4; ++t) b[u][t] = ip[off[t]];
       }
 #pragma unroll
-      for (int kx = 0; kx < KS; ++kx)
+      for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kx][mt], b1[kx][t], acc[mt][t], 0, 0, 0);
+          for (int t = 0; t < 4; ++t)
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt] * wokm[mt], b[u][t] * okm[t], acc[mt][t], 0, 0, 0);
+    }
+    for (; ci0 < cend; ci0 += 4) {
+      const int ci = ci0 + q;
+      const float* ip = inb + (long)min(ci, Cin - 1) * HW;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float av = wk[(long)ci * Cout + wco[mt]] * wokm[mt];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ip[off[t]] * okm[t], acc[mt][t], 0, 0, 0);
+      }
     }
   }
   if constexpr (WV > 1) {

@@ -58,8 +58,11 @@ def gram_weighted(A, w, y, c=None, want_stats=False):
     return (AtA, Atb, stats) if want_stats else (AtA, Atb)
 
 
+_GRAM_KERNEL = __import__("os").environ.get("COMO_GRAM_KERNEL", "1") != "0"     # 0: gather + concatenate + slab GEMMs (A/B)
+
+
 def _fast(Kt):
-    return Kt.is_cuda and Kt.dtype == torch.float64 and Kt.shape[0] == 1 and Kt.shape[2] <= 64 and Kt.shape[2] % 4 == 0 and \
+    return _GRAM_KERNEL and Kt.is_cuda and Kt.dtype == torch.float64 and Kt.shape[0] == 1 and Kt.shape[2] <= 64 and Kt.shape[2] % 4 == 0 and \
         Kt.stride(2) == 1 and Kt.stride(1) % 2 == 0 and Kt.data_ptr() % 16 == 0
 
 

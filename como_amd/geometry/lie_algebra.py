@@ -13,7 +13,11 @@ functions the hot path calls.  Tangent ordering is COMO's: xi = [omega(0:3), v(3
   prior; the reference's V^-1 expression is reproduced as written, including its
   `(0.5 * t) * (w_norm x t)` elementwise term).
 """
+import os
+
 import torch
+
+_SE3_KERNEL = os.environ.get("COMO_SE3_KERNEL", "1") != "0"      # 0: invertSE3 as six torch launches (A/B)
 
 
 def skew_symmetric(p):
@@ -54,7 +58,7 @@ def batch_se3(poses, delta_T):
 
 
 def invertSE3(T):
-    if T.is_cuda and T.dtype in (torch.float32, torch.float64) and T.numel() > 0:
+    if _SE3_KERNEL and T.is_cuda and T.dtype in (torch.float32, torch.float64) and T.numel() > 0:
         # one launch (csrc/window.hip se3_inverse_kernel) instead of six tiny torch ops: this runs several times per frame
         from como_amd import _lib
         Tc = T.contiguous()

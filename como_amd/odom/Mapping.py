@@ -17,7 +17,11 @@ Deviations, documented: (1) no checkpoint loader -- `setup(model)` takes a `Dept
 B x H x W x m products per GN iteration only to keep this cache warm; the per-keyframe median of that image, which the
 priors and the landmark re-initialisation read, IS computed every iteration -- WindowBA's full-image median pass).
 """
+import os
+
 import torch
+
+_PIX_MIRRORS = os.environ.get("COMO_PIX_MIRRORS", "1") != "0"       # 0: every window rebuild converts the whole K~ / image window (A/B)
 
 from como_amd.depth_cov.core.covariance import prep_predictor as _prep_predictor
 from como_amd.depth_cov.core.DepthCovModule import DepthCovModule, run_model as _run_model
@@ -112,7 +116,7 @@ class Mapping:
 
     def _cat(self, name, new_var, i):
         old = getattr(self, name)
-        if name in self._PIX_MIRRORED and new_var.is_cuda and self.pix_dtype != new_var.dtype:
+        if _PIX_MIRRORS and name in self._PIX_MIRRORED and new_var.is_cuda and self.pix_dtype != new_var.dtype:
             pix = name + "_pix"
             if getattr(self, pix, None) is None or (old.numel() == 0 and old.dim() == 1):
                 setattr(self, pix, torch.empty((0), device=new_var.device, dtype=self.pix_dtype))
