@@ -197,7 +197,7 @@ def git_sha():
         return None
 
 
-def committed_traffic(kernel_substr, summaries=("r3_bench_pmc_summary.json", "r2_bench_pmc_summary.json")):
+def committed_traffic(kernel_substr, summaries=("r4_bench_pmc_summary.json", "r3_bench_pmc_summary.json", "r2_bench_pmc_summary.json")):
     """HBM bytes per launch of a kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled per the
     gfx950 note of guides/MI355X_MICROARCH.md, WRITE_SIZE as is).  NOT measured by this run: counters need rocprofv3
     around the process (scripts/collect_profiles.sh); the value is labelled with its source file."""
@@ -265,11 +265,11 @@ def block_kernel_roofline(wb, dtype_name, reps=5):
     pixel_pairs = wb.table.b * (0 if wb.idle else wb.n)          # wb.n = this rank's reference pixels per keyframe
     bytes_per = ALGO_SCALARS_PER_PIXEL_PAIR * (4 if dtype_name == "f32" else 8)
     achieved = pixel_pairs * bytes_per / (blk_ms * 1e-3) / 1e9 if blk_ms > 0 else 0.0
-    kname = "ba_blocks_pair2_kernel<2,4>" if dtype_name == "f32" else "ba_blocks_pair2_f64_kernel<4,true,1>"
+    kname = "ba_blocks_pair2_kernel<2,4>" if dtype_name == "f32" else "ba_blocks_pair2_f64_kernel<4,true,1,false>"
     traffic, src = committed_traffic("ba_blocks_pair2_kernel" if dtype_name == "f32" else "ba_blocks_pair2_f64")
     # the same launch priced on the matrix pipe: 320 v_mfma_*_16x16x4 (2048 flop each) per 64-pixel tile of a reference-keyframe
     # group (two pairs share the 10 depth x depth tiles); data-sheet dense peaks of guides/MI355X_MICROARCH.md, and -- float64 --
-    # the rate scripts/micro/mfma_f64_rate.hip sustained on this part with every CU busy (profiles/r3_mfma_f64_rate.txt)
+    # the bare-stream rate of scripts/micro/mfma_f64_rate.hip with every CU busy (profiles/r4_mfma_f64_rate.txt)
     ngrp = int(getattr(wb.table, "ngroups", 0) or 0)
     tiles = 0 if wb.idle else (wb.n + 63) // 64
     flops = ngrp * tiles * 320 * 2048.0
@@ -281,13 +281,17 @@ def block_kernel_roofline(wb, dtype_name, reps=5):
            "algorithmic_bytes_per_pixel_pair": bytes_per,
            "mfma_flop_per_launch": flops, "mfma_tflops": tf, "mfma_peak_tflops": peak_tf, "mfma_frac": tf / peak_tf}
     if dtype_name == "f64":
+        # what a BARE back-to-back stream of the same instruction sustains with every CU busy (scripts/micro/mfma_f64_rate.hip, two
+        # waves per SIMD; sclk logged at 2.39 GHz).  Not a ceiling of this kernel: interleaved with its vector work the stream runs
+        # at the nominal 64 cycles per instruction and the bound is matrix + vector issue on one pipe
         try:
-            for ln in open(os.path.join(ROOT, "profiles", "r3_mfma_f64_rate.txt")):
+            for ln in open(os.path.join(ROOT, "profiles", "r4_mfma_f64_rate.txt")):
                 if ln.startswith("f64 mfma 16x16x4 only") and "blocks= 512" in ln:
                     sus = float(ln.split("MFMA")[1].split("TFLOP/s")[0])
-                    out["mfma_sustained_probe_tflops"] = sus
-                    out["mfma_frac_of_sustained"] = tf / sus
-                    out["mfma_probe_source"] = "committed_profile:profiles/r3_mfma_f64_rate.txt (scripts/micro/mfma_f64_rate.hip, two waves per SIMD)"
+                    out["mfma_bare_stream_probe_tflops"] = sus
+                    out["mfma_frac_of_bare_stream"] = tf / sus
+                    out["mfma_probe_source"] = "committed_profile:profiles/r4_mfma_f64_rate.txt (scripts/micro/mfma_f64_rate.hip, two waves per SIMD)"
+                    break
         except Exception:                                   # noqa: BLE001
             pass
     return out
@@ -363,11 +367,11 @@ def tracking_leg(device, steps=200):
         # iterations of the same 640x480 level; FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is)
         tr_iter, tr_src = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r3_track_pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r4_track_pmc_summary.json")))
             key = [k for k in pm if "track_level_kernel" in k][0]
             per_launch = (2.0 * pm[key]["FETCH_SIZE"]["avg_per_launch"] + pm[key]["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
             tr_iter = per_launch / float(pm["_meta"]["track_iterations_per_launch"])
-            tr_src = "committed_profile:profiles/r3_track_pmc_summary.json:" + key[:40]
+            tr_src = "committed_profile:profiles/r4_track_pmc_summary.json:" + key[:40]
         except Exception:                                   # noqa: BLE001
             pass
         # the coarser pyramid levels of the same frame size (one persistent launch each; a tracked frame runs all three)
