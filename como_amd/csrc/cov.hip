@@ -312,14 +312,27 @@ __global__ __launch_bounds__(256) void greedy_append_kernel(const float* __restr
     float sum = 0.f;
     if (lane < N) sum = cov_value_f32(sx[2 * lane], sx[2 * lane + 1], sE + 4 * lane, sx[2 * N], sx[2 * N + 1], sE + 4 * N, scale);
     float sumsq = 0.f;
-    for (int i = 0; i < N; ++i) {
-      float li = 0.f;
-      if (lane == i) li = sum / sL[i * 65 + i];
-      li = __shfl(li, i, 64);
-      sumsq += li * li;
-      if (lane == i) lrow[i] = li;
-      if (lane > i && lane < N) sum -= sL[lane * 65 + i] * li;
+    // Row `lane` of L in registers, the step's value broadcast through a scalar register: the dependent chain of a step is
+    // division -> readlane -> multiply-add (~0.05 us).  The first version read the row element and the diagonal from LDS inside the
+    // step and broadcast through ds_bpermute: two LDS round trips, an LDS crossbar trip and three divergent branches per step,
+    // 0.4 us each -- 25 us of a 30 us launch at N = 60, in every one of the 64 launches of a sampling pass.  Same operations on the
+    // same operands (lane i's quotient is sum_i / L_ii; the other lanes' quotients are discarded).
+    float Lr[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) Lr[i] = sL[lane * 65 + i];
+    const float diag = sL[lane * 65 + lane];
+    float mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      if (i < N) {
+        const float q = sum / diag;
+        const float li = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q), i));
+        sumsq += li * li;
+        if (lane == i) mine = li;
+        if (lane > i && lane < N) sum -= Lr[i] * li;
+      }
     }
+    if (lane < N) lrow[lane] = mine;
     if (lane == 0) lrow[N] = sqrtf(k_ii - sumsq);
   }
   __syncthreads();

@@ -61,9 +61,15 @@ def gram_weighted(A, w, y, c=None, want_stats=False):
 _GRAM_KERNEL = __import__("os").environ.get("COMO_GRAM_KERNEL", "1") != "0"     # 0: gather + concatenate + slab GEMMs (A/B)
 
 
+def padded_predictor(Kt):
+    """The (B,n,mp) buffer behind a `get_predictor(pad4=True)` result (the tensor itself when no padding was needed)."""
+    return getattr(Kt, "_como_padded", Kt)
+
+
 def _fast(Kt):
-    return _GRAM_KERNEL and Kt.is_cuda and Kt.dtype == torch.float64 and Kt.shape[0] == 1 and Kt.shape[2] <= 64 and Kt.shape[2] % 4 == 0 and \
-        Kt.stride(2) == 1 and Kt.stride(1) % 2 == 0 and Kt.data_ptr() % 16 == 0
+    Kt = padded_predictor(Kt)
+    return _GRAM_KERNEL and Kt.is_cuda and Kt.dtype == torch.float64 and Kt.shape[0] == 1 and 0 < Kt.shape[2] <= 64 and \
+        Kt.shape[2] % 4 == 0 and Kt.stride(2) == 1 and Kt.stride(1) % 2 == 0 and Kt.data_ptr() % 16 == 0
 
 
 def lstsq_chol(A, b):
@@ -82,11 +88,20 @@ def calc_kernel_matrices(coords_m, coords_n, cov_params_img, model):
     return (model.cov_modules[-1](cm, Em), model.cross_cov_modules[-1](cn, En, cm, Em), model.diagonal_cov_modules[-1](cn, En))
 
 
-def get_predictor(K_mm, K_nm, K_nn_diag):
-    """:30-48 -> Knm_Kmminv (B,n,m), L_mm, 1/stdev of the conditional variance (B,n,1)."""
+def get_predictor(K_mm, K_nm, K_nn_diag, pad4=False):
+    """:30-48 -> Knm_Kmminv (B,n,m), L_mm, 1/stdev of the conditional variance (B,n,1).
+    pad4: Knm_Kmminv is returned as the leading m columns of a (B,n,mp) buffer, mp = m rounded up to a multiple of 4, whose other
+    columns are exactly zero (K_mm^-1 padded with zero columns before the product) -- 16-byte aligned rows for `gram_weighted`
+    whatever the number of tracked points; `padded_predictor(Kt)` recovers the buffer."""
     f = chol_small(K_mm, want_L=True, want_inv=True)          # csrc/smallsolve.hip: L_mm and K_mm^-1 in one launch
     L_mm = f["L"]
-    Kt = K_nm @ f["inv"]
+    m = K_mm.shape[-1]
+    if pad4 and m % 4:
+        full = K_nm @ torch.nn.functional.pad(f["inv"], (0, 4 - m % 4))
+        Kt = full[:, :, :m]
+        Kt._como_padded = full
+    else:
+        Kt = K_nm @ f["inv"]
     var_n = K_nn_diag - torch.sum(K_nm * Kt, dim=2)
     var_n = var_n + (torch.min(var_n) + 1e-8)
     return Kt, L_mm, 1.0 / torch.sqrt(var_n.unsqueeze(-1))
@@ -109,7 +124,7 @@ def distill_depth(Knm_Kmminv, z_obs, with_prior, L_mm=None, stdev_inv_obs=None):
 def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model, distill_with_prior, min_depth, stdev_obs=None):
     """:88-118"""
     assert coords_m.shape[0] == 1
-    Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model))
+    Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL)
     if stdev_obs is not None:
         sinv = (1.0 / stdev_obs) * torch.ones_like(sinv)
     if _fast(Kt):
@@ -118,13 +133,14 @@ def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model,
         okm = z_obs[:, :, 0:1] > min_depth
         y = torch.log(torch.where(okm, z_obs[:, :, 0:1], torch.ones_like(z_obs[:, :, 0:1])))
         m = Kt.shape[2]
+        wgt = okm * (sinv * sinv) if distill_with_prior else okm.to(Kt.dtype)
+        AtA, Atb = gram_weighted(padded_predictor(Kt), wgt, y)
+        if AtA.shape[1] != m:                                 # (zero-padded columns: their rows / columns of the products are zero)
+            AtA, Atb = AtA[:, :m, :m].contiguous(), Atb[:, :m].contiguous()
         if distill_with_prior:
-            AtA, Atb = gram_weighted(Kt, okm * (sinv * sinv), y)
             eye = torch.eye(m, device=Kt.device, dtype=Kt.dtype).reshape(1, m, m)
             Lm1 = trsm_lower(L_mm, eye)                       # the prior rows L_mm^-1 (distill_depth.py:60-63)
             AtA = AtA + Lm1.mT @ Lm1
-        else:
-            AtA, Atb = gram_weighted(Kt, okm.to(Kt.dtype), y)
         logz_m = chol_small(AtA, want_L=False, rhs=Atb)["X"]
         ok = torch.nonzero(okm[0, :, 0])[:, 0]
         return logz_m, (Kt @ logz_m - y).index_select(1, ok)
@@ -151,7 +167,7 @@ def distill_conditional_depth_with_scale_prior(Knm_Kmminv, z_obs, z1, stdev_inv_
 def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_img, z_obs, model, min_depth, stdev_obs):
     """:152-175"""
     assert coords_m.shape[0] == 1
-    Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model))
+    Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL)
     sinv = (1.0 / stdev_obs) * torch.ones_like(sinv)
     m, m1 = Kt.shape[2], z_m1.shape[1]
     if _fast(Kt):
@@ -162,11 +178,12 @@ def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_
         zs = torch.where(okm, z_obs[:, :, 0:1], torch.ones_like(z_obs[:, :, 0:1]))
         s_med = torch.log(masked_median(zs[0, :, 0], okm[0, :, 0]))
         sp2 = (1.0 / 5e-2) ** 2
-        c = torch.cat((torch.log(z_m1).reshape(1, m1, 1), torch.zeros((1, m - m1, 1), device=Kt.device, dtype=Kt.dtype)), dim=1)
-        AtA, Atb = gram_weighted(Kt, okm * (sinv * sinv), torch.log(zs), c=c)
+        Kp = padded_predictor(Kt)
+        c = torch.cat((torch.log(z_m1).reshape(1, m1, 1), torch.zeros((1, Kp.shape[2] - m1, 1), device=Kt.device, dtype=Kt.dtype)), dim=1)
+        AtA, Atb = gram_weighted(Kp, okm * (sinv * sinv), torch.log(zs), c=c)
         m2 = m - m1
-        A22 = AtA[:, m1:, m1:] + sp2 * torch.eye(m2, device=Kt.device, dtype=Kt.dtype)
-        b2 = Atb[:, m1:] + sp2 * s_med
+        A22 = AtA[:, m1:m, m1:m] + sp2 * torch.eye(m2, device=Kt.device, dtype=Kt.dtype)
+        b2 = Atb[:, m1:m] + sp2 * s_med
         return chol_small(A22.contiguous(), want_L=False, rhs=b2.contiguous())["X"]
     ok = torch.nonzero(z_obs[0, :, 0] > min_depth)[:, 0]
     return distill_conditional_depth_with_scale_prior(Kt.index_select(1, ok), z_obs.index_select(1, ok), z_m1,

@@ -42,7 +42,14 @@ _DTYPES = {"float": torch.float32, "double": torch.float64}
 
 def normalizeSE3_inplace(T):
     """Project the rotation block onto SO(3) (reference geometry/lie_algebra.py:98-101)."""
-    U, _, Vh = torch.linalg.svd(T[..., :3, :3])
+    R = T[..., :3, :3]
+    if R.is_cuda:
+        # one 3x3 per keyframe: the device SVD (a dozen solver launches and its own synchronisations, ~1 ms) on 72 bytes --
+        # LAPACK on the host, as the torch-CPU reference does it
+        U, _, Vh = torch.linalg.svd(R.cpu())
+        T[..., :3, :3] = (U @ Vh).to(R.device)
+        return
+    U, _, Vh = torch.linalg.svd(R)
     T[..., :3, :3] = U @ Vh
 
 
@@ -122,31 +129,46 @@ class Mapping:
                 setattr(self, pix, torch.empty((0), device=new_var.device, dtype=self.pix_dtype))
             self._cat(pix, new_var.to(self.pix_dtype), i)
         if name.startswith("Knm_Kmminv") and new_var.is_cuda:
-            return self._cat_pingpong(name, old, new_var, i)
+            return self._cat_sliding(name, old, new_var, i)
         setattr(self, name, new_var.clone() if old.numel() == 0 and old.dim() == 1 else torch.cat((old[i:, ...], new_var), dim=0))
 
-    def _cat_pingpong(self, name, old, new_var, i):
+    def _cat_sliding(self, name, old, new_var, i):
         """The dense predictors K~ are 157 MB per keyframe at 640x480 (float64): `torch.cat` of a growing window asks the allocator
-        for a new, larger block on every keyframe (a hipMalloc of > 1 GB: ~12 ms each while the window fills).  Two buffers of
-        the window's full capacity, allocated once, alternate instead; the window is a view of the current one."""
+        for a new, larger block on every keyframe (a hipMalloc of > 1 GB: ~12 ms each while the window fills), and copying the kept
+        keyframes into a second buffer moved 1.3 GB (+ the pixel-type mirror) per keyframe (0.55 ms).  ONE buffer of twice the
+        window's capacity instead: the window is a view [start, start + count) that slides -- the kept keyframes stay where they
+        are, the new one is written behind them -- and is moved back to the front when it reaches the end (once per
+        `num_keyframes` insertions)."""
         cap = self.cfg["graph"]["num_keyframes"]
         store = self.__dict__.setdefault("_kt_pp", {})              # per window tensor (K~ and its pixel-type mirror)
-        pp, cur = store.get(name, (None, 0))
-        if pp is None or pp[0].shape[1:] != new_var.shape[1:] or pp[0].dtype != new_var.dtype or pp[0].shape[0] != cap:
-            pp = [torch.empty((cap,) + tuple(new_var.shape[1:]), dtype=new_var.dtype, device=new_var.device) for _ in range(2)]
-            cur = 0
+        st = store.get(name)
+        n_new = new_var.shape[0]
+        if (st is None or st["buf"].shape[1:] != new_var.shape[1:] or st["buf"].dtype != new_var.dtype or st["buf"].shape[0] != 2 * cap or
+                st["buf"].device != new_var.device):
+            st = store[name] = {"buf": torch.empty((2 * cap,) + tuple(new_var.shape[1:]), dtype=new_var.dtype, device=new_var.device),
+                                "start": 0, "count": 0}
+        buf = st["buf"]
         empty = old.numel() == 0 and old.dim() == 1
         keep = old[0:0] if empty else old[i:, ...]
         k = keep.shape[0]
-        if k + new_var.shape[0] > cap:
+        if k + n_new > cap:
             raise RuntimeError("como_amd Mapping: more keyframes than graph.num_keyframes")
-        cur ^= 1
-        store[name] = (pp, cur)
-        dst = pp[cur]
-        if k:
-            dst[:k].copy_(keep)
-        dst[k:k + new_var.shape[0]].copy_(new_var)
-        setattr(self, name, dst[:k + new_var.shape[0]])
+        in_place = (not empty and old.shape[0] == st["count"] and old.stride() == buf.stride() and
+                    old.data_ptr() == buf[st["start"]].data_ptr())
+        if in_place:
+            s0 = st["start"] + st["count"] - k                      # the kept keyframes stay where they are
+            if s0 + k + n_new > 2 * cap:                            # (then s0 > cap >= k: source and destination are disjoint)
+                if k:
+                    buf[:k].copy_(buf[s0:s0 + k])
+                s0 = 0
+        else:                                                       # a window tensor that is not the view handed out last time
+            s0 = 0
+            if k:
+                same = keep.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr()
+                buf[:k].copy_(keep.clone() if same else keep)
+        buf[s0 + k:s0 + k + n_new].copy_(new_var)
+        st["start"], st["count"] = s0, k + n_new
+        setattr(self, name, buf[s0:s0 + k + n_new])
 
     def window_cat_helper_list(self, var, new_var, i):
         del var[:i]
@@ -238,10 +260,14 @@ class Mapping:
                 swap_coords_xy(self.pm).clone(), self.P_m.clone(), self.obs_ref_mask.clone(), self.recent_poses.clone(),
                 list(getattr(self, "kf_pairs", [])), list(getattr(self, "one_way_pairs", [])))
 
-    def store_vars(self, pm, logzm, Knm_Kmminv):
-        """Mapping.py:749-758"""
+    def store_vars(self, pm, logzm, Knm_Kmminv, kept_depths=None):
+        """Mapping.py:749-758.  kept_depths: depth images of keyframes 0..B-2 that are known to be current (add_keyframe: the
+        log-depths of the keyframes that stay are untouched by the insertion) -- only the new keyframe's image is evaluated."""
         self.pm, self.logzm = pm, logzm
         self._depth_cache = None
+        B = self.logzm.shape[0]
+        if kept_depths is not None and B > 1 and kept_depths.shape[0] == B - 1:
+            self._depth_cache = torch.cat((kept_depths, self.depth_imgs_of(B - 1, B)), dim=0)
         d = self.depth_imgs
         d2 = d.reshape(d.shape[0], -1)
         # per-keyframe exact median of the full depth image: one segmented device select instead of B sorts
@@ -274,6 +300,9 @@ class Mapping:
             self.kf_poses[-1:, ...], kf_pose_init, coords_m_last, zm_last, self.depth_imgs_of(self.kf_poses.shape[0] - 1,
                                                                                              self.kf_poses.shape[0]), cov_params_img,
             self.intrinsics, self.model, self.cfg["corr"], self.cfg["sampling"], self.kf_img_and_grads.shape[-2:])
+        # depth images of the current window, if a snapshot just evaluated them (handle_tracking_data): still valid for the keyframes
+        # that stay -- the insertion below does not touch their log-depths
+        kept_depths = self._depth_cache[self.get_kf_start_window_ind():] if self._depth_cache is not None else None
         p_m_new = swap_coords_xy(coords_m_new).to(dtype=z_m_new.dtype)
         Pc_new, _ = backprojection(self.intrinsics[0], p_m_new, z_m_new)
         Pw_new, _, _ = transform_points(kf_pose_init, Pc_new)
@@ -285,7 +314,7 @@ class Mapping:
         self.initialize_sparse_pixel_vars(pm_first_obs, zm_first_obs, coords_m_new.shape[1], Kmm_inv, L_mm, Knm_Kmminv)
         self.initialize_sparse_landmark_vars(corr_mask, Pw_new.squeeze(0))
         self.reset_iteration_vars(new_kf=True)
-        self.store_vars(self.pm, self.logzm, self.Knm_Kmminv)
+        self.store_vars(self.pm, self.logzm, self.Knm_Kmminv, kept_depths=kept_depths)
         self.prune_one_way()
 
     def prune_one_way(self):
@@ -433,20 +462,19 @@ class Mapping:
             self._ba_prev = None
         ba = self._ba
         ba.step()
-        # refresh the public state from the solver's buffers
-        self.kf_poses = ba.kf_poses.to(self.dtype).clone()
-        self.kf_aff_params = ba.kf_aff_params.to(self.dtype).clone()
-        if ba.F > ba.B:
-            self.recent_poses = ba.recent_poses.to(self.dtype).clone()
-            self.recent_aff_params = ba.recent_aff_params.to(self.dtype).clone()
-        self.P_m = ba.P_m.to(self.dtype).clone()
+        # refresh the public state from the solver's buffers (two copies: snapshot_state)
+        sn = ba.snapshot_state(self.dtype)
+        B = ba.B
+        self.kf_poses, self.kf_aff_params = sn["poses"][:B], sn["aff"][:B].view(B, 2, 1)
+        if ba.F > B:
+            self.recent_poses, self.recent_aff_params = sn["poses"][B:], sn["aff"][B:].view(ba.F - B, 2, 1)
+        self.P_m = sn["P_m"]
         self.kf_pairs, self.one_way_pairs = ba.kf_pairs, ba.one_way_pairs
-        if ba.fused:
-            pm, logzm = ba.w["pm"], ba.w["logzm"].unsqueeze(-1)
+        if "pm" in sn:
+            self.pm, self.logzm = sn["pm"], sn["logzm"].unsqueeze(-1)
         else:
-            pm, logzm = ba.pm, ba.logzm
-        self.pm, self.logzm = pm.to(self.dtype).clone(), logzm.to(self.dtype).clone()
+            self.pm, self.logzm = ba.pm.to(self.dtype).clone(), ba.logzm.to(self.dtype).clone()
         self._depth_cache = None
-        self.median_depths = ba.median_depths.to(self.dtype).clone()
+        self.median_depths = sn["median"]
         self.iter += 1
         return self.converged

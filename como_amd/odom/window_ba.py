@@ -40,6 +40,7 @@ DEFAULT_CFG = {
 
 
 _REUSE_TOPOLOGY = __import__("os").environ.get("COMO_BA_REUSE", "1") != "0"      # (measurement switch)
+_REUSE_WORKSPACES = __import__("os").environ.get("COMO_BA_REUSE_WS", "1") != "0"  # (measurement switch)
 
 
 class WindowBA:
@@ -72,9 +73,18 @@ class WindowBA:
         nrec = int(rec_poses.shape[0]) if rec_poses is not None else 0      # one-way frames (Mapping.add_one_way_frame)
         self.F = B + nrec
         self.intrinsics = f64(state["intrinsics"])
-        # all frame poses / affine params in ONE buffer each (keyframes first): the views below alias it
-        self.poses_all = torch.zeros((self.F, 4, 4), device=dev, dtype=self.dt)
-        self.aff_all = torch.zeros((self.F, 2), device=dev, dtype=self.dt)
+        # the state the iteration updates -- all frame poses | affine params (keyframes first) | landmarks | median depths -- in
+        # ONE buffer (the views below alias it): the sequential loop publishes it after every iteration with one copy
+        # (`snapshot_state`) instead of one per tensor
+        F_, nP = self.F, int(state["P_m"].shape[0])
+        ev = lambda n: (n + 1) // 2 * 2                       # 16-byte steps
+        o_aff, o_P = 16 * F_, 16 * F_ + ev(2 * F_)
+        o_med = o_P + ev(3 * nP)
+        self.state_flat = torch.zeros((o_med + ev(B),), device=dev, dtype=self.dt)
+        self._state_layout = (("poses", 0, (F_, 4, 4)), ("aff", o_aff, (F_, 2)), ("P_m", o_P, (nP, 3)), ("median", o_med, (B,)))
+        carve1 = lambda flat, off, shp: flat[off:off + int(torch.Size(shp).numel())].view(shp)
+        self.poses_all = carve1(self.state_flat, 0, (F_, 4, 4))
+        self.aff_all = carve1(self.state_flat, o_aff, (F_, 2))
         self.poses_all[:B] = f64(state["kf_poses"])
         self.aff_all[:B] = f64(state["kf_aff_params"]).reshape(B, 2)
         self.kf_poses = self.poses_all[:B]
@@ -87,7 +97,8 @@ class WindowBA:
             self.recent_timestamps = state["recent_timestamps"]
         else:
             self.recent_timestamps = torch.empty((0,), device=dev, dtype=self.dt)
-        self.P_m = f64(state["P_m"])
+        self.P_m = carve1(self.state_flat, o_P, (nP, 3))
+        self.P_m.copy_(state["P_m"])
         self.correspondence_mask = state["correspondence_mask"]
         self.obs_ref_mask = state["obs_ref_mask"].contiguous()
         self.pm_first_obs = f64(state["pm_first_obs"])
@@ -106,8 +117,11 @@ class WindowBA:
         self.img = imgs.to(pix_dtype).contiguous()
         self.Kt = pix("Knm_Kmminv").to(pix_dtype).reshape(B, self.Himg * self.Wimg, self.m).contiguous()
         self.K_pix = self.intrinsics[0].to(pix_dtype).contiguous()
-        self.median_depths = (f64(state["median_depth_init"]) if "median_depth_init" in state
-                              else torch.full((B,), 1.0, device=dev, dtype=self.dt))
+        self.median_depths = carve1(self.state_flat, o_med, (B,))
+        if "median_depth_init" in state:
+            self.median_depths.copy_(state["median_depth_init"])
+        else:
+            self.median_depths.fill_(1.0)
         self.window_full = window_full
         self.pose_anchor = f64(state["pose_anchor"]) if "pose_anchor" in state else self.kf_poses[0:1].clone()
         self.aff_anchor = torch.zeros((1, 2, 1), device=dev, dtype=self.dt)
@@ -150,7 +164,9 @@ class WindowBA:
             for a in self._KF_SET_ATTRS:
                 setattr(self, a, getattr(prev, a))
             self.idle = False
+            self._inherit = prev                             # (its scratch workspaces too: _prepare_fused)
             self._finish_topology()
+            self._inherit = None
             return
         w = self.cfg["photo_construction"]["nonmax_suppression_window"]
         coords_n, _ = smap.subselect_pixels(self.img[:B], w)                   # Mapping.py:665-668
@@ -256,12 +272,16 @@ class WindowBA:
             out, o = {}, 0
             for k, shp, n in sizes:
                 out[k] = buf[o:o + int(torch.Size(shp).numel())].view(shp)
+                out["_off_" + k] = o
                 o += n
+            out["_buf"] = buf
             return out
         self.w = carve((("pm", (B, m, 2)), ("logzm", (B, m)), ("invz", (B, m)), ("dzdP", (B, 3)), ("dlogz_dT", (B, m, 6)),
                         ("dlogz_dP", (B, m, 3)), ("dp_dP", (B, m, 6)), ("dp_dT", (B, m, 12)), ("init_Pm", (L, 3))), self.dt)
+        self._w_head = (self.w["_buf"], self.w["_off_logzm"])           # [pm | logzm | ...]: what snapshot_state copies
         self.w.update(carve((("px_logzm", (B, m)), ("px_invz", (B, m)), ("px_dzdP", (B, 3)), ("px_dlogz_dT", (B, m, 6)),
                              ("px_poses", (F, 4, 4)), ("px_aff", (F, 2)), ("med3", (B, 3)), ("med3_full", (B, 3))), p))
+        self.w = {k: v for k, v in self.w.items() if not k.startswith("_")}
         self.w["reinit_flag"] = torch.zeros(L, device=dev, dtype=torch.int32)
         # The reference keeps TWO medians per keyframe: the one of the sub-selected reference pixels (setup_test_points,
         # sparse_map.py:220 -- only the pair graph reads it) and `self.median_depths` = the median of the FULL depth image
@@ -317,7 +337,40 @@ class WindowBA:
         self.w["chol_ws"] = {}                             # Cholesky workspace + delta
         self.with_priors = True                            # tests: False leaves H = the photometric system alone
         self.overlap_priors = True
-        self._side_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
+        inh = getattr(self, "_inherit", None)
+        if (inh is not None and _REUSE_WORKSPACES and getattr(inh, "graph", None) is None and isinstance(getattr(inh, "w", None), dict)
+                and "dr_ws" in inh.w and inh.Kt.data_ptr() == self.Kt.data_ptr() and inh.Kt.shape == self.Kt.shape):
+            # Same keyframe set (the sequential loop's rebuild on a one-way frame): the retired window's scratch -- planes keyed by
+            # (B, n), grow-only buffers of the block chain, Cholesky workspaces keyed by the system size -- is taken over instead of
+            # being allocated and zero-filled again in the first iteration; so is the state of the band median (it only depends on
+            # K~ and the log-depths): the previous medians move into this window's buffer.
+            self.w["dr_ws"], self.w["ba_ws"], self.w["chol_ws"] = inh.w["dr_ws"], inh.w["ba_ws"], inh.w["chol_ws"]
+            for e in self.w["dr_ws"].values():
+                st = e.get("band") if isinstance(e, dict) else None
+                if st is not None:
+                    if st["med"] == inh.w["med3_full"].data_ptr() and inh.w["med3_full"].shape == self.w["med3_full"].shape:
+                        self.w["med3_full"].copy_(inh.w["med3_full"])
+                        st["med"] = self.w["med3_full"].data_ptr()
+                    else:
+                        e.pop("band")
+            self._side_stream = inh._side_stream
+        else:
+            self._side_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
+
+    def snapshot_state(self, dtype=None):
+        """Copies of the iteration's state for the caller (Mapping.iterate): {"poses" (F,4,4), "aff" (F,2), "P_m" (L,3), "median" (B,),
+        and on the fused chain "pm" (B,m,2), "logzm" (B,m)} -- views of TWO copied buffers (the state buffer and the head of the
+        scaffold's output buffer) instead of seven separate clones."""
+        dtype = dtype or self.dt
+        snap = self.state_flat.to(dtype, copy=True)
+        out = {k: snap[o:o + int(torch.Size(shp).numel())].view(shp) for k, o, shp in self._state_layout}
+        if self.fused and getattr(self, "_w_head", None) is not None:
+            buf, o_lz = self._w_head
+            B, m = self.B, self.m
+            head = buf[:o_lz + B * m].to(dtype, copy=True)
+            out["pm"] = head[:2 * B * m].view(B, m, 2)
+            out["logzm"] = head[o_lz:o_lz + B * m].view(B, m)
+        return out
 
     # ---- fused HIP chain -----------------------------------------------------------------------------------------
     def linearize_fused(self):

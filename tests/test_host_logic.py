@@ -2,6 +2,7 @@
 drop-in registration -- against the golden vectors captured from the reference."""
 import sys
 
+import pytest
 import torch
 
 from tests.conftest import load_golden
@@ -153,6 +154,36 @@ def test_mapping_window_bookkeeping_vs_reference_snapshots():
     mp.recent_img_and_grads = torch.zeros((4, 3, 2, 2), dtype=torch.float64)
     mp.prune_one_way()
     assert mp.recent_timestamps == [5.5, 6.5] and mp.recent_poses[:, 0, 0].tolist() == [2.0, 3.0]
+
+
+def test_sliding_predictor_window_equals_cat():
+    """Mapping._cat_sliding (the K~ window as a sliding view of one buffer of twice the window's capacity): after every insertion the
+    window equals what `torch.cat((old[i:], new))` gives, the kept keyframes are not moved except when the view wraps, and a
+    window tensor that is not the view handed out last time (a caller replaced the attribute) is taken over by value."""
+    N = 4
+    mp = _cpu_mapping(N)
+    g = torch.Generator().manual_seed(3)
+    ref = torch.empty((0), dtype=torch.float64)
+    mp.Knm_Kmminv = torch.empty((0), dtype=torch.float64)
+    i = mp.get_kf_start_window_ind()
+    moves = 0
+    for k in range(23):
+        new = torch.randn((1, 5, 6, 3), generator=g, dtype=torch.float64)
+        ref = new.clone() if ref.dim() == 1 else torch.cat((ref[i:], new), dim=0)
+        old_ptr = mp.Knm_Kmminv[i:].data_ptr() if mp.Knm_Kmminv.dim() > 1 else None
+        if k == 11:                                   # a caller swaps in its own tensor: taken over by value
+            mp.Knm_Kmminv = mp.Knm_Kmminv.clone()
+            old_ptr = None
+        mp._cat_sliding("Knm_Kmminv", mp.Knm_Kmminv, new, i)
+        assert torch.equal(mp.Knm_Kmminv, ref), k
+        assert mp.Knm_Kmminv.shape[0] == min(k + 1, N)
+        if old_ptr is not None and mp.Knm_Kmminv.data_ptr() != old_ptr:
+            moves += 1
+    buf = mp._kt_pp["Knm_Kmminv"]["buf"]
+    assert buf.shape[0] == 2 * N
+    assert moves <= 23 // N + 1, moves                # the kept keyframes move only when the view reaches the end of the buffer
+    with pytest.raises(RuntimeError):
+        mp._cat_sliding("Knm_Kmminv", mp.Knm_Kmminv, torch.zeros((2, 5, 6, 3), dtype=torch.float64), -N)
 
 
 def test_fill_image_last_point_wins_like_torch_cpu():
