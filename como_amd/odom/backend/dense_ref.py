@@ -134,10 +134,18 @@ def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=Non
         # the band bound is only valid for the K~ it was built from: a reused workspace with another predictor (a recycled
         # ping-pong buffer, another row range) rebuilds the state instead of returning medians of stale row norms
         ident = (Kt.data_ptr(), Kt.stride(0), B, rows, m)
-        if st is not None and st.get("ident") != ident:
-            st = None
         init = st is None
-        if init:
+        if st is not None and st.get("ident") != ident:
+            if st["lref"].shape == (B, rows) and st["lref"].dtype == dt and st["prev"].shape == (B, m) and st["med"] == med_out.data_ptr():
+                # same shapes: the state is rebuilt IN the planes it has (the init pass overwrites every row of them; only the
+                # running maximum of the row norms starts from zero)
+                st["l1max"].zero_()
+                st["ncand"].zero_()
+                st["calls"], st["ident"] = 0, ident
+                init = True
+            else:
+                st, init = None, True
+        if st is None:
             st = w["band"] = {"lref": torch.zeros((B, rows), device=dev, dtype=dt), "err": torch.zeros((B, rows), device=dev, dtype=dt),
                               "l1": torch.zeros((B, rows), device=dev, dtype=dt), "l1max": torch.zeros(B, device=dev, dtype=torch.float32),
                               "prev": torch.zeros((B, m), device=dev, dtype=dt), "ncand": torch.zeros(B, device=dev, dtype=torch.int32),

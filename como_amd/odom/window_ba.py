@@ -168,6 +168,9 @@ class WindowBA:
             self._finish_topology()
             self._inherit = None
             return
+        if (prev is not None and _REUSE_TOPOLOGY and prev.shard is None and self.shard is None and prev.dev == self.dev and
+                prev.pix_dtype == self.pix_dtype):
+            self._inherit = prev                             # another keyframe set: only its scratch workspaces (_prepare_fused)
         w = self.cfg["photo_construction"]["nonmax_suppression_window"]
         coords_n, _ = smap.subselect_pixels(self.img[:B], w)                   # Mapping.py:665-668
         self.coords_n = coords_n
@@ -208,6 +211,7 @@ class WindowBA:
         self.first_frame = first_obs.to(torch.int32).contiguous()
         self.first_slot = slot_of[first_obs, torch.arange(L, device=dev)].contiguous()
         self._finish_topology()
+        self._inherit = None
 
     # ---- ... and what also depends on the number of one-way frames --------------------------------------------------------
     def _finish_topology(self):
@@ -339,20 +343,26 @@ class WindowBA:
         self.overlap_priors = True
         inh = getattr(self, "_inherit", None)
         if (inh is not None and _REUSE_WORKSPACES and getattr(inh, "graph", None) is None and isinstance(getattr(inh, "w", None), dict)
-                and "dr_ws" in inh.w and inh.Kt.data_ptr() == self.Kt.data_ptr() and inh.Kt.shape == self.Kt.shape):
-            # Same keyframe set (the sequential loop's rebuild on a one-way frame): the retired window's scratch -- planes keyed by
-            # (B, n), grow-only buffers of the block chain, Cholesky workspaces keyed by the system size -- is taken over instead of
-            # being allocated and zero-filled again in the first iteration; so is the state of the band median (it only depends on
-            # K~ and the log-depths): the previous medians move into this window's buffer.
-            self.w["dr_ws"], self.w["ba_ws"], self.w["chol_ws"] = inh.w["dr_ws"], inh.w["ba_ws"], inh.w["chol_ws"]
+                and "dr_ws" in inh.w):
+            # The retired window's scratch -- planes keyed by (B, n), grow-only buffers of the block chain, Cholesky workspaces keyed
+            # by the system size -- is taken over instead of being allocated and zero-filled again in the first iteration (the
+            # sequential loop rebuilds the window on every keyframe and one-way frame).  With the SAME predictors (a one-way frame)
+            # the state of the band median carries over too -- it only depends on K~ and the log-depths: the previous medians move
+            # into this window's buffer; with other predictors its planes are kept and the state is rebuilt in them.
+            same_kt = inh.Kt.data_ptr() == self.Kt.data_ptr() and inh.Kt.shape == self.Kt.shape
+            self.w["ba_ws"], self.w["chol_ws"] = inh.w["ba_ws"], inh.w["chol_ws"]
+            self.w["dr_ws"] = {k: e for k, e in inh.w["dr_ws"].items() if isinstance(k, tuple) and B in k[2:4]}   # (planes of this B only)
             for e in self.w["dr_ws"].values():
                 st = e.get("band") if isinstance(e, dict) else None
                 if st is not None:
-                    if st["med"] == inh.w["med3_full"].data_ptr() and inh.w["med3_full"].shape == self.w["med3_full"].shape:
+                    if same_kt and st["med"] == inh.w["med3_full"].data_ptr() and inh.w["med3_full"].shape == self.w["med3_full"].shape:
                         self.w["med3_full"].copy_(inh.w["med3_full"])
-                        st["med"] = self.w["med3_full"].data_ptr()
                     else:
-                        e.pop("band")
+                        st["ident"] = None                   # (full_image_median rebuilds the state in the same planes)
+                    st["med"] = self.w["med3_full"].data_ptr()
+        # (a side stream of the lowest priority was tried for the branch below: nothing in the eager loop, and +0.7 ms per replay
+        # of a captured iteration -- 777 -> 506 it/s on the bench window -- so it is a plain pool stream, kept across rebuilds)
+        if inh is not None and getattr(inh, "_side_stream", None) is not None:
             self._side_stream = inh._side_stream
         else:
             self._side_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
@@ -388,15 +398,21 @@ class WindowBA:
             return self._linearize_sharded(dr)
         if fork and self.full_median:
             # the full-image median needs only the scaffold's log-depths: its whole branch (depth image, select passes,
-            # priors) runs beside the dense reference points and the photometric system
+            # priors) runs beside the dense reference points and the photometric system.  The dense reference is SUBMITTED first:
+            # the band kernel streams up to the whole K~ window (0.7 GB) for a result only the priors read, and launched first it
+            # held the critical chain back
             main = torch.cuda.current_stream(dev)
             side = self._side_stream
-            side.wait_stream(main)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            Pwn, dT, uvec, med, _ = dr("points")
+            side.wait_event(ev)
             with torch.cuda.stream(side):
                 fm("all")
                 if self.with_priors:
                     _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
-        Pwn, dT, uvec, med, _ = dr("points" if fork else "all")
+        else:
+            Pwn, dT, uvec, med, _ = dr("points" if fork else "all")
         if fork and not self.full_median:
             # Nothing between the reference points and the solve needs the median depths except the priors, and the priors
             # only ADD into H / g (atomics): the median's select passes and the prior kernel run on a second stream (a

@@ -138,3 +138,69 @@ def test_weighted_normal_equations_kernel():
         AtA2, Atb2 = gram_weighted(Av.nan_to_num(0.0), None, y.to(DEV))            # no weights, no c
         assert rel_err(AtA2, torch.where(dead[None, :, None], torch.zeros_like(Ar), Ar).mT @ torch.where(dead[None, :, None], torch.zeros_like(Ar), Ar)) < 1e-12
     report("gram_kernel", ok=True)
+
+
+@pytest.mark.gpu
+def test_rebuilt_window_with_inherited_workspaces_equals_fresh_window():
+    """The sequential loop rebuilds the window solver on every one-way frame and keyframe with `WindowBA(prev=...)`: topology
+    tables (same keyframe set), scratch workspaces and -- with the same predictors -- the band-median state are taken over from the
+    retired window.  None of it may change a result: after the same two iterations the rebuilt window equals a window built from
+    scratch bit for bit (the chain is order-independent by construction), for a one-way frame added to the same keyframes AND for a
+    window over other predictors that reuses the planes; and `snapshot_state` returns what the separate tensors hold."""
+    import copy
+    from como_amd import synth
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    pix = torch.float32
+
+    def predictor(cov, cm):
+        Kinv, L, Kt = prep_predictor(cov.double(), cm.double(), 1.0)
+        return Kinv, L, Kt.to(pix)
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = 4
+    st = synth.make_window(B=4, H=192, W=256, m=64, dtype=torch.float64, device=DEV, seed=5, predictor=predictor)
+    st["Knm_Kmminv_pix"] = st["Knm_Kmminv"]                    # (already in the pixel type: every window aliases the same K~)
+    w0 = WindowBA(st, cfg=cfg, pix_dtype=pix, window_full=True)
+    for _ in range(3):
+        w0.step()
+    sn = w0.snapshot_state()
+    assert torch.equal(sn["poses"], w0.poses_all) and torch.equal(sn["aff"], w0.aff_all) and torch.equal(sn["P_m"], w0.P_m)
+    assert torch.equal(sn["median"], w0.median_depths) and torch.equal(sn["pm"], w0.w["pm"]) and torch.equal(sn["logzm"], w0.w["logzm"])
+    assert sn["poses"].data_ptr() != w0.poses_all.data_ptr()
+
+    def state_after(w):
+        out = dict(st)
+        out.update({"kf_poses": sn["poses"][:4].clone(), "kf_aff_params": sn["aff"][:4].reshape(4, 2, 1).clone(), "P_m": sn["P_m"].clone(),
+                    "median_depth_init": sn["median"].clone()})
+        return out
+    # (1) same keyframes + a one-way frame (a copy of keyframe 3's image at a perturbed pose)
+    s1 = state_after(w0)
+    T = s1["kf_poses"][3:4].clone()
+    T[0, 0, 3] += 2e-3
+    s1.update({"recent_poses": T, "recent_aff_params": torch.zeros((1, 2, 1), dtype=torch.float64, device=DEV),
+               "recent_img_and_grads": st["kf_img_and_grads"][3:4].clone(), "recent_timestamps": torch.tensor([3.5], dtype=torch.float64)})
+    res = {}
+    for how in ("prev", "fresh"):
+        w = WindowBA(s1, cfg=cfg, pix_dtype=pix, window_full=True, prev=w0 if how == "prev" else None)
+        if how == "prev":
+            assert w.w["ba_ws"] is w0.w["ba_ws"] and len(w.w["dr_ws"]) > 0          # workspaces (and band state) inherited
+            band = [e["band"] for k, e in w.w["dr_ws"].items() if k[0] == "full"][0]
+            assert band["ident"] is not None and band["calls"] == 3
+        for _ in range(2):
+            w.step()
+        res[how] = {k: v.clone() for k, v in w.snapshot_state().items()}
+        w1 = w
+    for k in res["fresh"]:
+        assert torch.equal(res["prev"][k], res["fresh"][k]), k
+    # (2) other predictors (another keyframe set): planes reused, band state rebuilt in them
+    st2 = synth.make_window(B=4, H=192, W=256, m=64, dtype=torch.float64, device=DEV, seed=6, predictor=predictor)
+    res = {}
+    for how in ("prev", "fresh"):
+        w = WindowBA(st2, cfg=cfg, pix_dtype=pix, window_full=True, prev=w1 if how == "prev" else None)
+        if how == "prev":
+            assert w.w["ba_ws"] is w1.w["ba_ws"]
+        for _ in range(2):
+            w.step()
+        res[how] = {k: v.clone() for k, v in w.snapshot_state().items()}
+    for k in res["fresh"]:
+        assert torch.equal(res["prev"][k], res["fresh"][k]), k
