@@ -85,6 +85,8 @@ SIGNATURES = {
     "como_track_reference_f64": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_double] + [c_void_p] * 4),
     "como_reproject_depth_f32": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int] + [c_void_p] * 6),
     "como_reproject_depth_f64": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int] + [c_void_p] * 6),
+    "como_reproject_points_f32": (c_int, [c_void_p] * 4 + [c_long, c_int, c_int, c_int, c_float] + [c_void_p] * 4),
+    "como_reproject_points_f64": (c_int, [c_void_p] * 4 + [c_long, c_int, c_int, c_int, c_double] + [c_void_p] * 4),
     "como_ba_partials_elems": (c_long, [c_int, c_int, c_int]),
     "como_sys_fix_plane_elems": (c_long, [c_long]),
     "como_sys_finalize": (c_int, [c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),

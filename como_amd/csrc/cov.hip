@@ -154,13 +154,13 @@ __global__ __launch_bounds__(1024) void greedy_next_kernel(const float* __restri
 
 // ---- the whole greedy loop on the device (samplers.py:196-282 without early termination): per step two launches ----
 // greedy_pick: get_next_inds (running distance mask, first maximum) and the gather of the chosen point into slot `slot`.
-__global__ __launch_bounds__(1024) void greedy_pick_kernel(const float* __restrict__ var, const float* __restrict__ dom,
-                                                           const float* __restrict__ Edom, float* __restrict__ coords_n,
-                                                           float* __restrict__ E_n, long* __restrict__ inds, int n, int k0,
-                                                           int k, uint8_t* __restrict__ mask, float thresh_sq, int slot,
-                                                           long* __restrict__ best_idx, float* __restrict__ max_stdev, int d) {
+// (body shared with greedy_small_loop_kernel, where the arrays the steps write -- var, coords_n, E_n, mask -- are re-read inside
+// ONE launch: no __restrict__ on them, so that no load of them is treated as invariant)
+__device__ __forceinline__ void greedy_pick_body(const int b, const int tid, const float* var, const float* __restrict__ dom,
+                                                 const float* __restrict__ Edom, float* coords_n, float* E_n, long* inds, int n,
+                                                 int k0, int k, uint8_t* mask, float thresh_sq, int slot, long* best_idx,
+                                                 float* max_stdev, int d) {
 #pragma clang fp contract(off)
-  const int b = blockIdx.x, tid = threadIdx.x;
   const float* vb = var + (long)b * d;
   const float* db = dom + (long)b * d * 2;
   uint8_t* mb = mask + (long)b * d;
@@ -205,6 +205,13 @@ __global__ __launch_bounds__(1024) void greedy_pick_kernel(const float* __restri
       for (int e = 0; e < 4; ++e) E_n[((long)b * n + slot) * 4 + e] = Edom[((long)b * d + w) * 4 + e];
     }
   }
+}
+
+__global__ __launch_bounds__(1024) void greedy_pick_kernel(const float* var, const float* __restrict__ dom,
+                                                           const float* __restrict__ Edom, float* coords_n, float* E_n, long* inds,
+                                                           int n, int k0, int k, uint8_t* mask, float thresh_sq, int slot,
+                                                           long* best_idx, float* max_stdev, int d) {
+  greedy_pick_body(blockIdx.x, threadIdx.x, var, dom, Edom, coords_n, E_n, inds, n, k0, k, mask, thresh_sq, slot, best_idx, max_stdev, d);
 }
 
 // Two-stage form of greedy_pick for large domains (one workgroup walking 300k candidates took 250 us per added point):
@@ -295,17 +302,15 @@ __global__ __launch_bounds__(256) void greedy_pick2_kernel(const float4* __restr
 // greedy_append: k_ni, the new Cholesky row (every workgroup redoes the tiny forward substitution from an LDS copy of L;
 // workgroup 0 stores it), then k_id, the obs_info row and the variance downdate of this workgroup's 256 domain pixels.
 // Arithmetic = cross_cov_kernel<float> + chol_row_kernel + obs_info_kernel.
-__global__ __launch_bounds__(256) void greedy_append_kernel(const float* __restrict__ coords_n, const float* __restrict__ E_n,
-                                                            const float* __restrict__ dom, const float* __restrict__ Edom,
-                                                            float* __restrict__ L, float* __restrict__ obs_info,
-                                                            float* __restrict__ var, float scale, float k_ii, int n, int d,
-                                                            int N) {
+template <int NT>
+__device__ __forceinline__ void greedy_append_body(const int b, const int blk, const int tid, const float* coords_n, const float* E_n,
+                                                   const float* __restrict__ dom, const float* __restrict__ Edom, float* L,
+                                                   float* obs_info, float* var, float scale, float k_ii, int n, int d, int N) {
   __shared__ float sx[64 * 2], sE[64 * 4], sL[64 * 65], lrow[64];
-  const int b = blockIdx.y, tid = threadIdx.x;
   float* Lb = L + (long)b * n * n;
-  for (int e = tid; e < (N + 1) * 2; e += 256) sx[e] = coords_n[(long)b * n * 2 + e];
-  for (int e = tid; e < (N + 1) * 4; e += 256) sE[e] = E_n[(long)b * n * 4 + e];
-  for (int e = tid; e < N * N; e += 256) { const int r = e / N, c = e % N; sL[r * 65 + c] = Lb[(long)r * n + c]; }
+  for (int e = tid; e < (N + 1) * 2; e += NT) sx[e] = coords_n[(long)b * n * 2 + e];
+  for (int e = tid; e < (N + 1) * 4; e += NT) sE[e] = E_n[(long)b * n * 4 + e];
+  for (int e = tid; e < N * N; e += NT) { const int r = e / N, c = e % N; sL[r * 65 + c] = Lb[(long)r * n + c]; }
   __syncthreads();
   if (tid < 64) {
     const int lane = tid;
@@ -336,16 +341,43 @@ __global__ __launch_bounds__(256) void greedy_append_kernel(const float* __restr
     if (lane == 0) lrow[N] = sqrtf(k_ii - sumsq);
   }
   __syncthreads();
-  if (blockIdx.x == 0 && tid <= N) Lb[(long)N * n + tid] = lrow[tid];
-  const int j = blockIdx.x * 256 + tid;
-  if (j >= d) return;
-  const float* xd = dom + ((long)b * d + j) * 2;
-  float sum = cov_value_f32(sx[2 * N], sx[2 * N + 1], sE + 4 * N, xd[0], xd[1], Edom + ((long)b * d + j) * 4, scale);
-  float* ob = obs_info + (long)b * n * d;
-  for (int i = 0; i < N; ++i) sum -= ob[(long)i * d + j] * lrow[i];
-  const float v = sum / lrow[N];
-  ob[(long)N * d + j] = v;
-  var[(long)b * d + j] -= v * v;
+  if (blk == 0 && tid <= N) Lb[(long)N * n + tid] = lrow[tid];
+  const int j = blk * NT + tid;
+  if (j < d) {
+    const float* xd = dom + ((long)b * d + j) * 2;
+    float sum = cov_value_f32(sx[2 * N], sx[2 * N + 1], sE + 4 * N, xd[0], xd[1], Edom + ((long)b * d + j) * 4, scale);
+    float* ob = obs_info + (long)b * n * d;
+    for (int i = 0; i < N; ++i) sum -= ob[(long)i * d + j] * lrow[i];
+    const float v = sum / lrow[N];
+    ob[(long)N * d + j] = v;
+    var[(long)b * d + j] -= v * v;
+  }
+}
+
+__global__ __launch_bounds__(256) void greedy_append_kernel(const float* coords_n, const float* E_n, const float* __restrict__ dom,
+                                                            const float* __restrict__ Edom, float* L, float* obs_info, float* var,
+                                                            float scale, float k_ii, int n, int d, int N) {
+  greedy_append_body<256>(blockIdx.y, blockIdx.x, threadIdx.x, coords_n, E_n, dom, Edom, L, obs_info, var, scale, k_ii, n, d, N);
+}
+
+// Small domains (d <= 1024: the thinning of a keyframe's tracked points, <= 64 candidates) -- the whole greedy loop in ONE launch of
+// one workgroup per batch item: the same two bodies step after step (pick, then append + pick per added point), workgroup barriers
+// where the launches were.  Bit-identical to the launch-per-step form (same code on the same data in the same order); 2 (n - m) + 1
+// launches of ~4 us become one.
+__global__ __launch_bounds__(1024) void greedy_small_loop_kernel(float* coords_n, float* E_n, long* inds, const float* __restrict__ dom,
+                                                                 const float* __restrict__ Edom, float* L, float* obs_info, float* var,
+                                                                 uint8_t* mask, long* best_idx, float* max_stdev, float scale, float k_ii,
+                                                                 float thresh_sq, int B, int n, int d, int m, float* sd_trace) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  greedy_pick_body(b, tid, var, dom, Edom, coords_n, E_n, inds, n, 0, m, mask, thresh_sq, m, best_idx,
+                   sd_trace ? sd_trace + (long)m * B : max_stdev, d);
+  for (int i = m; i < n; ++i) {
+    __syncthreads();
+    greedy_append_body<1024>(b, 0, tid, coords_n, E_n, dom, Edom, L, obs_info, var, scale, k_ii, n, d, i);
+    __syncthreads();
+    greedy_pick_body(b, tid, var, dom, Edom, coords_n, E_n, inds, n, i, 1, mask, thresh_sq, i + 1, best_idx,
+                     sd_trace ? sd_trace + (long)(i + 1) * B : max_stdev, d);
+  }
 }
 
 template <typename T>
@@ -429,6 +461,13 @@ int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, cons
                          coord_vec_inds, n, k0, k, mask, dist_thresh_sq, slot, best_idx, sd_out, d);
     }
   };
+  static const bool fused_small = [] { const char* e = getenv("COMO_GREEDY_FUSED"); return !e || e[0] != '0'; }();
+  if (fused_small && d <= 1024) {
+    hipLaunchKernelGGL(greedy_small_loop_kernel, dim3(B), dim3(1024), 0, s, coords_n, E_n, coord_vec_inds, coords_domain, E_domain, L,
+                       obs_info, var, mask, best_idx, max_stdev, scale, k_ii, dist_thresh_sq, B, n, d, m, sd_trace);
+    COMO_CHECK_LAUNCH();
+    return COMO_OK;
+  }
   pick(0, m, m, sd_trace ? sd_trace + (long)m * B : max_stdev);
   COMO_CHECK_LAUNCH();
   for (int i = m; i < n; ++i) {

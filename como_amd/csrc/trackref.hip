@@ -119,6 +119,42 @@ __global__ __launch_bounds__(256) void reproject_gather_kernel(long long* __rest
   }
 }
 
+// Points of frame i (row/col coordinates + depths) seen from frame j: back-projection, rigid transform, projection and the
+// in-image / minimum-depth test of the new keyframe's correspondence search (reference como/odom/frontend/corr.py:17-43:
+// filter_reproj_coords + reproject_points = camera.py:43-54 backprojection, transforms.py:17-23 transform_points, camera.py:20-26
+// projection) -- one launch instead of ~26 elementwise torch launches per call (three calls per keyframe, one of them over every
+// pixel of the previous keyframe's depth image).  coords == nullptr: the points are the pixel grid of width `wgrid` (row = i / wgrid,
+// col = i % wgrid).  keep == nullptr: no test.  Same operation order as the torch expressions (no contraction); the rigid transform
+// accumulates in k order.
+template <typename T>
+__global__ __launch_bounds__(256) void reproject_points_kernel(const T* __restrict__ coords, const T* __restrict__ z,
+                                                               const T* __restrict__ Tji, const T* __restrict__ Kmat, long n, int wgrid,
+                                                               int h, int w, T min_depth, T* __restrict__ rc_out, T* __restrict__ P_out,
+                                                               uint8_t* __restrict__ keep) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const T fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  T X, Y, Z, u, v;
+  {
+#pragma clang fp contract(off)
+    const T row = coords ? coords[2 * i] : T((int)(i / wgrid));
+    const T col = coords ? coords[2 * i + 1] : T((int)(i % wgrid));
+    const T zi = z[i];
+    const T rx = (col - cx) / fx, ry = (row - cy) / fy;
+    const T px = zi * rx, py = zi * ry, pz = zi * T(1);
+    X = ((px * Tji[0] + py * Tji[1]) + pz * Tji[2]) + Tji[3];
+    Y = ((px * Tji[4] + py * Tji[5]) + pz * Tji[6]) + Tji[7];
+    Z = ((px * Tji[8] + py * Tji[9]) + pz * Tji[10]) + Tji[11];
+    u = fx * X / Z + cx;
+    v = fy * Y / Z + cy;
+  }
+  rc_out[2 * i] = v;
+  rc_out[2 * i + 1] = u;
+  P_out[3 * i] = X; P_out[3 * i + 1] = Y; P_out[3 * i + 2] = Z;
+  // at least one pixel inside the image, deeper than min_depth (corr.py:17-29)
+  if (keep) keep[i] = ((u >= T(1)) && (u < T(w - 1)) && (v >= T(1)) && (v < T(h - 1)) && (Z > min_depth)) ? 1 : 0;
+}
+
 }  // namespace como
 
 extern "C" {
@@ -149,5 +185,17 @@ extern "C" {
   }
 COMO_DEF_TRACKREF(f32, float)
 COMO_DEF_TRACKREF(f64, double)
+
+#define COMO_DEF_REPROJ_POINTS(SFX, T)                                                                                          \
+  int como_reproject_points_##SFX(const T* coords, const T* z, const T* Tji, const T* K, long n, int wgrid, int h, int w,         \
+                                  T min_depth, T* rc_out, T* P_out, uint8_t* keep, como_stream_t stream) {                        \
+    if (!z || !Tji || !K || !rc_out || !P_out || n <= 0 || (!coords && wgrid <= 0) || h <= 0 || w <= 0) return COMO_ERR_ARG;     \
+    hipLaunchKernelGGL(como::reproject_points_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,    \
+                       coords, z, Tji, K, n, wgrid, h, w, min_depth, rc_out, P_out, keep);                                        \
+    COMO_CHECK_LAUNCH();                                                                                                        \
+    return COMO_OK;                                                                                                             \
+  }
+COMO_DEF_REPROJ_POINTS(f32, float)
+COMO_DEF_REPROJ_POINTS(f64, double)
 
 }  // extern "C"

@@ -298,7 +298,10 @@ class Tracking:
         T_w = get_T_w_curr(fg["T_w_kf"], T)
         _, _, n_seen, med = self.reproj_stats_last_kf(T, P=fg["pb"].levels[-1]["P"][0])
         dt = T.dtype
-        sc = torch.cat((torch.linalg.norm(T[:, :3, 3]).reshape(1), med.reshape(1).to(dt), n_seen.reshape(1).to(dt), recs[:, 104]))
+        # everything the host reads and keeps of a frame in ONE buffer: [|t|, median depth, pixels seen, per-level barrier status |
+        # T_curr_kf (16) | aff_curr_kf (2) | T_w_curr (16)] -- one read-back and one copy per frame instead of one + three
+        sc = torch.cat((torch.linalg.norm(T[:, :3, 3]).reshape(1), med.reshape(1).to(dt), n_seen.reshape(1).to(dt), recs[:, 104],
+                        T.reshape(-1), aff.reshape(-1).to(dt), T_w.reshape(-1).to(dt)))
         return T, aff, T_w, sc
 
     def _track_frame_graph(self, rgb):
@@ -339,10 +342,13 @@ class Tracking:
                 return None
         T, aff, T_w, sc = out
         v = sc.tolist()                                 # the frame's one host synchronisation
-        if min(v[3:]) < 0:                              # a device-wide barrier of a level kernel timed out: track eagerly
+        nl = len(v) - 34 - 3                            # pyramid levels
+        if min(v[3:3 + nl]) < 0:                        # a device-wide barrier of a level kernel timed out: track eagerly
             _pt.photo_tracking_pyr.fallbacks = getattr(_pt.photo_tracking_pyr, "fallbacks", 0) + 1
             return None
-        return T.clone(), aff.clone(), T_w.clone(), v[0], v[1], int(v[2])
+        keep = sc[3 + nl:].clone()                      # (the graph's buffers are overwritten by the next replay)
+        return (keep[:16].view(1, 4, 4).to(T.dtype), keep[16:18].view(1, 2, 1).to(aff.dtype), keep[18:34].view(1, 4, 4).to(T_w.dtype),
+                v[0], v[1], int(v[2]))
 
     # ---- one frame (Tracking.py:315-379) -----------------------------------------------------------------------------
     def handle_frame(self, data):

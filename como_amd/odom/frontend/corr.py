@@ -27,6 +27,34 @@ def filter_reproj_coords(coords, P, img_size, min_depth):
     return coords.index_select(1, idx), P.index_select(1, idx), keep
 
 
+def reproject_and_filter(coords_i, zi, Tji, K, img_size=None, min_depth=0.0, grid_width=None):
+    """reproject_points (+ filter_reproj_coords when img_size is given) as ONE launch (csrc/trackref.hip
+    `como_reproject_points_*`): coords_i (1,n,2) row/col or None with grid_width = W (the points are the pixel grid), zi (1,n,1).
+    Returns (coords_j (1,k,2), P_j (1,k,3), keep (n,) bool or None): the kept points in index order."""
+    from como_amd import _lib
+    dt, dev = zi.dtype, zi.device
+    n = zi.shape[1]
+    L = _lib.lib()
+    rc = torch.empty((1, n, 2), dtype=dt, device=dev)
+    P = torch.empty((1, n, 3), dtype=dt, device=dev)
+    keep = torch.empty((n,), dtype=torch.uint8, device=dev) if img_size is not None else None
+    c = None if coords_i is None else coords_i.to(dt).contiguous()
+    h, w = (int(img_size[-2]), int(img_size[-1])) if img_size is not None else (1, 1)
+    rcode = getattr(L, "como_reproject_points_" + _lib.suffix(dt))(
+        _lib.ptr(c), zi.contiguous().data_ptr(), Tji.to(dt).reshape(4, 4).contiguous().data_ptr(), K[0].to(dt).contiguous().data_ptr(), n,
+        int(grid_width or 0), h, w, float(min_depth), rc.data_ptr(), P.data_ptr(), _lib.ptr(keep), _lib.stream_ptr(dev))
+    _lib.check(rcode, "como_reproject_points")
+    if keep is None:
+        return rc, P, None
+    keep = keep.view(torch.bool)
+    idx = torch.nonzero(keep)[:, 0]
+    return rc.index_select(1, idx), P.index_select(1, idx), keep
+
+
+def _kernel_path(z):
+    return z.is_cuda and z.dtype in (torch.float32, torch.float64) and z.shape[0] == 1
+
+
 def condition_depth(logz_m, Knm_Kmminv):
     return Knm_Kmminv @ logz_m
 
@@ -77,12 +105,17 @@ def track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, cov_params_img2, K, mo
 
     # previous keyframe (1) -> new frame (2): the sparse points and the whole depth image
     Tji = invertSE3(pose2) @ pose1
-    coords_n1 = get_test_coords(z_img1.shape[-2:], device=dev, batch_size=b)
     z_n1 = z_img1.reshape(b, 1, N).permute(0, 2, 1)
-    cj_m, Pj_m = reproject_points(coords_m1, z_m1, Tji, K)
-    cj_n, Pj_n = reproject_points(coords_n1, z_n1, Tji, K)
-    cj_m, Pj_m, keep_m = filter_reproj_coords(cj_m, Pj_m, cov_size, min_d)
-    cj_n, Pj_n, _ = filter_reproj_coords(cj_n, Pj_n, cov_size, min_d)
+    fused = _kernel_path(z_n1) and z_m1.dtype == z_n1.dtype
+    if fused:
+        cj_m, Pj_m, keep_m = reproject_and_filter(coords_m1, z_m1, Tji, K, cov_size, min_d)
+        cj_n, Pj_n, _ = reproject_and_filter(None, z_n1, Tji, K, cov_size, min_d, grid_width=z_img1.shape[-1])
+    else:
+        coords_n1 = get_test_coords(z_img1.shape[-2:], device=dev, batch_size=b)
+        cj_m, Pj_m = reproject_points(coords_m1, z_m1, Tji, K)
+        cj_n, Pj_n = reproject_points(coords_n1, z_n1, Tji, K)
+        cj_m, Pj_m, keep_m = filter_reproj_coords(cj_m, Pj_m, cov_size, min_d)
+        cj_n, Pj_n, _ = filter_reproj_coords(cj_n, Pj_n, cov_size, min_d)
     zj_n = Pj_n[:, :, 2:3]
 
     # latent depths of the reprojected sparse points under the NEW frame's covariance, from the reprojected dense depths
@@ -92,7 +125,10 @@ def track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, cov_params_img2, K, mo
     P_m, _ = backprojection(K[0], swap_coords_xy(cj_m), z_m)
 
     # back into frame 1: compare with the interpolated reference depth there
-    ci_m, Pi_m = reproject_points(cj_m, z_m, invertSE3(Tji), K)
+    if fused and z_m.dtype == z_n1.dtype and cj_m.shape[1] > 0:
+        ci_m, Pi_m, _ = reproject_and_filter(cj_m, z_m, invertSE3(Tji), K)
+    else:
+        ci_m, Pi_m = reproject_points(cj_m, z_m, invertSE3(Tji), K)
     P_proj, _ = backprojection(K[0], swap_coords_xy(ci_m), _sample_at(z_img1, ci_m, cov_size))
 
     # depth discontinuities of the reference: |grad log z| at the original sparse coordinates

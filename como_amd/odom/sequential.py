@@ -65,6 +65,10 @@ class ComoSeq:
             to_map = ("init", timestamp, rgb.clone())
         kf_viz, kf_ref = mp.map(to_map)
         if kf_ref is not None:
+            if trk.mapping_init and kf_ref[0][-1] == trk.kf_received_ts:
+                # same keyframe image(s) as last time: the tracker only reads the poses and the depth (update_kf_reference),
+                # so the window's colour images are not converted to its element type again on every frame
+                kf_ref = (kf_ref[0], None) + tuple(kf_ref[2:])
             trk.update_kf_reference(transfer_data(kf_ref, trk.device, trk.dtype))
         if kf_viz is not None:
             self.last_kf_viz = kf_viz

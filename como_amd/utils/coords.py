@@ -6,10 +6,27 @@ def swap_coords_xy(coords):
     return coords.flip(-1)
 
 
+_A_cache = {}
+
+
+def _inv_dims(dims, device, dtype):
+    """(A, 2 A) with A = 1 / dims on the device: built once per (dims, device, dtype) -- the keyframe path normalises coordinates
+    a dozen times per keyframe, each time with a host list -> device copy and two tiny launches for the same two numbers."""
+    key = (tuple(float(d) for d in dims), str(device), dtype)
+    v = _A_cache.get(key)
+    if v is None:
+        A = 1.0 / torch.as_tensor([float(d) for d in dims], device=device, dtype=dtype)
+        v = _A_cache[key] = (A, 2 * A)
+    return v
+
+
 def normalize_coordinates(x_pixel, dims):
     """Pixel -> [-1,1] with pixel centres at fractional positions: x_norm = 2 A x + A - 1, A = 1/dims (coords.py:12-15)."""
-    A = 1.0 / torch.as_tensor(dims, device=x_pixel.device, dtype=x_pixel.dtype)
-    return 2 * A * x_pixel + A - 1
+    if torch.is_tensor(dims) or not x_pixel.is_floating_point():
+        A = 1.0 / torch.as_tensor(dims, device=x_pixel.device, dtype=x_pixel.dtype)
+        return 2 * A * x_pixel + A - 1
+    A, A2 = _inv_dims(dims, x_pixel.device, x_pixel.dtype)
+    return A2 * x_pixel + A - 1
 
 
 def normalize_coordinates_A(x_pixel, A):
@@ -21,10 +38,18 @@ def unnormalize_coordinates(x_norm, dims):
     return A * x_norm + A - 0.5
 
 
+_grid_cache = {}
+
+
 def get_test_coords(img_size, device, batch_size=1):
-    h, w = img_size
-    r, c = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
-    return torch.stack((r.reshape(-1), c.reshape(-1)), dim=1).repeat(batch_size, 1, 1)
+    """(batch, h*w, 2) row/col of every pixel (coords.py:31-36).  Cached per (size, device, batch): callers only read it."""
+    h, w = int(img_size[0]), int(img_size[1])
+    key = (h, w, str(device), int(batch_size))
+    t = _grid_cache.get(key)
+    if t is None:
+        r, c = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
+        t = _grid_cache[key] = torch.stack((r.reshape(-1), c.reshape(-1)), dim=1).repeat(batch_size, 1, 1)
+    return t
 
 
 def get_coord_img(img_size, device, batch_size=1):

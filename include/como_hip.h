@@ -136,6 +136,15 @@ int como_reproject_depth_f32(const float* Tck, const float* K, const float* P, l
                              float* img, uint8_t* seen, int* nseen, como_stream_t stream);
 int como_reproject_depth_f64(const double* Tck, const double* K, const double* P, long n, int h, int w, void* order_ws,
                              double* zbuf, double* img, uint8_t* seen, int* nseen, como_stream_t stream);
+/* como_reproject_points_*: n points of frame i -- row/col coordinates `coords` (n,2) (NULL: the pixel grid of width `wgrid`) and
+ * depths z (n) -- seen from frame j (Tji (4,4), K (3,3)): rc_out (n,2) row/col there, P_out (n,3) camera points, keep (n) (may be
+ * NULL) = at least one pixel inside the (h, w) image and deeper than min_depth.  Replaces como/odom/frontend/corr.py:17-43
+ * (filter_reproj_coords + reproject_points: backprojection camera.py:43-54, transform_points transforms.py:17-23, projection
+ * camera.py:20-26) of the new keyframe's correspondence search. */
+int como_reproject_points_f32(const float* coords, const float* z, const float* Tji, const float* K, long n, int wgrid, int h, int w,
+                              float min_depth, float* rc_out, float* P_out, uint8_t* keep, como_stream_t stream);
+int como_reproject_points_f64(const double* coords, const double* z, const double* Tji, const double* K, long n, int wgrid, int h, int w,
+                              double min_depth, double* rc_out, double* P_out, uint8_t* keep, como_stream_t stream);
 
 /* Colour images (`color: rgb`, config/como.yml:7; photo_tracking.py works on (1,N,c) values and (1,N,c,8) Jacobians): the
  * same iteration / level with `channels` = c image channels.  vals_i (N,c), J8 (N,c,8), img (c,H,W) planes, r_ws (N,c),

@@ -204,3 +204,37 @@ def test_rebuilt_window_with_inherited_workspaces_equals_fresh_window():
         res[how] = {k: v.clone() for k, v in w.snapshot_state().items()}
     for k in res["fresh"]:
         assert torch.equal(res["prev"][k], res["fresh"][k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_reproject_points_kernel_vs_torch_formulas(dt):
+    """csrc/trackref.hip `como_reproject_points_*` against the torch expressions it replaces in the correspondence search
+    (frontend/corr.py reproject_points + filter_reproj_coords = reference corr.py:17-43): camera points and row/col coordinates to
+    rounding (the rigid transform accumulates in k order, the library product it replaces in its own), the in-image / depth test
+    identical away from the boundaries, kept points in index order; explicit coordinates and the pixel-grid form."""
+    from como_amd import synth
+    from como_amd.odom.frontend import corr
+    from como_amd.utils.coords import get_test_coords
+    g = torch.Generator().manual_seed(11)
+    H, W = 96, 128
+    K = synth.intrinsics_for(H, W).to(dt)[None].to(DEV)
+    T = synth.gt_poses(3, step=0.05, deg=2.0)[2:3].to(dt).to(DEV)
+    z = (1.0 + torch.rand((1, H * W, 1), generator=g, dtype=torch.float64)).to(dt).to(DEV)
+    z[0, ::17, 0] = 1e-4                                        # some points below the depth threshold
+    grid = get_test_coords((H, W), device=DEV)
+    tol = 1e-12 if dt == torch.float64 else 2e-5
+    for coords in (None, (grid.to(dt) + 0.25)):
+        c_in = grid if coords is None else coords
+        rc_ref, P_ref = corr.reproject_points(c_in, z, T, K)
+        rc_f, P_f, keep_ref = corr.filter_reproj_coords(rc_ref, P_ref, (H, W), 0.05)
+        rc, P, keep = corr.reproject_and_filter(coords, z, T, K, (H, W), 0.05, grid_width=W if coords is None else None)
+        near = ((rc_ref[0] - 1).abs().min(dim=1).values < 1e-6) | ((rc_ref[0, :, 0] - (H - 1)).abs() < 1e-6) | \
+               ((rc_ref[0, :, 1] - (W - 1)).abs() < 1e-6)
+        assert not bool(near.any())                            # (no point of this case sits on a boundary of the test)
+        assert torch.equal(keep, keep_ref) and 0 < int(keep.sum()) < H * W
+        assert rc.shape == rc_f.shape and P.shape == P_f.shape
+        assert float((rc - rc_f).abs().max()) <= tol * W and float((P - P_f).abs().max()) <= tol * 4
+        rc2, P2, none = corr.reproject_and_filter(coords if coords is not None else grid.to(dt), z, T, K)
+        assert none is None and float((rc2 - rc_ref).abs().max()) <= tol * W * 40 and float((P2 - P_ref).abs().max()) <= tol * 4
+    report("reproject_points_kernel", dtype=str(dt), kept=int(keep.sum()), of=H * W)
