@@ -145,8 +145,11 @@ SIGNATURES = {
     "como_win_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
     "como_gram_workspace_bytes": (c_long, []),
     "como_gram_f64": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "como_predictor_f64": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p] * 3),
     "como_se3_inverse_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "como_se3_inverse_f64": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "como_se3_compose_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
+    "como_se3_compose_f64": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),
 }
 
 

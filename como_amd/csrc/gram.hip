@@ -151,9 +151,75 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const double* __restri
   }
 }
 
+// ---- the GP predictor of the distillation (distill_depth.py:30-48 get_predictor) ---------------------------------------------------
+//   Kt = K_nm K_mm^-1 (n x m),   var_i = K_nn,ii - sum_c K_nm[i][c] Kt[i][c]
+// The reference forms Kt with a library GEMM (157 MB in, 157 MB out at 640x480, m = 64), then an elementwise product and a row
+// reduction (two more passes over both matrices).  One pass here: a wave takes 16 rows; lane (j = l & 15, g = l >> 4) holds the
+// contiguous columns 16 g .. 16 g + 15 of row j as the A operands of sixteen v_mfma_f64_16x16x4_f64 steps (step s multiplies the
+// columns {s, 16 + s, 32 + s, 48 + s}), K_mm^-1 sits in registers in the matching order (64 values per lane, loaded once per wave),
+// the four 16-column output tiles are stored with row stride `ldo` (columns m .. ldo - 1 come out as exact zeros: the padded form
+// `gram_weighted` reads) and folded with the L1-hot K_nm entries into the row's variance.
+__global__ __launch_bounds__(256) void predictor_kernel(const double* __restrict__ Knm, const double* __restrict__ inv,
+                                                        const double* __restrict__ diag, int n, int m, int ldo,
+                                                        double* __restrict__ Kt, double* __restrict__ var) {
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, j = l & 15, g = l >> 4;
+  double Bq[16][4];
+#pragma unroll
+  for (int s = 0; s < 16; ++s)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int kr = 16 * g + s, kc = 16 * c + j;
+      Bq[s][c] = (kr < m && kc < m) ? inv[(long)kr * m + kc] : 0.0;
+    }
+  const long ntiles = ((long)n + 15) / 16;
+  for (long t = (long)blockIdx.x * 4 + wv; t < ntiles; t += (long)gridDim.x * 4) {
+    const long r0 = 16 * t;
+    const long ra = min(r0 + j, (long)n - 1);                      // (rows past the end: clamped loads, nothing stored)
+    double a[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) a[s] = (16 * g + s < m) ? Knm[ra * m + 16 * g + s] : 0.0;
+    g4_t acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = g4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], Bq[s][c], acc[c], 0, 0, 0);
+    // tile c, register rg: row r0 + 4 rg + g, column 16 c + j
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const long row = r0 + 4 * rg + g;
+      const bool rin = row < n;
+      const long rr = rin ? row : (long)n - 1;
+      double p = 0.0;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int col = 16 * c + j;
+        if (rin && col < ldo) Kt[rr * ldo + col] = acc[c][rg];
+        const double k = (col < m) ? Knm[rr * m + col] : 0.0;
+        p = __builtin_fma(k, acc[c][rg], p);
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) p += __shfl_xor(p, off, 64);
+      if (rin && j == 0) var[row] = diag[row] - p;
+    }
+  }
+}
+
 }  // namespace como
 
 extern "C" {
+
+int como_predictor_f64(const double* Knm, const double* inv, const double* diag, int n, int m, int ldo, double* Kt, double* var,
+                       como_stream_t stream) {
+  if (!Knm || !inv || !diag || !Kt || !var || n <= 0 || m <= 0 || m > 64 || ldo < m || ldo > 64) return COMO_ERR_ARG;
+  long tiles = ((long)n + 15) / 16;
+  int blocks = (int)((tiles + 3) / 4);
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(como::predictor_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Knm, inv, diag, n, m, ldo, Kt, var);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
 
 long como_gram_workspace_bytes(void) { return 256L * como::GRAM_REC * (long)sizeof(double); }
 

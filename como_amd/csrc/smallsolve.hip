@@ -48,11 +48,14 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const T* __restrict__ A
     __syncthreads();
     for (int i = j + tid; i < n; i += 256) a[i * ld + j] = (i == j) ? d : a[i * ld + j] / d;
     __syncthreads();
-    // trailing update of the lower triangle: (i, c) with j < c <= i < n
+    // trailing update of the lower triangle: (i, c) with j < c <= i < n -- 16 x 16 thread tiles (the flat form spent its time in
+    // two integer divisions per element: 150 us for the 70 x 70 system of the two-frame initialiser); one update per element
+    // either way
     const int r = n - 1 - j;
-    for (int e = tid; e < r * r; e += 256) {
-      const int i = j + 1 + e / r, c = j + 1 + e % r;
-      if (c <= i) a[i * ld + c] -= a[i * ld + j] * a[c * ld + j];
+    for (int ii = tid >> 4; ii < r; ii += 16) {
+      const int i = j + 1 + ii;
+      const T aij = a[i * ld + j];
+      for (int cc = tid & 15; cc <= ii; cc += 16) a[i * ld + j + 1 + cc] -= aij * a[(j + 1 + cc) * ld + j];
     }
     __syncthreads();
   }
@@ -77,18 +80,18 @@ __global__ __launch_bounds__(256) void chol_small_kernel(const T* __restrict__ A
       for (int j = 0; j < n; ++j) {                     // L y = b
         if (tid < kc) rb[j * SM_RHS + tid] /= a[j * ld + j];
         __syncthreads();
-        for (int e = tid; e < (n - 1 - j) * kc; e += 256) {
-          const int i = j + 1 + e / kc, c = e % kc;
-          rb[i * SM_RHS + c] -= a[i * ld + j] * rb[j * SM_RHS + c];
+        for (int i = j + 1 + (tid >> 3); i < n; i += 32) {
+          const int c = tid & 7;
+          if (c < kc) rb[i * SM_RHS + c] -= a[i * ld + j] * rb[j * SM_RHS + c];
         }
         __syncthreads();
       }
       for (int j = n - 1; j >= 0; --j) {                // L^T x = y
         if (tid < kc) rb[j * SM_RHS + tid] /= a[j * ld + j];
         __syncthreads();
-        for (int e = tid; e < j * kc; e += 256) {
-          const int i = e / kc, c = e % kc;
-          rb[i * SM_RHS + c] -= a[j * ld + i] * rb[j * SM_RHS + c];
+        for (int i = tid >> 3; i < j; i += 32) {
+          const int c = tid & 7;
+          if (c < kc) rb[i * SM_RHS + c] -= a[j * ld + i] * rb[j * SM_RHS + c];
         }
         __syncthreads();
       }

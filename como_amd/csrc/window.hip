@@ -454,6 +454,48 @@ __global__ __launch_bounds__(64) void se3_inverse_kernel(const T* __restrict__ i
   o[12] = T(0); o[13] = T(0); o[14] = T(0); o[15] = T(1);
 }
 
+// out_i = op(A_i) op(B_i) for n pose pairs, one thread each; mode 1: inv(A) B (relative pose, transforms.py:11-13), mode 2: A inv(B)
+// (world pose of the current frame, transforms.py:6-8), mode 0: A B.  na / nb = 1 broadcasts that operand.  The inverse is formed
+// exactly as se3_inverse_kernel does, the 4x4 product as plain left-to-right sums -- one launch instead of the inverse kernel + a
+// library GEMM (4x4 products were the last library calls of a plain frame of the sequential loop).
+template <typename T>
+__global__ __launch_bounds__(64) void se3_compose_kernel(const T* __restrict__ A, const T* __restrict__ B, T* __restrict__ out, int n,
+                                                         int na, int nb, int mode) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  T a[16], b[16];
+  auto load = [](const T* p, T* m, bool inv) {
+    if (!inv) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) m[e] = p[e];
+      return;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      T s = p[r] * p[3];
+      s = s + p[4 + r] * p[7];
+      s = s + p[8 + r] * p[11];
+      m[4 * r + 0] = p[r]; m[4 * r + 1] = p[4 + r]; m[4 * r + 2] = p[8 + r]; m[4 * r + 3] = -s;
+    }
+    m[12] = T(0); m[13] = T(0); m[14] = T(0); m[15] = T(1);
+  };
+  load(A + 16 * (long)(na == 1 ? 0 : i), a, mode == 1);
+  load(B + 16 * (long)(nb == 1 ? 0 : i), b, mode == 2);
+  T* o = out + 16 * (long)i;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      T s = a[4 * r] * b[c];
+      s = s + a[4 * r + 1] * b[4 + c];
+      s = s + a[4 * r + 2] * b[8 + c];
+      s = s + a[4 * r + 3] * b[12 + c];
+      o[4 * r + c] = s;
+    }
+  }
+}
+
 }  // namespace como
 
 extern "C" {
@@ -535,6 +577,17 @@ int como_se3_inverse_f32(const float* T, float* out, int n, como_stream_t stream
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }
+#define COMO_DEF_SE3_COMPOSE(SFX, T)                                                                                            \
+  int como_se3_compose_##SFX(const T* A, const T* B, T* out, int n, int na, int nb, int mode, como_stream_t stream) {             \
+    if (!A || !B || !out || n <= 0 || (na != 1 && na != n) || (nb != 1 && nb != n) || mode < 0 || mode > 2) return COMO_ERR_ARG;  \
+    hipLaunchKernelGGL(como::se3_compose_kernel<T>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, A, B, out, n, na, nb,    \
+                       mode);                                                                                                   \
+    COMO_CHECK_LAUNCH();                                                                                                        \
+    return COMO_OK;                                                                                                             \
+  }
+COMO_DEF_SE3_COMPOSE(f32, float)
+COMO_DEF_SE3_COMPOSE(f64, double)
+
 int como_se3_inverse_f64(const double* T, double* out, int n, como_stream_t stream) {
   if (!T || !out || n <= 0) return COMO_ERR_ARG;
   hipLaunchKernelGGL(como::se3_inverse_kernel<double>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, T, out, n);

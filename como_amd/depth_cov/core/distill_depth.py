@@ -96,6 +96,22 @@ def get_predictor(K_mm, K_nm, K_nn_diag, pad4=False):
     f = chol_small(K_mm, want_L=True, want_inv=True)          # csrc/smallsolve.hip: L_mm and K_mm^-1 in one launch
     L_mm = f["L"]
     m = K_mm.shape[-1]
+    if (_GRAM_KERNEL and K_nm.is_cuda and K_nm.dtype == torch.float64 and K_nm.shape[0] == 1 and 0 < m <= 64 and K_nm.shape[1] > 0):
+        # product, elementwise product and row reduction in ONE pass over K_nm (csrc/gram.hip `como_predictor_f64`) instead of a
+        # library GEMM and two more passes over both n x m matrices
+        from como_amd import _lib
+        n = K_nm.shape[1]
+        mp = (m + 3) // 4 * 4 if pad4 else m
+        full = torch.empty((1, n, mp), dtype=K_nm.dtype, device=K_nm.device)
+        var_n = torch.empty((1, n), dtype=K_nm.dtype, device=K_nm.device)
+        Kc, ic, dc = K_nm.contiguous(), f["inv"].contiguous(), K_nn_diag.reshape(1, n).contiguous()
+        _lib.check(_lib.lib().como_predictor_f64(Kc.data_ptr(), ic.data_ptr(), dc.data_ptr(), n, m, mp, full.data_ptr(), var_n.data_ptr(),
+                                                 _lib.stream_ptr(K_nm.device)), "como_predictor_f64")
+        Kt = full[:, :, :m] if mp != m else full
+        if mp != m:
+            Kt._como_padded = full
+        var_n = var_n + (torch.min(var_n) + 1e-8)
+        return Kt, L_mm, 1.0 / torch.sqrt(var_n.unsqueeze(-1))
     if pad4 and m % 4:
         full = K_nm @ torch.nn.functional.pad(f["inv"], (0, 4 - m % 4))
         Kt = full[:, :, :m]
@@ -143,7 +159,16 @@ def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model,
             AtA = AtA + Lm1.mT @ Lm1
         logz_m = chol_small(AtA, want_L=False, rhs=Atb)["X"]
         ok = torch.nonzero(okm[0, :, 0])[:, 0]
-        return logz_m, (Kt @ logz_m - y).index_select(1, ok)
+        # residuals K~ logz_m - y: the predicted log-depths come from the depth-only pass of the dense-reference kernel (one
+        # streaming pass, csrc/densify.hip) instead of a (n x m)(m x 1) library product
+        from como_amd.odom.backend.dense_ref import depth_image
+        Kp = padded_predictor(Kt)
+        lz = logz_m.reshape(1, m)
+        if Kp.shape[2] != m:
+            lz = torch.nn.functional.pad(lz, (0, Kp.shape[2] - m))
+        pred = torch.empty((1, Kp.shape[1]), dtype=Kp.dtype, device=Kp.device)
+        depth_image(Kp, lz, logz_out=pred)
+        return logz_m, (pred.unsqueeze(-1) - y).index_select(1, ok)
     ok = torch.nonzero(z_obs[0, :, 0] > min_depth)[:, 0]
     return distill_depth(Kt.index_select(1, ok), z_obs.index_select(1, ok), distill_with_prior, L_mm=L_mm,
                          stdev_inv_obs=sinv.index_select(1, ok))

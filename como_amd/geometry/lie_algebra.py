@@ -74,6 +74,27 @@ def invertSE3(T):
     return Ti
 
 
+def composeSE3(A, B, mode):
+    """op(A) op(B) for pose batches (n,4,4) / (1,4,4) broadcast -- mode 1: inv(A) B, mode 2: A inv(B), mode 0: A B -- as ONE launch
+    (csrc/window.hip se3_compose_kernel) where the mirror's form is the inverse kernel + a 4x4 library product; the torch form for
+    anything the kernel does not take (CPU tensors, other dtypes, higher-rank batches)."""
+    if (_SE3_KERNEL and A.is_cuda and B.is_cuda and A.dtype == B.dtype and A.dtype in (torch.float32, torch.float64) and A.dim() == 3 and
+            B.dim() == 3 and A.shape[0] > 0 and B.shape[0] > 0 and (A.shape[0] == B.shape[0] or 1 in (A.shape[0], B.shape[0]))):
+        from como_amd import _lib
+        n = max(A.shape[0], B.shape[0])
+        Ac, Bc = A.contiguous(), B.contiguous()
+        out = torch.empty((n, 4, 4), dtype=A.dtype, device=A.device)
+        fn = getattr(_lib.lib(), "como_se3_compose_" + _lib.suffix(A.dtype))
+        _lib.check(fn(Ac.data_ptr(), Bc.data_ptr(), out.data_ptr(), n, Ac.shape[0], Bc.shape[0], mode, _lib.stream_ptr(A.device)),
+                   "como_se3_compose")
+        return out
+    if mode == 1:
+        return invertSE3(A) @ B
+    if mode == 2:
+        return A @ invertSE3(B)
+    return A @ B
+
+
 def adjoint_matrix(T):
     R = T[:, :3, :3]
     Ad = torch.zeros((T.shape[0], 6, 6), dtype=T.dtype, device=T.device)

@@ -1,17 +1,17 @@
 """Rigid-transform helpers (reference como/geometry/transforms.py:6-39)."""
 import torch
 
-from como_amd.geometry.lie_algebra import invertSE3, skew_symmetric
+from como_amd.geometry.lie_algebra import composeSE3, invertSE3, skew_symmetric  # noqa: F401
 
 
 def get_T_w_curr(T_w_ref, T_curr_ref):
     """World pose of the current frame from its pose relative to a reference frame (transforms.py:6-8)."""
-    return T_w_ref @ invertSE3(T_curr_ref)
+    return composeSE3(T_w_ref, T_curr_ref, 2)
 
 
 def get_rel_pose(pose1, pose2):
     """T_12 = T_w1^-1 T_w2 (transforms.py:11-13)."""
-    return invertSE3(pose1) @ pose2
+    return composeSE3(pose1, pose2, 1)
 
 
 def transform_points(Tji, Pi):

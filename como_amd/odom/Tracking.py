@@ -12,7 +12,7 @@ import torch
 
 from como_amd.geometry.affine_brightness import get_aff_w_curr, get_rel_aff
 from como_amd.geometry.camera import backprojection
-from como_amd.geometry.lie_algebra import invertSE3
+from como_amd.geometry.lie_algebra import composeSE3, invertSE3  # noqa: F401
 from como_amd.geometry.transforms import get_rel_pose, get_T_w_curr
 import os
 
@@ -194,7 +194,7 @@ class Tracking:
                 self.coords_pyr.append(get_test_coords((h, w), device=self.device, batch_size=b))
 
         self.P_pyr, self.dI_dT_pyr, self.mask_pyr = [], [], []
-        rel = invertSE3(kf_pose[nk - 1:nk]) @ kf_pose       # every keyframe -> the last keyframe's frame
+        rel = composeSE3(kf_pose[nk - 1:nk], kf_pose, 1)    # every keyframe -> the last keyframe's frame
         depth_pyr = self.depth_pyr_module(depth)
         pb = None
         if (depth.is_cuda and self.vals_pyr[0].shape[2] == 1 and depth.dtype == self.vals_pyr[0].dtype and

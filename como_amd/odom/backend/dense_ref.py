@@ -63,11 +63,12 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
 _di_ws = {}
 
 
-def depth_image(Kt, logzm, out=None):
+def depth_image(Kt, logzm, out=None, logz_out=None):
     """exp(K~ logz_m) for every row of K~ (Mapping.store_vars' depth images, Mapping.py:749-758; the tracker asks for the newest
     keyframe's on every frame): the depth-only pass of `como_dense_ref_*` (flag 8) -- one streaming pass over K~ at HBM rate --
     instead of a (rows x m) . (m x 1) library GEMM + exp (rocBLAS ran that GEMV shape at 0.7 TB/s: 216 us per 640x480 keyframe).
-    Kt (B,rows,m) (a view with a row stride is fine), logzm (B,m[,1]); returns (B,rows) depths (into `out` when given)."""
+    Kt (B,rows,m) (a view with a row stride is fine), logzm (B,m[,1]); returns (B,rows) depths (into `out` when given);
+    logz_out (B,rows): also receives the log-depths K~ logz_m themselves."""
     _lib.require_cuda(Kt, logzm)
     dt, dev = Kt.dtype, Kt.device
     B, rows, m = Kt.shape
@@ -87,7 +88,7 @@ def depth_image(Kt, logzm, out=None):
         lz = lz.to(dt).contiguous()
     rc = getattr(L, "como_dense_ref_" + _lib.suffix(dt))(
         Kt.data_ptr(), Kt.stride(0), None, lz.data_ptr(), w["eye"].data_ptr(), w["K"].data_ptr(), w["dl"].data_ptr(), B, rows, m, 1,
-        None, None, None, z.data_ptr(), None, w["hists"].data_ptr(), w["med"].data_ptr(), None, 8 | 2, _lib.stream_ptr(dev))
+        None, None, None, z.data_ptr(), _lib.ptr(logz_out), w["hists"].data_ptr(), w["med"].data_ptr(), None, 8 | 2, _lib.stream_ptr(dev))
     _lib.check(rc, "como_dense_ref (depth image)")
     return z
 

@@ -332,7 +332,12 @@ class WindowBA:
         if not self.window_full:
             # mean_log_depth_cost (gp_priors.py:84-150): J = column means of keyframe 0's K~ (float64 sum of the pix-dtype rows, as the
             # mirror path forms it), anchor = the initial scale, sigma = cfg mean_depth_prior; constant for this topology
-            self.mld_J = (self.Kt[0].to(self.dt).sum(0) / self.Kt.shape[1]).contiguous()
+            inh0 = getattr(self, "_inherit", None)
+            if (inh0 is not None and getattr(inh0, "mld_J", None) is not None and inh0.Kt.data_ptr() == self.Kt.data_ptr() and
+                    inh0.Kt.shape == self.Kt.shape):
+                self.mld_J = inh0.mld_J                     # same predictors (a rebuild on a one-way frame): same column means
+            else:
+                self.mld_J = (self.Kt[0].to(self.dt).sum(0) / self.Kt.shape[1]).contiguous()
             self.mld_anchor = torch.as_tensor(self.init_scale_anchor, dtype=self.dt, device=dev).reshape(-1)[:1].contiguous()
             a.mld_J, a.mld_anchor, a.s_mld = ptr(self.mld_J), ptr(self.mld_anchor), float(sg["mean_depth_prior"])
         self.win_args = a

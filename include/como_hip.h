@@ -365,6 +365,11 @@ int como_ktilde_f64(const double* cov, int Hc, int Wc, const double* xm, const d
 long como_gram_workspace_bytes(void);
 int como_gram_f64(const double* A, long row_stride, int n, int m, const double* w, const double* y, const double* c, double* AtA,
                   double* Atb, double* stats, void* workspace, como_stream_t stream);
+/* como_predictor_f64: the GP predictor of the distillation (como/depth_cov/core/distill_depth.py:30-48 get_predictor) in one pass:
+ * Kt (n x m, row stride ldo >= m, ldo <= 64; columns m .. ldo-1 are written as zeros) = Knm (n x m) inv (m x m),
+ * var (n) = diag (n) - rowsum(Knm o Kt).  float64, m <= 64. */
+int como_predictor_f64(const double* Knm, const double* inv, const double* diag, int n, int m, int ldo, double* Kt, double* var,
+                       como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense SPD solve delta = H^-1 g, float64 (python path: backend/linear_system.py:101-112 solve_system).
@@ -470,6 +475,10 @@ int como_win_update(const double* delta, double* poses, double* aff, const long*
  * transforms.py:6-13): out[i] = [R^T | -(R^T t); 0 0 0 1] for n row-major 4x4 poses (in and out may not alias). */
 int como_se3_inverse_f32(const float* T, float* out, int n, como_stream_t stream);
 int como_se3_inverse_f64(const double* T, double* out, int n, como_stream_t stream);
+/* como_se3_compose_*: out_i = op(A_i) op(B_i) for n pose pairs (4x4 row-major; na / nb = 1: that operand is one pose for all i);
+ * mode 0: A B, 1: inv(A) B (get_rel_pose, como/geometry/transforms.py:11-13), 2: A inv(B) (get_T_w_curr, transforms.py:6-8). */
+int como_se3_compose_f32(const float* A, const float* B, float* out, int n, int na, int nb, int mode, como_stream_t stream);
+int como_se3_compose_f64(const double* A, const double* B, double* out, int n, int na, int nb, int mode, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * DepthCov covariance network, float32 inference (python path: como/depth_cov/nn/UNet.py:57-78 UNet.forward,

@@ -42,6 +42,8 @@ PY
 # the whole odometry loop
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_odo -- python scripts/gpu_odometry_bench.py --frames 100 > $OUT/odometry_run.log 2>&1
 cp $(find /tmp/p_odo -name "*kernel_stats.csv" | head -1) $OUT/odometry_kernel_stats.csv
+# GPU timeline of the loop after the initialisation: busy time, gaps by length, kernel time per frame (same trace)
+python scripts/odometry_timeline.py /tmp/p_odo $OUT/odometry_timeline.txt > /dev/null 2>&1
 tail -1 $OUT/odometry_run.log > $OUT/odometry_loop_profiled.json
 COMO_ODO_BREAKDOWN=0 timeout 300 python scripts/gpu_odometry_bench.py --frames 100 > $OUT/odometry_loop.json 2> $OUT/odometry_loop.err
 # config 4's window at full size, both dtypes

@@ -238,3 +238,52 @@ def test_reproject_points_kernel_vs_torch_formulas(dt):
         rc2, P2, none = corr.reproject_and_filter(coords if coords is not None else grid.to(dt), z, T, K)
         assert none is None and float((rc2 - rc_ref).abs().max()) <= tol * W * 40 and float((P2 - P_ref).abs().max()) <= tol * 4
     report("reproject_points_kernel", dtype=str(dt), kept=int(keep.sum()), of=H * W)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,m", [(4999, 64), (307200, 61), (37, 8), (16, 1)])
+def test_predictor_kernel_vs_torch(n, m):
+    """csrc/gram.hip `como_predictor_f64` through `distill_depth.get_predictor` against the torch expressions of the reference
+    (distill_depth.py:30-48): K~ = K_nm K_mm^-1, the conditional variances and their inverse standard deviations; padded form
+    (m not a multiple of 4): the extra columns are exact zeros and the view has the padded row stride `gram_weighted` reads."""
+    from como_amd.depth_cov.core import distill_depth as dd
+    from como_amd.utils.lin_alg import chol_small
+    g = torch.Generator().manual_seed(n + m)
+    X = torch.randn((1, m, m + 3), generator=g, dtype=torch.float64)
+    K_mm = (X @ X.mT / (m + 3) + 0.5 * torch.eye(m, dtype=torch.float64)).to(DEV)
+    K_nm = torch.randn((1, n, m), generator=g, dtype=torch.float64).to(DEV)
+    diag = (10.0 + torch.rand((1, n), generator=g, dtype=torch.float64)).to(DEV) * m      # (> k^T K_mm^-1 k: positive variances)
+    inv = chol_small(K_mm, want_L=True, want_inv=True)["inv"]
+    Kt_ref = K_nm @ inv
+    var_ref = diag - torch.sum(K_nm * Kt_ref, dim=2)
+    var_ref = var_ref + (torch.min(var_ref) + 1e-8)
+    sinv_ref = 1.0 / torch.sqrt(var_ref.unsqueeze(-1))
+    for pad4 in (False, True):
+        Kt, L_mm, sinv = dd.get_predictor(K_mm, K_nm, diag, pad4=pad4)
+        scale = float(Kt_ref.abs().max())
+        assert Kt.shape == (1, n, m) and float((Kt - Kt_ref).abs().max()) <= 1e-13 * scale * m
+        assert float(((sinv - sinv_ref) / sinv_ref).abs().max()) <= 1e-9
+        full = dd.padded_predictor(Kt)
+        if pad4 and m % 4:
+            assert full.shape[2] == (m + 3) // 4 * 4 and float(full[:, :, m:].abs().max()) == 0.0 and Kt.stride(1) == full.shape[2]
+        else:
+            assert full is Kt
+    report("predictor_kernel", n=n, m=m, max_abs_err=float((Kt - Kt_ref).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float64, torch.float32])
+def test_se3_compose_kernel_vs_torch(dt):
+    """csrc/window.hip `como_se3_compose_*` (lie_algebra.composeSE3) against the torch forms of get_rel_pose / get_T_w_curr
+    (reference transforms.py:6-13): inv(A) B and A inv(B) for batches and broadcast operands."""
+    from como_amd import synth
+    from como_amd.geometry.lie_algebra import composeSE3, invertSE3
+    g = torch.Generator().manual_seed(4)
+    A = synth.se3_exp(0.3 * torch.randn((7, 6), generator=g, dtype=torch.float64)).to(dt).to(DEV)
+    B = synth.se3_exp(0.3 * torch.randn((7, 6), generator=g, dtype=torch.float64)).to(dt).to(DEV)
+    tol = 1e-14 if dt == torch.float64 else 1e-6
+    for a, b in ((A, B), (A[:1], B), (A, B[3:4])):
+        for mode, ref in ((0, a @ b), (1, invertSE3(a) @ b), (2, a @ invertSE3(b))):
+            out = composeSE3(a, b, mode)
+            assert out.shape == ref.shape and float((out - ref).abs().max()) <= tol * 4
+            assert torch.equal(out[:, 3], torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=dt, device=DEV).expand(out.shape[0], 4))
