@@ -128,6 +128,8 @@ SIGNATURES = {
     "como_nn_cov_act_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "como_nn_resize_aa_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "como_nn_resize_aa_f64": (c_int, [c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "como_rgb_to_gray_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
+    "como_rgb_to_gray_f64": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),
     "como_img_grads_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "como_img_grads_f64": (c_int, [c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "como_img_blur_down_f32": (c_int, [c_void_p, c_void_p] + [c_int] * 3 + [c_void_p]),

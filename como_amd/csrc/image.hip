@@ -37,6 +37,21 @@ __global__ __launch_bounds__(256) void img_grads_kernel(const T* __restrict__ im
   o[(long)(2 * C + c) * HW + pix] = gy;
 }
 
+// ITU-R 601-2 luma of (N,3,H,W) colour images -> (N,1,H,W): (0.2989 r + 0.587 g) + 0.114 b with every product and sum rounded on
+// its own, i.e. the five elementwise launches of the torch expression (utils/image_processing.py rgb_to_grayscale; the reference
+// calls torchvision's in Mapping.get_img_and_grads / Tracking.prep_tracking_img, on every frame) in one.
+template <typename T>
+__global__ __launch_bounds__(256) void rgb_to_gray_kernel(const T* __restrict__ rgb, T* __restrict__ out, long HW, long total) {
+#pragma clang fp contract(off)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long n = i / HW, p = i - n * HW;
+  const T* c = rgb + n * 3 * HW + p;
+  const T r = c[0], g = c[HW], b = c[2 * HW];
+  const T s = T(0.2989) * r + T(0.587) * g;
+  out[i] = s + T(0.114) * b;
+}
+
 // out (NC, ceil(H/2), ceil(W/2)) = blur(img)[0::2, 0::2]
 template <typename T>
 __global__ __launch_bounds__(256) void blur_down_kernel(const T* __restrict__ img, T* __restrict__ out, int H, int W, int Ho,
@@ -165,6 +180,14 @@ extern "C" {
     const long total = (long)N * C * H * W;                                                                            \
     hipLaunchKernelGGL(como::img_grads_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,                 \
                        (hipStream_t)stream, img, out, C, H, W, total);                                                 \
+    COMO_CHECK_LAUNCH();                                                                                               \
+    return COMO_OK;                                                                                                    \
+  }                                                                                                                    \
+  int como_rgb_to_gray_##SFX(const T* rgb, T* out, int N, int H, int W, como_stream_t stream) {                        \
+    if (!rgb || !out || N <= 0 || H <= 0 || W <= 0) return COMO_ERR_ARG;                                               \
+    const long HW = (long)H * W, total = (long)N * HW;                                                                 \
+    hipLaunchKernelGGL(como::rgb_to_gray_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,               \
+                       (hipStream_t)stream, rgb, out, HW, total);                                                      \
     COMO_CHECK_LAUNCH();                                                                                               \
     return COMO_OK;                                                                                                    \
   }                                                                                                                    \

@@ -134,5 +134,14 @@ class IntrinsicsPyramidModule:
 def rgb_to_grayscale(rgb):
     """ITU-R 601-2 luma of a (..,3,H,W) image, the weights torchvision's functional.rgb_to_grayscale applies (the reference
     calls it in Mapping.get_img_and_grads / Tracking.prep_tracking_img)."""
+    if rgb.is_cuda and rgb.dtype in (torch.float32, torch.float64) and rgb.dim() == 4 and rgb.shape[1] == 3 and rgb.numel() > 0:
+        # one launch (csrc/image.hip rgb_to_gray_kernel: the same five roundings) instead of five: this runs on every frame
+        from como_amd import _lib
+        x = rgb.contiguous()
+        n, _, h, w = x.shape
+        out = torch.empty((n, 1, h, w), dtype=x.dtype, device=x.device)
+        _lib.check(getattr(_lib.lib(), "como_rgb_to_gray_" + _lib.suffix(x.dtype))(x.data_ptr(), out.data_ptr(), n, h, w, _lib.stream_ptr(x.device)),
+                   "como_rgb_to_gray")
+        return out
     r, g, b = rgb.unbind(dim=-3)
     return (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(-3)

@@ -524,6 +524,10 @@ int como_nn_resize_aa_f64(const double* in, double* out, int NC, int Hi, int Wi,
  *  track_precalc_jac: dI_dw (N,2), P (N,3), vals (N), K (3,3) -> J (N,8), c = 1. */
 int como_img_grads_f32(const float* img, float* out, int N, int C, int H, int W, como_stream_t stream);
 int como_img_grads_f64(const double* img, double* out, int N, int C, int H, int W, como_stream_t stream);
+/* rgb_to_gray: (N,3,H,W) -> (N,1,H,W), ITU-R 601-2 luma (0.2989 r + 0.587 g) + 0.114 b, each operation rounded on its own
+ * (torchvision's rgb_to_grayscale as the reference calls it in Mapping.get_img_and_grads / Tracking.prep_tracking_img). */
+int como_rgb_to_gray_f32(const float* rgb, float* out, int N, int H, int W, como_stream_t stream);
+int como_rgb_to_gray_f64(const double* rgb, double* out, int N, int H, int W, como_stream_t stream);
 int como_img_blur_down_f32(const float* img, float* out, int NC, int H, int W, como_stream_t stream);
 int como_img_blur_down_f64(const double* img, double* out, int NC, int H, int W, como_stream_t stream);
 /* img_blur: the same blur without decimation (GaussianBlurModule); depth_pool2: pyr_depth (como/data/depth_resize.py:6-36)

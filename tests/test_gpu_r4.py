@@ -287,3 +287,18 @@ def test_se3_compose_kernel_vs_torch(dt):
             out = composeSE3(a, b, mode)
             assert out.shape == ref.shape and float((out - ref).abs().max()) <= tol * 4
             assert torch.equal(out[:, 3], torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=dt, device=DEV).expand(out.shape[0], 4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.float64])
+def test_rgb_to_gray_kernel_equals_torch_expression(dt):
+    """csrc/image.hip `como_rgb_to_gray_*` = the five-launch torch expression of rgb_to_grayscale, bit for bit (same products and
+    sums, each rounded on its own)."""
+    from como_amd.utils.image_processing import rgb_to_grayscale
+    g = torch.Generator().manual_seed(2)
+    rgb = torch.rand((2, 3, 37, 53), generator=g, dtype=torch.float64).to(dt).to(DEV)
+    r, gg, b = rgb.unbind(dim=-3)
+    ref = (0.2989 * r + 0.587 * gg + 0.114 * b).unsqueeze(-3)
+    out = rgb_to_grayscale(rgb)
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    assert torch.equal(rgb_to_grayscale(rgb.cpu()), ref.cpu())
