@@ -33,6 +33,33 @@ for s, e, n in post[1:]:
 busy = (busy + cur_e - cur_s) / 1e3
 print("post-init: %d dispatches over %.1f tracked frames: span %.1f us/frame, busy %.1f us/frame (%.0f %%), sum of durations %.1f us/frame, "
       "%.0f dispatches/frame" % (len(post), nfr, span / nfr, busy / nfr, 100 * busy / span, dur / nfr, len(post) / nfr), file=out)
+def shares(rs, label):
+    tot = sum(e - s for s, e, _ in rs) / 1e6
+    como = sum(e - s for s, e, n in rs if "como::" in n) / 1e6
+    blas = sum(e - s for s, e, n in rs if n.startswith("Cijk")) / 1e6
+    cp = sum(e - s for s, e, n in rs if "copyBuffer" in n or "fillBuffer" in n) / 1e6
+    print("%s: %d dispatches, %.1f ms of kernel time: como:: %.1f ms (%.0f %%), library GEMMs %.1f ms, copy / fill %.1f ms, other torch "
+          "kernels %.1f ms" % (label, len(rs), tot, como, 100 * como / tot, blas, cp, tot - como - blas - cp), file=out)
+
+
+shares(rows, "whole run")
+shares(post, "after the initialisation")
+# frames by kind: a frame = the dispatches from one level-0 tracking launch to the next; keyframe insertions and one-way frames
+# (window rebuild) are told apart by their dispatch count
+tl = [i for i, r in enumerate(rows) if "track_level" in r[2]][::3]
+kinds = {"plain tracked frame": [], "one-way frame + window rebuild": [], "keyframe insertion": []}
+for a, b in zip(tl[:-1], tl[1:]):
+    prev, fb = rows[a][0], 0
+    for s, e, _ in rows[a:b]:
+        if e > prev:
+            fb += e - max(s, prev)
+            prev = e
+    k = "keyframe insertion" if b - a > 400 else ("one-way frame + window rebuild" if b - a > 105 else "plain tracked frame")
+    kinds[k].append((fb / 1e3, b - a))
+for k, v in kinds.items():
+    if v:
+        print("%-32s %3d frames: GPU busy %7.0f us, %5.0f dispatches per frame" % (k, len(v), sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v)), file=out)
+print("", file=out)
 cls = [(0, 2), (2, 5), (5, 10), (10, 20), (20, 50), (50, 100), (100, 300), (300, 1000), (1000, 1e9)]
 for lo, hi in cls:
     g = [x for x in gaps if lo <= x[0] < hi]
