@@ -58,7 +58,10 @@ class ComoSeq:
     def iter(self, timestamp, rgb):
         trk, mp = self.tracking, self.mapping
         if mp.is_init:
-            viz, to_map = trk.track(transfer_data((timestamp, rgb.clone()), trk.device, trk.dtype))
+            # (the tracker gets its own copy of the frame: the conversion to its element type already is one -- a clone first only
+            # when there is no conversion)
+            own = rgb if rgb.dtype != trk.dtype else rgb.clone()
+            viz, to_map = trk.track(transfer_data((timestamp, own), trk.device, trk.dtype))
             self.timestamps.append(viz[0])
             self.est_poses.append(viz[1])
         else:
