@@ -127,12 +127,16 @@ class Mapping:
             pix = name + "_pix"
             if getattr(self, pix, None) is None or (old.numel() == 0 and old.dim() == 1):
                 setattr(self, pix, torch.empty((0), device=new_var.device, dtype=self.pix_dtype))
-            self._cat(pix, new_var.to(self.pix_dtype), i)
+            if name == "Knm_Kmminv":
+                # (157 MB per keyframe: converted by the copy into the window buffer itself, not into a temporary first)
+                self._cat_sliding(pix, getattr(self, pix), new_var, i, dtype=self.pix_dtype)
+            else:
+                self._cat(pix, new_var.to(self.pix_dtype), i)
         if name.startswith("Knm_Kmminv") and new_var.is_cuda:
             return self._cat_sliding(name, old, new_var, i)
         setattr(self, name, new_var.clone() if old.numel() == 0 and old.dim() == 1 else torch.cat((old[i:, ...], new_var), dim=0))
 
-    def _cat_sliding(self, name, old, new_var, i):
+    def _cat_sliding(self, name, old, new_var, i, dtype=None):
         """The dense predictors K~ are 157 MB per keyframe at 640x480 (float64): `torch.cat` of a growing window asks the allocator
         for a new, larger block on every keyframe (a hipMalloc of > 1 GB: ~12 ms each while the window fills), and copying the kept
         keyframes into a second buffer moved 1.3 GB (+ the pixel-type mirror) per keyframe (0.55 ms).  ONE buffer of twice the
@@ -143,9 +147,10 @@ class Mapping:
         store = self.__dict__.setdefault("_kt_pp", {})              # per window tensor (K~ and its pixel-type mirror)
         st = store.get(name)
         n_new = new_var.shape[0]
-        if (st is None or st["buf"].shape[1:] != new_var.shape[1:] or st["buf"].dtype != new_var.dtype or st["buf"].shape[0] != 2 * cap or
+        dtype = dtype or new_var.dtype                              # (the window's element type: the copy below converts)
+        if (st is None or st["buf"].shape[1:] != new_var.shape[1:] or st["buf"].dtype != dtype or st["buf"].shape[0] != 2 * cap or
                 st["buf"].device != new_var.device):
-            st = store[name] = {"buf": torch.empty((2 * cap,) + tuple(new_var.shape[1:]), dtype=new_var.dtype, device=new_var.device),
+            st = store[name] = {"buf": torch.empty((2 * cap,) + tuple(new_var.shape[1:]), dtype=dtype, device=new_var.device),
                                 "start": 0, "count": 0}
         buf = st["buf"]
         empty = old.numel() == 0 and old.dim() == 1

@@ -184,6 +184,14 @@ def test_sliding_predictor_window_equals_cat():
     assert moves <= 23 // N + 1, moves                # the kept keyframes move only when the view reaches the end of the buffer
     with pytest.raises(RuntimeError):
         mp._cat_sliding("Knm_Kmminv", mp.Knm_Kmminv, torch.zeros((2, 5, 6, 3), dtype=torch.float64), -N)
+    # a window kept in another element type (the float32 mirror of the float64 predictors): the copy into the window converts
+    mp.Knm_Kmminv_pix = torch.empty((0), dtype=torch.float32)
+    ref32 = torch.empty((0), dtype=torch.float32)
+    for k in range(7):
+        new = torch.randn((1, 5, 6, 3), generator=g, dtype=torch.float64)
+        ref32 = new.float() if ref32.dim() == 1 else torch.cat((ref32[i:], new.float()), dim=0)
+        mp._cat_sliding("Knm_Kmminv_pix", mp.Knm_Kmminv_pix, new, i, dtype=torch.float32)
+        assert mp.Knm_Kmminv_pix.dtype == torch.float32 and torch.equal(mp.Knm_Kmminv_pix, ref32), k
 
 
 def test_fill_image_last_point_wins_like_torch_cpu():
