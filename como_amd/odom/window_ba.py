@@ -348,7 +348,7 @@ class WindowBA:
         self.overlap_priors = True
         inh = getattr(self, "_inherit", None)
         if (inh is not None and _REUSE_WORKSPACES and getattr(inh, "graph", None) is None and isinstance(getattr(inh, "w", None), dict)
-                and "dr_ws" in inh.w):
+                and "dr_ws" in inh.w and inh.m == self.m):
             # The retired window's scratch -- planes keyed by (B, n), grow-only buffers of the block chain, Cholesky workspaces keyed
             # by the system size -- is taken over instead of being allocated and zero-filled again in the first iteration (the
             # sequential loop rebuilds the window on every keyframe and one-way frame).  With the SAME predictors (a one-way frame)
