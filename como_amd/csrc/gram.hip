@@ -12,8 +12,8 @@
 // are added by the caller (an m x m product).  Lane (c, q) of a wave holds the quad A[row 4 s + q][4 c .. 4 c + 3] of step s
 // -- one fully coalesced KiB per wave load -- and feeds element t of it to column block t, exactly the operand layout of the
 // window kernels (csrc/ba.hip): ten 16x16 tiles of v_mfma_f64_16x16x4_f64 cover the upper block triangle, K = rows.
-// Two kernels: per-workgroup partial sums (fixed row ranges), then ONE workgroup adds the partials in order -> the result does
-// not depend on scheduling.
+// Two kernels: per-workgroup partial sums (fixed row ranges), then the partials are added in a fixed order (four waves per 64
+// outputs, gram_finish_kernel) -> the result does not depend on scheduling.
 #include "common.cuh"
 #include "../../include/como_hip.h"
 

@@ -132,8 +132,8 @@ def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=Non
     use_band = (BAND_MEDIAN if band is None else band) and hists is not None and part_flag != 4
     if use_band:
         st = w.get("band")
-        # the band bound is only valid for the K~ it was built from: a reused workspace with another predictor (a recycled
-        # ping-pong buffer, another row range) rebuilds the state instead of returning medians of stale row norms
+        # the band bound is only valid for the K~ it was built from: a reused workspace with another predictor (a window that
+        # slid inside its buffer, another row range) rebuilds the state instead of returning medians of stale row norms
         ident = (Kt.data_ptr(), Kt.stride(0), B, rows, m)
         init = st is None
         if st is not None and st.get("ident") != ident:
