@@ -389,3 +389,32 @@ def test_pair_table_colour_expansion():
                 seen.append(b_)
                 assert int(t.ref_slot[a]) == int(t.ref_slot[b_]) and a % c == b_ % c       # same keyframe, same channel
         assert sorted(seen) == list(range(t.b))                                          # every entry exactly once
+
+
+def test_window_state_lives_in_one_buffer_and_snapshot_is_a_copy():
+    """WindowBA keeps poses | affine parameters | landmarks | median depths in ONE buffer (`state_flat`; the kernels get pointers into
+    it) so that the sequential loop publishes the state with one copy: the named tensors are views of it at 16-byte steps, and
+    `snapshot_state` returns equal but independent tensors."""
+    import copy
+    from como_amd import synth
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    B, m = 3, 16
+    eye = torch.eye(m, dtype=torch.float64)[None].repeat(B, 1, 1)
+    g = torch.Generator().manual_seed(0)
+    st = synth.make_window(B=B, H=48, W=64, m=m, dtype=torch.float64, device="cpu", seed=1,
+                           predictor=lambda cov, cm: (eye, eye, torch.rand((B, 48, 64, m), generator=g, dtype=torch.float64)))
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = 4
+    w = WindowBA(st, cfg=cfg, pix_dtype=torch.float64, window_full=True, fused=False)
+    base = w.state_flat.data_ptr()
+    for t in (w.poses_all, w.aff_all, w.P_m, w.median_depths):
+        off = t.data_ptr() - base
+        assert 0 <= off < w.state_flat.numel() * 8 and off % 16 == 0 and t.is_contiguous()
+    assert torch.equal(w.P_m, st["P_m"]) and w.P_m.data_ptr() != st["P_m"].data_ptr()        # (a copy: the caller's tensor is not updated in place)
+    assert torch.equal(w.kf_poses, st["kf_poses"]) and torch.equal(w.median_depths, st["median_depth_init"])
+    sn = w.snapshot_state()
+    assert torch.equal(sn["poses"], w.poses_all) and torch.equal(sn["aff"], w.aff_all) and torch.equal(sn["P_m"], w.P_m)
+    w.poses_all[0, 0, 3] += 1.0
+    w.P_m[0, 0] -= 1.0
+    assert float(w.state_flat[3]) == float(w.poses_all[0, 0, 3]) and not torch.equal(sn["poses"], w.poses_all) and not torch.equal(sn["P_m"], w.P_m)
+    assert sn["poses"].dtype == torch.float64 and w.snapshot_state(torch.float32)["poses"].dtype == torch.float32
