@@ -18,6 +18,7 @@ _ws = {}
 BLOCK_VARIANT = int(__import__("os").environ.get("COMO_BA_VARIANT", "0"))   # 0 = software-pipelined block kernel, 1 = plain
 CHUNKS_OVERRIDE = int(__import__("os").environ.get("COMO_BA_CHUNKS", "0"))   # tuning runs: pixel chunks per pair group
 BLOCK_STAGGER = int(__import__("os").environ.get("COMO_BA_STAGGER", "0"))
+MIN_TILES_PER_CHUNK = int(__import__("os").environ.get("COMO_BA_MIN_TILES", "0"))   # > 0: lower bound on a chunk's 64-pixel tiles (opt-in, see linearize)
 last_aux = {}   # diagnostics of the most recent call: valid mask, sigma, nvalid (tests / callers that want them)
 
 
@@ -87,6 +88,18 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
             chunks = default_chunks(grp_pairs.shape[0], nl, dtype, per_cu=1)
         else:
             chunks = default_chunks(b, nl, dtype)
+        if grp_pairs is not None and grp_pairs.numel() > 0 and zmode == 2:
+            # OPT-IN (COMO_BA_MIN_TILES=8; default 0 = off): a lower bound on a chunk's 64-pixel tiles for sub-selected windows
+            # (n = 19,200 = 300 tiles at window 4).  Measured, same box: the window-4 bench legs gain 4 % with 8 tiles per chunk (75 -> 38
+            # chunks: float64 block kernel 96.6 -> 81.3 us, 2083 -> 2160 it/s; float32 2443 -> 2540 it/s, the assembly reduces half the
+            # partial records) but the sequential loop LOSES 4 % (447 -> 427 frames/s): its filling windows have one to three pair groups,
+            # too few workgroups already, and fatter ones only stretch the kernel.  The bound below (never fewer than one workgroup per
+            # CU because of the rule) was written for that and could not be measured any more in round 4 -- hence off by default.
+            if MIN_TILES_PER_CHUNK > 0:
+                tiles = (nl + 63) // 64
+                ngrp = max(1, int(grp_pairs.shape[0]))
+                lowest = max((tiles + MIN_TILES_PER_CHUNK - 1) // MIN_TILES_PER_CHUNK, (256 + ngrp - 1) // ngrp)
+                chunks = int(max(1, min(chunks, lowest)))
     a = _lib.BAArgs()
     a.b, a.n, a.m, a.H, a.W, a.zmode, a.chunks, a.phase = b, n, m, H_img, W_img, zmode, chunks, phase
     a.pix_begin, a.pix_end = pb, pe
