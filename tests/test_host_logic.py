@@ -418,3 +418,28 @@ def test_window_state_lives_in_one_buffer_and_snapshot_is_a_copy():
     w.P_m[0, 0] -= 1.0
     assert float(w.state_flat[3]) == float(w.poses_all[0, 0, 3]) and not torch.equal(sn["poses"], w.poses_all) and not torch.equal(sn["P_m"], w.P_m)
     assert sn["poses"].dtype == torch.float64 and w.snapshot_state(torch.float32)["poses"].dtype == torch.float32
+
+
+def test_cached_coordinate_helpers_and_pose_composition_equal_the_plain_forms():
+    """Host-side helpers of the keyframe path: the cached normalisation constants / pixel grids return what the uncached
+    expressions give (reference como/utils/coords.py:12-15, 31-36), and `composeSE3`'s torch form (CPU tensors; the GPU path is
+    `como_se3_compose_*`) equals get_rel_pose / get_T_w_curr as the reference writes them (transforms.py:6-13)."""
+    from como_amd import synth
+    from como_amd.geometry.lie_algebra import composeSE3, invertSE3
+    from como_amd.geometry.transforms import get_rel_pose, get_T_w_curr
+    from como_amd.utils.coords import get_test_coords, normalize_coordinates
+    g = torch.Generator().manual_seed(5)
+    x = 200.0 * torch.rand((1, 37, 2), generator=g, dtype=torch.float64)
+    for dims in ((192, 256), torch.Size((480, 640)), [48, 64]):
+        A = 1.0 / torch.as_tensor([float(d) for d in dims], dtype=torch.float64)
+        ref = 2 * A * x + A - 1
+        assert torch.equal(normalize_coordinates(x, dims), ref) and torch.equal(normalize_coordinates(x, dims), ref)   # (second call: cached)
+        assert torch.equal(normalize_coordinates(x.float(), dims), 2 * A.float() * x.float() + A.float() - 1)
+    c1, c2 = get_test_coords((5, 7), "cpu"), get_test_coords((5, 7), "cpu")
+    assert c1 is c2 and c1.shape == (1, 35, 2) and c1[0, 8].tolist() == [1, 1] and c1[0, -1].tolist() == [4, 6]
+    assert get_test_coords((5, 7), "cpu", batch_size=2).shape == (2, 35, 2)
+    A = synth.se3_exp(0.3 * torch.randn((4, 6), generator=g, dtype=torch.float64))
+    B = synth.se3_exp(0.3 * torch.randn((4, 6), generator=g, dtype=torch.float64))
+    assert torch.equal(composeSE3(A, B, 1), invertSE3(A) @ B) and torch.equal(composeSE3(A[:1], B, 2), A[:1] @ invertSE3(B))
+    assert torch.equal(get_rel_pose(A, B), invertSE3(A) @ B) and torch.equal(get_T_w_curr(A, B), A @ invertSE3(B))
+    assert float((get_rel_pose(A, A) - torch.eye(4, dtype=torch.float64)).abs().max()) < 1e-14
