@@ -1477,6 +1477,7 @@ __device__ __forceinline__ void lds_barrier() {      // this wave's LDS traffic 
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+#ifdef COMO_AB_VARIANTS   // the wave-specialised float64 kernel LOST (0.66-0.78 ms against 0.58): kept for measurement builds only
 template <int PFZ, int PFT, int WPS>   // depth of the K~ register ring of consumer Z / T (steps of 4 pixels; divides 16), waves / SIMD
 __global__ __launch_bounds__(192, WPS) void ba_blocks_ws_f64_kernel(
     const double* __restrict__ Pwn, const double* __restrict__ vals, const double* __restrict__ dlz,
@@ -1807,6 +1808,7 @@ __global__ __launch_bounds__(192, WPS) void ba_blocks_ws_f64_kernel(
     }
   }
 }
+#endif  // COMO_AB_VARIANTS
 
 // ---------------------------------------- stage 2 ------------------------------------------------
 // One thread per record element: fixed-order fp64 sum over the pair's wave partials, then the
@@ -2084,11 +2086,18 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
       (const float*)pair_aff, (const float*)pair_ref, (const float*)A->img_base, (const float*)A->K, A->H, A->W, n, m,  \
       pb, pe, chunk_len, hists, (float*)A->ws_partials, (float*)A->sigma_out, A->stagger, MAP
       if constexpr (sizeof(T) == 4) {
-        // variant 0: two waves per SIMD (no spills); 3: one wave per SIMD; 11 / 12: timing ablations; 2: one pair at a time
+        // variant 0: two waves per SIMD (no spills).  Measurement builds only (-DCOMO_AB_VARIANTS, `python -m como_amd.build --ab`):
+        // 3: one wave per SIMD; 11 / 12: timing ablations; 2: one pair at a time
+#ifdef COMO_AB_VARIANTS
         if (A->variant == 3) { hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 1>), PIPE_ARGS(b, (const int*)nullptr)); }
         else if (A->variant == 11) { hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2, 1>), PIPE_ARGS(b, (const int*)nullptr)); }
         else if (A->variant == 12) { hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2, 2>), PIPE_ARGS(b, (const int*)nullptr)); }
-        else if (A->variant != 2 && grouped && (A->nsingle == 0 || A->single_pairs)) {
+        else if (A->variant == 2) { hipLaunchKernelGGL((ba_blocks_pipe_kernel<float, 2>), PIPE_ARGS(b, (const int*)nullptr)); }
+        else
+#else
+        if (A->variant != 0) return COMO_ERR_ARG;          // (variant 1 = the plain kernel was taken above)
+#endif
+        if (grouped && (A->nsingle == 0 || A->single_pairs)) {
           // pairs that share their reference keyframe go through the two-pair kernel, the rest through the one-pair kernel
           // two waves per SIMD and a 4-deep K~ ring (256 VGPRs): 329 us; one wave per SIMD with an 8-deep ring: 371 us
           hipLaunchKernelGGL((ba_blocks_pair2_kernel<2, 4>), dim3(chunks, A->ngrp), blk, 0, s, (const float*)A->Pwn,
@@ -2117,6 +2126,14 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
       (const double*)A->zjac, A->pixidx, (const double*)A->invz, A->kt_slot_stride, pr, (const double*)pair_T,          \
       (const double*)pair_aff, (const double*)pair_ref, (const double*)A->img_base, (const double*)A->K, A->H, A->W, n,  \
       m, pb, pe, chunk_len, hists, (double*)A->ws_partials, (double*)A->sigma_out, A->grp_pairs
+#ifndef COMO_AB_VARIANTS
+        if (A->variant != 0) return COMO_ERR_ARG;          // (variant 1 = the plain kernel was taken above)
+        if (grouped && A->nsingle == 0 && fits32) {
+          hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<4, true, 1>), F64_ARGS);
+        } else {
+          LAUNCH_BLOCKS(2);
+        }
+#else
         if (A->variant != 2 && grouped && A->nsingle == 0 && fits32) {
           if (A->variant == 0) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<4, true, 1>), F64_ARGS); }
           else if (A->variant == 13) { hipLaunchKernelGGL((ba_blocks_pair2_f64_kernel<4, true, 1, true>), F64_ARGS); }
@@ -2141,6 +2158,7 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
         } else {
           LAUNCH_BLOCKS(2);
         }
+#endif
 #undef F64_ARGS
       }
 #undef PIPE_ARGS

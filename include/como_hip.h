@@ -408,7 +408,7 @@ int como_trsm_lower_f64(const double* L, const double* Bm, double* X, int B, int
 
 /* ------------------------------------------------------------------------------------------------
  * Fused O(B*m) bookkeeping of one window GN iteration (python path: Mapping.prep_geometry_scaffold
- * Mapping.py:603-659 + sparse_map.py:18-60; the prior factors of Mapping.iterate :809-917 = odom/factors/*.py;
+ * Mapping.py:603-659 + sparse_map.py:18-60; the prior factors of Mapping.iterate :809-917 = the files of odom/factors/;
  * linear_system.update_vars :115-152).  All state is float64; px_* are mirrors in the per-pixel dtype. */
 typedef struct como_win_args {
   int B, F, m, L, nfix;          /* keyframes, frames (keyframes + recent), inducing points per KF, landmarks, anchored landmarks */

@@ -12,6 +12,8 @@ def run_ate_sequence(G, pix="float", dev="cuda:0"):
     from como_amd.odom.sequential import ComoSeq
     H, W, n, seed = int(G["H"]), int(G["W"]), int(G["nframes"]), int(G["seed"])
     colour = bool(int(G["colour"])) if "colour" in G else False       # `color: rgb`: one texture per channel
+    # network input: the image size in the small fixtures, the reference's fixed 192 x 256 in the 640 x 480 one (Mapping.py:399)
+    net = [int(x) for x in G["network_size"]] if "network_size" in G else [H, W]
     scenes = [synth.PlaneScene(seed=seed + 1000 * ch, freq_scale=W / 640.0) for ch in range(3 if colour else 1)]
     K = synth.intrinsics_for(H, W)
     T = synth.gt_poses(n, step=float(G["step"]), deg=float(G["deg"]))
@@ -22,7 +24,7 @@ def run_ate_sequence(G, pix="float", dev="cuda:0"):
             "sigmas": {"photo": 1.0e-1},
             "keyframing": {"kf_depth_motion_ratio": 0.12, "kf_num_pixels_frac": 0.75, "one_way_freq": 3}}
     mcfg = {"device": dev, "dtype": "double", "pix_dtype": pix, "color": "rgb" if colour else "gray", "track_ref": {"num_keyframes": 1},
-            "graph": {"num_keyframes": 9, "num_one_way_frames": 24}, "network_size": [H, W], "graph_network": False,
+            "graph": {"num_keyframes": 9, "num_one_way_frames": 24}, "network_size": net, "graph_network": False,
             "photo_construction": {"nonmax_suppression_window": 4, "pairwise_batch_size": 128, "radius_thresh": 0.0,
                                    "degrees_thresh": 0.0},
             "term_criteria": {"max_iter": 20, "delta_norm": 1.0e-8, "abs_tol": 1.0e-6, "rel_tol": 1.0e-6},

@@ -1,28 +1,37 @@
-"""At which frame does the two-frame initialisation of the rendered 640x480 bench sequence succeed?  (development aid)"""
-import os, sys
+"""Development aid (GPU box): what the HIP loop's two-frame initialisation sees on the first frames of the rendered 640x480
+sequence of tests/golden/ate_sequence_640.npz -- per frame: overlap fraction, |t|, median depth, the decision.  The same numbers
+of the reference's loop: scripts/init_diag_ref.py (build container).   python scripts/init_diag.py [frames] [step] [deg] [seed]"""
+import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import argparse
 import torch
-from como_amd import synth
-from como_amd.depth_cov.core.DepthCovModule import DepthCovModule
-from como_amd.odom.sequential import ComoSeq
-from scripts.gpu_odometry_bench import cfgs
-dev = "cuda:0"
-H, W, frames = 480, 640, 14
-scene = synth.PlaneScene(seed=1, freq_scale=1.0)
-K = synth.intrinsics_for(H, W)
-T = synth.gt_poses(frames, step=0.01, deg=0.3)
-g = torch.Generator().manual_seed(1)
-rgbs = []
-for k in range(frames):
-    I, _ = scene.render(T[k], K, H, W)
-    I = I + 0.002 * torch.randn(I.shape, generator=g, dtype=torch.float64)
-    rgbs.append(I[None, None].repeat(1, 3, 1, 1).to(dev))
-model = DepthCovModule({k: v.to(dev) for k, v in synth.depthcov_state_dict(0).items()})
-odo = ComoSeq(cfgs(dev, argparse.Namespace(pix="float")), K.clone(), (H, W), model)
-first = None
-for k in range(frames):
-    odo.iter(1.0 + 0.033 * k, rgbs[k])
-    if first is None and odo.mapping.is_init:
-        first = k
-print("init at frame", first, {k: os.environ.get(k) for k in ("COMO_SE3_KERNEL", "COMO_GRAM_KERNEL", "COMO_PIX_MIRRORS", "COMO_CHOL_SMALL_FAST")}, flush=True)
+from como_amd.odom.frontend import TwoFrameSfm as tfm
+from como_amd.utils.coords import fill_image
+from scripts.ate_sequence import run_ate_sequence
+
+nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 9
+step = float(sys.argv[2]) if len(sys.argv) > 2 else 0.01
+deg = float(sys.argv[3]) if len(sys.argv) > 3 else 0.3
+seed = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+orig = tfm.TwoFrameSfm.handle_frame
+
+
+def handle_frame(self, rgb, timestamp):
+    had = self.has_reference
+    out = orig(self, rgb, timestamp)
+    if had:
+        T, depth = out[1], out[5]
+        reproj = fill_image(out[4], depth, self.img_and_grads[-1].shape[-2:])
+        seen = torch.count_nonzero(~torch.isnan(reproj)).item()
+        print(f"DIAG ts {timestamp}: is_init {out[0]} has_ref_after {self.has_reference} seen/px {seen}/{self.vals_pyr[-1].shape[2]} "
+              f"|t| {torch.linalg.norm(T[:, :3, 3]).item():.6f} med_depth {torch.median(depth).item():.6f} "
+              f"mean_logd {float(out[6]):.6f} t {T[0, :3, 3].tolist()}", flush=True)
+    else:
+        print(f"DIAG ts {timestamp}: new reference; coords_m[:3] {self.coords_m[0, :3].tolist()}", flush=True)
+    return out
+
+
+tfm.TwoFrameSfm.handle_frame = handle_frame
+G = {"H": 480, "W": 640, "nframes": nframes, "seed": seed, "step": step, "deg": deg, "colour": 0, "network_size": [192, 256]}
+kinds, poses, odo = run_ate_sequence(G, os.environ.get("PIX", "double"))
+print("kinds", kinds)

@@ -382,7 +382,7 @@ def ate_frames(nframes, H, W, seed, step, deg, colour=False):
     return K, T, rgbs
 
 
-def ate_case(seed=17, H=192, W=256, nframes=72, step=0.02, deg=0.4, colour=False):
+def ate_case(seed=17, H=192, W=256, nframes=72, step=0.02, deg=0.4, colour=False, network_size=None):
     """"ATE vs ref" (BASELINE.json metric): the reference's OWN sequential odometry loop (sequential/ComoSeq.py without the
     GUI: TrackingSeq.track -> MappingSeq.map per frame) on a rendered 72-frame sequence at the reference's native network
     resolution 192x256 with the parameters of config/como.yml (9-keyframe window, 24 one-way frames, 64 inducing points,
@@ -406,15 +406,16 @@ def ate_case(seed=17, H=192, W=256, nframes=72, step=0.02, deg=0.4, colour=False
     mp = MappingSeq(mcfg, K.clone())
     mp.init_basic_vars()
     mp.cov_level = -1
-    mp.network_size = torch.tensor([H, W])
-    mp.network_size_list = [H, W]
+    # the reference fixes the network input at 192 x 256 (Mapping.py:399-400); the small cases run the network at image size
+    mp.network_size = torch.tensor(list(network_size) if network_size is not None else [H, W])
+    mp.network_size_list = mp.network_size.tolist()
     mp.model = model
     mp.init_keyframe_vars()
     mp.init_prior_vals()
     mp.reset_iteration_vars(new_kf=True, converged=True)
     mp.two_frame_sfm = TwoFrameSfm(mcfg, mp.intrinsics[0, :, :], model, -1, mp.network_size)
     out = {"K": K, "poses_gt": T, "seed": seed, "H": H, "W": W, "nframes": nframes, "step": step, "deg": deg,
-           "colour": int(colour)}
+           "colour": int(colour), "network_size": mp.network_size.clone()}
     kinds, poses, valid = [], [], []
     code = {None: 0, "init": 3, "keyframe": 1, "one-way": 2}
     t0 = time.time()
@@ -433,7 +434,7 @@ def ate_case(seed=17, H=192, W=256, nframes=72, step=0.02, deg=0.4, colour=False
             _, kf_ref = mp.map(to_map)
             if kf_ref is not None:
                 trk.update_kf_reference(transfer_data(kf_ref, trk.device, trk.dtype))
-            if k % 10 == 0:
+            if k % 10 == 0 or H >= 480:
                 print(f"  ate frame {k}: kind {kinds[-1]}, keyframes {mp.kf_poses.shape[0] if mp.kf_poses.dim() > 1 else 0}, {time.time() - t0:.0f} s")
     out["kinds"] = np.array(kinds)
     out["T_w_curr"] = torch.stack(poses)
@@ -489,6 +490,11 @@ if __name__ == "__main__":
         mg.save("dataset_intrinsics.npz", dataset_intrinsics_case())
     if "ate_rgb" in which:
         mg.save("ate_sequence_rgb.npz", ate_case(seed=23, H=96, W=128, nframes=40, colour=True))
+    if "ate640" in which:
+        # the sequence bench.py's `odometry_loop` times (scripts/gpu_odometry_bench.py: seed 1, step 0.01, 0.3 deg, 640 x 480,
+        # network input 192 x 256), through the reference's own sequential loop
+        mg.save("ate_sequence_640.npz", ate_case(seed=1, H=480, W=640, nframes=int(os.environ.get("ATE640_FRAMES", "48")), step=0.01,
+                                                 deg=0.3, network_size=(192, 256)))
     if "rgb" in which:
         mg.save("ba_window_rgb_f64.npz", rgb_window_case())
         mg.save("ba_window_rgb_kf_f64.npz", rgb_window_case(with_recent=False))     # keyframe pairs only: the oracle's window
