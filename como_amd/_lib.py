@@ -10,7 +10,9 @@ import os
 import torch  # noqa: F401  (must precede CDLL: shares the HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcomo_hip.so")
+# COMO_HIP_LIB: measurement scripts point this at the -DCOMO_AB_VARIANTS build (como_amd/lib_ab/libcomo_hip_ab.so); the product path
+# is the in-tree library
+LIB_PATH = os.environ.get("COMO_HIP_LIB") or os.path.join(_HERE, "lib", "libcomo_hip.so")
 _lib = None
 
 c_void_p, c_int, c_long, c_double, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_double, ctypes.c_float

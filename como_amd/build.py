@@ -2,6 +2,9 @@
 
     python -m como_amd.build            # incremental
     python -m como_amd.build --force
+    python -m como_amd.build --ab       # libcomo_hip_ab.so: the same sources with -DCOMO_AB_VARIANTS (the losing / ablation kernel
+                                        # variants of csrc/ba.hip and csrc/chol.hip, for scripts/ab/ and scripts/micro/ only;
+                                        # COMO_HIP_LIB=<path> makes como_amd._lib load it)
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the gpurun snapshot.
 """
@@ -27,19 +30,22 @@ def _deps():
     return hdr
 
 
-def build(force=False, verbose=False):
-    os.makedirs(LIBDIR, exist_ok=True)
+def build(force=False, verbose=False, ab=False):
+    libdir = os.path.join(HERE, "lib_ab") if ab else LIBDIR
+    lib = os.path.join(libdir, "libcomo_hip_ab.so") if ab else LIB
+    flags = FLAGS + (["-DCOMO_AB_VARIANTS"] if ab else [])
+    os.makedirs(libdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     newest_hdr = max(os.path.getmtime(h) for h in _deps())
     procs = []
     for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(libdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if (not force and os.path.exists(obj)
                 and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_hdr)):
             continue
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *flags, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -47,11 +53,11 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{out.decode()}")
-    if procs or not os.path.exists(LIB) or force:
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    if procs or not os.path.exists(lib) or force:
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, ab="--ab" in sys.argv))

@@ -1979,6 +1979,7 @@ __global__ __launch_bounds__(256) void sys_finalize_pack_kernel(const long long*
                                                                 int* __restrict__ info) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx == 0) *info = 0;
+  cholp_reset_sync(W, D, idx);
   if (idx < FIX_ERR_SLOTS && err8) err8[idx] = fix_value(fix[D * D + D + idx], (unsigned long long)fix[plane + D * D + D + idx]);
   if (idx >= Dp * Dp) return;
   const long i = idx / Dp, j = idx - i * Dp;
@@ -2217,7 +2218,7 @@ int como_sys_finalize_pack(const void* sysfix, long fix_plane, long D, double* H
                            int* info, como_stream_t stream) {
   if (!sysfix || !H || !g || !chol_workspace || !info || D <= 0 || D > 4000 || fix_plane < D * D + D + como::FIX_ERR_SLOTS)
     return COMO_ERR_ARG;
-  const long Dp = ((D + 1 + 31) / 32) * 32;        // como_chol_workspace_bytes' padding: whole 32-wide block columns
+  const long Dp = como::chol_dp(D);                // como_chol_workspace_bytes' padding (common.cuh)
   const long total = Dp * Dp;
   hipLaunchKernelGGL(como::sys_finalize_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      (const long long*)sysfix, fix_plane, D, H, g, err8, (double*)chol_workspace, Dp, info);

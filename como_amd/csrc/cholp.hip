@@ -1,0 +1,396 @@
+// Dense SPD solve delta = H^-1 g in ONE persistent launch (float64, 2 .. 16 column pairs: D + 1 <= 1024).
+//
+// Reference: como/odom/backend/linear_system.py:101-112 (`solve_system`: cholesky_ex + cholesky_solve).
+//
+// csrc/chol.hip eliminates one PAIR of 32-wide block columns per launch; its chain workgroup spends 17.6 us per launch of
+// which only 9.4 us are the factorisation of the next 64 x 64 diagonal block -- the rest is re-loading tiles that were on chip
+// a moment ago, three dependent panel products, and the launch boundary (dense solve).  Here the launch boundaries
+// are replaced by counters in memory and every piece of the matrix has ONE owner for the whole solve:
+//
+//   * the matrix is cut into 64 x 64 SUPER-TILES (I, J) (pair units; np = Dp / 64 pairs).  One workgroup (512 threads, one
+//     per compute unit: np^2 - 2 + ... <= 240 workgroups, all co-resident) owns one super-tile and keeps it in the accumulator
+//     registers of its 8 waves (two 16 x 16 quadrants each) from the first to the last update -- no read-modify-write of the
+//     working copy between steps.  Step s (columns of pair s): X_I = A(I, s) Vp_s^T, X_J = A(J, s) Vp_s^T with the published
+//     INVERSE of the factored diagonal pair (Vp_s = L_ss^-1, 64 x 64 lower triangular: ONE product stage instead of three
+//     dependent ones), S -= X_I X_J^T.  When column pair J is next, the owner publishes its super-tile once (it is the panel
+//     A(I, J) of every later step) and retires.
+//   * the CHAIN workgroup factors the diagonal pairs one after the other (factor_pair_lean, csrc/chol_tile.cuh), keeping the
+//     factor, its inverse and the panel of the next pair on chip: X = A(p, p-1) Vp^T, T(p, p) -= X X^T, factor, invert,
+//     publish Vp_p, next.  Its inputs A(p, p-1) and T(p, p) come from their owners one step earlier (counter chainin[p]).
+//   * the back-substitution rides along as in csrc/chol.hip: an identity block appended under H turns, super-tile by
+//     super-tile, into L^-T; the owners of the appended super-tiles (R, np-1) accumulate x_R += (L^-T)_{R,s} y_s in registers
+//     and write delta at the end -- no pass over the factor, no second launch.
+//
+// Memory protocol (measured with scripts/micro/handoff.hip, profiles/r5_handoff.txt): data that crosses workgroups is written
+// ONCE with agent-scope (sc1, write-through) stores, followed by s_waitcnt vmcnt(0), a workgroup barrier and one agent-scope
+// atomic on a counter; it is read -- after polling the counter -- with plain loads, for the first time in this launch by that
+// XCD (nothing is ever re-read after an update by another workgroup), so no stale line can sit in an XCD-private L2 and no
+// release / acquire fence (2.7 - 4.3 us / 1.5 us each, measured) is needed.  Plain stores instead of sc1 stores DO produce
+// stale reads (same measurement).  Every wait is bounded: a time-out (~2 s; workgroups not co-resident, device wedged) sets
+// the error word, every workgroup leaves, and info becomes -1.
+#include "chol_tile.cuh"
+#include "../../include/como_hip.h"
+#include <cstdlib>
+
+namespace como {
+
+constexpr int PB = 64;                 // pair / super-tile width
+constexpr int PLD = 65;                // LDS leading dimension of a super-tile (same bank pattern as CLD = 33)
+constexpr int PSZ = PB * PLD;          // one super-tile in LDS (doubles)
+constexpr int CP_THREADS = 512;           // 8 waves: wave w owns the quadrants (w >> 1, 2 (w & 1)) and (w >> 1, 2 (w & 1) + 1) of a super-tile
+constexpr int CP_LPT = PB * PB / CP_THREADS;       // elements per thread of a super-tile copy
+constexpr int CP_LDS_DOUBLES = NT2 * TSZ + 2 * PSZ + 256;     // chain: factor tiles | Vp | A;  workers: Vp | A_I | A_J | misc
+
+struct CholpArgs {
+  double* W;            // working copy (2 Dp x Dp): H lower + g row + identity pad | appended identity rows (never initialised)
+  double* Vpg;          // published pair inverses, np x [64][64]
+  double* ylast;        // y of the last pair (64)
+  unsigned* sync;       // counters (cholp_sync_words)
+  double* delta;
+  int* info;
+  int Dp, D, np;
+};
+
+#ifdef COMO_CP_PROFILE                         // scripts/micro/cholp_stamps.hip: wall-clock stamps (100 MHz) of the chain workgroup, [pair][8]
+__device__ long long* cp_stamps = nullptr;
+#define CP_STAMP(p, k) do { if (threadIdx.x == 0 && cp_stamps) cp_stamps[(p) * 8 + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define CP_STAMP(p, k) do { } while (0)
+#endif
+
+__device__ __forceinline__ unsigned cp_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// agent-scope (write-through) store: visible to the other XCDs once acknowledged
+__device__ __forceinline__ void cp_st(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ unsigned* cp_pairflag(const CholpArgs& a) { return a.sync; }
+__device__ __forceinline__ unsigned* cp_colcnt(const CholpArgs& a, int c) { return a.sync + (1 + c) * CHOLP_SYNC_STRIDE; }
+__device__ __forceinline__ unsigned* cp_chainin(const CholpArgs& a, int p) { return a.sync + (1 + a.np + p) * CHOLP_SYNC_STRIDE; }
+__device__ __forceinline__ unsigned* cp_err(const CholpArgs& a) { return a.sync + (1 + 2 * a.np) * CHOLP_SYNC_STRIDE; }
+
+// Wait until *p >= target (thread 0 polls, everybody gets the verdict).  false: timed out / another workgroup did.
+__device__ __forceinline__ bool cp_wait(const unsigned* p, unsigned target, const CholpArgs& a, volatile int* ok_s) {
+  if (threadIdx.x == 0) {
+    unsigned* errf = cp_err(a);
+    int ok = 1;
+    for (long spin = 0; cp_ld(p) < target; ++spin) {
+      if ((spin & 63) == 63 && cp_ld(errf)) { ok = 0; break; }
+      if (spin > 1500000) { atomicExch(errf, 1u); ok = 0; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) atomicCAS(a.info, 0, -1);
+    *ok_s = ok;
+  }
+  __syncthreads();
+  const bool r = *ok_s != 0;
+  __syncthreads();
+  return r;
+}
+
+// every thread has issued its sc1 stores: wait for their acknowledgement, then one arrival on each counter
+__device__ __forceinline__ void cp_signal(unsigned* c0, unsigned* c1 = nullptr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(c0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c1) __hip_atomic_fetch_add(c1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// acc[j] (+/-)= sum over the 32-wide k blocks kb0 .. kb1-1 of X[16 qr + r][k] Y[16 (qc0 + j) + r][k], j = 0, 1  (super-tiles in LDS,
+// leading dimension PLD): the NT product of csrc/chol_tile.cuh's tile_nt_mfma on 64-wide operands, two quadrants of one quadrant
+// row per wave (the X operand is read once); lane l feeds row r = l & 15, k group l >> 4.
+template <bool NEG>
+__device__ __forceinline__ void st_nt(const double* X, const double* Y, int qr, int qc0, int l, int kb0, int kb1, d4_t (&acc)[2]) {
+  const int r = l & 15, q = l >> 4, ko = 16 * (q & 1) + 8 * (q >> 1);
+  const double* x = X + (16 * qr + r) * PLD + ko;
+  const double* y0 = Y + (16 * qc0 + r) * PLD + ko;
+  const double* y1 = y0 + 16 * PLD;
+  for (int kb = kb0; kb < kb1; ++kb) {
+    double xa[8], ya[8], yb[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { xa[s] = x[32 * kb + s]; ya[s] = y0[32 * kb + s]; yb[s] = y1[32 * kb + s]; }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const double xs = NEG ? -xa[s] : xa[s];
+      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, ya[s], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, yb[s], acc[1], 0, 0, 0);
+    }
+  }
+}
+// element (row, col) inside the super-tile of accumulator register i of lane l, quadrant (qr, qc)
+__device__ __forceinline__ int srow(int qr, int l, int i) { return 16 * qr + (l >> 4) + 4 * i; }
+__device__ __forceinline__ int scol(int qc, int l) { return 16 * qc + (l & 15); }
+
+__device__ __forceinline__ void st_store(double* dst, int qr, int qc0, int l, const d4_t (&a)[2]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dst[srow(qr, l, i) * PLD + scol(qc0 + j, l)] = a[j][i];
+}
+
+// 64 x 64 block of a row-major matrix (leading dimension ld) -> LDS super-tile
+__device__ __forceinline__ void st_load(double* dst, const double* __restrict__ src, long ld) {
+  double v[CP_LPT];
+#pragma unroll
+  for (int u = 0; u < CP_LPT; ++u) { const int e = threadIdx.x + CP_THREADS * u; v[u] = src[(long)(e >> 6) * ld + (e & 63)]; }
+#pragma unroll
+  for (int u = 0; u < CP_LPT; ++u) { const int e = threadIdx.x + CP_THREADS * u; dst[(e >> 6) * PLD + (e & 63)] = v[u]; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// chain workgroup
+__device__ void cp_chain(const CholpArgs& a, double* dsm) {
+  double* sm = dsm;                               // factor tiles 0 .. 6 (CLD layout): T10 / L10, T00 / L00, T11 / L11, V0, V1, scratch
+  double* Vp = dsm + NT2 * TSZ;                   // inverse of the last factored pair, [64][PLD]
+  double* Ab = Vp + PSZ;                          // A(p, p-1) -> X
+  volatile int* ok_s = (volatile int*)(Ab + PSZ);
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, qr = wv >> 1, qc0 = 2 * (wv & 1);
+  const long Dp = a.Dp;
+  const int np = a.np, D = a.D;
+  // pair 0 straight from the working copy
+  for (int e = tid; e < 3 * CB * CB; e += CP_THREADS) {
+    const int t = e >> 10, r = (e >> 5) & 31, c = e & 31;
+    const long gr = (t == 1 ? 0 : CB) + r, gc = (t == 2 ? CB : 0) + c;     // tile 1 = (0,0), tile 0 = (1,0), tile 2 = (1,1)
+    sm[t * TSZ + r * CLD + c] = a.W[gr * Dp + gc];
+  }
+  __syncthreads();
+  for (int p = 0; p < np; ++p) {
+    CP_STAMP(p, 0);
+    if (p > 0) {
+      if (p >= 2 && !cp_wait(cp_chainin(a, p), 2u, a, ok_s)) return;
+      CP_STAMP(p, 1);
+      // A(p, p-1) and the lower quadrants of T(p, p), updated through pair p - 2 by their owners
+      st_load(Ab, a.W + (long)p * PB * Dp + (long)(p - 1) * PB, Dp);
+      d4_t tq[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (qc0 + j <= qr) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tq[j][i] = a.W[((long)p * PB + srow(qr, l, i)) * Dp + (long)p * PB + scol(qc0 + j, l)];
+        }
+      __syncthreads();
+      CP_STAMP(p, 2);
+      d4_t x[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+      st_nt<false>(Ab, Vp, qr, qc0, l, 0, qc0 < 2 ? 1 : 2, x);      // X = A Vp^T (Vp lower triangular: columns >= 32 of its rows < 32 are zero)
+      __syncthreads();
+      st_store(Ab, qr, qc0, l, x);
+      __syncthreads();
+      CP_STAMP(p, 3);
+      if (qc0 <= qr) {                                               // T -= X X^T (lower quadrants), into the factor's tiles
+        st_nt<true>(Ab, Ab, qr, qc0, l, 0, 2, tq);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (qc0 + j <= qr) {
+            const int t = qr < 2 ? 1 : (qc0 < 2 ? 0 : 2);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sm[t * TSZ + (srow(qr, l, i) & 31) * CLD + (scol(qc0 + j, l) & 31)] = tq[j][i];
+          }
+      }
+      __syncthreads();
+    }
+    CP_STAMP(p, 4);
+    factor_pair_lean(sm, true, 2 * p, (double*)nullptr, (double*)nullptr, (int)Dp, D, a.info, sm, sm + 3 * TSZ);
+    __syncthreads();
+    CP_STAMP(p, 5);
+    const double* L10 = sm;
+    const double* L00 = sm + 1 * TSZ;
+    const double* L11 = sm + 2 * TSZ;
+    const double* V0 = sm + 3 * TSZ;
+    const double* V1 = sm + 4 * TSZ;
+    double* S5 = sm + 5 * TSZ;
+    // V10 = -V1 (L10 V0): the off-diagonal block of the pair's inverse
+    if (wv < 4) {
+      d4_t y = {0.0, 0.0, 0.0, 0.0};
+      tile_mm_mfma<false, false>(L10, V0, wv, l, y);
+      tile_store_mfma(S5, wv, l, y);
+    }
+    __syncthreads();
+    if (wv < 4) {
+      d4_t v = {0.0, 0.0, 0.0, 0.0};
+      tile_mm_mfma<false, false>(V1, S5, wv, l, v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) Vp[(32 + mrow(wv, l, i)) * PLD + mcol(wv, l)] = -v[i];
+    } else {                                                         // [V0 | 0] and V1 into the 64-wide layout (zeros above the diagonals)
+      for (int e = tid - 256; e < CB * CB; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        Vp[r * PLD + c] = c <= r ? V0[r * CLD + c] : 0.0;
+        Vp[r * PLD + 32 + c] = 0.0;
+        Vp[(32 + r) * PLD + 32 + c] = c <= r ? V1[r * CLD + c] : 0.0;
+      }
+    }
+    __syncthreads();
+    CP_STAMP(p, 6);
+    {                                                                // publish Vp_p
+      double* dst = a.Vpg + (long)p * PB * PB;
+#pragma unroll
+      for (int u = 0; u < CP_LPT; ++u) { const int e = tid + CP_THREADS * u; cp_st(&dst[e], Vp[(e >> 6) * PLD + (e & 63)]); }
+    }
+    if (p == np - 1) {
+      // y of the last pair = row D of L (the appended right-hand side), columns below it; delta of the last pair's own rows:
+      // its appended super-tile is still the identity, (L^-T)_{last,last} = Vp^T
+      const int gl = D - PB * (np - 1);
+      double* yl = S5;
+      if (tid < PB) {
+        double v = 0.0;
+        if (tid < gl) v = gl < CB ? (tid < CB ? L00[gl * CLD + tid] : 0.0)
+                                  : (tid < CB ? L10[(gl - CB) * CLD + tid] : L11[(gl - CB) * CLD + tid - CB]);
+        yl[tid] = v;
+        cp_st(&a.ylast[tid], v);
+      }
+      __syncthreads();
+      if (tid < gl) {
+        double s = 0.0;
+        for (int k = 0; k < PB; ++k) s = __builtin_fma(Vp[k * PLD + tid], yl[k], s);
+        a.delta[(long)PB * (np - 1) + tid] = s;
+      }
+    }
+    cp_signal(cp_pairflag(a));
+    CP_STAMP(p, 7);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// owner of super-tile (I, J): regular (rows 64 I of the matrix, J <= I) or appended (row block R = I of the identity rows, J > I)
+__device__ void cp_worker(const CholpArgs& a, double* dsm, int I, int J, bool app) {
+  double* Vp = dsm;
+  double* AI = dsm + PSZ;
+  double* AJ = dsm + 2 * PSZ;
+  double* misc = dsm + 3 * PSZ;                   // ylast [64] | verdict word
+  volatile int* ok_s = (volatile int*)(misc + 64);
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, qr = wv >> 1, qc0 = 2 * (wv & 1);
+  const long Dp = a.Dp;
+  const int np = a.np, D = a.D;
+  const bool diag = !app && I == J;
+  const int s_first = app ? I : 0;
+  const int s_last = diag ? J - 2 : J - 1;
+  const bool lastcol = app && J == np - 1;
+  const int gl = D - PB * (np - 1);
+  const long row0 = (app ? Dp : 0) + (long)I * PB;                  // first row of the super-tile in the working copy
+  d4_t S[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+  if (!app) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) S[j][i] = a.W[(row0 + srow(qr, l, i)) * Dp + (long)J * PB + scol(qc0 + j, l)];
+  }
+  double xr = 0.0;                                                   // thread t < 64 of an owner (R, np-1): x_R[t]
+  for (int s = s_first; s <= s_last; ++s) {
+    if (s >= 1 && !cp_wait(cp_colcnt(a, s), (unsigned)(np - 1), a, ok_s)) return;
+    // panels of this step: A(I, s) (the identity for an appended row block that meets its own column pair) and A(J, s)
+    if (app && s == I) {
+#pragma unroll
+      for (int u = 0; u < CP_LPT; ++u) { const int e = tid + CP_THREADS * u; AI[(e >> 6) * PLD + (e & 63)] = (e >> 6) == (e & 63) ? 1.0 : 0.0; }
+    } else {
+      st_load(AI, a.W + row0 * Dp + (long)s * PB, Dp);
+    }
+    if (!diag) st_load(AJ, a.W + (long)J * PB * Dp + (long)s * PB, Dp);
+    if (!cp_wait(cp_pairflag(a), (unsigned)(s + 1), a, ok_s)) return;
+    st_load(Vp, a.Vpg + (long)s * PB * PB, PB);
+    __syncthreads();
+    const int kb1 = qc0 < 2 ? 1 : 2;
+    d4_t xi[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, xj[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    st_nt<false>(AI, Vp, qr, qc0, l, 0, kb1, xi);
+    if (!diag) st_nt<false>(AJ, Vp, qr, qc0, l, 0, kb1, xj);
+    __syncthreads();
+    st_store(AI, qr, qc0, l, xi);
+    if (!diag) st_store(AJ, qr, qc0, l, xj);
+    __syncthreads();
+    st_nt<true>(AI, diag ? AI : AJ, qr, qc0, l, 0, 2, S);            // S -= X_I X_J^T
+    if (lastcol && tid < PB) {                                       // x_R += (L^-T)_{R,s} y_s;  y_s = row gl of X_J (J = np - 1)
+      double acc = 0.0;
+      for (int k = 0; k < PB; ++k) acc = __builtin_fma(AI[tid * PLD + k], AJ[gl * PLD + k], acc);
+      xr += acc;
+    }
+    __syncthreads();
+  }
+  if (lastcol) {
+    // the last pair: delta_R = x_R + (S Vp_last^T) y_last
+    if (!cp_wait(cp_pairflag(a), (unsigned)np, a, ok_s)) return;
+    st_load(Vp, a.Vpg + (long)(np - 1) * PB * PB, PB);
+    if (tid < PB) misc[tid] = a.ylast[tid];
+    st_store(AI, qr, qc0, l, S);
+    __syncthreads();
+    d4_t x[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    st_nt<false>(AI, Vp, qr, qc0, l, 0, qc0 < 2 ? 1 : 2, x);
+    __syncthreads();
+    st_store(AI, qr, qc0, l, x);
+    __syncthreads();
+    if (tid < PB) {
+      double acc = 0.0;
+      for (int k = 0; k < PB; ++k) acc = __builtin_fma(AI[tid * PLD + k], misc[k], acc);
+      a.delta[(long)I * PB + tid] = xr + acc;
+    }
+    return;
+  }
+  // publish: this super-tile is the panel A(I, J) of every later step (a diagonal one goes to the chain only)
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cp_st(&a.W[(row0 + srow(qr, l, i)) * Dp + (long)J * PB + scol(qc0 + j, l)], S[j][i]);
+  if (diag) cp_signal(cp_chainin(a, I));
+  else if (!app && I == J + 1) cp_signal(cp_colcnt(a, J), cp_chainin(a, I));
+  else cp_signal(cp_colcnt(a, J));
+}
+
+__global__ __launch_bounds__(CP_THREADS) void cholp_kernel(CholpArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double dsm[];
+  const int np = a.np;
+  int b = blockIdx.x;
+  if (b == 0) { cp_chain(a, dsm); return; }
+  b -= 1;
+  const int nOff = (np - 1) * (np - 2) / 2, nDiag = np - 2;
+  if (b < nOff) {                                  // (I, J), 1 <= J < I
+    int I = 2;
+    while (b >= I - 1) { b -= I - 1; ++I; }
+    cp_worker(a, dsm, I, b + 1, false);
+  } else if (b < nOff + nDiag) {
+    const int I = b - nOff + 2;
+    cp_worker(a, dsm, I, I, false);
+  } else {                                         // appended (R, C), R < C
+    b -= nOff + nDiag;
+    int C = 1;
+    while (b >= C) { b -= C; ++C; }
+    cp_worker(a, dsm, b, C, true);
+  }
+}
+
+int cholp_workgroups(int np) { return 1 + (np - 1) * (np - 2) / 2 + (np - 2) + np * (np - 1) / 2; }
+
+// The persistent solve of a system that is already packed into `workspace` (chol_pack_kernel / como_sys_finalize_pack: they also
+// reset info and the counters).  COMO_ERR_ARG when the size or the device does not allow it (the caller falls back to the
+// multi-launch solver).
+// compute units of the device if the kernel's LDS request was accepted, else 0 (called from como_chol_workspace_bytes, i.e.
+// outside any stream capture, before the first solve)
+int cholp_init() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    if (hipFuncSetAttribute((const void*)cholp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            CP_LDS_DOUBLES * (int)sizeof(double)) != hipSuccess) n = 0;
+    (void)hipGetLastError();
+    const char* e = getenv("COMO_CHOLP");                  // COMO_CHOLP=0: the multi-launch solver (the fallback), for A/B runs
+    if (e && atoi(e) == 0) n = 0;
+    return n;
+  }();
+  return cus;
+}
+
+int cholp_solve(double* delta, void* workspace, int D, int* info, hipStream_t s) {
+  if (!cholp_size_ok(D)) return COMO_ERR_ARG;
+  const int np = chol_np(D);
+  const int G = cholp_workgroups(np);
+  if (G > cholp_init()) return COMO_ERR_ARG;               // one workgroup per compute unit, all co-resident
+  CholpArgs a;
+  a.Dp = 64 * np; a.D = D; a.np = np;
+  a.W = (double*)workspace;
+  a.Vpg = a.W + 2L * a.Dp * a.Dp;
+  a.ylast = a.Vpg + (long)np * PB * PB;
+  a.sync = (unsigned*)(a.W + cholp_sync_offset(a.Dp, np));
+  a.delta = delta;
+  a.info = info;
+  hipLaunchKernelGGL(cholp_kernel, dim3(G), dim3(CP_THREADS), CP_LDS_DOUBLES * sizeof(double), s, a);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+}  // namespace como

@@ -22,6 +22,24 @@ namespace como {
 
 constexpr int WAVE = 64;
 
+// ---- layout of the dense solver's workspace, shared by the packing kernels (csrc/ba.hip, csrc/chol.hip) and the solvers ------
+// Systems of 2 .. CHOLP_MAX_NP column PAIRS (64 columns: D + 1 <= 1024) are padded to whole pairs -- the persistent one-launch
+// solver (csrc/cholp.hip) works on 64 x 64 super-tiles --, larger (and tiny) ones to whole 32-wide block columns.
+constexpr int CHOLP_MAX_NP = 16;
+constexpr int CHOLP_SYNC_STRIDE = 32;                 // 32-bit words: every counter on its own 128-byte line
+__host__ __device__ inline int chol_np(long D) { return (int)((D + 1 + 63) / 64); }
+__host__ __device__ inline bool cholp_size_ok(long D) { return chol_np(D) >= 2 && chol_np(D) <= CHOLP_MAX_NP; }
+__host__ __device__ inline long chol_dp(long D) { return cholp_size_ok(D) ? 64L * chol_np(D) : ((D + 1 + 31) / 32) * 32; }
+// persistent solver: W (2 Dp x Dp) | published pair inverses (np x 64 x 64) | y of the last pair (64) | counters
+__host__ __device__ inline long cholp_sync_offset(long Dp, long np) { return 2 * Dp * Dp + np * 4096 + 64; }   // in doubles
+__host__ __device__ inline long cholp_sync_words(long np) { return (2 + 2 * np) * CHOLP_SYNC_STRIDE; }
+// (called by the packing kernels with their linear thread index: the counters start every solve at zero)
+__device__ __forceinline__ void cholp_reset_sync(double* __restrict__ W, long D, long idx) {
+  if (!cholp_size_ok(D)) return;
+  const long np = chol_np(D), Dp = 64 * np;
+  if (idx < cholp_sync_words(np)) ((unsigned*)(W + cholp_sync_offset(Dp, np)))[idx] = 0u;
+}
+
 // ---- exact-order primitives (reference geometry/*.py as executed by torch CPU) ----------
 template <typename T>
 __device__ __forceinline__ T dot3_seq(T a0, T a1, T a2, T x, T y, T z) {

@@ -36,4 +36,5 @@ torch.set_num_threads(8)
 step = float(sys.argv[2]) if len(sys.argv) > 2 else 0.01
 deg = float(sys.argv[3]) if len(sys.argv) > 3 else 0.3
 seed = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-r2.ate_case(seed=seed, H=480, W=640, nframes=nframes, step=step, deg=deg, network_size=(192, 256))
+fs = float(sys.argv[5]) if len(sys.argv) > 5 else None
+r2.ate_case(seed=seed, H=480, W=640, nframes=nframes, step=step, deg=deg, network_size=(192, 256), freq_scale=fs)
