@@ -3,6 +3,8 @@
 // tiles (factor_pair_lean), 32^3 products on the float64 matrix cores.  Reference: como/odom/backend/linear_system.py:101-112.
 #pragma once
 #include "common.cuh"
+#include <type_traits>
+#include <utility>
 
 namespace como {
 
@@ -467,8 +469,15 @@ __device__ __forceinline__ void fp_inverse_wave(double* sc, int nsteps, int itil
 }
 
 // T10 in tile 0, T00 in tile 1, T11 in tile 2 of `sm` (as factor_pair_tail); scratch = tiles 5, 6.
+// Idle: what waves 5 and 7 -- which have no role in the factorisation of a full pair and only keep the barrier count -- do
+// between the barriers: idle(i, s), i = 0 (wave 5) / 1 (wave 7), after barrier s = 0 .. 16, fully unrolled.  It must never block
+// for long (everybody waits for it at the next barrier).  The persistent solver (csrc/cholp.hip) prefetches the next pair's
+// inputs there.
+struct FpNoIdle { __device__ __forceinline__ void operator()(int, int) const {} };
+template <class Idle = FpNoIdle>
 __device__ __forceinline__ void factor_pair_lean(double* sm, bool has1, int d0, double* __restrict__ Lw, double* __restrict__ Iw,
-                                                 int Dp, int D, int* __restrict__ info, double* Ls = nullptr, double* Vs = nullptr) {
+                                                 int Dp, int D, int* __restrict__ info, double* Ls = nullptr, double* Vs = nullptr,
+                                                 Idle&& idle = Idle()) {
   const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
   const double* T10 = sm;
   const double* T00 = sm + 1 * TSZ;
@@ -482,7 +491,14 @@ __device__ __forceinline__ void factor_pair_lean(double* sm, bool has1, int d0, 
   else if (wv == 3) fp_micro_wave(T00, sc, nsteps, kk, D, info, l);
   else if (wv == 6) fp_inverse_wave(sc, nsteps, 0, Iw ? Iw + (long)d0 * CB * CB : nullptr, l, Vs);
   else if (wv == 4 && has1) fp_inverse_wave(sc, nsteps, 1, Iw ? Iw + (long)(d0 + 1) * CB * CB : nullptr, l, Vs);
-  else {
+  else if (!std::is_same<typename std::decay<Idle>::type, FpNoIdle>::value && has1 && (wv == 5 || wv == 7)) {
+    const int i = wv == 7 ? 1 : 0;
+#pragma unroll
+    for (int s = 0; s <= 16; ++s) {
+      lds_only_barrier();
+      idle(i, s);
+    }
+  } else {
 #pragma unroll 1
     for (int s = 0; s <= nsteps; ++s) lds_only_barrier();
   }

@@ -39,7 +39,7 @@ constexpr int PLD = 65;                // LDS leading dimension of a super-tile 
 constexpr int PSZ = PB * PLD;          // one super-tile in LDS (doubles)
 constexpr int CP_THREADS = 512;           // 8 waves: wave w owns the quadrants (w >> 1, 2 (w & 1)) and (w >> 1, 2 (w & 1) + 1) of a super-tile
 constexpr int CP_LPT = PB * PB / CP_THREADS;       // elements per thread of a super-tile copy
-constexpr int CP_LDS_DOUBLES = NT2 * TSZ + 2 * PSZ + 256;     // chain: factor tiles | Vp | A;  workers: Vp | A_I | A_J | misc
+constexpr int CP_LDS_DOUBLES = NT2 * TSZ + 2 * PSZ + TSZ + 64;     // chain: factor tiles | Vp | A | Y | flags;  workers: Vp | A_I | A_J | misc
 
 struct CholpArgs {
   double* W;            // working copy (2 Dp x Dp): H lower + g row + identity pad | appended identity rows (never initialised)
@@ -100,20 +100,26 @@ __device__ __forceinline__ void cp_signal(unsigned* c0, unsigned* c1 = nullptr) 
 // leading dimension PLD): the NT product of csrc/chol_tile.cuh's tile_nt_mfma on 64-wide operands, two quadrants of one quadrant
 // row per wave (the X operand is read once); lane l feeds row r = l & 15, k group l >> 4.
 template <bool NEG>
-__device__ __forceinline__ void st_nt(const double* X, const double* Y, int qr, int qc0, int l, int kb0, int kb1, d4_t (&acc)[2]) {
+__device__ __forceinline__ void st_nt(const double* X, const double* Y, int qr, int qc0, int l, int kb0, int kb1, d4_t (&acc)[2],
+                                      int nq = 2) {
   const int r = l & 15, q = l >> 4, ko = 16 * (q & 1) + 8 * (q >> 1);
   const double* x = X + (16 * qr + r) * PLD + ko;
   const double* y0 = Y + (16 * qc0 + r) * PLD + ko;
-  const double* y1 = y0 + 16 * PLD;
+  const double* y1 = y0 + (nq > 1 ? 16 * PLD : 0);
   for (int kb = kb0; kb < kb1; ++kb) {
     double xa[8], ya[8], yb[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) { xa[s] = x[32 * kb + s]; ya[s] = y0[32 * kb + s]; yb[s] = y1[32 * kb + s]; }
+    if (nq > 1) {
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const double xs = NEG ? -xa[s] : xa[s];
-      acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, ya[s], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, yb[s], acc[1], 0, 0, 0);
+      for (int s = 0; s < 8; ++s) {
+        const double xs = NEG ? -xa[s] : xa[s];
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, ya[s], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xs, yb[s], acc[1], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(NEG ? -xa[s] : xa[s], ya[s], acc[0], 0, 0, 0);
     }
   }
 }
@@ -139,57 +145,101 @@ __device__ __forceinline__ void st_load(double* dst, const double* __restrict__ 
 
 // ------------------------------------------------------------------------------------------------------------------------
 // chain workgroup
+//
+// What the two spare waves of the chain workgroup do DURING a factorisation (factor_pair_lean's Idle hook; one call per barrier
+// step, must not block): wave 5 forms Y = L10 V0 (one quadrant per step from step 10 on: L10 and V0 are complete after barrier 9),
+// so that the off-diagonal block of the pair's inverse, V10 = -V1 Y, is ONE product after the factorisation; both waves poll the
+// counter of the next pair's inputs -- three polls in flight, each consumed three steps (1.6 us) after its issue, i.e. when it has
+// long returned -- and, once the inputs are published, start the direct-to-LDS loads of A(q, q-1); three steps later they have landed.
+struct CpIdle {
+  const double* L10; const double* V0; double* Yb; double* Vp;
+  const double* Asrc; long ld; double* Ab;           // the next pair's A(q, q-1) (nullptr: there is no next pair)
+  const unsigned* flag;                              // chainin[q] (nullptr: original data, nothing to wait for)
+  int* done;                                         // LDS: done[i] = 1 once wave i has put its half of A into Ab
+  unsigned pv[3] = {0u, 0u, 0u};                     // polls in flight: slot s % 3 holds the one issued at step s - 3
+  bool ready = false, written = false;
+  int issued = 1 << 20;
+  // A(q, q-1) goes from memory STRAIGHT into LDS (global_load_lds_dword: no registers, nothing for the wave to do when the data
+  // arrives): one instruction moves 256 contiguous bytes = half a row of the super-tile (the LDS rows are padded to 65 doubles, so a
+  // wider form cannot span two rows); wave i takes rows i, i + 2, ...  `store` = the data has landed: tell the workgroup.
+  __device__ __forceinline__ void load(int i) {
+    const char* src = (const char*)(Asrc + (long)i * ld) + 4 * (threadIdx.x & 63);
+    double* dst = Ab + i * PLD;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 4, 256, 0);
+      src += 16 * ld;
+      dst += 2 * PLD;
+    }
+  }
+  __device__ __forceinline__ void store(int i) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if ((threadIdx.x & 63) == 0) done[i] = 1;
+    written = true;
+  }
+  __device__ __forceinline__ void operator()(int i, int s) {
+    if (i == 0 && s >= 10 && s < 14) {
+      d4_t y = {0.0, 0.0, 0.0, 0.0};
+      tile_mm_mfma<false, false>(L10, V0, s - 10, threadIdx.x & 63, y);
+      tile_store_mfma(Yb, s - 10, threadIdx.x & 63, y);
+    }
+    if (i == 1 && s >= 10 && s < 14) {               // rows 8 (s - 10) .. + 7 of [V0 | 0] into the 64-wide inverse (zeros above the diagonal)
+      const int lane = threadIdx.x & 63, c = lane & 31;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int r = 8 * (s - 10) + 2 * u + (lane >> 5);
+        Vp[r * PLD + c] = c <= r ? V0[r * CLD + c] : 0.0;
+        Vp[r * PLD + 32 + c] = 0.0;
+      }
+    }
+    if (!Asrc) return;
+    if (!ready) {
+      if (flag) { const unsigned v = pv[s % 3]; pv[s % 3] = cp_ld(flag); ready = v >= 2u; }
+      else ready = true;
+      if (ready) { load(i); issued = s; }
+    } else if (!written && s >= issued + 3) {
+      store(i);
+    }
+  }
+  __device__ __forceinline__ void finish(int i) { if (Asrc && ready && !written) store(i); }
+};
+
 __device__ void cp_chain(const CholpArgs& a, double* dsm) {
   double* sm = dsm;                               // factor tiles 0 .. 6 (CLD layout): T10 / L10, T00 / L00, T11 / L11, V0, V1, scratch
   double* Vp = dsm + NT2 * TSZ;                   // inverse of the last factored pair, [64][PLD]
-  double* Ab = Vp + PSZ;                          // A(p, p-1) -> X
-  volatile int* ok_s = (volatile int*)(Ab + PSZ);
-  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, qr = wv >> 1, qc0 = 2 * (wv & 1);
+  double* Ab = Vp + PSZ;                          // A(q, q-1) -> X
+  double* Yb = Ab + PSZ;                          // L10 V0 (one tile)
+  volatile int* ok_s = (volatile int*)(Yb + TSZ);
+  int* done = (int*)(Yb + TSZ) + 2;
+  const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63;
   const long Dp = a.Dp;
   const int np = a.np, D = a.D;
+  // Quadrants per wave, balanced over the SIMDs (waves w and w + 4 share one; a float64 matrix instruction holds its pipe for 64
+  // cycles, so a stage is bound by the quadrant-products of its fullest SIMD).  X stage: 16 quadrants, those of the right half
+  // cost two k blocks; T stage: the 10 lower quadrants.
+  const int xqr = wv >> 1, xqc0 = 2 * ((wv ^ (wv >> 2)) & 1);
+  const int tqr = (0x02101233 >> (4 * wv)) & 15, tqc0 = (0x02100020 >> (4 * wv)) & 15, tnq = (0x01111222 >> (4 * wv)) & 15;
+  constexpr int PUBW = 7;                         // the publishing wave: 16 matrix instructions in the X stage, none in the T stage
   // pair 0 straight from the working copy
   for (int e = tid; e < 3 * CB * CB; e += CP_THREADS) {
     const int t = e >> 10, r = (e >> 5) & 31, c = e & 31;
     const long gr = (t == 1 ? 0 : CB) + r, gc = (t == 2 ? CB : 0) + c;     // tile 1 = (0,0), tile 0 = (1,0), tile 2 = (1,1)
     sm[t * TSZ + r * CLD + c] = a.W[gr * Dp + gc];
   }
+  if (tid < 2) done[tid] = 0;
   __syncthreads();
   for (int p = 0; p < np; ++p) {
-    CP_STAMP(p, 0);
-    if (p > 0) {
-      if (p >= 2 && !cp_wait(cp_chainin(a, p), 2u, a, ok_s)) return;
-      CP_STAMP(p, 1);
-      // A(p, p-1) and the lower quadrants of T(p, p), updated through pair p - 2 by their owners
-      st_load(Ab, a.W + (long)p * PB * Dp + (long)(p - 1) * PB, Dp);
-      d4_t tq[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-        if (qc0 + j <= qr) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) tq[j][i] = a.W[((long)p * PB + srow(qr, l, i)) * Dp + (long)p * PB + scol(qc0 + j, l)];
-        }
-      __syncthreads();
-      CP_STAMP(p, 2);
-      d4_t x[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-      st_nt<false>(Ab, Vp, qr, qc0, l, 0, qc0 < 2 ? 1 : 2, x);      // X = A Vp^T (Vp lower triangular: columns >= 32 of its rows < 32 are zero)
-      __syncthreads();
-      st_store(Ab, qr, qc0, l, x);
-      __syncthreads();
-      CP_STAMP(p, 3);
-      if (qc0 <= qr) {                                               // T -= X X^T (lower quadrants), into the factor's tiles
-        st_nt<true>(Ab, Ab, qr, qc0, l, 0, 2, tq);
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          if (qc0 + j <= qr) {
-            const int t = qr < 2 ? 1 : (qc0 < 2 ? 0 : 2);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) sm[t * TSZ + (srow(qr, l, i) & 31) * CLD + (scol(qc0 + j, l) & 31)] = tq[j][i];
-          }
-      }
-      __syncthreads();
-    }
+    const int q = p + 1;                          // the pair whose inputs are fetched while this one is factored
     CP_STAMP(p, 4);
-    factor_pair_lean(sm, true, 2 * p, (double*)nullptr, (double*)nullptr, (int)Dp, D, a.info, sm, sm + 3 * TSZ);
+    CpIdle idle;
+    idle.L10 = sm; idle.V0 = sm + 3 * TSZ; idle.Yb = Yb; idle.Vp = Vp;
+    idle.Asrc = q < np ? a.W + (long)q * PB * Dp + (long)p * PB : nullptr;
+    idle.ld = Dp; idle.Ab = Ab;
+    idle.flag = q >= 2 ? cp_chainin(a, q) : nullptr;
+    idle.done = done;
+    factor_pair_lean(sm, true, 2 * p, (double*)nullptr, (double*)nullptr, (int)Dp, D, a.info, sm, sm + 3 * TSZ, idle);
+    if (wv == 5 || wv == 7) idle.finish(wv == 7 ? 1 : 0);
     __syncthreads();
     CP_STAMP(p, 5);
     const double* L10 = sm;
@@ -197,39 +247,59 @@ __device__ void cp_chain(const CholpArgs& a, double* dsm) {
     const double* L11 = sm + 2 * TSZ;
     const double* V0 = sm + 3 * TSZ;
     const double* V1 = sm + 4 * TSZ;
-    double* S5 = sm + 5 * TSZ;
-    // V10 = -V1 (L10 V0): the off-diagonal block of the pair's inverse
-    if (wv < 4) {
-      d4_t y = {0.0, 0.0, 0.0, 0.0};
-      tile_mm_mfma<false, false>(L10, V0, wv, l, y);
-      tile_store_mfma(S5, wv, l, y);
+    d4_t tq[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    if (q < np) {
+      if (!(done[0] && done[1])) {                // the inputs were not there in time: wait for them now (every wave: uniform verdict)
+        if (q >= 2 && !cp_wait(cp_chainin(a, q), 2u, a, ok_s)) return;
+        st_load(Ab, a.W + (long)q * PB * Dp + (long)p * PB, Dp);
+      }
+      CP_STAMP(q, 1);
+      // the lower quadrants of T(q, q), updated through pair p - 1 by their owner: in flight during the next two stages
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (j < tnq) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tq[j][i] = a.W[((long)q * PB + srow(tqr, l, i)) * Dp + (long)q * PB + scol(tqc0 + j, l)];
+        }
     }
-    __syncthreads();
+    // V10 = -V1 Y, [V0 | 0] and V1 into the 64-wide layout (zeros above the diagonals)
     if (wv < 4) {
       d4_t v = {0.0, 0.0, 0.0, 0.0};
-      tile_mm_mfma<false, false>(V1, S5, wv, l, v);
+      tile_mm_mfma<false, false>(V1, Yb, wv, l, v);
 #pragma unroll
       for (int i = 0; i < 4; ++i) Vp[(32 + mrow(wv, l, i)) * PLD + mcol(wv, l)] = -v[i];
-    } else {                                                         // [V0 | 0] and V1 into the 64-wide layout (zeros above the diagonals)
+    } else {                                                         // ([V0 | 0] was put there during the factorisation)
       for (int e = tid - 256; e < CB * CB; e += 256) {
         const int r = e >> 5, c = e & 31;
-        Vp[r * PLD + c] = c <= r ? V0[r * CLD + c] : 0.0;
-        Vp[r * PLD + 32 + c] = 0.0;
         Vp[(32 + r) * PLD + 32 + c] = c <= r ? V1[r * CLD + c] : 0.0;
       }
     }
+    if (tid < 2) done[tid] = 0;
     __syncthreads();
     CP_STAMP(p, 6);
-    {                                                                // publish Vp_p
+    // Publish Vp_p: ONE wave issues all the agent-scope stores and goes on; it collects their acknowledgement (~2 us) when it is
+    // idle during the T stage and raises the pair counter itself -- nobody else ever waits for these stores.  (The last pair
+    // publishes with every wave and a barrier: nothing follows.)
+    if (q == np) {
       double* dst = a.Vpg + (long)p * PB * PB;
+      for (int e = tid; e < PB * PB; e += CP_THREADS) cp_st(&dst[e], Vp[(e >> 6) * PLD + (e & 63)]);
+    } else if (wv == PUBW) {
+      double* dst = a.Vpg + (long)p * PB * PB + l;
+      const double* src = Vp + l;
+#pragma unroll 1
+      for (int b = 0; b < 4; ++b) {                                  // 16 rows per batch: all LDS reads, then all stores
+        double v[16];
 #pragma unroll
-      for (int u = 0; u < CP_LPT; ++u) { const int e = tid + CP_THREADS * u; cp_st(&dst[e], Vp[(e >> 6) * PLD + (e & 63)]); }
+        for (int u = 0; u < 16; ++u) v[u] = src[(16 * b + u) * PLD];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) cp_st(&dst[(16 * b + u) * PB], v[u]);
+      }
     }
-    if (p == np - 1) {
+    if (q == np) {
       // y of the last pair = row D of L (the appended right-hand side), columns below it; delta of the last pair's own rows:
       // its appended super-tile is still the identity, (L^-T)_{last,last} = Vp^T
       const int gl = D - PB * (np - 1);
-      double* yl = S5;
+      double* yl = Ab;
       if (tid < PB) {
         double v = 0.0;
         if (tid < gl) v = gl < CB ? (tid < CB ? L00[gl * CLD + tid] : 0.0)
@@ -243,9 +313,37 @@ __device__ void cp_chain(const CholpArgs& a, double* dsm) {
         for (int k = 0; k < PB; ++k) s = __builtin_fma(Vp[k * PLD + tid], yl[k], s);
         a.delta[(long)PB * (np - 1) + tid] = s;
       }
+      cp_signal(cp_pairflag(a));
+      CP_STAMP(p, 7);
+      return;
     }
-    cp_signal(cp_pairflag(a));
-    CP_STAMP(p, 7);
+    // X = A Vp^T (Vp lower triangular: columns >= 32 of its rows < 32 are zero).  The publishing wave is busy issuing its stores:
+    // its two quadrants go to the wave it shares a SIMD with (the matrix pipe of that SIMD sees the same 48 instructions).
+    d4_t x[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, x2[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    constexpr int PQR = PUBW >> 1, PQC0 = 2 * ((PUBW ^ (PUBW >> 2)) & 1);
+    if (wv != PUBW) st_nt<false>(Ab, Vp, xqr, xqc0, l, 0, xqc0 < 2 ? 1 : 2, x);
+    if (wv == PUBW - 4) st_nt<false>(Ab, Vp, PQR, PQC0, l, 0, PQC0 < 2 ? 1 : 2, x2);
+    lds_only_barrier();                                              // (LDS only: the published stores and the loads of T stay in flight)
+    CP_STAMP(q, 2);
+    if (wv != PUBW) st_store(Ab, xqr, xqc0, l, x);
+    if (wv == PUBW - 4) st_store(Ab, PQR, PQC0, l, x2);
+    lds_only_barrier();
+    CP_STAMP(q, 3);
+    if (wv == PUBW) {                                                // (the publishing wave owns no quadrant of the T stage)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (l == 0) __hip_atomic_fetch_add(cp_pairflag(a), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tnq > 0) {                                                   // T -= X X^T (lower quadrants), into the factor's tiles
+      st_nt<true>(Ab, Ab, tqr, tqc0, l, 0, 2, tq, tnq);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        if (j < tnq) {
+          const int t = tqr < 2 ? 1 : (tqc0 + j < 2 ? 0 : 2);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sm[t * TSZ + (srow(tqr, l, i) & 31) * CLD + (scol(tqc0 + j, l) & 31)] = tq[j][i];
+        }
+    }
+    __syncthreads();
   }
 }
 

@@ -14,7 +14,8 @@ def run_ate_sequence(G, pix="float", dev="cuda:0"):
     colour = bool(int(G["colour"])) if "colour" in G else False       # `color: rgb`: one texture per channel
     # network input: the image size in the small fixtures, the reference's fixed 192 x 256 in the 640 x 480 one (Mapping.py:399)
     net = [int(x) for x in G["network_size"]] if "network_size" in G else [H, W]
-    scenes = [synth.PlaneScene(seed=seed + 1000 * ch, freq_scale=W / 640.0) for ch in range(3 if colour else 1)]
+    fs = float(G["freq_scale"]) if "freq_scale" in G else W / 640.0
+    scenes = [synth.PlaneScene(seed=seed + 1000 * ch, freq_scale=fs) for ch in range(3 if colour else 1)]
     K = synth.intrinsics_for(H, W)
     T = synth.gt_poses(n, step=float(G["step"]), deg=float(G["deg"]))
     g = torch.Generator().manual_seed(seed)

@@ -13,6 +13,7 @@ nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 9
 step = float(sys.argv[2]) if len(sys.argv) > 2 else 0.01
 deg = float(sys.argv[3]) if len(sys.argv) > 3 else 0.3
 seed = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+fs = float(sys.argv[5]) if len(sys.argv) > 5 else 1.0
 orig = tfm.TwoFrameSfm.handle_frame
 
 
@@ -32,6 +33,6 @@ def handle_frame(self, rgb, timestamp):
 
 
 tfm.TwoFrameSfm.handle_frame = handle_frame
-G = {"H": 480, "W": 640, "nframes": nframes, "seed": seed, "step": step, "deg": deg, "colour": 0, "network_size": [192, 256]}
+G = {"H": 480, "W": 640, "nframes": nframes, "seed": seed, "step": step, "deg": deg, "colour": 0, "network_size": [192, 256], "freq_scale": fs}
 kinds, poses, odo = run_ate_sequence(G, os.environ.get("PIX", "double"))
 print("kinds", kinds)

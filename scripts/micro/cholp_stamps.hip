@@ -91,14 +91,17 @@ int main(int argc, char** argv) {
   for (int i = 0; i < D; ++i) { num += (got[i] - x[i]) * (got[i] - x[i]); den += x[i] * x[i]; }
   printf("D = %d, np = %d, %d workgroups; info %d; |delta - host| / |host| = %.3e; launch-to-end (HIP events, best of %d): %.1f us\n", D, np,
          cholp_workgroups(np), hinfo, std::sqrt(num / den), reps, best * 1e3);
-  printf("chain workgroup, per pair (us): wait-inputs  load  X-stage  T-stage  factor  V10+assemble  publish+signal | period (top -> top)\n");
+  printf("chain workgroup, per pair p (us): factor | then for the next pair: inputs-ready  V10+assemble  X-products(+publish ack)  X-store  T-stage | period\n");
+  auto us = [](long long a, long long b) { return (a && b) ? (double)(b - a) / 100.0 : 0.0; };
   for (int p = 0; p < np; ++p) {
     const long long* s = &st[p * 8];
-    auto us = [](long long a, long long b) { return (a && b) ? (double)(b - a) / 100.0 : 0.0; };
-    const double period = p + 1 < np ? us(s[0], st[(p + 1) * 8]) : us(s[0], s[7]);
-    printf("  pair %2d: %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f %6.2f | %6.2f\n", p, us(s[0], s[1]), us(s[1], s[2]), us(s[2], s[3]), us(s[3], s[4]),
-           us(s[4], s[5]), us(s[5], s[6]), us(s[6], s[7]), period);
+    const long long* n = &st[(p + 1) * 8];
+    if (p + 1 < np)
+      printf("  pair %2d: %6.2f | %6.2f %6.2f %6.2f %6.2f %6.2f | %6.2f\n", p, us(s[4], s[5]), us(s[5], n[1]), us(n[1], s[6]), us(s[6], n[2]),
+             us(n[2], n[3]), us(n[3], n[4]), us(s[4], n[4]));
+    else
+      printf("  pair %2d: %6.2f | last pair: V10 + publish + delta %6.2f\n", p, us(s[4], s[5]), us(s[5], s[7]));
   }
-  printf("chain total (first stamp -> last): %.1f us\n", (double)(st[(np - 1) * 8 + 7] - st[0]) / 100.0);
+  printf("chain total (first stamp -> last): %.1f us\n", (double)(st[(np - 1) * 8 + 7] - st[4]) / 100.0);
   return 0;
 }
