@@ -37,6 +37,7 @@ import time
 # multi-process GPU work on this driver stack needs dmabuf IPC (RCCL / tensor sharing fail with the legacy mode)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -133,29 +134,32 @@ def cpu_baseline(args, state_cpu, reps=5):
 
 def odometry_loop(device, frames=100, seed=1, pix="float", warm=0, barrier=None, timed_frames=None):
     """The whole headless sequential odometry loop (tracking + keyframe management + DepthCov network on every new keyframe +
-    one mapping iteration per frame, como_amd/odom/sequential.py <-> como/odom/sequential/ComoSeq.py:42-127) on a rendered
-    640x480 sequence with the parameters of the reference's config/como.yml; frames/s after the two-frame initialisation
-    (+ `warm` further untimed frames).  `seed` picks the scene texture and the camera path (--replicas: one sequence per rank);
-    pix = "float" (mixed precision) / "double" (the reference's mapping dtype) per-pixel kernels of the window BA.
-    timed_frames: time EXACTLY that many frames (the sequence is rendered long enough); barrier: called right before / after
-    the timed region (multi-rank).  Never fails the bench line: returns {"error": ...} instead."""
+    one mapping iteration per frame, como_amd/odom/sequential.py <-> como/odom/sequential/ComoSeq.py:42-127) on the rendered
+    640x480 sequence that is PINNED against the reference's own loop (scripts/ate_sequence.py SEQ640; seed 1, 100 frames =
+    tests/golden/ate_sequence_640.npz, checked by tests/test_gpu_r5.py incl. a perturbed-network run) with the parameters of the
+    reference's config/como.yml; frames/s after the two-frame initialisation (+ `warm` further untimed frames).  `seed` picks the
+    scene texture and the noise (--replicas: one sequence per rank); pix = "float" (mixed precision) / "double" (the reference's
+    mapping dtype) per-pixel kernels of the window BA.  timed_frames: time EXACTLY that many frames (the sequence is rendered long
+    enough); barrier: called right before / after the timed region (multi-rank).  Reported beside the rate: the frame at which the
+    initialisation completed, keyframes / one-way frames inserted, the trajectory error against the ground truth (scale-aligned:
+    monocular) and, for the pinned seed, decisions and ATE against the reference's trajectory.
+    Never fails the bench line: returns {"error": ...} instead."""
     try:
-        import argparse
         from como_amd import synth
         from como_amd.depth_cov.core.DepthCovModule import DepthCovModule
         from como_amd.odom.sequential import ComoSeq
-        from scripts.gpu_odometry_bench import cfgs
-        H, W = 480, 640
+        from como_amd.utils.ate import ate_rmse
+        from scripts.ate_sequence import KIND_CODE, SEQ640, loop_cfgs, render_frames
         if timed_frames is not None:
-            frames = timed_frames + warm + 24               # the two-frame initialisation succeeds within the first ~10 frames
-        scene = synth.PlaneScene(seed=seed, freq_scale=1.0, device=device)
-        K = synth.intrinsics_for(H, W, device=device)
-        T = synth.gt_poses(frames, step=0.01, deg=0.3 + 0.02 * ((seed - 1) % 5), device=device)
-        rgbs = [scene.render(T[k], K, H, W)[0][None, None].repeat(1, 3, 1, 1) for k in range(frames)]
+            frames = timed_frames + warm + 8                # the two-frame initialisation completes on the third frame
+        G = dict(SEQ640, seed=seed, nframes=frames)
+        K, T, rgbs_cpu = render_frames(G)
+        rgbs = [r.to(device) for r in rgbs_cpu]
         model = DepthCovModule({k: v.to(device) for k, v in synth.depthcov_state_dict(0).items()})
-        odo = ComoSeq(cfgs(str(device), argparse.Namespace(pix=pix)), K.cpu().clone(), (H, W), model)
+        odo = ComoSeq(loop_cfgs(G, pix, str(device), graph_network=True), K.clone(), (G["H"], G["W"]), model)
         t0, k0, kinds, k_end = None, None, [], frames
         k_init = None
+        poses = {}
         for k in range(frames):
             if k_init is None and odo.mapping.is_init:
                 k_init = k
@@ -168,7 +172,10 @@ def odometry_loop(device, frames=100, seed=1, pix="float", warm=0, barrier=None,
                     k_end = k + timed_frames
             if k >= k_end:
                 break
-            kinds.append(odo.iter(1.0 + 0.033 * k, rgbs[k]))
+            nb = len(odo.est_poses)
+            kinds.append(odo.iter(1.0 + k, rgbs[k]))
+            if len(odo.est_poses) > nb:
+                poses[k] = odo.est_poses[-1]                # (device tensors: read back after the timed region)
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
         if barrier is not None:
@@ -177,11 +184,27 @@ def odometry_loop(device, frames=100, seed=1, pix="float", warm=0, barrier=None,
         if timed_frames is not None and n != timed_frames:
             return {"error": f"only {n} of {timed_frames} frames could be timed (initialisation at frame {k_init})"}
         from como_amd.odom.frontend.photo_tracking import photo_tracking_pyr
-        return {"workload": f"sequential odometry loop, rendered 640x480 sequence (seed {seed}), config/como.yml parameters (9 keyframes, "
-                            f"24 one-way frames, m=64, window 4, float32 tracking, float64 mapping system / {pix} pixel kernels)",
-                "value": n / el, "unit": "frames/s", "ms_per_frame": 1e3 * el / n, "frames": n, "elapsed_s": el,
-                "keyframes_inserted": kinds.count("keyframe"), "one_way_inserted": kinds.count("one-way"),
-                "tracking_chain_fallbacks": int(getattr(photo_tracking_pyr, "fallbacks", 0))}
+        tracked = sorted(poses)
+        est = [poses[k].detach().cpu().double().reshape(4, 4) for k in tracked]
+        out = {"workload": f"sequential odometry loop, rendered 640x480 sequence (scripts/ate_sequence.py SEQ640, seed {seed}), config/como.yml "
+                           f"parameters (9 keyframes, 24 one-way frames, m=64, window 4, float32 tracking, float64 mapping system / {pix} "
+                           "pixel kernels)",
+               "value": n / el, "unit": "frames/s", "ms_per_frame": 1e3 * el / n, "frames": n, "elapsed_s": el,
+               "init_completed_at_frame": k_init, "keyframes_inserted": kinds.count("keyframe"), "one_way_inserted": kinds.count("one-way"),
+               "tracking_chain_fallbacks": int(getattr(photo_tracking_pyr, "fallbacks", 0)),
+               "ate_vs_gt_sim3_m": float(ate_rmse(est, [T[k] for k in tracked], "sim3")) if len(est) > 3 else None}
+        ref_path = os.path.join(ROOT, "tests", "golden", "ate_sequence_640.npz")
+        if seed == 1 and os.path.exists(ref_path):          # the pinned sequence: the reference's own loop on the same frames
+            R = np.load(ref_path)
+            m = min(len(kinds), int(R["nframes"]))
+            codes = [KIND_CODE[x] for x in kinds[:m]]
+            both = [k for k in tracked if k < m and bool(R["tracked"][k])]
+            out["vs_reference_loop"] = {
+                "frames_compared": m, "same_decisions": int(sum(int(a == int(b)) for a, b in zip(codes, R["kinds"][:m]))),
+                "ate_rmse_m": float(ate_rmse([poses[k].detach().cpu().double().reshape(4, 4) for k in both],
+                                             [torch.from_numpy(R["T_w_curr"][k]) for k in both])) if len(both) > 3 else None,
+                "fixture": "tests/golden/ate_sequence_640.npz (reference ComoSeq loop, tests/golden/make_golden_r2.py ate640)"}
+        return out
     except Exception as e:                                  # noqa: BLE001
         return {"error": repr(e)[:300]}
 

@@ -44,7 +44,7 @@ constexpr int CP_LDS_DOUBLES = NT2 * TSZ + 2 * PSZ + TSZ + 64;     // chain: fac
 struct CholpArgs {
   double* W;            // working copy (2 Dp x Dp): H lower + g row + identity pad | appended identity rows (never initialised)
   double* Vpg;          // published pair inverses, np x [64][64]
-  double* ylast;        // y of the last pair (64)
+  double* ylast;        // z = Vp_last^T y_last (64): the last pair's contribution to every delta_R is S_R z
   unsigned* sync;       // counters (cholp_sync_words)
   double* delta;
   int* info;
@@ -151,6 +151,9 @@ __device__ __forceinline__ void st_load(double* dst, const double* __restrict__ 
 // so that the off-diagonal block of the pair's inverse, V10 = -V1 Y, is ONE product after the factorisation; both waves poll the
 // counter of the next pair's inputs -- three polls in flight, each consumed three steps (1.6 us) after its issue, i.e. when it has
 // long returned -- and, once the inputs are published, start the direct-to-LDS loads of A(q, q-1); three steps later they have landed.
+#ifndef COMO_CP_PFW
+#define COMO_CP_PFW 2          // waves that prefetch (2: waves 5 and 7, rows interleaved; 1: wave 5 alone, half the rows per step)
+#endif
 struct CpIdle {
   const double* L10; const double* V0; double* Yb; double* Vp;
   const double* Asrc; long ld; double* Ab;           // the next pair's A(q, q-1) (nullptr: there is no next pair)
@@ -162,7 +165,7 @@ struct CpIdle {
   // A(q, q-1) goes from memory STRAIGHT into LDS (global_load_lds_dword: no registers, nothing for the wave to do when the data
   // arrives): one instruction moves 256 contiguous bytes = half a row of the super-tile (the LDS rows are padded to 65 doubles, so a
   // wider form cannot span two rows); wave i takes rows i, i + 2, ...  `store` = the data has landed: tell the workgroup.
-  __device__ __forceinline__ void load(int i) {
+  __device__ __forceinline__ void load(int i) {              // rows i, i + 2, ... (32 rows, 64 instructions)
     const char* src = (const char*)(Asrc + (long)i * ld) + 4 * (threadIdx.x & 63);
     double* dst = Ab + i * PLD;
 #pragma unroll
@@ -193,16 +196,23 @@ struct CpIdle {
         Vp[r * PLD + 32 + c] = 0.0;
       }
     }
-    if (!Asrc) return;
+    if (!Asrc || (COMO_CP_PFW == 1 && i == 1)) return;
     if (!ready) {
       if (flag) { const unsigned v = pv[s % 3]; pv[s % 3] = cp_ld(flag); ready = v >= 2u; }
       else ready = true;
-      if (ready) { load(i); issued = s; }
-    } else if (!written && s >= issued + 3) {
+      if (ready) { load(COMO_CP_PFW == 1 ? 0 : i); issued = s; }
+    } else if (COMO_CP_PFW == 1 && s == issued + 1) {
+      load(1);
+    } else if (!written && s >= issued + 4) {
       store(i);
+      if (COMO_CP_PFW == 1 && (threadIdx.x & 63) == 0) done[1] = 1;
     }
   }
-  __device__ __forceinline__ void finish(int i) { if (Asrc && ready && !written) store(i); }
+  __device__ __forceinline__ void finish(int i) {
+    if (!Asrc || (COMO_CP_PFW == 1 && i == 1)) return;
+    if (ready && COMO_CP_PFW == 1 && issued == 16) load(1);          // (detected at the last step: the second half was never issued)
+    if (ready && !written) { store(i); if (COMO_CP_PFW == 1 && (threadIdx.x & 63) == 0) done[1] = 1; }
+  }
 };
 
 __device__ void cp_chain(const CholpArgs& a, double* dsm) {
@@ -275,15 +285,11 @@ __device__ void cp_chain(const CholpArgs& a, double* dsm) {
       }
     }
     if (tid < 2) done[tid] = 0;
-    __syncthreads();
+    lds_only_barrier();                                              // (not __syncthreads: the loads of T(q, q) stay in flight)
     CP_STAMP(p, 6);
     // Publish Vp_p: ONE wave issues all the agent-scope stores and goes on; it collects their acknowledgement (~2 us) when it is
-    // idle during the T stage and raises the pair counter itself -- nobody else ever waits for these stores.  (The last pair
-    // publishes with every wave and a barrier: nothing follows.)
-    if (q == np) {
-      double* dst = a.Vpg + (long)p * PB * PB;
-      for (int e = tid; e < PB * PB; e += CP_THREADS) cp_st(&dst[e], Vp[(e >> 6) * PLD + (e & 63)]);
-    } else if (wv == PUBW) {
+    // idle during the T stage and raises the pair counter itself -- nobody else ever waits for these stores.
+    if (q < np && wv == PUBW) {                                      // (nobody reads the last pair's inverse: its product with y is published)
       double* dst = a.Vpg + (long)p * PB * PB + l;
       const double* src = Vp + l;
 #pragma unroll 1
@@ -305,13 +311,13 @@ __device__ void cp_chain(const CholpArgs& a, double* dsm) {
         if (tid < gl) v = gl < CB ? (tid < CB ? L00[gl * CLD + tid] : 0.0)
                                   : (tid < CB ? L10[(gl - CB) * CLD + tid] : L11[(gl - CB) * CLD + tid - CB]);
         yl[tid] = v;
-        cp_st(&a.ylast[tid], v);
       }
       __syncthreads();
-      if (tid < gl) {
-        double s = 0.0;
+      if (tid < PB) {                                                // z = Vp^T y: delta of the last pair's rows (zero from row gl on), and
+        double s = 0.0;                                              // what every appended row block still has to add: delta_R = x_R + S_R z
         for (int k = 0; k < PB; ++k) s = __builtin_fma(Vp[k * PLD + tid], yl[k], s);
-        a.delta[(long)PB * (np - 1) + tid] = s;
+        cp_st(&a.ylast[tid], s);
+        if (tid < gl) a.delta[(long)PB * (np - 1) + tid] = s;
       }
       cp_signal(cp_pairflag(a));
       CP_STAMP(p, 7);
@@ -402,16 +408,10 @@ __device__ void cp_worker(const CholpArgs& a, double* dsm, int I, int J, bool ap
     __syncthreads();
   }
   if (lastcol) {
-    // the last pair: delta_R = x_R + (S Vp_last^T) y_last
-    if (!cp_wait(cp_pairflag(a), (unsigned)np, a, ok_s)) return;
-    st_load(Vp, a.Vpg + (long)(np - 1) * PB * PB, PB);
-    if (tid < PB) misc[tid] = a.ylast[tid];
+    // the last pair: delta_R = x_R + (L^-T)_{R,last} y_last = x_R + S (Vp_last^T y_last); the chain publishes z = Vp_last^T y_last
     st_store(AI, qr, qc0, l, S);
-    __syncthreads();
-    d4_t x[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    st_nt<false>(AI, Vp, qr, qc0, l, 0, qc0 < 2 ? 1 : 2, x);
-    __syncthreads();
-    st_store(AI, qr, qc0, l, x);
+    if (!cp_wait(cp_pairflag(a), (unsigned)np, a, ok_s)) return;
+    if (tid < PB) misc[tid] = a.ylast[tid];
     __syncthreads();
     if (tid < PB) {
       double acc = 0.0;

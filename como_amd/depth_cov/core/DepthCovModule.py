@@ -73,9 +73,14 @@ class DepthCovModule:
         return outs
 
 
+OUTPUT_HOOK = None      # tests only: cov -> cov applied to the network's output (the robustness test perturbs it by 1e-6 relative)
+
+
 def run_model(model, rgb, network_size=(192, 256), dtype=torch.float64, graphed=True):
     """Mapping.run_model (Mapping.py:409-428): antialiased resize to the network size, finest covariance level, cast to
     the mapping dtype, antialiased resize back to the image size."""
     rgb_r = unet.resize_aa(rgb.float(), network_size)
     cov = (model.forward_graphed(rgb_r) if graphed else model(rgb_r))[-1].to(dtype)
+    if OUTPUT_HOOK is not None:
+        cov = OUTPUT_HOOK(cov)
     return unet.resize_aa(cov, rgb.shape[-2:])

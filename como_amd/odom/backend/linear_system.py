@@ -41,31 +41,54 @@ def landmark_to_batched_3d_point_inds(landmark_inds, num_kf):
 
 
 _chol_ws = {}
+_CHOL_WS_MAX = 8          # process-wide store (reference-signature calls): at most this many system sizes keep a workspace
+
+
+def _chol_entry(D, device, store, shared):
+    """(workspace, info, delta) for a D x D float64 system in `store`.
+    shared = True (a caller-owned store: one window, one stream): ONE grow-only workspace buffer serves every system size the
+    store has seen -- the window is rebuilt with a new D on almost every keyframe, and a buffer per size (37 MB at D = 1240) kept by
+    the inherited store would pile up over a long sequence; only the current size keeps its (info, delta) pair.
+    shared = False (the process-wide store, which several streams may use with different sizes at once): a buffer per size, the
+    oldest sizes evicted beyond _CHOL_WS_MAX."""
+    from como_amd import _lib
+    key = (str(device), D)
+    w = store.get(key)
+    if w is not None:
+        return w
+    need = _lib.lib().como_chol_workspace_bytes(D) // 8
+    if shared:
+        buf = store.get("buffer")
+        if buf is None or buf.numel() < need or buf.device != torch.device(device):
+            buf = store["buffer"] = torch.empty(need, dtype=torch.float64, device=device)
+        for k in [k for k in store if isinstance(k, tuple)]:
+            del store[k]
+    else:
+        buf = torch.empty(need, dtype=torch.float64, device=device)
+        for k in [k for k in store if isinstance(k, tuple)][:max(0, len(store) + 1 - _CHOL_WS_MAX)]:
+            del store[k]
+    w = store[key] = (buf, torch.zeros(1, dtype=torch.int32, device=device), torch.empty((D, 1), dtype=torch.float64, device=device))
+    return w
 
 
 def solve_system(H, g, ws=None):
     """ws: caller-owned dict for the factorisation workspace (a captured graph records its address; None: process-wide).
-    delta (D,1) = H^-1 g by dense Cholesky (reference :101-112).  float64 systems on the GPU run the blocked HIP
-    factorisation of csrc/chol.hip (graph-capturable, ~10x hipSOLVER at D = 760); float32 systems (the reference-signature
-    path with a float32 H) go through torch.linalg.  `solve_system.last_info` holds the factorisation status (device int)."""
+    delta (D,1) = H^-1 g by dense Cholesky (reference :101-112).  float64 systems on the GPU run the HIP factorisation of
+    csrc/cholp.hip (one persistent launch, D < 1024) / csrc/chol.hip (graph-capturable, ~13x hipSOLVER at D = 760); float32 systems
+    (the reference-signature path with a float32 H) go through torch.linalg.  `solve_system.last_info` holds the factorisation
+    status (device int)."""
     if H.is_cuda and H.dtype == torch.float64:
         from como_amd import _lib
         L = _lib.lib()
         D = H.shape[0]
-        key = (str(H.device), D)
-        store = _chol_ws if ws is None else ws
-        ws = store.get(key)
-        if ws is None:
-            ws = (torch.empty(L.como_chol_workspace_bytes(D) // 8, dtype=torch.float64, device=H.device),
-                  torch.zeros(1, dtype=torch.int32, device=H.device),
-                  torch.empty((D, 1), dtype=torch.float64, device=H.device))
-            store[key] = ws
-        delta = ws[2] if store is not _chol_ws else torch.empty((D, 1), dtype=torch.float64, device=H.device)
+        own = ws is not None
+        w = _chol_entry(D, H.device, ws if own else _chol_ws, shared=own)
+        delta = w[2] if own else torch.empty((D, 1), dtype=torch.float64, device=H.device)
         Hc = H if H.is_contiguous() else H.contiguous()
-        rc = L.como_chol_solve_f64(Hc.data_ptr(), g.contiguous().data_ptr(), delta.data_ptr(), ws[0].data_ptr(), D,
-                                   ws[1].data_ptr(), _lib.stream_ptr(H.device))
+        rc = L.como_chol_solve_f64(Hc.data_ptr(), g.contiguous().data_ptr(), delta.data_ptr(), w[0].data_ptr(), D,
+                                   w[1].data_ptr(), _lib.stream_ptr(H.device))
         _lib.check(rc, "como_chol_solve")
-        solve_system.last_info = ws[1]
+        solve_system.last_info = w[1]
         return delta
     Lf, info = torch.linalg.cholesky_ex(H, upper=False, check_errors=False)
     solve_system.last_info = info
@@ -73,16 +96,9 @@ def solve_system(H, g, ws=None):
 
 
 def chol_workspace(D, device, ws):
-    """(workspace, info, delta) of the blocked HIP factorisation for a D x D float64 system, kept in the caller-owned dict `ws`
+    """(workspace, info, delta) of the HIP factorisation for a D x D float64 system, kept in the caller-owned dict `ws`
     (a captured graph records the addresses)."""
-    from como_amd import _lib
-    key = (str(device), D)
-    w = ws.get(key)
-    if w is None:
-        w = (torch.empty(_lib.lib().como_chol_workspace_bytes(D) // 8, dtype=torch.float64, device=device),
-             torch.zeros(1, dtype=torch.int32, device=device), torch.empty((D, 1), dtype=torch.float64, device=device))
-        ws[key] = w
-    return w
+    return _chol_entry(D, device, ws, shared=True)
 
 
 def solve_packed(D, device, ws):
