@@ -455,6 +455,7 @@ def replicas_main(args, shard, device):
         raise SystemExit("replica sequence failed on rank %d: %s" % (shard.rank, r["error"]))
     elapsed = shard.max_scalar(r["elapsed_s"], device)
     per_rank = shard.gather_scalars(r["value"], device)
+    dist_rec = cdist.dist_record(shard, device)
     if shard.rank == 0:
         out = {"metric": "frames/sec, one 640x480 sequence per GPU through the whole odometry loop (config 5, throughput mode)",
                "value": shard.world * args.steps / elapsed, "unit": "frames/s", "n_gpus": args.gpus, "steps": args.steps,
@@ -465,7 +466,7 @@ def replicas_main(args, shard, device):
                           "parallelism": "replicas: one sequence per GPU, no collective", "frames_per_rank": args.steps,
                           "keyframes_inserted_rank0": r["keyframes_inserted"], "one_way_inserted_rank0": r["one_way_inserted"],
                           "tracking_chain_fallbacks_rank0": r["tracking_chain_fallbacks"]},
-               "per_rank_frames_per_s": per_rank, "git": git_sha()}
+               "per_rank_frames_per_s": per_rank, "dist": dist_rec, "git": git_sha()}
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
     shard.barrier()
@@ -550,6 +551,10 @@ def main():
     pose_err = (wb.kf_poses - state["poses_gt"]).abs().max().item()
     pose_err0 = (state["kf_poses"] - state["poses_gt"]).abs().max().item()
     npairs = wb.table.b
+    # what the process group saw (every rank takes part): backend, devices, collectives per iteration, capture per rank, and where a
+    # rank's eager iteration goes -- so that an N-GPU line shows by itself that RCCL ran on N distinct GPUs (como_amd/dist.py)
+    dist_rec = cdist.dist_record(shard, device, wb, graphed)
+    dist_rec["sharded_path"] = bool(sharded)
 
     legs, flat = {}, {}
     single = args.gpus == 1 and not args.no_secondary and args.window == 1 and args.keyframes == 8
@@ -616,6 +621,7 @@ def main():
             "config": cfg,
             "roofline": roof,
             "solution": {"cholesky_info": info, "max_pose_abs_err_vs_gt_start": pose_err0, "max_pose_abs_err_vs_gt_end": pose_err},
+            "dist": dist_rec,
             "git": git_sha(),
         }
         out.update(legs)

@@ -29,6 +29,8 @@ class Shard:
         RCCL path -- dtypes, stream semantics, graph capture -- on a one-GPU box)."""
         self.rank, self.world, self.group = rank, world, group
         self.force = force_collectives
+        self.n_collectives = 0            # data-path collectives issued so far (all_reduce_sum / _max / all_gather)
+        self.timing = None                # a list: every data-path collective is bracketed by two events appended to it
 
     def pixel_range(self, n):
         per = (n + self.world - 1) // self.world
@@ -54,23 +56,34 @@ class Shard:
         except Exception:   # noqa: BLE001
             return False
 
+    def _bracket(self, fn):
+        """Run one data-path collective; count it, and in timing mode bracket it with events on the current stream."""
+        self.n_collectives += 1
+        if self.timing is None or not torch.cuda.is_available():
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.timing.append((e0, e1))
+
     def all_reduce_sum(self, t):
         if self.world > 1 or self.force:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._bracket(lambda: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group))
         return t
 
     def all_reduce_max(self, t):
         if self.world > 1 or self.force:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            self._bracket(lambda: dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group))
         return t
 
     def all_gather(self, out, inp):
         """out (world, *inp.shape) <- every rank's inp, in rank order (the candidate exchange of the float64 select)."""
         if self.world > 1 or self.force:
             if "nccl" in str(dist.get_backend(self.group)).lower():
-                dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group)
+                self._bracket(lambda: dist.all_gather_into_tensor(out.view(-1), inp.view(-1), group=self.group))
             else:                                           # gloo (test rigs): per-rank views of the same buffer
-                dist.all_gather([out[r] for r in range(self.world)], inp, group=self.group)
+                self._bracket(lambda: dist.all_gather([out[r] for r in range(self.world)], inp, group=self.group))
         else:
             out[0].copy_(inp)
         return out
@@ -111,3 +124,53 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group(backend or ("nccl" if use_cuda else "gloo"), rank=rank, world_size=world)
     return Shard(rank, world), device
+
+
+def device_identity(device):
+    """What tells two GPUs apart: ordinal, PCI bus id and uuid as far as this torch build exposes them."""
+    out = {"ordinal": int(device.index or 0) if device.type == "cuda" else -1}
+    if device.type == "cuda":
+        p = torch.cuda.get_device_properties(device)
+        out["name"] = p.name
+        for k in ("pci_bus_id", "pci_device_id", "pci_domain_id", "uuid"):
+            if hasattr(p, k):
+                out[k] = str(getattr(p, k))
+    return out
+
+
+def dist_record(shard, device, wb=None, graph_captured=None, eager_iters=5):
+    """Self-verifying record of a (multi-)GPU run, gathered over the process group so that rank 0 can print it with the bench
+    line: backend, world, every rank's device identity (N distinct GPUs?), the ranks that answered the all-gather, the data-path
+    collectives one GN iteration issues (counted on the `Shard` calls, as tests/test_gpu_dist.py does), whether the iteration
+    was captured into a hipGraph on every rank, and -- from HIP events around `eager_iters` eager iterations of `wb` -- where a
+    rank's iteration goes: sharded per-pixel work + set-up (before the packed system), the collectives, the replicated tail
+    (fixed-point -> float64 + packing, Cholesky solve, update).  Collective: every rank must call it."""
+    me = {"rank": shard.rank, "device": device_identity(device), "graph_captured": None if graph_captured is None else bool(graph_captured)}
+    if wb is not None and device.type == "cuda":
+        n0 = shard.n_collectives
+        wb.iterate()                                                 # (eager; also settles lazily created buffers)
+        me["collectives_per_iteration"] = shard.n_collectives - n0
+        tot = sh = co = rep = 0.0
+        for _ in range(eager_iters):
+            shard.timing = []
+            marks = wb.timed_iterate()
+            torch.cuda.synchronize(device)
+            c = sum(a.elapsed_time(b) for a, b in shard.timing)
+            t_all = marks["start"].elapsed_time(marks["end"])
+            t_tail = marks["packed"].elapsed_time(marks["end"])
+            tot, co, rep, sh = tot + t_all, co + c, rep + t_tail, sh + (t_all - t_tail - c)
+        shard.timing = None
+        k = 1e3 / eager_iters
+        me["eager_us_per_iteration"] = {"total": tot * k, "sharded_and_setup": sh * k, "collectives": co * k, "replicated_tail": rep * k}
+    backend = "none"
+    if dist.is_initialized():
+        backend = str(dist.get_backend(shard.group))
+    ranks = [me]
+    if shard.world > 1 and dist.is_initialized():
+        ranks = [None] * shard.world
+        dist.all_gather_object(ranks, me, group=shard.group)
+    ids = {(r["device"].get("uuid") or r["device"].get("pci_bus_id") or r["device"]["ordinal"]) for r in ranks if r}
+    return {"backend": backend, "world": shard.world, "ranks_answered": sorted(r["rank"] for r in ranks if r),
+            "distinct_devices": len(ids), "graph_captured_all": all(bool(r["graph_captured"]) for r in ranks if r),
+            "collectives_per_iteration": sorted({r.get("collectives_per_iteration") for r in ranks if r and "collectives_per_iteration" in r}),
+            "per_rank": ranks}

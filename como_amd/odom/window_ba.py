@@ -451,6 +451,8 @@ class WindowBA:
         _lib.check(_lib.lib().como_sys_finalize_pack(self.sysfix.data_ptr(), self.fix_plane, self.dim, self.H.data_ptr(), self.g.data_ptr(),
                                                      self.err8.data_ptr(), cw[0].data_ptr(), cw[1].data_ptr(), s), "como_sys_finalize_pack")
         self._packed = True
+        if getattr(self, "_marks", None) is not None:
+            self._marks["packed"].record()
 
     def _linearize_sharded(self, dr):
         """The multi-GPU iteration: the same kernels on this rank's pixel range, plus two kinds of collectives (all
@@ -560,6 +562,19 @@ class WindowBA:
                 _lib.check(L.como_win_priors(ctypes.byref(a), s), "como_win_priors")
         self._finalize(s)
         return self.H, self.g
+
+    def timed_iterate(self):
+        """One eager iteration with three events on the current stream: "start", "packed" (the normal equations are complete and
+        packed: everything after it -- solve, update -- is replicated on every rank) and "end" (como_amd/dist.py dist_record)."""
+        ev = {k: torch.cuda.Event(enable_timing=True) for k in ("start", "packed", "end")}
+        self._marks = ev
+        ev["start"].record()
+        try:
+            self.iterate()
+        finally:
+            self._marks = None
+        ev["end"].record()
+        return ev
 
     def iterate_fused(self):
         self._packed = False

@@ -211,3 +211,45 @@ def test_bench_self_launch_builds_the_drivers_command(monkeypatch):
     i = cmd.index(os.path.join(root, "bench.py"))
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def _record_worker(rank, world, port, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
+    from como_amd import dist as cdist
+    shard, device = cdist.init_from_env(backend="gloo")
+    try:
+        h = torch.ones(8, dtype=torch.int32)
+        for _ in range(3):
+            shard.all_reduce_sum(h)
+        shard.all_gather(torch.zeros((world, 4), dtype=torch.int32), torch.full((4,), rank, dtype=torch.int32))
+        shard.all_reduce_sum(torch.ones(16, dtype=torch.int64))
+        rec = cdist.dist_record(shard, device, graph_captured=False)
+        q.put((rank, rec, shard.n_collectives))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_dist_record_gathers_every_rank(world):
+    """The record bench.py prints with a multi-GPU line (como_amd/dist.py dist_record), on CPU ranks: every rank answers the
+    gather, the `Shard` wrappers count the data-path collectives (3 histogram all-reduces + the candidate all-gather + the sums =
+    the five of a float64 iteration), every rank ends with the same record."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 300) + world
+    procs = [ctx.Process(target=_record_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, rec, n = q.get(timeout=240)
+        res[rank] = (rec, n)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank in range(world):
+        rec, n = res[rank]
+        assert n == 5
+        assert rec["backend"] == "gloo" and rec["world"] == world and rec["ranks_answered"] == list(range(world))
+        assert [r["rank"] for r in rec["per_rank"]] == list(range(world))
+        assert rec["graph_captured_all"] is False and rec["per_rank"] == res[0][0]["per_rank"]

@@ -230,6 +230,16 @@ def test_bench_two_ranks_share_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 0
     assert d["metric"] and d["roofline"]["kernel_ms"] > 0 and d["solution"]["cholesky_info"] == 0
     assert d["solution"]["max_pose_abs_err_vs_gt_end"] < d["solution"]["max_pose_abs_err_vs_gt_start"]
+    # the self-verifying record of the process group (como_amd/dist.py dist_record)
+    rec = d["dist"]
+    assert rec["backend"] == "gloo" and rec["world"] == 2 and rec["ranks_answered"] == [0, 1] and rec["sharded_path"] is True
+    assert rec["distinct_devices"] == 1                       # (the one-GPU rig: an N-GPU node must report N here)
+    assert rec["collectives_per_iteration"] == [5]            # float64: 3 histogram all-reduces + 1 candidate all-gather + 1 sums
+    assert rec["graph_captured_all"] is False                 # gloo stages through the host: eager on every rank
+    for r in rec["per_rank"]:
+        t = r["eager_us_per_iteration"]
+        assert t["total"] > 0 and t["collectives"] > 0 and t["replicated_tail"] > 0
+        assert abs(t["total"] - t["sharded_and_setup"] - t["collectives"] - t["replicated_tail"]) < 1e-6 * t["total"]
 
 
 def test_bench_self_launch_without_world_size():
@@ -251,6 +261,54 @@ def test_bench_self_launch_without_world_size():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["solution"]["cholesky_info"] == 0
+    assert d["dist"]["world"] == 2 and d["dist"]["ranks_answered"] == [0, 1]
+
+
+def _dist_record_worker(rank, world, port, q):
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world),
+                       "LOCAL_RANK": "0"})
+    import torch.distributed as dist
+    from como_amd import dist as cdist
+    from como_amd import synth
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    from como_amd.odom.window_ba import WindowBA
+    shard, device = cdist.init_from_env(backend="gloo")
+    try:
+        def predictor(cov, cm):
+            return prep_predictor(cov.double(), cm.double(), 1.0)
+        st = synth.make_window(B=4, H=96, W=128, m=16, dtype=torch.float64, device=device, seed=3, predictor=predictor)
+        wb = WindowBA(st, pix_dtype=torch.float64, window_full=True, shard=shard)
+        wb.iterate()
+        rec = cdist.dist_record(shard, device, wb, graph_captured=False, eager_iters=2)
+        q.put((rank, rec))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_dist_record_world8():
+    """The record the bench line carries for a multi-GPU run, gathered over an EIGHT-rank group (the target node's world, emulated
+    on the one GPU with gloo): every rank answers, every rank reports the same five collectives per float64 iteration and a
+    consistent split of its eager iteration, every rank ends with the same record."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_dist_record_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(8))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank in range(8):
+        rec = res[rank]
+        assert rec["backend"] == "gloo" and rec["world"] == 8 and rec["ranks_answered"] == list(range(8))
+        assert rec["collectives_per_iteration"] == [5] and rec["distinct_devices"] == 1 and rec["graph_captured_all"] is False
+        assert [r["rank"] for r in rec["per_rank"]] == list(range(8))
+        for r in rec["per_rank"]:
+            t = r["eager_us_per_iteration"]
+            assert t["total"] > 0 and t["replicated_tail"] > 0 and t["collectives"] > 0
+    assert all(res[r]["per_rank"] == res[0]["per_rank"] for r in range(8))
 
 
 def test_bench_replicas_one_sequence_per_rank():
@@ -275,6 +333,7 @@ def test_bench_replicas_one_sequence_per_rank():
     assert len(d["per_rank_frames_per_s"]) == 2 and min(d["per_rank_frames_per_s"]) > 0
     assert d["value"] > 0 and abs(d["value"] - 2 * 30 / (d["ms_per_step"] * 30 / 1e3)) < 1e-6 * d["value"]
     assert d["config"]["frames_per_rank"] == 30
+    assert d["dist"]["world"] == 2 and d["dist"]["ranks_answered"] == [0, 1] and d["dist"]["backend"] == "gloo"
 
 
 def test_replica_sequences_share_one_gpu():
