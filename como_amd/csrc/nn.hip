@@ -24,11 +24,21 @@ typedef float nf4 __attribute__((ext_vector_type(4)));
 // for the wide levels.  Loads are unconditional on clamped addresses and the channel loop is unrolled so that several
 // steps' loads are in flight per wave.  Optional epilogue: per-channel sum / sum of squares of the outputs accumulated
 // into gn_sums (N, G, 2) doubles -- the GroupNorm statistics of the next layer, without a separate pass over the tensor.
-template <int KS, int MT, int WV>
+// Round 5 -- the network built around FUSED layers instead of one kernel per torch module:
+//   PRO: the input is read through the GroupNorm + LeakyReLU that precedes the convolution (layers.py:21: act(norm(conv1(x))) feeds
+//        conv2): x' = lrelu(x * sc[c] + sh[c]) with the per-channel scale / shift the PRODUCER of x left behind (gn_finalize /
+//        deep_reduce below) -- the normalised tensor is never written or read;
+//   res: the epilogue of ResidualConv's 1x1 skip convolution adds the normalised main branch and applies the activation
+//        (layers.py:22-24: act(conv3(x) + norm(conv2(y)))): out = lrelu(conv + bias + res * rsc[c] + rsh[c]).
+// A ResidualConv is three launches (conv1, conv2 with PRO, conv3 with res) instead of five, and two tensor round trips shorter.
+template <int KS, int MT, int WV, bool PRO = false>
 __global__ __launch_bounds__(64 * WV) void conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ out, int Cin,
                                                             int CinP, int Cout, int H, int W, int out_ctot, int out_coff,
-                                                            double* __restrict__ gn_sums, int gn_groups) {
+                                                            double* __restrict__ gn_sums, int gn_groups,
+                                                            const float2* __restrict__ pro_scsh = nullptr,
+                                                            const float* __restrict__ res = nullptr,
+                                                            const float2* __restrict__ res_scsh = nullptr, float slope = 0.f) {
   constexpr int GN_SLOTS = 32;
   constexpr int PAD = KS / 2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
@@ -84,31 +94,44 @@ __global__ __launch_bounds__(64 * WV) void conv_mfma_kernel(const float* __restr
     int ci0 = cbeg;
     for (; ci0 + 4 * U <= cend; ci0 += 4 * U) {
       float a[U][MT], b[U][4];
+      float2 ss[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int ci = ci0 + 4 * u + q;                    // ci < CinP: weight rows exist (zero rows beyond Cin)
-        const float* ip = inb + (long)min(ci, Cin - 1) * HW;
+        const int cic = min(ci, Cin - 1);
+        const float* ip = inb + (long)cic * HW;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) a[u][mt] = wk[(long)ci * Cout + wco[mt]];
 #pragma unroll
         for (int t = 0; t < 4; ++t) b[u][t] = ip[off[t]];
+        if (PRO) ss[u] = pro_scsh[(long)n * Cin + cic];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
-            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt] * wokm[mt], b[u][t] * okm[t], acc[mt][t], 0, 0, 0);
+          for (int t = 0; t < 4; ++t) {
+            float bv = b[u][t];
+            if (PRO) { bv = __builtin_fmaf(bv, ss[u].x, ss[u].y); bv = bv > 0.f ? bv : bv * slope; }
+            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][mt] * wokm[mt], bv * okm[t], acc[mt][t], 0, 0, 0);
+          }
     }
     for (; ci0 < cend; ci0 += 4) {
       const int ci = ci0 + q;
-      const float* ip = inb + (long)min(ci, Cin - 1) * HW;
+      const int cic = min(ci, Cin - 1);
+      const float* ip = inb + (long)cic * HW;
+      float2 s1 = {1.f, 0.f};
+      if (PRO) s1 = pro_scsh[(long)n * Cin + cic];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const float av = wk[(long)ci * Cout + wco[mt]] * wokm[mt];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, ip[off[t]] * okm[t], acc[mt][t], 0, 0, 0);
+        for (int t = 0; t < 4; ++t) {
+          float bv = ip[off[t]];
+          if (PRO) { bv = __builtin_fmaf(bv, s1.x, s1.y); bv = bv > 0.f ? bv : bv * slope; }
+          acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv * okm[t], acc[mt][t], 0, 0, 0);
+        }
       }
     }
   }
@@ -142,12 +165,18 @@ __global__ __launch_bounds__(64 * WV) void conv_mfma_kernel(const float* __restr
       const int co = co0 + 16 * mt + 4 * q + r;
       const bool cok = co < Cout;
       const float bv = (bias && cok) ? bias[co] : 0.f;
+      float2 rs = {0.f, 0.f};
+      if (res && cok) rs = res_scsh[(long)n * Cout + co];
       double s1 = 0.0, s2 = 0.0;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int p = p0 + 16 * t + c;
         if (cok && p < HW) {
-          const float v = acc[mt][t][r] + bv;
+          float v = acc[mt][t][r] + bv;
+          if (res) {
+            v += __builtin_fmaf(res[((long)n * Cout + co) * HW + p], rs.x, rs.y);
+            v = v > 0.f ? v : v * slope;
+          }
           ob[(long)co * HW + p] = v;
           s1 += (double)v;
           s2 += (double)v * (double)v;
@@ -166,6 +195,179 @@ __global__ __launch_bounds__(64 * WV) void conv_mfma_kernel(const float* __restr
           atomicAdd(dst + 1, s2);
         }
       }
+    }
+}
+
+// (sum, sum of squares) the producing convolution accumulated (32 contention slots) -> per-channel scale / shift of the GroupNorm
+// that follows: y = x * sc[c] + sh[c], sc = rstd_g gamma_c, sh = beta_c - mean_g sc  (biased variance, as nn.GroupNorm).
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ sums, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int N, int C, int G, int HW, float eps,
+                                                          float2* __restrict__ scsh) {
+  __shared__ float sm[2 * 256];
+  for (int idx = threadIdx.x; idx < N * G; idx += 256) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int sl = 0; sl < 32; ++sl) {
+      s1 += sums[((long)sl * N * G + idx) * 2];
+      s2 += sums[((long)sl * N * G + idx) * 2 + 1];
+    }
+    const double cnt = (double)(C / G) * (double)HW;
+    const double m = s1 / cnt;
+    double var = s2 / cnt - m * m;
+    if (var < 0.0) var = 0.0;
+    sm[2 * idx] = (float)m;
+    sm[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N * C; i += 256) {
+    const int n = i / C, ch = i - n * C, g = ch / (C / G);
+    const float sc = sm[2 * (n * G + g) + 1] * gamma[ch];
+    scsh[i] = float2{sc, beta[ch] - sm[2 * (n * G + g)] * sc};
+  }
+}
+
+// ---- the DEEP levels (24x32 and below: <= 768 pixels, 128 .. 512 channels, 0.3 .. 9.4 MB of weights per layer) ----
+// The generic kernel maps a layer to (pixel tiles) x (Cout / 16) workgroups: 32 workgroups at 6x8, each a chain of 72 dependent
+// load -> matrix batches behind one another -- 36 us for 226 MFLOP, on 32 of 256 compute units.  Here a 3x3 layer is cut along its
+// REDUCTION dimension as well: workgroup (pixel tile, 16 output channels, channel slice) = 9 waves, one per kernel tap (its
+// padding mask and offsets are computed once), each walking its slice of the input channels with 8 steps' loads in flight; the nine
+// taps are summed in LDS in a fixed order, the channel slices leave partial sums, and deep_reduce_kernel adds them in a fixed order
+// (+ bias), writes the layer's output, its GroupNorm statistics and the scale / shift of the normalisation that follows -- one
+// workgroup per (sample, group): no atomics anywhere, the same bits every run.  512 / 384 / 384 workgroups at 6x8 / 12x16 / 24x32.
+template <bool PRO>
+__global__ __launch_bounds__(576) void conv3_deep_kernel(const float* __restrict__ in, const float* __restrict__ wt,
+                                                         float* __restrict__ part, int Cin, int CinP, int Cout, int H, int W,
+                                                         int nslice, const float2* __restrict__ pro_scsh, float slope) {
+  const int lane = threadIdx.x & 63, kk = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
+  const int HW = H * W;
+  const int p0 = blockIdx.x * 64, co0 = blockIdx.y * 16;
+  const int n = blockIdx.z / nslice, slice = blockIdx.z - n * nslice;
+  const float* inb = in + (long)n * Cin * HW;
+  const int ky = kk / 3, kx = kk - 3 * ky;
+  int off[4];
+  float okm[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int p = p0 + 16 * t + c;
+    const int pc = p < HW ? p : HW - 1;
+    const int y = pc / W, x = pc - y * W;
+    const int yy = y + ky - 1, xx = x + kx - 1;
+    const bool ok = p < HW && yy >= 0 && yy < H && xx >= 0 && xx < W;
+    okm[t] = ok ? 1.f : 0.f;
+    off[t] = ok ? yy * W + xx : 0;
+  }
+  const int co = co0 + c;
+  const float wok = co < Cout ? 1.f : 0.f;
+  const int wco = co < Cout ? co : 0;
+  const int steps = CinP >> 2, per = (steps + nslice - 1) / nslice;
+  const int cbeg = 4 * min(steps, slice * per), cend = 4 * min(steps, (slice + 1) * per);
+  const float* wk = wt + (long)kk * CinP * Cout;
+  nf4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = nf4{0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;
+  int ci0 = cbeg;
+  for (; ci0 + 4 * U <= cend; ci0 += 4 * U) {
+    float a[U], b[U][4];
+    float2 ss[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int ci = ci0 + 4 * u + q, cic = min(ci, Cin - 1);
+      const float* ip = inb + (long)cic * HW;
+      a[u] = wk[(long)ci * Cout + wco];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) b[u][t] = ip[off[t]];
+      if (PRO) ss[u] = pro_scsh[(long)n * Cin + cic];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float bv = b[u][t];
+        if (PRO) { bv = __builtin_fmaf(bv, ss[u].x, ss[u].y); bv = bv > 0.f ? bv : bv * slope; }
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u] * wok, bv * okm[t], acc[t], 0, 0, 0);
+      }
+  }
+  for (; ci0 < cend; ci0 += 4) {
+    const int ci = ci0 + q, cic = min(ci, Cin - 1);
+    const float* ip = inb + (long)cic * HW;
+    const float av = wk[(long)ci * Cout + wco] * wok;
+    float2 s1 = {1.f, 0.f};
+    if (PRO) s1 = pro_scsh[(long)n * Cin + cic];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float bv = ip[off[t]];
+      if (PRO) { bv = __builtin_fmaf(bv, s1.x, s1.y); bv = bv > 0.f ? bv : bv * slope; }
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv * okm[t], acc[t], 0, 0, 0);
+    }
+  }
+  // the nine taps, summed by wave 0 in tap order
+  __shared__ float red[8 * 4 * 4 * 64];
+  if (kk > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(((kk - 1) * 4 + t) * 4 + r) * 64 + lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (kk > 0) return;
+#pragma unroll 1
+  for (int w2 = 0; w2 < 8; ++w2)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] += red[((w2 * 4 + t) * 4 + r) * 64 + lane];
+  float* pb = part + ((long)(n * nslice + slice) * Cout) * HW;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int cor = co0 + 4 * q + r;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int p = p0 + 16 * t + c;
+      if (cor < Cout && p < HW) pb[(long)cor * HW + p] = acc[t][r];
+    }
+  }
+}
+
+// out[n][co][p] = bias[co] + sum over the channel slices (fixed order); one workgroup per (sample, group): the group's statistics
+// in float64, then -- when gamma is given -- the scale / shift of the GroupNorm that follows (see gn_finalize_kernel).
+__global__ __launch_bounds__(1024) void deep_reduce_kernel(const float* __restrict__ part, int nslice, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int N, int Cout, int HW, int out_ctot,
+                                                           int out_coff, int G, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps,
+                                                           float2* __restrict__ scsh) {
+  const int n = blockIdx.x / G, g = blockIdx.x - n * G;
+  const int cg = Cout / G;
+  const long cnt = (long)cg * HW;
+  double s1 = 0.0, s2 = 0.0;
+  for (long e = threadIdx.x; e < cnt; e += 1024) {
+    const int co = g * cg + (int)(e / HW), p = (int)(e % HW);
+    float v = bias ? bias[co] : 0.f;
+    for (int sl = 0; sl < nslice; ++sl) v += part[(((long)(n * nslice + sl)) * Cout + co) * HW + p];
+    out[((long)n * out_ctot + out_coff + co) * HW + p] = v;
+    s1 += (double)v;
+    s2 += (double)v * (double)v;
+  }
+  __shared__ double rs[16], rss[16];
+  __shared__ float ms[2];
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s1; rss[threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double S = 0.0, SS = 0.0;
+    for (int w = 0; w < 16; ++w) { S += rs[w]; SS += rss[w]; }
+    const double mean = S / (double)cnt;
+    double var = SS / (double)cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    ms[0] = (float)mean;
+    ms[1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+  __syncthreads();
+  if (gamma && scsh)
+    for (int i = threadIdx.x; i < cg; i += 1024) {
+      const int ch = g * cg + i;
+      const float sc = ms[1] * gamma[ch];
+      scsh[(long)n * Cout + ch] = float2{sc, beta[ch] - ms[0] * sc};
     }
 }
 
@@ -336,11 +538,44 @@ __global__ __launch_bounds__(256) void resize_aa_kernel(const T* __restrict__ in
 }  // namespace como
 
 namespace como {
-template <int KS, int MT, int WV>
+template <int KS, int MT, int WV, bool PRO>
 static void launch_conv(dim3 grid, hipStream_t s, const float* in, const float* wt, const float* bias, float* out, int Cin, int CinP,
-                        int Cout, int H, int W, int out_ctot, int out_coff, double* gn_sums, int gn_groups) {
-  hipLaunchKernelGGL((conv_mfma_kernel<KS, MT, WV>), grid, dim3(64 * WV), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W,
-                     out_ctot, out_coff, gn_sums, gn_groups);
+                        int Cout, int H, int W, int out_ctot, int out_coff, double* gn_sums, int gn_groups, const float2* pro_scsh,
+                        const float* res, const float2* res_scsh, float slope) {
+  hipLaunchKernelGGL((conv_mfma_kernel<KS, MT, WV, PRO>), grid, dim3(64 * WV), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W,
+                     out_ctot, out_coff, gn_sums, gn_groups, pro_scsh, res, res_scsh, slope);
+}
+
+static int conv2d_impl(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout, int H,
+                       int W, int ks, int out_ctot, int out_coff, double* gn_sums, int gn_groups, const float2* pro_scsh,
+                       const float* res, const float2* res_scsh, float slope, hipStream_t s) {
+  if (!in || !wt || !out || N <= 0 || Cin <= 0 || CinP < Cin || (CinP & 3) || Cout <= 0 || H <= 0 || W <= 0 ||
+      (ks != 1 && ks != 3) || out_ctot < out_coff + Cout || (gn_sums && (gn_groups <= 0 || Cout % gn_groups)) ||
+      ((res != nullptr) != (res_scsh != nullptr)) || (pro_scsh && ks != 3))
+    return COMO_ERR_ARG;
+  const int HW = H * W;
+  const int tiles_px = (HW + 63) / 64;
+  // channel-tile height and split-K width: enough waves to fill the chip, at least ~16 reduction steps per wave
+  int mt = (Cout >= 32) ? 2 : 1;
+  long waves = (long)tiles_px * ((Cout + 16 * mt - 1) / (16 * mt)) * N;
+  if (mt == 2 && waves < 2048) { mt = 1; waves = (long)tiles_px * ((Cout + 15) / 16) * N; }
+  int wvs = 1;
+  while (wvs < 16 && waves * wvs < 2048 && (CinP / 4) / (wvs * 2) >= 4) wvs *= 2;
+  const dim3 grid((unsigned)tiles_px, (unsigned)((Cout + 16 * mt - 1) / (16 * mt)), (unsigned)N);
+#define COMO_CONV(KS_, MT_, WV_, PRO_) launch_conv<KS_, MT_, WV_, PRO_>(grid, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff, gn_sums, gn_groups, pro_scsh, res, res_scsh, slope)
+#define COMO_CONV_W(KS_, MT_, PRO_)                                                                               \
+  switch (wvs) { case 1: COMO_CONV(KS_, MT_, 1, PRO_); break; case 2: COMO_CONV(KS_, MT_, 2, PRO_); break;        \
+                 case 4: COMO_CONV(KS_, MT_, 4, PRO_); break; case 8: COMO_CONV(KS_, MT_, 8, PRO_); break;        \
+                 default: COMO_CONV(KS_, MT_, 16, PRO_); break; }
+  if (ks == 3 && pro_scsh) { if (mt == 2) { COMO_CONV_W(3, 2, true) } else { COMO_CONV_W(3, 1, true) } }
+  else if (ks == 3 && mt == 2) { COMO_CONV_W(3, 2, false) }
+  else if (ks == 3) { COMO_CONV_W(3, 1, false) }
+  else if (mt == 2) { COMO_CONV_W(1, 2, false) }
+  else { COMO_CONV_W(1, 1, false) }
+#undef COMO_CONV_W
+#undef COMO_CONV
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
 }
 
 }  // namespace como
@@ -350,32 +585,54 @@ extern "C" {
 int como_nn_conv2d_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
                        int H, int W, int ks, int out_ctot, int out_coff, double* gn_sums, int gn_groups,
                        como_stream_t stream) {
-  if (!in || !wt || !out || N <= 0 || Cin <= 0 || CinP < Cin || (CinP & 3) || Cout <= 0 || H <= 0 || W <= 0 ||
-      (ks != 1 && ks != 3) || out_ctot < out_coff + Cout || (gn_sums && (gn_groups <= 0 || Cout % gn_groups)))
+  return como::conv2d_impl(in, wt, bias, out, N, Cin, CinP, Cout, H, W, ks, out_ctot, out_coff, gn_sums, gn_groups, nullptr, nullptr,
+                           nullptr, 0.f, (hipStream_t)stream);
+}
+
+int como_nn_conv2d_fused_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
+                             int H, int W, int ks, int out_ctot, int out_coff, double* gn_sums, int gn_groups,
+                             const float* pro_scsh, const float* res, const float* res_scsh, float slope, como_stream_t stream) {
+  return como::conv2d_impl(in, wt, bias, out, N, Cin, CinP, Cout, H, W, ks, out_ctot, out_coff, gn_sums, gn_groups,
+                           (const float2*)pro_scsh, res, (const float2*)res_scsh, slope, (hipStream_t)stream);
+}
+
+int como_nn_gn_finalize_f32(const double* sums, const float* gamma, const float* beta, int N, int C, int G, int HW, float eps,
+                            float* scsh, como_stream_t stream) {
+  if (!sums || !gamma || !beta || !scsh || N <= 0 || C <= 0 || G <= 0 || (C % G) || HW <= 0 || N * G > 256) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::gn_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, gamma, beta, N, C, G, HW, eps,
+                     (float2*)scsh);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+long como_nn_deep_part_floats(int N, int Cin, int Cout, int H, int W) {
+  const int HW = H * W, tiles = ((HW + 63) / 64) * ((Cout + 15) / 16) * N;
+  int ns = 1;
+  while (ns < 16 && tiles * ns < 384 && (((Cin + 3) / 4) / (ns * 2)) >= 8) ns *= 2;
+  return (long)ns * N * Cout * HW;
+}
+
+int como_nn_conv3x3_deep_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
+                             int H, int W, int out_ctot, int out_coff, const float* pro_scsh, float slope, float* part,
+                             long part_floats, int G, const float* gamma, const float* beta, float eps, float* scsh,
+                             como_stream_t stream) {
+  using namespace como;
+  if (!in || !wt || !out || !part || N <= 0 || Cin <= 0 || CinP < Cin || (CinP & 3) || Cout <= 0 || H <= 0 || W <= 0 ||
+      out_ctot < out_coff + Cout || G <= 0 || (Cout % G) || ((gamma != nullptr) != (beta != nullptr)) || (scsh && !gamma))
     return COMO_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int HW = H * W;
-  const int tiles_px = (HW + 63) / 64;
-  const long ksteps = (long)ks * ks * (CinP / 4);
-  // channel-tile height and split-K width: enough waves to fill the chip, at least ~16 reduction steps per wave
-  int mt = (Cout >= 32) ? 2 : 1;
-  long waves = (long)tiles_px * ((Cout + 16 * mt - 1) / (16 * mt)) * N;
-  if (mt == 2 && waves < 2048) { mt = 1; waves = (long)tiles_px * ((Cout + 15) / 16) * N; }
-  int wvs = 1;
-  while (wvs < 16 && waves * wvs < 2048 && (CinP / 4) / (wvs * 2) >= 4) wvs *= 2;
-  (void)ksteps;
-  const dim3 grid((unsigned)tiles_px, (unsigned)((Cout + 16 * mt - 1) / (16 * mt)), (unsigned)N);
-#define COMO_CONV(KS_, MT_, WV_) como::launch_conv<KS_, MT_, WV_>(grid, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff, gn_sums, gn_groups)
-#define COMO_CONV_W(KS_, MT_)                                                                         \
-  switch (wvs) { case 1: COMO_CONV(KS_, MT_, 1); break; case 2: COMO_CONV(KS_, MT_, 2); break;        \
-                 case 4: COMO_CONV(KS_, MT_, 4); break; case 8: COMO_CONV(KS_, MT_, 8); break;        \
-                 default: COMO_CONV(KS_, MT_, 16); break; }
-  if (ks == 3 && mt == 2) { COMO_CONV_W(3, 2) }
-  else if (ks == 3) { COMO_CONV_W(3, 1) }
-  else if (mt == 2) { COMO_CONV_W(1, 2) }
-  else { COMO_CONV_W(1, 1) }
-#undef COMO_CONV_W
-#undef COMO_CONV
+  const int HW = H * W, tiles = ((HW + 63) / 64) * ((Cout + 15) / 16) * N;
+  int ns = 1;                                               // channel slices: >= 384 workgroups, >= 8 reduction steps per wave
+  while (ns < 16 && tiles * ns < 384 && ((CinP / 4) / (ns * 2)) >= 8) ns *= 2;
+  if ((long)ns * N * Cout * HW > part_floats) return COMO_ERR_ARG;
+  const dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((Cout + 15) / 16), (unsigned)(N * ns));
+  if (pro_scsh)
+    hipLaunchKernelGGL(conv3_deep_kernel<true>, grid, dim3(576), 0, s, in, wt, part, Cin, CinP, Cout, H, W, ns, (const float2*)pro_scsh, slope);
+  else
+    hipLaunchKernelGGL(conv3_deep_kernel<false>, grid, dim3(576), 0, s, in, wt, part, Cin, CinP, Cout, H, W, ns, (const float2*)nullptr, slope);
+  COMO_CHECK_LAUNCH();
+  hipLaunchKernelGGL(deep_reduce_kernel, dim3((unsigned)(N * G)), dim3(1024), 0, s, (const float*)part, ns, bias, out, N, Cout, HW,
+                     out_ctot, out_coff, G, gamma, beta, eps, (float2*)scsh);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }

@@ -58,6 +58,48 @@ def _groupnorm(x, gamma, beta, act, residual=None, sums=None):
     return out
 
 
+DEEP_MAX_PIXELS = 768   # levels of 24x32 and below run their 3x3 layers on the reduction-split kernels (csrc/nn.hip conv3_deep)
+_deep_part = {}         # per device: the partial-sum scratch of the deep layers (grow-only; one stream at a time per device)
+
+
+def _deep_scratch(dev, need):
+    key = str(dev)
+    buf = _deep_part.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _deep_part[key] = torch.empty(need, dtype=torch.float32, device=dev)
+    return buf
+
+
+def _conv3_any(conv, x, out=None, coff=0, pro_scsh=None, norm=None, sums=None):
+    """One 3x3 layer of the fused network -> (output, scsh of the GroupNorm `norm` = (gamma, beta) that follows, or None).
+    Deep levels: the reduction-split kernel + its deterministic reduce (statistics included); wide levels: the generic kernel with
+    the statistics accumulated into `sums` (pre-zeroed (32,N,16,2) float64) and finalised by one tiny launch."""
+    N, C, H, W = x.shape
+    L, s = _lib.lib(), _lib.stream_ptr(x.device)
+    if out is None:
+        out = torch.empty((N, conv.cout, H, W), dtype=torch.float32, device=x.device)
+    scsh = torch.empty((N, conv.cout, 2), dtype=torch.float32, device=x.device) if norm is not None else None
+    if H * W <= DEEP_MAX_PIXELS and conv.cin >= 64:
+        need = L.como_nn_deep_part_floats(N, conv.cin, conv.cout, H, W)
+        part = _deep_scratch(x.device, need)
+        rc = L.como_nn_conv3x3_deep_f32(x.data_ptr(), conv.wt.data_ptr(), conv.bias.data_ptr(), out.data_ptr(), N, conv.cin, conv.cinp,
+                                        conv.cout, H, W, out.shape[1], coff, _lib.ptr(pro_scsh), LEAKY_SLOPE, part.data_ptr(),
+                                        part.numel(), GN_GROUPS, norm[0].data_ptr() if norm else None,
+                                        norm[1].data_ptr() if norm else None, GN_EPS, _lib.ptr(scsh), s)
+        _lib.check(rc, "como_nn_conv3x3_deep_f32")
+        return out, scsh
+    if norm is not None and sums is None:
+        sums = torch.zeros((32, N, GN_GROUPS, 2), dtype=torch.float64, device=x.device)
+    rc = L.como_nn_conv2d_fused_f32(x.data_ptr(), conv.wt.data_ptr(), conv.bias.data_ptr(), out.data_ptr(), N, conv.cin, conv.cinp,
+                                    conv.cout, H, W, 3, out.shape[1], coff, sums.data_ptr() if norm is not None else None, GN_GROUPS,
+                                    _lib.ptr(pro_scsh), None, None, LEAKY_SLOPE, s)
+    _lib.check(rc, "como_nn_conv2d_fused_f32")
+    if norm is not None:
+        _lib.check(L.como_nn_gn_finalize_f32(sums.data_ptr(), norm[0].data_ptr(), norm[1].data_ptr(), N, conv.cout, GN_GROUPS, H * W,
+                                             GN_EPS, scsh.data_ptr(), s), "como_nn_gn_finalize_f32")
+    return out, scsh
+
+
 class ResidualConv:
     """layers.py:5-27: act(conv3(x) + norm(conv2(act(norm(conv1(x)))))) -- ONE GroupNorm module used twice."""
 
@@ -68,8 +110,27 @@ class ResidualConv:
         self.gamma = sd[prefix + "norm.weight"].float().contiguous()
         self.beta = sd[prefix + "norm.bias"].float().contiguous()
 
-    def __call__(self, x, sums=None):
-        """sums: (2, 32, N, 16, 2) zeroed float64 scratch for the two GroupNorm statistics (None: separate stats passes)."""
+    def __call__(self, x, sums=None, out=None, coff=0):
+        """The fused form: conv1 -> conv2 reading its input through norm + act -> conv3 with `+ norm(conv2)`, act in its epilogue.
+        sums: (2, 32, N, 16, 2) zeroed float64 scratch for the statistics of the wide levels (None: allocated here);
+        out / coff: write the block's output into channels [coff, coff + Cout) of `out` (the concatenation of UpConv)."""
+        N, C, H, W = x.shape
+        assert C == self.conv1.cin and x.dtype == torch.float32 and x.is_contiguous()
+        norm = (self.gamma, self.beta)
+        s1, s2 = (sums[0], sums[1]) if sums is not None else (None, None)
+        y1, scsh1 = _conv3_any(self.conv1, x, norm=norm, sums=s1)
+        y2, scsh2 = _conv3_any(self.conv2, y1, pro_scsh=scsh1, norm=norm, sums=s2)
+        if out is None:
+            out = torch.empty((N, self.conv3.cout, H, W), dtype=torch.float32, device=x.device)
+        c3 = self.conv3
+        rc = _lib.lib().como_nn_conv2d_fused_f32(x.data_ptr(), c3.wt.data_ptr(), c3.bias.data_ptr(), out.data_ptr(), N, c3.cin, c3.cinp,
+                                                 c3.cout, H, W, 1, out.shape[1], coff, None, GN_GROUPS, None, y2.data_ptr(),
+                                                 scsh2.data_ptr(), LEAKY_SLOPE, _lib.stream_ptr(x.device))
+        _lib.check(rc, "como_nn_conv2d_fused_f32")
+        return out
+
+    def unfused(self, x, sums=None):
+        """Round 2-4's form (five launches: two separate GroupNorm passes): kept as the layer-by-layer check of the fused one."""
         s1, s2 = (sums[0], sums[1]) if sums is not None else (None, None)
         y = _groupnorm(self.conv1(x, gn_sums=s1), self.gamma, self.beta, 1, sums=s1)
         y2 = self.conv2(y, gn_sums=s2)
@@ -158,7 +219,7 @@ class UNet:
             skip = enc[i]
             N, c, H, W = skip.shape
             cat = torch.empty((N, 2 * c, H, W), dtype=torch.float32, device=x.device)
-            self.up_conv[i](upsample2x(dec), out=cat, coff=0)
+            _conv3_any(self.up_conv[i], upsample2x(dec), out=cat, coff=0)
             cat[:, c:].copy_(skip)
             dec = self.up_block[i](cat, sums[1 + self.num_levels + i])
             if i < self.num_levels - 1:

@@ -258,9 +258,13 @@ class Mapping:
                 self.depth_imgs_of(ind, end))
 
     def get_kf_viz_data(self, ind=-1):
-        """Mapping.py:514-544: cloned snapshot for a viewer."""
+        """Mapping.py:514-544: cloned snapshot for a viewer.  The GUI is out of scope: the headless loop
+        takes no snapshot -- 2 x all depth images + clones of the colour images and the window state per keyframe, ~40 launches --
+        unless the mapping config says `viewer_snapshots: true`; the send time is kept either way (MappingSeq.map's 1 s rule)."""
         import time
         self.last_kf_send_time = time.time()
+        if not self.cfg.get("viewer_snapshots", False):
+            return None
         return (self.kf_timestamps.copy(), self.rgb.clone(), self.kf_poses.clone(), self.depth_imgs.clone(),
                 swap_coords_xy(self.pm).clone(), self.P_m.clone(), self.obs_ref_mask.clone(), self.recent_poses.clone(),
                 list(getattr(self, "kf_pairs", [])), list(getattr(self, "one_way_pairs", [])))

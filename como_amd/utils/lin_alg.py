@@ -31,9 +31,10 @@ def chol_small(A, want_L=True, want_inv=False, rhs=None, want_info=False):
         k = r3.shape[2]
         X = torch.empty_like(r3)
     info = torch.zeros(B, dtype=torch.int32, device=dev)
-    fn = getattr(_lib.lib(), "como_chol_small_" + _lib.suffix(dt))
-    rc = fn(A3.data_ptr(), B, n, _lib.ptr(L), _lib.ptr(inv), _lib.ptr(r3), k, _lib.ptr(X), info.data_ptr(), _lib.stream_ptr(dev))
-    _lib.check(rc, "como_chol_small")
+    if n > 0 and B > 0:                                   # (an empty system -- a keyframe that tracked no point of the previous one --
+        fn = getattr(_lib.lib(), "como_chol_small_" + _lib.suffix(dt))      # has empty factors, as torch.linalg.cholesky returns)
+        rc = fn(A3.data_ptr(), B, n, _lib.ptr(L), _lib.ptr(inv), _lib.ptr(r3), k, _lib.ptr(X), info.data_ptr(), _lib.stream_ptr(dev))
+        _lib.check(rc, "como_chol_small")
     out = {}
     un = (lambda t: t[0]) if squeeze else (lambda t: t)
     if want_L:

@@ -500,6 +500,24 @@ int como_se3_compose_f64(const double* A, const double* B, double* out, int n, i
 int como_nn_conv2d_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
                        int H, int W, int ks, int out_ctot, int out_coff, double* gn_sums, int gn_groups,
                        como_stream_t stream);
+/* Round 5, fused layers (csrc/nn.hip): a ResidualConv (layers.py:5-27) is conv1 -> conv2 (reading its input THROUGH the GroupNorm +
+ * LeakyReLU in between) -> conv3 (adding the normalised main branch and the activation in its epilogue).
+ *  conv2d_fused : conv2d with   pro_scsh (N,Cin,2) floats, optional, ks = 3: the input is lrelu(in * sc[c] + sh[c]);
+ *                               res (N,Cout,H,W) + res_scsh (N,Cout,2), optional: out = lrelu(conv + bias + res * sc[c] + sh[c]).
+ *  gn_finalize  : the (32,N,G,2) sums a convolution accumulated -> scsh (N,C,2): sc = rstd_g gamma_c, sh = beta_c - mean_g sc.
+ *  conv3x3_deep : a 3x3 layer of the deep levels (<= 768 pixels) split along its reduction dimension, deterministic: partial sums
+ *                 in `part` (como_nn_deep_part_floats floats), a second launch adds them + bias, writes `out`, and -- gamma / beta
+ *                 given -- scsh (N,Cout,2) of the GroupNorm(G, Cout) that follows. */
+int como_nn_conv2d_fused_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
+                             int H, int W, int ks, int out_ctot, int out_coff, double* gn_sums, int gn_groups,
+                             const float* pro_scsh, const float* res, const float* res_scsh, float slope, como_stream_t stream);
+int como_nn_gn_finalize_f32(const double* sums, const float* gamma, const float* beta, int N, int C, int G, int HW, float eps,
+                            float* scsh, como_stream_t stream);
+long como_nn_deep_part_floats(int N, int Cin, int Cout, int H, int W);
+int como_nn_conv3x3_deep_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
+                             int H, int W, int out_ctot, int out_coff, const float* pro_scsh, float slope, float* part,
+                             long part_floats, int G, const float* gamma, const float* beta, float eps, float* scsh,
+                             como_stream_t stream);
 int como_nn_groupnorm_f32(const float* x, const float* gamma, const float* beta, const float* residual, float* out,
                           float* stats, const double* sums, int N, int C, int G, int HW, float eps, float slope, int act,
                           como_stream_t stream);
