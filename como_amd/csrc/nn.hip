@@ -13,6 +13,7 @@
 // 192x256: it is launch-count bound, not MFMA bound; the kernels are kept simple and exact-shape.
 #include "common.cuh"
 #include "../../include/como_hip.h"
+#include <cstdlib>
 
 namespace como {
 
@@ -225,6 +226,221 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
   }
 }
 
+// ---- the WIDE levels (48x64 .. 192x256): 3x3 layers with the input tile staged in LDS ----
+// The generic kernel reads every input value nine times from L2 through per-lane gathers, behind which its matrix instructions
+// wait: a 16 -> 16 layer at 192x256 is 768 one-wave workgroups, each a chain of nine load -> matrix batches (21 us for 226 MFLOP).
+// Here a workgroup (4 waves) owns a TH x 32 pixel tile and 16 output channels: the (TH + 2) x 34 halo tile of EVERY input channel
+// is fetched once, coalesced, all loads in flight together -- through the preceding GroupNorm + LeakyReLU when PRO, so the
+// normalisation is applied once per value, not once per tap -- into LDS planes whose stride makes the matrix operand reads
+// conflict-free (lane (x, q) reads plane 4 step + q at x: plane stride = 16 or 48 mod 64 words); the reduction loop then touches
+// never touches global memory: the workgroup's 16 columns of the weights are staged too.  TH x KW = 8: the four waves are TH / 2
+// pixel groups (two rows of 32 pixels each) x KW slices of the input channels (summed in LDS in a fixed order): 4 x 2 at 192x256,
+// 2 x 4 at 96x128 and 48x64.  Measured: 21 -> 14-17 us per layer; what is left is the chain stage -> barrier -> reduction ->
+// epilogue on one 4-wave workgroup per compute unit (each piece one round trip to the memory side: the tensors come from another XCD).
+template <int TH, bool PRO>
+__global__ __launch_bounds__(256) void conv3_tile_kernel(const float* __restrict__ in, const float* __restrict__ wt,
+                                                         const float* __restrict__ bias, float* __restrict__ out, int Cin, int CinP,
+                                                         int Cout, int H, int W, int out_ctot, int out_coff,
+                                                         double* __restrict__ gn_sums, int gn_groups,
+                                                         const float2* __restrict__ pro_scsh, float slope) {
+  constexpr int KW = 8 / TH, R = TH + 2, LW = TH == 2 ? 44 : 40, PS = R * LW, GN_SLOTS = 32;   // PS = 16 or 48 mod 64; interior at column 4
+  extern __shared__ float tile[];                              // [CinP][R][LW]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
+  const int pg = wv / KW, kw = wv - pg * KW;                   // pixel group (rows 2 pg, 2 pg + 1 of the tile), channel slice
+  const int HW = H * W;
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * TH;
+  const int ntc = (Cout + 15) / 16;
+  const int n = blockIdx.z / ntc, co0 = (blockIdx.z - n * ntc) * 16;
+  const float* inb = in + (long)n * Cin * HW;
+  // ---- stage the halo tile of all channels (zero padding outside the image and beyond Cin) and this workgroup's 16 columns of
+  //      the weights ([9][CinP][16]: lane (c, q) reads word 16 q + c of a 64-word row -- conflict-free) ----
+  float* wl = tile + CinP * PS;
+  // (every phase's FIRST round of loads is issued before anything is written to LDS: the tensors were just produced by another
+  // kernel, usually on another XCD -- each dependent phase costs a ~2 us round trip to the memory side, and a small layer is three
+  // phases of one round each)
+  const int EV = CinP * R * 8, EH = CinP * R * 2, EW = 9 * CinP * 4;
+  const bool vec = (Cout & 15) == 0;
+  constexpr int SB = 8;
+  auto load_in = [&](int e0, float4 (&v)[SB], int (&dst)[SB]) {
+    // interior: rows of 32 floats = eight 16-byte vectors, 16-byte aligned in memory (W, x0 multiples of 32) and in LDS (column 4)
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int e = min(e0 + 256 * u, EV - 1);
+      const int ci = e / (R * 8), rem = e - ci * (R * 8), r = rem >> 3, j = rem & 7;
+      const int yy = y0 + r - 1;
+      const bool ok = ci < Cin && yy >= 0 && yy < H;
+      dst[u] = e0 + 256 * u < EV ? ci * PS + r * LW + 4 + 4 * j : -1;
+      const int cic = min(ci, Cin - 1), yc = min(max(yy, 0), H - 1);
+      float4 x = *reinterpret_cast<const float4*>(&inb[(long)cic * HW + (long)yc * W + x0 + 4 * j]);
+      if (PRO) {
+        const float2 ss = pro_scsh[(long)n * Cin + cic];
+        x.x = __builtin_fmaf(x.x, ss.x, ss.y); x.x = x.x > 0.f ? x.x : x.x * slope;
+        x.y = __builtin_fmaf(x.y, ss.x, ss.y); x.y = x.y > 0.f ? x.y : x.y * slope;
+        x.z = __builtin_fmaf(x.z, ss.x, ss.y); x.z = x.z > 0.f ? x.z : x.z * slope;
+        x.w = __builtin_fmaf(x.w, ss.x, ss.y); x.w = x.w > 0.f ? x.w : x.w * slope;
+      }
+      const float m = ok ? 1.f : 0.f;
+      v[u] = float4{x.x * m, x.y * m, x.z * m, x.w * m};
+    }
+  };
+  auto load_halo = [&](int e0, float (&v)[4], int (&dst)[4]) {      // the two halo columns (tile columns 3 and 36)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(e0 + 256 * u, EH - 1);
+      const int ci = e / (R * 2), rem = e - ci * (R * 2), r = rem >> 1, side = rem & 1;
+      const int yy = y0 + r - 1, xx = side ? x0 + 32 : x0 - 1;
+      const bool ok = ci < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W;
+      dst[u] = e0 + 256 * u < EH ? ci * PS + r * LW + (side ? 36 : 3) : -1;
+      const int cic = min(ci, Cin - 1), yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+      float x = inb[(long)cic * HW + (long)yc * W + xc];
+      if (PRO) {
+        const float2 ss = pro_scsh[(long)n * Cin + cic];
+        x = __builtin_fmaf(x, ss.x, ss.y);
+        x = x > 0.f ? x : x * slope;
+      }
+      v[u] = x * (ok ? 1.f : 0.f);
+    }
+  };
+  auto load_w = [&](int e0, float4 (&v)[4]) {      // 16 columns of the weights: four 16-byte vectors per (tap, channel) row
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = min(e0 + 256 * u, EW - 1), row = e >> 2, j = e & 3;
+      if (vec) {
+        v[u] = *reinterpret_cast<const float4*>(&wt[(long)row * Cout + co0 + 4 * j]);
+      } else {
+        float t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int cc = co0 + 4 * j + k; t[k] = wt[(long)row * Cout + min(cc, Cout - 1)] * (cc < Cout ? 1.f : 0.f); }
+        v[u] = float4{t[0], t[1], t[2], t[3]};
+      }
+    }
+  };
+  {
+    float4 vi[SB], vw[4];
+    float vh[4];
+    int di[SB], dh[4];
+    load_in(tid, vi, di);
+    load_halo(tid, vh, dh);
+    load_w(tid, vw);
+#pragma unroll
+    for (int u = 0; u < SB; ++u)
+      if (di[u] >= 0) *reinterpret_cast<float4*>(&tile[di[u]]) = vi[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (dh[u] >= 0) tile[dh[u]] = vh[u];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (tid + 256 * u < EW) *reinterpret_cast<float4*>(&wl[4 * (tid + 256 * u)]) = vw[u];
+    for (int e0 = tid + 256 * SB; e0 < EV; e0 += 256 * SB) {
+      load_in(e0, vi, di);
+#pragma unroll
+      for (int u = 0; u < SB; ++u)
+        if (di[u] >= 0) *reinterpret_cast<float4*>(&tile[di[u]]) = vi[u];
+    }
+    for (int e0 = tid + 256 * 4; e0 < EH; e0 += 256 * 4) {
+      load_halo(e0, vh, dh);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (dh[u] >= 0) tile[dh[u]] = vh[u];
+    }
+    for (int e0 = tid + 256 * 4; e0 < EW; e0 += 256 * 4) {
+      load_w(e0, vw);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (e0 + 256 * u < EW) *reinterpret_cast<float4*>(&wl[4 * (e0 + 256 * u)]) = vw[u];
+    }
+  }
+  __syncthreads();
+  // ---- the reduction: this wave's pixel group x its slice of the channels, all nine taps -- LDS and the matrix pipe only ----
+  const int steps = CinP >> 2, per = (steps + KW - 1) / KW;
+  const int sbeg = min(steps, kw * per), send = min(steps, (kw + 1) * per);
+  float bvr[4];                                                // (the epilogue's bias: fetched now, not after the reduction)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bvr[r] = bias ? bias[min(co0 + 4 * q + r, Cout - 1)] : 0.f;
+  nf4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = nf4{0.f, 0.f, 0.f, 0.f};
+  // operand t: row 2 pg + (t >> 1) of the tile, columns 16 (t & 1) + c
+  const float* tb = tile + (2 * pg) * LW + c + q * PS;
+  const float* wb = wl + 16 * q + c;
+#pragma unroll 1
+  for (int kk = 0; kk < 9; ++kk) {
+    const int ky = kk / 3, kx = kk - 3 * ky;
+    const float* wk = wb + kk * CinP * 16;
+    const float* tk = tb + ky * LW + kx + 3;                   // (interior at column 4: tap kx - 1 of pixel x reads column 3 + x + kx)
+    constexpr int U = 4;
+    int st = sbeg;
+    for (; st + U <= send; st += U) {
+      float a[U], b[U][4];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        a[u] = wk[64 * (st + u)];
+        const float* tp = tk + 4 * (st + u) * PS;
+        b[u][0] = tp[0]; b[u][1] = tp[16]; b[u][2] = tp[LW]; b[u][3] = tp[LW + 16];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u][t], acc[t], 0, 0, 0);
+    }
+    for (; st < send; ++st) {
+      const float av = wk[64 * st];
+      const float* tp = tk + 4 * st * PS;
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tp[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tp[16], acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tp[LW], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, tp[LW + 16], acc[3], 0, 0, 0);
+    }
+  }
+  if (KW > 1) {                                                // channel slices: summed by slice 0 in slice order (over the dead tile)
+    __syncthreads();
+    float* red = tile;
+    if (kw > 0) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[(((pg * (KW - 1) + kw - 1) * 4 + t) * 4 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (kw > 0) return;
+#pragma unroll 1
+    for (int k2 = 0; k2 < KW - 1; ++k2)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += red[(((pg * (KW - 1) + k2) * 4 + t) * 4 + r) * 64 + lane];
+  }
+  float* ob = out + ((long)n * out_ctot + out_coff) * HW;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int cor = co0 + 4 * q + r;
+    const bool cok = cor < Cout;
+    const float bv = cok ? bvr[r] : 0.f;
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int yy = y0 + 2 * pg + (t >> 1), xx = x0 + 16 * (t & 1) + c;
+      if (cok && yy < H && xx < W) {
+        const float v = acc[t][r] + bv;
+        ob[(long)cor * HW + (long)yy * W + xx] = v;
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+      }
+    }
+    if (gn_sums) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 16); s2 += __shfl_xor(s2, o, 16); }
+      if (c == 0 && cok) {
+        const int g = cor / (Cout / gn_groups);
+        const int slot = (blockIdx.x + blockIdx.y + wv) % GN_SLOTS;
+        double* dst = gn_sums + (((long)slot * (gridDim.z / ntc) + n) * gn_groups + g) * 2;
+        atomicAdd(dst, s1);
+        atomicAdd(dst + 1, s2);
+      }
+    }
+  }
+}
+
 // ---- the DEEP levels (24x32 and below: <= 768 pixels, 128 .. 512 channels, 0.3 .. 9.4 MB of weights per layer) ----
 // The generic kernel maps a layer to (pixel tiles) x (Cout / 16) workgroups: 32 workgroups at 6x8, each a chain of 72 dependent
 // load -> matrix batches behind one another -- 36 us for 226 MFLOP, on 32 of 256 compute units.  Here a 3x3 layer is cut along its
@@ -339,13 +555,31 @@ __global__ __launch_bounds__(1024) void deep_reduce_kernel(const float* __restri
   const int cg = Cout / G;
   const long cnt = (long)cg * HW;
   double s1 = 0.0, s2 = 0.0;
-  for (long e = threadIdx.x; e < cnt; e += 1024) {
-    const int co = g * cg + (int)(e / HW), p = (int)(e % HW);
-    float v = bias ? bias[co] : 0.f;
-    for (int sl = 0; sl < nslice; ++sl) v += part[(((long)(n * nslice + sl)) * Cout + co) * HW + p];
-    out[((long)n * out_ctot + out_coff + co) * HW + p] = v;
-    s1 += (double)v;
-    s2 += (double)v * (double)v;
+  if ((HW & 3) == 0) {                                       // four pixels per thread and step, the slices' loads in flight together
+    const int HW4 = HW >> 2;
+    for (int e = threadIdx.x; e < cg * HW4; e += 1024) {
+      const int cl = e / HW4, p4 = e - cl * HW4, co = g * cg + cl;
+      const float bv = bias ? bias[co] : 0.f;
+      float4 v = {bv, bv, bv, bv};
+      const float* base = part + ((long)n * nslice * Cout + co) * HW + 4 * p4;
+#pragma unroll 4
+      for (int sl = 0; sl < nslice; ++sl) {
+        const float4 t = *reinterpret_cast<const float4*>(base + (long)sl * Cout * HW);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      *reinterpret_cast<float4*>(&out[((long)n * out_ctot + out_coff + co) * HW + 4 * p4]) = v;
+      s1 += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+      s2 += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+  } else {
+    for (long e = threadIdx.x; e < cnt; e += 1024) {
+      const int co = g * cg + (int)(e / HW), p = (int)(e % HW);
+      float v = bias ? bias[co] : 0.f;
+      for (int sl = 0; sl < nslice; ++sl) v += part[(((long)(n * nslice + sl)) * Cout + co) * HW + p];
+      out[((long)n * out_ctot + out_coff + co) * HW + p] = v;
+      s1 += (double)v;
+      s2 += (double)v * (double)v;
+    }
   }
   __shared__ double rs[16], rss[16];
   __shared__ float ms[2];
@@ -554,6 +788,32 @@ static int conv2d_impl(const float* in, const float* wt, const float* bias, floa
       ((res != nullptr) != (res_scsh != nullptr)) || (pro_scsh && ks != 3))
     return COMO_ERR_ARG;
   const int HW = H * W;
+  static const bool use_tile = [] { const char* e = getenv("COMO_NN_TILE"); return !e || e[0] != '0'; }();   // (=0: the generic kernel, A/B)
+  if (ks == 3 && !res && use_tile && (W % 32) == 0 && HW >= 3072) {
+    // LDS-tiled form: 4 rows per tile at 192x256 (384 workgroups), 2 below (384 / 96 x Cout / 16)
+    const int th = HW >= 49152 ? 4 : 2;                     // (measured: 4 / 2 / 2 beats 8 / 4 / 2 by 2 %: twice the workgroups per level)
+    if ((H % th) == 0) {
+      const int R = th + 2, LW = th == 2 ? 44 : 40;
+      const size_t lds = ((size_t)CinP * R * LW + (size_t)9 * CinP * 16) * sizeof(float);      // halo tile + 16 weight columns
+      const size_t red = (size_t)(8 / th - 1) * (th / 2) * 16 * 64 * sizeof(float);
+      const size_t bytes = lds > red ? lds : red;
+      if (bytes <= 158 * 1024) {
+        const dim3 g2((unsigned)(W / 32), (unsigned)(H / th), (unsigned)(N * ((Cout + 15) / 16)));
+#define COMO_TILE(TH_, PRO_)                                                                                                     \
+  do {                                                                                                                           \
+    static bool attr = false;                                                                                                    \
+    if (!attr) { (void)hipFuncSetAttribute((const void*)conv3_tile_kernel<TH_, PRO_>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); attr = true; } \
+    hipLaunchKernelGGL((conv3_tile_kernel<TH_, PRO_>), g2, dim3(256), bytes, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, \
+                       out_coff, gn_sums, gn_groups, pro_scsh, slope);                                                           \
+  } while (0)
+        if (th == 4) { if (pro_scsh) COMO_TILE(4, true); else COMO_TILE(4, false); }
+        else { if (pro_scsh) COMO_TILE(2, true); else COMO_TILE(2, false); }
+#undef COMO_TILE
+        COMO_CHECK_LAUNCH();
+        return COMO_OK;
+      }
+    }
+  }
   const int tiles_px = (HW + 63) / 64;
   // channel-tile height and split-K width: enough waves to fill the chip, at least ~16 reduction steps per wave
   int mt = (Cout >= 32) ? 2 : 1;

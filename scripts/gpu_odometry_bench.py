@@ -59,17 +59,13 @@ def main():
     args = ap.parse_args()
     dev = "cuda:0"
     H, W = args.H, args.W
-    scene = synth.PlaneScene(seed=1, freq_scale=W / 640.0)
-    K = synth.intrinsics_for(H, W)
-    T = synth.gt_poses(args.frames, step=args.step, deg=0.3)
-    g = torch.Generator().manual_seed(1)
-    rgbs = []
-    for k in range(args.frames):
-        I, _ = scene.render(T[k], K, H, W)
-        I = I + 0.002 * torch.randn(I.shape, generator=g, dtype=torch.float64)
-        rgbs.append(I[None, None].repeat(1, 3, 1, 1).to(dev))
+    # the sequence pinned against the reference's own loop (scripts/ate_sequence.py SEQ640 = tests/golden/ate_sequence_640.npz)
+    from scripts.ate_sequence import SEQ640, loop_cfgs, render_frames
+    G = dict(SEQ640, seed=1, nframes=args.frames, H=H, W=W)
+    K, T, rgbs_cpu = render_frames(G)
+    rgbs = [r.to(dev) for r in rgbs_cpu]
     model = DepthCovModule({k: v.to(dev) for k, v in synth.depthcov_state_dict(0).items()})
-    odo = ComoSeq(cfgs(dev, args), K.clone(), (H, W), model)
+    odo = ComoSeq(loop_cfgs(G, args.pix, dev, graph_network=True), K.clone(), (H, W), model)
 
     # instrument the parts (synchronising timers: this is a breakdown, the loop total below is measured without them)
     parts = {}
@@ -128,7 +124,7 @@ def main():
             from torch.profiler import ProfilerActivity, profile
             tprof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True)
             tprof.__enter__()
-        kinds.append(odo.iter(1.0 + 0.033 * k, rgbs[k]))
+        kinds.append(odo.iter(1.0 + k, rgbs[k]))
         if t_first_tracked is None and odo.mapping.is_init:
             torch.cuda.synchronize()
             t_first_tracked = (k, time.perf_counter())
