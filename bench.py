@@ -320,6 +320,11 @@ def block_kernel_roofline(wb, dtype_name, reps=5):
     return out
 
 
+def _lib_probe():
+    from como_amd import _lib
+    return _lib.lib().como_track_level_probe() == 1
+
+
 def _tracking_level_us(device, H, W, steps=200):
     """microseconds per GN iteration of ONE persistent level launch at H x W (the pyramid levels of a 640x480 frame)."""
     import como_amd.odom.frontend.photo_tracking as pt
@@ -399,7 +404,7 @@ def tracking_leg(device, steps=200):
             pass
         # the coarser pyramid levels of the same frame size (one persistent launch each; a tracked frame runs all three)
         per_level = {"640x480": us}
-        for (hh, ww) in ((240, 320), (120, 160)):
+        for (hh, ww) in ((240, 320), (120, 160), (60, 80)):       # (160x120 and 80x60 run XCD-local when the probe allows it)
             try:
                 per_level[f"{ww}x{hh}"] = _tracking_level_us(device, hh, ww, steps)[0]
             except Exception as e:                          # noqa: BLE001
@@ -408,6 +413,7 @@ def tracking_leg(device, steps=200):
                 "value": steps / el, "unit": "GN iters/s", "us_per_iter": us, "us_per_iter_by_level": per_level, "steps": steps,
                 "hip_graph": bool(graphed),
                 "persistent_level_kernel": bool(fused),
+                "xcd_local_coarse_levels": bool(_lib_probe()),
                 "pixels_per_s": N * steps / el, "max_pose_abs_err_vs_gt_end": terr,
                 "roofline": {"bound": "hbm", "kernel": "track_level_kernel (per iteration)", "achieved": ach, "peak": HBM_PEAK_GBPS,
                              "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "traffic": tr_iter, "traffic_source": tr_src,

@@ -83,6 +83,9 @@ SIGNATURES = {
     "como_track_iter_channels_f64": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int] + [c_void_p] * 10),
     "como_track_level_channels_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_int, c_float,
                                               c_float, c_float, c_void_p, c_int, c_void_p, c_void_p]),
+    "como_track_level_local_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_int, c_float,
+                                           c_float, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "como_track_level_probe": (c_int, []),
     "como_track_reference_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_float, c_float] + [c_void_p] * 4),
     "como_track_reference_f64": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_double] + [c_void_p] * 4),
     "como_reproject_depth_f32": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int] + [c_void_p] * 6),

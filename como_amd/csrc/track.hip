@@ -290,6 +290,8 @@ struct TLBarrier {
   unsigned epoch;
   int G;
   int cached;          // the workspace lives in ordinary (L2-cacheable) device memory: bracket the barrier with an L2 invalidate
+  int local;           // XCD-local mode: every participating workgroup sits behind ONE L2 (see track_level_kernel)
+  int bidx;            // index of this workgroup among the participants
 };
 
 // returns false if the barrier timed out (a workgroup never arrived: not co-resident, or the device is wedged)
@@ -302,7 +304,11 @@ __device__ __forceinline__ bool tl_barrier(TLBarrier& B) {
     // (No release fence: every cross-workgroup write of a phase is a RETURNING atomic whose value the issuing wave has
     // already received -- see `flush` -- i.e. it is performed at the memory side before this arrival is issued.  Measured:
     // a release fence = L2 write-back costs 3.7 us per barrier, waiting for the returns 2 us.)
-    if (lane == 0) __hip_atomic_fetch_add(&B.bar[32 * (blockIdx.x % TL_NC)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) {
+      // (XCD-local: the read-modify-write is performed in the one L2 all participants share -- no trip to the memory side)
+      if (B.local) __hip_atomic_fetch_add(&B.bar[32 * (B.bidx % TL_NC)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __hip_atomic_fetch_add(&B.bar[32 * (B.bidx % TL_NC)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const unsigned target = (unsigned)B.G * B.epoch;
     unsigned* errf = B.bar + 32 * TL_NC;
     int ok = 1;
@@ -318,7 +324,7 @@ __device__ __forceinline__ bool tl_barrier(TLBarrier& B) {
     // acquire (cacheable workspace only): drop this XCD's L2 copies of the words other XCDs have updated since (device-scope
     // loads allocate in L2; a recycled histogram would be read stale).  1.7 us per barrier; an UNCACHED workspace
     // (como_track_level_workspace_create) does not need it.
-    if (B.cached) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (B.cached && !B.local) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     if (lane == 0) ok_s = ok;
   }
   __syncthreads();
@@ -329,7 +335,7 @@ struct TLCriteria { int max_iter; float delta_norm, rel_tol, grad_norm; };
 
 // -DCOMO_TL_PROFILE: workgroup 0 stamps the phases of iteration 3 (100 MHz wall clock) into the tail of the workspace
 #ifdef COMO_TL_PROFILE
-#define TL_STAMP(k) do { if (blockIdx.x == 0 && tid == 0 && it == 3) stamps[k] = (long long)wall_clock64(); } while (0)
+#define TL_STAMP(k) do { if (bidx == 0 && tid == 0 && it == 3) stamps[k] = (long long)wall_clock64(); } while (0)
 #else
 #define TL_STAMP(k) do { } while (0)
 #endif
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
     const float* __restrict__ P, const float* __restrict__ vals_i, const float* __restrict__ img, int H, int W, long N,
     const float* __restrict__ J8, const uint8_t* __restrict__ in_mask, TLCriteria crit, unsigned* __restrict__ bar,
     uint32_t* __restrict__ hists2, long long* __restrict__ sums2, long long* __restrict__ stamps, float* __restrict__ out,
-    int ppt, int ws_cached, int C) {
+    int ppt, int ws_cached, int C, int xl) {
   using T = float;
   using KeyT = uint32_t;
   __shared__ uint32_t lh[SEL_BINS];
@@ -385,8 +391,16 @@ __global__ __launch_bounds__(256) void track_level_kernel(
   __shared__ double red[4][TRK_ACC];
   __shared__ double tot[TRK_ACC];
   __shared__ float state[24];          // 16 T | 2 aff | mse | gnorm | dnorm
-  const int tid = threadIdx.x, G = gridDim.x;
-  TLBarrier B{bar, 0u, G, ws_cached};
+  // XCD-LOCAL mode (xl, the coarse levels: <= 32 workgroups of pixels): the grid is launched 8x oversized and only the workgroups
+  // the dispatcher places on XCD 0 stay (workgroup b goes to XCD b % 8: verified once per process by como_track_level_probe) --
+  // all participants then sit behind ONE L2, so the counters, histograms and sums are updated by plain L2 read-modify-writes
+  // (workgroup-scope atomics, no wait for a value returned from the memory side) and read back with L1-bypassing loads: a barrier
+  // is an L2 round trip (~0.5 us) instead of a trip to the memory side + an L2 invalidate (~4.5 us).
+  const int tid = threadIdx.x;
+  if (xl && (blockIdx.x & 7)) return;
+  const int bidx = xl ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int G = xl ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+  TLBarrier B{bar, 0u, G, ws_cached, xl, bidx};
 
   // ---- this thread's reference pixels, register-resident for the whole level ----
   // (C channels: an element = (pixel, channel) of vals_i (N,C) / J8 (N,C,8); its target plane is img + channel * H * W)
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
   bool sel[TL_MAXP];
 #pragma unroll
   for (int k = 0; k < TL_MAXP; ++k) {
-    const long i = ((long)k * G + blockIdx.x) * 256 + tid;
+    const long i = ((long)k * G + bidx) * 256 + tid;
     sel[k] = (k < ppt) && (i < N * C);
     const long ic = sel[k] ? i : 0;
     const long ip = C == 1 ? ic : (long)((unsigned)ic / (unsigned)C);
@@ -419,7 +433,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
   bool alive = true;
   // the result record starts as "no iteration done": the initial pose / affine parameters -- a barrier time-out in the
   // first iteration (workgroups not co-resident) must not hand uninitialised memory to the caller as the tracked pose
-  if (blockIdx.x == 0 && tid < 24) {
+  if (bidx == 0 && tid < 24) {
     if (tid < 16) out[80 + tid] = Tji_init[tid];
     else if (tid < 18) out[96 + (tid - 16)] = aff_init[tid - 16];
     else if (tid == 18) out[104] = T(0);
@@ -434,7 +448,10 @@ __global__ __launch_bounds__(256) void track_level_kernel(
     uint32_t sink = 0;
     for (int b = tid; b < SEL_BINS; b += 256) {
       const uint32_t v = src[b];
-      if (v) sink += __hip_atomic_fetch_add(&gh[b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v) {
+        if (xl) __hip_atomic_fetch_add(&gh[b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else sink += __hip_atomic_fetch_add(&gh[b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     asm volatile("" ::"v"(sink));
   };
@@ -499,10 +516,14 @@ __global__ __launch_bounds__(256) void track_level_kernel(
         // cleared with read-modify-write atomics (performed at the memory side like the adds that follow): a device-scope
         // STORE may linger in this XCD's write-back L2 and land after other workgroups' atomic adds, wiping them
         uint32_t sink = 0;
-        for (int e = blockIdx.x * 256 + tid; e < 4 * SEL_BINS; e += G * 256)
-          sink += __hip_atomic_fetch_and(&hother[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (blockIdx.x == G - 1 && tid < 128)
-          sink += (uint32_t)__hip_atomic_fetch_and((unsigned long long*)&smother[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int e = bidx * 256 + tid; e < 4 * SEL_BINS; e += G * 256) {
+          if (xl) __hip_atomic_fetch_and(&hother[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else sink += __hip_atomic_fetch_and(&hother[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (bidx == G - 1 && tid < 128) {
+          if (xl) __hip_atomic_fetch_and((unsigned long long*)&smother[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else sink += (uint32_t)__hip_atomic_fetch_and((unsigned long long*)&smother[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("" ::"v"(sink));
       }
       // digit ps - 1 from its finished histogram; after a successful speculation digit 1 sits in region 3
@@ -588,10 +609,17 @@ __global__ __launch_bounds__(256) void track_level_kernel(
       unsigned long long sink = 0;
       // non-finite: counted in a dedicated word (sm[63], cleared with the rest of the buffer), never encoded in the summed
       // value -- an additive sentinel wraps once enough workgroups add it (8 x 2^61 = 0)
-      if (!(fabs(v) < 4.0e18)) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[TL_POISON], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else fix_split(v, hi, lo);
-      if (hi) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[tid], (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (lo) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[64 + tid], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (xl) {
+        if (!(fabs(v) < 4.0e18)) __hip_atomic_fetch_add((unsigned long long*)&sm[TL_POISON], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else fix_split(v, hi, lo);
+        if (hi) __hip_atomic_fetch_add((unsigned long long*)&sm[tid], (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (lo) __hip_atomic_fetch_add((unsigned long long*)&sm[64 + tid], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else {
+        if (!(fabs(v) < 4.0e18)) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[TL_POISON], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else fix_split(v, hi, lo);
+        if (hi) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[tid], (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lo) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[64 + tid], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       asm volatile("" ::"v"(sink));
     }
     TL_STAMP(11);
@@ -645,7 +673,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
       state[18] = (T)(tot[44] / (double)(nv / C));    // mean over valid pixels
       state[19] = (T)sqrt(gn);
       state[20] = (T)sqrt(dn);
-      if (blockIdx.x == 0) {                                   // the record of this iteration, layout of como_track_iter_*
+      if (bidx == 0) {                                         // the record of this iteration, layout of como_track_iter_*
         for (int i = 0; i < 64; ++i) out[i] = (T)Hm[i];
         for (int i = 0; i < 8; ++i) { out[64 + i] = (T)g[i]; out[72 + i] = (T)d[i]; }
         for (int i = 0; i < 16; ++i) out[80 + i] = state[i];
@@ -668,7 +696,15 @@ __global__ __launch_bounds__(256) void track_level_kernel(
     __syncthreads();                                           // `state` / `tot` are rewritten next iteration
     if (it >= crit.max_iter || dnorm < crit.delta_norm || rel < crit.rel_tol || gnorm < crit.grad_norm) break;
   }
-  if (!alive && blockIdx.x == 0 && tid == 0) out[104] = T(-1);  // a barrier timed out
+  if (!alive && bidx == 0 && tid == 0) out[104] = T(-1);        // a barrier timed out
+}
+
+__global__ void xcc_probe_kernel(int* __restrict__ xcc) {
+  if (threadIdx.x == 0) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    xcc[blockIdx.x] = (int)(id & 0xf);
+  }
 }
 
 }  // namespace como
@@ -676,6 +712,7 @@ __global__ __launch_bounds__(256) void track_level_kernel(
 extern "C" {
 
 long como_track_level_workspace_bytes(void);
+int como_track_level_probe(void);
 
 /* Optional: a workspace in UNCACHED device memory (hipDeviceMallocUncached: not held in the XCD-private L2s), created once
  * outside any stream capture.  NULL if the runtime refuses. */
@@ -689,13 +726,40 @@ void* como_track_level_workspace_create(void) {
 void como_track_level_workspace_destroy(void* p) { if (p) (void)hipFree(p); }
 
 long como_track_level_workspace_bytes(void) {
+  (void)como_track_level_probe();                            // (once per process, outside any stream capture)
   return (long)como::TL_BAR_WORDS * 4 + 2L * 6 * como::SEL_BINS * 4 + (long)como::TL_SUM_WORDS * 8 + 32 * 8;   // (+ profile stamps)
 }
 
-int como_track_level_channels_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P,
-                                  const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
-                                  const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
-                                  void* workspace, int workspace_uncached, float* out, como_stream_t stream) {
+/* Does the dispatcher place workgroup b of a launch on XCD b % 8 (and are there 8 of them)?  Probed once per process with a tiny
+ * kernel (outside any stream capture: como_track_level_workspace_bytes calls it); the XCD-local form of the level kernel relies on it. */
+int como_track_level_probe(void) {
+  static int ok = -1;
+  if (ok >= 0) return ok;
+  ok = 0;
+  const char* e = getenv("COMO_TRACK_LOCAL");                // COMO_TRACK_LOCAL=0: the device-wide form for every level (A/B)
+  if (e && atoi(e) == 0) return ok;
+  int* d = nullptr;
+  if (hipMalloc((void**)&d, 64 * sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return ok; }
+  hipLaunchKernelGGL(como::xcc_probe_kernel, dim3(64), dim3(64), 0, 0, d);
+  int h[64];
+  if (hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+    bool good = true;
+    unsigned seen = 0;
+    for (int b = 0; b < 64; ++b) good = good && h[b] == h[b & 7];
+    for (int b = 0; b < 8; ++b) seen |= 1u << (h[b] & 15);
+    ok = (good && __builtin_popcount(seen) == 8) ? 1 : 0;
+  }
+  (void)hipGetLastError();
+  (void)hipFree(d);
+  return ok;
+}
+
+/* local_workspace (optional): a second workspace of como_track_level_workspace_bytes() bytes in ORDINARY (L2-cacheable) device
+ * memory: levels of at most 32 x 256 x TL_MAXP elements then run XCD-local (see track_level_kernel) when the probe allows it. */
+int como_track_level_local_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P,
+                               const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
+                               const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
+                               void* workspace, int workspace_uncached, void* local_workspace, float* out, como_stream_t stream) {
   using namespace como;
   if (!Tji_init || !K || !aff_init || !P || !vals_i || !img || !J8 || !workspace || !out || N <= 0 || H < 3 || W < 3 ||
       max_iter < 1 || channels < 1 || channels > 4)
@@ -710,8 +774,15 @@ int como_track_level_channels_f32(const float* Tji_init, const float* K, const f
     ncu = prop.multiProcessorCount;
   }
   long G = (NE + 255) / 256;
-  if (G > ncu) G = ncu;                       // one workgroup per compute unit: all co-resident (the barrier needs that)
-  if (G > 512) G = 512;
+  const bool local = local_workspace && NE <= 32L * 256 * TL_MAXP && ncu >= 256 && como_track_level_probe() == 1;
+  if (local) {
+    if (G > 32) G = 32;                       // the compute units of one XCD: all co-resident
+    workspace = local_workspace;
+    workspace_uncached = 0;
+  } else {
+    if (G > ncu) G = ncu;                     // one workgroup per compute unit: all co-resident (the barrier needs that)
+    if (G > 512) G = 512;
+  }
   const long ppt = (NE + G * 256 - 1) / (G * 256);
   if (ppt > TL_MAXP) return COMO_ERR_ARG;     // larger than TL_MAXP x 256 x #CU pixels: use the como_track_iter_* chain
   unsigned* bar = (unsigned*)workspace;
@@ -720,10 +791,19 @@ int como_track_level_channels_f32(const float* Tji_init, const float* K, const f
   long long* stamps = sums2 + TL_SUM_WORDS;
   if (!zero_words(workspace, TL_BAR_WORDS + 2 * 6 * SEL_BINS + 2 * TL_SUM_WORDS, s)) return COMO_ERR_LAUNCH;
   TLCriteria crit{max_iter, delta_norm, rel_tol, grad_norm};
-  hipLaunchKernelGGL(track_level_kernel, dim3((unsigned)G), dim3(256), 0, s, Tji_init, K, aff_init, P, vals_i, img, H, W, N, J8,
-                     in_mask, crit, bar, hists2, sums2, stamps, out, (int)ppt, workspace_uncached ? 0 : 1, channels);
+  hipLaunchKernelGGL(track_level_kernel, dim3((unsigned)(local ? 8 * G : G)), dim3(256), 0, s, Tji_init, K, aff_init, P, vals_i, img,
+                     H, W, N, J8, in_mask, crit, bar, hists2, sums2, stamps, out, (int)ppt, workspace_uncached ? 0 : 1, channels,
+                     local ? 1 : 0);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
+}
+
+int como_track_level_channels_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P,
+                                  const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
+                                  const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
+                                  void* workspace, int workspace_uncached, float* out, como_stream_t stream) {
+  return como_track_level_local_f32(Tji_init, K, aff_init, P, vals_i, img, H, W, N, channels, J8, in_mask, max_iter, delta_norm,
+                                    rel_tol, grad_norm, workspace, workspace_uncached, nullptr, out, stream);
 }
 
 int como_track_level_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P, const float* vals_i,

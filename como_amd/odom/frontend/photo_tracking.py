@@ -203,11 +203,13 @@ def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, int
         ws, wsp = ws_pair
         if out is None:
             out = torch.empty(106, device=dev, dtype=dt)
-        rc = L.como_track_level_channels_f32(_lib.ptr(Tji_init), _lib.ptr(intrinsics), _lib.ptr(aff_init), _lib.ptr(Pi),
-                                             _lib.ptr(vals_i), _lib.ptr(img_j), H, W, N, c, _lib.ptr(dI_dT), _lib.ptr(in_mask),
-                                             int(term_criteria["max_iter"]), float(term_criteria["delta_norm"]),
-                                             float(term_criteria["rel_tol"]), float(term_criteria["grad_norm"]),
-                                             wsp if wsp else _lib.ptr(ws), 1 if wsp else 0, _lib.ptr(out), _lib.stream_ptr(dev))
+        # (the cached workspace doubles as the XCD-local one of the coarse levels, csrc/track.hip)
+        rc = L.como_track_level_local_f32(_lib.ptr(Tji_init), _lib.ptr(intrinsics), _lib.ptr(aff_init), _lib.ptr(Pi),
+                                          _lib.ptr(vals_i), _lib.ptr(img_j), H, W, N, c, _lib.ptr(dI_dT), _lib.ptr(in_mask),
+                                          int(term_criteria["max_iter"]), float(term_criteria["delta_norm"]),
+                                          float(term_criteria["rel_tol"]), float(term_criteria["grad_norm"]),
+                                          wsp if wsp else _lib.ptr(ws), 1 if wsp else 0, _lib.ptr(ws), _lib.ptr(out),
+                                          _lib.stream_ptr(dev))
         if rc == 1:
             return None
         _lib.check(rc, "como_track_level")
@@ -229,11 +231,11 @@ def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, int
             ws_ptr, uncached = wsp, 1
     if out is None:
         out = torch.empty(106, device=dev, dtype=dt)
-    rc = L.como_track_level_channels_f32(_lib.ptr(Tji_init), _lib.ptr(intrinsics), _lib.ptr(aff_init), _lib.ptr(Pi),
-                                         _lib.ptr(vals_i), _lib.ptr(img_j), H, W, N, c, _lib.ptr(dI_dT), _lib.ptr(in_mask),
-                                         int(term_criteria["max_iter"]), float(term_criteria["delta_norm"]),
-                                         float(term_criteria["rel_tol"]), float(term_criteria["grad_norm"]), ws_ptr, uncached,
-                                         _lib.ptr(out), _lib.stream_ptr(dev))
+    rc = L.como_track_level_local_f32(_lib.ptr(Tji_init), _lib.ptr(intrinsics), _lib.ptr(aff_init), _lib.ptr(Pi),
+                                      _lib.ptr(vals_i), _lib.ptr(img_j), H, W, N, c, _lib.ptr(dI_dT), _lib.ptr(in_mask),
+                                      int(term_criteria["max_iter"]), float(term_criteria["delta_norm"]),
+                                      float(term_criteria["rel_tol"]), float(term_criteria["grad_norm"]), ws_ptr, uncached,
+                                      _lib.ptr(ws), _lib.ptr(out), _lib.stream_ptr(dev))
     if rc == 1:                                            # COMO_ERR_ARG: more pixels than the persistent kernel holds
         return None
     _lib.check(rc, "como_track_level")

@@ -164,6 +164,15 @@ int como_track_level_channels_f32(const float* Tji_init, const float* K, const f
                                   const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
                                   const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
                                   void* workspace, int workspace_uncached, float* out, como_stream_t stream);
+/* Round 5: the same with a second workspace in ORDINARY (L2-cacheable) device memory (may be NULL).  Levels of at most
+ * 32 x 256 x 5 elements (160x120 and below) then run XCD-LOCAL: the grid is restricted to the workgroups of one XCD, whose
+ * three barriers per iteration are read-modify-writes in the one L2 they share instead of round trips to the memory side.
+ * como_track_level_probe: 1 when the dispatcher places workgroup b on XCD b % 8 on this device (probed once per process). */
+int como_track_level_local_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P,
+                               const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
+                               const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
+                               void* workspace, int workspace_uncached, void* local_workspace, float* out, como_stream_t stream);
+int como_track_level_probe(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Window BA linearisation (python path: backend/photo.py:83-233 batch_photo_cost).

@@ -517,11 +517,14 @@ def _tracking_level_inputs(H, W, seed):
     return tp, K, P, vals, J
 
 
-@pytest.mark.parametrize("H,W,masked", [(480, 640, False), (480, 640, True), (96, 128, True), (37, 53, False)])
+@pytest.mark.parametrize("H,W,masked", [(480, 640, False), (480, 640, True), (240, 320, True), (120, 160, False), (120, 160, True),
+                                        (60, 80, False), (96, 128, True), (37, 53, False)])
 def test_fused_tracking_level_matches_iteration_chain(H, W, masked):
     """The persistent one-launch level kernel (como_track_level_f32) against the per-iteration chain (como_track_iter_*,
     itself pinned to the reference by the golden tests): same number of iterations, same stop decision, pose / affine within
-    float32 summation-order noise; also for a fixed iteration count (every intermediate state the same)."""
+    float32 summation-order noise; also for a fixed iteration count (every intermediate state the same).  All four pyramid levels
+    of a 640x480 frame: 160x120 and below run in the XCD-local form (one L2 behind every barrier, csrc/track.hip) when
+    como_track_level_probe allows it -- same arithmetic, same stop test."""
     import como_amd.odom.frontend.photo_tracking as pt
     tp, K, P, vals, J = _tracking_level_inputs(H, W, 3)
     aff = torch.zeros((1, 2, 1), device=DEV)
@@ -542,8 +545,10 @@ def test_fused_tracking_level_matches_iteration_chain(H, W, masked):
     eT, ea = (Tf - Tc).abs().max().item(), (af - ac).abs().max().item()
     e6 = (T6f - T6c).abs().max().item()
     gt = (Tf - tp["Tji_gt"]).abs().max().item()
+    from como_amd import _lib
     report("fused_tracking_level", H=H, W=W, masked=masked, iters_chain=it_chain, iters_fused=it_fused, status=status, T_err=eT,
-           aff_err=ea, T6_err=e6, iters6=int(rec6[105]), err_vs_gt=gt)
+           aff_err=ea, T6_err=e6, iters6=int(rec6[105]), err_vs_gt=gt,
+           xcd_local=bool(_lib.lib().como_track_level_probe() == 1 and H * W <= 32 * 256 * 5))
     assert status == 0 and it_fused == it_chain and int(rec6[105]) == 6
     assert eT < 2e-6 and ea < 2e-6 and e6 < 2e-6
 
