@@ -18,7 +18,7 @@ _ws = {}
 BLOCK_VARIANT = int(__import__("os").environ.get("COMO_BA_VARIANT", "0"))   # 0 = software-pipelined block kernel, 1 = plain
 CHUNKS_OVERRIDE = int(__import__("os").environ.get("COMO_BA_CHUNKS", "0"))   # tuning runs: pixel chunks per pair group
 BLOCK_STAGGER = int(__import__("os").environ.get("COMO_BA_STAGGER", "0"))
-MIN_TILES_PER_CHUNK = int(__import__("os").environ.get("COMO_BA_MIN_TILES", "0"))   # > 0: lower bound on a chunk's 64-pixel tiles (opt-in, see linearize)
+MIN_TILES_PER_CHUNK = int(__import__("os").environ.get("COMO_BA_MIN_TILES", "8"))   # lower bound on a chunk's 64-pixel tiles (0: off; see linearize)
 last_aux = {}   # diagnostics of the most recent call: valid mask, sigma, nvalid (tests / callers that want them)
 
 
@@ -89,12 +89,13 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
         else:
             chunks = default_chunks(b, nl, dtype)
         if grp_pairs is not None and grp_pairs.numel() > 0 and zmode == 2:
-            # OPT-IN (COMO_BA_MIN_TILES=8; default 0 = off): a lower bound on a chunk's 64-pixel tiles for sub-selected windows
-            # (n = 19,200 = 300 tiles at window 4).  Measured, same box: the window-4 bench legs gain 4 % with 8 tiles per chunk (75 -> 38
-            # chunks: float64 block kernel 96.6 -> 81.3 us, 2083 -> 2160 it/s; float32 2443 -> 2540 it/s, the assembly reduces half the
-            # partial records) but the sequential loop LOSES 4 % (447 -> 427 frames/s): its filling windows have one to three pair groups,
-            # too few workgroups already, and fatter ones only stretch the kernel.  The bound below (never fewer than one workgroup per
-            # CU because of the rule) was written for that and could not be measured any more in round 4 -- hence off by default.
+            # A lower bound (8) on a chunk's 64-pixel tiles for sub-selected windows (n = 19,200 = 300 tiles at window 4: 75 -> 38 chunks,
+            # the block kernel's fixed prologue / epilogue is shared by twice the tiles and the assembly reduces half the partial records),
+            # itself bounded so that a launch never has fewer than one workgroup per compute unit -- the sequential loop's filling windows
+            # have one to three pair groups, and fatter workgroups alone would only stretch their kernel (round 4: -4 % on the loop
+            # without that bound).  Round 5, same box, two repetitions (scripts/ab/min_tiles_ab.sh, profiles/r5_min_tiles_ab.txt): window-4
+            # float64 2342 / 2346 -> 2446 / 2444 it/s, float32 2822 / 2776 -> 2940 / 2918, the pinned odometry loop 294 / 313 -> 303 / 294
+            # frames/s (unchanged within its spread).  COMO_BA_MIN_TILES=0 switches it off.
             if MIN_TILES_PER_CHUNK > 0:
                 tiles = (nl + 63) // 64
                 ngrp = max(1, int(grp_pairs.shape[0]))
