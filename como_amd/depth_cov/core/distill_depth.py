@@ -43,9 +43,10 @@ def gram_weighted(A, w, y, c=None, want_stats=False):
         raise RuntimeError("como_amd gram_weighted: needs a (1,n,m) float64 tensor with m <= 64, m % 4 == 0 and 16-byte aligned rows")
     L = _lib.lib()
     dev = A.device
-    ws = _gram_ws.get(str(dev))
+    key = f"{dev}:{torch.cuda.current_stream(dev).cuda_stream}"     # (one scratch per stream: two mappers on one device must not share it)
+    ws = _gram_ws.get(key)
     if ws is None:
-        ws = _gram_ws[str(dev)] = torch.empty(L.como_gram_workspace_bytes() // 8, dtype=torch.float64, device=dev)
+        ws = _gram_ws[key] = torch.empty(L.como_gram_workspace_bytes() // 8, dtype=torch.float64, device=dev)
     AtA = torch.empty((1, m, m), dtype=torch.float64, device=dev)
     Atb = torch.empty((1, m, 1), dtype=torch.float64, device=dev)
     stats = torch.empty(4, dtype=torch.float64, device=dev) if want_stats else None

@@ -280,7 +280,7 @@ class Mapping:
         d = self.depth_imgs
         d2 = d.reshape(d.shape[0], -1)
         # per-keyframe exact median of the full depth image: one segmented device select instead of B sorts
-        self.median_depths = masked_median(d2).to(d2.dtype) if d2.is_cuda else torch.median(d2, dim=1).values
+        self.median_depths = masked_median(d2).to(d2.dtype)     # (device tensors only: dense_ref.depth_image has no CPU form)
 
     # ---- keyframe insertion (Mapping.py:138-229) -------------------------------------------------------------------------
     def init_keyframe(self, rgb, cov_params_img, coords_m, pose_init, logz_m, aff_init, timestamp):

@@ -75,7 +75,7 @@ def depth_image(Kt, logzm, out=None, logz_out=None):
     if Kt.stride(2) != 1 or Kt.stride(1) != m:
         Kt = Kt.contiguous()
     L = _lib.lib()
-    key = (str(dev), dt, B, m)
+    key = (str(dev), torch.cuda.current_stream(dev).cuda_stream, dt, B, m)     # (per stream: see photo._buf)
     w = _di_ws.get(key)
     if w is None:
         w = _di_ws[key] = {"hists": torch.zeros((B * L.como_select_workspace_bytes() // 4,), device=dev, dtype=torch.int32),

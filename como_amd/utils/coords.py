@@ -42,9 +42,11 @@ _grid_cache = {}
 
 
 def get_test_coords(img_size, device, batch_size=1):
-    """(batch, h*w, 2) row/col of every pixel (coords.py:31-36).  Cached per (size, device, batch): callers only read it."""
+    """(batch, h*w, 2) row/col of every pixel (coords.py:31-36).  READ-ONLY: one tensor per (size, device, batch) is cached and
+    shared by every caller (the tracker's pyramid and the two-frame initialiser hold the same object) -- clone it before any
+    in-place use."""
     h, w = int(img_size[0]), int(img_size[1])
-    key = (h, w, str(device), int(batch_size))
+    key = (h, w, str(torch.device(device)), int(batch_size))
     t = _grid_cache.get(key)
     if t is None:
         r, c = torch.meshgrid(torch.arange(h, device=device), torch.arange(w, device=device), indexing="ij")
