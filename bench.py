@@ -220,7 +220,7 @@ def git_sha():
         return None
 
 
-def committed_traffic(kernel_substr, summaries=("r4_bench_pmc_summary.json", "r3_bench_pmc_summary.json", "r2_bench_pmc_summary.json")):
+def committed_traffic(kernel_substr, summaries=("r5_bench_pmc_summary.json", "r4_bench_pmc_summary.json", "r3_bench_pmc_summary.json")):
     """HBM bytes per launch of a kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled per the
     gfx950 note of guides/MI355X_MICROARCH.md, WRITE_SIZE as is).  NOT measured by this run: counters need rocprofv3
     around the process (scripts/collect_profiles.sh); the value is labelled with its source file."""
@@ -395,11 +395,12 @@ def tracking_leg(device, steps=200):
         # iterations of the same 640x480 level; FETCH_SIZE doubled per the gfx950 note, WRITE_SIZE as is)
         tr_iter, tr_src = None, None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r4_track_pmc_summary.json")))
+            tr_file = "r5_track_pmc_summary.json" if os.path.exists(os.path.join(ROOT, "profiles", "r5_track_pmc_summary.json")) else "r4_track_pmc_summary.json"
+            pm = json.load(open(os.path.join(ROOT, "profiles", tr_file)))
             key = [k for k in pm if "track_level_kernel" in k][0]
             per_launch = (2.0 * pm[key]["FETCH_SIZE"]["avg_per_launch"] + pm[key]["WRITE_SIZE"]["avg_per_launch"]) * 1024.0
             tr_iter = per_launch / float(pm["_meta"]["track_iterations_per_launch"])
-            tr_src = "committed_profile:profiles/r4_track_pmc_summary.json:" + key[:40]
+            tr_src = f"committed_profile:profiles/{tr_file}:" + key[:40]
         except Exception:                                   # noqa: BLE001
             pass
         # the coarser pyramid levels of the same frame size (one persistent launch each; a tracked frame runs all three)

@@ -197,11 +197,12 @@ __global__ __launch_bounds__(512) void chol_panel2_kernel(double* __restrict__ W
         double* dst = &W[((long)ti * CB + r) * Dp + (long)tj * CB + c];
         if (ti != tj || c <= r) *dst = (virgin ? 0.0 : *dst) - acc[i];
       }
-    } else if (app && tj == nb - 1 && tid < 256 + CB) {
+    } else if (app && tj == D / CB && tid < 256 + CB) {
       // x_r += (L^-T)_{r,c0} y_c0 + (L^-T)_{r,c1} y_c1: sI0 / sI1 hold the two finished tiles of appended row r, and row
-      // D - 32 (nb - 1) of sJ0 / sJ1 (block row nb - 1 holds the appended right-hand side) is y for these two block columns.
+      // D mod 32 of sJ0 / sJ1 -- block row D / 32 holds the appended right-hand side: the last block row, or the one before it
+      // when the system is padded to whole column PAIRS (common.cuh chol_dp) -- is y for these two block columns.
       // One owner per x_r and launch, launches in stream order: a fixed summation order, no atomics.
-      const int t = tid - 256, gl = D - (nb - 1) * CB;
+      const int t = tid - 256, gl = D - (D / CB) * CB;
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll 8
       for (int k = 0; k < CB; ++k) {
