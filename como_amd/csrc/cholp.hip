@@ -123,6 +123,26 @@ __device__ __forceinline__ void st_nt(const double* X, const double* Y, int qr, 
     }
   }
 }
+// The LAST k block of X = A Vp^T for the quadrant pair (qr, qc0), (qr, qc0 + 1) (qc0 even): Vp is lower triangular, so quadrant
+// qc0 + 1 needs the whole 32-wide block kb = qc0 / 2 but quadrant qc0 only its first 16 columns -- four matrix instructions with the
+// k mapping 4 s + q instead of eight (the 64-bit reads of this mapping are 2-4-way bank conflicted: eight extra reads per wave).
+__device__ __forceinline__ void st_nt_tail(const double* X, const double* Y, int qr, int qc0, int l, d4_t (&acc)[2]) {
+  const int r = l & 15, q = l >> 4, ko = 16 * (q & 1) + 8 * (q >> 1), kb = qc0 >> 1;
+  const double* x = X + (16 * qr + r) * PLD + 32 * kb;
+  const double* y0 = Y + (16 * qc0 + r) * PLD + 32 * kb;
+  const double* y1 = y0 + 16 * PLD;
+  double xa[8], yb[8], xh[4], yh[4];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) { xa[s] = x[ko + s]; yb[s] = y1[ko + s]; }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) { xh[s] = x[4 * s + q]; yh[s] = y0[4 * s + q]; }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[s], yb[s], acc[1], 0, 0, 0);
+    if (s < 4) acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(xh[s], yh[s], acc[0], 0, 0, 0);
+  }
+}
+
 // element (row, col) inside the super-tile of accumulator register i of lane l, quadrant (qr, qc)
 __device__ __forceinline__ int srow(int qr, int l, int i) { return 16 * qr + (l >> 4) + 4 * i; }
 __device__ __forceinline__ int scol(int qc, int l) { return 16 * qc + (l & 15); }
@@ -278,7 +298,7 @@ __device__ void cp_chain(const CholpArgs& a, double* dsm) {
       tile_mm_mfma<false, false>(V1, Yb, wv, l, v);
 #pragma unroll
       for (int i = 0; i < 4; ++i) Vp[(32 + mrow(wv, l, i)) * PLD + mcol(wv, l)] = -v[i];
-    } else {                                                         // ([V0 | 0] was put there during the factorisation)
+    } else {                                                         // ([V0 | 0] was put there during the factorisation: 1.3 -> 1.0 us)
       for (int e = tid - 256; e < CB * CB; e += 256) {
         const int r = e >> 5, c = e & 31;
         Vp[(32 + r) * PLD + 32 + c] = c <= r ? V1[r * CLD + c] : 0.0;
@@ -327,8 +347,8 @@ __device__ void cp_chain(const CholpArgs& a, double* dsm) {
     // its two quadrants go to the wave it shares a SIMD with (the matrix pipe of that SIMD sees the same 48 instructions).
     d4_t x[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, x2[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     constexpr int PQR = PUBW >> 1, PQC0 = 2 * ((PUBW ^ (PUBW >> 2)) & 1);
-    if (wv != PUBW) st_nt<false>(Ab, Vp, xqr, xqc0, l, 0, xqc0 < 2 ? 1 : 2, x);
-    if (wv == PUBW - 4) st_nt<false>(Ab, Vp, PQR, PQC0, l, 0, PQC0 < 2 ? 1 : 2, x2);
+    if (wv != PUBW) { st_nt<false>(Ab, Vp, xqr, xqc0, l, 0, xqc0 >> 1, x); st_nt_tail(Ab, Vp, xqr, xqc0, l, x); }
+    if (wv == PUBW - 4) { st_nt<false>(Ab, Vp, PQR, PQC0, l, 0, PQC0 >> 1, x2); st_nt_tail(Ab, Vp, PQR, PQC0, l, x2); }
     lds_only_barrier();                                              // (LDS only: the published stores and the loads of T stay in flight)
     CP_STAMP(q, 2);
     if (wv != PUBW) st_store(Ab, xqr, xqc0, l, x);
