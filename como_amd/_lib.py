@@ -192,8 +192,22 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_dev_index = {}
+
+
 def stream_ptr(device=None):
-    return torch.cuda.current_stream(device).cuda_stream
+    """The current HIP stream of `device` as an integer handle.  Called before every launch (~25 times per eager GN iteration):
+    torch's own raw accessor (0.3 us) instead of `torch.cuda.current_stream(device).cuda_stream` (5.6 us of Python per call)."""
+    if _raw_stream is None:
+        return torch.cuda.current_stream(device).cuda_stream
+    idx = _dev_index.get(device)
+    if idx is None:
+        d = torch.device("cuda" if device is None else device)
+        idx = d.index if d.index is not None else torch.cuda.current_device()
+        if device is not None and torch.device(device).index is not None:
+            _dev_index[device] = idx                        # (an explicit ordinal never changes; "cuda" follows the current device)
+    return _raw_stream(idx)
 
 
 def capture_graph(fn, device, thread_local=False):

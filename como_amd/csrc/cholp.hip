@@ -235,7 +235,7 @@ struct CpIdle {
   }
 };
 
-__device__ void cp_chain(const CholpArgs& a, double* dsm) {
+__device__ __forceinline__ void cp_chain(const CholpArgs& a, double* dsm) {
   double* sm = dsm;                               // factor tiles 0 .. 6 (CLD layout): T10 / L10, T00 / L00, T11 / L11, V0, V1, scratch
   double* Vp = dsm + NT2 * TSZ;                   // inverse of the last factored pair, [64][PLD]
   double* Ab = Vp + PSZ;                          // A(q, q-1) -> X
@@ -374,117 +374,166 @@ __device__ void cp_chain(const CholpArgs& a, double* dsm) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// owner of super-tile (I, J): regular (rows 64 I of the matrix, J <= I) or appended (row block R = I of the identity rows, J > I)
-__device__ void cp_worker(const CholpArgs& a, double* dsm, int I, int J, bool app) {
+// The owners.  Super-tiles are enumerated COLUMN by column (column c = 1 .. np-1: the regular (I, c), I > c; the diagonal (c, c)
+// from c = 2 on; the appended (R, c), R < c) and dealt round-robin to the worker workgroups, so that a workgroup's tiles are sorted by
+// the column pair at which they retire -- the tile the chain or the next step waits for is always the first one it works on.  Up to
+// 16 column pairs every super-tile has its own workgroup (MAXT = 1, the metric window); larger systems (the full sliding windows of
+// the odometry loop at D ~ 1300, config 4 at D = 2680: 1722 super-tiles) give each of the 255 workers up to MAXT = 8 of them, all
+// register-resident, processed one after the other within a step (the pair inverse is fetched once per step).
+struct CpTile {
+  int I, J, s_first, s_last;
+  bool app, diag, lastcol;
+  long row0;
+};
+__device__ __forceinline__ int cp_ntiles(int np) { return (np - 1) + np * (np - 2); }
+__device__ __forceinline__ CpTile cp_tile(int t, int np, long Dp) {
+  CpTile T;
+  int c, o;
+  if (t < np - 1) { c = 1; o = t; } else { const int u = t - (np - 1); c = 2 + u / np; o = u - (c - 2) * np; }
+  const int nreg = np - 1 - c, hasdiag = c >= 2 ? 1 : 0;
+  if (o < nreg) { T.app = false; T.I = c + 1 + o; }
+  else if (hasdiag && o == nreg) { T.app = false; T.I = c; }
+  else { T.app = true; T.I = o - nreg - hasdiag; }
+  T.J = c;
+  T.diag = !T.app && T.I == T.J;
+  T.s_first = T.app ? T.I : 0;
+  T.s_last = T.diag ? T.J - 2 : T.J - 1;
+  T.lastcol = T.app && T.J == np - 1;
+  T.row0 = (T.app ? Dp : 0) + (long)T.I * PB;                       // first row of the super-tile in the working copy
+  return T;
+}
+
+template <int MAXT>
+__device__ __forceinline__ void cp_workers_body(const CholpArgs& a, double* dsm, int w, int nworkers) {
   double* Vp = dsm;
   double* AI = dsm + PSZ;
   double* AJ = dsm + 2 * PSZ;
-  double* misc = dsm + 3 * PSZ;                   // ylast [64] | verdict word
+  double* misc = dsm + 3 * PSZ;                   // z [64] | verdict word
   volatile int* ok_s = (volatile int*)(misc + 64);
   const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, qr = wv >> 1, qc0 = 2 * (wv & 1);
   const long Dp = a.Dp;
   const int np = a.np, D = a.D;
-  const bool diag = !app && I == J;
-  const int s_first = app ? I : 0;
-  const int s_last = diag ? J - 2 : J - 1;
-  const bool lastcol = app && J == np - 1;
   const int gl = D - PB * (np - 1);
-  const long row0 = (app ? Dp : 0) + (long)I * PB;                  // first row of the super-tile in the working copy
-  d4_t S[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-  if (!app) {
+  const int ntot = cp_ntiles(np);
+  CpTile tl[MAXT];
+  bool have[MAXT];
+  d4_t S[MAXT][2];
+  double xr[MAXT];                                                   // thread t < 64 of an owner (R, np-1): x_R[t]
+  int s_lo = np, s_hi = -1;
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k) {
+    const int t = w + k * nworkers;
+    have[k] = t < ntot;
+    tl[k] = cp_tile(have[k] ? t : 0, np, Dp);
+    xr[k] = 0.0;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) S[j][i] = a.W[(row0 + srow(qr, l, i)) * Dp + (long)J * PB + scol(qc0 + j, l)];
+      for (int i = 0; i < 4; ++i)
+        S[k][j][i] = (have[k] && !tl[k].app) ? a.W[(tl[k].row0 + srow(qr, l, i)) * Dp + (long)tl[k].J * PB + scol(qc0 + j, l)] : 0.0;
+    if (have[k]) { s_lo = min(s_lo, tl[k].s_first); s_hi = max(s_hi, tl[k].s_last); }
   }
-  double xr = 0.0;                                                   // thread t < 64 of an owner (R, np-1): x_R[t]
-  for (int s = s_first; s <= s_last; ++s) {
-    if (s >= 1 && !cp_wait(cp_colcnt(a, s), (unsigned)(np - 1), a, ok_s)) return;
-    // panels of this step: A(I, s) (the identity for an appended row block that meets its own column pair) and A(J, s)
-    if (app && s == I) {
+  for (int s = s_lo; s <= s_hi; ++s) {
+    bool waited = false, have_vp = false;
 #pragma unroll
-      for (int u = 0; u < CP_LPT; ++u) { const int e = tid + CP_THREADS * u; AI[(e >> 6) * PLD + (e & 63)] = (e >> 6) == (e & 63) ? 1.0 : 0.0; }
-    } else {
-      st_load(AI, a.W + row0 * Dp + (long)s * PB, Dp);
+    for (int k = 0; k < MAXT; ++k) {
+      const CpTile& T = tl[k];
+      if (!have[k] || s < T.s_first || s > T.s_last) continue;      // (uniform over the workgroup)
+      if (!waited) {                                                  // every super-tile of column pair s is published
+        if (s >= 1 && !cp_wait(cp_colcnt(a, s), (unsigned)(np - 1), a, ok_s)) return;
+        waited = true;
+      }
+      // panels of this step: A(I, s) (the identity for an appended row block that meets its own column pair) and A(J, s)
+      if (T.app && s == T.I) {
+#pragma unroll
+        for (int u = 0; u < CP_LPT; ++u) { const int e = tid + CP_THREADS * u; AI[(e >> 6) * PLD + (e & 63)] = (e >> 6) == (e & 63) ? 1.0 : 0.0; }
+      } else {
+        st_load(AI, a.W + T.row0 * Dp + (long)s * PB, Dp);
+      }
+      if (!T.diag) st_load(AJ, a.W + (long)T.J * PB * Dp + (long)s * PB, Dp);
+      if (!have_vp) {                                                 // the pair inverse: once per step
+        if (!cp_wait(cp_pairflag(a), (unsigned)(s + 1), a, ok_s)) return;
+        st_load(Vp, a.Vpg + (long)s * PB * PB, PB);
+        have_vp = true;
+      }
+      __syncthreads();
+      d4_t xi[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, xj[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+      st_nt<false>(AI, Vp, qr, qc0, l, 0, qc0 >> 1, xi);
+      st_nt_tail(AI, Vp, qr, qc0, l, xi);
+      if (!T.diag) { st_nt<false>(AJ, Vp, qr, qc0, l, 0, qc0 >> 1, xj); st_nt_tail(AJ, Vp, qr, qc0, l, xj); }
+      __syncthreads();
+      st_store(AI, qr, qc0, l, xi);
+      if (!T.diag) st_store(AJ, qr, qc0, l, xj);
+      __syncthreads();
+      st_nt<true>(AI, T.diag ? AI : AJ, qr, qc0, l, 0, 2, S[k]);    // S -= X_I X_J^T
+      if (T.lastcol && tid < PB) {                                   // x_R += (L^-T)_{R,s} y_s;  y_s = row gl of X_J (J = np - 1)
+        double acc = 0.0;
+        for (int q = 0; q < PB; ++q) acc = __builtin_fma(AI[tid * PLD + q], AJ[gl * PLD + q], acc);
+        xr[k] += acc;
+      }
+      if (s == T.s_last && !T.lastcol) {
+        // publish: this super-tile is the panel A(I, J) of every later step (a diagonal one goes to the chain only)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) cp_st(&a.W[(T.row0 + srow(qr, l, i)) * Dp + (long)T.J * PB + scol(qc0 + j, l)], S[k][j][i]);
+        if (T.diag) cp_signal(cp_chainin(a, T.I));
+        else if (!T.app && T.I == T.J + 1) cp_signal(cp_colcnt(a, T.J), cp_chainin(a, T.I));
+        else cp_signal(cp_colcnt(a, T.J));
+      }
+      __syncthreads();
     }
-    if (!diag) st_load(AJ, a.W + (long)J * PB * Dp + (long)s * PB, Dp);
-    if (!cp_wait(cp_pairflag(a), (unsigned)(s + 1), a, ok_s)) return;
-    st_load(Vp, a.Vpg + (long)s * PB * PB, PB);
-    __syncthreads();
-    const int kb1 = qc0 < 2 ? 1 : 2;
-    d4_t xi[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}}, xj[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    st_nt<false>(AI, Vp, qr, qc0, l, 0, kb1, xi);
-    if (!diag) st_nt<false>(AJ, Vp, qr, qc0, l, 0, kb1, xj);
-    __syncthreads();
-    st_store(AI, qr, qc0, l, xi);
-    if (!diag) st_store(AJ, qr, qc0, l, xj);
-    __syncthreads();
-    st_nt<true>(AI, diag ? AI : AJ, qr, qc0, l, 0, 2, S);            // S -= X_I X_J^T
-    if (lastcol && tid < PB) {                                       // x_R += (L^-T)_{R,s} y_s;  y_s = row gl of X_J (J = np - 1)
-      double acc = 0.0;
-      for (int k = 0; k < PB; ++k) acc = __builtin_fma(AI[tid * PLD + k], AJ[gl * PLD + k], acc);
-      xr += acc;
-    }
-    __syncthreads();
   }
-  if (lastcol) {
-    // the last pair: delta_R = x_R + (L^-T)_{R,last} y_last = x_R + S (Vp_last^T y_last); the chain publishes z = Vp_last^T y_last
-    st_store(AI, qr, qc0, l, S);
-    if (!cp_wait(cp_pairflag(a), (unsigned)np, a, ok_s)) return;
-    if (tid < PB) misc[tid] = a.ylast[tid];
+  // the last pair: delta_R = x_R + (L^-T)_{R,last} y_last = x_R + S (Vp_last^T y_last); the chain publishes z = Vp_last^T y_last
+  bool got = false;
+#pragma unroll
+  for (int k = 0; k < MAXT; ++k) {
+    if (!have[k] || !tl[k].lastcol) continue;
+    st_store(AI, qr, qc0, l, S[k]);
+    if (!got) {
+      if (!cp_wait(cp_pairflag(a), (unsigned)np, a, ok_s)) return;
+      if (tid < PB) misc[tid] = a.ylast[tid];
+      got = true;
+    }
     __syncthreads();
     if (tid < PB) {
       double acc = 0.0;
-      for (int k = 0; k < PB; ++k) acc = __builtin_fma(AI[tid * PLD + k], misc[k], acc);
-      a.delta[(long)I * PB + tid] = xr + acc;
+      for (int q = 0; q < PB; ++q) acc = __builtin_fma(AI[tid * PLD + q], misc[q], acc);
+      a.delta[(long)tl[k].I * PB + tid] = xr[k] + acc;
     }
-    return;
+    __syncthreads();
   }
-  // publish: this super-tile is the panel A(I, J) of every later step (a diagonal one goes to the chain only)
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) cp_st(&a.W[(row0 + srow(qr, l, i)) * Dp + (long)J * PB + scol(qc0 + j, l)], S[j][i]);
-  if (diag) cp_signal(cp_chainin(a, I));
-  else if (!app && I == J + 1) cp_signal(cp_colcnt(a, J), cp_chainin(a, I));
-  else cp_signal(cp_colcnt(a, J));
 }
 
+// (many super-tiles per workgroup: the owners' accumulator arrays must not take registers from the chain's waves -- the owners are
+// a function of their own there; with one or two super-tiles everything is one body, as measured fastest)
+template <int MAXT>
+__device__ __attribute__((noinline)) void cp_workers_call(CholpArgs a, double* dsm, int w, int nworkers) {
+  cp_workers_body<MAXT>(a, dsm, w, nworkers);
+}
+
+template <int MAXT>
 __global__ __launch_bounds__(CP_THREADS) void cholp_kernel(CholpArgs a) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
-  const int np = a.np;
-  int b = blockIdx.x;
-  if (b == 0) { cp_chain(a, dsm); return; }
-  b -= 1;
-  const int nOff = (np - 1) * (np - 2) / 2, nDiag = np - 2;
-  if (b < nOff) {                                  // (I, J), 1 <= J < I
-    int I = 2;
-    while (b >= I - 1) { b -= I - 1; ++I; }
-    cp_worker(a, dsm, I, b + 1, false);
-  } else if (b < nOff + nDiag) {
-    const int I = b - nOff + 2;
-    cp_worker(a, dsm, I, I, false);
-  } else {                                         // appended (R, C), R < C
-    b -= nOff + nDiag;
-    int C = 1;
-    while (b >= C) { b -= C; ++C; }
-    cp_worker(a, dsm, b, C, true);
-  }
+  if (blockIdx.x == 0) cp_chain(a, dsm);
+  else if (MAXT <= 2) cp_workers_body<MAXT>(a, dsm, (int)blockIdx.x - 1, (int)gridDim.x - 1);
+  else cp_workers_call<MAXT>(a, dsm, (int)blockIdx.x - 1, (int)gridDim.x - 1);
 }
 
-int cholp_workgroups(int np) { return 1 + (np - 1) * (np - 2) / 2 + (np - 2) + np * (np - 1) / 2; }
+int cholp_tiles(int np) { return (np - 1) + np * (np - 2); }
 
-// The persistent solve of a system that is already packed into `workspace` (chol_pack_kernel / como_sys_finalize_pack: they also
-// reset info and the counters).  COMO_ERR_ARG when the size or the device does not allow it (the caller falls back to the
-// multi-launch solver).
 // compute units of the device if the kernel's LDS request was accepted, else 0 (called from como_chol_workspace_bytes, i.e.
 // outside any stream capture, before the first solve)
 int cholp_init() {
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-    if (hipFuncSetAttribute((const void*)cholp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            CP_LDS_DOUBLES * (int)sizeof(double)) != hipSuccess) n = 0;
+    const int bytes = CP_LDS_DOUBLES * (int)sizeof(double);
+    if (hipFuncSetAttribute((const void*)cholp_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cholp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cholp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)cholp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+      n = 0;
     (void)hipGetLastError();
     const char* e = getenv("COMO_CHOLP");                  // COMO_CHOLP=0: the multi-launch solver (the fallback), for A/B runs
     if (e && atoi(e) == 0) n = 0;
@@ -493,11 +542,20 @@ int cholp_init() {
   return cus;
 }
 
+// The persistent solve of a system that is already packed into `workspace` (chol_pack_kernel / como_sys_finalize_pack: they also
+// reset info and the counters).  COMO_ERR_ARG when the size or the device does not allow it (the caller falls back to the
+// multi-launch solver).
 int cholp_solve(double* delta, void* workspace, int D, int* info, hipStream_t s) {
   if (!cholp_size_ok(D)) return COMO_ERR_ARG;
   const int np = chol_np(D);
-  const int G = cholp_workgroups(np);
-  if (G > cholp_init()) return COMO_ERR_ARG;               // one workgroup per compute unit, all co-resident
+  const int cus = cholp_init();
+  if (cus < 2) return COMO_ERR_ARG;
+  const int T = cholp_tiles(np);
+  const int workers = T < cus - 1 ? T : cus - 1;           // one workgroup per compute unit, all co-resident: chain + workers
+  const int per = (T + workers - 1) / workers;
+  if (per > 8) return COMO_ERR_ARG;
+  static const int maxnp = [] { const char* e = getenv("COMO_CHOLP_MAX_NP"); return e ? atoi(e) : CHOLP_RUN_MAX_NP; }();
+  if (np > maxnp) return COMO_ERR_ARG;
   CholpArgs a;
   a.Dp = 64 * np; a.D = D; a.np = np;
   a.W = (double*)workspace;
@@ -506,7 +564,12 @@ int cholp_solve(double* delta, void* workspace, int D, int* info, hipStream_t s)
   a.sync = (unsigned*)(a.W + cholp_sync_offset(a.Dp, np));
   a.delta = delta;
   a.info = info;
-  hipLaunchKernelGGL(cholp_kernel, dim3(G), dim3(CP_THREADS), CP_LDS_DOUBLES * sizeof(double), s, a);
+  const dim3 grid(1 + workers), blk(CP_THREADS);
+  const size_t lds = CP_LDS_DOUBLES * sizeof(double);
+  if (per <= 1) hipLaunchKernelGGL(cholp_kernel<1>, grid, blk, lds, s, a);
+  else if (per <= 2) hipLaunchKernelGGL(cholp_kernel<2>, grid, blk, lds, s, a);
+  else if (per <= 4) hipLaunchKernelGGL(cholp_kernel<4>, grid, blk, lds, s, a);
+  else hipLaunchKernelGGL(cholp_kernel<8>, grid, blk, lds, s, a);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }

@@ -23,9 +23,12 @@ namespace como {
 constexpr int WAVE = 64;
 
 // ---- layout of the dense solver's workspace, shared by the packing kernels (csrc/ba.hip, csrc/chol.hip) and the solvers ------
-// Systems of 2 .. CHOLP_MAX_NP column PAIRS (64 columns: D + 1 <= 1024) are padded to whole pairs -- the persistent one-launch
+// Systems of 2 .. CHOLP_MAX_NP column PAIRS (64 columns: D + 1 <= 2816) are padded to whole pairs -- the persistent one-launch
 // solver (csrc/cholp.hip) works on 64 x 64 super-tiles --, larger (and tiny) ones to whole 32-wide block columns.
-constexpr int CHOLP_MAX_NP = 16;
+constexpr int CHOLP_MAX_NP = 44;
+// the persistent solver runs up to this many pairs (measured, us persistent / multi-launch: D = 1240 305 / 386, 1500 409 / 556,
+// 2000 726 / 854, 2680 1636 / 1502: beyond ~2300 columns the owners' three products per super-tile step lose to the multi-launch panels)
+constexpr int CHOLP_RUN_MAX_NP = 34;
 constexpr int CHOLP_SYNC_STRIDE = 32;                 // 32-bit words: every counter on its own 128-byte line
 __host__ __device__ inline int chol_np(long D) { return (int)((D + 1 + 63) / 64); }
 __host__ __device__ inline bool cholp_size_ok(long D) { return chol_np(D) >= 2 && chol_np(D) <= CHOLP_MAX_NP; }
