@@ -110,6 +110,13 @@ SIGNATURES = {
     "como_dense_ref_f64": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8 + [c_int, c_void_p]),
     "como_depth_band_f32": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, c_void_p]),
     "como_depth_band_f64": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, c_void_p]),
+    "como_cov_params_at": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "como_diag_cov_f32": (c_int, [c_void_p, c_long, c_float, c_void_p, c_void_p]),
+    "como_diag_cov_f64": (c_int, [c_void_p, c_long, c_double, c_void_p, c_void_p]),
+    "como_kernel_matrices_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_float] + [c_void_p] * 7 + [c_int, c_void_p]),
+    "como_kernel_matrices_f64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_double] + [c_void_p] * 7 + [c_int, c_void_p]),
+    "como_backproject_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "como_backproject_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "como_kernel_matrix_f32": (c_int, [c_void_p] * 4 + [c_float, c_void_p, c_int, c_int, c_int, c_void_p]),
     "como_kernel_matrix_f64": (c_int, [c_void_p] * 4 + [c_double, c_void_p, c_int, c_int, c_int, c_void_p]),
     "como_ktilde_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,

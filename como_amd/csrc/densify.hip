@@ -435,6 +435,108 @@ __global__ __launch_bounds__(256) void kernel_matrix_py_kernel(const T* __restri
       kernel_py(a[0], a[1], E1 + ((long)b * N + i) * 4, c[0], c[1], E2 + ((long)b * M + j) * 4) * scale;
 }
 
+// ---- keyframe-insertion glue: the covariance parameters AT a list of points, the diagonal prior variance, back-projection --------
+// One launch each for what the keyframe path (corr.py track_and_init, distill_depth.py calc_kernel_matrices, samplers.py,
+// Mapping.prep_predictor) did as chains of tiny torch launches -- ~8 per call of normalize_coordinates + interpolate_kernel_params,
+// ~20 per DiagonalCovarianceModule call, 7 per backprojection --, with EXACTLY the arithmetic of those chains: every torch
+// elementwise kernel rounds its own result (no fusion across them: contraction off here), torch's grid_sample kernel is one
+// expression per value (contracted by the compiler: the same expressions under the same default here).
+//
+// normalize_coordinates (coords.py:12-15 of the reference): x_norm = (2A x + A) - 1, A = 1 / dims, in the coordinates' type
+template <typename TC>
+__device__ __forceinline__ TC norm_coord(TC x, int dim) {
+#pragma clang fp contract(off)
+  const TC A = TC(1) / TC(dim);
+  const TC A2 = TC(2) * A;
+  TC t = A2 * x;
+  t = t + A;
+  return t - TC(1);
+}
+
+// torch.nn.functional.grid_sample(bilinear, padding_mode="border", align_corners=False) at ONE normalised (x, y): the four
+// channels of the covariance image (ATen GridSampler.cu grid_sampler_2d_kernel: unnormalise, clip, floor, corner weights as
+// products of differences, out = sum of value * weight over the in-bounds corners in the order nw, ne, sw, se)
+template <typename T>
+__device__ __forceinline__ void grid_sample_border4(const T* __restrict__ img, int H, int W, T x, T y, T* __restrict__ out) {
+  T ix = ((x + 1.f) * W - 1) / 2;
+  T iy = ((y + 1.f) * H - 1) / 2;
+  ix = fmin((T)(W - 1), fmax(ix, (T)0));
+  iy = fmin((T)(H - 1), fmax(iy, (T)0));
+  const long ix_nw = (long)floor(ix), iy_nw = (long)floor(iy);
+  const long ix_ne = ix_nw + 1, iy_ne = iy_nw, ix_sw = ix_nw, iy_sw = iy_nw + 1, ix_se = ix_nw + 1, iy_se = iy_nw + 1;
+  const T nw = (ix_se - ix) * (iy_se - iy);
+  const T ne = (ix - ix_sw) * (iy_sw - iy);
+  const T sw = (ix_ne - ix) * (iy - iy_ne);
+  const T se = (ix - ix_nw) * (iy - iy_nw);
+  const long HW = (long)H * W;
+  auto inb = [&](long yy, long xx) { return yy >= 0 && yy < H && xx >= 0 && xx < W; };
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const T* pl = img + c * HW;
+    T acc = 0;
+    if (inb(iy_nw, ix_nw)) acc += pl[iy_nw * W + ix_nw] * nw;
+    if (inb(iy_ne, ix_ne)) acc += pl[iy_ne * W + ix_ne] * ne;
+    if (inb(iy_sw, ix_sw)) acc += pl[iy_sw * W + ix_sw] * sw;
+    if (inb(iy_se, ix_se)) acc += pl[iy_se * W + ix_se] * se;
+    out[c] = acc;
+  }
+}
+
+// coords (B,N,2) row/col pixel coordinates (type TC) -> cn (B,N,2) normalised (type T: computed in TC, then cast -- the sampler
+// normalises float64 coordinates and casts to float32) and E (B,N,4) = interpolate_kernel_params(cov, cn) (gaussian_kernel.py:52-79)
+template <typename TC, typename T>
+__global__ __launch_bounds__(256) void cov_params_at_kernel(const T* __restrict__ cov, int H, int W, const TC* __restrict__ coords,
+                                                            int N, T* __restrict__ cn, T* __restrict__ E) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const long o = (long)b * N + i;
+  const T r = (T)norm_coord<TC>(coords[2 * o], H), c = (T)norm_coord<TC>(coords[2 * o + 1], W);
+  cn[2 * o] = r;
+  cn[2 * o + 1] = c;
+  T e[4];
+  grid_sample_border4<T>(cov + (long)b * 4 * H * W, H, W, c, r, e);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) E[4 * o + k] = e[k];
+}
+
+// DiagonalCovarianceModule (covariance.py:42-50 + kernels.py:69-88 with Q = 0), operation by operation
+template <typename T>
+__global__ __launch_bounds__(256) void diag_cov_kernel(const T* __restrict__ E, long total, T scale, T* __restrict__ out) {
+#pragma clang fp contract(off)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const T e00 = E[4 * i], e01 = E[4 * i + 1], e10 = E[4 * i + 2], e11 = E[4 * i + 3];
+  const T p0 = e00 * e11, p1 = e01 * e10;
+  const T det = p0 - p1;
+  const T f00 = T(2) * e00, f01 = T(2) * e01, f10 = T(2) * e10, f11 = T(2) * e11;
+  const T q0 = f00 * f11, q1 = f01 * f10;
+  const T det2 = q0 - q1;
+  const T num = T(2.0) * sqrt(det);
+  const T C = num / sqrt(det2 + T(1e-8));
+  const T q = sqrt(T(0) + T(1e-8));
+  const T tmp = T(1.7320508075688772) * q;
+  const T ex = exp(-tmp);
+  const T mat = (T(1) + tmp) * ex;
+  const T v = C * mat;
+  out[i] = v * scale;
+}
+
+// backprojection values (camera.py:43-54): P = z * ((p_x - cx) / fx, (p_y - cy) / fy, 1); p (n,2) x/y, z (n), K (3,3) row-major
+template <typename T>
+__global__ __launch_bounds__(256) void backproject_kernel(const T* __restrict__ K, const T* __restrict__ p, const T* __restrict__ z,
+                                                          long n, T* __restrict__ P) {
+#pragma clang fp contract(off)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const T fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+  const T r0 = (p[2 * i] - cx) / fx, r1 = (p[2 * i + 1] - cy) / fy;
+  const T zz = z[i];
+  P[3 * i] = zz * r0;
+  P[3 * i + 1] = zz * r1;
+  P[3 * i + 2] = zz * T(1);
+}
+
 // K~ rows for every photo pixel on the matrix cores.  One wave owns 16 pixels per trip: lane (px = l & 15, kq = l >> 4)
 // evaluates the 16 kernel values k(pixel px, inducing point 4 s + kq), s = 0..15 -- which is exactly the A-operand layout of
 // the 16x16x4 MFMA (row = l & 15, k = l >> 4) -- and multiplies by K_mm^-1 (B operand from LDS: one ds_read per MFMA
@@ -615,5 +717,77 @@ COMO_DEF_BAND(f64, double)
   }
 COMO_DEF_KMAT(f32, float)
 COMO_DEF_KMAT(f64, double)
+
+#define COMO_DEF_KFGLUE(SFX, T)                                                                                                  \
+  int como_diag_cov_##SFX(const T* E, long total, T scale, T* out, como_stream_t stream) {                                       \
+    if (!E || !out || total < 0) return COMO_ERR_ARG;                                                                            \
+    if (!total) return COMO_OK;                                                                                                  \
+    hipLaunchKernelGGL(como::diag_cov_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, E,     \
+                       total, scale, out);                                                                                       \
+    COMO_CHECK_LAUNCH();                                                                                                         \
+    return COMO_OK;                                                                                                              \
+  }                                                                                                                              \
+  int como_backproject_##SFX(const T* K, const T* p, const T* z, long n, T* P, como_stream_t stream) {                           \
+    if (!K || !p || !z || !P || n < 0) return COMO_ERR_ARG;                                                                      \
+    if (!n) return COMO_OK;                                                                                                      \
+    hipLaunchKernelGGL(como::backproject_kernel<T>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, K, p,   \
+                       z, n, P);                                                                                                 \
+    COMO_CHECK_LAUNCH();                                                                                                         \
+    return COMO_OK;                                                                                                              \
+  }                                                                                                                              \
+  /* calc_kernel_matrices (distill_depth.py:8-27): normalised coordinates + interpolated parameters of both point sets, */       \
+  /* K_mm, K_nm and the diagonal of K_nn in one call (5 launches)                                                        */      \
+  int como_kernel_matrices_##SFX(const T* cov, int Hc, int Wc, const T* coords_m, int m, const T* coords_n, int n, T scale,      \
+                                 T* cm, T* Em, T* cn, T* En, T* Kmm, T* Knm, T* Kdiag, int B, como_stream_t stream) {            \
+    if (!cov || B <= 0 || m < 0 || n < 0 || Hc <= 0 || Wc <= 0 || (m && (!coords_m || !cm || !Em || !Kmm)) ||                    \
+        (n && (!coords_n || !cn || !En || !Kdiag)) || (m && n && !Knm))       /* (an empty set's buffers may be null) */          \
+      return COMO_ERR_ARG;                                                                                                       \
+    hipStream_t s = (hipStream_t)stream;                                                                                         \
+    if (m) {                                                                                                                     \
+      hipLaunchKernelGGL((como::cov_params_at_kernel<T, T>), dim3((m + 255) / 256, B), dim3(256), 0, s, cov, Hc, Wc, coords_m,   \
+                         m, cm, Em);                                                                                             \
+      COMO_CHECK_LAUNCH();                                                                                                       \
+      hipLaunchKernelGGL(como::kernel_matrix_py_kernel<T>, dim3((unsigned)(((long)m * m + 255) / 256), B), dim3(256), 0, s,       \
+                         (const T*)cm, (const T*)Em, (const T*)cm, (const T*)Em, scale, Kmm, m, m);                              \
+      COMO_CHECK_LAUNCH();                                                                                                       \
+    }                                                                                                                            \
+    if (n) {                                                                                                                     \
+      hipLaunchKernelGGL((como::cov_params_at_kernel<T, T>), dim3((n + 255) / 256, B), dim3(256), 0, s, cov, Hc, Wc, coords_n,   \
+                         n, cn, En);                                                                                             \
+      COMO_CHECK_LAUNCH();                                                                                                       \
+      hipLaunchKernelGGL(como::diag_cov_kernel<T>, dim3((unsigned)(((long)B * n + 255) / 256)), dim3(256), 0, s, (const T*)En,    \
+                         (long)B * n, scale, Kdiag);                                                                             \
+      COMO_CHECK_LAUNCH();                                                                                                       \
+    }                                                                                                                            \
+    if (m && n) {                                                                                                                \
+      hipLaunchKernelGGL(como::kernel_matrix_py_kernel<T>, dim3((unsigned)(((long)n * m + 255) / 256), B), dim3(256), 0, s,       \
+                         (const T*)cn, (const T*)En, (const T*)cm, (const T*)Em, scale, Knm, n, m);                              \
+      COMO_CHECK_LAUNCH();                                                                                                       \
+    }                                                                                                                            \
+    return COMO_OK;                                                                                                              \
+  }
+COMO_DEF_KFGLUE(f32, float)
+COMO_DEF_KFGLUE(f64, double)
+
+/* normalize_coordinates + interpolate_kernel_params at a list of points: coords of type f64 or f32 (coords_is_f64), covariance
+ * image / outputs f32 or f64 (out_is_f64; f32 coordinates with f64 outputs are not a combination the path has) */
+int como_cov_params_at(const void* cov, int Hc, int Wc, const void* coords, int coords_is_f64, int out_is_f64, int N, void* cn,
+                       void* E, int B, como_stream_t stream) {
+  if (!cov || !coords || !cn || !E || B <= 0 || N < 0 || Hc <= 0 || Wc <= 0 || (out_is_f64 && !coords_is_f64)) return COMO_ERR_ARG;
+  if (!N) return COMO_OK;
+  const dim3 grid((N + 255) / 256, B), blk(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (out_is_f64)
+    hipLaunchKernelGGL((como::cov_params_at_kernel<double, double>), grid, blk, 0, s, (const double*)cov, Hc, Wc,
+                       (const double*)coords, N, (double*)cn, (double*)E);
+  else if (coords_is_f64)
+    hipLaunchKernelGGL((como::cov_params_at_kernel<double, float>), grid, blk, 0, s, (const float*)cov, Hc, Wc,
+                       (const double*)coords, N, (float*)cn, (float*)E);
+  else
+    hipLaunchKernelGGL((como::cov_params_at_kernel<float, float>), grid, blk, 0, s, (const float*)cov, Hc, Wc,
+                       (const float*)coords, N, (float*)cn, (float*)E);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
 
 }  // extern "C"

@@ -61,6 +61,12 @@ class DiagonalCovarianceModule(CovarianceModule):
     elementwise torch ops."""
 
     def __call__(self, coords, E):
+        if E.is_cuda and E.dtype in (torch.float32, torch.float64) and E.shape[-2:] == (2, 2):
+            out = torch.empty(E.shape[:-2], dtype=E.dtype, device=E.device)
+            rc = getattr(_lib.lib(), "como_diag_cov_" + _lib.suffix(E.dtype))(E.contiguous().data_ptr(), out.numel(), self.scale,
+                                                                             out.data_ptr(), _lib.stream_ptr(E.device))
+            _lib.check(rc, "como_diag_cov")
+            return out
         det = E[..., 0, 0] * E[..., 1, 1] - E[..., 0, 1] * E[..., 1, 0]
         E2 = 2 * E
         det2 = E2[..., 0, 0] * E2[..., 1, 1] - E2[..., 0, 1] * E2[..., 1, 0]
@@ -82,8 +88,8 @@ def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None, K_mm_in
     dt, dev = cov_params_img.dtype, cov_params_img.device
     Hp, Wp = photo_img_size or (Hc, Wc)
     m = coords_m.shape[1]
-    cm = normalize_coordinates(coords_m.to(dt), (Hc, Wc))
-    Em = interpolate_kernel_params(cov_params_img, cm)
+    from como_amd.depth_cov.core.gaussian_kernel import kernel_params_at
+    cm, Em = kernel_params_at(cov_params_img, coords_m.to(dt))         # normalised coordinates + interpolated parameters, one launch
     if K_mm_inv is None:
         K_mm = covariance(cm, Em, scale)
         K_mm = K_mm + torch.diag_embed((1e-6 * torch.ones(B, m, device=dev)).to(dt))      # float32 jitter as Mapping.py:450

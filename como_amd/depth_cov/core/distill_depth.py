@@ -82,6 +82,23 @@ def lstsq_chol(A, b):
 def calc_kernel_matrices(coords_m, coords_n, cov_params_img, model):
     """:8-27 -> K_mm (B,m,m), K_nm (B,n,m), K_nn_diag (B,n)."""
     size = cov_params_img.shape[-2:]
+    dt = cov_params_img.dtype
+    mods = (model.cov_modules[-1], model.cross_cov_modules[-1], model.diagonal_cov_modules[-1])
+    if (cov_params_img.is_cuda and dt in (torch.float32, torch.float64) and coords_m.dtype == dt and coords_n.dtype == dt and
+            cov_params_img.shape[1] == 4 and len({float(x.scale) for x in mods}) == 1 and type(mods[2]).__name__ == "DiagonalCovarianceModule"):
+        # one native call (csrc/densify.hip `como_kernel_matrices_*`: 5 launches) for ~45 torch launches, value for value
+        from como_amd import _lib
+        B, m, n = coords_m.shape[0], coords_m.shape[1], coords_n.shape[1]
+        dev = cov_params_img.device
+        e = lambda *shape: torch.empty(shape, dtype=dt, device=dev)
+        cm, Em, cn, En = e(B, m, 2), e(B, m, 2, 2), e(B, n, 2), e(B, n, 2, 2)
+        K_mm, K_nm, K_d = e(B, m, m), e(B, n, m), e(B, n)
+        rc = getattr(_lib.lib(), "como_kernel_matrices_" + _lib.suffix(dt))(
+            cov_params_img.contiguous().data_ptr(), int(size[0]), int(size[1]), coords_m.contiguous().data_ptr(), m,
+            coords_n.contiguous().data_ptr(), n, float(mods[0].scale), cm.data_ptr(), Em.data_ptr(), cn.data_ptr(), En.data_ptr(),
+            K_mm.data_ptr(), K_nm.data_ptr(), K_d.data_ptr(), B, _lib.stream_ptr(dev))
+        _lib.check(rc, "como_kernel_matrices")
+        return K_mm, K_nm, K_d
     cm = normalize_coordinates(coords_m, size)
     Em = interpolate_kernel_params(cov_params_img, cm)
     cn = normalize_coordinates(coords_n, size)

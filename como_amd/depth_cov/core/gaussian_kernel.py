@@ -24,3 +24,27 @@ def interpolate_kernel_params(kernel_img, x):
     grid = x.flip(-1).unsqueeze(1)
     s = torch.nn.functional.grid_sample(kernel_img, grid, mode="bilinear", padding_mode="border", align_corners=False)
     return s.squeeze(2).permute(0, 2, 1).reshape(B, N, 2, 2)
+
+
+def kernel_params_at(kernel_img, coords_pix, out_dtype=None):
+    """normalize_coordinates(coords_pix, image size) -> cast to `out_dtype` (default: the image's) -> interpolate_kernel_params, as
+    ONE launch on the GPU (csrc/densify.hip `como_cov_params_at`: the arithmetic of the torch chain, value for value) instead of
+    eight.  coords_pix (B,N,2) row/col pixels -> (normalised coords (B,N,2), E (B,N,2,2)) in `out_dtype`."""
+    from como_amd.utils.coords import normalize_coordinates
+    dt = out_dtype or kernel_img.dtype
+    B, N = coords_pix.shape[:2]
+    size = kernel_img.shape[-2:]
+    ok = (kernel_img.is_cuda and kernel_img.dtype == dt and dt in (torch.float32, torch.float64) and kernel_img.shape[1] == 4 and
+          coords_pix.dtype in (torch.float32, torch.float64) and not (dt == torch.float64 and coords_pix.dtype == torch.float32))
+    if not ok:
+        cn = normalize_coordinates(coords_pix, size).to(dt)
+        return cn, interpolate_kernel_params(kernel_img, cn)
+    from como_amd import _lib
+    cn = torch.empty((B, N, 2), dtype=dt, device=kernel_img.device)
+    E = torch.empty((B, N, 2, 2), dtype=dt, device=kernel_img.device)
+    if N:
+        rc = _lib.lib().como_cov_params_at(kernel_img.contiguous().data_ptr(), int(size[0]), int(size[1]), coords_pix.contiguous().data_ptr(),
+                                           int(coords_pix.dtype == torch.float64), int(dt == torch.float64), N, cn.data_ptr(), E.data_ptr(),
+                                           B, _lib.stream_ptr(kernel_img.device))
+        _lib.check(rc, "como_cov_params_at")
+    return cn, E

@@ -15,6 +15,9 @@ from como_amd.utils.coords import normalize_coordinates
 from como_amd.utils.lin_alg import chol_small, trsm_lower
 
 
+_domain_cache = {}
+
+
 def get_coords_domain(cov_params_img, border=0):
     b, c, h, w = cov_params_img.shape
     dev = cov_params_img.device
@@ -45,7 +48,7 @@ def calc_var(obs_info, K_diag):
     return K_diag - torch.sum(obs_info * obs_info, dim=1)
 
 
-def precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_coords_norm, curr_var, fixed_var, scale):
+def precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_coords_norm, curr_var, fixed_var, scale, curr_E=None):
     b, m, _ = curr_coords_norm.shape
     dev, dt = E_domain.device, E_domain.dtype
     d = coords_domain_norm.shape[-2]
@@ -53,11 +56,14 @@ def precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_co
     coords_n_norm = torch.empty((b, n, 2), device=dev, dtype=dt)
     E_n = torch.empty((b, n, 2, 2), device=dev, dtype=dt)
     L = torch.eye(n, device=dev, dtype=dt).unsqueeze(0).repeat(b, 1, 1)
-    obs_info = torch.zeros((b, n, d), device=dev, dtype=dt)
+    # (rows >= m are written by the step that adds them before any later step reads them, rows < m below: no 77 MB zero-fill at
+    # a 640x480 domain)
+    obs_info = torch.empty((b, n, d), device=dev, dtype=dt)
     if m > 0:
         coord_vec_inds[:, :m] = -1
         coords_n_norm[:, 0:m, :] = curr_coords_norm
-        E_n[:, :m, :, :] = gk.interpolate_kernel_params(gaussian_covs, curr_coords_norm)
+        # (curr_E: the parameters at the current points when the caller already interpolated them with the coordinates)
+        E_n[:, :m, :, :] = curr_E if curr_E is not None else gk.interpolate_kernel_params(gaussian_covs, curr_coords_norm)
     else:
         areas = E_domain[..., 0, 0] * E_domain[..., 1, 1] - E_domain[..., 0, 1] * E_domain[..., 1, 0]
         best = torch.argmax(areas.view(b, -1), dim=1)
@@ -71,7 +77,7 @@ def precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_co
     if curr_var.shape[1] > 0:
         assert curr_var.shape[1] == curr_coords_norm.shape[1]
         K_nn += torch.diag_embed(curr_var)
-    if fixed_var is not None:
+    if fixed_var is not None and float(fixed_var) != 0.0:           # (+ 0.0 on the diagonal changes no bit of K_nn)
         K_nn += torch.diag_embed(fixed_var * torch.ones(b, m, device=dev))
     f = chol_small(K_nn, want_L=True, want_info=True)          # the initial factor (torch.linalg.cholesky in the reference)
     if int(f["info"].max()) != 0:                              # ... which raises on a non-positive-definite K_nn: so does this
@@ -79,7 +85,10 @@ def precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_co
     L[:, :m, :m] = f["L"]
     K_md = como_backends.cross_covariance(coords_n_norm[:, :m, :], E_n[:, :m, :, :], coords_domain_norm.view(b, -1, 2), E_domain,
                                           scale)
-    obs_info[:, :m, :] = get_obs_info(L[:, :m, :m], K_md)
+    if b == 1:
+        trsm_lower(L[:, :m, :m], K_md, out=obs_info[:, :m, :])      # straight into the leading rows (contiguous for one image)
+    else:
+        obs_info[:, :m, :] = get_obs_info(L[:, :m, :m], K_md)
     return coord_vec_inds, coords_n_norm, E_n, L, obs_info, m
 
 
@@ -142,9 +151,9 @@ def greedy_loop(coord_vec_inds, coords_n_norm, E_n, coords_domain_norm, E_domain
 
 
 def greedy_conditional_entropy(gaussian_covs, E_domain, n, coords_domain_norm, curr_coords_norm, curr_var, fixed_var,
-                               signal_var, max_stdev_thresh, terminate_early, dist_thresh):
+                               signal_var, max_stdev_thresh, terminate_early, dist_thresh, curr_E=None):
     cvi, cn, E_n, L, obs, m = precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_coords_norm, curr_var,
-                                                   fixed_var, signal_var)
+                                                   fixed_var, signal_var, curr_E=curr_E)
     return greedy_loop(cvi, cn, E_n, coords_domain_norm, E_domain, L, obs, m, n, signal_var, fixed_var, max_stdev_thresh,
                        terminate_early, dist_thresh)
 
@@ -162,21 +171,35 @@ def sample_sparse_coords(cov_params_img, num_samples, mode, max_stdev_thresh=-1e
     if curr_var is None:
         curr_var = torch.zeros((b, 0), device=dev, dtype=dtype)
     if coords_domain is None:
-        coords_domain = get_coords_domain(cov, border=border)
-        cdn = normalize_coordinates(coords_domain, img_size).to(dtype)
+        # the pixel grid inside the border and its normalised form only depend on the image size: built once (READ-ONLY, shared)
+        key = (b, int(img_size[0]), int(img_size[1]), int(border), str(dev), dtype)
+        ent = _domain_cache.get(key)
+        if ent is None:
+            coords_domain = get_coords_domain(cov, border=border)
+            ent = _domain_cache[key] = (coords_domain, normalize_coordinates(coords_domain, img_size).to(dtype))
+        coords_domain, cdn = ent
         E_domain = get_cov_domain(coords_domain, cov)
     else:
-        cdn = normalize_coordinates(coords_domain, img_size).to(dtype)
-        E_domain = gk.interpolate_kernel_params(cov, cdn)
+        cdn, E_domain = gk.kernel_params_at(cov, coords_domain, dtype)
     if mode == "random_uniform":
         inds = random_uniform(num_samples - curr_coords.shape[-2], cdn)
     elif mode == "greedy_conditional_entropy":
         n = min(num_samples, coords_domain.shape[1])
-        ccn = normalize_coordinates(curr_coords, img_size).to(dtype)
+        if curr_coords.shape[1] > 0:
+            ccn, curr_E = gk.kernel_params_at(cov, curr_coords, dtype)
+        else:
+            ccn, curr_E = normalize_coordinates(curr_coords, img_size).to(dtype), None
         inds = greedy_conditional_entropy(cov, E_domain, n, cdn, ccn, curr_var, fixed_var, signal_var, max_stdev_thresh,
-                                          terminate_early, dist_thresh)
+                                          terminate_early, dist_thresh, curr_E=curr_E)
     else:
         raise ValueError("sample_sparse_coords mode: " + mode + " is not implemented.")
-    domain_inds = inds[:, inds[0, :] >= 0]
+    if mode == "greedy_conditional_entropy":
+        # the -1 entries are exactly the leading columns of the current points (precalc_entropy_vars; none when it seeded the set
+        # itself): a slice instead of a boolean column mask (which synchronises with the host to learn its size)
+        domain_inds = inds[:, curr_coords.shape[1]:]
+    else:
+        domain_inds = inds[:, inds[0, :] >= 0]
+    if b == 1:
+        return coords_domain.index_select(1, domain_inds[0]), domain_inds
     bi = torch.arange(b, device=dev).unsqueeze(1).repeat(1, domain_inds.shape[1])
     return coords_domain[bi, domain_inds, :], domain_inds

@@ -26,6 +26,22 @@ def backprojection(K, p, z):
     return z * ray, ray[..., None]
 
 
+def backprojection_points(K, p, z):
+    """The values of `backprojection` alone -- P = z * ray (…,3) -- as one launch on the GPU (csrc/densify.hip `como_backproject_*`,
+    same operations in the same order) instead of seven; K (3,3), p (…,2) x/y, z (…,1)."""
+    if not (p.is_cuda and p.dtype in (torch.float32, torch.float64) and z.dtype == p.dtype and K.dtype == p.dtype and
+            z.shape[:-1] == p.shape[:-1] and z.shape[-1] == 1):
+        return backprojection(K, p, z)[0]
+    from como_amd import _lib
+    n = p.numel() // 2
+    P = torch.empty(p.shape[:-1] + (3,), dtype=p.dtype, device=p.device)
+    if n:
+        rc = getattr(_lib.lib(), "como_backproject_" + _lib.suffix(p.dtype))(K.contiguous().data_ptr(), p.contiguous().data_ptr(),
+                                                                             z.contiguous().data_ptr(), n, P.data_ptr(), _lib.stream_ptr(p.device))
+        _lib.check(rc, "como_backproject")
+    return P
+
+
 def transform_project(K, Tji, Pi):
     """camera.py:57-68 with sequential accumulation (K T[:3,:]) P (see csrc/track.hip for the device version)."""
     def dot3(a0, a1, a2, x, y, z):

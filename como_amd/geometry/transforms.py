@@ -14,6 +14,13 @@ def get_rel_pose(pose1, pose2):
     return composeSE3(pose1, pose2, 1)
 
 
+def transform_points_values(Tji, Pi):
+    """P_j of `transform_points` alone (the same batched product): the keyframe path never reads the Jacobians."""
+    R = Tji[:, None, :3, :3].contiguous()
+    t = Tji[:, None, :3, 3:4].contiguous()
+    return (R @ Pi[..., None] + t).squeeze(-1)
+
+
 def transform_points(Tji, Pi):
     """P_j = R P_i + t for every point, with dP_j/dT (left se3 perturbation, [rot | trans] columns) and dP_j/dP_i = R
     (transforms.py:17-39).  Pi (b,n,3) or (1,n,3) broadcast over the poses (B,4,4)."""

@@ -26,9 +26,9 @@ _PIX_MIRRORS = os.environ.get("COMO_PIX_MIRRORS", "1") != "0"       # 0: every w
 from como_amd.depth_cov.core.covariance import prep_predictor as _prep_predictor
 from como_amd.depth_cov.core.DepthCovModule import DepthCovModule, run_model as _run_model
 from como_amd.geometry.affine_brightness import get_aff_w_curr
-from como_amd.geometry.camera import backprojection
-from como_amd.geometry.transforms import get_T_w_curr, transform_points
-from como_amd.odom.frontend.corr import track_and_init
+from como_amd.geometry.camera import backprojection, backprojection_points
+from como_amd.geometry.transforms import get_T_w_curr, transform_points, transform_points_values
+from como_amd.odom.frontend.corr import prepare_track_and_init, track_and_init
 from como_amd.odom.frontend.TwoFrameSfm import TwoFrameSfm
 from como_amd.odom.backend.dense_ref import depth_image
 from como_amd.odom.window_ba import WindowBA
@@ -302,19 +302,23 @@ class Mapping:
 
     def add_keyframe(self, rgb, kf_pose_init, kf_aff_init, timestamp):
         img_and_grads = self.get_img_and_grads(rgb)
-        cov_params_img = self.run_model(rgb)
         coords_m_last = swap_coords_xy(self.pm[-1:, ...])
         zm_last = torch.exp(self.logzm[-1:, ...])
+        z_img_last = self.depth_imgs_of(self.kf_poses.shape[0] - 1, self.kf_poses.shape[0])
+        # the reprojection of the last keyframe into the new frame does not need the network's output (the covariance image has the
+        # frame's size): issued first, its host synchronisation does not wait for the network, which then runs under the host work
+        pre = prepare_track_and_init(self.kf_poses[-1:, ...], kf_pose_init, coords_m_last, zm_last, z_img_last, self.intrinsics,
+                                     tuple(rgb.shape[-2:]), self.cfg["corr"])
+        cov_params_img = self.run_model(rgb)
         coords_m_new, z_m_new, corr_mask, coords_m, zm_first_obs = track_and_init(
-            self.kf_poses[-1:, ...], kf_pose_init, coords_m_last, zm_last, self.depth_imgs_of(self.kf_poses.shape[0] - 1,
-                                                                                             self.kf_poses.shape[0]), cov_params_img,
-            self.intrinsics, self.model, self.cfg["corr"], self.cfg["sampling"], self.kf_img_and_grads.shape[-2:])
+            self.kf_poses[-1:, ...], kf_pose_init, coords_m_last, zm_last, z_img_last, cov_params_img,
+            self.intrinsics, self.model, self.cfg["corr"], self.cfg["sampling"], self.kf_img_and_grads.shape[-2:], prepared=pre)
         # depth images of the current window, if a snapshot just evaluated them (handle_tracking_data): still valid for the keyframes
         # that stay -- the insertion below does not touch their log-depths
         kept_depths = self._depth_cache[self.get_kf_start_window_ind():] if self._depth_cache is not None else None
         p_m_new = swap_coords_xy(coords_m_new).to(dtype=z_m_new.dtype)
-        Pc_new, _ = backprojection(self.intrinsics[0], p_m_new, z_m_new)
-        Pw_new, _, _ = transform_points(kf_pose_init, Pc_new)
+        Pc_new = backprojection_points(self.intrinsics[0], p_m_new, z_m_new)
+        Pw_new = transform_points_values(kf_pose_init, Pc_new)
         Kmm_inv, L_mm, Knm_Kmminv = self.prep_predictor(cov_params_img, coords_m)
         pm_first_obs = swap_coords_xy(coords_m)
         self.window_cat_helper_list(self.kf_timestamps, timestamp, self.get_kf_start_window_ind())

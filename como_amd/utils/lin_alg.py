@@ -48,7 +48,7 @@ def chol_small(A, want_L=True, want_inv=False, rhs=None, want_info=False):
     return out
 
 
-def trsm_lower(L, Bm, trans=False):
+def trsm_lower(L, Bm, trans=False, out=None):
     """X = L^-1 Bm (trans: L^-T Bm), L (B,n,n) lower triangular (n <= 64), Bm (B,n,d) with many columns
     (torch.linalg.solve_triangular(L, Bm, upper=False); trans: the second half of torch.cholesky_solve)."""
     _lib.require_cuda(L, Bm)
@@ -57,7 +57,10 @@ def trsm_lower(L, Bm, trans=False):
         raise RuntimeError("como_amd trsm_lower: L (B,n,n), Bm (B,n,d)")
     if L3.shape[1] > 64 or L3.dtype not in (torch.float32, torch.float64):
         raise RuntimeError("como_amd trsm_lower: n <= 64, float32 / float64")
-    X = torch.empty_like(B3)
+    # out: a contiguous (B,n,d) tensor of L's type that receives X (e.g. the leading rows of a larger buffer, B = 1)
+    if out is not None and (out.shape != B3.shape or out.dtype != B3.dtype or not out.is_contiguous() or out.device != B3.device):
+        raise RuntimeError("como_amd trsm_lower: `out` must be a contiguous tensor of the shape and type of the right-hand side")
+    X = out if out is not None else torch.empty_like(B3)
     fn = getattr(_lib.lib(), "como_trsm_lower_" + _lib.suffix(L3.dtype))
     rc = fn(L3.data_ptr(), B3.data_ptr(), X.data_ptr(), L3.shape[0], L3.shape[1], B3.shape[2], 1 if trans else 0,
             _lib.stream_ptr(L3.device))

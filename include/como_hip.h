@@ -365,6 +365,29 @@ int como_ktilde_f64(const double* cov, int Hc, int Wc, const double* xm, const d
                     double scale, int B, int Hp, int Wp, int m, double* out, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Keyframe-insertion glue with the arithmetic of the reference's torch chains, one launch per chain:
+ * como_cov_params_at  replaces  normalize_coordinates (como/utils/coords.py:12-15) + interpolate_kernel_params
+ *   (depth_cov/core/gaussian_kernel.py:52-79: grid_sample bilinear / border / align_corners=False): coords (B,N,2) row/col pixels
+ *   (float64 or float32) -> cn (B,N,2) normalised and E (B,N,2,2), both in the covariance image's type (float32 or float64;
+ *   float64 coordinates are normalised in float64 and then cast, as samplers.py:64-78 does).
+ * como_diag_cov_*     replaces  DiagonalCovarianceModule.forward (depth_cov/core/covariance.py:42-50, kernels.py:69-88 at Q = 0).
+ * como_kernel_matrices_*  replaces  calc_kernel_matrices (depth_cov/core/distill_depth.py:8-27): cm, Em, cn, En, K_mm (B,m,m),
+ *   K_nm (B,n,m), diag K_nn (B,n) of pixel coordinates coords_m (B,m,2), coords_n (B,n,2).
+ * como_backproject_*  replaces  backprojection (como/geometry/camera.py:43-54, values only): P (n,3) = z (n) * ray(p (n,2) x/y; K (3,3)). */
+int como_cov_params_at(const void* cov, int Hc, int Wc, const void* coords, int coords_is_f64, int out_is_f64, int N, void* cn,
+                       void* E, int B, como_stream_t stream);
+int como_diag_cov_f32(const float* E, long total, float scale, float* out, como_stream_t stream);
+int como_diag_cov_f64(const double* E, long total, double scale, double* out, como_stream_t stream);
+int como_kernel_matrices_f32(const float* cov, int Hc, int Wc, const float* coords_m, int m, const float* coords_n, int n,
+                             float scale, float* cm, float* Em, float* cn, float* En, float* Kmm, float* Knm, float* Kdiag, int B,
+                             como_stream_t stream);
+int como_kernel_matrices_f64(const double* cov, int Hc, int Wc, const double* coords_m, int m, const double* coords_n, int n,
+                             double scale, double* cm, double* Em, double* cn, double* En, double* Kmm, double* Knm, double* Kdiag,
+                             int B, como_stream_t stream);
+int como_backproject_f32(const float* K, const float* p, const float* z, long n, float* P, como_stream_t stream);
+int como_backproject_f64(const double* K, const double* p, const double* z, long n, double* P, como_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Weighted normal equations of the depth distillation (python path: como/utils/lin_alg.py:82-87 lstsq_chol's A^T A / A^T b as
  * used by depth_cov/core/distill_depth.py:52-84, 122-148), float64, the rows read in place:
  *   r_i = y_i - sum_k A[i][k] c[k] (c may be NULL);  AtA (m,m) = sum_i w_i A_i A_i^T (both triangles);  Atb (m) = sum_i w_i A_i r_i;
