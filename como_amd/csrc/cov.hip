@@ -360,6 +360,52 @@ __global__ __launch_bounds__(256) void greedy_append_kernel(const float* coords_
   greedy_append_body<256>(blockIdx.y, blockIdx.x, threadIdx.x, coords_n, E_n, dom, Edom, L, obs_info, var, scale, k_ii, n, d, N);
 }
 
+// greedy_append + the greedy_scan of the NEXT pick in one launch (large domains): the thread that just downdated the variance of
+// its domain pixel applies the distance mask of the point being added (the one new point a scan after an append sees) and the
+// workgroup leaves its best candidate for greedy_pick2 -- the separate scan launch re-read var, dom and mask (6 us x 33 per
+// sampling pass at 640x480).  Same operations on the same values as the two kernels (the scan part keeps their contraction-off
+// arithmetic), same ordering rule, so the same picks.
+__global__ __launch_bounds__(256) void greedy_append_scan_kernel(const float* coords_n, const float* E_n, const float* __restrict__ dom,
+                                                                 const float* __restrict__ Edom, float* L, float* obs_info, float* var,
+                                                                 float scale, float k_ii, int n, int d, int N, uint8_t* mask,
+                                                                 float thresh_sq, float4* __restrict__ part) {
+  const int b = blockIdx.y, tid = threadIdx.x;
+  greedy_append_body<256>(b, blockIdx.x, tid, coords_n, E_n, dom, Edom, L, obs_info, var, scale, k_ii, n, d, N);
+  const int j = blockIdx.x * 256 + tid;
+  float best = -1.f, best_sd = 0.f;
+  int bi = 0x7fffffff;
+  if (j < d) {
+#pragma clang fp contract(off)
+    uint8_t* mb = mask + (long)b * d;
+    const float* db = dom + (long)b * d * 2;
+    const float* chosen = coords_n + ((long)b * n + N) * 2;
+    uint8_t ok = mb[j];
+    const float y = db[2 * j], x = db[2 * j + 1];
+    const float dy = chosen[0] - y, dx = chosen[1] - x;
+    const float d2 = dy * dy + dx * dx;
+    ok = ok && (d2 > thresh_sq);
+    mb[j] = ok;
+    float sd = sqrtf(var[(long)b * d + j]);                 // (this thread's own store in greedy_append_body)
+    if (sd != sd) sd = 0.f;
+    sd += 1e-10f;
+    const float cost = ok ? sd : 0.f;
+    if (cost > best) { best = cost; bi = j; best_sd = sd; }
+  }
+  __shared__ float sc[256], ss[256];
+  __shared__ int si[256];
+  sc[tid] = best; si[tid] = bi; ss[tid] = best_sd;
+  __syncthreads();
+  for (int h = 128; h > 0; h >>= 1) {
+    if (tid < h) {
+      const float c2 = sc[tid + h];
+      const int i2 = si[tid + h];
+      if (c2 > sc[tid] || (c2 == sc[tid] && i2 < si[tid])) { sc[tid] = c2; si[tid] = i2; ss[tid] = ss[tid + h]; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) part[(long)b * gridDim.x + blockIdx.x] = make_float4(sc[0], __int_as_float(si[0]), ss[0], 0.f);
+}
+
 // Small domains (d <= 1024: the thinning of a keyframe's tracked points, <= 64 candidates) -- the whole greedy loop in ONE launch of
 // one workgroup per batch item: the same two bodies step after step (pick, then append + pick per added point), workgroup barriers
 // where the launches were.  Bit-identical to the launch-per-step form (same code on the same data in the same order); 2 (n - m) + 1
@@ -438,10 +484,10 @@ int como_greedy_next_f32(const float* var, const float* coords_domain, const flo
   return COMO_OK;
 }
 
-int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,
-                         float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
-                         float k_ii, float dist_thresh_sq, int B, int n, int d, int m, float* sd_trace, void* scratch,
-                         como_stream_t stream) {
+static int greedy_loop_impl(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,
+                            float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
+                            float k_ii, float dist_thresh_sq, int B, int n, int d, int m, float* sd_trace, void* scratch,
+                            long scratch_floats, como_stream_t stream) {
   using namespace como;
   if (!coords_n || !E_n || !coord_vec_inds || !coords_domain || !E_domain || !L || !obs_info || !var || !mask || !best_idx ||
       !max_stdev || B <= 0 || n <= 0 || n > 64 || d <= 0 || m < 1 || m > n)
@@ -470,6 +516,21 @@ int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, cons
   }
   pick(0, m, m, sd_trace ? sd_trace + (long)m * B : max_stdev);
   COMO_CHECK_LAUNCH();
+  // append + the next pick's scan in one launch when the scratch holds one candidate per append workgroup (COMO_GREEDY_FUSED_SCAN=0:
+  // the separate scan, for A/B runs)
+  static const bool fused_scan = [] { const char* e = getenv("COMO_GREEDY_FUSED_SCAN"); return !e || e[0] != '0'; }();
+  const int G2 = (d + 255) / 256;
+  if (fused_scan && two_stage && scratch_floats >= 4L * B * G2) {
+    for (int i = m; i < n; ++i) {
+      hipLaunchKernelGGL(greedy_append_scan_kernel, dim3(G2, B), dim3(256), 0, s, coords_n, E_n, coords_domain, E_domain, L, obs_info,
+                         var, scale, k_ii, n, d, i, mask, dist_thresh_sq, (float4*)scratch);
+      COMO_CHECK_LAUNCH();
+      hipLaunchKernelGGL(greedy_pick2_kernel, dim3(B), dim3(256), 0, s, (const float4*)scratch, G2, coords_domain, E_domain, coords_n,
+                         E_n, coord_vec_inds, n, i + 1, best_idx, sd_trace ? sd_trace + (long)(i + 1) * B : max_stdev, d);
+      COMO_CHECK_LAUNCH();
+    }
+    return COMO_OK;
+  }
   for (int i = m; i < n; ++i) {
     hipLaunchKernelGGL(greedy_append_kernel, dim3((d + 255) / 256, B), dim3(256), 0, s, coords_n, E_n, coords_domain, E_domain, L,
                        obs_info, var, scale, k_ii, n, d, i);
@@ -478,6 +539,23 @@ int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, cons
     COMO_CHECK_LAUNCH();
   }
   return COMO_OK;
+}
+
+int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,
+                         float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
+                         float k_ii, float dist_thresh_sq, int B, int n, int d, int m, float* sd_trace, void* scratch,
+                         como_stream_t stream) {
+  return greedy_loop_impl(coords_n, E_n, coord_vec_inds, coords_domain, E_domain, L, obs_info, var, mask, best_idx, max_stdev, scale,
+                          k_ii, dist_thresh_sq, B, n, d, m, sd_trace, scratch, scratch ? 4096L * B : 0, stream);
+}
+
+int como_greedy_loop_ws_f32(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,
+                            float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
+                            float k_ii, float dist_thresh_sq, int B, int n, int d, int m, float* sd_trace, void* scratch,
+                            long scratch_floats, como_stream_t stream) {
+  if (scratch && scratch_floats < 4096L * B) return COMO_ERR_ARG;
+  return greedy_loop_impl(coords_n, E_n, coord_vec_inds, coords_domain, E_domain, L, obs_info, var, mask, best_idx, max_stdev, scale,
+                          k_ii, dist_thresh_sq, B, n, d, m, sd_trace, scratch, scratch_floats, stream);
 }
 
 }  // extern "C"

@@ -135,13 +135,14 @@ def greedy_loop(coord_vec_inds, coords_n_norm, E_n, coords_domain_norm, E_domain
     # depend on where it is cut -- with ONE read-back instead of one per step.  (Only the returned indices leave this function:
     # the packed copies above are NOT written back into strided arguments.)
     trace = torch.zeros((n + 1, b), device=dev, dtype=torch.float32) if terminate_early else None
-    scratch = torch.empty((b * 4096,), device=dev, dtype=torch.float32)      # per-slice argmax partials (two-stage pick)
-    rc = _lib.lib().como_greedy_loop_f32(coords_n_norm.data_ptr(), E_n.data_ptr(), coord_vec_inds.data_ptr(),
-                                         nxt.dom.data_ptr(), E_domain.data_ptr(), L.data_ptr(), obs_info.data_ptr(),
-                                         pred_var.data_ptr(), nxt.mask.data_ptr(), nxt.best.data_ptr(), nxt.sd.data_ptr(),
-                                         sv, k_ii, nxt.t2, b, n, nxt.d, m, _lib.ptr(trace), scratch.data_ptr(),
-                                         _lib.stream_ptr(dev))
-    _lib.check(rc, "como_greedy_loop_f32")
+    # per-workgroup argmax partials: one float4 per scan slice / per append workgroup (the append also scans: csrc/cov.hip)
+    scratch = torch.empty((b * max(4096, 4 * ((nxt.d + 255) // 256)),), device=dev, dtype=torch.float32)
+    rc = _lib.lib().como_greedy_loop_ws_f32(coords_n_norm.data_ptr(), E_n.data_ptr(), coord_vec_inds.data_ptr(),
+                                            nxt.dom.data_ptr(), E_domain.data_ptr(), L.data_ptr(), obs_info.data_ptr(),
+                                            pred_var.data_ptr(), nxt.mask.data_ptr(), nxt.best.data_ptr(), nxt.sd.data_ptr(),
+                                            sv, k_ii, nxt.t2, b, n, nxt.d, m, _lib.ptr(trace), scratch.data_ptr(), scratch.numel(),
+                                            _lib.stream_ptr(dev))
+    _lib.check(rc, "como_greedy_loop_ws_f32")
     if terminate_early:
         below = (trace[m:n] < max_stdev_thresh).all(dim=1).tolist()
         for k, stop in enumerate(below):

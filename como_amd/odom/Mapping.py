@@ -120,6 +120,11 @@ class Mapping:
     # (1.26 GB at 9 x 640x480) and all image stacks again.  The mirrors below follow the same window operations, so only the
     # NEW keyframe / frame is converted, once.
     _PIX_MIRRORED = ("Knm_Kmminv", "kf_img_and_grads", "recent_img_and_grads")
+    # the large per-frame stacks live in sliding double-capacity buffers (`_cat_sliding`): a window operation writes the NEW frame
+    # only -- `torch.cat` of the kept frames copied 59 MB (images of 8 keyframes) to 177 MB (24 one-way frames) per stack, on every
+    # keyframe / one-way frame
+    _SLIDING = {"Knm_Kmminv": "num_keyframes", "kf_img_and_grads": "num_keyframes", "rgb": "num_keyframes",
+                "cov_params_img": "num_keyframes", "recent_img_and_grads": "num_one_way_frames"}
 
     def _cat(self, name, new_var, i):
         old = getattr(self, name)
@@ -127,24 +132,22 @@ class Mapping:
             pix = name + "_pix"
             if getattr(self, pix, None) is None or (old.numel() == 0 and old.dim() == 1):
                 setattr(self, pix, torch.empty((0), device=new_var.device, dtype=self.pix_dtype))
-            if name == "Knm_Kmminv":
-                # (157 MB per keyframe: converted by the copy into the window buffer itself, not into a temporary first)
-                self._cat_sliding(pix, getattr(self, pix), new_var, i, dtype=self.pix_dtype)
-            else:
-                self._cat(pix, new_var.to(self.pix_dtype), i)
-        if name.startswith("Knm_Kmminv") and new_var.is_cuda:
-            return self._cat_sliding(name, old, new_var, i)
+            # (converted by the copy into the window buffer itself, not into a temporary first: 157 MB per keyframe for K~)
+            self._cat_sliding(pix, getattr(self, pix), new_var, i, dtype=self.pix_dtype, cap=self.cfg["graph"][self._SLIDING[name]])
+        base = name[:-4] if name.endswith("_pix") else name
+        if base in self._SLIDING and new_var.is_cuda and new_var.dim() > 1:
+            return self._cat_sliding(name, old, new_var, i, cap=self.cfg["graph"][self._SLIDING[base]])
         setattr(self, name, new_var.clone() if old.numel() == 0 and old.dim() == 1 else torch.cat((old[i:, ...], new_var), dim=0))
 
-    def _cat_sliding(self, name, old, new_var, i, dtype=None):
+    def _cat_sliding(self, name, old, new_var, i, dtype=None, cap=None):
         """The dense predictors K~ are 157 MB per keyframe at 640x480 (float64): `torch.cat` of a growing window asks the allocator
         for a new, larger block on every keyframe (a hipMalloc of > 1 GB: ~12 ms each while the window fills), and copying the kept
         keyframes into a second buffer moved 1.3 GB (+ the pixel-type mirror) per keyframe (0.55 ms).  ONE buffer of twice the
         window's capacity instead: the window is a view [start, start + count) that slides -- the kept keyframes stay where they
         are, the new one is written behind them -- and is moved back to the front when it reaches the end (once per
         `num_keyframes` insertions)."""
-        cap = self.cfg["graph"]["num_keyframes"]
-        store = self.__dict__.setdefault("_kt_pp", {})              # per window tensor (K~ and its pixel-type mirror)
+        cap = cap or self.cfg["graph"]["num_keyframes"]
+        store = self.__dict__.setdefault("_kt_pp", {})              # per window tensor (e.g. K~ and its pixel-type mirror)
         st = store.get(name)
         n_new = new_var.shape[0]
         dtype = dtype or new_var.dtype                              # (the window's element type: the copy below converts)
@@ -158,10 +161,16 @@ class Mapping:
         k = keep.shape[0]
         if k + n_new > cap:
             raise RuntimeError("como_amd Mapping: more keyframes than graph.num_keyframes")
-        in_place = (not empty and old.shape[0] == st["count"] and old.stride() == buf.stride() and
-                    old.data_ptr() == buf[st["start"]].data_ptr())
+        # `old` is the view handed out last time, or a suffix / sub-range of it (prune_one_way slices the one-way stacks): any view
+        # of whole slots of this buffer stays where it is
+        in_place = False
+        if (not empty and old.dtype == buf.dtype and old.stride() == buf.stride() and old.device == buf.device and
+                old.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr()):
+            slot = buf.stride(0) * buf.element_size()
+            rel = old.data_ptr() - buf.data_ptr()
+            in_place = slot > 0 and rel >= 0 and rel % slot == 0 and rel // slot + old.shape[0] <= 2 * cap
         if in_place:
-            s0 = st["start"] + st["count"] - k                      # the kept keyframes stay where they are
+            s0 = rel // slot + old.shape[0] - k                     # the kept frames stay where they are
             if s0 + k + n_new > 2 * cap:                            # (then s0 > cap >= k: source and destination are disjoint)
                 if k:
                     buf[:k].copy_(buf[s0:s0 + k])

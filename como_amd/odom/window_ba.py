@@ -113,8 +113,17 @@ class WindowBA:
             t = state.get(name + "_pix")
             return t if t is not None and t.dtype == pix_dtype and t.shape == state[name].shape else state[name]
         kf_img = pix("kf_img_and_grads")
-        imgs = kf_img if not nrec else torch.cat((kf_img, pix("recent_img_and_grads").to(kf_img.dtype)))
-        self.img = imgs.to(pix_dtype).contiguous()
+        rec_img = pix("recent_img_and_grads") if nrec else None
+        self._rec_img, self._rec_img_off = None, None
+        if (nrec and rec_img.dtype == pix_dtype and kf_img.dtype == pix_dtype and rec_img.is_contiguous() and kf_img.is_contiguous() and
+                rec_img.device == kf_img.device and (rec_img.data_ptr() - kf_img.data_ptr()) % kf_img.element_size() == 0):
+            # both stacks stay where they are (the sequential loop's sliding buffers): the one-way targets are addressed relative to
+            # the keyframe stack by their element offset, whatever its sign -- no 122 MB concatenation per rebuild
+            self.img, self._rec_img = kf_img, rec_img
+            self._rec_img_off = (rec_img.data_ptr() - kf_img.data_ptr()) // kf_img.element_size()
+        else:
+            imgs = kf_img if not nrec else torch.cat((kf_img, rec_img.to(kf_img.dtype)))
+            self.img = imgs.to(pix_dtype).contiguous()
         self.Kt = pix("Knm_Kmminv").to(pix_dtype).reshape(B, self.Himg * self.Wimg, self.m).contiguous()
         self.K_pix = self.intrinsics[0].to(pix_dtype).contiguous()
         self.median_depths = carve1(self.state_flat, o_med, (B,))
@@ -264,7 +273,8 @@ class WindowBA:
         self.kf_pairs, self.one_way_pairs = pairs
         stack = 3 * self.channels * self.Himg * self.Wimg          # one frame's [I | dI/dx | dI/dy] stack
         self.table = photo.PairTable(ref + ow_kf, tgt + ow_t, [False] * len(ref) + [True] * len(ow_kf), B, self.kf_inds,
-                                     self.recent_inds, self.landmark_inds, stack, B * stack, dev, channels=self.channels)
+                                     self.recent_inds, self.landmark_inds, stack,
+                                     B * stack if self._rec_img_off is None else self._rec_img_off, dev, channels=self.channels)
 
     def _prepare_fused(self):
         B, m, L, F, dev, p = self.B, self.m, self.L, self.F, self.dev, self.pix_dtype
@@ -398,6 +408,7 @@ class WindowBA:
                                                    w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"],
                                                    hists=w["hist_dr"], ws=w["dr_ws"], part=part, compact=True)
         fork = self.shard is None and self.overlap_priors
+        late_side = False
         fm = lambda part: full_image_median(w["px_logzm"], self.Kt, w["med3_full"], w["dr_ws"], hists=w["hist_full"], part=part)
         if self.shard is not None:
             return self._linearize_sharded(dr)
@@ -411,11 +422,7 @@ class WindowBA:
             ev = torch.cuda.Event()
             ev.record(main)
             Pwn, dT, uvec, med, _ = dr("points")
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                fm("all")
-                if self.with_priors:
-                    _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
+            late_side = True                                 # (the branch is submitted AFTER the photometric chain, below)
         else:
             Pwn, dT, uvec, med, _ = dr("points" if fork else "all")
         if fork and not self.full_median:
@@ -430,11 +437,21 @@ class WindowBA:
                 dr("median")
                 if self.with_priors:
                     _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
+        # (eager launches execute in submission order whenever a kernel fills the chip: submitted between the dense reference and
+        # the photometric chain, the band kernel + its select passes + the priors -- 165 us at 9 x 640x480 -- sat ON the critical
+        # path of every eager iteration of the sequential loop although they are a side branch; submitted after the chain they run
+        # beside / behind it and only the final pack waits for them.  The captured graph has the same two branches either way.)
         photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=Pwn, vals=self.vals_n,
                                     dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],
                                     img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=None, g=None,
                                     err_out=None, sigma_out=self.sigma, events=self.events, zeroed_hists=w["hist_ba"],
                                     ws=w["ba_ws"], sysfix=self.sysfix, fix_plane=self.fix_plane, D=self.dim)
+        if late_side:
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                fm("all")
+                if self.with_priors:
+                    _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
         if fork:
             torch.cuda.current_stream(dev).wait_stream(side)
         else:

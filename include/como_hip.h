@@ -306,6 +306,13 @@ int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, cons
                          float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
                          float k_ii, float dist_thresh_sq, int B, int n, int d, int m, float* sd_trace, void* scratch,
                          como_stream_t stream);
+/* como_greedy_loop_ws_f32: the same with the scratch size stated (floats, >= 4096 B): with >= 4 B ceil(d / 256) floats the
+ *   append launch of a step also does the scan of the next pick (mask of the point being added, best candidate per workgroup), so
+ *   a step is two launches (append + scan, pick) instead of three; same picks. */
+int como_greedy_loop_ws_f32(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,
+                            float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
+                            float k_ii, float dist_thresh_sq, int B, int n, int d, int m, float* sd_trace, void* scratch,
+                            long scratch_floats, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense reference points in factored form (python path: backend/sparse_map.py:184-230 backproject_cloud +

@@ -90,6 +90,7 @@ def main():
         timed(odo.mapping, "add_one_way_frame", "add_one_way_frame")
         timed(odo.mapping, "attempt_two_frame_init", "two_frame_init_attempt")
     kinds = []
+    t_frame = []                                             # (no extra synchronisation: every tracked frame reads its result back)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     t_first_tracked = None
@@ -124,6 +125,7 @@ def main():
             from torch.profiler import ProfilerActivity, profile
             tprof = profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True)
             tprof.__enter__()
+        t_frame.append(time.perf_counter())
         kinds.append(odo.iter(1.0 + k, rgbs[k]))
         if t_first_tracked is None and odo.mapping.is_init:
             torch.cuda.synchronize()
@@ -181,6 +183,13 @@ def main():
            "landmarks": int(odo.mapping.P_m.shape[0]), "window_full": bool(odo.mapping.window_full),
            "parts_ms": {k: {"mean": 1e3 * sum(v) / len(v), "max": 1e3 * max(v), "n": len(v)} for k, v in parts.items()},
            "traj_scale": float(s), "traj_rmse_after_scale": float(((s * est - gt) ** 2).sum(1).mean().sqrt())}
+    # wall time from the start of a frame to the start of the next, by what the frame asked the mapper for (the tracker's read-back
+    # of frame k + 1 waits for the mapping work of frame k: the cost of a request shows up in the frame that issued it and the next)
+    t_frame.append(t1)
+    by_kind = {}
+    for k in range(t_first_tracked[0] + 1, args.frames):
+        by_kind.setdefault(str(kinds[k]), []).append(1e3 * (t_frame[k + 1] - t_frame[k]))
+    out["frame_ms_by_request"] = {k: {"mean": sum(v) / len(v), "n": len(v)} for k, v in by_kind.items()}
     if args.save_traj:
         from como_amd.utils.io import save_traj
         save_traj(args.save_traj, odo.timestamps, torch.cat([p.double().cpu() for p in odo.est_poses]))
