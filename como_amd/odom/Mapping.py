@@ -415,11 +415,12 @@ class Mapping:
             alive = old[i:, :].any(dim=0)                          # landmarks still seen by a keyframe that stays
             tracked = torch.zeros_like(old[0, :])
             tracked[torch.nonzero(old[-1, :])[:, 0]] = corr_mask   # the last keyframe's landmarks that were tracked on
-            kept = torch.cat((old[i:, alive], tracked[None, alive]), dim=0)
+            ai = torch.nonzero(alive)[:, 0]                        # ONE index list for the three selections (each boolean mask = a nonzero + a sync)
+            kept = torch.cat((old[i:, :].index_select(1, ai), tracked.index_select(0, ai)[None]), dim=0)
             fresh = torch.zeros((kept.shape[0], n_new), device=self.device, dtype=torch.bool)
             fresh[-1, :] = True
             self.correspondence_mask = torch.cat((kept, fresh), dim=1)
-            self.P_m = torch.cat((self.P_m[alive, :], P), dim=0)
+            self.P_m = torch.cat((self.P_m.index_select(0, ai), P), dim=0)
         if self.window_full:
             # landmarks of the (new) oldest keyframe carry what left the window: pin them
             self.P_m_anchors = self.P_m[self.correspondence_mask[0, :], :]

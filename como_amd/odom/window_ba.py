@@ -43,6 +43,19 @@ _REUSE_TOPOLOGY = __import__("os").environ.get("COMO_BA_REUSE", "1") != "0"     
 _REUSE_WORKSPACES = __import__("os").environ.get("COMO_BA_REUSE_WS", "1") != "0"  # (measurement switch)
 
 
+_ARANGE = {}
+
+
+def _ar(n, dev, dtype=torch.long):
+    """torch.arange(n) as a READ-ONLY view of one cached ramp per (device, dtype): the window is rebuilt on every keyframe and
+    one-way frame of the sequential loop, each rebuild with half a dozen tiny arange launches."""
+    key = (str(dev), dtype)
+    t = _ARANGE.get(key)
+    if t is None or t.shape[0] < n:
+        t = _ARANGE[key] = torch.arange(max(4096, 2 * n), device=dev, dtype=dtype)
+    return t[:n]
+
+
 class WindowBA:
     def __init__(self, state, cfg=None, pix_dtype=torch.float32, window_full=True, shard=None, fused=True, prev=None):
         """state: dict as produced by como_amd.synth.make_window (plus K_mm_inv / L_mm / Knm_Kmminv).
@@ -147,7 +160,7 @@ class WindowBA:
         Returns (remap, landmark_ids (B*m,2) as the reference's list, lm_of (B,m) landmark index per slot, ascending)."""
         B = mask.shape[0]
         lm_of = torch.argsort((~mask).to(torch.uint8), dim=1, stable=True)[:, :m].contiguous()     # the m True columns, in order
-        rows = torch.arange(B, device=mask.device).repeat_interleave(m)
+        rows = _ar(B, mask.device).repeat_interleave(m)
         landmark_ids = torch.stack((rows, lm_of.reshape(-1)), dim=1)
 
         def remap(variable, default_val=-1):           # variable (B,L,...) -> (B,m,...); every slot is filled
@@ -206,19 +219,19 @@ class WindowBA:
         self.point_inds = lin_sys.landmark_to_batched_3d_point_inds(landmark_ids, B)
         L = self.P_m.shape[0]
         self.L = L
-        self.kf_inds = torch.arange(8 * B, device=dev).reshape(B, 8)
+        self.kf_inds = _ar(8 * B, dev).reshape(B, 8)
         # index lists of the oldest keyframe's landmarks (their anchors, Mapping.py:884-898): precomputed -- boolean-mask
         # indexing inside the iteration would synchronise with the host (and cannot be captured in a hipGraph)
         self.fix_idx = lm_of[0]
         self.lm_ids = (self.point_inds[:, ::3] // 3).to(torch.int32).contiguous()          # (B,m)
         first_obs = torch.argmax(self.correspondence_mask.int(), dim=0)                    # first observer keyframe
         fom = torch.zeros_like(self.correspondence_mask)
-        fom[first_obs, torch.arange(L, device=dev)] = True
+        fom[first_obs, _ar(L, dev)] = True
         self.first_obs_mask = self.remap(fom, False)
         slot_of = torch.full((B, L), -1, device=dev, dtype=torch.int32)
-        slot_of.scatter_(1, self.lm_ids.long(), torch.arange(m, device=dev, dtype=torch.int32)[None].expand(B, m).contiguous())
+        slot_of.scatter_(1, self.lm_ids.long(), _ar(m, dev, torch.int32)[None].expand(B, m).contiguous())
         self.first_frame = first_obs.to(torch.int32).contiguous()
-        self.first_slot = slot_of[first_obs, torch.arange(L, device=dev)].contiguous()
+        self.first_slot = slot_of[first_obs, _ar(L, dev)].contiguous()
         self._finish_topology()
         self._inherit = None
 
@@ -227,12 +240,12 @@ class WindowBA:
         B, dev, L = self.B, self.dev, self.L
         nrec = self.F - B
         self.dim = 8 * B + 8 * nrec + 3 * L
-        self.recent_inds = (torch.arange(8 * nrec, device=dev).reshape(nrec, 8) + 8 * B) if nrec else \
+        self.recent_inds = _ar(8 * self.F, dev)[8 * B:].reshape(nrec, 8) if nrec else \
             torch.empty((0), device=dev, dtype=torch.long)
-        self.frame_inds = torch.arange(8 * self.F, device=dev).reshape(self.F, 8).contiguous()
+        self.frame_inds = _ar(8 * self.F, dev).reshape(self.F, 8)
         self.lm_start = 8 * B + 8 * nrec
         self.landmark_inds = (self.point_inds + self.lm_start).contiguous()
-        self.landmark_inds_flat = torch.arange(3 * L, device=dev).reshape(L, 3) + self.lm_start
+        self.landmark_inds_flat = _ar(self.lm_start + 3 * L, dev)[self.lm_start:].reshape(L, 3)
         self.fix_inds_flat = self.landmark_inds_flat[self.fix_idx].flatten().contiguous()
         pc = self.cfg["photo_construction"]
         if self.fused and pc.get("radius_thresh", 0.0) > 0.0 and pc.get("degrees_thresh", 0.0) > 0.0:
