@@ -40,16 +40,18 @@ class DepthCovModule:
     def to(self, *a, **k):
         return self
 
-    def forward(self, rgb):
-        """(N,3,H,W) float in [0,1] -> list of 4 covariance images (N,4,h,w), coarse to fine (DepthCovModule.py:80-87)."""
-        return [unet.cov_activation(f) for f in self.net(rgb)]
+    def forward(self, rgb, finest_only=False):
+        """(N,3,H,W) float in [0,1] -> list of 4 covariance images (N,4,h,w), coarse to fine (DepthCovModule.py:80-87).
+        finest_only: only the last entry is evaluated (the others are None): `Mapping.run_model` reads `[-1]` alone, the three
+        coarser heads (a 1x1 convolution + the activation each) are dead work on that path."""
+        return [None if f is None else unet.cov_activation(f) for f in self.net(rgb, finest_only=finest_only)]
 
     __call__ = forward
 
-    def forward_graphed(self, rgb):
+    def forward_graphed(self, rgb, finest_only=False):
         """Same result through a hipGraph captured once per input shape (~95 launches replayed without the host in the
         loop).  The returned tensors are the graph's static outputs: consume them before the next call."""
-        key = (tuple(rgb.shape), str(rgb.device))
+        key = (tuple(rgb.shape), str(rgb.device), bool(finest_only))
         ent = self._graphs.get(key) if hasattr(self, "_graphs") else None
         if ent is None:
             if not hasattr(self, "_graphs"):
@@ -59,15 +61,15 @@ class DepthCovModule:
             side = torch.cuda.Stream(device=rgb.device)
             side.wait_stream(torch.cuda.current_stream(rgb.device))
             with torch.cuda.stream(side):
-                self.forward(x)
+                self.forward(x, finest_only)
             torch.cuda.current_stream(rgb.device).wait_stream(side)
             torch.cuda.synchronize(rgb.device)
-            g, outs = _lib.capture_graph(lambda: self.forward(x), rgb.device)     # (on failure the eager path keeps working)
+            g, outs = _lib.capture_graph(lambda: self.forward(x, finest_only), rgb.device)     # (on failure the eager path keeps working)
             ent = (g, x, outs if g is not None else None)
             self._graphs[key] = ent
         g, x, outs = ent
         if g is None:
-            return self.forward(rgb)
+            return self.forward(rgb, finest_only)
         x.copy_(rgb)
         g.replay()
         return outs
@@ -80,7 +82,7 @@ def run_model(model, rgb, network_size=(192, 256), dtype=torch.float64, graphed=
     """Mapping.run_model (Mapping.py:409-428): antialiased resize to the network size, finest covariance level, cast to
     the mapping dtype, antialiased resize back to the image size."""
     rgb_r = unet.resize_aa(rgb.float(), network_size)
-    cov = (model.forward_graphed(rgb_r) if graphed else model(rgb_r))[-1].to(dtype)
+    cov = (model.forward_graphed(rgb_r, finest_only=True) if graphed else model(rgb_r, finest_only=True))[-1].to(dtype)
     if OUTPUT_HOOK is not None:
         cov = OUTPUT_HOOK(cov)
     return unet.resize_aa(cov, rgb.shape[-2:])

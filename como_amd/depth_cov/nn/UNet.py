@@ -204,25 +204,51 @@ class UNet:
                         for i in range(num_levels - 1)]
         self.feature_act = feature_act
 
-    def forward(self, x):
+    def forward(self, x, finest_only=False):
+        """finest_only: evaluate only the LAST (finest) feature head -- the one level the odometry path reads
+        (Mapping.run_model: `model(rgb)[-1]`); the other entries of the returned list are None."""
         _lib.require_cuda(x)
         x = normalize_imagenet(x.float().contiguous())
         # GroupNorm statistics of all 2 * (1 + 2 * levels) normalisations: one zero-fill, accumulated by the convolutions
         nres = 1 + 2 * self.num_levels
-        sums = torch.zeros((nres, 2, 32, x.shape[0], GN_GROUPS, 2), dtype=torch.float64, device=x.device)   # 32 slots
-        enc = [self.base(x, sums[0])]
-        for i in range(self.num_levels):
-            enc.append(self.down[i](maxpool2(enc[-1]), sums[1 + i]))        # DownConv (layers.py:30-43)
+        N = x.shape[0]
+        sums = torch.zeros((nres, 2, 32, N, GN_GROUPS, 2), dtype=torch.float64, device=x.device)   # 32 slots
+        # One image: an encoder block writes its output straight into the second half of the decoder's concatenation buffer of
+        # its level (channels [c, 2c) of one image are one contiguous block, so the pooling that follows reads it in place)
+        # instead of being copied there later.
+        direct = N == 1
+        cats = [None] * self.num_levels
+        enc = []
+        blocks = [self.base] + self.down
+        cur = x
+        for i in range(self.num_levels + 1):
+            blk = blocks[i]
+            c = blk.conv3.cout
+            H, W = cur.shape[-2:]
+            if direct and i < self.num_levels:
+                cats[i] = torch.empty((N, 2 * c, H, W), dtype=torch.float32, device=x.device)
+                blk(cur, sums[i], out=cats[i], coff=c)
+                e = cats[i][:, c:]
+            else:
+                e = blk(cur, sums[i])
+            enc.append(e)
+            if i < self.num_levels:
+                cur = maxpool2(e)                                            # DownConv (layers.py:30-43)
         out = []
         dec = enc[-1]
         for i in range(self.num_levels - 1, -1, -1):                         # UpConv (layers.py:46-75)
             skip = enc[i]
-            N, c, H, W = skip.shape
-            cat = torch.empty((N, 2 * c, H, W), dtype=torch.float32, device=x.device)
+            _, c, H, W = skip.shape
+            cat = cats[i]
+            if cat is None:
+                cat = torch.empty((N, 2 * c, H, W), dtype=torch.float32, device=x.device)
+                cat[:, c:].copy_(skip)
             _conv3_any(self.up_conv[i], upsample2x(dec), out=cat, coff=0)
-            cat[:, c:].copy_(skip)
             dec = self.up_block[i](cat, sums[1 + self.num_levels + i])
             if i < self.num_levels - 1:
+                if finest_only and i > 0:
+                    out.append(None)
+                    continue
                 f = self.feature[i](dec)
                 out.append(self.feature_act(f) if self.feature_act else f)
         return out

@@ -31,6 +31,19 @@ with torch.cuda.stream(st):
         g.replay()
     st.synchronize()
 print(f"graph: {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per forward")
+# the form Mapping.run_model uses: only the finest covariance head (the level the odometry path reads)
+with torch.cuda.stream(st):
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g2, stream=st):
+        y2 = model(x, finest_only=True)
+    g2.replay()
+    st.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        g2.replay()
+    st.synchronize()
+print(f"graph, finest head only (run_model): {(time.perf_counter() - t0) / 20 * 1e3:.3f} ms per forward; "
+      f"equal to the full forward's finest level: {bool(torch.equal(y[-1], y2[-1]))}")
 if "--layers" in sys.argv:
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CUDA]) as prof:
