@@ -20,6 +20,19 @@ constexpr int SEL_CAND_WORDS = 2 + 2 * SEL_CAND_CAP;   // packed candidate list 
 __device__ __forceinline__ uint32_t* sel_cand_count(uint32_t* h) { return h + 4 * SEL_BINS + 1024; }
 __device__ __forceinline__ uint32_t* sel_cand_done(uint32_t* h) { return h + 4 * SEL_BINS + 1025; }
 __device__ __forceinline__ uint64_t* sel_cand_keys(uint32_t* h) { return reinterpret_cast<uint64_t*>(h + 5 * SEL_BINS + 1024); }
+// running maximum of the candidate keys and of their complements (slot 4, words 1026..1029: both start from the cleared scratch's
+// zero): when the list overflows but max == min -- massive ties on ONE value, the only way thousands of residuals share 33 leading
+// bits in practice (saturated / identical pixels) -- the candidates are `count` copies of that key and still representable
+__device__ __forceinline__ unsigned long long* sel_cand_max(uint32_t* h) { return reinterpret_cast<unsigned long long*>(h + 4 * SEL_BINS + 1026); }
+__device__ __forceinline__ unsigned long long* sel_cand_maxnot(uint32_t* h) { return reinterpret_cast<unsigned long long*>(h + 4 * SEL_BINS + 1028); }
+__device__ __forceinline__ void sel_cand_add(uint32_t* hists, uint64_t key) {
+  const uint32_t slot = atomicAdd(sel_cand_count(hists), 1u);
+  if (slot < (uint32_t)SEL_CAND_CAP) sel_cand_keys(hists)[slot] = key;
+  if (slot >= (uint32_t)SEL_CAND_CAP - 1) {             // (only lists that fill up pay for the two extra atomics; the entry that fills
+    atomicMax(sel_cand_max(hists), (unsigned long long)key);          //  the last slot and every later one are folded in, the
+    atomicMax(sel_cand_maxnot(hists), ~(unsigned long long)key);      //  stored ones are compared by the pack kernel)
+  }
+}
 
 // NTHR = 256, or 1024 for long slices: the flush at the end of a workgroup (up to 2048 same-address global atomics) caps the
 // number of workgroups at one per compute unit, and four waves per compute unit keep too few loads in flight to stream
@@ -101,10 +114,7 @@ __global__ __launch_bounds__(NTHR) void select_hist_kernel(const T* __restrict__
             const KeyT key = abs_key((T)e[k]);
             if (sel_match<KeyT>(key, prefix, pass)) {
               atomicAdd(&lh[sel_digit<KeyT>(key, pass)], 1u);
-              if (collect) {
-                const uint32_t slot = atomicAdd(sel_cand_count(hists), 1u);
-                if (slot < (uint32_t)SEL_CAND_CAP) sel_cand_keys(hists)[slot] = (uint64_t)key;
-              }
+              if (collect) sel_cand_add(hists, (uint64_t)key);
             }
           }
         }
@@ -132,10 +142,7 @@ __global__ __launch_bounds__(NTHR) void select_hist_kernel(const T* __restrict__
           if (sel_match<KeyT>(key, prefix, pass)) {
             atomicAdd(&lh[sel_digit<KeyT>(key, pass)], 1u);
             if constexpr (sizeof(T) == 8) {
-              if (collect) {
-                const uint32_t slot = atomicAdd(sel_cand_count(hists), 1u);
-                if (slot < (uint32_t)SEL_CAND_CAP) sel_cand_keys(hists)[slot] = (uint64_t)key;
-              }
+              if (collect) sel_cand_add(hists, (uint64_t)key);
             }
           }
         }
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void select_tail_kernel(uint32_t* __restrict__
   __syncthreads();
   // clean the scratch: consumers scan whole slots
   for (int i = tid; i < 1024; i += 256) hists[5 * SEL_BINS + 1024 + i] = 0u;
-  if (tid == 0) *sel_cand_count(hists) = 0u;
+  if (tid == 0) { *sel_cand_count(hists) = 0u; *sel_cand_max(hists) = 0ull; *sel_cand_maxnot(hists) = 0ull; }
   KeyT prefix; uint32_t k_rem, nv;
   sel_resolve<KeyT>(hists, 4, &sc, prefix, k_rem, nv);
   for (int p = 4; p < 6; ++p) {
@@ -221,20 +228,36 @@ __global__ __launch_bounds__(256) void select_tail_kernel(uint32_t* __restrict__
 //   (the caller all-gathers the records: (world, nseg, SEL_CAND_WORDS) words)
 //   select_cand_merge_kernel: every rank builds, from the union of all ranks' candidates, the histograms of digits 3, 4, 5 that
 //                             three more all-reduced passes would have produced -- consumers resolve exactly as before.
-// A rank with more than 512 candidates (more than 512 keys sharing 33 leading bits: constant images, i.e. sigma = 0 and a
-// non-finite system in the reference as well) cannot be represented: the merge then clears the digit-0 histogram -- zero valid
-// keys: the median reads NaN, the robust scale 0, the system is poisoned and the factorisation reports it.
+// A rank with more than 512 candidates travels as (count, key) when they are all ONE value (massive ties: saturated / identical
+// pixels -- the case that produces thousands of keys with 33 equal leading bits); more than 512 candidates of DIFFERENT values
+// cannot be represented: the merge then clears the digit-0 histogram -- zero valid keys: the median reads NaN, the robust scale
+// 0, the system is poisoned and the factorisation reports it.
 __global__ __launch_bounds__(256) void select_cand_pack_kernel(uint32_t* __restrict__ hists, uint32_t* __restrict__ out) {
   hists += (long)blockIdx.x * 6 * SEL_BINS;
   out += (long)blockIdx.x * SEL_CAND_WORDS;
   const int tid = threadIdx.x;
   const uint32_t cnt = *sel_cand_count(hists);
   const uint32_t* kw = hists + 5 * SEL_BINS + 1024;
+  // an overflowing list whose keys are all ONE value (stored ones included) travels as (count, that key): out[1] = 1
+  __shared__ uint32_t differ;
+  if (tid == 0) differ = 0u;
+  __syncthreads();
+  const unsigned long long kmax = *sel_cand_max(hists), kmin = ~*sel_cand_maxnot(hists);
+  if (cnt > (uint32_t)SEL_CAND_CAP) {
+    if (kmax != kmin) differ = 1u;
+    for (int i = tid; i < SEL_CAND_CAP; i += 256)
+      if (sel_cand_keys(hists)[i] != kmax) differ = 1u;
+  }
+  __syncthreads();
+  const bool uniform = cnt > (uint32_t)SEL_CAND_CAP && !differ;
   for (int i = tid; i < 2 * SEL_CAND_CAP; i += 256) out[2 + i] = (i < 2 * (int)min(cnt, (uint32_t)SEL_CAND_CAP)) ? kw[i] : 0u;
   __syncthreads();
   for (int i = tid; i < 1024; i += 256) hists[5 * SEL_BINS + 1024 + i] = 0u;
   for (int i = tid; i < SEL_BINS; i += 256) hists[3 * SEL_BINS + i] = 0u;
-  if (tid == 0) { out[0] = cnt; out[1] = 0u; *sel_cand_count(hists) = 0u; }
+  if (tid == 0) {
+    out[0] = cnt; out[1] = uniform ? 1u : 0u; *sel_cand_count(hists) = 0u;
+    *sel_cand_max(hists) = 0ull; *sel_cand_maxnot(hists) = 0ull;
+  }
 }
 
 __global__ __launch_bounds__(256) void select_cand_merge_kernel(uint32_t* __restrict__ hists, const uint32_t* __restrict__ gathered,
@@ -249,8 +272,10 @@ __global__ __launch_bounds__(256) void select_cand_merge_kernel(uint32_t* __rest
   hists += (long)seg * 6 * SEL_BINS;
   if (tid == 0) over = 0u;
   __syncthreads();
-  for (int r = tid; r < world; r += 256)
-    if (gathered[((long)r * nseg_total + seg0 + seg) * SEL_CAND_WORDS] > (uint32_t)SEL_CAND_CAP) over = 1u;
+  for (int r = tid; r < world; r += 256) {
+    const uint32_t* rec = gathered + ((long)r * nseg_total + seg0 + seg) * SEL_CAND_WORDS;
+    if (rec[0] > (uint32_t)SEL_CAND_CAP && rec[1] != 1u) over = 1u;      // (rec[1] == 1: rec[0] copies of ONE key)
+  }
   __syncthreads();
   if (over) {                                            // not representable: zero valid keys (see above)
     for (int b = tid; b < SEL_BINS; b += 256) hists[b] = 0u;
@@ -266,6 +291,10 @@ __global__ __launch_bounds__(256) void select_cand_merge_kernel(uint32_t* __rest
       const uint32_t* rec = gathered + ((long)r * nseg_total + seg0 + seg) * SEL_CAND_WORDS;
       const uint32_t cnt = rec[0];
       const KeyT* keys = reinterpret_cast<const KeyT*>(rec + 2);
+      if (rec[1] == 1u) {                                 // an overflowing list of one value
+        if (tid == 0 && sel_match<KeyT>(keys[0], prefix, p)) atomicAdd(&lh[sel_digit<KeyT>(keys[0], p)], cnt);
+        continue;
+      }
       for (uint32_t i = tid; i < cnt; i += 256)
         if (sel_match<KeyT>(keys[i], prefix, p)) atomicAdd(&lh[sel_digit<KeyT>(keys[i], p)], 1u);
     }

@@ -31,9 +31,10 @@ if has bench; then
 fi
 if has aux; then
   # dense solve: graph replay timings (persistent / multi-launch), in-kernel stamps of the chain workgroup, the hand-off protocols
-  { echo "== default (persistent one-launch solver up to D = 1023)"; timeout 200 python scripts/chol_time.py 200 760 1000 1240 2680;
-    echo "== COMO_CHOLP=0 (multi-launch solver)"; COMO_CHOLP=0 timeout 200 python scripts/chol_time.py 200 760 1000; } > $OUT/chol_time.txt 2>&1
-  for D in 760 1000 200; do timeout 60 scripts/micro/bin/cholp_stamps $D; done > $OUT/cholp_stamps.txt 2>&1
+  { echo "== default (persistent one-launch solver up to 34 column pairs, D <= 2175; the multi-launch solver beyond)"; timeout 200 python scripts/chol_time.py 200 760 1000 1240 1300 1500 2000 2680;
+    echo "== COMO_CHOLP_MAX_NP=42 (persistent at D = 2680 too: slower than the multi-launch solver there)"; COMO_CHOLP_MAX_NP=42 timeout 200 python scripts/chol_time.py 2680;
+    echo "== COMO_CHOLP=0 (multi-launch solver)"; COMO_CHOLP=0 timeout 200 python scripts/chol_time.py 200 760 1000 1240 1300 1500 2000; } > $OUT/chol_time.txt 2>&1
+  for D in 760 1000 200 1300; do timeout 60 scripts/micro/bin/cholp_stamps $D; done > $OUT/cholp_stamps.txt 2>&1
   timeout 120 scripts/micro/bin/handoff > $OUT/handoff.txt 2>&1
   rm -rf /tmp/p_chol; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_chol -- python scripts/chol_time.py 760 > $OUT/chol_stats_run.log 2>&1
   cp $(find /tmp/p_chol -name "*kernel_stats.csv" | head -1) $OUT/chol_kernel_stats.csv
@@ -70,6 +71,7 @@ if has odo; then
   python scripts/odometry_timeline.py /tmp/p_odo $OUT/odometry_timeline.txt > /dev/null 2>&1
   F=$(find /tmp/p_odo -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $OUT/odometry_kernel_stats.csv
   COMO_ODO_BREAKDOWN=0 timeout 300 python scripts/gpu_odometry_bench.py --frames 100 > $OUT/odometry_loop.json 2>> $OUT/odo.err
+  timeout 300 python scripts/kf_insert_profile.py --out $OUT/kf_insert.txt > /dev/null 2>> $OUT/odo.err
   COMO_ODO_BREAKDOWN=0 timeout 300 python scripts/gpu_odometry_bench.py --frames 300 > $OUT/odometry_loop300.json 2>> $OUT/odo.err
 fi
 if has line; then

@@ -167,7 +167,11 @@ def main():
         buf = io.StringIO()
         pstats.Stats(prof, stream=buf).sort_stats("cumulative").print_stats(60)
         buf.write("\n==== by own time ====\n")
-        pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(40)
+        pstats.Stats(prof, stream=buf).sort_stats("tottime").print_stats(90)
+        buf.write("\n==== window rebuild: callees of WindowBA.__init__ and below ====\n")
+        st_ = pstats.Stats(prof, stream=buf).sort_stats("cumulative")
+        for fn_ in ("__init__", "_prepare_topology", "_finish_topology", "_build_pair_table", "_prepare_fused", "add_one_way_frame", "_window_state"):
+            st_.print_callees("window_ba.py.*" + fn_ if fn_.startswith("_") or fn_ == "__init__" else fn_)
         os.makedirs("gpurun_out", exist_ok=True)
         open("gpurun_out/odo_cprofile.txt", "w").write(buf.getvalue())
     n_tracked = args.frames - 1 - t_first_tracked[0]
