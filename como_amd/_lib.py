@@ -105,6 +105,7 @@ SIGNATURES = {
                                                         ctypes.POINTER(c_long), c_void_p]),
     "como_chol_append_obs_info_f32": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_int, c_int, c_void_p]),
     "como_greedy_loop_f32": (c_int, [c_void_p] * 11 + [c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "como_greedy_thin_f32": (c_int, [c_void_p] * 11 + [c_float] * 5 + [c_int, c_int, c_void_p, c_void_p]),
     "como_greedy_loop_ws_f32": (c_int, [c_void_p] * 11 + [c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_long,
                                         c_void_p]),
     "como_greedy_next_f32": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),

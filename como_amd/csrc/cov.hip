@@ -426,6 +426,82 @@ __global__ __launch_bounds__(1024) void greedy_small_loop_kernel(float* coords_n
   }
 }
 
+// The THINNING pass of a keyframe insertion (corr.py:166-176 of the reference: sample_sparse_coords with coords_domain = the <= 64
+// tracked points, no current points, terminate_early) in ONE launch of one workgroup: the seed of precalc_entropy_vars' m = 0 branch
+// (samplers.py:149-165: largest det E, K_nn = k(x0, x0) [+ fixed_var], L00 = sqrt, K_md, obs_info row 0 = K_md / L00,
+// var = signal_var - obs^2 -- each with the rounding of the torch op / native kernel it replaces), then the greedy loop of
+// greedy_small_loop_kernel, cut at the first step whose largest remaining standard deviation falls below the threshold
+// (samplers.py:255-259).  count_out: number of valid entries of inds (0: K_nn not positive -- the caller raises as the reference's
+// torch.linalg.cholesky does).  ~45 torch / native launches and one read-back of the trace become this launch and one read-back.
+__global__ __launch_bounds__(1024) void greedy_thin_kernel(const float* __restrict__ dom, const float* __restrict__ Edom, float* coords_n,
+                                                           float* E_n, long* inds, float* L, float* obs_info, float* var, uint8_t* mask,
+                                                           long* best_idx, float* sd_trace, float scale, float signal_var,
+                                                           float fixed_var, float thresh_sq, float stdev_thresh, int n, int d,
+                                                           long* count_out) {
+  const int tid = threadIdx.x;
+  __shared__ float sa[1024];
+  __shared__ int sj[1024];
+  __shared__ float seedv[8];
+  {
+#pragma clang fp contract(off)
+    float area = -__builtin_inff();
+    if (tid < d) {
+      const float* e = Edom + 4 * tid;
+      const float p0 = e[0] * e[3], p1 = e[1] * e[2];
+      area = p0 - p1;
+    }
+    sa[tid] = area; sj[tid] = tid < d ? tid : 0x7fffffff;
+    __syncthreads();
+    for (int h = 512; h > 0; h >>= 1) {
+      if (tid < h) {
+        const float a2 = sa[tid + h];
+        const int j2 = sj[tid + h];
+        if (a2 > sa[tid] || (a2 == sa[tid] && j2 < sj[tid])) { sa[tid] = a2; sj[tid] = j2; }
+      }
+      __syncthreads();
+    }
+    const int w0 = sj[0];
+    if (tid == 0) {
+      inds[0] = w0;
+      coords_n[0] = dom[2 * w0]; coords_n[1] = dom[2 * w0 + 1];
+      for (int e = 0; e < 4; ++e) E_n[e] = Edom[4 * w0 + e];
+      float k00 = cov_value_f32(dom[2 * w0], dom[2 * w0 + 1], Edom + 4 * w0, dom[2 * w0], dom[2 * w0 + 1], Edom + 4 * w0, scale);
+      if (fixed_var != 0.f) k00 = k00 + fixed_var;
+      seedv[0] = k00;
+      seedv[1] = sqrtf(k00);
+      L[0] = seedv[1];
+    }
+    __syncthreads();
+    if (!(seedv[0] > 0.f)) {                              // not positive definite (or NaN): nothing is valid
+      if (tid == 0) *count_out = 0;
+      return;
+    }
+    if (tid < d) {
+      const float kmd = cov_value_f32(dom[2 * w0], dom[2 * w0 + 1], Edom + 4 * w0, dom[2 * tid], dom[2 * tid + 1], Edom + 4 * tid, scale);
+      const float o = kmd / seedv[1];
+      obs_info[tid] = o;
+      const float o2 = o * o;
+      var[tid] = signal_var - o2;
+      mask[tid] = 1;
+    }
+  }
+  __syncthreads();
+  const float k_ii = signal_var + fixed_var;
+  int count = n;
+  greedy_pick_body(0, tid, var, dom, Edom, coords_n, E_n, inds, n, 0, 1, mask, thresh_sq, 1, best_idx, sd_trace + 1, d);
+  __syncthreads();
+  for (int i = 1; i < n; ++i) {
+    // (written by thread 0 before the barrier; read through an atomic load: a uniform address could otherwise be served from the
+    // scalar cache, which does not see vector stores)
+    if (__hip_atomic_load(&sd_trace[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < stdev_thresh) { count = i; break; }
+    greedy_append_body<1024>(0, 0, tid, coords_n, E_n, dom, Edom, L, obs_info, var, scale, k_ii, n, d, i);
+    __syncthreads();
+    greedy_pick_body(0, tid, var, dom, Edom, coords_n, E_n, inds, n, i, 1, mask, thresh_sq, i + 1, best_idx, sd_trace + i + 1, d);
+    __syncthreads();
+  }
+  if (tid == 0) *count_out = count;
+}
+
 template <typename T>
 int cross_cov(const T* x1, const T* E1, const T* x2, const T* E2, T scale, T* K12, int B, int N, int M,
               const long* strides_host, hipStream_t s) {
@@ -547,6 +623,20 @@ int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, cons
                          como_stream_t stream) {
   return greedy_loop_impl(coords_n, E_n, coord_vec_inds, coords_domain, E_domain, L, obs_info, var, mask, best_idx, max_stdev, scale,
                           k_ii, dist_thresh_sq, B, n, d, m, sd_trace, scratch, scratch ? 4096L * B : 0, stream);
+}
+
+int como_greedy_thin_f32(const float* coords_domain, const float* E_domain, float* coords_n, float* E_n, long* coord_vec_inds,
+                         float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* sd_trace, float scale,
+                         float signal_var, float fixed_var, float dist_thresh_sq, float stdev_thresh, int n, int d, long* count_out,
+                         como_stream_t stream) {
+  if (!coords_domain || !E_domain || !coords_n || !E_n || !coord_vec_inds || !L || !obs_info || !var || !mask || !best_idx ||
+      !sd_trace || !count_out || n <= 0 || n > 64 || d <= 0 || d > 1024 || n > d)
+    return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::greedy_thin_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, coords_domain, E_domain, coords_n, E_n,
+                     coord_vec_inds, L, obs_info, var, mask, best_idx, sd_trace, scale, signal_var, fixed_var, dist_thresh_sq,
+                     stdev_thresh, n, d, count_out);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
 }
 
 int como_greedy_loop_ws_f32(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,

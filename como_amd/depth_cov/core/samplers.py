@@ -151,6 +151,31 @@ def greedy_loop(coord_vec_inds, coords_n_norm, E_n, coords_domain_norm, E_domain
     return coord_vec_inds
 
 
+THIN_KERNEL = __import__("os").environ.get("COMO_GREEDY_THIN", "1") != "0"      # 0: the generic path (A/B, tests flip the attribute)
+
+
+def _thin(cdn, E_domain, n, signal_var, fixed_var, max_stdev_thresh, dist_thresh):
+    """The thinning pass of a keyframe insertion -- given candidate points, no current points, early termination -- as ONE launch
+    (csrc/cov.hip `como_greedy_thin_f32`: the m = 0 seed of precalc_entropy_vars, the greedy loop and the cut) and one read-back
+    (the number of picks) instead of ~45 launches and the read-back of the trace.  cdn (1,d,2), E_domain (1,d,2,2) float32."""
+    dev, d = cdn.device, cdn.shape[1]
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    coords_n, E_n, L, obs, var, trace = f(n, 2), f(n, 4), f(n, n), f(n, d), f(d), f(n + 1)
+    mask = torch.empty(d, dtype=torch.uint8, device=dev)
+    inds = torch.empty((1, n), dtype=torch.long, device=dev)
+    aux = torch.empty(2, dtype=torch.long, device=dev)                # [best index, count]
+    rc = _lib.lib().como_greedy_thin_f32(cdn.contiguous().data_ptr(), E_domain.contiguous().data_ptr(), coords_n.data_ptr(), E_n.data_ptr(),
+                                         inds.data_ptr(), L.data_ptr(), obs.data_ptr(), var.data_ptr(), mask.data_ptr(), aux.data_ptr(),
+                                         trace.data_ptr(), float(signal_var), float(signal_var),
+                                         float(fixed_var) if fixed_var is not None else 0.0, float(dist_thresh) * float(dist_thresh),
+                                         float(max_stdev_thresh), n, d, aux[1:].data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "como_greedy_thin_f32")
+    count = int(aux[1])                                               # the one host synchronisation
+    if count == 0:
+        raise RuntimeError("como_amd sample_sparse_coords: K_nn is not positive definite")
+    return inds[:, :count]
+
+
 def greedy_conditional_entropy(gaussian_covs, E_domain, n, coords_domain_norm, curr_coords_norm, curr_var, fixed_var,
                                signal_var, max_stdev_thresh, terminate_early, dist_thresh, curr_E=None):
     cvi, cn, E_n, L, obs, m = precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_coords_norm, curr_var,
@@ -182,6 +207,10 @@ def sample_sparse_coords(cov_params_img, num_samples, mode, max_stdev_thresh=-1e
         E_domain = get_cov_domain(coords_domain, cov)
     else:
         cdn, E_domain = gk.kernel_params_at(cov, coords_domain, dtype)
+        if (THIN_KERNEL and mode == "greedy_conditional_entropy" and terminate_early and b == 1 and curr_coords.shape[1] == 0 and
+                curr_var.shape[1] == 0 and dtype == torch.float32 and cdn.is_cuda and 0 < coords_domain.shape[1] <= 1024):
+            inds = _thin(cdn, E_domain, min(num_samples, coords_domain.shape[1]), signal_var, fixed_var, max_stdev_thresh, dist_thresh)
+            return coords_domain.index_select(1, inds[0]), inds
     if mode == "random_uniform":
         inds = random_uniform(num_samples - curr_coords.shape[-2], cdn)
     elif mode == "greedy_conditional_entropy":

@@ -306,6 +306,16 @@ int como_greedy_loop_f32(float* coords_n, float* E_n, long* coord_vec_inds, cons
                          float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
                          float k_ii, float dist_thresh_sq, int B, int n, int d, int m, float* sd_trace, void* scratch,
                          como_stream_t stream);
+/* como_greedy_thin_f32  replaces  sample_sparse_coords(coords_domain = <= 1024 given points, no current points, terminate_early)
+ *   (depth_cov/core/samplers.py:38-107 -> precalc_entropy_vars' m = 0 seed :149-165 + greedy_loop :196-282 + the cut :255-259; the
+ *   thinning of a new keyframe's tracked points, como/odom/frontend/corr.py:166-176) as ONE launch: coords_domain (d,2) normalised,
+ *   E_domain (d,2,2); work arrays coords_n (n,2), E_n (n,2,2), L (n,n), obs_info (n,d), var (d), mask (d), best_idx (1),
+ *   sd_trace (n+1); coord_vec_inds (n) int64 receives the picks, *count_out how many of them are valid (cut at the first step whose
+ *   largest remaining standard deviation is below stdev_thresh; 0 = K_nn not positive definite). */
+int como_greedy_thin_f32(const float* coords_domain, const float* E_domain, float* coords_n, float* E_n, long* coord_vec_inds,
+                         float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* sd_trace, float scale,
+                         float signal_var, float fixed_var, float dist_thresh_sq, float stdev_thresh, int n, int d, long* count_out,
+                         como_stream_t stream);
 /* como_greedy_loop_ws_f32: the same with the scratch size stated (floats, >= 4096 B): with >= 4 B ceil(d / 256) floats the
  *   append launch of a step also does the scan of the next pick (mask of the point being added, best candidate per workgroup), so
  *   a step is two launches (append + scan, pick) instead of three; same picks. */
