@@ -44,8 +44,7 @@ def shares(rs, label):
 
 shares(rows, "whole run")
 shares(post, "after the initialisation")
-# frames by kind: a frame = the dispatches from one level-0 tracking launch to the next; keyframe insertions and one-way frames
-# (window rebuild) are told apart by their dispatch count
+# frames by kind: a frame = the dispatches from one level-0 tracking launch to the next
 tl = [i for i, r in enumerate(rows) if "track_level" in r[2]][::3]
 kinds = {"plain tracked frame": [], "one-way frame + window rebuild": [], "keyframe insertion": []}
 for a, b in zip(tl[:-1], tl[1:]):
@@ -54,7 +53,11 @@ for a, b in zip(tl[:-1], tl[1:]):
         if e > prev:
             fb += e - max(s, prev)
             prev = e
-    k = "keyframe insertion" if b - a > 400 else ("one-way frame + window rebuild" if b - a > 105 else "plain tracked frame")
+    # (by content, not by dispatch count: a keyframe insertion runs the covariance network, a one-way insertion the float64
+    # image gradients of Mapping.get_img_and_grads)
+    names = [n for _, _, n in rows[a:b]]
+    k = ("keyframe insertion" if any("conv3_" in n or "conv_mfma" in n for n in names) else
+         ("one-way frame + window rebuild" if any("img_grads_kernel<double>" in n for n in names) else "plain tracked frame"))
     kinds[k].append((fb / 1e3, b - a))
 for k, v in kinds.items():
     if v:

@@ -63,7 +63,14 @@ def test_double_select_candidate_exchange(world):
     for sgm in range(nseg):
         ref = torch.median(x[sgm][valid[sgm]])
         if sgm == 1:                                            # ~53 k identical keys: more than 512 candidates on a rank
-            assert int(cnt[:, 1].max()) > 512 and torch.isnan(med[1]) and nv[1] == 0     # reported, not silently wrong
+            # round 5: an overflowing candidate list of ONE value travels as (count, key) and the median is exact; only if a rank's
+            # overflowing list also holds another key with the same 33 leading bits it is unrepresentable -- then it is REPORTED
+            # (NaN, zero valid keys), never silently wrong
+            assert int(cnt[:, 1].max()) > 512
+            if torch.isnan(med[1]):
+                assert nv[1] == 0
+            else:
+                assert med[1].item() == ref.item() and int(nv[1]) == int(valid[1].sum())
         else:
             assert med[sgm].item() == ref.item() and int(nv[sgm]) == int(valid[sgm].sum())
             assert int(cnt[:, sgm].max()) <= 512
