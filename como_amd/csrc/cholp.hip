@@ -1,4 +1,5 @@
-// Dense SPD solve delta = H^-1 g in ONE persistent launch (float64, 2 .. 16 column pairs: D + 1 <= 1024).
+// Dense SPD solve delta = H^-1 g in ONE persistent launch (float64, 2 .. 34 column pairs: D <= 2175; one super-tile per
+// workgroup up to 16 pairs, then two, four, eight -- see cp_tile / cp_workers_body).
 //
 // Reference: como/odom/backend/linear_system.py:101-112 (`solve_system`: cholesky_ex + cholesky_solve).
 //
@@ -8,7 +9,8 @@
 // are replaced by counters in memory and every piece of the matrix has ONE owner for the whole solve:
 //
 //   * the matrix is cut into 64 x 64 SUPER-TILES (I, J) (pair units; np = Dp / 64 pairs).  One workgroup (512 threads, one
-//     per compute unit: np^2 - 2 + ... <= 240 workgroups, all co-resident) owns one super-tile and keeps it in the accumulator
+//     per compute unit, all co-resident: (np - 1) + np (np - 2) super-tiles <= 255 up to 16 pairs; beyond that the super-tiles
+//     are dealt out column-major and cyclically, several per workgroup) owns a super-tile and keeps it in the accumulator
 //     registers of its 8 waves (two 16 x 16 quadrants each) from the first to the last update -- no read-modify-write of the
 //     working copy between steps.  Step s (columns of pair s): X_I = A(I, s) Vp_s^T, X_J = A(J, s) Vp_s^T with the published
 //     INVERSE of the factored diagonal pair (Vp_s = L_ss^-1, 64 x 64 lower triangular: ONE product stage instead of three
@@ -378,8 +380,10 @@ __device__ __forceinline__ void cp_chain(const CholpArgs& a, double* dsm) {
 // from c = 2 on; the appended (R, c), R < c) and dealt round-robin to the worker workgroups, so that a workgroup's tiles are sorted by
 // the column pair at which they retire -- the tile the chain or the next step waits for is always the first one it works on.  Up to
 // 16 column pairs every super-tile has its own workgroup (MAXT = 1, the metric window); larger systems (the full sliding windows of
-// the odometry loop at D ~ 1300, config 4 at D = 2680: 1722 super-tiles) give each of the 255 workers up to MAXT = 8 of them, all
-// register-resident, processed one after the other within a step (the pair inverse is fetched once per step).
+// the odometry loop at D ~ 1300; up to config 4 at D = 2680: 1722 super-tiles) give each of the 255 workers up to MAXT = 8 of them, all
+// register-resident, processed one after the other within a step (the pair inverse is fetched once per step).  By default the
+// launcher stops at CHOLP_RUN_MAX_NP = 34 pairs: at 42 the owners' three products per super-tile step lose to the multi-launch
+// solver's shared panels (1634 vs 1504 us, profiles/r5_chol_time.txt); COMO_CHOLP_MAX_NP moves the cross-over.
 struct CpTile {
   int I, J, s_first, s_last;
   bool app, diag, lastcol;
