@@ -194,6 +194,33 @@ def test_sliding_predictor_window_equals_cat():
         assert mp.Knm_Kmminv_pix.dtype == torch.float32 and torch.equal(mp.Knm_Kmminv_pix, ref32), k
 
 
+def test_sliding_one_way_stack_with_pruned_views_and_its_own_capacity():
+    """Round 5: the image stacks live in sliding buffers too -- with the capacity of THEIR window (24 one-way frames, not 9 keyframes)
+    and with `prune_one_way` handing back a SUFFIX view of the stack: the next insertion must find the kept frames where they are
+    (no copy of the stack) and the window must equal what slicing + `torch.cat` give."""
+    N, R = 4, 6
+    mp = _cpu_mapping(N)
+    g = torch.Generator().manual_seed(9)
+    mp.recent_img_and_grads = torch.empty((0), dtype=torch.float64)
+    ref = torch.empty((0), dtype=torch.float64)
+    i = -R + 1
+    moved = 0
+    for k in range(40):
+        new = torch.randn((1, 3, 5, 7), generator=g, dtype=torch.float64)
+        if k in (9, 10, 23) and ref.shape[0] > 2:       # prune_one_way: the two oldest one-way frames leave the window
+            ref = ref[2:]
+            mp.recent_img_and_grads = mp.recent_img_and_grads[2:]
+        ref = new.clone() if ref.dim() == 1 else torch.cat((ref[i:], new), dim=0)
+        keep_ptr = mp.recent_img_and_grads[i:].data_ptr() if mp.recent_img_and_grads.dim() > 1 else None
+        mp._cat_sliding("recent_img_and_grads", mp.recent_img_and_grads, new, i, cap=R)
+        assert torch.equal(mp.recent_img_and_grads, ref), k
+        assert mp.recent_img_and_grads.shape[0] <= R
+        if keep_ptr is not None and mp.recent_img_and_grads.data_ptr() != keep_ptr:
+            moved += 1
+    assert mp._kt_pp["recent_img_and_grads"]["buf"].shape[0] == 2 * R
+    assert moved <= 40 // R + 1, moved                # the kept frames only move when the view wraps, pruned or not
+
+
 def test_fill_image_last_point_wins_like_torch_cpu():
     """fill_image's explicit last-wins rule equals what the reference's `img[:, r, c] = vals` does on the CPU."""
     from como_amd.utils.coords import fill_image
