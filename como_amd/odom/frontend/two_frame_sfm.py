@@ -15,6 +15,7 @@ from como_amd.odom.backend.dense_ref import dense_reference_factored
 from como_amd.utils.lin_alg import chol_small, cholesky_solve_many, trsm_lower
 
 _tables = {}
+_LEGACY_LOOP = __import__("os").environ.get("COMO_SFM_PER_ITERATION", "0") == "1"
 
 
 def _table(m, device, c=1):
@@ -37,12 +38,51 @@ def _table(m, device, c=1):
     return t
 
 
+def photo_statics(test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, intrinsics):
+    """Everything `construct_photo_system` derives from its iteration-independent arguments (one pyramid level of one frame pair):
+    built once per level by `two_frame_sfm` instead of once per Gauss-Newton iteration (pixel indices, the value layout the kernels
+    read, image / intrinsics in the system's type, the constant pose / affine / Jacobian stubs -- ~25 launches and a host-to-device
+    copy per iteration)."""
+    dt, dev = Knm_Kmminv.dtype, Knm_Kmminv.device
+    N, m = Knm_Kmminv.shape[1], Knm_Kmminv.shape[2]
+    Ww = img_and_grads_j.shape[-1]
+    c = img_and_grads_j.shape[1] // 3
+    poses = torch.zeros((2, 4, 4), dtype=dt, device=dev)
+    poses[1] = torch.eye(4, dtype=dt, device=dev)
+    K = intrinsics
+    ray = torch.stack(((test_coords_i[..., 1].to(dt) - K[0, 2]) / K[0, 0], (test_coords_i[..., 0].to(dt) - K[1, 2]) / K[1, 1],
+                       torch.ones((1, N), dtype=dt, device=dev)), dim=-1)
+    return {"pixcoord": (test_coords_i[..., 0] * Ww + test_coords_i[..., 1]).to(torch.int32).reshape(1, N).contiguous(),
+            "zeros6": torch.zeros((1, m, 6), dtype=dt, device=dev), "Kt": Knm_Kmminv.contiguous(), "poses": poses,
+            "aff0": torch.zeros((2, 2), dtype=dt, device=dev), "ones": torch.ones((1, m), dtype=dt, device=dev),
+            "dzdP": torch.tensor([[1.0, 0.0, 0.0]], dtype=dt, device=dev),
+            "vals": vals_i.reshape(1, c, N).transpose(1, 2).to(dt).contiguous(),        # (1,N,c): the kernels' (slots,n,c) layout
+            "img": img_and_grads_j.to(dt).contiguous(), "K": intrinsics.to(dt).contiguous(), "ray": ray}
+
+
+def photo_points(st, Pj, logz, c, N):
+    """The per-point return values of `construct_photo_system` from the most recent linearisation (photo.last_aux):
+    (coords_j, depths_j, valid (1,N), Pi (1,N,3)) -- reference two_frame_sfm.py:262-269."""
+    aux = photo.last_aux
+    valid = aux["valid"].reshape(c, N)[:1].bool()              # the mask does not depend on the channel
+    # Pi = Tji^-1 Pj is not needed by the kernels; the reference returns it (two_frame_sfm.py:269) -> rebuild from logz
+    Pi = torch.exp(logz.reshape(1, N, 1)) * st["ray"]
+    pj = aux["pj"].reshape(c, N, 2)[:1]
+    vi = torch.nonzero(valid[0])[:, 0]                          # (one index list for both gathers)
+    coords_j = torch.stack((pj[0, :, 1].index_select(0, vi), pj[0, :, 0].index_select(0, vi)), dim=-1)[None]   # swap_coords_xy(pj)[valid]
+    depths_j = Pj[0, 2].index_select(0, vi).reshape(1, -1, 1)
+    return coords_j, depths_j, valid, Pi
+
+
 def construct_photo_system(Tji, sparse_log_depth, aff, test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, intrinsics,
-                           photo_sigma, H, g):
+                           photo_sigma, H, g, statics=None, want_points=True):
     """reference two_frame_sfm.py:232-269, same arguments and return tuple
     (total_err, log_depth_i (1,N,1), coords_j, depths_j, valid_mask (1,N), Pi (1,N,3)); H (6+m,6+m), g (6+m) accumulated.
     vals_i (1,c,N) and img_and_grads_j (1,3c,H,W) as the reference passes them (c = 1 gray, 3 rgb: linearize_photo :180-200);
-    `aff` and `photo_sigma` are unused there as well."""
+    `aff` and `photo_sigma` are unused there as well.
+    statics: `photo_statics(...)` of the same arguments (the Gauss-Newton loop builds it once per level); want_points = False: the
+    four per-point values are not extracted (None) and log_depth_i is a view of the kernel's buffer, valid until the next call --
+    the loop reads them once, after its last iteration (`photo_points`)."""
     _lib.require_cuda(Tji, sparse_log_depth, test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, intrinsics, H, g)
     dt, dev = Knm_Kmminv.dtype, Knm_Kmminv.device
     N, m = Knm_Kmminv.shape[1], Knm_Kmminv.shape[2]
@@ -51,13 +91,12 @@ def construct_photo_system(Tji, sparse_log_depth, aff, test_coords_i, vals_i, Kn
     if img_and_grads_j.shape[1] != 3 * c or vals_i.numel() != c * N:
         raise RuntimeError("como_amd two_frame_sfm: img_and_grads_j must be (1,3c,H,W) and vals_i (1,c,N)")
     tb = _table(m, dev, c)
-    pixcoord = (test_coords_i[..., 0] * Ww + test_coords_i[..., 1]).to(torch.int32).reshape(1, N).contiguous()
-    zeros6 = torch.zeros((1, m, 6), dtype=dt, device=dev)
-    Kt = Knm_Kmminv.contiguous()
+    st = statics if statics is not None else photo_statics(test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, intrinsics)
+    Kt = st["Kt"]
     Pj, dPj_dT, uvec, _, logz = dense_reference_factored(sparse_log_depth.reshape(1, m), Tji.reshape(1, 4, 4), Kt, None,
-                                                         intrinsics, zeros6, Ww, pixcoord=pixcoord, compact=True)
-    poses = torch.stack((Tji.reshape(4, 4).to(dt), torch.eye(4, dtype=dt, device=dev))).contiguous()
-    aff0 = torch.zeros((2, 2), dtype=dt, device=dev)
+                                                         intrinsics, st["zeros6"], Ww, pixcoord=st["pixcoord"], compact=True)
+    poses = st["poses"]
+    poses[0].copy_(Tji.reshape(4, 4))
     D = tb["D"]
     # order-independent assembly (exact integer atomics into the fixed-point system buffer, then ONE conversion) -- the
     # float-atomic accumulation into H cost 213 us per call here: every workgroup's 70 x 70 block lands on the same entries
@@ -69,16 +108,13 @@ def construct_photo_system(Tji, sparse_log_depth, aff, test_coords_i, vals_i, Kn
         tb["sys64"] = torch.empty((D * D + D + 8,), dtype=torch.float64, device=dev)
     sysfix, sys64 = tb["sysfix"], tb["sys64"]
     sysfix.zero_()
-    ones = torch.ones((1, m), dtype=dt, device=dev)
-    dzdP = torch.tensor([[1.0, 0.0, 0.0]], dtype=dt, device=dev)
-    vals = vals_i.reshape(1, c, N).transpose(1, 2).to(dt).contiguous()        # (1,N,c): the kernels' (slots,n,c) layout
-    photo.linearize(dtype=dt, b=c, n=N, m=m, H_img=Hh, W_img=Ww, zmode=2, ref_pose=tb["ref_slot"], Pwn=Pj, vals=vals, channels=c,
+    photo.linearize(dtype=dt, b=c, n=N, m=m, H_img=Hh, W_img=Ww, zmode=2, ref_pose=tb["ref_slot"], Pwn=Pj, vals=st["vals"], channels=c,
                     pair_chan=tb["chan"],
-                    dPwn_dTwc=dPj_dT, zjac=Kt, uvec=uvec, pixidx=None, invz=ones, kt_slot_stride=Kt.stride(0), poses_all=poses,
-                    aff_all=aff0, img_base=img_and_grads_j.to(dt).contiguous(), K=intrinsics.to(dt).contiguous(),
+                    dPwn_dTwc=dPj_dT, zjac=Kt, uvec=uvec, pixidx=None, invz=st["ones"], kt_slot_stride=Kt.stride(0), poses_all=poses,
+                    aff_all=st["aff0"], img_base=st["img"], K=st["K"],
                     ref_slot=tb["ref_slot"], ref_aff=tb["ref_aff"], tgt_aff=tb["tgt_aff"], tgt_pose=tb["tgt_pose"],
                     tgt_img=tb["tgt_img"], pose_ref_inds=tb["pose_ref"], pose_tgt_inds=tb["pose_tgt"], landmark_inds=tb["lm"],
-                    dzdP=dzdP, H=None, g=None, err_out=None, want_pj=True, anorm_f32=True, sysfix=sysfix, fix_plane=fp, D=D)
+                    dzdP=st["dzdP"], H=None, g=None, err_out=None, want_pj=True, anorm_f32=True, sysfix=sysfix, fix_plane=fp, D=D)
     Hs, gs, err8 = sys64[:D * D].view(D, D), sys64[D * D:D * D + D], sys64[D * D + D:]
     _lib.check(Lb.como_sys_finalize(sysfix.data_ptr(), fp, D, Hs.data_ptr(), gs.data_ptr(), err8.data_ptr(), _lib.stream_ptr(dev)),
                "como_sys_finalize")
@@ -86,18 +122,9 @@ def construct_photo_system(Tji, sparse_log_depth, aff, test_coords_i, vals_i, Kn
     sel = tb["sel"]
     H += Hs[sel][:, sel].to(H.dtype)
     g += gs[sel].to(g.dtype)
-    aux = photo.last_aux
-    valid = aux["valid"].reshape(c, N)[:1].bool()              # the mask does not depend on the channel
-    # Pi = Tji^-1 Pj is not needed by the kernels; the reference returns it (two_frame_sfm.py:269) -> rebuild from logz
-    z = torch.exp(logz.reshape(1, N, 1))
-    K = intrinsics
-    ray = torch.stack(((test_coords_i[..., 1].to(dt) - K[0, 2]) / K[0, 0], (test_coords_i[..., 0].to(dt) - K[1, 2]) / K[1, 1],
-                       torch.ones((1, N), dtype=dt, device=dev)), dim=-1)
-    Pi = z * ray
-    pj = aux["pj"].reshape(c, N, 2)[:1]
-    vm = valid[0]
-    coords_j = torch.stack((pj[0, vm, 1], pj[0, vm, 0]), dim=-1)[None]                   # swap_coords_xy(pj)[valid]
-    depths_j = Pj[0, 2, vm].reshape(1, -1, 1)
+    if not want_points:
+        return err.to(dt), logz.reshape(1, N, 1), None, None, None, (st, Pj, logz, c, N)
+    coords_j, depths_j, valid, Pi = photo_points(st, Pj, logz, c, N)
     return err.to(dt), logz.reshape(1, N, 1).clone(), coords_j, depths_j, valid, Pi
 
 
@@ -153,26 +180,39 @@ def two_frame_sfm(Tji_init, sparse_log_depth_init, aff_init, test_coords_i, vals
     D = 6 + m
     Tji, d, aff = Tji_init.clone(), sparse_log_depth_init.clone(), aff_init.clone()
     dr_mean_dd, H_mean_d_d = linearize_mean_log_depth_prior_system(Knm_Kmminv)
+    # (COMO_SFM_PER_ITERATION=1: round 4's loop -- statics rebuilt, per-point values extracted and two read-backs in EVERY
+    # iteration -- for A/B timing, scripts/init_time.py; same numbers either way)
+    legacy = _LEGACY_LOOP
+    statics = None if legacy else photo_statics(test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, intrinsics)   # once per level
     it, prev = 0, float("inf")
     while True:
         H = torch.zeros((D, D), device=dev, dtype=dt)
         g = torch.zeros((D,), device=dev, dtype=dt)
-        photo_err, log_depth, coords_j, depths_j, valid, Pi = construct_photo_system(
-            Tji, d, aff, test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, intrinsics, sigmas["photo"], H, g)
+        photo_err, log_depth, cj_, dj_, vm_, last = construct_photo_system(
+            Tji, d, aff, test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j, intrinsics, sigmas["photo"], H, g, statics=statics,
+            want_points=legacy)
         e_d = construct_sparse_depth_prior_system(d, H, g, dr_prior_dd, H_prior_d_d)
         e_m = construct_mean_log_depth_prior_system(log_depth, H, g, dr_mean_dd, H_mean_d_d, sigma=1e0)
-        total = float(photo_err + e_d + e_m)
+        total_t = photo_err + e_d + e_m
+        if legacy:
+            total = float(total_t)
         delta = solve_delta(H, g)
         Tji, d, aff = update_vars(Tji, d, aff, delta)
         it += 1
-        dn = float(torch.norm(delta[:6]))
+        if legacy:
+            dn = float(torch.norm(delta[:6]))
+        else:
+            total, dn = torch.stack((total_t.reshape(-1)[0], torch.norm(delta[:6]).to(total_t.dtype))).tolist()   # ONE read-back
         dec = prev - total
         rel = abs(dec) / prev
         if it >= init_cfg["max_iter"] or dn < init_cfg["delta_norm"] or (rel < init_cfg["rel_tol"] and dec > 0):
             break
         prev = total
+    # the per-point values of the LAST linearisation (what the reference's last construct_photo_system call returned)
+    mean_log_depth = torch.mean(log_depth, dim=(1, 2), keepdim=True)
+    coords_j, depths_j = (cj_, dj_) if legacy else photo_points(*last)[:2]
     two_frame_sfm.last_iters = it
-    return Tji, d, aff, coords_j, depths_j, torch.mean(log_depth, dim=(1, 2), keepdim=True)
+    return Tji, d, aff, coords_j, depths_j, mean_log_depth
 
 
 def two_frame_sfm_pyr(Tji_init, sparse_log_depth_init, aff_init, test_coords_i, vals_i, Knm_Kmminv, img_and_grads_j,
