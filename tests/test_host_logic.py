@@ -470,3 +470,37 @@ def test_cached_coordinate_helpers_and_pose_composition_equal_the_plain_forms():
     assert torch.equal(composeSE3(A, B, 1), invertSE3(A) @ B) and torch.equal(composeSE3(A[:1], B, 2), A[:1] @ invertSE3(B))
     assert torch.equal(get_rel_pose(A, B), invertSE3(A) @ B) and torch.equal(get_T_w_curr(A, B), A @ invertSE3(B))
     assert float((get_rel_pose(A, A) - torch.eye(4, dtype=torch.float64)).abs().max()) < 1e-14
+
+
+def test_cached_index_ramp_and_initialiser_statics():
+    """Round 5 host helpers: `window_ba._ar` hands out views of ONE cached ramp (equal to torch.arange, also after it had to grow);
+    `two_frame_sfm.photo_statics` holds exactly what `construct_photo_system` used to build in every Gauss-Newton iteration
+    (reference two_frame_sfm.py:232-269: pixel index row * W + col, intensities as (1,N,c), ray = ((col - cx) / fx, (row - cy) / fy, 1))."""
+    from como_amd.odom import window_ba as wb
+    a = wb._ar(37, "cpu")
+    assert torch.equal(a, torch.arange(37)) and a.dtype == torch.long
+    big = wb._ar(10000, "cpu")                                      # beyond the first allocation: a new ramp, the old view stays valid
+    assert torch.equal(big, torch.arange(10000)) and torch.equal(a, torch.arange(37))
+    assert wb._ar(5, "cpu").data_ptr() == wb._ar(9, "cpu").data_ptr()
+    assert torch.equal(wb._ar(6, "cpu", torch.int32), torch.arange(6, dtype=torch.int32))
+    assert torch.equal(wb._ar(24, "cpu")[8:].reshape(2, 8), torch.arange(16).reshape(2, 8) + 8)
+
+    from como_amd.odom.frontend.two_frame_sfm import photo_statics
+    g = torch.Generator().manual_seed(2)
+    h, w, m, c = 6, 8, 4, 3
+    N = h * w
+    rows, cols = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+    coords = torch.stack((rows.reshape(-1), cols.reshape(-1)), dim=-1)[None]
+    vals = torch.rand((1, c, N), generator=g, dtype=torch.float64)
+    Kt = torch.rand((1, N, m), generator=g, dtype=torch.float64)
+    img = torch.rand((1, 3 * c, h, w), generator=g, dtype=torch.float64)
+    K = torch.tensor([[5.0, 0, 3.5], [0, 4.0, 2.5], [0, 0, 1]], dtype=torch.float64)
+    st = photo_statics(coords, vals, Kt, img, K)
+    assert torch.equal(st["pixcoord"], torch.arange(N, dtype=torch.int32)[None])
+    assert st["vals"].shape == (1, N, c) and torch.equal(st["vals"][0, :, 1], vals[0, 1])
+    assert torch.equal(st["poses"][1], torch.eye(4, dtype=torch.float64)) and st["poses"].shape == (2, 4, 4)
+    ray = st["ray"]
+    assert ray.shape == (1, N, 3) and torch.equal(ray[0, :, 2], torch.ones(N, dtype=torch.float64))
+    k = 2 * w + 5                                                   # pixel (row 2, col 5)
+    assert ray[0, k, 0].item() == (5 - 3.5) / 5.0 and ray[0, k, 1].item() == (2 - 2.5) / 4.0
+    assert st["Kt"].data_ptr() == Kt.data_ptr() and st["img"].data_ptr() == img.data_ptr()      # (already in the system's type: no copies)
