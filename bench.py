@@ -158,6 +158,7 @@ def odometry_loop(device, frames=100, seed=1, pix="float", warm=0, barrier=None,
         model = DepthCovModule({k: v.to(device) for k, v in synth.depthcov_state_dict(0).items()})
         odo = ComoSeq(loop_cfgs(G, pix, str(device), graph_network=True), K.clone(), (G["H"], G["W"]), model)
         t0, k0, kinds, k_end = None, None, [], frames
+        t_start = []
         k_init = None
         poses = {}
         for k in range(frames):
@@ -173,14 +174,23 @@ def odometry_loop(device, frames=100, seed=1, pix="float", warm=0, barrier=None,
             if k >= k_end:
                 break
             nb = len(odo.est_poses)
+            t_start.append(time.perf_counter())              # (no synchronisation added: a tracked frame reads its result back)
             kinds.append(odo.iter(1.0 + k, rgbs[k]))
             if len(odo.est_poses) > nb:
                 poses[k] = odo.est_poses[-1]                # (device tensors: read back after the timed region)
         torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        t_end = time.perf_counter()
+        el = t_end - t0
         if barrier is not None:
             barrier()
         n = min(k_end, frames) - k0
+        # wall time from the start of a frame to the start of the next, by what the frame asked the mapper for (None = a plain
+        # tracked frame): the tracker's read-back of the next frame waits for the mapping work this frame queued
+        t_start.append(t_end)
+        by_req = {}
+        for j in range(k0, len(kinds)):
+            by_req.setdefault(str(kinds[j]), []).append(1e3 * (t_start[j + 1] - t_start[j]))
+        frame_ms = {r: {"mean_ms": sum(v) / len(v), "frames": len(v)} for r, v in by_req.items()}
         if timed_frames is not None and n != timed_frames:
             return {"error": f"only {n} of {timed_frames} frames could be timed (initialisation at frame {k_init})"}
         from como_amd.odom.frontend.photo_tracking import photo_tracking_pyr
@@ -191,7 +201,7 @@ def odometry_loop(device, frames=100, seed=1, pix="float", warm=0, barrier=None,
                            "pixel kernels)",
                "value": n / el, "unit": "frames/s", "ms_per_frame": 1e3 * el / n, "frames": n, "elapsed_s": el,
                "init_completed_at_frame": k_init, "keyframes_inserted": kinds.count("keyframe"), "one_way_inserted": kinds.count("one-way"),
-               "tracking_chain_fallbacks": int(getattr(photo_tracking_pyr, "fallbacks", 0)),
+               "tracking_chain_fallbacks": int(getattr(photo_tracking_pyr, "fallbacks", 0)), "frame_ms_by_request": frame_ms,
                "ate_vs_gt_sim3_m": float(ate_rmse(est, [T[k] for k in tracked], "sim3")) if len(est) > 3 else None}
         ref_path = os.path.join(ROOT, "tests", "golden", "ate_sequence_640.npz")
         if seed == 1 and os.path.exists(ref_path):          # the pinned sequence: the reference's own loop on the same frames
