@@ -86,6 +86,9 @@ SIGNATURES = {
     "como_track_level_local_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_int, c_float,
                                            c_float, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "como_track_level_probe": (c_int, []),
+    "como_track_level_set_local": (c_int, [c_int]),
+    "como_track_level_local_state": (c_int, []),
+    "como_track_level_debug_mismatch": (None, [c_int]),
     "como_track_reference_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_float, c_float] + [c_void_p] * 4),
     "como_track_reference_f64": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_double] + [c_void_p] * 4),
     "como_reproject_depth_f32": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int] + [c_void_p] * 6),
@@ -129,6 +132,9 @@ SIGNATURES = {
     "como_chol_workspace_bytes": (c_long, [c_int]),
     "como_chol_solve_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "como_chol_solve_packed_f64": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "como_chol_set_persistent": (c_int, [c_int]),
+    "como_chol_persistent_state": (c_int, []),
+    "como_chol_debug_stall": (None, [c_int]),
     "como_sys_finalize_pack": (c_int, [c_void_p, c_long, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "como_chol_small_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "como_chol_small_f64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
@@ -165,6 +171,7 @@ SIGNATURES = {
     "como_win_scaffold": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
     "como_win_priors": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
     "como_win_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
+    "como_win_update_checked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "como_gram_workspace_bytes": (c_long, []),
     "como_gram_f64": (c_int, [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "como_predictor_f64": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p] * 3),

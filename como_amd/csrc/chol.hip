@@ -24,6 +24,9 @@ namespace como {
 
 int cholp_init();                                                                      // csrc/cholp.hip
 int cholp_solve(double* delta, void* workspace, int D, int* info, hipStream_t s);      // COMO_OK, or COMO_ERR_ARG: not applicable
+int cholp_set_enabled(int e);
+int cholp_enabled();
+void cholp_set_stall(int on);
 
 
 __global__ __launch_bounds__(256) void chol_pack_kernel(const double* __restrict__ H, const double* __restrict__ g,
@@ -719,5 +722,9 @@ int como_chol_solve_f64(const double* H, const double* g, double* delta, void* w
 int como_chol_solve_packed_f64(double* delta, void* workspace, int D, int* info, como_stream_t stream) {
   return chol_solve_impl(nullptr, nullptr, delta, workspace, D, info, stream, true);
 }
+
+int como_chol_set_persistent(int enable) { return como::cholp_set_enabled(enable); }
+int como_chol_persistent_state(void) { return como::cholp_enabled(); }
+void como_chol_debug_stall(int on) { como::cholp_set_stall(on); }
 
 }  // extern "C"

@@ -51,6 +51,7 @@ struct CholpArgs {
   double* delta;
   int* info;
   int Dp, D, np;
+  int dbg_stall;        // test switch (como_chol_debug_stall): the chain workgroup leaves at once -> every other workgroup's wait times out
 };
 
 #ifdef COMO_CP_PROFILE                         // scripts/micro/cholp_stamps.hip: wall-clock stamps (100 MHz) of the chain workgroup, [pair][8]
@@ -519,7 +520,7 @@ __device__ __attribute__((noinline)) void cp_workers_call(CholpArgs a, double* d
 template <int MAXT>
 __global__ __launch_bounds__(CP_THREADS) void cholp_kernel(CholpArgs a) {
   extern __shared__ __attribute__((aligned(16))) double dsm[];
-  if (blockIdx.x == 0) cp_chain(a, dsm);
+  if (blockIdx.x == 0) { if (!a.dbg_stall) cp_chain(a, dsm); }
   else if (MAXT <= 2) cp_workers_body<MAXT>(a, dsm, (int)blockIdx.x - 1, (int)gridDim.x - 1);
   else cp_workers_call<MAXT>(a, dsm, (int)blockIdx.x - 1, (int)gridDim.x - 1);
 }
@@ -538,6 +539,13 @@ int cholp_init() {
         hipFuncSetAttribute((const void*)cholp_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess ||
         hipFuncSetAttribute((const void*)cholp_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
       n = 0;
+    // every workgroup of the launch (at most one per compute unit) must be resident at once: the kernel spin-waits on its peers
+    int occ = 0;
+    if (n > 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)cholp_kernel<1>, CP_THREADS, (size_t)bytes) != hipSuccess || occ < 1 ||
+                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)cholp_kernel<2>, CP_THREADS, (size_t)bytes) != hipSuccess || occ < 1 ||
+                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)cholp_kernel<4>, CP_THREADS, (size_t)bytes) != hipSuccess || occ < 1 ||
+                  hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)cholp_kernel<8>, CP_THREADS, (size_t)bytes) != hipSuccess || occ < 1))
+      n = 0;
     (void)hipGetLastError();
     const char* e = getenv("COMO_CHOLP");                  // COMO_CHOLP=0: the multi-launch solver (the fallback), for A/B runs
     if (e && atoi(e) == 0) n = 0;
@@ -549,8 +557,14 @@ int cholp_init() {
 // The persistent solve of a system that is already packed into `workspace` (chol_pack_kernel / como_sys_finalize_pack: they also
 // reset info and the counters).  COMO_ERR_ARG when the size or the device does not allow it (the caller falls back to the
 // multi-launch solver).
+static int g_cholp_enabled = 1;        // como_chol_set_persistent
+static int g_cholp_stall = 0;          // como_chol_debug_stall
+void cholp_set_stall(int on) { g_cholp_stall = on ? 1 : 0; }
+int cholp_set_enabled(int e) { const int p = g_cholp_enabled; g_cholp_enabled = e ? 1 : 0; return p; }
+int cholp_enabled() { return g_cholp_enabled && cholp_init() >= 2; }
+
 int cholp_solve(double* delta, void* workspace, int D, int* info, hipStream_t s) {
-  if (!cholp_size_ok(D)) return COMO_ERR_ARG;
+  if (!g_cholp_enabled || !cholp_size_ok(D)) return COMO_ERR_ARG;
   const int np = chol_np(D);
   const int cus = cholp_init();
   if (cus < 2) return COMO_ERR_ARG;
@@ -568,6 +582,7 @@ int cholp_solve(double* delta, void* workspace, int D, int* info, hipStream_t s)
   a.sync = (unsigned*)(a.W + cholp_sync_offset(a.Dp, np));
   a.delta = delta;
   a.info = info;
+  a.dbg_stall = g_cholp_stall;
   const dim3 grid(1 + workers), blk(CP_THREADS);
   const size_t lds = CP_LDS_DOUBLES * sizeof(double);
   if (per <= 1) hipLaunchKernelGGL(cholp_kernel<1>, grid, blk, lds, s, a);

@@ -865,11 +865,17 @@ int como_nn_gn_finalize_f32(const double* sums, const float* gamma, const float*
   return COMO_OK;
 }
 
-long como_nn_deep_part_floats(int N, int Cin, int Cout, int H, int W) {
-  const int HW = H * W, tiles = ((HW + 63) / 64) * ((Cout + 15) / 16) * N;
+// channel slices of a reduction-split layer: >= 384 workgroups, >= 8 reduction steps per wave -- counted on the REAL input channels
+// (rounded up to 4), whatever padding CinP carries, so that the scratch size below and the launcher always agree
+static int deep_slices(int N, int Cin, int Cout, int HW) {
+  const int tiles = ((HW + 63) / 64) * ((Cout + 15) / 16) * N;
   int ns = 1;
   while (ns < 16 && tiles * ns < 384 && (((Cin + 3) / 4) / (ns * 2)) >= 8) ns *= 2;
-  return (long)ns * N * Cout * HW;
+  return ns;
+}
+
+long como_nn_deep_part_floats(int N, int Cin, int Cout, int H, int W) {
+  return (long)deep_slices(N, Cin, Cout, H * W) * N * Cout * H * W;
 }
 
 int como_nn_conv3x3_deep_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
@@ -881,9 +887,8 @@ int como_nn_conv3x3_deep_f32(const float* in, const float* wt, const float* bias
       out_ctot < out_coff + Cout || G <= 0 || (Cout % G) || ((gamma != nullptr) != (beta != nullptr)) || (scsh && !gamma))
     return COMO_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const int HW = H * W, tiles = ((HW + 63) / 64) * ((Cout + 15) / 16) * N;
-  int ns = 1;                                               // channel slices: >= 384 workgroups, >= 8 reduction steps per wave
-  while (ns < 16 && tiles * ns < 384 && ((CinP / 4) / (ns * 2)) >= 8) ns *= 2;
+  const int HW = H * W;
+  const int ns = deep_slices(N, Cin, Cout, HW);
   if ((long)ns * N * Cout * HW > part_floats) return COMO_ERR_ARG;
   const dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((Cout + 15) / 16), (unsigned)(N * ns));
   if (pro_scsh)

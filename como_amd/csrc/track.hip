@@ -277,7 +277,8 @@ int track_iter(const T* Tji, const T* Kmat, const T* aff, const T* P, const T* v
 constexpr int TL_MAXP = 5;          // reference pixels per thread
 constexpr int TL_POISON = 63;       // word of the 64-entry integer plane of the device-wide sums that counts non-finite shares (TRK_ACC <= 63)
 constexpr int TL_NC = 8;            // arrival counters of the device-wide barrier (workgroup b -> counter b % 8)
-constexpr int TL_BAR_WORDS = 32 * (TL_NC + 1);       // counters 128 B apart, then the error flag
+constexpr int TL_BAR_WORDS = 32 * (TL_NC + 2);       // counters 128 B apart, then the error flag, then the XCD census (own line)
+constexpr int TL_XCC_WORD = 32 * (TL_NC + 1);        // 64-bit word: byte x = number of participating workgroups that run on XCD x
 constexpr int TL_SUM_WORDS = 2 * 2 * 64;             // two parities x {integer parts, fractions} x 64 (46 used) 64-bit sums
 
 template <typename U>
@@ -397,10 +398,23 @@ __global__ __launch_bounds__(256) void track_level_kernel(
   // (workgroup-scope atomics, no wait for a value returned from the memory side) and read back with L1-bypassing loads: a barrier
   // is an L2 round trip (~0.5 us) instead of a trip to the memory side + an L2 invalidate (~4.5 us).
   const int tid = threadIdx.x;
+  const int xdbg = xl >> 1;            // (debug switch of the census test: workgroup 1 reports a neighbouring XCD)
+  xl &= 1;
   if (xl && (blockIdx.x & 7)) return;
   const int bidx = xl ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int G = xl ? (int)(gridDim.x >> 3) : (int)gridDim.x;
   TLBarrier B{bar, 0u, G, ws_cached, xl, bidx};
+  // XCD census: that the kept workgroups share one XCD is an assumption about the dispatcher (round robin from XCD 0), checked
+  // INSIDE the launch that depends on it: every participant adds one to the byte of the XCD it really runs on (HW_REG_XCC_ID),
+  // memory-side (agent scope) on a line nothing else touches; workgroup 0 reads the census after the last iteration and
+  // reports status -2 unless all G sit on one XCD (the host then discards the result and stops using this form).
+  if (xl && tid == 0) {
+    unsigned id;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(id));
+    id &= 7u;
+    if (xdbg && bidx == 1) id = (id + 1u) & 7u;
+    __hip_atomic_fetch_add((unsigned long long*)(bar + TL_XCC_WORD), 1ull << (8 * id), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 
   // ---- this thread's reference pixels, register-resident for the whole level ----
   // (C channels: an element = (pixel, channel) of vals_i (N,C) / J8 (N,C,8); its target plane is img + channel * H * W)
@@ -697,6 +711,20 @@ __global__ __launch_bounds__(256) void track_level_kernel(
     if (it >= crit.max_iter || dnorm < crit.delta_norm || rel < crit.rel_tol || gnorm < crit.grad_norm) break;
   }
   if (!alive && bidx == 0 && tid == 0) out[104] = T(-1);        // a barrier timed out
+  if (xl && bidx == 0 && tid == 0) {
+    // the census is complete when its bytes add up to G (the other workgroups added theirs when they started, tens of
+    // microseconds ago; returning memory-side atomics as the read: never a stale cached copy); bounded wait
+    unsigned long long v = 0;
+    unsigned total = 0, used = 0;
+    for (int spin = 0; spin < 20000; ++spin) {
+      v = __hip_atomic_fetch_add((unsigned long long*)(bar + TL_XCC_WORD), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      total = 0; used = 0;
+      for (int x = 0; x < 8; ++x) { const unsigned c = (unsigned)((v >> (8 * x)) & 0xffull); total += c; used += c != 0; }
+      if (total >= (unsigned)G) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (total != (unsigned)G || used != 1) out[104] = T(-2);    // not one XCD: every cross-workgroup value above is suspect
+  }
 }
 
 __global__ void xcc_probe_kernel(int* __restrict__ xcc) {
@@ -708,6 +736,9 @@ __global__ void xcc_probe_kernel(int* __restrict__ xcc) {
 }
 
 }  // namespace como
+
+static int g_track_local_enabled = 1;   // como_track_level_set_local
+static int g_track_local_debug = 0;     // como_track_level_debug_mismatch
 
 extern "C" {
 
@@ -774,7 +805,8 @@ int como_track_level_local_f32(const float* Tji_init, const float* K, const floa
     ncu = prop.multiProcessorCount;
   }
   long G = (NE + 255) / 256;
-  const bool local = local_workspace && NE <= 32L * 256 * TL_MAXP && ncu >= 256 && como_track_level_probe() == 1;
+  const bool local = local_workspace && NE <= 32L * 256 * TL_MAXP && ncu >= 256 && como_track_level_probe() == 1 &&
+                     g_track_local_enabled;
   if (local) {
     if (G > 32) G = 32;                       // the compute units of one XCD: all co-resident
     workspace = local_workspace;
@@ -793,10 +825,21 @@ int como_track_level_local_f32(const float* Tji_init, const float* K, const floa
   TLCriteria crit{max_iter, delta_norm, rel_tol, grad_norm};
   hipLaunchKernelGGL(track_level_kernel, dim3((unsigned)(local ? 8 * G : G)), dim3(256), 0, s, Tji_init, K, aff_init, P, vals_i, img,
                      H, W, N, J8, in_mask, crit, bar, hists2, sums2, stamps, out, (int)ppt, workspace_uncached ? 0 : 1, channels,
-                     local ? 1 : 0);
+                     local ? (1 | (g_track_local_debug ? 2 : 0)) : 0);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }
+
+/* The XCD-local form can be switched off for the rest of the process (the host does so when a level reports status -2 or a
+ * time-out); returns the previous setting.  como_track_level_local_state: 1 = the coarse levels run XCD-local. */
+int como_track_level_set_local(int enable) {
+  const int prev = g_track_local_enabled;
+  g_track_local_enabled = enable ? 1 : 0;
+  return prev;
+}
+int como_track_level_local_state(void) { return (g_track_local_enabled && como_track_level_probe() == 1) ? 1 : 0; }
+/* Test switch: workgroup 1 of an XCD-local launch reports a neighbouring XCD in the census -> status -2. */
+void como_track_level_debug_mismatch(int on) { g_track_local_debug = on ? 1 : 0; }
 
 int como_track_level_channels_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P,
                                   const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,

@@ -405,7 +405,11 @@ __global__ __launch_bounds__(256) void win_priors_kernel(PriorArgs A, int B, int
 
 __global__ __launch_bounds__(256) void win_update_kernel(const double* __restrict__ delta, double* __restrict__ poses,
                                                          double* __restrict__ aff, const long* __restrict__ frame_inds,
-                                                         int F, double* __restrict__ P_m, int L, long lm_start) {
+                                                         int F, double* __restrict__ P_m, int L, long lm_start,
+                                                         const int* __restrict__ info) {
+  // a solve that did not complete (info != 0: non-positive pivot, or -1 = the persistent solver timed out and left `delta`
+  // unwritten) must not move the state: the update is skipped and the caller reads `info` at its next synchronisation
+  if (info && *info != 0) return;
   const int tid = blockIdx.x * 256 + threadIdx.x;
   if (tid < F) {
     const long* ix = frame_inds + 8 * (long)tid;
@@ -560,15 +564,20 @@ int como_win_priors(const como_win_args* a, como_stream_t stream) {
   return COMO_OK;
 }
 
-int como_win_update(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
-                    long lm_start, como_stream_t stream) {
+int como_win_update_checked(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
+                            long lm_start, const int* info, como_stream_t stream) {
   if (!delta || !poses || !aff || !frame_inds || !P_m || F <= 0 || L <= 0) return COMO_ERR_ARG;
   int blocks = (3 * L + 255) / 256;
   if (blocks < (F + 255) / 256) blocks = (F + 255) / 256;
   hipLaunchKernelGGL(como::win_update_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, delta, poses, aff, frame_inds, F,
-                     P_m, L, lm_start);
+                     P_m, L, lm_start, info);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
+}
+
+int como_win_update(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
+                    long lm_start, como_stream_t stream) {
+  return como_win_update_checked(delta, poses, aff, frame_inds, F, P_m, L, lm_start, nullptr, stream);
 }
 
 int como_se3_inverse_f32(const float* T, float* out, int n, como_stream_t stream) {

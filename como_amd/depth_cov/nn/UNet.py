@@ -59,13 +59,21 @@ def _groupnorm(x, gamma, beta, act, residual=None, sums=None):
 
 
 DEEP_MAX_PIXELS = 768   # levels of 24x32 and below run their 3x3 layers on the reduction-split kernels (csrc/nn.hip conv3_deep)
-_deep_part = {}         # per device: the partial-sum scratch of the deep layers (grow-only; one stream at a time per device)
+_deep_part = {}         # per (device, stream): the partial-sum scratch of the deep layers (grow-only)
+_deep_retired = []      # superseded scratch blocks: NEVER released -- a captured forward (DepthCovModule.forward_graphed) has the raw
+                        # address of the block that was current at capture time baked into its kernel arguments; handing that block
+                        # back to the caching allocator would let a replay write partial sums into somebody else's tensor.
+                        # (1.5 MB per network size: a handful of blocks per process at most.)
 
 
 def _deep_scratch(dev, need):
-    key = str(dev)
+    """Scratch of at least `need` floats for the reduction-split layers, keyed by device AND stream (two networks running on two
+    streams of one device -- two mappers -- must not share partial sums, like distill_depth._gram_ws / dense_ref._di_ws)."""
+    key = (str(dev), _lib.stream_ptr(dev))
     buf = _deep_part.get(key)
     if buf is None or buf.numel() < need:
+        if buf is not None:
+            _deep_retired.append(buf)
         buf = _deep_part[key] = torch.empty(need, dtype=torch.float32, device=dev)
     return buf
 

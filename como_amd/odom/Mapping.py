@@ -267,12 +267,14 @@ class Mapping:
                 self.depth_imgs_of(ind, end))
 
     def get_kf_viz_data(self, ind=-1):
-        """Mapping.py:514-544: cloned snapshot for a viewer.  The GUI is out of scope: the headless loop
-        takes no snapshot -- 2 x all depth images + clones of the colour images and the window state per keyframe, ~40 launches --
-        unless the mapping config says `viewer_snapshots: true`; the send time is kept either way (MappingSeq.map's 1 s rule)."""
+        """Mapping.py:514-544: cloned snapshot for a viewer -- the reference's 10-tuple, returned by default as the reference does.
+        The GUI is out of scope: a headless loop that has no consumer for it sets `viewer_snapshots: false`
+        in the mapping config (bench.py, como_amd.run, scripts/ate_sequence.py do) and gets None -- 2 x all depth images + clones of
+        the colour images and the window state per keyframe, ~40 launches saved; the send time is kept either way (MappingSeq.map's
+        1 s rule)."""
         import time
         self.last_kf_send_time = time.time()
-        if not self.cfg.get("viewer_snapshots", False):
+        if not self.cfg.get("viewer_snapshots", True):
             return None
         return (self.kf_timestamps.copy(), self.rgb.clone(), self.kf_poses.clone(), self.depth_imgs.clone(),
                 swap_coords_xy(self.pm).clone(), self.P_m.clone(), self.obs_ref_mask.clone(), self.recent_poses.clone(),
@@ -476,7 +478,31 @@ class Mapping:
                 st[name + "_pix"] = mirror
         return st
 
+    def _check_solver(self):
+        """The status word of the PREVIOUS iteration's solve, acted on without a synchronisation of its own: iterate() leaves an
+        asynchronous copy of it in pinned host memory behind the iteration; by the time the next frame reaches the mapper the
+        tracker has synchronised with the device (its per-frame read-back), so the event below is long complete.
+        -1 (the persistent solver timed out -- csrc/cholp.hip; the device-side guard of the update kept the state): the persistent
+        form is switched off for the process and the loop goes on (that frame simply had no Gauss-Newton step); > 0 (H not positive
+        definite / non-finite): RuntimeError -- the reference would silently continue on garbage (linear_system.py:109)."""
+        ev = getattr(self, "_info_event", None)
+        if ev is None:
+            return
+        self._info_event = None
+        ev.synchronize()
+        v = int(self._info_host[0])
+        if v == 0:
+            return
+        if v == -1:
+            from como_amd import _lib
+            _lib.lib().como_chol_set_persistent(0)
+            self.solver_fallbacks = getattr(self, "solver_fallbacks", 0) + 1
+            return
+        raise RuntimeError(f"como_amd Mapping: the window's normal equations were not positive definite (Cholesky info {v}) in "
+                           f"iteration {self.iter}; that update was not applied")
+
     def iterate(self):
+        self._check_solver()
         if self._ba is None:
             cfg = {"photo_construction": self.cfg["photo_construction"], "sigmas": self.cfg["sigmas"]}
             # (eager launches: a topology lives for ~2-3 iterations in the sequential loop, less than a graph capture costs)
@@ -485,6 +511,13 @@ class Mapping:
             self._ba_prev = None
         ba = self._ba
         ba.step()
+        info = getattr(ba, "info", None)
+        if info is not None and info.is_cuda:
+            if getattr(self, "_info_host", None) is None:
+                self._info_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._info_host.copy_(info, non_blocking=True)
+            self._info_event = torch.cuda.Event()
+            self._info_event.record()
         # refresh the public state from the solver's buffers (two copies: snapshot_state)
         sn = ba.snapshot_state(self.dtype)
         B = ba.B

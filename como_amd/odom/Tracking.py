@@ -343,8 +343,9 @@ class Tracking:
         T, aff, T_w, sc = out
         v = sc.tolist()                                 # the frame's one host synchronisation
         nl = len(v) - 34 - 3                            # pyramid levels
-        if min(v[3:3 + nl]) < 0:                        # a device-wide barrier of a level kernel timed out: track eagerly
-            _pt.photo_tracking_pyr.fallbacks = getattr(_pt.photo_tracking_pyr, "fallbacks", 0) + 1
+        if min(v[3:3 + nl]) < 0:                        # a level kernel's barrier timed out / XCD census failed: track eagerly
+            if _pt.level_kernel_failed():               # (the XCD-local form is off from now on: the graph holds the old launches)
+                self._fg = None
             return None
         keep = sc[3 + nl:].clone()                      # (the graph's buffers are overwritten by the next replay)
         return (keep[:16].view(1, 4, 4).to(T.dtype), keep[16:18].view(1, 2, 1).to(aff.dtype), keep[18:34].view(1, 4, 4).to(T_w.dtype),

@@ -1,8 +1,11 @@
 """Normal-equation helpers, mirroring the reference's como/odom/backend/linear_system.py.
 
-solve_system / update_vars keep the reference signatures (:101-152).  The dense Cholesky runs on the
-device through torch.linalg (rocSOLVER) -- D is 8 B + 8 R + 3 L ~ 760..2400; `info` from the
-factorisation is kept in `solve_system.last_info` instead of being swallowed.
+solve_system / update_vars keep the reference signatures (:101-152).  The dense float64 Cholesky (D = 8 B + 8 R + 3 L ~ 760..2700)
+runs on the hand-written HIP solvers: csrc/cholp.hip -- the whole solve in ONE persistent launch, up to 34 column pairs
+(D <= 2175) -- and csrc/chol.hip -- the multi-launch panel solver beyond that, or everywhere after
+`como_chol_set_persistent(0)` / COMO_CHOLP=0.  `info` from the factorisation is kept in `solve_system.last_info` instead of
+being swallowed (-1 = the persistent solver timed out); WindowBA guards its update with it and `WindowBA.check_solver` /
+`Mapping._check_solver` act on it.
 """
 import torch
 
@@ -74,9 +77,9 @@ def _chol_entry(D, device, store, shared):
 def solve_system(H, g, ws=None):
     """ws: caller-owned dict for the factorisation workspace (a captured graph records its address; None: process-wide).
     delta (D,1) = H^-1 g by dense Cholesky (reference :101-112).  float64 systems on the GPU run the HIP factorisation of
-    csrc/cholp.hip (one persistent launch, D < 1024) / csrc/chol.hip (graph-capturable, ~13x hipSOLVER at D = 760); float32 systems
-    (the reference-signature path with a float32 H) go through torch.linalg.  `solve_system.last_info` holds the factorisation
-    status (device int)."""
+    csrc/cholp.hip (one persistent launch, D <= 2175) / csrc/chol.hip (multi-launch, larger systems; both graph-capturable);
+    float32 systems (the reference-signature path with a float32 H) go through torch.linalg.  `solve_system.last_info` holds
+    the factorisation status (device int: 0, the 1-based pivot that was not positive, or -1 = persistent solver timed out)."""
     if H.is_cuda and H.dtype == torch.float64:
         from como_amd import _lib
         L = _lib.lib()

@@ -382,6 +382,15 @@ def photo_tracking_levels_static(Tji_init, aff_init, pb, img_j, intrinsics, term
     return Tji, aff, outs
 
 
+def level_kernel_failed():
+    """A persistent level kernel reported a negative status ([104] = -1: a barrier timed out, -2: an XCD-local level did not sit on
+    one XCD -- csrc/track.hip's in-launch census): the caller discards the frame's result and tracks it again on the per-iteration
+    chain; the XCD-local form is switched off for the rest of the process (every later level runs device-wide).  Returns True when
+    that changed the form the next launches take -- a captured frame graph holds the old form and has to be dropped."""
+    photo_tracking_pyr.fallbacks = getattr(photo_tracking_pyr, "fallbacks", 0) + 1
+    return _lib.lib().como_track_level_set_local(0) == 1
+
+
 def photo_tracking_pyr(Tji_init, aff_init, vals_i, Pi, dI_dT, masks, intrinsics, img_j, photo_sigma, term_criteria):
     """reference photo_tracking.py:10-42 (lists ordered coarse -> fine).
     The reference gathers the masked subset of vals / P / dI_dT on every frame; here the full arrays are copied into
@@ -410,6 +419,6 @@ def photo_tracking_pyr(Tji_init, aff_init, vals_i, Pi, dI_dT, masks, intrinsics,
     # the converged one.  ONE scalar per frame decides (the caller synchronises right after tracking anyway for its keyframe
     # tests): on a time-out the frame is tracked again by the per-iteration chain.
     if bad is not None and bool(bad):
-        photo_tracking_pyr.fallbacks = getattr(photo_tracking_pyr, "fallbacks", 0) + 1
+        level_kernel_failed()
         Tji, aff, _ = run(False)
     return Tji, aff

@@ -611,12 +611,42 @@ class WindowBA:
         H, g = self.linearize_fused()
         delta = (lin_sys.solve_packed(self.dim, self.dev, self.w["chol_ws"]) if self._packed
                  else lin_sys.solve_system(H, g, ws=self.w["chol_ws"]))
-        rc = _lib.lib().como_win_update(delta.data_ptr(), self.poses_all.data_ptr(), self.aff_all.data_ptr(),
-                                        self.frame_inds.data_ptr(), self.F, self.P_m.data_ptr(), self.L, self.lm_start,
-                                        _lib.stream_ptr(self.dev))
+        # the update is guarded by the solver's status word ON THE DEVICE: a solve that did not complete (non-positive pivot;
+        # -1 = the persistent solver timed out and left delta unwritten) leaves the state as it is -- `check_solver` / the
+        # sequential loop's read-back (Mapping._check_solver) decide what happens next
+        self.info = lin_sys.solve_system.last_info
+        rc = _lib.lib().como_win_update_checked(delta.data_ptr(), self.poses_all.data_ptr(), self.aff_all.data_ptr(),
+                                                self.frame_inds.data_ptr(), self.F, self.P_m.data_ptr(), self.L, self.lm_start,
+                                                self.info.data_ptr(), _lib.stream_ptr(self.dev))
         _lib.check(rc, "como_win_update")
         self.delta = delta
         return delta
+
+    def check_solver(self):
+        """Read the status of the last solve (one host synchronisation) and act on it -- the reference swallows it
+        (linear_system.py:109 cholesky_ex(check_errors=False)); SURVEY.md section 5 asks for it to be acted on:
+          0   -> True;
+          -1  -> the persistent one-launch solver's waits timed out (its workgroups were not co-resident: another process or
+                 kernel on the device): the guarded update did not run; the persistent form is switched off for the process, a
+                 captured iteration is captured again on the multi-launch solver, the iteration is redone; returns False;
+          > 0 -> H is not positive definite at that pivot (or holds a non-finite entry): RuntimeError, state untouched."""
+        info = getattr(self, "info", None)
+        if info is None:
+            return True
+        v = int(info.item())
+        if v == 0:
+            return True
+        if v == -1:
+            _lib.lib().como_chol_set_persistent(0)
+            WindowBA.solver_fallbacks = getattr(WindowBA, "solver_fallbacks", 0) + 1
+            if self.graph is not None:
+                self.capture()
+            self.step()
+            if int(self.info.item()) != 0:
+                raise RuntimeError(f"como_amd: window solve failed again on the multi-launch solver (info {int(self.info.item())})")
+            return False
+        raise RuntimeError(f"como_amd: the window's normal equations are not positive definite (Cholesky info {v}); "
+                           "the state was left unchanged")
 
     # ---- the same iteration through the reference-signature mirrors (torch ops for the O(B m) parts) ---------------
     def scaffold(self):

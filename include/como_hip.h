@@ -104,7 +104,7 @@ int como_track_iter_masked_f64(const double* Tji, const double* K, const double*
  *   como_track_level_workspace_create() (uncached device memory: the device-wide barriers then need no L2 invalidate,
  *   40 instead of 50 us per iteration at 640x480), 0 for ordinary device memory.
  *   out (106): the como_track_iter_* record of the LAST iteration run (T at [80:96), aff at [96:98)), [104] = cholesky
- *   info or -1 if the device-wide barrier timed out, [105] = number of iterations run.
+ *   info, -1 if a barrier timed out, -2 if an XCD-local level did not sit on one XCD; [105] = number of iterations run.
  * Returns COMO_ERR_ARG when N exceeds 5 x 256 x (number of compute units) pixels (use the chain then). */
 long como_track_level_workspace_bytes(void);
 /* allocator of such a workspace in UNCACHED device memory (hipDeviceMallocUncached; call outside stream capture); NULL if the
@@ -173,6 +173,14 @@ int como_track_level_local_f32(const float* Tji_init, const float* K, const floa
                                const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
                                void* workspace, int workspace_uncached, void* local_workspace, float* out, como_stream_t stream);
 int como_track_level_probe(void);
+/* Round 6: the XCD-local form verifies its own placement INSIDE the launch: every participating workgroup records the XCD it runs
+ * on (HW_REG_XCC_ID) and out[104] = -2 is reported unless all of them share one (the result must then be discarded: the caller
+ * tracks the frame again and calls como_track_level_set_local(0), after which every level runs in the device-wide form).
+ * como_track_level_set_local returns the previous setting; como_track_level_local_state = 1 while coarse levels run XCD-local;
+ * como_track_level_debug_mismatch(1) makes workgroup 1 report a neighbouring XCD (the test of the -2 path). */
+int como_track_level_set_local(int enable);
+int como_track_level_local_state(void);
+void como_track_level_debug_mismatch(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Window BA linearisation (python path: backend/photo.py:83-233 batch_photo_cost).
@@ -434,6 +442,16 @@ int como_chol_solve_f64(const double* H, const double* g, double* delta, void* w
                         como_stream_t stream);
 /* the factorisation + substitutions of a system como_sys_finalize_pack already packed into `workspace` */
 int como_chol_solve_packed_f64(double* delta, void* workspace, int D, int* info, como_stream_t stream);
+/* The persistent one-launch solver (csrc/cholp.hip) spin-waits on counters and needs all its workgroups co-resident (checked once
+ * against hipOccupancyMaxActiveBlocksPerMultiprocessor x compute units); when they are not -- another process or kernel holds
+ * compute units -- its bounded waits time out, *info = -1 and delta is left unwritten.  como_chol_set_persistent(0) selects the
+ * multi-launch solver for the rest of the process (what a caller does after reading info = -1, before solving again; several
+ * processes sharing one device should start with it off: COMO_CHOLP=0).  Returns the previous setting. */
+int como_chol_set_persistent(int enable);
+int como_chol_persistent_state(void);
+/* test switch: the persistent solver's chain workgroup leaves at once, so that the other workgroups' waits run into their
+ * time-out (~2 s) and the solve ends with *info = -1 -- the path a lost co-residency takes */
+void como_chol_debug_stall(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * Conditioning of the small SPD systems of the DepthCov path (n <= 80), batched: ONE launch, one workgroup per matrix, float32
@@ -520,6 +538,12 @@ int como_sys_finalize_pack(const void* sysfix, long fix_plane, long D, double* H
                            int* info, como_stream_t stream);
 int como_win_update(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
                     long lm_start, como_stream_t stream);
+/* The same, guarded by the solver's status word (device int, como_chol_solve_*'s `info`): with *info != 0 -- a non-positive pivot,
+ * or -1 = the persistent solver's time-out, which leaves delta unwritten -- nothing is updated (the reference swallows the error,
+ * linear_system.py:109, and applies whatever came out; SURVEY.md section 5 asks for the status to be acted on).  The caller reads
+ * `info` at its next synchronisation point and decides (re-solve on the multi-launch solver / raise). */
+int como_win_update_checked(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
+                            long lm_start, const int* info, como_stream_t stream);
 /* invertSE3 (como/geometry/lie_algebra.py:83-95 without the Jacobian; the inverse inside get_T_w_curr / get_rel_pose,
  * transforms.py:6-13): out[i] = [R^T | -(R^T t); 0 0 0 1] for n row-major 4x4 poses (in and out may not alias). */
 int como_se3_inverse_f32(const float* T, float* out, int n, como_stream_t stream);

@@ -38,7 +38,7 @@ def loop_cfgs(G, pix="float", dev="cuda:0", graph_network=False):
             "term_criteria": {"max_iter": 50, "delta_norm": 1.0e-3, "rel_tol": 1.0e-3, "grad_norm": 1.0},
             "sigmas": {"photo": 1.0e-1},
             "keyframing": {"kf_depth_motion_ratio": 0.12, "kf_num_pixels_frac": 0.75, "one_way_freq": 3}}
-    mcfg = {"device": dev, "dtype": "double", "pix_dtype": pix, "color": "rgb" if colour else "gray", "track_ref": {"num_keyframes": 1},
+    mcfg = {"device": dev, "dtype": "double", "pix_dtype": pix, "color": "rgb" if colour else "gray", "track_ref": {"num_keyframes": 1}, "viewer_snapshots": False,
             "graph": {"num_keyframes": 9, "num_one_way_frames": 24}, "network_size": net, "graph_network": graph_network,
             "photo_construction": {"nonmax_suppression_window": 4, "pairwise_batch_size": 128, "radius_thresh": 0.0,
                                    "degrees_thresh": 0.0},

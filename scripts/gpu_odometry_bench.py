@@ -28,7 +28,7 @@ def cfgs(dev, args):
                 "term_criteria": {"max_iter": 50, "delta_norm": 1.0e-3, "rel_tol": 1.0e-3, "grad_norm": 1.0},
                 "sigmas": {"photo": 1.0e-1},
                 "keyframing": {"kf_depth_motion_ratio": 0.12, "kf_num_pixels_frac": 0.75, "one_way_freq": 3}}
-    mapping = {"device": dev, "dtype": "double", "pix_dtype": args.pix, "color": "gray", "track_ref": {"num_keyframes": 1},
+    mapping = {"device": dev, "dtype": "double", "pix_dtype": args.pix, "color": "gray", "track_ref": {"num_keyframes": 1}, "viewer_snapshots": False,
                "graph": {"num_keyframes": 9, "num_one_way_frames": 24}, "network_size": [192, 256],
                "photo_construction": {"nonmax_suppression_window": 4, "pairwise_batch_size": 128, "radius_thresh": 0.0,
                                       "degrees_thresh": 0.0},

@@ -1,0 +1,134 @@
+"""Round-6 pins of the HIP path (through the C ABI), `-m gpu` on an MI355X:
+  * the two spin-wait kernels fail LOUDLY and recoverably: the XCD-local tracking level checks its own placement inside the
+    launch (status -2) and the host falls back; the persistent Cholesky's time-out (info -1) and a non-positive pivot never
+    reach the state (device-side guard of the update) and are acted on by `WindowBA.check_solver` / `Mapping._check_solver`
+    (the reference swallows the status: como/odom/backend/linear_system.py:109);
+  * (further down) the round's new kernels against the forms they replace."""
+import copy
+
+import pytest
+import torch
+
+from tests.conftest import report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_xcd_local_level_checks_its_own_placement():
+    """csrc/track.hip: every workgroup of an XCD-local level adds itself to a per-XCD census (HW_REG_XCC_ID) and workgroup 0 reports
+    status -2 unless all of them share one XCD.  (i) an ordinary launch passes the census (status 0); (ii) with the debug switch
+    one workgroup reports a neighbouring XCD: the level's record carries -2, `photo_tracking_pyr` discards the result, tracks
+    the frame on the per-iteration chain (the same pose as an undisturbed run) and switches the local form off for the process:
+    the next level launch runs device-wide with status 0."""
+    import como_amd.odom.frontend.photo_tracking as pt
+    from como_amd import _lib
+    from tests.test_gpu_r2 import _tracking_level_inputs
+    L = _lib.lib()
+    if L.como_track_level_probe() != 1:
+        pytest.skip("dispatcher placement probe says no XCD-local form on this device")
+    prev = L.como_track_level_set_local(1)
+    try:
+        H, W = 60, 80
+        tp, K, P, vals, J = _tracking_level_inputs(H, W, 3)
+        aff = torch.zeros((1, 2, 1), device=DEV)
+        mask = torch.ones(P.shape[1], dtype=torch.uint8, device=DEV)
+        term = {"max_iter": 50, "delta_norm": 1e-3, "rel_tol": 1e-3, "grad_norm": 1.0}
+        assert L.como_track_level_local_state() == 1
+        T0, a0 = pt.photo_level_tracking(tp["Tji_init"], aff, vals, P, J.clone(), tp["img_cur"], K, 0.1, term, in_mask=mask, fused=True)
+        rec0 = pt.photo_level_tracking.last_out.cpu()
+        assert int(rec0[104]) == 0 and int(rec0[105]) >= 1
+        # --- forced mismatch: the level itself reports it
+        L.como_track_level_debug_mismatch(1)
+        pt.photo_level_tracking(tp["Tji_init"], aff, vals, P, J.clone(), tp["img_cur"], K, 0.1, term, in_mask=mask, fused=True)
+        rec1 = pt.photo_level_tracking.last_out.cpu()
+        assert int(rec1[104]) == -2
+        # --- the pyramid entry point acts on it
+        fb0 = getattr(pt.photo_tracking_pyr, "fallbacks", 0)
+        Tp, ap = pt.photo_tracking_pyr(tp["Tji_init"], aff, [vals], [P], [J.clone()], [mask.bool()], [K], [tp["img_cur"]], 0.1, term)
+        assert getattr(pt.photo_tracking_pyr, "fallbacks", 0) == fb0 + 1
+        assert L.como_track_level_local_state() == 0
+        L.como_track_level_debug_mismatch(0)
+        Tc, ac = pt.photo_level_tracking(tp["Tji_init"], aff, vals, P, J.clone(), tp["img_cur"], K, 0.1, term, in_mask=mask, fused=False)
+        eT = (Tp - Tc).abs().max().item()
+        # --- and the device-wide form serves the same level from now on
+        T2, a2 = pt.photo_level_tracking(tp["Tji_init"], aff, vals, P, J.clone(), tp["img_cur"], K, 0.1, term, in_mask=mask, fused=True)
+        rec2 = pt.photo_level_tracking.last_out.cpu()
+        report("xcd_census", status_ok=int(rec0[104]), status_forced=int(rec1[104]), status_after=int(rec2[104]),
+               fallback_vs_chain=eT, wide_vs_local=(T2 - T0).abs().max().item())
+        assert int(rec2[104]) == 0 and int(rec2[105]) == int(rec0[105])
+        assert eT < 1e-7
+        assert (T2 - T0).abs().max().item() < 2e-6
+    finally:
+        L.como_track_level_debug_mismatch(0)
+        L.como_track_level_set_local(prev)
+
+
+def _small_window(seed=5, B=3, H=96, W=128, m=16):
+    from como_amd import synth
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    st = synth.make_window(B=B, H=H, W=W, m=m, dtype=torch.float64, device=DEV, seed=seed,
+                           predictor=lambda cov, cm: prep_predictor(cov, cm, 1.0))
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = 2
+    return WindowBA(st, cfg=cfg, pix_dtype=torch.float64, window_full=True)
+
+
+def test_solver_status_guards_the_update():
+    """(i) como_win_update_checked leaves poses / affine parameters / landmarks alone when the status word is non-zero;
+    (ii) the persistent solver's time-out (forced: its chain workgroup leaves at once, the others' bounded waits expire) ends with
+    info = -1, the window's state is bit-for-bit what it was, `check_solver` switches to the multi-launch solver, redoes the
+    iteration and lands where an undisturbed window lands; (iii) a non-finite system (a NaN landmark -> H[0][0] poisoned) raises
+    instead of updating."""
+    from como_amd import _lib
+    L = _lib.lib()
+    prev = L.como_chol_set_persistent(1)
+    try:
+        ref = _small_window()
+        d_ref = ref.iterate().clone()
+        assert ref.check_solver() is True
+        # (i)
+        wb = _small_window()
+        s0 = wb.state_flat.clone()
+        one = torch.ones(1, dtype=torch.int32, device=DEV)
+        rc = L.como_win_update_checked(d_ref.data_ptr(), wb.poses_all.data_ptr(), wb.aff_all.data_ptr(), wb.frame_inds.data_ptr(), wb.F,
+                                       wb.P_m.data_ptr(), wb.L, wb.lm_start, one.data_ptr(), _lib.stream_ptr(torch.device(DEV)))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.equal(wb.state_flat, s0)
+        # (ii)
+        persistent = L.como_chol_persistent_state() == 1
+        if persistent:
+            L.como_chol_debug_stall(1)
+            wb.iterate()
+            L.como_chol_debug_stall(0)
+            torch.cuda.synchronize()
+            assert int(wb.info.item()) == -1
+            # (the scaffold may re-initialise landmarks and the priors store median depths before the solve: compare poses / affine)
+            assert torch.equal(wb.poses_all.reshape(-1), s0[:16 * wb.F])
+            assert wb.check_solver() is False
+            assert L.como_chol_persistent_state() == 0
+            # the undisturbed twin: the timed-out pass had linearised once (median depths / re-initialised landmarks stored)
+            twin = _small_window()
+            twin.linearize()
+            twin.iterate()
+            e = (wb.poses_all - twin.poses_all).abs().max().item()
+            report("solver_timeout", info_after=int(wb.info.item()), pose_diff_vs_undisturbed=e)
+            assert int(wb.info.item()) == 0 and e < 1e-9
+            L.como_chol_set_persistent(1)
+        # (iii)
+        bad = _small_window()
+        p0 = bad.poses_all.clone()
+        bad.P_m[0, 0] = float("nan")
+        bad.iterate()
+        torch.cuda.synchronize()
+        assert int(bad.info.item()) > 0
+        assert torch.equal(bad.poses_all, p0)
+        with pytest.raises(RuntimeError, match="not positive definite"):
+            bad.check_solver()
+        report("solver_status", persistent=persistent, info_nan=int(bad.info.item()))
+    finally:
+        L.como_chol_debug_stall(0)
+        L.como_chol_set_persistent(prev)
