@@ -135,3 +135,36 @@ def test_ate_helpers():
     assert abs(s - 2.5) < 1e-12 and np.abs(Rr - R).max() < 1e-12
     assert ate_rmse(Q, P, "se3") > 1e-3                                          # a scale change is not an SE(3) alignment
     assert associate([0.0, 0.1, 0.2], [0.101, 0.3, 0.001]) == [(0, 2), (1, 0)]
+
+
+def test_runner_config_and_keyframe_history(tmp_path):
+    """como_amd.run: the YAML of config/como.yml parses into the two sections `ComoSeq` takes (one device, the reference's
+    constants); `device: cpu` is refused; `KeyframeHistory` is GuiWindow.update_kf_vars (:329-357) for timestamps / poses."""
+    import yaml
+    from como_amd import run
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = run.load_slam_cfg(os.path.join(root, "config", "como.yml"), device="cuda:3")
+    assert cfg["tracking"]["device"] == cfg["mapping"]["device"] == "cuda:3"
+    assert cfg["mapping"]["graph"] == {"num_keyframes": 9, "num_one_way_frames": 24}
+    assert cfg["mapping"]["sampling"]["max_num_coords"] == 64 and cfg["mapping"]["photo_construction"]["nonmax_suppression_window"] == 4
+    assert cfg["tracking"]["term_criteria"] == {"max_iter": 50, "delta_norm": 1e-3, "rel_tol": 1e-3, "grad_norm": 1.0}
+    assert cfg["mapping"]["pix_dtype"] == "double" and cfg["mapping"]["network_size"] == [192, 256] and cfg["mapping"]["viewer_snapshots"] is False
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        run.load_slam_cfg(os.path.join(root, "config", "como.yml"), device="cpu")
+    bad = tmp_path / "bad.yml"
+    bad.write_text(yaml.safe_dump({"tracking": {}}))
+    with pytest.raises(ValueError, match="mapping"):
+        run.load_slam_cfg(str(bad))
+    with pytest.raises(FileNotFoundError, match="random_weights"):
+        run.load_model({"model_path": str(tmp_path / "none.ckpt")}, "cpu")
+    # the history: window of 3; keyframes 1..5 inserted one at a time, poses refined while in the window
+    h = run.KeyframeHistory()
+    P = lambda v, n: torch.full((n, 4, 4), float(v))
+    h.update([1.0], P(10, 1))
+    h.update([1.0, 2.0], P(11, 2))
+    h.update([1.0, 2.0, 3.0], P(12, 3))
+    h.update([2.0, 3.0, 4.0], P(13, 3))            # keyframe 1 left the window: its last pose (12) stays
+    h.update([2.0, 3.0, 4.0], P(14, 3))
+    h.update([3.0, 4.0, 5.0], P(15, 3))
+    assert h.timestamps == [1.0, 2.0, 3.0, 4.0, 5.0]
+    assert [float(p[0, 0]) for p in h.poses] == [12.0, 14.0, 15.0, 15.0, 15.0]

@@ -132,3 +132,68 @@ def test_solver_status_guards_the_update():
     finally:
         L.como_chol_debug_stall(0)
         L.como_chol_set_persistent(prev)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def _write_tum_tree(root, n, step=0.02, deg=0.4, seed=1):
+    """A TUM-format sequence (`rgb.txt` + `rgb/<timestamp>.png`, freiburg3 = no rectification) rendered from the plane scene of the
+    pinned loop fixtures at the camera's native 480x640 with the freiburg3 intrinsics; returns (sequence path, GT poses)."""
+    import numpy as np
+    from PIL import Image
+    from como_amd import synth
+    from como_amd.data.odom_datasets import TumOdometryDataset
+    seq = root / "tum" / "rgbd_dataset_freiburg3_synthetic_plane"
+    (seq / "rgb").mkdir(parents=True)
+    K = torch.tensor(TumOdometryDataset.CAMERAS[3][0], dtype=torch.float64)
+    sc = synth.PlaneScene(seed=seed, freq_scale=0.4)
+    T = synth.gt_poses(n, step=step, deg=deg)
+    lines = ["# color images\n", "# file: synthetic\n", "# timestamp filename\n"]
+    for k in range(n):
+        I = sc.render(T[k], K, 480, 640)[0].clamp(0, 1)
+        u8 = (I * 255.0 + 0.5).to(torch.uint8).numpy()
+        ts = "%.6f" % (1000.0 + k / 30.0)
+        Image.fromarray(np.repeat(u8[..., None], 3, axis=2)).save(str(seq / "rgb" / (ts + ".png")))
+        lines.append(f"{ts} rgb/{ts}.png\n")
+    (seq / "rgb.txt").write_text("".join(lines))
+    return str(seq) + "/", T
+
+
+def test_headless_runner_on_a_tum_tree(tmp_path):
+    """`python -m como_amd.run` (como/como_dataset.py:11-37 + GuiWindow.update_main :528-599 + save_traj :359-367 without the
+    GUI): YAML -> dataset reader -> ComoSeq.iter per frame -> keyframe trajectory in TUM format.  The file equals what driving the
+    same pieces by hand writes (same frames, same config), the first frame never reaches the loop (as in the reference), the
+    initialisation completes, and the tracked trajectory follows the rendered camera path (sim(3)-aligned ATE)."""
+    import os
+    import numpy as np
+    from como_amd import run
+    from como_amd.utils.ate import ate_rmse
+    from como_amd.utils.io import tq_to_pose
+    n = 40
+    seq, T_gt = _write_tum_tree(tmp_path, n)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "results" / "traj.txt")
+    argv = ["--dataset_type", "tum", "--dataset_dir", seq, "--config", os.path.join(root, "config", "como.yml"), "--out", out,
+            "--device", DEV, "--random_weights", "0", "--pix_dtype", "float"]
+    assert run.main(argv) == out
+    rows = np.loadtxt(out).reshape(-1, 8)
+    frames = np.loadtxt(out[:-4] + "_frames.txt").reshape(-1, 8)
+    # by hand
+    ds = run.get_dataset("tum", [192, 256], seq)
+    cfg = run.load_slam_cfg(os.path.join(root, "config", "como.yml"), DEV, "float")
+    odo, hist, kinds = run.run_sequence(ds, cfg, run.load_model(cfg["mapping"], DEV, 0), first_frame=1)
+    assert len(kinds) == n - 1 and kinds[0] == "init"
+    assert rows.shape[0] == len(hist.timestamps) >= 3
+    assert np.allclose(rows[:, 0], np.round(np.array(hist.timestamps), 4))
+    want = torch.stack(hist.poses).numpy()
+    got = tq_to_pose(rows[:, 1:])
+    assert np.abs(got[:, :3, 3] - want[:, :3, 3]).max() < 1.01e-4            # (four decimals in the file)
+    assert rows[0, 0] == pytest.approx(round(1000.0 + 1 / 30.0, 4))          # keyframe 0 = frame 1: frame 0 is the renderer's
+    # the tracked poses against the rendered camera path
+    idx = [int(round((t - 1000.0) * 30.0)) for t in frames[:, 0]]
+    est = [torch.from_numpy(tq_to_pose(r[1:])) for r in frames]
+    gt = [T_gt[i] for i in idx]
+    ate = ate_rmse(est, gt, "sim3")
+    path = float(sum((T_gt[k + 1, :3, 3] - T_gt[k, :3, 3]).norm() for k in range(n - 1)))
+    report("headless_runner", frames=len(kinds), keyframes=int(rows.shape[0]), tracked=len(est), ate_sim3_vs_gt=ate, path_length=path,
+           kinds={str(k): kinds.count(k) for k in set(kinds)})
+    assert len(est) >= n - 6 and ate < 0.02 * path
