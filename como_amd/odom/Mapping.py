@@ -22,6 +22,8 @@ import os
 import torch
 
 _PIX_MIRRORS = os.environ.get("COMO_PIX_MIRRORS", "1") != "0"       # 0: every window rebuild converts the whole K~ / image window (A/B)
+_KEPT_MEDIANS = os.environ.get("COMO_KF_KEPT_MEDIANS", "1") != "0"  # 0: a keyframe insertion re-evaluates every keyframe's depth image (A/B)
+_RETARGET = os.environ.get("COMO_BA_RETARGET", "1") != "0"          # 0: a one-way frame builds a new window object, as round 5 (A/B)
 
 from como_amd.depth_cov.core.covariance import prep_predictor as _prep_predictor
 from como_amd.depth_cov.core.DepthCovModule import DepthCovModule, run_model as _run_model
@@ -280,14 +282,23 @@ class Mapping:
                 swap_coords_xy(self.pm).clone(), self.P_m.clone(), self.obs_ref_mask.clone(), self.recent_poses.clone(),
                 list(getattr(self, "kf_pairs", [])), list(getattr(self, "one_way_pairs", [])))
 
-    def store_vars(self, pm, logzm, Knm_Kmminv, kept_depths=None):
+    def store_vars(self, pm, logzm, Knm_Kmminv, kept_depths=None, kept_medians=None):
         """Mapping.py:749-758.  kept_depths: depth images of keyframes 0..B-2 that are known to be current (add_keyframe: the
-        log-depths of the keyframes that stay are untouched by the insertion) -- only the new keyframe's image is evaluated."""
+        log-depths of the keyframes that stay are untouched by the insertion) -- only the new keyframe's image is evaluated.
+        kept_medians (B-1,): the median depths of those keyframes as the last iteration stored them -- the exact medians of
+        exp(K~ logz_m) at the very log-depths `logzm` holds for them (Mapping.iterate publishes the scaffold's log-depths and the
+        medians of their depth images together): with them only the NEW keyframe's predictor is streamed (one 157 MB pass at
+        640x480 instead of nine + a nine-segment select: ~0.4 ms per keyframe insertion)."""
         self.pm, self.logzm = pm, logzm
         self._depth_cache = None
         B = self.logzm.shape[0]
         if kept_depths is not None and B > 1 and kept_depths.shape[0] == B - 1:
             self._depth_cache = torch.cat((kept_depths, self.depth_imgs_of(B - 1, B)), dim=0)
+        elif kept_medians is not None and B > 1 and kept_medians.dim() == 1 and kept_medians.shape[0] == B - 1 and _KEPT_MEDIANS:
+            d_new = self.depth_imgs_of(B - 1, B)
+            med_new = masked_median(d_new.reshape(1, -1)).to(d_new.dtype)
+            self.median_depths = torch.cat((kept_medians.to(d_new.dtype), med_new))
+            return
         d = self.depth_imgs
         d2 = d.reshape(d.shape[0], -1)
         # per-keyframe exact median of the full depth image: one segmented device select instead of B sorts
@@ -327,6 +338,9 @@ class Mapping:
         # depth images of the current window, if a snapshot just evaluated them (handle_tracking_data): still valid for the keyframes
         # that stay -- the insertion below does not touch their log-depths
         kept_depths = self._depth_cache[self.get_kf_start_window_ind():] if self._depth_cache is not None else None
+        md = getattr(self, "median_depths", None)
+        kept_medians = (md[self.get_kf_start_window_ind():] if (torch.is_tensor(md) and md.dim() == 1 and
+                                                                 md.shape[0] == self.kf_poses.shape[0]) else None)
         p_m_new = swap_coords_xy(coords_m_new).to(dtype=z_m_new.dtype)
         Pc_new = backprojection_points(self.intrinsics[0], p_m_new, z_m_new)
         Pw_new = transform_points_values(kf_pose_init, Pc_new)
@@ -338,7 +352,7 @@ class Mapping:
         self.initialize_sparse_pixel_vars(pm_first_obs, zm_first_obs, coords_m_new.shape[1], Kmm_inv, L_mm, Knm_Kmminv)
         self.initialize_sparse_landmark_vars(corr_mask, Pw_new.squeeze(0))
         self.reset_iteration_vars(new_kf=True)
-        self.store_vars(self.pm, self.logzm, self.Knm_Kmminv, kept_depths=kept_depths)
+        self.store_vars(self.pm, self.logzm, self.Knm_Kmminv, kept_depths=kept_depths, kept_medians=kept_medians)
         self.prune_one_way()
 
     def prune_one_way(self):
@@ -505,9 +519,14 @@ class Mapping:
         self._check_solver()
         if self._ba is None:
             cfg = {"photo_construction": self.cfg["photo_construction"], "sigmas": self.cfg["sigmas"]}
+            prev = getattr(self, "_ba_prev", None)
+            st = self._window_state()
             # (eager launches: a topology lives for ~2-3 iterations in the sequential loop, less than a graph capture costs)
-            self._ba = WindowBA(self._window_state(), cfg=cfg, pix_dtype=self.pix_dtype, window_full=self.window_full,
-                                prev=getattr(self, "_ba_prev", None))
+            if prev is not None and _RETARGET and prev.retarget(st, window_full=self.window_full):
+                self._ba = prev                              # same keyframes, another set of one-way frames: the object stays
+            else:
+                self._ba = WindowBA(st, cfg=cfg, pix_dtype=self.pix_dtype, window_full=self.window_full, prev=prev,
+                                    rec_capacity=self.cfg["graph"]["num_one_way_frames"])
             self._ba_prev = None
         ba = self._ba
         ba.step()

@@ -57,12 +57,16 @@ def _ar(n, dev, dtype=torch.long):
 
 
 class WindowBA:
-    def __init__(self, state, cfg=None, pix_dtype=torch.float32, window_full=True, shard=None, fused=True, prev=None):
+    def __init__(self, state, cfg=None, pix_dtype=torch.float32, window_full=True, shard=None, fused=True, prev=None, rec_capacity=None):
         """state: dict as produced by como_amd.synth.make_window (plus K_mm_inv / L_mm / Knm_Kmminv).
         shard: como_amd.dist.Shard for the one-process-per-GPU data-parallel mode (None = single GPU).
-        prev: the WindowBA this one replaces (the sequential loop rebuilds the window on every one-way frame and keyframe): when
+        prev: the WindowBA this one replaces (the sequential loop rebuilds the window on every keyframe): when
         the KEYFRAME SET is the same -- the very same image-stack and correspondence-mask tensors -- everything that depends on
-        it only (reference-pixel selection, landmark remap / index tables) is taken over instead of being recomputed."""
+        it only (reference-pixel selection, landmark remap / index tables) is taken over instead of being recomputed.
+        rec_capacity: the largest number of one-way frames this keyframe set will see (Mapping: graph.num_one_way_frames): the state
+        buffer, the system buffers and the per-frame scratch are sized for it once, so that `retarget` -- same keyframes, another
+        set of one-way frames, 55 % of the sequential loop's frames -- only rewrites the frame count, the index tables that move
+        with it and the pair table instead of building a new object (None: exactly the frames of `state`)."""
         self.shard = shard
         self._prev = prev
         self._src_kf_img, self._src_mask = state["kf_img_and_grads"], state["correspondence_mask"]
@@ -84,20 +88,58 @@ class WindowBA:
         self.m = state["coords_m"].shape[1]
         rec_poses = state.get("recent_poses")
         nrec = int(rec_poses.shape[0]) if rec_poses is not None else 0      # one-way frames (Mapping.add_one_way_frame)
-        self.F = B + nrec
+        self.rec_cap = max(nrec, int(rec_capacity or 0))
         self.intrinsics = f64(state["intrinsics"])
         # the state the iteration updates -- all frame poses | affine params (keyframes first) | landmarks | median depths -- in
         # ONE buffer (the views below alias it): the sequential loop publishes it after every iteration with one copy
-        # (`snapshot_state`) instead of one per tensor
-        F_, nP = self.F, int(state["P_m"].shape[0])
+        # (`snapshot_state`) instead of one per tensor.  Frame-indexed parts are laid out for the CAPACITY B + rec_cap.
+        Fc, nP = B + self.rec_cap, int(state["P_m"].shape[0])
+        self.Fcap = Fc
         ev = lambda n: (n + 1) // 2 * 2                       # 16-byte steps
-        o_aff, o_P = 16 * F_, 16 * F_ + ev(2 * F_)
+        o_aff, o_P = 16 * Fc, 16 * Fc + ev(2 * Fc)
         o_med = o_P + ev(3 * nP)
+        self._state_off = (o_aff, o_P, o_med, nP)
         self.state_flat = torch.zeros((o_med + ev(B),), device=dev, dtype=self.dt)
+        self.P_m = self.state_flat[o_P:o_P + 3 * nP].view(nP, 3)
+        self.median_depths = self.state_flat[o_med:o_med + B]
+        self._load_frames(state)
+        self.correspondence_mask = state["correspondence_mask"]
+        self.obs_ref_mask = state["obs_ref_mask"].contiguous()
+        self.pm_first_obs = f64(state["pm_first_obs"])
+        self.L_mm = f64(state["L_mm"])
+        self.K_mm_inv = f64(state["K_mm_inv"])
+        self.kf_timestamps = state["kf_timestamps"]
+        if not self._load_images(state):
+            raise RuntimeError("como_amd WindowBA: image stacks could not be addressed")       # (cannot happen: the concatenating form always applies)
+        pix = lambda name: self._pix(state, name)
+        self.Kt = pix("Knm_Kmminv").to(pix_dtype).reshape(B, self.Himg * self.Wimg, self.m).contiguous()
+        self.K_pix = self.intrinsics[0].to(pix_dtype).contiguous()
+        self.window_full = window_full
+        self.pose_anchor = f64(state["pose_anchor"]) if "pose_anchor" in state else self.kf_poses[0:1].clone()
+        self.aff_anchor = torch.zeros((1, 2, 1), device=dev, dtype=self.dt)
+        self.P_m_anchors = f64(state["P_anchor"]) if "P_anchor" in state else self.P_m[self.correspondence_mask[0]].clone()
+        self.init_scale_anchor = state.get("init_scale_anchor")
+        self._prepare_topology()
+
+    def _pix(self, state, name):
+        # (the sequential loop hands over mirrors that are already in pix_dtype -- Mapping._cat -- so that a rebuild does not
+        # convert the whole K~ window and every image stack again)
+        t = state.get(name + "_pix")
+        return t if t is not None and t.dtype == self.pix_dtype and t.shape == state[name].shape else state[name]
+
+    def _load_frames(self, state):
+        """The frame set of `state` into the capacity-sized state buffer: frame count, the views of the first F frames, the values."""
+        B, dev = self.B, self.dev
+        f64 = lambda t: t.to(self.dt).contiguous()
+        rec_poses = state.get("recent_poses")
+        nrec = int(rec_poses.shape[0]) if rec_poses is not None else 0
+        if nrec > self.rec_cap:
+            raise RuntimeError("como_amd WindowBA: more one-way frames than the window was sized for")
+        F_ = self.F = B + nrec
+        o_aff, o_P, o_med, nP = self._state_off
         self._state_layout = (("poses", 0, (F_, 4, 4)), ("aff", o_aff, (F_, 2)), ("P_m", o_P, (nP, 3)), ("median", o_med, (B,)))
-        carve1 = lambda flat, off, shp: flat[off:off + int(torch.Size(shp).numel())].view(shp)
-        self.poses_all = carve1(self.state_flat, 0, (F_, 4, 4))
-        self.aff_all = carve1(self.state_flat, o_aff, (F_, 2))
+        self.poses_all = self.state_flat[:16 * F_].view(F_, 4, 4)
+        self.aff_all = self.state_flat[o_aff:o_aff + 2 * F_].view(F_, 2)
         self.poses_all[:B] = f64(state["kf_poses"])
         self.aff_all[:B] = f64(state["kf_aff_params"]).reshape(B, 2)
         self.kf_poses = self.poses_all[:B]
@@ -110,46 +152,57 @@ class WindowBA:
             self.recent_timestamps = state["recent_timestamps"]
         else:
             self.recent_timestamps = torch.empty((0,), device=dev, dtype=self.dt)
-        self.P_m = carve1(self.state_flat, o_P, (nP, 3))
         self.P_m.copy_(state["P_m"])
-        self.correspondence_mask = state["correspondence_mask"]
-        self.obs_ref_mask = state["obs_ref_mask"].contiguous()
-        self.pm_first_obs = f64(state["pm_first_obs"])
-        self.L_mm = f64(state["L_mm"])
-        self.K_mm_inv = f64(state["K_mm_inv"])
-        self.kf_timestamps = state["kf_timestamps"]
-        # per-pixel data in pix_dtype
-        # keyframe image stacks followed by the one-way frames' in ONE buffer (targets are addressed by element offset)
-        # (the sequential loop hands over mirrors that are already in pix_dtype -- Mapping._cat -- so that a rebuild does not
-        # convert the whole K~ window and every image stack again)
-        def pix(name):
-            t = state.get(name + "_pix")
-            return t if t is not None and t.dtype == pix_dtype and t.shape == state[name].shape else state[name]
-        kf_img = pix("kf_img_and_grads")
-        rec_img = pix("recent_img_and_grads") if nrec else None
+        if "median_depth_init" in state:
+            self.median_depths.copy_(state["median_depth_init"])
+        else:
+            self.median_depths.fill_(1.0)
+
+    def _load_images(self, state, allow_concat=True):
+        """Per-pixel image data in pix_dtype: the keyframe stacks and the one-way frames' stacks, addressed as ONE buffer (targets
+        are element offsets from the keyframe stack).  Returns False when that needs a concatenation and allow_concat is off."""
+        nrec = self.F - self.B
+        kf_img = self._pix(state, "kf_img_and_grads")
+        rec_img = self._pix(state, "recent_img_and_grads") if nrec else None
         self._rec_img, self._rec_img_off = None, None
-        if (nrec and rec_img.dtype == pix_dtype and kf_img.dtype == pix_dtype and rec_img.is_contiguous() and kf_img.is_contiguous() and
+        pd = self.pix_dtype
+        if (nrec and rec_img.dtype == pd and kf_img.dtype == pd and rec_img.is_contiguous() and kf_img.is_contiguous() and
                 rec_img.device == kf_img.device and (rec_img.data_ptr() - kf_img.data_ptr()) % kf_img.element_size() == 0):
             # both stacks stay where they are (the sequential loop's sliding buffers): the one-way targets are addressed relative to
             # the keyframe stack by their element offset, whatever its sign -- no 122 MB concatenation per rebuild
             self.img, self._rec_img = kf_img, rec_img
             self._rec_img_off = (rec_img.data_ptr() - kf_img.data_ptr()) // kf_img.element_size()
-        else:
-            imgs = kf_img if not nrec else torch.cat((kf_img, rec_img.to(kf_img.dtype)))
-            self.img = imgs.to(pix_dtype).contiguous()
-        self.Kt = pix("Knm_Kmminv").to(pix_dtype).reshape(B, self.Himg * self.Wimg, self.m).contiguous()
-        self.K_pix = self.intrinsics[0].to(pix_dtype).contiguous()
-        self.median_depths = carve1(self.state_flat, o_med, (B,))
-        if "median_depth_init" in state:
-            self.median_depths.copy_(state["median_depth_init"])
-        else:
-            self.median_depths.fill_(1.0)
-        self.window_full = window_full
-        self.pose_anchor = f64(state["pose_anchor"]) if "pose_anchor" in state else self.kf_poses[0:1].clone()
-        self.aff_anchor = torch.zeros((1, 2, 1), device=dev, dtype=self.dt)
-        self.P_m_anchors = f64(state["P_anchor"]) if "P_anchor" in state else self.P_m[self.correspondence_mask[0]].clone()
-        self.init_scale_anchor = state.get("init_scale_anchor")
-        self._prepare_topology()
+            return True
+        if nrec and not allow_concat:
+            return False
+        imgs = kf_img if not nrec else torch.cat((kf_img, rec_img.to(kf_img.dtype)))
+        self.img = imgs.to(pd).contiguous()
+        return True
+
+    def retarget(self, state, window_full=None):
+        """The SAME keyframe set with another set of one-way frames (`Mapping.add_one_way_frame`: 55 % of the sequential loop's frames
+        rebuilt the whole window object for it: ~0.65 ms of host time and ~55 small launches while the GPU waited).  Everything
+        sized by the frame count lives in capacity-sized buffers (`rec_capacity`), so this only loads the frames' values, moves the
+        landmark columns of the system (they sit behind the frame blocks: D = 8 F + 3 L), rebuilds the pair table and patches the
+        kernels' argument block; scratch, band-median state, reference pixels and landmark tables stay as they are.
+        Returns False -- nothing touched that matters -- when this window cannot take the state (another keyframe set, not the
+        fused single-GPU chain, more frames than its capacity, image stacks that would have to be concatenated): build a new one."""
+        rec = state.get("recent_poses")
+        nrec = int(rec.shape[0]) if rec is not None else 0
+        if not (self.fused and self.shard is None and self.dev.type == "cuda" and _REUSE_TOPOLOGY and nrec <= self.rec_cap and
+                state["kf_img_and_grads"] is self._src_kf_img and state["correspondence_mask"] is self._src_mask and
+                int(state["P_m"].shape[0]) == self.L and (window_full is None or window_full == self.window_full) and
+                getattr(self, "win_args", None) is not None):
+            return False
+        F_old = self.F
+        self.F = self.B + nrec
+        if not self._load_images(state, allow_concat=False):
+            self.F = F_old
+            return False
+        self.graph = None                                    # (a captured iteration holds the old frame count)
+        self._load_frames(state)
+        self._finish_topology(first=False)
+        return True
 
     @staticmethod
     def _fixed_remap(mask, m):
@@ -236,7 +289,9 @@ class WindowBA:
         self._inherit = None
 
     # ---- ... and what also depends on the number of one-way frames --------------------------------------------------------
-    def _finish_topology(self):
+    def _finish_topology(self, first=True):
+        """first: the buffers are created (sized for the capacity B + rec_cap frames); a `retarget` only re-derives what moves
+        with the frame count."""
         B, dev, L = self.B, self.dev, self.L
         nrec = self.F - B
         self.dim = 8 * B + 8 * nrec + 3 * L
@@ -244,9 +299,13 @@ class WindowBA:
             torch.empty((0), device=dev, dtype=torch.long)
         self.frame_inds = _ar(8 * self.F, dev).reshape(self.F, 8)
         self.lm_start = 8 * B + 8 * nrec
-        self.landmark_inds = (self.point_inds + self.lm_start).contiguous()
+        if first:
+            self.landmark_inds = (self.point_inds + self.lm_start).contiguous()
+            self.fix_inds_flat = torch.empty((3 * int(self.fix_idx.numel()),), device=dev, dtype=torch.long)
+        else:
+            torch.add(self.point_inds, self.lm_start, out=self.landmark_inds)      # (same address: the argument blocks keep it)
         self.landmark_inds_flat = _ar(self.lm_start + 3 * L, dev)[self.lm_start:].reshape(L, 3)
-        self.fix_inds_flat = self.landmark_inds_flat[self.fix_idx].flatten().contiguous()
+        torch.index_select(self.landmark_inds_flat, 0, self.fix_idx, out=self.fix_inds_flat.view(-1, 3))
         pc = self.cfg["photo_construction"]
         if self.fused and pc.get("radius_thresh", 0.0) > 0.0 and pc.get("degrees_thresh", 0.0) > 0.0:
             # The reference rebuilds the pair graph on every iterate from the CURRENT poses and median depths
@@ -254,25 +313,40 @@ class WindowBA:
             # depends on the topology; pose-dependent radius edges would go stale inside the fused / captured iteration.
             raise RuntimeError("como_amd: radius / degree pair edges need the pair graph rebuilt every iteration: use "
                                "WindowBA(fused=False) (it re-evaluates the pairs in linearize()) for radius_thresh, degrees_thresh > 0")
+        self.table = None                                    # (its rows hold system indices: they moved with lm_start)
         self._build_pair_table()
         # H | g | err(8) in ONE float64 buffer.  The fused chain does not accumulate into it: every contribution (pair blocks,
         # priors) goes through exact integer atomics into the fixed-point buffer `sysfix` (order-independent: the normal
         # equations are bit-identical from run to run, eager or graph replay, whatever order workgroups and streams finish
         # in) and como_sys_finalize converts once per iteration.  err block: [0] photometric, [1..6] the prior factors.
+        # Both buffers are sized for the capacity's system once; a smaller system uses their head (plane stride = the capacity's).
         D = self.dim
-        self.sys = torch.zeros((D * D + D + 8,), device=dev, dtype=self.dt)
+        if first:
+            Dc = 8 * self.Fcap + 3 * L
+            self._sys_cap = torch.zeros((Dc * Dc + Dc + 8,), device=dev, dtype=self.dt)
+            self.sysfix, self.fix_plane = None, 0
+            if self.fused and dev.type == "cuda":
+                self.fix_plane = int(_lib.lib().como_sys_fix_plane_elems(Dc))
+                self.sysfix = torch.zeros((2 * self.fix_plane,), device=dev, dtype=torch.int64)
+            self.sigma = torch.zeros(2, device=dev, dtype=self.pix_dtype)
+        self.sys = self._sys_cap[:D * D + D + 8]
         self.H = self.sys[:D * D].view(D, D)
         self.g = self.sys[D * D:D * D + D]
         self.err8 = self.sys[D * D + D:]
         self.err = self.err8[0]
         self.prior_err = self.err8[1:7] if (self.fused and dev.type == "cuda") else torch.zeros(8, device=dev, dtype=self.dt)
-        self.sysfix, self.fix_plane = None, 0
-        if self.fused and dev.type == "cuda":
-            self.fix_plane = int(_lib.lib().como_sys_fix_plane_elems(D))
-            self.sysfix = torch.zeros((2 * self.fix_plane,), device=dev, dtype=torch.int64)
-        self.sigma = torch.zeros(2, device=dev, dtype=self.pix_dtype)
         self.pix_range = (0, 0) if self.idle else None     # (the shard is already cut out of pixidx / vals_n)
-        self._prepare_fused()
+        if first:
+            self._prepare_fused()
+        else:
+            self._patch_args()
+
+    def _patch_args(self):
+        """The fields of the kernels' argument block that move with the frame count (everything else points into buffers that stay)."""
+        a, ptr = self.win_args, _lib.ptr
+        a.F, a.D = self.F, self.dim
+        a.H, a.g = ptr(self.H), ptr(self.g)
+        a.poses, a.aff = ptr(self.poses_all), ptr(self.aff_all)
 
     def _build_pair_table(self):
         """Pair graph from the current poses / median depths (graph_pair_construction.py:155-182) -> device-resident PairTable."""
@@ -307,7 +381,7 @@ class WindowBA:
                         ("dlogz_dP", (B, m, 3)), ("dp_dP", (B, m, 6)), ("dp_dT", (B, m, 12)), ("init_Pm", (L, 3))), self.dt)
         self._w_head = (self.w["_buf"], self.w["_off_logzm"])           # [pm | logzm | ...]: what snapshot_state copies
         self.w.update(carve((("px_logzm", (B, m)), ("px_invz", (B, m)), ("px_dzdP", (B, 3)), ("px_dlogz_dT", (B, m, 6)),
-                             ("px_poses", (F, 4, 4)), ("px_aff", (F, 2)), ("med3", (B, 3)), ("med3_full", (B, 3))), p))
+                             ("px_poses", (self.Fcap, 4, 4)), ("px_aff", (self.Fcap, 2)), ("med3", (B, 3)), ("med3_full", (B, 3))), p))
         self.w = {k: v for k, v in self.w.items() if not k.startswith("_")}
         self.w["reinit_flag"] = torch.zeros(L, device=dev, dtype=torch.int32)
         # The reference keeps TWO medians per keyframe: the one of the sub-selected reference pixels (setup_test_points,
