@@ -52,6 +52,45 @@ __global__ __launch_bounds__(256) void rgb_to_gray_kernel(const T* __restrict__ 
   out[i] = s + T(0.114) * b;
 }
 
+// Mapping.get_img_and_grads (Mapping.py:369-379) of ONE gray-mode frame in one launch: luma of the (3,H,W) colour frame (float32 as
+// the tracker holds it, widened -- exactly what `.to(float64)` does -- or float64), its Scharr gradients, written as the
+// (3,H,W) float64 stack [I | dI/dx | dI/dy] straight into the window's slot, and -- when the per-pixel kernels run in float32 -- the
+// rounded float32 copy into the mirror's slot.  The luma of a pixel's eight neighbours is recomputed from the colour planes (the
+// same three products and two sums per value as rgb_to_gray_kernel<double>: identical bits wherever it is evaluated), the gradient
+// expressions are img_grads_kernel<double>'s: the chain rgb.to(float64) -> rgb_to_grayscale -> ImageGradientModule -> cat ->
+// copy into the sliding buffers (+ mirror), ~9 launches on every one-way frame and keyframe, as one.
+template <typename TIN>
+__global__ __launch_bounds__(256) void frame_stack_kernel(const TIN* __restrict__ rgb, double* __restrict__ out,
+                                                          float* __restrict__ out_pix, int H, int W) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long HW = (long)H * W;
+  if (i >= HW) return;
+  const int x = (int)(i % W), y = (int)(i / W);
+  auto luma = [&](int yy, int xx) -> double {
+#pragma clang fp contract(off)
+    const long q = (long)yy * W + xx;
+    const double r = (double)rgb[q], g = (double)rgb[HW + q], b = (double)rgb[2 * HW + q];
+    const double s = 0.2989 * r + 0.587 * g;
+    return s + 0.114 * b;
+  };
+  using T = double;
+  const int xm = reflect1(x - 1, W), xp = reflect1(x + 1, W), ym = reflect1(y - 1, H), yp = reflect1(y + 1, H);
+  const T tl = luma(ym, xm), tc = luma(ym, x), tr = luma(ym, xp);
+  const T ml = luma(y, xm), mc = luma(y, x), mr = luma(y, xp);
+  const T bl = luma(yp, xm), bc = luma(yp, x), br = luma(yp, xp);
+  const T k3 = T(3) / T(32), k10 = T(10) / T(32);           // the reference's kernel entries (1/32 * {3, 10})
+  const T gx = k3 * (tr - tl) + k10 * (mr - ml) + k3 * (br - bl);
+  const T gy = k3 * (bl - tl) + k10 * (bc - tc) + k3 * (br - tr);
+  out[i] = mc;
+  out[HW + i] = gx;
+  out[2 * HW + i] = gy;
+  if (out_pix) {
+    out_pix[i] = (float)mc;
+    out_pix[HW + i] = (float)gx;
+    out_pix[2 * HW + i] = (float)gy;
+  }
+}
+
 // out (NC, ceil(H/2), ceil(W/2)) = blur(img)[0::2, 0::2]
 template <typename T>
 __global__ __launch_bounds__(256) void blur_down_kernel(const T* __restrict__ img, T* __restrict__ out, int H, int W, int Ho,
@@ -237,5 +276,17 @@ extern "C" {
   }
 COMO_DEF_IMAGE(f32, float)
 COMO_DEF_IMAGE(f64, double)
+
+int como_frame_stack_f64(const void* rgb, int rgb_is_f32, int H, int W, double* stack, float* stack_pix, como_stream_t stream) {
+  if (!rgb || !stack || H < 2 || W < 2) return COMO_ERR_ARG;
+  const long HW = (long)H * W;
+  const dim3 grid((unsigned)((HW + 255) / 256)), blk(256);
+  if (rgb_is_f32)
+    hipLaunchKernelGGL(como::frame_stack_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)rgb, stack, stack_pix, H, W);
+  else
+    hipLaunchKernelGGL(como::frame_stack_kernel<double>, grid, blk, 0, (hipStream_t)stream, (const double*)rgb, stack, stack_pix, H, W);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
 
 }  // extern "C"

@@ -500,9 +500,55 @@ __global__ __launch_bounds__(64) void se3_compose_kernel(const T* __restrict__ A
   }
 }
 
+// A tracked frame's state in the world frame, as the mapper needs it when the tracker hands a frame over (Mapping.handle_tracking_data,
+// Mapping.py:580-598): T_w_curr = T_w_kf inv(T_curr_kf) (get_T_w_curr, transforms.py:6-8: se3_compose_kernel mode 2's arithmetic) and
+// aff_w_curr = (a_kf + a_cur, b_kf + b_cur exp(a_cur)) (get_aff_w_curr, affine_brightness.py:5-10: product and sums rounded on
+// their own, the device library's exp).  The tracker's float32 values are widened first, as `.to(float64)` does.  One thread,
+// one launch, for the ~10 launches of the torch forms.
+template <typename TIN>
+__global__ void frame_world_kernel(const double* __restrict__ T_w_kf, const TIN* __restrict__ T_curr_kf, const double* __restrict__ aff_w_kf,
+                                   const TIN* __restrict__ aff_curr_kf, double* __restrict__ T_out, double* __restrict__ aff_out) {
+#pragma clang fp contract(off)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double a[16], p[16], b[16];
+  for (int e = 0; e < 16; ++e) { a[e] = T_w_kf[e]; p[e] = (double)T_curr_kf[e]; }
+  for (int r = 0; r < 3; ++r) {
+    double s = p[r] * p[3];
+    s = s + p[4 + r] * p[7];
+    s = s + p[8 + r] * p[11];
+    b[4 * r + 0] = p[r]; b[4 * r + 1] = p[4 + r]; b[4 * r + 2] = p[8 + r]; b[4 * r + 3] = -s;
+  }
+  b[12] = 0.0; b[13] = 0.0; b[14] = 0.0; b[15] = 1.0;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double s = a[4 * r] * b[c];
+      s = s + a[4 * r + 1] * b[4 + c];
+      s = s + a[4 * r + 2] * b[8 + c];
+      s = s + a[4 * r + 3] * b[12 + c];
+      T_out[4 * r + c] = s;
+    }
+  const double a_cur = (double)aff_curr_kf[0], b_cur = (double)aff_curr_kf[1];
+  aff_out[0] = aff_w_kf[0] + a_cur;
+  const double t = b_cur * exp(a_cur);
+  aff_out[1] = aff_w_kf[1] + t;
+}
+
 }  // namespace como
 
 extern "C" {
+
+int como_frame_world_f64(const double* T_w_kf, const void* T_curr_kf, const double* aff_w_kf, const void* aff_curr_kf, int cur_is_f32,
+                         double* T_out, double* aff_out, como_stream_t stream) {
+  if (!T_w_kf || !T_curr_kf || !aff_w_kf || !aff_curr_kf || !T_out || !aff_out) return COMO_ERR_ARG;
+  if (cur_is_f32)
+    hipLaunchKernelGGL(como::frame_world_kernel<float>, dim3(1), dim3(64), 0, (hipStream_t)stream, T_w_kf, (const float*)T_curr_kf, aff_w_kf,
+                       (const float*)aff_curr_kf, T_out, aff_out);
+  else
+    hipLaunchKernelGGL(como::frame_world_kernel<double>, dim3(1), dim3(64), 0, (hipStream_t)stream, T_w_kf, (const double*)T_curr_kf, aff_w_kf,
+                       (const double*)aff_curr_kf, T_out, aff_out);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
 
 int como_win_scaffold(const como_win_args* a, como_stream_t stream) {
   using namespace como;

@@ -22,6 +22,7 @@ import os
 import torch
 
 _PIX_MIRRORS = os.environ.get("COMO_PIX_MIRRORS", "1") != "0"       # 0: every window rebuild converts the whole K~ / image window (A/B)
+_FUSED_FRAME = os.environ.get("COMO_FUSED_FRAME", "1") != "0"       # 0: the torch chains of a frame hand-over (world pose / affine, gray + gradients + cat + copies) (A/B)
 _KEPT_MEDIANS = os.environ.get("COMO_KF_KEPT_MEDIANS", "1") != "0"  # 0: a keyframe insertion re-evaluates every keyframe's depth image (A/B)
 _RETARGET = os.environ.get("COMO_BA_RETARGET", "1") != "0"          # 0: a one-way frame builds a new window object, as round 5 (A/B)
 
@@ -148,14 +149,19 @@ class Mapping:
         window's capacity instead: the window is a view [start, start + count) that slides -- the kept keyframes stay where they
         are, the new one is written behind them -- and is moved back to the front when it reaches the end (once per
         `num_keyframes` insertions)."""
+        dst = self._slide_reserve(name, old, new_var.shape[0], tuple(new_var.shape[1:]), i, dtype or new_var.dtype, new_var.device, cap)
+        dst.copy_(new_var)                                          # (the window's element type: the copy converts)
+
+    def _slide_reserve(self, name, old, n_new, tail, i, dtype, device, cap=None):
+        """The sliding-window step of `_cat_sliding` without the copy: makes room for n_new frames of shape `tail` behind the kept
+        ones, points the attribute `name` at the new window and returns the view of the NEW frames' slots for the producer to
+        write into (csrc/image.hip frame_stack_kernel writes a frame's image stack there directly)."""
         cap = cap or self.cfg["graph"]["num_keyframes"]
         store = self.__dict__.setdefault("_kt_pp", {})              # per window tensor (e.g. K~ and its pixel-type mirror)
         st = store.get(name)
-        n_new = new_var.shape[0]
-        dtype = dtype or new_var.dtype                              # (the window's element type: the copy below converts)
-        if (st is None or st["buf"].shape[1:] != new_var.shape[1:] or st["buf"].dtype != dtype or st["buf"].shape[0] != 2 * cap or
-                st["buf"].device != new_var.device):
-            st = store[name] = {"buf": torch.empty((2 * cap,) + tuple(new_var.shape[1:]), dtype=dtype, device=new_var.device),
+        if (st is None or tuple(st["buf"].shape[1:]) != tuple(tail) or st["buf"].dtype != dtype or st["buf"].shape[0] != 2 * cap or
+                st["buf"].device != torch.device(device)):
+            st = store[name] = {"buf": torch.empty((2 * cap,) + tuple(tail), dtype=dtype, device=device),
                                 "start": 0, "count": 0}
         buf = st["buf"]
         empty = old.numel() == 0 and old.dim() == 1
@@ -182,9 +188,9 @@ class Mapping:
             if k:
                 same = keep.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr()
                 buf[:k].copy_(keep.clone() if same else keep)
-        buf[s0 + k:s0 + k + n_new].copy_(new_var)
         st["start"], st["count"] = s0, k + n_new
         setattr(self, name, buf[s0:s0 + k + n_new])
+        return buf[s0 + k:s0 + k + n_new]
 
     def window_cat_helper_list(self, var, new_var, i):
         del var[:i]
@@ -205,6 +211,8 @@ class Mapping:
 
     def reset_iteration_vars(self, new_kf, converged=False):
         self.converged = converged
+        if new_kf:
+            self._state_owner = None                          # keyframe state changed outside an iteration
         self._retire_ba()                                 # topology (or a frame's initial values) changed
         if new_kf:
             self.iter = 0
@@ -216,7 +224,10 @@ class Mapping:
 
     # ---- images / network / predictor ------------------------------------------------------------------------------------
     def get_img_and_grads(self, rgb):
-        img = rgb_to_grayscale(rgb) if self.cfg["color"] == "gray" else rgb.clone()
+        img = rgb_to_grayscale(rgb) if self.cfg["color"] == "gray" else rgb
+        if img.is_cuda:
+            from como_amd.utils.image_processing import img_and_grads
+            return img_and_grads(img)                         # the kernel writes [img | gx | gy] itself (csrc/image.hip): no cat
         gx, gy = self.gradient_module(img)
         return torch.cat((img, gx, gy), dim=1)
 
@@ -242,6 +253,23 @@ class Mapping:
 
     def get_curr_world_aff(self, aff_curr_kf, kf_ind):
         return get_aff_w_curr(self.kf_aff_params[kf_ind:kf_ind + 1, ...], aff_curr_kf)
+
+    def get_curr_world_state(self, pose_curr_kf, aff_curr_kf, kf_ind):
+        """(get_curr_world_pose, get_curr_world_aff) of a tracked frame in ONE launch (csrc/window.hip frame_world_kernel: the same
+        arithmetic, the tracker's float32 values widened first) -> ((1,4,4), (1,2,1)) in the mapping dtype."""
+        if (_FUSED_FRAME and pose_curr_kf.is_cuda and self.dtype == torch.float64 and pose_curr_kf.dtype == aff_curr_kf.dtype and
+                pose_curr_kf.dtype in (torch.float32, torch.float64) and pose_curr_kf.numel() == 16 and aff_curr_kf.numel() == 2 and
+                self.kf_poses.dtype == torch.float64 and self.kf_aff_params.dtype == torch.float64):
+            from como_amd import _lib
+            dev = pose_curr_kf.device
+            out = torch.empty(18, dtype=torch.float64, device=dev)
+            Tk = self.kf_poses[kf_ind:kf_ind + 1].contiguous()
+            ak = self.kf_aff_params[kf_ind:kf_ind + 1].contiguous()
+            _lib.check(_lib.lib().como_frame_world_f64(Tk.data_ptr(), pose_curr_kf.contiguous().data_ptr(), ak.data_ptr(),
+                                                       aff_curr_kf.contiguous().data_ptr(), 1 if pose_curr_kf.dtype == torch.float32 else 0,
+                                                       out.data_ptr(), out[16:].data_ptr(), _lib.stream_ptr(dev)), "como_frame_world_f64")
+            return out[:16].view(1, 4, 4), out[16:].view(1, 2, 1)
+        return (self.get_curr_world_pose(pose_curr_kf.to(self.dtype), kf_ind), self.get_curr_world_aff(aff_curr_kf.to(self.dtype), kf_ind))
 
     @property
     def depth_imgs(self):
@@ -372,10 +400,28 @@ class Mapping:
             self._retire_ba()
 
     def add_one_way_frame(self, rgb, pose_init, aff_init, timestamp):
-        img_and_grads = self.get_img_and_grads(rgb)
         i = self.get_recent_start_window_ind()
         self.window_cat_helper_list(self.recent_timestamps, timestamp, i)
-        self._cat("recent_img_and_grads", img_and_grads, i)
+        if (_FUSED_FRAME and rgb.is_cuda and self.cfg["color"] == "gray" and self.dtype == torch.float64 and rgb.dim() == 4 and
+                rgb.shape[:2] == (1, 3) and rgb.dtype in (torch.float32, torch.float64) and rgb.is_contiguous()):
+            # gray + Scharr gradients + the [I | gx | gy] stack in ONE launch, written straight into the slots of the sliding
+            # buffers (float64 state + the per-pixel kernels' float32 mirror): csrc/image.hip frame_stack_kernel
+            from como_amd import _lib
+            H, W = rgb.shape[-2:]
+            cap = self.cfg["graph"]["num_one_way_frames"]
+            old64 = self.recent_img_and_grads
+            was_empty = old64.numel() == 0 and old64.dim() == 1
+            dst = self._slide_reserve("recent_img_and_grads", old64, 1, (3, H, W), i, torch.float64, rgb.device, cap)
+            dpix = None
+            if _PIX_MIRRORS and self.pix_dtype == torch.float32:
+                old = self.recent_img_and_grads_pix
+                if old is None or was_empty:                  # (as _cat: the mirror starts over with the window tensor)
+                    old = torch.empty((0), device=rgb.device, dtype=torch.float32)
+                dpix = self._slide_reserve("recent_img_and_grads_pix", old, 1, (3, H, W), i, torch.float32, rgb.device, cap)
+            _lib.check(_lib.lib().como_frame_stack_f64(rgb.data_ptr(), 1 if rgb.dtype == torch.float32 else 0, H, W, dst.data_ptr(),
+                                                       _lib.ptr(dpix), _lib.stream_ptr(rgb.device)), "como_frame_stack_f64")
+        else:
+            self._cat("recent_img_and_grads", self.get_img_and_grads(rgb.to(self.dtype)), i)
         self._cat("recent_poses", pose_init, i)
         self._cat("recent_aff_params", aff_init, i)
         self.reset_iteration_vars(new_kf=False)
@@ -462,10 +508,9 @@ class Mapping:
         if data[0] in ("one-way", "keyframe"):
             rgb, pose_curr_kf, aff_curr_kf, kf_timestamp, timestamp = data[1:]
             k = self.find_kf_from_timestamp(kf_timestamp)
-            pose_w = self.get_curr_world_pose(pose_curr_kf.to(self.dtype), k)
-            aff_w = self.get_curr_world_aff(aff_curr_kf.to(self.dtype), k)
+            pose_w, aff_w = self.get_curr_world_state(pose_curr_kf, aff_curr_kf, k)
             if data[0] == "one-way":
-                self.add_one_way_frame(rgb.to(self.dtype), pose_w, aff_w, timestamp)
+                self.add_one_way_frame(rgb, pose_w, aff_w, timestamp)        # (the frame in the tracker's element type is fine)
             else:
                 kf_viz_data = self.get_kf_viz_data()          # snapshot BEFORE the insertion, as the reference
                 self.add_keyframe(rgb.to(self.dtype), pose_w, aff_w, timestamp)
@@ -486,6 +531,8 @@ class Mapping:
         if len(self.recent_timestamps):
             st.update({"recent_poses": self.recent_poses, "recent_aff_params": self.recent_aff_params,
                        "recent_img_and_grads": self.recent_img_and_grads, "recent_timestamps": ts(self.recent_timestamps)})
+        # whose state these tensors were published from (iterate): a re-targeted window need not load them again
+        st["_published_by"] = getattr(self, "_state_owner", None)
         for name in self._PIX_MIRRORED:                       # already in the solver's per-pixel element type (see _cat)
             mirror = getattr(self, name + "_pix", None)
             if mirror is not None and name in st and mirror.shape == st[name].shape:
@@ -551,5 +598,6 @@ class Mapping:
             self.pm, self.logzm = ba.pm.to(self.dtype).clone(), ba.logzm.to(self.dtype).clone()
         self._depth_cache = None
         self.median_depths = sn["median"]
+        self._state_owner = ba                               # (kf poses / affine / landmarks / medians above == ba's buffer)
         self.iter += 1
         return self.converged

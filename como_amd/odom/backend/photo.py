@@ -321,27 +321,90 @@ class PairTable:
                 grp.append([lst.pop(0), lst.pop(0)])
             if lst:
                 grp.append([lst[0], -1])                   # a lone pair rides the same kernel with its second half masked
-        # every host-built index array in TWO host->device copies (int32 | int64) instead of one small pageable copy each: the
-        # window is rebuilt on every keyframe / one-way frame of the sequential loop
+        # every host-built index array -- including the system rows of the reference / target FRAMES, which are plain ramps
+        # (frame f owns rows 8 f .. 8 f + 7: `kf_inds` / `recent_inds` are views of one arange) -- in ONE host->device copy of a
+        # pinned int64 staging block: the window's pair table is rebuilt on every keyframe / one-way frame of the sequential loop
         chan = [p_ % c for p_ in range(b)]
-        i32 = torch.tensor(list(ref_ids) + tgt_frame + chan + [x for g_ in grp for x in g_], dtype=torch.int32).to(device)
-        i64 = torch.tensor(off + list(ref_ids) + tgt_frame, dtype=torch.int64).to(device)
+        flat_grp = [x for g_ in grp for x in g_]
+        ramp = _frame_rows_are_ramps(kf_inds, recent_inds, num_kf)
+        rows_ref = [8 * int(r_) + k for r_ in ref_ids for k in range(8)] if ramp else []
+        rows_tgt = [8 * f_ + k for f_ in tgt_frame for k in range(8)] if ramp else []
+        import numpy as np
+        ng = len(flat_grp)
+        h32 = np.asarray(list(ref_ids) + tgt_frame + chan + flat_grp + ([0] if (3 * b + ng) % 2 else []), dtype=np.int32)
+        h64 = np.asarray(off + list(ref_ids) + rows_ref + rows_tgt, dtype=np.int64)
+        nb32, nb = h32.nbytes, h32.nbytes + h64.nbytes                   # (int32 block first, padded to 8 bytes; then the int64 block)
+        dev_t = torch.device(device)
+        if dev_t.type == "cuda":
+            stage = _pinned_stage(nb)
+            sn = stage.numpy()
+            sn[:nb32] = h32.view(np.uint8)
+            sn[nb32:nb] = h64.view(np.uint8)
+            raw = torch.empty(nb, dtype=torch.uint8, device=dev_t)
+            raw.copy_(stage[:nb], non_blocking=True)
+            _stage_fence(dev_t)
+        else:
+            raw = torch.from_numpy(np.concatenate((h32.view(np.uint8), h64.view(np.uint8)))).to(dev_t)
+        i32 = raw[:nb32].view(torch.int32)
+        i64 = raw[nb32:nb].view(torch.int64)
         self.ref_slot = i32[0:b]
         self.ref_pose = self.ref_slot                       # keyframes come first in the pose buffer: slot b = pose b
         self.ref_aff = self.ref_slot
         self.tgt_aff = i32[b:2 * b]
         self.tgt_pose = self.tgt_aff
         self.pair_chan = i32[2 * b:3 * b] if c > 1 else None
-        self.grp_pairs = i32[3 * b:].reshape(-1, 2)
+        self.grp_pairs = i32[3 * b:3 * b + ng].reshape(-1, 2)
         self.tgt_img = i64[0:b]
         rid = i64[b:2 * b]
-        self.pose_ref_inds = kf_inds[rid].contiguous()
-        # system rows of every target frame with ONE gather (keyframes first, then the one-way frames)
-        frame_rows = torch.cat((kf_inds, recent_inds), dim=0) if any(tgt_is_recent) else kf_inds
-        self.pose_tgt_inds = frame_rows[i64[2 * b:3 * b]].contiguous()
-        self.landmark_inds = landmark_inds[rid].contiguous()
-        self.single_pairs = torch.zeros(0, dtype=torch.int32, device=device)
+        if ramp:
+            self.pose_ref_inds = i64[2 * b:10 * b].view(b, 8)
+            self.pose_tgt_inds = i64[10 * b:18 * b].view(b, 8)
+        else:
+            self.pose_ref_inds = kf_inds[rid].contiguous()
+            # system rows of every target frame with ONE gather (keyframes first, then the one-way frames)
+            frame_rows = torch.cat((kf_inds, recent_inds), dim=0) if any(tgt_is_recent) else kf_inds
+            self.pose_tgt_inds = frame_rows[torch.as_tensor(tgt_frame, dtype=torch.int64, device=dev_t)].contiguous()
+        self.landmark_inds = landmark_inds.index_select(0, rid)
+        self.single_pairs = _empty_i32(dev_t)
         self.ngroups = len(grp)
+
+
+_stage = {}
+
+
+def _pinned_stage(n):
+    """A pinned byte staging block (grow-only) for the pair table's one host->device copy."""
+    t = _stage.get("buf")
+    if t is None or t.numel() < n:
+        t = _stage["buf"] = torch.empty(max(1 << 16, 2 * n), dtype=torch.uint8).pin_memory()
+        _stage["event"] = None
+    else:
+        ev = _stage.get("event")
+        if ev is not None:
+            ev.synchronize()                                  # the previous table's copy has left the block (long ago)
+    return t
+
+
+def _stage_fence(device):
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    _stage["event"] = ev
+
+
+_empties = {}
+
+
+def _empty_i32(device):
+    t = _empties.get(str(device))
+    if t is None:
+        t = _empties[str(device)] = torch.zeros(0, dtype=torch.int32, device=device)
+    return t
+
+
+def _frame_rows_are_ramps(kf_inds, recent_inds, num_kf):
+    """True when the caller's row tables are the window's own ramps (frame f -> rows 8 f .. 8 f + 7): shapes only -- WindowBA builds
+    them as views of one arange; any other caller (tests with hand-made tables) takes the gather path."""
+    return getattr(kf_inds, "_como_ramp", False) and (recent_inds.numel() == 0 or getattr(recent_inds, "_como_ramp", False))
 
 
 def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uvec, Kt, pixidx, invz, dzdP, img_base, K,

@@ -26,7 +26,10 @@ class MappingSeq(Mapping):
         kf_viz_data = kf_ref_data = None
         kf_updated = False
         if data is not None:
-            data = transfer_data(data, self.device, self.dtype)
+            if data[0] in ("one-way", "keyframe") and all(torch.is_tensor(t) and t.device == torch.device(self.device) for t in data[1:4]):
+                pass        # (same device: handle_tracking_data widens the tracker's float32 values inside its fused kernels)
+            else:
+                data = transfer_data(data, self.device, self.dtype)
             if not self.is_init:
                 if data[0] == "init":
                     kf_updated = self.attempt_two_frame_init(data[1], data[2])

@@ -127,8 +127,11 @@ class WindowBA:
         t = state.get(name + "_pix")
         return t if t is not None and t.dtype == self.pix_dtype and t.shape == state[name].shape else state[name]
 
-    def _load_frames(self, state):
-        """The frame set of `state` into the capacity-sized state buffer: frame count, the views of the first F frames, the values."""
+    def _load_frames(self, state, only_recent=False):
+        """The frame set of `state` into the capacity-sized state buffer: frame count, the views of the first F frames, the values.
+        only_recent (`retarget`): the keyframe poses / affine parameters / landmarks / medians of `state` ARE this buffer's current
+        values (Mapping.iterate published them from it and nothing but an iteration changes them): only the one-way frames' rows
+        are written."""
         B, dev = self.B, self.dev
         f64 = lambda t: t.to(self.dt).contiguous()
         rec_poses = state.get("recent_poses")
@@ -140,8 +143,9 @@ class WindowBA:
         self._state_layout = (("poses", 0, (F_, 4, 4)), ("aff", o_aff, (F_, 2)), ("P_m", o_P, (nP, 3)), ("median", o_med, (B,)))
         self.poses_all = self.state_flat[:16 * F_].view(F_, 4, 4)
         self.aff_all = self.state_flat[o_aff:o_aff + 2 * F_].view(F_, 2)
-        self.poses_all[:B] = f64(state["kf_poses"])
-        self.aff_all[:B] = f64(state["kf_aff_params"]).reshape(B, 2)
+        if not only_recent:
+            self.poses_all[:B] = f64(state["kf_poses"])
+            self.aff_all[:B] = f64(state["kf_aff_params"]).reshape(B, 2)
         self.kf_poses = self.poses_all[:B]
         self.kf_aff_params = self.aff_all[:B].view(B, 2, 1)
         self.recent_poses = self.poses_all[B:]
@@ -152,6 +156,8 @@ class WindowBA:
             self.recent_timestamps = state["recent_timestamps"]
         else:
             self.recent_timestamps = torch.empty((0,), device=dev, dtype=self.dt)
+        if only_recent:
+            return
         self.P_m.copy_(state["P_m"])
         if "median_depth_init" in state:
             self.median_depths.copy_(state["median_depth_init"])
@@ -200,7 +206,7 @@ class WindowBA:
             self.F = F_old
             return False
         self.graph = None                                    # (a captured iteration holds the old frame count)
-        self._load_frames(state)
+        self._load_frames(state, only_recent=state.get("_published_by") is self)
         self._finish_topology(first=False)
         return True
 
@@ -297,6 +303,8 @@ class WindowBA:
         self.dim = 8 * B + 8 * nrec + 3 * L
         self.recent_inds = _ar(8 * self.F, dev)[8 * B:].reshape(nrec, 8) if nrec else \
             torch.empty((0), device=dev, dtype=torch.long)
+        self.recent_inds._como_ramp = True                   # (frame f owns rows 8 f .. 8 f + 7: photo.PairTable builds them on the host)
+        self.kf_inds._como_ramp = True
         self.frame_inds = _ar(8 * self.F, dev).reshape(self.F, 8)
         self.lm_start = 8 * B + 8 * nrec
         if first:

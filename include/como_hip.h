@@ -542,6 +542,11 @@ int como_win_update(const double* delta, double* poses, double* aff, const long*
  * or -1 = the persistent solver's time-out, which leaves delta unwritten -- nothing is updated (the reference swallows the error,
  * linear_system.py:109, and applies whatever came out; SURVEY.md section 5 asks for the status to be acted on).  The caller reads
  * `info` at its next synchronisation point and decides (re-solve on the multi-launch solver / raise). */
+/* A tracked frame's pose and affine brightness in the world frame (Mapping.handle_tracking_data, Mapping.py:580-598): T_out (4,4) =
+ * T_w_kf inv(T_curr_kf) (get_T_w_curr, como/geometry/transforms.py:6-8), aff_out (2) = (a_kf + a_cur, b_kf + b_cur exp(a_cur))
+ * (get_aff_w_curr, como/geometry/affine_brightness.py:5-10).  T_curr_kf / aff_curr_kf: float32 (cur_is_f32, widened first) or float64. */
+int como_frame_world_f64(const double* T_w_kf, const void* T_curr_kf, const double* aff_w_kf, const void* aff_curr_kf, int cur_is_f32,
+                         double* T_out, double* aff_out, como_stream_t stream);
 int como_win_update_checked(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
                             long lm_start, const int* info, como_stream_t stream);
 /* invertSE3 (como/geometry/lie_algebra.py:83-95 without the Jacobian; the inverse inside get_T_w_curr / get_rel_pose,
@@ -619,6 +624,11 @@ int como_img_grads_f64(const double* img, double* out, int N, int C, int H, int 
  * (torchvision's rgb_to_grayscale as the reference calls it in Mapping.get_img_and_grads / Tracking.prep_tracking_img). */
 int como_rgb_to_gray_f32(const float* rgb, float* out, int N, int H, int W, como_stream_t stream);
 int como_rgb_to_gray_f64(const double* rgb, double* out, int N, int H, int W, como_stream_t stream);
+/* frame_stack: Mapping.get_img_and_grads (Mapping.py:369-379) of one gray-mode frame in ONE launch: rgb (3,H,W) float32
+ * (rgb_is_f32: widened, as .to(float64)) or float64 -> stack (3,H,W) float64 = [luma | Scharr_x/32 | Scharr_y/32] (the values of
+ * rgb_to_gray_f64 followed by img_grads_f64), and, when stack_pix != NULL, the same rounded to float32 (the per-pixel kernels'
+ * mirror).  Both destinations may be slots of the window's image buffers. */
+int como_frame_stack_f64(const void* rgb, int rgb_is_f32, int H, int W, double* stack, float* stack_pix, como_stream_t stream);
 int como_img_blur_down_f32(const float* img, float* out, int NC, int H, int W, como_stream_t stream);
 int como_img_blur_down_f64(const double* img, double* out, int NC, int H, int W, como_stream_t stream);
 /* img_blur: the same blur without decimation (GaussianBlurModule); depth_pool2: pyr_depth (como/data/depth_resize.py:6-36)

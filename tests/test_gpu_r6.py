@@ -197,3 +197,83 @@ def test_headless_runner_on_a_tum_tree(tmp_path):
     report("headless_runner", frames=len(kinds), keyframes=int(rows.shape[0]), tracked=len(est), ate_sim3_vs_gt=ate, path_length=path,
            kinds={str(k): kinds.count(k) for k in set(kinds)})
     assert len(est) >= n - 6 and ate < 0.02 * path
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rgb_dtype", [torch.float32, torch.float64])
+def test_frame_handover_kernels_equal_the_torch_chains(rgb_dtype):
+    """The one-launch forms of a frame hand-over (tracker -> mapper, Mapping.py:580-598 / :369-379) against the chains they replace,
+    BIT for bit: como_frame_stack_f64 = rgb.to(float64) -> rgb_to_grayscale -> ImageGradientModule -> cat (+ the float32 mirror's
+    rounding); como_frame_world_f64 = get_T_w_curr (transforms.py:6-8) and get_aff_w_curr (affine_brightness.py:5-10) on the
+    widened values."""
+    from como_amd import _lib, synth
+    from como_amd.geometry.affine_brightness import get_aff_w_curr
+    from como_amd.geometry.transforms import get_T_w_curr
+    from como_amd.utils.image_processing import img_and_grads, rgb_to_grayscale
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(3)
+    H, W = 96, 130
+    rgb = torch.rand((1, 3, H, W), generator=g, dtype=torch.float64).to(rgb_dtype).to(DEV)
+    want = img_and_grads(rgb_to_grayscale(rgb.to(torch.float64)))
+    stack = torch.empty((1, 3, H, W), dtype=torch.float64, device=DEV)
+    pix = torch.empty((1, 3, H, W), dtype=torch.float32, device=DEV)
+    s = _lib.stream_ptr(torch.device(DEV))
+    assert L.como_frame_stack_f64(rgb.data_ptr(), 1 if rgb_dtype == torch.float32 else 0, H, W, stack.data_ptr(), pix.data_ptr(), s) == 0
+    assert torch.equal(stack, want) and torch.equal(pix, want.float())
+    stack2 = torch.zeros_like(stack)
+    assert L.como_frame_stack_f64(rgb.data_ptr(), 1 if rgb_dtype == torch.float32 else 0, H, W, stack2.data_ptr(), None, s) == 0
+    assert torch.equal(stack2, want)
+    T_w_kf = synth.se3_exp(0.3 * torch.randn((1, 6), generator=g, dtype=torch.float64)).to(DEV)
+    T_c = synth.se3_exp(0.05 * torch.randn((1, 6), generator=g, dtype=torch.float64)).to(rgb_dtype).to(DEV)
+    a_kf = (0.1 * torch.randn((1, 2, 1), generator=g, dtype=torch.float64)).to(DEV)
+    a_c = (0.1 * torch.randn((1, 2, 1), generator=g, dtype=torch.float64)).to(rgb_dtype).to(DEV)
+    out = torch.empty(18, dtype=torch.float64, device=DEV)
+    assert L.como_frame_world_f64(T_w_kf.data_ptr(), T_c.data_ptr(), a_kf.data_ptr(), a_c.data_ptr(), 1 if rgb_dtype == torch.float32 else 0,
+                                  out.data_ptr(), out[16:].data_ptr(), s) == 0
+    Tw = get_T_w_curr(T_w_kf, T_c.to(torch.float64))
+    aw = get_aff_w_curr(a_kf, a_c.to(torch.float64))
+    assert torch.equal(out[:16].view(1, 4, 4), Tw) and torch.equal(out[16:].view(1, 2, 1), aw)
+
+
+def test_retargeted_window_equals_a_rebuilt_one():
+    """WindowBA.retarget (same keyframes, another set of one-way frames -- what 55 % of the sequential loop's frames ask for) against
+    a window built from scratch on the same state: the pair lists, the system size and one Gauss-Newton iteration's result
+    (poses / affine parameters of every frame, landmarks) are identical, bit for bit -- the normal equations are assembled in
+    fixed point, so nothing depends on which buffers were reused."""
+    from como_amd import synth
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    B, H, W, m = 3, 96, 128, 16
+    st = synth.make_window(B=B, H=H, W=W, m=m, dtype=torch.float64, device=DEV, seed=7,
+                           predictor=lambda cov, cm: prep_predictor(cov, cm, 1.0))
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = 2
+    def with_recent(k):
+        s2 = dict(st)
+        if k:
+            s2.update(synth.make_recent([0.3, 1.3, 1.6, 0.6, 1.8][:k], H, W, 7, device=DEV))
+        return s2
+
+    s1, s3 = with_recent(1), with_recent(3)
+    wb = WindowBA(s1, cfg=cfg, pix_dtype=torch.float64, window_full=True, rec_capacity=4)
+    wb.iterate()
+    # the caller's state after that iteration (what Mapping.iterate publishes), then two more one-way frames
+    sn = wb.snapshot_state()
+    for s_ in (s3,):
+        s_["kf_poses"], s_["kf_aff_params"] = sn["poses"][:B].clone(), sn["aff"][:B].reshape(B, 2, 1).clone()
+        s_["P_m"], s_["median_depth_init"] = sn["P_m"].clone(), sn["median"].clone()
+        s_["recent_poses"] = torch.cat((sn["poses"][B:B + 1], s_["recent_poses"][1:]))
+    fresh = WindowBA(s3, cfg=cfg, pix_dtype=torch.float64, window_full=True)
+    assert wb.retarget(s3) is True
+    assert wb.F == fresh.F == B + 3 and wb.dim == fresh.dim
+    assert (wb.kf_pairs, wb.one_way_pairs) == (fresh.kf_pairs, fresh.one_way_pairs)
+    d1, d2 = wb.iterate().clone(), fresh.iterate().clone()
+    assert int(wb.info.item()) == 0 and int(fresh.info.item()) == 0
+    report("retarget", dim=wb.dim, delta_diff=(d1 - d2).abs().max().item(), pose_diff=(wb.poses_all - fresh.poses_all).abs().max().item())
+    assert torch.equal(wb.H, fresh.H) and torch.equal(wb.g, fresh.g)
+    assert torch.equal(d1, d2) and torch.equal(wb.poses_all, fresh.poses_all) and torch.equal(wb.P_m, fresh.P_m)
+    # a state this window cannot take: more one-way frames than its capacity, another keyframe set
+    assert wb.retarget(with_recent(5)) is False
+    other = dict(s3)
+    other["kf_img_and_grads"] = st["kf_img_and_grads"].clone()
+    assert wb.retarget(other) is False
