@@ -171,6 +171,8 @@ SIGNATURES = {
     "como_win_scaffold": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
     "como_win_priors": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
     "como_win_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
+    "como_se3_normalize_f32": (c_int, [c_void_p, c_int, c_void_p]),
+    "como_se3_normalize_f64": (c_int, [c_void_p, c_int, c_void_p]),
     "como_frame_world_f64": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),
     "como_frame_stack_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "como_win_update_checked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p]),

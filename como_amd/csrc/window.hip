@@ -500,6 +500,33 @@ __global__ __launch_bounds__(64) void se3_compose_kernel(const T* __restrict__ A
   }
 }
 
+// normalizeSE3_inplace (como/geometry/lie_algebra.py:98-101: R <- U V^T of R's SVD), for rotation blocks that are rotations up to
+// rounding (a float32 tracked pose composed in float64): U V^T is the orthogonal polar factor of R, which Newton's iteration
+// X <- (X + X^-T) / 2 reaches quadratically from such a start (error e -> e^2 / 2: three steps from 1e-7 are below 1e-16; eight are
+// run).  The reference's device SVD is a dozen solver launches with their own synchronisations (~1 ms), the host LAPACK form a
+// device -> host -> device round trip in the middle of a keyframe insertion; this is one thread per pose.  Differs from an SVD's
+// U V^T by rounding only (|dR| ~ 2e-16).
+template <typename T>
+__global__ void se3_normalize_kernel(T* __restrict__ poses, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  T* P = poses + 16 * (long)i;
+  double X[9];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) X[3 * r + c] = (double)P[4 * r + c];
+  for (int it = 0; it < 8; ++it) {
+    double C[9];                                             // cofactors: X^-T = C / det
+    C[0] = X[4] * X[8] - X[5] * X[7]; C[1] = X[5] * X[6] - X[3] * X[8]; C[2] = X[3] * X[7] - X[4] * X[6];
+    C[3] = X[2] * X[7] - X[1] * X[8]; C[4] = X[0] * X[8] - X[2] * X[6]; C[5] = X[1] * X[6] - X[0] * X[7];
+    C[6] = X[1] * X[5] - X[2] * X[4]; C[7] = X[2] * X[3] - X[0] * X[5]; C[8] = X[0] * X[4] - X[1] * X[3];
+    const double det = X[0] * C[0] + X[1] * C[1] + X[2] * C[2];
+    const double inv = 1.0 / det;
+    for (int e = 0; e < 9; ++e) X[e] = 0.5 * (X[e] + C[e] * inv);
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) P[4 * r + c] = (T)X[3 * r + c];
+}
+
 // A tracked frame's state in the world frame, as the mapper needs it when the tracker hands a frame over (Mapping.handle_tracking_data,
 // Mapping.py:580-598): T_w_curr = T_w_kf inv(T_curr_kf) (get_T_w_curr, transforms.py:6-8: se3_compose_kernel mode 2's arithmetic) and
 // aff_w_curr = (a_kf + a_cur, b_kf + b_cur exp(a_cur)) (get_aff_w_curr, affine_brightness.py:5-10: product and sums rounded on
@@ -536,6 +563,19 @@ __global__ void frame_world_kernel(const double* __restrict__ T_w_kf, const TIN*
 }  // namespace como
 
 extern "C" {
+
+int como_se3_normalize_f64(double* poses, int n, como_stream_t stream) {
+  if (!poses || n <= 0) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::se3_normalize_kernel<double>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, n);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+int como_se3_normalize_f32(float* poses, int n, como_stream_t stream) {
+  if (!poses || n <= 0) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::se3_normalize_kernel<float>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, n);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
 
 int como_frame_world_f64(const double* T_w_kf, const void* T_curr_kf, const double* aff_w_kf, const void* aff_curr_kf, int cur_is_f32,
                          double* T_out, double* aff_out, como_stream_t stream) {

@@ -106,8 +106,30 @@ def calc_kernel_matrices(coords_m, coords_n, cov_params_img, model):
     return (model.cov_modules[-1](cm, Em), model.cross_cov_modules[-1](cn, En, cm, Em), model.diagonal_cov_modules[-1](cn, En))
 
 
-def get_predictor(K_mm, K_nm, K_nn_diag, pad4=False):
+class MaskedResidual:
+    """The residuals of a distillation over ALL rows together with the row mask of the valid ones -- what
+    `distill_depth_from_scratch(..., masked_residual=True)` returns instead of the gathered valid residuals (whose number only the
+    device knows: the gather costs a `nonzero` + a host synchronisation).  `std()` is torch.std of the valid entries (unbiased),
+    from masked sums: equal to the gathered form up to the rounding of a different summation order."""
+
+    def __init__(self, res, okm):
+        self.res, self.okm = res, okm
+
+    def std(self):
+        zero = torch.zeros_like(self.res)
+        n = self.okm.sum().to(self.res.dtype)
+        mean = torch.where(self.okm, self.res, zero).sum() / n          # (selects: a masked row may hold anything)
+        d = torch.where(self.okm, self.res - mean, zero)
+        return torch.sqrt((d * d).sum() / (n - 1.0))
+
+    def compact(self):
+        return self.res.index_select(1, torch.nonzero(self.okm[0, :, 0])[:, 0])
+
+
+def get_predictor(K_mm, K_nm, K_nn_diag, pad4=False, row_mask=None):
     """:30-48 -> Knm_Kmminv (B,n,m), L_mm, 1/stdev of the conditional variance (B,n,1).
+    row_mask (1,n) bool or None: the rows that count (the others ride along with zero weights in the caller's normal equations):
+    the smallest conditional variance -- the shift that keeps every variance positive -- is taken over THEM only.
     pad4: Knm_Kmminv is returned as the leading m columns of a (B,n,mp) buffer, mp = m rounded up to a multiple of 4, whose other
     columns are exactly zero (K_mm^-1 padded with zero columns before the product) -- 16-byte aligned rows for `gram_weighted`
     whatever the number of tracked points; `padded_predictor(Kt)` recovers the buffer."""
@@ -128,7 +150,8 @@ def get_predictor(K_mm, K_nm, K_nn_diag, pad4=False):
         Kt = full[:, :, :m] if mp != m else full
         if mp != m:
             Kt._como_padded = full
-        var_n = var_n + (torch.min(var_n) + 1e-8)
+        vmin = torch.min(var_n) if row_mask is None else torch.min(torch.where(row_mask.reshape(1, n), var_n, torch.full_like(var_n, float("inf"))))
+        var_n = var_n + (vmin + 1e-8)
         return Kt, L_mm, 1.0 / torch.sqrt(var_n.unsqueeze(-1))
     if pad4 and m % 4:
         full = K_nm @ torch.nn.functional.pad(f["inv"], (0, 4 - m % 4))
@@ -137,7 +160,8 @@ def get_predictor(K_mm, K_nm, K_nn_diag, pad4=False):
     else:
         Kt = K_nm @ f["inv"]
     var_n = K_nn_diag - torch.sum(K_nm * Kt, dim=2)
-    var_n = var_n + (torch.min(var_n) + 1e-8)
+    vmin = torch.min(var_n) if row_mask is None else torch.min(torch.where(row_mask.reshape(var_n.shape), var_n, torch.full_like(var_n, float("inf"))))
+    var_n = var_n + (vmin + 1e-8)
     return Kt, L_mm, 1.0 / torch.sqrt(var_n.unsqueeze(-1))
 
 
@@ -155,19 +179,30 @@ def distill_depth(Knm_Kmminv, z_obs, with_prior, L_mm=None, stdev_inv_obs=None):
     return logz_m, Knm_Kmminv @ logz_m - logz_obs
 
 
-def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model, distill_with_prior, min_depth, stdev_obs=None):
-    """:88-118"""
+def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model, distill_with_prior, min_depth, stdev_obs=None,
+                               obs_mask=None, masked_residual=False):
+    """:88-118.  obs_mask (n,) bool or None: the observation rows that exist at all (a caller that did NOT gather the points that
+    reproject into the image passes their mask: every row rides along, the masked ones with zero weight).  masked_residual: the
+    second result is a `MaskedResidual` (all rows + the mask of the valid ones) instead of the gathered valid residuals."""
     assert coords_m.shape[0] == 1
-    Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL)
+    rm = None if obs_mask is None else obs_mask.reshape(1, -1)
+    Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL, row_mask=rm)
     if stdev_obs is not None:
         sinv = (1.0 / stdev_obs) * torch.ones_like(sinv)
+    if obs_mask is not None and not _fast(Kt):
+        # (the gathering form below needs gathered inputs)
+        sel = torch.nonzero(obs_mask)[:, 0]
+        Kt, z_obs, sinv, obs_mask = Kt.index_select(1, sel), z_obs.index_select(1, sel), sinv.index_select(1, sel), None
     if _fast(Kt):
         # the same normal equations with the rows read in place: the validity test becomes a zero weight (no gather of the
         # valid rows, no [prior ; observations] concatenation, no library GEMM with a single output tile)
         okm = z_obs[:, :, 0:1] > min_depth
+        if obs_mask is not None:
+            okm = okm & obs_mask.reshape(1, -1, 1)
         y = torch.log(torch.where(okm, z_obs[:, :, 0:1], torch.ones_like(z_obs[:, :, 0:1])))
         m = Kt.shape[2]
-        wgt = okm * (sinv * sinv) if distill_with_prior else okm.to(Kt.dtype)
+        # (a select, not a product: a masked row may hold anything -- a point behind the camera reprojects to non-finite coordinates)
+        wgt = torch.where(okm, sinv * sinv, torch.zeros_like(sinv)) if distill_with_prior else okm.to(Kt.dtype)
         AtA, Atb = gram_weighted(padded_predictor(Kt), wgt, y)
         if AtA.shape[1] != m:                                 # (zero-padded columns: their rows / columns of the products are zero)
             AtA, Atb = AtA[:, :m, :m].contiguous(), Atb[:, :m].contiguous()
@@ -176,7 +211,6 @@ def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model,
             Lm1 = trsm_lower(L_mm, eye)                       # the prior rows L_mm^-1 (distill_depth.py:60-63)
             AtA = AtA + Lm1.mT @ Lm1
         logz_m = chol_small(AtA, want_L=False, rhs=Atb)["X"]
-        ok = torch.nonzero(okm[0, :, 0])[:, 0]
         # residuals K~ logz_m - y: the predicted log-depths come from the depth-only pass of the dense-reference kernel (one
         # streaming pass, csrc/densify.hip) instead of a (n x m)(m x 1) library product
         from como_amd.odom.backend.dense_ref import depth_image
@@ -186,10 +220,12 @@ def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model,
             lz = torch.nn.functional.pad(lz, (0, Kp.shape[2] - m))
         pred = torch.empty((1, Kp.shape[1]), dtype=Kp.dtype, device=Kp.device)
         depth_image(Kp, lz, logz_out=pred)
-        return logz_m, (pred.unsqueeze(-1) - y).index_select(1, ok)
+        res = MaskedResidual(pred.unsqueeze(-1) - y, okm)
+        return logz_m, (res if masked_residual else res.compact())
     ok = torch.nonzero(z_obs[0, :, 0] > min_depth)[:, 0]
-    return distill_depth(Kt.index_select(1, ok), z_obs.index_select(1, ok), distill_with_prior, L_mm=L_mm,
-                         stdev_inv_obs=sinv.index_select(1, ok))
+    logz_m, res = distill_depth(Kt.index_select(1, ok), z_obs.index_select(1, ok), distill_with_prior, L_mm=L_mm,
+                                stdev_inv_obs=sinv.index_select(1, ok))
+    return logz_m, (MaskedResidual(res, torch.ones_like(res, dtype=torch.bool)) if masked_residual else res)
 
 
 def distill_conditional_depth_with_scale_prior(Knm_Kmminv, z_obs, z1, stdev_inv_obs):
@@ -207,23 +243,28 @@ def distill_conditional_depth_with_scale_prior(Knm_Kmminv, z_obs, z1, stdev_inv_
     return lstsq_chol(A, b)
 
 
-def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_img, z_obs, model, min_depth, stdev_obs):
-    """:152-175"""
+def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_img, z_obs, model, min_depth, stdev_obs, obs_mask=None):
+    """:152-175.  obs_mask: as in distill_depth_from_scratch."""
     assert coords_m.shape[0] == 1
     Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL)
     sinv = (1.0 / stdev_obs) * torch.ones_like(sinv)
     m, m1 = Kt.shape[2], z_m1.shape[1]
+    if obs_mask is not None and not _fast(Kt):
+        sel = torch.nonzero(obs_mask)[:, 0]
+        Kt, z_obs, sinv, obs_mask = Kt.index_select(1, sel), z_obs.index_select(1, sel), sinv.index_select(1, sel), None
     if _fast(Kt):
         # [sp I ; sinv K~[:, m1:]] x = [sp s ; sinv (log z_obs - K~[:, :m1] log z_1)] as weighted normal equations of the rows in place:
         # the known columns enter through c = [log z_1 ; 0] (r = y - K~ c), the unknown block is the lower-right corner
         from como_amd.utils.select import masked_median
         okm = z_obs[:, :, 0:1] > min_depth
+        if obs_mask is not None:
+            okm = okm & obs_mask.reshape(1, -1, 1)
         zs = torch.where(okm, z_obs[:, :, 0:1], torch.ones_like(z_obs[:, :, 0:1]))
         s_med = torch.log(masked_median(zs[0, :, 0], okm[0, :, 0]))
         sp2 = (1.0 / 5e-2) ** 2
         Kp = padded_predictor(Kt)
         c = torch.cat((torch.log(z_m1).reshape(1, m1, 1), torch.zeros((1, Kp.shape[2] - m1, 1), device=Kt.device, dtype=Kt.dtype)), dim=1)
-        AtA, Atb = gram_weighted(Kp, okm * (sinv * sinv), torch.log(zs), c=c)
+        AtA, Atb = gram_weighted(Kp, torch.where(okm, sinv * sinv, torch.zeros_like(sinv)), torch.log(zs), c=c)
         m2 = m - m1
         A22 = AtA[:, m1:m, m1:m] + sp2 * torch.eye(m2, device=Kt.device, dtype=Kt.dtype)
         b2 = Atb[:, m1:m] + sp2 * s_med

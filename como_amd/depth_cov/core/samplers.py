@@ -16,6 +16,28 @@ from como_amd.utils.lin_alg import chol_small, trsm_lower
 
 
 _domain_cache = {}
+_pending_info = []
+_INFO_SYNC = __import__("os").environ.get("COMO_SAMPLER_INFO_SYNC", "0") == "1"
+
+
+def check_info(info):
+    v = int(info.max())
+    if v != 0:
+        raise RuntimeError(f"como_amd precalc_entropy_vars: K_nn is not positive definite (leading minor {v})")
+
+
+def check_pending_info(wait=False):
+    """Raise if a sampler set-up since the last call found its K_nn not positive definite (the reference's torch.linalg.cholesky
+    raises inside precalc_entropy_vars).  The status words travel to the host asynchronously (utils/hostlist.read_later); the ones
+    that have arrived are checked -- all of them with wait=True."""
+    keep = []
+    while _pending_info:
+        h = _pending_info.pop(0)
+        if wait or h.ready():
+            check_info(h.value())
+        else:
+            keep.append(h)
+    _pending_info.extend(keep)
 
 
 def get_coords_domain(cov_params_img, border=0):
@@ -80,8 +102,15 @@ def precalc_entropy_vars(E_domain, gaussian_covs, n, coords_domain_norm, curr_co
     if fixed_var is not None and float(fixed_var) != 0.0:           # (+ 0.0 on the diagonal changes no bit of K_nn)
         K_nn += torch.diag_embed(fixed_var * torch.ones(b, m, device=dev))
     f = chol_small(K_nn, want_L=True, want_info=True)          # the initial factor (torch.linalg.cholesky in the reference)
-    if int(f["info"].max()) != 0:                              # ... which raises on a non-positive-definite K_nn: so does this
-        raise RuntimeError(f"como_amd precalc_entropy_vars: K_nn is not positive definite (leading minor {int(f['info'].max())})")
+    # ... which raises on a non-positive-definite K_nn: so does this -- at the caller's next synchronisation point
+    # (`check_pending_info`, called by Mapping.add_keyframe / by sample_sparse_coords' callers that read anything back) instead of
+    # a read-back of its own in the middle of the sampler's set-up (COMO_SAMPLER_INFO_SYNC=1: at once, as before)
+    if _INFO_SYNC:
+        check_info(f["info"])
+    else:
+        from como_amd.utils.hostlist import read_later
+        check_pending_info(wait=len(_pending_info) >= 8)
+        _pending_info.append(read_later(f["info"]))
     L[:, :m, :m] = f["L"]
     K_md = como_backends.cross_covariance(coords_n_norm[:, :m, :], E_n[:, :m, :, :], coords_domain_norm.view(b, -1, 2), E_domain,
                                           scale)
@@ -145,6 +174,7 @@ def greedy_loop(coord_vec_inds, coords_n_norm, E_n, coords_domain_norm, E_domain
     _lib.check(rc, "como_greedy_loop_ws_f32")
     if terminate_early:
         below = (trace[m:n] < max_stdev_thresh).all(dim=1).tolist()
+        check_pending_info(wait=True)                       # (that read-back synchronised: every pending status word has arrived)
         for k, stop in enumerate(below):
             if stop:
                 return coord_vec_inds[:, :m + k]
@@ -162,17 +192,19 @@ def _thin(cdn, E_domain, n, signal_var, fixed_var, max_stdev_thresh, dist_thresh
     f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     coords_n, E_n, L, obs, var, trace = f(n, 2), f(n, 4), f(n, n), f(n, d), f(d), f(n + 1)
     mask = torch.empty(d, dtype=torch.uint8, device=dev)
-    inds = torch.empty((1, n), dtype=torch.long, device=dev)
-    aux = torch.empty(2, dtype=torch.long, device=dev)                # [best index, count]
+    both = torch.empty(2 + n, dtype=torch.long, device=dev)           # [best index, count | picked indices]: ONE read-back
+    aux, inds = both[:2], both[2:].view(1, n)
     rc = _lib.lib().como_greedy_thin_f32(cdn.contiguous().data_ptr(), E_domain.contiguous().data_ptr(), coords_n.data_ptr(), E_n.data_ptr(),
                                          inds.data_ptr(), L.data_ptr(), obs.data_ptr(), var.data_ptr(), mask.data_ptr(), aux.data_ptr(),
                                          trace.data_ptr(), float(signal_var), float(signal_var),
                                          float(fixed_var) if fixed_var is not None else 0.0, float(dist_thresh) * float(dist_thresh),
                                          float(max_stdev_thresh), n, d, aux[1:].data_ptr(), _lib.stream_ptr(dev))
     _lib.check(rc, "como_greedy_thin_f32")
-    count = int(aux[1])                                               # the one host synchronisation
+    vals = both[1:].tolist()                                          # the one host synchronisation: count AND the picks
+    count = int(vals[0])
     if count == 0:
         raise RuntimeError("como_amd sample_sparse_coords: K_nn is not positive definite")
+    _thin.last_list = [int(v) for v in vals[1:1 + count]]
     return inds[:, :count]
 
 
@@ -192,6 +224,7 @@ def sample_sparse_coords(cov_params_img, num_samples, mode, max_stdev_thresh=-1e
     img_size = cov_params_img.shape[-2:]
     dev = cov_params_img.device
     cov = cov_params_img.to(device=dev, dtype=dtype)
+    sample_sparse_coords.last_picked_list = None            # host copy of the returned indices, when a read-back produced one
     if curr_coords is None:
         curr_coords = torch.empty((b, 0, 2), device=dev, dtype=dtype)
     if curr_var is None:
@@ -210,6 +243,7 @@ def sample_sparse_coords(cov_params_img, num_samples, mode, max_stdev_thresh=-1e
         if (THIN_KERNEL and mode == "greedy_conditional_entropy" and terminate_early and b == 1 and curr_coords.shape[1] == 0 and
                 curr_var.shape[1] == 0 and dtype == torch.float32 and cdn.is_cuda and 0 < coords_domain.shape[1] <= 1024):
             inds = _thin(cdn, E_domain, min(num_samples, coords_domain.shape[1]), signal_var, fixed_var, max_stdev_thresh, dist_thresh)
+            sample_sparse_coords.last_picked_list = _thin.last_list
             return coords_domain.index_select(1, inds[0]), inds
     if mode == "random_uniform":
         inds = random_uniform(num_samples - curr_coords.shape[-2], cdn)

@@ -22,6 +22,8 @@ import os
 import torch
 
 _PIX_MIRRORS = os.environ.get("COMO_PIX_MIRRORS", "1") != "0"       # 0: every window rebuild converts the whole K~ / image window (A/B)
+_HOST_CORR = os.environ.get("COMO_KF_HOST_CORR", "1") != "0"        # 0: the correspondence-mask bookkeeping of a keyframe insertion on the device (A/B)
+_SE3_NORMALIZE_KERNEL = os.environ.get("COMO_SE3_NORMALIZE_KERNEL", "1") != "0"   # 0: LAPACK SVD on the host (A/B)
 _FUSED_FRAME = os.environ.get("COMO_FUSED_FRAME", "1") != "0"       # 0: the torch chains of a frame hand-over (world pose / affine, gray + gradients + cat + copies) (A/B)
 _KEPT_MEDIANS = os.environ.get("COMO_KF_KEPT_MEDIANS", "1") != "0"  # 0: a keyframe insertion re-evaluates every keyframe's depth image (A/B)
 _RETARGET = os.environ.get("COMO_BA_RETARGET", "1") != "0"          # 0: a one-way frame builds a new window object, as round 5 (A/B)
@@ -44,16 +46,18 @@ _DTYPES = {"float": torch.float32, "double": torch.float64}
 
 
 def normalizeSE3_inplace(T):
-    """Project the rotation block onto SO(3) (reference geometry/lie_algebra.py:98-101)."""
-    R = T[..., :3, :3]
-    if R.is_cuda:
-        # one 3x3 per keyframe: the device SVD (a dozen solver launches and its own synchronisations, ~1 ms) on 72 bytes --
-        # LAPACK on the host, as the torch-CPU reference does it
-        U, _, Vh = torch.linalg.svd(R.cpu())
-        T[..., :3, :3] = (U @ Vh).to(R.device)
+    """Project the rotation block onto SO(3) (reference geometry/lie_algebra.py:98-101: U V^T of the SVD).  On the GPU: one thread
+    per pose running Newton's polar iteration (csrc/window.hip se3_normalize_kernel) -- the pose comes from a tracked float32
+    transform, i.e. its rotation block is a rotation up to 1e-7; the device SVD is a dozen solver launches with their own
+    synchronisations (~1 ms) and the host LAPACK form a device -> host -> device round trip in the middle of a keyframe insertion."""
+    if T.is_cuda and T.dtype in (torch.float32, torch.float64) and T.is_contiguous() and T.dim() == 3 and _SE3_NORMALIZE_KERNEL:
+        from como_amd import _lib
+        _lib.check(getattr(_lib.lib(), "como_se3_normalize_" + _lib.suffix(T.dtype))(T.data_ptr(), T.shape[0], _lib.stream_ptr(T.device)),
+                   "como_se3_normalize")
         return
-    U, _, Vh = torch.linalg.svd(R)
-    T[..., :3, :3] = U @ Vh
+    R = T[..., :3, :3]
+    U, _, Vh = torch.linalg.svd(R.cpu())
+    T[..., :3, :3] = (U @ Vh).to(R.device)
 
 
 class Mapping:
@@ -351,6 +355,8 @@ class Mapping:
         self.store_vars(pm, logz_m, Knm_Kmminv)
 
     def add_keyframe(self, rgb, kf_pose_init, kf_aff_init, timestamp):
+        from como_amd.depth_cov.core.samplers import check_pending_info
+        check_pending_info()                                  # (status words of the previous insertion's sampler: arrived long ago)
         img_and_grads = self.get_img_and_grads(rgb)
         coords_m_last = swap_coords_xy(self.pm[-1:, ...])
         zm_last = torch.exp(self.logzm[-1:, ...])
@@ -378,7 +384,7 @@ class Mapping:
         self.initialize_pose_vars(kf_pose_init, kf_aff_init)
         self.initialize_kf_img_vars_vars(rgb, img_and_grads, cov_params_img)
         self.initialize_sparse_pixel_vars(pm_first_obs, zm_first_obs, coords_m_new.shape[1], Kmm_inv, L_mm, Knm_Kmminv)
-        self.initialize_sparse_landmark_vars(corr_mask, Pw_new.squeeze(0))
+        self.initialize_sparse_landmark_vars(corr_mask, Pw_new.squeeze(0), corr_host=getattr(track_and_init, "corr_host", None))
         self.reset_iteration_vars(new_kf=True)
         self.store_vars(self.pm, self.logzm, self.Knm_Kmminv, kept_depths=kept_depths, kept_medians=kept_medians)
         self.prune_one_way()
@@ -463,16 +469,45 @@ class Mapping:
         self._cat("L_mm", L_mm, i)
         self._cat("Knm_Kmminv", Knm_Kmminv, i)
 
-    def initialize_sparse_landmark_vars(self, corr_mask, P):
-        """Correspondence mask (num_kf x num_landmarks) and landmark list after inserting a keyframe (Mapping.py:321-367)."""
+    def initialize_sparse_landmark_vars(self, corr_mask, P, corr_host=None):
+        """Correspondence mask (num_kf x num_landmarks) and landmark list after inserting a keyframe (Mapping.py:321-367).
+        corr_host: `corr_mask` as a host list (frontend/corr.py reads it back with the sampler's picks).  With it the bookkeeping --
+        which landmarks are still seen by a keyframe that stays, which of the last keyframe's were tracked on -- runs on a HOST
+        mirror of the correspondence mask (`_corr_host`, numpy) and the device tensors are gathered with index lists built there:
+        no boolean-mask indexing, i.e. no `nonzero` + host synchronisation in the middle of a keyframe insertion (two of them
+        before).  Without it (or once the mirror is lost) the device form below runs."""
+        import numpy as np
+        from como_amd.utils.hostlist import to_device
         i = self.get_kf_start_window_ind()
         num_kf = self.correspondence_mask.shape[0] if self.correspondence_mask.dim() > 1 else 0
         self.window_full = num_kf >= self.cfg["graph"]["num_keyframes"]
         n_new = P.shape[0]
+        mirror = getattr(self, "_corr_host", None)
         if num_kf == 0:
             self.correspondence_mask = corr_mask
             self.P_m = P
+            # (the first keyframe: every point is its own landmark -- init_keyframe passes an all-true mask)
+            self._corr_host = np.ones(tuple(corr_mask.shape), dtype=bool) if corr_host is None and n_new == corr_mask.shape[-1] else (
+                np.asarray(corr_host, dtype=bool).reshape(tuple(corr_mask.shape)) if corr_host is not None else None)
+        elif (corr_host is not None and mirror is not None and mirror.shape == tuple(self.correspondence_mask.shape) and _HOST_CORR
+              and self.P_m.is_cuda):
+            old = mirror
+            alive = old[i:, :].any(axis=0)
+            tracked = np.zeros(old.shape[1], dtype=bool)
+            tracked[np.nonzero(old[-1, :])[0]] = np.asarray(corr_host, dtype=bool)
+            ai = np.nonzero(alive)[0]
+            kept = np.concatenate((old[i:, :][:, ai], tracked[ai][None]), axis=0)
+            fresh = np.zeros((kept.shape[0], n_new), dtype=bool)
+            fresh[-1, :] = True
+            new = np.concatenate((kept, fresh), axis=1)
+            self._corr_host = new
+            self.correspondence_mask = to_device(new, torch.bool, self.device)
+            self.P_m = torch.cat((self.P_m.index_select(0, to_device(ai, torch.int64, self.device)), P), dim=0)
+            if self.window_full:
+                self.P_m_anchors = self.P_m.index_select(0, to_device(np.nonzero(new[0, :])[0], torch.int64, self.device))
+            return
         else:
+            self._corr_host = None                                   # (the mirror cannot follow: device form from here on)
             old = self.correspondence_mask
             alive = old[i:, :].any(dim=0)                          # landmarks still seen by a keyframe that stays
             tracked = torch.zeros_like(old[0, :])
@@ -533,6 +568,9 @@ class Mapping:
                        "recent_img_and_grads": self.recent_img_and_grads, "recent_timestamps": ts(self.recent_timestamps)})
         # whose state these tensors were published from (iterate): a re-targeted window need not load them again
         st["_published_by"] = getattr(self, "_state_owner", None)
+        mirror = getattr(self, "_corr_host", None)
+        if mirror is not None and mirror.shape == tuple(self.correspondence_mask.shape):
+            st["corr_host"] = mirror
         for name in self._PIX_MIRRORED:                       # already in the solver's per-pixel element type (see _cat)
             mirror = getattr(self, name + "_pix", None)
             if mirror is not None and name in st and mirror.shape == st[name].shape:

@@ -27,10 +27,15 @@ def filter_reproj_coords(coords, P, img_size, min_depth):
     return coords.index_select(1, idx), P.index_select(1, idx), keep
 
 
-def reproject_and_filter(coords_i, zi, Tji, K, img_size=None, min_depth=0.0, grid_width=None, want_idx=False):
+def reproject_and_filter(coords_i, zi, Tji, K, img_size=None, min_depth=0.0, grid_width=None, want_idx=False, compact=True,
+                         host_idx=False):
     """reproject_points (+ filter_reproj_coords when img_size is given) as ONE launch (csrc/trackref.hip
     `como_reproject_points_*`): coords_i (1,n,2) row/col or None with grid_width = W (the points are the pixel grid), zi (1,n,1).
-    Returns (coords_j (1,k,2), P_j (1,k,3), keep (n,) bool or None): the kept points in index order."""
+    Returns (coords_j (1,k,2), P_j (1,k,3), keep (n,) bool or None): the kept points in index order.
+    compact=False: ALL n points come back (coords_j (1,n,2), P_j (1,n,3), keep (n,) bool) -- the caller carries `keep` as a row
+    mask (zero weights) instead of gathering the kept rows: no `nonzero`, no host synchronisation, no 300k-row gathers.
+    host_idx: the kept indices are read back as a Python list (the one synchronisation `nonzero` costs anyway) and returned
+    as (..., keep, idx device tensor, idx list)."""
     from como_amd import _lib
     dt, dev = zi.dtype, zi.device
     n = zi.shape[1]
@@ -47,10 +52,20 @@ def reproject_and_filter(coords_i, zi, Tji, K, img_size=None, min_depth=0.0, gri
     if keep is None:
         return rc, P, None
     keep = keep.view(torch.bool)
+    if not compact:
+        return rc, P, keep
+    if host_idx:
+        from como_amd.utils.hostlist import to_device
+        idx_list = [j for j, kp in enumerate(keep.tolist()) if kp]
+        idx = to_device(idx_list, torch.int64, dev)
+        return rc.index_select(1, idx), P.index_select(1, idx), keep, idx, idx_list
     idx = torch.nonzero(keep)[:, 0]
     if want_idx:
         return rc.index_select(1, idx), P.index_select(1, idx), keep, idx
     return rc.index_select(1, idx), P.index_select(1, idx), keep
+
+
+_MASKED_DENSE = __import__("os").environ.get("COMO_KF_MASKED_DENSE", "1") != "0"     # 0: compact the reprojected dense points (A/B)
 
 
 def _kernel_path(z):
@@ -105,9 +120,15 @@ def prepare_track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, K, cov_size, c
     Tji = composeSE3(pose2, pose1, 1)
     z_n1 = z_img1.reshape(b, 1, N).permute(0, 2, 1)
     fused = _kernel_path(z_n1) and z_m1.dtype == z_n1.dtype
+    idx_list, keep_n = None, None
     if fused:
-        cj_m, Pj_m, keep_m, idx_m = reproject_and_filter(coords_m1, z_m1, Tji, K, cov_size, min_d, want_idx=True)
-        cj_n, Pj_n, _ = reproject_and_filter(None, z_n1, Tji, K, cov_size, min_d, grid_width=z_img1.shape[-1])
+        # the m sparse points: compacted (their number shapes the small systems), the kept indices ALSO as a host list (this is the
+        # keyframe path's first synchronisation either way); the H W dense points: NOT compacted -- `keep_n` travels as a row mask
+        cj_m, Pj_m, keep_m, idx_m, idx_list = reproject_and_filter(coords_m1, z_m1, Tji, K, cov_size, min_d, host_idx=True)
+        if _MASKED_DENSE:
+            cj_n, Pj_n, keep_n = reproject_and_filter(None, z_n1, Tji, K, cov_size, min_d, grid_width=z_img1.shape[-1], compact=False)
+        else:
+            cj_n, Pj_n, _ = reproject_and_filter(None, z_n1, Tji, K, cov_size, min_d, grid_width=z_img1.shape[-1])
     else:
         coords_n1 = get_test_coords(z_img1.shape[-2:], device=dev, batch_size=b)
         cj_m, Pj_m = reproject_points(coords_m1, z_m1, Tji, K)
@@ -119,7 +140,8 @@ def prepare_track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, K, cov_size, c
     gx, gy = ImageGradientModule(channels=1, device=dev, dtype=z_img1.dtype)(torch.log(z_img1))
     grad_ref = _sample_at(torch.sqrt(gx * gx + gy * gy), coords_m1.index_select(1, idx_m), cov_size)
     return {"Tji": Tji, "Tij": invertSE3(Tji), "fused": fused, "cj_m": cj_m, "Pj_m": Pj_m, "keep_m": keep_m, "cj_n": cj_n,
-            "zj_n": Pj_n[:, :, 2:3], "grad_ref": grad_ref, "z_dtype": z_n1.dtype, "idx_m": idx_m}
+            "zj_n": Pj_n[:, :, 2:3], "grad_ref": grad_ref, "z_dtype": z_n1.dtype, "idx_m": idx_m, "idx_m_list": idx_list,
+            "keep_n": keep_n}
 
 
 def track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, cov_params_img2, K, model, corr_params, sampling_params,
@@ -136,10 +158,13 @@ def track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, cov_params_img2, K, mo
     min_d = corr_params["min_obs_depth"]
     pre = prepared if prepared is not None else prepare_track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, K, cov_size, corr_params)
     cj_m, Pj_m, keep_m, cj_n, zj_n, grad_ref = pre["cj_m"], pre["Pj_m"], pre["keep_m"], pre["cj_n"], pre["zj_n"], pre["grad_ref"]
+    keep_n = pre.get("keep_n")                             # row mask of the (uncompacted) dense points, or None (compacted)
+    track_and_init.corr_host = None
 
     # latent depths of the reprojected sparse points under the NEW frame's covariance, from the reprojected dense depths
     logz_m, logz_res = distill_depth_from_scratch(cj_m, cj_n, zj_n, cov_params_img2, model,
-                                                  distill_with_prior=corr_params["distill_with_prior"], min_depth=min_d)
+                                                  distill_with_prior=corr_params["distill_with_prior"], min_depth=min_d,
+                                                  obs_mask=keep_n, masked_residual=keep_n is not None)
     z_m = torch.exp(logz_m)
     P_m = backprojection_points(K[0], swap_coords_xy(cj_m), z_m)
 
@@ -155,8 +180,16 @@ def track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, cov_params_img2, K, mo
     good = ((err < corr_params["corr_thresh"]) & (grad_ref < corr_params["logz_grad_mag_thresh"]))[0, :, 0]
 
     # (index lists instead of boolean masks from here on: every boolean-mask selection / assignment synchronises with the host to
-    # learn its size -- one `nonzero` does, the rest are gathers and scatters with the same element order)
-    gi = torch.nonzero(good)[:, 0]
+    # learn its size -- one read-back does, the rest are gathers and scatters with the same element order; the read-back returns
+    # the VALUES, so that the caller can keep its landmark bookkeeping on the host: `track_and_init.corr_host`)
+    from como_amd.utils.hostlist import to_device
+    host = pre.get("idx_m_list") is not None and good.is_cuda
+    if host:
+        gi_list = [j for j, g_ in enumerate(good.tolist()) if g_]
+        gi = to_device(gi_list, torch.int64, dev)
+    else:
+        gi = torch.nonzero(good)[:, 0]
+        gi_list = None
     coords_1 = cj_m.index_select(1, gi)
     z1 = Pj_m[:, :, 2:3].index_select(1, gi)
     n_max = sampling_params["max_num_coords"]
@@ -168,12 +201,26 @@ def track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, cov_params_img2, K, mo
                                              terminate_early=True, dist_thresh=sampling_params["dist_thresh"],
                                              signal_var=model.get_scale(-1), fixed_var=sampling_params["fixed_var"],
                                              coords_domain=coords_1)
-        ps = torch.sort(picked[0, :])[0]                     # the picked points in their original order (= a boolean mask's order)
+        picked_list = getattr(sample_sparse_coords, "last_picked_list", None) if host else None
+        if picked_list is not None and len(picked_list) == picked.shape[1]:
+            ps_list = sorted(picked_list)                    # the picked points in their original order (= a boolean mask's order)
+            ps = to_device(ps_list, torch.int64, dev)
+            gi_list = [gi_list[p_] for p_ in ps_list]
+        else:
+            ps = torch.sort(picked[0, :])[0]
+            gi_list = None
         coords_1 = coords_1.index_select(1, ps)
         z1 = z1.index_select(1, ps)
         gi = gi.index_select(0, ps)
     corr_mask = torch.zeros_like(keep_m)
-    corr_mask[pre["idx_m"].index_select(0, gi)] = True
+    if gi_list is not None:
+        corr_list = [False] * int(keep_m.shape[0])
+        for j in gi_list:
+            corr_list[pre["idx_m_list"][j]] = True
+        track_and_init.corr_host = corr_list                 # which of the previous keyframe's m points stay (host copy)
+        corr_mask = to_device(corr_list, torch.bool, dev)
+    else:
+        corr_mask[pre["idx_m"].index_select(0, gi)] = True
 
     if coords_1.shape[1] < n_max:
         with torch.no_grad():
@@ -185,8 +232,9 @@ def track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, cov_params_img2, K, mo
             coords_2 = coords_2.to(dtype=coords_1.dtype)
         coords_all = torch.cat((coords_1, coords_2), dim=1)
         # depths of the new points conditioned on the tracked ones; observation noise = spread of the first fit
+        stdev_obs = logz_res.std() if hasattr(logz_res, "okm") else torch.std(logz_res)
         logz_2 = distill_conditional_depth_from_scratch(coords_all, z1, cj_n, cov_params_img2, zj_n, model, min_depth=0.0,
-                                                        stdev_obs=torch.std(logz_res))
+                                                        stdev_obs=stdev_obs, obs_mask=keep_n)
         z2 = torch.exp(logz_2)
         z_all = torch.cat((z1, z2), dim=1)
     else:

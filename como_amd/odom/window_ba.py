@@ -104,6 +104,7 @@ class WindowBA:
         self.median_depths = self.state_flat[o_med:o_med + B]
         self._load_frames(state)
         self.correspondence_mask = state["correspondence_mask"]
+        self._corr_host = state.get("corr_host")             # numpy copy of it, when the caller keeps one (Mapping does)
         self.obs_ref_mask = state["obs_ref_mask"].contiguous()
         self.pm_first_obs = f64(state["pm_first_obs"])
         self.L_mm = f64(state["L_mm"])
@@ -228,6 +229,48 @@ class WindowBA:
 
         return remap, landmark_ids, lm_of
 
+    def _host_tables(self, mask):
+        """The landmark index tables of `_prepare_topology` from a HOST copy of the correspondence mask (Mapping keeps one: numpy
+        bool (B,L)), built with numpy and uploaded in ONE pinned copy -- ~25 small device launches (argsort, gathers, scatters,
+        arange slices) of every keyframe insertion's window rebuild otherwise.  False when there is no usable host copy."""
+        import numpy as np
+        B, m, L, dev = self.B, self.m, self.L, self.dev
+        if mask is None or dev.type != "cuda" or tuple(mask.shape) != (B, L) or not (mask.sum(axis=1) == m).all():
+            return False
+        from como_amd.utils.hostlist import to_device
+        lm_of = np.stack([np.nonzero(mask[b])[0] for b in range(B)]).astype(np.int64)            # (B,m) landmark of every slot
+        point_inds = (3 * np.repeat(lm_of, 3, axis=1) + np.tile(np.arange(3), m)[None]).astype(np.int64)
+        first_obs = np.argmax(mask, axis=0).astype(np.int64)                                      # first observer keyframe (L,)
+        fom = np.zeros_like(mask)
+        fom[first_obs, np.arange(L)] = True
+        first_obs_mask = np.take_along_axis(fom, lm_of, axis=1)
+        slot_of = np.full((B, L), -1, dtype=np.int32)
+        np.put_along_axis(slot_of, lm_of, np.arange(m, dtype=np.int32)[None].repeat(B, 0), axis=1)
+        first_slot = slot_of[first_obs, np.arange(L)]
+        # one byte block: [int64: lm_of | point_inds] [int32: lm_ids | first_frame | first_slot | pad] [bool: first_obs_mask]
+        i64 = np.concatenate((lm_of.reshape(-1), point_inds.reshape(-1)))
+        i32 = np.concatenate((lm_of.reshape(-1).astype(np.int32), first_obs.astype(np.int32), first_slot.astype(np.int32)))
+        if i32.size % 2:
+            i32 = np.concatenate((i32, np.zeros(1, np.int32)))
+        raw = np.concatenate((i64.view(np.uint8), i32.view(np.uint8), first_obs_mask.reshape(-1).view(np.uint8)))
+        d = to_device(raw, torch.uint8, dev)
+        o1, o2 = i64.nbytes, i64.nbytes + i32.nbytes
+        d64, d32 = d[:o1].view(torch.int64), d[o1:o2].view(torch.int32)
+        lm_dev = d64[:B * m].view(B, m)
+        self.point_inds = d64[B * m:].view(B, 3 * m)
+        self.lm_ids = d32[:B * m].view(B, m)
+        self.first_frame = d32[B * m:B * m + L]
+        self.first_slot = d32[B * m + L:B * m + 2 * L]
+        self.first_obs_mask = d[o2:o2 + B * m].view(torch.bool).view(B, m)
+        self.fix_idx = lm_dev[0]
+
+        def remap(variable, default_val=-1):           # variable (B,L,...) -> (B,m,...); every slot is filled
+            idx = lm_dev.reshape((B, m) + (1,) * (variable.dim() - 2)).expand((B, m) + tuple(variable.shape[2:]))
+            return torch.gather(variable, 1, idx)
+
+        self.remap = remap
+        return True
+
     # ---- things that change only when the keyframe set changes ---------------------------------------------------
     _KF_SET_ATTRS = ("coords_n", "n_total", "pixidx", "channels", "vals_n", "n", "remap", "point_inds", "L", "kf_inds", "fix_idx",
                      "lm_ids", "first_obs_mask", "first_frame", "first_slot")
@@ -274,11 +317,15 @@ class WindowBA:
             self.vals_n = self.vals_n[:, pb:pe].contiguous()
             self.row_range = self.shard.row_range(self.Himg * self.Wimg)
         self.n = self.pixidx.shape[1]
-        self.remap, landmark_ids, lm_of = self._fixed_remap(self.correspondence_mask, m)
-        self.point_inds = lin_sys.landmark_to_batched_3d_point_inds(landmark_ids, B)
         L = self.P_m.shape[0]
         self.L = L
         self.kf_inds = _ar(8 * B, dev).reshape(B, 8)
+        if self._host_tables(getattr(self, "_corr_host", None)):
+            self._finish_topology()
+            self._inherit = None
+            return
+        self.remap, landmark_ids, lm_of = self._fixed_remap(self.correspondence_mask, m)
+        self.point_inds = lin_sys.landmark_to_batched_3d_point_inds(landmark_ids, B)
         # index lists of the oldest keyframe's landmarks (their anchors, Mapping.py:884-898): precomputed -- boolean-mask
         # indexing inside the iteration would synchronise with the host (and cannot be captured in a hipGraph)
         self.fix_idx = lm_of[0]

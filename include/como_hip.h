@@ -542,6 +542,11 @@ int como_win_update(const double* delta, double* poses, double* aff, const long*
  * or -1 = the persistent solver's time-out, which leaves delta unwritten -- nothing is updated (the reference swallows the error,
  * linear_system.py:109, and applies whatever came out; SURVEY.md section 5 asks for the status to be acted on).  The caller reads
  * `info` at its next synchronisation point and decides (re-solve on the multi-launch solver / raise). */
+/* normalizeSE3_inplace (como/geometry/lie_algebra.py:98-101): the rotation block of n contiguous (4,4) poses is replaced by its
+ * nearest rotation (the orthogonal polar factor = U V^T of the SVD the reference takes), by Newton's iteration on the device; the
+ * input must be a rotation up to rounding / float32 noise.  In place. */
+int como_se3_normalize_f32(float* poses, int n, como_stream_t stream);
+int como_se3_normalize_f64(double* poses, int n, como_stream_t stream);
 /* A tracked frame's pose and affine brightness in the world frame (Mapping.handle_tracking_data, Mapping.py:580-598): T_out (4,4) =
  * T_w_kf inv(T_curr_kf) (get_T_w_curr, como/geometry/transforms.py:6-8), aff_out (2) = (a_kf + a_cur, b_kf + b_cur exp(a_cur))
  * (get_aff_w_curr, como/geometry/affine_brightness.py:5-10).  T_curr_kf / aff_curr_kf: float32 (cur_is_f32, widened first) or float64. */
