@@ -111,6 +111,9 @@ SIGNATURES = {
     "como_greedy_thin_f32": (c_int, [c_void_p] * 11 + [c_float] * 5 + [c_int, c_int, c_void_p, c_void_p]),
     "como_greedy_loop_ws_f32": (c_int, [c_void_p] * 11 + [c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_long,
                                         c_void_p]),
+    "como_greedy_persist_workspace_bytes": (c_long, [c_int, c_int]),
+    "como_greedy_persist_f32": (c_int, [c_void_p] * 11 + [c_float, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
     "como_greedy_next_f32": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "como_dense_ref_f32": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8 + [c_int, c_void_p]),
     "como_dense_ref_f64": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8 + [c_int, c_void_p]),

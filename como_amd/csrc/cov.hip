@@ -502,6 +502,285 @@ __global__ __launch_bounds__(1024) void greedy_thin_kernel(const float* __restri
   if (tid == 0) *count_out = count;
 }
 
+// ---- the large-domain greedy loop as ONE persistent launch (round 6) -----------------------------------------------------------
+// The launch-per-step form streams, for the i-th added point, the i previous obs_info rows of every domain pixel (1.2 MB each at a
+// 640x480 domain: 34-63 rows = 40-76 MB per step, 19.7 us at 2.9 TB/s) -- byte-bound, ~1 ms per keyframe insertion -- although a
+// pixel's column obs_info[0..i][j] is only ever read by the thread that owns pixel j.  Here every thread keeps the columns of its
+// GP_PPT pixels in REGISTERS for the whole loop (64 rows x 3 pixels = 192 VGPRs: 448 pixel threads per workgroup, one workgroup per
+// compute unit, 224 workgroups cover 300k pixels), so a step is arithmetic + ONE grid-wide exchange of the workgroups' best
+// candidates (the "pick2" reduction every workgroup then redoes for itself):
+//   * wave 7 of every workgroup is the CHAIN wave: it keeps row `lane` of L in registers and forms the new Cholesky row
+//     (greedy_append_body's readlane chain) while the seven pixel waves evaluate k(x_new, x_j) for their pixels;
+//   * the pixel waves then subtract their column . row, downdate the variance, apply the new point's distance mask and leave the
+//     workgroup's best candidate in its own 128-byte line of `part[step]` (agent-scope stores, one arrival on the step's counter --
+//     csrc/cholp.hip's hand-off protocol: every line is written once before anyone reads it);
+//   * after the arrivals every workgroup reduces the G candidates with the same order rule (largest cost, then smallest index) and
+//     workgroup 0 records the pick.
+// Same operations on the same values as greedy_append_scan_kernel + greedy_pick2_kernel, hence the same picks (tested); obs_info
+// rows and the downdated variance are NOT written back (the loop's caller discards them).  One image (B = 1).
+constexpr int GP_THREADS = 512;
+constexpr int GP_PIX_THREADS = 448;    // waves 0..6 own pixels, wave 7 is the chain wave
+constexpr int GP_PPT = 3;
+constexpr int GP_LINE = 32;            // floats per workgroup record of `part` (its own 128-byte line)
+constexpr int GP_LROWS = 16;           // the first rows of every column live in LDS (86 KB), rows 16..63 in registers (144 VGPRs)
+constexpr int GP_RROWS = 64 - GP_LROWS;
+constexpr int GP_LDS_BYTES = GP_LROWS * GP_PPT * GP_PIX_THREADS * 4;
+
+struct GPArgs {
+  float* coords_n; float* E_n; long* inds;
+  const float* dom; const float* Edom;
+  float* L; const float* obs_info; const float* var; const uint8_t* mask;
+  long* best_idx; float* max_stdev; float* sd_trace;
+  float* part;            // (n + 1) x G x GP_LINE
+  unsigned* cnt;          // (n + 2) x 32 words: arrival counter per step, then the error flag
+  int* status;            // 0 ok, -1 a wait timed out (workgroups not co-resident)
+  float scale, k_ii, thresh_sq;
+  int n, d, m;
+};
+
+__device__ __forceinline__ bool gp_better(float c2, int i2, float c1, int i1) { return c2 > c1 || (c2 == c1 && i2 < i1); }
+
+// every workgroup: publish (cost, idx, sd), wait for all G, reduce -> the pick of this step (same on every workgroup).
+// false: a wait timed out.
+__device__ __forceinline__ bool gp_exchange(const GPArgs& a, int step, int G, float cost, int idx, float sd, float* red_c, int* red_i,
+                                            float* red_s, int* ok_s, int& w_out, float& sd_out) {
+  const int tid = threadIdx.x;
+  red_c[tid] = cost; red_i[tid] = idx; red_s[tid] = sd;
+  __syncthreads();
+  for (int h = GP_THREADS / 2; h > 0; h >>= 1) {
+    if (tid < h && gp_better(red_c[tid + h], red_i[tid + h], red_c[tid], red_i[tid])) {
+      red_c[tid] = red_c[tid + h]; red_i[tid] = red_i[tid + h]; red_s[tid] = red_s[tid + h];
+    }
+    __syncthreads();
+  }
+  float* line = a.part + ((long)step * G + blockIdx.x) * GP_LINE;
+  unsigned* cnt = a.cnt + 32 * step;
+  unsigned* errf = a.cnt + 32 * (a.n + 1);
+  if (tid == 0) {
+    __hip_atomic_store(&line[0], red_c[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&line[1], __int_as_float(red_i[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&line[2], red_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int ok = 1;
+    for (long spin = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G; ++spin) {
+      if ((spin & 63) == 63 && __hip_atomic_load(errf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+      if (spin > 1500000) { atomicExch(errf, 1u); ok = 0; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    *ok_s = ok;
+  }
+  __syncthreads();
+  if (!*ok_s) return false;
+  float c = -1.f, s2 = 0.f;
+  int bi = 0x7fffffff;
+  if (tid < G) {
+    const float* ln = a.part + ((long)step * G + tid) * GP_LINE;
+    c = __hip_atomic_load(&ln[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bi = __float_as_int(__hip_atomic_load(&ln[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    s2 = __hip_atomic_load(&ln[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  red_c[tid] = c; red_i[tid] = bi; red_s[tid] = s2;
+  __syncthreads();
+  for (int h = GP_THREADS / 2; h > 0; h >>= 1) {
+    if (tid < h && gp_better(red_c[tid + h], red_i[tid + h], red_c[tid], red_i[tid])) {
+      red_c[tid] = red_c[tid + h]; red_i[tid] = red_i[tid + h]; red_s[tid] = red_s[tid + h];
+    }
+    __syncthreads();
+  }
+  w_out = red_i[0];
+  sd_out = red_s[0];
+  __syncthreads();
+  return true;
+}
+
+__global__ __launch_bounds__(GP_THREADS) void greedy_persist_kernel(GPArgs a) {
+  __shared__ float red_c[GP_THREADS], red_s[GP_THREADS];
+  __shared__ int red_i[GP_THREADS];
+  __shared__ float s_new[8];            // the point being added: y, x, E (4)
+  __shared__ float s_lrow[64];          // its Cholesky row l_0 .. l_{N-1}, zero beyond
+  __shared__ float s_lnn;               // ... and its diagonal entry
+  __shared__ int ok_s;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int G = gridDim.x, n = a.n, d = a.d, m = a.m;
+  const bool chain = wv == 7;
+  // ONE register array for both roles (the compiler cannot know that the roles never meet in a wave): a pixel thread's columns
+  // obs_info[16..63][pixel k] at R[48 k + i - 16] (rows 0..15 in LDS: s_col[i][k][tid], conflict-free); the chain wave's row `lane`
+  // of L at R[0..63].  Every register index below is static.
+  extern __shared__ float s_col[];
+  float R[GP_PPT * GP_RROWS];
+  float pvar[GP_PPT];
+  int pj[GP_PPT];
+  bool pin[GP_PPT], pok[GP_PPT];
+  float cy = 0.f, cx = 0.f, cE[4] = {0.f, 0.f, 0.f, 0.f}, diag = 1.f;      // chain wave: point `lane`
+#pragma unroll
+  for (int k = 0; k < GP_PPT; ++k) {
+    const long j = ((long)k * G + blockIdx.x) * GP_PIX_THREADS + tid;
+    pin[k] = !chain && j < d;
+    pj[k] = pin[k] ? (int)j : d - 1;
+    pvar[k] = a.var[pj[k]];
+    pok[k] = pin[k] && a.mask[pj[k]] != 0;
+  }
+  if (!chain) {
+#pragma unroll
+    for (int k = 0; k < GP_PPT; ++k) {
+#pragma unroll
+      for (int i = 0; i < GP_LROWS; ++i) s_col[(i * GP_PPT + k) * GP_PIX_THREADS + tid] = (i < m) ? a.obs_info[(long)i * d + pj[k]] : 0.f;
+#pragma unroll
+      for (int i = 0; i < GP_RROWS; ++i) R[GP_RROWS * k + i] = (i + GP_LROWS < m) ? a.obs_info[(long)(i + GP_LROWS) * d + pj[k]] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < GP_PPT * GP_RROWS; ++i) R[i] = (i < 64 && lane < m && i < m) ? a.L[(long)lane * n + i] : 0.f;
+    if (lane < m) {
+      cy = a.coords_n[2 * lane]; cx = a.coords_n[2 * lane + 1];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cE[e] = a.E_n[4 * lane + e];
+      diag = a.L[(long)lane * n + lane];
+    }
+  }
+  // ---- the first pick: distance mask against the m current points (greedy_scan_kernel with k = m) ----
+  float best = -1.f, best_sd = 0.f;
+  int bi = 0x7fffffff;
+  {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int k = 0; k < GP_PPT; ++k) {
+      bool ok = pok[k];
+      const float pyk = a.dom[2 * (long)pj[k]], pxk = a.dom[2 * (long)pj[k] + 1];
+      for (int c = 0; c < m; ++c) {
+        const float dy = a.coords_n[2 * c] - pyk, dx = a.coords_n[2 * c + 1] - pxk;
+        const float d2 = dy * dy + dx * dx;
+        ok = ok && (d2 > a.thresh_sq);
+      }
+      pok[k] = ok;
+      float sd = sqrtf(pvar[k]);
+      if (sd != sd) sd = 0.f;
+      sd += 1e-10f;
+      const float cost = ok ? sd : 0.f;
+      if (pin[k] && cost > best) { best = cost; bi = pj[k]; best_sd = sd; }
+    }
+  }
+  int w = 0;
+  float wsd = 0.f;
+  if (!gp_exchange(a, m, G, best, bi, best_sd, red_c, red_i, red_s, &ok_s, w, wsd)) {
+    if (blockIdx.x == 0 && tid == 0) *a.status = -1;
+    return;
+  }
+  auto record = [&](int slot) {          // greedy_pick2_kernel's tail + the new point into LDS for everybody
+    if (tid == 0) {
+      const float y = a.dom[2 * (long)w], x = a.dom[2 * (long)w + 1];
+      s_new[0] = y; s_new[1] = x;
+      for (int e = 0; e < 4; ++e) s_new[2 + e] = a.Edom[4 * (long)w + e];
+      if (blockIdx.x == 0) {
+        a.best_idx[0] = w;
+        if (a.sd_trace) a.sd_trace[slot] = wsd; else a.max_stdev[0] = wsd;
+        if (slot < n) {
+          a.inds[slot] = w;
+          a.coords_n[2 * slot] = y; a.coords_n[2 * slot + 1] = x;
+          for (int e = 0; e < 4; ++e) a.E_n[4 * slot + e] = s_new[2 + e];
+        }
+      }
+    }
+    __syncthreads();
+  };
+  record(m);
+  // ---- the loop: point N = m .. n-1 ----
+  for (int N = m; N < n; ++N) {
+    float kid[GP_PPT], py[GP_PPT], px[GP_PPT];
+    if (chain) {
+      // new Cholesky row (greedy_append_body): lane i < N holds k(x_i, x_N), the chain resolves l_0 .. l_{N-1}
+      float sum = 0.f;
+      if (lane < N) sum = cov_value_f32(cy, cx, cE, s_new[0], s_new[1], s_new + 2, a.scale);
+      float sumsq = 0.f, mine = 0.f;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        if (i < N) {
+          const float q = sum / diag;
+          const float li = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q), i));
+          sumsq += li * li;
+          if (lane == i) mine = li;
+          if (lane > i && lane < N) sum -= R[i] * li;
+        }
+      }
+      const float lNN = sqrtf(a.k_ii - sumsq);
+      s_lrow[lane] = lane < N ? mine : 0.f;
+      if (lane == 0) s_lnn = lNN;
+      // lane N becomes point N: its row of L, its coordinates
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        const float li = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), i));
+        R[i] = (lane == N && i < N) ? li : ((lane == N && i == N) ? lNN : R[i]);
+      }
+      if (lane == N) {
+        diag = lNN;
+        cy = s_new[0]; cx = s_new[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cE[e] = s_new[2 + e];
+      }
+      if (blockIdx.x == 0) {
+        if (lane < N) a.L[(long)N * n + lane] = mine;
+        if (lane == 0) a.L[(long)N * n + N] = lNN;
+      }
+    } else {
+      // (coordinates / kernel parameters of the thread's pixels are re-read every step -- 24 bytes per pixel from L2 / the
+      // memory-side cache -- rather than held in 18 more registers)
+#pragma unroll
+      for (int k = 0; k < GP_PPT; ++k) {
+        py[k] = a.dom[2 * (long)pj[k]]; px[k] = a.dom[2 * (long)pj[k] + 1];
+        const float4 e4 = *reinterpret_cast<const float4*>(a.Edom + 4 * (long)pj[k]);
+        const float Ek[4] = {e4.x, e4.y, e4.z, e4.w};
+        kid[k] = cov_value_f32(s_new[0], s_new[1], s_new + 2, py[k], px[k], Ek, a.scale);
+      }
+    }
+    __syncthreads();
+    best = -1.f; best_sd = 0.f; bi = 0x7fffffff;
+    if (!chain) {
+      const float lNN = s_lnn;
+#pragma unroll
+      for (int k = 0; k < GP_PPT; ++k) {
+        float sum = kid[k];
+#pragma unroll
+        for (int i = 0; i < GP_LROWS; ++i)
+          if (i < N) sum -= s_col[(i * GP_PPT + k) * GP_PIX_THREADS + tid] * s_lrow[i];
+#pragma unroll
+        for (int i = 0; i < GP_RROWS; ++i)
+          if (i + GP_LROWS < N) sum -= R[GP_RROWS * k + i] * s_lrow[i + GP_LROWS];
+        const float v = sum / lNN;
+        if (N < GP_LROWS) s_col[(N * GP_PPT + k) * GP_PIX_THREADS + tid] = v;
+#pragma unroll
+        for (int i = 0; i < GP_RROWS; ++i) R[GP_RROWS * k + i] = (i + GP_LROWS == N) ? v : R[GP_RROWS * k + i];
+        pvar[k] -= v * v;
+      }
+      {
+#pragma clang fp contract(off)
+#pragma unroll
+        for (int k = 0; k < GP_PPT; ++k) {
+          const float dy = s_new[0] - py[k], dx = s_new[1] - px[k];
+          const float d2 = dy * dy + dx * dx;
+          pok[k] = pok[k] && (d2 > a.thresh_sq);
+          float sd = sqrtf(pvar[k]);
+          if (sd != sd) sd = 0.f;
+          sd += 1e-10f;
+          const float cost = pok[k] ? sd : 0.f;
+          if (pin[k] && cost > best) { best = cost; bi = pj[k]; best_sd = sd; }
+        }
+      }
+    }
+    if (!gp_exchange(a, N + 1, G, best, bi, best_sd, red_c, red_i, red_s, &ok_s, w, wsd)) {
+      if (blockIdx.x == 0 && tid == 0) *a.status = -1;
+      return;
+    }
+    record(N + 1);
+  }
+}
+
+long greedy_persist_workspace_bytes(int n, int d) {
+  const long G = (d + (long)GP_PIX_THREADS * GP_PPT - 1) / ((long)GP_PIX_THREADS * GP_PPT);
+  return ((long)(n + 1) * G * GP_LINE + 32L * (n + 2) + 32) * 4;
+}
+
 template <typename T>
 int cross_cov(const T* x1, const T* E1, const T* x2, const T* E2, T scale, T* K12, int B, int N, int M,
               const long* strides_host, hipStream_t s) {
@@ -614,6 +893,46 @@ static int greedy_loop_impl(float* coords_n, float* E_n, long* coord_vec_inds, c
     pick(i, 1, i + 1, sd_trace ? sd_trace + (long)(i + 1) * B : max_stdev);
     COMO_CHECK_LAUNCH();
   }
+  return COMO_OK;
+}
+
+/* The large-domain loop as one persistent launch (greedy_persist_kernel above).  workspace: como_greedy_persist_workspace_bytes(n, d)
+ * bytes (cleared here); status (device int, zeroed here): -1 if a grid-wide wait timed out (the picks are then invalid).
+ * COMO_ERR_ARG when the shape does not fit (B != 1 is not offered; more workgroups than compute units). */
+long como_greedy_persist_workspace_bytes(int n, int d) { return como::greedy_persist_workspace_bytes(n, d); }
+
+int como_greedy_persist_f32(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,
+                            float* L, const float* obs_info, const float* var, const uint8_t* mask, long* best_idx, float* max_stdev,
+                            float scale, float k_ii, float dist_thresh_sq, int n, int d, int m, float* sd_trace, void* workspace,
+                            int* status, como_stream_t stream) {
+  using namespace como;
+  if (!coords_n || !E_n || !coord_vec_inds || !coords_domain || !E_domain || !L || !obs_info || !var || !mask || !best_idx ||
+      !max_stdev || !workspace || !status || n <= 0 || n > 64 || d <= 0 || m < 1 || m > n)
+    return COMO_ERR_ARG;
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) ncu = -1;
+    int occ = 0;
+    if (ncu > 0 && (hipFuncSetAttribute((const void*)greedy_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GP_LDS_BYTES) != hipSuccess ||
+                    hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)greedy_persist_kernel, GP_THREADS, GP_LDS_BYTES) != hipSuccess ||
+                    occ < 1))
+      ncu = -1;
+    (void)hipGetLastError();
+  }
+  const long G = (d + (long)GP_PIX_THREADS * GP_PPT - 1) / ((long)GP_PIX_THREADS * GP_PPT);
+  if (ncu < 1 || G > ncu) return COMO_ERR_ARG;             // every workgroup must be resident: at most one per compute unit
+  hipStream_t s = (hipStream_t)stream;
+  GPArgs a;
+  a.coords_n = coords_n; a.E_n = E_n; a.inds = coord_vec_inds; a.dom = coords_domain; a.Edom = E_domain; a.L = L;
+  a.obs_info = obs_info; a.var = var; a.mask = mask; a.best_idx = best_idx; a.max_stdev = max_stdev; a.sd_trace = sd_trace;
+  a.part = (float*)workspace;
+  a.cnt = (unsigned*)(a.part + (long)(n + 1) * G * GP_LINE);
+  a.status = status;
+  a.scale = scale; a.k_ii = k_ii; a.thresh_sq = dist_thresh_sq; a.n = n; a.d = d; a.m = m;
+  if (hipMemsetAsync(a.cnt, 0, (32L * (n + 2)) * 4, s) != hipSuccess || hipMemsetAsync(status, 0, 4, s) != hipSuccess) return COMO_ERR_LAUNCH;
+  hipLaunchKernelGGL(greedy_persist_kernel, dim3((unsigned)G), dim3(GP_THREADS), GP_LDS_BYTES, s, a);
+  COMO_CHECK_LAUNCH();
   return COMO_OK;
 }
 

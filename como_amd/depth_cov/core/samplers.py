@@ -21,7 +21,10 @@ _INFO_SYNC = __import__("os").environ.get("COMO_SAMPLER_INFO_SYNC", "0") == "1"
 
 
 def check_info(info):
-    v = int(info.max())
+    v = int(info.max()) if int(info.min()) >= 0 else int(info.min())
+    if v < 0:
+        raise RuntimeError("como_amd greedy_loop: the persistent sampler kernel timed out waiting for its workgroups (another kernel "
+                           "or process holds compute units); set COMO_GREEDY_PERSIST=0")
     if v != 0:
         raise RuntimeError(f"como_amd precalc_entropy_vars: K_nn is not positive definite (leading minor {v})")
 
@@ -164,6 +167,29 @@ def greedy_loop(coord_vec_inds, coords_n_norm, E_n, coords_domain_norm, E_domain
     # depend on where it is cut -- with ONE read-back instead of one per step.  (Only the returned indices leave this function:
     # the packed copies above are NOT written back into strided arguments.)
     trace = torch.zeros((n + 1, b), device=dev, dtype=torch.float32) if terminate_early else None
+    if PERSISTENT_LOOP and b == 1 and nxt.d > 4096 and m < n:
+        # ONE persistent launch (csrc/cov.hip greedy_persist_kernel): the obs_info columns stay in registers / LDS, a step is one
+        # grid-wide exchange instead of a pass over the 34-63 previous obs_info rows (1.2 MB each at 640x480).  Its status word
+        # (-1: a grid-wide wait timed out) is checked like the set-up's, at the caller's next synchronisation.
+        Lb = _lib.lib()
+        ws = torch.empty(Lb.como_greedy_persist_workspace_bytes(n, nxt.d) // 4, device=dev, dtype=torch.float32)
+        status = torch.zeros(1, device=dev, dtype=torch.int32)
+        rc = Lb.como_greedy_persist_f32(coords_n_norm.data_ptr(), E_n.data_ptr(), coord_vec_inds.data_ptr(), nxt.dom.data_ptr(),
+                                        E_domain.data_ptr(), L.data_ptr(), obs_info.data_ptr(), pred_var.data_ptr(), nxt.mask.data_ptr(),
+                                        nxt.best.data_ptr(), nxt.sd.data_ptr(), sv, k_ii, nxt.t2, n, nxt.d, m, _lib.ptr(trace),
+                                        ws.data_ptr(), status.data_ptr(), _lib.stream_ptr(dev))
+        if rc == 0:
+            from como_amd.utils.hostlist import read_later
+            _pending_info.append(read_later(status))
+            if terminate_early:
+                below = (trace[m:n] < max_stdev_thresh).all(dim=1).tolist()
+                check_pending_info(wait=True)
+                for k, stop in enumerate(below):
+                    if stop:
+                        return coord_vec_inds[:, :m + k]
+            return coord_vec_inds
+        if rc != 1:
+            _lib.check(rc, "como_greedy_persist_f32")           # (1 = the shape does not fit the persistent form: the loop below)
     # per-workgroup argmax partials: one float4 per scan slice / per append workgroup (the append also scans: csrc/cov.hip)
     scratch = torch.empty((b * max(4096, 4 * ((nxt.d + 255) // 256)),), device=dev, dtype=torch.float32)
     rc = _lib.lib().como_greedy_loop_ws_f32(coords_n_norm.data_ptr(), E_n.data_ptr(), coord_vec_inds.data_ptr(),
@@ -181,6 +207,7 @@ def greedy_loop(coord_vec_inds, coords_n_norm, E_n, coords_domain_norm, E_domain
     return coord_vec_inds
 
 
+PERSISTENT_LOOP = __import__("os").environ.get("COMO_GREEDY_PERSIST", "1") != "0"   # 0: two launches per added point (A/B, tests flip the attribute)
 THIN_KERNEL = __import__("os").environ.get("COMO_GREEDY_THIN", "1") != "0"      # 0: the generic path (A/B, tests flip the attribute)
 
 

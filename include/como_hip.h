@@ -331,6 +331,19 @@ int como_greedy_loop_ws_f32(float* coords_n, float* E_n, long* coord_vec_inds, c
                             float* L, float* obs_info, float* var, uint8_t* mask, long* best_idx, float* max_stdev, float scale,
                             float k_ii, float dist_thresh_sq, int B, int n, int d, int m, float* sd_trace, void* scratch,
                             long scratch_floats, como_stream_t stream);
+/* Round 6: the same loop for ONE image (B = 1) over a large domain as ONE persistent launch: every thread keeps the obs_info columns of
+ * its domain pixels in registers / LDS for the whole loop (the launch-per-step form streams the i previous rows of every pixel for
+ * the i-th point: 40-76 MB per step at a 640x480 domain), a step costs one grid-wide exchange of the workgroups' best candidates.
+ * Same picks (same operations on the same values, same order rule).  obs_info / var / mask are read only (rows < m of obs_info, the
+ * variance and the mask as they stand before the loop); L rows m..n-1, coords_n / E_n / coord_vec_inds slots m..n-1, best_idx,
+ * max_stdev / sd_trace are written as by como_greedy_loop_ws_f32.  workspace: como_greedy_persist_workspace_bytes(n, d) bytes;
+ * status (device int): 0, or -1 when a grid-wide wait timed out (workgroups not co-resident: the results are invalid).
+ * COMO_ERR_ARG when the domain needs more workgroups than the device has compute units (use the launch-per-step loop then). */
+long como_greedy_persist_workspace_bytes(int n, int d);
+int como_greedy_persist_f32(float* coords_n, float* E_n, long* coord_vec_inds, const float* coords_domain, const float* E_domain,
+                            float* L, const float* obs_info, const float* var, const uint8_t* mask, long* best_idx, float* max_stdev,
+                            float scale, float k_ii, float dist_thresh_sq, int n, int d, int m, float* sd_trace, void* workspace,
+                            int* status, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Dense reference points in factored form (python path: backend/sparse_map.py:184-230 backproject_cloud +

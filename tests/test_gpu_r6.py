@@ -277,3 +277,53 @@ def test_retargeted_window_equals_a_rebuilt_one():
     other = dict(s3)
     other["kf_img_and_grads"] = st["kf_img_and_grads"].clone()
     assert wb.retarget(other) is False
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("h,w", [(240, 320), (480, 640)])
+def test_persistent_sampler_loop_gives_the_same_picks(h, w, monkeypatch):
+    """como_greedy_persist_f32 (csrc/cov.hip greedy_persist_kernel: the large-domain greedy loop as ONE launch, obs_info columns in
+    registers / LDS, one grid-wide exchange per added point) against the launch-per-step loop (como_greedy_loop_ws_f32, itself pinned
+    to the reference's picks by tests/test_gpu_hotpath.py): the same indices in the same order -- seeded by the area rule (m = 1),
+    by three current points, and with early termination (the trace of the largest remaining standard deviation decides where the
+    sequence is cut: the same cut)."""
+    from como_amd.depth_cov.core import samplers
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand((1, 1, h, w), generator=g) * 2e-3 + 2e-4
+    z = torch.rand((1, 1, h, w), generator=g) * 2e-3 + 2e-4
+    o = (torch.rand((1, 1, h, w), generator=g) - 0.5) * 2e-4
+    cov = torch.cat((x, o, o, z), dim=1).to(DEV)
+    curr = torch.tensor([[[20.0, 30.0], [200.0, 100.5], [120.25, 300.0]]], dtype=torch.float64).to(DEV)
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(samplers, "PERSISTENT_LOOP", flag)
+        res = []
+        for cc, early, thresh in ((None, False, -1e8), (curr, False, -1e8), (curr, True, 0.55), (None, True, 0.6)):
+            c, inds = samplers.sample_sparse_coords(cov, 64, "greedy_conditional_entropy", thresh, border=3, dist_thresh=0.05,
+                                                    signal_var=1.0, fixed_var=0.0, curr_coords=cc, terminate_early=early)
+            res.append(inds.cpu())
+        samplers.check_pending_info(wait=True)
+        out[flag] = res
+    report("persistent_sampler", h=h, w=w, picks=[int(r.shape[1]) for r in out[True]])
+    for a, b in zip(out[True], out[False]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert out[True][0].shape[1] == 64 and len(set(out[True][0][0].tolist())) == 64
+
+
+def test_se3_normalisation_kernel_vs_svd():
+    """como_se3_normalize_f64 (normalizeSE3_inplace, como/geometry/lie_algebra.py:98-101) against U V^T of the SVD for rotation blocks
+    with float32-sized and larger defects: equal to rounding; the result is orthonormal."""
+    from como_amd import _lib, synth
+    g = torch.Generator().manual_seed(2)
+    T = synth.se3_exp(0.7 * torch.randn((33, 6), generator=g, dtype=torch.float64))
+    T[:, :3, :3] += 1e-7 * torch.randn((33, 3, 3), generator=g, dtype=torch.float64)
+    T[20:, :3, :3] += 1e-3 * torch.randn((13, 3, 3), generator=g, dtype=torch.float64)
+    U, _, Vh = torch.linalg.svd(T[:, :3, :3])
+    want = U @ Vh
+    Td = T.to(DEV).contiguous()
+    assert _lib.lib().como_se3_normalize_f64(Td.data_ptr(), Td.shape[0], _lib.stream_ptr(torch.device(DEV))) == 0
+    got = Td.cpu()
+    e = (got[:, :3, :3] - want).abs().max().item()
+    ortho = (got[:, :3, :3] @ got[:, :3, :3].mT - torch.eye(3, dtype=torch.float64)).abs().max().item()
+    report("se3_normalize", err_vs_svd=e, orthonormality=ortho)
+    assert e < 5e-15 and ortho < 5e-15 and torch.equal(got[:, :3, 3], T[:, :3, 3]) and torch.equal(got[:, 3], T[:, 3])
