@@ -132,6 +132,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p]),
     "como_ktilde_f64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int, c_int, c_int,
                                 c_void_p, c_void_p]),
+    "como_ktilde_mirror_f64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_double, c_int, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p]),
     "como_chol_workspace_bytes": (c_long, [c_int]),
     "como_chol_solve_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "como_chol_solve_packed_f64": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

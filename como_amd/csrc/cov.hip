@@ -540,35 +540,52 @@ struct GPArgs {
 
 __device__ __forceinline__ bool gp_better(float c2, int i2, float c1, int i1) { return c2 > c1 || (c2 == c1 && i2 < i1); }
 
-// every workgroup: publish (cost, idx, sd), wait for all G, reduce -> the pick of this step (same on every workgroup).
-// false: a wait timed out.
-__device__ __forceinline__ bool gp_exchange(const GPArgs& a, int step, int G, float cost, int idx, float sd, float* red_c, int* red_i,
-                                            float* red_s, int* ok_s, int& w_out, float& sd_out) {
-  const int tid = threadIdx.x;
-  red_c[tid] = cost; red_i[tid] = idx; red_s[tid] = sd;
-  __syncthreads();
-  for (int h = GP_THREADS / 2; h > 0; h >>= 1) {
-    if (tid < h && gp_better(red_c[tid + h], red_i[tid + h], red_c[tid], red_i[tid])) {
-      red_c[tid] = red_c[tid + h]; red_i[tid] = red_i[tid + h]; red_s[tid] = red_s[tid + h];
-    }
-    __syncthreads();
+// workgroup argmax under the order rule (largest cost, then smallest index): wave shuffles, then the 8 wave results through LDS
+__device__ __forceinline__ void gp_wg_best(float& c, int& i, float& sdv, float* red_c, int* red_i, float* red_s) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float c2 = __shfl_xor(c, off, 64);
+    const int i2 = __shfl_xor(i, off, 64);
+    const float s2 = __shfl_xor(sdv, off, 64);
+    if (gp_better(c2, i2, c, i)) { c = c2; i = i2; sdv = s2; }
   }
+  if (lane == 0) { red_c[wv] = c; red_i[wv] = i; red_s[wv] = sdv; }
+  __syncthreads();
+  c = red_c[0]; i = red_i[0]; sdv = red_s[0];
+#pragma unroll
+  for (int k = 1; k < GP_THREADS / 64; ++k)
+    if (gp_better(red_c[k], red_i[k], c, i)) { c = red_c[k]; i = red_i[k]; sdv = red_s[k]; }
+  __syncthreads();
+}
+
+// every workgroup: publish its best candidate (cost, idx, sd | y, x, E of that pixel), wait for all G, reduce -> the pick of this
+// step (same on every workgroup) with its coordinates / kernel parameters in s_new.  false: a wait timed out.
+__device__ __forceinline__ bool gp_exchange(const GPArgs& a, int step, int G, float cost, int idx, float sd, float* red_c, int* red_i,
+                                            float* red_s, int* ok_s, float* s_new, int& w_out, float& sd_out) {
+  const int tid = threadIdx.x;
+  gp_wg_best(cost, idx, sd, red_c, red_i, red_s);
   float* line = a.part + ((long)step * G + blockIdx.x) * GP_LINE;
   unsigned* cnt = a.cnt + 32 * step;
   unsigned* errf = a.cnt + 32 * (a.n + 1);
-  if (tid == 0) {
-    __hip_atomic_store(&line[0], red_c[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&line[1], __int_as_float(red_i[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&line[2], red_s[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < 9) {
+    // (idx is a pixel of THIS workgroup, or 0x7fffffff when it owns none: its record then never wins)
+    const long jj = idx < a.d ? idx : 0;
+    float v = tid == 0 ? cost : (tid == 1 ? __int_as_float(idx) : (tid == 2 ? sd : (tid < 5 ? a.dom[2 * jj + (tid - 3)] : a.Edom[4 * jj + (tid - 5)])));
+    __hip_atomic_store(&line[tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int ok = 1;
-    for (long spin = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G; ++spin) {
-      if ((spin & 63) == 63 && __hip_atomic_load(errf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
-      if (spin > 1500000) { atomicExch(errf, 1u); ok = 0; break; }
-      __builtin_amdgcn_s_sleep(1);
+  }
+  if (tid < 64) {                                            // (wave 0: its lanes' stores are acknowledged; one arrival, one poller)
+    if (tid == 0) {
+      __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int ok = 1;
+      for (long spin = 0; __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)G; ++spin) {
+        if ((spin & 63) == 63 && __hip_atomic_load(errf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ok = 0; break; }
+        if (spin > 1500000) { atomicExch(errf, 1u); ok = 0; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+      *ok_s = ok;
     }
-    *ok_s = ok;
   }
   __syncthreads();
   if (!*ok_s) return false;
@@ -580,24 +597,21 @@ __device__ __forceinline__ bool gp_exchange(const GPArgs& a, int step, int G, fl
     bi = __float_as_int(__hip_atomic_load(&ln[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     s2 = __hip_atomic_load(&ln[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  __syncthreads();
-  red_c[tid] = c; red_i[tid] = bi; red_s[tid] = s2;
-  __syncthreads();
-  for (int h = GP_THREADS / 2; h > 0; h >>= 1) {
-    if (tid < h && gp_better(red_c[tid + h], red_i[tid + h], red_c[tid], red_i[tid])) {
-      red_c[tid] = red_c[tid + h]; red_i[tid] = red_i[tid + h]; red_s[tid] = red_s[tid + h];
-    }
-    __syncthreads();
+  gp_wg_best(c, bi, s2, red_c, red_i, red_s);
+  w_out = bi;
+  sd_out = s2;
+  // the winner's coordinates / kernel parameters ride in its workgroup's record: pixel j belongs to workgroup (j / 448) % G
+  if (tid < 6) {
+    const int gw = (int)(((long)bi / GP_PIX_THREADS) % G);
+    s_new[tid] = __hip_atomic_load(&a.part[((long)step * G + gw) * GP_LINE + 3 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  w_out = red_i[0];
-  sd_out = red_s[0];
   __syncthreads();
   return true;
 }
 
 __global__ __launch_bounds__(GP_THREADS) void greedy_persist_kernel(GPArgs a) {
-  __shared__ float red_c[GP_THREADS], red_s[GP_THREADS];
-  __shared__ int red_i[GP_THREADS];
+  __shared__ float red_c[GP_THREADS / 64], red_s[GP_THREADS / 64];
+  __shared__ int red_i[GP_THREADS / 64];
   __shared__ float s_new[8];            // the point being added: y, x, E (4)
   __shared__ float s_lrow[64];          // its Cholesky row l_0 .. l_{N-1}, zero beyond
   __shared__ float s_lnn;               // ... and its diagonal entry
@@ -664,26 +678,20 @@ __global__ __launch_bounds__(GP_THREADS) void greedy_persist_kernel(GPArgs a) {
   }
   int w = 0;
   float wsd = 0.f;
-  if (!gp_exchange(a, m, G, best, bi, best_sd, red_c, red_i, red_s, &ok_s, w, wsd)) {
+  if (!gp_exchange(a, m, G, best, bi, best_sd, red_c, red_i, red_s, &ok_s, s_new, w, wsd)) {
     if (blockIdx.x == 0 && tid == 0) *a.status = -1;
     return;
   }
-  auto record = [&](int slot) {          // greedy_pick2_kernel's tail + the new point into LDS for everybody
-    if (tid == 0) {
-      const float y = a.dom[2 * (long)w], x = a.dom[2 * (long)w + 1];
-      s_new[0] = y; s_new[1] = x;
-      for (int e = 0; e < 4; ++e) s_new[2 + e] = a.Edom[4 * (long)w + e];
-      if (blockIdx.x == 0) {
-        a.best_idx[0] = w;
-        if (a.sd_trace) a.sd_trace[slot] = wsd; else a.max_stdev[0] = wsd;
-        if (slot < n) {
-          a.inds[slot] = w;
-          a.coords_n[2 * slot] = y; a.coords_n[2 * slot + 1] = x;
-          for (int e = 0; e < 4; ++e) a.E_n[4 * slot + e] = s_new[2 + e];
-        }
+  auto record = [&](int slot) {          // greedy_pick2_kernel's tail (the new point already sits in s_new)
+    if (tid == 0 && blockIdx.x == 0) {
+      a.best_idx[0] = w;
+      if (a.sd_trace) a.sd_trace[slot] = wsd; else a.max_stdev[0] = wsd;
+      if (slot < n) {
+        a.inds[slot] = w;
+        a.coords_n[2 * slot] = s_new[0]; a.coords_n[2 * slot + 1] = s_new[1];
+        for (int e = 0; e < 4; ++e) a.E_n[4 * slot + e] = s_new[2 + e];
       }
     }
-    __syncthreads();
   };
   record(m);
   // ---- the loop: point N = m .. n-1 ----
@@ -742,11 +750,11 @@ __global__ __launch_bounds__(GP_THREADS) void greedy_persist_kernel(GPArgs a) {
       for (int k = 0; k < GP_PPT; ++k) {
         float sum = kid[k];
 #pragma unroll
-        for (int i = 0; i < GP_LROWS; ++i)
-          if (i < N) sum -= s_col[(i * GP_PPT + k) * GP_PIX_THREADS + tid] * s_lrow[i];
+        // (no `i < N` tests: rows N.. of the column and of l are exact zeros, and x - 0 * 0 = x bit for bit -- with the tests every
+        // step of the dot product waited for its own LDS read: 8 us per added point)
+        for (int i = 0; i < GP_LROWS; ++i) sum -= s_col[(i * GP_PPT + k) * GP_PIX_THREADS + tid] * s_lrow[i];
 #pragma unroll
-        for (int i = 0; i < GP_RROWS; ++i)
-          if (i + GP_LROWS < N) sum -= R[GP_RROWS * k + i] * s_lrow[i + GP_LROWS];
+        for (int i = 0; i < GP_RROWS; ++i) sum -= R[GP_RROWS * k + i] * s_lrow[i + GP_LROWS];
         const float v = sum / lNN;
         if (N < GP_LROWS) s_col[(N * GP_PPT + k) * GP_PIX_THREADS + tid] = v;
 #pragma unroll
@@ -768,7 +776,7 @@ __global__ __launch_bounds__(GP_THREADS) void greedy_persist_kernel(GPArgs a) {
         }
       }
     }
-    if (!gp_exchange(a, N + 1, G, best, bi, best_sd, red_c, red_i, red_s, &ok_s, w, wsd)) {
+    if (!gp_exchange(a, N + 1, G, best, bi, best_sd, red_c, red_i, red_s, &ok_s, s_new, w, wsd)) {
       if (blockIdx.x == 0 && tid == 0) *a.status = -1;
       return;
     }
@@ -779,6 +787,159 @@ __global__ __launch_bounds__(GP_THREADS) void greedy_persist_kernel(GPArgs a) {
 long greedy_persist_workspace_bytes(int n, int d) {
   const long G = (d + (long)GP_PIX_THREADS * GP_PPT - 1) / ((long)GP_PIX_THREADS * GP_PPT);
   return ((long)(n + 1) * G * GP_LINE + 32L * (n + 2) + 32) * 4;
+}
+
+// ---- the thinning pass for d <= 64 candidates in ONE WAVE (round 6) ----------------------------------------------------------------
+// greedy_thin_kernel walks its <= 64 steps with 1024 threads and two workgroup barriers + an LDS tree reduction per step (4.4 us
+// each: 280 us per keyframe insertion) although a keyframe never has more than 64 tracked points.  Here lane j IS candidate j (its
+// obs_info column in registers) and lane i ALSO holds chosen point i (its row of L in registers): a step is register arithmetic,
+// the Cholesky chain of greedy_append_body and two shuffle reductions -- no LDS, no barrier.  Same operations on the same values
+// as greedy_thin_kernel, hence the same picks and the same cut (tested).  Writes inds, count, sd_trace, L, coords_n, E_n; the
+// scratch arrays obs_info / var / mask of the wide kernel are not touched.
+__device__ __forceinline__ void wave_best(float& c, int& i, float& sdv) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float c2 = __shfl_xor(c, off, 64);
+    const int i2 = __shfl_xor(i, off, 64);
+    const float s2 = __shfl_xor(sdv, off, 64);
+    if (c2 > c || (c2 == c && i2 < i)) { c = c2; i = i2; sdv = s2; }
+  }
+}
+
+__global__ __launch_bounds__(64) void greedy_thin_wave_kernel(const float* __restrict__ dom, const float* __restrict__ Edom,
+                                                              float* __restrict__ coords_n, float* __restrict__ E_n, long* __restrict__ inds,
+                                                              float* __restrict__ L, long* __restrict__ best_idx, float* __restrict__ sd_trace,
+                                                              float scale, float signal_var, float fixed_var, float thresh_sq,
+                                                              float stdev_thresh, int n, int d, long* __restrict__ count_out) {
+  const int lane = threadIdx.x;
+  const bool in = lane < d;
+  const int jc = in ? lane : 0;
+  // candidate role
+  const float py = dom[2 * jc], px = dom[2 * jc + 1];
+  float pE[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) pE[e] = Edom[4 * jc + e];
+  float obs[64];
+#pragma unroll
+  for (int i = 0; i < 64; ++i) obs[i] = 0.f;
+  // chosen-point role: point `lane`
+  float qy = 0.f, qx = 0.f, qE[4] = {1.f, 0.f, 0.f, 1.f}, Lr[64], diag = 1.f;
+#pragma unroll
+  for (int i = 0; i < 64; ++i) Lr[i] = 0.f;
+  // ---- seed: largest det E (first maximum) ----
+  float area = -__builtin_inff();
+  {
+#pragma clang fp contract(off)
+    if (in) {
+      const float p0 = pE[0] * pE[3], p1 = pE[1] * pE[2];
+      area = p0 - p1;
+    }
+  }
+  int w = in ? lane : 0x7fffffff;
+  {
+    float dummy = 0.f;
+    wave_best(area, w, dummy);
+  }
+  auto bcast = [&](float v, int src) { return __shfl(v, src, 64); };
+  float ny = bcast(py, w), nx = bcast(px, w), nE[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) nE[e] = bcast(pE[e], w);
+  float k00 = cov_value_f32(ny, nx, nE, ny, nx, nE, scale);
+  {
+#pragma clang fp contract(off)
+    if (fixed_var != 0.f) k00 = k00 + fixed_var;
+  }
+  if (!(k00 > 0.f)) {                                      // not positive definite (or NaN): nothing is valid
+    if (lane == 0) *count_out = 0;
+    return;
+  }
+  const float l00 = sqrtf(k00);
+  if (lane == 0) {
+    inds[0] = w; coords_n[0] = ny; coords_n[1] = nx;
+    for (int e = 0; e < 4; ++e) E_n[e] = nE[e];
+    L[0] = l00;
+    qy = ny; qx = nx;
+    for (int e = 0; e < 4; ++e) qE[e] = nE[e];
+    Lr[0] = l00; diag = l00;
+  }
+  float var;
+  bool ok = in;
+  {
+#pragma clang fp contract(off)
+    const float kmd = cov_value_f32(ny, nx, nE, py, px, pE, scale);
+    const float o = kmd / l00;
+    obs[0] = o;
+    const float o2 = o * o;
+    var = signal_var - o2;
+  }
+  const float k_ii = signal_var + fixed_var;
+  // pick against the point just added: distance mask, largest remaining standard deviation (greedy_pick_body)
+  auto pick = [&](float cy_, float cx_, int& w_out, float& sd_out) {
+#pragma clang fp contract(off)
+    const float dy = cy_ - py, dx = cx_ - px;
+    const float d2 = dy * dy + dx * dx;
+    ok = ok && (d2 > thresh_sq);
+    float sd = sqrtf(var);
+    if (sd != sd) sd = 0.f;
+    sd += 1e-10f;
+    float cost = in ? (ok ? sd : 0.f) : -1.f;
+    int bi = in ? lane : 0x7fffffff;
+    wave_best(cost, bi, sd);
+    w_out = bi;
+    sd_out = sd;
+  };
+  float wsd;
+  pick(ny, nx, w, wsd);
+  if (lane == 0) { best_idx[0] = w; sd_trace[1] = wsd; }
+  int count = n;
+  for (int N = 1; N < n; ++N) {
+    if (wsd < stdev_thresh) { count = N; break; }          // sd_trace[N] of the wide kernel
+    // point N = candidate w
+    ny = bcast(py, w); nx = bcast(px, w);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) nE[e] = bcast(pE[e], w);
+    if (lane == 0) {
+      inds[N] = w; coords_n[2 * N] = ny; coords_n[2 * N + 1] = nx;
+      for (int e = 0; e < 4; ++e) E_n[4 * N + e] = nE[e];
+    }
+    // its Cholesky row (greedy_append_body): lane i < N holds k(x_i, x_N)
+    float sum = 0.f;
+    if (lane < N) sum = cov_value_f32(qy, qx, qE, ny, nx, nE, scale);
+    float sumsq = 0.f, mine = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      if (i < N) {
+        const float q = sum / diag;
+        const float li = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q), i));
+        sumsq += li * li;
+        if (lane == i) mine = li;
+        if (lane > i && lane < N) sum -= Lr[i] * li;
+      }
+    }
+    const float lNN = sqrtf(k_ii - sumsq);
+    if (lane < N) L[(long)N * n + lane] = mine;
+    if (lane == 0) L[(long)N * n + N] = lNN;
+    // the candidates' obs_info row N and the variance downdate; lane N becomes point N
+    float s2 = cov_value_f32(ny, nx, nE, py, px, pE, scale);
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const float li = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), i));      // 0 for i >= N
+      s2 -= obs[i] * li;
+      Lr[i] = (lane == N && i < N) ? li : ((lane == N && i == N) ? lNN : Lr[i]);
+    }
+    const float v = s2 / lNN;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) obs[i] = (i == N) ? v : obs[i];
+    var -= v * v;
+    if (lane == N) {
+      diag = lNN; qy = ny; qx = nx;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) qE[e] = nE[e];
+    }
+    pick(ny, nx, w, wsd);
+    if (lane == 0) { best_idx[0] = w; sd_trace[N + 1] = wsd; }
+  }
+  if (lane == 0) *count_out = count;
 }
 
 template <typename T>
@@ -951,6 +1112,14 @@ int como_greedy_thin_f32(const float* coords_domain, const float* E_domain, floa
   if (!coords_domain || !E_domain || !coords_n || !E_n || !coord_vec_inds || !L || !obs_info || !var || !mask || !best_idx ||
       !sd_trace || !count_out || n <= 0 || n > 64 || d <= 0 || d > 1024 || n > d)
     return COMO_ERR_ARG;
+  static const bool wave_form = [] { const char* e = getenv("COMO_GREEDY_THIN_WAVE"); return !e || e[0] != '0'; }();
+  if (wave_form && d <= 64) {
+    // (<= 64 candidates -- every keyframe insertion: a keyframe holds at most 64 points -- run in ONE wave, registers only)
+    hipLaunchKernelGGL(como::greedy_thin_wave_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, coords_domain, E_domain, coords_n, E_n,
+                       coord_vec_inds, L, best_idx, sd_trace, scale, signal_var, fixed_var, dist_thresh_sq, stdev_thresh, n, d, count_out);
+    COMO_CHECK_LAUNCH();
+    return COMO_OK;
+  }
   hipLaunchKernelGGL(como::greedy_thin_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, coords_domain, E_domain, coords_n, E_n,
                      coord_vec_inds, L, obs_info, var, mask, best_idx, sd_trace, scale, signal_var, fixed_var, dist_thresh_sq,
                      stdev_thresh, n, d, count_out);

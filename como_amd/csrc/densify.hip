@@ -556,7 +556,9 @@ template <> __device__ __forceinline__ int k_mfma_row<double>(int lane, int reg)
 template <typename T>
 __global__ __launch_bounds__(256) void ktilde_kernel(const T* __restrict__ cov, int Hc, int Wc, const T* __restrict__ xm,
                                                      const T* __restrict__ Em, const T* __restrict__ Kinv, T scale,
-                                                     int Hp, int Wp, int m, T* __restrict__ out) {
+                                                     int Hp, int Wp, int m, T* __restrict__ out, float* __restrict__ out32) {
+  // out32 (float64 instantiation, may be NULL): the same values rounded to float32 -- the per-pixel kernels' mirror of K~, written
+  // here instead of by a conversion pass over the 157 MB the kernel has just stored
   using acc_t = typename KAcc<T>::type;
   __shared__ T sK[64 * 65];                                // K_mm^-1, row stride 65 (zero-padded to 64 x 64)
   __shared__ T sx[64 * 2];
@@ -601,7 +603,10 @@ __global__ __launch_bounds__(256) void ktilde_kernel(const T* __restrict__ cov, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const long pr = grp * 16 + k_mfma_row<T>(lane, r);
-        if (pr < np && j < m) out[((long)b * np + pr) * m + j] = acc[r];
+        if (pr < np && j < m) {
+          out[((long)b * np + pr) * m + j] = acc[r];
+          if (out32) out32[((long)b * np + pr) * m + j] = (float)acc[r];
+        }
       }
     }
   }
@@ -711,12 +716,23 @@ COMO_DEF_BAND(f64, double)
     long blocks = ((long)Hp * Wp + 63) / 64;                                                                           \
     if (blocks > 2048) blocks = 2048;                                                                                  \
     hipLaunchKernelGGL(como::ktilde_kernel<T>, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, cov, Hc,   \
-                       Wc, xm, Em, Kinv, scale, Hp, Wp, m, out);                                                       \
+                       Wc, xm, Em, Kinv, scale, Hp, Wp, m, out, (float*)nullptr);                                      \
     COMO_CHECK_LAUNCH();                                                                                               \
     return COMO_OK;                                                                                                    \
   }
 COMO_DEF_KMAT(f32, float)
 COMO_DEF_KMAT(f64, double)
+
+int como_ktilde_mirror_f64(const double* cov, int Hc, int Wc, const double* xm, const double* Em, const double* Kinv, double scale, int B,
+                           int Hp, int Wp, int m, double* out, float* out_f32, como_stream_t stream) {
+  if (!cov || !xm || !Em || !Kinv || !out || B <= 0 || m <= 0 || m > 64 || Hp <= 0 || Wp <= 0) return COMO_ERR_ARG;
+  long blocks = ((long)Hp * Wp + 63) / 64;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(como::ktilde_kernel<double>, dim3((unsigned)blocks, B), dim3(256), 0, (hipStream_t)stream, cov, Hc, Wc, xm, Em,
+                     Kinv, scale, Hp, Wp, m, out, out_f32);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
 
 #define COMO_DEF_KFGLUE(SFX, T)                                                                                                  \
   int como_diag_cov_##SFX(const T* E, long total, T scale, T* out, como_stream_t stream) {                                       \

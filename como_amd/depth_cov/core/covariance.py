@@ -78,7 +78,7 @@ class DiagonalCovarianceModule(CovarianceModule):
     forward = __call__
 
 
-def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None, K_mm_inv=None):
+def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None, K_mm_inv=None, out=None, out_pix=None):
     """Mapping.prep_predictor (Mapping.py:430-468): returns (K_mm_inv (B,m,m), L_mm (B,m,m), Knm_Kmminv (B,H,W,m)).
     K_nm (H*W x m per keyframe) is never materialised.  K_mm_inv: optional precomputed inverse (then L_mm is returned as
     None and only K~ = K_nm K_mm^-1 is formed) -- K_mm is ill-conditioned (~1e8), so two float64 LAPACKs agree on its
@@ -99,9 +99,22 @@ def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None, K_mm_in
     else:
         L_mm = None
         K_mm_inv = K_mm_inv.to(device=dev, dtype=dt).contiguous()
-    out = torch.empty((B, Hp, Wp, m), dtype=dt, device=dev)
-    fn = getattr(_lib.lib(), "como_ktilde_" + _lib.suffix(dt))
-    rc = fn(cov_params_img.contiguous().data_ptr(), Hc, Wc, cm.contiguous().data_ptr(), Em.contiguous().data_ptr(),
-            K_mm_inv.data_ptr(), float(scale), B, Hp, Wp, m, out.data_ptr(), _lib.stream_ptr(dev))
+    # out / out_pix: caller-owned destinations -- (B,Hp,Wp,m) in the image's dtype (e.g. the new keyframe's slot of the window's
+    # predictor buffer) and, float64 only, a float32 tensor of the same shape that receives the rounded values (the per-pixel kernels'
+    # mirror): the kernel writes both, no 157 MB copy + conversion pass afterwards
+    if out is None:
+        out = torch.empty((B, Hp, Wp, m), dtype=dt, device=dev)
+    elif tuple(out.shape) != (B, Hp, Wp, m) or out.dtype != dt or not out.is_contiguous():
+        raise RuntimeError("como_amd prep_predictor: `out` must be a contiguous (B,Hp,Wp,m) tensor of the covariance image's dtype")
+    if out_pix is not None:
+        if dt != torch.float64 or out_pix.dtype != torch.float32 or tuple(out_pix.shape) != (B, Hp, Wp, m) or not out_pix.is_contiguous():
+            raise RuntimeError("como_amd prep_predictor: `out_pix` needs a float64 covariance image and a contiguous float32 (B,Hp,Wp,m) tensor")
+        rc = _lib.lib().como_ktilde_mirror_f64(cov_params_img.contiguous().data_ptr(), Hc, Wc, cm.contiguous().data_ptr(),
+                                               Em.contiguous().data_ptr(), K_mm_inv.data_ptr(), float(scale), B, Hp, Wp, m, out.data_ptr(),
+                                               out_pix.data_ptr(), _lib.stream_ptr(dev))
+    else:
+        fn = getattr(_lib.lib(), "como_ktilde_" + _lib.suffix(dt))
+        rc = fn(cov_params_img.contiguous().data_ptr(), Hc, Wc, cm.contiguous().data_ptr(), Em.contiguous().data_ptr(),
+                K_mm_inv.data_ptr(), float(scale), B, Hp, Wp, m, out.data_ptr(), _lib.stream_ptr(dev))
     _lib.check(rc, "como_ktilde")
     return K_mm_inv, L_mm, out

@@ -22,6 +22,7 @@ import os
 import torch
 
 _PIX_MIRRORS = os.environ.get("COMO_PIX_MIRRORS", "1") != "0"       # 0: every window rebuild converts the whole K~ / image window (A/B)
+_KT_DIRECT = os.environ.get("COMO_KF_KT_DIRECT", "1") != "0"        # 0: K~ of a new keyframe is formed in a temporary and copied / converted into the window (A/B)
 _HOST_CORR = os.environ.get("COMO_KF_HOST_CORR", "1") != "0"        # 0: the correspondence-mask bookkeeping of a keyframe insertion on the device (A/B)
 _SE3_NORMALIZE_KERNEL = os.environ.get("COMO_SE3_NORMALIZE_KERNEL", "1") != "0"   # 0: LAPACK SVD on the host (A/B)
 _FUSED_FRAME = os.environ.get("COMO_FUSED_FRAME", "1") != "0"       # 0: the torch chains of a frame hand-over (world pose / affine, gray + gradients + cat + copies) (A/B)
@@ -240,10 +241,30 @@ class Mapping:
         return _run_model(self.model, rgb, network_size=self.network_size_list, dtype=self.dtype,
                           graphed=self.cfg.get("graph_network", True))
 
-    def prep_predictor(self, cov_params_img, coords_m):
-        """Mapping.py:430-468 -> (K_mm_inv, L_mm, Knm_Kmminv (b,H,W,m)); K_nm is never materialised (csrc/densify.hip)."""
+    def prep_predictor(self, cov_params_img, coords_m, into_window=False):
+        """Mapping.py:430-468 -> (K_mm_inv, L_mm, Knm_Kmminv (b,H,W,m)); K_nm is never materialised (csrc/densify.hip).
+        into_window (add_keyframe): K~ is written STRAIGHT into the new keyframe's slot of the window's sliding predictor buffer (and,
+        with float32 per-pixel kernels, rounded into the mirror's slot by the same launch) -- `self.Knm_Kmminv` then already is the
+        new window and initialize_sparse_pixel_vars must not append it again (pass Knm_Kmminv=None): saves the 157 MB copy and the
+        conversion pass of every keyframe insertion at 640x480."""
         size = tuple(self.kf_img_and_grads.shape[-2:]) if self.kf_img_and_grads.numel() else tuple(cov_params_img.shape[-2:])
-        return _prep_predictor(cov_params_img, coords_m.to(cov_params_img.dtype), self.model.get_scale(-1), photo_img_size=size)
+        cm = coords_m.to(cov_params_img.dtype)
+        need_mirror = _PIX_MIRRORS and self.pix_dtype != cov_params_img.dtype
+        mirror_ok = (not need_mirror) or (self.pix_dtype == torch.float32 and cov_params_img.dtype == torch.float64 and
+                                          getattr(self, "Knm_Kmminv_pix", None) is not None and self.Knm_Kmminv_pix.dim() == 4)
+        if (into_window and _KT_DIRECT and mirror_ok and cov_params_img.is_cuda and cov_params_img.shape[0] == 1 and
+                self.Knm_Kmminv.dim() == 4 and cov_params_img.dtype == self.Knm_Kmminv.dtype and
+                tuple(self.Knm_Kmminv.shape[1:]) == size + (cm.shape[1],)):
+            i = self.get_kf_start_window_ind()
+            cap = self.cfg["graph"]["num_keyframes"]
+            tail = size + (cm.shape[1],)
+            dst = self._slide_reserve("Knm_Kmminv", self.Knm_Kmminv, 1, tail, i, cov_params_img.dtype, cov_params_img.device, cap)
+            dpix = None
+            if need_mirror:
+                dpix = self._slide_reserve("Knm_Kmminv_pix", self.Knm_Kmminv_pix, 1, tail, i, torch.float32, cov_params_img.device, cap)
+            Kinv, L_mm, _ = _prep_predictor(cov_params_img, cm, self.model.get_scale(-1), photo_img_size=size, out=dst, out_pix=dpix)
+            return Kinv, L_mm, None
+        return _prep_predictor(cov_params_img, cm, self.model.get_scale(-1), photo_img_size=size)
 
     # ---- tracker-facing accessors ----------------------------------------------------------------------------------------
     def find_kf_from_timestamp(self, kf_timestamp):
@@ -378,7 +399,7 @@ class Mapping:
         p_m_new = swap_coords_xy(coords_m_new).to(dtype=z_m_new.dtype)
         Pc_new = backprojection_points(self.intrinsics[0], p_m_new, z_m_new)
         Pw_new = transform_points_values(kf_pose_init, Pc_new)
-        Kmm_inv, L_mm, Knm_Kmminv = self.prep_predictor(cov_params_img, coords_m)
+        Kmm_inv, L_mm, Knm_Kmminv = self.prep_predictor(cov_params_img, coords_m, into_window=True)
         pm_first_obs = swap_coords_xy(coords_m)
         self.window_cat_helper_list(self.kf_timestamps, timestamp, self.get_kf_start_window_ind())
         self.initialize_pose_vars(kf_pose_init, kf_aff_init)
@@ -467,7 +488,8 @@ class Mapping:
         self._cat("obs_ref_mask", first, i)
         self._cat("Kmm_inv", Kmm_inv, i)
         self._cat("L_mm", L_mm, i)
-        self._cat("Knm_Kmminv", Knm_Kmminv, i)
+        if Knm_Kmminv is not None:                            # (None: prep_predictor(into_window=True) already placed it)
+            self._cat("Knm_Kmminv", Knm_Kmminv, i)
 
     def initialize_sparse_landmark_vars(self, corr_mask, P, corr_host=None):
         """Correspondence mask (num_kf x num_landmarks) and landmark list after inserting a keyframe (Mapping.py:321-367).

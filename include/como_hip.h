@@ -401,6 +401,11 @@ int como_ktilde_f32(const float* cov, int Hc, int Wc, const float* xm, const flo
                     int B, int Hp, int Wp, int m, float* out, como_stream_t stream);
 int como_ktilde_f64(const double* cov, int Hc, int Wc, const double* xm, const double* Em, const double* Kinv,
                     double scale, int B, int Hp, int Wp, int m, double* out, como_stream_t stream);
+/* the same with a second output: out_f32 (may be NULL) receives the values rounded to float32 -- the predictor mirror of the
+ * per-pixel kernels (mapping `pix_dtype: float`), written by the kernel that forms K~ instead of a conversion pass over it.
+ * Both outputs may be slots of the window's predictor buffers. */
+int como_ktilde_mirror_f64(const double* cov, int Hc, int Wc, const double* xm, const double* Em, const double* Kinv, double scale, int B,
+                           int Hp, int Wp, int m, double* out, float* out_f32, como_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Keyframe-insertion glue with the arithmetic of the reference's torch chains, one launch per chain:
