@@ -369,6 +369,7 @@ class WindowBA:
             raise RuntimeError("como_amd: radius / degree pair edges need the pair graph rebuilt every iteration: use "
                                "WindowBA(fused=False) (it re-evaluates the pairs in linearize()) for radius_thresh, degrees_thresh > 0")
         self.table = None                                    # (its rows hold system indices: they moved with lm_start)
+        self._ba_prepared = {}                               # (the marshalled argument block of the BA chain: photo.linearize)
         self._build_pair_table()
         # H | g | err(8) in ONE float64 buffer.  The fused chain does not accumulate into it: every contribution (pair blocks,
         # priors) goes through exact integer atomics into the fixed-point buffer `sysfix` (order-independent: the normal
@@ -587,7 +588,8 @@ class WindowBA:
                                     dPwn_dTwc=dT, uvec=uvec, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"], dzdP=w["px_dzdP"],
                                     img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=None, g=None,
                                     err_out=None, sigma_out=self.sigma, events=self.events, zeroed_hists=w["hist_ba"],
-                                    ws=w["ba_ws"], sysfix=self.sysfix, fix_plane=self.fix_plane, D=self.dim)
+                                    ws=w["ba_ws"], sysfix=self.sysfix, fix_plane=self.fix_plane, D=self.dim,
+                                    prepared=self._ba_prepared if self.events is None else None)
         if late_side:
             side.wait_event(ev)
             with torch.cuda.stream(side):

@@ -132,6 +132,17 @@ def main():
             t_first_tracked = (k, time.perf_counter())
     torch.cuda.synchronize()
     t1 = time.perf_counter()
+    band = None
+    try:                                                   # the band median's candidate share over the window's life (csrc/densify.hip)
+        ba = odo.mapping._ba or getattr(odo.mapping, "_ba_prev", None)
+        for e in ba.w["dr_ws"].values():
+            st = e.get("band") if isinstance(e, dict) else None
+            if st is not None:
+                rows = int(st["lref"].shape[1])
+                band = {"calls": int(st["calls"]), "candidates_per_call_and_keyframe": float(st["ncand"].double().mean()) / max(1, int(st["calls"])),
+                        "rows": rows}
+    except Exception:   # noqa: BLE001
+        pass
     if census is not None:
         census.__exit__(None, None, None)
         os.makedirs("gpurun_out", exist_ok=True)
@@ -185,6 +196,7 @@ def main():
            "requests": {str(k): kinds.count(k) for k in set(kinds)},
            "keyframes": len(odo.mapping.kf_timestamps), "one_way_frames": len(odo.mapping.recent_timestamps),
            "landmarks": int(odo.mapping.P_m.shape[0]), "window_full": bool(odo.mapping.window_full),
+           "band_median": band,
            "parts_ms": {k: {"mean": 1e3 * sum(v) / len(v), "max": 1e3 * max(v), "n": len(v)} for k, v in parts.items()},
            "traj_scale": float(s), "traj_rmse_after_scale": float(((s * est - gt) ** 2).sum(1).mean().sqrt())}
     # wall time from the start of a frame to the start of the next, by what the frame asked the mapper for (the tracker's read-back
