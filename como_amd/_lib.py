@@ -35,6 +35,7 @@ class BAArgs(ctypes.Structure):
         ("ngrp", c_int), ("nsingle", c_int),
         ("fix_plane", c_long), ("reduce_mode", c_int), ("blocks_fix", c_void_p),
         ("channels", c_int), ("pair_chan", c_void_p), ("ref_pose", c_void_p),
+        ("asm_grp_start", c_void_p), ("asm_grp_list", c_void_p), ("n_asm_grp", c_int),
     ]
 
 

@@ -1949,6 +1949,108 @@ __global__ __launch_bounds__(256) void ba_reduce_assemble_kernel(
   }
 }
 
+// The same assembly with the pairs GROUPED BY REFERENCE SLOT (fixed-point mode, reduce + expand in one launch): the pairs of a
+// group write the same depth x depth blocks (192 x 192 after the expansion), the same reference-pose rows and gradient parts --
+// everything except what involves their TARGET frames.  Thread e sums its record element over the group's pairs in list order
+// (each pair's wave partials in the fixed order of the kernel above), then expands / scatters ONCE: a window of the sequential loop
+// holds 3-6 pairs per reference keyframe (forward, backward, one-way frames), i.e. a quarter of the integer atomics -- they were
+// 120-190 us of a full window's iteration, most of it contention of the groups' pairs on the same entries.  Target-frame entries
+// are added per pair as before.  (The sums over a group are formed in float64 before the fixed-point split: the same bits from
+// run to run and from topology to topology, but not those of the per-pair form.)
+template <typename T>
+__global__ __launch_bounds__(256) void ba_reduce_assemble_grouped_kernel(
+    const T* __restrict__ partials, int nrec_per_pair, const int* __restrict__ grp_start, const int* __restrict__ grp_list,
+    BAPairs pr, const long* __restrict__ pose_ref_inds, const long* __restrict__ pose_tgt_inds,
+    const long* __restrict__ landmark_inds, const T* __restrict__ dzdP, int m, long long* __restrict__ Hm, long D, long fix_plane) {
+  using Cfg = BACfg;
+  constexpr int NE = Cfg::NT * 256 + Cfg::NB * 16 + 1;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= NE) return;
+  const int g0 = grp_start[blockIdx.y], g1 = grp_start[blockIdx.y + 1];
+  if (g1 <= g0) return;
+  long long* poison = Hm + D * D + D + FIX_POISON;
+  auto pair_sum = [&](int p) {
+    const T* base = partials + (long)p * nrec_per_pair * Cfg::REC + e;
+    double s = 0;
+    int w = 0;
+    for (; w + 8 <= nrec_per_pair; w += 8) {
+      T v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = base[(long)(w + q) * Cfg::REC];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s += (double)v[q];
+    }
+    for (; w < nrec_per_pair; ++w) s += (double)base[(long)w * Cfg::REC];
+    return s;
+  };
+  auto add_low = [&](long ia, long ib, double v) {          // one entry of the lower triangle
+    const long r = ia > ib ? ia : ib, c = ia > ib ? ib : ia;
+    fix_add(Hm, fix_plane, r * D + c, v, poison);
+  };
+  const int p0 = grp_list[g0];
+  const int slot = pr.ref_slot[p0];
+  const long* pri = pose_ref_inds + 8 * (long)p0;
+  const long* lmi = landmark_inds + 3 * (long)m * p0;
+  const T* dz = dzdP + 3 * (long)slot;
+  // does this element involve the target frame (then it is per pair)?
+  bool per_pair = false;
+  int tt = 0, rg = 0, lane = 0, ti = 0, tj = 0, ri = 0, ci = 0, gt = 0;
+  if (e < Cfg::NT * 256) {
+    tt = e >> 8; rg = (e >> 6) & 3; lane = e & 63;
+    int cnt = 0;
+    for (int a = 0; a < Cfg::NB; ++a)
+      for (int b = a; b < Cfg::NB; ++b) { if (cnt == tt) { ti = a; tj = b; } ++cnt; }
+    ri = mfma_row<T>(lane, rg); ci = lane & 15;
+    per_pair = (ti == 0) && (ri >= 8 || (tj == 0 && ci >= 8));
+  } else if (e < Cfg::NT * 256 + Cfg::NB * 16) {
+    gt = (e - Cfg::NT * 256) >> 4; ci = e & 15;
+    per_pair = (gt == 0) && ci >= 8;
+  }
+  double s = 0;
+  if (!per_pair)
+    for (int q = g0; q < g1; ++q) s += pair_sum(grp_list[q]);
+  for (int q = g0; q < (per_pair ? g1 : g0 + 1); ++q) {
+    const int p = grp_list[q];
+    if (per_pair) s = pair_sum(p);
+    const long* pti = pose_tgt_inds + 8 * (long)p;
+    if (e < Cfg::NT * 256) {
+      if (ti == 0 && tj == 0) {
+        const long ia = ri < 8 ? pri[ri] : pti[ri - 8];
+        const long ib = ci < 8 ? pri[ci] : pti[ci - 8];
+        if (ia >= ib) add_low(ia, ib, s);
+      } else if (ti == 0) {
+        const int k = kcol(tj, ci);
+        if (k < m) {
+          const long ia = ri < 8 ? pri[ri] : pti[ri - 8];
+          for (int d = 0; d < 3; ++d) add_low(ia, lmi[3 * k + d], s * (double)dz[d]);
+        }
+      } else {
+        const int k1 = kcol(ti, ri), k2 = kcol(tj, ci);
+        if (k1 < m && k2 < m) {
+          for (int d1 = 0; d1 < 3; ++d1)
+            for (int d2 = 0; d2 < 3; ++d2) {
+              const double v = (double)dz[d1] * s * (double)dz[d2];
+              const long i1 = lmi[3 * k1 + d1], i2 = lmi[3 * k2 + d2];
+              if (ti != tj) add_low(i1, i2, v);
+              else if (i1 >= i2) add_low(i1, i2, v);
+            }
+        }
+      }
+    } else if (e < Cfg::NT * 256 + Cfg::NB * 16) {
+      const double gval = -s;
+      if (gt == 0) {
+        fix_add(Hm, fix_plane, D * D + (ci < 8 ? pri[ci] : pti[ci - 8]), gval, poison);
+      } else {
+        const int k = kcol(gt, ci);
+        if (k < m)
+          for (int d = 0; d < 3; ++d) fix_add(Hm, fix_plane, D * D + lmi[3 * k + d], gval * (double)dz[d], poison);
+      }
+    } else {
+      fix_add(Hm, fix_plane, D * D + D, s, poison);
+    }
+  }
+}
+
 // fixed-point system buffer -> float64 H (both triangles, exactly symmetric), g, errors
 __global__ __launch_bounds__(256) void sys_finalize_kernel(const long long* __restrict__ fix, long plane, long D,
                                                            double* __restrict__ H, double* __restrict__ g,
@@ -2186,6 +2288,11 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
       if (A->reduce_mode != 0 && !A->blocks_fix) return COMO_ERR_ARG;
       if (A->reduce_mode == 1) { LAUNCH_ASM(long long, 1); }
       else if (A->reduce_mode == 2) { LAUNCH_ASM(long long, 2); }
+      else if (A->asm_grp_start && A->asm_grp_list && A->n_asm_grp > 0 && !A->pair_blocks_out) {
+        hipLaunchKernelGGL((ba_reduce_assemble_grouped_kernel<T>), dim3((BACfg::REC + 255) / 256, A->n_asm_grp), dim3(256), 0, s,
+                           (const T*)A->ws_partials, nrec, A->asm_grp_start, A->asm_grp_list, pr, A->pose_ref_inds, A->pose_tgt_inds,
+                           A->landmark_inds, (const T*)A->dzdP, m, (long long*)A->Hmat, A->D, A->fix_plane);
+      }
       else { LAUNCH_ASM(long long, 0); }
     } else if (A->h_is_f64) { LAUNCH_ASM(double, 0); } else { LAUNCH_ASM(float, 0); }
 #undef LAUNCH_ASM

@@ -633,7 +633,8 @@ class Mapping:
                 self._ba = prev                              # same keyframes, another set of one-way frames: the object stays
             else:
                 self._ba = WindowBA(st, cfg=cfg, pix_dtype=self.pix_dtype, window_full=self.window_full, prev=prev,
-                                    rec_capacity=self.cfg["graph"]["num_one_way_frames"])
+                                    rec_capacity=self.cfg["graph"]["num_one_way_frames"],
+                                    band_median=self.cfg.get("band_median", False))
             self._ba_prev = None
         ba = self._ba
         ba.step()

@@ -50,6 +50,9 @@ def _in_image(p, depth, img_size, border, depth_thresh, strict):
     return ok & (depth[..., 0] > depth_thresh)
 
 
+_DIRECT_REF = os.environ.get("COMO_TRACK_DIRECT_REF", "1") != "0"     # (read once: an os.environ look-up costs ~25 us, this ran per frame)
+
+
 class Tracking:
     def __init__(self, cfg, intrinsics, img_size):
         self.cfg = cfg
@@ -198,7 +201,7 @@ class Tracking:
         depth_pyr = self.depth_pyr_module(depth)
         pb = None
         if (depth.is_cuda and self.vals_pyr[0].shape[2] == 1 and depth.dtype == self.vals_pyr[0].dtype and
-                os.environ.get("COMO_TRACK_DIRECT_REF", "1") != "0"):
+                _DIRECT_REF):
             # this tracker's own persistent reference buffers (the level kernels and the captured frame graph read them): the
             # reference kernels below write straight into them -- no per-update allocations, no copies before the next frame
             key = (nk, depth.dtype, tuple(tuple(d.shape[-2:]) for d in depth_pyr))

@@ -18,6 +18,7 @@ _ws = {}
 BLOCK_VARIANT = int(__import__("os").environ.get("COMO_BA_VARIANT", "0"))   # 0 = software-pipelined block kernel, 1 = plain
 CHUNKS_OVERRIDE = int(__import__("os").environ.get("COMO_BA_CHUNKS", "0"))   # tuning runs: pixel chunks per pair group
 BLOCK_STAGGER = int(__import__("os").environ.get("COMO_BA_STAGGER", "0"))
+ASM_GROUPED = __import__("os").environ.get("COMO_BA_ASM_GROUPED", "1") != "0"   # 0: the assembly expands / scatters every pair on its own (A/B)
 MIN_TILES_PER_CHUNK = int(__import__("os").environ.get("COMO_BA_MIN_TILES", "8"))   # lower bound on a chunk's 64-pixel tiles (0: off; see linearize)
 last_aux = {}   # diagnostics of the most recent call: valid mask, sigma, nvalid (tests / callers that want them)
 
@@ -51,7 +52,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
               err_out, uvec=None, pixidx=None, invz=None, kt_slot_stride=0, chunks=None, phase=0xFF, want_pj=False,
               want_blocks=False, sigma_out=None, pix_range=None, reduce_hists=None, events=None, anorm_f32=False,
               grp_pairs=None, single_pairs=None, zeroed_hists=None, ws=None, sysfix=None, fix_plane=0, D=None,
-              reduce_blocks=None, channels=1, pair_chan=None, ref_pose=None, prepared=None):
+              reduce_blocks=None, channels=1, pair_chan=None, ref_pose=None, prepared=None, asm_groups=None):
     """Thin marshalling layer over como_ba_linearize_* (see include/como_hip.h for every field).
 
     prepared: a caller-owned dict that lives as long as NOTHING about the call changes (same tensors, same sizes: one window
@@ -132,6 +133,9 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
             raise RuntimeError("como_amd: pair_chan must be a contiguous int32 tensor with one channel per pair entry")
         _lib.require_cuda(pair_chan)
         a.pair_chan = _lib.ptr(pair_chan)
+    if asm_groups is not None and ASM_GROUPED and sysfix is not None and reduce_blocks is None and not want_blocks:
+        # (start offsets, pair list, number of groups): the assembly sums what the pairs of one reference keyframe share first
+        a.asm_grp_start, a.asm_grp_list, a.n_asm_grp = _lib.ptr(asm_groups[0]), _lib.ptr(asm_groups[1]), int(asm_groups[2])
     if sysfix is not None:
         a.h_is_f64, a.fix_plane = 2, int(fix_plane)
     else:
@@ -347,7 +351,17 @@ class PairTable:
         rows_tgt = [8 * f_ + k for f_ in tgt_frame for k in range(8)] if ramp else []
         import numpy as np
         ng = len(flat_grp)
-        h32 = np.asarray(list(ref_ids) + tgt_frame + chan + flat_grp + ([0] if (3 * b + ng) % 2 else []), dtype=np.int32)
+        # the pairs grouped by reference keyframe for the assembly (como_ba_args.asm_grp_*): group starts, then the pair list
+        by_slot = {}
+        for p_, r_ in enumerate(ref_ids):
+            by_slot.setdefault(int(r_), []).append(p_)
+        asm_list = [p_ for lst in by_slot.values() for p_ in lst]
+        asm_start = [0]
+        for lst in by_slot.values():
+            asm_start.append(asm_start[-1] + len(lst))
+        self.n_asm_grp = len(by_slot)
+        n32 = 3 * b + ng + len(asm_start) + len(asm_list)
+        h32 = np.asarray(list(ref_ids) + tgt_frame + chan + flat_grp + asm_start + asm_list + ([0] if n32 % 2 else []), dtype=np.int32)
         h64 = np.asarray(off + list(ref_ids) + rows_ref + rows_tgt, dtype=np.int64)
         nb32, nb = h32.nbytes, h32.nbytes + h64.nbytes                   # (int32 block first, padded to 8 bytes; then the int64 block)
         dev_t = torch.device(device)
@@ -370,6 +384,9 @@ class PairTable:
         self.tgt_pose = self.tgt_aff
         self.pair_chan = i32[2 * b:3 * b] if c > 1 else None
         self.grp_pairs = i32[3 * b:3 * b + ng].reshape(-1, 2)
+        o32 = 3 * b + ng
+        self.asm_grp_start = i32[o32:o32 + len(asm_start)]
+        self.asm_grp_list = i32[o32 + len(asm_start):o32 + len(asm_start) + b]
         self.tgt_img = i64[0:b]
         rid = i64[b:2 * b]
         if ramp:
@@ -452,4 +469,4 @@ def photo_system_factored(table, *, poses_all, aff_all, Pwn, vals, dPwn_dTwc, uv
                      phase=phase, sigma_out=sigma_out, pix_range=pix_range, reduce_hists=reduce_hists, events=events,
                      grp_pairs=table.grp_pairs, single_pairs=table.single_pairs,
                      zeroed_hists=zeroed_hists, ws=ws, sysfix=sysfix, fix_plane=fix_plane, D=D, reduce_blocks=reduce_blocks,
-                     prepared=prepared)
+                     prepared=prepared, asm_groups=(table.asm_grp_start, table.asm_grp_list, table.n_asm_grp))

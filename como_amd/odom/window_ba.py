@@ -57,7 +57,8 @@ def _ar(n, dev, dtype=torch.long):
 
 
 class WindowBA:
-    def __init__(self, state, cfg=None, pix_dtype=torch.float32, window_full=True, shard=None, fused=True, prev=None, rec_capacity=None):
+    def __init__(self, state, cfg=None, pix_dtype=torch.float32, window_full=True, shard=None, fused=True, prev=None, rec_capacity=None,
+                 band_median=None):
         """state: dict as produced by como_amd.synth.make_window (plus K_mm_inv / L_mm / Knm_Kmminv).
         shard: como_amd.dist.Shard for the one-process-per-GPU data-parallel mode (None = single GPU).
         prev: the WindowBA this one replaces (the sequential loop rebuilds the window on every keyframe): when
@@ -67,6 +68,12 @@ class WindowBA:
         buffer, the system buffers and the per-frame scratch are sized for it once, so that `retarget` -- same keyframes, another
         set of one-way frames, 55 % of the sequential loop's frames -- only rewrites the frame count, the index tables that move
         with it and the pair table instead of building a new object (None: exactly the frames of `state`)."""
+        # band_median: the full-image median of sub-selected windows from the pixels whose depth can still cross the median
+        # (csrc/densify.hip depth_band_kernel) -- wins when the log-depths barely move between iterations (a converging window: 1-2 %
+        # of the pixels are re-evaluated); in the sequential loop every iteration follows a new frame and ~64 % of the pixels stay
+        # candidates (scripts/gpu_odometry_bench.py `band_median`): there the plain streaming pass on the matrix cores is faster.
+        # None: the module default (dense_ref.BAND_MEDIAN).
+        self.band_median = band_median
         self.shard = shard
         self._prev = prev
         self._src_kf_img, self._src_mask = state["kf_img_and_grads"], state["correspondence_mask"]
@@ -552,7 +559,8 @@ class WindowBA:
                                                    hists=w["hist_dr"], ws=w["dr_ws"], part=part, compact=True)
         fork = self.shard is None and self.overlap_priors
         late_side = False
-        fm = lambda part: full_image_median(w["px_logzm"], self.Kt, w["med3_full"], w["dr_ws"], hists=w["hist_full"], part=part)
+        fm = lambda part: full_image_median(w["px_logzm"], self.Kt, w["med3_full"], w["dr_ws"], hists=w["hist_full"], part=part,
+                                            band=self.band_median)
         if self.shard is not None:
             return self._linearize_sharded(dr)
         if fork and self.full_median:

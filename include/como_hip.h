@@ -266,6 +266,15 @@ typedef struct como_ba_args {
   int channels;
   const int* pair_chan;      /* [b] */
   const int* ref_pose;       /* zmode 2: [b] index into poses_all of the REFERENCE keyframe's pose T_wc */
+  /* Round 6, phase 128 with the fixed-point system (h_is_f64 = 2, reduce_mode 0): optional grouping of the pairs BY REFERENCE
+     SLOT for the assembly -- asm_grp_start (n_asm_grp + 1) offsets into asm_grp_list (b pair indices, every pair once, the pairs
+     of a group sharing slot, pose_ref_inds and landmark_inds).  Everything a group's pairs add to the SAME system entries (the
+     64 x 64 depth blocks, the reference-pose rows, their gradient parts, the error) is summed over the group first and
+     expanded / scattered once: the window of the sequential loop has 3-6 pairs per reference keyframe.  NULL: one pair at a
+     time (as before; also whenever pair_blocks_out is requested). */
+  const int* asm_grp_start;
+  const int* asm_grp_list;
+  int n_asm_grp;
 } como_ba_args;
 
 long como_ba_partials_elems(int b, int chunks, int m);

@@ -183,6 +183,9 @@ def main():
         st_ = pstats.Stats(prof, stream=buf).sort_stats("cumulative")
         for fn_ in ("__init__", "_prepare_topology", "_finish_topology", "_build_pair_table", "_prepare_fused", "add_one_way_frame", "_window_state"):
             st_.print_callees("window_ba.py.*" + fn_ if fn_.startswith("_") or fn_ == "__init__" else fn_)
+        buf.write("\n==== who asks os.environ / converts / allocates ====\n")
+        for pat in ("os.py.*__getitem__", "method 'to' of", "built-in method torch.empty", "method 'tolist'", "method 'copy_'", "built-in method torch.zeros"):
+            st_.print_callers(pat)
         os.makedirs("gpurun_out", exist_ok=True)
         open("gpurun_out/odo_cprofile.txt", "w").write(buf.getvalue())
     n_tracked = args.frames - 1 - t_first_tracked[0]

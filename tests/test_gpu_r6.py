@@ -327,3 +327,34 @@ def test_se3_normalisation_kernel_vs_svd():
     ortho = (got[:, :3, :3] @ got[:, :3, :3].mT - torch.eye(3, dtype=torch.float64)).abs().max().item()
     report("se3_normalize", err_vs_svd=e, orthonormality=ortho)
     assert e < 5e-15 and ortho < 5e-15 and torch.equal(got[:, :3, 3], T[:, :3, 3]) and torch.equal(got[:, 3], T[:, 3])
+
+
+def test_grouped_assembly_equals_the_per_pair_form(monkeypatch):
+    """ba_reduce_assemble_grouped_kernel (csrc/ba.hip: the pairs of one reference keyframe summed before the dz/dP expansion and
+    the fixed-point scatter) against the per-pair assembly on a window with one-way frames (3-4 pairs per reference keyframe):
+    the normal equations agree to float64 rounding of the regrouped sums, and are bit-identical from run to run."""
+    import como_amd.odom.backend.photo as photo
+    from como_amd import synth
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    from como_amd.odom.window_ba import WindowBA, DEFAULT_CFG
+    B, H, W, m = 3, 96, 128, 16
+    st = synth.make_window(B=B, H=H, W=W, m=m, dtype=torch.float64, device=DEV, seed=7,
+                           predictor=lambda cov, cm: prep_predictor(cov, cm, 1.0))
+    st.update(synth.make_recent([0.3, 1.3, 1.6, 0.6], H, W, 7, device=DEV))
+    cfg = copy.deepcopy(DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = 2
+    out = {}
+    for flag in (True, False, True):
+        monkeypatch.setattr(photo, "ASM_GROUPED", flag)
+        wb = WindowBA(st, cfg=cfg, pix_dtype=torch.float64, window_full=True)
+        Hm, g = wb.linearize()
+        torch.cuda.synchronize()
+        out.setdefault(flag, []).append((Hm.clone(), g.clone(), wb.table.n_asm_grp, wb.table.b))
+    (H1, g1, ng, b), (H1b, g1b, _, _) = out[True]
+    (H0, g0, _, _), = out[False]
+    assert ng == B and b > 2 * (B - 1)                        # one-way pairs joined the keyframes' groups
+    assert torch.equal(H1, H1b) and torch.equal(g1, g1b)
+    dH = ((H1 - H0).abs() / (H0.diagonal().abs().sqrt()[:, None] * H0.diagonal().abs().sqrt()[None, :] + 1e-300)).max().item()
+    dg = ((g1 - g0).abs().max() / g0.abs().max()).item()
+    report("grouped_assembly", pairs=b, groups=ng, H_jacobi_scaled_diff=dH, g_rel_diff=dg)
+    assert dH < 1e-13 and dg < 1e-13
