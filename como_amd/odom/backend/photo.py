@@ -318,51 +318,56 @@ class PairTable:
     reused by every GN iteration: no per-iteration host->device traffic)."""
 
     def __init__(self, ref_ids, tgt_ids, tgt_is_recent, num_kf, kf_inds, recent_inds, landmark_inds, img_stride,
-                 recent_img_offset, device, channels=1):
+                 recent_img_offset, device, channels=1, landmark_inds_host=None, extra_i64=None):
+        """landmark_inds_host: numpy (num_kf, 3m) copy of `landmark_inds` when the caller keeps one: the per-pair rows are then built
+        here and travel in the table's one upload (no device gather).  extra_i64: optional dict name -> int64 numpy array uploaded in
+        the same block and left in `self.extra[name]` (the window's own small index tables that move with the frame count)."""
+        import numpy as np
         # colour images: every keyframe pair becomes `channels` consecutive entries, one per channel (como_ba_args.channels);
         # img_stride is the size of a frame's whole (3c,H,W) stack
         self.channels = c = int(channels)
         self.npairs = len(ref_ids)
-        if c > 1:
-            ref_ids = [r for r in ref_ids for _ in range(c)]
-            tgt_ids = [t for t in tgt_ids for _ in range(c)]
-            tgt_is_recent = [r for r in tgt_is_recent for _ in range(c)]
-        b = len(ref_ids)
+        ref = np.repeat(np.asarray(ref_ids, dtype=np.int64), c)
+        tgt = np.repeat(np.asarray(tgt_ids, dtype=np.int64), c)
+        rec = np.repeat(np.asarray(tgt_is_recent, dtype=bool), c)
+        b = int(ref.shape[0])
         self.b = b
-        tgt_frame = [t + (num_kf if r else 0) for t, r in zip(tgt_ids, tgt_is_recent)]
-        off = [(recent_img_offset + t * img_stride) if r else t * img_stride for t, r in zip(tgt_ids, tgt_is_recent)]
-        # pairs sharing their reference keyframe, two at a time (csrc/ba.hip ba_blocks_pair2_kernel); the rest one by one
-        by_ref = {}
-        for p_, r_ in enumerate(ref_ids):
-            by_ref.setdefault((int(r_), p_ % c), []).append(p_)     # same reference keyframe AND channel
+        tgt_frame = tgt + np.where(rec, num_kf, 0)
+        off = np.where(rec, recent_img_offset + tgt * img_stride, tgt * img_stride).astype(np.int64)
+        chan = (np.arange(b) % c).astype(np.int64)
+        # pairs sharing their reference keyframe (AND channel), two at a time (csrc/ba.hip ba_blocks_pair2_kernel); a lone pair rides
+        # the same kernel with its second half masked.  Order: by first appearance of (reference, channel), pairs in index order.
         grp = []
+        by_ref = {}
+        for p_ in range(b):
+            by_ref.setdefault((int(ref[p_]), int(chan[p_])), []).append(p_)
         for lst in by_ref.values():
-            while len(lst) >= 2:
-                grp.append([lst.pop(0), lst.pop(0)])
-            if lst:
-                grp.append([lst[0], -1])                   # a lone pair rides the same kernel with its second half masked
-        # every host-built index array -- including the system rows of the reference / target FRAMES, which are plain ramps
-        # (frame f owns rows 8 f .. 8 f + 7: `kf_inds` / `recent_inds` are views of one arange) -- in ONE host->device copy of a
-        # pinned int64 staging block: the window's pair table is rebuilt on every keyframe / one-way frame of the sequential loop
-        chan = [p_ % c for p_ in range(b)]
-        flat_grp = [x for g_ in grp for x in g_]
-        ramp = _frame_rows_are_ramps(kf_inds, recent_inds, num_kf)
-        rows_ref = [8 * int(r_) + k for r_ in ref_ids for k in range(8)] if ramp else []
-        rows_tgt = [8 * f_ + k for f_ in tgt_frame for k in range(8)] if ramp else []
-        import numpy as np
-        ng = len(flat_grp)
+            for q in range(0, len(lst) - 1, 2):
+                grp.append((lst[q], lst[q + 1]))
+            if len(lst) % 2:
+                grp.append((lst[-1], -1))
+        flat_grp = np.asarray(grp, dtype=np.int64).reshape(-1)
+        ng = int(flat_grp.shape[0])
         # the pairs grouped by reference keyframe for the assembly (como_ba_args.asm_grp_*): group starts, then the pair list
         by_slot = {}
-        for p_, r_ in enumerate(ref_ids):
-            by_slot.setdefault(int(r_), []).append(p_)
-        asm_list = [p_ for lst in by_slot.values() for p_ in lst]
-        asm_start = [0]
-        for lst in by_slot.values():
-            asm_start.append(asm_start[-1] + len(lst))
+        for p_ in range(b):
+            by_slot.setdefault(int(ref[p_]), []).append(p_)
+        asm_list = np.asarray([p_ for lst in by_slot.values() for p_ in lst], dtype=np.int64)
+        asm_start = np.cumsum([0] + [len(lst) for lst in by_slot.values()]).astype(np.int64)
         self.n_asm_grp = len(by_slot)
-        n32 = 3 * b + ng + len(asm_start) + len(asm_list)
-        h32 = np.asarray(list(ref_ids) + tgt_frame + chan + flat_grp + asm_start + asm_list + ([0] if n32 % 2 else []), dtype=np.int32)
-        h64 = np.asarray(off + list(ref_ids) + rows_ref + rows_tgt, dtype=np.int64)
+        # every host-built index array -- including the system rows of the reference / target FRAMES, which are plain ramps
+        # (frame f owns rows 8 f .. 8 f + 7: `kf_inds` / `recent_inds` are views of one arange) -- in ONE host->device copy of a
+        # pinned staging block: the window's pair table is rebuilt on every keyframe / one-way frame of the sequential loop
+        ramp = _frame_rows_are_ramps(kf_inds, recent_inds, num_kf)
+        ar8 = np.arange(8, dtype=np.int64)[None]
+        rows_ref = (8 * ref[:, None] + ar8).reshape(-1) if ramp else np.zeros(0, np.int64)
+        rows_tgt = (8 * tgt_frame[:, None] + ar8).reshape(-1) if ramp else np.zeros(0, np.int64)
+        lm_rows = landmark_inds_host[ref].reshape(-1).astype(np.int64) if landmark_inds_host is not None else np.zeros(0, np.int64)
+        extra = extra_i64 or {}
+        h32 = np.concatenate((ref, tgt_frame, chan, flat_grp, asm_start, asm_list)).astype(np.int32)
+        if h32.shape[0] % 2:
+            h32 = np.concatenate((h32, np.zeros(1, np.int32)))
+        h64 = np.concatenate([off, ref, rows_ref, rows_tgt, lm_rows] + [np.asarray(v, dtype=np.int64).reshape(-1) for v in extra.values()])
         nb32, nb = h32.nbytes, h32.nbytes + h64.nbytes                   # (int32 block first, padded to 8 bytes; then the int64 block)
         dev_t = torch.device(device)
         if dev_t.type == "cuda":
@@ -385,19 +390,31 @@ class PairTable:
         self.pair_chan = i32[2 * b:3 * b] if c > 1 else None
         self.grp_pairs = i32[3 * b:3 * b + ng].reshape(-1, 2)
         o32 = 3 * b + ng
-        self.asm_grp_start = i32[o32:o32 + len(asm_start)]
-        self.asm_grp_list = i32[o32 + len(asm_start):o32 + len(asm_start) + b]
+        self.asm_grp_start = i32[o32:o32 + asm_start.shape[0]]
+        self.asm_grp_list = i32[o32 + asm_start.shape[0]:o32 + asm_start.shape[0] + b]
         self.tgt_img = i64[0:b]
         rid = i64[b:2 * b]
+        o = 2 * b
         if ramp:
-            self.pose_ref_inds = i64[2 * b:10 * b].view(b, 8)
-            self.pose_tgt_inds = i64[10 * b:18 * b].view(b, 8)
+            self.pose_ref_inds = i64[o:o + 8 * b].view(b, 8)
+            self.pose_tgt_inds = i64[o + 8 * b:o + 16 * b].view(b, 8)
+            o += 16 * b
         else:
             self.pose_ref_inds = kf_inds[rid].contiguous()
             # system rows of every target frame with ONE gather (keyframes first, then the one-way frames)
-            frame_rows = torch.cat((kf_inds, recent_inds), dim=0) if any(tgt_is_recent) else kf_inds
+            frame_rows = torch.cat((kf_inds, recent_inds), dim=0) if bool(rec.any()) else kf_inds
             self.pose_tgt_inds = frame_rows[torch.as_tensor(tgt_frame, dtype=torch.int64, device=dev_t)].contiguous()
-        self.landmark_inds = landmark_inds.index_select(0, rid)
+        if landmark_inds_host is not None:
+            w3m = int(landmark_inds_host.shape[1])
+            self.landmark_inds = i64[o:o + b * w3m].view(b, w3m)
+            o += b * w3m
+        else:
+            self.landmark_inds = landmark_inds.index_select(0, rid)
+        self.extra = {}
+        for k_, v in extra.items():
+            nv = int(np.asarray(v).size)
+            self.extra[k_] = i64[o:o + nv].view(tuple(np.asarray(v).shape))
+            o += nv
         self.single_pairs = _empty_i32(dev_t)
         self.ngroups = len(grp)
 

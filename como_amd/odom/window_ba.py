@@ -270,6 +270,7 @@ class WindowBA:
         self.first_slot = d32[B * m + L:B * m + 2 * L]
         self.first_obs_mask = d[o2:o2 + B * m].view(torch.bool).view(B, m)
         self.fix_idx = lm_dev[0]
+        self._host_np = {"point_inds": point_inds, "fix_idx": lm_of[0].copy()}      # (for the tables that move with the frame count)
 
         def remap(variable, default_val=-1):           # variable (B,L,...) -> (B,m,...); every slot is filled
             idx = lm_dev.reshape((B, m) + (1,) * (variable.dim() - 2)).expand((B, m) + tuple(variable.shape[2:]))
@@ -280,7 +281,7 @@ class WindowBA:
 
     # ---- things that change only when the keyframe set changes ---------------------------------------------------
     _KF_SET_ATTRS = ("coords_n", "n_total", "pixidx", "channels", "vals_n", "n", "remap", "point_inds", "L", "kf_inds", "fix_idx",
-                     "lm_ids", "first_obs_mask", "first_frame", "first_slot")
+                     "lm_ids", "first_obs_mask", "first_frame", "first_slot", "_host_np")
 
     def _same_keyframe_set(self, prev):
         return (prev is not None and _REUSE_TOPOLOGY and prev.shard is None and self.shard is None and prev._src_kf_img is self._src_kf_img and
@@ -293,7 +294,7 @@ class WindowBA:
         prev, self._prev = self._prev, None                  # (no chain of old windows kept alive)
         if self._same_keyframe_set(prev):
             for a in self._KF_SET_ATTRS:
-                setattr(self, a, getattr(prev, a))
+                setattr(self, a, getattr(prev, a, None))
             self.idle = False
             self._inherit = prev                             # (its scratch workspaces too: _prepare_fused)
             self._finish_topology()
@@ -361,13 +362,23 @@ class WindowBA:
         self.kf_inds._como_ramp = True
         self.frame_inds = _ar(8 * self.F, dev).reshape(self.F, 8)
         self.lm_start = 8 * B + 8 * nrec
-        if first:
+        self.landmark_inds_flat = _ar(self.lm_start + 3 * L, dev)[self.lm_start:].reshape(L, 3)
+        hn = getattr(self, "_host_np", None)
+        self._host_extra = None
+        if hn is not None and dev.type == "cuda":
+            # the two landmark index tables that move with the frame count, built on the host (Mapping's host copy of the
+            # correspondence mask, _host_tables) and uploaded WITH the pair table: no device launch for them
+            import numpy as np
+            lmi = hn["point_inds"] + self.lm_start
+            fix = (self.lm_start + 3 * hn["fix_idx"][:, None] + np.arange(3)[None]).reshape(-1)
+            self._host_extra = {"landmark_inds": lmi, "fix_inds": fix}
+        elif first:
             self.landmark_inds = (self.point_inds + self.lm_start).contiguous()
             self.fix_inds_flat = torch.empty((3 * int(self.fix_idx.numel()),), device=dev, dtype=torch.long)
+            torch.index_select(self.landmark_inds_flat, 0, self.fix_idx, out=self.fix_inds_flat.view(-1, 3))
         else:
             torch.add(self.point_inds, self.lm_start, out=self.landmark_inds)      # (same address: the argument blocks keep it)
-        self.landmark_inds_flat = _ar(self.lm_start + 3 * L, dev)[self.lm_start:].reshape(L, 3)
-        torch.index_select(self.landmark_inds_flat, 0, self.fix_idx, out=self.fix_inds_flat.view(-1, 3))
+            torch.index_select(self.landmark_inds_flat, 0, self.fix_idx, out=self.fix_inds_flat.view(-1, 3))
         pc = self.cfg["photo_construction"]
         if self.fused and pc.get("radius_thresh", 0.0) > 0.0 and pc.get("degrees_thresh", 0.0) > 0.0:
             # The reference rebuilds the pair graph on every iterate from the CURRENT poses and median depths
@@ -410,6 +421,7 @@ class WindowBA:
         a.F, a.D = self.F, self.dim
         a.H, a.g = ptr(self.H), ptr(self.g)
         a.poses, a.aff = ptr(self.poses_all), ptr(self.aff_all)
+        a.landmark_inds, a.fix_inds = ptr(self.landmark_inds), ptr(self.fix_inds_flat)
 
     def _build_pair_table(self):
         """Pair graph from the current poses / median depths (graph_pair_construction.py:155-182) -> device-resident PairTable."""
@@ -422,9 +434,14 @@ class WindowBA:
             return
         self.kf_pairs, self.one_way_pairs = pairs
         stack = 3 * self.channels * self.Himg * self.Wimg          # one frame's [I | dI/dx | dI/dy] stack
+        ex = getattr(self, "_host_extra", None)
         self.table = photo.PairTable(ref + ow_kf, tgt + ow_t, [False] * len(ref) + [True] * len(ow_kf), B, self.kf_inds,
-                                     self.recent_inds, self.landmark_inds, stack,
-                                     B * stack if self._rec_img_off is None else self._rec_img_off, dev, channels=self.channels)
+                                     self.recent_inds, None if ex is not None else self.landmark_inds, stack,
+                                     B * stack if self._rec_img_off is None else self._rec_img_off, dev, channels=self.channels,
+                                     landmark_inds_host=ex["landmark_inds"] if ex is not None else None, extra_i64=ex)
+        if ex is not None:
+            self.landmark_inds = self.table.extra["landmark_inds"]
+            self.fix_inds_flat = self.table.extra["fix_inds"]
 
     def _prepare_fused(self):
         B, m, L, F, dev, p = self.B, self.m, self.L, self.F, self.dev, self.pix_dtype
