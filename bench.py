@@ -611,7 +611,15 @@ def main():
                              "hip_graph": sec["f64"]["hip_graph"], "dtype": "f64", "f32": sec["f32"]}
         torch.cuda.empty_cache()
         legs["tracking"] = tracking_leg(device)
+        # the sequence is run twice: the first pass meets every one-time cost of a process (hipGraph captures of the tracker frame
+        # and the network, pinned staging blocks, the allocator growing to the window's final sizes: ~0.1 s in total, e.g. 15-40 ms
+        # on the frame at which the window first fills) -- `value` is the steady-state rate of the second pass, the first pass's
+        # rate is reported beside it
+        first = odometry_loop(device)
         legs["odometry_loop"] = odometry_loop(device)
+        if "value" in legs["odometry_loop"] and "value" in first:
+            legs["odometry_loop"]["first_pass_frames_per_s"] = first["value"]
+            legs["odometry_loop"]["protocol"] = "second pass over the sequence in this process (first pass = first_pass_frames_per_s, incl. one-time captures / allocations)"
         if "value" in legs["odometry_loop"]:
             flat["odometry_loop_frames_per_s"] = legs["odometry_loop"]["value"]
         if "value" in legs["tracking"]:

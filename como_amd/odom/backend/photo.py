@@ -426,7 +426,9 @@ def _pinned_stage(n):
     """A pinned byte staging block (grow-only) for the pair table's one host->device copy."""
     t = _stage.get("buf")
     if t is None or t.numel() < n:
-        t = _stage["buf"] = torch.empty(max(1 << 16, 2 * n), dtype=torch.uint8).pin_memory()
+        # (1 MiB from the start: a pinned allocation is a 40 ms driver call -- growing from 64 KiB when the window first held 40
+        # pairs stalled one frame of the sequential loop by that much)
+        t = _stage["buf"] = torch.empty(max(1 << 20, 2 * n), dtype=torch.uint8).pin_memory()
         _stage["event"] = None
     else:
         ev = _stage.get("event")

@@ -18,7 +18,7 @@ def _block(nbytes):
     if ev is not None:
         ev.synchronize()
     if blk is None or blk.numel() < nbytes:
-        blk = _ring["blocks"][k] = torch.empty(max(1 << 14, 2 * nbytes), dtype=torch.uint8).pin_memory()
+        blk = _ring["blocks"][k] = torch.empty(max(1 << 16, 2 * nbytes), dtype=torch.uint8).pin_memory()
     return k, blk
 
 

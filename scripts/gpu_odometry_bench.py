@@ -208,7 +208,9 @@ def main():
     by_kind = {}
     for k in range(t_first_tracked[0] + 1, args.frames):
         by_kind.setdefault(str(kinds[k]), []).append(1e3 * (t_frame[k + 1] - t_frame[k]))
-    out["frame_ms_by_request"] = {k: {"mean": sum(v) / len(v), "n": len(v)} for k, v in by_kind.items()}
+    out["frame_ms_by_request"] = {k: {"mean": sum(v) / len(v), "median": sorted(v)[len(v) // 2], "max": max(v), "n": len(v)} for k, v in by_kind.items()}
+    slow = sorted(((1e3 * (t_frame[k + 1] - t_frame[k]), k, str(kinds[k])) for k in range(t_first_tracked[0] + 1, args.frames)), reverse=True)[:5]
+    out["slowest_frames_ms"] = [(round(t, 2), k, kd) for t, k, kd in slow]
     if args.save_traj:
         from como_amd.utils.io import save_traj
         save_traj(args.save_traj, odo.timestamps, torch.cat([p.double().cpu() for p in odo.est_poses]))
