@@ -39,6 +39,13 @@ class BAArgs(ctypes.Structure):
     ]
 
 
+class DRFuse(ctypes.Structure):
+    """Mirror of `struct como_dr_fuse` (include/como_hip.h)."""
+    _fields_ = [("ref_pairs", c_void_p), ("np_max", c_int), ("pair_T", c_void_p), ("pair_aff", c_void_p), ("vals", c_void_p),
+                ("img_base", c_void_p), ("tgt_img", c_void_p), ("r_out", c_void_p), ("valid_out", c_void_p), ("rhists", c_void_p),
+                ("H", c_int), ("W", c_int), ("anorm_f32", c_int)]
+
+
 class WinArgs(ctypes.Structure):
     """Mirror of `struct como_win_args` (include/como_hip.h) -- field order must match."""
     _fields_ = ([(n, c_int) for n in ("B", "F", "m", "L", "nfix", "pix_is_f64", "median_new_is_f32", "median_new_stride")]
@@ -118,6 +125,8 @@ SIGNATURES = {
     "como_greedy_next_f32": (c_int, [c_void_p] * 3 + [c_int, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "como_dense_ref_f32": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8 + [c_int, c_void_p]),
     "como_dense_ref_f64": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8 + [c_int, c_void_p]),
+    "como_dense_ref_fused_f32": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8 + [c_int, ctypes.POINTER(DRFuse), c_void_p]),
+    "como_dense_ref_fused_f64": (c_int, [c_void_p, c_long] + [c_void_p] * 5 + [c_int] * 4 + [c_void_p] * 8 + [c_int, ctypes.POINTER(DRFuse), c_void_p]),
     "como_depth_band_f32": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, c_void_p]),
     "como_depth_band_f64": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int] + [c_void_p] * 8 + [c_int, c_void_p]),
     "como_cov_params_at": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),

@@ -1951,12 +1951,32 @@ __global__ __launch_bounds__(256) void ba_reduce_assemble_kernel(
 
 // The same assembly with the pairs GROUPED BY REFERENCE SLOT (fixed-point mode, reduce + expand in one launch): the pairs of a
 // group write the same depth x depth blocks (192 x 192 after the expansion), the same reference-pose rows and gradient parts --
-// everything except what involves their TARGET frames.  Thread e sums its record element over the group's pairs in list order
-// (each pair's wave partials in the fixed order of the kernel above), then expands / scatters ONCE: a window of the sequential loop
-// holds 3-6 pairs per reference keyframe (forward, backward, one-way frames), i.e. a quarter of the integer atomics -- they were
-// 120-190 us of a full window's iteration, most of it contention of the groups' pairs on the same entries.  Target-frame entries
-// are added per pair as before.  (The sums over a group are formed in float64 before the fixed-point split: the same bits from
-// run to run and from topology to topology, but not those of the per-pair form.)
+// everything except what involves their TARGET frames.  Thread e forms every pair's contributions exactly as the per-pair kernel
+// does (the pair's wave partials summed in the same fixed order, the same dz products), splits each into its fixed-point parts and
+// adds those INTEGERS over the group's pairs in registers; one pair of integer atomics per system entry and group follows instead
+// of one per pair: a window of the sequential loop holds 3-6 pairs per reference keyframe (forward, backward, one-way frames),
+// i.e. a quarter of the atomics -- they were 120-190 us of a full window's iteration, most of it contention of a group's pairs on
+// the same entries.  Integer addition is associative: the system buffer ends with the SAME bits as after the per-pair kernel
+// (and as on every rank of the sharded form, which keeps the per-pair kernel).  Target-frame entries are added per pair.
+struct FixAcc {
+  long long hi = 0;
+  unsigned long long lo = 0;
+  unsigned bad = 0;
+  __device__ __forceinline__ void add(double v) {
+    if (!(fabs(v) < 4.0e18)) { ++bad; return; }
+    long long h;
+    unsigned long long l;
+    fix_split(v, h, l);
+    hi += h;
+    lo += l;
+  }
+  __device__ __forceinline__ void emit(long long* __restrict__ fix, long plane, long idx, long long* __restrict__ poison) const {
+    if (bad) atomicAdd((unsigned long long*)poison, (unsigned long long)bad);
+    if (hi) atomicAdd((unsigned long long*)&fix[idx], (unsigned long long)hi);
+    if (lo) atomicAdd((unsigned long long*)&fix[plane + idx], lo);
+  }
+};
+
 template <typename T>
 __global__ __launch_bounds__(256) void ba_reduce_assemble_grouped_kernel(
     const T* __restrict__ partials, int nrec_per_pair, const int* __restrict__ grp_start, const int* __restrict__ grp_list,
@@ -1983,71 +2003,104 @@ __global__ __launch_bounds__(256) void ba_reduce_assemble_grouped_kernel(
     for (; w < nrec_per_pair; ++w) s += (double)base[(long)w * Cfg::REC];
     return s;
   };
-  auto add_low = [&](long ia, long ib, double v) {          // one entry of the lower triangle
-    const long r = ia > ib ? ia : ib, c = ia > ib ? ib : ia;
-    fix_add(Hm, fix_plane, r * D + c, v, poison);
-  };
+  auto low = [&](long ia, long ib) { return (ia > ib ? ia : ib) * D + (ia > ib ? ib : ia); };     // entry of the lower triangle
   const int p0 = grp_list[g0];
   const int slot = pr.ref_slot[p0];
   const long* pri = pose_ref_inds + 8 * (long)p0;
   const long* lmi = landmark_inds + 3 * (long)m * p0;
   const T* dz = dzdP + 3 * (long)slot;
-  // does this element involve the target frame (then it is per pair)?
+  // what this element is, and whether it involves the target frame (then it is added per pair)
   bool per_pair = false;
   int tt = 0, rg = 0, lane = 0, ti = 0, tj = 0, ri = 0, ci = 0, gt = 0;
-  if (e < Cfg::NT * 256) {
+  const bool is_tile = e < Cfg::NT * 256, is_grad = !is_tile && e < Cfg::NT * 256 + Cfg::NB * 16;
+  if (is_tile) {
     tt = e >> 8; rg = (e >> 6) & 3; lane = e & 63;
     int cnt = 0;
     for (int a = 0; a < Cfg::NB; ++a)
       for (int b = a; b < Cfg::NB; ++b) { if (cnt == tt) { ti = a; tj = b; } ++cnt; }
     ri = mfma_row<T>(lane, rg); ci = lane & 15;
     per_pair = (ti == 0) && (ri >= 8 || (tj == 0 && ci >= 8));
-  } else if (e < Cfg::NT * 256 + Cfg::NB * 16) {
+  } else if (is_grad) {
     gt = (e - Cfg::NT * 256) >> 4; ci = e & 15;
     per_pair = (gt == 0) && ci >= 8;
   }
-  double s = 0;
-  if (!per_pair)
-    for (int q = g0; q < g1; ++q) s += pair_sum(grp_list[q]);
-  for (int q = g0; q < (per_pair ? g1 : g0 + 1); ++q) {
+  FixAcc acc[9];
+  for (int q = g0; q < g1; ++q) {
     const int p = grp_list[q];
-    if (per_pair) s = pair_sum(p);
+    const double s = pair_sum(p);
     const long* pti = pose_tgt_inds + 8 * (long)p;
-    if (e < Cfg::NT * 256) {
+    if (is_tile) {
       if (ti == 0 && tj == 0) {
         const long ia = ri < 8 ? pri[ri] : pti[ri - 8];
         const long ib = ci < 8 ? pri[ci] : pti[ci - 8];
-        if (ia >= ib) add_low(ia, ib, s);
+        if (ia >= ib) {
+          if (per_pair) fix_add(Hm, fix_plane, low(ia, ib), s, poison);
+          else acc[0].add(s);
+        }
       } else if (ti == 0) {
         const int k = kcol(tj, ci);
         if (k < m) {
           const long ia = ri < 8 ? pri[ri] : pti[ri - 8];
-          for (int d = 0; d < 3; ++d) add_low(ia, lmi[3 * k + d], s * (double)dz[d]);
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const double v = s * (double)dz[d];
+            if (per_pair) fix_add(Hm, fix_plane, low(ia, lmi[3 * k + d]), v, poison);
+            else acc[d].add(v);
+          }
         }
       } else {
         const int k1 = kcol(ti, ri), k2 = kcol(tj, ci);
         if (k1 < m && k2 < m) {
+#pragma unroll
           for (int d1 = 0; d1 < 3; ++d1)
-            for (int d2 = 0; d2 < 3; ++d2) {
-              const double v = (double)dz[d1] * s * (double)dz[d2];
-              const long i1 = lmi[3 * k1 + d1], i2 = lmi[3 * k2 + d2];
-              if (ti != tj) add_low(i1, i2, v);
-              else if (i1 >= i2) add_low(i1, i2, v);
-            }
+#pragma unroll
+            for (int d2 = 0; d2 < 3; ++d2) acc[3 * d1 + d2].add((double)dz[d1] * s * (double)dz[d2]);
         }
       }
-    } else if (e < Cfg::NT * 256 + Cfg::NB * 16) {
+    } else if (is_grad) {
       const double gval = -s;
       if (gt == 0) {
-        fix_add(Hm, fix_plane, D * D + (ci < 8 ? pri[ci] : pti[ci - 8]), gval, poison);
+        if (per_pair) fix_add(Hm, fix_plane, D * D + pti[ci - 8], gval, poison);
+        else acc[0].add(gval);
       } else {
         const int k = kcol(gt, ci);
-        if (k < m)
-          for (int d = 0; d < 3; ++d) fix_add(Hm, fix_plane, D * D + lmi[3 * k + d], gval * (double)dz[d], poison);
+        if (k < m) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) acc[d].add(gval * (double)dz[d]);
+        }
       }
     } else {
-      fix_add(Hm, fix_plane, D * D + D, s, poison);
+      acc[0].add(s);
     }
+  }
+  if (per_pair) return;
+  // one pair of integer atomics per entry for the whole group
+  if (is_tile) {
+    if (ti == 0 && tj == 0) {
+      const long ia = pri[ri], ib = pri[ci];
+      if (ia >= ib) acc[0].emit(Hm, fix_plane, low(ia, ib), poison);
+    } else if (ti == 0) {
+      const int k = kcol(tj, ci);
+      if (k < m)
+        for (int d = 0; d < 3; ++d) acc[d].emit(Hm, fix_plane, low(pri[ri], lmi[3 * k + d]), poison);
+    } else {
+      const int k1 = kcol(ti, ri), k2 = kcol(tj, ci);
+      if (k1 < m && k2 < m)
+        for (int d1 = 0; d1 < 3; ++d1)
+          for (int d2 = 0; d2 < 3; ++d2) {
+            const long i1 = lmi[3 * k1 + d1], i2 = lmi[3 * k2 + d2];
+            if (ti != tj || i1 >= i2) acc[3 * d1 + d2].emit(Hm, fix_plane, low(i1, i2), poison);
+          }
+    }
+  } else if (is_grad) {
+    if (gt == 0) acc[0].emit(Hm, fix_plane, D * D + pri[ci], poison);
+    else {
+      const int k = kcol(gt, ci);
+      if (k < m)
+        for (int d = 0; d < 3; ++d) acc[d].emit(Hm, fix_plane, D * D + lmi[3 * k + d], poison);
+    }
+  } else {
+    acc[0].emit(Hm, fix_plane, D * D + D, poison);
   }
 }
 
@@ -2130,6 +2183,14 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
   T* pair_ref = pair_aff + 2 * (long)b;
   uint32_t* hists = (uint32_t*)A->ws_hists;
 
+  if (A->phase & 1024) {
+    // the pair constants alone (phase 1 = constants + residual pass): the residual pass then runs fused into the dense reference
+    // (csrc/densify.hip como_dense_ref_fused_*), which needs ws_pair before the reference points exist
+    if (!(A->phase & 256) && !zero_words(hists, 6 * SEL_BINS, s)) return COMO_ERR_LAUNCH;
+    hipLaunchKernelGGL(ba_pair_setup_kernel<T>, dim3((b + 63) / 64), dim3(64), 0, s, (const T*)A->poses_all,
+                       (const T*)A->aff_all, pr, b, pair_T, pair_aff, pair_ref);
+    COMO_CHECK_LAUNCH();
+  }
   if (A->phase & 1) {
     if (!(A->phase & 256) && !zero_words(hists, 6 * SEL_BINS, s)) return COMO_ERR_LAUNCH;
     hipLaunchKernelGGL(ba_pair_setup_kernel<T>, dim3((b + 63) / 64), dim3(64), 0, s, (const T*)A->poses_all,

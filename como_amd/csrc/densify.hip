@@ -152,16 +152,42 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// Pass 1 of the window's photometric system (csrc/ba.hip ba_residual_kernel: warp into the target frame, bilinear sample, affine
+// residual, validity, first digit of the robust scale's histogram) FUSED into the dense reference (round 6): the reference point
+// P_w of a pixel is in a register here, and the pairs that use keyframe b as their reference (two keyframe pairs, plus one-way
+// frames) only need it, the pixel's reference intensity and their own 12 + 2 pair constants -- the separate kernel re-read P_w
+// (3 planes) and the intensities for every PAIR of the pixel: 138 MB of the dense float64 window's 177, 53 us per iteration.
+// Same operations on the same values (warp_point / make_taps / tap_sum of common.cuh, the residual expression of
+// ba_residual_kernel): r, the validity bytes and the histogram are those of the separate kernel, bit for bit (tested).
 template <typename T>
+struct DRFuse {
+  const int* ref_pairs;     // (B, np_max): the pairs whose reference slot is keyframe b, -1 padded
+  int np_max;
+  const T* pair_T;          // (b, 12) inverse target poses      (ba_pair_setup_kernel)
+  const T* pair_aff;        // (b, 2)  exp(a_j - a_i), b_j - b_i
+  const T* vals;            // (B, n)  reference intensities (one channel)
+  const T* img_base;        // target stacks: img_base + tgt_img[p]
+  const long* tgt_img;
+  T* r_out;                 // (b, n)
+  uint8_t* valid_out;       // (b, n)
+  uint32_t* rhists;         // the robust scale's select workspace (digit 0 accumulated here)
+  int H, W, anorm_f32;
+};
+
+template <typename T, bool FUSE>
 __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
     const T* __restrict__ Kt, long kt_slot_stride, const int* __restrict__ pixidx, const T* __restrict__ logzm,
     const T* __restrict__ Twc, const T* __restrict__ Kmat, const T* __restrict__ dlogzm_dTwc, int n, int m,
     int Wimg, T* __restrict__ Pwn, T* __restrict__ dPwn_dTwc, T* __restrict__ uvec, T* __restrict__ zbuf,
-    T* __restrict__ logzn_out, uint32_t* __restrict__ hists, const int* __restrict__ pixcoord, int compact) {
+    T* __restrict__ logzn_out, uint32_t* __restrict__ hists, const int* __restrict__ pixcoord, int compact, DRFuse<T> fz) {
   using KeyT = typename KeyOf<T>::type;
   using acc_t = typename DAcc<T>::type;
   __shared__ uint32_t lh[SEL_BINS];
+  __shared__ uint32_t lh2[FUSE ? SEL_BINS : 1];
   __shared__ T sD[4][64 * 9];
+  if constexpr (FUSE) {
+    for (int k = threadIdx.x; k < SEL_BINS; k += 256) lh2[k] = 0;
+  }
   const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
   for (int k = tid; k < SEL_BINS; k += 256) lh[k] = 0;
   T bop[16];                          // coefficient operand: column c of {logz_m, dlogz_m/dT (6), 0...}, k = 16 s + 4 q + e
@@ -277,9 +303,36 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
       if (logzn_out) logzn_out[(long)b * n + i] = logz;
     }
     sel_lds_add(lh, sel_digit<KeyT>(abs_key(Zc), 0), inr);
+    if constexpr (FUSE) {
+      const T vr = fz.vals[(long)b * n + i];
+      const T ax = fz.anorm_f32 ? (T)(1.0f / (float)fz.W) : T(1) / T(fz.W), ay = fz.anorm_f32 ? (T)(1.0f / (float)fz.H) : T(1) / T(fz.H);
+      for (int q = 0; q < fz.np_max; ++q) {
+        const int p = fz.ref_pairs[(long)b * fz.np_max + q];                 // (uniform)
+        if (p < 0) break;
+        const T* M = fz.pair_T + 12 * (long)p;
+        const T scale = fz.pair_aff[2 * p], bias = fz.pair_aff[2 * p + 1];
+        const T* img = fz.img_base + fz.tgt_img[p];
+        // warp_point of csrc/ba.hip (photo.py:106, camera.py:20-26, photo.py:15-21)
+        T X, Y, Z;
+        rigid_apply(M, Xw, Yw, Zw, X, Y, Z);
+        const T pu = project1(fx, X, Z, cx);
+        const T pv = project1(fy, Y, Z, cy);
+        const bool ok = in_image(pu, pv, fz.H, fz.W) && (Z > T(0));
+        Taps<T> t = make_taps(grid_position(pu, fz.W, ax), grid_position(pv, fz.H, ay), fz.H, fz.W);
+        const T It = tap_sum(img, t);
+        const T r = It - scale * vr + bias;         // photo.py:114-118
+        if (inr) {
+          const long oi = (long)p * n + i;
+          fz.r_out[oi] = r;
+          fz.valid_out[oi] = ok ? 1 : 0;
+        }
+        sel_lds_add(lh2, sel_digit<KeyT>(abs_key(r), 0), inr && ok);
+      }
+    }
   }
   __syncthreads();
   sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
+  if constexpr (FUSE) sel_flush(lh2, fz.rhists);
 }
 
 template <typename T>
@@ -615,7 +668,7 @@ __global__ __launch_bounds__(256) void ktilde_kernel(const T* __restrict__ cov, 
 template <typename T>
 int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logzm, const T* Twc, const T* Kmat,
               const T* dlogzm_dTwc, int B, int n, int m, int Wimg, T* Pwn, T* dPwn_dTwc, T* uvec, T* zbuf, T* logzn_out,
-              void* hists_v, T* med_out3, const int* pixcoord, int flags, hipStream_t s) {
+              void* hists_v, T* med_out3, const int* pixcoord, int flags, hipStream_t s, const DRFuse<T>* fuse = nullptr) {
   using KeyT = typename KeyOf<T>::type;
   const int compact = (flags & 16) ? 1 : 0;   // dPwn_dTwc receives the 6 planes dlogz_n/dT_wc only, uvec is not written
   const bool depth_only = (flags & 8) != 0;   // z_n = exp(K~ logz_m) of every row + its exact median: Mapping.store_vars (Mapping.py:749-758)
@@ -636,9 +689,14 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
   if (sizeof(T) == 4 || (!depth_only && !(flags & 32))) {
     int gm = ((n + 63) / 64 + 3) / 4;
     if (gm > 256) gm = 256;
-    hipLaunchKernelGGL(dense_ref_mfma_kernel<T>, dim3(gm, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
-                       dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord, compact);
+    if (fuse && !depth_only)
+      hipLaunchKernelGGL((dense_ref_mfma_kernel<T, true>), dim3(gm, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
+                         dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord, compact, *fuse);
+    else
+      hipLaunchKernelGGL((dense_ref_mfma_kernel<T, false>), dim3(gm, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
+                         dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord, compact, DRFuse<T>{});
   } else {
+    if (fuse) return COMO_ERR_ARG;                          // (the fused pass exists in the matrix-core kernel only)
     hipLaunchKernelGGL(dense_ref_kernel<T>, dim3(gx, B), dim3(256), 0, s, Kt, kt_slot_stride, pixidx, logzm, Twc, Kmat,
                        dlogzm_dTwc, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, logzn_out, hists, pixcoord, compact);
   }
@@ -677,6 +735,26 @@ int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx,
   if (rc || (flags & 2)) return rc;
   return como_select_finish_f64(hists, B, med_out3, stream);
 }
+
+/* como_dense_ref_* with pass 1 of the photometric system fused in (see DRFuse above / include/como_hip.h como_dr_fuse). */
+#define COMO_DEF_DR_FUSED(SFX, T)                                                                                               \
+  int como_dense_ref_fused_##SFX(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logzm, const T* Twc, const T* K,   \
+                                 const T* dlogzm_dTwc, int B, int n, int m, int Wimg, T* Pwn, T* dPwn_dTwc, T* uvec, T* zbuf,     \
+                                 T* logzn_out, void* hists, T* med_out3, const int* pixcoord, int flags, const como_dr_fuse* f,   \
+                                 como_stream_t stream) {                                                                        \
+    if (!f || !f->ref_pairs || f->np_max <= 0 || !f->pair_T || !f->pair_aff || !f->vals || !f->img_base || !f->tgt_img ||        \
+        !f->r_out || !f->valid_out || !f->rhists || f->H < 3 || f->W < 3 || (flags & (4 | 8)))                                  \
+      return COMO_ERR_ARG;                                                                                                      \
+    como::DRFuse<T> fz{f->ref_pairs, f->np_max, (const T*)f->pair_T, (const T*)f->pair_aff, (const T*)f->vals,                   \
+                       (const T*)f->img_base, f->tgt_img, (T*)f->r_out, (uint8_t*)f->valid_out, (uint32_t*)f->rhists, f->H, f->W,  \
+                       f->anorm_f32};                                                                                           \
+    int rc = como::dense_ref<T>(Kt, kt_slot_stride, pixidx, logzm, Twc, K, dlogzm_dTwc, B, n, m, Wimg, Pwn, dPwn_dTwc, uvec, zbuf, \
+                                logzn_out, hists, med_out3, pixcoord, flags, (hipStream_t)stream, &fz);                         \
+    if (rc || (flags & 2)) return rc;                                                                                           \
+    return como_select_finish_##SFX(hists, B, med_out3, stream);                                                                \
+  }
+COMO_DEF_DR_FUSED(f32, float)
+COMO_DEF_DR_FUSED(f64, double)
 
 #define COMO_DEF_BAND(SFX, T)                                                                                          \
   int como_depth_band_##SFX(const T* Kt, long kt_slot_stride, const T* logzm, T* logzm_prev, int B, int rows, int m, T* lref,  \

@@ -11,8 +11,32 @@ from como_amd import _lib
 _ws = {}
 
 
+def dense_reference_planes(Kt, n, compact, ws=None):
+    """The output planes `dense_reference_factored` writes for (Kt, n, compact) -- created on first use in the caller-owned dict `ws`
+    (or the module's) -- without launching anything: {"Pwn", "dT", "uvec", "z", "logz", "med", "hists"}.  (A caller that marshals
+    the consumers' argument blocks before the first launch needs their addresses.)"""
+    dt, dev = Kt.dtype, Kt.device
+    B = Kt.shape[0]
+    key = (str(dev), dt, B, n) if not compact else (str(dev), dt, B, n, "compact")
+    own = ws
+    w = own.get(key) if own is not None else _ws.get(key)
+    if w is None:
+        w = {"Pwn": torch.empty((B, 3, n), device=dev, dtype=dt),
+             "dT": torch.empty((B, 6 if compact else 18, n), device=dev, dtype=dt),
+             "uvec": None if compact else torch.empty((B, 3, n), device=dev, dtype=dt),
+             "z": torch.empty((B, n), device=dev, dtype=dt),
+             "logz": torch.empty((B, n), device=dev, dtype=dt), "med": torch.empty((B, 3), device=dev, dtype=dt),
+             "hists": torch.empty((B * _lib.lib().como_select_workspace_bytes() // 4,), device=dev, dtype=torch.int32)}
+        if own is not None:
+            own[key] = w
+        else:
+            _ws.clear()
+            _ws[key] = w
+    return w
+
+
 def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_logz=True, med_out=None, pixcoord=None,
-                             hists=None, ws=None, part="all", compact=False):
+                             hists=None, ws=None, part="all", compact=False, fuse=None):
     """logzm (B,m[,1]) Twc (B,4,4) Kt (B,rows,m) pixidx (B,n) int32 or None K (3,3) dlogzm_dTwc (B,m[,1],6).
     pixcoord: optional (B,n) int32 linear pixel index (row*W+col) when it differs from the K~ row index.
     hists: optional caller-owned, ALREADY ZEROED select workspace (B * como_select_workspace_bytes()): skips the clear.
@@ -30,32 +54,23 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
     B, rows, m = Kt.shape
     n = pixidx.shape[1] if pixidx is not None else rows
     L = _lib.lib()
-    key = (str(dev), dt, B, n) if not compact else (str(dev), dt, B, n, "compact")
-    own = ws
-    ws = own.get(key) if own is not None else _ws.get(key)
-    if ws is None:
-        ws = {"Pwn": torch.empty((B, 3, n), device=dev, dtype=dt),
-              "dT": torch.empty((B, 6 if compact else 18, n), device=dev, dtype=dt),
-              "uvec": None if compact else torch.empty((B, 3, n), device=dev, dtype=dt),
-              "z": torch.empty((B, n), device=dev, dtype=dt),
-              "logz": torch.empty((B, n), device=dev, dtype=dt), "med": torch.empty((B, 3), device=dev, dtype=dt),
-              "hists": torch.empty((B * L.como_select_workspace_bytes() // 4,), device=dev, dtype=torch.int32)}
-        if own is not None:
-            own[key] = ws
-        else:
-            _ws.clear()
-            _ws[key] = ws
+    ws = dense_reference_planes(Kt, n, compact, ws)
     med = med_out if med_out is not None else ws["med"]
     lz = logzm.reshape(B, m).to(dt).contiguous()
     dl = dlogzm_dTwc.reshape(B, m, 6).to(dt).contiguous()
     Tw = Twc.to(dt).contiguous()
     Kc = K.to(dt).contiguous()
-    fn = getattr(L, "como_dense_ref_" + _lib.suffix(dt))
-    rc = fn(Kt.data_ptr(), Kt.stride(0), _lib.ptr(pixidx), lz.data_ptr(), Tw.data_ptr(), Kc.data_ptr(), dl.data_ptr(), B, n, m,
+    flags = (1 if hists is not None else 0) | {"all": 0, "points": 2, "median": 4}[part] | (16 if compact else 0)
+    args = (Kt.data_ptr(), Kt.stride(0), _lib.ptr(pixidx), lz.data_ptr(), Tw.data_ptr(), Kc.data_ptr(), dl.data_ptr(), B, n, m,
             int(Wimg), ws["Pwn"].data_ptr(), ws["dT"].data_ptr(), _lib.ptr(ws["uvec"]), ws["z"].data_ptr(),
             ws["logz"].data_ptr() if want_logz else None, (hists if hists is not None else ws["hists"]).data_ptr(), med.data_ptr(),
-            _lib.ptr(pixcoord), (1 if hists is not None else 0) | {"all": 0, "points": 2, "median": 4}[part] | (16 if compact else 0),
-            _lib.stream_ptr(dev))
+            _lib.ptr(pixcoord), flags)
+    if fuse is not None and part != "median":
+        # fuse: a filled _lib.DRFuse (pass 1 of the photometric system rides in this launch: include/como_hip.h como_dr_fuse)
+        import ctypes
+        rc = getattr(L, "como_dense_ref_fused_" + _lib.suffix(dt))(*args, ctypes.byref(fuse), _lib.stream_ptr(dev))
+    else:
+        rc = getattr(L, "como_dense_ref_" + _lib.suffix(dt))(*args, _lib.stream_ptr(dev))
     _lib.check(rc, "como_dense_ref")
     return ws["Pwn"], ws["dT"], ws["uvec"], med[:, 0], ws["logz"]
 

@@ -226,7 +226,7 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
         assemble()
     last_aux.clear()
     last_aux.update({"valid": ws_valid, "r": ws_r, "sigma": sigma_out, "pj": pj, "blocks": blocks, "hists": ws_hists,
-                     "chunks": chunks})
+                     "chunks": chunks, "pair": ws_pair, "b": b})
     if prepared is not None and reduce_hists is None and events is None and reduce_blocks is None:
         # (the argument block `a` and every tensor it points to stay alive in the closure / the aux dict)
         prepared["run"] = run
@@ -355,6 +355,12 @@ class PairTable:
         asm_list = np.asarray([p_ for lst in by_slot.values() for p_ in lst], dtype=np.int64)
         asm_start = np.cumsum([0] + [len(lst) for lst in by_slot.values()]).astype(np.int64)
         self.n_asm_grp = len(by_slot)
+        # ... and per reference keyframe (slot) its pairs, -1 padded: the residual pass fused into the dense reference walks them
+        self.np_max = max(len(v) for v in by_slot.values()) if by_slot else 1
+        refp = -np.ones((num_kf, self.np_max), dtype=np.int64)
+        for slot_, lst in by_slot.items():
+            if 0 <= slot_ < num_kf:
+                refp[slot_, :len(lst)] = lst
         # every host-built index array -- including the system rows of the reference / target FRAMES, which are plain ramps
         # (frame f owns rows 8 f .. 8 f + 7: `kf_inds` / `recent_inds` are views of one arange) -- in ONE host->device copy of a
         # pinned staging block: the window's pair table is rebuilt on every keyframe / one-way frame of the sequential loop
@@ -364,7 +370,7 @@ class PairTable:
         rows_tgt = (8 * tgt_frame[:, None] + ar8).reshape(-1) if ramp else np.zeros(0, np.int64)
         lm_rows = landmark_inds_host[ref].reshape(-1).astype(np.int64) if landmark_inds_host is not None else np.zeros(0, np.int64)
         extra = extra_i64 or {}
-        h32 = np.concatenate((ref, tgt_frame, chan, flat_grp, asm_start, asm_list)).astype(np.int32)
+        h32 = np.concatenate((ref, tgt_frame, chan, flat_grp, asm_start, asm_list, refp.reshape(-1))).astype(np.int32)
         if h32.shape[0] % 2:
             h32 = np.concatenate((h32, np.zeros(1, np.int32)))
         h64 = np.concatenate([off, ref, rows_ref, rows_tgt, lm_rows] + [np.asarray(v, dtype=np.int64).reshape(-1) for v in extra.values()])
@@ -392,6 +398,8 @@ class PairTable:
         o32 = 3 * b + ng
         self.asm_grp_start = i32[o32:o32 + asm_start.shape[0]]
         self.asm_grp_list = i32[o32 + asm_start.shape[0]:o32 + asm_start.shape[0] + b]
+        o32 += asm_start.shape[0] + b
+        self.ref_pairs = i32[o32:o32 + num_kf * self.np_max].view(num_kf, self.np_max)
         self.tgt_img = i64[0:b]
         rid = i64[b:2 * b]
         o = 2 * b

@@ -24,7 +24,7 @@ import como_amd.odom.backend.photo as photo
 import como_amd.odom.backend.sparse_map as smap
 from como_amd import _lib
 from como_amd.geometry.camera import backprojection
-from como_amd.odom.backend.dense_ref import dense_reference_factored, full_image_median, median_passes
+from como_amd.odom.backend.dense_ref import dense_reference_factored, dense_reference_planes, full_image_median, median_passes
 from como_amd.odom.backend.graph_pair_construction import setup_photometric_pairs
 from como_amd.odom.factors.depth_prior import log_depth_prior
 from como_amd.odom.factors.gp_priors import gp_ml_cost, mean_log_depth_cost
@@ -39,6 +39,7 @@ DEFAULT_CFG = {
 }
 
 
+_FUSE_PASS1 = __import__("os").environ.get("COMO_BA_FUSE_PASS1", "1") != "0"      # 0: the residual pass as its own launch (A/B)
 _REUSE_TOPOLOGY = __import__("os").environ.get("COMO_BA_REUSE", "1") != "0"      # (measurement switch)
 _REUSE_WORKSPACES = __import__("os").environ.get("COMO_BA_REUSE_WS", "1") != "0"  # (measurement switch)
 
@@ -571,9 +572,33 @@ class WindowBA:
         _lib.check(L.como_win_scaffold(ctypes.byref(a), s), "como_win_scaffold")
         if not a.zero_c:
             self.sysfix.zero_()
+        # Pass 1 of the photometric system (warp / sample / residual / validity + the first digit of the robust scale) rides in the
+        # dense-reference launch (csrc/densify.hip DRFuse): the pair constants first (phase 1024), then the fused launch, then the
+        # rest of the chain (phase 0xFE).  Gray images, the whole pixel range, one GPU, no per-kernel events.
+        fuse = None
+        if (_FUSE_PASS1 and self.shard is None and self.channels == 1 and self.events is None and self.pix_range is None and
+                self.table.b > 0 and self.n > 0):
+            planes = dense_reference_planes(self.Kt, self.n, True, w["dr_ws"])
+            prep = self._ba_prepared
+            photo.photo_system_factored(self.table, poses_all=w["px_poses"], aff_all=w["px_aff"], Pwn=planes["Pwn"], vals=self.vals_n,
+                                        dPwn_dTwc=planes["dT"], uvec=None, Kt=self.Kt, pixidx=self.pixidx, invz=w["px_invz"],
+                                        dzdP=w["px_dzdP"], img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=None,
+                                        g=None, err_out=None, sigma_out=self.sigma, zeroed_hists=w["hist_ba"], ws=w["ba_ws"],
+                                        sysfix=self.sysfix, fix_plane=self.fix_plane, D=self.dim, prepared=prep, phase=1024)
+            fuse = prep.get("fuse")
+            if fuse is None and "aux" in prep:
+                aux, b = prep["aux"], self.table.b
+                fuse = _lib.DRFuse()
+                fuse.ref_pairs, fuse.np_max = _lib.ptr(self.table.ref_pairs), int(self.table.np_max)
+                fuse.pair_T = aux["pair"].data_ptr()
+                fuse.pair_aff = aux["pair"].data_ptr() + 12 * b * aux["pair"].element_size()
+                fuse.vals, fuse.img_base, fuse.tgt_img = _lib.ptr(self.vals_n), _lib.ptr(self.img), _lib.ptr(self.table.tgt_img)
+                fuse.r_out, fuse.valid_out, fuse.rhists = aux["r"].data_ptr(), aux["valid"].data_ptr(), aux["hists"].data_ptr()
+                fuse.H, fuse.W, fuse.anorm_f32 = self.Himg, self.Wimg, 0
+                prep["fuse"] = fuse
         dr = lambda part: dense_reference_factored(w["px_logzm"], w["px_poses"][:self.B], self.Kt, self.pixidx, self.K_pix,
                                                    w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"],
-                                                   hists=w["hist_dr"], ws=w["dr_ws"], part=part, compact=True)
+                                                   hists=w["hist_dr"], ws=w["dr_ws"], part=part, compact=True, fuse=fuse)
         fork = self.shard is None and self.overlap_priors
         late_side = False
         fm = lambda part: full_image_median(w["px_logzm"], self.Kt, w["med3_full"], w["dr_ws"], hists=w["hist_full"], part=part,
@@ -614,7 +639,8 @@ class WindowBA:
                                     img_base=self.img, K=self.K_pix, H_img=self.Himg, W_img=self.Wimg, H=None, g=None,
                                     err_out=None, sigma_out=self.sigma, events=self.events, zeroed_hists=w["hist_ba"],
                                     ws=w["ba_ws"], sysfix=self.sysfix, fix_plane=self.fix_plane, D=self.dim,
-                                    prepared=self._ba_prepared if self.events is None else None)
+                                    prepared=self._ba_prepared if self.events is None else None,
+                                    phase=0xFE if fuse is not None else 0xFF)
         if late_side:
             side.wait_event(ev)
             with torch.cuda.stream(side):

@@ -200,7 +200,9 @@ typedef struct como_ba_args {
   int chunks;                /* pixel chunks per pair (grid.x of the block kernel); partial records = b*chunks */
   int phase;                 /* bit mask: 1 setup+residual(+hist pass 0), 2<<(p-1) hist pass p>=1, 64 blocks, 128 reduce+assemble,
                                 256 = ws_hists is already zero (skip the clear), 512 = float64 hist pass 3 collects the candidate
-                                keys of the multi-GPU exchange instead of finishing locally (como_select_cand_*) */
+                                keys of the multi-GPU exchange instead of finishing locally (como_select_cand_*),
+                                1024 = the pair constants alone (setup without the residual pass: that pass then runs fused into
+                                como_dense_ref_fused_*; continue with phase 0xFE) */
   int h_is_f64;              /* element type of Hmat / gvec: 1 = double, 0 = float */
   int variant;               /* zmode 2 only: 0 = software-pipelined block kernels (default; the two-pair kernels where
                                 grp_pairs lists pairs), 1 = straightforward one, 2 = pipelined one-pair kernel only (float32),
@@ -379,6 +381,34 @@ int como_dense_ref_f64(const double* Kt, long kt_slot_stride, const int* pixidx,
                        const double* K, const double* dlogzm_dTwc, int B, int n, int m, int Wimg, double* Pwn,
                        double* dPwn_dTwc, double* uvec, double* zbuf, double* logzn_out, void* hists, double* med_out3,
                        const int* pixcoord, int flags, como_stream_t stream);
+/* Round 6: the dense reference with PASS 1 of the window's photometric system fused in (como_ba_linearize_* phase 1 =
+ * batch_photo_cost's warp / sample / residual / validity, photo.py:104-121, + the first digit of the robust scale's select): the
+ * reference point of a pixel is in a register when the dense reference forms it, and the pairs that use keyframe b as reference only
+ * need it, the pixel's intensity and their pair constants.  Call como_ba_linearize_* with phase 1024 first (pair constants into
+ * ws_pair), this with the fields below, then como_ba_linearize_* with phase 0xFE (select passes, blocks, assembly).  Gray images,
+ * the whole pixel range, the matrix-core kernel (float32, or float64 points).  r_out / valid_out / rhists receive exactly what the
+ * separate pass writes. */
+typedef struct como_dr_fuse {
+  const int* ref_pairs;      /* (B, np_max): pairs whose reference slot is keyframe b, -1 padded */
+  int np_max;
+  const void* pair_T;        /* como_ba_args.ws_pair: (b,12) inverse target poses ... */
+  const void* pair_aff;      /* ... followed by (b,2) relative affine parameters (ws_pair + 12 b elements) */
+  const void* vals;          /* (B,n) reference intensities */
+  const void* img_base;      /* as como_ba_args.img_base / tgt_img */
+  const long* tgt_img;
+  void* r_out;               /* como_ba_args.ws_r (b,n) */
+  void* valid_out;           /* como_ba_args.ws_valid (b,n) u8 */
+  void* rhists;              /* como_ba_args.ws_hists (zeroed) */
+  int H, W, anorm_f32;
+} como_dr_fuse;
+int como_dense_ref_fused_f32(const float* Kt, long kt_slot_stride, const int* pixidx, const float* logzm, const float* Twc,
+                             const float* K, const float* dlogzm_dTwc, int B, int n, int m, int Wimg, float* Pwn, float* dPwn_dTwc,
+                             float* uvec, float* zbuf, float* logzn_out, void* hists, float* med_out3, const int* pixcoord, int flags,
+                             const como_dr_fuse* fuse, como_stream_t stream);
+int como_dense_ref_fused_f64(const double* Kt, long kt_slot_stride, const int* pixidx, const double* logzm, const double* Twc,
+                             const double* K, const double* dlogzm_dTwc, int B, int n, int m, int Wimg, double* Pwn, double* dPwn_dTwc,
+                             double* uvec, double* zbuf, double* logzn_out, void* hists, double* med_out3, const int* pixcoord, int flags,
+                             const como_dr_fuse* fuse, como_stream_t stream);
 
 /* Mapping.store_vars' full-image median depth (Mapping.py:749-758) WITHOUT re-reading all of K~ every GN iteration: instead of
  * the depth-only pass of como_dense_ref_* (flag 8) this evaluates z_n = exp(K~[n,:] logz_m) only for the pixels whose cached

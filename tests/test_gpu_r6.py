@@ -330,9 +330,9 @@ def test_se3_normalisation_kernel_vs_svd():
 
 
 def test_grouped_assembly_equals_the_per_pair_form(monkeypatch):
-    """ba_reduce_assemble_grouped_kernel (csrc/ba.hip: the pairs of one reference keyframe summed before the dz/dP expansion and
-    the fixed-point scatter) against the per-pair assembly on a window with one-way frames (3-4 pairs per reference keyframe):
-    the normal equations agree to float64 rounding of the regrouped sums, and are bit-identical from run to run."""
+    """ba_reduce_assemble_grouped_kernel (csrc/ba.hip: the fixed-point parts of what the pairs of one reference keyframe add to the
+    same system entries summed in registers, one pair of integer atomics per entry and group) against the per-pair assembly on a
+    window with one-way frames (3-4 pairs per reference keyframe): the SAME bits (integer addition is associative)."""
     import como_amd.odom.backend.photo as photo
     from como_amd import synth
     from como_amd.depth_cov.core.covariance import prep_predictor
@@ -354,7 +354,40 @@ def test_grouped_assembly_equals_the_per_pair_form(monkeypatch):
     (H0, g0, _, _), = out[False]
     assert ng == B and b > 2 * (B - 1)                        # one-way pairs joined the keyframes' groups
     assert torch.equal(H1, H1b) and torch.equal(g1, g1b)
-    dH = ((H1 - H0).abs() / (H0.diagonal().abs().sqrt()[:, None] * H0.diagonal().abs().sqrt()[None, :] + 1e-300)).max().item()
-    dg = ((g1 - g0).abs().max() / g0.abs().max()).item()
-    report("grouped_assembly", pairs=b, groups=ng, H_jacobi_scaled_diff=dH, g_rel_diff=dg)
-    assert dH < 1e-13 and dg < 1e-13
+    report("grouped_assembly", pairs=b, groups=ng, H_max_abs_diff=(H1 - H0).abs().max().item(), g_max_abs_diff=(g1 - g0).abs().max().item())
+    assert torch.equal(H1, H0) and torch.equal(g1, g0)
+
+
+@pytest.mark.parametrize("pix,win", [(torch.float64, 1), (torch.float64, 2), (torch.float32, 1), (torch.float32, 4)])
+def test_residual_pass_fused_into_the_dense_reference(pix, win, monkeypatch):
+    """como_dense_ref_fused_* (csrc/densify.hip DRFuse: pass 1 of batch_photo_cost -- warp, sample, residual, validity, first digit
+    of the robust scale, photo.py:104-128 -- inside the dense-reference launch) against the separate residual kernel: residuals,
+    validity bytes, the robust scale and the normal equations are IDENTICAL, bit for bit; with one-way frames (pairs whose target
+    is not a keyframe) and without."""
+    import como_amd.odom.backend.photo as photo
+    import como_amd.odom.window_ba as wba
+    from como_amd import synth
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    B, H, W, m = 3, 96, 128, 16
+    st = synth.make_window(B=B, H=H, W=W, m=m, dtype=torch.float64, device=DEV, seed=9,
+                           predictor=lambda cov, cm: prep_predictor(cov, cm, 1.0))
+    if win == 2:
+        st.update(synth.make_recent([0.4, 1.5], H, W, 9, device=DEV))
+    cfg = copy.deepcopy(wba.DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = win
+    out = {}
+    for flag in (True, False):
+        monkeypatch.setattr(wba, "_FUSE_PASS1", flag)
+        wb = wba.WindowBA(st, cfg=cfg, pix_dtype=pix, window_full=True)
+        Hm, g = wb.linearize()
+        torch.cuda.synchronize()
+        aux = photo.last_aux
+        out[flag] = (aux["r"].clone(), aux["valid"].clone(), wb.sigma.clone(), Hm.clone(), g.clone(), wb.table.b)
+        d = wb.iterate()                                   # (a second pass through the cached argument block)
+        out[flag] += (d.clone(),)
+    a, b_ = out[True], out[False]
+    v = b_[1].bool()
+    report("fused_pass1", pix=str(pix), window=win, pairs=a[5], valid=int(v.sum()), sigma=float(a[2][0]))
+    assert torch.equal(a[1], b_[1]) and int(v.sum()) > 1000
+    assert torch.equal(a[0][v], b_[0][v]) and torch.equal(a[0], b_[0])
+    assert torch.equal(a[2], b_[2]) and torch.equal(a[3], b_[3]) and torch.equal(a[4], b_[4]) and torch.equal(a[6], b_[6])
