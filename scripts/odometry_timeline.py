@@ -54,10 +54,11 @@ for a, b in zip(tl[:-1], tl[1:]):
             fb += e - max(s, prev)
             prev = e
     # (by content, not by dispatch count: a keyframe insertion runs the covariance network, a one-way insertion the float64
-    # image gradients of Mapping.get_img_and_grads)
+    # image stack of Mapping.add_one_way_frame -- round 6: frame_stack_kernel; before: img_grads_kernel<double>)
     names = [n for _, _, n in rows[a:b]]
     k = ("keyframe insertion" if any("conv3_" in n or "conv_mfma" in n for n in names) else
-         ("one-way frame + window rebuild" if any("img_grads_kernel<double>" in n for n in names) else "plain tracked frame"))
+         ("one-way frame + window rebuild" if any("img_grads_kernel<double>" in n or "frame_stack_kernel" in n for n in names)
+          else "plain tracked frame"))
     kinds[k].append((fb / 1e3, b - a))
 for k, v in kinds.items():
     if v:
