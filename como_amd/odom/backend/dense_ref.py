@@ -36,7 +36,7 @@ def dense_reference_planes(Kt, n, compact, ws=None):
 
 
 def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_logz=True, med_out=None, pixcoord=None,
-                             hists=None, ws=None, part="all", compact=False, fuse=None):
+                             hists=None, ws=None, part="all", compact=False, fuse=None, call_cache=None, stream=None):
     """logzm (B,m[,1]) Twc (B,4,4) Kt (B,rows,m) pixidx (B,n) int32 or None K (3,3) dlogzm_dTwc (B,m[,1],6).
     pixcoord: optional (B,n) int32 linear pixel index (row*W+col) when it differs from the K~ row index.
     hists: optional caller-owned, ALREADY ZEROED select workspace (B * como_select_workspace_bytes()): skips the clear.
@@ -49,6 +49,17 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
     dP_w/dT_wc = [-[u]x R, R] + u (x) dlogz_n/dT_wc with u = P_w - t_wc from the reference pose.
     Returns Pwn (B,3,n), dPwn_dTwc (B,18,n) [compact: dlogzn_dTwc (B,6,n)], uvec (B,3,n) [compact: None], median depth (B,),
     logzn (B,n)."""
+    # call_cache: caller-owned dict valid while NOTHING about the call changes (one window topology: the same buffers every
+    # iteration): the marshalled argument tuple is kept per `part` and replayed -- the conversions / views / pointer look-ups below
+    # were ~40 us of host time per call.  stream: raw stream handle to launch on (None: the current stream).
+    if call_cache is not None:
+        ent = call_cache.get(("dr", part))
+        if ent is not None:
+            fn, args, fz, out = ent
+            st = stream if stream is not None else _lib.stream_ptr(Kt.device)
+            rc = fn(*args, fz, st) if fz is not None else fn(*args, st)
+            _lib.check(rc, "como_dense_ref")
+            return out
     _lib.require_cuda(logzm, Twc, Kt, K, dlogzm_dTwc)
     dt, dev = Kt.dtype, Kt.device
     B, rows, m = Kt.shape
@@ -65,14 +76,22 @@ def dense_reference_factored(logzm, Twc, Kt, pixidx, K, dlogzm_dTwc, Wimg, want_
             int(Wimg), ws["Pwn"].data_ptr(), ws["dT"].data_ptr(), _lib.ptr(ws["uvec"]), ws["z"].data_ptr(),
             ws["logz"].data_ptr() if want_logz else None, (hists if hists is not None else ws["hists"]).data_ptr(), med.data_ptr(),
             _lib.ptr(pixcoord), flags)
+    st = stream if stream is not None else _lib.stream_ptr(dev)
+    out = (ws["Pwn"], ws["dT"], ws["uvec"], med[:, 0], ws["logz"])
     if fuse is not None and part != "median":
         # fuse: a filled _lib.DRFuse (pass 1 of the photometric system rides in this launch: include/como_hip.h como_dr_fuse)
         import ctypes
-        rc = getattr(L, "como_dense_ref_fused_" + _lib.suffix(dt))(*args, ctypes.byref(fuse), _lib.stream_ptr(dev))
+        fn, fz = getattr(L, "como_dense_ref_fused_" + _lib.suffix(dt)), ctypes.byref(fuse)
+        rc = fn(*args, fz, st)
     else:
-        rc = getattr(L, "como_dense_ref_" + _lib.suffix(dt))(*args, _lib.stream_ptr(dev))
+        fn, fz = getattr(L, "como_dense_ref_" + _lib.suffix(dt)), None
+        rc = fn(*args, st)
     _lib.check(rc, "como_dense_ref")
-    return ws["Pwn"], ws["dT"], ws["uvec"], med[:, 0], ws["logz"]
+    if call_cache is not None:
+        # (the tensors behind the pointers stay alive in the entry)
+        call_cache[("dr", part)] = (fn, args, fz, out)
+        call_cache[("dr_keep", part)] = (lz, dl, Tw, Kc, ws, med, fuse, hists, pixidx, pixcoord, Kt)
+    return out
 
 
 _di_ws = {}
@@ -111,7 +130,8 @@ def depth_image(Kt, logzm, out=None, logz_out=None):
 BAND_MEDIAN = __import__("os").environ.get("COMO_BAND_MEDIAN", "1") != "0"
 
 
-def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=None, band=None, reduce_max=None):
+def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=None, band=None, reduce_max=None, call_cache=None,
+                      stream=None):
     """Mapping.store_vars (Mapping.py:749-758): per keyframe the exact median of exp(K~ logz_m) over ALL rows of K~
     (the full depth image).  logzm (B,m), Kt (B,rows,m); med_out (B,3) caller-owned {median, 1.4826 median, n};
     ws: caller-owned dict (depth plane + select histograms; a captured graph records the addresses).
@@ -123,6 +143,12 @@ def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=Non
     part: "all", or "points" (kernel + pass-0 histogram) then "median" (remaining select passes + finish).
     reduce: multi-GPU -- Kt is then this rank's ROW RANGE of every keyframe's predictor (a view) and the digit histograms
     are all-reduced between the passes (median_passes), so every rank gets the median of the whole image."""
+    if call_cache is not None:
+        ent = call_cache.get(("fm", part))
+        if ent is not None:                                  # (the plain streaming pass only: the band form keeps host-side state)
+            fn, args, out = ent
+            _lib.check(fn(*args, stream if stream is not None else _lib.stream_ptr(Kt.device)), "como_dense_ref (depth only)")
+            return out
     _lib.require_cuda(logzm, Kt)
     dt, dev = Kt.dtype, Kt.device
     B, rows, m = Kt.shape
@@ -184,10 +210,14 @@ def full_image_median(logzm, Kt, med_out, ws, hists=None, part="all", reduce=Non
                     _lib.stream_ptr(dev))
             _lib.check(rc, "como_dense_ref (median of the band plane)")
     else:
-        rc = fn(Kt.data_ptr(), Kt.stride(0), None, lz.data_ptr(), w["eye"].data_ptr(), w["K"].data_ptr(), w["dl"].data_ptr(), B, rows,
+        args = (Kt.data_ptr(), Kt.stride(0), None, lz.data_ptr(), w["eye"].data_ptr(), w["K"].data_ptr(), w["dl"].data_ptr(), B, rows,
                 m, 1, None, None, None, w["z"].data_ptr(), None, h.data_ptr(), med_out.data_ptr(), None,
-                8 | (1 if hists is not None else 0) | part_flag, _lib.stream_ptr(dev))
+                8 | (1 if hists is not None else 0) | part_flag)
+        rc = fn(*args, stream if stream is not None else _lib.stream_ptr(dev))
         _lib.check(rc, "como_dense_ref (depth only)")
+        if call_cache is not None and reduce is None:
+            call_cache[("fm", part)] = (fn, args, med_out[:, 0])
+            call_cache[("fm_keep", part)] = (Kt, lz, w, h, med_out)
     if reduce == "defer":
         return w["z"]                                    # the caller drives the select passes (shared all-reduces)
     if reduce is not None:

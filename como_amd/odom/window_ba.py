@@ -24,7 +24,7 @@ import como_amd.odom.backend.photo as photo
 import como_amd.odom.backend.sparse_map as smap
 from como_amd import _lib
 from como_amd.geometry.camera import backprojection
-from como_amd.odom.backend.dense_ref import dense_reference_factored, dense_reference_planes, full_image_median, median_passes
+from como_amd.odom.backend.dense_ref import BAND_MEDIAN, dense_reference_factored, dense_reference_planes, full_image_median, median_passes
 from como_amd.odom.backend.graph_pair_construction import setup_photometric_pairs
 from como_amd.odom.factors.depth_prior import log_depth_prior
 from como_amd.odom.factors.gp_priors import gp_ml_cost, mean_log_depth_cost
@@ -596,13 +596,17 @@ class WindowBA:
                 fuse.r_out, fuse.valid_out, fuse.rhists = aux["r"].data_ptr(), aux["valid"].data_ptr(), aux["hists"].data_ptr()
                 fuse.H, fuse.W, fuse.anorm_f32 = self.Himg, self.Wimg, 0
                 prep["fuse"] = fuse
-        dr = lambda part: dense_reference_factored(w["px_logzm"], w["px_poses"][:self.B], self.Kt, self.pixidx, self.K_pix,
-                                                   w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"],
-                                                   hists=w["hist_dr"], ws=w["dr_ws"], part=part, compact=True, fuse=fuse)
+        # (single GPU without per-kernel events: the marshalled calls of the dense reference / the full-image median are cached with
+        # the BA chain's argument block, per topology; launches on the side stream take its handle instead of a stream context)
+        cc = self._ba_prepared if (self.shard is None and self.events is None) else None
+        dr = lambda part, stream=None: dense_reference_factored(w["px_logzm"], w["px_poses"][:self.B], self.Kt, self.pixidx, self.K_pix,
+                                                                w["px_dlogz_dT"], self.Wimg, want_logz=False, med_out=w["med3"],
+                                                                hists=w["hist_dr"], ws=w["dr_ws"], part=part, compact=True, fuse=fuse,
+                                                                call_cache=cc, stream=stream)
         fork = self.shard is None and self.overlap_priors
         late_side = False
-        fm = lambda part: full_image_median(w["px_logzm"], self.Kt, w["med3_full"], w["dr_ws"], hists=w["hist_full"], part=part,
-                                            band=self.band_median)
+        fm = lambda part, stream=None: full_image_median(w["px_logzm"], self.Kt, w["med3_full"], w["dr_ws"], hists=w["hist_full"],
+                                                         part=part, band=self.band_median, call_cache=cc, stream=stream)
         if self.shard is not None:
             return self._linearize_sharded(dr)
         if fork and self.full_median:
@@ -626,10 +630,10 @@ class WindowBA:
             main = torch.cuda.current_stream(dev)
             side = self._side_stream
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                dr("median")
-                if self.with_priors:
-                    _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
+            ss = side.cuda_stream
+            dr("median", ss)
+            if self.with_priors:
+                _lib.check(L.como_win_priors(ctypes.byref(a), ss), "como_win_priors")
         # (eager launches execute in submission order whenever a kernel fills the chip: submitted between the dense reference and
         # the photometric chain, the band kernel + its select passes + the priors -- 165 us at 9 x 640x480 -- sat ON the critical
         # path of every eager iteration of the sequential loop although they are a side branch; submitted after the chain they run
@@ -643,10 +647,16 @@ class WindowBA:
                                     phase=0xFE if fuse is not None else 0xFF)
         if late_side:
             side.wait_event(ev)
-            with torch.cuda.stream(side):
-                fm("all")
+            if self.band_median is False or (self.band_median is None and not BAND_MEDIAN):
+                ss = side.cuda_stream                        # (the plain streaming pass: kernels only, no torch op in between)
+                fm("all", ss)
                 if self.with_priors:
-                    _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
+                    _lib.check(L.como_win_priors(ctypes.byref(a), ss), "como_win_priors")
+            else:
+                with torch.cuda.stream(side):                # (the band form zeroes / copies state with torch ops: a stream context)
+                    fm("all")
+                    if self.with_priors:
+                        _lib.check(L.como_win_priors(ctypes.byref(a), _lib.stream_ptr(dev)), "como_win_priors")
         if fork:
             torch.cuda.current_stream(dev).wait_stream(side)
         else:

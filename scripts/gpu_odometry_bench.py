@@ -82,6 +82,28 @@ def main():
             return r
         setattr(obj, name, wrap)
 
+    def host_timed(obj, name, label):
+        # host time spent INSIDE the call (no synchronisation added): where the Python side of a frame goes
+        fn = getattr(obj, name)
+
+        def wrap(*a, **k):
+            t0 = time.perf_counter()
+            r = fn(*a, **k)
+            parts.setdefault("host:" + label, []).append(time.perf_counter() - t0)
+            return r
+        setattr(obj, name, wrap)
+
+    if os.environ.get("COMO_ODO_BREAKDOWN", "1") == "2":
+        from como_amd.odom import window_ba as _wba
+        host_timed(odo.tracking, "handle_frame", "track_frame (incl. its read-back wait)")
+        host_timed(odo.tracking, "update_kf_reference", "tracker_reference_refresh")
+        host_timed(odo.mapping, "handle_tracking_data", "handle_tracking_data")
+        host_timed(odo.mapping, "iterate", "mapping_iterate (retarget / rebuild + enqueue + publish)")
+        host_timed(odo.mapping, "get_kf_ref_data", "get_kf_ref_data")
+        host_timed(odo.mapping, "_window_state", "_window_state")
+        host_timed(_wba.WindowBA, "retarget", "WindowBA.retarget")
+        host_timed(_wba.WindowBA, "step", "WindowBA.step (enqueue one iteration)")
+        host_timed(_wba.WindowBA, "snapshot_state", "WindowBA.snapshot_state")
     if os.environ.get("COMO_ODO_BREAKDOWN", "1") == "1":
         timed(odo.tracking, "handle_frame", "track_frame")
         timed(odo.tracking, "update_kf_reference", "tracker_reference_refresh")
