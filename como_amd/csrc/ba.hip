@@ -1984,10 +1984,18 @@ __global__ __launch_bounds__(256) void ba_reduce_assemble_grouped_kernel(
     const long* __restrict__ landmark_inds, const T* __restrict__ dzdP, int m, long long* __restrict__ Hm, long D, long fix_plane) {
   using Cfg = BACfg;
   constexpr int NE = Cfg::NT * 256 + Cfg::NB * 16 + 1;
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= NE) return;
+  // 64 elements per workgroup, the group's pairs dealt out over its four waves (the sum over a pair's records is a chain of
+  // dependent round trips to the memory side: 4.4 pairs x 37 records one after the other were 91 us in the sequential loop's
+  // windows); the waves' integer accumulators meet in LDS -- integer addition: the same bits as one thread walking all pairs
+  const int ql = threadIdx.x >> 6;
+  const int e_raw = blockIdx.x * 64 + (threadIdx.x & 63);
+  const bool act = e_raw < NE;
+  const int e = act ? e_raw : NE - 1;
   const int g0 = grp_start[blockIdx.y], g1 = grp_start[blockIdx.y + 1];
   if (g1 <= g0) return;
+  __shared__ long long sh_hi[3][9][64];
+  __shared__ unsigned long long sh_lo[3][9][64];
+  __shared__ unsigned sh_bad[3][9][64];
   long long* poison = Hm + D * D + D + FIX_POISON;
   auto pair_sum = [&](int p) {
     const T* base = partials + (long)p * nrec_per_pair * Cfg::REC + e;
@@ -2025,7 +2033,7 @@ __global__ __launch_bounds__(256) void ba_reduce_assemble_grouped_kernel(
     per_pair = (gt == 0) && ci >= 8;
   }
   FixAcc acc[9];
-  for (int q = g0; q < g1; ++q) {
+  for (int q = g0 + ql; q < g1 && act; q += 4) {
     const int p = grp_list[q];
     const double s = pair_sum(p);
     const long* pti = pose_tgt_inds + 8 * (long)p;
@@ -2073,7 +2081,21 @@ __global__ __launch_bounds__(256) void ba_reduce_assemble_grouped_kernel(
       acc[0].add(s);
     }
   }
-  if (per_pair) return;
+  if (g1 - g0 > 1) {                                   // (uniform over the workgroup)
+    const int l = threadIdx.x & 63;
+    if (ql > 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { sh_hi[ql - 1][k][l] = acc[k].hi; sh_lo[ql - 1][k][l] = acc[k].lo; sh_bad[ql - 1][k][l] = acc[k].bad; }
+    }
+    __syncthreads();
+    if (ql == 0) {
+#pragma unroll
+      for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { acc[k].hi += sh_hi[w][k][l]; acc[k].lo += sh_lo[w][k][l]; acc[k].bad += sh_bad[w][k][l]; }
+    }
+  }
+  if (per_pair || ql != 0 || !act) return;
   // one pair of integer atomics per entry for the whole group
   if (is_tile) {
     if (ti == 0 && tj == 0) {
@@ -2350,7 +2372,7 @@ int ba_linearize(const como_ba_args* A, hipStream_t s) {
       if (A->reduce_mode == 1) { LAUNCH_ASM(long long, 1); }
       else if (A->reduce_mode == 2) { LAUNCH_ASM(long long, 2); }
       else if (A->asm_grp_start && A->asm_grp_list && A->n_asm_grp > 0 && !A->pair_blocks_out) {
-        hipLaunchKernelGGL((ba_reduce_assemble_grouped_kernel<T>), dim3((BACfg::REC + 255) / 256, A->n_asm_grp), dim3(256), 0, s,
+        hipLaunchKernelGGL((ba_reduce_assemble_grouped_kernel<T>), dim3((BACfg::NT * 256 + BACfg::NB * 16 + 1 + 63) / 64, A->n_asm_grp), dim3(256), 0, s,
                            (const T*)A->ws_partials, nrec, A->asm_grp_start, A->asm_grp_list, pr, A->pose_ref_inds, A->pose_tgt_inds,
                            A->landmark_inds, (const T*)A->dzdP, m, (long long*)A->Hmat, A->D, A->fix_plane);
       }

@@ -27,6 +27,7 @@ _HOST_CORR = os.environ.get("COMO_KF_HOST_CORR", "1") != "0"        # 0: the cor
 _SE3_NORMALIZE_KERNEL = os.environ.get("COMO_SE3_NORMALIZE_KERNEL", "1") != "0"   # 0: LAPACK SVD on the host (A/B)
 _FUSED_FRAME = os.environ.get("COMO_FUSED_FRAME", "1") != "0"       # 0: the torch chains of a frame hand-over (world pose / affine, gray + gradients + cat + copies) (A/B)
 _KEPT_MEDIANS = os.environ.get("COMO_KF_KEPT_MEDIANS", "1") != "0"  # 0: a keyframe insertion re-evaluates every keyframe's depth image (A/B)
+_ASYNC_NETWORK = os.environ.get("COMO_KF_ASYNC_NETWORK", "1") != "0"   # 0: the covariance network of a keyframe insertion in line on the main stream (A/B)
 _RETARGET = os.environ.get("COMO_BA_RETARGET", "1") != "0"          # 0: a one-way frame builds a new window object, as round 5 (A/B)
 
 from como_amd.depth_cov.core.covariance import prep_predictor as _prep_predictor
@@ -241,6 +242,35 @@ class Mapping:
         return _run_model(self.model, rgb, network_size=self.network_size_list, dtype=self.dtype,
                           graphed=self.cfg.get("graph_network", True))
 
+    def start_model(self, rgb):
+        """`run_model` on a side stream, started as soon as the tracker has asked for a keyframe: the network only reads the frame,
+        while the ~45 small launches and two read-backs that precede its first use in `add_keyframe` (world pose, image stack,
+        depth image and reprojection of the last keyframe) are host-bound -- 0.65 ms during which the device sat idle and the
+        network (0.7 ms: a chain of ~60 dependent launches on a fraction of the compute units) had not even been submitted."""
+        dev = rgb.device
+        main = torch.cuda.current_stream(dev)
+        side = getattr(self, "_net_stream", None)
+        if side is None:
+            side = self._net_stream = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)                                # (the frame is ready; an unclaimed earlier evaluation ran on `side` too)
+        with torch.cuda.stream(side):
+            cov = self.run_model(rgb)
+        cov.record_stream(main)
+        ev = torch.cuda.Event()
+        ev.record(side)
+        self._net_pending = (rgb.data_ptr(), tuple(rgb.shape), cov, ev)
+
+    def take_model(self, rgb):
+        """The covariance image of `rgb`: the side-stream evaluation `start_model` began for this frame, or `run_model` in line."""
+        pend, self._net_pending = getattr(self, "_net_pending", None), None
+        if pend is not None:
+            # (also when the result is not the one asked for: the graphed network owns ONE set of static buffers per input shape,
+            # an evaluation in line must not start while the side stream still runs in them)
+            torch.cuda.current_stream(rgb.device).wait_event(pend[3])
+            if pend[1] == tuple(rgb.shape):
+                return pend[2]
+        return self.run_model(rgb)
+
     def prep_predictor(self, cov_params_img, coords_m, into_window=False):
         """Mapping.py:430-468 -> (K_mm_inv, L_mm, Knm_Kmminv (b,H,W,m)); K_nm is never materialised (csrc/densify.hip).
         into_window (add_keyframe): K~ is written STRAIGHT into the new keyframe's slot of the window's sliding predictor buffer (and,
@@ -386,7 +416,7 @@ class Mapping:
         # frame's size): issued first, its host synchronisation does not wait for the network, which then runs under the host work
         pre = prepare_track_and_init(self.kf_poses[-1:, ...], kf_pose_init, coords_m_last, zm_last, z_img_last, self.intrinsics,
                                      tuple(rgb.shape[-2:]), self.cfg["corr"])
-        cov_params_img = self.run_model(rgb)
+        cov_params_img = self.take_model(rgb)
         coords_m_new, z_m_new, corr_mask, coords_m, zm_first_obs = track_and_init(
             self.kf_poses[-1:, ...], kf_pose_init, coords_m_last, zm_last, z_img_last, cov_params_img,
             self.intrinsics, self.model, self.cfg["corr"], self.cfg["sampling"], self.kf_img_and_grads.shape[-2:], prepared=pre)
@@ -564,6 +594,8 @@ class Mapping:
         kf_viz_data, kf_updated = None, False
         if data[0] in ("one-way", "keyframe"):
             rgb, pose_curr_kf, aff_curr_kf, kf_timestamp, timestamp = data[1:]
+            if data[0] == "keyframe" and _ASYNC_NETWORK and rgb.is_cuda:
+                self.start_model(rgb)                         # (float(rgb) is what run_model reads, whatever add_keyframe gets)
             k = self.find_kf_from_timestamp(kf_timestamp)
             pose_w, aff_w = self.get_curr_world_state(pose_curr_kf, aff_curr_kf, k)
             if data[0] == "one-way":

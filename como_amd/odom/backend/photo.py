@@ -19,6 +19,7 @@ BLOCK_VARIANT = int(__import__("os").environ.get("COMO_BA_VARIANT", "0"))   # 0 
 CHUNKS_OVERRIDE = int(__import__("os").environ.get("COMO_BA_CHUNKS", "0"))   # tuning runs: pixel chunks per pair group
 BLOCK_STAGGER = int(__import__("os").environ.get("COMO_BA_STAGGER", "0"))
 ASM_GROUPED = __import__("os").environ.get("COMO_BA_ASM_GROUPED", "1") != "0"   # 0: the assembly expands / scatters every pair on its own (A/B)
+ASM_GROUPED_MIN_PAIRS = 3      # the grouped assembly runs from this many pairs per reference keyframe on average (see linearize)
 MIN_TILES_PER_CHUNK = int(__import__("os").environ.get("COMO_BA_MIN_TILES", "8"))   # lower bound on a chunk's 64-pixel tiles (0: off; see linearize)
 last_aux = {}   # diagnostics of the most recent call: valid mask, sigma, nvalid (tests / callers that want them)
 
@@ -133,7 +134,10 @@ def linearize(*, dtype, b, n, m, H_img, W_img, zmode, Pwn, vals, dPwn_dTwc, zjac
             raise RuntimeError("como_amd: pair_chan must be a contiguous int32 tensor with one channel per pair entry")
         _lib.require_cuda(pair_chan)
         a.pair_chan = _lib.ptr(pair_chan)
-    if asm_groups is not None and ASM_GROUPED and sysfix is not None and reduce_blocks is None and not want_blocks:
+    # (only where a group holds three or more pairs on average -- the sequential loop's windows with their one-way frames: with
+    # the two pairs per keyframe of a plain window the grouped launch has half the workgroups and is slower, 39 vs 29 us at 14 pairs)
+    if (asm_groups is not None and ASM_GROUPED and sysfix is not None and reduce_blocks is None and not want_blocks and
+            ASM_GROUPED_MIN_PAIRS * int(asm_groups[2]) <= b):
         # (start offsets, pair list, number of groups): the assembly sums what the pairs of one reference keyframe share first
         a.asm_grp_start, a.asm_grp_list, a.n_asm_grp = _lib.ptr(asm_groups[0]), _lib.ptr(asm_groups[1]), int(asm_groups[2])
     if sysfix is not None:

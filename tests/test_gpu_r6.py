@@ -340,9 +340,10 @@ def test_grouped_assembly_equals_the_per_pair_form(monkeypatch):
     B, H, W, m = 3, 96, 128, 16
     st = synth.make_window(B=B, H=H, W=W, m=m, dtype=torch.float64, device=DEV, seed=7,
                            predictor=lambda cov, cm: prep_predictor(cov, cm, 1.0))
-    st.update(synth.make_recent([0.3, 1.3, 1.6, 0.6], H, W, 7, device=DEV))
-    cfg = copy.deepcopy(DEFAULT_CFG)
+    st.update(synth.make_recent([0.3, 1.3, 1.6, 0.6, 1.1, 1.45, 1.8, 1.2], H, W, 7, device=DEV))    # (a group of > 4 pairs: the
+    cfg = copy.deepcopy(DEFAULT_CFG)                                                                 #  waves of a workgroup wrap)
     cfg["photo_construction"]["nonmax_suppression_window"] = 2
+    monkeypatch.setattr(photo, "ASM_GROUPED_MIN_PAIRS", 0)
     out = {}
     for flag in (True, False, True):
         monkeypatch.setattr(photo, "ASM_GROUPED", flag)
@@ -391,3 +392,30 @@ def test_residual_pass_fused_into_the_dense_reference(pix, win, monkeypatch):
     assert torch.equal(a[1], b_[1]) and int(v.sum()) > 1000
     assert torch.equal(a[0][v], b_[0][v]) and torch.equal(a[0], b_[0])
     assert torch.equal(a[2], b_[2]) and torch.equal(a[3], b_[3]) and torch.equal(a[4], b_[4]) and torch.equal(a[6], b_[6])
+
+
+def test_network_on_the_side_stream_equals_the_inline_call():
+    """Mapping.start_model / take_model (the covariance network of a keyframe insertion submitted on a side stream as soon as the
+    tracker asks for a keyframe, joined where add_keyframe first reads it) against run_model in line: the same covariance image,
+    bit for bit, with main-stream work queued in between; a pending result of another frame size is not handed out."""
+    import types
+    from como_amd import synth
+    from como_amd.depth_cov.core.DepthCovModule import DepthCovModule, run_model
+    from como_amd.odom.Mapping import Mapping
+    model = DepthCovModule({k: v.to(DEV) for k, v in synth.depthcov_state_dict(3).items()})
+    g = torch.Generator().manual_seed(5)
+    rgb = torch.rand((1, 3, 120, 160), generator=g).to(DEV)
+    ns = types.SimpleNamespace(run_model=lambda x: run_model(model, x, network_size=[96, 128], dtype=torch.float64))
+    want = ns.run_model(rgb).clone()
+    for _ in range(2):
+        Mapping.start_model(ns, rgb)
+        busy = torch.randn(2048, 2048, device=DEV)
+        for _ in range(4):
+            busy = busy @ busy.mT * 1e-3                   # (main-stream work between the submission and the join)
+        got = Mapping.take_model(ns, rgb.double())
+        assert ns._net_pending is None and got.dtype == torch.float64 and torch.equal(got, want)
+    Mapping.start_model(ns, rgb)
+    other = torch.rand((1, 3, 96, 128), generator=g).to(DEV)
+    assert torch.equal(Mapping.take_model(ns, other), ns.run_model(other)) and ns._net_pending is None
+    torch.cuda.synchronize()
+    report("async_network", max_abs=float(want.abs().max()))
