@@ -27,6 +27,7 @@ _HOST_CORR = os.environ.get("COMO_KF_HOST_CORR", "1") != "0"        # 0: the cor
 _SE3_NORMALIZE_KERNEL = os.environ.get("COMO_SE3_NORMALIZE_KERNEL", "1") != "0"   # 0: LAPACK SVD on the host (A/B)
 _FUSED_FRAME = os.environ.get("COMO_FUSED_FRAME", "1") != "0"       # 0: the torch chains of a frame hand-over (world pose / affine, gray + gradients + cat + copies) (A/B)
 _KEPT_MEDIANS = os.environ.get("COMO_KF_KEPT_MEDIANS", "1") != "0"  # 0: a keyframe insertion re-evaluates every keyframe's depth image (A/B)
+_TRACK_REF_PIX = os.environ.get("COMO_TRACK_REF_PIX", "1") != "0"    # 0: the tracker's reference depth image from the float64 K~ whatever pix_dtype is (A/B)
 _ASYNC_NETWORK = os.environ.get("COMO_KF_ASYNC_NETWORK", "1") != "0"   # 0: the covariance network of a keyframe insertion in line on the main stream (A/B)
 _RETARGET = os.environ.get("COMO_BA_RETARGET", "1") != "0"          # 0: a one-way frame builds a new window object, as round 5 (A/B)
 
@@ -198,6 +199,48 @@ class Mapping:
         setattr(self, name, buf[s0:s0 + k + n_new])
         return buf[s0 + k:s0 + k + n_new]
 
+    def _slide_peek(self, name, old, n_new, i, cap):
+        """Device address the window tensor `name` WOULD start at after `_slide_reserve(name, old, n_new, ..., i, ...)`, without
+        doing it (None when that cannot be told: no buffer yet, a view that is not the one handed out last time)."""
+        st = self.__dict__.get("_kt_pp", {}).get(name)
+        if st is None or old is None:
+            return None
+        buf = st["buf"]
+        if buf.shape[0] != 2 * cap:
+            return None
+        slot = buf.stride(0) * buf.element_size()
+        if old.numel() == 0 and old.dim() == 1:
+            return buf.data_ptr()
+        if not (old.dtype == buf.dtype and old.stride() == buf.stride() and old.device == buf.device and
+                old.untyped_storage().data_ptr() == buf.untyped_storage().data_ptr()) or slot <= 0:
+            return None
+        rel = old.data_ptr() - buf.data_ptr()
+        if rel < 0 or rel % slot or rel // slot + old.shape[0] > 2 * cap:
+            return None
+        k = old[i:, ...].shape[0]
+        s0 = rel // slot + old.shape[0] - k
+        if s0 + k + n_new > 2 * cap:
+            s0 = 0
+        return buf.data_ptr() + s0 * slot
+
+    def speculate_one_way(self, timestamp):
+        """Called by the tracker between the launch of a frame's tracking and the wait for its result (`Tracking.while_waiting`):
+        if this frame turns out to be a one-way frame, the window the next iteration runs on is the current keyframe set + the
+        one-way frames below -- its pair table is built NOW (`WindowBA.speculate`), while the host has nothing else to do.
+        Nothing of the mapper's state is touched; a wrong guess (plain frame, keyframe) costs idle host time only."""
+        ba = self._ba
+        if ba is None or not self.is_init or not hasattr(ba, "speculate"):
+            return
+        i = self.get_recent_start_window_ind()
+        rec = list(self.recent_timestamps[i:]) + [timestamp]
+        cap = self.cfg["graph"]["num_one_way_frames"]
+        name = "recent_img_and_grads_pix" if (_PIX_MIRRORS and self.pix_dtype == torch.float32 and self.dtype != self.pix_dtype) else \
+            "recent_img_and_grads"
+        old = getattr(self, name, None)
+        if name.endswith("_pix") and (old is None or (self.recent_img_and_grads.numel() == 0 and self.recent_img_and_grads.dim() == 1)):
+            old = torch.empty((0), device=self.kf_poses.device, dtype=torch.float32)     # (add_one_way_frame starts the mirror over)
+        ba.speculate(self.kf_timestamps, rec, self._slide_peek(name, old, 1, i, cap))
+
     def window_cat_helper_list(self, var, new_var, i):
         del var[:i]
         var.append(new_var)
@@ -335,11 +378,19 @@ class Mapping:
             self._depth_cache = depth_image(self.Knm_Kmminv.reshape(b, h * w, m), self.logzm).reshape(b, 1, h, w)
         return self._depth_cache
 
-    def depth_imgs_of(self, lo, hi):
+    def depth_imgs_of(self, lo, hi, for_tracker=False):
         """Depth images of keyframes lo..hi-1 only (one 157 MB predictor each at 640x480: the tracker asks for the newest one
-        on every frame, `depth_imgs` would evaluate all nine)."""
+        on every frame, `depth_imgs` would evaluate all nine).  for_tracker: with float32 pixel kernels (`pix_dtype: float`) the
+        image is formed from the float32 mirror of K~ that the window's own dense reference reads (half the bytes, matrix-core
+        kernel: 41 -> 18 us per frame) and handed over in float32 -- the tracker's element type, which it was cast to anyway."""
         if self._depth_cache is not None:
             return self._depth_cache[lo:hi]
+        mirror = getattr(self, "Knm_Kmminv_pix", None)
+        if (for_tracker and _TRACK_REF_PIX and mirror is not None and mirror.dtype == torch.float32 and mirror.dim() == 4 and
+                mirror.shape == self.Knm_Kmminv.shape):
+            Kt = mirror[lo:hi]
+            b, h, w, m = Kt.shape
+            return depth_image(Kt.reshape(b, h * w, m), self.logzm[lo:hi]).reshape(b, 1, h, w)
         Kt = self.Knm_Kmminv[lo:hi]
         b, h, w, m = Kt.shape
         return depth_image(Kt.reshape(b, h * w, m), self.logzm[lo:hi]).reshape(b, 1, h, w)   # one pass over K~ (csrc/densify.hip)
@@ -349,7 +400,7 @@ class Mapping:
         end = self.kf_poses.shape[0]
         ind = max(0, end - self.cfg["track_ref"]["num_keyframes"])
         return (self.kf_timestamps[ind:end], self.rgb[ind:end], self.kf_poses[ind:end], self.kf_aff_params[ind:end],
-                self.depth_imgs_of(ind, end))
+                self.depth_imgs_of(ind, end, for_tracker=True))
 
     def get_kf_viz_data(self, ind=-1):
         """Mapping.py:514-544: cloned snapshot for a viewer -- the reference's 10-tuple, returned by default as the reference does.

@@ -344,6 +344,9 @@ class Tracking:
                 self._fg_disabled = True
                 return None
         T, aff, T_w, sc = out
+        hook = getattr(self, "while_waiting", None)
+        if hook is not None:                            # (host work that fits under the tracking launches: sequential.py sets it)
+            hook(getattr(self, "_cur_timestamp", None))
         v = sc.tolist()                                 # the frame's one host synchronisation
         nl = len(v) - 34 - 3                            # pyramid levels
         if min(v[3:3 + nl]) < 0:                        # a level kernel's barrier timed out / XCD census failed: track eagerly
@@ -357,6 +360,7 @@ class Tracking:
     # ---- one frame (Tracking.py:315-379) -----------------------------------------------------------------------------
     def handle_frame(self, data):
         timestamp, rgb = data
+        self._cur_timestamp = timestamp
         if self._frame_graph_applies(rgb):
             res = self._track_frame_graph(rgb)
             if res is not None:

@@ -57,6 +57,10 @@ class ComoSeq:
         self.mapping.setup(model)
         self.timestamps, self.est_poses = [], []
         self.last_kf_viz = None
+        if torch.device(self.tracking.device) == torch.device(self.mapping.device):
+            # one process, one device: while the tracker waits for a frame's result the mapper prepares the window that frame
+            # would need as a one-way frame (Mapping.speculate_one_way)
+            self.tracking.while_waiting = self.mapping.speculate_one_way
 
     def iter(self, timestamp, rgb):
         trk, mp = self.tracking, self.mapping

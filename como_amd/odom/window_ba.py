@@ -41,6 +41,8 @@ DEFAULT_CFG = {
 
 _FUSE_PASS1 = __import__("os").environ.get("COMO_BA_FUSE_PASS1", "1") != "0"      # 0: the residual pass as its own launch (A/B)
 _REUSE_TOPOLOGY = __import__("os").environ.get("COMO_BA_REUSE", "1") != "0"      # (measurement switch)
+_SPECULATE = __import__("os").environ.get("COMO_BA_SPECULATE", "1") != "0"      # 0: no pair table is built ahead of the tracker's decision (A/B)
+SPEC_STATS = {"built": 0, "adopted": 0}     # pair tables built ahead / adopted by a re-target (process-wide; bench.py reports them)
 _REUSE_WORKSPACES = __import__("os").environ.get("COMO_BA_REUSE_WS", "1") != "0"  # (measurement switch)
 
 
@@ -218,6 +220,50 @@ class WindowBA:
         self._load_frames(state, only_recent=state.get("_published_by") is self)
         self._finish_topology(first=False)
         return True
+
+    def speculate(self, kf_ts, rec_ts, rec_ptr):
+        """Build -- while the host would only wait for the tracker's read-back -- the pair table of THIS keyframe set with the
+        one-way frames `rec_ts` (host floats: what `Mapping.add_one_way_frame` would leave behind if the frame being tracked
+        becomes a one-way frame), their image stack starting at device address `rec_ptr`.  The table (numpy + ONE pinned upload,
+        on a stream of its own so that the tracker's read-back does not queue behind it) is only kept aside; `_build_pair_table`
+        takes it when the topology a `retarget` arrives at is exactly this one, and builds its own otherwise.  A one-way frame
+        spent 0.17 ms of host time there between the tracker's decision and the first kernel of its iteration."""
+        self._spec = None
+        pc = self.cfg["photo_construction"]
+        hn = getattr(self, "_host_np", None)
+        nrec = len(rec_ts)
+        why = ("off" if not (_SPECULATE and _REUSE_TOPOLOGY) else "not the fused single-GPU chain" if not (
+            self.fused and self.shard is None and self.dev.type == "cuda" and getattr(self, "win_args", None) is not None) else
+            "no host mirror of the landmark tables" if hn is None else "frame count" if not 0 < nrec <= self.rec_cap else
+            "image stack address unknown" if rec_ptr is None or getattr(self, "_rec_img_off", None) is None else
+            "pose-dependent pair graph" if pc.get("radius_thresh", 0.0) > 0.0 and pc.get("degrees_thresh", 0.0) > 0.0 else None)
+        if why is not None:
+            SPEC_STATS["skipped: " + why] = SPEC_STATS.get("skipped: " + why, 0) + 1
+            return
+        import numpy as np
+        from como_amd.odom.backend.graph_pair_construction import get_backward_edges, get_forward_edges, get_one_way_temporal_neighbors
+        B, dev = self.B, self.dev
+        rf, tf = get_forward_edges(B)
+        rb, tb = get_backward_edges(B)
+        ow_kf, ow_t = get_one_way_temporal_neighbors([float(t) for t in kf_ts], [float(t) for t in rec_ts])
+        ref, tgt = rf + rb, tf + tb
+        off = (int(rec_ptr) - self.img.data_ptr()) // self.img.element_size()
+        lm_start = 8 * B + 8 * nrec
+        ex = {"landmark_inds": hn["point_inds"] + lm_start,
+              "fix_inds": (lm_start + 3 * hn["fix_idx"][:, None] + np.arange(3)[None]).reshape(-1)}
+        recent_inds = _ar(8 * (B + nrec), dev)[8 * B:].reshape(nrec, 8)
+        recent_inds._como_ramp = True
+        side = getattr(self, "_spec_stream", None)
+        if side is None:
+            side = self._spec_stream = torch.cuda.Stream(device=dev)
+        stack = 3 * self.channels * self.Himg * self.Wimg
+        with torch.cuda.stream(side):
+            table = photo.PairTable(ref + ow_kf, tgt + ow_t, [False] * len(ref) + [True] * len(ow_kf), B, self.kf_inds, recent_inds, None,
+                                    stack, off, dev, channels=self.channels, landmark_inds_host=ex["landmark_inds"], extra_i64=ex)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        SPEC_STATS["built"] += 1
+        self._spec = {"pairs": ([ref, tgt], [ow_kf, ow_t]), "nrec": nrec, "off": off, "table": table, "event": ev, "host_np": hn}
 
     @staticmethod
     def _fixed_remap(mask, m):
@@ -436,6 +482,20 @@ class WindowBA:
         self.kf_pairs, self.one_way_pairs = pairs
         stack = 3 * self.channels * self.Himg * self.Wimg          # one frame's [I | dI/dx | dI/dy] stack
         ex = getattr(self, "_host_extra", None)
+        sp, self._spec = getattr(self, "_spec", None), None
+        if (sp is not None and ex is not None and sp["pairs"] == pairs and sp["nrec"] == self.F - B and sp["off"] == self._rec_img_off and
+                sp["host_np"] is getattr(self, "_host_np", None)):
+            # the table `speculate` built for exactly this topology while the tracker ran: wait for its upload, adopt it
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(sp["event"])
+            self.table = sp["table"]
+            for t in (self.table.ref_slot, self.table.tgt_img):
+                t.record_stream(main)                        # (both are views of the table's one device block)
+            self.landmark_inds = self.table.extra["landmark_inds"]
+            self.fix_inds_flat = self.table.extra["fix_inds"]
+            self.spec_hits = getattr(self, "spec_hits", 0) + 1
+            SPEC_STATS["adopted"] += 1
+            return
         self.table = photo.PairTable(ref + ow_kf, tgt + ow_t, [False] * len(ref) + [True] * len(ow_kf), B, self.kf_inds,
                                      self.recent_inds, None if ex is not None else self.landmark_inds, stack,
                                      B * stack if self._rec_img_off is None else self._rec_img_off, dev, channels=self.channels,

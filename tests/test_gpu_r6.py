@@ -235,8 +235,11 @@ def test_frame_handover_kernels_equal_the_torch_chains(rgb_dtype):
     assert torch.equal(out[:16].view(1, 4, 4), Tw) and torch.equal(out[16:].view(1, 2, 1), aw)
 
 
-def test_retargeted_window_equals_a_rebuilt_one():
-    """WindowBA.retarget (same keyframes, another set of one-way frames -- what 55 % of the sequential loop's frames ask for) against
+@pytest.mark.parametrize("speculate", [None, "hit", "miss"])
+def test_retargeted_window_equals_a_rebuilt_one(speculate):
+    """(speculate: the pair table of the re-targeted topology built ahead by `WindowBA.speculate` -- what the sequential loop does
+    while the tracker runs -- for the right / for another set of one-way frames: adopted / ignored, same result either way.)
+    WindowBA.retarget (same keyframes, another set of one-way frames -- what 55 % of the sequential loop's frames ask for) against
     a window built from scratch on the same state: the pair lists, the system size and one Gauss-Newton iteration's result
     (poses / affine parameters of every frame, landmarks) are identical, bit for bit -- the normal equations are assembled in
     fixed point, so nothing depends on which buffers were reused."""
@@ -255,6 +258,8 @@ def test_retargeted_window_equals_a_rebuilt_one():
         return s2
 
     s1, s3 = with_recent(1), with_recent(3)
+    if speculate:
+        s1["corr_host"] = s3["corr_host"] = st["correspondence_mask"].cpu().numpy()      # (the host mirror Mapping keeps)
     wb = WindowBA(s1, cfg=cfg, pix_dtype=torch.float64, window_full=True, rec_capacity=4)
     wb.iterate()
     # the caller's state after that iteration (what Mapping.iterate publishes), then two more one-way frames
@@ -264,7 +269,14 @@ def test_retargeted_window_equals_a_rebuilt_one():
         s_["P_m"], s_["median_depth_init"] = sn["P_m"].clone(), sn["median"].clone()
         s_["recent_poses"] = torch.cat((sn["poses"][B:B + 1], s_["recent_poses"][1:]))
     fresh = WindowBA(s3, cfg=cfg, pix_dtype=torch.float64, window_full=True)
+    if speculate:
+        assert getattr(wb, "_host_np", None) is not None
+        rec_ts = s3["recent_timestamps"].tolist()
+        wb.speculate(s3["kf_timestamps"].tolist(), rec_ts if speculate == "hit" else rec_ts[:2],
+                     s3["recent_img_and_grads"].data_ptr())
+        assert wb._spec is not None
     assert wb.retarget(s3) is True
+    assert getattr(wb, "spec_hits", 0) == (1 if speculate == "hit" else 0) and getattr(wb, "_spec", None) is None
     assert wb.F == fresh.F == B + 3 and wb.dim == fresh.dim
     assert (wb.kf_pairs, wb.one_way_pairs) == (fresh.kf_pairs, fresh.one_way_pairs)
     d1, d2 = wb.iterate().clone(), fresh.iterate().clone()
