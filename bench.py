@@ -157,6 +157,8 @@ def odometry_loop(device, frames=100, seed=1, pix="float", warm=0, barrier=None,
         rgbs = [r.to(device) for r in rgbs_cpu]
         model = DepthCovModule({k: v.to(device) for k, v in synth.depthcov_state_dict(0).items()})
         odo = ComoSeq(loop_cfgs(G, pix, str(device), graph_network=True), K.clone(), (G["H"], G["W"]), model)
+        from como_amd.odom import window_ba as _wba
+        spec0 = dict(_wba.SPEC_STATS)
         t0, k0, kinds, k_end = None, None, [], frames
         t_start = []
         k_init = None
@@ -202,6 +204,9 @@ def odometry_loop(device, frames=100, seed=1, pix="float", warm=0, barrier=None,
                "value": n / el, "unit": "frames/s", "ms_per_frame": 1e3 * el / n, "frames": n, "elapsed_s": el,
                "init_completed_at_frame": k_init, "keyframes_inserted": kinds.count("keyframe"), "one_way_inserted": kinds.count("one-way"),
                "tracking_chain_fallbacks": int(getattr(photo_tracking_pyr, "fallbacks", 0)), "frame_ms_by_request": frame_ms,
+               # pair tables of the next one-way topology built while the tracker ran / adopted by the re-target that followed
+               "pair_tables_built_ahead": {k: v - spec0.get(k, 0) for k, v in _wba.SPEC_STATS.items() if v - spec0.get(k, 0)},
+               "solver_fallbacks": int(getattr(odo.mapping, "solver_fallbacks", 0)),
                "ate_vs_gt_sim3_m": float(ate_rmse(est, [T[k] for k in tracked], "sim3")) if len(est) > 3 else None}
         ref_path = os.path.join(ROOT, "tests", "golden", "ate_sequence_640.npz")
         if seed == 1 and os.path.exists(ref_path):          # the pinned sequence: the reference's own loop on the same frames

@@ -35,11 +35,12 @@ if has odo; then
   python scripts/odometry_timeline.py /tmp/p_odo $OUT/odometry_timeline.txt > /dev/null 2>&1
   F=$(find /tmp/p_odo -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $OUT/odometry_kernel_stats.csv
   timeout 300 python scripts/loop_passes.py > $OUT/odometry_loop_passes.txt 2>> $OUT/odo.err
-  for SW in "" "COMO_BA_RETARGET=0 COMO_FUSED_FRAME=0 COMO_KF_KEPT_MEDIANS=0 COMO_KF_HOST_CORR=0 COMO_KF_MASKED_DENSE=0 COMO_KF_KT_DIRECT=0 COMO_GREEDY_PERSIST=0 COMO_GREEDY_THIN_WAVE=0 COMO_BA_ASM_GROUPED=0 COMO_BA_FUSE_PASS1=0 COMO_SE3_NORMALIZE_KERNEL=0"; do
+  for SW in "" "COMO_BA_RETARGET=0 COMO_FUSED_FRAME=0 COMO_KF_KEPT_MEDIANS=0 COMO_KF_HOST_CORR=0 COMO_KF_MASKED_DENSE=0 COMO_KF_KT_DIRECT=0 COMO_GREEDY_PERSIST=0 COMO_GREEDY_THIN_WAVE=0 COMO_BA_ASM_GROUPED=0 COMO_BA_FUSE_PASS1=0 COMO_SE3_NORMALIZE_KERNEL=0 COMO_KF_ASYNC_NETWORK=0 COMO_BA_SPECULATE=0 COMO_TRACK_REF_PIX=0"; do
     echo "== switches: ${SW:-defaults}" >> $OUT/odometry_loop_ab.txt
     for i in 1 2; do env $SW COMO_ODO_BREAKDOWN=0 timeout 300 python scripts/gpu_odometry_bench.py --frames 100 2>> $OUT/odo.err | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['loop_fps_after_init'],1), {k:(round(v['median'],2)) for k,v in d['frame_ms_by_request'].items()}, d['slowest_frames_ms'][:2])" >> $OUT/odometry_loop_ab.txt; done
   done
   timeout 200 python scripts/sampler_time.py > $OUT/sampler_time.txt 2>> $OUT/odo.err
+  timeout 300 python scripts/frame_host_timeline.py $OUT/frame_host_timeline.txt > /dev/null 2>> $OUT/odo.err
 fi
 if has aux; then
   { echo "== default"; timeout 200 python scripts/chol_time.py 200 760 1000 1300 2000 2680; } > $OUT/chol_time.txt 2>&1

@@ -34,12 +34,13 @@ def wrap(obj, name, label):
         r = fn(*a, **k)
         stamps.append((label, t0 - frame_t0[0], time.perf_counter() - frame_t0[0]))
         return r
-    if hasattr(fn, "__dict__") and not isinstance(obj, type):
+    if hasattr(fn, "__dict__") and not isinstance(obj, type) and not isinstance(fn, type):
         w.__dict__ = fn.__dict__          # (function attributes -- track_and_init.corr_host -- are read through the wrapper too)
     setattr(obj, name, w)
 
 
-for cls, names in ((wba.WindowBA, ("retarget", "_load_images", "_load_frames", "_finish_topology", "_build_pair_table", "_patch_args", "step", "speculate",
+for cls, names in ((wba.WindowBA, ("retarget", "_load_images", "_load_frames", "_finish_topology", "_build_pair_table", "_patch_args", "step", "speculate", "__init__",
+                                   "_prepare_topology", "_host_tables", "_prepare_fused",
                                    "linearize_fused", "_finalize", "snapshot_state")),
                    (mapping_mod.Mapping, ("handle_tracking_data", "add_one_way_frame", "add_keyframe", "get_curr_world_state", "_window_state",
                                           "iterate", "get_kf_ref_data", "_check_solver", "start_model", "take_model"))):
@@ -76,13 +77,56 @@ for n in ("get_predictor",):
     if hasattr(dd_mod, n):
         wrap(dd_mod, n, "distill:" + n)
 
+wrap(wba.smap, "subselect_pixels", "smap.subselect_pixels")
+for n in ("prep_tracking_img", "gradient_module", "depth_pyr_module"):
+    if hasattr(tracking_mod.Tracking, n):
+        wrap(tracking_mod.Tracking, n, "Tracking." + n)
+wrap(wba.photo, "PairTable", "photo.PairTable")
+
+# device-side clock of a few host markers: an event where the tracker's result has just been read back (the device is idle there:
+# device time = host time) and events at later host points; elapsed_time between them = when the DEVICE got there
+gpu_marks, gpu_prev = [], []
+
+
+def mark(obj, name, label, at_exit=False):
+    fn = getattr(obj, name)
+
+    def w(*a, **k):
+        if not at_exit:
+            e = torch.cuda.Event(enable_timing=True); e.record(); gpu_marks.append((label, time.perf_counter() - frame_t0[0], e))
+        r = fn(*a, **k)
+        if at_exit:
+            e = torch.cuda.Event(enable_timing=True); e.record(); gpu_marks.append((label, time.perf_counter() - frame_t0[0], e))
+        return r
+    setattr(obj, name, w)
+
+
+mark(tracking_mod.Tracking, "decide_frame", "A decision read back")
+mark(mapping_mod.Mapping, "add_keyframe", "B add_keyframe done", at_exit=True)
+mark(mapping_mod.Mapping, "add_one_way_frame", "B add_one_way_frame done", at_exit=True)
+mark(wba.WindowBA, "step", "C iteration enqueue begins")
+mark(wba.WindowBA, "step", "D iteration enqueued", at_exit=True)
+mark(tracking_mod.Tracking, "update_kf_reference", "E tracker refresh enqueued", at_exit=True)
+gagg = {}
+
 agg = {}
 for p in range(2):
     odo = ComoSeq(loop_cfgs(G, "float", dev, graph_network=True), K.clone(), (G["H"], G["W"]), model)
     for k in range(100):
         del stamps[:]
+        prev_marks, prev_kind = list(gpu_marks), (kind if k else None)
+        del gpu_marks[:]
         frame_t0[0] = time.perf_counter()
         kind = odo.iter(1.0 + k, rgbs[k])
+        if p == 1 and k > 6 and prev_marks and prev_marks[0][0].startswith("A") and gpu_marks and gpu_marks[0][0].startswith("A"):
+            # (this frame's read-back has synchronised: the previous frame's events are complete)
+            a0 = prev_marks[0]
+            g = gagg.setdefault(str(prev_kind), {})
+            for lab, th, e in prev_marks[1:]:
+                v = g.setdefault(lab, [0, 0.0, 0.0])
+                v[0] += 1
+                v[1] += th - a0[1]
+                v[2] += 1e-3 * a0[2].elapsed_time(e)
         t_end = time.perf_counter() - frame_t0[0]
         if p == 1 and odo.mapping.is_init and k > 5:
             a = agg.setdefault(str(kind), {"n": 0, "end": 0.0, "lab": {}})
@@ -104,3 +148,7 @@ for kind, a in agg.items():
           file=out)
     for lab, (c, t0, t1) in sorted(a["lab"].items(), key=lambda kv: kv[1][1] / kv[1][0]):
         print(f"   {1e3 * t0 / c:7.3f} .. {1e3 * t1 / c:7.3f}  ({1e3 * (t1 - t0) / c:6.3f})  x{c / a['n']:.2f}  {lab}", file=out)
+for kind, g in gagg.items():
+    print(f"== {kind}: host / device time after the tracker's result was read back, ms (device later than host = the device is behind: GPU-bound there)", file=out)
+    for lab, (c, th, tg) in sorted(g.items()):
+        print(f"   host {1e3 * th / c:7.3f}   device {1e3 * tg / c:7.3f}   {lab}", file=out)
