@@ -189,6 +189,7 @@ SIGNATURES = {
     "como_se3_normalize_f32": (c_int, [c_void_p, c_int, c_void_p]),
     "como_se3_normalize_f64": (c_int, [c_void_p, c_int, c_void_p]),
     "como_frame_world_f64": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),
+    "como_track_frame_record_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p]),
     "como_frame_stack_f64": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "como_win_update_checked": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_void_p, c_void_p]),
     "como_gram_workspace_bytes": (c_long, []),

@@ -527,6 +527,42 @@ __global__ void se3_normalize_kernel(T* __restrict__ poses, int n) {
     for (int c = 0; c < 3; ++c) P[4 * r + c] = (T)X[3 * r + c];
 }
 
+// Everything the host reads and keeps of a tracked frame (Tracking.handle_frame, Tracking.py:315-379) in ONE record:
+// [|t| of T_curr_kf | median depth | pixels seen | status word of every pyramid level | T_curr_kf (16) | aff_curr_kf (2) | T_w_curr (16)],
+// T_w_curr = T_w_kf inv(T_curr_kf) with se3_compose_kernel mode 2's arithmetic.  One thread: it replaces the pose composition, a
+// clone, a norm reduction, two casts and a concatenation -- five dependent launches of >= 4.5 us each behind every tracked frame.
+__global__ void track_frame_record_kernel(const float* __restrict__ T, const float* __restrict__ aff, const float* __restrict__ T_w_kf,
+                                          const float* __restrict__ median, const int* __restrict__ nseen,
+                                          const float* __restrict__ recs, int levels, int stride, float* __restrict__ out) {
+#pragma clang fp contract(off)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float a[16], p[16], b[16];
+  for (int e = 0; e < 16; ++e) { a[e] = T_w_kf[e]; p[e] = T[e]; }
+  for (int r = 0; r < 3; ++r) {
+    float s = p[r] * p[3];
+    s = s + p[4 + r] * p[7];
+    s = s + p[8 + r] * p[11];
+    b[4 * r + 0] = p[r]; b[4 * r + 1] = p[4 + r]; b[4 * r + 2] = p[8 + r]; b[4 * r + 3] = -s;
+  }
+  b[12] = 0.f; b[13] = 0.f; b[14] = 0.f; b[15] = 1.f;
+  out[0] = sqrtf((p[3] * p[3] + p[7] * p[7]) + p[11] * p[11]);
+  out[1] = median[0];
+  out[2] = (float)nseen[0];
+  for (int l = 0; l < levels; ++l) out[3 + l] = recs[(long)l * stride + 104];
+  float* o = out + 3 + levels;
+  for (int e = 0; e < 16; ++e) o[e] = p[e];
+  o[16] = aff[0]; o[17] = aff[1];
+  o += 18;
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      float s = a[4 * r] * b[c];
+      s = s + a[4 * r + 1] * b[4 + c];
+      s = s + a[4 * r + 2] * b[8 + c];
+      s = s + a[4 * r + 3] * b[12 + c];
+      o[4 * r + c] = s;
+    }
+}
+
 // A tracked frame's state in the world frame, as the mapper needs it when the tracker hands a frame over (Mapping.handle_tracking_data,
 // Mapping.py:580-598): T_w_curr = T_w_kf inv(T_curr_kf) (get_T_w_curr, transforms.py:6-8: se3_compose_kernel mode 2's arithmetic) and
 // aff_w_curr = (a_kf + a_cur, b_kf + b_cur exp(a_cur)) (get_aff_w_curr, affine_brightness.py:5-10: product and sums rounded on
@@ -573,6 +609,17 @@ int como_se3_normalize_f64(double* poses, int n, como_stream_t stream) {
 int como_se3_normalize_f32(float* poses, int n, como_stream_t stream) {
   if (!poses || n <= 0) return COMO_ERR_ARG;
   hipLaunchKernelGGL(como::se3_normalize_kernel<float>, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, poses, n);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+int como_track_frame_record_f32(const float* T_curr_kf, const float* aff_curr_kf, const float* T_w_kf, const float* median, const int* nseen,
+                                const float* level_records, int levels, int record_stride, float* out, como_stream_t stream) {
+  if (!T_curr_kf || !aff_curr_kf || !T_w_kf || !median || !nseen || !level_records || levels < 1 || levels > 16 || record_stride < 105 ||
+      !out)
+    return COMO_ERR_ARG;
+  hipLaunchKernelGGL(como::track_frame_record_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, T_curr_kf, aff_curr_kf, T_w_kf, median, nseen,
+                     level_records, levels, record_stride, out);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }

@@ -50,6 +50,8 @@ def _in_image(p, depth, img_size, border, depth_thresh, strict):
     return ok & (depth[..., 0] > depth_thresh)
 
 
+_FRAME_RECORD = os.environ.get("COMO_TRACK_FRAME_RECORD", "1") != "0"      # 0: the frame's record by pose composition + norm + casts + cat (A/B)
+_FOREACH_INPUTS = os.environ.get("COMO_TRACK_FOREACH_INPUTS", "1") != "0"   # 0: one copy launch per input of the frame graph (A/B)
 _DIRECT_REF = os.environ.get("COMO_TRACK_DIRECT_REF", "1") != "0"     # (read once: an os.environ look-up costs ~25 us, this ran per frame)
 
 
@@ -137,7 +139,7 @@ class Tracking:
             self.T_w_rec_last = T_w_curr
         return new
 
-    def reproj_stats_last_kf(self, T_curr_kf, P=None):
+    def reproj_stats_last_kf(self, T_curr_kf, P=None, clone_count=True):
         """(reprojected depth image (1,h,w), seen mask, number of pixels seen, their exact median depth) of the newest keyframe's
         finest-level points in the current frame (Tracking.py:163-185 get_reproj_last_kf + :341-345): two launches
         (csrc/trackref.hip `como_reproject_depth_*`) + the device select -- no boolean-mask gathers, no host synchronisation."""
@@ -160,7 +162,7 @@ class Tracking:
                       P.contiguous().data_ptr(), n, h, w, ws["order"].data_ptr(), ws["z"].data_ptr(), ws["img"].data_ptr(),
                       ws["seen"].data_ptr(), ws["nseen"].data_ptr(), _lib.stream_ptr(dev)), "como_reproject_depth")
         med = masked_median(ws["img"], ws["seen"])
-        return ws["img"].view(1, h, w), ws["seen"].view(1, h, w), ws["nseen"][0].clone(), med
+        return ws["img"].view(1, h, w), ws["seen"].view(1, h, w), (ws["nseen"][0].clone() if clone_count else ws["nseen"][0]), med
 
     def get_reproj_last_kf(self, T_curr_kf):
         """Depth image of the newest keyframe's finest-level points seen from the current frame, NaN where nothing lands
@@ -298,9 +300,21 @@ class Tracking:
         if res is None:
             return None
         T, aff, recs = res
+        dt = T.dtype
+        if (_FRAME_RECORD and dt == torch.float32 and aff.dtype == dt and recs.dtype == dt and recs.dim() == 2 and recs.is_contiguous() and
+                fg["T_w_kf"].dtype == dt):
+            # the frame's record in ONE launch (csrc/window.hip track_frame_record_kernel): world pose, |t|, casts, concatenation
+            _, _, n_seen, med = self.reproj_stats_last_kf(T, P=fg["pb"].levels[-1]["P"][0], clone_count=False)
+            nl = int(recs.shape[0])
+            sc = torch.empty((3 + nl + 34,), dtype=dt, device=T.device)
+            if med.dtype == dt and n_seen.dtype == torch.int32:
+                _lib.check(_lib.lib().como_track_frame_record_f32(
+                    T.contiguous().data_ptr(), aff.contiguous().data_ptr(), fg["T_w_kf"].contiguous().data_ptr(), med.data_ptr(),
+                    n_seen.data_ptr(), recs.data_ptr(), nl, int(recs.stride(0)), sc.data_ptr(), _lib.stream_ptr(T.device)),
+                    "como_track_frame_record_f32")
+                return T, aff, sc[3 + nl + 18:].view(1, 4, 4), sc
         T_w = get_T_w_curr(fg["T_w_kf"], T)
         _, _, n_seen, med = self.reproj_stats_last_kf(T, P=fg["pb"].levels[-1]["P"][0])
-        dt = T.dtype
         # everything the host reads and keeps of a frame in ONE buffer: [|t|, median depth, pixels seen, per-level barrier status |
         # T_curr_kf (16) | aff_curr_kf (2) | T_w_curr (16)] -- one read-back and one copy per frame instead of one + three
         sc = torch.cat((torch.linalg.norm(T[:, :3, 3]).reshape(1), med.reshape(1).to(dt), n_seen.reshape(1).to(dt), recs[:, 104],
@@ -322,10 +336,13 @@ class Tracking:
             fg = self._fg = {"rgb": torch.empty_like(rgb), "T": torch.empty_like(self.T_curr_kf), "aff": torch.empty_like(self.aff_curr_kf),
                              "T_w_kf": torch.empty_like(self.T_w_kf), "pb": pb, "ws": wsp,
                              "graph": None, "out": None, "warm": 0}
-        fg["rgb"].copy_(rgb)
-        fg["T"].copy_(self.T_curr_kf.reshape(1, 4, 4))
-        fg["aff"].copy_(self.aff_curr_kf.reshape(1, 2, 1))
-        fg["T_w_kf"].copy_(self.T_w_kf)
+        srcs = [rgb, self.T_curr_kf.reshape(1, 4, 4), self.aff_curr_kf.reshape(1, 2, 1), self.T_w_kf]
+        dsts = [fg["rgb"], fg["T"], fg["aff"], fg["T_w_kf"]]
+        if _FOREACH_INPUTS and all(a.dtype == b.dtype and a.device == b.device and a.shape == b.shape for a, b in zip(srcs, dsts)):
+            torch._foreach_copy_(dsts, srcs)            # the frame graph's four inputs in ONE launch (a dependent launch is >= 4.5 us)
+        else:
+            for b, a in zip(dsts, srcs):
+                b.copy_(a)
         fg["pb"].load_reference(self.vals_pyr, self.P_pyr, self.dI_dT_pyr, self.mask_pyr)
         if fg["graph"] is None and fg["warm"] >= 2:
             torch.cuda.synchronize(rgb.device)

@@ -615,12 +615,21 @@ class WindowBA:
         and on the fused chain "pm" (B,m,2), "logzm" (B,m)} -- views of TWO copied buffers (the state buffer and the head of the
         scaffold's output buffer) instead of seven separate clones."""
         dtype = dtype or self.dt
-        snap = self.state_flat.to(dtype, copy=True)
+        both = self.fused and getattr(self, "_w_head", None) is not None
+        if both and dtype == self.state_flat.dtype == self._w_head[0].dtype and self.state_flat.is_cuda:
+            # (both copies in ONE launch: every dependent launch of the sequential loop's frame chain costs >= 4.5 us)
+            buf, o_lz = self._w_head
+            src_head = buf[:o_lz + self.B * self.m]
+            snap, head = torch.empty_like(self.state_flat), torch.empty_like(src_head)
+            torch._foreach_copy_([snap, head], [self.state_flat, src_head])
+        else:
+            snap, head = self.state_flat.to(dtype, copy=True), None
         out = {k: snap[o:o + int(torch.Size(shp).numel())].view(shp) for k, o, shp in self._state_layout}
-        if self.fused and getattr(self, "_w_head", None) is not None:
+        if both:
             buf, o_lz = self._w_head
             B, m = self.B, self.m
-            head = buf[:o_lz + B * m].to(dtype, copy=True)
+            if head is None:
+                head = buf[:o_lz + B * m].to(dtype, copy=True)
             out["pm"] = head[:2 * B * m].view(B, m, 2)
             out["logzm"] = head[o_lz:o_lz + B * m].view(B, m)
         return out

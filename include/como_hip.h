@@ -609,6 +609,12 @@ int como_se3_normalize_f64(double* poses, int n, como_stream_t stream);
  * (get_aff_w_curr, como/geometry/affine_brightness.py:5-10).  T_curr_kf / aff_curr_kf: float32 (cur_is_f32, widened first) or float64. */
 int como_frame_world_f64(const double* T_w_kf, const void* T_curr_kf, const double* aff_w_kf, const void* aff_curr_kf, int cur_is_f32,
                          double* T_out, double* aff_out, como_stream_t stream);
+/* The record the host reads back of a tracked frame (Tracking.handle_frame, como/odom/Tracking.py:315-379: |t| of T_curr_kf and the
+ * reprojection statistics feed check_keyframe / check_one_way_frame, :117-161; poses as the reference keeps them), one launch:
+ * out[3 + levels + 34] = [|t| | median[0] | (float) nseen[0] | level_records[l * record_stride + 104] for every level |
+ * T_curr_kf (16) | aff_curr_kf (2) | T_w_curr = T_w_kf inv(T_curr_kf) (16), get_T_w_curr, como/geometry/transforms.py:6-8]. */
+int como_track_frame_record_f32(const float* T_curr_kf, const float* aff_curr_kf, const float* T_w_kf, const float* median, const int* nseen,
+                                const float* level_records, int levels, int record_stride, float* out, como_stream_t stream);
 int como_win_update_checked(const double* delta, double* poses, double* aff, const long* frame_inds, int F, double* P_m, int L,
                             long lm_start, const int* info, como_stream_t stream);
 /* invertSE3 (como/geometry/lie_algebra.py:83-95 without the Jacobian; the inverse inside get_T_w_curr / get_rel_pose,

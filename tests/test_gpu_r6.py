@@ -431,3 +431,35 @@ def test_network_on_the_side_stream_equals_the_inline_call():
     assert torch.equal(Mapping.take_model(ns, other), ns.run_model(other)) and ns._net_pending is None
     torch.cuda.synchronize()
     report("async_network", max_abs=float(want.abs().max()))
+
+
+def test_frame_record_kernel_equals_the_torch_chain():
+    """como_track_frame_record_f32 (the record the host reads back of a tracked frame: world pose, |t|, reprojection statistics,
+    level status words in one launch) against the chain it replaces in Tracking._frame_body -- composeSE3 mode 2, linalg.norm, two
+    casts, cat: poses and statistics bit for bit, |t| within one float32 ulp of torch's reduction (reported; it only feeds the
+    keyframe thresholds)."""
+    from como_amd import _lib
+    from como_amd.geometry.lie_algebra import composeSE3
+    from como_amd.synth import se3_exp
+    g = torch.Generator().manual_seed(11)
+    worst = 0.0
+    for trial in range(20):
+        T = se3_exp(0.3 * torch.randn((1, 6), generator=g, dtype=torch.float64)).float().to(DEV)
+        Tw = se3_exp(0.5 * torch.randn((1, 6), generator=g, dtype=torch.float64)).float().to(DEV)
+        aff = (0.1 * torch.randn((1, 2, 1), generator=g)).to(DEV)
+        nl = 3
+        recs = torch.randn((nl, 106), generator=g).to(DEV)
+        recs[:, 104] = torch.tensor([0.0, -1.0, -2.0])[:nl]
+        med3 = torch.rand((1, 3), generator=g).to(DEV)
+        nseen = torch.tensor([123456 + trial], dtype=torch.int32, device=DEV)
+        sc = torch.empty(3 + nl + 34, device=DEV)
+        _lib.check(_lib.lib().como_track_frame_record_f32(T.data_ptr(), aff.data_ptr(), Tw.data_ptr(), med3.data_ptr(), nseen.data_ptr(),
+                                                          recs.data_ptr(), nl, 106, sc.data_ptr(), _lib.stream_ptr(torch.device(DEV))), "record")
+        T_w = composeSE3(Tw, T, 2)
+        want = torch.cat((torch.linalg.norm(T[:, :3, 3]).reshape(1), med3[0, 0].reshape(1), nseen.float(), recs[:, 104], T.reshape(-1),
+                          aff.reshape(-1), T_w.reshape(-1)))
+        assert torch.equal(sc[1:], want[1:])
+        ulp = abs(float(sc[0]) - float(want[0])) / float(torch.finfo(torch.float32).eps * want[0].abs())
+        worst = max(worst, ulp)
+    report("frame_record", norm_worst_ulp=worst)
+    assert worst <= 1.0
