@@ -235,7 +235,7 @@ def git_sha():
         return None
 
 
-def committed_traffic(kernel_substr, summaries=("r5_bench_pmc_summary.json", "r4_bench_pmc_summary.json", "r3_bench_pmc_summary.json")):
+def committed_traffic(kernel_substr, summaries=("r6_bench_pmc_summary.json", "r5_bench_pmc_summary.json", "r4_bench_pmc_summary.json", "r3_bench_pmc_summary.json")):
     """HBM bytes per launch of a kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE doubled per the
     gfx950 note of guides/MI355X_MICROARCH.md, WRITE_SIZE as is).  NOT measured by this run: counters need rocprofv3
     around the process (scripts/collect_profiles.sh); the value is labelled with its source file."""

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void dense_ref_kernel(
     sel_lds_add(lh, sel_digit<KeyT>(abs_key(Zc), 0), inr);
   }
   __syncthreads();
-  sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
+  if (hists) sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
 }
 
 // float32 fast path: the (pixels x m) . (m x 7) product runs on the matrix cores straight out of the load registers.
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void dense_ref_mfma_kernel(
     }
   }
   __syncthreads();
-  sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
+  if (hists) sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
   if constexpr (FUSE) sel_flush(lh2, fz.rhists);
 }
 
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void depth_band_kernel(
     if ((threadIdx.x & 63) == 0 && mycand) atomicAdd(&ncand[b], mycand);
   }
   __syncthreads();
-  sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
+  if (hists) sel_flush(lh, hists + (long)b * 6 * SEL_BINS);
 }
 
 // ---- K~ --------------------------------------------------------------------------------------------------------
@@ -679,7 +679,9 @@ int dense_ref(const T* Kt, long kt_slot_stride, const int* pixidx, const T* logz
   else if (!Pwn || !dPwn_dTwc || (!uvec && !compact)) return COMO_ERR_ARG;
   uint32_t* hists = (uint32_t*)hists_v;
   if (!(flags & 4)) {
-  if (!(flags & 1) && !zero_words(hists, (size_t)B * 6 * SEL_BINS, s))
+  // flags & 64 (with flags & 2, points / depths only): nobody will ask for the median -- no histogram zero-fill, no flush
+  if ((flags & 64) && (flags & 2)) hists = nullptr;
+  if (hists && !(flags & 1) && !zero_words(hists, (size_t)B * 6 * SEL_BINS, s))
     return COMO_ERR_LAUNCH;
   int gx = (n + 255) / 256;
   if (gx > 512) gx = 512;

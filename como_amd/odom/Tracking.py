@@ -293,6 +293,11 @@ class Tracking:
                 self.cfg["color"] == "gray" and len(self.P_pyr) > 0 and self.P_pyr[-1].shape[0] == 1 and
                 not getattr(self, "_fg_disabled", False))
 
+    def copies_its_input(self, rgb):
+        """True when handle_frame will not keep a reference to `rgb` itself (the frame graph works on its own static copy and a
+        frame handed to the mapper is cloned): the caller need not clone the frame for the tracker."""
+        return self._frame_graph_applies(rgb) and getattr(self, "_fg", None) is not None and self._fg.get("graph") is not None
+
     def _frame_body(self, fg):
         img_pyr = self.prep_tracking_img(fg["rgb"])
         res = _pt.photo_tracking_levels_static(fg["T"], fg["aff"], fg["pb"], img_pyr, self.intrinsics_pyr, self.cfg["term_criteria"],

@@ -122,7 +122,7 @@ def depth_image(Kt, logzm, out=None, logz_out=None):
         lz = lz.to(dt).contiguous()
     rc = getattr(L, "como_dense_ref_" + _lib.suffix(dt))(
         Kt.data_ptr(), Kt.stride(0), None, lz.data_ptr(), w["eye"].data_ptr(), w["K"].data_ptr(), w["dl"].data_ptr(), B, rows, m, 1,
-        None, None, None, z.data_ptr(), _lib.ptr(logz_out), w["hists"].data_ptr(), w["med"].data_ptr(), None, 8 | 2, _lib.stream_ptr(dev))
+        None, None, None, z.data_ptr(), _lib.ptr(logz_out), w["hists"].data_ptr(), w["med"].data_ptr(), None, 8 | 2 | 64, _lib.stream_ptr(dev))
     _lib.check(rc, "como_dense_ref (depth image)")
     return z
 

@@ -67,7 +67,9 @@ class ComoSeq:
         if mp.is_init:
             # (the tracker gets its own copy of the frame: the conversion to its element type already is one -- a clone first only
             # when there is no conversion)
-            own = rgb if rgb.dtype != trk.dtype else rgb.clone()
+            # -- and not at all when the tracker runs its frame graph: that copies the frame into the graph's input buffer before
+            # anything else and clones it again if it hands the frame to the mapper)
+            own = rgb if (rgb.dtype != trk.dtype or trk.copies_its_input(rgb)) else rgb.clone()
             viz, to_map = trk.track(transfer_data((timestamp, own), trk.device, trk.dtype))
             self.timestamps.append(viz[0])
             self.est_poses.append(viz[1])

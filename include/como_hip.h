@@ -372,7 +372,9 @@ int como_greedy_persist_f32(float* coords_n, float* E_n, long* coord_vec_inds, c
  * (Pwn / dPwn_dTwc / uvec may be NULL): Mapping.store_vars' full-image median depth (Mapping.py:749-758), the value
  * the priors and the landmark re-initialisation use;
  * bit 4: compact -- dPwn_dTwc receives only the six planes (B,6,n) dlogz_n/dT_wc = K~[n,:] dlogz_m/dT_wc and uvec is not
- * written (may be NULL): what como_ba_args.zmode 2 consumes (9 planes written per pixel instead of 24). */
+ * written (may be NULL): what como_ba_args.zmode 2 consumes (9 planes written per pixel instead of 24);
+ * bit 6 (with bit 1): no median will be asked for -- the pass-0 histogram is neither cleared nor accumulated (the depth image the
+ * tracker's reference is rebuilt from on every frame, Mapping.get_kf_ref_data, Mapping.py:499-512). */
 int como_dense_ref_f32(const float* Kt, long kt_slot_stride, const int* pixidx, const float* logzm, const float* Twc,
                        const float* K, const float* dlogzm_dTwc, int B, int n, int m, int Wimg, float* Pwn,
                        float* dPwn_dTwc, float* uvec, float* zbuf, float* logzn_out, void* hists, float* med_out3,
