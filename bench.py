@@ -158,7 +158,9 @@ def odometry_loop(device, frames=100, seed=1, pix="float", warm=0, barrier=None,
         model = DepthCovModule({k: v.to(device) for k, v in synth.depthcov_state_dict(0).items()})
         odo = ComoSeq(loop_cfgs(G, pix, str(device), graph_network=True), K.clone(), (G["H"], G["W"]), model)
         from como_amd.odom import window_ba as _wba
-        spec0 = dict(_wba.SPEC_STATS)
+        import gc
+        gc.collect()                                        # (what an earlier leg / pass left behind is not this loop's garbage: a
+        spec0 = dict(_wba.SPEC_STATS)                       #  generation-2 collection of it cost one frame of the pass 4 ms)
         t0, k0, kinds, k_end = None, None, [], frames
         t_start = []
         k_init = None
@@ -620,11 +622,17 @@ def main():
         # and the network, pinned staging blocks, the allocator growing to the window's final sizes: ~0.1 s in total, e.g. 15-40 ms
         # on the frame at which the window first fills) -- `value` is the steady-state rate of the second pass, the first pass's
         # rate is reported beside it
+        # ... and the steady state is taken from THREE further passes (median): a single pass of 0.2 s is at the mercy of one host
+        # hiccup (a 20-130 ms stall in one frame was seen in about one pass of twenty on the test boxes); all rates are in the line
         first = odometry_loop(device)
-        legs["odometry_loop"] = odometry_loop(device)
+        steady = [odometry_loop(device) for _ in range(3)]
+        ok = sorted((r for r in steady if "value" in r), key=lambda r: r["value"])
+        legs["odometry_loop"] = ok[len(ok) // 2] if ok else steady[-1]
         if "value" in legs["odometry_loop"] and "value" in first:
             legs["odometry_loop"]["first_pass_frames_per_s"] = first["value"]
-            legs["odometry_loop"]["protocol"] = "second pass over the sequence in this process (first pass = first_pass_frames_per_s, incl. one-time captures / allocations)"
+            legs["odometry_loop"]["steady_passes_frames_per_s"] = [r.get("value") for r in steady]
+            legs["odometry_loop"]["protocol"] = ("median of three steady-state passes over the sequence in this process (steady_passes_frames_per_s) after a "
+                                                 "first pass that meets the one-time captures / allocations (first_pass_frames_per_s)")
         if "value" in legs["odometry_loop"]:
             flat["odometry_loop_frames_per_s"] = legs["odometry_loop"]["value"]
         if "value" in legs["tracking"]:

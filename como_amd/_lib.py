@@ -99,6 +99,7 @@ SIGNATURES = {
     "como_track_level_debug_mismatch": (None, [c_int]),
     "como_track_reference_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_float, c_float] + [c_void_p] * 4),
     "como_track_reference_f64": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_double, c_double] + [c_void_p] * 4),
+    "como_track_reference_pyr_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 7 + [c_float, c_float, c_void_p]),
     "como_reproject_depth_f32": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int] + [c_void_p] * 6),
     "como_reproject_depth_f64": (c_int, [c_void_p] * 3 + [c_long, c_int, c_int] + [c_void_p] * 6),
     "como_reproject_points_f32": (c_int, [c_void_p] * 4 + [c_long, c_int, c_int, c_int, c_float] + [c_void_p] * 4),

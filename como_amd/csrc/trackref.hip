@@ -63,6 +63,94 @@ __global__ __launch_bounds__(256) void track_reference_kernel(const T* __restric
   o[7] = T(1);
 }
 
+// The whole reference pyramid of the tracker in ONE launch (Tracking.update_kf_reference, Tracking.py:187-313, with
+// depth_interp_mode nearest_neighbor): rel_b = T_lastkf^-1 T_kf_b (se3_compose_kernel mode 1's arithmetic), the depth of level l at
+// (y, x) = the finest depth at (y << l, x << l) -- what l applications of pyr_depth's nearest-neighbour pooling (depth_pool2_kernel
+// mode 1: out(y, x) = in(2 y, 2 x)) leave -- and per pixel exactly what track_reference_kernel computes.  It replaces a pose
+// composition, levels - 1 pooling launches and `levels` reference launches: five dependent launches of >= 4.5 us behind every
+// mapping iteration of the sequential loop.
+struct TrackRefPyr {
+  const float* K[4];
+  const float* dI_dw[4];
+  const float* vals[4];
+  float* P[4];
+  uint8_t* mask[4];
+  float* J[4];
+  int h[4], w[4], shift[4];
+  unsigned block0[5];      // first block of every level (prefix sums)
+  int levels;
+};
+
+__global__ __launch_bounds__(256) void track_reference_pyr_kernel(const float* __restrict__ depth0, int W0, long hw0,
+                                                                  const float* __restrict__ poses, int nk, TrackRefPyr A, float border,
+                                                                  float depth_thresh) {
+  int l = 0;
+  while (l + 1 < A.levels && blockIdx.x >= A.block0[l + 1]) ++l;
+  const int h = A.h[l], w = A.w[l];
+  const long n = (long)h * w;
+  const long i = (long)(blockIdx.x - A.block0[l]) * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= n) return;
+  float M[12];
+  {
+#pragma clang fp contract(off)
+    const float* pa = poses + 16 * (long)(nk - 1);
+    const float* pb = poses + 16 * (long)b;
+    float a[12];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float s = pa[r] * pa[3];
+      s = s + pa[4 + r] * pa[7];
+      s = s + pa[8 + r] * pa[11];
+      a[4 * r + 0] = pa[r]; a[4 * r + 1] = pa[4 + r]; a[4 * r + 2] = pa[8 + r]; a[4 * r + 3] = -s;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float s = a[4 * r] * pb[c];
+        s = s + a[4 * r + 1] * pb[4 + c];
+        s = s + a[4 * r + 2] * pb[8 + c];
+        s = s + a[4 * r + 3] * pb[12 + c];
+        M[4 * r + c] = s;
+      }
+    }
+  }
+  const float* Kmat = A.K[l];
+  const float fx = Kmat[0], fy = Kmat[4], cx = Kmat[2], cy = Kmat[5];
+  const long bi = (long)b * n + i;
+  const int x = (int)(i % w), y = (int)(i / w);
+  const float z = depth0[(long)b * hw0 + ((long)y << A.shift[l]) * W0 + ((long)x << A.shift[l])];
+  float X, Y, Z, u, v;
+  {
+#pragma clang fp contract(off)
+    const float rx = (float(x) - cx) / fx;
+    const float ry = (float(y) - cy) / fy;
+    const float px = z * rx, py = z * ry, pz = z * 1.0f;
+    X = ((px * M[0] + py * M[1]) + pz * M[2]) + M[3];
+    Y = ((px * M[4] + py * M[5]) + pz * M[6]) + M[7];
+    Z = ((px * M[8] + py * M[9]) + pz * M[10]) + M[11];
+    u = fx * X / Z + cx;
+    v = fy * Y / Z + cy;
+  }
+  float* P_out = A.P[l];
+  P_out[3 * bi] = X; P_out[3 * bi + 1] = Y; P_out[3 * bi + 2] = Z;
+  const bool ok = (u >= -border) && (u <= float(w - 1) + border) && (v >= -border) && (v <= float(h - 1) + border) && (Z > depth_thresh);
+  A.mask[l][bi] = ok ? 1 : 0;
+  const float gx = A.dI_dw[l][2 * bi], gy = A.dI_dw[l][2 * bi + 1];
+  const float a_ = gx * (fx / Z), bb = gy * (fy / Z);
+  const float c_ = gx * (-(fx * X / Z) / Z) + gy * (-(fy * Y / Z) / Z);
+  float* o = A.J[l] + 8 * bi;
+  o[0] = bb * (-Z) + c_ * Y;
+  o[1] = a_ * Z + c_ * (-X);
+  o[2] = a_ * (-Y) + bb * X;
+  o[3] = a_;
+  o[4] = bb;
+  o[5] = c_;
+  o[6] = A.vals[l][bi];
+  o[7] = 1.0f;
+}
+
 // pass 1: every point that projects strictly inside the image with positive depth claims its (truncated) pixel with its index
 template <typename T>
 __global__ __launch_bounds__(256) void reproject_claim_kernel(const T* __restrict__ Tck, const T* __restrict__ Kmat,
@@ -185,6 +273,33 @@ extern "C" {
   }
 COMO_DEF_TRACKREF(f32, float)
 COMO_DEF_TRACKREF(f64, double)
+
+int como_track_reference_pyr_f32(const float* depth0, int H0, int W0, const float* kf_poses, int nk, int levels, const int* hw,
+                                 const float* const* K, const float* const* dI_dw, const float* const* vals, float* const* P_out,
+                                 uint8_t* const* mask_out, float* const* J_out, float border, float depth_thresh, como_stream_t stream) {
+  if (!depth0 || !kf_poses || !hw || !K || !dI_dw || !vals || !P_out || !mask_out || !J_out || nk <= 0 || levels < 1 || levels > 4 ||
+      H0 <= 0 || W0 <= 0)
+    return COMO_ERR_ARG;
+  como::TrackRefPyr A;
+  A.levels = levels;
+  unsigned blocks = 0;
+  for (int l = 0; l < levels; ++l) {
+    // levels come coarse -> fine (DepthPyramidModule's order): level l is the finest depth pooled levels - 1 - l times
+    const int sh = levels - 1 - l;
+    int h = H0, w = W0;
+    for (int k = 0; k < sh; ++k) { h = (h + 1) / 2; w = (w + 1) / 2; }
+    if (hw[2 * l] != h || hw[2 * l + 1] != w || !K[l] || !dI_dw[l] || !vals[l] || !P_out[l] || !mask_out[l] || !J_out[l]) return COMO_ERR_ARG;
+    A.K[l] = K[l]; A.dI_dw[l] = dI_dw[l]; A.vals[l] = vals[l]; A.P[l] = P_out[l]; A.mask[l] = mask_out[l]; A.J[l] = J_out[l];
+    A.h[l] = h; A.w[l] = w; A.shift[l] = sh;
+    A.block0[l] = blocks;
+    blocks += (unsigned)(((long)h * w + 255) / 256);
+  }
+  A.block0[levels] = blocks;
+  hipLaunchKernelGGL(como::track_reference_pyr_kernel, dim3(blocks, nk), dim3(256), 0, (hipStream_t)stream, depth0, W0, (long)H0 * W0,
+                     kf_poses, nk, A, border, depth_thresh);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
 
 #define COMO_DEF_REPROJ_POINTS(SFX, T)                                                                                          \
   int como_reproject_points_##SFX(const T* coords, const T* z, const T* Tji, const T* K, long n, int wgrid, int h, int w,         \

@@ -50,6 +50,7 @@ def _in_image(p, depth, img_size, border, depth_thresh, strict):
     return ok & (depth[..., 0] > depth_thresh)
 
 
+_PYR_REFERENCE = os.environ.get("COMO_TRACK_PYR_REFERENCE", "1") != "0"    # 0: pose composition + depth pyramid + one reference launch per level (A/B)
 _FRAME_RECORD = os.environ.get("COMO_TRACK_FRAME_RECORD", "1") != "0"      # 0: the frame's record by pose composition + norm + casts + cat (A/B)
 _FOREACH_INPUTS = os.environ.get("COMO_TRACK_FOREACH_INPUTS", "1") != "0"   # 0: one copy launch per input of the frame graph (A/B)
 _DIRECT_REF = os.environ.get("COMO_TRACK_DIRECT_REF", "1") != "0"     # (read once: an os.environ look-up costs ~25 us, this ran per frame)
@@ -199,16 +200,15 @@ class Tracking:
                 self.coords_pyr.append(get_test_coords((h, w), device=self.device, batch_size=b))
 
         self.P_pyr, self.dI_dT_pyr, self.mask_pyr = [], [], []
-        rel = composeSE3(kf_pose[nk - 1:nk], kf_pose, 1)    # every keyframe -> the last keyframe's frame
-        depth_pyr = self.depth_pyr_module(depth)
         pb = None
         if (depth.is_cuda and self.vals_pyr[0].shape[2] == 1 and depth.dtype == self.vals_pyr[0].dtype and
                 _DIRECT_REF):
             # this tracker's own persistent reference buffers (the level kernels and the captured frame graph read them): the
             # reference kernels below write straight into them -- no per-update allocations, no copies before the next frame
-            key = (nk, depth.dtype, tuple(tuple(d.shape[-2:]) for d in depth_pyr))
+            sizes = self._depth_pyramid_sizes(tuple(depth.shape[-2:]))
+            key = (nk, depth.dtype, sizes)
             if getattr(self, "_pb_key", None) != key:
-                self._pb = _pt._PyrBuffers.from_shapes(nk, 1, [tuple(d.shape[-2:]) for d in depth_pyr], depth.device, depth.dtype)
+                self._pb = _pt._PyrBuffers.from_shapes(nk, 1, list(sizes), depth.device, depth.dtype)
                 self._pb_key, self._pb_vals_ts = key, None
             pb = self._pb
             if self._pb_vals_ts != timestamps[-1]:          # the keyframe image(s) changed
@@ -216,6 +216,13 @@ class Tracking:
                     c["vals"].copy_(self.vals_pyr[i].reshape(c["vals"].shape))
                     self.vals_pyr[i] = c["vals"].view(self.vals_pyr[i].shape)
                 self._pb_vals_ts = timestamps[-1]
+        if self._reference_pyramid_in_one_launch(kf_pose, depth, pb):
+            self.kf_received_ts = timestamps[-1]
+            self.T_w_kf = kf_pose[nk - 1:nk]
+            self.aff_w_kf = kf_aff[nk - 1:nk]
+            return
+        rel = composeSE3(kf_pose[nk - 1:nk], kf_pose, 1)    # every keyframe -> the last keyframe's frame
+        depth_pyr = self.depth_pyr_module(depth)
         for i, d in enumerate(depth_pyr):
             coords = self.coords_pyr[i]
             b, _, h, w = d.shape
@@ -248,6 +255,56 @@ class Tracking:
         self.kf_received_ts = timestamps[-1]
         self.T_w_kf = kf_pose[nk - 1:nk]
         self.aff_w_kf = kf_aff[nk - 1:nk]
+
+    def _depth_pyramid_sizes(self, hw):
+        """Sizes (h, w) of `depth_pyr_module`'s levels, coarse -> fine, for a finest depth image of size hw (pyr_depth with
+        kernel_size 2: nearest_neighbor keeps (n + 1) // 2 samples, the pooling modes n // 2)."""
+        lo, hi = self.cfg["pyr"]["start_level"], self.cfg["pyr"]["end_level"]
+        nn = self.cfg["pyr"]["depth_interp_mode"] == "nearest_neighbor"
+        out, (h, w) = [], hw
+        for i in range(hi - 1):
+            if i >= lo:
+                out.insert(0, (h, w))
+            h, w = ((h + 1) // 2, (w + 1) // 2) if nn else (h // 2, w // 2)
+        out.insert(0, (h, w))
+        return tuple(out)
+
+    def _reference_pyramid_in_one_launch(self, kf_pose, depth, pb):
+        """The reference arrays of every pyramid level -- points in the last keyframe's frame, projection masks, Jacobians --
+        straight from the finest depth image and the keyframe poses in ONE launch (csrc/trackref.hip track_reference_pyr_kernel:
+        pose composition, nearest-neighbour depth pyramid and the per-level reference kernels of the loop below).  Applies to the
+        tracker's own persistent buffers, gray float32 frames, `depth_interp_mode: nearest_neighbor`, start_level 0, <= 4 levels."""
+        import ctypes
+        pyr = self.cfg["pyr"]
+        nl = len(self.vals_pyr)
+        if not (_PYR_REFERENCE and pb is not None and depth.is_cuda and depth.dtype == torch.float32 and kf_pose.dtype == torch.float32 and
+                pyr["depth_interp_mode"] == "nearest_neighbor" and pyr["start_level"] == 0 and 1 <= nl <= 4 and len(pb.levels) == nl and
+                depth.dim() == 4 and depth.shape[1] == 1 and all(v.shape[2] == 1 for v in self.vals_pyr)):
+            return False
+        nk, _, H0, W0 = depth.shape
+        sizes = self._depth_pyramid_sizes((H0, W0))
+        if len(sizes) != nl or any(self.vals_pyr[i].shape[1] != h * w for i, (h, w) in enumerate(sizes)):
+            return False
+        dt, dev = depth.dtype, depth.device
+        grads = [g if (g.dtype == dt and g.is_contiguous()) else g.to(dt).contiguous() for g in self.img_grads_pyr]
+        Ks = [k if (k.dtype == dt and k.is_contiguous()) else k.to(dt).contiguous() for k in self.intrinsics_pyr]
+        vals = [pb.levels[i]["vals"] for i in range(nl)]
+        if any(self.vals_pyr[i].data_ptr() != vals[i].data_ptr() for i in range(nl)):
+            return False
+        arr = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])
+        hw = (ctypes.c_int * (2 * nl))(*[x for s in sizes for x in s])
+        d0, kp = depth.contiguous(), kf_pose.contiguous()
+        _lib.check(_lib.lib().como_track_reference_pyr_f32(
+            d0.data_ptr(), H0, W0, kp.data_ptr(), nk, nl, hw, arr(Ks), arr(grads), arr(vals), arr([c["P"] for c in pb.levels]),
+            arr([c["mask"] for c in pb.levels]), arr([c["dI"] for c in pb.levels]), 50.0, 1e-4, _lib.stream_ptr(dev)),
+            "como_track_reference_pyr_f32")
+        self.P_pyr, self.dI_dT_pyr, self.mask_pyr = [], [], []
+        for i, (h, w) in enumerate(sizes):
+            c = pb.levels[i]
+            self.P_pyr.append(c["P"].view(nk, h * w, 3))
+            self.dI_dT_pyr.append(c["dI"].view(nk, h * w, 1, 8))
+            self.mask_pyr.append(c["mask"].view(nk, h * w).view(torch.bool))
+        return True
 
     # ---- the same two tests on host scalars (one read-back per frame instead of four synchronising bool()s) ----------------
     def decide_frame(self, norm_t, median_depth, num_reproj_depth, T_w_curr):

@@ -132,6 +132,15 @@ int como_track_reference_f32(const float* depth, const float* rel, const float* 
 int como_track_reference_f64(const double* depth, const double* rel, const double* K, const double* dI_dw, const double* vals,
                              int b, int h, int w, double border, double depth_thresh, double* P_out, uint8_t* mask_out,
                              double* J_out, como_stream_t stream);
+/* The tracker's whole reference pyramid in one launch (Tracking.update_kf_reference, como/odom/Tracking.py:187-313, with
+ * pyr.depth_interp_mode nearest_neighbor, como/data/depth_resize.py:6-36): depth0 (nk,H0,W0) the finest depth images, kf_poses
+ * (nk,4,4) world poses of the reference keyframes (the LAST one is the frame the points are expressed in: rel_b = T_last^-1 T_b);
+ * levels <= 4 pyramid levels COARSE -> FINE, hw[2 l], hw[2 l + 1] their sizes (= the finest size pooled levels - 1 - l times:
+ * checked), per level (host arrays of device pointers) K (3,3), dI_dw (nk,n,1,2), vals (nk,n,1) and the outputs P (nk,n,3),
+ * mask (nk,n), J (nk,n,1,8) -- per pixel what como_track_reference_f32 writes. */
+int como_track_reference_pyr_f32(const float* depth0, int H0, int W0, const float* kf_poses, int nk, int levels, const int* hw,
+                                 const float* const* K, const float* const* dI_dw, const float* const* vals, float* const* P_out,
+                                 uint8_t* const* mask_out, float* const* J_out, float border, float depth_thresh, como_stream_t stream);
 int como_reproject_depth_f32(const float* Tck, const float* K, const float* P, long n, int h, int w, void* order_ws, float* zbuf,
                              float* img, uint8_t* seen, int* nseen, como_stream_t stream);
 int como_reproject_depth_f64(const double* Tck, const double* K, const double* P, long n, int h, int w, void* order_ws,

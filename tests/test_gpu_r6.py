@@ -463,3 +463,53 @@ def test_frame_record_kernel_equals_the_torch_chain():
         worst = max(worst, ulp)
     report("frame_record", norm_worst_ulp=worst)
     assert worst <= 1.0
+
+
+def test_reference_pyramid_in_one_launch_equals_the_per_level_chain():
+    """como_track_reference_pyr_f32 (pose composition + nearest-neighbour depth pyramid + the reference arrays of every level in one
+    launch) against the chain it replaces in Tracking.update_kf_reference -- composeSE3 mode 1, pyr_depth, one
+    como_track_reference_f32 per level: points, masks, Jacobians bit for bit; two reference keyframes, odd image sizes."""
+    import ctypes
+    from como_amd import _lib
+    from como_amd.geometry.lie_algebra import composeSE3, se3_exp
+    from como_amd.utils.image_processing import pyr_depth
+    g = torch.Generator().manual_seed(3)
+    for (H0, W0, nl, nk) in ((48, 64, 3, 1), (51, 67, 3, 2), (30, 40, 2, 2), (24, 32, 4, 1)):
+        depth = (0.5 + torch.rand((nk, 1, H0, W0), generator=g)).to(DEV)
+        poses = se3_exp(0.2 * torch.randn((nk, 6), generator=g, dtype=torch.float64)).float().to(DEV)
+        dpyr, lvl = [], depth
+        for i in range(nl - 1):
+            dpyr.insert(0, lvl)
+            lvl = pyr_depth(lvl, "nearest_neighbor", kernel_size=2)
+        dpyr.insert(0, lvl)
+        rel = composeSE3(poses[nk - 1:nk], poses, 1).contiguous()
+        Ks, grads, vals, want, got = [], [], [], [], []
+        for i, d in enumerate(dpyr):
+            h, w = d.shape[-2:]
+            sc = 2.0 ** (nl - 1 - i)
+            K = torch.tensor([[500.0 / sc, 0, W0 / 2 / sc], [0, 480.0 / sc, H0 / 2 / sc], [0, 0, 1]], device=DEV)
+            gr = torch.randn((nk, h * w, 1, 2), generator=g).to(DEV)
+            va = torch.rand((nk, h * w, 1), generator=g).to(DEV)
+            P = torch.empty((nk, h * w, 3), device=DEV)
+            M = torch.empty((nk, h * w), dtype=torch.uint8, device=DEV)
+            J = torch.empty((nk, h * w, 1, 8), device=DEV)
+            _lib.check(_lib.lib().como_track_reference_f32(d.contiguous().data_ptr(), rel.data_ptr(), K.data_ptr(), gr.data_ptr(), va.data_ptr(),
+                                                           nk, h, w, 50.0, 1e-4, P.data_ptr(), M.data_ptr(), J.data_ptr(),
+                                                           _lib.stream_ptr(torch.device(DEV))), "ref")
+            Ks.append(K); grads.append(gr); vals.append(va); want.append((P, M, J))
+            got.append((torch.empty_like(P), torch.empty_like(M), torch.empty_like(J)))
+        arr = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])
+        hw = (ctypes.c_int * (2 * nl))(*[x for d in dpyr for x in d.shape[-2:]])
+        _lib.check(_lib.lib().como_track_reference_pyr_f32(depth.data_ptr(), H0, W0, poses.contiguous().data_ptr(), nk, nl, hw, arr(Ks), arr(grads),
+                                                           arr(vals), arr([t[0] for t in got]), arr([t[1] for t in got]), arr([t[2] for t in got]),
+                                                           50.0, 1e-4, _lib.stream_ptr(torch.device(DEV))), "pyr")
+        torch.cuda.synchronize()
+        for (P, M, J), (P2, M2, J2) in zip(want, got):
+            assert torch.equal(P, P2) and torch.equal(M, M2) and torch.equal(J, J2)
+        assert int(sum(int(t[1].sum()) for t in got)) > 0
+    # a size that is not the finest size pooled: refused
+    bad = (ctypes.c_int * (2 * nl))(*([1, 1] * nl))
+    assert _lib.lib().como_track_reference_pyr_f32(depth.data_ptr(), H0, W0, poses.data_ptr(), nk, nl, bad, arr(Ks), arr(grads), arr(vals),
+                                                   arr([t[0] for t in got]), arr([t[1] for t in got]), arr([t[2] for t in got]), 50.0, 1e-4,
+                                                   _lib.stream_ptr(torch.device(DEV))) != 0
+    report("reference_pyramid", cases=4)
