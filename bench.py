@@ -194,7 +194,7 @@ def odometry_loop(device, frames=100, seed=1, pix="float", warm=0, barrier=None,
         by_req = {}
         for j in range(k0, len(kinds)):
             by_req.setdefault(str(kinds[j]), []).append(1e3 * (t_start[j + 1] - t_start[j]))
-        frame_ms = {r: {"mean_ms": sum(v) / len(v), "frames": len(v)} for r, v in by_req.items()}
+        frame_ms = {r: {"mean_ms": sum(v) / len(v), "median_ms": sorted(v)[len(v) // 2], "frames": len(v)} for r, v in by_req.items()}
         if timed_frames is not None and n != timed_frames:
             return {"error": f"only {n} of {timed_frames} frames could be timed (initialisation at frame {k_init})"}
         from como_amd.odom.frontend.photo_tracking import photo_tracking_pyr

@@ -93,8 +93,14 @@ SIGNATURES = {
                                               c_float, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "como_track_level_local_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_int, c_float,
                                            c_float, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "como_track_level_prezeroed_f32": (c_int, [c_void_p] * 6 + [c_int, c_int, c_long, c_int, c_void_p, c_void_p, c_int, c_float,
+                                               c_float, c_float, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "como_track_level_zero_bytes": (c_long, []),
+    "como_track_frame_pyramid3_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "como_track_level_probe": (c_int, []),
     "como_track_level_set_local": (c_int, [c_int]),
+    "como_track_level_set_split": (c_int, [c_int]),
+    "como_track_level_debug_amb_cap": (None, [c_int]),
     "como_track_level_local_state": (c_int, []),
     "como_track_level_debug_mismatch": (None, [c_int]),
     "como_track_reference_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_float, c_float] + [c_void_p] * 4),
@@ -186,6 +192,8 @@ SIGNATURES = {
     "como_track_precalc_jac_f64": (c_int, [c_void_p] * 5 + [c_long, c_void_p]),
     "como_win_scaffold": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
     "como_win_priors": (c_int, [ctypes.POINTER(WinArgs), c_void_p]),
+    "como_win_logz_ahead_scratch_bytes": (c_long, [c_int, c_int, c_int, c_int]),
+    "como_win_logz_ahead": (c_int, [ctypes.POINTER(WinArgs), c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p]),
     "como_win_update": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_long, c_void_p]),
     "como_se3_normalize_f32": (c_int, [c_void_p, c_int, c_void_p]),
     "como_se3_normalize_f64": (c_int, [c_void_p, c_int, c_void_p]),

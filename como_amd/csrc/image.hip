@@ -92,6 +92,12 @@ __global__ __launch_bounds__(256) void frame_stack_kernel(const TIN* __restrict_
 }
 
 // out (NC, ceil(H/2), ceil(W/2)) = blur(img)[0::2, 0::2]
+// the [1 2 1]^2 / 16 stencil value (ONE definition: blur_down_kernel and the fused frame pyramid must round alike)
+template <typename T>
+__device__ __forceinline__ T blur9(T tl, T tc, T tr, T ml, T mc, T mr, T bl, T bc, T br) {
+  const T k1 = T(1) / T(16), k2 = T(2) / T(16), k4 = T(4) / T(16);
+  return k1 * (tl + tr + bl + br) + k2 * (tc + ml + mr + bc) + k4 * mc;
+}
 template <typename T>
 __global__ __launch_bounds__(256) void blur_down_kernel(const T* __restrict__ img, T* __restrict__ out, int H, int W, int Ho,
                                                         int Wo, long total) {
@@ -102,9 +108,55 @@ __global__ __launch_bounds__(256) void blur_down_kernel(const T* __restrict__ im
   const T* p = img + nc * H * W;
   const int x = 2 * xo, y = 2 * yo;
   const int xm = reflect1(x - 1, W), xp = reflect1(x + 1, W), ym = reflect1(y - 1, H), yp = reflect1(y + 1, H);
-  const T k1 = T(1) / T(16), k2 = T(2) / T(16), k4 = T(4) / T(16);
-  out[i] = k1 * (p[(long)ym * W + xm] + p[(long)ym * W + xp] + p[(long)yp * W + xm] + p[(long)yp * W + xp]) +
-           k2 * (p[(long)ym * W + x] + p[(long)y * W + xm] + p[(long)y * W + xp] + p[(long)yp * W + x]) + k4 * p[(long)y * W + x];
+  out[i] = blur9<T>(p[(long)ym * W + xm], p[(long)ym * W + x], p[(long)ym * W + xp], p[(long)y * W + xm], p[(long)y * W + x],
+                    p[(long)y * W + xp], p[(long)yp * W + xm], p[(long)yp * W + x], p[(long)yp * W + xp]);
+}
+
+// The tracker's image pyramid of ONE colour frame in one launch (Tracking.prep_tracking_img, como/odom/Tracking.py:103-107:
+// rgb_to_grayscale + ImagePyramidModule with three levels): gray (H,W), level 1 = blur_down(gray), level 2 = blur_down(level 1).
+// One thread per level-1 pixel: it writes its 2x2 block of luma values, its own level-1 value, and -- where both coordinates are even
+// -- the level-2 value, re-evaluating the level-1 neighbours (and the luma values under them) it needs instead of waiting for the
+// threads that own them: the same expressions on the same inputs (rgb_luma / blur9) give the same bits wherever they are evaluated,
+// so the three images equal the three-launch chain's (tested).  The frame graph's head was three dependent launches of ~4.7 us for
+// ~1 us of work; `z` clears up to eight small buffers in the same launch (the level kernels' barrier workspaces and the select
+// histograms of the frame: four more launches).
+struct ZeroList { uint4* p[8]; long n16[8]; int n; };
+__device__ __forceinline__ float rgb_luma(const float* __restrict__ rgb, long HW, long q) {
+#pragma clang fp contract(off)
+  const float r = rgb[q], g = rgb[HW + q], b = rgb[2 * HW + q];
+  const float s = 0.2989f * r + 0.587f * g;
+  return s + 0.114f * b;
+}
+__global__ __launch_bounds__(256) void frame_pyramid3_kernel(const float* __restrict__ rgb, float* __restrict__ gray,
+                                                             float* __restrict__ l1, float* __restrict__ l2, int H, int W, ZeroList z) {
+  const long gtid = (long)blockIdx.x * 256 + threadIdx.x, gsz = (long)gridDim.x * 256;
+  for (int k = 0; k < z.n; ++k)
+    for (long e = gtid; e < z.n16[k]; e += gsz) z.p[k][e] = make_uint4(0u, 0u, 0u, 0u);
+  const int H1 = (H + 1) / 2, W1 = (W + 1) / 2, H2 = (H1 + 1) / 2, W2 = (W1 + 1) / 2;
+  if (gtid >= (long)H1 * W1) return;
+  const long HW = (long)H * W;
+  const int x1 = (int)(gtid % W1), y1 = (int)(gtid / W1);
+  // level-1 value at (xx, yy) from the luma values around (2 xx, 2 yy)
+  auto lvl1 = [&](int xx, int yy) -> float {
+    const int x = 2 * xx, y = 2 * yy;
+    const int xm = reflect1(x - 1, W), xp = reflect1(x + 1, W), ym = reflect1(y - 1, H), yp = reflect1(y + 1, H);
+    return blur9<float>(rgb_luma(rgb, HW, (long)ym * W + xm), rgb_luma(rgb, HW, (long)ym * W + x), rgb_luma(rgb, HW, (long)ym * W + xp),
+                        rgb_luma(rgb, HW, (long)y * W + xm), rgb_luma(rgb, HW, (long)y * W + x), rgb_luma(rgb, HW, (long)y * W + xp),
+                        rgb_luma(rgb, HW, (long)yp * W + xm), rgb_luma(rgb, HW, (long)yp * W + x), rgb_luma(rgb, HW, (long)yp * W + xp));
+  };
+#pragma unroll
+  for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 2; ++dx) {
+      const int x = 2 * x1 + dx, y = 2 * y1 + dy;
+      if (x < W && y < H) gray[(long)y * W + x] = rgb_luma(rgb, HW, (long)y * W + x);
+    }
+  l1[(long)y1 * W1 + x1] = lvl1(x1, y1);
+  if (!(x1 & 1) && !(y1 & 1)) {
+    const int xm = reflect1(x1 - 1, W1), xp = reflect1(x1 + 1, W1), ym = reflect1(y1 - 1, H1), yp = reflect1(y1 + 1, H1);
+    l2[(long)(y1 >> 1) * W2 + (x1 >> 1)] = blur9<float>(lvl1(xm, ym), lvl1(x1, ym), lvl1(xp, ym), lvl1(xm, y1), lvl1(x1, y1), lvl1(xp, y1),
+                                                        lvl1(xm, yp), lvl1(x1, yp), lvl1(xp, yp));
+  }
 }
 
 
@@ -285,6 +337,36 @@ int como_frame_stack_f64(const void* rgb, int rgb_is_f32, int H, int W, double* 
     hipLaunchKernelGGL(como::frame_stack_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)rgb, stack, stack_pix, H, W);
   else
     hipLaunchKernelGGL(como::frame_stack_kernel<double>, grid, blk, 0, (hipStream_t)stream, (const double*)rgb, stack, stack_pix, H, W);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
+
+/* The tracker's three-level image pyramid of one colour frame (3,H,W) in one launch -- gray (H,W), l1 (ceil(H/2),ceil(W/2)), l2 (half of
+ * that again): bit-identical to como_rgb_to_gray_f32 + 2 x como_img_blur_down_f32.  zero_ptrs / zero_bytes (n_zero <= 8, 16-byte
+ * aligned, multiples of 16 bytes): buffers cleared in the same launch. */
+int como_track_frame_pyramid3_f32(const float* rgb, float* gray, float* l1, float* l2, int H, int W, void* const* zero_ptrs,
+                                  const long* zero_bytes, int n_zero, como_stream_t stream) {
+  if (!rgb || !gray || !l1 || !l2 || H < 4 || W < 4 || n_zero < 0 || n_zero > 8 || (n_zero && (!zero_ptrs || !zero_bytes)))
+    return COMO_ERR_ARG;
+  como::ZeroList z;
+  z.n = n_zero;
+  long most = 0;
+  for (int k = 0; k < 8; ++k) {
+    z.p[k] = nullptr; z.n16[k] = 0;
+    if (k < n_zero) {
+      if (!zero_ptrs[k] || ((uintptr_t)zero_ptrs[k] & 15) || zero_bytes[k] < 0 || (zero_bytes[k] & 15)) return COMO_ERR_ARG;
+      z.p[k] = (uint4*)zero_ptrs[k];
+      z.n16[k] = zero_bytes[k] / 16;
+      if (z.n16[k] > most) most = z.n16[k];
+    }
+  }
+  const long n1 = (long)((H + 1) / 2) * ((W + 1) / 2);
+  long threads = n1 > most ? n1 : most;
+  if (threads > 1L << 22) threads = 1L << 22;                // (the clears are grid-stride loops)
+  if (threads < n1) threads = n1;
+  hipLaunchKernelGGL(como::frame_pyramid3_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rgb, gray, l1,
+                     l2, H, W, z);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }

@@ -140,6 +140,80 @@ __global__ __launch_bounds__(256) void track_reduce_kernel(const T* __restrict__
         ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+// The 8x8 solve + pose update of one tracking iteration (photo_tracking.py:96-114: cholesky_ex / cholesky_solve, T <- T Exp(-delta)),
+// float64, ONE definition for the per-iteration chain (track_finish_kernel) and the persistent level kernel -- both run it on one
+// lane, on the critical path of every iteration.  The factorisation keeps 1 / L_jj (one v_rsq_f64-based reciprocal square root per
+// column) and multiplies by it: 8 of them instead of 8 square roots + 52 divisions (~30 dependent instructions each), 3.0 -> 1.3 us.
+// info as torch.linalg.cholesky_ex: 0, or the 1-based column of the first non-positive pivot.
+struct TrkSolve { double d[8], Tn[16], gn, dn; int info; };
+// index of H[a][b] (a <= b) in the 36 upper-triangle sums
+__device__ __forceinline__ constexpr int trk_q(int a, int b) { return a * 8 - a * (a - 1) / 2 + (b - a); }
+template <typename T>
+__device__ inline void trk_solve8(const double* __restrict__ tot, const T* __restrict__ Tcur, TrkSolve& S) {
+  double L[36], rd[8], y[8];          // lower triangle, row-major packed: L[i][j] at i (i + 1) / 2 + j
+  double gn = 0;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) gn += tot[36 + a] * tot[36 + a];
+  S.gn = gn;
+  int info = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    double s = tot[trk_q(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j * (j + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+    if (!(s > 0) && info == 0) info = j + 1;
+    const double r = rsqrt(s);
+    rd[j] = r;
+#pragma unroll
+    for (int i = j + 1; i < 8; ++i) {
+      double t = tot[trk_q(j, i)];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i * (i + 1) / 2 + k] * L[j * (j + 1) / 2 + k];
+      L[i * (i + 1) / 2 + j] = t * r;
+    }
+  }
+  S.info = info;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    double t = tot[36 + i];
+#pragma unroll
+    for (int k = 0; k < i; ++k) t -= L[i * (i + 1) / 2 + k] * y[k];
+    y[i] = t * rd[i];
+  }
+#pragma unroll
+  for (int i = 7; i >= 0; --i) {
+    double t = y[i];
+#pragma unroll
+    for (int k = i + 1; k < 8; ++k) t -= L[k * (k + 1) / 2 + i] * S.d[k];
+    S.d[i] = t * rd[i];
+  }
+  double xi[6], E[16], dn = 0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) xi[i] = -S.d[i];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dn += S.d[i] * S.d[i];
+  S.dn = dn;
+  se3_exp_f64(xi, E);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double t = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) t += (double)Tcur[i * 4 + k] * E[k * 4 + j];
+      S.Tn[i * 4 + j] = t;
+    }
+  }
+}
+// H (8x8, symmetric) and g of an iteration's record from the 46 sums
+template <typename T>
+__device__ inline void trk_store_Hg(const double* __restrict__ tot, T* __restrict__ out) {
+  int q = 0;
+  for (int a = 0; a < 8; ++a)
+    for (int b = a; b < 8; ++b) { const T v = (T)tot[q++]; out[a * 8 + b] = v; out[b * 8 + a] = v; }
+  for (int a = 0; a < 8; ++a) out[64 + a] = (T)tot[36 + a];
+}
+
 // out layout (T): [0:64) H | [64:72) g | [72:80) delta | [80:96) T_new | [96:98) aff_new |
 //                 98 mse | 99 grad_norm | 100 total_err | 101 sigma | 102 nvalid | 103 delta_norm | 104 chol_info
 template <typename T>
@@ -175,51 +249,20 @@ __global__ __launch_bounds__(256) void track_finish_kernel(const double* __restr
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double Hm[64], g[8], L[64], y[8], d[8];
-    int q = 0;
-    for (int a = 0; a < 8; ++a)
-      for (int b = a; b < 8; ++b) { Hm[a * 8 + b] = tot[q]; Hm[b * 8 + a] = tot[q]; ++q; }
-    double gn = 0;
-    for (int a = 0; a < 8; ++a) { g[a] = tot[36 + a]; gn += g[a] * g[a]; }
-    // Cholesky (lower), errors reported not raised (cholesky_ex(check_errors=False), photo_tracking.py:97)
-    int info = 0;
-    for (int i = 0; i < 64; ++i) L[i] = 0;
-    for (int j = 0; j < 8; ++j) {
-      double s = Hm[j * 8 + j];
-      for (int k = 0; k < j; ++k) s -= L[j * 8 + k] * L[j * 8 + k];
-      if (!(s > 0) && info == 0) info = j + 1;
-      const double dj = sqrt(s);
-      L[j * 8 + j] = dj;
-      for (int i = j + 1; i < 8; ++i) {
-        double t = Hm[i * 8 + j];
-        for (int k = 0; k < j; ++k) t -= L[i * 8 + k] * L[j * 8 + k];
-        L[i * 8 + j] = t / dj;
-      }
-    }
-    for (int i = 0; i < 8; ++i) { double t = g[i]; for (int k = 0; k < i; ++k) t -= L[i * 8 + k] * y[k]; y[i] = t / L[i * 8 + i]; }
-    for (int i = 7; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < 8; ++k) t -= L[k * 8 + i] * d[k]; d[i] = t / L[i * 8 + i]; }
-    double xi[6], E[16], Tn[16], dn = 0;
-    for (int i = 0; i < 6; ++i) xi[i] = -d[i];
-    for (int i = 0; i < 8; ++i) dn += d[i] * d[i];
-    se3_exp_f64(xi, E);
-    for (int i = 0; i < 4; ++i)
-      for (int j = 0; j < 4; ++j) {
-        double t = 0;
-        for (int k = 0; k < 4; ++k) t += (double)Tji[i * 4 + k] * E[k * 4 + j];
-        Tn[i * 4 + j] = t;
-      }
-    for (int i = 0; i < 64; ++i) out[i] = (T)Hm[i];
-    for (int i = 0; i < 8; ++i) { out[64 + i] = (T)g[i]; out[72 + i] = (T)d[i]; }
-    for (int i = 0; i < 16; ++i) out[80 + i] = (T)Tn[i];
-    out[96] = (T)((double)aff[0] - d[6]);
-    out[97] = (T)((double)aff[1] - d[7]);
+    TrkSolve S;
+    trk_solve8<T>(tot, Tji, S);
+    trk_store_Hg<T>(tot, out);
+    for (int i = 0; i < 8; ++i) out[72 + i] = (T)S.d[i];
+    for (int i = 0; i < 16; ++i) out[80 + i] = (T)S.Tn[i];
+    out[96] = (T)((double)aff[0] - S.d[6]);
+    out[97] = (T)((double)aff[1] - S.d[7]);
     out[98] = (T)(tot[44] / (double)(nv / C));    // mean over the valid PIXELS (photo_tracking.py:83-85), nv counts channels
-    out[99] = (T)sqrt(gn);
+    out[99] = (T)sqrt(S.gn);
     out[100] = (T)tot[44];
     out[101] = T(1.4826) * key_value(prefix);
     out[102] = (T)(nv / C);
-    out[103] = (T)sqrt(dn);
-    out[104] = (T)info;
+    out[103] = (T)sqrt(S.dn);
+    out[104] = (T)S.info;
   }
 }
 
@@ -275,11 +318,19 @@ int track_iter(const T* Tji, const T* Kmat, const T* aff, const T* P, const T* v
 // the barrier is one non-returning atomic per workgroup (8 counters, one per XCD-aligned residue class) + one polling round.
 // All workgroups must be co-resident: the host launches at most one workgroup per compute unit.
 constexpr int TL_MAXP = 5;          // reference pixels per thread
-constexpr int TL_POISON = 63;       // word of the 64-entry integer plane of the device-wide sums that counts non-finite shares (TRK_ACC <= 63)
 constexpr int TL_NC = 8;            // arrival counters of the device-wide barrier (workgroup b -> counter b % 8)
 constexpr int TL_BAR_WORDS = 32 * (TL_NC + 2);       // counters 128 B apart, then the error flag, then the XCD census (own line)
 constexpr int TL_XCC_WORD = 32 * (TL_NC + 1);        // 64-bit word: byte x = number of participating workgroups that run on XCD x
-constexpr int TL_SUM_WORDS = 2 * 2 * 64;             // two parities x {integer parts, fractions} x 64 (46 used) 64-bit sums
+// device-wide sums: per parity THREE planes of 64 (46 used) exact fixed-point sums -- integer parts [plane][64], then fractions:
+// plane 0 = pixels that are inliers of the Huber weight for every robust scale the median can still take, plane 1 = the
+// certain outliers (band-split form, see the kernel), plane 2 = the sums of the exact form (scale known)
+constexpr int TL_PLANE = 64;
+constexpr int TL_NPLANE = 3;
+constexpr int TL_SUM_PAR = 2 * TL_NPLANE * TL_PLANE;
+constexpr int TL_SUM_WORDS = 2 * TL_SUM_PAR;         // two parities
+constexpr int TL_POISON = 63;       // word of plane 0's integer parts that counts non-finite shares (TRK_ACC <= 63)
+constexpr int TL_AMB_CAP = 128;     // pixels whose weight class depends on the last 10 bits of the median: region 4 of the histograms
+constexpr int TL_AMB_WORDS = 12;    // [J0 J1 | J2 J3 | J4 J5 | J6 J7 | r -] as five 64-bit words (+ one spare), from word 16 on
 
 template <typename U>
 __device__ __forceinline__ U ld_dev(const U* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -343,11 +394,16 @@ struct TLCriteria { int max_iter; float delta_norm, rel_tol, grad_norm; };
 
 // one more digit of the exact k-th key: `hist` (2048 device-scope counters) is the histogram of this digit among the keys
 // that match the digits resolved so far; returns the digit and lowers k_rem to the rank inside that bin
-__device__ __forceinline__ uint32_t tl_resolve_digit(const uint32_t* hist, uint32_t& k_rem, uint32_t* total, SelScratch* sc) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  uint32_t c[8], local = 0;
+// (the loads and the scan are separate so that the counters of the NEXT digit's speculated histogram travel with this digit's)
+__device__ __forceinline__ void tl_load_hist(const uint32_t* hist, uint32_t (&c)[8]) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { c[j] = ld_dev(&hist[tid * 8 + j]); local += c[j]; }
+  for (int j = 0; j < 8; ++j) c[j] = ld_dev(&hist[threadIdx.x * 8 + j]);
+}
+__device__ __forceinline__ uint32_t tl_resolve_loaded(const uint32_t (&c)[8], uint32_t& k_rem, uint32_t* total, SelScratch* sc) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint32_t local = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) local += c[j];
   uint32_t incl = local;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -376,28 +432,75 @@ __device__ __forceinline__ uint32_t tl_resolve_digit(const uint32_t* hist, uint3
   __syncthreads();
   return bin;
 }
+__device__ __forceinline__ uint32_t tl_resolve_digit(const uint32_t* hist, uint32_t& k_rem, uint32_t* total, SelScratch* sc) {
+  uint32_t c[8];
+  tl_load_hist(hist, c);
+  return tl_resolve_loaded(c, k_rem, total, sc);
+}
+
+// Sum over the 64 lanes of a wave of N values per lane in ~N shuffles instead of 6 N: at every step a lane keeps one half of its
+// values, hands the other half to its partner (lane ^ mask) and adds what it receives -- the values halve while the lanes summed
+// double.  Fixed tree: the result does not depend on anything but the inputs.  Afterwards lane l holds the complete sums of the
+// values with index wr_index(l) (+ 64 for the second one); indices >= N are padding.
+__device__ __forceinline__ int wr_index(int lane) {
+  return ((lane & 1) << 5) | ((lane & 2) << 3) | ((lane & 4) << 1) | ((lane & 8) >> 1) | ((lane & 16) >> 3) | ((lane & 32) >> 5);
+}
+template <int NIN>
+__device__ __forceinline__ void wr_step(const float (&in)[NIN], float (&out)[NIN / 2], int mask, bool hi) {
+#pragma unroll
+  for (int i = 0; i < NIN / 2; ++i) {
+    const float keep = hi ? in[2 * i + 1] : in[2 * i];
+    const float send = hi ? in[2 * i] : in[2 * i + 1];
+    out[i] = keep + __shfl_xor(send, mask, 64);
+  }
+}
+__device__ __forceinline__ void wave_reduce96(const float (&a)[96], int lane, float& r0, float& r1) {
+  float b[48], c[24], d[12], e[6], f[3], g[4], h[2];
+  wr_step<96>(a, b, 32, (lane & 32) != 0);
+  wr_step<48>(b, c, 16, (lane & 16) != 0);
+  wr_step<24>(c, d, 8, (lane & 8) != 0);
+  wr_step<12>(d, e, 4, (lane & 4) != 0);
+  wr_step<6>(e, f, 2, (lane & 2) != 0);
+  g[0] = f[0]; g[1] = f[1]; g[2] = f[2]; g[3] = 0.f;
+  wr_step<4>(g, h, 1, (lane & 1) != 0);
+  r0 = h[0]; r1 = h[1];
+}
+__device__ __forceinline__ float wave_reduce48(const float (&a)[48], int lane) {
+  float c[24], d[12], e[6], f[3], g[4], h[2], k[1];
+  wr_step<48>(a, c, 32, (lane & 32) != 0);
+  wr_step<24>(c, d, 16, (lane & 16) != 0);
+  wr_step<12>(d, e, 8, (lane & 8) != 0);
+  wr_step<6>(e, f, 4, (lane & 4) != 0);
+  g[0] = f[0]; g[1] = f[1]; g[2] = f[2]; g[3] = 0.f;
+  wr_step<4>(g, h, 2, (lane & 2) != 0);
+  wr_step<2>(h, k, 1, (lane & 1) != 0);
+  return k[0];
+}
+
+typedef float tl_f2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void track_level_kernel(
     const float* __restrict__ Tji_init, const float* __restrict__ Kmat, const float* __restrict__ aff_init,
     const float* __restrict__ P, const float* __restrict__ vals_i, const float* __restrict__ img, int H, int W, long N,
     const float* __restrict__ J8, const uint8_t* __restrict__ in_mask, TLCriteria crit, unsigned* __restrict__ bar,
     uint32_t* __restrict__ hists2, long long* __restrict__ sums2, long long* __restrict__ stamps, float* __restrict__ out,
-    int ppt, int ws_cached, int C, int xl) {
+    int ppt, int ws_cached, int C, int xl, int split, int amb_cap) {
   using T = float;
   using KeyT = uint32_t;
   __shared__ uint32_t lh[SEL_BINS];
   __shared__ uint32_t lh1[SEL_BINS];   // speculative digit-1 histogram (see `spec_bin`)
   __shared__ SelScratch sc;
-  __shared__ float tile[128][TRK_ACC + 1];
-  __shared__ double red[4][TRK_ACC];
+  __shared__ float redw[4][96];        // per-wave sums (wave_reduce96 / wave_reduce48)
+  __shared__ float ambs[TL_AMB_CAP][10];
   __shared__ double tot[TRK_ACC];
   __shared__ float state[24];          // 16 T | 2 aff | mse | gnorm | dnorm
+  __shared__ float rec_s[112];         // the iteration's record, staged (one lane's 106 global stores were 1 us per iteration)
   // XCD-LOCAL mode (xl, the coarse levels: <= 32 workgroups of pixels): the grid is launched 8x oversized and only the workgroups
   // the dispatcher places on XCD 0 stay (workgroup b goes to XCD b % 8: verified once per process by como_track_level_probe) --
   // all participants then sit behind ONE L2, so the counters, histograms and sums are updated by plain L2 read-modify-writes
   // (workgroup-scope atomics, no wait for a value returned from the memory side) and read back with L1-bypassing loads: a barrier
   // is an L2 round trip (~0.5 us) instead of a trip to the memory side + an L2 invalidate (~4.5 us).
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int xdbg = xl >> 1;            // (debug switch of the census test: workgroup 1 reports a neighbouring XCD)
   xl &= 1;
   if (xl && (blockIdx.x & 7)) return;
@@ -445,6 +548,13 @@ __global__ __launch_bounds__(256) void track_level_kernel(
   T mse_prev = __builtin_inff();
   int it = 0;
   bool alive = true;
+  // (row, column) of the upper-triangle entry this thread owns when it evaluates the few band pixels (tid < 36)
+  int qa = 0, qb = 0;
+  {
+    int q = 0;
+    for (int a = 0; a < 8; ++a)
+      for (int b = a; b < 8; ++b) { if (q == tid) { qa = a; qb = b; } ++q; }
+  }
   // the result record starts as "no iteration done": the initial pose / affine parameters -- a barrier time-out in the
   // first iteration (workgroups not co-resident) must not hand uninitialised memory to the caller as the tracked pose
   if (bidx == 0 && tid < 24) {
@@ -469,18 +579,57 @@ __global__ __launch_bounds__(256) void track_level_kernel(
     }
     asm volatile("" ::"v"(sink));
   };
+  // this workgroup's share of sum `k` of `plane` into the device-wide sums, exact fixed point (common.cuh fix_split):
+  // order-independent.  Non-finite: counted in a dedicated word (cleared with the rest of the buffer), never encoded in the summed
+  // value -- an additive sentinel wraps once enough workgroups add it (8 x 2^61 = 0)
+  auto share = [&](long long* sm, int plane, int k, double v) {
+    long long hi = 0;
+    unsigned long long lo = 0, sink = 0;
+    unsigned long long* ip = (unsigned long long*)&sm[plane * TL_PLANE + k];
+    unsigned long long* fp = (unsigned long long*)&sm[TL_NPLANE * TL_PLANE + plane * TL_PLANE + k];
+    if (xl) {
+      if (!(fabs(v) < 4.0e18)) __hip_atomic_fetch_add((unsigned long long*)&sm[TL_POISON], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else fix_split(v, hi, lo);
+      if (hi) __hip_atomic_fetch_add(ip, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lo) __hip_atomic_fetch_add(fp, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+      if (!(fabs(v) < 4.0e18)) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[TL_POISON], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else fix_split(v, hi, lo);
+      if (hi) sink += __hip_atomic_fetch_add(ip, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lo) sink += __hip_atomic_fetch_add(fp, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("" ::"v"(sink));
+  };
+  auto plane_total = [&](const long long* sm, int plane, int k) {
+    const long long hi = ld_dev(&sm[plane * TL_PLANE + k]);
+    const unsigned long long lo = (unsigned long long)ld_dev(&sm[TL_NPLANE * TL_PLANE + plane * TL_PLANE + k]);
+    return fix_value(hi, lo);
+  };
 
   // SPECULATION on the first digit of the median: the robust scale moves little between iterations, so phase A also counts
   // the SECOND digit of the keys whose first digit equals the previous iteration's (`spec_bin`), into region 3 of the
   // histograms.  If the first digit resolves to that bin again, the second digit's histogram is already complete and one of
-  // the four device-wide synchronisations of the iteration (phase B: histogram, flush, barrier) is skipped; if not, region 3
+  // the device-wide synchronisations of the iteration (phase B: histogram, flush, barrier) is skipped; if not, region 3
   // is ignored and phase B runs as always -- the result is the exact median either way.
+  //
+  // BAND-SPLIT SUMS (`split`): once 22 of the 32 key bits of the median are known, the robust scale sigma = 1.4826 median is
+  // known to 2^-13, and with it the Huber class of all but a handful of pixels: |r| / sigma < 1.345 for EVERY scale in that band
+  // (weight 1) or >= 1.345 for every one (weight 1.345 sigma / |r|: LINEAR in sigma).  So the 46 sums do not wait for the last
+  // digit: its histogram pass also accumulates  S_in = sum_in J^T J  and  S_out = sum_out (1.345 / |r|) J^T J  (planes 0 / 1) and
+  // lists the few pixels whose class the last 10 bits decide (region 4 of the histograms: ~N x 2^-13 x density of them); after the
+  // ONE barrier that completes the last digit every workgroup forms  S_in + S_out / info_sqrt  and adds the listed pixels with the
+  // exact per-pixel arithmetic.  An iteration is two device-wide synchronisations instead of three (three instead of four when
+  // the first-digit speculation misses).  More than TL_AMB_CAP listed pixels (a degenerate residual distribution): the exact
+  // form runs after all (one more barrier) -- also what split = 0 selects.  MEASURED: the exact form is the faster one on MI355X
+  // (the second set of 45 contended shares, the doubled multiply-adds and the list cost more than the barrier saves): split is OFF
+  // by default, kept as a tested switch (como_track_level_set_split, COMO_TRACK_SPLIT=1).
   int spec_bin = -1;
   while (true) {
     uint32_t* hs = hists2 + (it & 1) * 6 * SEL_BINS;          // this iteration's digit histograms / sums
     uint32_t* hother = hists2 + ((it + 1) & 1) * 6 * SEL_BINS;
-    long long* sm = sums2 + (it & 1) * 128;
-    long long* smother = sums2 + ((it + 1) & 1) * 128;
+    long long* sm = sums2 + (it & 1) * TL_SUM_PAR;
+    long long* smother = sums2 + ((it + 1) & 1) * TL_SUM_PAR;
+    uint32_t* amb = hs + 4 * SEL_BINS;                         // [0] count, entries from word 16
     TL_STAMP(0);
     // ---- phase A: warp, sample, residual, validity, digit-0 histogram ----
     for (int b = tid; b < SEL_BINS; b += 256) { lh[b] = 0; lh1[b] = 0; }
@@ -520,184 +669,239 @@ __global__ __launch_bounds__(256) void track_level_kernel(
     TL_STAMP(2);
     if (!tl_barrier(B)) { alive = false; break; }
     TL_STAMP(3);
-    // ---- phases B, C: digits 1 and 2 of the exact median (keys come from registers: no memory pass) ----
+    {
+      // the other parity's histograms / sums / list counter: free since the barrier above, used by the next iteration.
+      // Cleared with read-modify-write atomics (performed at the memory side like the adds that follow): a device-scope
+      // STORE may linger in this XCD's write-back L2 and land after other workgroups' atomic adds, wiping them
+      uint32_t sink = 0;
+      for (int e = bidx * 256 + tid; e < 4 * SEL_BINS + 1; e += G * 256) {
+        if (xl) __hip_atomic_fetch_and(&hother[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else sink += __hip_atomic_fetch_and(&hother[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (bidx == G - 1) {
+        for (int e = tid; e < TL_SUM_PAR; e += 256) {
+          if (xl) __hip_atomic_fetch_and((unsigned long long*)&smother[e], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          else sink += (uint32_t)__hip_atomic_fetch_and((unsigned long long*)&smother[e], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      asm volatile("" ::"v"(sink));
+    }
+    // ---- digits 0 and 1 of the exact median (keys come from registers: no memory pass) ----
     KeyT prefix = 0;
     uint32_t k_rem = 0, nv = 0;
-    bool spec_hit = false;
-    for (int ps = 1; ps < 3; ++ps) {
-      for (int b = tid; b < SEL_BINS; b += 256) lh[b] = 0;
-      if (ps == 1) {   // the other parity's histograms / sums: free since the last barrier, used by the next iteration
-        // cleared with read-modify-write atomics (performed at the memory side like the adds that follow): a device-scope
-        // STORE may linger in this XCD's write-back L2 and land after other workgroups' atomic adds, wiping them
-        uint32_t sink = 0;
-        for (int e = bidx * 256 + tid; e < 4 * SEL_BINS; e += G * 256) {
-          if (xl) __hip_atomic_fetch_and(&hother[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          else sink += __hip_atomic_fetch_and(&hother[e], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int b = tid; b < SEL_BINS; b += 256) lh[b] = 0;
+    {
+      // (the speculated second digit's counters are requested together with the first digit's: one round trip for both)
+      uint32_t c0[8], c1[8];
+      tl_load_hist(hs, c0);
+      if (spec_bin >= 0) tl_load_hist(hs + 3 * SEL_BINS, c1);
+      const uint32_t bin = tl_resolve_loaded(c0, k_rem, &nv, &sc);                         // (orders the lh clear)
+      prefix |= ((KeyT)bin) << SelCfg<KeyT>::shift(0);
+      const bool spec_hit = (int)bin == spec_bin;     // uniform over the grid: every workgroup resolves the same histogram
+      spec_bin = (int)bin;
+      if (!spec_hit) {                                // phase B: the second digit's histogram, one more synchronisation
+#pragma unroll
+        for (int k = 0; k < TL_MAXP; ++k) {
+          const KeyT key = abs_key(rk[k]);
+          if (ok[k] && sel_match<KeyT>(key, prefix, 1)) atomicAdd(&lh[sel_digit<KeyT>(key, 1)], 1u);
         }
-        if (bidx == G - 1 && tid < 128) {
-          if (xl) __hip_atomic_fetch_and((unsigned long long*)&smother[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          else sink += (uint32_t)__hip_atomic_fetch_and((unsigned long long*)&smother[tid], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("" ::"v"(sink));
+        __syncthreads();
+        TL_STAMP(4);
+        flush(hs + SEL_BINS);
+        TL_STAMP(5);
+        if (!tl_barrier(B)) { alive = false; break; }
+        TL_STAMP(6);
+        for (int b = tid; b < SEL_BINS; b += 256) lh[b] = 0;
+        tl_load_hist(hs + SEL_BINS, c1);
       }
-      // digit ps - 1 from its finished histogram; after a successful speculation digit 1 sits in region 3
-      const uint32_t bin = tl_resolve_digit(hs + ((ps == 2 && spec_hit) ? 3 : ps - 1) * SEL_BINS, k_rem, ps == 1 ? &nv : nullptr,
-                                            &sc);                                        // (orders the lh clear)
-      prefix |= ((KeyT)bin) << SelCfg<KeyT>::shift(ps - 1);
-      if (ps == 1) {
-        spec_hit = (int)bin == spec_bin;              // uniform over the grid: every workgroup resolves the same histogram
-        spec_bin = (int)bin;
-        if (spec_hit) continue;                       // phase B is already done: no histogram, no flush, no barrier
-      }
+      const uint32_t bin1 = tl_resolve_loaded(c1, k_rem, nullptr, &sc);
+      prefix |= ((KeyT)bin1) << SelCfg<KeyT>::shift(1);
+    }
+    // ---- phase C: the last digit's histogram + (split) the band-split sums ----
+    {
+      // every value 1 / sigma can still take lies in [i_lo, i_hi] (monotone float arithmetic, widened by 2^-20 against a
+      // division that is not correctly rounded): a pixel is classed only if both ends agree
+      const T m_lo = key_value(prefix), m_hi = key_value(prefix | (KeyT)0x3ffu);
+      const T i_lo = (T(1) / (T(1.4826) * m_hi)) * T(1.0 - 1.0 / 1048576.0), i_hi = (T(1) / (T(1.4826) * m_lo)) * T(1.0 + 1.0 / 1048576.0);
+      tl_f2 acc2[48];
+#pragma unroll
+      for (int k = 0; k < 48; ++k) acc2[k] = tl_f2{0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < TL_MAXP; ++k) {
-        const KeyT key = abs_key(rk[k]);
-        if (ok[k] && sel_match<KeyT>(key, prefix, ps)) atomicAdd(&lh[sel_digit<KeyT>(key, ps)], 1u);
+        if (!ok[k]) continue;
+        const T r = rk[k];
+        const KeyT key = abs_key(r);
+        if (sel_match<KeyT>(key, prefix, 2)) atomicAdd(&lh[sel_digit<KeyT>(key, 2)], 1u);
+        if (!split) continue;
+        const T a = fabsf(r);
+        const bool inl = a * i_hi < T(1.345), outl = a * i_lo >= T(1.345);     // (a non-finite product is neither)
+        const T J[8] = {Jc[k][0], Jc[k][1], Jc[k][2], Jc[k][3], Jc[k][4], Jc[k][5], j6[k], Jc[k][6]};
+        if (inl || outl) {
+          const tl_f2 c = {inl ? T(1) : T(0), outl ? T(1.345) / a : T(0)};
+          const tl_f2 r2 = {r, r};
+          int q = 0;
+#pragma unroll
+          for (int x = 0; x < 8; ++x) {
+            const tl_f2 wa = c * tl_f2{J[x], J[x]};
+#pragma unroll
+            for (int y = x; y < 8; ++y) { acc2[q] = wa * tl_f2{J[y], J[y]} + acc2[q]; ++q; }
+            acc2[36 + x] = wa * r2 + acc2[36 + x];
+          }
+          acc2[44] = tl_f2{inl ? r * r : T(0), outl ? a : T(0)} + acc2[44];
+        } else {
+          const uint32_t slot = xl ? __hip_atomic_fetch_add(&amb[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                   : __hip_atomic_fetch_add(&amb[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (slot < (uint32_t)amb_cap) {
+            unsigned long long* e = (unsigned long long*)(amb + 16 + slot * TL_AMB_WORDS);
+            unsigned long long sink = 0;
+#pragma unroll
+            for (int w = 0; w < 5; ++w) {
+              const T lo = w < 4 ? J[2 * w] : r, hi = w < 4 ? J[2 * w + 1] : T(0);
+              const unsigned long long bits = (unsigned long long)__float_as_uint(lo) | ((unsigned long long)__float_as_uint(hi) << 32);
+              if (xl) __hip_atomic_exchange(&e[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              else sink += __hip_atomic_exchange(&e[w], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("" ::"v"(sink));
+          }
+        }
+      }
+      TL_STAMP(7);
+      if (split) {
+        float a96[96];
+#pragma unroll
+        for (int k = 0; k < 48; ++k) { a96[k] = acc2[k].x; a96[48 + k] = acc2[k].y; }
+        float r0, r1;
+        wave_reduce96(a96, lane, r0, r1);
+        const int ix = wr_index(lane);
+        redw[wv][ix] = r0;
+        if (ix < 32) redw[wv][64 + ix] = r1;
       }
       __syncthreads();
-      TL_STAMP(4 + 3 * (ps - 1));
-      flush(hs + ps * SEL_BINS);
-      TL_STAMP(5 + 3 * (ps - 1));
+      if (split && tid < 96 && (tid % 48) < TRK_ACC - 1) {
+        const double v = (((double)redw[0][tid] + (double)redw[1][tid]) + (double)redw[2][tid]) + (double)redw[3][tid];
+        share(sm, tid / 48, tid % 48, v);
+      }
+      TL_STAMP(8);
+      flush(hs + 2 * SEL_BINS);
+      TL_STAMP(9);
       if (!tl_barrier(B)) { alive = false; break; }
-      TL_STAMP(6 + 3 * (ps - 1));
     }
-    if (!alive) break;
-    // ---- phase D: robust weights, 8x8 system sums ----
     {
       const uint32_t bin = tl_resolve_digit(hs + 2 * SEL_BINS, k_rem, nullptr, &sc);
       prefix |= ((KeyT)bin) << SelCfg<KeyT>::shift(2);
     }
     const T sigma = T(1.4826) * key_value(prefix);
     const T info_sqrt = T(1) / sigma;
-    T acc[TRK_ACC];
-#pragma unroll
-    for (int k = 0; k < TRK_ACC; ++k) acc[k] = T(0);
-#pragma unroll
-    for (int k = 0; k < TL_MAXP; ++k) {
-      if (!ok[k]) continue;
-      const T r = rk[k];
-      const T wr = r * info_sqrt;
-      const T w = huber(wr);
-      const T J[8] = {Jc[k][0], Jc[k][1], Jc[k][2], Jc[k][3], Jc[k][4], Jc[k][5], j6[k], Jc[k][6]};
-      int q = 0;
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const T wa = w * J[a];
-#pragma unroll
-        for (int b = a; b < 8; ++b) acc[q++] += wa * J[b];
-        acc[36 + a] += wa * r;
-      }
-      acc[44] += w * wr * wr;
-    }
+    const uint32_t namb = split ? ld_dev(&amb[0]) : 0u;       // (complete since the barrier; the same value in every workgroup)
     TL_STAMP(10);
-    // fixed-order block reduction: upper half of the block folds into the lower half, then 4 x 32-row column sums in fp64
-    if (tid >= 128) {
+    if (!split || namb > (uint32_t)amb_cap) {
+      // ---- phase D, exact form: robust weights with the known scale, 8x8 system sums (plane 2), one more barrier ----
+      // (accumulated in the same two-lane registers as the split pass -- lane y idle: a plain float[48] here was demoted to scratch)
+      tl_f2 acc2[48];
 #pragma unroll
-      for (int k = 0; k < TRK_ACC; ++k) tile[tid - 128][k] = acc[k];
-    }
-    __syncthreads();
-    if (tid < 128) {
+      for (int k = 0; k < 48; ++k) acc2[k] = tl_f2{0.f, 0.f};
 #pragma unroll
-      for (int k = 0; k < TRK_ACC; ++k) acc[k] += tile[tid][k];
-    }
-    __syncthreads();
-    if (tid < 128) {
+      for (int k = 0; k < TL_MAXP; ++k) {
+        if (!ok[k]) continue;
+        const T r = rk[k];
+        const T wr = r * info_sqrt;
+        const T w = huber(wr);
+        const T J[8] = {Jc[k][0], Jc[k][1], Jc[k][2], Jc[k][3], Jc[k][4], Jc[k][5], j6[k], Jc[k][6]};
+        const tl_f2 c = {w, T(0)};
+        const tl_f2 r2 = {r, r};
+        int q = 0;
 #pragma unroll
-      for (int k = 0; k < TRK_ACC; ++k) tile[tid][k] = acc[k];
-    }
-    __syncthreads();
-    {
-      const int k = tid & 63, pp = tid >> 6;
-      if (k < TRK_ACC) {
-        double s = 0;
-        for (int rr = 0; rr < 32; ++rr) s += (double)tile[pp * 32 + rr][k];
-        red[pp][k] = s;
+        for (int x = 0; x < 8; ++x) {
+          const tl_f2 wa = c * tl_f2{J[x], J[x]};
+#pragma unroll
+          for (int y = x; y < 8; ++y) { acc2[q] = wa * tl_f2{J[y], J[y]} + acc2[q]; ++q; }
+          acc2[36 + x] = wa * r2 + acc2[36 + x];
+        }
+        acc2[44] = tl_f2{w * wr * wr, T(0)} + acc2[44];
       }
-    }
-    __syncthreads();
-    if (tid < TRK_ACC) {
-      // this workgroup's share into the device-wide sums, exact fixed point (common.cuh fix_split): order-independent
-      const double v = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-      long long hi = 0;
-      unsigned long long lo = 0;
-      unsigned long long sink = 0;
-      // non-finite: counted in a dedicated word (sm[63], cleared with the rest of the buffer), never encoded in the summed
-      // value -- an additive sentinel wraps once enough workgroups add it (8 x 2^61 = 0)
-      if (xl) {
-        if (!(fabs(v) < 4.0e18)) __hip_atomic_fetch_add((unsigned long long*)&sm[TL_POISON], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else fix_split(v, hi, lo);
-        if (hi) __hip_atomic_fetch_add((unsigned long long*)&sm[tid], (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (lo) __hip_atomic_fetch_add((unsigned long long*)&sm[64 + tid], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      } else {
-        if (!(fabs(v) < 4.0e18)) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[TL_POISON], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else fix_split(v, hi, lo);
-        if (hi) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[tid], (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (lo) sink += __hip_atomic_fetch_add((unsigned long long*)&sm[64 + tid], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float a48[48];
+#pragma unroll
+      for (int k = 0; k < 48; ++k) a48[k] = acc2[k].x;
+      const float rr = wave_reduce48(a48, lane);
+      redw[wv][wr_index(lane)] = rr;
+      __syncthreads();
+      if (tid < TRK_ACC - 1) {
+        const double v = (((double)redw[0][tid] + (double)redw[1][tid]) + (double)redw[2][tid]) + (double)redw[3][tid];
+        share(sm, 2, tid, v);
       }
-      asm volatile("" ::"v"(sink));
+      TL_STAMP(11);
+      if (!tl_barrier(B)) { alive = false; break; }
+      TL_STAMP(12);
+      if (tid < TRK_ACC) tot[tid] = (ld_dev(&sm[TL_POISON]) != 0) ? __builtin_nan("") : (tid < TRK_ACC - 1 ? plane_total(sm, 2, tid) : 0.0);
+    } else {
+      // ---- the totals from the two planes + the listed pixels (every workgroup, identically) ----
+      for (int e = tid; e < (int)namb * 5; e += 256) {
+        const unsigned long long bits = ld_dev((const unsigned long long*)(amb + 16 + (e / 5) * TL_AMB_WORDS) + (e % 5));
+        ambs[e / 5][2 * (e % 5)] = __uint_as_float((uint32_t)bits);
+        ambs[e / 5][2 * (e % 5) + 1] = __uint_as_float((uint32_t)(bits >> 32));
+      }
+      __syncthreads();
+      TL_STAMP(11);
+      if (tid < TRK_ACC) {
+        double v = 0.0;
+        if (tid < TRK_ACC - 1) {
+          const double s_in = plane_total(sm, 0, tid), s_out = plane_total(sm, 1, tid);
+          const double info = (double)info_sqrt;
+          v = tid < 44 ? s_in + s_out / info : s_in * info * info + s_out * 1.345 * info;
+          // the pixels the last digit classes: the exact form's float arithmetic per pixel, summed as integers (order-free)
+          long long hi = 0;
+          unsigned long long lo = 0;
+          bool bad = false;
+          for (int e = 0; e < (int)namb; ++e) {
+            const T r = ambs[e][8];
+            const T wr = r * info_sqrt;
+            const T w = huber(wr);
+            T t;
+            if (tid < 36) t = (w * ambs[e][qa]) * ambs[e][qb];
+            else if (tid < 44) t = (w * ambs[e][tid - 36]) * r;
+            else t = w * wr * wr;
+            const double td = (double)t;
+            if (!(fabs(td) < 4.0e18)) { bad = true; continue; }
+            long long h1;
+            unsigned long long l1;
+            fix_split(td, h1, l1);
+            hi += h1;
+            lo += l1;
+          }
+          v += fix_value(hi, lo);
+          if (bad) v = __builtin_nan("");
+        }
+        tot[tid] = (ld_dev(&sm[TL_POISON]) != 0) ? __builtin_nan("") : v;
+      }
+      TL_STAMP(12);
     }
-    TL_STAMP(11);
-    if (!tl_barrier(B)) { alive = false; break; }
-    TL_STAMP(12);
-    // ---- phase E (every workgroup, identically): totals, 8x8 Cholesky, T <- T Exp(-delta), stop test ----
-    if (tid < TRK_ACC) {
-      const long long hi = ld_dev(&sm[tid]);
-      const unsigned long long lo = (unsigned long long)ld_dev(&sm[64 + tid]);
-      tot[tid] = (ld_dev(&sm[TL_POISON]) != 0) ? __builtin_nan("") : fix_value(hi, lo);
-    }
+    // ---- phase E (every workgroup, identically): 8x8 Cholesky, T <- T Exp(-delta), stop test ----
     __syncthreads();
     TL_STAMP(13);
     if (tid == 0) {
-      double Hm[64], g[8], L[64], y[8], d[8];
-      int q = 0;
-      for (int a = 0; a < 8; ++a)
-        for (int b = a; b < 8; ++b) { Hm[a * 8 + b] = tot[q]; Hm[b * 8 + a] = tot[q]; ++q; }
-      double gn = 0;
-      for (int a = 0; a < 8; ++a) { g[a] = tot[36 + a]; gn += g[a] * g[a]; }
-      int info = 0;
-      for (int i = 0; i < 64; ++i) L[i] = 0;
-      for (int j = 0; j < 8; ++j) {
-        double s = Hm[j * 8 + j];
-        for (int k = 0; k < j; ++k) s -= L[j * 8 + k] * L[j * 8 + k];
-        if (!(s > 0) && info == 0) info = j + 1;
-        const double dj = sqrt(s);
-        L[j * 8 + j] = dj;
-        for (int i = j + 1; i < 8; ++i) {
-          double t = Hm[i * 8 + j];
-          for (int k = 0; k < j; ++k) t -= L[i * 8 + k] * L[j * 8 + k];
-          L[i * 8 + j] = t / dj;
-        }
-      }
-      for (int i = 0; i < 8; ++i) { double t = g[i]; for (int k = 0; k < i; ++k) t -= L[i * 8 + k] * y[k]; y[i] = t / L[i * 8 + i]; }
-      for (int i = 7; i >= 0; --i) { double t = y[i]; for (int k = i + 1; k < 8; ++k) t -= L[k * 8 + i] * d[k]; d[i] = t / L[i * 8 + i]; }
+      TrkSolve S;
+      trk_solve8<T>(tot, Tc, S);
       TL_STAMP(14);
-      double xi[6], E[16], dn = 0;
-      for (int i = 0; i < 6; ++i) xi[i] = -d[i];
-      for (int i = 0; i < 8; ++i) dn += d[i] * d[i];
-      se3_exp_f64(xi, E);
-      for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) {
-          double t = 0;
-          for (int k = 0; k < 4; ++k) t += (double)Tc[i * 4 + k] * E[k * 4 + j];
-          state[i * 4 + j] = (T)t;
-        }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) state[i] = (T)S.Tn[i];
       TL_STAMP(15);
-      state[16] = (T)((double)a0 - d[6]);
-      state[17] = (T)((double)a1 - d[7]);
+      state[16] = (T)((double)a0 - S.d[6]);
+      state[17] = (T)((double)a1 - S.d[7]);
       state[18] = (T)(tot[44] / (double)(nv / C));    // mean over valid pixels
-      state[19] = (T)sqrt(gn);
-      state[20] = (T)sqrt(dn);
+      state[19] = (T)sqrt(S.gn);
+      state[20] = (T)sqrt(S.dn);
       if (bidx == 0) {                                         // the record of this iteration, layout of como_track_iter_*
-        for (int i = 0; i < 64; ++i) out[i] = (T)Hm[i];
-        for (int i = 0; i < 8; ++i) { out[64 + i] = (T)g[i]; out[72 + i] = (T)d[i]; }
-        for (int i = 0; i < 16; ++i) out[80 + i] = state[i];
-        out[96] = state[16]; out[97] = state[17];
-        out[98] = state[18]; out[99] = state[19]; out[100] = (T)tot[44];
-        out[101] = sigma; out[102] = (T)(nv / C); out[103] = state[20]; out[104] = (T)info;
-        out[105] = (T)(it + 1);
+        trk_store_Hg<T>(tot, rec_s);
+        for (int i = 0; i < 8; ++i) rec_s[72 + i] = (T)S.d[i];
+        for (int i = 0; i < 16; ++i) rec_s[80 + i] = state[i];
+        rec_s[96] = state[16]; rec_s[97] = state[17];
+        rec_s[98] = state[18]; rec_s[99] = state[19]; rec_s[100] = (T)tot[44];
+        rec_s[101] = sigma; rec_s[102] = (T)(nv / C); rec_s[103] = state[20]; rec_s[104] = (T)S.info;
+        rec_s[105] = (T)(it + 1);
       }
     }
     __syncthreads();
+    if (bidx == 0 && tid < 106) out[tid] = rec_s[tid];
 #pragma unroll
     for (int k = 0; k < 16; ++k) Tc[k] = state[k];
     a0 = state[16]; a1 = state[17];
@@ -739,6 +943,8 @@ __global__ void xcc_probe_kernel(int* __restrict__ xcc) {
 
 static int g_track_local_enabled = 1;   // como_track_level_set_local
 static int g_track_local_debug = 0;     // como_track_level_debug_mismatch
+static int g_track_split = -1;          // como_track_level_set_split (-1: COMO_TRACK_SPLIT, default off)
+static int g_track_amb_cap = como::TL_AMB_CAP;   // como_track_level_debug_amb_cap
 
 extern "C" {
 
@@ -787,10 +993,11 @@ int como_track_level_probe(void) {
 
 /* local_workspace (optional): a second workspace of como_track_level_workspace_bytes() bytes in ORDINARY (L2-cacheable) device
  * memory: levels of at most 32 x 256 x TL_MAXP elements then run XCD-local (see track_level_kernel) when the probe allows it. */
-int como_track_level_local_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P,
-                               const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
-                               const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
-                               void* workspace, int workspace_uncached, void* local_workspace, float* out, como_stream_t stream) {
+static int track_level_launch(const float* Tji_init, const float* K, const float* aff_init, const float* P,
+                              const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
+                              const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
+                              void* workspace, int workspace_uncached, void* local_workspace, float* out, como_stream_t stream,
+                              bool prezeroed) {
   using namespace como;
   if (!Tji_init || !K || !aff_init || !P || !vals_i || !img || !J8 || !workspace || !out || N <= 0 || H < 3 || W < 3 ||
       max_iter < 1 || channels < 1 || channels > 4)
@@ -821,13 +1028,56 @@ int como_track_level_local_f32(const float* Tji_init, const float* K, const floa
   uint32_t* hists2 = (uint32_t*)workspace + TL_BAR_WORDS;
   long long* sums2 = (long long*)(hists2 + 2 * 6 * SEL_BINS);
   long long* stamps = sums2 + TL_SUM_WORDS;
-  if (!zero_words(workspace, TL_BAR_WORDS + 2 * 6 * SEL_BINS + 2 * TL_SUM_WORDS, s)) return COMO_ERR_LAUNCH;
+  if (!prezeroed && !zero_words(workspace, TL_BAR_WORDS + 2 * 6 * SEL_BINS + 2 * TL_SUM_WORDS, s)) return COMO_ERR_LAUNCH;
   TLCriteria crit{max_iter, delta_norm, rel_tol, grad_norm};
+  if (g_track_split < 0) {
+    // (default OFF: measured slower than the exact form at every level -- one barrier less, but 90 instead of 45 contended
+    // fixed-point shares per workgroup, twice the multiply-adds and the list: 34.5 / 30.6 / 20.8 / 18.7 us per iteration against
+    // 33.5 / 30.5 / 18.8 / 17.7 at 640x480 .. 80x60)
+    const char* e = getenv("COMO_TRACK_SPLIT");
+    g_track_split = (e && atoi(e) != 0) ? 1 : 0;
+  }
   hipLaunchKernelGGL(track_level_kernel, dim3((unsigned)(local ? 8 * G : G)), dim3(256), 0, s, Tji_init, K, aff_init, P, vals_i, img,
                      H, W, N, J8, in_mask, crit, bar, hists2, sums2, stamps, out, (int)ppt, workspace_uncached ? 0 : 1, channels,
-                     local ? (1 | (g_track_local_debug ? 2 : 0)) : 0);
+                     local ? (1 | (g_track_local_debug ? 2 : 0)) : 0, g_track_split, g_track_amb_cap);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
+}
+
+int como_track_level_local_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P,
+                               const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
+                               const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
+                               void* workspace, int workspace_uncached, void* local_workspace, float* out, como_stream_t stream) {
+  return track_level_launch(Tji_init, K, aff_init, P, vals_i, img, H, W, N, channels, J8, in_mask, max_iter, delta_norm, rel_tol,
+                            grad_norm, workspace, workspace_uncached, local_workspace, out, stream, false);
+}
+
+/* The same launch WITHOUT the clear of the barrier workspace: the caller has zeroed the first como_track_level_zero_bytes() bytes of
+ * `workspace` AND of `local_workspace` on this stream since their last use (the tracker's frame graph clears the workspaces of its
+ * three levels inside its first launch, como_track_frame_pyramid3_f32: a clear of its own is a dependent ~4.7 us launch per level). */
+int como_track_level_prezeroed_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P,
+                                   const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
+                                   const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
+                                   void* workspace, int workspace_uncached, void* local_workspace, float* out, como_stream_t stream) {
+  return track_level_launch(Tji_init, K, aff_init, P, vals_i, img, H, W, N, channels, J8, in_mask, max_iter, delta_norm, rel_tol,
+                            grad_norm, workspace, workspace_uncached, local_workspace, out, stream, true);
+}
+long como_track_level_zero_bytes(void) {
+  return ((long)como::TL_BAR_WORDS + 2L * 6 * como::SEL_BINS + 2L * como::TL_SUM_WORDS) * 4;
+}
+
+/* The band-split form of the level kernel's sums (two device-wide synchronisations per iteration, see track_level_kernel) can be
+ * switched off: every iteration then resolves the robust scale first and sums afterwards, the exact form (A/B, tests; also
+ * COMO_TRACK_SPLIT=0).  Returns the previous setting. */
+/* Test switch: the capacity of the band-pixel list (0 .. TL_AMB_CAP = 128; negative restores the default) -- a small capacity makes the
+ * overflow path (exact form after the split sums, one more barrier) run on ordinary data. */
+void como_track_level_debug_amb_cap(int cap) {
+  g_track_amb_cap = (cap < 0 || cap > como::TL_AMB_CAP) ? como::TL_AMB_CAP : cap;
+}
+int como_track_level_set_split(int enable) {
+  const int prev = g_track_split;
+  g_track_split = enable ? 1 : 0;
+  return prev < 0 ? 0 : prev;
 }
 
 /* The XCD-local form can be switched off for the rest of the process (the host does so when a level reports status -2 or a

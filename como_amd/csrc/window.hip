@@ -672,6 +672,72 @@ int como_win_scaffold(const como_win_args* a, como_stream_t stream) {
   return COMO_OK;
 }
 
+/* The log-depths the NEXT iteration's scaffold will compute, ahead of it: the SAME kernel (bit-identical arithmetic) over the state as it
+ * stands now, with every output redirected to `scratch` except the pix-dtype log-depths (-> px_logzm_out); nothing of the window is
+ * written, no landmark is re-initialised.  `zero` (optional, a multiple of 16 bytes) is cleared in the same launch (the radix-select
+ * histograms of the median pass that follows).  Between the end of an iteration and the next one's scaffold nothing changes the
+ * keyframes' poses / landmarks / medians in the sequential loop's plain and one-way frames (Mapping.py:760-807 rebuilds its tensors from the
+ * same values), so the full-image median of the next iteration (Mapping.store_vars, Mapping.py:749-758) can be streamed while the
+ * tracker runs instead of beside the block kernel. */
+long como_win_logz_ahead_scratch_bytes(int B, int m, int L, int F) {
+  const long bm = (long)B * m;
+  return 8 * (31 * bm + 3L * B + 3L * L + 8) + 4 * ((long)L + 4) + 8 * (7 * bm + 3L * B + 18L * F + 8);
+}
+
+int como_win_logz_ahead(const como_win_args* a, void* scratch, long scratch_bytes, void* px_logzm_out, void* zero, long zero_bytes,
+                        como_stream_t stream) {
+  using namespace como;
+  if (!a || !scratch || !px_logzm_out || a->B <= 0 || a->m <= 0 || a->m > 64 || a->F < a->B || (zero && (zero_bytes & 15)) ||
+      scratch_bytes < como_win_logz_ahead_scratch_bytes(a->B, a->m, a->L, a->F) || ((uintptr_t)scratch & 15))
+    return COMO_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const long bm = (long)a->B * a->m;
+  double* d = (double*)scratch;
+  ScaffoldOut o;
+  o.pm = d; d += 2 * bm;
+  o.logzm = d; d += bm;
+  o.invz = d; d += bm;
+  o.dzdP = d; d += 3L * a->B;
+  o.dlogz_dT = d; d += 6 * bm;
+  o.dlogz_dP = d; d += 3 * bm;
+  o.dp_dP = d; d += 6 * bm;
+  o.dp_dT = d; d += 12 * bm;
+  o.init_Pm = d; d += 3L * a->L;
+  d += ((uintptr_t)d & 8) ? 1 : 0;
+  o.reinit_flag = (int*)d;
+  d += ((long)a->L + 3) / 2 + 1;
+  int grid = a->B > (a->F * 16 + 63) / 64 ? a->B : (a->F * 16 + 63) / 64;
+  const long za16 = zero ? zero_bytes / 16 : 0;
+  if (za16 > 0 && grid < 64) grid = 64;
+  if (a->pix_is_f64) {
+    double* q = d;
+    ScaffoldPix<double> px;
+    px.logzm = (double*)px_logzm_out;
+    px.invz = q; q += bm;
+    px.dzdP = q; q += 3L * a->B;
+    px.dlogz_dT = q; q += 6 * bm;
+    px.poses = q; q += 16L * a->F;
+    px.aff = q;
+    hipLaunchKernelGGL(win_scaffold_kernel<double>, dim3(grid), dim3(64), 0, s, a->poses, a->aff, a->F, a->P_m, a->lm_ids,
+                       a->first_frame, a->first_slot, a->K, a->median, a->pm_first, a->B, a->m, o, px, (uint4*)zero, za16,
+                       (uint4*)nullptr, 0L, (double*)nullptr, (uint4*)nullptr, 0L);
+  } else {
+    float* q = (float*)d;
+    ScaffoldPix<float> px;
+    px.logzm = (float*)px_logzm_out;
+    px.invz = q; q += bm;
+    px.dzdP = q; q += 3L * a->B;
+    px.dlogz_dT = q; q += 6 * bm;
+    px.poses = q; q += 16L * a->F;
+    px.aff = q;
+    hipLaunchKernelGGL(win_scaffold_kernel<float>, dim3(grid), dim3(64), 0, s, a->poses, a->aff, a->F, a->P_m, a->lm_ids,
+                       a->first_frame, a->first_slot, a->K, a->median, a->pm_first, a->B, a->m, o, px, (uint4*)zero, za16,
+                       (uint4*)nullptr, 0L, (double*)nullptr, (uint4*)nullptr, 0L);
+  }
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+
 int como_win_priors(const como_win_args* a, como_stream_t stream) {
   using namespace como;
   if (!a || a->B <= 0 || a->m <= 0 || a->m > 64 || (!a->sysfix && (!a->H || !a->g || !a->err))) return COMO_ERR_ARG;

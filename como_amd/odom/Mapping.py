@@ -241,6 +241,16 @@ class Mapping:
             old = torch.empty((0), device=self.kf_poses.device, dtype=torch.float32)     # (add_one_way_frame starts the mirror over)
         ba.speculate(self.kf_timestamps, rec, self._slide_peek(name, old, 1, i, cap))
 
+    def median_ahead_now(self, kind):
+        """`median_ahead: gap` -- called by the tracker the moment a frame's request is known (`Tracking.after_decision`): a one-way
+        frame leaves the device idle for ~0.25 ms while the host hands the frame over and re-targets the window; the full-image
+        median of the iteration that follows (0.7 GB of K~: ~100 us of streaming) only depends on the keyframes' state, which that
+        hand-over does not touch -- it is streamed into the gap (`WindowBA._issue_median_ahead`) and the iteration's side branch
+        is left with the priors.  Not for a keyframe (another window follows) nor a plain frame (no gap: its iteration is queued at once)."""
+        ba = self._ba
+        if (kind == "one-way" and ba is not None and self.is_init and not self.converged and getattr(ba, "median_ahead", False) == "gap"):
+            ba._issue_median_ahead()
+
     def window_cat_helper_list(self, var, new_var, i):
         del var[:i]
         var.append(new_var)
@@ -719,6 +729,9 @@ class Mapping:
                                     rec_capacity=self.cfg["graph"]["num_one_way_frames"],
                                     band_median=self.cfg.get("band_median", False))
             self._ba_prev = None
+            # (`median_ahead: true`: the next iteration's full-image median streamed right after this one's update.  Off by default:
+            # in the eager loop the median branch already hides beside the block kernel -- measured no gain)
+            self._ba.median_ahead = self.cfg.get("median_ahead", False)
         ba = self._ba
         ba.step()
         info = getattr(ba, "info", None)

@@ -53,6 +53,7 @@ def _in_image(p, depth, img_size, border, depth_thresh, strict):
 _PYR_REFERENCE = os.environ.get("COMO_TRACK_PYR_REFERENCE", "1") != "0"    # 0: pose composition + depth pyramid + one reference launch per level (A/B)
 _FRAME_RECORD = os.environ.get("COMO_TRACK_FRAME_RECORD", "1") != "0"      # 0: the frame's record by pose composition + norm + casts + cat (A/B)
 _FOREACH_INPUTS = os.environ.get("COMO_TRACK_FOREACH_INPUTS", "1") != "0"   # 0: one copy launch per input of the frame graph (A/B)
+_LEAN_HEAD = os.environ.get("COMO_TRACK_LEAN_HEAD", "1") != "0"      # 0: gray + 2 x blur_down + one workspace clear per level / per median (A/B)
 _DIRECT_REF = os.environ.get("COMO_TRACK_DIRECT_REF", "1") != "0"     # (read once: an os.environ look-up costs ~25 us, this ran per frame)
 
 
@@ -140,7 +141,7 @@ class Tracking:
             self.T_w_rec_last = T_w_curr
         return new
 
-    def reproj_stats_last_kf(self, T_curr_kf, P=None, clone_count=True):
+    def reproj_stats_last_kf(self, T_curr_kf, P=None, clone_count=True, hist_prezeroed=False):
         """(reprojected depth image (1,h,w), seen mask, number of pixels seen, their exact median depth) of the newest keyframe's
         finest-level points in the current frame (Tracking.py:163-185 get_reproj_last_kf + :341-345): two launches
         (csrc/trackref.hip `como_reproject_depth_*`) + the device select -- no boolean-mask gathers, no host synchronisation."""
@@ -162,7 +163,7 @@ class Tracking:
         _lib.check(fn(T_curr_kf.reshape(4, 4).contiguous().data_ptr(), self.intrinsics_pyr[-1].contiguous().data_ptr(),
                       P.contiguous().data_ptr(), n, h, w, ws["order"].data_ptr(), ws["z"].data_ptr(), ws["img"].data_ptr(),
                       ws["seen"].data_ptr(), ws["nseen"].data_ptr(), _lib.stream_ptr(dev)), "como_reproject_depth")
-        med = masked_median(ws["img"], ws["seen"])
+        med = masked_median(ws["img"], ws["seen"], prezeroed=hist_prezeroed)
         return ws["img"].view(1, h, w), ws["seen"].view(1, h, w), (ws["nseen"][0].clone() if clone_count else ws["nseen"][0]), med
 
     def get_reproj_last_kf(self, T_curr_kf):
@@ -355,10 +356,44 @@ class Tracking:
         frame handed to the mapper is cloned): the caller need not clone the frame for the tracker."""
         return self._frame_graph_applies(rgb) and getattr(self, "_fg", None) is not None and self._fg.get("graph") is not None
 
+    def _lean_head_applies(self, rgb):
+        """The frame graph's head as ONE launch (csrc/image.hip frame_pyramid3_kernel: luma + both blur_down levels + the clears of
+        the three levels' barrier workspaces and of the median's histograms): gray float32 frames, three pyramid levels from 0."""
+        pyr = self.cfg["pyr"]
+        return (_LEAN_HEAD and rgb.dtype == torch.float32 and rgb.dim() == 4 and rgb.shape[0] == 1 and rgb.shape[1] == 3 and
+                rgb.shape[2] >= 4 and rgb.shape[3] >= 4 and pyr["start_level"] == 0 and pyr["end_level"] == 3 and len(self.P_pyr) == 3)
+
+    def _frame_head_fused(self, fg):
+        import ctypes
+        rgb = fg["rgb"]
+        _, _, H, W = rgb.shape
+        H1, W1 = (H + 1) // 2, (W + 1) // 2
+        dev = rgb.device
+        gray = torch.empty((1, 1, H, W), dtype=torch.float32, device=dev)
+        l1 = torch.empty((1, 1, H1, W1), dtype=torch.float32, device=dev)
+        l2 = torch.empty((1, 1, (H1 + 1) // 2, (W1 + 1) // 2), dtype=torch.float32, device=dev)
+        zl = fg.get("zero_list")
+        if zl is None:
+            L = _lib.lib()
+            nb = int(L.como_track_level_zero_bytes())
+            ptrs, nbytes = [], []
+            for ws, wsp in fg["ws"]:
+                ptrs.append(ws.data_ptr()); nbytes.append(nb)
+                if wsp:
+                    ptrs.append(int(wsp)); nbytes.append(nb)
+            from como_amd.utils.select import median_workspace
+            h = median_workspace(dev, 1)
+            ptrs.append(h.data_ptr()); nbytes.append(h.numel() * 4)
+            zl = fg["zero_list"] = ((ctypes.c_void_p * len(ptrs))(*ptrs), (ctypes.c_long * len(ptrs))(*nbytes), len(ptrs), h)
+        _lib.check(_lib.lib().como_track_frame_pyramid3_f32(rgb.data_ptr(), gray.data_ptr(), l1.data_ptr(), l2.data_ptr(), H, W, zl[0], zl[1],
+                                                            zl[2], _lib.stream_ptr(dev)), "como_track_frame_pyramid3_f32")
+        return [l2, l1, gray]
+
     def _frame_body(self, fg):
-        img_pyr = self.prep_tracking_img(fg["rgb"])
+        lean = bool(fg.get("lean"))
+        img_pyr = self._frame_head_fused(fg) if lean else self.prep_tracking_img(fg["rgb"])
         res = _pt.photo_tracking_levels_static(fg["T"], fg["aff"], fg["pb"], img_pyr, self.intrinsics_pyr, self.cfg["term_criteria"],
-                                               fg["ws"])
+                                               fg["ws"], prezeroed=lean)
         if res is None:
             return None
         T, aff, recs = res
@@ -366,7 +401,7 @@ class Tracking:
         if (_FRAME_RECORD and dt == torch.float32 and aff.dtype == dt and recs.dtype == dt and recs.dim() == 2 and recs.is_contiguous() and
                 fg["T_w_kf"].dtype == dt):
             # the frame's record in ONE launch (csrc/window.hip track_frame_record_kernel): world pose, |t|, casts, concatenation
-            _, _, n_seen, med = self.reproj_stats_last_kf(T, P=fg["pb"].levels[-1]["P"][0], clone_count=False)
+            _, _, n_seen, med = self.reproj_stats_last_kf(T, P=fg["pb"].levels[-1]["P"][0], clone_count=False, hist_prezeroed=lean)
             nl = int(recs.shape[0])
             sc = torch.empty((3 + nl + 34,), dtype=dt, device=T.device)
             if med.dtype == dt and n_seen.dtype == torch.int32:
@@ -376,7 +411,7 @@ class Tracking:
                     "como_track_frame_record_f32")
                 return T, aff, sc[3 + nl + 18:].view(1, 4, 4), sc
         T_w = get_T_w_curr(fg["T_w_kf"], T)
-        _, _, n_seen, med = self.reproj_stats_last_kf(T, P=fg["pb"].levels[-1]["P"][0])
+        _, _, n_seen, med = self.reproj_stats_last_kf(T, P=fg["pb"].levels[-1]["P"][0], hist_prezeroed=lean)
         # everything the host reads and keeps of a frame in ONE buffer: [|t|, median depth, pixels seen, per-level barrier status |
         # T_curr_kf (16) | aff_curr_kf (2) | T_w_curr (16)] -- one read-back and one copy per frame instead of one + three
         sc = torch.cat((torch.linalg.norm(T[:, :3, 3]).reshape(1), med.reshape(1).to(dt), n_seen.reshape(1).to(dt), recs[:, 104],
@@ -392,11 +427,14 @@ class Tracking:
                 pb = _pt.pyr_buffers(self.vals_pyr, self.P_pyr, self.dI_dT_pyr, self.prep_tracking_img(rgb), self.intrinsics_pyr)
             # ONE barrier workspace pair per tracker (the uncached allocation has no destroy entry point): a rebuilt frame graph
             # -- new pyramid buffers, another image size -- reuses it; the old graph is dropped with the old dict
+            lean = self._lean_head_applies(rgb)
             wsp = getattr(self, "_fg_ws", None)
-            if wsp is None or wsp[0].device != rgb.device:
-                wsp = self._fg_ws = _pt.level_workspace_pair(rgb.device)
+            if wsp is None or (wsp[0][0] if isinstance(wsp, list) else wsp[0]).device != rgb.device or isinstance(wsp, list) != lean:
+                # (lean head: one pair PER level -- all cleared inside the graph's first launch instead of one clear launch per level)
+                wsp = self._fg_ws = ([_pt.level_workspace_pair(rgb.device) for _ in range(3)] if lean else
+                                     _pt.level_workspace_pair(rgb.device))
             fg = self._fg = {"rgb": torch.empty_like(rgb), "T": torch.empty_like(self.T_curr_kf), "aff": torch.empty_like(self.aff_curr_kf),
-                             "T_w_kf": torch.empty_like(self.T_w_kf), "pb": pb, "ws": wsp,
+                             "T_w_kf": torch.empty_like(self.T_w_kf), "pb": pb, "ws": wsp, "lean": lean,
                              "graph": None, "out": None, "warm": 0}
         srcs = [rgb, self.T_curr_kf.reshape(1, 4, 4), self.aff_curr_kf.reshape(1, 2, 1), self.T_w_kf]
         dsts = [fg["rgb"], fg["T"], fg["aff"], fg["T_w_kf"]]
@@ -448,6 +486,9 @@ class Tracking:
                 track_data_viz = (timestamp, T_w_curr)
                 track_data_map = None
                 kind = self.decide_frame(norm_t, median_depth, n_seen, T_w_curr)
+                hook = getattr(self, "after_decision", None)
+                if hook is not None:                    # (device work that fits into the host-bound hand-over: sequential.py sets it)
+                    hook(kind)
                 if kind == "keyframe":
                     track_data_map = ("keyframe", rgb.clone(), self.T_curr_kf, self.aff_curr_kf, self.kf_received_ts, timestamp)
                     self.last_kf_sent_ts = timestamp

@@ -181,7 +181,7 @@ UNCACHED_WS = __import__("os").environ.get("COMO_TRACK_UNCACHED_WS", "1") == "1"
 
 
 def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, intrinsics, term_criteria, in_mask=None, out=None,
-                               ws_pair=None):
+                               ws_pair=None, prezeroed=False):
     """The whole level in ONE launch (csrc/track.hip track_level_kernel): Gauss-Newton loop + stop test on the device, no
     host read-back.  Returns (Tji (1,4,4), aff (1,2,1), out (106,)) -- all device tensors; out[105] = iterations run.
     None if the level does not fit the persistent kernel (then the per-iteration chain runs)."""
@@ -204,7 +204,8 @@ def photo_level_tracking_fused(Tji_init, aff_init, vals_i, Pi, dI_dT, img_j, int
         if out is None:
             out = torch.empty(106, device=dev, dtype=dt)
         # (the cached workspace doubles as the XCD-local one of the coarse levels, csrc/track.hip)
-        rc = L.como_track_level_local_f32(_lib.ptr(Tji_init), _lib.ptr(intrinsics), _lib.ptr(aff_init), _lib.ptr(Pi),
+        # prezeroed: the caller cleared BOTH workspaces of the pair on this stream (the frame graph does, in its first launch)
+        rc = (L.como_track_level_prezeroed_f32 if prezeroed else L.como_track_level_local_f32)(_lib.ptr(Tji_init), _lib.ptr(intrinsics), _lib.ptr(aff_init), _lib.ptr(Pi),
                                           _lib.ptr(vals_i), _lib.ptr(img_j), H, W, N, c, _lib.ptr(dI_dT), _lib.ptr(in_mask),
                                           int(term_criteria["max_iter"]), float(term_criteria["delta_norm"]),
                                           float(term_criteria["rel_tol"]), float(term_criteria["grad_norm"]),
@@ -365,7 +366,7 @@ def level_workspace_pair(device):
     return ws, wsp
 
 
-def photo_tracking_levels_static(Tji_init, aff_init, pb, img_j, intrinsics, term_criteria, ws_pair):
+def photo_tracking_levels_static(Tji_init, aff_init, pb, img_j, intrinsics, term_criteria, ws_pair, prezeroed=False):
     """Coarse -> fine through the persistent level kernels on the persistent reference buffers `pb`, every level starting from
     the previous level's result record in place; no host synchronisation, nothing but launches (capturable).  Returns
     (Tji (1,4,4), aff (1,2,1), records (levels,106): [.,104] < 0 = a device-wide barrier timed out) or None when a level does
@@ -374,8 +375,10 @@ def photo_tracking_levels_static(Tji_init, aff_init, pb, img_j, intrinsics, term
     outs = torch.empty((nl, 106), device=Tji_init.device, dtype=Tji_init.dtype)
     Tji, aff = Tji_init, aff_init
     for l, c in enumerate(pb.levels):
+        # (ws_pair: one pair for all levels, or one PER level -- then `prezeroed` says the caller has cleared them all)
+        wp = ws_pair[l] if isinstance(ws_pair, list) else ws_pair
         res = photo_level_tracking_fused(Tji, aff, c["vals"], c["P"], c["dI"], img_j[l], intrinsics[l], term_criteria, c["mask"],
-                                         out=outs[l], ws_pair=ws_pair)
+                                         out=outs[l], ws_pair=wp, prezeroed=prezeroed and isinstance(ws_pair, list))
         if res is None:
             return None
         Tji, aff = res[0], res[1]

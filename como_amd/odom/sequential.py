@@ -2,6 +2,7 @@
 without the GUI.  Per frame: track against the newest keyframe (once mapping is initialised), hand the tracker's request
 (keyframe / one-way frame / initialisation frame) to the mapper, run ONE mapping GN iteration, and give the tracker the
 refreshed keyframe reference (pose, affine parameters, dense depth) -- the order of ComoSeq.iter (ComoSeq.py:41-71)."""
+import os
 import time
 
 import torch
@@ -52,7 +53,11 @@ class ComoSeq:
 
     def __init__(self, slam_cfg, intrinsics, img_size, model=None):
         self.tracking = TrackingSeq(slam_cfg["tracking"], intrinsics.clone(), img_size)
-        self.mapping = MappingSeq(slam_cfg["mapping"], intrinsics.clone())
+        mcfg = slam_cfg["mapping"]
+        mode = os.environ.get("COMO_MEDIAN_AHEAD_MODE")       # (measurement switch: "gap" / "end" without editing the configuration)
+        if mode and "median_ahead" not in mcfg:
+            mcfg = dict(mcfg, median_ahead=mode)
+        self.mapping = MappingSeq(mcfg, intrinsics.clone())
         self.tracking.setup()
         self.mapping.setup(model)
         self.timestamps, self.est_poses = [], []
@@ -61,6 +66,8 @@ class ComoSeq:
             # one process, one device: while the tracker waits for a frame's result the mapper prepares the window that frame
             # would need as a one-way frame (Mapping.speculate_one_way)
             self.tracking.while_waiting = self.mapping.speculate_one_way
+            if self.mapping.cfg.get("median_ahead", False) == "gap":
+                self.tracking.after_decision = self.mapping.median_ahead_now
 
     def iter(self, timestamp, rgb):
         trk, mp = self.tracking, self.mapping

@@ -44,6 +44,11 @@ _REUSE_TOPOLOGY = __import__("os").environ.get("COMO_BA_REUSE", "1") != "0"     
 _SPECULATE = __import__("os").environ.get("COMO_BA_SPECULATE", "1") != "0"      # 0: no pair table is built ahead of the tracker's decision (A/B)
 SPEC_STATS = {"built": 0, "adopted": 0}     # pair tables built ahead / adopted by a re-target (process-wide; bench.py reports them)
 _REUSE_WORKSPACES = __import__("os").environ.get("COMO_BA_REUSE_WS", "1") != "0"  # (measurement switch)
+# The sequential loop's full-image median of iteration t+1 streamed right after iteration t's update, beside the tracker, instead of
+# beside iteration t+1's block kernel (`WindowBA.median_ahead`, set by Mapping).  0: off (A/B); 2: every adopted median is ALSO computed
+# the usual way and compared bit for bit (one host synchronisation per iteration: tests only) -- AHEAD_STATS["mismatch"].
+_MEDIAN_AHEAD = int(__import__("os").environ.get("COMO_MEDIAN_AHEAD", "1"))
+AHEAD_STATS = {"issued": 0, "adopted": 0, "checked": 0, "mismatch": 0}
 
 
 _ARANGE = {}
@@ -77,6 +82,8 @@ class WindowBA:
         # candidates (scripts/gpu_odometry_bench.py `band_median`): there the plain streaming pass on the matrix cores is faster.
         # None: the module default (dense_ref.BAND_MEDIAN).
         self.band_median = band_median
+        self.median_ahead = False                            # (Mapping turns it on for the sequential loop)
+        self._ahead = None
         self.shard = shard
         self._prev = prev
         self._src_kf_img, self._src_mask = state["kf_img_and_grads"], state["correspondence_mask"]
@@ -155,6 +162,7 @@ class WindowBA:
         self.poses_all = self.state_flat[:16 * F_].view(F_, 4, 4)
         self.aff_all = self.state_flat[o_aff:o_aff + 2 * F_].view(F_, 2)
         if not only_recent:
+            self._ahead = None                               # (a median streamed ahead belongs to the keyframe state it was computed from)
             self.poses_all[:B] = f64(state["kf_poses"])
             self.aff_all[:B] = f64(state["kf_aff_params"]).reshape(B, 2)
         self.kf_poses = self.poses_all[:B]
@@ -714,7 +722,24 @@ class WindowBA:
                                     ws=w["ba_ws"], sysfix=self.sysfix, fix_plane=self.fix_plane, D=self.dim,
                                     prepared=self._ba_prepared if self.events is None else None,
                                     phase=0xFE if fuse is not None else 0xFF)
-        if late_side:
+        ahead, self._ahead = self._ahead, None
+        if late_side and ahead is not None:
+            # iteration t's epilogue already streamed this iteration's full-image median into med3_full on the side stream
+            # (`_issue_median_ahead`): only the priors are left for the branch -- they follow it in stream order
+            side.wait_event(ev)
+            ss = side.cuda_stream
+            AHEAD_STATS["adopted"] += 1
+            if _MEDIAN_AHEAD == 2:
+                side.synchronize()
+                got = w["med3_full"].clone()
+                fm("all", ss)
+                side.synchronize()
+                AHEAD_STATS["checked"] += 1
+                if not torch.equal(got.contiguous().view(torch.uint8), w["med3_full"].contiguous().view(torch.uint8)):
+                    AHEAD_STATS["mismatch"] += 1
+            if self.with_priors:
+                _lib.check(L.como_win_priors(ctypes.byref(a), ss), "como_win_priors")
+        elif late_side:
             side.wait_event(ev)
             if self.band_median is False or (self.band_median is None and not BAND_MEDIAN):
                 ss = side.cuda_stream                        # (the plain streaming pass: kernels only, no torch op in between)
@@ -881,7 +906,51 @@ class WindowBA:
                                                 self.info.data_ptr(), _lib.stream_ptr(self.dev))
         _lib.check(rc, "como_win_update")
         self.delta = delta
+        if self.median_ahead and self.median_ahead != "gap" and _MEDIAN_AHEAD:
+            self._issue_median_ahead()                       # ("gap": the caller issues it -- Mapping.median_ahead_now)
         return delta
+
+    def _issue_median_ahead(self):
+        """The sequential loop runs ONE iteration per frame; between two of them the tracker works (latency-bound level kernels, a
+        host read-back) while nothing touches the keyframes' state -- so the next iteration's full-image median (0.7 GB of K~ at 9 x
+        640x480: byte-bound, ~100 us alone, and the block kernel ran at half speed beside it) is streamed NOW on the side stream: the
+        scaffold kernel itself computes the log-depths the next scaffold will compute (`como_win_logz_ahead`: same code, outputs into
+        scratch), the depth-only pass + select passes write med3_full, and the next `linearize_fused` only submits the priors.
+        Valid while this object keeps its keyframe state (`_load_frames` of another state drops it); plain streaming form, one GPU,
+        eager iterations only."""
+        self._ahead = None
+        if not (self.fused and self.full_median and self.overlap_priors and self.shard is None and self.events is None and
+                self.graph is None and self._side_stream is not None and self.with_priors and
+                (self.band_median is False or (self.band_median is None and not BAND_MEDIAN)) and
+                not torch.cuda.is_current_stream_capturing()):
+            return
+        ent = self._ba_prepared.get(("fm", "all")) if isinstance(self._ba_prepared, dict) else None
+        st = getattr(self, "_ahead_state", None)
+        if st is None:
+            if ent is None:
+                return                                       # (the first iteration of this object has not marshalled the call yet)
+            L, w, a = _lib.lib(), self.w, self.win_args
+            nb = int(L.como_win_logz_ahead_scratch_bytes(self.B, self.m, self.L, self.Fcap))
+            hb = self.B * int(L.como_select_workspace_bytes())
+            fn, args, _ = ent
+            keep = self._ba_prepared[("fm_keep", "all")]
+            if args[3] != w["px_logzm"].data_ptr() or args[16] != w["hist_full"].data_ptr() or args[17] != w["med3_full"].data_ptr():
+                return                                       # (not the call this was written for)
+            st = {"scratch": torch.empty((nb + 15) // 8, device=self.dev, dtype=torch.float64),
+                  "lz": torch.empty_like(w["px_logzm"]), "hist": torch.zeros(hb // 4, device=self.dev, dtype=torch.int32),
+                  "fn": fn, "nb": nb, "hb": hb, "keep": keep}
+            st["args"] = args[:3] + (st["lz"].data_ptr(),) + args[4:16] + (st["hist"].data_ptr(),) + args[17:]
+            self._ahead_state = st
+        main, side = torch.cuda.current_stream(self.dev), self._side_stream
+        ev = torch.cuda.Event()
+        ev.record(main)
+        side.wait_event(ev)
+        ss = side.cuda_stream
+        _lib.check(_lib.lib().como_win_logz_ahead(ctypes.byref(self.win_args), st["scratch"].data_ptr(), st["nb"], st["lz"].data_ptr(),
+                                                  st["hist"].data_ptr(), st["hb"], ss), "como_win_logz_ahead")
+        _lib.check(st["fn"](*st["args"], ss), "como_dense_ref (depth only, ahead)")
+        AHEAD_STATS["issued"] += 1
+        self._ahead = True
 
     def check_solver(self):
         """Read the status of the last solve (one host synchronisation) and act on it -- the reference swallows it

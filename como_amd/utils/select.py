@@ -8,7 +8,17 @@ from como_amd import _lib
 _ws = {}
 
 
-def masked_median(x, valid=None):
+def median_workspace(device, nseg=1):
+    """The select workspace `masked_median` uses for `nseg` segments on `device` (a caller that clears it itself -- the tracker's
+    frame graph, inside its first launch -- passes prezeroed=True)."""
+    key = (str(device), nseg)
+    h = _ws.get(key)
+    if h is None:
+        h = _ws[key] = torch.empty(nseg * _lib.lib().como_select_workspace_bytes() // 4, dtype=torch.int32, device=device)
+    return h
+
+
+def masked_median(x, valid=None, prezeroed=False):
     """x (nseg, n) or (n,) float32 / float64 CUDA tensor of NON-NEGATIVE values; valid: same shape, bool / uint8, None = all.
     Returns (nseg,) [or a 0-dim tensor for 1-D input]: per segment the lower median of the valid entries (the select orders by
     |x|), NaN-free as long as the valid entries are.  A segment WITHOUT valid entries returns NaN (csrc/select.hip
@@ -30,7 +40,8 @@ def masked_median(x, valid=None):
         h = _ws[key] = torch.empty(nseg * L.como_select_workspace_bytes() // 4, dtype=torch.int32, device=dev)
     s = _lib.stream_ptr(dev)
     sfx = _lib.suffix(dt)
-    _lib.check(L.como_select_begin(h.data_ptr(), nseg, s), "como_select_begin")
+    if not prezeroed:
+        _lib.check(L.como_select_begin(h.data_ptr(), nseg, s), "como_select_begin")
     for p in range(3 if dt == torch.float32 else 6):
         _lib.check(getattr(L, "como_select_hist_" + sfx)(x2.data_ptr(), _lib.ptr(v), n, nseg, h.data_ptr(), p, s), "como_select_hist")
     out3 = torch.empty((nseg, 3), dtype=dt, device=dev)

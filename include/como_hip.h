@@ -187,9 +187,24 @@ int como_track_level_probe(void);
  * tracks the frame again and calls como_track_level_set_local(0), after which every level runs in the device-wide form).
  * como_track_level_set_local returns the previous setting; como_track_level_local_state = 1 while coarse levels run XCD-local;
  * como_track_level_debug_mismatch(1) makes workgroup 1 report a neighbouring XCD (the test of the -2 path). */
+/* como_track_level_local_f32 without the clear of the barrier workspace (the caller cleared the first
+ * como_track_level_zero_bytes() bytes of BOTH workspaces on this stream since their last use). */
+int como_track_level_prezeroed_f32(const float* Tji_init, const float* K, const float* aff_init, const float* P,
+                                   const float* vals_i, const float* img, int H, int W, long N, int channels, const float* J8,
+                                   const uint8_t* in_mask, int max_iter, float delta_norm, float rel_tol, float grad_norm,
+                                   void* workspace, int workspace_uncached, void* local_workspace, float* out, como_stream_t stream);
+long como_track_level_zero_bytes(void);
 int como_track_level_set_local(int enable);
 int como_track_level_local_state(void);
 void como_track_level_debug_mismatch(int on);
+/* Band-split sums of the level kernel (csrc/track.hip): with 22 of the 32 key bits of the median |r| known, the Huber class of all but
+ * a handful of pixels is known for every robust scale the median can still take (photo_tracking.py:77-93: weight 1, or 1.345 sigma / |r|,
+ * linear in sigma), so the last digit's histogram pass also accumulates the inlier / outlier sums and lists the few undecided pixels: an
+ * iteration is two device-wide synchronisations instead of three.  OFF by default (measured slower than the exact form -- scale first,
+ * sums afterwards -- on MI355X); como_track_level_set_split(1) / COMO_TRACK_SPLIT=1 selects it, the call returns the previous setting; como_track_level_debug_amb_cap(c) shrinks the list
+ * (0 .. 128, negative = default) so that the overflow path -- exact form after the split pass -- runs on ordinary data. */
+int como_track_level_set_split(int enable);
+void como_track_level_debug_amb_cap(int cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Window BA linearisation (python path: backend/photo.py:83-233 batch_photo_cost).
@@ -592,6 +607,15 @@ typedef struct como_win_args {
 
 int como_win_scaffold(const como_win_args* args_host, como_stream_t stream);
 int como_win_priors(const como_win_args* args_host, como_stream_t stream);
+/* The log-depths the NEXT iteration's como_win_scaffold will compute (same kernel, same arithmetic) over the state as it stands, every
+ * other output into `scratch` (como_win_logz_ahead_scratch_bytes, 16-byte aligned); the window is not written.  px_logzm_out (B,m) in
+ * the window's pix dtype; zero / zero_bytes: an optional buffer (multiple of 16 bytes) cleared in the same launch.  Lets the
+ * full-image median of the next iteration (Mapping.store_vars, /root/reference/como/odom/Mapping.py:749-758) be streamed between two
+ * iterations of the sequential loop instead of beside the block kernel. */
+long como_win_logz_ahead_scratch_bytes(int B, int m, int L, int F);
+int como_win_logz_ahead(const como_win_args* args_host, void* scratch, long scratch_bytes, void* px_logzm_out, void* zero,
+                        long zero_bytes, como_stream_t stream);
+
 /* Order-independent normal equations.  sysfix = 2 planes x fix_plane int64 (fix_plane >= D*D + D + 8): plane 0 holds
  * floor(v) sums, plane 1 the fractional parts in units of 2^-56, of {H[i][j] for i >= j at i*D+j | g at D*D | errors at
  * D*D+D (slot 0 photometric, 1..6 priors, 7 = count of non-finite contributions)}.  como_sys_finalize converts to float64:
@@ -709,6 +733,12 @@ int como_rgb_to_gray_f64(const double* rgb, double* out, int N, int H, int W, co
  * mirror).  Both destinations may be slots of the window's image buffers. */
 int como_frame_stack_f64(const void* rgb, int rgb_is_f32, int H, int W, double* stack, float* stack_pix, como_stream_t stream);
 int como_img_blur_down_f32(const float* img, float* out, int NC, int H, int W, como_stream_t stream);
+/* The tracker's three-level image pyramid of one colour frame (3,H,W) in one launch (Tracking.prep_tracking_img,
+ * /root/reference/como/odom/Tracking.py:103-107): gray (H,W), l1 = blur_down(gray), l2 = blur_down(l1) -- bit-identical to
+ * como_rgb_to_gray_f32 + 2 x como_img_blur_down_f32; up to eight small buffers (16-byte aligned, multiples of 16 bytes) are cleared in
+ * the same launch. */
+int como_track_frame_pyramid3_f32(const float* rgb, float* gray, float* l1, float* l2, int H, int W, void* const* zero_ptrs,
+                                  const long* zero_bytes, int n_zero, como_stream_t stream);
 int como_img_blur_down_f64(const double* img, double* out, int NC, int H, int W, como_stream_t stream);
 /* img_blur: the same blur without decimation (GaussianBlurModule); depth_pool2: pyr_depth (como/data/depth_resize.py:6-36)
  * with kernel_size 2, mode 0 bilinear, 1 nearest_neighbor, 2 max, 3 min, 4 masked_bilinear. */

@@ -29,10 +29,14 @@ torch.cuda.synchronize()
 print(f"{H}x{W}: {e0.elapsed_time(e1) * 1e3 / 20 / 8:.2f} us per iteration (8 iterations per launch), local form = {L.como_track_level_local_state()}, "
       f"status {int(res[2][104])}")
 words = 32 * 10 + 2 * 6 * 2048                      # TL_BAR_WORDS + the two parities' digit histograms (uint32 words)
-off = (words * 4 + 2 * 2 * 64 * 8) // 8             # + TL_SUM_WORDS 64-bit sums
+off = (words * 4 + 2 * 2 * 3 * 64 * 8) // 8         # + TL_SUM_WORDS 64-bit sums (two parities x {integer, fraction} x three planes x 64)
 st = ws.view(torch.int64)[off:off + 17].cpu().tolist()
-names = ["A compute", "flush0", "barrier1", "B resolve+hist", "flush1", "barrier2", "C resolve+hist", "flush2", "barrier3",
-         "D resolve+accumulate", "block reduce", "barrier4", "partial sums", "8x8 solve", "exp+update", "state bcast"]
-for i, nm in enumerate(names):
-    print(f"{nm:24s} {(st[i + 1] - st[i]) * 0.01:8.2f} us")
-print("iteration total", (st[16] - st[0]) * 0.01, "us")
+# stamps of iteration 3 (round 6 layout; 4-6 are only written when the first-digit speculation misses)
+segs = [("A warp / residual / digit-0 histogram", 0, 1), ("flush 0 (+ speculated digit 1)", 1, 2), ("barrier 1", 2, 3),
+        ("clear other parity, resolve digits 0-1, digit-2 histogram + split sums", 3, 7), ("wave-tree reduce + shares", 7, 8),
+        ("flush 2", 8, 9), ("barrier 2 + resolve digit 2", 9, 10), ("exact: sums+shares | split: list staged", 10, 11),
+        ("exact: barrier 3 | split: totals + listed pixels", 11, 12), ("sync", 12, 13), ("8x8 solve + exp", 13, 14), ("state", 14, 15),
+        ("record + broadcast", 15, 16)]
+for nm, a, b in segs:
+    print(f"{nm:72s} {(st[b] - st[a]) * 0.01:8.2f} us")
+print("iteration total", (st[16] - st[0]) * 0.01, "us;  speculation-miss stamps (4..6):", [(st[k] - st[3]) * 0.01 if st[k] else None for k in (4, 5, 6)])

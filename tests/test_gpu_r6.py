@@ -513,3 +513,152 @@ def test_reference_pyramid_in_one_launch_equals_the_per_level_chain():
                                                    arr([t[0] for t in got]), arr([t[1] for t in got]), arr([t[2] for t in got]), 50.0, 1e-4,
                                                    _lib.stream_ptr(torch.device(DEV))) != 0
     report("reference_pyramid", cases=4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_median_streamed_ahead_equals_the_in_iteration_one(monkeypatch):
+    """`WindowBA._issue_median_ahead` (csrc/window.hip como_win_logz_ahead + the depth-only pass, on the side stream right after an
+    iteration's update) against the full-image median computed inside the next iteration (Mapping.store_vars, Mapping.py:749-758):
+    (i) three iterations of one window, then a re-targeted set of one-way frames, with and without the switch: state, normal
+    equations and medians identical bit for bit; (ii) the 72-frame sequence of the ATE fixture in check mode (every adopted median
+    is also computed the usual way and compared): same decisions as the reference's loop, no mismatch."""
+    import como_amd.odom.window_ba as wba
+    from como_amd import synth
+    from como_amd.depth_cov.core.covariance import prep_predictor
+    from tests.conftest import load_golden
+    B, H, W, m = 3, 96, 128, 16
+    st = synth.make_window(B=B, H=H, W=W, m=m, dtype=torch.float64, device=DEV, seed=11,
+                           predictor=lambda cov, cm: prep_predictor(cov, cm, 1.0))
+    st.update(synth.make_recent([0.3, 1.3], H, W, 11, device=DEV))
+    cfg = copy.deepcopy(wba.DEFAULT_CFG)
+    cfg["photo_construction"]["nonmax_suppression_window"] = 2
+    res = []
+    for ahead in (False, True):
+        for k in wba.AHEAD_STATS:
+            wba.AHEAD_STATS[k] = 0
+        wb = wba.WindowBA({k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()}, cfg=cfg, pix_dtype=torch.float64,
+                          window_full=True, rec_capacity=4, band_median=False)
+        assert wb.full_median
+        wb.median_ahead = ahead
+        for _ in range(3):
+            wb.iterate()
+        s2 = dict(st)
+        s2.update(synth.make_recent([0.3, 1.3, 1.6], H, W, 11, device=DEV))
+        sn = wb.snapshot_state()
+        s2["kf_poses"], s2["kf_aff_params"] = sn["poses"][:B].clone(), sn["aff"][:B].reshape(B, 2, 1).clone()
+        s2["P_m"], s2["median_depth_init"] = sn["P_m"].clone(), sn["median"].clone()
+        s2["recent_poses"] = torch.cat((sn["poses"][B:B + 2], s2["recent_poses"][2:]))
+        s2["kf_img_and_grads"], s2["correspondence_mask"] = wb._src_kf_img, wb._src_mask
+        s2["_published_by"] = wb                             # (what Mapping.iterate records: the keyframe rows are this buffer's own)
+        assert wb.retarget(s2) is True
+        wb.iterate()
+        torch.cuda.synchronize()
+        assert int(wb.info.item()) == 0
+        # (med3_full itself is not compared: with the switch on it already holds the NEXT iteration's median)
+        res.append((wb.state_flat.clone(), wb.H.clone(), wb.g.clone(), dict(wba.AHEAD_STATS)))
+    off, on = res
+    report("median_ahead_window", stats=on[3], state_diff=(off[0] - on[0]).abs().max().item())
+    assert off[3]["issued"] == 0 and on[3]["issued"] == 4 and on[3]["adopted"] == 3
+    assert all(torch.equal(a, b) for a, b in zip(off[:3], on[:3]))
+    # a state written from outside drops the streamed median
+    s3 = dict(s2)
+    s3["_published_by"] = None
+    assert wb.retarget(s3) is True and wb._ahead is None
+    # --- the sequential loop, check mode
+    import scripts.ate_sequence as ats
+    from scripts.ate_sequence import run_ate_sequence
+    loop_cfgs = ats.loop_cfgs
+
+    def cfgs_with_ahead(*a, **k):
+        c = loop_cfgs(*a, **k)
+        c["mapping"]["median_ahead"] = True
+        return c
+    monkeypatch.setattr(ats, "loop_cfgs", cfgs_with_ahead)
+    monkeypatch.setattr(wba, "_MEDIAN_AHEAD", 2)
+    for k in wba.AHEAD_STATS:
+        wba.AHEAD_STATS[k] = 0
+    G = load_golden("ate_sequence.npz")
+    kinds, poses, odo = run_ate_sequence(G, "float")
+    stats = dict(wba.AHEAD_STATS)
+    report("median_ahead_loop", **stats)
+    assert kinds == [int(x) for x in G["kinds"]]
+    assert stats["adopted"] >= 30 and stats["checked"] == stats["adopted"] and stats["mismatch"] == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,W,masked", [(480, 640, False), (240, 320, True), (120, 160, False), (60, 80, True), (37, 53, False)])
+def test_band_split_level_kernel_vs_exact_form(H, W, masked):
+    """csrc/track.hip: the band-split sums of the persistent level kernel (inlier / outlier sums formed while the last digit of the
+    median is still open, the undecided pixels listed and added exactly afterwards: two device-wide synchronisations per
+    iteration) against the exact form of the same kernel (`como_track_level_set_split(0)`: scale first, sums afterwards) and
+    against the per-iteration chain: same iteration count and stop decision, pose / affine within float32 summation noise --
+    also when the list overflows (`como_track_level_debug_amb_cap`: 0 and 1 entries -> the exact form runs after the split pass)."""
+    import como_amd.odom.frontend.photo_tracking as pt
+    from como_amd import _lib
+    from tests.test_gpu_r2 import _tracking_level_inputs
+    L = _lib.lib()
+    L.como_track_level_workspace_bytes()                       # (reads COMO_TRACK_SPLIT on the first launch only: prime the switch below)
+    tp, K, P, vals, J = _tracking_level_inputs(H, W, 5)
+    aff = torch.zeros((1, 2, 1), device=DEV)
+    mask = None
+    if masked:
+        g = torch.Generator().manual_seed(2)
+        mask = (torch.rand(P.shape[1], generator=g) < 0.7).to(torch.uint8).to(DEV)
+    term = {"max_iter": 50, "delta_norm": 1e-3, "rel_tol": 1e-3, "grad_norm": 1.0}
+    term6 = {"max_iter": 6, "delta_norm": 0.0, "rel_tol": 0.0, "grad_norm": 0.0}
+
+    def run(tc, fused):
+        T, a = pt.photo_level_tracking(tp["Tji_init"], aff, vals, P, J.clone(), tp["img_cur"], K, 0.1, tc, in_mask=mask, fused=fused)
+        if not fused:
+            return T, a, pt.photo_level_tracking.last_iters, 0
+        rec = pt.photo_level_tracking.last_out.cpu()
+        return T, a, int(rec[105]), int(rec[104])
+
+    Tc, ac, itc, _ = run(term, False)
+    T6c, _, _, _ = run(term6, False)
+    out = {}
+    prev = L.como_track_level_set_split(0)
+    try:
+        for name, split, cap in (("split", 1, -1), ("exact", 0, -1), ("overflow0", 1, 0), ("overflow1", 1, 1)):
+            L.como_track_level_set_split(split)
+            L.como_track_level_debug_amb_cap(cap)
+            out[name] = run(term, True), run(term6, True)
+    finally:
+        L.como_track_level_set_split(prev)
+        L.como_track_level_debug_amb_cap(-1)
+    errs = {n: ((r[0][0] - Tc).abs().max().item(), (r[0][1] - ac).abs().max().item(), (r[1][0] - T6c).abs().max().item())
+            for n, r in out.items()}
+    report("band_split_level", H=H, W=W, masked=masked, iters_chain=itc, iters={n: r[0][2] for n, r in out.items()},
+           status={n: r[0][3] for n, r in out.items()}, errs=errs,
+           split_vs_exact=(out["split"][0][0] - out["exact"][0][0]).abs().max().item())
+    for n, r in out.items():
+        assert r[0][3] == 0 and r[1][3] == 0 and r[0][2] == itc and r[1][2] == 6, n
+        assert max(errs[n]) < 2e-6, n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,W", [(480, 640), (97, 131), (192, 256)])
+def test_frame_pyramid_in_one_launch_equals_the_chain(H, W):
+    """csrc/image.hip frame_pyramid3_kernel (the head of the tracker's frame graph: luma + both blur_down levels + the clears of the
+    level kernels' barrier workspaces, one launch) against Tracking.prep_tracking_img's chain (rgb_to_grayscale + ImagePyramidModule:
+    three launches): the three images are identical bit for bit, odd sizes included; the listed buffers are cleared."""
+    import ctypes
+    from como_amd import _lib
+    from como_amd.utils import image_processing as ip
+    g = torch.Generator().manual_seed(H + W)
+    rgb = torch.rand((1, 3, H, W), generator=g).to(DEV)
+    ref = ip.ImagePyramidModule(1, 0, 3, DEV, torch.float32)(ip.rgb_to_grayscale(rgb))            # [coarse .. fine]
+    H1, W1 = (H + 1) // 2, (W + 1) // 2
+    gray = torch.empty((1, 1, H, W), device=DEV)
+    l1 = torch.empty((1, 1, H1, W1), device=DEV)
+    l2 = torch.empty((1, 1, (H1 + 1) // 2, (W1 + 1) // 2), device=DEV)
+    bufs = [torch.full((n,), 7, dtype=torch.int32, device=DEV) for n in (4, 26432, 4096 * 3)]
+    ptrs = (ctypes.c_void_p * 3)(*[b.data_ptr() for b in bufs])
+    nb = (ctypes.c_long * 3)(*[b.numel() * 4 for b in bufs])
+    rc = _lib.lib().como_track_frame_pyramid3_f32(rgb.data_ptr(), gray.data_ptr(), l1.data_ptr(), l2.data_ptr(), H, W, ptrs, nb, 3,
+                                                  _lib.stream_ptr(torch.device(DEV)))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert [tuple(t.shape) for t in ref] == [tuple(l2.shape), tuple(l1.shape), tuple(gray.shape)]
+    assert torch.equal(ref[2], gray) and torch.equal(ref[1], l1) and torch.equal(ref[0], l2)
+    assert all(int(b.abs().max()) == 0 for b in bufs)
