@@ -657,6 +657,9 @@ class Mapping:
             rgb, pose_curr_kf, aff_curr_kf, kf_timestamp, timestamp = data[1:]
             if data[0] == "keyframe" and _ASYNC_NETWORK and rgb.is_cuda:
                 self.start_model(rgb)                         # (float(rgb) is what run_model reads, whatever add_keyframe gets)
+                hook = getattr(self, "while_network_runs", None)
+                if hook is not None:                          # (sequential.py: the tracker prepares its side of the new keyframe now)
+                    hook(timestamp, rgb)
             k = self.find_kf_from_timestamp(kf_timestamp)
             pose_w, aff_w = self.get_curr_world_state(pose_curr_kf, aff_curr_kf, k)
             if data[0] == "one-way":
@@ -729,8 +732,9 @@ class Mapping:
                                     rec_capacity=self.cfg["graph"]["num_one_way_frames"],
                                     band_median=self.cfg.get("band_median", False))
             self._ba_prev = None
-            # (`median_ahead: true`: the next iteration's full-image median streamed right after this one's update.  Off by default:
-            # in the eager loop the median branch already hides beside the block kernel -- measured no gain)
+            # (`median_ahead`: "gap" -- the sequential loop's default, sequential.py -- the next iteration's full-image median is
+            # streamed into a one-way frame's hand-over (median_ahead_now); "end" / True: right after every iteration's update --
+            # measured no gain: in the eager loop the median branch already hides beside the block kernel)
             self._ba.median_ahead = self.cfg.get("median_ahead", False)
         ba = self._ba
         ba.step()

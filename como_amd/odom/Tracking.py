@@ -175,6 +175,27 @@ class Tracking:
         ok = _in_image(p, depth, self.img_size, 0, 0.0, strict=True)
         return fill_image(swap_coords_xy(p)[ok, :], depth[ok, :], self.img_size)
 
+    def _kf_images(self, kf_rgb):
+        """Intensities, gradients and pixel coordinates of the keyframe image(s) at every pyramid level (Tracking.py:203-222)."""
+        coords_pyr, vals_pyr, img_grads_pyr = [], [], []
+        for lvl in self.prep_tracking_img(kf_rgb):
+            gx, gy = self.gradient_module(lvl)
+            b, c, h, w = lvl.shape
+            flat = lambda t: t.reshape(b, c, h * w).permute(0, 2, 1)       # (B,N,C), row-major pixel order
+            vals_pyr.append(flat(lvl).contiguous())
+            img_grads_pyr.append(torch.stack((flat(gx), flat(gy)), dim=-1).contiguous())
+            coords_pyr.append(get_test_coords((h, w), device=self.device, batch_size=b))
+        return coords_pyr, vals_pyr, img_grads_pyr
+
+    def prepare_kf_images(self, timestamp, rgb):
+        """The image half of `update_kf_reference` for the frame that was just sent to the mapper as a keyframe (one reference
+        keyframe: `track_ref.num_keyframes: 1`), AHEAD of the mapper's answer: it only depends on the frame itself.  The sequential
+        loop calls it while the covariance network of the insertion runs (`Mapping.while_network_runs`): ~30 torch calls that
+        otherwise sit in the host-bound tail of a keyframe frame, behind the window's first iteration, with the device idle.
+        `update_kf_reference` adopts the result when timestamp, shape and element type are those of the image it receives."""
+        rgb = rgb.to(self.dtype) if rgb.dtype != self.dtype else rgb
+        self._kf_img_ahead = (timestamp, tuple(rgb.shape), rgb.dtype, self._kf_images(rgb))
+
     # ---- new reference keyframe(s) from mapping (Tracking.py:187-313) ------------------------------------------------
     def update_kf_reference(self, kf_data):
         timestamps, kf_rgb, kf_pose, kf_aff, depth = kf_data
@@ -191,14 +212,12 @@ class Tracking:
             self.last_kf_sent_ts = timestamps[-1]
 
         if timestamps[-1] != self.kf_received_ts:          # new image(s): intensities and gradients at every pixel
-            self.coords_pyr, self.vals_pyr, self.img_grads_pyr = [], [], []
-            for lvl in self.prep_tracking_img(kf_rgb):
-                gx, gy = self.gradient_module(lvl)
-                b, c, h, w = lvl.shape
-                flat = lambda t: t.reshape(b, c, h * w).permute(0, 2, 1)       # (B,N,C), row-major pixel order
-                self.vals_pyr.append(flat(lvl).contiguous())
-                self.img_grads_pyr.append(torch.stack((flat(gx), flat(gy)), dim=-1).contiguous())
-                self.coords_pyr.append(get_test_coords((h, w), device=self.device, batch_size=b))
+            ah, self._kf_img_ahead = getattr(self, "_kf_img_ahead", None), None
+            if (ah is not None and ah[0] == timestamps[-1] and nk == 1 and kf_rgb is not None and tuple(kf_rgb.shape) == ah[1] and
+                    kf_rgb.dtype == ah[2]):
+                self.coords_pyr, self.vals_pyr, self.img_grads_pyr = ah[3]     # (`prepare_kf_images`: the same calls on the same frame)
+            else:
+                self.coords_pyr, self.vals_pyr, self.img_grads_pyr = self._kf_images(kf_rgb)
 
         self.P_pyr, self.dI_dT_pyr, self.mask_pyr = [], [], []
         pb = None

@@ -54,9 +54,11 @@ class ComoSeq:
     def __init__(self, slam_cfg, intrinsics, img_size, model=None):
         self.tracking = TrackingSeq(slam_cfg["tracking"], intrinsics.clone(), img_size)
         mcfg = slam_cfg["mapping"]
-        mode = os.environ.get("COMO_MEDIAN_AHEAD_MODE")       # (measurement switch: "gap" / "end" without editing the configuration)
-        if mode and "median_ahead" not in mcfg:
-            mcfg = dict(mcfg, median_ahead=mode)
+        # the next iteration's full-image median streamed into the host-bound hand-over of a one-way frame (Mapping.median_ahead_now):
+        # on unless the configuration says otherwise (`median_ahead: false | gap | end`; COMO_MEDIAN_AHEAD_MODE=off|gap|end for A/B)
+        mode = os.environ.get("COMO_MEDIAN_AHEAD_MODE", "gap")
+        if "median_ahead" not in mcfg:
+            mcfg = dict(mcfg, median_ahead=(False if mode in ("off", "0", "") else mode))
         self.mapping = MappingSeq(mcfg, intrinsics.clone())
         self.tracking.setup()
         self.mapping.setup(model)
@@ -66,6 +68,9 @@ class ComoSeq:
             # one process, one device: while the tracker waits for a frame's result the mapper prepares the window that frame
             # would need as a one-way frame (Mapping.speculate_one_way)
             self.tracking.while_waiting = self.mapping.speculate_one_way
+            if os.environ.get("COMO_KF_IMAGES_AHEAD", "1") != "0" and slam_cfg["mapping"].get("track_ref", {}).get("num_keyframes", 1) == 1:
+                # ... and the tracker prepares its pyramids of a new keyframe's image while the insertion's network runs
+                self.mapping.while_network_runs = self.tracking.prepare_kf_images
             if self.mapping.cfg.get("median_ahead", False) == "gap":
                 self.tracking.after_decision = self.mapping.median_ahead_now
 

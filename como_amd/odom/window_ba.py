@@ -646,6 +646,10 @@ class WindowBA:
     def linearize_fused(self):
         L, a, w, dev = _lib.lib(), self.win_args, self.w, self.dev
         s = _lib.stream_ptr(dev)
+        if self._ahead is not None:
+            # a median streamed ahead computed its log-depths from the landmarks as they stand: the scaffold launch below moves the
+            # re-initialised ones (win_apply_reinit) -- not before that read is done (back-to-back iterations; long done in the loop)
+            torch.cuda.current_stream(dev).wait_event(self._ahead)
         _lib.check(L.como_win_scaffold(ctypes.byref(a), s), "como_win_scaffold")
         if not a.zero_c:
             self.sysfix.zero_()
@@ -948,9 +952,11 @@ class WindowBA:
         ss = side.cuda_stream
         _lib.check(_lib.lib().como_win_logz_ahead(ctypes.byref(self.win_args), st["scratch"].data_ptr(), st["nb"], st["lz"].data_ptr(),
                                                   st["hist"].data_ptr(), st["hb"], ss), "como_win_logz_ahead")
+        read = torch.cuda.Event()
+        read.record(side)                                    # (the state has been read: the next scaffold's re-initialisation may write it)
         _lib.check(st["fn"](*st["args"], ss), "como_dense_ref (depth only, ahead)")
         AHEAD_STATS["issued"] += 1
-        self._ahead = True
+        self._ahead = read
 
     def check_solver(self):
         """Read the status of the last solve (one host synchronisation) and act on it -- the reference swallows it

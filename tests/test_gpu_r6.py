@@ -568,21 +568,21 @@ def test_median_streamed_ahead_equals_the_in_iteration_one(monkeypatch):
     import scripts.ate_sequence as ats
     from scripts.ate_sequence import run_ate_sequence
     loop_cfgs = ats.loop_cfgs
-
-    def cfgs_with_ahead(*a, **k):
-        c = loop_cfgs(*a, **k)
-        c["mapping"]["median_ahead"] = True
-        return c
-    monkeypatch.setattr(ats, "loop_cfgs", cfgs_with_ahead)
     monkeypatch.setattr(wba, "_MEDIAN_AHEAD", 2)
-    for k in wba.AHEAD_STATS:
-        wba.AHEAD_STATS[k] = 0
     G = load_golden("ate_sequence.npz")
-    kinds, poses, odo = run_ate_sequence(G, "float")
-    stats = dict(wba.AHEAD_STATS)
-    report("median_ahead_loop", **stats)
-    assert kinds == [int(x) for x in G["kinds"]]
-    assert stats["adopted"] >= 30 and stats["checked"] == stats["adopted"] and stats["mismatch"] == 0
+    for mode, least in (("gap", 8), ("end", 30)):           # "gap": one-way frames only (the sequential loop's default)
+        def cfgs_with_ahead(*a, **k):
+            c = loop_cfgs(*a, **k)
+            c["mapping"]["median_ahead"] = mode
+            return c
+        monkeypatch.setattr(ats, "loop_cfgs", cfgs_with_ahead)
+        for k in wba.AHEAD_STATS:
+            wba.AHEAD_STATS[k] = 0
+        kinds, poses, odo = run_ate_sequence(G, "float")
+        stats = dict(wba.AHEAD_STATS)
+        report("median_ahead_loop", mode=mode, **stats)
+        assert kinds == [int(x) for x in G["kinds"]]
+        assert stats["adopted"] >= least and stats["checked"] == stats["adopted"] and stats["mismatch"] == 0
 
 
 # ---------------------------------------------------------------------------------------------------------------------
