@@ -114,10 +114,11 @@ __global__ __launch_bounds__(256) void blur_down_kernel(const T* __restrict__ im
 
 // The tracker's image pyramid of ONE colour frame in one launch (Tracking.prep_tracking_img, como/odom/Tracking.py:103-107:
 // rgb_to_grayscale + ImagePyramidModule with three levels): gray (H,W), level 1 = blur_down(gray), level 2 = blur_down(level 1).
-// One thread per level-1 pixel: it writes its 2x2 block of luma values, its own level-1 value, and -- where both coordinates are even
-// -- the level-2 value, re-evaluating the level-1 neighbours (and the luma values under them) it needs instead of waiting for the
-// threads that own them: the same expressions on the same inputs (rgb_luma / blur9) give the same bits wherever they are evaluated,
-// so the three images equal the three-launch chain's (tested).  The frame graph's head was three dependent launches of ~4.7 us for
+// One workgroup per 16 x 16 tile of level 1: every thread evaluates one (or two) of the 17 x 17 level-1 values the tile's level-2
+// stencils touch -- the luma values under them re-evaluated from the colour planes instead of waiting for a neighbour -- writes the
+// ones the tile owns together with their 2 x 2 luma blocks, and 64 threads form the level-2 pixels from LDS: the same expressions on
+// the same inputs (rgb_luma / blur9) give the same bits wherever they are evaluated, so the three images equal the three-launch
+// chain's (tested).  (A first form -- a thread per level-1 pixel re-evaluating 81 luma values for its level-2 pixel -- took 14.5 us.)  The frame graph's head was three dependent launches of ~4.7 us for
 // ~1 us of work; `z` clears up to eight small buffers in the same launch (the level kernels' barrier workspaces and the select
 // histograms of the frame: four more launches).
 struct ZeroList { uint4* p[8]; long n16[8]; int n; };
@@ -129,33 +130,46 @@ __device__ __forceinline__ float rgb_luma(const float* __restrict__ rgb, long HW
 }
 __global__ __launch_bounds__(256) void frame_pyramid3_kernel(const float* __restrict__ rgb, float* __restrict__ gray,
                                                              float* __restrict__ l1, float* __restrict__ l2, int H, int W, ZeroList z) {
-  const long gtid = (long)blockIdx.x * 256 + threadIdx.x, gsz = (long)gridDim.x * 256;
+  // one workgroup = a 16 x 16 tile of level 1 (its 32 x 32 luma block, its 8 x 8 level-2 pixels): the 17 x 17 level-1 values the
+  // level-2 stencils touch (reflected at the level-1 border, as blur_down does) go through LDS
+  __shared__ float t1[17][18];
+  const int tid = threadIdx.x;
+  const long nwg = (long)gridDim.x * gridDim.y, gtid = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid, gsz = nwg * 256;
   for (int k = 0; k < z.n; ++k)
     for (long e = gtid; e < z.n16[k]; e += gsz) z.p[k][e] = make_uint4(0u, 0u, 0u, 0u);
   const int H1 = (H + 1) / 2, W1 = (W + 1) / 2, H2 = (H1 + 1) / 2, W2 = (W1 + 1) / 2;
-  if (gtid >= (long)H1 * W1) return;
   const long HW = (long)H * W;
-  const int x1 = (int)(gtid % W1), y1 = (int)(gtid / W1);
-  // level-1 value at (xx, yy) from the luma values around (2 xx, 2 yy)
-  auto lvl1 = [&](int xx, int yy) -> float {
-    const int x = 2 * xx, y = 2 * yy;
+  const int tx0 = blockIdx.x * 16, ty0 = blockIdx.y * 16;
+  for (int e = tid; e < 17 * 17; e += 256) {
+    const int j = e / 17, i = e - j * 17;
+    const int x1 = tx0 - 1 + i, y1 = ty0 - 1 + j;                      // level-1 position of this halo entry
+    const int xr = reflect1(min(x1, W1), W1), yr = reflect1(min(y1, H1), H1);
+    const int x = 2 * xr, y = 2 * yr;
     const int xm = reflect1(x - 1, W), xp = reflect1(x + 1, W), ym = reflect1(y - 1, H), yp = reflect1(y + 1, H);
-    return blur9<float>(rgb_luma(rgb, HW, (long)ym * W + xm), rgb_luma(rgb, HW, (long)ym * W + x), rgb_luma(rgb, HW, (long)ym * W + xp),
-                        rgb_luma(rgb, HW, (long)y * W + xm), rgb_luma(rgb, HW, (long)y * W + x), rgb_luma(rgb, HW, (long)y * W + xp),
-                        rgb_luma(rgb, HW, (long)yp * W + xm), rgb_luma(rgb, HW, (long)yp * W + x), rgb_luma(rgb, HW, (long)yp * W + xp));
-  };
-#pragma unroll
-  for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-    for (int dx = 0; dx < 2; ++dx) {
-      const int x = 2 * x1 + dx, y = 2 * y1 + dy;
-      if (x < W && y < H) gray[(long)y * W + x] = rgb_luma(rgb, HW, (long)y * W + x);
+    const float mc = rgb_luma(rgb, HW, (long)y * W + x), mr = rgb_luma(rgb, HW, (long)y * W + xp);
+    const float bc = rgb_luma(rgb, HW, (long)yp * W + x), br = rgb_luma(rgb, HW, (long)yp * W + xp);
+    const float v = blur9<float>(rgb_luma(rgb, HW, (long)ym * W + xm), rgb_luma(rgb, HW, (long)ym * W + x), rgb_luma(rgb, HW, (long)ym * W + xp),
+                                 rgb_luma(rgb, HW, (long)y * W + xm), mc, mr, rgb_luma(rgb, HW, (long)yp * W + xm), bc, br);
+    t1[j][i] = v;
+    if (i >= 1 && j >= 1 && x1 < W1 && y1 < H1) {                      // this workgroup owns the pixel: level 1 and its 2 x 2 luma block
+      l1[(long)y1 * W1 + x1] = v;
+      gray[(long)y * W + x] = mc;
+      if (x + 1 < W) gray[(long)y * W + x + 1] = mr;
+      if (y + 1 < H) {
+        gray[(long)(y + 1) * W + x] = bc;
+        if (x + 1 < W) gray[(long)(y + 1) * W + x + 1] = br;
+      }
     }
-  l1[(long)y1 * W1 + x1] = lvl1(x1, y1);
-  if (!(x1 & 1) && !(y1 & 1)) {
-    const int xm = reflect1(x1 - 1, W1), xp = reflect1(x1 + 1, W1), ym = reflect1(y1 - 1, H1), yp = reflect1(y1 + 1, H1);
-    l2[(long)(y1 >> 1) * W2 + (x1 >> 1)] = blur9<float>(lvl1(xm, ym), lvl1(x1, ym), lvl1(xp, ym), lvl1(xm, y1), lvl1(x1, y1), lvl1(xp, y1),
-                                                        lvl1(xm, yp), lvl1(x1, yp), lvl1(xp, yp));
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int lx = tid & 7, ly = tid >> 3;
+    const int x2 = (tx0 >> 1) + lx, y2 = (ty0 >> 1) + ly;
+    if (x2 < W2 && y2 < H2) {
+      const int i = 2 * lx + 1, j = 2 * ly + 1;
+      l2[(long)y2 * W2 + x2] = blur9<float>(t1[j - 1][i - 1], t1[j - 1][i], t1[j - 1][i + 1], t1[j][i - 1], t1[j][i], t1[j][i + 1],
+                                            t1[j + 1][i - 1], t1[j + 1][i], t1[j + 1][i + 1]);
+    }
   }
 }
 
@@ -361,12 +375,10 @@ int como_track_frame_pyramid3_f32(const float* rgb, float* gray, float* l1, floa
       if (z.n16[k] > most) most = z.n16[k];
     }
   }
-  const long n1 = (long)((H + 1) / 2) * ((W + 1) / 2);
-  long threads = n1 > most ? n1 : most;
-  if (threads > 1L << 22) threads = 1L << 22;                // (the clears are grid-stride loops)
-  if (threads < n1) threads = n1;
-  hipLaunchKernelGGL(como::frame_pyramid3_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rgb, gray, l1,
-                     l2, H, W, z);
+  (void)most;                                                // (the clears are grid-stride loops over the tiles' threads)
+  const int H1 = (H + 1) / 2, W1 = (W + 1) / 2;
+  hipLaunchKernelGGL(como::frame_pyramid3_kernel, dim3((unsigned)((W1 + 15) / 16), (unsigned)((H1 + 15) / 16)), dim3(256), 0,
+                     (hipStream_t)stream, rgb, gray, l1, l2, H, W, z);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }

@@ -400,7 +400,9 @@ class Mapping:
                 mirror.shape == self.Knm_Kmminv.shape):
             Kt = mirror[lo:hi]
             b, h, w, m = Kt.shape
-            return depth_image(Kt.reshape(b, h * w, m), self.logzm[lo:hi]).reshape(b, 1, h, w)
+            lp = getattr(self, "_logzm_pix", None)
+            lz = lp[0][lo:hi] if (lp is not None and lp[1] is self.logzm and lp[0].shape[0] == self.logzm.shape[0]) else self.logzm[lo:hi]
+            return depth_image(Kt.reshape(b, h * w, m), lz).reshape(b, 1, h, w)
         Kt = self.Knm_Kmminv[lo:hi]
         b, h, w, m = Kt.shape
         return depth_image(Kt.reshape(b, h * w, m), self.logzm[lo:hi]).reshape(b, 1, h, w)   # one pass over K~ (csrc/densify.hip)
@@ -755,6 +757,10 @@ class Mapping:
         self.kf_pairs, self.one_way_pairs = ba.kf_pairs, ba.one_way_pairs
         if "pm" in sn:
             self.pm, self.logzm = sn["pm"], sn["logzm"].unsqueeze(-1)
+            # (the scaffold's float32 mirror of these very log-depths -- the window's live buffer, valid until its next scaffold: the
+            # tracker's depth image is formed from it right below, without the cast launch `depth_image` would need)
+            pl = ba.w.get("px_logzm") if isinstance(getattr(ba, "w", None), dict) else None
+            self._logzm_pix = (pl, self.logzm) if (pl is not None and pl.dtype == torch.float32 and pl.shape[0] == B) else None
         else:
             self.pm, self.logzm = ba.pm.to(self.dtype).clone(), ba.logzm.to(self.dtype).clone()
         self._depth_cache = None

@@ -93,6 +93,13 @@ class ComoSeq:
                 # same keyframe image(s) as last time: the tracker only reads the poses and the depth (update_kf_reference),
                 # so the window's colour images are not converted to its element type again on every frame
                 kf_ref = (kf_ref[0], None) + tuple(kf_ref[2:])
+            pose, aff = kf_ref[2], kf_ref[3]
+            if (torch.is_tensor(pose) and torch.is_tensor(aff) and pose.is_cuda and aff.is_cuda and pose.dtype == aff.dtype != trk.dtype and
+                    pose.device == aff.device == torch.device(trk.device)):
+                # the keyframe pose and affine parameters in the tracker's element type: both conversions in one launch
+                p2, a2 = torch.empty_like(pose, dtype=trk.dtype), torch.empty_like(aff, dtype=trk.dtype)
+                torch._foreach_copy_([p2, a2], [pose, aff])
+                kf_ref = tuple(kf_ref[:2]) + (p2, a2) + tuple(kf_ref[4:])
             trk.update_kf_reference(transfer_data(kf_ref, trk.device, trk.dtype))
         if kf_viz is not None:
             self.last_kf_viz = kf_viz
