@@ -99,6 +99,7 @@ SIGNATURES = {
     "como_track_frame_pyramid3_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "como_track_level_probe": (c_int, []),
     "como_track_level_set_local": (c_int, [c_int]),
+    "como_track_level_set_one": (c_int, [c_int]),
     "como_track_level_set_split": (c_int, [c_int]),
     "como_track_level_debug_amb_cap": (None, [c_int]),
     "como_track_level_local_state": (c_int, []),

@@ -477,6 +477,22 @@ __device__ __forceinline__ float wave_reduce48(const float (&a)[48], int lane) {
   return k[0];
 }
 
+// 24 values per lane: five halving steps, then one butterfly add -- lanes l and l ^ 1 both hold the complete sum of the value
+// with index wr_index24(l) (>= 24: padding)
+__device__ __forceinline__ int wr_index24(int lane) {
+  return ((lane & 2) << 3) | ((lane & 4) << 1) | ((lane & 8) >> 1) | ((lane & 16) >> 3) | ((lane & 32) >> 5);
+}
+__device__ __forceinline__ float wave_reduce24(const float (&a)[24], int lane) {
+  float d[12], e[6], f[3], g[4], h[2], k[1];
+  wr_step<24>(a, d, 32, (lane & 32) != 0);
+  wr_step<12>(d, e, 16, (lane & 16) != 0);
+  wr_step<6>(e, f, 8, (lane & 8) != 0);
+  g[0] = f[0]; g[1] = f[1]; g[2] = f[2]; g[3] = 0.f;
+  wr_step<4>(g, h, 4, (lane & 4) != 0);
+  wr_step<2>(h, k, 2, (lane & 2) != 0);
+  return k[0] + __shfl_xor(k[0], 1, 64);
+}
+
 typedef float tl_f2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void track_level_kernel(
@@ -878,6 +894,13 @@ __global__ __launch_bounds__(256) void track_level_kernel(
     // ---- phase E (every workgroup, identically): 8x8 Cholesky, T <- T Exp(-delta), stop test ----
     __syncthreads();
     TL_STAMP(13);
+    // (H and g of the record: one entry per lane of wave 1, beside the solve on lane 0 of wave 0 -- as a loop on that one lane,
+    // behind the solve, the 80 dependent LDS round trips were 1.4 us of every iteration)
+    if (bidx == 0 && wv == 1) {
+      const int a = lane >> 3, b = lane & 7;
+      rec_s[lane] = (T)tot[a <= b ? trk_q(a, b) : trk_q(b, a)];
+      if (lane < 8) rec_s[64 + lane] = (T)tot[36 + lane];
+    }
     if (tid == 0) {
       TrkSolve S;
       trk_solve8<T>(tot, Tc, S);
@@ -891,8 +914,9 @@ __global__ __launch_bounds__(256) void track_level_kernel(
       state[19] = (T)sqrt(S.gn);
       state[20] = (T)sqrt(S.dn);
       if (bidx == 0) {                                         // the record of this iteration, layout of como_track_iter_*
-        trk_store_Hg<T>(tot, rec_s);
+#pragma unroll
         for (int i = 0; i < 8; ++i) rec_s[72 + i] = (T)S.d[i];
+#pragma unroll
         for (int i = 0; i < 16; ++i) rec_s[80 + i] = state[i];
         rec_s[96] = state[16]; rec_s[97] = state[17];
         rec_s[98] = state[18]; rec_s[99] = state[19]; rec_s[100] = (T)tot[44];
@@ -931,6 +955,386 @@ __global__ __launch_bounds__(256) void track_level_kernel(
   }
 }
 
+// ---------------------------------- one pyramid level in ONE WORKGROUP (the coarsest level) ------------------------------------
+// A level of at most TL1_CAP elements (80x60 gray = 4800) fits ONE workgroup: the pixel waves keep their elements in LDS planes +
+// registers, the three digit histograms of the exact median live in LDS, the 46 sums go wave tree -> LDS -> one fixed sum over the
+// waves -- every dependency point of an iteration is a __syncthreads.  Nothing crosses workgroups: no workspace, no atomics outside
+// LDS, no placement assumption, no time-out.  The XCD-local form spends ~8 of its ~19 us per iteration at this size on exchanges
+// (flush 1.2 + 0.6, barriers 0.7 + 2.9 + 1.7, counters fetched from L2: profiles/r6b_track_stamps.txt).
+// WAVE SPECIALISATION: the last wave holds no pixels -- it resolves the median's digits from the LDS histograms (32 bins per lane, one
+// wave scan), sums the waves' partials and runs the 8x8 solve + pose update (one lane, float64, > 128 live registers with the SE(3)
+// exponential); the pixel waves run the same loop skeleton (tl1_loop<NT, true / false>: ONE source for both, so the barrier
+// sequences agree by construction) without any of it, so their registers are not spilled around the solve.
+// One compute unit has 64 float32 lanes: the level is bound by its INSTRUCTION count (4800 elements x ~200 per iteration), hence the
+// packed (two-lane) multiply-adds of the sums and the one-wave digit resolution.
+// Same arithmetic per pixel as track_level_kernel / the como_track_iter_* chain (photo_tracking.py:117-185); the per-thread partial
+// sums follow this kernel's element -> thread assignment (element i -> pixel thread i % PT), a fixed order.
+constexpr int TL1_CAP = 4800;       // elements (80x60 gray): 15 pixel waves x 64 lanes x 5
+constexpr int TL1_PLANES = 7;       // X Y Z I_ref J0 J1 J2 in LDS (131 KB); J3 J4 J5 J7 in registers
+struct Sel1Scratch { uint32_t bin[3]; uint32_t hit; };
+struct TL1Shared {
+  uint32_t *lh0, *lh1, *lh2;
+  Sel1Scratch* sc;
+  float* redw;         // [pixel waves][48], packed order (tl1_packed_pos)
+  double* tot;         // [TRK_ACC]
+  float* state;        // 16 T | 2 aff | mse | gnorm | dnorm
+  float* rec_s;        // [112]
+  float* planes;       // [TL1_PLANES][TL1_CAP]
+};
+
+// one digit of the k-th key from a COMPLETE LDS histogram of NB bins, by ONE wave: lane l owns bins [l NB / 64, (l + 1) NB / 64)
+template <int NB>
+__device__ __forceinline__ uint32_t tl1_resolve_wave(const uint32_t* lh, uint32_t& k_rem, uint32_t* total, int lane) {
+  constexpr int PER = NB / 64;
+  uint32_t c[PER], local = 0;
+#pragma unroll
+  for (int j = 0; j < PER; j += 4) {
+    const uint4 v = *reinterpret_cast<const uint4*>(&lh[lane * PER + j]);
+    c[j] = v.x; c[j + 1] = v.y; c[j + 2] = v.z; c[j + 3] = v.w;
+    local += (v.x + v.y) + (v.z + v.w);
+  }
+  uint32_t incl = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  const uint32_t tot = __shfl(incl, 63, 64);
+  if (total) { *total = tot; k_rem = tot ? (tot - 1) / 2 : 0; }          // first digit: lower median of all valid keys
+  const uint32_t excl = incl - local;
+  const bool hit = local > 0 && k_rem >= excl && k_rem < excl + local;
+  uint32_t bin = 0, below = 0, run = excl;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    if (k_rem >= run && k_rem < run + c[j]) { bin = lane * PER + j; below = run; }
+    run += c[j];
+  }
+  const unsigned long long m = __ballot(hit ? 1 : 0);
+  const int src = m ? (int)__ffsll((long long)m) - 1 : 0;
+  bin = m ? __shfl(bin, src, 64) : 0u;
+  below = m ? __shfl(below, src, 64) : 0u;
+  k_rem -= below;
+  return bin;
+}
+
+// The 45 sums of one pixel in 23 two-lane accumulators (v_pk_fma_f32): rows of the upper triangle in pairs -- even rows start at an
+// even column (pairs (J0,J1) (J2,J3) (J4,J5) (J6,J7)), odd rows at an odd one (pairs (J1,J2) (J3,J4) (J5,J6) (J7,r): the last entry
+// is g[row]); the even rows' g entries and the error follow.  tl1_packed_pos(q) = position of sum q (trk_q order, 36 + a = g[a],
+// 44 = error) in that layout.
+__device__ __forceinline__ constexpr int tl1_row_base(int x) { return x == 0 ? 0 : x == 1 ? 4 : x == 2 ? 8 : x == 3 ? 11 : x == 4 ? 14 : x == 5 ? 16 : x == 6 ? 18 : 19; }
+__device__ __forceinline__ int tl1_packed_pos(int q) {
+  if (q == 44) return 44;
+  if (q >= 36) { const int a = q - 36; return (a & 1) ? 2 * (tl1_row_base(a) + (8 - a) / 2) + 1 : 40 + a / 2; }
+  int x = 0;
+  while (x < 7 && q >= trk_q(x + 1, x + 1)) ++x;
+  const int d = q - trk_q(x, x);                        // y - x
+  return 2 * (tl1_row_base(x) + d / 2) + (d & 1);
+}
+__device__ __forceinline__ void tl1_accumulate_pk(tl_f2 (&acc)[23], float w, const float (&J)[8], float r, float wr) {
+  const tl_f2 Je[4] = {{J[0], J[1]}, {J[2], J[3]}, {J[4], J[5]}, {J[6], J[7]}};
+  const tl_f2 Jo[4] = {{J[1], J[2]}, {J[3], J[4]}, {J[5], J[6]}, {J[7], r}};
+  float wa[8];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) wa[x] = w * J[x];
+#pragma unroll
+  for (int x = 0; x < 8; ++x) {
+    const tl_f2 w2 = {wa[x], wa[x]};
+#pragma unroll
+    for (int i = x / 2; i < 4; ++i) {
+      const int slot = tl1_row_base(x) + (i - x / 2);
+      acc[slot] = w2 * ((x & 1) ? Jo[i] : Je[i]) + acc[slot];
+    }
+  }
+  const tl_f2 r2 = {r, r};
+  acc[20] = tl_f2{wa[0], wa[2]} * r2 + acc[20];
+  acc[21] = tl_f2{wa[4], wa[6]} * r2 + acc[21];
+  acc[22] = tl_f2{w * wr, 0.f} * tl_f2{wr, 0.f} + acc[22];
+}
+
+#ifndef TL1_GROUP
+#define TL1_GROUP 4
+#endif
+#ifdef COMO_TL_PROFILE
+// tid 0 (a pixel wave) stamps slots 0..15, lane 0 of the solver wave slots 16..31 of iteration 3
+#define TL1_STAMP(k) do { if (it == 3 && (PIX ? tid == 0 : lane == 0)) stamps[(PIX ? 0 : 16) + (k)] = (long long)wall_clock64(); } while (0)
+#else
+#define TL1_STAMP(k) do { } while (0)
+#endif
+// The level's loop, ONE definition for the pixel waves (PIX) and the solver wave (!PIX): every __syncthreads below is executed by
+// both instantiations the same number of times (all branch conditions around them are uniform over the workgroup).
+template <int NT, bool PIX>
+__device__ __forceinline__ void tl1_loop(const TL1Shared sh, const float* __restrict__ Kmat, const float* __restrict__ P,
+                                         const float* __restrict__ vals_i, const float* __restrict__ img, int H, int W, int NE,
+                                         const float* __restrict__ J8, const uint8_t* __restrict__ in_mask, TLCriteria crit,
+                                         float* __restrict__ out, int C, long long* __restrict__ stamps) {
+  using T = float;
+  using KeyT = uint32_t;
+  constexpr int PW = NT / 64 - 1, PT = PW * 64;                  // pixel waves / threads
+  constexpr int MAXP = PIX ? (TL1_CAP + PT - 1) / PT : 1;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int HW = H * W;
+  float* const pXs = sh.planes;
+  float* const pYs = pXs + TL1_CAP;
+  float* const pZs = pYs + TL1_CAP;
+  float* const vrs = pZs + TL1_CAP;
+  float* const j0s = vrs + TL1_CAP;
+  float* const j1s = j0s + TL1_CAP;
+  float* const j2s = j1s + TL1_CAP;
+
+  T Jc[MAXP][4];
+  bool sel[MAXP];
+  int mypos = 0;                                                 // solver lane k < 45: where sum k sits in the packed order
+  if (PIX) {
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int i = k * PT + tid;
+      sel[k] = i < NE;
+      const int ic = sel[k] ? i : 0;
+      const int ip = C == 1 ? ic : (int)((unsigned)ic / (unsigned)C);
+      const float4 a = *reinterpret_cast<const float4*>(&J8[8 * ic]);
+      const float4 b = *reinterpret_cast<const float4*>(&J8[8 * ic + 4]);
+      if (sel[k]) {
+        pXs[i] = P[3 * ip]; pYs[i] = P[3 * ip + 1]; pZs[i] = P[3 * ip + 2];
+        vrs[i] = vals_i[ic];
+        j0s[i] = a.x; j1s[i] = a.y; j2s[i] = a.z;
+      }
+      Jc[k][0] = a.w; Jc[k][1] = b.x; Jc[k][2] = b.y; Jc[k][3] = b.w;     // J3 J4 J5 J7 (J6 = -exp(-a) I is per iteration)
+      if (sel[k] && in_mask) sel[k] = in_mask[ip] != 0;
+    }
+  } else {
+    mypos = tl1_packed_pos(lane < TRK_ACC - 1 ? lane : 0);
+  }
+  const T ax = T(1) / T(W), ay = T(1) / T(H);
+  T mse_prev = __builtin_inff();
+  int it = 0, spec_bin = -1;
+  uint32_t k_rem = 0, nv = 0;                                    // (carried by the solver wave)
+
+  while (true) {
+    // ---- warp, sample, residual, validity; first digit's histogram (+ the second digit's, speculated: see track_level_kernel) ----
+    TL1_STAMP(0);
+    for (int b = tid; b < SEL_BINS; b += NT) { sh.lh0[b] = 0; sh.lh1[b] = 0; sh.lh2[b] = 0; }
+    T Pm[12];
+    T ea = T(0), bb = T(0);
+    if (PIX) {
+      {
+#pragma clang fp contract(off)
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 4; ++j)
+            Pm[i * 4 + j] = dot3_seq(Kmat[i * 3 + 0], Kmat[i * 3 + 1], Kmat[i * 3 + 2], sh.state[0 * 4 + j], sh.state[1 * 4 + j],
+                                     sh.state[2 * 4 + j]);
+      }
+      ea = exp(-sh.state[16]);
+      bb = sh.state[17];
+    }
+    __syncthreads();
+    TL1_STAMP(1);
+    T rk[MAXP], j6[MAXP];
+    bool ok[MAXP];
+    if (PIX) {
+      // (straight-line over the thread's elements: their image gathers overlap; the histogram adds -- divergent -- come after)
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        const int i = k * PT + tid;
+        const int il = i < NE ? i : 0;           // (slots beyond the level are never written: read element 0, discarded by sel)
+        T hx, hy, hz;
+        rigid_apply(Pm, pXs[il], pYs[il], pZs[il], hx, hy, hz);
+        const T u = hx / hz, v = hy / hz;
+        ok[k] = sel[k] && in_image(u, v, H, W) && (hz > T(0));
+        Taps<T> t = make_taps(grid_position(u, W, ax), grid_position(v, H, ay), H, W);
+        const int choff = C == 1 ? 0 : (int)((unsigned)il % (unsigned)C) * HW;
+        const T It = tap_sum(img + choff, t);
+        const T tmp = ea * It;
+        j6[k] = -tmp;
+        rk[k] = (tmp + bb) - vrs[il];
+        if ((k % TL1_GROUP) == TL1_GROUP - 1) __builtin_amdgcn_sched_barrier(0);    // (bounds the gathers in flight: registers)
+      }
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        if (ok[k]) {
+          const KeyT key = abs_key(rk[k]);
+          const uint32_t d0 = sel_digit<KeyT>(key, 0);
+          atomicAdd(&sh.lh0[d0], 1u);
+          if ((int)d0 == spec_bin) atomicAdd(&sh.lh1[sel_digit<KeyT>(key, 1)], 1u);
+        }
+      }
+    }
+    TL1_STAMP(2);
+    __syncthreads();
+    TL1_STAMP(3);
+    // ---- exact lower median of |r| over the valid elements: three digits, histograms in LDS, resolved by the solver wave ----
+    KeyT prefix = 0;
+    if (!PIX) {
+      const uint32_t bin = tl1_resolve_wave<SEL_BINS>(sh.lh0, k_rem, &nv, lane);
+      const bool hit = (int)bin == spec_bin;
+      uint32_t bin1 = 0;
+      if (hit) bin1 = tl1_resolve_wave<SEL_BINS>(sh.lh1, k_rem, nullptr, lane);       // (the speculated histogram is complete)
+      if (lane == 0) { sh.sc->bin[0] = bin; sh.sc->bin[1] = bin1; sh.sc->hit = hit ? 1u : 0u; }
+    }
+    __syncthreads();
+    TL1_STAMP(4);
+    {
+      const uint32_t bin = sh.sc->bin[0];
+      prefix |= ((KeyT)bin) << SelCfg<KeyT>::shift(0);
+      const bool spec_hit = sh.sc->hit != 0;
+      const bool spec_dirty = spec_bin >= 0;
+      spec_bin = (int)bin;
+      if (!spec_hit) {
+        if (spec_dirty) {                                  // counts of the wrong first digit
+          for (int b = tid; b < SEL_BINS; b += NT) sh.lh1[b] = 0;
+          __syncthreads();
+        }
+        if (PIX) {
+#pragma unroll
+          for (int k = 0; k < MAXP; ++k) {
+            const KeyT key = abs_key(rk[k]);
+            if (ok[k] && sel_match<KeyT>(key, prefix, 1)) atomicAdd(&sh.lh1[sel_digit<KeyT>(key, 1)], 1u);
+          }
+        }
+        __syncthreads();
+        if (!PIX) {
+          const uint32_t bin1 = tl1_resolve_wave<SEL_BINS>(sh.lh1, k_rem, nullptr, lane);
+          if (lane == 0) sh.sc->bin[1] = bin1;
+        }
+        __syncthreads();
+      }
+      prefix |= ((KeyT)sh.sc->bin[1]) << SelCfg<KeyT>::shift(1);
+      TL1_STAMP(5);
+      if (PIX) {
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) {
+          const KeyT key = abs_key(rk[k]);
+          if (ok[k] && sel_match<KeyT>(key, prefix, 2)) atomicAdd(&sh.lh2[sel_digit<KeyT>(key, 2)], 1u);
+        }
+      }
+      __syncthreads();
+      TL1_STAMP(6);
+      if (!PIX) {
+        const uint32_t bin2 = tl1_resolve_wave<SEL_BINS / 2>(sh.lh2, k_rem, nullptr, lane);      // (10 bits)
+        if (lane == 0) sh.sc->bin[2] = bin2;
+      }
+      __syncthreads();
+      prefix |= ((KeyT)sh.sc->bin[2]) << SelCfg<KeyT>::shift(2);
+      TL1_STAMP(7);
+    }
+    const T sigma = T(1.4826) * key_value(prefix);
+    const T info_sqrt = T(1) / sigma;
+    // ---- robust weights, the 8x8 system's sums: 23 two-lane accumulators, one wave tree ----
+    if (PIX) {
+      tl_f2 acc[23];
+#pragma unroll
+      for (int q = 0; q < 23; ++q) acc[q] = tl_f2{0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        const int i = k * PT + tid;
+        const int il = i < NE ? i : 0;
+        // (an invalid element contributes exactly zero, also when it carries non-finite J / r: selected away, not multiplied)
+        const bool o = ok[k];
+        const T r = o ? rk[k] : T(0), wr = r * info_sqrt, w = huber(wr);
+        const T J[8] = {o ? j0s[il] : T(0), o ? j1s[il] : T(0), o ? j2s[il] : T(0), o ? Jc[k][0] : T(0), o ? Jc[k][1] : T(0),
+                        o ? Jc[k][2] : T(0), o ? j6[k] : T(0), o ? Jc[k][3] : T(0)};
+        tl1_accumulate_pk(acc, w, J, r, wr);
+      }
+      TL1_STAMP(8);
+      float a48[48];
+#pragma unroll
+      for (int q = 0; q < 23; ++q) { a48[2 * q] = acc[q].x; a48[2 * q + 1] = acc[q].y; }
+      a48[46] = 0.f; a48[47] = 0.f;
+      const float rr = wave_reduce48(a48, lane);
+      if (wr_index(lane) < 48) sh.redw[wv * 48 + wr_index(lane)] = rr;       // (64 lanes, 48 values: the rest is padding)
+      TL1_STAMP(9);
+    }
+    __syncthreads();
+    TL1_STAMP(10);
+    // ---- the solver wave: totals, 8x8 Cholesky, T <- T Exp(-delta), the iteration's record ----
+    if (!PIX) {
+      // fixed-order sum over the pixel waves; a non-finite sum poisons all of them (as the fixed-point shares of
+      // track_level_kernel: NaN totals -> info != 0)
+      double v = 0.0;
+      if (lane < TRK_ACC - 1) {
+#pragma unroll
+        for (int w = 0; w < PW; ++w) v += (double)sh.redw[w * 48 + mypos];
+      }
+      const bool bad = __any((lane < TRK_ACC - 1 && !(fabs(v) < 4.0e18)) ? 1 : 0) != 0;
+      if (bad) v = __builtin_nan("");
+      if (lane < TRK_ACC) sh.tot[lane] = lane < TRK_ACC - 1 ? v : 0.0;
+      // (LDS operations of one wave complete in order: lane 0 below reads what the other lanes have just written)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      TL1_STAMP(11);
+      // H (symmetric) and g of the record, one entry per lane
+      {
+        const int a = lane >> 3, b = lane & 7;
+        sh.rec_s[lane] = (T)sh.tot[a <= b ? trk_q(a, b) : trk_q(b, a)];
+        if (lane < 8) sh.rec_s[64 + lane] = (T)sh.tot[36 + lane];
+      }
+      if (lane == 0) {
+        const T a0 = sh.state[16], a1 = sh.state[17];
+        TrkSolve S;
+        trk_solve8<T>(sh.tot, sh.state, S);     // (reads the pose from LDS; `state` is rewritten from S below)
+        TL1_STAMP(14);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const T t = (T)S.Tn[i]; sh.state[i] = t; sh.rec_s[80 + i] = t; }
+        const T na0 = (T)((double)a0 - S.d[6]), na1 = (T)((double)a1 - S.d[7]);
+        const T mse = (T)(sh.tot[44] / (double)(nv / C));         // mean over valid pixels
+        const T gno = (T)sqrt(S.gn), dno = (T)sqrt(S.dn);
+        sh.state[16] = na0; sh.state[17] = na1; sh.state[18] = mse; sh.state[19] = gno; sh.state[20] = dno;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sh.rec_s[72 + i] = (T)S.d[i];
+        sh.rec_s[96] = na0; sh.rec_s[97] = na1;
+        sh.rec_s[98] = mse; sh.rec_s[99] = gno; sh.rec_s[100] = (T)sh.tot[44];
+        sh.rec_s[101] = sigma; sh.rec_s[102] = (T)(nv / C); sh.rec_s[103] = dno; sh.rec_s[104] = (T)S.info;
+        sh.rec_s[105] = (T)(it + 1);
+        TL1_STAMP(15);
+      }
+    }
+    __syncthreads();
+    TL1_STAMP(12);
+    if (tid < 106) out[tid] = sh.rec_s[tid];
+    const T mse = sh.state[18], gnorm = sh.state[19], dnorm = sh.state[20];
+    ++it;
+    // stop test: photo_tracking.py:166-180, float32 arithmetic as the reference's 0-dim tensors (every thread, identically)
+    const T rel = fabsf((mse_prev - mse) / mse_prev);
+    mse_prev = mse;
+#ifdef COMO_TL_PROFILE
+    if (it == 4 && (PIX ? tid == 0 : lane == 0)) stamps[(PIX ? 0 : 16) + 13] = (long long)wall_clock64();
+#endif
+    if (it >= crit.max_iter || dnorm < crit.delta_norm || rel < crit.rel_tol || gnorm < crit.grad_norm) break;
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void track_level_one_kernel(
+    const float* __restrict__ Tji_init, const float* __restrict__ Kmat, const float* __restrict__ aff_init,
+    const float* __restrict__ P, const float* __restrict__ vals_i, const float* __restrict__ img, int H, int W, long N,
+    const float* __restrict__ J8, const uint8_t* __restrict__ in_mask, TLCriteria crit, float* __restrict__ out, int C,
+    long long* __restrict__ stamps) {
+  constexpr int NWV = NT / 64;
+  // (keys are |r| bit patterns: the sign bit is clear, so the first digit uses 1024 of its 2048 bins, the last digit has 10 bits)
+  __shared__ __attribute__((aligned(16))) uint32_t lh0[SEL_BINS];
+  __shared__ __attribute__((aligned(16))) uint32_t lh1[SEL_BINS];
+  __shared__ __attribute__((aligned(16))) uint32_t lh2[SEL_BINS];
+  __shared__ Sel1Scratch sc;
+  __shared__ float redw[(NWV - 1) * 48];
+  __shared__ double tot[TRK_ACC];
+  __shared__ float state[24];
+  __shared__ float rec_s[112];
+  extern __shared__ __attribute__((aligned(16))) unsigned char tl1_dyn[];
+  const int tid = threadIdx.x;
+  if (tid < 16) state[tid] = Tji_init[tid];
+  else if (tid < 18) state[tid] = aff_init[tid - 16];
+  // the record starts as "no iteration done" (as track_level_kernel)
+  if (tid < 16) out[80 + tid] = Tji_init[tid];
+  else if (tid < 18) out[96 + (tid - 16)] = aff_init[tid - 16];
+  else if (tid == 18) out[104] = 0.f;
+  else if (tid == 19) out[105] = 0.f;
+  __syncthreads();
+  const TL1Shared sh{lh0, lh1, lh2, &sc, redw, tot, state, rec_s, reinterpret_cast<float*>(tl1_dyn)};
+  const int NE = (int)N * C;
+  if ((tid >> 6) == NWV - 1) tl1_loop<NT, false>(sh, Kmat, P, vals_i, img, H, W, NE, J8, in_mask, crit, out, C, stamps);
+  else tl1_loop<NT, true>(sh, Kmat, P, vals_i, img, H, W, NE, J8, in_mask, crit, out, C, stamps);
+}
+
 __global__ void xcc_probe_kernel(int* __restrict__ xcc) {
   if (threadIdx.x == 0) {
     unsigned id;
@@ -945,6 +1349,7 @@ static int g_track_local_enabled = 1;   // como_track_level_set_local
 static int g_track_local_debug = 0;     // como_track_level_debug_mismatch
 static int g_track_split = -1;          // como_track_level_set_split (-1: COMO_TRACK_SPLIT, default off)
 static int g_track_amb_cap = como::TL_AMB_CAP;   // como_track_level_debug_amb_cap
+static int g_track_one = -1;            // como_track_level_set_one (-1: COMO_TRACK_ONE, default 0 = off; 512 / 768 / 1024 = threads of the workgroup)
 
 extern "C" {
 
@@ -1010,6 +1415,39 @@ static int track_level_launch(const float* Tji_init, const float* K, const float
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return COMO_ERR_LAUNCH;
     ncu = prop.multiProcessorCount;
+  }
+  if (g_track_one < 0) {
+    // COMO_TRACK_ONE=512 / 768 / 1024: levels of at most 4800 elements in ONE workgroup of that many threads.  Default OFF --
+    // measured on MI355X at 80x60: 16.6 / 17.3 / 17.7 us per iteration against 17.4 for the XCD-local form on 19 compute units
+    // (one compute unit's 64 float32 lanes are instruction-bound at ~250 instructions per element: profiles/r6c_track_one.txt)
+    const char* e = getenv("COMO_TRACK_ONE");
+    g_track_one = e ? atoi(e) : 0;
+    if (g_track_one != 0 && g_track_one != 512 && g_track_one != 768) g_track_one = 1024;
+  }
+  if (g_track_one && NE <= TL1_CAP) {
+    // the coarsest level: ONE workgroup, everything in registers + LDS (no workspace, nothing to clear)
+    TLCriteria crit1{max_iter, delta_norm, rel_tol, grad_norm};
+    long long* stamps1 = (long long*)((uint32_t*)workspace + TL_BAR_WORDS + 2 * 6 * SEL_BINS) + TL_SUM_WORDS;   // (-DCOMO_TL_PROFILE only)
+    constexpr unsigned dyn = (unsigned)(TL1_PLANES * TL1_CAP * sizeof(float));   // 133 KB of planes (static LDS: 28 KB)
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)track_level_one_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+          hipFuncSetAttribute((const void*)track_level_one_kernel<768>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess ||
+          hipFuncSetAttribute((const void*)track_level_one_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess)
+        return COMO_ERR_LAUNCH;
+      attr = true;
+    }
+    if (g_track_one == 768)
+      hipLaunchKernelGGL(track_level_one_kernel<768>, dim3(1), dim3(768), dyn, s, Tji_init, K, aff_init, P, vals_i, img, H, W, N, J8,
+                         in_mask, crit1, out, channels, stamps1);
+    else if (g_track_one == 512)
+      hipLaunchKernelGGL(track_level_one_kernel<512>, dim3(1), dim3(512), dyn, s, Tji_init, K, aff_init, P, vals_i, img, H, W, N, J8,
+                         in_mask, crit1, out, channels, stamps1);
+    else
+      hipLaunchKernelGGL(track_level_one_kernel<1024>, dim3(1), dim3(1024), dyn, s, Tji_init, K, aff_init, P, vals_i, img, H, W, N, J8,
+                         in_mask, crit1, out, channels, stamps1);
+    COMO_CHECK_LAUNCH();
+    return COMO_OK;
   }
   long G = (NE + 255) / 256;
   const bool local = local_workspace && NE <= 32L * 256 * TL_MAXP && ncu >= 256 && como_track_level_probe() == 1 &&
@@ -1078,6 +1516,15 @@ int como_track_level_set_split(int enable) {
   const int prev = g_track_split;
   g_track_split = enable ? 1 : 0;
   return prev < 0 ? 0 : prev;
+}
+
+/* Levels of at most 4800 elements (80x60 gray) can run in ONE workgroup (track_level_one_kernel: LDS histograms, __syncthreads
+ * only): como_track_level_set_one(512 / 768 / 1024) picks that form and its workgroup size, 0 (the default: measured no faster)
+ * the multi-workgroup forms (A/B, tests; also COMO_TRACK_ONE); returns the previous setting. */
+int como_track_level_set_one(int threads) {
+  const int prev = g_track_one < 0 ? 0 : g_track_one;
+  g_track_one = (threads == 0 || threads == 512 || threads == 768) ? threads : 1024;
+  return prev;
 }
 
 /* The XCD-local form can be switched off for the rest of the process (the host does so when a level reports status -2 or a

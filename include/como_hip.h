@@ -205,6 +205,14 @@ void como_track_level_debug_mismatch(int on);
  * (0 .. 128, negative = default) so that the overflow path -- exact form after the split pass -- runs on ordinary data. */
 int como_track_level_set_split(int enable);
 void como_track_level_debug_amb_cap(int cap);
+/* A level of at most 4800 elements (N * channels; 80x60 gray, the coarsest level of a 640x480 frame) can run in ONE workgroup
+ * (csrc/track.hip track_level_one_kernel: pixel waves with their elements in LDS planes + registers and one solver wave; the median's
+ * digit histograms in LDS, the 46 sums through packed accumulators, a wave tree and LDS; every dependency point of
+ * photo_level_tracking's loop, photo_tracking.py:147-185, is a workgroup barrier; the workspaces are not touched).
+ * como_track_level_set_one(512 / 768 / 1024) selects that form and its workgroup size, 0 the multi-workgroup forms -- the DEFAULT:
+ * on MI355X the one-workgroup form measured 16.6 - 17.7 us per iteration against 17.4 (one compute unit is instruction-bound).
+ * COMO_TRACK_ONE sets the initial value; the call returns the previous setting. */
+int como_track_level_set_one(int threads);
 
 /* ------------------------------------------------------------------------------------------------
  * Window BA linearisation (python path: backend/photo.py:83-233 batch_photo_cost).

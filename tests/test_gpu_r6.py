@@ -662,3 +662,60 @@ def test_frame_pyramid_in_one_launch_equals_the_chain(H, W):
     assert [tuple(t.shape) for t in ref] == [tuple(l2.shape), tuple(l1.shape), tuple(gray.shape)]
     assert torch.equal(ref[2], gray) and torch.equal(ref[1], l1) and torch.equal(ref[0], l2)
     assert all(int(b.abs().max()) == 0 for b in bufs)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("H,W,c,masked", [(60, 80, 1, False), (60, 80, 1, True), (37, 53, 1, False), (30, 40, 3, True), (24, 32, 1, False)])
+def test_one_workgroup_level_kernel(H, W, c, masked):
+    """csrc/track.hip track_level_one_kernel: a level of at most 4800 elements (80x60 gray, the coarsest level of a 640x480 frame)
+    in ONE workgroup -- pixel waves + one solver wave, LDS histograms, workgroup barriers only -- in its three workgroup sizes against
+    the multi-workgroup form of the level kernel (`como_track_level_set_one(0)`) and the per-iteration chain: same iteration
+    count and stop decision, pose / affine within float32 summation noise, the same bits on a second launch; one more element
+    than the capacity goes through the multi-workgroup form."""
+    import como_amd.odom.frontend.photo_tracking as pt
+    from como_amd import _lib
+    from tests.test_gpu_r2 import _tracking_level_inputs
+    L = _lib.lib()
+    tp, K, P, vals, J = _tracking_level_inputs(H, W, 7)
+    img = tp["img_cur"]
+    if c > 1:                                             # c channels: one residual per (pixel, channel)
+        sc = torch.tensor([1.0, 0.8, 1.1], device=DEV)[:c]
+        img = (img[:, :1] * sc.view(1, c, 1, 1)).contiguous()
+        vals = (vals * sc.view(1, 1, c)).contiguous()
+        Jc = (J.reshape(1, -1, 1, 8) * sc.view(1, 1, c, 1)).contiguous()
+        Jc[..., 7] = J.reshape(1, -1, 1, 8)[..., 7]      # (the offset's derivative does not scale with the channel)
+        J = Jc
+    aff = torch.zeros((1, 2, 1), device=DEV)
+    mask = None
+    if masked:
+        g = torch.Generator().manual_seed(4)
+        mask = (torch.rand(P.shape[1], generator=g) < 0.7).to(torch.uint8).to(DEV)
+    term = {"max_iter": 50, "delta_norm": 1e-3, "rel_tol": 1e-3, "grad_norm": 1.0}
+    term6 = {"max_iter": 6, "delta_norm": 0.0, "rel_tol": 0.0, "grad_norm": 0.0}
+
+    def run(tc, fused):
+        T, a = pt.photo_level_tracking(tp["Tji_init"], aff, vals, P, J.clone(), img, K, 0.1, tc, in_mask=mask, fused=fused)
+        if not fused:
+            return T.clone(), a.clone(), pt.photo_level_tracking.last_iters, 0
+        rec = pt.photo_level_tracking.last_out.cpu()
+        return T.clone(), a.clone(), int(rec[105]), int(rec[104])
+
+    Tc, ac, itc, _ = run(term, False)
+    T6c, _, _, _ = run(term6, False)
+    out = {}
+    prev = L.como_track_level_set_one(0)
+    try:
+        for name, nt in (("multi", 0), ("one1024", 1024), ("one768", 768), ("one512", 512)):
+            L.como_track_level_set_one(nt)
+            out[name] = run(term, True), run(term6, True), run(term, True)
+    finally:
+        L.como_track_level_set_one(prev)
+    errs = {n: ((r[0][0] - Tc).abs().max().item(), (r[0][1] - ac).abs().max().item(), (r[1][0] - T6c).abs().max().item())
+            for n, r in out.items()}
+    report("one_workgroup_level", H=H, W=W, c=c, masked=masked, iters_chain=itc, iters={n: r[0][2] for n, r in out.items()},
+           status={n: r[0][3] for n, r in out.items()}, errs=errs,
+           one_vs_multi=(out["one1024"][0][0] - out["multi"][0][0]).abs().max().item())
+    for n, r in out.items():
+        assert r[0][3] == 0 and r[1][3] == 0 and r[0][2] == itc and r[1][2] == 6, n
+        assert max(errs[n]) < 2e-6, n
+        assert torch.equal(r[0][0], r[2][0]) and torch.equal(r[0][1], r[2][1]), n        # repeatable bits
