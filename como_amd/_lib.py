@@ -165,6 +165,8 @@ SIGNATURES = {
     "como_trsm_lower_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),
     "como_nn_conv2d_f32": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_int, c_void_p]),
     "como_nn_conv2d_fused_f32": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_int] + [c_void_p] * 3 + [c_float, c_void_p]),
+    "como_nn_conv2d_gn_f32": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p,
+                                      c_void_p]),
     "como_nn_gn_finalize_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float, c_void_p, c_void_p]),
     "como_nn_deep_part_floats": (c_long, [c_int] * 5),
     "como_nn_conv3x3_deep_f32": (c_int, [c_void_p] * 4 + [c_int] * 8 + [c_void_p, c_float, c_void_p, c_long, c_int, c_void_p, c_void_p,

@@ -32,6 +32,54 @@ typedef float nf4 __attribute__((ext_vector_type(4)));
 //   res: the epilogue of ResidualConv's 1x1 skip convolution adds the normalised main branch and applies the activation
 //        (layers.py:22-24: act(conv3(x) + norm(conv2(y)))): out = lrelu(conv + bias + res * rsc[c] + rsh[c]).
 // A ResidualConv is three launches (conv1, conv2 with PRO, conv3 with res) instead of five, and two tensor round trips shorter.
+// Round 6: the scale / shift of the GroupNorm that follows a wide-level convolution are formed INSIDE that convolution by its last
+// wave (gn_finalize_kernel's arithmetic, value for value) -- the separate one-workgroup launch was 4.7 us of dependent latency per
+// normalisation, twelve times per forward.  Protocol: a wave adds its statistics with RETURNING agent-scope atomics (the returned
+// value comes from the memory side, where the read-modify-write was performed: once the wave holds it the add is globally done),
+// then arrives on a counter that lives right behind the 32 slots (zeroed with them); the wave that finds total - 1 earlier
+// arrivals reads every slot with agent-scope loads (first touch of those lines by this kernel: nothing stale in an XCD's L2).
+struct GnFin {
+  const float* gamma;
+  const float* beta;
+  float2* scsh;         // nullptr: no in-kernel finalisation (como_nn_gn_finalize_f32 does it)
+  float eps;
+};
+__device__ __forceinline__ void gn_arrive_finalize(double* __restrict__ gn_sums, int N, int C, int G, int HW, unsigned total,
+                                                   const GnFin& f, int lane) {
+  unsigned* cnt = reinterpret_cast<unsigned*>(gn_sums + (long)32 * N * G * 2);
+  unsigned prev = 0;
+  if (lane == 0) prev = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  prev = __shfl(prev, 0, 64);
+  if (prev + 1u != total) return;
+  const double cntd = (double)(C / G) * (double)HW;
+  for (int i = lane; i < N * C; i += 64) {
+    const int n = i / C, ch = i - n * C, g = ch / (C / G);
+    double s1 = 0.0, s2 = 0.0;
+    for (int sl = 0; sl < 32; ++sl) {
+      const double* src = gn_sums + (((long)sl * N + n) * G + g) * 2;
+      s1 += __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s2 += __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const double m = s1 / cntd;
+    double var = s2 / cntd - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mf = (float)m, rs = (float)(1.0 / sqrt(var + (double)f.eps));
+    const float sc = rs * f.gamma[ch];
+    f.scsh[i] = float2{sc, f.beta[ch] - mf * sc};
+  }
+}
+// a wave's share of a group's statistics; `returning`: wait for the memory side's answer (see above)
+__device__ __forceinline__ void gn_add(double* dst, double s1, double s2, bool returning) {
+  if (returning) {
+    const double o1 = __hip_atomic_fetch_add(dst, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double o2 = __hip_atomic_fetch_add(dst + 1, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"(o1), "v"(o2));
+  } else {
+    atomicAdd(dst, s1);
+    atomicAdd(dst + 1, s2);
+  }
+}
+
 template <int KS, int MT, int WV, bool PRO = false>
 __global__ __launch_bounds__(64 * WV) void conv_mfma_kernel(const float* __restrict__ in, const float* __restrict__ wt,
                                                             const float* __restrict__ bias, float* __restrict__ out, int Cin,
@@ -39,7 +87,8 @@ __global__ __launch_bounds__(64 * WV) void conv_mfma_kernel(const float* __restr
                                                             double* __restrict__ gn_sums, int gn_groups,
                                                             const float2* __restrict__ pro_scsh = nullptr,
                                                             const float* __restrict__ res = nullptr,
-                                                            const float2* __restrict__ res_scsh = nullptr, float slope = 0.f) {
+                                                            const float2* __restrict__ res_scsh = nullptr, float slope = 0.f,
+                                                            GnFin fin = GnFin{nullptr, nullptr, nullptr, 0.f}) {
   constexpr int GN_SLOTS = 32;
   constexpr int PAD = KS / 2;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, c = lane & 15, q = lane >> 4;
@@ -192,11 +241,13 @@ __global__ __launch_bounds__(64 * WV) void conv_mfma_kernel(const float* __restr
           const int g = co / (Cout / gn_groups);
           const int slot = (blockIdx.x + blockIdx.y) % GN_SLOTS;
           double* dst = gn_sums + (((long)slot * gridDim.z + n) * gn_groups + g) * 2;
-          atomicAdd(dst, s1);
-          atomicAdd(dst + 1, s2);
+          gn_add(dst, s1, s2, fin.scsh != nullptr);
         }
       }
     }
+  // (one wave per workgroup reaches this point: the channel-slice waves have left above)
+  if (gn_sums && fin.scsh)
+    gn_arrive_finalize(gn_sums, (int)gridDim.z, Cout, gn_groups, HW, gridDim.x * gridDim.y * gridDim.z, fin, lane);
 }
 
 // (sum, sum of squares) the producing convolution accumulated (32 contention slots) -> per-channel scale / shift of the GroupNorm
@@ -242,7 +293,7 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(const float* __restrict
                                                          const float* __restrict__ bias, float* __restrict__ out, int Cin, int CinP,
                                                          int Cout, int H, int W, int out_ctot, int out_coff,
                                                          double* __restrict__ gn_sums, int gn_groups,
-                                                         const float2* __restrict__ pro_scsh, float slope) {
+                                                         const float2* __restrict__ pro_scsh, float slope, GnFin fin) {
   constexpr int KW = 8 / TH, R = TH + 2, LW = TH == 2 ? 44 : 40, PS = R * LW, GN_SLOTS = 32;   // PS = 16 or 48 mod 64; interior at column 4
   extern __shared__ float tile[];                              // [CinP][R][LW]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, c = lane & 15, q = lane >> 4;
@@ -434,11 +485,13 @@ __global__ __launch_bounds__(256) void conv3_tile_kernel(const float* __restrict
         const int g = cor / (Cout / gn_groups);
         const int slot = (blockIdx.x + blockIdx.y + wv) % GN_SLOTS;
         double* dst = gn_sums + (((long)slot * (gridDim.z / ntc) + n) * gn_groups + g) * 2;
-        atomicAdd(dst, s1);
-        atomicAdd(dst + 1, s2);
+        gn_add(dst, s1, s2, fin.scsh != nullptr);
       }
     }
   }
+  // (the TH / 2 waves of channel slice 0 reach this point, one arrival each)
+  if (gn_sums && fin.scsh)
+    gn_arrive_finalize(gn_sums, (int)(gridDim.z / ntc), Cout, gn_groups, HW, gridDim.x * gridDim.y * gridDim.z * (TH / 2), fin, lane);
 }
 
 // ---- the DEEP levels (24x32 and below: <= 768 pixels, 128 .. 512 channels, 0.3 .. 9.4 MB of weights per layer) ----
@@ -775,14 +828,16 @@ namespace como {
 template <int KS, int MT, int WV, bool PRO>
 static void launch_conv(dim3 grid, hipStream_t s, const float* in, const float* wt, const float* bias, float* out, int Cin, int CinP,
                         int Cout, int H, int W, int out_ctot, int out_coff, double* gn_sums, int gn_groups, const float2* pro_scsh,
-                        const float* res, const float2* res_scsh, float slope) {
+                        const float* res, const float2* res_scsh, float slope, GnFin fin) {
   hipLaunchKernelGGL((conv_mfma_kernel<KS, MT, WV, PRO>), grid, dim3(64 * WV), 0, s, in, wt, bias, out, Cin, CinP, Cout, H, W,
-                     out_ctot, out_coff, gn_sums, gn_groups, pro_scsh, res, res_scsh, slope);
+                     out_ctot, out_coff, gn_sums, gn_groups, pro_scsh, res, res_scsh, slope, fin);
 }
 
 static int conv2d_impl(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout, int H,
                        int W, int ks, int out_ctot, int out_coff, double* gn_sums, int gn_groups, const float2* pro_scsh,
-                       const float* res, const float2* res_scsh, float slope, hipStream_t s) {
+                       const float* res, const float2* res_scsh, float slope, hipStream_t s,
+                       GnFin fin = GnFin{nullptr, nullptr, nullptr, 0.f}) {
+  if (fin.scsh && (!gn_sums || !fin.gamma || !fin.beta || res)) return COMO_ERR_ARG;
   if (!in || !wt || !out || N <= 0 || Cin <= 0 || CinP < Cin || (CinP & 3) || Cout <= 0 || H <= 0 || W <= 0 ||
       (ks != 1 && ks != 3) || out_ctot < out_coff + Cout || (gn_sums && (gn_groups <= 0 || Cout % gn_groups)) ||
       ((res != nullptr) != (res_scsh != nullptr)) || (pro_scsh && ks != 3))
@@ -804,7 +859,7 @@ static int conv2d_impl(const float* in, const float* wt, const float* bias, floa
     static bool attr = false;                                                                                                    \
     if (!attr) { (void)hipFuncSetAttribute((const void*)conv3_tile_kernel<TH_, PRO_>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024); attr = true; } \
     hipLaunchKernelGGL((conv3_tile_kernel<TH_, PRO_>), g2, dim3(256), bytes, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, \
-                       out_coff, gn_sums, gn_groups, pro_scsh, slope);                                                           \
+                       out_coff, gn_sums, gn_groups, pro_scsh, slope, fin);                                                      \
   } while (0)
         if (th == 4) { if (pro_scsh) COMO_TILE(4, true); else COMO_TILE(4, false); }
         else { if (pro_scsh) COMO_TILE(2, true); else COMO_TILE(2, false); }
@@ -822,7 +877,7 @@ static int conv2d_impl(const float* in, const float* wt, const float* bias, floa
   int wvs = 1;
   while (wvs < 16 && waves * wvs < 2048 && (CinP / 4) / (wvs * 2) >= 4) wvs *= 2;
   const dim3 grid((unsigned)tiles_px, (unsigned)((Cout + 16 * mt - 1) / (16 * mt)), (unsigned)N);
-#define COMO_CONV(KS_, MT_, WV_, PRO_) launch_conv<KS_, MT_, WV_, PRO_>(grid, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff, gn_sums, gn_groups, pro_scsh, res, res_scsh, slope)
+#define COMO_CONV(KS_, MT_, WV_, PRO_) launch_conv<KS_, MT_, WV_, PRO_>(grid, s, in, wt, bias, out, Cin, CinP, Cout, H, W, out_ctot, out_coff, gn_sums, gn_groups, pro_scsh, res, res_scsh, slope, fin)
 #define COMO_CONV_W(KS_, MT_, PRO_)                                                                               \
   switch (wvs) { case 1: COMO_CONV(KS_, MT_, 1, PRO_); break; case 2: COMO_CONV(KS_, MT_, 2, PRO_); break;        \
                  case 4: COMO_CONV(KS_, MT_, 4, PRO_); break; case 8: COMO_CONV(KS_, MT_, 8, PRO_); break;        \
@@ -854,6 +909,18 @@ int como_nn_conv2d_fused_f32(const float* in, const float* wt, const float* bias
                              const float* pro_scsh, const float* res, const float* res_scsh, float slope, como_stream_t stream) {
   return como::conv2d_impl(in, wt, bias, out, N, Cin, CinP, Cout, H, W, ks, out_ctot, out_coff, gn_sums, gn_groups,
                            (const float2*)pro_scsh, res, (const float2*)res_scsh, slope, (hipStream_t)stream);
+}
+
+/* como_nn_conv2d_fused_f32 (no residual) + the finalisation of the GroupNorm that follows, inside the same launch: gn_sums holds
+ * 32 * N * gn_groups * 2 doubles AND one more 8-byte word behind them (the arrival counter), all zeroed by the caller; scsh (N, Cout, 2)
+ * receives what como_nn_gn_finalize_f32 would write, value for value. */
+int como_nn_conv2d_gn_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
+                          int H, int W, int ks, int out_ctot, int out_coff, double* gn_sums, int gn_groups, const float* pro_scsh,
+                          float slope, const float* gamma, const float* beta, float eps, float* scsh, como_stream_t stream) {
+  if (!gn_sums || !gamma || !beta || !scsh) return COMO_ERR_ARG;
+  return como::conv2d_impl(in, wt, bias, out, N, Cin, CinP, Cout, H, W, ks, out_ctot, out_coff, gn_sums, gn_groups,
+                           (const float2*)pro_scsh, nullptr, nullptr, slope, (hipStream_t)stream,
+                           como::GnFin{gamma, beta, (float2*)scsh, eps});
 }
 
 int como_nn_gn_finalize_f32(const double* sums, const float* gamma, const float* beta, int N, int C, int G, int HW, float eps,

@@ -58,6 +58,18 @@ def _groupnorm(x, gamma, beta, act, residual=None, sums=None):
     return out
 
 
+# 1: the scale / shift of a wide level's GroupNorm formed by the producing convolution's last wave (csrc/nn.hip gn_arrive_finalize)
+# instead of the separate gn_finalize launch.  Built, tested, measured SLOWER on MI355X (forward 0.703 -> 0.753 ms: the returning
+# memory-side adds and the last wave's uncached read of the 32 slots cost a tiled layer 5-8 us, the launch they replace 4.7): OFF.
+GN_IN_CONV = __import__("os").environ.get("COMO_NN_GN_IN_CONV", "0") == "1"
+
+
+def gn_sums_doubles(N):
+    """float64 words of one normalisation's statistics: 32 contention slots x N x groups x (sum, sum of squares) + the arrival
+    counter of the in-kernel finalisation (one 8-byte word; + one of padding)."""
+    return 32 * N * GN_GROUPS * 2 + 2
+
+
 DEEP_MAX_PIXELS = 768   # levels of 24x32 and below run their 3x3 layers on the reduction-split kernels (csrc/nn.hip conv3_deep)
 _deep_part = {}         # per (device, stream): the partial-sum scratch of the deep layers (grow-only)
 _deep_retired = []      # superseded scratch blocks: NEVER released -- a captured forward (DepthCovModule.forward_graphed) has the raw
@@ -97,7 +109,14 @@ def _conv3_any(conv, x, out=None, coff=0, pro_scsh=None, norm=None, sums=None):
         _lib.check(rc, "como_nn_conv3x3_deep_f32")
         return out, scsh
     if norm is not None and sums is None:
-        sums = torch.zeros((32, N, GN_GROUPS, 2), dtype=torch.float64, device=x.device)
+        sums = torch.zeros(gn_sums_doubles(N), dtype=torch.float64, device=x.device)
+    if norm is not None and GN_IN_CONV:
+        # the scale / shift of the normalisation that follows are formed by the convolution's last wave (csrc/nn.hip gn_arrive_finalize)
+        rc = L.como_nn_conv2d_gn_f32(x.data_ptr(), conv.wt.data_ptr(), conv.bias.data_ptr(), out.data_ptr(), N, conv.cin, conv.cinp,
+                                     conv.cout, H, W, 3, out.shape[1], coff, sums.data_ptr(), GN_GROUPS, _lib.ptr(pro_scsh),
+                                     LEAKY_SLOPE, norm[0].data_ptr(), norm[1].data_ptr(), GN_EPS, scsh.data_ptr(), s)
+        _lib.check(rc, "como_nn_conv2d_gn_f32")
+        return out, scsh
     rc = L.como_nn_conv2d_fused_f32(x.data_ptr(), conv.wt.data_ptr(), conv.bias.data_ptr(), out.data_ptr(), N, conv.cin, conv.cinp,
                                     conv.cout, H, W, 3, out.shape[1], coff, sums.data_ptr() if norm is not None else None, GN_GROUPS,
                                     _lib.ptr(pro_scsh), None, None, LEAKY_SLOPE, s)
@@ -220,7 +239,7 @@ class UNet:
         # GroupNorm statistics of all 2 * (1 + 2 * levels) normalisations: one zero-fill, accumulated by the convolutions
         nres = 1 + 2 * self.num_levels
         N = x.shape[0]
-        sums = torch.zeros((nres, 2, 32, N, GN_GROUPS, 2), dtype=torch.float64, device=x.device)   # 32 slots
+        sums = torch.zeros((nres, 2, gn_sums_doubles(N)), dtype=torch.float64, device=x.device)   # 32 slots + arrival counter each
         # One image: an encoder block writes its output straight into the second half of the decoder's concatenation buffer of
         # its level (channels [c, 2c) of one image are one contiguous block, so the pooling that follows reads it in place)
         # instead of being copied there later.

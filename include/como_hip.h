@@ -702,6 +702,14 @@ int como_nn_conv2d_fused_f32(const float* in, const float* wt, const float* bias
                              const float* pro_scsh, const float* res, const float* res_scsh, float slope, como_stream_t stream);
 int como_nn_gn_finalize_f32(const double* sums, const float* gamma, const float* beta, int N, int C, int G, int HW, float eps,
                             float* scsh, como_stream_t stream);
+/* Round 6: conv2d_fused (no residual) + gn_finalize in ONE launch -- the convolution's last wave (an arrival counter behind the
+ * statistics) forms scsh (N,Cout,2) of the GroupNorm(gn_groups, Cout) that follows (layers.py:21-24), value for value what
+ * como_nn_gn_finalize_f32 writes.  gn_sums: 32 * N * gn_groups * 2 doubles + ONE more 8-byte word (the counter), zeroed by the caller.
+ * Measured slower than the two launches on MI355X (a tiled layer 14-17 -> 20-29 us against 4.7 us for the launch it replaces): the
+ * product uses it only with COMO_NN_GN_IN_CONV=1. */
+int como_nn_conv2d_gn_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
+                          int H, int W, int ks, int out_ctot, int out_coff, double* gn_sums, int gn_groups, const float* pro_scsh,
+                          float slope, const float* gamma, const float* beta, float eps, float* scsh, como_stream_t stream);
 long como_nn_deep_part_floats(int N, int Cin, int Cout, int H, int W);
 int como_nn_conv3x3_deep_f32(const float* in, const float* wt, const float* bias, float* out, int N, int Cin, int CinP, int Cout,
                              int H, int W, int out_ctot, int out_coff, const float* pro_scsh, float slope, float* part,

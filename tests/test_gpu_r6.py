@@ -719,3 +719,42 @@ def test_one_workgroup_level_kernel(H, W, c, masked):
         assert r[0][3] == 0 and r[1][3] == 0 and r[0][2] == itc and r[1][2] == 6, n
         assert max(errs[n]) < 2e-6, n
         assert torch.equal(r[0][0], r[2][0]) and torch.equal(r[0][1], r[2][1]), n        # repeatable bits
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,cin,cout,H,W", [(1, 3, 16, 192, 256), (1, 32, 16, 192, 256), (2, 64, 32, 96, 128), (1, 64, 32, 48, 64), (2, 16, 32, 20, 28)])
+def test_groupnorm_finalised_inside_the_convolution(N, cin, cout, H, W):
+    """csrc/nn.hip gn_arrive_finalize: the scale / shift of the GroupNorm behind a wide-level convolution formed by that
+    convolution's LAST wave (returning agent-scope adds, an arrival counter behind the statistics) against the separate
+    `como_nn_gn_finalize_f32` launch -- the same scsh up to the arrival order of the float64 adds, on the three tile shapes of the
+    LDS-tiled kernel and on the generic kernel; repeated, because a finalisation that ran before every add had landed would show
+    as an occasional large error, not a constant one."""
+    from como_amd.depth_cov.nn import UNet as U
+    from como_amd import _lib
+    from tests.conftest import rel_err
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    conv = U._Conv(torch.randn(cout, cin, 3, 3, generator=g).to(DEV) / (cin * 9) ** 0.5, (torch.randn(cout, generator=g) * 0.1).to(DEV))
+    gamma = (1.0 + 0.2 * torch.randn(cout, generator=g)).to(DEV).contiguous()
+    beta = (0.2 * torch.randn(cout, generator=g)).to(DEV).contiguous()
+    x = torch.randn(N, cin, H, W, generator=g).to(DEV)
+    prev = U.GN_IN_CONV
+    worst = 0.0
+    try:
+        U.GN_IN_CONV = False
+        y0, sc0 = U._conv3_any(conv, x, norm=(gamma, beta))
+        U.GN_IN_CONV = True
+        for _ in range(25):
+            y1, sc1 = U._conv3_any(conv, x, norm=(gamma, beta))
+            worst = max(worst, rel_err(sc1, sc0))
+            assert torch.equal(y1, y0)
+    finally:
+        U.GN_IN_CONV = prev
+    # against torch's statistics of the same output
+    m = y0.double().reshape(N, 16, -1).mean(-1)
+    v = y0.double().reshape(N, 16, -1).var(-1, unbiased=False)
+    rstd = (1.0 / torch.sqrt(v + 1e-5)).repeat_interleave(cout // 16, 1)
+    sc_ref = rstd * gamma.double()[None]
+    sh_ref = beta.double()[None] - m.repeat_interleave(cout // 16, 1) * sc_ref
+    ref = torch.stack((sc_ref, sh_ref), -1).float()
+    report("gn_in_conv", N=N, cin=cin, cout=cout, H=H, W=W, vs_separate_launch=worst, vs_torch=rel_err(sc1, ref))
+    assert worst < 1e-6 and rel_err(sc1, ref) < 1e-5
