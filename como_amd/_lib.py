@@ -165,6 +165,18 @@ SIGNATURES = {
     "como_trsm_lower_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_long, c_int, c_void_p]),
     "como_nn_conv2d_f32": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_int, c_void_p]),
     "como_nn_conv2d_fused_f32": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_int] + [c_void_p] * 3 + [c_float, c_void_p]),
+    "como_kf_predictor_sinv_f64": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "como_kf_distill_prep_f64": (c_int, [c_void_p, c_void_p, c_long, c_double, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p]),
+    "como_kf_corr_good_f64": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_long, c_double, c_double, c_void_p, c_void_p]),
+    "como_kf_normalize_coords_f32": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "como_kf_normalize_coords_f64": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "como_kf_normalize_coords_swap_f32": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "como_kf_normalize_coords_swap_f64": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "como_kf_grad_mag_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "como_kf_grad_mag_f64": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "como_kf_aff_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "como_kf_aff_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "como_nn_conv2d_gn_f32": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p,
                                       c_void_p]),
     "como_nn_gn_finalize_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_float, c_void_p, c_void_p]),

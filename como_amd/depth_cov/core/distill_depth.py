@@ -60,6 +60,31 @@ def gram_weighted(A, w, y, c=None, want_stats=False):
 
 
 _GRAM_KERNEL = __import__("os").environ.get("COMO_GRAM_KERNEL", "1") != "0"     # 0: gather + concatenate + slab GEMMs (A/B)
+# 1 (default): the element-wise chains around the distillation's kernels as ONE launch each (csrc/kfglue.hip: the same operations
+# in the same order); 0: the torch chains (A/B, tests)
+KF_GLUE = __import__("os").environ.get("COMO_KF_GLUE", "1") != "0"
+
+
+def _glue_ok(*ts):
+    return KF_GLUE and all(t is None or (t.is_cuda and t.is_contiguous()) for t in ts)
+
+
+def distill_prep(z_obs, obs_mask, min_depth, sinv, sinv_scalar, weighted, want_zs=False):
+    """ok = z > min_depth [& obs_mask]; y = log(ok ? z : 1); w = ok ? s^2 : 0 (weighted) or ok as 0 / 1 -- the validity test of the
+    observations as zero weights (distill_depth.py:96-111, 152-166), ONE launch (csrc/kfglue.hip kg_distill_prep_kernel).
+    z_obs (1,n,1) float64 contiguous, obs_mask (n,) bool or None, sinv (1,n,1) or None (then the scalar).
+    Returns (okm (1,n,1) bool, zs (1,n,1) or None, y (1,n,1), w (1,n,1))."""
+    from como_amd import _lib
+    n = z_obs.shape[1]
+    dev = z_obs.device
+    okm = torch.empty((1, n, 1), dtype=torch.bool, device=dev)
+    y = torch.empty((1, n, 1), dtype=torch.float64, device=dev)
+    w = torch.empty((1, n, 1), dtype=torch.float64, device=dev)
+    zs = torch.empty((1, n, 1), dtype=torch.float64, device=dev) if want_zs else None
+    _lib.check(_lib.lib().como_kf_distill_prep_f64(z_obs.data_ptr(), _lib.ptr(obs_mask), n, float(min_depth), _lib.ptr(sinv),
+                                                   float(sinv_scalar), 1 if weighted else 0, okm.data_ptr(), _lib.ptr(zs),
+                                                   y.data_ptr(), w.data_ptr(), _lib.stream_ptr(dev)), "como_kf_distill_prep_f64")
+    return okm, zs, y, w
 
 
 def padded_predictor(Kt):
@@ -126,13 +151,14 @@ class MaskedResidual:
         return self.res.index_select(1, torch.nonzero(self.okm[0, :, 0])[:, 0])
 
 
-def get_predictor(K_mm, K_nm, K_nn_diag, pad4=False, row_mask=None):
+def get_predictor(K_mm, K_nm, K_nn_diag, pad4=False, row_mask=None, want_sinv=True):
     """:30-48 -> Knm_Kmminv (B,n,m), L_mm, 1/stdev of the conditional variance (B,n,1).
     row_mask (1,n) bool or None: the rows that count (the others ride along with zero weights in the caller's normal equations):
     the smallest conditional variance -- the shift that keeps every variance positive -- is taken over THEM only.
     pad4: Knm_Kmminv is returned as the leading m columns of a (B,n,mp) buffer, mp = m rounded up to a multiple of 4, whose other
     columns are exactly zero (K_mm^-1 padded with zero columns before the product) -- 16-byte aligned rows for `gram_weighted`
-    whatever the number of tracked points; `padded_predictor(Kt)` recovers the buffer."""
+    whatever the number of tracked points; `padded_predictor(Kt)` recovers the buffer.
+    want_sinv=False: the third result is None (a caller with a fixed observation stdev does not read it)."""
     f = chol_small(K_mm, want_L=True, want_inv=True)          # csrc/smallsolve.hip: L_mm and K_mm^-1 in one launch
     L_mm = f["L"]
     m = K_mm.shape[-1]
@@ -150,6 +176,16 @@ def get_predictor(K_mm, K_nm, K_nn_diag, pad4=False, row_mask=None):
         Kt = full[:, :, :m] if mp != m else full
         if mp != m:
             Kt._como_padded = full
+        if not want_sinv:
+            return Kt, L_mm, None
+        rmask = None if row_mask is None else row_mask.reshape(n)
+        if _glue_ok(rmask) and (rmask is None or rmask.dtype == torch.bool):
+            # min over the rows that count, the shift and 1 / sqrt in two launches (seven as torch ops), the same values
+            sinv = torch.empty((1, n, 1), dtype=K_nm.dtype, device=K_nm.device)
+            part = torch.empty(64, dtype=K_nm.dtype, device=K_nm.device)
+            _lib.check(_lib.lib().como_kf_predictor_sinv_f64(var_n.data_ptr(), _lib.ptr(rmask), n, part.data_ptr(), sinv.data_ptr(),
+                                                             _lib.stream_ptr(K_nm.device)), "como_kf_predictor_sinv_f64")
+            return Kt, L_mm, sinv
         vmin = torch.min(var_n) if row_mask is None else torch.min(torch.where(row_mask.reshape(1, n), var_n, torch.full_like(var_n, float("inf"))))
         var_n = var_n + (vmin + 1e-8)
         return Kt, L_mm, 1.0 / torch.sqrt(var_n.unsqueeze(-1))
@@ -186,9 +222,13 @@ def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model,
     second result is a `MaskedResidual` (all rows + the mask of the valid ones) instead of the gathered valid residuals."""
     assert coords_m.shape[0] == 1
     rm = None if obs_mask is None else obs_mask.reshape(1, -1)
-    Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL, row_mask=rm)
-    if stdev_obs is not None:
-        sinv = (1.0 / stdev_obs) * torch.ones_like(sinv)
+    pre = z_obs.dtype == torch.float64 and z_obs.dim() == 3 and z_obs.shape[2] == 1 and _glue_ok(z_obs, obs_mask) and \
+        (obs_mask is None or obs_mask.dtype == torch.bool)
+    Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL, row_mask=rm,
+                                   want_sinv=not (pre and stdev_obs is not None))
+    glue = pre and _fast(Kt) and _glue_ok(sinv)
+    if stdev_obs is not None and not glue:
+        sinv = (1.0 / stdev_obs) * torch.ones((Kt.shape[0], Kt.shape[1], 1), dtype=Kt.dtype, device=Kt.device)
     if obs_mask is not None and not _fast(Kt):
         # (the gathering form below needs gathered inputs)
         sel = torch.nonzero(obs_mask)[:, 0]
@@ -196,13 +236,18 @@ def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model,
     if _fast(Kt):
         # the same normal equations with the rows read in place: the validity test becomes a zero weight (no gather of the
         # valid rows, no [prior ; observations] concatenation, no library GEMM with a single output tile)
-        okm = z_obs[:, :, 0:1] > min_depth
-        if obs_mask is not None:
-            okm = okm & obs_mask.reshape(1, -1, 1)
-        y = torch.log(torch.where(okm, z_obs[:, :, 0:1], torch.ones_like(z_obs[:, :, 0:1])))
         m = Kt.shape[2]
-        # (a select, not a product: a masked row may hold anything -- a point behind the camera reprojects to non-finite coordinates)
-        wgt = torch.where(okm, sinv * sinv, torch.zeros_like(sinv)) if distill_with_prior else okm.to(Kt.dtype)
+        if glue:
+            okm, _, y, wgt = distill_prep(z_obs, None if obs_mask is None else obs_mask.reshape(-1), min_depth,
+                                          sinv if stdev_obs is None else None, 0.0 if stdev_obs is None else 1.0 / stdev_obs,
+                                          bool(distill_with_prior))
+        else:
+            okm = z_obs[:, :, 0:1] > min_depth
+            if obs_mask is not None:
+                okm = okm & obs_mask.reshape(1, -1, 1)
+            y = torch.log(torch.where(okm, z_obs[:, :, 0:1], torch.ones_like(z_obs[:, :, 0:1])))
+            # (a select, not a product: a masked row may hold anything -- a point behind the camera reprojects to non-finite coordinates)
+            wgt = torch.where(okm, sinv * sinv, torch.zeros_like(sinv)) if distill_with_prior else okm.to(Kt.dtype)
         AtA, Atb = gram_weighted(padded_predictor(Kt), wgt, y)
         if AtA.shape[1] != m:                                 # (zero-padded columns: their rows / columns of the products are zero)
             AtA, Atb = AtA[:, :m, :m].contiguous(), Atb[:, :m].contiguous()
@@ -246,8 +291,12 @@ def distill_conditional_depth_with_scale_prior(Knm_Kmminv, z_obs, z1, stdev_inv_
 def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_img, z_obs, model, min_depth, stdev_obs, obs_mask=None):
     """:152-175.  obs_mask: as in distill_depth_from_scratch."""
     assert coords_m.shape[0] == 1
-    Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL)
-    sinv = (1.0 / stdev_obs) * torch.ones_like(sinv)
+    pre = z_obs.dtype == torch.float64 and z_obs.dim() == 3 and z_obs.shape[2] == 1 and _glue_ok(z_obs, obs_mask) and \
+        (obs_mask is None or obs_mask.dtype == torch.bool)
+    Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL, want_sinv=not pre)
+    glue = pre and _fast(Kt)
+    if not glue:
+        sinv = (1.0 / stdev_obs) * torch.ones((Kt.shape[0], Kt.shape[1], 1), dtype=Kt.dtype, device=Kt.device)
     m, m1 = Kt.shape[2], z_m1.shape[1]
     if obs_mask is not None and not _fast(Kt):
         sel = torch.nonzero(obs_mask)[:, 0]
@@ -256,15 +305,22 @@ def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_
         # [sp I ; sinv K~[:, m1:]] x = [sp s ; sinv (log z_obs - K~[:, :m1] log z_1)] as weighted normal equations of the rows in place:
         # the known columns enter through c = [log z_1 ; 0] (r = y - K~ c), the unknown block is the lower-right corner
         from como_amd.utils.select import masked_median
-        okm = z_obs[:, :, 0:1] > min_depth
-        if obs_mask is not None:
-            okm = okm & obs_mask.reshape(1, -1, 1)
-        zs = torch.where(okm, z_obs[:, :, 0:1], torch.ones_like(z_obs[:, :, 0:1]))
+        if glue:
+            okm, zs, logzs, wgt = distill_prep(z_obs, None if obs_mask is None else obs_mask.reshape(-1), min_depth, None,
+                                               1.0 / stdev_obs, True, want_zs=True)
+        else:
+            okm = z_obs[:, :, 0:1] > min_depth
+            if obs_mask is not None:
+                okm = okm & obs_mask.reshape(1, -1, 1)
+            zs = torch.where(okm, z_obs[:, :, 0:1], torch.ones_like(z_obs[:, :, 0:1]))
+            logzs, wgt = None, None
         s_med = torch.log(masked_median(zs[0, :, 0], okm[0, :, 0]))
         sp2 = (1.0 / 5e-2) ** 2
         Kp = padded_predictor(Kt)
         c = torch.cat((torch.log(z_m1).reshape(1, m1, 1), torch.zeros((1, Kp.shape[2] - m1, 1), device=Kt.device, dtype=Kt.dtype)), dim=1)
-        AtA, Atb = gram_weighted(Kp, torch.where(okm, sinv * sinv, torch.zeros_like(sinv)), torch.log(zs), c=c)
+        if not glue:
+            logzs, wgt = torch.log(zs), torch.where(okm, sinv * sinv, torch.zeros_like(sinv))
+        AtA, Atb = gram_weighted(Kp, wgt, logzs, c=c)
         m2 = m - m1
         A22 = AtA[:, m1:m, m1:m] + sp2 * torch.eye(m2, device=Kt.device, dtype=Kt.dtype)
         b2 = Atb[:, m1:m] + sp2 * s_med

@@ -100,9 +100,22 @@ def get_correspondence_errors(P_reproj, P_new, mode):
     raise ValueError(f"unknown correspondence mode {mode!r}")
 
 
+def _grad_mag(gx, gy):
+    """sqrt(gx^2 + gy^2): one launch (csrc/kfglue.hip kg_grad_mag_kernel, the same three roundings per pixel) instead of four."""
+    from como_amd.depth_cov.core import distill_depth as _dd
+    if (_dd.KF_GLUE and gx.is_cuda and gx.dtype in (torch.float32, torch.float64) and gy.dtype == gx.dtype and gx.shape == gy.shape and
+            gx.is_contiguous() and gy.is_contiguous() and gx.numel() > 0):
+        from como_amd import _lib
+        out = torch.empty_like(gx)
+        _lib.check(getattr(_lib.lib(), "como_kf_grad_mag_" + _lib.suffix(gx.dtype))(gx.data_ptr(), gy.data_ptr(), gx.numel(), out.data_ptr(),
+                                                                                   _lib.stream_ptr(gx.device)), "como_kf_grad_mag")
+        return out
+    return torch.sqrt(gx * gx + gy * gy)
+
+
 def _sample_at(img, coords, size):
     """Bilinear look-up of a (1,1,h,w) image at row/col coords (1,k,2) -> (1,k,1) (zeros outside, align_corners=False)."""
-    grid = swap_coords_xy(normalize_coordinates(coords, size)).unsqueeze(1)
+    grid = normalize_coordinates(coords, size, swap=True).unsqueeze(1)
     out = F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
     return out.reshape(1, 1, coords.shape[1]).permute(0, 2, 1)
 
@@ -138,7 +151,7 @@ def prepare_track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, K, cov_size, c
         idx_m = torch.nonzero(keep_m)[:, 0]
     # depth discontinuities of the reference: |grad log z| at the original sparse coordinates that were kept
     gx, gy = ImageGradientModule(channels=1, device=dev, dtype=z_img1.dtype)(torch.log(z_img1))
-    grad_ref = _sample_at(torch.sqrt(gx * gx + gy * gy), coords_m1.index_select(1, idx_m), cov_size)
+    grad_ref = _sample_at(_grad_mag(gx, gy), coords_m1.index_select(1, idx_m), cov_size)
     return {"Tji": Tji, "Tij": invertSE3(Tji), "fused": fused, "cj_m": cj_m, "Pj_m": Pj_m, "keep_m": keep_m, "cj_n": cj_n,
             "zj_n": Pj_n[:, :, 2:3], "grad_ref": grad_ref, "z_dtype": z_n1.dtype, "idx_m": idx_m, "idx_m_list": idx_list,
             "keep_n": keep_n}
@@ -176,8 +189,21 @@ def track_and_init(pose1, pose2, coords_m1, z_m1, z_img1, cov_params_img2, K, mo
     P_proj = backprojection_points(K[0], swap_coords_xy(ci_m), _sample_at(z_img1, ci_m, cov_size))
 
     mode = corr_params["corr_mode"]
-    err = torch.maximum(get_correspondence_errors(P_proj, Pi_m, mode), get_correspondence_errors(Pj_m, P_m, mode))
-    good = ((err < corr_params["corr_thresh"]) & (grad_ref < corr_params["logz_grad_mag_thresh"]))[0, :, 0]
+    from como_amd.depth_cov.core import distill_depth as _dd
+    gr = grad_ref.reshape(-1)
+    pts = (P_proj, Pi_m, Pj_m, P_m)
+    if (_dd.KF_GLUE and mode in ("logz", "logr") and gr.is_contiguous() and gr.dtype == torch.float64 and gr.is_cuda and
+            all(t.is_cuda and t.dtype == torch.float64 and t.is_contiguous() and t.shape == (1, gr.shape[0], 3) for t in pts)):
+        # the two correspondence errors, their maximum and both threshold tests in ONE launch (twelve as torch ops on ~64 points)
+        from como_amd import _lib
+        good = torch.empty((gr.shape[0],), dtype=torch.bool, device=gr.device)
+        _lib.check(_lib.lib().como_kf_corr_good_f64(P_proj.data_ptr() + 16, Pi_m.data_ptr() + 16, Pj_m.data_ptr() + 16,
+                                                    P_m.data_ptr() + 16, 3, gr.data_ptr(), gr.shape[0],
+                                                    float(corr_params["corr_thresh"]), float(corr_params["logz_grad_mag_thresh"]),
+                                                    good.data_ptr(), _lib.stream_ptr(gr.device)), "como_kf_corr_good_f64")
+    else:
+        err = torch.maximum(get_correspondence_errors(P_proj, Pi_m, mode), get_correspondence_errors(Pj_m, P_m, mode))
+        good = ((err < corr_params["corr_thresh"]) & (grad_ref < corr_params["logz_grad_mag_thresh"]))[0, :, 0]
 
     # (index lists instead of boolean masks from here on: every boolean-mask selection / assignment synchronises with the host to
     # learn its size -- one read-back does, the rest are gathers and scatters with the same element order; the read-back returns

@@ -7,6 +7,7 @@ def swap_coords_xy(coords):
 
 
 _A_cache = {}
+_KF_GLUE = __import__("os").environ.get("COMO_KF_GLUE", "1") != "0"
 
 
 def _inv_dims(dims, device, dtype):
@@ -20,12 +21,34 @@ def _inv_dims(dims, device, dtype):
     return v
 
 
-def normalize_coordinates(x_pixel, dims):
-    """Pixel -> [-1,1] with pixel centres at fractional positions: x_norm = 2 A x + A - 1, A = 1/dims (coords.py:12-15)."""
+def normalize_coordinates(x_pixel, dims, swap=False):
+    """Pixel -> [-1,1] with pixel centres at fractional positions: x_norm = 2 A x + A - 1, A = 1/dims (coords.py:12-15).
+    swap: swap_coords_xy of the result (the grid a bilinear look-up wants), in the same launch."""
+    if swap:
+        if (not torch.is_tensor(dims) and _KF_GLUE and x_pixel.is_cuda and x_pixel.dtype in (torch.float32, torch.float64) and
+                x_pixel.dim() >= 1 and x_pixel.shape[-1] == 2 and x_pixel.is_contiguous() and x_pixel.numel() > 0 and
+                not x_pixel.requires_grad):
+            from como_amd import _lib
+            A, A2 = _inv_dims(dims, x_pixel.device, x_pixel.dtype)
+            out = torch.empty_like(x_pixel)
+            fn = getattr(_lib.lib(), "como_kf_normalize_coords_swap_" + _lib.suffix(x_pixel.dtype))
+            _lib.check(fn(x_pixel.data_ptr(), x_pixel.numel(), A.data_ptr(), A2.data_ptr(), out.data_ptr(),
+                          _lib.stream_ptr(x_pixel.device)), "como_kf_normalize_coords_swap")
+            return out
+        return swap_coords_xy(normalize_coordinates(x_pixel, dims))
     if torch.is_tensor(dims) or not x_pixel.is_floating_point():
         A = 1.0 / torch.as_tensor(dims, device=x_pixel.device, dtype=x_pixel.dtype)
         return 2 * A * x_pixel + A - 1
     A, A2 = _inv_dims(dims, x_pixel.device, x_pixel.dtype)
+    if (_KF_GLUE and x_pixel.is_cuda and x_pixel.dtype in (torch.float32, torch.float64) and x_pixel.dim() >= 1 and
+            x_pixel.shape[-1] == 2 and x_pixel.is_contiguous() and x_pixel.numel() > 0 and not x_pixel.requires_grad):
+        # one launch instead of three (csrc/kfglue.hip kg_normalize_coords_kernel: the same three roundings per element)
+        from como_amd import _lib
+        out = torch.empty_like(x_pixel)
+        fn = getattr(_lib.lib(), "como_kf_normalize_coords_" + _lib.suffix(x_pixel.dtype))
+        _lib.check(fn(x_pixel.data_ptr(), x_pixel.numel(), A.data_ptr(), A2.data_ptr(), out.data_ptr(), _lib.stream_ptr(x_pixel.device)),
+                   "como_kf_normalize_coords")
+        return out
     return A2 * x_pixel + A - 1
 
 

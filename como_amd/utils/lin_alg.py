@@ -30,7 +30,8 @@ def chol_small(A, want_L=True, want_inv=False, rhs=None, want_info=False):
             raise RuntimeError("como_amd chol_small: rhs must be (B,n,k)")
         k = r3.shape[2]
         X = torch.empty_like(r3)
-    info = torch.zeros(B, dtype=torch.int32, device=dev)
+    # (both kernels write info[b] of every system: no zero-fill launch; an empty system reports 0)
+    info = torch.empty(B, dtype=torch.int32, device=dev) if (n > 0 and B > 0) else torch.zeros(B, dtype=torch.int32, device=dev)
     if n > 0 and B > 0:                                   # (an empty system -- a keyframe that tracked no point of the previous one --
         fn = getattr(_lib.lib(), "como_chol_small_" + _lib.suffix(dt))      # has empty factors, as torch.linalg.cholesky returns)
         rc = fn(A3.data_ptr(), B, n, _lib.ptr(L), _lib.ptr(inv), _lib.ptr(r3), k, _lib.ptr(X), info.data_ptr(), _lib.stream_ptr(dev))

@@ -771,6 +771,37 @@ int como_track_precalc_jac_f32(const float* dI_dw, const float* P, const float* 
 int como_track_precalc_jac_f64(const double* dI_dw, const double* P, const double* vals, const double* K, double* J, long N,
                                como_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Element-wise glue of a keyframe insertion, fused (csrc/kfglue.hip): each entry replaces a chain of 4 .. 12 tiny torch launches
+ * with the same operations in the same order (one rounding per torch op, no contraction).
+ *  predictor_sinv   : como/depth_cov/core/distill_depth.py:42-46 -- var += min over the rows that count (row_mask bytes, optional)
+ *                     + 1e-8; sinv = 1 / sqrt(var).  partial: scratch of >= 64 doubles.
+ *  distill_prep     : distill_depth.py:96-111, 152-166 -- ok = z > min_depth [& obs_mask]; zs = ok ? z : 1 (optional output);
+ *                     y = log(zs); w = ok ? s^2 : 0 with s = sinv[i] (or sinv_scalar when sinv is NULL) for weight_mode 1,
+ *                     w = ok ? 1 : 0 for weight_mode 0.
+ *  corr_good        : como/odom/frontend/corr.py:47-59, 113-118 (modes logz / logr) -- the z components (element 2 of rows of
+ *                     `stride` doubles: pass the address of the first z) of four point sets and the depth-gradient measure:
+ *                     good = max(|log a - log b|, |log c - log d|) < corr_thresh & grad < grad_thresh.
+ *  normalize_coords : como/utils/coords.py:12-15 -- out = A2[k] x + A[k] - 1, k = coordinate index (n2 = 2 x points). */
+int como_kf_predictor_sinv_f64(const double* var_n, const uint8_t* row_mask, long n, double* partial, double* sinv,
+                               como_stream_t stream);
+int como_kf_distill_prep_f64(const double* z_obs, const uint8_t* obs_mask, long n, double min_depth, const double* sinv,
+                             double sinv_scalar, int weight_mode, uint8_t* okm, double* zs, double* y, double* w,
+                             como_stream_t stream);
+int como_kf_corr_good_f64(const double* a, const double* b, const double* c, const double* d, int stride, const double* grad, long m,
+                          double corr_thresh, double grad_thresh, uint8_t* good, como_stream_t stream);
+int como_kf_normalize_coords_f32(const float* x, long n2, const float* A, const float* A2, float* out, como_stream_t stream);
+int como_kf_normalize_coords_f64(const double* x, long n2, const double* A, const double* A2, double* out, como_stream_t stream);
+/* normalize_coords_swap: the same values written with x / y exchanged (swap_coords_xy of the result, coords.py:5-6; out != x);
+ * grad_mag: sqrt(gx^2 + gy^2) (corr.py:95-96); aff: affine brightness parameters (B,2) -- mode 0 get_aff_w_curr(p, q) =
+ * (p0 + q0, p1 + q1 exp(q0)), mode 1 get_rel_aff(p, q) = (p0 - q0, exp(-(p0 - q0)) (p1 - q1)) (geometry/affine_brightness.py:5-16). */
+int como_kf_normalize_coords_swap_f32(const float* x, long n2, const float* A, const float* A2, float* out, como_stream_t stream);
+int como_kf_normalize_coords_swap_f64(const double* x, long n2, const double* A, const double* A2, double* out, como_stream_t stream);
+int como_kf_grad_mag_f32(const float* gx, const float* gy, long n, float* out, como_stream_t stream);
+int como_kf_grad_mag_f64(const double* gx, const double* gy, long n, double* out, como_stream_t stream);
+int como_kf_aff_f32(const float* p, const float* q, int B, int mode, float* out, como_stream_t stream);
+int como_kf_aff_f64(const double* p, const double* q, int B, int mode, double* out, como_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

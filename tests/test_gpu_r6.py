@@ -758,3 +758,89 @@ def test_groupnorm_finalised_inside_the_convolution(N, cin, cout, H, W):
     ref = torch.stack((sc_ref, sh_ref), -1).float()
     report("gn_in_conv", N=N, cin=cin, cout=cout, H=H, W=W, vs_separate_launch=worst, vs_torch=rel_err(sc1, ref))
     assert worst < 1e-6 and rel_err(sc1, ref) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_keyframe_glue_kernels_vs_torch_chains():
+    """csrc/kfglue.hip: the element-wise chains of a keyframe insertion as one launch each -- shift + 1 / sqrt of the conditional
+    variances (min over the rows that count), the observations' validity as zero weights, the correspondence test, the coordinate
+    normalisation -- against the torch op chains they replace: the SAME bits (one rounding per op, same order), masked rows and
+    non-finite / non-positive depths included."""
+    import como_amd.depth_cov.core.distill_depth as dd
+    from como_amd import _lib
+    from como_amd.utils import coords as cu
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(11)
+    n = 70001
+    # ---- predictor_sinv
+    var = (torch.rand(1, n, generator=g, dtype=torch.float64) - 0.01).to(DEV)
+    mask = (torch.rand(n, generator=g) < 0.6).to(DEV)
+    for rm in (None, mask):
+        vmin = torch.min(var) if rm is None else torch.min(torch.where(rm.reshape(1, n), var, torch.full_like(var, float("inf"))))
+        ref = 1.0 / torch.sqrt((var + (vmin + 1e-8)).unsqueeze(-1))
+        out = torch.empty((1, n, 1), dtype=torch.float64, device=DEV)
+        part = torch.empty(64, dtype=torch.float64, device=DEV)
+        _lib.check(L.como_kf_predictor_sinv_f64(var.data_ptr(), _lib.ptr(rm), n, part.data_ptr(), out.data_ptr(), _lib.stream_ptr(var.device)), "sinv")
+        assert torch.equal(out, ref) or bool(((out == ref) | (out.isnan() & ref.isnan())).all())
+    # ---- distill_prep
+    z = (torch.rand(1, n, 1, generator=g, dtype=torch.float64) * 3.0 - 0.3).to(DEV)
+    z[0, 5, 0] = float("nan"); z[0, 6, 0] = float("inf"); z[0, 7, 0] = 0.0
+    sinv = (0.5 + torch.rand(1, n, 1, generator=g, dtype=torch.float64)).to(DEV)
+    for om in (None, mask):
+        for weighted, s_t, s_sc in ((True, sinv, 0.0), (True, None, 1.0 / 0.07), (False, None, 0.0)):
+            okm = z[:, :, 0:1] > 0.1
+            if om is not None:
+                okm = okm & om.reshape(1, -1, 1)
+            zs = torch.where(okm, z, torch.ones_like(z))
+            y = torch.log(zs)
+            sv = s_t if s_t is not None else s_sc * torch.ones_like(z)
+            w = torch.where(okm, sv * sv, torch.zeros_like(sv)) if weighted else okm.to(torch.float64)
+            ok2, zs2, y2, w2 = dd.distill_prep(z, om, 0.1, s_t, s_sc, weighted, want_zs=True)
+            assert torch.equal(ok2, okm) and torch.equal(zs2, zs) and torch.equal(y2, y) and torch.equal(w2, w)
+    # ---- corr_good
+    m = 257
+    P = [(0.2 + 2.0 * torch.rand(1, m, 3, generator=g, dtype=torch.float64)).to(DEV) for _ in range(4)]
+    P[1][0, 3, 2] = -1.0                                   # log of a negative depth: NaN -> not good
+    P[2][0, 4, 2] = 0.0
+    for k in range(0, m, 2):
+        P[1][0, k, 2] = P[0][0, k, 2] * 1.01
+        P[3][0, k, 2] = P[2][0, k, 2] * 0.995
+    grad = torch.rand(1, m, 1, generator=g, dtype=torch.float64).to(DEV)
+    err = torch.maximum(torch.abs(torch.log(P[0][..., 2:3]) - torch.log(P[1][..., 2:3])), torch.abs(torch.log(P[2][..., 2:3]) - torch.log(P[3][..., 2:3])))
+    ref = ((err < 0.02) & (grad < 0.5))[0, :, 0]
+    good = torch.empty((m,), dtype=torch.bool, device=DEV)
+    _lib.check(L.como_kf_corr_good_f64(P[0].data_ptr() + 16, P[1].data_ptr() + 16, P[2].data_ptr() + 16, P[3].data_ptr() + 16, 3,
+                                       grad.reshape(-1).data_ptr(), m, 0.02, 0.5, good.data_ptr(), _lib.stream_ptr(grad.device)), "corr_good")
+    assert torch.equal(good, ref) and 0 < int(ref.sum()) < m
+    # ---- normalize_coords (both element types; the fused path is what normalize_coordinates takes for contiguous (.., 2) tensors)
+    for dt in (torch.float32, torch.float64):
+        x = (torch.rand(1, 4099, 2, generator=g, dtype=torch.float64) * 600.0).to(dt).to(DEV)
+        A, A2 = cu._inv_dims((480, 640), x.device, dt)
+        ref = A2 * x + A - 1
+        prev = cu._KF_GLUE
+        try:
+            cu._KF_GLUE = True
+            got = cu.normalize_coordinates(x, (480, 640))
+        finally:
+            cu._KF_GLUE = prev
+        assert torch.equal(got, ref)
+        got_s = cu.normalize_coordinates(x, (480, 640), swap=True)
+        assert torch.equal(got_s, cu.swap_coords_xy(ref))
+        # ---- gradient magnitude, affine brightness composition (both element types)
+        from como_amd.odom.frontend import corr as cr
+        from como_amd.geometry import affine_brightness as ab
+        gx = torch.randn(1, 1, 37, 53, generator=g, dtype=torch.float64).to(dt).to(DEV)
+        gy = torch.randn(1, 1, 37, 53, generator=g, dtype=torch.float64).to(dt).to(DEV)
+        assert torch.equal(cr._grad_mag(gx, gy), torch.sqrt(gx * gx + gy * gy))
+        p_ = (0.3 * torch.randn(3, 2, 1, generator=g, dtype=torch.float64)).to(dt).to(DEV)
+        q_ = (0.3 * torch.randn(3, 2, 1, generator=g, dtype=torch.float64)).to(dt).to(DEV)
+        prev = ab._KF_GLUE
+        try:
+            ab._KF_GLUE = False
+            r0, r1 = ab.get_aff_w_curr(p_, q_), ab.get_rel_aff(p_, q_)
+            ab._KF_GLUE = True
+            f0, f1 = ab.get_aff_w_curr(p_, q_), ab.get_rel_aff(p_, q_)
+        finally:
+            ab._KF_GLUE = prev
+        assert torch.equal(f0, r0) and torch.equal(f1, r1)
+    report("kf_glue", sinv="equal", distill_prep="equal", corr_good="equal", normalize="equal", grad_mag="equal", aff="equal")
