@@ -51,14 +51,14 @@ __global__ __launch_bounds__(256) void kg_sinv_kernel(const double* __restrict__
   if (i < n) sinv[i] = 1.0 / sqrt(var[i] + shift);               // reciprocal(sqrt(var + shift)) (x 1.0: exact)
 }
 
-__global__ __launch_bounds__(256) void kg_distill_prep_kernel(const double* __restrict__ z, const uint8_t* __restrict__ mask, long n,
+__global__ __launch_bounds__(256) void kg_distill_prep_kernel(const double* __restrict__ z, long zstride, const uint8_t* __restrict__ mask, long n,
                                                               double min_depth, const double* __restrict__ sinv, double sinv_scalar,
                                                               int weight_mode, uint8_t* __restrict__ okm, double* __restrict__ zs,
                                                               double* __restrict__ y, double* __restrict__ w) {
 #pragma clang fp contract(off)
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const double zi = z[i];
+  const double zi = z[i * zstride];
   const bool ok = (zi > min_depth) && (!mask || mask[i]);
   const double zz = ok ? zi : 1.0;
   okm[i] = ok ? 1 : 0;
@@ -142,6 +142,28 @@ __global__ void kg_aff_kernel(const T* __restrict__ p, const T* __restrict__ q, 
   }
 }
 
+// The small system of the conditional distillation (distill_depth.py:122-148 of the reference, normal-equation form): the known
+// columns' coefficient vector c = [log z_1 ; 0] and  A22 = AtA[m1:, m1:] + sp2 I,  b2 = Atb[m1:] + sp2 s  (s: a device scalar).
+__global__ __launch_bounds__(256) void kg_cond_c_kernel(const double* __restrict__ z1, int m1, int mp, double* __restrict__ c) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < mp) c[i] = i < m1 ? log(z1[i]) : 0.0;
+}
+__global__ __launch_bounds__(256) void kg_cond_system_kernel(const double* __restrict__ AtA, const double* __restrict__ Atb, int ld,
+                                                             int m1, int m2, double sp2, const double* __restrict__ s_med,
+                                                             double* __restrict__ A22, double* __restrict__ b2) {
+#pragma clang fp contract(off)
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < m2 * m2) {
+    const int i = e / m2, j = e - i * m2;
+    const double d = (i == j) ? sp2 * 1.0 : sp2 * 0.0;           // sp2 * eye
+    A22[e] = AtA[(long)(m1 + i) * ld + (m1 + j)] + d;
+  }
+  if (e < m2) {
+    const double t = sp2 * s_med[0];
+    b2[e] = Atb[m1 + e] + t;
+  }
+}
+
 template <typename T>
 static int grad_mag(const T* gx, const T* gy, long n, T* out, hipStream_t s) {
   if (!gx || !gy || !out || n < 0) return COMO_ERR_ARG;
@@ -195,12 +217,12 @@ int como_kf_predictor_sinv_f64(const double* var_n, const uint8_t* row_mask, lon
   return COMO_OK;
 }
 
-int como_kf_distill_prep_f64(const double* z_obs, const uint8_t* obs_mask, long n, double min_depth, const double* sinv,
+int como_kf_distill_prep_f64(const double* z_obs, long z_stride, const uint8_t* obs_mask, long n, double min_depth, const double* sinv,
                              double sinv_scalar, int weight_mode, uint8_t* okm, double* zs, double* y, double* w,
                              como_stream_t stream) {
   using namespace como;
-  if (!z_obs || !okm || !y || !w || n <= 0 || weight_mode < 0 || weight_mode > 1) return COMO_ERR_ARG;
-  hipLaunchKernelGGL(kg_distill_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z_obs, obs_mask, n,
+  if (!z_obs || z_stride < 1 || !okm || !y || !w || n <= 0 || weight_mode < 0 || weight_mode > 1) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(kg_distill_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z_obs, z_stride, obs_mask, n,
                      min_depth, sinv, sinv_scalar, weight_mode, okm, zs, y, w);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
@@ -224,6 +246,22 @@ int como_kf_normalize_coords_f64(const double* x, long n2, const double* A, cons
   return como::normalize_coords<double>(x, n2, A, A2, out, (hipStream_t)stream);
 }
 
+int como_kf_cond_c_f64(const double* z1, int m1, int mp, double* c, como_stream_t stream) {
+  using namespace como;
+  if (!c || m1 < 0 || mp < m1 || mp <= 0 || (m1 > 0 && !z1)) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(kg_cond_c_kernel, dim3((unsigned)((mp + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z1, m1, mp, c);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
+int como_kf_cond_system_f64(const double* AtA, const double* Atb, int ld, int m1, int m2, double sp2, const double* s_med,
+                            double* A22, double* b2, como_stream_t stream) {
+  using namespace como;
+  if (!AtA || !Atb || !s_med || !A22 || !b2 || m1 < 0 || m2 <= 0 || ld < m1 + m2) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(kg_cond_system_kernel, dim3((unsigned)((m2 * m2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, AtA, Atb, ld, m1,
+                     m2, sp2, s_med, A22, b2);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
 int como_kf_normalize_coords_swap_f32(const float* x, long n2, const float* A, const float* A2, float* out, como_stream_t stream) {
   return como::normalize_coords_swap<float>(x, n2, A, A2, out, (hipStream_t)stream);
 }

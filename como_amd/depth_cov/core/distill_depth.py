@@ -72,7 +72,8 @@ def _glue_ok(*ts):
 def distill_prep(z_obs, obs_mask, min_depth, sinv, sinv_scalar, weighted, want_zs=False):
     """ok = z > min_depth [& obs_mask]; y = log(ok ? z : 1); w = ok ? s^2 : 0 (weighted) or ok as 0 / 1 -- the validity test of the
     observations as zero weights (distill_depth.py:96-111, 152-166), ONE launch (csrc/kfglue.hip kg_distill_prep_kernel).
-    z_obs (1,n,1) float64 contiguous, obs_mask (n,) bool or None, sinv (1,n,1) or None (then the scalar).
+    z_obs (1,n,1) float64 (any stride along n: e.g. the depth column of (1,n,3) points), obs_mask (n,) bool or None, sinv (1,n,1) or
+    None (then the scalar).
     Returns (okm (1,n,1) bool, zs (1,n,1) or None, y (1,n,1), w (1,n,1))."""
     from como_amd import _lib
     n = z_obs.shape[1]
@@ -81,7 +82,8 @@ def distill_prep(z_obs, obs_mask, min_depth, sinv, sinv_scalar, weighted, want_z
     y = torch.empty((1, n, 1), dtype=torch.float64, device=dev)
     w = torch.empty((1, n, 1), dtype=torch.float64, device=dev)
     zs = torch.empty((1, n, 1), dtype=torch.float64, device=dev) if want_zs else None
-    _lib.check(_lib.lib().como_kf_distill_prep_f64(z_obs.data_ptr(), _lib.ptr(obs_mask), n, float(min_depth), _lib.ptr(sinv),
+    _lib.check(_lib.lib().como_kf_distill_prep_f64(z_obs.data_ptr(), int(z_obs.stride(1)) if n > 1 else 1, _lib.ptr(obs_mask), n,
+                                                   float(min_depth), _lib.ptr(sinv),
                                                    float(sinv_scalar), 1 if weighted else 0, okm.data_ptr(), _lib.ptr(zs),
                                                    y.data_ptr(), w.data_ptr(), _lib.stream_ptr(dev)), "como_kf_distill_prep_f64")
     return okm, zs, y, w
@@ -222,8 +224,8 @@ def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model,
     second result is a `MaskedResidual` (all rows + the mask of the valid ones) instead of the gathered valid residuals."""
     assert coords_m.shape[0] == 1
     rm = None if obs_mask is None else obs_mask.reshape(1, -1)
-    pre = z_obs.dtype == torch.float64 and z_obs.dim() == 3 and z_obs.shape[2] == 1 and _glue_ok(z_obs, obs_mask) and \
-        (obs_mask is None or obs_mask.dtype == torch.bool)
+    pre = KF_GLUE and z_obs.is_cuda and z_obs.dtype == torch.float64 and z_obs.dim() == 3 and z_obs.shape[2] == 1 and \
+        z_obs.shape[1] > 0 and z_obs.stride(1) >= 1 and _glue_ok(obs_mask) and (obs_mask is None or obs_mask.dtype == torch.bool)
     Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL, row_mask=rm,
                                    want_sinv=not (pre and stdev_obs is not None))
     glue = pre and _fast(Kt) and _glue_ok(sinv)
@@ -291,8 +293,8 @@ def distill_conditional_depth_with_scale_prior(Knm_Kmminv, z_obs, z1, stdev_inv_
 def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_img, z_obs, model, min_depth, stdev_obs, obs_mask=None):
     """:152-175.  obs_mask: as in distill_depth_from_scratch."""
     assert coords_m.shape[0] == 1
-    pre = z_obs.dtype == torch.float64 and z_obs.dim() == 3 and z_obs.shape[2] == 1 and _glue_ok(z_obs, obs_mask) and \
-        (obs_mask is None or obs_mask.dtype == torch.bool)
+    pre = KF_GLUE and z_obs.is_cuda and z_obs.dtype == torch.float64 and z_obs.dim() == 3 and z_obs.shape[2] == 1 and \
+        z_obs.shape[1] > 0 and z_obs.stride(1) >= 1 and _glue_ok(obs_mask) and (obs_mask is None or obs_mask.dtype == torch.bool)
     Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL, want_sinv=not pre)
     glue = pre and _fast(Kt)
     if not glue:
@@ -317,11 +319,25 @@ def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_
         s_med = torch.log(masked_median(zs[0, :, 0], okm[0, :, 0]))
         sp2 = (1.0 / 5e-2) ** 2
         Kp = padded_predictor(Kt)
-        c = torch.cat((torch.log(z_m1).reshape(1, m1, 1), torch.zeros((1, Kp.shape[2] - m1, 1), device=Kt.device, dtype=Kt.dtype)), dim=1)
+        m2 = m - m1
+        small = glue and m2 > 0 and z_m1.dtype == torch.float64 and z_m1.is_cuda and z_m1.is_contiguous() and s_med.dtype == torch.float64
+        if small:
+            from como_amd import _lib
+            Lb, st = _lib.lib(), _lib.stream_ptr(Kt.device)
+            c = torch.empty((1, Kp.shape[2], 1), device=Kt.device, dtype=Kt.dtype)
+            _lib.check(Lb.como_kf_cond_c_f64(z_m1.data_ptr(), m1, Kp.shape[2], c.data_ptr(), st), "como_kf_cond_c_f64")
+        else:
+            c = torch.cat((torch.log(z_m1).reshape(1, m1, 1), torch.zeros((1, Kp.shape[2] - m1, 1), device=Kt.device, dtype=Kt.dtype)), dim=1)
         if not glue:
             logzs, wgt = torch.log(zs), torch.where(okm, sinv * sinv, torch.zeros_like(sinv))
         AtA, Atb = gram_weighted(Kp, wgt, logzs, c=c)
-        m2 = m - m1
+        if small and AtA.is_contiguous() and Atb.is_contiguous():
+            # A22 = AtA[m1:, m1:] + sp2 I and b2 = Atb[m1:] + sp2 s in ONE launch (eye, two products, two sums, two copies as torch ops)
+            A22 = torch.empty((1, m2, m2), device=Kt.device, dtype=Kt.dtype)
+            b2 = torch.empty((1, m2, 1), device=Kt.device, dtype=Kt.dtype)
+            _lib.check(Lb.como_kf_cond_system_f64(AtA.data_ptr(), Atb.data_ptr(), AtA.shape[2], m1, m2, sp2, s_med.data_ptr(),
+                                                  A22.data_ptr(), b2.data_ptr(), st), "como_kf_cond_system_f64")
+            return chol_small(A22, want_L=False, rhs=b2)["X"]
         A22 = AtA[:, m1:m, m1:m] + sp2 * torch.eye(m2, device=Kt.device, dtype=Kt.dtype)
         b2 = Atb[:, m1:m] + sp2 * s_med
         return chol_small(A22.contiguous(), want_L=False, rhs=b2.contiguous())["X"]

@@ -776,7 +776,8 @@ int como_track_precalc_jac_f64(const double* dI_dw, const double* P, const doubl
  * with the same operations in the same order (one rounding per torch op, no contraction).
  *  predictor_sinv   : como/depth_cov/core/distill_depth.py:42-46 -- var += min over the rows that count (row_mask bytes, optional)
  *                     + 1e-8; sinv = 1 / sqrt(var).  partial: scratch of >= 64 doubles.
- *  distill_prep     : distill_depth.py:96-111, 152-166 -- ok = z > min_depth [& obs_mask]; zs = ok ? z : 1 (optional output);
+ *  distill_prep     : distill_depth.py:96-111, 152-166 -- z = z_obs[i * z_stride] (e.g. the third component of points (n,3));
+ *                     ok = z > min_depth [& obs_mask]; zs = ok ? z : 1 (optional output);
  *                     y = log(zs); w = ok ? s^2 : 0 with s = sinv[i] (or sinv_scalar when sinv is NULL) for weight_mode 1,
  *                     w = ok ? 1 : 0 for weight_mode 0.
  *  corr_good        : como/odom/frontend/corr.py:47-59, 113-118 (modes logz / logr) -- the z components (element 2 of rows of
@@ -785,7 +786,7 @@ int como_track_precalc_jac_f64(const double* dI_dw, const double* P, const doubl
  *  normalize_coords : como/utils/coords.py:12-15 -- out = A2[k] x + A[k] - 1, k = coordinate index (n2 = 2 x points). */
 int como_kf_predictor_sinv_f64(const double* var_n, const uint8_t* row_mask, long n, double* partial, double* sinv,
                                como_stream_t stream);
-int como_kf_distill_prep_f64(const double* z_obs, const uint8_t* obs_mask, long n, double min_depth, const double* sinv,
+int como_kf_distill_prep_f64(const double* z_obs, long z_stride, const uint8_t* obs_mask, long n, double min_depth, const double* sinv,
                              double sinv_scalar, int weight_mode, uint8_t* okm, double* zs, double* y, double* w,
                              como_stream_t stream);
 int como_kf_corr_good_f64(const double* a, const double* b, const double* c, const double* d, int stride, const double* grad, long m,
@@ -801,6 +802,11 @@ int como_kf_grad_mag_f32(const float* gx, const float* gy, long n, float* out, c
 int como_kf_grad_mag_f64(const double* gx, const double* gy, long n, double* out, como_stream_t stream);
 int como_kf_aff_f32(const float* p, const float* q, int B, int mode, float* out, como_stream_t stream);
 int como_kf_aff_f64(const double* p, const double* q, int B, int mode, double* out, como_stream_t stream);
+/* The small system of the conditional distillation (distill_depth.py:122-148, normal-equation form): cond_c: c (mp) = [log z1 (m1) ; 0];
+ * cond_system: A22 (m2,m2) = AtA[m1:m1+m2, m1:m1+m2] + sp2 I (AtA row stride ld), b2 (m2) = Atb[m1:m1+m2] + sp2 * s_med[0]. */
+int como_kf_cond_c_f64(const double* z1, int m1, int mp, double* c, como_stream_t stream);
+int como_kf_cond_system_f64(const double* AtA, const double* Atb, int ld, int m1, int m2, double sp2, const double* s_med,
+                            double* A22, double* b2, como_stream_t stream);
 
 #ifdef __cplusplus
 }

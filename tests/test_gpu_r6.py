@@ -797,6 +797,11 @@ def test_keyframe_glue_kernels_vs_torch_chains():
             w = torch.where(okm, sv * sv, torch.zeros_like(sv)) if weighted else okm.to(torch.float64)
             ok2, zs2, y2, w2 = dd.distill_prep(z, om, 0.1, s_t, s_sc, weighted, want_zs=True)
             assert torch.equal(ok2, okm) and torch.equal(zs2, zs) and torch.equal(y2, y) and torch.equal(w2, w)
+            # the depth column of (1,n,3) points: a strided view
+            P3 = torch.zeros((1, n, 3), dtype=torch.float64, device=DEV)
+            P3[:, :, 2:3] = z
+            ok3, zs3, y3, w3 = dd.distill_prep(P3[:, :, 2:3], om, 0.1, s_t, s_sc, weighted, want_zs=True)
+            assert torch.equal(ok3, okm) and torch.equal(zs3, zs) and torch.equal(y3, y) and torch.equal(w3, w)
     # ---- corr_good
     m = 257
     P = [(0.2 + 2.0 * torch.rand(1, m, 3, generator=g, dtype=torch.float64)).to(DEV) for _ in range(4)]
@@ -843,4 +848,23 @@ def test_keyframe_glue_kernels_vs_torch_chains():
         finally:
             ab._KF_GLUE = prev
         assert torch.equal(f0, r0) and torch.equal(f1, r1)
-    report("kf_glue", sinv="equal", distill_prep="equal", corr_good="equal", normalize="equal", grad_mag="equal", aff="equal")
+    # ---- the small system of the conditional distillation
+    m1, m2, mp = 23, 37, 60
+    z1 = (0.3 + torch.rand(1, m1, 1, generator=g, dtype=torch.float64)).to(DEV)
+    AtA = torch.randn(1, mp, mp, generator=g, dtype=torch.float64).to(DEV)
+    AtA[0, m1 + 3, m1 + 5] = -0.0
+    Atb = torch.randn(1, mp, 1, generator=g, dtype=torch.float64).to(DEV)
+    s_med = torch.log(torch.tensor(1.7, dtype=torch.float64, device=DEV))
+    sp2 = (1.0 / 5e-2) ** 2
+    c_ref = torch.cat((torch.log(z1).reshape(1, m1, 1), torch.zeros((1, mp - m1, 1), device=DEV, dtype=torch.float64)), dim=1)
+    A_ref = AtA[:, m1:m1 + m2, m1:m1 + m2] + sp2 * torch.eye(m2, device=DEV, dtype=torch.float64)
+    b_ref = Atb[:, m1:m1 + m2] + sp2 * s_med
+    c_ = torch.empty((1, mp, 1), dtype=torch.float64, device=DEV)
+    A_ = torch.empty((1, m2, m2), dtype=torch.float64, device=DEV)
+    b_ = torch.empty((1, m2, 1), dtype=torch.float64, device=DEV)
+    st = _lib.stream_ptr(c_.device)
+    _lib.check(L.como_kf_cond_c_f64(z1.data_ptr(), m1, mp, c_.data_ptr(), st), "cond_c")
+    _lib.check(L.como_kf_cond_system_f64(AtA.data_ptr(), Atb.data_ptr(), mp, m1, m2, sp2, s_med.data_ptr(), A_.data_ptr(), b_.data_ptr(), st), "cond_system")
+    same_bits = lambda a, b: torch.equal(a.view(torch.int64), b.contiguous().view(torch.int64))
+    assert torch.equal(c_, c_ref) and same_bits(A_, A_ref) and same_bits(b_, b_ref)
+    report("kf_glue", sinv="equal", distill_prep="equal", corr_good="equal", normalize="equal", grad_mag="equal", aff="equal", cond="equal")
