@@ -166,7 +166,7 @@ SIGNATURES = {
     "como_nn_conv2d_f32": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_int, c_void_p]),
     "como_nn_conv2d_fused_f32": (c_int, [c_void_p] * 4 + [c_int] * 9 + [c_void_p, c_int] + [c_void_p] * 3 + [c_float, c_void_p]),
     "como_kf_predictor_sinv_f64": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
-    "como_kf_distill_prep_f64": (c_int, [c_void_p, c_long, c_void_p, c_long, c_double, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p,
+    "como_kf_distill_prep_f64": (c_int, [c_void_p, c_long, c_void_p, c_long, c_double, c_void_p, c_double, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p]),
     "como_kf_corr_good_f64": (c_int, [c_void_p] * 4 + [c_int, c_void_p, c_long, c_double, c_double, c_void_p, c_void_p]),
     "como_kf_normalize_coords_f32": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void kg_sinv_kernel(const double* __restrict__
 
 __global__ __launch_bounds__(256) void kg_distill_prep_kernel(const double* __restrict__ z, long zstride, const uint8_t* __restrict__ mask, long n,
                                                               double min_depth, const double* __restrict__ sinv, double sinv_scalar,
-                                                              int weight_mode, uint8_t* __restrict__ okm, double* __restrict__ zs,
+                                                              const double* __restrict__ stdev_dev, int weight_mode,
+                                                              uint8_t* __restrict__ okm, double* __restrict__ zs,
                                                               double* __restrict__ y, double* __restrict__ w) {
 #pragma clang fp contract(off)
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -67,7 +68,9 @@ __global__ __launch_bounds__(256) void kg_distill_prep_kernel(const double* __re
   if (weight_mode == 0) {
     w[i] = ok ? 1.0 : 0.0;
   } else {
-    const double s = sinv ? sinv[i] : sinv_scalar;
+    // (a fixed observation stdev that lives on the device -- the residual spread of an earlier distillation -- is inverted here:
+    // 1.0 / stdev, the reference's (1.0 / stdev_obs) * ones)
+    const double s = sinv ? sinv[i] : (stdev_dev ? 1.0 / stdev_dev[0] : sinv_scalar);
     w[i] = ok ? s * s : 0.0;                                     // (a select: a masked row may hold anything)
   }
 }
@@ -218,12 +221,12 @@ int como_kf_predictor_sinv_f64(const double* var_n, const uint8_t* row_mask, lon
 }
 
 int como_kf_distill_prep_f64(const double* z_obs, long z_stride, const uint8_t* obs_mask, long n, double min_depth, const double* sinv,
-                             double sinv_scalar, int weight_mode, uint8_t* okm, double* zs, double* y, double* w,
-                             como_stream_t stream) {
+                             double sinv_scalar, const double* stdev_dev, int weight_mode, uint8_t* okm, double* zs, double* y,
+                             double* w, como_stream_t stream) {
   using namespace como;
   if (!z_obs || z_stride < 1 || !okm || !y || !w || n <= 0 || weight_mode < 0 || weight_mode > 1) return COMO_ERR_ARG;
   hipLaunchKernelGGL(kg_distill_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, z_obs, z_stride, obs_mask, n,
-                     min_depth, sinv, sinv_scalar, weight_mode, okm, zs, y, w);
+                     min_depth, sinv, sinv_scalar, stdev_dev, weight_mode, okm, zs, y, w);
   COMO_CHECK_LAUNCH();
   return COMO_OK;
 }

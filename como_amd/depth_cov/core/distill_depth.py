@@ -69,11 +69,17 @@ def _glue_ok(*ts):
     return KF_GLUE and all(t is None or (t.is_cuda and t.is_contiguous()) for t in ts)
 
 
-def distill_prep(z_obs, obs_mask, min_depth, sinv, sinv_scalar, weighted, want_zs=False):
+def _stdev_ok(stdev_obs):
+    """A fixed observation stdev the fused path can take: None, a Python number, or a float64 scalar on the device."""
+    return (not torch.is_tensor(stdev_obs)) or (stdev_obs.is_cuda and stdev_obs.dtype == torch.float64 and stdev_obs.numel() == 1)
+
+
+def distill_prep(z_obs, obs_mask, min_depth, sinv, stdev_obs, weighted, want_zs=False):
     """ok = z > min_depth [& obs_mask]; y = log(ok ? z : 1); w = ok ? s^2 : 0 (weighted) or ok as 0 / 1 -- the validity test of the
     observations as zero weights (distill_depth.py:96-111, 152-166), ONE launch (csrc/kfglue.hip kg_distill_prep_kernel).
-    z_obs (1,n,1) float64 (any stride along n: e.g. the depth column of (1,n,3) points), obs_mask (n,) bool or None, sinv (1,n,1) or
-    None (then the scalar).
+    z_obs (1,n,1) float64 (any stride along n: e.g. the depth column of (1,n,3) points), obs_mask (n,) bool or None; s = sinv (1,n,1)
+    per row, or -- sinv None -- 1 / stdev_obs for a fixed observation stdev: a Python number, or a float64 scalar ON THE DEVICE
+    (the residual spread of an earlier distillation), which is inverted inside the launch: no read-back.
     Returns (okm (1,n,1) bool, zs (1,n,1) or None, y (1,n,1), w (1,n,1))."""
     from como_amd import _lib
     n = z_obs.shape[1]
@@ -82,10 +88,16 @@ def distill_prep(z_obs, obs_mask, min_depth, sinv, sinv_scalar, weighted, want_z
     y = torch.empty((1, n, 1), dtype=torch.float64, device=dev)
     w = torch.empty((1, n, 1), dtype=torch.float64, device=dev)
     zs = torch.empty((1, n, 1), dtype=torch.float64, device=dev) if want_zs else None
+    sdev, sval = None, 0.0
+    if sinv is None and stdev_obs is not None:
+        if torch.is_tensor(stdev_obs):
+            sdev = stdev_obs
+        else:
+            sval = 1.0 / float(stdev_obs)
     _lib.check(_lib.lib().como_kf_distill_prep_f64(z_obs.data_ptr(), int(z_obs.stride(1)) if n > 1 else 1, _lib.ptr(obs_mask), n,
-                                                   float(min_depth), _lib.ptr(sinv),
-                                                   float(sinv_scalar), 1 if weighted else 0, okm.data_ptr(), _lib.ptr(zs),
-                                                   y.data_ptr(), w.data_ptr(), _lib.stream_ptr(dev)), "como_kf_distill_prep_f64")
+                                                   float(min_depth), _lib.ptr(sinv), sval, _lib.ptr(sdev), 1 if weighted else 0,
+                                                   okm.data_ptr(), _lib.ptr(zs), y.data_ptr(), w.data_ptr(), _lib.stream_ptr(dev)),
+               "como_kf_distill_prep_f64")
     return okm, zs, y, w
 
 
@@ -225,7 +237,8 @@ def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model,
     assert coords_m.shape[0] == 1
     rm = None if obs_mask is None else obs_mask.reshape(1, -1)
     pre = KF_GLUE and z_obs.is_cuda and z_obs.dtype == torch.float64 and z_obs.dim() == 3 and z_obs.shape[2] == 1 and \
-        z_obs.shape[1] > 0 and z_obs.stride(1) >= 1 and _glue_ok(obs_mask) and (obs_mask is None or obs_mask.dtype == torch.bool)
+        z_obs.shape[1] > 0 and z_obs.stride(1) >= 1 and _glue_ok(obs_mask) and (obs_mask is None or obs_mask.dtype == torch.bool) and \
+        _stdev_ok(stdev_obs)
     Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL, row_mask=rm,
                                    want_sinv=not (pre and stdev_obs is not None))
     glue = pre and _fast(Kt) and _glue_ok(sinv)
@@ -241,8 +254,7 @@ def distill_depth_from_scratch(coords_m, coords_n, z_obs, cov_params_img, model,
         m = Kt.shape[2]
         if glue:
             okm, _, y, wgt = distill_prep(z_obs, None if obs_mask is None else obs_mask.reshape(-1), min_depth,
-                                          sinv if stdev_obs is None else None, 0.0 if stdev_obs is None else 1.0 / stdev_obs,
-                                          bool(distill_with_prior))
+                                          sinv if stdev_obs is None else None, stdev_obs, bool(distill_with_prior))
         else:
             okm = z_obs[:, :, 0:1] > min_depth
             if obs_mask is not None:
@@ -294,7 +306,8 @@ def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_
     """:152-175.  obs_mask: as in distill_depth_from_scratch."""
     assert coords_m.shape[0] == 1
     pre = KF_GLUE and z_obs.is_cuda and z_obs.dtype == torch.float64 and z_obs.dim() == 3 and z_obs.shape[2] == 1 and \
-        z_obs.shape[1] > 0 and z_obs.stride(1) >= 1 and _glue_ok(obs_mask) and (obs_mask is None or obs_mask.dtype == torch.bool)
+        z_obs.shape[1] > 0 and z_obs.stride(1) >= 1 and _glue_ok(obs_mask) and (obs_mask is None or obs_mask.dtype == torch.bool) and \
+        _stdev_ok(stdev_obs)
     Kt, L_mm, sinv = get_predictor(*calc_kernel_matrices(coords_m, coords_n, cov_params_img, model), pad4=_GRAM_KERNEL, want_sinv=not pre)
     glue = pre and _fast(Kt)
     if not glue:
@@ -309,7 +322,7 @@ def distill_conditional_depth_from_scratch(coords_m, z_m1, coords_n, cov_params_
         from como_amd.utils.select import masked_median
         if glue:
             okm, zs, logzs, wgt = distill_prep(z_obs, None if obs_mask is None else obs_mask.reshape(-1), min_depth, None,
-                                               1.0 / stdev_obs, True, want_zs=True)
+                                               stdev_obs, True, want_zs=True)
         else:
             okm = z_obs[:, :, 0:1] > min_depth
             if obs_mask is not None:

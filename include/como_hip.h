@@ -778,7 +778,8 @@ int como_track_precalc_jac_f64(const double* dI_dw, const double* P, const doubl
  *                     + 1e-8; sinv = 1 / sqrt(var).  partial: scratch of >= 64 doubles.
  *  distill_prep     : distill_depth.py:96-111, 152-166 -- z = z_obs[i * z_stride] (e.g. the third component of points (n,3));
  *                     ok = z > min_depth [& obs_mask]; zs = ok ? z : 1 (optional output);
- *                     y = log(zs); w = ok ? s^2 : 0 with s = sinv[i] (or sinv_scalar when sinv is NULL) for weight_mode 1,
+ *                     y = log(zs); w = ok ? s^2 : 0 with s = sinv[i] (sinv NULL: 1 / stdev_dev[0] -- a device scalar, no read-back --
+ *                     or, stdev_dev NULL too, sinv_scalar) for weight_mode 1,
  *                     w = ok ? 1 : 0 for weight_mode 0.
  *  corr_good        : como/odom/frontend/corr.py:47-59, 113-118 (modes logz / logr) -- the z components (element 2 of rows of
  *                     `stride` doubles: pass the address of the first z) of four point sets and the depth-gradient measure:
@@ -787,8 +788,8 @@ int como_track_precalc_jac_f64(const double* dI_dw, const double* P, const doubl
 int como_kf_predictor_sinv_f64(const double* var_n, const uint8_t* row_mask, long n, double* partial, double* sinv,
                                como_stream_t stream);
 int como_kf_distill_prep_f64(const double* z_obs, long z_stride, const uint8_t* obs_mask, long n, double min_depth, const double* sinv,
-                             double sinv_scalar, int weight_mode, uint8_t* okm, double* zs, double* y, double* w,
-                             como_stream_t stream);
+                             double sinv_scalar, const double* stdev_dev, int weight_mode, uint8_t* okm, double* zs, double* y,
+                             double* w, como_stream_t stream);
 int como_kf_corr_good_f64(const double* a, const double* b, const double* c, const double* d, int stride, const double* grad, long m,
                           double corr_thresh, double grad_thresh, uint8_t* good, como_stream_t stream);
 int como_kf_normalize_coords_f32(const float* x, long n2, const float* A, const float* A2, float* out, como_stream_t stream);

@@ -787,13 +787,14 @@ def test_keyframe_glue_kernels_vs_torch_chains():
     z[0, 5, 0] = float("nan"); z[0, 6, 0] = float("inf"); z[0, 7, 0] = 0.0
     sinv = (0.5 + torch.rand(1, n, 1, generator=g, dtype=torch.float64)).to(DEV)
     for om in (None, mask):
-        for weighted, s_t, s_sc in ((True, sinv, 0.0), (True, None, 1.0 / 0.07), (False, None, 0.0)):
+        for weighted, s_t, s_sc in ((True, sinv, None), (True, None, 0.07), (True, None, torch.tensor(0.07, dtype=torch.float64, device=DEV)),
+                                    (False, None, None)):
             okm = z[:, :, 0:1] > 0.1
             if om is not None:
                 okm = okm & om.reshape(1, -1, 1)
             zs = torch.where(okm, z, torch.ones_like(z))
             y = torch.log(zs)
-            sv = s_t if s_t is not None else s_sc * torch.ones_like(z)
+            sv = s_t if s_t is not None else ((1.0 / s_sc) * torch.ones_like(z) if s_sc is not None else torch.ones_like(z))
             w = torch.where(okm, sv * sv, torch.zeros_like(sv)) if weighted else okm.to(torch.float64)
             ok2, zs2, y2, w2 = dd.distill_prep(z, om, 0.1, s_t, s_sc, weighted, want_zs=True)
             assert torch.equal(ok2, okm) and torch.equal(zs2, zs) and torch.equal(y2, y) and torch.equal(w2, w)
