@@ -175,6 +175,7 @@ SIGNATURES = {
     "como_kf_normalize_coords_swap_f64": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p]),
     "como_kf_grad_mag_f32": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "como_kf_grad_mag_f64": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "como_kf_masked_std_f64": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
     "como_kf_cond_c_f64": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "como_kf_cond_system_f64": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_double, c_void_p, c_void_p, c_void_p, c_void_p]),
     "como_kf_aff_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

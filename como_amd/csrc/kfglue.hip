@@ -167,6 +167,45 @@ __global__ __launch_bounds__(256) void kg_cond_system_kernel(const double* __res
   }
 }
 
+// Unbiased standard deviation of the entries of `res` whose mask byte is set (torch.std of the gathered valid residuals,
+// distill_depth.py:113-116 of the reference): count, mean, then the centred squares -- ONE workgroup, two passes over n <= a few
+// 100 k values, every sum in a fixed order (per-thread strided partials, wave tree, 16 waves in sequence): deterministic; equal to
+// torch's masked-sum form up to the rounding of another summation order (as that form was to the gathered one).
+__global__ __launch_bounds__(1024) void kg_masked_std_kernel(const double* __restrict__ res, const uint8_t* __restrict__ okm, long n,
+                                                             double* __restrict__ out) {
+#pragma clang fp contract(off)
+  __shared__ double red[2][16];
+  __shared__ double bc[2];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double cnt = 0.0, s = 0.0;
+  for (long i = tid; i < n; i += 1024)
+    if (okm[i]) { cnt += 1.0; s += res[i]; }
+  cnt = wave_sum(cnt);
+  s = wave_sum(s);
+  if (lane == 0) { red[0][wv] = cnt; red[1][wv] = s; }
+  __syncthreads();
+  if (tid == 0) {
+    double c = 0.0, t = 0.0;
+    for (int w = 0; w < 16; ++w) { c += red[0][w]; t += red[1][w]; }
+    bc[0] = c;
+    bc[1] = t / c;
+  }
+  __syncthreads();
+  const double nn = bc[0], mean = bc[1];
+  double ss = 0.0;
+  for (long i = tid; i < n; i += 1024)
+    if (okm[i]) { const double d = res[i] - mean; ss += d * d; }
+  ss = wave_sum(ss);
+  __syncthreads();
+  if (lane == 0) red[0][wv] = ss;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[0][w];
+    out[0] = sqrt(t / (nn - 1.0));
+  }
+}
+
 template <typename T>
 static int grad_mag(const T* gx, const T* gy, long n, T* out, hipStream_t s) {
   if (!gx || !gy || !out || n < 0) return COMO_ERR_ARG;
@@ -249,6 +288,13 @@ int como_kf_normalize_coords_f64(const double* x, long n2, const double* A, cons
   return como::normalize_coords<double>(x, n2, A, A2, out, (hipStream_t)stream);
 }
 
+int como_kf_masked_std_f64(const double* res, const uint8_t* okm, long n, double* out, como_stream_t stream) {
+  using namespace como;
+  if (!res || !okm || !out || n <= 0) return COMO_ERR_ARG;
+  hipLaunchKernelGGL(kg_masked_std_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, res, okm, n, out);
+  COMO_CHECK_LAUNCH();
+  return COMO_OK;
+}
 int como_kf_cond_c_f64(const double* z1, int m1, int mp, double* c, como_stream_t stream) {
   using namespace como;
   if (!c || m1 < 0 || mp < m1 || mp <= 0 || (m1 > 0 && !z1)) return COMO_ERR_ARG;

@@ -78,6 +78,20 @@ class DiagonalCovarianceModule(CovarianceModule):
     forward = __call__
 
 
+_jitter_cache = {}
+
+
+def _jitter(B, m, dev, dt):
+    """diag_embed(1e-6 (float32) as dt) for (B, m): four tiny launches per keyframe for a constant -- built once per shape."""
+    key = (B, m, str(dev), dt)
+    J = _jitter_cache.get(key)
+    if J is None:
+        if len(_jitter_cache) > 64:
+            _jitter_cache.clear()
+        J = _jitter_cache[key] = torch.diag_embed((1e-6 * torch.ones(B, m, device=dev)).to(dt))
+    return J
+
+
 def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None, K_mm_inv=None, out=None, out_pix=None):
     """Mapping.prep_predictor (Mapping.py:430-468): returns (K_mm_inv (B,m,m), L_mm (B,m,m), Knm_Kmminv (B,H,W,m)).
     K_nm (H*W x m per keyframe) is never materialised.  K_mm_inv: optional precomputed inverse (then L_mm is returned as
@@ -92,7 +106,7 @@ def prep_predictor(cov_params_img, coords_m, scale, photo_img_size=None, K_mm_in
     cm, Em = kernel_params_at(cov_params_img, coords_m.to(dt))         # normalised coordinates + interpolated parameters, one launch
     if K_mm_inv is None:
         K_mm = covariance(cm, Em, scale)
-        K_mm = K_mm + torch.diag_embed((1e-6 * torch.ones(B, m, device=dev)).to(dt))      # float32 jitter as Mapping.py:450
+        K_mm = K_mm + _jitter(B, m, dev, dt)                   # float32 jitter as Mapping.py:450 (the constant matrix is cached)
         # conditioning on the device in ONE launch (csrc/smallsolve.hip): L_mm and K_mm^-1 = L^-T L^-1
         f = chol_small(K_mm, want_L=True, want_inv=True)
         L_mm, K_mm_inv = f["L"], f["inv"].contiguous()

@@ -155,6 +155,15 @@ class MaskedResidual:
         self.res, self.okm = res, okm
 
     def std(self):
+        r, o = self.res, self.okm
+        if (KF_GLUE and r.is_cuda and r.dtype == torch.float64 and o.dtype == torch.bool and r.is_contiguous() and o.is_contiguous() and
+                r.numel() == o.numel() and r.numel() > 0):
+            # one launch, fixed summation order (csrc/kfglue.hip kg_masked_std_kernel) instead of thirteen
+            from como_amd import _lib
+            out = torch.empty((), dtype=torch.float64, device=r.device)
+            _lib.check(_lib.lib().como_kf_masked_std_f64(r.data_ptr(), o.data_ptr(), r.numel(), out.data_ptr(), _lib.stream_ptr(r.device)),
+                       "como_kf_masked_std_f64")
+            return out
         zero = torch.zeros_like(self.res)
         n = self.okm.sum().to(self.res.dtype)
         mean = torch.where(self.okm, self.res, zero).sum() / n          # (selects: a masked row may hold anything)

@@ -806,6 +806,9 @@ int como_kf_aff_f64(const double* p, const double* q, int B, int mode, double* o
 /* The small system of the conditional distillation (distill_depth.py:122-148, normal-equation form): cond_c: c (mp) = [log z1 (m1) ; 0];
  * cond_system: A22 (m2,m2) = AtA[m1:m1+m2, m1:m1+m2] + sp2 I (AtA row stride ld), b2 (m2) = Atb[m1:m1+m2] + sp2 * s_med[0]. */
 int como_kf_cond_c_f64(const double* z1, int m1, int mp, double* c, como_stream_t stream);
+/* masked_std: torch.std (unbiased) of the entries of res (n) whose okm byte is set -- the spread of a distillation's valid residuals
+ * (distill_depth.py:113-116) -- into out[0], one launch, fixed summation order (not torch's: equal up to that rounding). */
+int como_kf_masked_std_f64(const double* res, const uint8_t* okm, long n, double* out, como_stream_t stream);
 int como_kf_cond_system_f64(const double* AtA, const double* Atb, int ld, int m1, int m2, double sp2, const double* s_med,
                             double* A22, double* b2, como_stream_t stream);
 

@@ -868,4 +868,15 @@ def test_keyframe_glue_kernels_vs_torch_chains():
     _lib.check(L.como_kf_cond_system_f64(AtA.data_ptr(), Atb.data_ptr(), mp, m1, m2, sp2, s_med.data_ptr(), A_.data_ptr(), b_.data_ptr(), st), "cond_system")
     same_bits = lambda a, b: torch.equal(a.view(torch.int64), b.contiguous().view(torch.int64))
     assert torch.equal(c_, c_ref) and same_bits(A_, A_ref) and same_bits(b_, b_ref)
-    report("kf_glue", sinv="equal", distill_prep="equal", corr_good="equal", normalize="equal", grad_mag="equal", aff="equal", cond="equal")
+    # ---- masked standard deviation (a reduction: fixed order of its own, equal to torch.std of the gathered entries to rounding)
+    resid = torch.randn(1, n, 1, generator=g, dtype=torch.float64).to(DEV) * 0.03 + 0.2
+    okb = (torch.rand(1, n, 1, generator=g) < 0.7).to(DEV)
+    resid[0, 9, 0] = float("nan")
+    okb[0, 9, 0] = False                                   # a masked row may hold anything
+    mr = dd.MaskedResidual(resid, okb)
+    ref_std = torch.std(resid[okb])
+    got_std = mr.std()
+    assert got_std.shape == () and abs(got_std.item() - ref_std.item()) < 1e-13 * ref_std.item()
+    assert torch.equal(got_std, mr.std())                  # the same bits every time
+    report("kf_glue", sinv="equal", distill_prep="equal", corr_good="equal", normalize="equal", grad_mag="equal", aff="equal", cond="equal",
+           masked_std_rel=abs(got_std.item() - ref_std.item()) / ref_std.item())
